@@ -1,0 +1,88 @@
+"""ctypes loader for libkrasis_hip.so (the C ABI declared in include/krasis_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libkrasis_hip.so")
+
+KR_OK, KR_ERR_STATE, KR_ERR_VALUE, KR_ERR_IO, KR_ERR_HIP = 0, 1, 2, 3, 4
+KR_OUT_F32, KR_OUT_BF16 = 0, 1
+KR_SCORE_SIGMOID, KR_SCORE_SOFTMAX, KR_SCORE_TOPK_SOFTMAX = 0, 1, 2
+KR_ROUTE_RULE_ENGINE, KR_ROUTE_RULE_DECODE = 0, 1
+
+# every symbol include/krasis_hip.h declares (checked by tests/test_abi.py without a GPU)
+SYMBOLS = [
+    "kr_last_error", "kr_version", "kr_engine_create", "kr_engine_destroy", "kr_engine_get_config",
+    "kr_engine_device_bytes", "kr_upload_expert_unified", "kr_upload_expert_gguf", "kr_fill_layer_synthetic",
+    "kr_download_expert_unified", "kr_moe_forward", "kr_set_routing_config", "kr_set_routing_weights",
+    "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_synchronize",
+]
+
+
+class KrasisHipError(RuntimeError):
+    """HIP runtime failure or missing native library (no CPU fallback exists)."""
+
+
+class ModelConfigC(C.Structure):
+    _fields_ = [("hidden_size", C.c_int), ("moe_intermediate_size", C.c_int), ("n_routed_experts", C.c_int),
+                ("num_experts_per_tok", C.c_int), ("num_moe_layers", C.c_int), ("n_shared_experts", C.c_int),
+                ("group_size", C.c_int), ("routed_scaling_factor", C.c_float), ("swiglu_limit", C.c_float),
+                ("activation_alpha", C.c_float)]
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB
+
+
+def load_library() -> C.CDLL:
+    """Load libkrasis_hip.so; raises KrasisHipError if it was not built (build with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise KrasisHipError(f"{_LIB} is missing: build it with `make -C krasis_amd/csrc` (hipcc, gfx950). "
+                             "krasis_amd has no CPU fallback.")
+    lib = C.CDLL(_LIB)
+    lib.kr_last_error.restype = C.c_char_p
+    lib.kr_engine_device_bytes.restype = C.c_size_t
+    lib.kr_engine_device_bytes.argtypes = [C.c_void_p]
+    lib.kr_engine_create.argtypes = [C.c_int, C.POINTER(ModelConfigC), C.POINTER(C.c_void_p)]
+    lib.kr_engine_destroy.argtypes = [C.c_void_p]
+    lib.kr_engine_destroy.restype = None
+    lib.kr_engine_get_config.argtypes = [C.c_void_p, C.POINTER(ModelConfigC)]
+    lib.kr_upload_expert_unified.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_int]
+    lib.kr_upload_expert_gguf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_int]
+    lib.kr_fill_layer_synthetic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64]
+    lib.kr_download_expert_unified.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.kr_moe_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.kr_set_routing_config.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.kr_set_routing_weights.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.kr_route_topk.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
+    lib.kr_forward_moe_routed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.kr_reduce_sum_bf16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.kr_synchronize.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Map C-ABI status codes onto the exception classes the reference raises."""
+    if rc == KR_OK:
+        return
+    msg = load_library().kr_last_error().decode("utf-8", "replace")
+    if rc == KR_ERR_STATE:
+        raise RuntimeError(msg)          # PyRuntimeError in the reference
+    if rc == KR_ERR_VALUE:
+        raise ValueError(msg)            # PyValueError
+    if rc == KR_ERR_IO:
+        raise IOError(msg)               # PyIOError
+    raise KrasisHipError(msg)

@@ -1,0 +1,142 @@
+// kr_device.h -- device-side helpers shared by the gfx950 kernels (wave64 only).
+//
+// Numerics contract: every kernel reproduces the evaluation order of the reference's CPU
+// kernels so results are bit-identical to the oracle.  This translation unit is
+// compiled with -ffp-contract=off; fused multiply-adds appear only where the reference issues
+// _mm256_fmadd_ps and are written as __builtin_fmaf explicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KR_WAVE 64
+#define KR_DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define KR_DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define KR_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each 8-lane half row
+#define KR_DPP_MIRROR 0x140      // lane i <-> 15-i inside each 16-lane row
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float kr_bf16_to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+// marlin.rs:25 -- RNE without NaN special-casing
+__device__ __forceinline__ uint16_t kr_f32_to_bf16(float f) {
+    uint32_t b = __float_as_uint(f);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
+}
+
+#define KR_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false)
+
+// sum / max over each aligned group of 8 lanes; every lane of the group receives the result
+__device__ __forceinline__ int kr_red8_add_i32(int v) {
+    v += KR_DPP(v, KR_DPP_XOR1);
+    v += KR_DPP(v, KR_DPP_XOR2);
+    v += KR_DPP(v, KR_DPP_HALF_MIRROR);
+    return v;
+}
+__device__ __forceinline__ float kr_red16_max_f32(float v) {
+    v = fmaxf(v, __int_as_float(KR_DPP(__float_as_int(v), KR_DPP_XOR1)));
+    v = fmaxf(v, __int_as_float(KR_DPP(__float_as_int(v), KR_DPP_XOR2)));
+    v = fmaxf(v, __int_as_float(KR_DPP(__float_as_int(v), KR_DPP_HALF_MIRROR)));
+    v = fmaxf(v, __int_as_float(KR_DPP(__float_as_int(v), KR_DPP_MIRROR)));
+    return v;
+}
+__device__ __forceinline__ float kr_red4_max_f32(float v) {
+    v = fmaxf(v, __int_as_float(KR_DPP(__float_as_int(v), KR_DPP_XOR1)));
+    v = fmaxf(v, __int_as_float(KR_DPP(__float_as_int(v), KR_DPP_XOR2)));
+    return v;
+}
+
+// streamed-once weight loads: non-temporal 16 B / 4 B
+__device__ __forceinline__ u32x4 kr_ldg_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ uint32_t kr_ldg_nt(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+
+// fast_exp_avx2 (avx2.rs:2235): 2^(x*log2e) with the degree-5 polynomial, fma Horner
+__device__ __forceinline__ float kr_fast_exp_poly5(float x) {
+    const float t = x * 1.4426950408889634f;
+    const float n = floorf(t);
+    const int ni = (int)n;
+    const float f = t - n;
+    float p = __builtin_fmaf(0.0013333558f, f, 0.009618129f);
+    p = __builtin_fmaf(p, f, 0.0555041f);
+    p = __builtin_fmaf(p, f, 0.2402265f);
+    p = __builtin_fmaf(p, f, 0.6931472f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return p * __int_as_float((ni + 127) << 23);
+}
+// fast_sigmoid_avx2 (avx2.rs:2277) with the reciprocal done as an IEEE divide (oracle mode KRO_SIG_POLY5_DIV;
+// the reference's rcpps+Newton step is host-CPU specific and differs from this by <= 2 ulp)
+__device__ __forceinline__ float kr_sigmoid_poly5(float x) {
+    float c = 0.0f - x;
+    c = c < 20.0f ? c : 20.0f;
+    c = c > -20.0f ? c : -20.0f;
+    return 1.0f / (1.0f + kr_fast_exp_poly5(c));
+}
+// scalar twin fast_sigmoid (moe.rs:1216): non-fused Horner
+__device__ __forceinline__ float kr_sigmoid_poly5_scalar(float x) {
+    float nx = -x;
+    nx = nx < -20.0f ? -20.0f : nx;
+    nx = nx > 20.0f ? 20.0f : nx;
+    const float t = nx * 1.4426950408889634f;
+    const float n = floorf(t);
+    const float f = t - n;
+    const float p = 1.0f + f * (0.6931472f + f * (0.2402265f + f * (0.0555041f + f * (0.009618129f + f * 0.0013333558f))));
+    return 1.0f / (1.0f + p * __int_as_float(((int)n + 127) << 23));
+}
+
+// ---------------------------------------------------------------------------------------------
+// INT16 activation image in LDS (gs = 128).  For every 8 consecutive k ("chunk") one 16-byte record
+//   { AH_even, AH_odd, AL_even, AL_odd }  with  a = AH*256 + AL,  AH = a >> 8 (signed), AL = a & 255
+//   *_even packs k = 0,2,4,6 of the chunk, *_odd packs k = 1,3,5,7 -- the order in which
+//   (w & 0x0F0F0F0F) and ((w >> 4) & 0x0F0F0F0F) present the nibbles of a packed INT4 word.
+// plus   asum16[k/16] = sum of the 16 quantized activations (for the "-8" nibble offset)
+// and    ascale[k/128] = the per-group activation scale.
+// INT8 weights use the natural-order image { AH[0..3] .. } described at kr_act_image_i8.
+// ---------------------------------------------------------------------------------------------
+struct KrActLds {
+    u32x4* planes;   // [K/8]
+    int* asum16;     // [K/16]
+    float* ascale;   // [K/128]
+    u32x4* planes8;  // INT8 image: [K/16][2] = {AH(16 k), AL'(16 k)} natural order, AL' = AL - 128
+};
+
+__device__ __forceinline__ uint32_t kr_pack4(int b0, int b1, int b2, int b3) {
+    return (uint32_t)(b0 & 0xFF) | ((uint32_t)(b1 & 0xFF) << 8) | ((uint32_t)(b2 & 0xFF) << 16) | ((uint32_t)(b3 & 0xFF) << 24);
+}
+
+// Quantize 8 values (one chunk) given the group's inverse scale; ROUND_EVEN selects
+// _mm256_cvtps_epi32 semantics (avx2.rs:2357) vs f32::round (avx2.rs:264,300).
+template <bool ROUND_EVEN>
+__device__ __forceinline__ void kr_quant8(const float (&x)[8], float inv, int (&q)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float s = x[i] * inv;
+        int v = ROUND_EVEN ? __float2int_rn(s) : (int)roundf(s);
+        v = v > 32767 ? 32767 : v;
+        v = v < -32768 ? -32768 : v;
+        q[i] = v;
+    }
+}
+
+// Store one chunk's records.  `chunk` is the global chunk index (k/8).  Pair sums for asum16 are
+// completed with the neighbouring lane (chunks are assigned lane-consecutively by every caller).
+template <bool WANT_I8_IMAGE>
+__device__ __forceinline__ void kr_store_chunk(const KrActLds& L, int chunk, const int (&q)[8]) {
+    u32x4 r;
+    r.x = kr_pack4(q[0] >> 8, q[2] >> 8, q[4] >> 8, q[6] >> 8);
+    r.y = kr_pack4(q[1] >> 8, q[3] >> 8, q[5] >> 8, q[7] >> 8);
+    r.z = kr_pack4(q[0], q[2], q[4], q[6]);
+    r.w = kr_pack4(q[1], q[3], q[5], q[7]);
+    L.planes[chunk] = r;
+    int s = q[0] + q[1] + q[2] + q[3] + q[4] + q[5] + q[6] + q[7];
+    s += KR_DPP(s, KR_DPP_XOR1);
+    if ((chunk & 1) == 0) L.asum16[chunk >> 1] = s;
+    if (WANT_I8_IMAGE) {
+        // natural order: half-record per chunk: AH[0..7] (2 dwords) and AL'[0..7] (2 dwords)
+        uint32_t* p = reinterpret_cast<uint32_t*>(L.planes8) + (chunk >> 1) * 8 + (chunk & 1) * 2;
+        p[0] = kr_pack4(q[0] >> 8, q[1] >> 8, q[2] >> 8, q[3] >> 8);
+        p[1] = kr_pack4(q[4] >> 8, q[5] >> 8, q[6] >> 8, q[7] >> 8);
+        p[4] = kr_pack4((q[0] & 255) - 128, (q[1] & 255) - 128, (q[2] & 255) - 128, (q[3] & 255) - 128);
+        p[5] = kr_pack4((q[4] & 255) - 128, (q[5] & 255) - 128, (q[6] & 255) - 128, (q[7] & 255) - 128);
+    }
+}

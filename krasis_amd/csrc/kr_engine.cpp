@@ -1,0 +1,592 @@
+// kr_engine.cpp -- host side of libkrasis_hip.so: engine state, weight store in HBM, re-tiling of the
+// reference's weight layouts, and the extern "C" entry points declared in include/krasis_hip.h.
+//
+// Mirrors the role of the reference's Rust host for this path: KrasisEngine (src/moe.rs:1377-3296) and
+// WeightStore (src/weights/mod.rs:814-850).  With 288 GB of HBM every expert of every layer is resident;
+// the reference's CPU/GPU split, expert DMA, LRU/HCS caches (python/krasis/gpu_prefill.py) do not exist here.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/krasis_hip.h"
+#include "kr_kernels.h"
+#include "kr_router.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int kr_fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define KR_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess) return kr_fail(KR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+extern "C" const char* kr_last_error(void) { return g_err.c_str(); }
+extern "C" int kr_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// engine state
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        if (hipMalloc(&p, n) != hipSuccess) return 1;
+        bytes = n; return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct MatSet {            // all experts of one layer for one projection, contiguous in HBM
+    DevBuf q, s;
+    int K = 0, N = 0, bits = 0, count = 0;
+    size_t q_stride = 0, s_stride = 0;
+    bool allocated() const { return q.p != nullptr; }
+    KrMatDev view() const {
+        KrMatDev m{};
+        m.q = q.p; m.s = (const uint32_t*)s.p; m.K = K; m.N = N;
+        m.ng = K / 128; m.ngp = (m.ng + 1) / 2; m.bits = bits; m.n_fma = (N / 8) * 8;
+        m.q_stride = q_stride; m.s_stride = s_stride;
+        return m;
+    }
+};
+
+struct Layer {
+    MatSet w13, w2;        // routed experts
+    MatSet sw13, sw2;      // shared expert (count == 1)
+    std::vector<uint8_t> present;
+    bool shared_present = false;
+    int inter = 0, shared_inter = 0;
+    // routing (set_routing_weights)
+    std::vector<float> gate_host;          // [E,H] f32 copy (bf16 inputs widen exactly)
+    bool gate_bf16_exact = false;          // every value representable in bf16 -> stored as bf16 in HBM
+    DevBuf gate_cm;                        // chain-major layout for rule DECODE
+    DevBuf gate_rm;                        // row-lane layout for rule ENGINE (built on first use)
+    DevBuf bias, esc; bool has_bias = false, has_esc = false, routing_present = false;
+};
+
+struct kr_engine {
+    int device = 0;
+    kr_model_config cfg{};
+    hipStream_t stream = nullptr;
+    std::vector<Layer> layers;
+    size_t weight_bytes = 0;
+    // scratch
+    DevBuf gu, eo, st_act, st_ids, st_w, st_out, ptr_table;
+    // routing config
+    bool routing_set = false; int r_scoring = 1, r_norm = 1, r_topk = 0, r_ne = 0, r_hidden = 0;
+    DevBuf r_logits, r_ids, r_w, r_x;
+    std::mutex mu;
+};
+
+static bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// ------------------------------------------------------------------------------------------------
+// re-tiling between the reference CPU layouts and the lane-tiled HBM layout
+// ------------------------------------------------------------------------------------------------
+// INT4: src packed [K/8, N] u32, scales [K/128, N] bf16 (weights/mod.rs:329-397)
+static void retile_int4(const uint32_t* src, const uint16_t* sc, int K, int N, uint32_t* dq, uint32_t* ds) {
+    const int ng = K / 128, ngp = (ng + 1) / 2, nt = (N + 7) / 8;
+    for (int t = 0; t < nt; t++)
+        for (int gp = 0; gp < ngp; gp++) {
+            uint32_t* rec = dq + ((size_t)t * ngp + gp) * 64 * 4;
+            for (int c = 0; c < 8; c++) {
+                const int col = t * 8 + c;
+                const int g0 = 2 * gp, g1 = g0 + 1;
+                for (int l = 0; l < 8; l++) {
+                    uint32_t* o = rec + (c * 8 + l) * 4;
+                    for (int h = 0; h < 2; h++) {
+                        const int g = h == 0 ? g0 : g1;
+                        for (int i = 0; i < 2; i++)
+                            o[h * 2 + i] = (g < ng && col < N) ? src[(size_t)(g * 16 + 2 * l + i) * N + col] : 0x88888888u;
+                    }
+                }
+                const uint32_t s0 = (col < N) ? sc[(size_t)g0 * N + col] : 0;
+                const uint32_t s1 = (g1 < ng && col < N) ? sc[(size_t)g1 * N + col] : 0;
+                ds[((size_t)t * ngp + gp) * 8 + c] = s0 | (s1 << 16);
+            }
+        }
+}
+static void untile_int4(const uint32_t* dq, const uint32_t* ds, int K, int N, uint32_t* dst, uint16_t* sc) {
+    const int ng = K / 128, ngp = (ng + 1) / 2, nt = (N + 7) / 8;
+    for (int t = 0; t < nt; t++)
+        for (int gp = 0; gp < ngp; gp++)
+            for (int c = 0; c < 8; c++) {
+                const int col = t * 8 + c;
+                if (col >= N) continue;
+                for (int l = 0; l < 8; l++)
+                    for (int h = 0; h < 2; h++) {
+                        const int g = 2 * gp + h;
+                        if (g >= ng) continue;
+                        for (int i = 0; i < 2; i++)
+                            dst[(size_t)(g * 16 + 2 * l + i) * N + col] = dq[(((size_t)t * ngp + gp) * 64 + c * 8 + l) * 4 + h * 2 + i];
+                    }
+                const uint32_t sp = ds[((size_t)t * ngp + gp) * 8 + c];
+                sc[(size_t)(2 * gp) * N + col] = (uint16_t)(sp & 0xFFFF);
+                if (2 * gp + 1 < ng) sc[(size_t)(2 * gp + 1) * N + col] = (uint16_t)(sp >> 16);
+            }
+}
+// INT8: src [K, N] i8, scales [K/128, N] bf16 (weights/mod.rs:403-470)
+static void retile_int8(const int8_t* src, const uint16_t* sc, int K, int N, uint32_t* dq, uint32_t* ds) {
+    const int ng = K / 128, ngp = (ng + 1) / 2, nt = (N + 7) / 8;
+    for (int t = 0; t < nt; t++) {
+        for (int g = 0; g < ng; g++) {
+            uint8_t* rec = reinterpret_cast<uint8_t*>(dq) + ((size_t)t * ng + g) * 64 * 16;
+            for (int c = 0; c < 8; c++) {
+                const int col = t * 8 + c;
+                for (int l = 0; l < 8; l++)
+                    for (int j = 0; j < 16; j++)
+                        rec[(c * 8 + l) * 16 + j] = (col < N) ? (uint8_t)src[(size_t)(g * 128 + 16 * l + j) * N + col] : 0;
+            }
+        }
+        for (int gp = 0; gp < ngp; gp++)
+            for (int c = 0; c < 8; c++) {
+                const int col = t * 8 + c;
+                const uint32_t s0 = (col < N) ? sc[(size_t)(2 * gp) * N + col] : 0;
+                const uint32_t s1 = (2 * gp + 1 < ng && col < N) ? sc[(size_t)(2 * gp + 1) * N + col] : 0;
+                ds[((size_t)t * ngp + gp) * 8 + c] = s0 | (s1 << 16);
+            }
+    }
+}
+static void untile_int8(const uint32_t* dq, const uint32_t* ds, int K, int N, int8_t* dst, uint16_t* sc) {
+    const int ng = K / 128, ngp = (ng + 1) / 2, nt = (N + 7) / 8;
+    for (int t = 0; t < nt; t++) {
+        for (int g = 0; g < ng; g++) {
+            const uint8_t* rec = reinterpret_cast<const uint8_t*>(dq) + ((size_t)t * ng + g) * 64 * 16;
+            for (int c = 0; c < 8; c++) {
+                const int col = t * 8 + c;
+                if (col >= N) continue;
+                for (int l = 0; l < 8; l++)
+                    for (int j = 0; j < 16; j++) dst[(size_t)(g * 128 + 16 * l + j) * N + col] = (int8_t)rec[(c * 8 + l) * 16 + j];
+            }
+        }
+        for (int gp = 0; gp < ngp; gp++)
+            for (int c = 0; c < 8; c++) {
+                const int col = t * 8 + c;
+                if (col >= N) continue;
+                const uint32_t sp = ds[((size_t)t * ngp + gp) * 8 + c];
+                sc[(size_t)(2 * gp) * N + col] = (uint16_t)(sp & 0xFFFF);
+                if (2 * gp + 1 < ng) sc[(size_t)(2 * gp + 1) * N + col] = (uint16_t)(sp >> 16);
+            }
+    }
+}
+
+static int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int count) {
+    if (ms.allocated()) {
+        if (ms.K != K || ms.N != N || ms.bits != bits)
+            return kr_fail(KR_ERR_VALUE, "expert shape/bits mismatch within layer: have K=%d N=%d bits=%d, got K=%d N=%d bits=%d",
+                           ms.K, ms.N, ms.bits, K, N, bits);
+        return KR_OK;
+    }
+    if (K % 128 != 0) return kr_fail(KR_ERR_VALUE, "reduction dim %d must be divisible by group_size 128", K);
+    ms.K = K; ms.N = N; ms.bits = bits; ms.count = count;
+    ms.q_stride = kr_mat_q_bytes(K, N, bits); ms.s_stride = kr_mat_s_bytes(K, N);
+    if (ms.q.ensure(ms.q_stride * count) || ms.s.ensure(ms.s_stride * count))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of %zu bytes failed", ms.q_stride * count);
+    e->weight_bytes += (ms.q_stride + ms.s_stride) * count;
+    return KR_OK;
+}
+
+static int upload_mat(kr_engine* e, MatSet& ms, int idx, const void* w, const uint16_t* sc) {
+    std::vector<uint32_t> dq(ms.q_stride / 4), ds(ms.s_stride / 4);
+    if (ms.bits == 4) retile_int4((const uint32_t*)w, sc, ms.K, ms.N, dq.data(), ds.data());
+    else retile_int8((const int8_t*)w, sc, ms.K, ms.N, dq.data(), ds.data());
+    KR_HIP(hipMemcpy((char*)ms.q.p + (size_t)idx * ms.q_stride, dq.data(), ms.q_stride, hipMemcpyHostToDevice));
+    KR_HIP(hipMemcpy((char*)ms.s.p + (size_t)idx * ms.s_stride, ds.data(), ms.s_stride, hipMemcpyHostToDevice));
+    (void)e;
+    return KR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int kr_engine_create(int device, const kr_model_config* cfg, kr_engine** out) {
+    if (!cfg || !out) return kr_fail(KR_ERR_VALUE, "null argument");
+    if (cfg->hidden_size <= 0 || cfg->hidden_size % 128 != 0)
+        return kr_fail(KR_ERR_VALUE, "hidden_size (%d) must be divisible by group_size (128)", cfg->hidden_size);
+    if (cfg->group_size != 128) return kr_fail(KR_ERR_VALUE, "group_size %d unsupported (reference default 128, marlin.rs:12)", cfg->group_size);
+    if (cfg->num_experts_per_tok > KR_MAX_TOPK) return kr_fail(KR_ERR_VALUE, "topk %d > MAX_TOPK 32", cfg->num_experts_per_tok);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return kr_fail(KR_ERR_HIP, "no HIP device available: libkrasis_hip.so has no CPU fallback");
+    }
+    if (device < 0 || device >= ndev) return kr_fail(KR_ERR_VALUE, "device ordinal %d out of range (%d devices)", device, ndev);
+    KR_HIP(hipSetDevice(device));
+    std::unique_ptr<kr_engine> e(new kr_engine);
+    e->device = device; e->cfg = *cfg;
+    e->layers.resize(cfg->num_moe_layers);
+    for (auto& l : e->layers) l.present.assign(cfg->n_routed_experts, 0);
+    KR_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    *out = e.release();
+    return KR_OK;
+}
+
+extern "C" void kr_engine_destroy(kr_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& l : e->layers) {
+        l.w13.q.release(); l.w13.s.release(); l.w2.q.release(); l.w2.s.release();
+        l.sw13.q.release(); l.sw13.s.release(); l.sw2.q.release(); l.sw2.s.release();
+        l.gate_cm.release(); l.gate_rm.release(); l.bias.release(); l.esc.release();
+    }
+    for (DevBuf* b : {&e->gu, &e->eo, &e->st_act, &e->st_ids, &e->st_w, &e->st_out, &e->ptr_table, &e->r_logits, &e->r_ids, &e->r_w, &e->r_x}) b->release();
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int kr_engine_get_config(const kr_engine* e, kr_model_config* out) {
+    if (!e || !out) return kr_fail(KR_ERR_VALUE, "null argument");
+    *out = e->cfg; return KR_OK;
+}
+extern "C" size_t kr_engine_device_bytes(const kr_engine* e) { return e ? e->weight_bytes : 0; }
+extern "C" int kr_synchronize(kr_engine* e) {
+    if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
+    KR_HIP(hipSetDevice(e->device));
+    KR_HIP(hipStreamSynchronize(e->stream));
+    return KR_OK;
+}
+
+static int check_layer(kr_engine* e, int layer) {
+    if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
+    if (layer < 0 || layer >= (int)e->layers.size())
+        return kr_fail(KR_ERR_VALUE, "moe_layer_idx %d out of range (have %zu MoE layers)", layer, e->layers.size());
+    return KR_OK;
+}
+
+extern "C" int kr_upload_expert_unified(kr_engine* e, int layer, int expert, int inter, const void* w13,
+                                        const uint16_t* w13_scales, int w13_bits, const void* w2,
+                                        const uint16_t* w2_scales, int w2_bits) {
+    if (int rc = check_layer(e, layer)) return rc;
+    if (!w13 || !w13_scales || !w2 || !w2_scales) return kr_fail(KR_ERR_VALUE, "null weight pointer");
+    if ((w13_bits != 4 && w13_bits != 8) || (w2_bits != 4 && w2_bits != 8))
+        return kr_fail(KR_ERR_VALUE, "Unsupported num_bits: %d/%d", w13_bits, w2_bits);
+    if (inter <= 0 || inter % 128 != 0) return kr_fail(KR_ERR_VALUE, "intermediate size (%d) must be divisible by group_size (128)", inter);
+    KR_HIP(hipSetDevice(e->device));
+    Layer& L = e->layers[layer];
+    const int H = e->cfg.hidden_size;
+    if (expert == -1) {
+        if (int rc = matset_alloc(e, L.sw13, H, 2 * inter, w13_bits, 1)) return rc;
+        if (int rc = matset_alloc(e, L.sw2, inter, H, w2_bits, 1)) return rc;
+        if (int rc = upload_mat(e, L.sw13, 0, w13, w13_scales)) return rc;
+        if (int rc = upload_mat(e, L.sw2, 0, w2, w2_scales)) return rc;
+        L.shared_present = true; L.shared_inter = inter;
+        return KR_OK;
+    }
+    if (expert < 0 || expert >= e->cfg.n_routed_experts)
+        return kr_fail(KR_ERR_VALUE, "expert index %d out of range (%d experts)", expert, e->cfg.n_routed_experts);
+    if (int rc = matset_alloc(e, L.w13, H, 2 * inter, w13_bits, e->cfg.n_routed_experts)) return rc;
+    if (int rc = matset_alloc(e, L.w2, inter, H, w2_bits, e->cfg.n_routed_experts)) return rc;
+    if (int rc = upload_mat(e, L.w13, expert, w13, w13_scales)) return rc;
+    if (int rc = upload_mat(e, L.w2, expert, w2, w2_scales)) return rc;
+    L.present[expert] = 1; L.inter = inter;
+    return KR_OK;
+}
+
+extern "C" int kr_fill_layer_synthetic(kr_engine* e, int layer, int bits, uint64_t seed) {
+    if (int rc = check_layer(e, layer)) return rc;
+    if (bits != 4 && bits != 8) return kr_fail(KR_ERR_VALUE, "Unsupported num_bits: %d", bits);
+    KR_HIP(hipSetDevice(e->device));
+    Layer& L = e->layers[layer];
+    const int H = e->cfg.hidden_size, I = e->cfg.moe_intermediate_size, E = e->cfg.n_routed_experts;
+    if (int rc = matset_alloc(e, L.w13, H, 2 * I, bits, E)) return rc;
+    if (int rc = matset_alloc(e, L.w2, I, H, bits, E)) return rc;
+    kr_launch_fill_synth(L.w13.q.p, L.w13.q_stride * E, (uint32_t*)L.w13.s.p, L.w13.s_stride * E / 4, seed * 4 + 0, e->stream);
+    kr_launch_fill_synth(L.w2.q.p, L.w2.q_stride * E, (uint32_t*)L.w2.s.p, L.w2.s_stride * E / 4, seed * 4 + 1, e->stream);
+    std::fill(L.present.begin(), L.present.end(), 1); L.inter = I;
+    if (e->cfg.n_shared_experts > 0) {
+        const int SI = I * e->cfg.n_shared_experts;
+        if (int rc = matset_alloc(e, L.sw13, H, 2 * SI, bits, 1)) return rc;
+        if (int rc = matset_alloc(e, L.sw2, SI, H, bits, 1)) return rc;
+        kr_launch_fill_synth(L.sw13.q.p, L.sw13.q_stride, (uint32_t*)L.sw13.s.p, L.sw13.s_stride / 4, seed * 4 + 2, e->stream);
+        kr_launch_fill_synth(L.sw2.q.p, L.sw2.q_stride, (uint32_t*)L.sw2.s.p, L.sw2.s_stride / 4, seed * 4 + 3, e->stream);
+        L.shared_present = true; L.shared_inter = SI;
+    }
+    KR_HIP(hipStreamSynchronize(e->stream));
+    return KR_OK;
+}
+
+extern "C" int kr_download_expert_unified(kr_engine* e, int layer, int expert, void* w13, uint16_t* w13_scales,
+                                          void* w2, uint16_t* w2_scales) {
+    if (int rc = check_layer(e, layer)) return rc;
+    KR_HIP(hipSetDevice(e->device));
+    Layer& L = e->layers[layer];
+    MatSet& a = expert == -1 ? L.sw13 : L.w13;
+    MatSet& b = expert == -1 ? L.sw2 : L.w2;
+    const int idx = expert == -1 ? 0 : expert;
+    if (!a.allocated() || (expert >= 0 && (expert >= a.count || !L.present[expert])) || (expert == -1 && !L.shared_present))
+        return kr_fail(KR_ERR_STATE, "expert %d of layer %d not loaded", expert, layer);
+    for (int which = 0; which < 2; which++) {
+        MatSet& ms = which == 0 ? a : b;
+        std::vector<uint32_t> dq(ms.q_stride / 4), ds(ms.s_stride / 4);
+        KR_HIP(hipMemcpy(dq.data(), (char*)ms.q.p + (size_t)idx * ms.q_stride, ms.q_stride, hipMemcpyDeviceToHost));
+        KR_HIP(hipMemcpy(ds.data(), (char*)ms.s.p + (size_t)idx * ms.s_stride, ms.s_stride, hipMemcpyDeviceToHost));
+        void* dst = which == 0 ? w13 : w2; uint16_t* sc = which == 0 ? w13_scales : w2_scales;
+        if (ms.bits == 4) untile_int4(dq.data(), ds.data(), ms.K, ms.N, (uint32_t*)dst, sc);
+        else untile_int8(dq.data(), ds.data(), ms.K, ms.N, (int8_t*)dst, sc);
+    }
+    return KR_OK;
+}
+
+extern "C" int kr_upload_expert_gguf(kr_engine*, int, int, int, const uint8_t*, const uint8_t*, int, const uint8_t*, int) {
+    return kr_fail(KR_ERR_STATE, "native GGUF block kernels are not built yet in this round (INT4/INT8-g128 only)");
+}
+
+// stage an argument that may live on the host
+static int stage_in(kr_engine* e, DevBuf& buf, const void* p, size_t bytes, const void** dev) {
+    if (is_device_ptr(p)) { *dev = p; return KR_OK; }
+    if (buf.ensure(bytes)) return kr_fail(KR_ERR_HIP, "hipMalloc of staging buffer failed");
+    KR_HIP(hipMemcpyAsync(buf.p, p, bytes, hipMemcpyHostToDevice, e->stream));
+    *dev = buf.p; return KR_OK;
+}
+
+extern "C" int kr_moe_forward(kr_engine* e, int layer, const void* act, const int32_t* ids, const float* wts,
+                              void* out, int batch, int topk, int out_dtype, int routed_only, void* stream) {
+    if (int rc = check_layer(e, layer)) return rc;
+    if (!act || !ids || !wts || !out) return kr_fail(KR_ERR_VALUE, "null pointer argument");
+    if (batch <= 0) return kr_fail(KR_ERR_VALUE, "batch_size must be > 0");
+    if (topk <= 0 || topk > KR_MAX_TOPK) return kr_fail(KR_ERR_VALUE, "topk %d exceeds MAX_TOPK %d", topk, KR_MAX_TOPK);
+    if (batch > 65535) return kr_fail(KR_ERR_VALUE, "batch %d too large for the decode path (use the prefill entry point)", batch);
+    Layer& L = e->layers[layer];
+    if (!L.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded -- call load() first (layer %d has no experts)", layer);
+    std::lock_guard<std::mutex> lk(e->mu);
+    KR_HIP(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    if (stream && st != e->stream) { /* staging copies are issued on the caller's stream too */ }
+    const int H = e->cfg.hidden_size;
+    const bool use_shared = L.shared_present && !routed_only;
+    KrMoeArgs a{};
+    a.B = batch; a.topk = topk; a.n_slots = topk + (use_shared ? 1 : 0);
+    a.H = H; a.I = L.inter; a.I_shared = L.shared_inter;
+    a.w13 = L.w13.view(); a.w2 = L.w2.view();
+    if (use_shared) { a.sw13 = L.sw13.view(); a.sw2 = L.sw2.view(); }
+    const int imax = use_shared && L.shared_inter > L.inter ? L.shared_inter : L.inter;
+    a.gu_ld = 2 * imax;
+    if (e->gu.ensure((size_t)batch * a.n_slots * a.gu_ld * 4) || e->eo.ensure((size_t)batch * a.n_slots * H * 4))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of MoE scratch failed");
+    a.gu = (float*)e->gu.p; a.eo = (float*)e->eo.p;
+    hipStream_t saved = e->stream; e->stream = st;
+    const void *d_act, *d_ids, *d_w;
+    int rc = stage_in(e, e->st_act, act, (size_t)batch * H * 2, &d_act);
+    if (!rc) rc = stage_in(e, e->st_ids, ids, (size_t)batch * topk * 4, &d_ids);
+    if (!rc) rc = stage_in(e, e->st_w, wts, (size_t)batch * topk * 4, &d_w);
+    e->stream = saved;
+    if (rc) return rc;
+    a.act = (const uint16_t*)d_act; a.ids = (const int32_t*)d_ids; a.wts = (const float*)d_w;
+    const size_t out_bytes = (size_t)batch * H * (out_dtype == KR_OUT_BF16 ? 2 : 4);
+    const bool out_dev = is_device_ptr(out);
+    if (!out_dev && e->st_out.ensure(out_bytes)) return kr_fail(KR_ERR_HIP, "hipMalloc of staging buffer failed");
+    a.out = out_dev ? out : e->st_out.p; a.out_bf16 = out_dtype == KR_OUT_BF16;
+    // moe.rs:703-706 applies rsf only together with a shared expert; callers that pass routed_only
+    // (GpuPrefillManager.forward(routed_only=True), gpu_prefill.py:4467) get the bare weighted sum.
+    a.rsf = e->cfg.routed_scaling_factor; a.swiglu_limit = e->cfg.swiglu_limit; a.alpha = e->cfg.activation_alpha;
+    a.act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
+    kr_launch_moe_decode(a, st);
+    KR_HIP(hipGetLastError());
+    if (!out_dev) {
+        KR_HIP(hipMemcpyAsync(out, e->st_out.p, out_bytes, hipMemcpyDeviceToHost, st));
+        KR_HIP(hipStreamSynchronize(st));
+    }
+    return KR_OK;
+}
+
+extern "C" int kr_reduce_sum_bf16(kr_engine* e, const void* const* inputs, int n_inputs, void* out, size_t n, void* stream) {
+    if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
+    if (n_inputs <= 0) return KR_OK;  // moe.rs:2511
+    KR_HIP(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    for (int i = 0; i < n_inputs; i++)
+        if (!is_device_ptr(inputs[i])) return kr_fail(KR_ERR_VALUE, "kr_reduce_sum_bf16 expects device pointers");
+    if (!is_device_ptr(out)) return kr_fail(KR_ERR_VALUE, "kr_reduce_sum_bf16 expects device pointers");
+    if (e->ptr_table.ensure(sizeof(void*) * 64)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    if (n_inputs > 64) return kr_fail(KR_ERR_VALUE, "too many inputs (%d > 64)", n_inputs);
+    KR_HIP(hipMemcpyAsync(e->ptr_table.p, inputs, sizeof(void*) * n_inputs, hipMemcpyHostToDevice, st));
+    kr_launch_reduce_sum_bf16((const uint16_t* const*)e->ptr_table.p, n_inputs, (uint16_t*)out, n, st);
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
+// routing entry points live in kr_router.cpp-equivalent section below (implemented with kr_router.hip)
+extern "C" int kr_set_routing_config(kr_engine* e, int scoring, int norm_topk_prob, int topk, int n_experts, int hidden) {
+    if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
+    if (scoring < 0 || scoring > 2) return kr_fail(KR_ERR_VALUE, "unknown scoring_func %d", scoring);
+    if (topk <= 0 || topk > KR_MAX_TOPK || topk > n_experts) return kr_fail(KR_ERR_VALUE, "bad topk %d for %d experts", topk, n_experts);
+    e->routing_set = true; e->r_scoring = scoring; e->r_norm = norm_topk_prob; e->r_topk = topk; e->r_ne = n_experts; e->r_hidden = hidden;
+    return KR_OK;
+}
+
+static inline uint16_t f32_to_bf16_bits(float f) {
+    uint32_t b; memcpy(&b, &f, 4);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
+}
+
+extern "C" int kr_set_routing_weights(kr_engine* e, int layer, const void* gate, int gate_is_f32, const float* bias,
+                                      const float* e_score_corr) {
+    if (int rc = check_layer(e, layer)) return rc;
+    if (!e->routing_set) return kr_fail(KR_ERR_STATE, "Routing config not set");
+    if (!gate) return kr_fail(KR_ERR_VALUE, "null gate pointer");
+    KR_HIP(hipSetDevice(e->device));
+    Layer& L = e->layers[layer];
+    const int E = e->r_ne, H = e->r_hidden;
+    if (H % 128 != 0) return kr_fail(KR_ERR_VALUE, "router hidden dim %d must be a multiple of 128", H);
+    L.gate_host.resize((size_t)E * H);
+    bool exact = true;
+    if (gate_is_f32) {
+        memcpy(L.gate_host.data(), gate, (size_t)E * H * 4);
+        for (size_t i = 0; i < (size_t)E * H && exact; i++) {
+            uint32_t b; memcpy(&b, &L.gate_host[i], 4);
+            exact = (b & 0xFFFFu) == 0;
+        }
+    } else {
+        const uint16_t* g = (const uint16_t*)gate;
+        for (size_t i = 0; i < (size_t)E * H; i++) { uint32_t b = (uint32_t)g[i] << 16; memcpy(&L.gate_host[i], &b, 4); }
+    }
+    L.gate_bf16_exact = exact;
+    const int neb = (E + 3) / 4;
+    if (exact) {
+        const int nc = H / 128;
+        std::vector<uint16_t> cm((size_t)neb * nc * 64 * 8, 0);
+        for (int eb = 0; eb < neb; eb++) for (int c = 0; c < nc; c++) for (int lane = 0; lane < 64; lane++) {
+            const int ex = eb * 4 + lane / 16, j = lane % 16;
+            if (ex >= E) continue;
+            for (int u = 0; u < 8; u++) {
+                uint32_t b; memcpy(&b, &L.gate_host[(size_t)ex * H + 16 * (8 * c + u) + j], 4);
+                cm[(((size_t)eb * nc + c) * 64 + lane) * 8 + u] = (uint16_t)(b >> 16);
+            }
+        }
+        if (L.gate_cm.ensure(cm.size() * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+        KR_HIP(hipMemcpy(L.gate_cm.p, cm.data(), cm.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        const int nc = H / 64;
+        std::vector<float> cm((size_t)neb * nc * 64 * 4, 0.0f);
+        for (int eb = 0; eb < neb; eb++) for (int c = 0; c < nc; c++) for (int lane = 0; lane < 64; lane++) {
+            const int ex = eb * 4 + lane / 16, j = lane % 16;
+            if (ex >= E) continue;
+            for (int u = 0; u < 4; u++) cm[(((size_t)eb * nc + c) * 64 + lane) * 4 + u] = L.gate_host[(size_t)ex * H + 16 * (4 * c + u) + j];
+        }
+        if (L.gate_cm.ensure(cm.size() * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+        KR_HIP(hipMemcpy(L.gate_cm.p, cm.data(), cm.size() * 4, hipMemcpyHostToDevice));
+    }
+    L.gate_rm.release();
+    L.has_bias = bias != nullptr; L.has_esc = e_score_corr != nullptr;
+    if (bias) { if (L.bias.ensure((size_t)E * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed"); KR_HIP(hipMemcpy(L.bias.p, bias, (size_t)E * 4, hipMemcpyHostToDevice)); }
+    if (e_score_corr) { if (L.esc.ensure((size_t)E * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed"); KR_HIP(hipMemcpy(L.esc.p, e_score_corr, (size_t)E * 4, hipMemcpyHostToDevice)); }
+    L.routing_present = true;
+    return KR_OK;
+}
+
+static int build_gate_rm(kr_engine* e, Layer& L) {
+    if (L.gate_rm.p) return KR_OK;
+    if (!L.gate_bf16_exact) return kr_fail(KR_ERR_VALUE, "engine routing rule needs a bf16 gate (moe.rs:2990); this layer's gate is not bf16-exact");
+    const int E = e->r_ne, H = e->r_hidden, neb = (E + 63) / 64;
+    std::vector<uint16_t> rm((size_t)neb * (H / 8) * 64 * 8, 0);
+    for (int eb = 0; eb < neb; eb++) for (int c = 0; c < H / 8; c++) for (int lane = 0; lane < 64; lane++) {
+        const int ex = eb * 64 + lane;
+        if (ex >= E) continue;
+        for (int u = 0; u < 8; u++) {
+            uint32_t b; memcpy(&b, &L.gate_host[(size_t)ex * H + 8 * c + u], 4);
+            rm[(((size_t)eb * (H / 8) + c) * 64 + lane) * 8 + u] = (uint16_t)(b >> 16);
+        }
+    }
+    if (L.gate_rm.ensure(rm.size() * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    KR_HIP(hipMemcpy(L.gate_rm.p, rm.data(), rm.size() * 2, hipMemcpyHostToDevice));
+    return KR_OK;
+}
+
+// routes m tokens; results stay on the device in e->r_ids / e->r_w (and e->r_logits)
+static int route_device(kr_engine* e, Layer& L, const void* d_x, int m, int rule, hipStream_t st) {
+    const int E = e->r_ne, H = e->r_hidden, k = e->r_topk;
+    if (e->r_logits.ensure((size_t)m * E * 4) || e->r_ids.ensure((size_t)m * k * 4) || e->r_w.ensure((size_t)m * k * 4))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of routing scratch failed");
+    const int gptoss = e->cfg.swiglu_limit > 0.0f;
+    if (rule == KR_ROUTE_RULE_DECODE) {
+        kr_launch_route_logits_decode(L.gate_cm.p, L.gate_bf16_exact, (const float*)d_x, L.has_bias ? (const float*)L.bias.p : nullptr,
+                                      (float*)e->r_logits.p, m, E, H, st);
+    } else {
+        if (int rc = build_gate_rm(e, L)) return rc;
+        kr_launch_route_logits_engine(L.gate_rm.p, (const uint16_t*)d_x, (float*)e->r_logits.p, m, E, H, st);
+    }
+    kr_launch_route_select((const float*)e->r_logits.p, L.has_esc ? (const float*)L.esc.p : nullptr, (int32_t*)e->r_ids.p,
+                           (float*)e->r_w.p, m, E, k, e->r_scoring, e->r_norm, rule, gptoss, st);
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
+static int copy_out(void* dst, const void* dev_src, size_t bytes, hipStream_t st, bool* need_sync) {
+    if (!dst) return KR_OK;
+    if (is_device_ptr(dst)) { KR_HIP(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToDevice, st)); }
+    else { KR_HIP(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToHost, st)); *need_sync = true; }
+    return KR_OK;
+}
+
+extern "C" int kr_route_topk(kr_engine* e, int layer, const void* x, int m, int rule, int32_t* ids_out, float* w_out,
+                             float* logits_out, void* stream) {
+    if (int rc = check_layer(e, layer)) return rc;
+    if (!e->routing_set) return kr_fail(KR_ERR_STATE, "Routing config not set");
+    Layer& L = e->layers[layer];
+    if (!L.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", layer);
+    if (!x || m <= 0) return kr_fail(KR_ERR_VALUE, "bad arguments");
+    if (rule != KR_ROUTE_RULE_DECODE && rule != KR_ROUTE_RULE_ENGINE) return kr_fail(KR_ERR_VALUE, "unknown routing rule %d", rule);
+    std::lock_guard<std::mutex> lk(e->mu);
+    KR_HIP(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const size_t xb = (size_t)m * e->r_hidden * (rule == KR_ROUTE_RULE_DECODE ? 4 : 2);
+    const void* d_x = x;
+    if (!is_device_ptr(x)) {
+        if (e->r_x.ensure(xb)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+        KR_HIP(hipMemcpyAsync(e->r_x.p, x, xb, hipMemcpyHostToDevice, st));
+        d_x = e->r_x.p;
+    }
+    if (int rc = route_device(e, L, d_x, m, rule, st)) return rc;
+    bool need_sync = false;
+    if (int rc = copy_out(ids_out, e->r_ids.p, (size_t)m * e->r_topk * 4, st, &need_sync)) return rc;
+    if (int rc = copy_out(w_out, e->r_w.p, (size_t)m * e->r_topk * 4, st, &need_sync)) return rc;
+    if (int rc = copy_out(logits_out, e->r_logits.p, (size_t)m * e->r_ne * 4, st, &need_sync)) return rc;
+    if (need_sync) KR_HIP(hipStreamSynchronize(st));
+    return KR_OK;
+}
+
+extern "C" int kr_forward_moe_routed(kr_engine* e, int layer, const void* act_bf16, void* out_bf16, void* stream) {
+    if (int rc = check_layer(e, layer)) return rc;
+    Layer& L = e->layers[layer];
+    if (!L.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded");
+    if (!e->routing_set) return kr_fail(KR_ERR_STATE, "Routing config not set");
+    if (!L.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", layer);
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const void* d_act = act_bf16;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        KR_HIP(hipSetDevice(e->device));
+        if (!is_device_ptr(act_bf16)) {
+            if (e->r_x.ensure((size_t)e->r_hidden * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+            KR_HIP(hipMemcpyAsync(e->r_x.p, act_bf16, (size_t)e->r_hidden * 2, hipMemcpyHostToDevice, st));
+            d_act = e->r_x.p;
+        }
+        if (int rc = route_device(e, L, d_act, 1, KR_ROUTE_RULE_ENGINE, st)) return rc;
+    }
+    return kr_moe_forward(e, layer, d_act, (const int32_t*)e->r_ids.p, (const float*)e->r_w.p, out_bf16, 1, e->r_topk,
+                          KR_OUT_BF16, 0, st);
+}

@@ -1,0 +1,60 @@
+// kr_kernels.h -- host-visible launch wrappers for the gfx950 kernels (implemented in *.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// One quantized [K -> N] matrix in the lane-tiled HBM layout:
+//   INT4-g128: q = [N/8 tiles][ngp group-pairs][64 lanes] x 16 B, lane = col*8 + l holds packed words
+//              {W(g0,2l), W(g0,2l+1), W(g1,2l), W(g1,2l+1)}, W(g,i) = nibbles k = g*128+8i..+8 of the column
+//   INT8-g128: q = [N/8 tiles][ng groups][64 lanes] x 16 B, lane holds k = g*128+16l..+16 of the column
+//   scales   : s = [N/8 tiles][ngp][8 cols] u32 = bf16(even group) | bf16(odd group) << 16
+struct KrMatDev {
+    const void* q;
+    const uint32_t* s;
+    int K, N;        // logical dims (N = outputs)
+    int ng, ngp;     // groups of 128, group pairs (ceil)
+    int bits;        // 4 or 8
+    int n_fma;       // columns < n_fma accumulate with fma (avx2.rs:1175), the tail with mul+add (avx2.rs:1201)
+    size_t q_stride; // bytes between consecutive experts (0 for a single matrix)
+    size_t s_stride;
+};
+
+static inline size_t kr_mat_q_bytes(int K, int N, int bits) {
+    const int ng = (K + 127) / 128, ngp = (ng + 1) / 2, nt = (N + 7) / 8;
+    return (size_t)nt * (bits == 4 ? ngp : ng) * 64 * 16;
+}
+static inline size_t kr_mat_s_bytes(int K, int N) {
+    const int ng = (K + 127) / 128, ngp = (ng + 1) / 2, nt = (N + 7) / 8;
+    return (size_t)nt * ngp * 8 * 4;
+}
+
+// activation transform feeding the down projection
+enum { KR_ACT_SILU_FUSED = 0,  // silu_quantize_int16_avx2 (avx2.rs:2310): poly sigmoid, RNE quant
+       KR_ACT_GPTOSS = 1,      // moe.rs:268-287: clamp, gate*sigmoid(alpha*gate)*(up+1), round-half-away quant
+       KR_ACT_SILU_MUL = 2 };  // fast_silu_mul_avx2 + quantize_activation_int16_f32 (decode.rs:3364-3374)
+
+struct KrMoeArgs {
+    const uint16_t* act;   // bf16 [B,H]
+    const int32_t* ids;    // [B,topk]
+    const float* wts;      // [B,topk]
+    int B, topk, n_slots;  // n_slots = topk (+1 when the shared expert runs in the same launches)
+    int H, I, I_shared;
+    KrMatDev w13, w2;      // routed experts of the layer: expert e at q + e*q_stride
+    KrMatDev sw13, sw2;    // shared expert (valid when n_slots > topk)
+    float* gu;             // scratch [B][n_slots][gu_ld]   (gate | up)
+    float* eo;             // scratch [B][n_slots][H]
+    int gu_ld;
+    void* out;             // [B,H] f32 or bf16
+    int out_bf16;
+    float rsf, swiglu_limit, alpha;
+    int act_mode;
+};
+
+void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st);
+
+// generic single-matrix matvec: y[N] = W . quant(x[K]); x f32 or bf16; used for projections / lm_head
+void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st);
+
+void kr_launch_fill_synth(void* q, size_t q_bytes, uint32_t* s, size_t s_words, uint64_t seed, hipStream_t st);
+void kr_launch_reduce_sum_bf16(const uint16_t* const* dev_ptr_table, int n_inputs, uint16_t* out, size_t n, hipStream_t st);

