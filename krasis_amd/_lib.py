@@ -17,7 +17,8 @@ SYMBOLS = [
     "kr_last_error", "kr_version", "kr_engine_create", "kr_engine_destroy", "kr_engine_get_config",
     "kr_engine_device_bytes", "kr_upload_expert_unified", "kr_upload_expert_gguf", "kr_fill_layer_synthetic",
     "kr_download_expert_unified", "kr_moe_forward", "kr_set_routing_config", "kr_set_routing_weights",
-    "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_synchronize",
+    "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_synchronize", "kr_set_profiling",
+    "kr_get_profile",
 ]
 
 
@@ -47,6 +48,12 @@ def load_library() -> C.CDLL:
     if not os.path.exists(_LIB):
         raise KrasisHipError(f"{_LIB} is missing: build it with `make -C krasis_amd/csrc` (hipcc, gfx950). "
                              "krasis_amd has no CPU fallback.")
+    # PyTorch-ROCm ships its own libamdhip64; import it first so this library binds to the SAME HIP runtime
+    # (one context, torch device pointers valid here).  Loading the system runtime next to torch's breaks both.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - C/C++ consumers link the system runtime directly
+        pass
     lib = C.CDLL(_LIB)
     lib.kr_last_error.restype = C.c_char_p
     lib.kr_engine_device_bytes.restype = C.c_size_t
@@ -70,6 +77,8 @@ def load_library() -> C.CDLL:
     lib.kr_forward_moe_routed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.kr_reduce_sum_bf16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.kr_synchronize.argtypes = [C.c_void_p]
+    lib.kr_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.kr_get_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     _lib = lib
     return lib
 

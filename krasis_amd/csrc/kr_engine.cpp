@@ -91,6 +91,8 @@ struct kr_engine {
     // routing config
     bool routing_set = false; int r_scoring = 1, r_norm = 1, r_topk = 0, r_ne = 0, r_hidden = 0;
     DevBuf r_logits, r_ids, r_w, r_x;
+    // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
+    bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};
     std::mutex mu;
 };
 
@@ -403,7 +405,17 @@ extern "C" int kr_moe_forward(kr_engine* e, int layer, const void* act, const in
     // (GpuPrefillManager.forward(routed_only=True), gpu_prefill.py:4467) get the bare weighted sum.
     a.rsf = e->cfg.routed_scaling_factor; a.swiglu_limit = e->cfg.swiglu_limit; a.alpha = e->cfg.activation_alpha;
     a.act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
-    kr_launch_moe_decode(a, st);
+    if (!e->prof) {
+        kr_launch_moe_decode(a, st);
+    } else {
+        for (int i = 0; i < 4; i++) if (!e->pev[i]) KR_HIP(hipEventCreate(&e->pev[i]));
+        KR_HIP(hipEventRecord(e->pev[0], st)); kr_launch_moe_w13(a, st);
+        KR_HIP(hipEventRecord(e->pev[1], st)); kr_launch_moe_w2(a, st);
+        KR_HIP(hipEventRecord(e->pev[2], st)); kr_launch_moe_combine(a, st);
+        KR_HIP(hipEventRecord(e->pev[3], st));
+        KR_HIP(hipEventSynchronize(e->pev[3]));
+        for (int i = 0; i < 3; i++) { float ms = 0; KR_HIP(hipEventElapsedTime(&ms, e->pev[i], e->pev[i + 1])); e->prof_ms[i] += ms; e->prof_n[i]++; }
+    }
     KR_HIP(hipGetLastError());
     if (!out_dev) {
         KR_HIP(hipMemcpyAsync(out, e->st_out.p, out_bytes, hipMemcpyDeviceToHost, st));
@@ -589,4 +601,19 @@ extern "C" int kr_forward_moe_routed(kr_engine* e, int layer, const void* act_bf
     }
     return kr_moe_forward(e, layer, d_act, (const int32_t*)e->r_ids.p, (const float*)e->r_w.p, out_bf16, 1, e->r_topk,
                           KR_OUT_BF16, 0, st);
+}
+
+// ---- profiling hooks used by bench.py (HIP events on the launch stream, per kernel kind) ----
+// kinds: 0 = kr_moe_w13_kernel, 1 = kr_moe_w2_kernel, 2 = kr_moe_combine_kernel
+extern "C" int kr_set_profiling(kr_engine* e, int enable) {
+    if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
+    e->prof = enable != 0;
+    for (int i = 0; i < 8; i++) { e->prof_ms[i] = 0; e->prof_n[i] = 0; }
+    return KR_OK;
+}
+extern "C" int kr_get_profile(kr_engine* e, int kind, double* total_ms, long* launches) {
+    if (!e || kind < 0 || kind >= 8) return kr_fail(KR_ERR_VALUE, "bad profile kind");
+    if (total_ms) *total_ms = e->prof_ms[kind];
+    if (launches) *launches = e->prof_n[kind];
+    return KR_OK;
 }

@@ -52,6 +52,9 @@ struct KrMoeArgs {
 };
 
 void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st);
+void kr_launch_moe_w13(const KrMoeArgs& a, hipStream_t st);
+void kr_launch_moe_w2(const KrMoeArgs& a, hipStream_t st);
+void kr_launch_moe_combine(const KrMoeArgs& a, hipStream_t st);
 
 // generic single-matrix matvec: y[N] = W . quant(x[K]); x f32 or bf16; used for projections / lm_head
 void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st);

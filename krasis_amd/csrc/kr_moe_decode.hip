@@ -333,39 +333,46 @@ static int kr_pick_tpw(int K, int ntiles) {
     return tpw;
 }
 
-void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st) {
+void kr_launch_moe_w13(const KrMoeArgs& a, hipStream_t st) {
     const bool has_shared = a.n_slots > a.topk;
-    {
-        int nt = (a.w13.N + 7) / 8;
-        if (has_shared && (a.sw13.N + 7) / 8 > nt) nt = (a.sw13.N + 7) / 8;
-        const int tpw = kr_pick_tpw(a.H, nt);
-        dim3 grid((nt + KR_WAVES * tpw - 1) / (KR_WAVES * tpw), a.n_slots, a.B);
-        const size_t lds = kr_lds_bytes(a.H, a.w13.bits == 8);
-        if (a.w13.bits == 4) hipLaunchKernelGGL(kr_moe_w13_kernel<4>, grid, dim3(KR_BLOCK), lds, st, a, tpw);
-        else hipLaunchKernelGGL(kr_moe_w13_kernel<8>, grid, dim3(KR_BLOCK), lds, st, a, tpw);
-    }
-    {
-        const int nt = (a.H + 7) / 8;
-        const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
-        const int tpw = kr_pick_tpw(a.I, nt);
-        dim3 grid((nt + KR_WAVES * tpw - 1) / (KR_WAVES * tpw), a.n_slots, a.B);
-        const size_t lds = kr_lds_bytes(imax, a.w2.bits == 8);
+    int nt = (a.w13.N + 7) / 8;
+    if (has_shared && (a.sw13.N + 7) / 8 > nt) nt = (a.sw13.N + 7) / 8;
+    const int tpw = kr_pick_tpw(a.H, nt);
+    dim3 grid((nt + KR_WAVES * tpw - 1) / (KR_WAVES * tpw), a.n_slots, a.B);
+    const size_t lds = kr_lds_bytes(a.H, a.w13.bits == 8);
+    if (a.w13.bits == 4) hipLaunchKernelGGL(kr_moe_w13_kernel<4>, grid, dim3(KR_BLOCK), lds, st, a, tpw);
+    else hipLaunchKernelGGL(kr_moe_w13_kernel<8>, grid, dim3(KR_BLOCK), lds, st, a, tpw);
+}
+
+void kr_launch_moe_w2(const KrMoeArgs& a, hipStream_t st) {
+    const bool has_shared = a.n_slots > a.topk;
+    const int nt = (a.H + 7) / 8;
+    const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
+    const int tpw = kr_pick_tpw(a.I, nt);
+    dim3 grid((nt + KR_WAVES * tpw - 1) / (KR_WAVES * tpw), a.n_slots, a.B);
+    const size_t lds = kr_lds_bytes(imax, a.w2.bits == 8);
 #define KR_W2(B_, A_) hipLaunchKernelGGL((kr_moe_w2_kernel<B_, A_>), grid, dim3(KR_BLOCK), lds, st, a, tpw)
-        if (a.w2.bits == 4) {
-            if (a.act_mode == KR_ACT_SILU_FUSED) KR_W2(4, KR_ACT_SILU_FUSED);
-            else if (a.act_mode == KR_ACT_GPTOSS) KR_W2(4, KR_ACT_GPTOSS);
-            else KR_W2(4, KR_ACT_SILU_MUL);
-        } else {
-            if (a.act_mode == KR_ACT_SILU_FUSED) KR_W2(8, KR_ACT_SILU_FUSED);
-            else if (a.act_mode == KR_ACT_GPTOSS) KR_W2(8, KR_ACT_GPTOSS);
-            else KR_W2(8, KR_ACT_SILU_MUL);
-        }
+    if (a.w2.bits == 4) {
+        if (a.act_mode == KR_ACT_SILU_FUSED) KR_W2(4, KR_ACT_SILU_FUSED);
+        else if (a.act_mode == KR_ACT_GPTOSS) KR_W2(4, KR_ACT_GPTOSS);
+        else KR_W2(4, KR_ACT_SILU_MUL);
+    } else {
+        if (a.act_mode == KR_ACT_SILU_FUSED) KR_W2(8, KR_ACT_SILU_FUSED);
+        else if (a.act_mode == KR_ACT_GPTOSS) KR_W2(8, KR_ACT_GPTOSS);
+        else KR_W2(8, KR_ACT_SILU_MUL);
+    }
 #undef KR_W2
-    }
-    {
-        dim3 grid((a.H + KR_BLOCK - 1) / KR_BLOCK, a.B);
-        hipLaunchKernelGGL(kr_moe_combine_kernel, grid, dim3(KR_BLOCK), 0, st, a);
-    }
+}
+
+void kr_launch_moe_combine(const KrMoeArgs& a, hipStream_t st) {
+    dim3 grid((a.H + KR_BLOCK - 1) / KR_BLOCK, a.B);
+    hipLaunchKernelGGL(kr_moe_combine_kernel, grid, dim3(KR_BLOCK), 0, st, a);
+}
+
+void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st) {
+    kr_launch_moe_w13(a, st);
+    kr_launch_moe_w2(a, st);
+    kr_launch_moe_combine(a, st);
 }
 
 void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st) {

@@ -1246,6 +1246,42 @@ void kro_matvec_int4_tiled_avx2(const uint32_t* pt, const uint16_t* st, const in
     }
 }
 
+/* CPU baseline for one MoE layer/token: the reference's moe_forward_unified on TILED weights with the AVX2 integer kernel,
+ * parallelised as 3 flat phases over (expert, 256-column tile) work items (the reference's moe_forward_flattened shape,
+ * moe.rs:727; results are bit-identical to the nested-rayon production path because every column is independent). */
+void kro_moe_forward_unified_tiled_avx2(const kro_unified_expert* const* ex, const float* weights, int n_sel,
+                                        const uint16_t* act, int sig_mode, float* out) {
+    if (n_sel <= 0) return;
+    const int H = ex[0]->hidden, I = ex[0]->inter, gs = ex[0]->gs;
+    int16_t* q = (int16_t*)malloc(2 * (size_t)H); float* qs = (float*)malloc(4 * (size_t)(H / gs));
+    float* gu = (float*)malloc(4 * (size_t)n_sel * 2 * I); float* eo = (float*)malloc(4 * (size_t)n_sel * H);
+    int16_t* hq = (int16_t*)malloc(2 * (size_t)n_sel * I); float* hs = (float*)malloc(4 * (size_t)n_sel * (I / gs));
+    kro_quant_act_int16_bf16(act, H, gs, q, qs);
+    const int t13 = (2 * I + KRO_TILE_N - 1) / KRO_TILE_N, t2 = (H + KRO_TILE_N - 1) / KRO_TILE_N;
+    const int kr13 = H / 8, ng13 = H / gs, kr2 = I / 8, ng2 = I / gs;
+#pragma omp parallel
+    {
+#pragma omp for schedule(dynamic, 1)
+        for (int it = 0; it < n_sel * t13; it++) {
+            int e = it / t13, t = it % t13; int n0 = t * KRO_TILE_N; int tn = 2 * I - n0 < KRO_TILE_N ? 2 * I - n0 : KRO_TILE_N;
+            int4_tile_avx2((const uint32_t*)ex[e]->w13 + (size_t)t * kr13 * KRO_TILE_N, ex[e]->w13_scales + (size_t)t * ng13 * KRO_TILE_N,
+                           q, qs, gu + (size_t)e * 2 * I + n0, H, KRO_TILE_N, tn & ~7, gs);
+        }
+#pragma omp for schedule(dynamic, 1)
+        for (int e = 0; e < n_sel; e++)
+            kro_silu_quant_int16(gu + (size_t)e * 2 * I, gu + (size_t)e * 2 * I + I, I, gs, sig_mode, NULL, hq + (size_t)e * I, hs + (size_t)e * (I / gs));
+#pragma omp for schedule(dynamic, 1)
+        for (int it = 0; it < n_sel * t2; it++) {
+            int e = it / t2, t = it % t2; int n0 = t * KRO_TILE_N; int tn = H - n0 < KRO_TILE_N ? H - n0 : KRO_TILE_N;
+            int4_tile_avx2((const uint32_t*)ex[e]->w2 + (size_t)t * kr2 * KRO_TILE_N, ex[e]->w2_scales + (size_t)t * ng2 * KRO_TILE_N,
+                           hq + (size_t)e * I, hs + (size_t)e * (I / gs), eo + (size_t)e * H + n0, I, KRO_TILE_N, tn & ~7, gs);
+        }
+    }
+    for (int j = 0; j < H; j++) out[j] = 0.0f;
+    for (int e = 0; e < n_sel; e++) { float w = weights[e]; for (int j = 0; j < H; j++) out[j] += w * eo[(size_t)e * H + j]; }
+    free(q); free(qs); free(gu); free(eo); free(hq); free(hs);
+}
+
 int kro_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

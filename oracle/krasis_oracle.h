@@ -175,6 +175,9 @@ void kro_xs_fill_f32_uniform(kro_xorshift64* r, float* dst, size_t n, float amp)
 /* ---- CPU baseline (AVX2 + OpenMP twin of kro_matvec_int4_t on the tiled layout; bit-identical) ---- */
 void kro_matvec_int4_tiled_avx2(const uint32_t* packed_tiled, const uint16_t* scales_tiled, const int16_t* a,
                                 const float* a_s, int k, int n, int gs, float* out, int parallel);
+/* experts' w13/w2 pointers must reference TILED arrays ([N/256][K/8][256] u32, scales [N/256][K/gs][256]) */
+void kro_moe_forward_unified_tiled_avx2(const kro_unified_expert* const* experts_tiled, const float* weights, int n_sel,
+                                        const uint16_t* act_bf16, int sig_mode, float* out);
 int  kro_num_threads(void);
 
 #ifdef __cplusplus

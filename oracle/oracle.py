@@ -279,6 +279,23 @@ def matvec_int4_tiled_avx2(packed_tiled, scales_tiled, a, a_s, k, n, gs=128, par
     return out
 
 
+def tile_expert(e: "UnifiedExpert") -> "UnifiedExpert":
+    """repack_experts_to_tiled (moe.rs:1435): [K/8,N] -> [N/256,K/8,256] for an INT4 expert."""
+    assert e.num_bits == 4 and e.w2_bits == 4
+    return UnifiedExpert(repack_tiled_u32(e.w13), repack_tiled_u16(e.w13_scales), repack_tiled_u32(e.w2),
+                         repack_tiled_u16(e.w2_scales), e.hidden, e.inter, e.gs, 4, 4)
+
+
+def moe_forward_unified_tiled_avx2(experts_tiled, weights, act_bf16, mode=SIG_POLY5_DIV):
+    n = len(experts_tiled)
+    cs = [e.c() for e in experts_tiled]
+    arr = (C.POINTER(_UnifiedExpertC) * n)(*[C.pointer(c) for c in cs])
+    w = _c(weights, np.float32); act = _c(act_bf16, np.uint16)
+    out = np.zeros(experts_tiled[0].hidden, np.float32)
+    lib().kro_moe_forward_unified_tiled_avx2(arr, _p(w), n, _p(act), mode, _p(out))
+    return out
+
+
 def num_threads() -> int:
     return int(lib().kro_num_threads())
 
