@@ -18,7 +18,11 @@ SYMBOLS = [
     "kr_engine_device_bytes", "kr_upload_expert_unified", "kr_upload_expert_gguf", "kr_fill_layer_synthetic",
     "kr_download_expert_unified", "kr_moe_forward", "kr_set_routing_config", "kr_set_routing_weights",
     "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_synchronize", "kr_set_profiling",
-    "kr_get_profile",
+    "kr_get_profile", "kr_decode_create", "kr_decode_destroy", "kr_decode_store_weight_f32", "kr_decode_store_weight_synthetic",
+    "kr_decode_download_weight", "kr_decode_store_norm_weight", "kr_decode_configure", "kr_decode_add_la_layer",
+    "kr_decode_add_gqa_layer", "kr_decode_set_layer_moe", "kr_decode_set_layer_dense", "kr_decode_set_rope", "kr_decode_finalize",
+    "kr_decode_set_state", "kr_decode_fill_state_synthetic", "kr_decode_get_state", "kr_decode_step", "kr_decode_generate_greedy",
+    "kr_decode_last_token", "kr_decode_set_use_graph", "kr_decode_read_buffer", "kr_decode_device_bytes",
 ]
 
 
@@ -79,6 +83,29 @@ def load_library() -> C.CDLL:
     lib.kr_synchronize.argtypes = [C.c_void_p]
     lib.kr_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.kr_get_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    lib.kr_decode_create.argtypes = [vp, ci, ci, C.POINTER(vp)]
+    lib.kr_decode_destroy.argtypes = [vp]; lib.kr_decode_destroy.restype = None
+    lib.kr_decode_store_weight_f32.argtypes = [vp, vp, ci, ci, ci, C.POINTER(ci)]
+    lib.kr_decode_store_weight_synthetic.argtypes = [vp, ci, ci, ci, C.c_uint64, C.POINTER(ci)]
+    lib.kr_decode_download_weight.argtypes = [vp, ci, vp, vp]
+    lib.kr_decode_store_norm_weight.argtypes = [vp, vp, ci, C.POINTER(ci)]
+    lib.kr_decode_configure.argtypes = [vp, ci, ci, cf, ci, ci, ci, ci, ci, ci, cf, vp, C.c_uint64]
+    lib.kr_decode_add_la_layer.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, cf]
+    lib.kr_decode_add_gqa_layer.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, ci, ci, ci, cf]
+    lib.kr_decode_set_layer_moe.argtypes = [vp, ci, ci, ci, ci, ci]
+    lib.kr_decode_set_layer_dense.argtypes = [vp, ci, ci, ci, ci]
+    lib.kr_decode_set_rope.argtypes = [vp, vp, vp, ci, ci]
+    lib.kr_decode_finalize.argtypes = [vp]
+    lib.kr_decode_set_state.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+    lib.kr_decode_fill_state_synthetic.argtypes = [vp, ci, C.c_uint64]
+    lib.kr_decode_get_state.argtypes = [vp, ci, vp, vp, vp, vp]
+    lib.kr_decode_step.argtypes = [vp, ci, ci, vp, vp]
+    lib.kr_decode_generate_greedy.argtypes = [vp, ci, ci, ci, vp, ci, vp, C.POINTER(ci), vp]
+    lib.kr_decode_last_token.argtypes = [vp, C.POINTER(ci)]
+    lib.kr_decode_set_use_graph.argtypes = [vp, ci]
+    lib.kr_decode_read_buffer.argtypes = [vp, ci, vp, ci]
+    lib.kr_decode_device_bytes.argtypes = [vp]; lib.kr_decode_device_bytes.restype = C.c_size_t
     _lib = lib
     return lib
 

@@ -1,0 +1,564 @@
+// kr_decode.cpp -- the decode graph ("CpuDecodeStore" in the reference, src/decode.rs:193-3602) resident on the GPU.
+//
+// Same construction API as the reference (store_weight_f32 / store_norm_weight / configure_decode / add_decode_*_layer /
+// set_decode_layer_moe / set_decode_rope / set_decode_state / decode_step / generate_batch), same numerics (bit-exact
+// against the oracle restatement), but every weight, KV page, recurrent state and scratch buffer lives in HBM and one
+// decode_step is a fixed sequence of kernel launches that reads (token, position) from device memory, i.e. it is
+// hipGraph-capturable and replayable per token.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/krasis_hip.h"
+#include "kr_decode_ops.h"
+#include "kr_engine_internal.h"
+#include "kr_kernels.h"
+#include "kr_router.h"
+
+struct DWeight { MatSet ms; int rows = 0, cols = 0; };
+
+enum { ATTN_NONE = 0, ATTN_LA = 1, ATTN_GQA = 2 };
+enum { MLP_NONE = 0, MLP_MOE = 1, MLP_DENSE = 2 };
+
+struct DLayer {
+    int input_norm = -1, post_norm = -1;
+    int attn = ATTN_NONE, mlp = MLP_NONE;
+    // LA
+    int qkvz_wid = -1, ba_wid = -1, out_wid = -1, nk = 0, nv = 0, dk = 0, dv = 0, kd = 4; float la_scale = 1.0f;
+    DevBuf conv_w, a_log, dt_bias, la_norm_w, conv_state, recur_state;
+    // GQA
+    int q_wid = -1, k_wid = -1, v_wid = -1, o_wid = -1, gated = 0, nh = 0, nkv = 0, hd = 0; float sm_scale = 1.0f;
+    DevBuf q_norm, k_norm, kv_k, kv_v; int q_norm_len = 0, k_norm_len = 0;
+    // MLP
+    int moe_layer = -1, sgu_wid = -1, sd_wid = -1, sg_wid = -1;
+    int gate_wid = -1, up_wid = -1, down_wid = -1;
+};
+
+struct kr_decode_store {
+    kr_engine* eng = nullptr;
+    int group_size = 128; bool norm_bias_one = false;
+    std::vector<std::unique_ptr<DWeight>> weights;
+    std::vector<std::unique_ptr<DevBuf>> norms; std::vector<int> norm_len;
+    bool configured = false;
+    int hidden = 0, n_layers = 0, vocab = 0, topk = 0, scoring = 1, norm_topk = 1, final_norm = -1, lm_head = -1;
+    float eps = 1e-6f, rsf = 1.0f;
+    DevBuf embedding;
+    std::vector<DLayer> layers;
+    DevBuf rope_cos, rope_sin; int rope_half = 0, max_rope_seq = 0;
+    int kv_max_seq = 0;
+    // scratch
+    DevBuf hid, res, proj_a, proj_b, qbuf, kbuf, vbuf, zbuf, gbuf, betabuf, gatebuf, recur_out, attn_out, logits, gate_val, tok;
+    DevBuf moe_gu, moe_eo, r_logits, r_ids, r_w;  // store-owned so a captured graph never sees them reallocated
+    DevBuf step_dev; KrStep* step_host = nullptr;
+    size_t weight_bytes = 0;
+    // captured graph of one decode step
+    hipGraphExec_t graph_exec = nullptr; bool graph_ok = false; bool use_graph = true;
+};
+
+static int chk_store(kr_decode_store* s) { return s ? KR_OK : kr_fail(KR_ERR_VALUE, "null decode store"); }
+static int chk_wid(kr_decode_store* s, int id, const char* what) {
+    if (id < 0 || id >= (int)s->weights.size()) return kr_fail(KR_ERR_VALUE, "%s: weight id %d out of range", what, id);
+    return KR_OK;
+}
+
+extern "C" int kr_decode_create(kr_engine* eng, int group_size, int norm_bias_one, kr_decode_store** out) {
+    if (!eng || !out) return kr_fail(KR_ERR_VALUE, "null argument");
+    if (group_size != 128) return kr_fail(KR_ERR_VALUE, "group_size %d unsupported", group_size);
+    KR_HIP(hipSetDevice(eng->device));
+    std::unique_ptr<kr_decode_store> s(new kr_decode_store);
+    s->eng = eng; s->group_size = group_size; s->norm_bias_one = norm_bias_one != 0;
+    if (s->step_dev.ensure(sizeof(KrStep))) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    KR_HIP(hipHostMalloc((void**)&s->step_host, sizeof(KrStep), hipHostMallocDefault));
+    *out = s.release();
+    return KR_OK;
+}
+
+extern "C" void kr_decode_destroy(kr_decode_store* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->eng->device);
+    (void)hipStreamSynchronize(s->eng->stream);
+    if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    for (auto& w : s->weights) { w->ms.q.release(); w->ms.s.release(); }
+    for (auto& n : s->norms) n->release();
+    for (auto& l : s->layers)
+        for (DevBuf* b : {&l.conv_w, &l.a_log, &l.dt_bias, &l.la_norm_w, &l.conv_state, &l.recur_state, &l.q_norm, &l.k_norm, &l.kv_k, &l.kv_v}) b->release();
+    for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
+                      &s->gbuf, &s->betabuf, &s->gatebuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
+                      &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w}) b->release();
+    if (s->step_host) (void)hipHostFree(s->step_host);
+    delete s;
+}
+
+// ---- host-side weight quantizers (decode.rs:46-178): f32 [N,K] -> transposed INT4/INT8 + bf16 scales ----
+static inline uint16_t bf16_rne(float f) { uint32_t b; memcpy(&b, &f, 4); b += 0x7FFFu + ((b >> 16) & 1u); return (uint16_t)(b >> 16); }
+static inline int32_t sat_i32(float x) { if (x != x) return 0; if (x >= 2147483648.0f) return INT32_MAX; if (x <= -2147483648.0f) return INT32_MIN; return (int32_t)x; }
+
+static void quantize_f32_transposed(const float* w, int rows, int cols, int bits, std::vector<uint32_t>& packed, std::vector<int8_t>& data8,
+                                    std::vector<uint16_t>& scales) {
+    const int gs = 128, ng = cols / gs;
+    scales.assign((size_t)ng * rows, 0);
+    if (bits == 4) packed.assign((size_t)(cols / 8) * rows, 0); else data8.assign((size_t)cols * rows, 0);
+    const float qmax = bits == 4 ? 7.0f : 127.0f; const int lo = bits == 4 ? -8 : -128, hi = bits == 4 ? 7 : 127;
+    for (int r = 0; r < rows; r++) {
+        const float* row = w + (size_t)r * cols;
+        for (int g = 0; g < ng; g++) {
+            float mx = 0.0f;
+            for (int i = 0; i < gs; i++) { const float a = fabsf(row[g * gs + i]); if (a > mx) mx = a; }
+            const float scale = mx > 0.0f ? mx / qmax : 1.0f, inv = mx > 0.0f ? qmax / mx : 0.0f;
+            scales[(size_t)g * rows + r] = bf16_rne(scale);
+            if (bits == 4) {
+                for (int p = 0; p < gs / 8; p++) {
+                    uint32_t word = 0;
+                    for (int j = 0; j < 8; j++) {
+                        int q = sat_i32(roundf(row[g * gs + p * 8 + j] * inv)); q = q < lo ? lo : (q > hi ? hi : q);
+                        word |= (uint32_t)(q + 8) << (j * 4);
+                    }
+                    packed[(size_t)(g * (gs / 8) + p) * rows + r] = word;
+                }
+            } else {
+                for (int i = 0; i < gs; i++) {
+                    int q = sat_i32(roundf(row[g * gs + i] * inv)); q = q < lo ? lo : (q > hi ? hi : q);
+                    data8[(size_t)(g * gs + i) * rows + r] = (int8_t)q;
+                }
+            }
+        }
+    }
+}
+
+static int new_weight(kr_decode_store* s, int rows, int cols, int bits, DWeight** out) {
+    if (cols % 128 != 0) return kr_fail(KR_ERR_VALUE, "cols %d must be divisible by group_size 128", cols);
+    if (bits != 4 && bits != 8) return kr_fail(KR_ERR_VALUE, "num_bits must be 4 or 8, got %d", bits);
+    std::unique_ptr<DWeight> w(new DWeight);
+    w->rows = rows; w->cols = cols;
+    if (int rc = matset_alloc(s->eng, w->ms, cols, rows, bits, 1)) return rc;
+    s->weight_bytes += w->ms.q_stride + w->ms.s_stride;
+    *out = w.get();
+    s->weights.push_back(std::move(w));
+    return KR_OK;
+}
+
+extern "C" int kr_decode_store_weight_f32(kr_decode_store* s, const float* w, int rows, int cols, int bits, int* id_out) {
+    if (int rc = chk_store(s)) return rc;
+    if (!w || !id_out) return kr_fail(KR_ERR_VALUE, "null argument");
+    KR_HIP(hipSetDevice(s->eng->device));
+    DWeight* dw;
+    if (int rc = new_weight(s, rows, cols, bits, &dw)) return rc;
+    std::vector<uint32_t> packed; std::vector<int8_t> d8; std::vector<uint16_t> sc;
+    quantize_f32_transposed(w, rows, cols, bits, packed, d8, sc);
+    if (int rc = upload_mat(s->eng, dw->ms, 0, bits == 4 ? (const void*)packed.data() : (const void*)d8.data(), sc.data())) return rc;
+    *id_out = (int)s->weights.size() - 1;
+    return KR_OK;
+}
+
+extern "C" int kr_decode_store_weight_synthetic(kr_decode_store* s, int rows, int cols, int bits, uint64_t seed, int* id_out) {
+    if (int rc = chk_store(s)) return rc;
+    KR_HIP(hipSetDevice(s->eng->device));
+    DWeight* dw;
+    if (int rc = new_weight(s, rows, cols, bits, &dw)) return rc;
+    kr_launch_fill_synth(dw->ms.q.p, dw->ms.q_stride, (uint32_t*)dw->ms.s.p, dw->ms.s_stride / 4, seed, s->eng->stream);
+    KR_HIP(hipStreamSynchronize(s->eng->stream));
+    *id_out = (int)s->weights.size() - 1;
+    return KR_OK;
+}
+
+extern "C" int kr_decode_download_weight(kr_decode_store* s, int wid, void* packed_t, uint16_t* scales_t) {
+    if (int rc = chk_store(s)) return rc;
+    if (int rc = chk_wid(s, wid, "download_weight")) return rc;
+    KR_HIP(hipSetDevice(s->eng->device));
+    return download_mat(s->eng, s->weights[wid]->ms, 0, packed_t, scales_t);
+}
+
+static int upload_f32(DevBuf& b, const float* src, size_t n) {
+    if (b.ensure(n * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    KR_HIP(hipMemcpy(b.p, src, n * 4, hipMemcpyHostToDevice));
+    return KR_OK;
+}
+
+extern "C" int kr_decode_store_norm_weight(kr_decode_store* s, const float* w, int n, int* id_out) {
+    if (int rc = chk_store(s)) return rc;
+    if (!w || !id_out) return kr_fail(KR_ERR_VALUE, "null argument");
+    KR_HIP(hipSetDevice(s->eng->device));
+    std::unique_ptr<DevBuf> b(new DevBuf);
+    if (int rc = upload_f32(*b, w, n)) return rc;
+    s->norms.push_back(std::move(b)); s->norm_len.push_back(n);
+    *id_out = (int)s->norms.size() - 1;
+    return KR_OK;
+}
+
+extern "C" int kr_decode_configure(kr_decode_store* s, int hidden, int n_layers, float eps, int final_norm_id, int lm_head_wid, int vocab,
+                                   int topk, int scoring, int norm_topk_prob, float rsf, const float* embedding, uint64_t synth_seed) {
+    if (int rc = chk_store(s)) return rc;
+    if (hidden % 128 != 0) return kr_fail(KR_ERR_VALUE, "hidden %d must be a multiple of 128", hidden);
+    if (int rc = chk_wid(s, lm_head_wid, "configure_decode lm_head")) return rc;
+    if (final_norm_id < 0 || final_norm_id >= (int)s->norms.size()) return kr_fail(KR_ERR_VALUE, "final norm id out of range");
+    KR_HIP(hipSetDevice(s->eng->device));
+    s->hidden = hidden; s->n_layers = n_layers; s->eps = eps; s->final_norm = final_norm_id; s->lm_head = lm_head_wid; s->vocab = vocab;
+    s->topk = topk; s->scoring = scoring; s->norm_topk = norm_topk_prob; s->rsf = rsf;
+    s->layers.clear(); s->layers.reserve(n_layers);
+    const size_t ne = (size_t)vocab * hidden;
+    if (embedding) { if (int rc = upload_f32(s->embedding, embedding, ne)) return rc; }
+    else {
+        // synthetic embedding +-0.1 (decode.rs:5364): generated on the GPU
+        if (s->embedding.ensure(ne * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+        kr_launch_fill_uniform_f32((float*)s->embedding.p, ne, 0.1f, synth_seed, s->eng->stream);
+        KR_HIP(hipStreamSynchronize(s->eng->stream));
+    }
+    if (s->hid.ensure((size_t)hidden * 4) || s->res.ensure((size_t)hidden * 4) || s->logits.ensure((size_t)vocab * 4) ||
+        s->gate_val.ensure(64) || s->tok.ensure(64))
+        return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    s->configured = true; s->graph_ok = false;
+    return KR_OK;
+}
+
+static int need_cfg(kr_decode_store* s) {
+    if (int rc = chk_store(s)) return rc;
+    if (!s->configured) return kr_fail(KR_ERR_STATE, "Call configure_decode first");
+    return KR_OK;
+}
+
+extern "C" int kr_decode_add_la_layer(kr_decode_store* s, int input_norm_id, int post_attn_norm_id, int qkvz_wid, int ba_wid, int out_wid,
+                                      const float* conv_weight, const float* a_log, const float* dt_bias, const float* norm_weight, int nk, int nv,
+                                      int dk, int dv, int kernel_dim, float scale) {
+    if (int rc = need_cfg(s)) return rc;
+    for (int id : {qkvz_wid, ba_wid, out_wid}) if (int rc = chk_wid(s, id, "add_decode_la_layer")) return rc;
+    if (kernel_dim != 4) return kr_fail(KR_ERR_VALUE, "linear-attention conv kernel_dim %d unsupported (4 only)", kernel_dim);
+    if (dk != 128 && dk != 64) return kr_fail(KR_ERR_VALUE, "linear_key_head_dim %d unsupported (64/128)", dk);
+    if (dv % 64 != 0 || dv > 256 || nv % nk != 0) return kr_fail(KR_ERR_VALUE, "unsupported linear-attention head geometry");
+    KR_HIP(hipSetDevice(s->eng->device));
+    DLayer L; L.input_norm = input_norm_id; L.post_norm = post_attn_norm_id; L.attn = ATTN_LA;
+    L.qkvz_wid = qkvz_wid; L.ba_wid = ba_wid; L.out_wid = out_wid; L.nk = nk; L.nv = nv; L.dk = dk; L.dv = dv; L.kd = kernel_dim; L.la_scale = scale;
+    const int conv_dim = 2 * nk * dk + nv * dv;
+    if (int rc = upload_f32(L.conv_w, conv_weight, (size_t)conv_dim * kernel_dim)) return rc;
+    if (int rc = upload_f32(L.a_log, a_log, nv)) return rc;
+    if (int rc = upload_f32(L.dt_bias, dt_bias, nv)) return rc;
+    if (int rc = upload_f32(L.la_norm_w, norm_weight, (size_t)nv * dv)) return rc;
+    if (L.conv_state.ensure((size_t)conv_dim * kernel_dim * 4) || L.recur_state.ensure((size_t)nv * dk * dv * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    KR_HIP(hipMemset(L.conv_state.p, 0, (size_t)conv_dim * kernel_dim * 4));
+    KR_HIP(hipMemset(L.recur_state.p, 0, (size_t)nv * dk * dv * 4));
+    s->layers.push_back(std::move(L)); s->graph_ok = false;
+    return KR_OK;
+}
+
+extern "C" int kr_decode_add_gqa_layer(kr_decode_store* s, int input_norm_id, int post_attn_norm_id, int q_wid, int k_wid, int v_wid, int o_wid,
+                                       const float* q_norm, int q_norm_len, const float* k_norm, int k_norm_len, int gated, int num_heads,
+                                       int num_kv_heads, int head_dim, float sm_scale) {
+    if (int rc = need_cfg(s)) return rc;
+    for (int id : {q_wid, k_wid, v_wid, o_wid}) if (int rc = chk_wid(s, id, "add_decode_gqa_layer")) return rc;
+    if (head_dim > 256 || head_dim % 8 != 0) return kr_fail(KR_ERR_VALUE, "head_dim %d unsupported", head_dim);
+    KR_HIP(hipSetDevice(s->eng->device));
+    DLayer L; L.input_norm = input_norm_id; L.post_norm = post_attn_norm_id; L.attn = ATTN_GQA;
+    L.q_wid = q_wid; L.k_wid = k_wid; L.v_wid = v_wid; L.o_wid = o_wid; L.gated = gated; L.nh = num_heads; L.nkv = num_kv_heads; L.hd = head_dim;
+    L.sm_scale = sm_scale; L.q_norm_len = q_norm ? q_norm_len : 0; L.k_norm_len = k_norm ? k_norm_len : 0;
+    if (q_norm) if (int rc = upload_f32(L.q_norm, q_norm, q_norm_len)) return rc;
+    if (k_norm) if (int rc = upload_f32(L.k_norm, k_norm, k_norm_len)) return rc;
+    s->layers.push_back(std::move(L)); s->graph_ok = false;
+    return KR_OK;
+}
+
+extern "C" int kr_decode_set_layer_moe(kr_decode_store* s, int layer, int moe_layer_idx, int shared_gate_up_wid, int shared_down_wid, int shared_gate_wid) {
+    if (int rc = need_cfg(s)) return rc;
+    if (layer < 0 || layer >= (int)s->layers.size()) return kr_fail(KR_ERR_VALUE, "layer %d out of range", layer);
+    if (moe_layer_idx < 0 || moe_layer_idx >= (int)s->eng->layers.size()) return kr_fail(KR_ERR_VALUE, "moe_layer_idx %d out of range", moe_layer_idx);
+    if ((shared_gate_up_wid >= 0) != (shared_down_wid >= 0)) return kr_fail(KR_ERR_VALUE, "shared gate_up and down weights must be set together");
+    for (int id : {shared_gate_up_wid, shared_down_wid, shared_gate_wid}) if (id >= 0) if (int rc = chk_wid(s, id, "set_decode_layer_moe")) return rc;
+    DLayer& L = s->layers[layer];
+    L.mlp = MLP_MOE; L.moe_layer = moe_layer_idx; L.sgu_wid = shared_gate_up_wid; L.sd_wid = shared_down_wid; L.sg_wid = shared_gate_wid;
+    s->graph_ok = false;
+    return KR_OK;
+}
+
+extern "C" int kr_decode_set_layer_dense(kr_decode_store* s, int layer, int gate_wid, int up_wid, int down_wid) {
+    if (int rc = need_cfg(s)) return rc;
+    if (layer < 0 || layer >= (int)s->layers.size()) return kr_fail(KR_ERR_VALUE, "layer %d out of range", layer);
+    for (int id : {gate_wid, up_wid, down_wid}) if (int rc = chk_wid(s, id, "set_decode_layer_dense")) return rc;
+    DLayer& L = s->layers[layer];
+    L.mlp = MLP_DENSE; L.gate_wid = gate_wid; L.up_wid = up_wid; L.down_wid = down_wid;
+    s->graph_ok = false;
+    return KR_OK;
+}
+
+extern "C" int kr_decode_set_rope(kr_decode_store* s, const float* cos_t, const float* sin_t, int half_dim, int max_seq) {
+    if (int rc = need_cfg(s)) return rc;
+    KR_HIP(hipSetDevice(s->eng->device));
+    if (int rc = upload_f32(s->rope_cos, cos_t, (size_t)half_dim * max_seq)) return rc;
+    if (int rc = upload_f32(s->rope_sin, sin_t, (size_t)half_dim * max_seq)) return rc;
+    s->rope_half = half_dim; s->max_rope_seq = max_seq; s->graph_ok = false;
+    return KR_OK;
+}
+
+static size_t maxz(size_t a, size_t b) { return a > b ? a : b; }
+
+// finalize_decode (decode.rs:2471): size scratch, check ids
+extern "C" int kr_decode_finalize(kr_decode_store* s) {
+    if (int rc = need_cfg(s)) return rc;
+    if ((int)s->layers.size() != s->n_layers) return kr_fail(KR_ERR_STATE, "configured %d layers but %zu were added", s->n_layers, s->layers.size());
+    KR_HIP(hipSetDevice(s->eng->device));
+    size_t pa = 0, pb = 0, qb = 0, kb = 0, vb = 0, zb = 0, ro = 0, ao = 0, gb = 0;
+    for (auto& L : s->layers) {
+        if (L.attn == ATTN_LA) {
+            pa = maxz(pa, s->weights[L.qkvz_wid]->rows); pb = maxz(pb, s->weights[L.ba_wid]->rows);
+            qb = maxz(qb, (size_t)L.nv * L.dk); kb = maxz(kb, (size_t)L.nv * L.dk); vb = maxz(vb, (size_t)L.nv * L.dv); zb = maxz(zb, (size_t)L.nv * L.dv);
+            ro = maxz(ro, (size_t)L.nv * L.dv); ao = maxz(ao, s->weights[L.out_wid]->cols); gb = maxz(gb, L.nv);
+        } else if (L.attn == ATTN_GQA) {
+            pa = maxz(pa, s->weights[L.q_wid]->rows); kb = maxz(kb, s->weights[L.k_wid]->rows); vb = maxz(vb, s->weights[L.v_wid]->rows);
+            qb = maxz(qb, (size_t)L.nh * L.hd); zb = maxz(zb, (size_t)L.nh * L.hd); ao = maxz(ao, s->weights[L.o_wid]->cols);
+        }
+        if (L.mlp == MLP_DENSE) { pa = maxz(pa, 2 * (size_t)s->weights[L.down_wid]->cols); }
+    }
+    ao = maxz(ao, (size_t)s->hidden);
+    if (s->proj_a.ensure(maxz(pa, 64) * 4) || s->proj_b.ensure(maxz(pb, 64) * 4) || s->qbuf.ensure(maxz(qb, 64) * 4) || s->kbuf.ensure(maxz(kb, 64) * 4) ||
+        s->vbuf.ensure(maxz(vb, 64) * 4) || s->zbuf.ensure(maxz(zb, 64) * 4) || s->recur_out.ensure(maxz(ro, 64) * 4) ||
+        s->attn_out.ensure(maxz(ao, 64) * 4) || s->gbuf.ensure(maxz(gb, 64) * 4) || s->betabuf.ensure(maxz(gb, 64) * 4) ||
+        s->gatebuf.ensure(maxz(zb, 64) * 4))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of decode scratch failed");
+    KR_HIP(hipMemset(s->proj_a.p, 0, s->proj_a.bytes));
+    KR_HIP(hipMemset(s->attn_out.p, 0, s->attn_out.bytes));
+    s->graph_ok = false;
+    return KR_OK;
+}
+
+// set_decode_state (decode.rs:2640): host pointers per layer (NULL where not applicable); contents are copied to HBM
+extern "C" int kr_decode_set_state(kr_decode_store* s, int seq_len, int kv_max_seq, const uint16_t* const* kv_k, const uint16_t* const* kv_v,
+                                   const float* const* conv_state, const float* const* recur_state) {
+    if (int rc = need_cfg(s)) return rc;
+    (void)seq_len;
+    KR_HIP(hipSetDevice(s->eng->device));
+    s->kv_max_seq = kv_max_seq;
+    for (size_t i = 0; i < s->layers.size(); i++) {
+        DLayer& L = s->layers[i];
+        if (L.attn == ATTN_GQA) {
+            const size_t n = (size_t)kv_max_seq * L.nkv * L.hd * 2;
+            if (L.kv_k.ensure(n) || L.kv_v.ensure(n)) return kr_fail(KR_ERR_HIP, "hipMalloc of KV cache failed");
+            if (kv_k && kv_k[i]) KR_HIP(hipMemcpy(L.kv_k.p, kv_k[i], n, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_k.p, 0, n));
+            if (kv_v && kv_v[i]) KR_HIP(hipMemcpy(L.kv_v.p, kv_v[i], n, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_v.p, 0, n));
+        } else if (L.attn == ATTN_LA) {
+            const size_t cn = (size_t)(2 * L.nk * L.dk + L.nv * L.dv) * L.kd * 4, rn = (size_t)L.nv * L.dk * L.dv * 4;
+            if (conv_state && conv_state[i]) KR_HIP(hipMemcpy(L.conv_state.p, conv_state[i], cn, hipMemcpyHostToDevice));
+            if (recur_state && recur_state[i]) KR_HIP(hipMemcpy(L.recur_state.p, recur_state[i], rn, hipMemcpyHostToDevice));
+        }
+    }
+    s->graph_ok = false;
+    return KR_OK;
+}
+
+// synthetic per-request state with the distributions of bench_decode_synthetic (decode.rs:5421-5424, 4402-4411)
+extern "C" int kr_decode_fill_state_synthetic(kr_decode_store* s, int kv_max_seq, uint64_t seed) {
+    if (int rc = need_cfg(s)) return rc;
+    KR_HIP(hipSetDevice(s->eng->device));
+    s->kv_max_seq = kv_max_seq;
+    for (size_t i = 0; i < s->layers.size(); i++) {
+        DLayer& L = s->layers[i];
+        if (L.attn == ATTN_GQA) {
+            const size_t n = (size_t)kv_max_seq * L.nkv * L.hd;
+            if (L.kv_k.ensure(n * 2) || L.kv_v.ensure(n * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc of KV cache failed");
+            kr_launch_fill_fp16_kv((uint16_t*)L.kv_k.p, n, seed + i * 4 + 0, s->eng->stream);
+            kr_launch_fill_fp16_kv((uint16_t*)L.kv_v.p, n, seed + i * 4 + 1, s->eng->stream);
+        } else if (L.attn == ATTN_LA) {
+            kr_launch_fill_uniform_f32((float*)L.conv_state.p, (size_t)(2 * L.nk * L.dk + L.nv * L.dv) * L.kd, 0.1f, seed + i * 4 + 2, s->eng->stream);
+            kr_launch_fill_uniform_f32((float*)L.recur_state.p, (size_t)L.nv * L.dk * L.dv, 0.01f, seed + i * 4 + 3, s->eng->stream);
+        }
+    }
+    KR_HIP(hipStreamSynchronize(s->eng->stream));
+    s->graph_ok = false;
+    return KR_OK;
+}
+
+extern "C" int kr_decode_get_state(kr_decode_store* s, int layer, uint16_t* kv_k, uint16_t* kv_v, float* conv_state, float* recur_state) {
+    if (int rc = need_cfg(s)) return rc;
+    if (layer < 0 || layer >= (int)s->layers.size()) return kr_fail(KR_ERR_VALUE, "layer out of range");
+    KR_HIP(hipSetDevice(s->eng->device));
+    KR_HIP(hipStreamSynchronize(s->eng->stream));
+    DLayer& L = s->layers[layer];
+    if (L.attn == ATTN_GQA) {
+        const size_t n = (size_t)s->kv_max_seq * L.nkv * L.hd * 2;
+        if (kv_k) KR_HIP(hipMemcpy(kv_k, L.kv_k.p, n, hipMemcpyDeviceToHost));
+        if (kv_v) KR_HIP(hipMemcpy(kv_v, L.kv_v.p, n, hipMemcpyDeviceToHost));
+    } else if (L.attn == ATTN_LA) {
+        if (conv_state) KR_HIP(hipMemcpy(conv_state, L.conv_state.p, (size_t)(2 * L.nk * L.dk + L.nv * L.dv) * L.kd * 4, hipMemcpyDeviceToHost));
+        if (recur_state) KR_HIP(hipMemcpy(recur_state, L.recur_state.p, (size_t)L.nv * L.dk * L.dv * 4, hipMemcpyDeviceToHost));
+    }
+    return KR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one decode step: the launch sequence of decode_step (decode.rs:2690-3520)
+// ------------------------------------------------------------------------------------------------
+static KrMatDev mv(kr_decode_store* s, int wid) { return s->weights[wid]->ms.view(); }
+
+static int enqueue_step(kr_decode_store* s, hipStream_t st) {
+    kr_engine* e = s->eng;
+    const int H = s->hidden;
+    float* hid = (float*)s->hid.p; float* res = (float*)s->res.p;
+    const KrStep* step = (const KrStep*)s->step_dev.p;
+    kr_launch_embed((const float*)s->embedding.p, step, hid, H, st);
+    bool first = true;
+    for (size_t li = 0; li < s->layers.size(); li++) {
+        DLayer& L = s->layers[li];
+        kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st);
+        first = false;
+        if (L.attn == ATTN_LA) {
+            kr_launch_matvec(mv(s, L.qkvz_wid), hid, 1, (float*)s->proj_a.p, st);
+            kr_launch_matvec(mv(s, L.ba_wid), hid, 1, (float*)s->proj_b.p, st);
+            KrLaArgs a{};
+            a.qkvz = (const float*)s->proj_a.p; a.ba = (const float*)s->proj_b.p; a.conv_state = (float*)L.conv_state.p;
+            a.conv_w = (const float*)L.conv_w.p; a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale;
+            a.q = (float*)s->qbuf.p; a.k = (float*)s->kbuf.p; a.v = (float*)s->vbuf.p; a.z = (float*)s->zbuf.p; a.g = (float*)s->gbuf.p; a.beta = (float*)s->betabuf.p;
+            a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
+            kr_launch_la_conv(a, st);
+            if (kr_launch_la_recurrent((float*)L.recur_state.p, a.q, a.k, a.v, a.g, a.beta, (float*)s->recur_out.p, L.nv, L.dk, L.dv, st))
+                return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
+            kr_launch_gated_rmsnorm_silu((const float*)s->recur_out.p, a.z, (const float*)L.la_norm_w.p, (float*)s->attn_out.p, L.nv, L.dv, s->eps, st);
+            kr_launch_matvec(mv(s, L.out_wid), s->attn_out.p, 1, hid, st);
+        } else if (L.attn == ATTN_GQA) {
+            if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
+            kr_launch_matvec(mv(s, L.q_wid), hid, 1, (float*)s->proj_a.p, st);
+            kr_launch_matvec(mv(s, L.k_wid), hid, 1, (float*)s->kbuf.p, st);
+            kr_launch_matvec(mv(s, L.v_wid), hid, 1, (float*)s->vbuf.p, st);
+            KrGqaArgs a{};
+            a.step = step; a.q_in = (const float*)s->proj_a.p; a.k_in = (const float*)s->kbuf.p; a.v_in = (const float*)s->vbuf.p;
+            a.q_norm = L.q_norm_len ? (const float*)L.q_norm.p : nullptr; a.k_norm = L.k_norm_len ? (const float*)L.k_norm.p : nullptr;
+            a.q_norm_per_head = L.q_norm_len == L.nh * L.hd; a.k_norm_per_head = L.k_norm_len == L.nkv * L.hd;
+            a.rope_cos = (const float*)s->rope_cos.p; a.rope_sin = (const float*)s->rope_sin.p; a.rope_half = s->rope_half;
+            a.k_cache = (uint16_t*)L.kv_k.p; a.v_cache = (uint16_t*)L.kv_v.p; a.q_out = (float*)s->qbuf.p; a.gate = (float*)s->gatebuf.p;
+            a.attn_out = (float*)s->attn_out.p; a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.eps = s->eps; a.sm_scale = L.sm_scale;
+            kr_launch_gqa(a, s->kv_max_seq, st);
+            kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st);
+        }
+        kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st);
+        if (L.mlp == MLP_MOE) {
+            Layer& EL = e->layers[L.moe_layer];
+            if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
+            if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
+            const int E = e->r_ne, k = s->topk;
+            kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, hid, EL.has_bias ? (const float*)EL.bias.p : nullptr, (float*)s->r_logits.p, 1, E, H, st);
+            kr_launch_route_select((const float*)s->r_logits.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p, (float*)s->r_w.p, 1, E, k,
+                                   s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
+            const bool has_shared = L.sgu_wid >= 0;
+            KrMoeArgs a{};
+            a.act = nullptr; a.act_f32 = hid; a.shared_decode = 1;
+            a.ids = (const int32_t*)s->r_ids.p; a.wts = (const float*)s->r_w.p;
+            a.B = 1; a.topk = k; a.n_slots = k + (has_shared ? 1 : 0); a.H = H; a.I = EL.inter;
+            a.w13 = EL.w13.view(); a.w2 = EL.w2.view();
+            if (has_shared) { a.sw13 = mv(s, L.sgu_wid); a.sw2 = mv(s, L.sd_wid); a.I_shared = s->weights[L.sgu_wid]->rows / 2; }
+            const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
+            a.gu_ld = 2 * imax;
+            a.gu = (float*)s->moe_gu.p; a.eo = (float*)s->moe_eo.p; a.out = nullptr; a.out_bf16 = 0;
+            a.rsf = s->rsf; a.swiglu_limit = e->cfg.swiglu_limit; a.alpha = e->cfg.activation_alpha;
+            a.act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
+            kr_launch_moe_w13(a, st);
+            if (has_shared && L.sg_wid >= 0) kr_launch_matvec(mv(s, L.sg_wid), hid, 1, (float*)s->gate_val.p, st);
+            kr_launch_moe_w2(a, st);
+            kr_launch_moe_combine_decode(a.eo, a.ids, a.wts, k, has_shared, (has_shared && L.sg_wid >= 0) ? (const float*)s->gate_val.p : nullptr, s->rsf, hid, H, st);
+        } else if (L.mlp == MLP_DENSE) {
+            // gate / up into [0,K) and [K,2K) of proj_a (K = padded intermediate), then down with the fused silu*up + quant prologue
+            const int K = s->weights[L.down_wid]->cols;
+            kr_launch_matvec(mv(s, L.gate_wid), hid, 1, (float*)s->proj_a.p, st);
+            kr_launch_matvec(mv(s, L.up_wid), hid, 1, (float*)s->proj_a.p + K, st);
+            kr_launch_matvec(mv(s, L.down_wid), s->proj_a.p, 1, hid, st, KR_ACT_SILU_MUL);
+        }
+    }
+    kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, 0, s->norm_bias_one, st);
+    kr_launch_matvec(mv(s, s->lm_head), hid, 1, (float*)s->logits.p, st);
+    kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, st);
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
+static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
+    if (token < 0 || token >= s->vocab) return kr_fail(KR_ERR_VALUE, "token id %d out of range (vocab %d)", token, s->vocab);
+    if (s->kv_max_seq > 0 && pos >= s->kv_max_seq) return kr_fail(KR_ERR_VALUE, "position %d >= kv_max_seq %d", pos, s->kv_max_seq);
+    if (s->max_rope_seq > 0 && pos >= s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "position %d >= rope table length %d", pos, s->max_rope_seq);
+    s->step_host->token = token; s->step_host->pos = pos;
+    KR_HIP(hipMemcpyAsync(s->step_dev.p, s->step_host, sizeof(KrStep), hipMemcpyHostToDevice, st));
+    if (s->use_graph) {
+        if (!s->graph_ok) {
+            if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            KR_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_step(s, st);
+            hipError_t ce = hipStreamEndCapture(st, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (ce != hipSuccess) return kr_fail(KR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            KR_HIP(hipGraphInstantiate(&s->graph_exec, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            s->graph_ok = true;
+        }
+        KR_HIP(hipGraphLaunch(s->graph_exec, st));
+        return KR_OK;
+    }
+    return enqueue_step(s, st);
+}
+
+extern "C" int kr_decode_set_use_graph(kr_decode_store* s, int enable) {
+    if (int rc = chk_store(s)) return rc;
+    s->use_graph = enable != 0; return KR_OK;
+}
+
+extern "C" int kr_decode_step(kr_decode_store* s, int token_id, int position, float* logits_out, void* stream) {
+    if (int rc = need_cfg(s)) return rc;
+    KR_HIP(hipSetDevice(s->eng->device));
+    hipStream_t st = stream ? (hipStream_t)stream : s->eng->stream;
+    // all scratch the MoE block needs must exist before capture (no allocation inside a capture)
+    {
+        kr_engine* e = s->eng; size_t gu = 0, eo = 0;
+        for (auto& L : s->layers) if (L.mlp == MLP_MOE) {
+            Layer& EL = e->layers[L.moe_layer];
+            const int sI = L.sgu_wid >= 0 ? s->weights[L.sgu_wid]->rows / 2 : 0;
+            const int imax = sI > EL.inter ? sI : EL.inter; const int ns = s->topk + (L.sgu_wid >= 0 ? 1 : 0);
+            gu = maxz(gu, (size_t)ns * 2 * imax * 4); eo = maxz(eo, (size_t)ns * s->hidden * 4);
+        }
+        if (gu && (gu > s->moe_gu.bytes || eo > s->moe_eo.bytes || (size_t)e->r_ne * 4 > s->r_logits.bytes)) s->graph_ok = false;
+        if (gu && (s->moe_gu.ensure(gu) || s->moe_eo.ensure(eo) || s->r_logits.ensure((size_t)e->r_ne * 4) || s->r_ids.ensure(256) || s->r_w.ensure(256)))
+            return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    }
+    if (int rc = run_step(s, token_id, position, st)) return rc;
+    if (logits_out) {
+        if (is_device_ptr(logits_out)) KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToDevice, st));
+        else { KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }
+    }
+    return KR_OK;
+}
+
+// generate_batch (decode.rs:3525), greedy only: next = argmax(logits) (first max wins); stop ids end generation
+extern "C" int kr_decode_generate_greedy(kr_decode_store* s, int first_token, int start_pos, int max_tokens, const int* stop_ids, int n_stop,
+                                         int* tokens_out, int* n_out, void* stream) {
+    if (int rc = need_cfg(s)) return rc;
+    KR_HIP(hipSetDevice(s->eng->device));
+    hipStream_t st = stream ? (hipStream_t)stream : s->eng->stream;
+    int tok = first_token, n = 0;
+    for (int i = 0; i < max_tokens; i++) {
+        if (int rc = kr_decode_step(s, tok, start_pos + i, nullptr, st)) return rc;
+        int next = 0;
+        KR_HIP(hipMemcpyAsync(&next, s->tok.p, 4, hipMemcpyDeviceToHost, st));
+        KR_HIP(hipStreamSynchronize(st));
+        bool stop = false;
+        for (int j = 0; j < n_stop; j++) stop |= (stop_ids[j] == next);
+        if (stop) break;
+        tokens_out[n++] = next; tok = next;
+    }
+    *n_out = n;
+    return KR_OK;
+}
+
+extern "C" int kr_decode_last_token(kr_decode_store* s, int* tok) {
+    if (int rc = need_cfg(s)) return rc;
+    KR_HIP(hipSetDevice(s->eng->device));
+    KR_HIP(hipMemcpy(tok, s->tok.p, 4, hipMemcpyDeviceToHost));
+    return KR_OK;
+}
+
+// debug/parity: copy a named scratch buffer (0 hidden, 1 residual) to the host
+extern "C" int kr_decode_read_buffer(kr_decode_store* s, int which, float* out, int n) {
+    if (int rc = need_cfg(s)) return rc;
+    KR_HIP(hipSetDevice(s->eng->device));
+    KR_HIP(hipStreamSynchronize(s->eng->stream));
+    DevBuf* b = which == 0 ? &s->hid : &s->res;
+    KR_HIP(hipMemcpy(out, b->p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return KR_OK;
+}
+
+extern "C" size_t kr_decode_device_bytes(const kr_decode_store* s) { return s ? s->weight_bytes + s->embedding.bytes : 0; }

@@ -1,0 +1,31 @@
+// kr_decode_ops.h -- launch wrappers of kr_decode_ops.hip (decode-graph operators)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct KrStep { int token; int pos; };  // lives in device memory so a captured graph can be replayed per token
+
+struct KrLaArgs {
+    const float* qkvz; const float* ba; float* conv_state; const float* conv_w; const float* a_log; const float* dt_bias;
+    float scale; float *q, *k, *v, *z, *g, *beta; int nk, nv, dk, dv, hr;
+};
+struct KrGqaArgs {
+    const KrStep* step;
+    const float *q_in, *k_in, *v_in;
+    const float *q_norm, *k_norm; int q_norm_per_head, k_norm_per_head;
+    const float *rope_cos, *rope_sin; int rope_half;
+    uint16_t *k_cache, *v_cache;
+    float *q_out, *gate, *attn_out;
+    int gated, nh, nkv, hd; float eps, sm_scale;
+};
+
+void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s);
+void kr_launch_fused_add_rmsnorm(float* hidden, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s);
+void kr_launch_la_conv(const KrLaArgs& a, hipStream_t s);
+int kr_launch_la_recurrent(float* state, const float* q, const float* k, const float* v, const float* g, const float* beta, float* out,
+                           int nv, int dk, int dv, hipStream_t s);
+void kr_launch_gated_rmsnorm_silu(const float* recur, const float* z, const float* w, float* out, int nv, int dv, float eps, hipStream_t s);
+void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s);
+void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const float* wts, int topk, int has_shared, const float* gate_val,
+                                  float rsf, float* hidden, int H, hipStream_t s);
+void kr_launch_argmax(const float* x, int n, int* out, hipStream_t s);

@@ -14,89 +14,24 @@
 #include <string>
 #include <vector>
 
-#include "../../include/krasis_hip.h"
-#include "kr_kernels.h"
+#include "kr_engine_internal.h"
 #include "kr_router.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int kr_fail(int code, const char* fmt, ...) {
+int kr_fail(int code, const char* fmt, ...) {
     char buf[1024];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     g_err = buf;
     return code;
 }
-#define KR_HIP(call)                                                                                   \
-    do {                                                                                               \
-        hipError_t e__ = (call);                                                                       \
-        if (e__ != hipSuccess) return kr_fail(KR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
-    } while (0)
 
 extern "C" const char* kr_last_error(void) { return g_err.c_str(); }
 extern "C" int kr_version(void) { return 1; }
 
-// ------------------------------------------------------------------------------------------------
-// engine state
-// ------------------------------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr; size_t bytes = 0;
-    int ensure(size_t n) {
-        if (n <= bytes) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        if (hipMalloc(&p, n) != hipSuccess) return 1;
-        bytes = n; return 0;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-};
-
-struct MatSet {            // all experts of one layer for one projection, contiguous in HBM
-    DevBuf q, s;
-    int K = 0, N = 0, bits = 0, count = 0;
-    size_t q_stride = 0, s_stride = 0;
-    bool allocated() const { return q.p != nullptr; }
-    KrMatDev view() const {
-        KrMatDev m{};
-        m.q = q.p; m.s = (const uint32_t*)s.p; m.K = K; m.N = N;
-        m.ng = K / 128; m.ngp = (m.ng + 1) / 2; m.bits = bits; m.n_fma = (N / 8) * 8;
-        m.q_stride = q_stride; m.s_stride = s_stride;
-        return m;
-    }
-};
-
-struct Layer {
-    MatSet w13, w2;        // routed experts
-    MatSet sw13, sw2;      // shared expert (count == 1)
-    std::vector<uint8_t> present;
-    bool shared_present = false;
-    int inter = 0, shared_inter = 0;
-    // routing (set_routing_weights)
-    std::vector<float> gate_host;          // [E,H] f32 copy (bf16 inputs widen exactly)
-    bool gate_bf16_exact = false;          // every value representable in bf16 -> stored as bf16 in HBM
-    DevBuf gate_cm;                        // chain-major layout for rule DECODE
-    DevBuf gate_rm;                        // row-lane layout for rule ENGINE (built on first use)
-    DevBuf bias, esc; bool has_bias = false, has_esc = false, routing_present = false;
-};
-
-struct kr_engine {
-    int device = 0;
-    kr_model_config cfg{};
-    hipStream_t stream = nullptr;
-    std::vector<Layer> layers;
-    size_t weight_bytes = 0;
-    // scratch
-    DevBuf gu, eo, st_act, st_ids, st_w, st_out, ptr_table;
-    // routing config
-    bool routing_set = false; int r_scoring = 1, r_norm = 1, r_topk = 0, r_ne = 0, r_hidden = 0;
-    DevBuf r_logits, r_ids, r_w, r_x;
-    // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
-    bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};
-    std::mutex mu;
-};
-
-static bool is_device_ptr(const void* p) {
+bool is_device_ptr(const void* p) {
     if (!p) return false;
     hipPointerAttribute_t a;
     hipError_t e = hipPointerGetAttributes(&a, p);
@@ -194,7 +129,7 @@ static void untile_int8(const uint32_t* dq, const uint32_t* ds, int K, int N, in
     }
 }
 
-static int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int count) {
+int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int count) {
     if (ms.allocated()) {
         if (ms.K != K || ms.N != N || ms.bits != bits)
             return kr_fail(KR_ERR_VALUE, "expert shape/bits mismatch within layer: have K=%d N=%d bits=%d, got K=%d N=%d bits=%d",
@@ -210,13 +145,23 @@ static int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int co
     return KR_OK;
 }
 
-static int upload_mat(kr_engine* e, MatSet& ms, int idx, const void* w, const uint16_t* sc) {
+int upload_mat(kr_engine* e, MatSet& ms, int idx, const void* w, const uint16_t* sc) {
     std::vector<uint32_t> dq(ms.q_stride / 4), ds(ms.s_stride / 4);
     if (ms.bits == 4) retile_int4((const uint32_t*)w, sc, ms.K, ms.N, dq.data(), ds.data());
     else retile_int8((const int8_t*)w, sc, ms.K, ms.N, dq.data(), ds.data());
     KR_HIP(hipMemcpy((char*)ms.q.p + (size_t)idx * ms.q_stride, dq.data(), ms.q_stride, hipMemcpyHostToDevice));
     KR_HIP(hipMemcpy((char*)ms.s.p + (size_t)idx * ms.s_stride, ds.data(), ms.s_stride, hipMemcpyHostToDevice));
     (void)e;
+    return KR_OK;
+}
+
+int download_mat(kr_engine* e, MatSet& ms, int idx, void* dst, uint16_t* sc) {
+    (void)e;
+    std::vector<uint32_t> dq(ms.q_stride / 4), ds(ms.s_stride / 4);
+    KR_HIP(hipMemcpy(dq.data(), (char*)ms.q.p + (size_t)idx * ms.q_stride, ms.q_stride, hipMemcpyDeviceToHost));
+    KR_HIP(hipMemcpy(ds.data(), (char*)ms.s.p + (size_t)idx * ms.s_stride, ms.s_stride, hipMemcpyDeviceToHost));
+    if (ms.bits == 4) untile_int4(dq.data(), ds.data(), ms.K, ms.N, (uint32_t*)dst, sc);
+    else untile_int8(dq.data(), ds.data(), ms.K, ms.N, (int8_t*)dst, sc);
     return KR_OK;
 }
 
@@ -340,15 +285,8 @@ extern "C" int kr_download_expert_unified(kr_engine* e, int layer, int expert, v
     const int idx = expert == -1 ? 0 : expert;
     if (!a.allocated() || (expert >= 0 && (expert >= a.count || !L.present[expert])) || (expert == -1 && !L.shared_present))
         return kr_fail(KR_ERR_STATE, "expert %d of layer %d not loaded", expert, layer);
-    for (int which = 0; which < 2; which++) {
-        MatSet& ms = which == 0 ? a : b;
-        std::vector<uint32_t> dq(ms.q_stride / 4), ds(ms.s_stride / 4);
-        KR_HIP(hipMemcpy(dq.data(), (char*)ms.q.p + (size_t)idx * ms.q_stride, ms.q_stride, hipMemcpyDeviceToHost));
-        KR_HIP(hipMemcpy(ds.data(), (char*)ms.s.p + (size_t)idx * ms.s_stride, ms.s_stride, hipMemcpyDeviceToHost));
-        void* dst = which == 0 ? w13 : w2; uint16_t* sc = which == 0 ? w13_scales : w2_scales;
-        if (ms.bits == 4) untile_int4(dq.data(), ds.data(), ms.K, ms.N, (uint32_t*)dst, sc);
-        else untile_int8(dq.data(), ds.data(), ms.K, ms.N, (int8_t*)dst, sc);
-    }
+    if (int rc = download_mat(e, a, idx, w13, w13_scales)) return rc;
+    if (int rc = download_mat(e, b, idx, w2, w2_scales)) return rc;
     return KR_OK;
 }
 

@@ -1,0 +1,80 @@
+// kr_engine_internal.h -- engine state shared by kr_engine.cpp and kr_decode.cpp (not part of the C ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/krasis_hip.h"
+#include "kr_kernels.h"
+
+int kr_fail(int code, const char* fmt, ...);
+#define KR_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess) return kr_fail(KR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        if (hipMalloc(&p, n) != hipSuccess) return 1;
+        bytes = n; return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct MatSet {            // all experts of one layer for one projection, contiguous in HBM
+    DevBuf q, s;
+    int K = 0, N = 0, bits = 0, count = 0;
+    size_t q_stride = 0, s_stride = 0;
+    bool allocated() const { return q.p != nullptr; }
+    KrMatDev view() const {
+        KrMatDev m{};
+        m.q = q.p; m.s = (const uint32_t*)s.p; m.K = K; m.N = N;
+        m.ng = K / 128; m.ngp = (m.ng + 1) / 2; m.bits = bits; m.n_fma = (N / 8) * 8;
+        m.q_stride = q_stride; m.s_stride = s_stride;
+        return m;
+    }
+};
+
+struct Layer {
+    MatSet w13, w2;        // routed experts
+    MatSet sw13, sw2;      // shared expert (count == 1)
+    std::vector<uint8_t> present;
+    bool shared_present = false;
+    int inter = 0, shared_inter = 0;
+    // routing (set_routing_weights)
+    std::vector<float> gate_host;          // [E,H] f32 copy (bf16 inputs widen exactly)
+    bool gate_bf16_exact = false;          // every value representable in bf16 -> stored as bf16 in HBM
+    DevBuf gate_cm;                        // chain-major layout for rule DECODE
+    DevBuf gate_rm;                        // row-lane layout for rule ENGINE (built on first use)
+    DevBuf bias, esc; bool has_bias = false, has_esc = false, routing_present = false;
+};
+
+struct kr_engine {
+    int device = 0;
+    kr_model_config cfg{};
+    hipStream_t stream = nullptr;
+    std::vector<Layer> layers;
+    size_t weight_bytes = 0;
+    // scratch
+    DevBuf gu, eo, st_act, st_ids, st_w, st_out, ptr_table;
+    // routing config
+    bool routing_set = false; int r_scoring = 1, r_norm = 1, r_topk = 0, r_ne = 0, r_hidden = 0;
+    DevBuf r_logits, r_ids, r_w, r_x;
+    // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
+    bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};
+    std::mutex mu;
+};
+
+bool is_device_ptr(const void* p);
+int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int count);
+int upload_mat(kr_engine* e, MatSet& ms, int idx, const void* w, const uint16_t* sc);
+int download_mat(kr_engine* e, MatSet& ms, int idx, void* w, uint16_t* sc);

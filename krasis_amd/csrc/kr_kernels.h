@@ -36,6 +36,8 @@ enum { KR_ACT_SILU_FUSED = 0,  // silu_quantize_int16_avx2 (avx2.rs:2310): poly 
 
 struct KrMoeArgs {
     const uint16_t* act;   // bf16 [B,H]
+    const float* act_f32;  // decode graph: f32 hidden [B,H]; routed experts see bf16(hidden) (decode.rs:3307), when set `act` is unused
+    int shared_decode;     // shared slot follows the decode-store numerics: f32 input quant, fast_silu_mul + f32::round quant (decode.rs:3356-3378)
     const int32_t* ids;    // [B,topk]
     const float* wts;      // [B,topk]
     int B, topk, n_slots;  // n_slots = topk (+1 when the shared expert runs in the same launches)
@@ -57,7 +59,10 @@ void kr_launch_moe_w2(const KrMoeArgs& a, hipStream_t st);
 void kr_launch_moe_combine(const KrMoeArgs& a, hipStream_t st);
 
 // generic single-matrix matvec: y[N] = W . quant(x[K]); x f32 or bf16; used for projections / lm_head
-void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st);
+// act_mode < 0: x[K] is quantized as is; otherwise x = [gate(K) | up(K)] and the kernel applies KR_ACT_* first (dense MLP)
+void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st, int act_mode = -1);
 
 void kr_launch_fill_synth(void* q, size_t q_bytes, uint32_t* s, size_t s_words, uint64_t seed, hipStream_t st);
+void kr_launch_fill_uniform_f32(float* x, size_t n, float amp, uint64_t seed, hipStream_t st);
+void kr_launch_fill_fp16_kv(uint16_t* x, size_t n, uint64_t seed, hipStream_t st);
 void kr_launch_reduce_sum_bf16(const uint16_t* const* dev_ptr_table, int n_inputs, uint16_t* out, size_t n, hipStream_t st);

@@ -80,6 +80,28 @@ __device__ __forceinline__ void kr_prologue_quant(const T* x, int K, const KrAct
     }
 }
 
+// decode graph: f32 hidden, optionally rounded to bf16 first (decode.rs:3307-3309 feeds bf16(hidden) to the routed experts)
+template <bool I8>
+__device__ __forceinline__ void kr_prologue_quant_f32(const float* x, int K, const KrActLds& L, bool round_bf16) {
+    const int nchunks = K / 8;
+    for (int c = threadIdx.x; c < nchunks; c += KR_BLOCK) {
+        float v[8];
+        kr_load8(x, c, v);
+        float mx = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (round_bf16) v[i] = kr_bf16_to_f32(kr_f32_to_bf16(v[i]));
+            mx = fmaxf(mx, fabsf(v[i]));
+        }
+        float scale, inv;
+        kr_group_scale(mx, scale, inv);
+        int q[8];
+        kr_quant8<false>(v, inv, q);
+        kr_store_chunk<I8>(L, c, q);
+        if ((c & 15) == 0) L.ascale[c >> 4] = scale;
+    }
+}
+
 // hidden = act(gate, up) then per-128 INT16 quantization, from gu = [gate(n) | up(n)] in global memory
 template <int ACT, bool I8>
 __device__ __forceinline__ void kr_prologue_hidden(const float* gu, int n, float swiglu_limit, float alpha, const KrActLds& L) {
@@ -249,7 +271,8 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a,
     const int tile0 = (blockIdx.x * KR_WAVES) * tiles_per_wave;
     if (tile0 >= ntiles) return;
     const KrActLds L = kr_carve_lds(kr_smem, a.H, BITS == 8);
-    kr_prologue_quant<uint16_t, BITS == 8>(a.act + (size_t)b * a.H, a.H, L);
+    if (a.act_f32) kr_prologue_quant_f32<BITS == 8>(a.act_f32 + (size_t)b * a.H, a.H, L, !(sl.shared && a.shared_decode));
+    else kr_prologue_quant<uint16_t, BITS == 8>(a.act + (size_t)b * a.H, a.H, L);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
@@ -274,7 +297,8 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w2_kernel(const KrMoeArgs a, 
     if (tile0 >= ntiles) return;
     const KrActLds L = kr_carve_lds(kr_smem, sl.inter, BITS == 8);
     const float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
-    kr_prologue_hidden<ACT, BITS == 8>(gu, sl.inter, a.swiglu_limit, a.alpha, L);
+    if (sl.shared && a.shared_decode) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(gu, sl.inter, a.swiglu_limit, a.alpha, L);
+    else kr_prologue_hidden<ACT, BITS == 8>(gu, sl.inter, a.swiglu_limit, a.alpha, L);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* eo = a.eo + ((size_t)b * a.n_slots + slot) * a.H;
@@ -305,12 +329,13 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_combine_kernel(const KrMoeArg
 }
 
 template <typename T, int BITS>
-__global__ void __launch_bounds__(KR_BLOCK) kr_matvec_kernel(const KrMatDev m, const T* x, float* y, int tiles_per_wave) {
+__global__ void __launch_bounds__(KR_BLOCK) kr_matvec_kernel(const KrMatDev m, const T* x, float* y, int tiles_per_wave, int act_mode) {
     const int ntiles = (m.N + 7) / 8;
     const int tile0 = (blockIdx.x * KR_WAVES) * tiles_per_wave;
     if (tile0 >= ntiles) return;
     const KrActLds L = kr_carve_lds(kr_smem, m.ng * 128, BITS == 8);
-    kr_prologue_quant<T, BITS == 8>(x, m.ng * 128, L);
+    if (act_mode == KR_ACT_SILU_MUL) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(reinterpret_cast<const float*>(x), m.ng * 128, 0.0f, 0.0f, L);
+    else kr_prologue_quant<T, BITS == 8>(x, m.ng * 128, L);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int t = 0; t < tiles_per_wave; t++) {
@@ -375,17 +400,17 @@ void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st) {
     kr_launch_moe_combine(a, st);
 }
 
-void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st) {
+void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st, int act_mode) {
     const int nt = (m.N + 7) / 8;
     const int tpw = kr_pick_tpw(m.K, nt);
     dim3 grid((nt + KR_WAVES * tpw - 1) / (KR_WAVES * tpw));
     const size_t lds = kr_lds_bytes(m.ng * 128, m.bits == 8);
     if (x_is_f32) {
-        if (m.bits == 4) hipLaunchKernelGGL((kr_matvec_kernel<float, 4>), grid, dim3(KR_BLOCK), lds, st, m, (const float*)x, y, tpw);
-        else hipLaunchKernelGGL((kr_matvec_kernel<float, 8>), grid, dim3(KR_BLOCK), lds, st, m, (const float*)x, y, tpw);
+        if (m.bits == 4) hipLaunchKernelGGL((kr_matvec_kernel<float, 4>), grid, dim3(KR_BLOCK), lds, st, m, (const float*)x, y, tpw, act_mode);
+        else hipLaunchKernelGGL((kr_matvec_kernel<float, 8>), grid, dim3(KR_BLOCK), lds, st, m, (const float*)x, y, tpw, act_mode);
     } else {
-        if (m.bits == 4) hipLaunchKernelGGL((kr_matvec_kernel<uint16_t, 4>), grid, dim3(KR_BLOCK), lds, st, m, (const uint16_t*)x, y, tpw);
-        else hipLaunchKernelGGL((kr_matvec_kernel<uint16_t, 8>), grid, dim3(KR_BLOCK), lds, st, m, (const uint16_t*)x, y, tpw);
+        if (m.bits == 4) hipLaunchKernelGGL((kr_matvec_kernel<uint16_t, 4>), grid, dim3(KR_BLOCK), lds, st, m, (const uint16_t*)x, y, tpw, act_mode);
+        else hipLaunchKernelGGL((kr_matvec_kernel<uint16_t, 8>), grid, dim3(KR_BLOCK), lds, st, m, (const uint16_t*)x, y, tpw, act_mode);
     }
 }
 
@@ -417,6 +442,27 @@ __global__ void kr_fill_scales_kernel(uint32_t* s, size_t n_words, uint64_t seed
 void kr_launch_fill_synth(void* q, size_t q_bytes, uint32_t* s, size_t s_words, uint64_t seed, hipStream_t st) {
     hipLaunchKernelGGL(kr_fill_words_kernel, dim3(2048), dim3(256), 0, st, (uint32_t*)q, q_bytes / 4, seed);
     hipLaunchKernelGGL(kr_fill_scales_kernel, dim3(512), dim3(256), 0, st, s, s_words, seed);
+}
+
+// uniform f32 in [-amp, amp] and random FP16 KV patterns (decode.rs:4371-4375, 4402-4411), counter-hash based
+__global__ void kr_fill_uniform_f32_kernel(float* x, size_t n, float amp, uint64_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int64_t b = (int64_t)kr_splitmix(seed * 0x100000001B3ull + i);
+        x[i] = (float)((double)b / 9223372036854775807.0) * amp;
+    }
+}
+__global__ void kr_fill_fp16_kv_kernel(uint16_t* x, size_t n, uint64_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t bits = kr_splitmix(seed * 0x100000001B3ull + i);
+        const uint16_t sign = (uint16_t)((bits >> 15) & 1), ex = (uint16_t)(((bits >> 5) & 0xF) + 8), mant = (uint16_t)(bits & 0x3FF);
+        x[i] = (uint16_t)((sign << 15) | (ex << 10) | mant);
+    }
+}
+void kr_launch_fill_uniform_f32(float* x, size_t n, float amp, uint64_t seed, hipStream_t st) {
+    hipLaunchKernelGGL(kr_fill_uniform_f32_kernel, dim3(2048), dim3(256), 0, st, x, n, amp, seed);
+}
+void kr_launch_fill_fp16_kv(uint16_t* x, size_t n, uint64_t seed, hipStream_t st) {
+    hipLaunchKernelGGL(kr_fill_fp16_kv_kernel, dim3(1024), dim3(256), 0, st, x, n, seed);
 }
 
 // reduce_sum_bf16 (moe.rs:2505): f32 accumulate in input order, RNE to bf16

@@ -1,0 +1,169 @@
+"""CpuDecodeStore -- host mirror of the reference's decode-graph class (src/decode.rs:193-3602) over the HIP C ABI.
+
+The class keeps the reference's NAME and builder methods so `decode_setup.py`-style callers are source compatible; the
+graph it builds runs on the MI355X (all weights / KV / recurrent state in HBM, one hipGraph replay per token).
+Pointer arguments are integer HOST addresses exactly like the reference (decode.rs:280-286).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, load_library
+from .engine import KrasisEngine, _addr
+
+
+class CpuDecodeStore:
+    def __init__(self, group_size: int = 128, parallel: bool = True, norm_bias_one: bool = False):
+        self._lib = load_library()
+        self._group_size = group_size
+        self._norm_bias_one = norm_bias_one
+        self._h = C.c_void_p()
+        self._engine: Optional[KrasisEngine] = None
+        self._keep: list = []
+        self._vocab = 0
+        self._n_layers = 0
+        self._pending = []      # weights stored before set_moe_store() binds an engine
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self._lib.kr_decode_destroy(self._h); self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # the reference shares its WeightStore with the engine via set_moe_store (decode.rs:2250); here the engine also owns the
+    # device/stream, so it must be bound before weights are stored.
+    def set_moe_store(self, engine: KrasisEngine) -> None:
+        engine._need("Model not loaded")
+        if self._h.value:
+            raise RuntimeError("MoE store already set")
+        self._engine = engine
+        check(self._lib.kr_decode_create(engine._h, self._group_size, int(self._norm_bias_one), C.byref(self._h)))
+
+    def _need(self):
+        if not self._h.value:
+            raise RuntimeError("Call set_moe_store(engine) first")
+
+    # ------------------------------------------------------------------ weights
+    def store_weight_f32(self, data_ptr: int, rows: int, cols: int, num_bits: int = 4) -> int:
+        self._need()
+        if num_bits not in (4, 8):
+            raise ValueError(f"num_bits must be 4 or 8, got {num_bits}")
+        wid = C.c_int()
+        check(self._lib.kr_decode_store_weight_f32(self._h, data_ptr, rows, cols, num_bits, C.byref(wid)))
+        return wid.value
+
+    def store_weight_synthetic(self, rows: int, cols: int, num_bits: int = 4, seed: int = 1) -> int:
+        self._need()
+        wid = C.c_int()
+        check(self._lib.kr_decode_store_weight_synthetic(self._h, rows, cols, num_bits, seed, C.byref(wid)))
+        return wid.value
+
+    def download_weight(self, wid: int, rows: int, cols: int, num_bits: int = 4):
+        self._need()
+        packed = np.empty((cols // 8, rows), np.uint32) if num_bits == 4 else np.empty((cols, rows), np.int8)
+        scales = np.empty((cols // 128, rows), np.uint16)
+        check(self._lib.kr_decode_download_weight(self._h, wid, _addr(packed), _addr(scales)))
+        return packed, scales
+
+    def store_norm_weight(self, data_ptr: int, size: int) -> int:
+        self._need()
+        nid = C.c_int()
+        check(self._lib.kr_decode_store_norm_weight(self._h, data_ptr, size, C.byref(nid)))
+        return nid.value
+
+    def store_route_weight(self, data_ptr: int, num_experts: int, hidden_dim: int, bias_ptr: int = 0, e_score_corr_ptr: int = 0,
+                           moe_layer_idx: Optional[int] = None) -> int:
+        """decode.rs:895 -- f32 gate [E, H] (+ optional bias / e_score_correction).  Routed through the engine's router store."""
+        self._need()
+        idx = moe_layer_idx if moe_layer_idx is not None else len(self._keep)
+        check(self._lib.kr_set_routing_weights(self._engine._h, idx, data_ptr, 1, bias_ptr or None, e_score_corr_ptr or None))
+        self._keep.append(idx)
+        return idx
+
+    # ------------------------------------------------------------------ graph
+    def configure_decode(self, hidden_size: int, num_layers: int, eps: float, final_norm_id: int, lm_head_wid: int, vocab_size: int,
+                         topk: int, scoring_func: int, norm_topk_prob: bool, routed_scaling_factor: float, embedding_ptr: int,
+                         synth_seed: int = 0) -> None:
+        self._need()
+        check(self._lib.kr_decode_configure(self._h, hidden_size, num_layers, eps, final_norm_id, lm_head_wid, vocab_size, topk,
+                                            scoring_func, int(norm_topk_prob), routed_scaling_factor, embedding_ptr or None, synth_seed))
+        self._vocab, self._n_layers = vocab_size, num_layers
+
+    def add_decode_la_layer(self, input_norm_id, post_attn_norm_id, in_proj_qkvz_wid, in_proj_ba_wid, out_proj_wid, conv_weight_ptr,
+                            a_log_ptr, dt_bias_ptr, norm_weight_ptr, nk, nv, dk, dv, kernel_dim, scale) -> None:
+        self._need()
+        check(self._lib.kr_decode_add_la_layer(self._h, input_norm_id, post_attn_norm_id, in_proj_qkvz_wid, in_proj_ba_wid, out_proj_wid,
+                                               conv_weight_ptr, a_log_ptr, dt_bias_ptr, norm_weight_ptr, nk, nv, dk, dv, kernel_dim, scale))
+
+    def add_decode_gqa_layer(self, input_norm_id, post_attn_norm_id, q_proj_wid, k_proj_wid, v_proj_wid, o_proj_wid, q_norm_ptr, q_norm_len,
+                             k_norm_ptr, k_norm_len, gated, num_heads, num_kv_heads, head_dim, sm_scale) -> None:
+        self._need()
+        check(self._lib.kr_decode_add_gqa_layer(self._h, input_norm_id, post_attn_norm_id, q_proj_wid, k_proj_wid, v_proj_wid, o_proj_wid,
+                                                q_norm_ptr or None, q_norm_len, k_norm_ptr or None, k_norm_len, int(gated), num_heads,
+                                                num_kv_heads, head_dim, sm_scale))
+
+    def set_decode_layer_moe(self, layer_idx: int, route_id: int, moe_layer_idx: int, shared_gate_up_wid: Optional[int] = None,
+                             shared_down_wid: Optional[int] = None, shared_gate_wid: Optional[int] = None) -> None:
+        self._need()
+        f = lambda v: -1 if v is None else v
+        check(self._lib.kr_decode_set_layer_moe(self._h, layer_idx, moe_layer_idx, f(shared_gate_up_wid), f(shared_down_wid), f(shared_gate_wid)))
+
+    def set_decode_layer_dense(self, layer_idx: int, gate_proj_wid: int, up_proj_wid: int, down_proj_wid: int) -> None:
+        self._need()
+        check(self._lib.kr_decode_set_layer_dense(self._h, layer_idx, gate_proj_wid, up_proj_wid, down_proj_wid))
+
+    def set_decode_rope(self, cos_ptr: int, sin_ptr: int, half_dim: int, max_seq: int) -> None:
+        self._need()
+        check(self._lib.kr_decode_set_rope(self._h, cos_ptr, sin_ptr, half_dim, max_seq))
+
+    def finalize_decode(self) -> None:
+        self._need()
+        check(self._lib.kr_decode_finalize(self._h))
+
+    def set_decode_state(self, seq_len: int, kv_max_seq: int, kv_k_ptrs: Sequence[int], kv_v_ptrs: Sequence[int],
+                         conv_state_ptrs: Sequence[int], recur_state_ptrs: Sequence[int], mla_ckv_ptrs=None, mla_kpe_ptrs=None) -> None:
+        self._need()
+        n = self._n_layers
+        mk = lambda xs: (C.c_void_p * n)(*[(x or None) for x in xs])
+        check(self._lib.kr_decode_set_state(self._h, seq_len, kv_max_seq, mk(kv_k_ptrs), mk(kv_v_ptrs), mk(conv_state_ptrs), mk(recur_state_ptrs)))
+
+    def fill_state_synthetic(self, kv_max_seq: int, seed: int = 7) -> None:
+        self._need()
+        check(self._lib.kr_decode_fill_state_synthetic(self._h, kv_max_seq, seed))
+
+    def get_decode_state(self, layer: int, kv_k=None, kv_v=None, conv_state=None, recur_state=None) -> None:
+        self._need()
+        check(self._lib.kr_decode_get_state(self._h, layer, _addr(kv_k) or None, _addr(kv_v) or None, _addr(conv_state) or None,
+                                            _addr(recur_state) or None))
+
+    # ------------------------------------------------------------------ run
+    def decode_step(self, token_id: int, position: int, output_ptr: int = 0, stream: int = 0) -> None:
+        self._need()
+        check(self._lib.kr_decode_step(self._h, token_id, position, output_ptr or None, stream or None))
+
+    def generate_batch(self, first_token: int, start_pos: int, max_tokens: int, temperature: float = 0.0, top_k: int = 0, top_p: float = 1.0,
+                       stop_ids: Sequence[int] = (), presence_penalty: float = 0.0) -> List[int]:
+        self._need()
+        if temperature > 0.0:
+            raise ValueError("only greedy sampling (temperature=0) is built in this round")
+        out = (C.c_int * max_tokens)(); n = C.c_int()
+        stops = (C.c_int * max(len(stop_ids), 1))(*stop_ids)
+        check(self._lib.kr_decode_generate_greedy(self._h, first_token, start_pos, max_tokens, stops, len(stop_ids), out, C.byref(n), None))
+        return list(out[: n.value])
+
+    def last_token(self) -> int:
+        t = C.c_int(); check(self._lib.kr_decode_last_token(self._h, C.byref(t))); return t.value
+
+    def set_use_graph(self, enable: bool) -> None:
+        self._need(); check(self._lib.kr_decode_set_use_graph(self._h, int(enable)))
+
+    def read_hidden(self, n: int) -> np.ndarray:
+        out = np.empty(n, np.float32); check(self._lib.kr_decode_read_buffer(self._h, 0, _addr(out), n)); return out
+
+    def device_bytes(self) -> int:
+        self._need(); return int(self._lib.kr_decode_device_bytes(self._h))

@@ -1,0 +1,128 @@
+"""GPU parity of the full decode step (hybrid linear-attention + gated GQA + MoE with shared expert) against the oracle
+driver: logits, sampled token and every piece of recurrent / KV state compared BIT FOR BIT."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.oracle_decode import OracleDecode
+from tests.util import make_experts, upload
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _ptr(a):
+    return a.ctypes.data
+
+
+def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False):
+    from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
+    rng = np.random.default_rng(seed)
+    H, V, E, k, I, SI = 256, 512, 16, 4, 128, 128
+    nk, nv, dk, dv = 2, 4, 128, 128
+    nh, nkv, hd, d2 = 4, 2, 64, 8
+    kv_max = 32
+    kinds = ["la", "gqa", "la"] + (["gqa"] if with_dense else [])
+    nL = len(kinds)
+    emb = ((rng.random((V, H)) - 0.5) * 0.2).astype(F)
+    eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, nL, 0, rsf))
+    eng.set_routing_config("softmax" if scoring == 1 else "sigmoid", True, k, E, H)
+    st = CpuDecodeStore(128, True, norm_bias_one); st.set_moe_store(eng)
+    orc = OracleDecode(H, 1e-6, norm_bias_one, k, scoring, True, rsf, emb, V)
+    keep = [emb]
+
+    def W(rows, cols, scale=0.05):
+        w = (rng.standard_normal((rows, cols)) * scale).astype(F); keep.append(w)
+        return st.store_weight_f32(_ptr(w), rows, cols, 4), orc.store_weight_f32(w, 4)
+
+    def N(n):
+        w = (rng.random(n) * 0.2 + (0.0 if norm_bias_one else 0.9)).astype(F); keep.append(w)
+        return st.store_norm_weight(_ptr(w), n), orc.store_norm(w)
+
+    fin = N(H); lm = W(V, H)
+    st.configure_decode(H, nL, 1e-6, fin[0], lm[0], V, k, scoring, True, rsf, _ptr(emb))
+    orc.final_norm, orc.lm_head = fin[1], lm[1]
+    cos = np.cos(np.arange(kv_max)[:, None] * (1.0 / 10000.0 ** (2 * np.arange(d2) / (2 * d2)))[None, :]).astype(F)
+    sin = np.sin(np.arange(kv_max)[:, None] * (1.0 / 10000.0 ** (2 * np.arange(d2) / (2 * d2)))[None, :]).astype(F)
+    keep += [cos, sin]; orc.rope = (cos, sin)
+    state = dict(kv_k=[None] * nL, kv_v=[None] * nL, conv=[None] * nL, recur=[None] * nL)
+    for li, kind in enumerate(kinds):
+        n_in, n_post = N(H), N(H)
+        L = dict(in_norm=n_in[1], post_norm=n_post[1], attn=kind)
+        if kind == "la":
+            hr = nv // nk; group_dim = 2 * dk + 2 * dv * hr; conv_dim = 2 * nk * dk + nv * dv
+            qkvz = W(nk * group_dim, H, 0.08); ba = W(nk * 2 * hr, H, 0.3); out = W(H, nv * dv)
+            conv_w = (rng.standard_normal(conv_dim * 4) * 0.4).astype(F); a_log = (rng.random(nv) * 1.5 - 1.0).astype(F)
+            dt_bias = (rng.random(nv) - 0.5).astype(F); norm_w = (rng.random(nv * dv) + 0.5).astype(F)
+            keep += [conv_w, a_log, dt_bias, norm_w]
+            scale = F(1.0 / np.sqrt(dk))
+            st.add_decode_la_layer(n_in[0], n_post[0], qkvz[0], ba[0], out[0], _ptr(conv_w), _ptr(a_log), _ptr(dt_bias), _ptr(norm_w),
+                                   nk, nv, dk, dv, 4, float(scale))
+            cs = ((rng.random(conv_dim * 4) - 0.5) * 0.2).astype(F); rs = ((rng.random(nv * dk * dv) - 0.5) * 0.02).astype(F)
+            state["conv"][li] = cs; state["recur"][li] = rs
+            L.update(qkvz=qkvz[1], ba=ba[1], out=out[1], conv_w=conv_w, a_log=a_log, dt_bias=dt_bias, norm_w=norm_w, nk=nk, nv=nv, dk=dk, dv=dv,
+                     scale=scale, conv_state=cs.copy(), recur_state=rs.copy())
+        else:
+            q = W(nh * hd * 2, H, 0.08); kk = W(nkv * hd, H, 0.08); v = W(nkv * hd, H, 0.08); o = W(H, nh * hd)
+            qn = (rng.random(hd) + 0.5).astype(F); kn = (rng.random(nkv * hd) + 0.5).astype(F); keep += [qn, kn]   # shared vs per-head norm weights
+            sm = F(1.0 / np.sqrt(hd))
+            st.add_decode_gqa_layer(n_in[0], n_post[0], q[0], kk[0], v[0], o[0], _ptr(qn), qn.size, _ptr(kn), kn.size, True, nh, nkv, hd, float(sm))
+            kc = O.f32_to_f16_bits((rng.standard_normal((kv_max, nkv * hd)) * 0.5).astype(F)); vc = O.f32_to_f16_bits((rng.standard_normal((kv_max, nkv * hd)) * 0.5).astype(F))
+            state["kv_k"][li] = kc; state["kv_v"][li] = vc
+            L.update(q=q[1], k=kk[1], v=v[1], o=o[1], q_norm=qn, k_norm=kn, gated=True, nh=nh, nkv=nkv, hd=hd, sm_scale=sm, kv_k=kc.copy(), kv_v=vc.copy())
+        if with_dense and li == nL - 1:
+            DI = 384                                    # dense MLP with a padded intermediate (cols of down = 384)
+            gw = W(DI - 40, H); uw = W(DI - 40, H)
+            wd = (rng.standard_normal((H, DI)) * 0.05).astype(F); wd[:, DI - 40:] = 0; keep.append(wd)
+            dw = (st.store_weight_f32(_ptr(wd), H, DI, 4), orc.store_weight_f32(wd, 4))
+            st.set_decode_layer_dense(li, gw[0], uw[0], dw[0]); L.update(mlp="dense", gate_w=gw[1], up_w=uw[1], down_w=dw[1])
+        else:
+            experts = make_experts(rng, E, H, I); upload(eng, li, experts)
+            gate = ((rng.random((E, H)) - 0.5) * 0.1).astype(F); keep.append(gate)
+            esc = ((rng.random(E) - 0.5) * 0.01).astype(F) if scoring == 0 else None
+            eng.set_route_weight_f32(li, gate, None, esc)
+            sgu = W(2 * SI, H); sd = W(H, SI); sg = W(1, H, 0.3)
+            st.set_decode_layer_moe(li, li, li, sgu[0], sd[0], sg[0])
+            L.update(mlp="moe", gate=gate, esc=esc, experts=experts, sgu=sgu[1], sd=sd[1], sg=sg[1])
+        orc.layers.append(L)
+    st.set_decode_rope(_ptr(cos), _ptr(sin), d2, kv_max)
+    st.finalize_decode()
+    z = lambda xs: [(_ptr(x) if x is not None else 0) for x in xs]
+    st.set_decode_state(5, kv_max, z(state["kv_k"]), z(state["kv_v"]), z(state["conv"]), z(state["recur"]))
+    return st, eng, orc, keep, dict(H=H, V=V, kinds=kinds, kv_max=kv_max, nkv=nkv, hd=hd, conv_dim=2 * nk * dk + nv * dv, nv=nv, dk=dk, dv=dv)
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True)])
+@pytest.mark.parametrize("graph", [True, False])
+def test_decode_step_bit_exact(cfg, graph):
+    st, eng, orc, keep, d = build(**cfg)
+    st.set_use_graph(graph)
+    tok = 7
+    for step, pos in enumerate([5, 6, 7]):
+        logits = np.empty(d["V"], F)
+        st.decode_step(tok, pos, logits.ctypes.data)
+        ref = orc.step(tok, pos)
+        assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (step, float(np.max(np.abs(logits - ref))))
+        nxt = st.last_token()
+        assert nxt == O.sample_greedy(ref)
+        tok = nxt
+    for li, kind in enumerate(d["kinds"]):
+        L = orc.layers[li]
+        if kind == "la":
+            cs = np.empty(d["conv_dim"] * 4, F); rs = np.empty(d["nv"] * d["dk"] * d["dv"], F)
+            st.get_decode_state(li, None, None, cs, rs)
+            assert np.array_equal(cs.view(np.uint32), L["conv_state"].view(np.uint32))
+            assert np.array_equal(rs.view(np.uint32), L["recur_state"].view(np.uint32))
+        else:
+            kc = np.empty((d["kv_max"], d["nkv"] * d["hd"]), np.uint16); vc = np.empty_like(kc)
+            st.get_decode_state(li, kc, vc, None, None)
+            assert np.array_equal(kc, L["kv_k"]) and np.array_equal(vc, L["kv_v"])
+
+
+def test_generate_batch_greedy_matches_oracle():
+    st, eng, orc, keep, d = build(seed=3)
+    toks = st.generate_batch(11, 5, 4)
+    ref, tok = [], 11
+    for i in range(4):
+        tok = O.sample_greedy(orc.step(tok, 5 + i)); ref.append(tok)
+    assert toks == ref
