@@ -52,6 +52,7 @@ struct kr_decode_store {
     int kv_max_seq = 0;
     // scratch
     DevBuf hid, res, proj_a, proj_b, qbuf, kbuf, vbuf, zbuf, gbuf, betabuf, gatebuf, recur_out, attn_out, logits, gate_val, tok;
+    DevBuf dense_gu;  // [gate(K) | up(K)] of the dense MLP; only [0,inter) of each half is ever written, the padding stays 0
     DevBuf moe_gu, moe_eo, r_logits, r_ids, r_w;  // store-owned so a captured graph never sees them reallocated
     DevBuf step_dev; KrStep* step_host = nullptr;
     size_t weight_bytes = 0;
@@ -88,7 +89,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
         for (DevBuf* b : {&l.conv_w, &l.a_log, &l.dt_bias, &l.la_norm_w, &l.conv_state, &l.recur_state, &l.q_norm, &l.k_norm, &l.kv_k, &l.kv_v}) b->release();
     for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
-                      &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w}) b->release();
+                      &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     if (s->step_host) (void)hipHostFree(s->step_host);
     delete s;
 }
@@ -297,7 +298,7 @@ extern "C" int kr_decode_finalize(kr_decode_store* s) {
     if (int rc = need_cfg(s)) return rc;
     if ((int)s->layers.size() != s->n_layers) return kr_fail(KR_ERR_STATE, "configured %d layers but %zu were added", s->n_layers, s->layers.size());
     KR_HIP(hipSetDevice(s->eng->device));
-    size_t pa = 0, pb = 0, qb = 0, kb = 0, vb = 0, zb = 0, ro = 0, ao = 0, gb = 0;
+    size_t pa = 0, pb = 0, qb = 0, kb = 0, vb = 0, zb = 0, ro = 0, ao = 0, gb = 0, dg = 0;
     for (auto& L : s->layers) {
         if (L.attn == ATTN_LA) {
             pa = maxz(pa, s->weights[L.qkvz_wid]->rows); pb = maxz(pb, s->weights[L.ba_wid]->rows);
@@ -307,7 +308,7 @@ extern "C" int kr_decode_finalize(kr_decode_store* s) {
             pa = maxz(pa, s->weights[L.q_wid]->rows); kb = maxz(kb, s->weights[L.k_wid]->rows); vb = maxz(vb, s->weights[L.v_wid]->rows);
             qb = maxz(qb, (size_t)L.nh * L.hd); zb = maxz(zb, (size_t)L.nh * L.hd); ao = maxz(ao, s->weights[L.o_wid]->cols);
         }
-        if (L.mlp == MLP_DENSE) { pa = maxz(pa, 2 * (size_t)s->weights[L.down_wid]->cols); }
+        if (L.mlp == MLP_DENSE) dg = maxz(dg, 2 * (size_t)s->weights[L.down_wid]->cols);
     }
     ao = maxz(ao, (size_t)s->hidden);
     if (s->proj_a.ensure(maxz(pa, 64) * 4) || s->proj_b.ensure(maxz(pb, 64) * 4) || s->qbuf.ensure(maxz(qb, 64) * 4) || s->kbuf.ensure(maxz(kb, 64) * 4) ||
@@ -315,6 +316,7 @@ extern "C" int kr_decode_finalize(kr_decode_store* s) {
         s->attn_out.ensure(maxz(ao, 64) * 4) || s->gbuf.ensure(maxz(gb, 64) * 4) || s->betabuf.ensure(maxz(gb, 64) * 4) ||
         s->gatebuf.ensure(maxz(zb, 64) * 4))
         return kr_fail(KR_ERR_HIP, "hipMalloc of decode scratch failed");
+    if (dg) { if (s->dense_gu.ensure(dg * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed"); KR_HIP(hipMemset(s->dense_gu.p, 0, s->dense_gu.bytes)); }
     KR_HIP(hipMemset(s->proj_a.p, 0, s->proj_a.bytes));
     KR_HIP(hipMemset(s->attn_out.p, 0, s->attn_out.bytes));
     s->graph_ok = false;
@@ -456,9 +458,9 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
         } else if (L.mlp == MLP_DENSE) {
             // gate / up into [0,K) and [K,2K) of proj_a (K = padded intermediate), then down with the fused silu*up + quant prologue
             const int K = s->weights[L.down_wid]->cols;
-            kr_launch_matvec(mv(s, L.gate_wid), hid, 1, (float*)s->proj_a.p, st);
-            kr_launch_matvec(mv(s, L.up_wid), hid, 1, (float*)s->proj_a.p + K, st);
-            kr_launch_matvec(mv(s, L.down_wid), s->proj_a.p, 1, hid, st, KR_ACT_SILU_MUL);
+            kr_launch_matvec(mv(s, L.gate_wid), hid, 1, (float*)s->dense_gu.p, st);
+            kr_launch_matvec(mv(s, L.up_wid), hid, 1, (float*)s->dense_gu.p + K, st);
+            kr_launch_matvec(mv(s, L.down_wid), s->dense_gu.p, 1, hid, st, KR_ACT_SILU_MUL);
         }
     }
     kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, 0, s->norm_bias_one, st);
