@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""bench.py -- Qwen3-Coder-Next (QCN) Q4 hot-path benchmark on MI355X.  Contract: see the task statement.
+"""bench.py -- decode tok/s of Qwen3-Coder-Next (QCN) Q4 on MI355X, the reference's headline metric (BASELINE.json).
 
-One "step" = one decode token through the hot path that exists on the GPU (see `config.scope` in the JSON line):
-  scope "moe"  : per token, for each of the 48 MoE layers: router (512 experts, top-10, f32 gate) + 10 routed INT4-g128
-                 experts + the shared expert.  Attention / linear-attention / lm_head are NOT included in this scope.
-Inputs are resident in HBM before the timed region.  Synthetic data: GPU-generated pseudo-random INT4 words and bf16
-scales in [0.005, 0.05] (the distribution of the reference's bench_decode_synthetic, src/decode.rs:4379-4392), router
-gate uniform +-0.02 (decode.rs:5181), hidden uniform +-0.5 (decode.rs:5437).
+One "step" = one full decode token through the GPU decode graph (the reference's `decode_step`, src/decode.rs:2690):
+embedding -> 48 x [fused add+RMSNorm -> gated-delta-net linear attention (36 layers) | gated GQA with FP16 KV (12 layers)
+-> fused add+RMSNorm -> router (512 experts, softmax, top-10) -> 10 routed INT4-g128 experts + shared expert with sigmoid
+gate] -> final norm -> lm_head (151936 x 2048 INT4) -> greedy argmax.  Same protocol as the reference's synthetic benchmark
+(bench_decode_synthetic, decode.rs:4618): token 0, positions 10.., kv_max_seq 256, random weights / state with the reference's
+value distributions, generated on the GPU.  Everything is resident in HBM before the timed region.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -17,10 +18,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Qwen3-Coder-Next dims (src/decode.rs:4670-4692)
-QCN = dict(hidden=2048, inter=512, experts=512, topk=10, layers=48, n_shared=1)
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-BYTES_PER_W_INT4 = 0.515625
+QCN = dict(hidden=2048, inter=512, experts=512, topk=10, layers=48, shared_inter=512, vocab=151936, nk=16, nv=32, dk=128, dv=128,
+           nh=16, nkv=2, hd=256, full_attn_interval=4, kv_max_seq=256, eps=1e-6)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable with a float4 copy)
+B4 = 0.515625              # bytes per INT4-g128 weight incl. bf16 group scale
+KINDS = ["embed", "fused_add_rmsnorm", "proj_matvec", "la_conv", "la_recurrent", "gated_rmsnorm_silu", "gqa", "route_logits",
+         "route_select", "moe_w13", "moe_w2", "moe_combine", "lm_head", "argmax", "shared_gate"]
+SYMBOL = {"proj_matvec": "kr_matvec_kernel<float,4>", "lm_head": "kr_matvec_kernel<float,4>", "shared_gate": "kr_matvec_kernel<float,4>",
+          "moe_w13": "kr_moe_w13_kernel<4>", "moe_w2": "kr_moe_w2_kernel<4,0>", "la_recurrent": "kr_la_recurrent_kernel<128>",
+          "route_logits": "kr_route_logits_decode_kernel<true>", "route_select": "kr_route_select_kernel",
+          "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
 
 
 def parse():
@@ -30,88 +37,170 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--layers", type=int, default=QCN["layers"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-graph", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(max_seconds):
-    """Reference CPU decode experts (AVX2 integer kernel on tiled weights, src/kernel/avx2.rs:1066, via the oracle port),
-    timed on this box's host cores on a bounded sample: one MoE layer (10 routed experts) per 'layer-token'."""
+def is_gqa(l):
+    return (l + 1) % QCN["full_attn_interval"] == 0
+
+
+def algorithmic_bytes(L):
+    """Bytes a decode token must touch, each weight/state byte once, per kernel kind."""
+    q = QCN; H, I, E, k = q["hidden"], q["inter"], q["experts"], q["topk"]
+    n_la = sum(1 for l in range(L) if not is_gqa(l)); n_gqa = L - n_la
+    group_dim = 2 * q["dk"] + 2 * q["dv"] * (q["nv"] // q["nk"])
+    la_w = (q["nk"] * group_dim + q["nk"] * 2 * (q["nv"] // q["nk"])) * H + H * (q["nv"] * q["dv"])
+    gqa_w = (q["nh"] * q["hd"] * 2 + 2 * q["nkv"] * q["hd"]) * H + H * (q["nh"] * q["hd"])
+    b = {
+        "proj_matvec": (n_la * la_w + n_gqa * gqa_w) * B4,
+        "moe_w13": L * (k + 1) * H * 2 * I * B4,          # 10 routed + shared expert
+        "moe_w2": L * (k + 1) * I * H * B4,
+        "lm_head": q["vocab"] * H * B4,
+        "route_logits": L * E * H * 2,                      # gate stored as bf16 in HBM
+        "la_recurrent": n_la * 2 * q["nv"] * q["dk"] * q["dv"] * 4,   # state read + write
+        "shared_gate": L * H * B4,
+    }
+    b["total"] = sum(b.values())
+    return b
+
+
+def build_qcn(rank, local_rank, L):
+    import numpy as np
+    from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
+    q = QCN; H, I, E, k, V = q["hidden"], q["inter"], q["experts"], q["topk"], q["vocab"]
+    eng = KrasisEngine(device=local_rank)
+    eng.configure(ModelConfig(H, I, E, k, L, 0, 1.0))
+    eng.fill_synthetic(4, seed=0x12345678ABCDEF01 + rank)
+    eng.set_routing_config("softmax", True, k, E, H)
+    st = CpuDecodeStore(128, True, True)                       # norm_bias_one: qwen3_next (decode.rs:4701)
+    st.set_moe_store(eng)
+    rng = np.random.default_rng(1234 + rank)
+    keep = []
+    seed = [100 + rank * 100000]
+
+    def W(rows, cols):
+        seed[0] += 1
+        return st.store_weight_synthetic(rows, cols, 4, seed[0])
+
+    def N(n):
+        w = ((rng.random(n, dtype=np.float32) - 0.5) * 0.2).astype(np.float32); keep.append(w)
+        return st.store_norm_weight(w.ctypes.data, n)
+
+    fin, lm = N(H), W(V, H)
+    st.configure_decode(H, L, q["eps"], fin, lm, V, k, 1, True, 1.0, 0, synth_seed=777 + rank)
+    nk, nv, dk, dv, nh, nkv, hd = q["nk"], q["nv"], q["dk"], q["dv"], q["nh"], q["nkv"], q["hd"]
+    hr = nv // nk; group_dim = 2 * dk + 2 * dv * hr; conv_dim = 2 * nk * dk + nv * dv
+    for l in range(L):
+        n_in, n_post = N(H), N(H)
+        if is_gqa(l):
+            qw, kw, vw, ow = W(nh * hd * 2, H), W(nkv * hd, H), W(nkv * hd, H), W(H, nh * hd)
+            qn = (rng.random(hd, dtype=np.float32) + 0.5).astype(np.float32); kn = (rng.random(hd, dtype=np.float32) + 0.5).astype(np.float32)
+            keep += [qn, kn]
+            st.add_decode_gqa_layer(n_in, n_post, qw, kw, vw, ow, qn.ctypes.data, hd, kn.ctypes.data, hd, True, nh, nkv, hd, 1.0 / hd ** 0.5)
+        else:
+            qkvz, ba, out = W(nk * group_dim, H), W(nk * 2 * hr, H), W(H, nv * dv)
+            cw = ((rng.random(conv_dim * 4, dtype=np.float32) - 0.5) * 1.0).astype(np.float32)
+            a_log = ((rng.random(nv, dtype=np.float32) - 0.5) * 2.0).astype(np.float32); dtb = ((rng.random(nv, dtype=np.float32) - 0.5)).astype(np.float32)
+            nw = (rng.random(nv * dv, dtype=np.float32) + 0.5).astype(np.float32); keep += [cw, a_log, dtb, nw]
+            st.add_decode_la_layer(n_in, n_post, qkvz, ba, out, cw.ctypes.data, a_log.ctypes.data, dtb.ctypes.data, nw.ctypes.data,
+                                   nk, nv, dk, dv, 4, 1.0 / dk ** 0.5)
+        # router gate +-0.02 (decode.rs:5181), rounded to bf16 like a real checkpoint -> stored as bf16 in HBM
+        gate = ((rng.random((E, H), dtype=np.float32) - 0.5) * 0.04).astype(np.float32)
+        gate = (gate.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        eng.set_route_weight_f32(l, gate)
+        sgu, sd, sg = W(2 * q["shared_inter"], H), W(H, q["shared_inter"]), W(1, H)
+        st.set_decode_layer_moe(l, l, l, sgu, sd, sg)
+    half = hd // 2                                                    # decode.rs:5379: full rotary in the synthetic bench
+    pos = np.arange(q["kv_max_seq"], dtype=np.float32)[:, None]
+    freq = (1.0 / (10000.0 ** (2.0 * np.arange(half, dtype=np.float32) / hd))).astype(np.float32)[None, :]
+    cos, sin = np.cos(pos * freq).astype(np.float32), np.sin(pos * freq).astype(np.float32); keep += [cos, sin]
+    st.set_decode_rope(cos.ctypes.data, sin.ctypes.data, half, q["kv_max_seq"])
+    st.finalize_decode()
+    st.fill_state_synthetic(q["kv_max_seq"], seed=4242 + rank)
+    return eng, st, keep
+
+
+def cpu_baseline(max_seconds, L):
+    """The reference's CPU decode arithmetic (AVX2 integer INT4 kernel on tiled weights, src/kernel/avx2.rs:1066, OpenMP over
+    256-column tiles like rayon) timed on this host on a BOUNDED sample: one MoE layer (10 routed + shared), the projections of one
+    LA and one GQA layer, lm_head once; then scaled to a full token.  Norms / recurrent state / attention are left out
+    (optimistic for the CPU).  Weights use the reference's xorshift generator."""
     import numpy as np
     from oracle import oracle as O
-    H, I, k = QCN["hidden"], QCN["inter"], QCN["topk"]
+    q = QCN; H, I, k = q["hidden"], q["inter"], q["topk"]
     rng = O.Xorshift64()
+
+    def tiled(rows, cols):
+        p = rng.fill_u32(cols // 8 * rows).reshape(cols // 8, rows); s = rng.fill_scales_bf16(cols // 128 * rows).reshape(cols // 128, rows)
+        return O.repack_tiled_u32(p), O.repack_tiled_u16(s), cols, rows
+
     experts = []
-    for _ in range(k):
+    for _ in range(k + 1):
         e = O.UnifiedExpert(rng.fill_u32(H // 8 * 2 * I).reshape(H // 8, 2 * I), rng.fill_scales_bf16(H // 128 * 2 * I).reshape(H // 128, 2 * I),
                             rng.fill_u32(I // 8 * H).reshape(I // 8, H), rng.fill_scales_bf16(I // 128 * H).reshape(I // 128, H), H, I)
         experts.append(O.tile_expert(e))
-    act = O.f32_to_bf16(rng.fill_f32(H, 0.5))
-    w = np.full(k, 1.0 / k, np.float32)
-    for _ in range(3):
-        O.moe_forward_unified_tiled_avx2(experts, w, act)
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < max_seconds:
-        for _ in range(20):
-            O.moe_forward_unified_tiled_avx2(experts, w, act)
-        n += 20
-    dt = time.perf_counter() - t0
-    layer_ms = dt / n * 1e3
-    return dict(value=1e3 / (layer_ms * QCN["layers"]), unit="tok/s", cores=O.num_threads(), kind="port",
-                sample=f"{n} x one QCN MoE layer (10 routed INT4 experts, weights L3-resident: optimistic for the CPU), "
-                       f"scaled to {QCN['layers']} layers; routed experts only",
-                layer_ms=layer_ms)
+    group_dim = 2 * q["dk"] + 2 * q["dv"] * (q["nv"] // q["nk"])
+    la = [tiled(q["nk"] * group_dim, H), tiled(H, q["nv"] * q["dv"])]
+    gqa = [tiled(q["nh"] * q["hd"] * 2 + 2 * q["nkv"] * q["hd"], H), tiled(H, q["nh"] * q["hd"])]
+    lm = tiled(q["vocab"], H)
+    act = O.f32_to_bf16(rng.fill_f32(H, 0.5)); w = np.full(k + 1, 1.0 / (k + 1), np.float32)
+    x2048 = rng.fill_f32(H, 0.5); x4096 = rng.fill_f32(4096, 0.5)
+    qa, sa = O.quant_act_int16_f32(x2048); qb, sb = O.quant_act_int16_f32(x4096)
+
+    def mv(t, qx, sx):
+        O.matvec_int4_tiled_avx2(t[0], t[1], qx, sx, t[2], t[3])
+
+    def timed(fn, budget):
+        fn(); n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            fn(); n += 1
+        return (time.perf_counter() - t0) / max(n, 1)
+
+    per = max_seconds / 4.0
+    t_moe = timed(lambda: O.moe_forward_unified_tiled_avx2(experts, w, act), per)
+    t_la = timed(lambda: (mv(la[0], qa, sa), mv(la[1], qb, sb)), per)
+    t_gqa = timed(lambda: (mv(gqa[0], qa, sa), mv(gqa[1], qb, sb)), per)
+    t_lm = timed(lambda: mv(lm, qa, sa), per)
+    n_la = sum(1 for l in range(L) if not is_gqa(l)); n_gqa = L - n_la
+    tok_s = 1.0 / (L * t_moe + n_la * t_la + n_gqa * t_gqa + t_lm)
+    return dict(value=tok_s, unit="tok/s", cores=O.num_threads(), kind="port",
+                sample="1 MoE layer (10 routed + shared INT4 experts) + LA-layer and GQA-layer projections + lm_head, AVX2+OpenMP port of "
+                       "avx2.rs:1066 on tiled weights; scaled to %d layers; norms/attention/state omitted (optimistic for the CPU)" % L,
+                ms={"moe_layer": t_moe * 1e3, "la_proj": t_la * 1e3, "gqa_proj": t_gqa * 1e3, "lm_head": t_lm * 1e3})
 
 
 def main():
     args = parse()
-    import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from krasis_amd import KrasisEngine, ModelConfig, _lib
+    from krasis_amd import _lib
     L = args.layers
-    H, I, E, k = QCN["hidden"], QCN["inter"], QCN["experts"], QCN["topk"]
-    eng = KrasisEngine(device=local_rank)
-    eng.configure(ModelConfig(H, I, E, k, L, QCN["n_shared"], 1.0))
-    eng.fill_synthetic(4, seed=0x12345678ABCDEF01 + rank)
-    eng.set_routing_config("softmax", True, k, E, H)
-    g = torch.Generator().manual_seed(1234 + rank)
-    for l in range(L):
-        gate = ((torch.rand((E, H), generator=g) - 0.5) * 0.04).numpy()
-        eng.set_route_weight_f32(l, gate)
-    x32 = ((torch.rand((L, H), generator=g) - 0.5)).cuda()            # hidden +-0.5, one row per layer
-    xbf = x32.to(torch.bfloat16).contiguous()                          # decode.rs:3307: experts see bf16(hidden)
-    ids = torch.empty((k,), dtype=torch.int32, device="cuda")
-    wts = torch.empty((k,), dtype=torch.float32, device="cuda")
-    out = torch.empty((L, H), dtype=torch.float32, device="cuda")
-    lib, h = eng._lib, eng._h
-    st = torch.cuda.current_stream().cuda_stream
+    eng, st, keep = build_qcn(rank, local_rank, L)
+    st.set_use_graph(not args.no_graph)
+    kvm = QCN["kv_max_seq"]
 
-    def step():
-        for l in range(L):
-            _lib.check(lib.kr_route_topk(h, l, x32[l].data_ptr(), 1, _lib.KR_ROUTE_RULE_DECODE, ids.data_ptr(), wts.data_ptr(), None, st))
-            _lib.check(lib.kr_moe_forward(h, l, xbf[l].data_ptr(), ids.data_ptr(), wts.data_ptr(), out[l].data_ptr(), 1, k,
-                                          _lib.KR_OUT_F32, 0, st))
+    def step(i):
+        st.decode_step(0, (10 + i) % (kvm - 1))
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -119,45 +208,50 @@ def main():
     if world > 1:
         t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
 
-    # per-kernel durations with HIP events on the launch stream (separate pass: events serialise launches)
-    _lib.check(lib.kr_set_profiling(h, 1))
-    import ctypes as C
-    for _ in range(max(3, min(args.steps, 20))):
-        step()
-    torch.cuda.synchronize()
-    prof = {}
-    for kind, name in enumerate(["kr_moe_w13_kernel", "kr_moe_w2_kernel", "kr_moe_combine_kernel"]):
-        ms, n = C.c_double(), C.c_long()
-        _lib.check(lib.kr_get_profile(h, kind, C.byref(ms), C.byref(n)))
-        prof[name] = (ms.value / max(n.value, 1)) * 1e3  # us per launch
-    _lib.check(lib.kr_set_profiling(h, 0))
+    # per-kernel durations: un-graphed steps with HIP events around every launch on the launch stream
+    ms = (C.c_double * 16)(); cnt = (C.c_long * 16)()
+    tot_ms = [0.0] * 16; tot_n = [0] * 16; P = 5
+    for i in range(P):
+        _lib.check(st._lib.kr_decode_profile_step(st._h, 0, (10 + i) % (kvm - 1), ms, cnt, 16))
+        for j in range(15):
+            tot_ms[j] += ms[j]; tot_n[j] += cnt[j]
+    per_kind_us = {KINDS[j]: (tot_ms[j] / P) * 1e3 for j in range(15)}            # us per step
+    per_launch_us = {KINDS[j]: (tot_ms[j] / max(tot_n[j], 1)) * 1e3 for j in range(15)}
 
     if rank == 0:
-        n_sh = QCN["n_shared"]
-        w13_bytes = (k + n_sh) * H * 2 * I * BYTES_PER_W_INT4      # algorithmic bytes of ONE w13 launch (weights once)
-        w2_bytes = (k + n_sh) * I * H * BYTES_PER_W_INT4
-        dom = "kr_moe_w13_kernel"
-        achieved = w13_bytes / (prof[dom] * 1e-6) / 1e9
+        ab = algorithmic_bytes(L)
+        sym_us, sym_bytes, sym_n = {}, {}, {}
+        for j in range(15):
+            kname = KINDS[j]; sym = SYMBOL.get(kname, kname)
+            sym_us[sym] = sym_us.get(sym, 0.0) + per_kind_us[kname]; sym_bytes[sym] = sym_bytes.get(sym, 0.0) + ab.get(kname, 0.0)
+            sym_n[sym] = sym_n.get(sym, 0) + tot_n[j] / P
+        dom = max(sym_us, key=lambda s: sym_us[s])
+        achieved = sym_bytes[dom] / (sym_us[dom] * 1e-6) / 1e9 if sym_us[dom] > 0 else 0.0
+        tok_s = world * args.steps / dt
         res = {
-            "metric": "decode tok/s, Qwen3-Coder-Next Q4 (INT4-g128 experts) @%d MI355X" % world,
-            "value": world * args.steps / dt, "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "decode tok/s, Qwen3-Coder-Next Q4 @%d MI355X" % world,
+            "value": tok_s, "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int4 weights x int16 activations -> i32, f32 scale chain", "data": "synthetic",
-            "config": {"workload": "Qwen3-Coder-Next Q4 int4gpu on 1xMI355X (512-expert top-10)", "scope": "moe",
-                       "scope_note": "router + routed experts + shared expert of all %d MoE layers per token; attention, linear "
-                                     "attention, norms and lm_head are not yet on the GPU path, so this is NOT the full decode step" % L,
-                       "layers": L, "hidden": H, "moe_intermediate": I, "experts": E, "topk": k,
-                       "parallelism": "replica x%d" % world},
+            "dtype": "int4-g128 weights x int16 activations -> i32, f32 scale chain (reference CPU-decode numerics, bit-exact)",
+            "data": "synthetic",
+            "config": {"workload": "Qwen3-Coder-Next Q4 int4gpu on 1xMI355X (512-expert top-10, hybrid linear+GQA)",
+                       "scope": "full decode_step: embedding, %d layers (LA/GQA + MoE + shared expert), final norm, lm_head, greedy sample" % L,
+                       "kv": "FP16 KV cache (reference CPU-decode numerics), kv_max_seq %d" % kvm, "layers": L,
+                       "parallelism": "replica x%d (QCN fits one GPU; decode is not expert-parallel)" % world,
+                       "hip_graph": not args.no_graph, "target_tok_s": 200},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": w13_bytes, "us_per_launch": prof[dom],
-                         "other_kernels_us": {n: v for n, v in prof.items() if n != dom},
-                         "w2_achieved_GBs": w2_bytes / (prof["kr_moe_w2_kernel"] * 1e-6) / 1e9},
+                         "algorithmic_bytes_per_launch": sym_bytes[dom] / max(sym_n[dom], 1), "us_per_launch": sym_us[dom] / max(sym_n[dom], 1),
+                         "launches_per_step": sym_n[dom],
+                         "step_algorithmic_bytes": ab["total"], "step_effective_GBs": ab["total"] * (args.steps / dt) / 1e9,
+                         "step_frac_of_hbm_peak": ab["total"] * (args.steps / dt) / 1e9 / HBM_PEAK_GBS,
+                         "per_kind_us_per_step": {k_: round(v, 2) for k_, v in per_kind_us.items()},
+                         "per_kind_us_per_launch": {k_: round(v, 2) for k_, v in per_launch_us.items()}},
         }
         if not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-            except Exception as ex:  # the baseline is a reported side number, never the product path
+                res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L)
+            except Exception as ex:  # a reported side number, never the product path
                 res["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(res))
     if world > 1:

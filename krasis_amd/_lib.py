@@ -22,7 +22,7 @@ SYMBOLS = [
     "kr_decode_download_weight", "kr_decode_store_norm_weight", "kr_decode_configure", "kr_decode_add_la_layer",
     "kr_decode_add_gqa_layer", "kr_decode_set_layer_moe", "kr_decode_set_layer_dense", "kr_decode_set_rope", "kr_decode_finalize",
     "kr_decode_set_state", "kr_decode_fill_state_synthetic", "kr_decode_get_state", "kr_decode_step", "kr_decode_generate_greedy",
-    "kr_decode_last_token", "kr_decode_set_use_graph", "kr_decode_read_buffer", "kr_decode_device_bytes",
+    "kr_decode_last_token", "kr_decode_set_use_graph", "kr_decode_read_buffer", "kr_decode_device_bytes", "kr_decode_profile_step",
 ]
 
 
@@ -105,6 +105,7 @@ def load_library() -> C.CDLL:
     lib.kr_decode_last_token.argtypes = [vp, C.POINTER(ci)]
     lib.kr_decode_set_use_graph.argtypes = [vp, ci]
     lib.kr_decode_read_buffer.argtypes = [vp, ci, vp, ci]
+    lib.kr_decode_profile_step.argtypes = [vp, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_long), ci]
     lib.kr_decode_device_bytes.argtypes = [vp]; lib.kr_decode_device_bytes.restype = C.c_size_t
     _lib = lib
     return lib

@@ -58,7 +58,20 @@ struct kr_decode_store {
     size_t weight_bytes = 0;
     // captured graph of one decode step
     hipGraphExec_t graph_exec = nullptr; bool graph_ok = false; bool use_graph = true;
+    // profiling pass (kr_decode_profile_step): HIP events around every launch, accumulated per kernel kind
+    bool prof = false; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0; std::vector<int> ev_kind;
 };
+
+enum { PK_EMBED = 0, PK_RMSNORM, PK_MATVEC, PK_LA_CONV, PK_LA_RECUR, PK_GATED_NORM, PK_GQA, PK_ROUTE_LOGITS, PK_ROUTE_SELECT, PK_MOE_W13,
+       PK_MOE_W2, PK_MOE_COMBINE, PK_LM_HEAD, PK_ARGMAX, PK_SHARED_GATE, PK_COUNT };
+
+static void prof_mark(kr_decode_store* s, int kind, hipStream_t st) {
+    if (!s->prof) return;
+    if (s->ev_used + 2 > s->ev_pool.size()) { for (int i = 0; i < 64; i++) { hipEvent_t e; (void)hipEventCreate(&e); s->ev_pool.push_back(e); } }
+    if (kind >= 0) s->ev_kind.push_back(kind);
+    (void)hipEventRecord(s->ev_pool[s->ev_used++], st);
+}
+#define PROF(kind, stmt) do { prof_mark(s, kind, st); stmt; prof_mark(s, -1, st); } while (0)
 
 static int chk_store(kr_decode_store* s) { return s ? KR_OK : kr_fail(KR_ERR_VALUE, "null decode store"); }
 static int chk_wid(kr_decode_store* s, int id, const char* what) {
@@ -396,30 +409,32 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
     const int H = s->hidden;
     float* hid = (float*)s->hid.p; float* res = (float*)s->res.p;
     const KrStep* step = (const KrStep*)s->step_dev.p;
-    kr_launch_embed((const float*)s->embedding.p, step, hid, H, st);
+    PROF(PK_EMBED, kr_launch_embed((const float*)s->embedding.p, step, hid, H, st));
     bool first = true;
     for (size_t li = 0; li < s->layers.size(); li++) {
         DLayer& L = s->layers[li];
-        kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st);
+        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st));
         first = false;
         if (L.attn == ATTN_LA) {
-            kr_launch_matvec(mv(s, L.qkvz_wid), hid, 1, (float*)s->proj_a.p, st);
-            kr_launch_matvec(mv(s, L.ba_wid), hid, 1, (float*)s->proj_b.p, st);
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.qkvz_wid), hid, 1, (float*)s->proj_a.p, st));
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.ba_wid), hid, 1, (float*)s->proj_b.p, st));
             KrLaArgs a{};
             a.qkvz = (const float*)s->proj_a.p; a.ba = (const float*)s->proj_b.p; a.conv_state = (float*)L.conv_state.p;
             a.conv_w = (const float*)L.conv_w.p; a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale;
             a.q = (float*)s->qbuf.p; a.k = (float*)s->kbuf.p; a.v = (float*)s->vbuf.p; a.z = (float*)s->zbuf.p; a.g = (float*)s->gbuf.p; a.beta = (float*)s->betabuf.p;
             a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
-            kr_launch_la_conv(a, st);
+            PROF(PK_LA_CONV, kr_launch_la_conv(a, st));
+            prof_mark(s, PK_LA_RECUR, st);
             if (kr_launch_la_recurrent((float*)L.recur_state.p, a.q, a.k, a.v, a.g, a.beta, (float*)s->recur_out.p, L.nv, L.dk, L.dv, st))
                 return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
-            kr_launch_gated_rmsnorm_silu((const float*)s->recur_out.p, a.z, (const float*)L.la_norm_w.p, (float*)s->attn_out.p, L.nv, L.dv, s->eps, st);
-            kr_launch_matvec(mv(s, L.out_wid), s->attn_out.p, 1, hid, st);
+            prof_mark(s, -1, st);
+            PROF(PK_GATED_NORM, kr_launch_gated_rmsnorm_silu((const float*)s->recur_out.p, a.z, (const float*)L.la_norm_w.p, (float*)s->attn_out.p, L.nv, L.dv, s->eps, st));
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->attn_out.p, 1, hid, st));
         } else if (L.attn == ATTN_GQA) {
             if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
-            kr_launch_matvec(mv(s, L.q_wid), hid, 1, (float*)s->proj_a.p, st);
-            kr_launch_matvec(mv(s, L.k_wid), hid, 1, (float*)s->kbuf.p, st);
-            kr_launch_matvec(mv(s, L.v_wid), hid, 1, (float*)s->vbuf.p, st);
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.q_wid), hid, 1, (float*)s->proj_a.p, st));
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.k_wid), hid, 1, (float*)s->kbuf.p, st));
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.v_wid), hid, 1, (float*)s->vbuf.p, st));
             KrGqaArgs a{};
             a.step = step; a.q_in = (const float*)s->proj_a.p; a.k_in = (const float*)s->kbuf.p; a.v_in = (const float*)s->vbuf.p;
             a.q_norm = L.q_norm_len ? (const float*)L.q_norm.p : nullptr; a.k_norm = L.k_norm_len ? (const float*)L.k_norm.p : nullptr;
@@ -427,18 +442,18 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.rope_cos = (const float*)s->rope_cos.p; a.rope_sin = (const float*)s->rope_sin.p; a.rope_half = s->rope_half;
             a.k_cache = (uint16_t*)L.kv_k.p; a.v_cache = (uint16_t*)L.kv_v.p; a.q_out = (float*)s->qbuf.p; a.gate = (float*)s->gatebuf.p;
             a.attn_out = (float*)s->attn_out.p; a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.eps = s->eps; a.sm_scale = L.sm_scale;
-            kr_launch_gqa(a, s->kv_max_seq, st);
-            kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st);
+            PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }
-        kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st);
+        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st));
         if (L.mlp == MLP_MOE) {
             Layer& EL = e->layers[L.moe_layer];
             if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
             if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
             const int E = e->r_ne, k = s->topk;
-            kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, hid, EL.has_bias ? (const float*)EL.bias.p : nullptr, (float*)s->r_logits.p, 1, E, H, st);
-            kr_launch_route_select((const float*)s->r_logits.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p, (float*)s->r_w.p, 1, E, k,
-                                   s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
+            PROF(PK_ROUTE_LOGITS, kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, hid, EL.has_bias ? (const float*)EL.bias.p : nullptr, (float*)s->r_logits.p, 1, E, H, st));
+            PROF(PK_ROUTE_SELECT, kr_launch_route_select((const float*)s->r_logits.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p, (float*)s->r_w.p, 1, E, k,
+                                   s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st));
             const bool has_shared = L.sgu_wid >= 0;
             KrMoeArgs a{};
             a.act = nullptr; a.act_f32 = hid; a.shared_decode = 1;
@@ -451,21 +466,21 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.gu = (float*)s->moe_gu.p; a.eo = (float*)s->moe_eo.p; a.out = nullptr; a.out_bf16 = 0;
             a.rsf = s->rsf; a.swiglu_limit = e->cfg.swiglu_limit; a.alpha = e->cfg.activation_alpha;
             a.act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
-            kr_launch_moe_w13(a, st);
-            if (has_shared && L.sg_wid >= 0) kr_launch_matvec(mv(s, L.sg_wid), hid, 1, (float*)s->gate_val.p, st);
-            kr_launch_moe_w2(a, st);
-            kr_launch_moe_combine_decode(a.eo, a.ids, a.wts, k, has_shared, (has_shared && L.sg_wid >= 0) ? (const float*)s->gate_val.p : nullptr, s->rsf, hid, H, st);
+            PROF(PK_MOE_W13, kr_launch_moe_w13(a, st));
+            if (has_shared && L.sg_wid >= 0) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), hid, 1, (float*)s->gate_val.p, st));
+            PROF(PK_MOE_W2, kr_launch_moe_w2(a, st));
+            PROF(PK_MOE_COMBINE, kr_launch_moe_combine_decode(a.eo, a.ids, a.wts, k, has_shared, (has_shared && L.sg_wid >= 0) ? (const float*)s->gate_val.p : nullptr, s->rsf, hid, H, st));
         } else if (L.mlp == MLP_DENSE) {
             // gate / up into [0,K) and [K,2K) of proj_a (K = padded intermediate), then down with the fused silu*up + quant prologue
             const int K = s->weights[L.down_wid]->cols;
-            kr_launch_matvec(mv(s, L.gate_wid), hid, 1, (float*)s->dense_gu.p, st);
-            kr_launch_matvec(mv(s, L.up_wid), hid, 1, (float*)s->dense_gu.p + K, st);
-            kr_launch_matvec(mv(s, L.down_wid), s->dense_gu.p, 1, hid, st, KR_ACT_SILU_MUL);
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.gate_wid), hid, 1, (float*)s->dense_gu.p, st));
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.up_wid), hid, 1, (float*)s->dense_gu.p + K, st));
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.down_wid), s->dense_gu.p, 1, hid, st, KR_ACT_SILU_MUL));
         }
     }
-    kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, 0, s->norm_bias_one, st);
-    kr_launch_matvec(mv(s, s->lm_head), hid, 1, (float*)s->logits.p, st);
-    kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, st);
+    PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, 0, s->norm_bias_one, st));
+    PROF(PK_LM_HEAD, kr_launch_matvec(mv(s, s->lm_head), hid, 1, (float*)s->logits.p, st));
+    PROF(PK_ARGMAX, kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, st));
     KR_HIP(hipGetLastError());
     return KR_OK;
 }
@@ -564,3 +579,23 @@ extern "C" int kr_decode_read_buffer(kr_decode_store* s, int which, float* out, 
 }
 
 extern "C" size_t kr_decode_device_bytes(const kr_decode_store* s) { return s ? s->weight_bytes + s->embedding.bytes : 0; }
+
+// One un-graphed decode step with HIP events around every launch (on the launch stream); returns per-kind totals for that step.
+extern "C" int kr_decode_profile_step(kr_decode_store* s, int token_id, int position, double* ms_by_kind, long* launches_by_kind, int n_kinds) {
+    if (int rc = need_cfg(s)) return rc;
+    if (n_kinds < PK_COUNT) return kr_fail(KR_ERR_VALUE, "need %d kinds", PK_COUNT);
+    KR_HIP(hipSetDevice(s->eng->device));
+    hipStream_t st = s->eng->stream;
+    const bool saved = s->use_graph;
+    s->use_graph = false; s->prof = true; s->ev_used = 0; s->ev_kind.clear();
+    const int rc = kr_decode_step(s, token_id, position, nullptr, st);
+    s->use_graph = saved; s->prof = false;
+    if (rc) return rc;
+    KR_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < n_kinds; i++) { ms_by_kind[i] = 0; launches_by_kind[i] = 0; }
+    for (size_t i = 0; i < s->ev_kind.size(); i++) {
+        float ms = 0; KR_HIP(hipEventElapsedTime(&ms, s->ev_pool[2 * i], s->ev_pool[2 * i + 1]));
+        ms_by_kind[s->ev_kind[i]] += ms; launches_by_kind[s->ev_kind[i]]++;
+    }
+    return KR_OK;
+}
