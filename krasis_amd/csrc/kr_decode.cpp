@@ -409,15 +409,21 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
     const int H = s->hidden;
     float* hid = (float*)s->hid.p; float* res = (float*)s->res.p;
     const KrStep* step = (const KrStep*)s->step_dev.p;
-    PROF(PK_EMBED, kr_launch_embed((const float*)s->embedding.p, step, hid, H, st));
+    // the value the next fused add+RMSNorm adds to the residual: embedding row, attention output, or the previous MoE epilogue
+    KrNormSrc src{}; src.mode = 1; src.emb = (const float*)s->embedding.p; src.step = step;
+    const KrNormSrc from_hidden{};  // mode 0
     bool first = true;
     for (size_t li = 0; li < s->layers.size(); li++) {
         DLayer& L = s->layers[li];
-        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st));
-        first = false;
+        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st));
+        first = false; src = from_hidden;
         if (L.attn == ATTN_LA) {
-            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.qkvz_wid), hid, 1, (float*)s->proj_a.p, st));
-            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.ba_wid), hid, 1, (float*)s->proj_b.p, st));
+            {
+                const KrMatDev mats[2] = {mv(s, L.qkvz_wid), mv(s, L.ba_wid)};
+                float* ys[2] = {(float*)s->proj_a.p, (float*)s->proj_b.p};
+                if (mats[0].bits == mats[1].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 2, hid, 1, st));
+                else { PROF(PK_MATVEC, kr_launch_matvec(mats[0], hid, 1, ys[0], st)); PROF(PK_MATVEC, kr_launch_matvec(mats[1], hid, 1, ys[1], st)); }
+            }
             KrLaArgs a{};
             a.qkvz = (const float*)s->proj_a.p; a.ba = (const float*)s->proj_b.p; a.conv_state = (float*)L.conv_state.p;
             a.conv_w = (const float*)L.conv_w.p; a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale;
@@ -425,16 +431,19 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
             PROF(PK_LA_CONV, kr_launch_la_conv(a, st));
             prof_mark(s, PK_LA_RECUR, st);
-            if (kr_launch_la_recurrent((float*)L.recur_state.p, a.q, a.k, a.v, a.g, a.beta, (float*)s->recur_out.p, L.nv, L.dk, L.dv, st))
+            if (kr_launch_la_recurrent_gnorm((float*)L.recur_state.p, a.q, a.k, a.v, a.g, a.beta, a.z, (const float*)L.la_norm_w.p, (float*)s->attn_out.p,
+                                             L.nv, L.dk, L.dv, s->eps, st))
                 return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
             prof_mark(s, -1, st);
-            PROF(PK_GATED_NORM, kr_launch_gated_rmsnorm_silu((const float*)s->recur_out.p, a.z, (const float*)L.la_norm_w.p, (float*)s->attn_out.p, L.nv, L.dv, s->eps, st));
             PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->attn_out.p, 1, hid, st));
         } else if (L.attn == ATTN_GQA) {
             if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
-            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.q_wid), hid, 1, (float*)s->proj_a.p, st));
-            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.k_wid), hid, 1, (float*)s->kbuf.p, st));
-            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.v_wid), hid, 1, (float*)s->vbuf.p, st));
+            {
+                const KrMatDev mats[3] = {mv(s, L.q_wid), mv(s, L.k_wid), mv(s, L.v_wid)};
+                float* ys[3] = {(float*)s->proj_a.p, (float*)s->kbuf.p, (float*)s->vbuf.p};
+                if (mats[0].bits == mats[1].bits && mats[0].bits == mats[2].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 3, hid, 1, st));
+                else for (int i = 0; i < 3; i++) PROF(PK_MATVEC, kr_launch_matvec(mats[i], hid, 1, ys[i], st));
+            }
             KrGqaArgs a{};
             a.step = step; a.q_in = (const float*)s->proj_a.p; a.k_in = (const float*)s->kbuf.p; a.v_in = (const float*)s->vbuf.p;
             a.q_norm = L.q_norm_len ? (const float*)L.q_norm.p : nullptr; a.k_norm = L.k_norm_len ? (const float*)L.k_norm.p : nullptr;
@@ -445,7 +454,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
             PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }
-        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st));
+        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st));
         if (L.mlp == MLP_MOE) {
             Layer& EL = e->layers[L.moe_layer];
             if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
@@ -455,6 +464,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             PROF(PK_ROUTE_SELECT, kr_launch_route_select((const float*)s->r_logits.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p, (float*)s->r_w.p, 1, E, k,
                                    s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st));
             const bool has_shared = L.sgu_wid >= 0;
+            const bool has_gate = has_shared && L.sg_wid >= 0;
             KrMoeArgs a{};
             a.act = nullptr; a.act_f32 = hid; a.shared_decode = 1;
             a.ids = (const int32_t*)s->r_ids.p; a.wts = (const float*)s->r_w.p;
@@ -466,19 +476,26 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.gu = (float*)s->moe_gu.p; a.eo = (float*)s->moe_eo.p; a.out = nullptr; a.out_bf16 = 0;
             a.rsf = s->rsf; a.swiglu_limit = e->cfg.swiglu_limit; a.alpha = e->cfg.activation_alpha;
             a.act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
+            // the shared expert's sigmoid-gate row rides in the shared slot's w13 launch when both are INT4
+            const bool fuse_gate = has_gate && a.w13.bits == 4 && a.sw13.bits == 4 && mv(s, L.sg_wid).bits == 4;
+            if (fuse_gate) { a.sgate = mv(s, L.sg_wid); a.gate_out = (float*)s->gate_val.p; }
             PROF(PK_MOE_W13, kr_launch_moe_w13(a, st));
-            if (has_shared && L.sg_wid >= 0) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), hid, 1, (float*)s->gate_val.p, st));
+            if (has_gate && !fuse_gate) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), hid, 1, (float*)s->gate_val.p, st));
             PROF(PK_MOE_W2, kr_launch_moe_w2(a, st));
-            PROF(PK_MOE_COMBINE, kr_launch_moe_combine_decode(a.eo, a.ids, a.wts, k, has_shared, (has_shared && L.sg_wid >= 0) ? (const float*)s->gate_val.p : nullptr, s->rsf, hid, H, st));
+            // epilogue (weighted sum, rsf, shared * sigmoid(gate)) is folded into the next fused add+RMSNorm
+            src = KrNormSrc{}; src.mode = 2; src.eo = a.eo; src.ids = a.ids; src.wts = a.wts; src.topk = k; src.has_shared = has_shared ? 1 : 0;
+            src.gate_val = has_gate ? (const float*)s->gate_val.p : nullptr; src.rsf = s->rsf;
         } else if (L.mlp == MLP_DENSE) {
-            // gate / up into [0,K) and [K,2K) of proj_a (K = padded intermediate), then down with the fused silu*up + quant prologue
+            // gate / up into [0,K) and [K,2K) of dense_gu (K = padded intermediate), then down with the fused silu*up + quant prologue
             const int K = s->weights[L.down_wid]->cols;
-            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.gate_wid), hid, 1, (float*)s->dense_gu.p, st));
-            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.up_wid), hid, 1, (float*)s->dense_gu.p + K, st));
+            const KrMatDev mats[2] = {mv(s, L.gate_wid), mv(s, L.up_wid)};
+            float* ys[2] = {(float*)s->dense_gu.p, (float*)s->dense_gu.p + K};
+            if (mats[0].bits == mats[1].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 2, hid, 1, st));
+            else { PROF(PK_MATVEC, kr_launch_matvec(mats[0], hid, 1, ys[0], st)); PROF(PK_MATVEC, kr_launch_matvec(mats[1], hid, 1, ys[1], st)); }
             PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.down_wid), s->dense_gu.p, 1, hid, st, KR_ACT_SILU_MUL));
         }
     }
-    PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(hid, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, 0, s->norm_bias_one, st));
+    PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st));
     PROF(PK_LM_HEAD, kr_launch_matvec(mv(s, s->lm_head), hid, 1, (float*)s->logits.p, st));
     PROF(PK_ARGMAX, kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, st));
     KR_HIP(hipGetLastError());

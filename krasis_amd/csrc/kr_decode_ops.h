@@ -20,10 +20,15 @@ struct KrGqaArgs {
 };
 
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s);
-void kr_launch_fused_add_rmsnorm(float* hidden, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s);
+struct KrNormSrc {   // where the value added to the residual comes from (see kr_fused_add_rmsnorm_kernel)
+    int mode;        // 0 hidden buffer, 1 embedding row of the current token, 2 MoE epilogue of the previous layer
+    const float* emb; const KrStep* step;
+    const float* eo; const int32_t* ids; const float* wts; int topk; int has_shared; const float* gate_val; float rsf;
+};
+void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s);
 void kr_launch_la_conv(const KrLaArgs& a, hipStream_t s);
-int kr_launch_la_recurrent(float* state, const float* q, const float* k, const float* v, const float* g, const float* beta, float* out,
-                           int nv, int dk, int dv, hipStream_t s);
+int kr_launch_la_recurrent_gnorm(float* state, const float* q, const float* k, const float* v, const float* g, const float* beta, const float* z,
+                                 const float* w, float* out, int nv, int dk, int dv, float eps, hipStream_t s);
 void kr_launch_gated_rmsnorm_silu(const float* recur, const float* z, const float* w, float* out, int nv, int dv, float eps, hipStream_t s);
 void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s);
 void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const float* wts, int topk, int has_shared, const float* gate_val,

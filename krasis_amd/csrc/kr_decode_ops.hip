@@ -39,13 +39,36 @@ __global__ void kr_embed_kernel(const float* __restrict__ emb, const KrStep* __r
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H; i += gridDim.x * blockDim.x) hidden[i] = emb[base + i];
 }
 
-// decode.rs:1199.  One workgroup.  hidden/residual are updated in place.
-__global__ void __launch_bounds__(256) kr_fused_add_rmsnorm_kernel(float* hidden, float* residual, const float* __restrict__ w,
+// decode.rs:1199.  One workgroup.  hidden/residual are updated in place.  The value added to the residual comes from
+//   src.mode 0: the hidden buffer (output of the attention out-projection),
+//   src.mode 1: the embedding row of the current token (decode.rs:2713-2717; first layer),
+//   src.mode 2: the MoE epilogue of the previous layer, hidden = moe (*rsf) + shared * sigmoid(gate) (decode.rs:3343-3402),
+// so the embedding copy and the MoE combine need no launch of their own.
+__device__ __forceinline__ float kr_norm_src(const KrNormSrc& src, const float* hidden, int i, int n, float sig) {
+    if (src.mode == 0) return hidden[i];
+    if (src.mode == 1) return src.emb[(size_t)src.step->token * n + i];
+    float acc = 0.0f;
+    for (int s = 0; s < src.topk; s++) {
+        if (src.ids[s] < 0) continue;
+        acc += src.wts[s] * src.eo[(size_t)s * n + i];
+    }
+    if (src.rsf != 1.0f) acc *= src.rsf;
+    if (src.has_shared) {
+        float sh = src.eo[(size_t)src.topk * n + i];
+        if (src.gate_val) sh *= sig;
+        acc = acc + sh;
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) kr_fused_add_rmsnorm_kernel(const KrNormSrc src, float* hidden, float* residual, const float* __restrict__ w,
                                                                   int n, float eps, int first, int bias_one) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* r = sm;  // [n]
+    const float sig = (src.mode == 2 && src.has_shared && src.gate_val) ? 1.0f / (1.0f + kr_expf(-src.gate_val[0])) : 1.0f;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const float v = first ? hidden[i] : (hidden[i] + residual[i]);
+        const float hv = kr_norm_src(src, hidden, i, n, sig);
+        const float v = first ? hv : (hv + residual[i]);
         r[i] = v; residual[i] = v;
     }
     __syncthreads();
@@ -116,33 +139,55 @@ __global__ void __launch_bounds__(256) kr_la_conv_kernel(const KrLaArgs a) {
     }
 }
 
-// decode.rs:1293.  grid (nv, dv/64), 64 threads: one thread per state column, whole column (dk <= 128) in registers.
+// decode.rs:1293 + decode.rs:3979 fused.  grid nv, dv threads (one thread per state column, one workgroup per value head):
+//   pass 1: kv[j] = sum_i fma(S[i][j]*e^g, k[i])  (chain over i), delta = (v - kv) * beta
+//   pass 2: S[i][j] = fma(k[i], delta, S[i][j]*e^g); o[j] = sum_i fma(S[i][j], q[i])
+// The decayed value is recomputed in pass 2 from the same operands (bit-identical), so a column never has to live in
+// registers; the second read of the 64 KiB head slice hits L2.  Then the head's gated RMSNorm runs in the same workgroup.
+#define KR_RB 32
 template <int DK>
-__global__ void __launch_bounds__(64) kr_la_recurrent_kernel(float* __restrict__ state, const float* __restrict__ q, const float* __restrict__ k,
-                                                            const float* __restrict__ v, const float* __restrict__ g,
-                                                            const float* __restrict__ beta, float* __restrict__ out, int dv) {
-    __shared__ float ks[DK], qs[DK];
-    const int h = blockIdx.x, j = blockIdx.y * 64 + threadIdx.x;
-    for (int i = threadIdx.x; i < DK; i += 64) { ks[i] = k[(size_t)h * DK + i]; qs[i] = q[(size_t)h * DK + i]; }
+__global__ void __launch_bounds__(256) kr_la_recurrent_gnorm_kernel(float* __restrict__ state, const float* __restrict__ q, const float* __restrict__ k,
+                                                                   const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ beta,
+                                                                   const float* __restrict__ z, const float* __restrict__ w, float* __restrict__ out,
+                                                                   int dv, float eps) {
+    __shared__ float ks[DK], qs[DK], r[256]; __shared__ float rms_s;
+    const int h = blockIdx.x, j = threadIdx.x;
+    for (int i = threadIdx.x; i < DK; i += blockDim.x) { ks[i] = k[(size_t)h * DK + i]; qs[i] = q[(size_t)h * DK + i]; }
     __syncthreads();
     const float g_exp = kr_expf(g[h]), beta_h = beta[h];
     float* S = state + (size_t)h * DK * dv + j;
-    float col[DK];
-#pragma unroll
-    for (int i = 0; i < DK; i++) col[i] = __builtin_nontemporal_load(S + (size_t)i * dv);
     float kv = 0.0f;
+    for (int i0 = 0; i0 < DK; i0 += KR_RB) {
+        float c[KR_RB];
 #pragma unroll
-    for (int i = 0; i < DK; i++) { col[i] = col[i] * g_exp; kv = __builtin_fmaf(col[i], ks[i], kv); }
+        for (int u = 0; u < KR_RB; u++) c[u] = S[(size_t)(i0 + u) * dv];
+#pragma unroll
+        for (int u = 0; u < KR_RB; u++) kv = __builtin_fmaf(c[u] * g_exp, ks[i0 + u], kv);
+    }
     const float delta = (v[(size_t)h * dv + j] - kv) * beta_h;
     float ob = 0.0f;
+    for (int i0 = 0; i0 < DK; i0 += KR_RB) {
+        float c[KR_RB];
 #pragma unroll
-    for (int i = 0; i < DK; i++) { col[i] = __builtin_fmaf(ks[i], delta, col[i]); ob = __builtin_fmaf(col[i], qs[i], ob); }
+        for (int u = 0; u < KR_RB; u++) c[u] = S[(size_t)(i0 + u) * dv];
 #pragma unroll
-    for (int i = 0; i < DK; i++) __builtin_nontemporal_store(col[i], S + (size_t)i * dv);
-    out[(size_t)h * dv + j] = ob;
+        for (int u = 0; u < KR_RB; u++) {
+            const float sn = __builtin_fmaf(ks[i0 + u], delta, c[u] * g_exp);
+            __builtin_nontemporal_store(sn, S + (size_t)(i0 + u) * dv);
+            ob = __builtin_fmaf(sn, qs[i0 + u], ob);
+        }
+    }
+    r[j] = ob;
+    __syncthreads();
+    if (j < 8) { const float ss = kr_sumsq_chain8(r, dv, j); if (j == 0) rms_s = 1.0f / sqrtf(ss / (float)dv + eps); }
+    __syncthreads();
+    const size_t o = (size_t)h * dv + j;
+    const float normed = (ob * rms_s) * w[o];
+    const float zz = z[o];
+    out[o] = (zz * kr_sigmoid_poly5(zz)) * normed;
 }
 
-// decode.rs:3979.  grid nv, dv threads (dv % 8 == 0, dv <= 256)
+// decode.rs:3979 (stand-alone form, kept for the per-op API gated_rmsnorm_silu, decode.rs:1062).  grid nv, dv threads
 __global__ void __launch_bounds__(256) kr_gated_rmsnorm_silu_kernel(const float* __restrict__ recur, const float* __restrict__ z,
                                                                    const float* __restrict__ w, float* __restrict__ out, int dv, float eps) {
     __shared__ float r[256]; __shared__ float rms_s;
@@ -299,18 +344,17 @@ __global__ void __launch_bounds__(1024) kr_argmax_kernel(const float* __restrict
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s) {
     hipLaunchKernelGGL(kr_embed_kernel, dim3((H + 255) / 256), dim3(256), 0, s, emb, st, hidden, H);
 }
-void kr_launch_fused_add_rmsnorm(float* hidden, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s) {
-    hipLaunchKernelGGL(kr_fused_add_rmsnorm_kernel, dim3(1), dim3(256), (size_t)(n + 4) * 4, s, hidden, residual, w, n, eps, first, bias_one);
+void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s) {
+    hipLaunchKernelGGL(kr_fused_add_rmsnorm_kernel, dim3(1), dim3(256), (size_t)(n + 4) * 4, s, src, hidden, residual, w, n, eps, first, bias_one);
 }
 void kr_launch_la_conv(const KrLaArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kr_la_conv_kernel, dim3(a.nk), dim3(256), (size_t)(2 * a.dk + 4) * 4, s, a);
 }
-int kr_launch_la_recurrent(float* state, const float* q, const float* k, const float* v, const float* g, const float* beta, float* out,
-                           int nv, int dk, int dv, hipStream_t s) {
-    if (dv % 64 != 0) return 1;
-    dim3 grid(nv, dv / 64);
-    if (dk == 128) hipLaunchKernelGGL(kr_la_recurrent_kernel<128>, grid, dim3(64), 0, s, state, q, k, v, g, beta, out, dv);
-    else if (dk == 64) hipLaunchKernelGGL(kr_la_recurrent_kernel<64>, grid, dim3(64), 0, s, state, q, k, v, g, beta, out, dv);
+int kr_launch_la_recurrent_gnorm(float* state, const float* q, const float* k, const float* v, const float* g, const float* beta, const float* z,
+                                 const float* w, float* out, int nv, int dk, int dv, float eps, hipStream_t s) {
+    if (dv > 256 || dv % 8 != 0) return 1;
+    if (dk == 128) hipLaunchKernelGGL(kr_la_recurrent_gnorm_kernel<128>, dim3(nv), dim3(dv), 0, s, state, q, k, v, g, beta, z, w, out, dv, eps);
+    else if (dk == 64) hipLaunchKernelGGL(kr_la_recurrent_gnorm_kernel<64>, dim3(nv), dim3(dv), 0, s, state, q, k, v, g, beta, z, w, out, dv, eps);
     else return 1;
     return 0;
 }

@@ -51,7 +51,12 @@ struct KrMoeArgs {
     int out_bf16;
     float rsf, swiglu_limit, alpha;
     int act_mode;
+    KrMatDev sgate;        // optional [H -> 1] sigmoid-gate row of the shared expert, evaluated by the shared slot's w13 launch
+    float* gate_out;       // [B]
 };
+
+#define KR_MAX_MULTI 4
+struct KrMultiMat { KrMatDev m[KR_MAX_MULTI]; float* y[KR_MAX_MULTI]; int tile_end[KR_MAX_MULTI]; int n; };
 
 void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st);
 void kr_launch_moe_w13(const KrMoeArgs& a, hipStream_t st);
@@ -61,6 +66,8 @@ void kr_launch_moe_combine(const KrMoeArgs& a, hipStream_t st);
 // generic single-matrix matvec: y[N] = W . quant(x[K]); x f32 or bf16; used for projections / lm_head
 // act_mode < 0: x[K] is quantized as is; otherwise x = [gate(K) | up(K)] and the kernel applies KR_ACT_* first (dense MLP)
 void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st, int act_mode = -1);
+// several matrices sharing one input vector (same K, same bits) in ONE launch
+void kr_launch_multi_matvec(const KrMatDev* mats, float* const* ys, int n, const void* x, int x_is_f32, hipStream_t st, int act_mode = -1);
 
 void kr_launch_fill_synth(void* q, size_t q_bytes, uint32_t* s, size_t s_words, uint64_t seed, hipStream_t st);
 void kr_launch_fill_uniform_f32(float* x, size_t n, float amp, uint64_t seed, hipStream_t st);

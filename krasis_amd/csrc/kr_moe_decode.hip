@@ -184,49 +184,46 @@ __device__ __forceinline__ float kr_chain(float acc, int isum, uint32_t sbits, f
     return fused ? __builtin_fmaf(gf, comb, acc) : (acc + gf * comb); // avx2.rs:1175 / :1201
 }
 
-#define KR_UNROLL 4
+#define KR_PRE 8   // group pairs (INT4) / groups (INT8) whose weights are fetched BEFORE the activation prologue runs
+
+// The first KR_PRE weight records of a tile are requested before the workgroup builds its activation image, so the HBM
+// latency of the stream overlaps the prologue (K = 2048 is covered entirely: 8 x 16 B per lane in flight).
+struct KrPre { u32x4 w[KR_PRE]; uint32_t sc[KR_PRE]; };
 
 template <int BITS>
-__device__ __forceinline__ float kr_matvec_tile(const void* qbase, const uint32_t* sbase, const KrMatDev& m, int tile,
+__device__ __forceinline__ void kr_preload(KrPre& p, const void* qbase, const uint32_t* sbase, const KrMatDev& m, int tile, int lane, int unit0) {
+    const int units = BITS == 4 ? m.ngp : m.ng;
+    const u32x4* q = reinterpret_cast<const u32x4*>(qbase) + (size_t)tile * units * 64 + lane;
+    const uint32_t* s = sbase + (size_t)tile * m.ngp * 8 + (lane >> 3);
+#pragma unroll
+    for (int u = 0; u < KR_PRE; u++)
+        if (unit0 + u < units) { p.w[u] = kr_ldg_nt(q + (size_t)(unit0 + u) * 64); p.sc[u] = kr_ldg_nt(s + (BITS == 4 ? (unit0 + u) : ((unit0 + u) >> 1)) * 8); }
+}
+
+template <int BITS>
+__device__ __forceinline__ float kr_matvec_tile(KrPre& p, bool preloaded, const void* qbase, const uint32_t* sbase, const KrMatDev& m, int tile,
                                                const KrActLds& L, int lane) {
     const int l8 = lane & 7, col = lane >> 3;
     const bool fused = (tile * 8 + col) < m.n_fma;
-    const uint32_t* s = sbase + (size_t)tile * m.ngp * 8 + col;
+    const int units = BITS == 4 ? m.ngp : m.ng;
     float acc = 0.0f;
-    if (BITS == 4) {
-        const u32x4* q = reinterpret_cast<const u32x4*>(qbase) + (size_t)tile * m.ngp * 64 + lane;
-        for (int gp0 = 0; gp0 < m.ngp; gp0 += KR_UNROLL) {
-            u32x4 w[KR_UNROLL]; uint32_t sc[KR_UNROLL];
+    for (int u0 = 0; u0 < units; u0 += KR_PRE) {
+        if (u0 > 0 || !preloaded) kr_preload<BITS>(p, qbase, sbase, m, tile, lane, u0);
 #pragma unroll
-            for (int u = 0; u < KR_UNROLL; u++)
-                if (gp0 + u < m.ngp) { w[u] = kr_ldg_nt(q + (size_t)(gp0 + u) * 64); sc[u] = kr_ldg_nt(s + (gp0 + u) * 8); }
-#pragma unroll
-            for (int u = 0; u < KR_UNROLL; u++) {
-                const int gp = gp0 + u;
-                if (gp < m.ngp) {
-                    const int g0 = 2 * gp, g1 = g0 + 1;
-                    int i0 = kr_red8_add_i32(kr_group_i4(w[u].x, w[u].y, g0, l8, L));
-                    acc = kr_chain(acc, i0, sc[u] & 0xFFFFu, L.ascale[g0], fused);
+        for (int u = 0; u < KR_PRE; u++) {
+            const int un = u0 + u;
+            if (un < units) {
+                if (BITS == 4) {
+                    const int g0 = 2 * un, g1 = g0 + 1;
+                    const int i0 = kr_red8_add_i32(kr_group_i4(p.w[u].x, p.w[u].y, g0, l8, L));
+                    acc = kr_chain(acc, i0, p.sc[u] & 0xFFFFu, L.ascale[g0], fused);
                     if (g1 < m.ng) {
-                        int i1 = kr_red8_add_i32(kr_group_i4(w[u].z, w[u].w, g1, l8, L));
-                        acc = kr_chain(acc, i1, sc[u] >> 16, L.ascale[g1], fused);
+                        const int i1 = kr_red8_add_i32(kr_group_i4(p.w[u].z, p.w[u].w, g1, l8, L));
+                        acc = kr_chain(acc, i1, p.sc[u] >> 16, L.ascale[g1], fused);
                     }
-                }
-            }
-        }
-    } else {
-        const u32x4* q = reinterpret_cast<const u32x4*>(qbase) + (size_t)tile * m.ng * 64 + lane;
-        for (int g0 = 0; g0 < m.ng; g0 += KR_UNROLL) {
-            u32x4 w[KR_UNROLL]; uint32_t sc[KR_UNROLL];
-#pragma unroll
-            for (int u = 0; u < KR_UNROLL; u++)
-                if (g0 + u < m.ng) { w[u] = kr_ldg_nt(q + (size_t)(g0 + u) * 64); sc[u] = kr_ldg_nt(s + ((g0 + u) >> 1) * 8); }
-#pragma unroll
-            for (int u = 0; u < KR_UNROLL; u++) {
-                const int g = g0 + u;
-                if (g < m.ng) {
-                    int i0 = kr_red8_add_i32(kr_group_i8(w[u], g, l8, L));
-                    acc = kr_chain(acc, i0, (g & 1) ? (sc[u] >> 16) : (sc[u] & 0xFFFFu), L.ascale[g], fused);
+                } else {
+                    const int i0 = kr_red8_add_i32(kr_group_i8(p.w[u], un, l8, L));
+                    acc = kr_chain(acc, i0, (un & 1) ? (p.sc[u] >> 16) : (p.sc[u] & 0xFFFFu), L.ascale[un], fused);
                 }
             }
         }
@@ -261,6 +258,7 @@ __device__ __forceinline__ KrSlot kr_resolve_slot(const KrMoeArgs& a, int b, int
 }
 
 // stage 1: gu[b][slot][0..2I) = W13 . q(act[b])      grid = (tile groups, n_slots, B)
+// The shared slot may carry one extra tile: the shared expert's sigmoid-gate row (decode.rs:3379-3390), N = 1.
 template <int BITS>
 __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a, int tiles_per_wave) {
     const int slot = blockIdx.y, b = blockIdx.z;
@@ -268,20 +266,30 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a,
     if (!sl.valid) return;
     const KrMatDev& m = sl.shared ? a.sw13 : a.w13;
     const int ntiles = (m.N + 7) / 8;
+    const bool with_gate = sl.shared && a.sgate.q != nullptr;
     const int tile0 = (blockIdx.x * KR_WAVES) * tiles_per_wave;
-    if (tile0 >= ntiles) return;
+    if (tile0 >= ntiles + (with_gate ? 1 : 0)) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int first = tile0 + wave * tiles_per_wave;
+    KrPre pre;
+    const bool gate_wave = with_gate && first == ntiles;
+    if (first < ntiles) kr_preload<BITS>(pre, sl.q13, sl.s13, m, first, lane, 0);
+    else if (gate_wave) kr_preload<4>(pre, a.sgate.q, a.sgate.s, a.sgate, 0, lane, 0);
     const KrActLds L = kr_carve_lds(kr_smem, a.H, BITS == 8);
     if (a.act_f32) kr_prologue_quant_f32<BITS == 8>(a.act_f32 + (size_t)b * a.H, a.H, L, !(sl.shared && a.shared_decode));
     else kr_prologue_quant<uint16_t, BITS == 8>(a.act + (size_t)b * a.H, a.H, L);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
     for (int t = 0; t < tiles_per_wave; t++) {
-        const int tile = tile0 + wave * tiles_per_wave + t;
-        if (tile >= ntiles) break;
-        const float acc = kr_matvec_tile<BITS>(sl.q13, sl.s13, m, tile, L, lane);
-        const int col = tile * 8 + (lane >> 3);
-        if ((lane & 7) == 0 && col < m.N) gu[col] = acc;
+        const int tile = first + t;
+        if (tile < ntiles) {
+            const float acc = kr_matvec_tile<BITS>(pre, t == 0, sl.q13, sl.s13, m, tile, L, lane);
+            const int col = tile * 8 + (lane >> 3);
+            if ((lane & 7) == 0 && col < m.N) gu[col] = acc;
+        } else if (with_gate && tile == ntiles) {
+            const float acc = kr_matvec_tile<4>(pre, t == 0, a.sgate.q, a.sgate.s, a.sgate, 0, L, lane);
+            if (lane == 0) a.gate_out[b] = acc;
+        }
     }
 }
 
@@ -295,17 +303,20 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w2_kernel(const KrMoeArgs a, 
     const int ntiles = (m.N + 7) / 8;
     const int tile0 = (blockIdx.x * KR_WAVES) * tiles_per_wave;
     if (tile0 >= ntiles) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int first = tile0 + wave * tiles_per_wave;
+    KrPre pre;
+    if (first < ntiles) kr_preload<BITS>(pre, sl.q2, sl.s2, m, first, lane, 0);
     const KrActLds L = kr_carve_lds(kr_smem, sl.inter, BITS == 8);
     const float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
     if (sl.shared && a.shared_decode) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(gu, sl.inter, a.swiglu_limit, a.alpha, L);
     else kr_prologue_hidden<ACT, BITS == 8>(gu, sl.inter, a.swiglu_limit, a.alpha, L);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* eo = a.eo + ((size_t)b * a.n_slots + slot) * a.H;
     for (int t = 0; t < tiles_per_wave; t++) {
-        const int tile = tile0 + wave * tiles_per_wave + t;
+        const int tile = first + t;
         if (tile >= ntiles) break;
-        const float acc = kr_matvec_tile<BITS>(sl.q2, sl.s2, m, tile, L, lane);
+        const float acc = kr_matvec_tile<BITS>(pre, t == 0, sl.q2, sl.s2, m, tile, L, lane);
         const int col = tile * 8 + (lane >> 3);
         if ((lane & 7) == 0 && col < m.N) eo[col] = acc;
     }
@@ -328,22 +339,33 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_combine_kernel(const KrMoeArg
     else reinterpret_cast<float*>(a.out)[(size_t)b * a.H + j] = acc;
 }
 
+// y_i[N_i] = W_i . quant(x[K]) for up to KR_MAX_MULTI matrices that share the same input vector (q|k|v, qkvz|ba, ...):
+// one launch, one activation prologue per workgroup, tiles of all matrices in one grid.
 template <typename T, int BITS>
-__global__ void __launch_bounds__(KR_BLOCK) kr_matvec_kernel(const KrMatDev m, const T* x, float* y, int tiles_per_wave, int act_mode) {
-    const int ntiles = (m.N + 7) / 8;
+__global__ void __launch_bounds__(KR_BLOCK) kr_matvec_kernel(const KrMultiMat mm, const T* x, int tiles_per_wave, int act_mode) {
+    const int total = mm.tile_end[mm.n - 1];
     const int tile0 = (blockIdx.x * KR_WAVES) * tiles_per_wave;
-    if (tile0 >= ntiles) return;
-    const KrActLds L = kr_carve_lds(kr_smem, m.ng * 128, BITS == 8);
-    if (act_mode == KR_ACT_SILU_MUL) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(reinterpret_cast<const float*>(x), m.ng * 128, 0.0f, 0.0f, L);
-    else kr_prologue_quant<T, BITS == 8>(x, m.ng * 128, L);
-    __syncthreads();
+    if (tile0 >= total) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int first = tile0 + wave * tiles_per_wave;
+    int mi = 0;
+    while (mi + 1 < mm.n && first >= mm.tile_end[mi]) mi++;
+    KrPre pre;
+    if (first < total) kr_preload<BITS>(pre, mm.m[mi].q, mm.m[mi].s, mm.m[mi], first - (mi ? mm.tile_end[mi - 1] : 0), lane, 0);
+    const int K = mm.m[0].ng * 128;
+    const KrActLds L = kr_carve_lds(kr_smem, K, BITS == 8);
+    if (act_mode == KR_ACT_SILU_MUL) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(reinterpret_cast<const float*>(x), K, 0.0f, 0.0f, L);
+    else kr_prologue_quant<T, BITS == 8>(x, K, L);
+    __syncthreads();
     for (int t = 0; t < tiles_per_wave; t++) {
-        const int tile = tile0 + wave * tiles_per_wave + t;
-        if (tile >= ntiles) break;
-        const float acc = kr_matvec_tile<BITS>(m.q, m.s, m, tile, L, lane);
+        const int gt = first + t;
+        if (gt >= total) break;
+        while (mi + 1 < mm.n && gt >= mm.tile_end[mi]) mi++;
+        const KrMatDev& m = mm.m[mi];
+        const int tile = gt - (mi ? mm.tile_end[mi - 1] : 0);
+        const float acc = kr_matvec_tile<BITS>(pre, t == 0, m.q, m.s, m, tile, L, lane);
         const int col = tile * 8 + (lane >> 3);
-        if ((lane & 7) == 0 && col < m.N) y[col] = acc;
+        if ((lane & 7) == 0 && col < m.N) mm.y[mi][col] = acc;
     }
 }
 
@@ -361,7 +383,7 @@ static int kr_pick_tpw(int K, int ntiles) {
 void kr_launch_moe_w13(const KrMoeArgs& a, hipStream_t st) {
     const bool has_shared = a.n_slots > a.topk;
     int nt = (a.w13.N + 7) / 8;
-    if (has_shared && (a.sw13.N + 7) / 8 > nt) nt = (a.sw13.N + 7) / 8;
+    if (has_shared && (a.sw13.N + 7) / 8 + (a.sgate.q ? 1 : 0) > nt) nt = (a.sw13.N + 7) / 8 + (a.sgate.q ? 1 : 0);
     const int tpw = kr_pick_tpw(a.H, nt);
     dim3 grid((nt + KR_WAVES * tpw - 1) / (KR_WAVES * tpw), a.n_slots, a.B);
     const size_t lds = kr_lds_bytes(a.H, a.w13.bits == 8);
@@ -400,18 +422,26 @@ void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st) {
     kr_launch_moe_combine(a, st);
 }
 
-void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st, int act_mode) {
-    const int nt = (m.N + 7) / 8;
-    const int tpw = kr_pick_tpw(m.K, nt);
-    dim3 grid((nt + KR_WAVES * tpw - 1) / (KR_WAVES * tpw));
-    const size_t lds = kr_lds_bytes(m.ng * 128, m.bits == 8);
+void kr_launch_multi_matvec(const KrMatDev* mats, float* const* ys, int n, const void* x, int x_is_f32, hipStream_t st, int act_mode) {
+    KrMultiMat mm{};
+    mm.n = n;
+    int total = 0;
+    for (int i = 0; i < n; i++) { mm.m[i] = mats[i]; mm.y[i] = ys[i]; total += (mats[i].N + 7) / 8; mm.tile_end[i] = total; }
+    const int tpw = kr_pick_tpw(mats[0].K, total);
+    dim3 grid((total + KR_WAVES * tpw - 1) / (KR_WAVES * tpw));
+    const int bits = mats[0].bits;
+    const size_t lds = kr_lds_bytes(mats[0].ng * 128, bits == 8);
     if (x_is_f32) {
-        if (m.bits == 4) hipLaunchKernelGGL((kr_matvec_kernel<float, 4>), grid, dim3(KR_BLOCK), lds, st, m, (const float*)x, y, tpw, act_mode);
-        else hipLaunchKernelGGL((kr_matvec_kernel<float, 8>), grid, dim3(KR_BLOCK), lds, st, m, (const float*)x, y, tpw, act_mode);
+        if (bits == 4) hipLaunchKernelGGL((kr_matvec_kernel<float, 4>), grid, dim3(KR_BLOCK), lds, st, mm, (const float*)x, tpw, act_mode);
+        else hipLaunchKernelGGL((kr_matvec_kernel<float, 8>), grid, dim3(KR_BLOCK), lds, st, mm, (const float*)x, tpw, act_mode);
     } else {
-        if (m.bits == 4) hipLaunchKernelGGL((kr_matvec_kernel<uint16_t, 4>), grid, dim3(KR_BLOCK), lds, st, m, (const uint16_t*)x, y, tpw, act_mode);
-        else hipLaunchKernelGGL((kr_matvec_kernel<uint16_t, 8>), grid, dim3(KR_BLOCK), lds, st, m, (const uint16_t*)x, y, tpw, act_mode);
+        if (bits == 4) hipLaunchKernelGGL((kr_matvec_kernel<uint16_t, 4>), grid, dim3(KR_BLOCK), lds, st, mm, (const uint16_t*)x, tpw, act_mode);
+        else hipLaunchKernelGGL((kr_matvec_kernel<uint16_t, 8>), grid, dim3(KR_BLOCK), lds, st, mm, (const uint16_t*)x, tpw, act_mode);
     }
+}
+
+void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st, int act_mode) {
+    kr_launch_multi_matvec(&m, &y, 1, x, x_is_f32, st, act_mode);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -160,25 +160,49 @@ __device__ void kr_topk_heap_serial(const float* v, int n, int k, float* hv, int
     for (int i = 0; i < k; i++) out[i] = hi[i];
 }
 
-// wave-parallel selection of the first (k+1) elements in (value desc, index asc) order.
-// sel lives in LDS; returns picks in pv/pi (LDS, k+1 entries).
-__device__ void kr_topk_wave(const float* sel, int n, int kp1, float* pv, int* pi) {
+// ---- wave-wide (value desc, index asc) arg-best over 64 lanes: DPP inside 16-lane rows, readlane across rows ----
+struct KrKey { float v; int i; };   // i == 0x7FFFFFFF marks "empty"
+__device__ __forceinline__ KrKey kr_key_best(KrKey a, KrKey b) {
+    const bool take_b = (b.i != 0x7FFFFFFF) && (a.i == 0x7FFFFFFF || kr_better(b.v, b.i, a.v, a.i));
+    return take_b ? b : a;
+}
+__device__ __forceinline__ KrKey kr_key_dpp(KrKey a, const int ctrl_sel) {
+    KrKey o;
+    switch (ctrl_sel) {
+        case 0: o.v = __int_as_float(KR_DPP(__float_as_int(a.v), KR_DPP_XOR1)); o.i = KR_DPP(a.i, KR_DPP_XOR1); break;
+        case 1: o.v = __int_as_float(KR_DPP(__float_as_int(a.v), KR_DPP_XOR2)); o.i = KR_DPP(a.i, KR_DPP_XOR2); break;
+        case 2: o.v = __int_as_float(KR_DPP(__float_as_int(a.v), KR_DPP_HALF_MIRROR)); o.i = KR_DPP(a.i, KR_DPP_HALF_MIRROR); break;
+        default: o.v = __int_as_float(KR_DPP(__float_as_int(a.v), KR_DPP_MIRROR)); o.i = KR_DPP(a.i, KR_DPP_MIRROR); break;
+    }
+    return o;
+}
+__device__ __forceinline__ KrKey kr_wave_best(KrKey k) {
+    k = kr_key_best(k, kr_key_dpp(k, 0));
+    k = kr_key_best(k, kr_key_dpp(k, 1));
+    k = kr_key_best(k, kr_key_dpp(k, 2));
+    k = kr_key_best(k, kr_key_dpp(k, 3));   // every lane of a 16-lane row now holds the row's best
+    KrKey r0{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(k.v), 0)), __builtin_amdgcn_readlane(k.i, 0)};
+    KrKey r1{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(k.v), 16)), __builtin_amdgcn_readlane(k.i, 16)};
+    KrKey r2{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(k.v), 32)), __builtin_amdgcn_readlane(k.i, 32)};
+    KrKey r3{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(k.v), 48)), __builtin_amdgcn_readlane(k.i, 48)};
+    return kr_key_best(kr_key_best(r0, r1), kr_key_best(r2, r3));
+}
+
+// first kp1 elements in (value desc, index asc) order; element e lives in lane e%64, slot e/64 (registers)
+template <int NV>
+__device__ __forceinline__ void kr_topk_wave_reg(const float (&val)[NV], int n, int kp1, float* pv, int* pi) {
     const int lane = threadIdx.x & 63;
-    uint64_t taken = 0;  // bit i <-> element lane + 64*i  (n <= 4096)
+    uint32_t taken = 0;
     for (int t = 0; t < kp1; t++) {
-        float bv = -__builtin_inff(); int bi = 0x7FFFFFFF;
-        for (int i = 0, e = lane; e < n; i++, e += 64) {
-            if ((taken >> i) & 1) continue;
-            const float v = sel[e];
-            if (bi == 0x7FFFFFFF || kr_better(v, e, bv, bi)) { bv = v; bi = e; }
-        }
+        KrKey best{0.0f, 0x7FFFFFFF};
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(bv, off); const int oi = __shfl_xor(bi, off);
-            if (oi != 0x7FFFFFFF && (bi == 0x7FFFFFFF || kr_better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+        for (int i = 0; i < NV; i++) {
+            const int e = i * 64 + lane;
+            if (e < n && !((taken >> i) & 1)) best = kr_key_best(best, KrKey{val[i], e});
         }
-        if (bi != 0x7FFFFFFF && (bi & 63) == lane) taken |= 1ull << (bi >> 6);
-        if (lane == 0) { pv[t] = bv; pi[t] = bi; }
+        const KrKey w = kr_wave_best(best);
+        if (w.i != 0x7FFFFFFF && (w.i & 63) == lane) taken |= 1u << (w.i >> 6);
+        if (lane == 0) { pv[t] = w.v; pi[t] = w.i; }
     }
 }
 
@@ -190,58 +214,73 @@ struct KrRouteSelArgs {
     int gptoss;           // rule ENGINE: swiglu_limit > 0 branch (moe.rs:3101)
 };
 
-__global__ void __launch_bounds__(64) kr_route_select_kernel(const KrRouteSelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* scores = sm;           // [E]
-    float* sel = sm + a.E;        // [E]
-    float* pv = sel + a.E;        // [33]
-    int* pi = reinterpret_cast<int*>(pv + 33);  // [33]
+// strictly sequential f32 sum of x[0..n) (reference order), register-batched so LDS latency is paid once per 16 values
+__device__ __forceinline__ float kr_seq_sum(const float* x, int n) {
+    float s = 0.0f; int e = 0;
+    for (; e + 16 <= n; e += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = x[e + u];
+#pragma unroll
+        for (int u = 0; u < 16; u++) s += v[u];
+    }
+    for (; e < n; e++) s += x[e];
+    return s;
+}
+
+template <int NV>
+__device__ __forceinline__ void kr_route_select_body(const KrRouteSelArgs& a, const float* lg, int32_t* ids, float* w, float* sm) {
+    float* scores = sm;            // [E]
+    float* sel = sm + a.E;         // [E]   (serial tie fallback only)
+    float* pv = sel + a.E;         // [33]
+    int* pi = reinterpret_cast<int*>(pv + 33);      // [33]
     float* hv = reinterpret_cast<float*>(pi + 33);  // [32]
     int* hi = reinterpret_cast<int*>(hv + 32);      // [32]
     float* red = reinterpret_cast<float*>(hi + 32); // [2]
-    const int lane = threadIdx.x, E = a.E, k = a.topk;
-    const int m = blockIdx.x;
-    const float* lg = a.logits + (size_t)m * E;
+    const int lane = threadIdx.x & 63, E = a.E, k = a.topk;
     const bool decode = a.rule == 1;
     const bool raw_topk = decode ? (a.scoring == 2) : (a.gptoss != 0);
-
+    float sc[NV], sl[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; sc[i] = e < E ? lg[e] : 0.0f; }
     if (raw_topk) {
-        // top-k on raw logits (+bias for the engine's GPT-OSS branch), softmax over the selected (decode.rs:4171, moe.rs:3101)
-        for (int e = lane; e < E; e += 64) { const float v = lg[e] + ((!decode && a.esc) ? a.esc[e] : 0.0f); scores[e] = v; sel[e] = v; }
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; if (e < E && !decode && a.esc) sc[i] += a.esc[e]; }
     } else if (a.scoring == 0) {
         const int e8 = (E / 8) * 8;
-        for (int e = lane; e < E; e += 64) {
-            const float l = lg[e];
-            scores[e] = (decode && e < e8) ? kr_sigmoid_poly4(l) : 1.0f / (1.0f + kr_expf(-l));
-        }
-    } else {
-        // softmax: max (exact), exp, sequential sum in index order (decode.rs:4154-4158, moe.rs:3198-3206)
-        float mx = -__builtin_inff();
-        for (int e = lane; e < E; e += 64) mx = fmaxf(mx, lg[e]);
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        for (int e = lane; e < E; e += 64) scores[e] = kr_expf(lg[e] - mx);
+        for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; if (e < E) sc[i] = (decode && e < e8) ? kr_sigmoid_poly4(sc[i]) : 1.0f / (1.0f + kr_expf(-sc[i])); }
+    } else {
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; if (e < E) mx = fmaxf(mx, sc[i]); }
+        mx = kr_red16_max_f32(mx);
+        mx = fmaxf(fmaxf(__shfl(mx, 0), __shfl(mx, 16)), fmaxf(__shfl(mx, 32), __shfl(mx, 48)));
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; if (e < E) { sc[i] = kr_expf(sc[i] - mx); scores[e] = sc[i]; } }
         __syncthreads();
-        if (lane == 0) { float s = 0.0f; for (int e = 0; e < E; e++) s += scores[e]; red[0] = s; }
+        if (lane == 0) red[0] = kr_seq_sum(scores, E);   // decode.rs:4156 / moe.rs:3201: sum in index order
         __syncthreads();
         const float se = red[0];
-        if (decode) { const float inv = 1.0f / se; for (int e = lane; e < E; e += 64) scores[e] *= inv; }
-        else { for (int e = lane; e < E; e += 64) scores[e] /= se; }
+        if (decode) { const float inv = 1.0f / se;
+#pragma unroll
+            for (int i = 0; i < NV; i++) sc[i] *= inv; }
+        else {
+#pragma unroll
+            for (int i = 0; i < NV; i++) sc[i] /= se; }
     }
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int e = i * 64 + lane;
+        sl[i] = (!raw_topk && a.esc && e < E) ? sc[i] + a.esc[e] : sc[i];
+        if (e < E) { scores[e] = sc[i]; sel[e] = sl[i]; }
+    }
+    const int np = k + 1 <= E ? k + 1 : k;
+    kr_topk_wave_reg<NV>(sl, E, np, pv, pi);
     __syncthreads();
-    if (!raw_topk) for (int e = lane; e < E; e += 64) sel[e] = a.esc ? scores[e] + a.esc[e] : scores[e];
-    __syncthreads();
-
-    kr_topk_wave(sel, E, k + 1 <= E ? k + 1 : k, pv, pi);
-    __syncthreads();
-    int32_t* ids = a.ids + (size_t)m * k;
-    float* w = a.w + (size_t)m * k;
     if (lane == 0) {
         bool tie = false;
-        if (decode) {
-            const int np = k + 1 <= E ? k + 1 : k;
-            for (int i = 0; i + 1 < np; i++) tie |= (pv[i] == pv[i + 1]);
-        }
+        if (decode) for (int i = 0; i + 1 < np; i++) tie |= (pv[i] == pv[i + 1]);
         if (tie) kr_topk_heap_serial(sel, E, k, hv, hi, ids);  // heap order governs ties (decode.rs:1531)
         else for (int i = 0; i < k; i++) ids[i] = pi[i];       // engine rule: lowest index wins == (value desc, index asc)
         if (raw_topk) {
@@ -260,6 +299,21 @@ __global__ void __launch_bounds__(64) kr_route_select_kernel(const KrRouteSelArg
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(64) kr_route_select_kernel(const KrRouteSelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int m = blockIdx.x;
+    const float* lg = a.logits + (size_t)m * a.E;
+    int32_t* ids = a.ids + (size_t)m * a.topk;
+    float* w = a.w + (size_t)m * a.topk;
+    const int nv = (a.E + 63) / 64;
+    if (nv <= 1) kr_route_select_body<1>(a, lg, ids, w, sm);
+    else if (nv <= 2) kr_route_select_body<2>(a, lg, ids, w, sm);
+    else if (nv <= 4) kr_route_select_body<4>(a, lg, ids, w, sm);
+    else if (nv <= 8) kr_route_select_body<8>(a, lg, ids, w, sm);
+    else if (nv <= 16) kr_route_select_body<16>(a, lg, ids, w, sm);
+    else kr_route_select_body<32>(a, lg, ids, w, sm);
 }
 
 // ------------------------------------------------------------------------------------------
