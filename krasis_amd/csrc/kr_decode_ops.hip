@@ -44,30 +44,39 @@ __global__ void kr_embed_kernel(const float* __restrict__ emb, const KrStep* __r
 //   src.mode 1: the embedding row of the current token (decode.rs:2713-2717; first layer),
 //   src.mode 2: the MoE epilogue of the previous layer, hidden = moe (*rsf) + shared * sigmoid(gate) (decode.rs:3343-3402),
 // so the embedding copy and the MoE combine need no launch of their own.
-__device__ __forceinline__ float kr_norm_src(const KrNormSrc& src, const float* hidden, int i, int n, float sig) {
-    if (src.mode == 0) return hidden[i];
-    if (src.mode == 1) return src.emb[(size_t)src.step->token * n + i];
-    float acc = 0.0f;
-    for (int s = 0; s < src.topk; s++) {
-        if (src.ids[s] < 0) continue;
-        acc += src.wts[s] * src.eo[(size_t)s * n + i];
-    }
-    if (src.rsf != 1.0f) acc *= src.rsf;
-    if (src.has_shared) {
-        float sh = src.eo[(size_t)src.topk * n + i];
-        if (src.gate_val) sh *= sig;
-        acc = acc + sh;
-    }
-    return acc;
-}
-
-__global__ void __launch_bounds__(256) kr_fused_add_rmsnorm_kernel(const KrNormSrc src, float* hidden, float* residual, const float* __restrict__ w,
-                                                                  int n, float eps, int first, int bias_one) {
+#define KR_NORM_THREADS 1024
+__global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(const KrNormSrc src, float* hidden, float* residual, const float* __restrict__ w,
+                                                                              int n, float eps, int first, int bias_one) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* r = sm;  // [n]
-    const float sig = (src.mode == 2 && src.has_shared && src.gate_val) ? 1.0f / (1.0f + kr_expf(-src.gate_val[0])) : 1.0f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float hv = kr_norm_src(src, hidden, i, n, sig);
+    float* r = sm;                       // [n]
+    __shared__ float s_w[32]; __shared__ int s_id[32]; __shared__ float s_sig;
+    if (src.mode == 2) {
+        if (threadIdx.x < src.topk) { s_w[threadIdx.x] = src.wts[threadIdx.x]; s_id[threadIdx.x] = src.ids[threadIdx.x]; }
+        if (threadIdx.x == 32) s_sig = (src.has_shared && src.gate_val) ? 1.0f / (1.0f + kr_expf(-src.gate_val[0])) : 1.0f;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += KR_NORM_THREADS) {
+        float hv;
+        if (src.mode == 0) hv = hidden[i];
+        else if (src.mode == 1) hv = src.emb[(size_t)src.step->token * n + i];
+        else {
+            // MoE epilogue: sum_i w_i * eo_i in routing order (moe.rs:661-667), *rsf, + shared * sigmoid(gate)
+            float acc = 0.0f;
+            for (int s0 = 0; s0 < src.topk; s0 += 8) {
+                float e[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) e[u] = (s0 + u < src.topk) ? src.eo[(size_t)(s0 + u) * n + i] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (s0 + u < src.topk && s_id[s0 + u] >= 0) acc += s_w[s0 + u] * e[u];
+            }
+            if (src.rsf != 1.0f) acc *= src.rsf;
+            if (src.has_shared) {
+                float sh = src.eo[(size_t)src.topk * n + i];
+                if (src.gate_val) sh *= s_sig;
+                acc = acc + sh;
+            }
+            hv = acc;
+        }
         const float v = first ? hv : (hv + residual[i]);
         r[i] = v; residual[i] = v;
     }
@@ -81,7 +90,7 @@ __global__ void __launch_bounds__(256) kr_fused_add_rmsnorm_kernel(const KrNormS
     }
     __syncthreads();
     const float rms = sm[n];
-    for (int i = threadIdx.x; i < n; i += 256) hidden[i] = (r[i] * rms) * (bias_one ? (w[i] + 1.0f) : w[i]);
+    for (int i = threadIdx.x; i < n; i += KR_NORM_THREADS) hidden[i] = (r[i] * rms) * (bias_one ? (w[i] + 1.0f) : w[i]);
 }
 
 // decode.rs:3815-3903 for kernel_dim == 4; one workgroup per key head.
@@ -345,7 +354,7 @@ void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, h
     hipLaunchKernelGGL(kr_embed_kernel, dim3((H + 255) / 256), dim3(256), 0, s, emb, st, hidden, H);
 }
 void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s) {
-    hipLaunchKernelGGL(kr_fused_add_rmsnorm_kernel, dim3(1), dim3(256), (size_t)(n + 4) * 4, s, src, hidden, residual, w, n, eps, first, bias_one);
+    hipLaunchKernelGGL(kr_fused_add_rmsnorm_kernel, dim3(1), dim3(KR_NORM_THREADS), (size_t)(n + 4) * 4, s, src, hidden, residual, w, n, eps, first, bias_one);
 }
 void kr_launch_la_conv(const KrLaArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kr_la_conv_kernel, dim3(a.nk), dim3(256), (size_t)(2 * a.dk + 4) * 4, s, a);

@@ -160,49 +160,49 @@ __device__ void kr_topk_heap_serial(const float* v, int n, int k, float* hv, int
     for (int i = 0; i < k; i++) out[i] = hi[i];
 }
 
-// ---- wave-wide (value desc, index asc) arg-best over 64 lanes: DPP inside 16-lane rows, readlane across rows ----
-struct KrKey { float v; int i; };   // i == 0x7FFFFFFF marks "empty"
-__device__ __forceinline__ KrKey kr_key_best(KrKey a, KrKey b) {
-    const bool take_b = (b.i != 0x7FFFFFFF) && (a.i == 0x7FFFFFFF || kr_better(b.v, b.i, a.v, a.i));
-    return take_b ? b : a;
+// ---- wave-wide (value desc, index asc) arg-best over 64 lanes on packed 64-bit keys ----
+// key = orderable(value) << 32 | (0xFFFFFFFF - index); larger key == better; 0 == empty / already taken.
+__device__ __forceinline__ uint64_t kr_make_key(float v, int e) {
+    if (v == 0.0f) v = 0.0f;                       // -0 and +0 compare equal in the reference
+    uint32_t u = __float_as_uint(v);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;    // monotone map float -> uint
+    return ((uint64_t)u << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)e);
 }
-__device__ __forceinline__ KrKey kr_key_dpp(KrKey a, const int ctrl_sel) {
-    KrKey o;
-    switch (ctrl_sel) {
-        case 0: o.v = __int_as_float(KR_DPP(__float_as_int(a.v), KR_DPP_XOR1)); o.i = KR_DPP(a.i, KR_DPP_XOR1); break;
-        case 1: o.v = __int_as_float(KR_DPP(__float_as_int(a.v), KR_DPP_XOR2)); o.i = KR_DPP(a.i, KR_DPP_XOR2); break;
-        case 2: o.v = __int_as_float(KR_DPP(__float_as_int(a.v), KR_DPP_HALF_MIRROR)); o.i = KR_DPP(a.i, KR_DPP_HALF_MIRROR); break;
-        default: o.v = __int_as_float(KR_DPP(__float_as_int(a.v), KR_DPP_MIRROR)); o.i = KR_DPP(a.i, KR_DPP_MIRROR); break;
-    }
-    return o;
+__device__ __forceinline__ float kr_key_value(uint64_t k) {
+    uint32_t u = (uint32_t)(k >> 32);
+    u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(u);
 }
-__device__ __forceinline__ KrKey kr_wave_best(KrKey k) {
-    k = kr_key_best(k, kr_key_dpp(k, 0));
-    k = kr_key_best(k, kr_key_dpp(k, 1));
-    k = kr_key_best(k, kr_key_dpp(k, 2));
-    k = kr_key_best(k, kr_key_dpp(k, 3));   // every lane of a 16-lane row now holds the row's best
-    KrKey r0{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(k.v), 0)), __builtin_amdgcn_readlane(k.i, 0)};
-    KrKey r1{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(k.v), 16)), __builtin_amdgcn_readlane(k.i, 16)};
-    KrKey r2{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(k.v), 32)), __builtin_amdgcn_readlane(k.i, 32)};
-    KrKey r3{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(k.v), 48)), __builtin_amdgcn_readlane(k.i, 48)};
-    return kr_key_best(kr_key_best(r0, r1), kr_key_best(r2, r3));
+__device__ __forceinline__ int kr_key_index(uint64_t k) { return (int)(0xFFFFFFFFu - (uint32_t)k); }
+__device__ __forceinline__ uint64_t kr_key_max(uint64_t a, uint64_t b) { return a > b ? a : b; }
+#define KR_DPP64(k, ctrl) (((uint64_t)(uint32_t)KR_DPP((int)((k) >> 32), ctrl) << 32) | (uint32_t)KR_DPP((int)(uint32_t)(k), ctrl))
+__device__ __forceinline__ uint64_t kr_wave_key_max(uint64_t k) {
+    k = kr_key_max(k, KR_DPP64(k, KR_DPP_XOR1));
+    k = kr_key_max(k, KR_DPP64(k, KR_DPP_XOR2));
+    k = kr_key_max(k, KR_DPP64(k, KR_DPP_HALF_MIRROR));
+    k = kr_key_max(k, KR_DPP64(k, KR_DPP_MIRROR));    // every lane of a 16-lane row holds the row maximum
+    uint64_t r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        r[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(k >> 32), 16 * j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 16 * j);
+    return kr_key_max(kr_key_max(r[0], r[1]), kr_key_max(r[2], r[3]));
 }
 
 // first kp1 elements in (value desc, index asc) order; element e lives in lane e%64, slot e/64 (registers)
 template <int NV>
 __device__ __forceinline__ void kr_topk_wave_reg(const float (&val)[NV], int n, int kp1, float* pv, int* pi) {
     const int lane = threadIdx.x & 63;
-    uint32_t taken = 0;
-    for (int t = 0; t < kp1; t++) {
-        KrKey best{0.0f, 0x7FFFFFFF};
+    uint64_t key[NV];
 #pragma unroll
-        for (int i = 0; i < NV; i++) {
-            const int e = i * 64 + lane;
-            if (e < n && !((taken >> i) & 1)) best = kr_key_best(best, KrKey{val[i], e});
-        }
-        const KrKey w = kr_wave_best(best);
-        if (w.i != 0x7FFFFFFF && (w.i & 63) == lane) taken |= 1u << (w.i >> 6);
-        if (lane == 0) { pv[t] = w.v; pi[t] = w.i; }
+    for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; key[i] = e < n ? kr_make_key(val[i], e) : 0ull; }
+    for (int t = 0; t < kp1; t++) {
+        uint64_t best = 0ull;
+#pragma unroll
+        for (int i = 0; i < NV; i++) best = kr_key_max(best, key[i]);
+        const uint64_t w = kr_wave_key_max(best);
+#pragma unroll
+        for (int i = 0; i < NV; i++) if (key[i] == w) key[i] = 0ull;   // keys are unique (index embedded): removes exactly the winner
+        if (lane == 0) { pv[t] = kr_key_value(w); pi[t] = kr_key_index(w); }
     }
 }
 
