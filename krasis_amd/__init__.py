@@ -7,5 +7,6 @@ There is NO CPU fallback: every operator fails loudly if libkrasis_hip.so or a G
 from ._lib import KrasisHipError, lib_path, load_library  # noqa: F401
 from .engine import KrasisEngine, ModelConfig  # noqa: F401
 from .decode_store import CpuDecodeStore  # noqa: F401
+from .prefill import GpuPrefillManager  # noqa: F401
 
-__all__ = ["KrasisEngine", "ModelConfig", "CpuDecodeStore", "KrasisHipError", "load_library", "lib_path"]
+__all__ = ["KrasisEngine", "ModelConfig", "CpuDecodeStore", "GpuPrefillManager", "KrasisHipError", "load_library", "lib_path"]

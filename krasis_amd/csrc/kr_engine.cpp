@@ -16,6 +16,7 @@
 
 #include "kr_engine_internal.h"
 #include "kr_router.h"
+#include "kr_prefill.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -195,11 +196,13 @@ extern "C" void kr_engine_destroy(kr_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& l : e->layers) {
+        for (MatSet* ms : {&l.w13, &l.w2, &l.sw13, &l.sw2}) ms->wsum.release();
         l.w13.q.release(); l.w13.s.release(); l.w2.q.release(); l.w2.s.release();
         l.sw13.q.release(); l.sw13.s.release(); l.sw2.q.release(); l.sw2.s.release();
         l.gate_cm.release(); l.gate_rm.release(); l.bias.release(); l.esc.release();
     }
-    for (DevBuf* b : {&e->gu, &e->eo, &e->st_act, &e->st_ids, &e->st_w, &e->st_out, &e->ptr_table, &e->r_logits, &e->r_ids, &e->r_w, &e->r_x}) b->release();
+    for (DevBuf* b : {&e->gu, &e->eo, &e->st_act, &e->st_ids, &e->st_w, &e->st_out, &e->ptr_table, &e->r_logits, &e->r_ids, &e->r_w, &e->r_x, &e->pf_i32, &e->pf_xh, &e->pf_xl, &e->pf_xs,
+                       &e->pf_gu, &e->pf_hh, &e->pf_hl, &e->pf_hs, &e->pf_eo, &e->pf_sgu, &e->pf_shh, &e->pf_shl, &e->pf_shs, &e->pf_seo}) b->release();
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -553,5 +556,84 @@ extern "C" int kr_get_profile(kr_engine* e, int kind, double* total_ms, long* la
     if (!e || kind < 0 || kind >= 8) return kr_fail(KR_ERR_VALUE, "bad profile kind");
     if (total_ms) *total_ms = e->prof_ms[kind];
     if (launches) *launches = e->prof_n[kind];
+    return KR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prefill: GpuPrefillManager.forward (python/krasis/gpu_prefill.py:4374-4484) on int8 MFMA, numerics == kr_moe_forward
+// ------------------------------------------------------------------------------------------------
+static int ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st) {
+    if (ms.wsum.p || !ms.allocated()) return KR_OK;
+    if (ms.bits != 4) return kr_fail(KR_ERR_VALUE, "prefill MFMA path is built for INT4-g128 experts (got %d-bit)", ms.bits);
+    if (ms.wsum.ensure(ms.s_stride * ms.count)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    e->weight_bytes += ms.s_stride * ms.count;
+    kr_launch_pf_wsum(ms.view(), ms.count, (uint32_t*)ms.wsum.p, st);
+    return KR_OK;
+}
+
+#define KR_PF_CHUNK 8192
+
+extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
+                              int out_dtype, int routed_only, void* stream) {
+    if (int rc = check_layer(e, layer)) return rc;
+    if (!x_bf16 || !ids || !wts || !out) return kr_fail(KR_ERR_VALUE, "null pointer argument");
+    if (M <= 0) return kr_fail(KR_ERR_VALUE, "M must be > 0");
+    if (topk <= 0 || topk > KR_MAX_TOPK) return kr_fail(KR_ERR_VALUE, "topk %d exceeds MAX_TOPK %d", topk, KR_MAX_TOPK);
+    Layer& L = e->layers[layer];
+    if (!L.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded -- call load() first (layer %d has no experts)", layer);
+    if (!is_device_ptr(x_bf16) || !is_device_ptr(ids) || !is_device_ptr(wts) || !is_device_ptr(out))
+        return kr_fail(KR_ERR_VALUE, "kr_moe_prefill expects device pointers (hidden/topk tensors live in HBM during prefill)");
+    if (e->cfg.hidden_size % 128 || L.inter % 128) return kr_fail(KR_ERR_VALUE, "prefill path needs dims divisible by 128");
+    std::lock_guard<std::mutex> lk(e->mu);
+    KR_HIP(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
+    const bool use_shared = L.shared_present && !routed_only;
+    const int SI = L.shared_inter;
+    if (int rc = ensure_wsum(e, L.w13, st)) return rc;
+    if (int rc = ensure_wsum(e, L.w2, st)) return rc;
+    if (use_shared) { if (int rc = ensure_wsum(e, L.sw13, st)) return rc; if (int rc = ensure_wsum(e, L.sw2, st)) return rc; }
+    const int CH = M < KR_PF_CHUNK ? M : KR_PF_CHUNK;
+    const size_t np = (size_t)CH * topk;
+    const int max_tiles = (int)(np / 64) + E + 1;
+    const size_t n_i32 = 3 * (size_t)E + 3 * (size_t)max_tiles + 4 + 2 * np;
+    if (e->pf_i32.ensure(n_i32 * 4) || e->pf_xh.ensure((size_t)CH * H) || e->pf_xl.ensure((size_t)CH * H) || e->pf_xs.ensure((size_t)CH * (H / 128) * 4) ||
+        e->pf_gu.ensure(np * 2 * I * 4) || e->pf_hh.ensure(np * I) || e->pf_hl.ensure(np * I) || e->pf_hs.ensure(np * (I / 128) * 4) || e->pf_eo.ensure(np * H * 4))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
+    if (use_shared && (e->pf_sgu.ensure((size_t)CH * 2 * SI * 4) || e->pf_shh.ensure((size_t)CH * SI) || e->pf_shl.ensure((size_t)CH * SI) ||
+                       e->pf_shs.ensure((size_t)CH * (SI / 128) * 4) || e->pf_seo.ensure((size_t)CH * H * 4)))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
+    int* ib = (int*)e->pf_i32.p;
+    KrPfSort so{};
+    so.counts = ib; so.offsets = ib + E; so.cursor = ib + 2 * E; ib += 3 * E;
+    so.tile_expert = ib; so.tile_row0 = ib + max_tiles; so.tile_rows = ib + 2 * max_tiles; ib += 3 * max_tiles;
+    so.n_tiles = ib; ib += 4; so.row_pair = ib; so.pair_row = ib + np;
+    const int act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
+    const size_t ob = out_dtype == KR_OUT_BF16 ? 2 : 4;
+    for (int m0 = 0; m0 < M; m0 += CH) {
+        const int mc = M - m0 < CH ? M - m0 : CH;
+        const uint16_t* xc = (const uint16_t*)x_bf16 + (size_t)m0 * H;
+        const int32_t* idc = ids + (size_t)m0 * topk; const float* wc = wts + (size_t)m0 * topk;
+        const int tiles_bound = (mc * topk) / 64 + E + 1;
+        kr_launch_pf_sort(idc, mc, topk, E, so, st);
+        kr_launch_pf_quant_x(xc, mc, H, (int8_t*)e->pf_xh.p, (int8_t*)e->pf_xl.p, (float*)e->pf_xs.p, st);
+        kr_launch_pf_gemm(L.w13.view(), (const uint32_t*)L.w13.wsum.p, (const int8_t*)e->pf_xh.p, (const int8_t*)e->pf_xl.p, (const float*)e->pf_xs.p, &so, topk, 1,
+                          tiles_bound, 0, (float*)e->pf_gu.p, 2 * I, st);
+        kr_launch_pf_act((const float*)e->pf_gu.p, mc * topk, I, 2 * I, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (int8_t*)e->pf_hh.p, (int8_t*)e->pf_hl.p,
+                         (float*)e->pf_hs.p, st);
+        kr_launch_pf_gemm(L.w2.view(), (const uint32_t*)L.w2.wsum.p, (const int8_t*)e->pf_hh.p, (const int8_t*)e->pf_hl.p, (const float*)e->pf_hs.p, &so, topk, 0,
+                          tiles_bound, 0, (float*)e->pf_eo.p, H, st);
+        if (use_shared) {
+            kr_launch_pf_gemm(L.sw13.view(), (const uint32_t*)L.sw13.wsum.p, (const int8_t*)e->pf_xh.p, (const int8_t*)e->pf_xl.p, (const float*)e->pf_xs.p, nullptr, topk, 0,
+                              0, mc, (float*)e->pf_sgu.p, 2 * SI, st);
+            kr_launch_pf_act((const float*)e->pf_sgu.p, mc, SI, 2 * SI, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (int8_t*)e->pf_shh.p, (int8_t*)e->pf_shl.p,
+                             (float*)e->pf_shs.p, st);
+            kr_launch_pf_gemm(L.sw2.view(), (const uint32_t*)L.sw2.wsum.p, (const int8_t*)e->pf_shh.p, (const int8_t*)e->pf_shl.p, (const float*)e->pf_shs.p, nullptr, topk, 0,
+                              0, mc, (float*)e->pf_seo.p, H, st);
+        }
+        kr_launch_pf_combine((const float*)e->pf_eo.p, so.pair_row, wc, mc, topk, H, use_shared ? (const float*)e->pf_seo.p : nullptr, e->cfg.routed_scaling_factor,
+                             (char*)out + (size_t)m0 * H * ob, out_dtype == KR_OUT_BF16, st);
+    }
+    KR_HIP(hipGetLastError());
     return KR_OK;
 }

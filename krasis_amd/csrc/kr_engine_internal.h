@@ -32,6 +32,7 @@ struct DevBuf {
 
 struct MatSet {            // all experts of one layer for one projection, contiguous in HBM
     DevBuf q, s;
+    DevBuf wsum;           // prefill: per (group, column) sum of (nibble-8), i16 pairs in the scale-pair layout (built on first use)
     int K = 0, N = 0, bits = 0, count = 0;
     size_t q_stride = 0, s_stride = 0;
     bool allocated() const { return q.p != nullptr; }
@@ -69,6 +70,8 @@ struct kr_engine {
     // routing config
     bool routing_set = false; int r_scoring = 1, r_norm = 1, r_topk = 0, r_ne = 0, r_hidden = 0;
     DevBuf r_logits, r_ids, r_w, r_x;
+    // prefill scratch (kr_moe_prefill)
+    DevBuf pf_i32, pf_xh, pf_xl, pf_xs, pf_gu, pf_hh, pf_hl, pf_hs, pf_eo, pf_sgu, pf_shh, pf_shl, pf_shs, pf_seo;
     // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
     bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};
     std::mutex mu;

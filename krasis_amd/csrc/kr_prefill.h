@@ -1,0 +1,22 @@
+// kr_prefill.h -- launch wrappers of kr_prefill.hip (token sort, activation digits, int8-MFMA grouped GEMM, combine)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kr_kernels.h"
+
+struct KrPfSort {
+    int* counts; int* offsets; int* cursor;        // [E]
+    int* tile_expert; int* tile_row0; int* tile_rows;  // [max_tiles]
+    int* n_tiles;                                   // [1]
+    int* row_pair;                                  // [n_pairs]  GEMM row -> (token*topk + slot)
+    int* pair_row;                                  // [n_pairs]  inverse (-1 for skipped ids)
+};
+size_t kr_pf_gemm_lds_bytes();
+void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, hipStream_t st);
+void kr_launch_pf_quant_x(const uint16_t* x, int M, int K, int8_t* xh, int8_t* xl, float* xs, hipStream_t st);
+void kr_launch_pf_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, int8_t* hh, int8_t* hl, float* hs, hipStream_t st);
+void kr_launch_pf_wsum(const KrMatDev& m, int n_experts, uint32_t* wsum, hipStream_t st);
+void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_hi, const int8_t* a_lo, const float* a_scale, const KrPfSort* sort, int topk,
+                       int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, hipStream_t st);
+void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
+                          int out_bf16, hipStream_t st);

@@ -1,0 +1,352 @@
+// kr_prefill.hip -- prefill (M >> 1) expert path for gfx950: token sort -> grouped GEMM on int8 MFMA -> combine.
+//
+// Replaces GpuPrefillManager.forward / fused_marlin_moe (python/krasis/gpu_prefill.py:64-239,4374-4484: moe_align_block_size,
+// moe_wna16_marlin_gemm x2, silu_and_mul, moe_sum_reduce -- all third-party CUDA) with ONE numerics story: every (token, expert)
+// row is computed with exactly the arithmetic of the reference's CPU engine (expert_forward_unified, src/moe.rs:184), i.e. the
+// result of kr_moe_prefill is bit-identical to kr_moe_forward / KrasisEngine.forward_moe_direct on the same batch.
+//
+// How INT16 activations ride the int8 matrix cores exactly:
+//   a (i16) = AH*256 + AL, AH = a >> 8 in [-128,127], AL' = (a & 255) - 128 in [-128,127]
+//   sum_k w*a = 256 * mfma(AH, w) + mfma(AL', w) + 128 * sum_k w       (w = nibble - 8, sum_k w precomputed per group/column)
+// Two v_mfma_i32_32x32x32_i8 per B fragment, i32 accumulators reset every 128-wide quantization group, then the same
+// one-fma-per-group f32 chain as the reference: out = fma(f32(isum), bf16(w_scale) * a_scale, out).
+//
+// Tile: 64 rows (tokens routed to one expert) x 128 columns per workgroup of 4 waves; one group PAIR (256 k) per LDS stage.
+#include "kr_device.h"
+#include "kr_kernels.h"
+#include "kr_prefill.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define PF_BM 64
+#define PF_BN 128
+#define PF_LDK 272          // bytes per LDS row: 256 k + 16 pad (keeps ds_read_b128 rows on distinct 16-B slots)
+
+// ------------------------------------------------------------------------------------------
+// token sort (moe_align_block_size equivalent): rows of the grouped GEMM = (token, slot) pairs grouped by expert
+// ------------------------------------------------------------------------------------------
+__global__ void kr_pf_count_kernel(const int32_t* __restrict__ ids, int n_pairs, int E, int* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const int e = ids[i];
+    if (e >= 0 && e < E) atomicAdd(&counts[e], 1);
+}
+
+// one block: exclusive scan of counts -> row offsets; tile table (expert, first row, rows) for every 64-row tile
+__global__ void __launch_bounds__(1024) kr_pf_scan_kernel(const int* __restrict__ counts, int E, int* __restrict__ offsets, int* __restrict__ cursor,
+                                                         int* __restrict__ tile_expert, int* __restrict__ tile_row0, int* __restrict__ tile_rows,
+                                                         int* __restrict__ n_tiles_out) {
+    __shared__ int s_off[1025], s_tile[1025];
+    const int t = threadIdx.x;
+    if (t == 0) {
+        int o = 0, tl = 0;
+        for (int e = 0; e < E; e++) { s_off[e] = o; s_tile[e] = tl; o += counts[e]; tl += (counts[e] + PF_BM - 1) / PF_BM; }
+        s_off[E] = o; s_tile[E] = tl; n_tiles_out[0] = tl;
+    }
+    __syncthreads();
+    for (int e = t; e < E; e += 1024) {
+        offsets[e] = s_off[e]; cursor[e] = 0;
+        const int c = counts[e];
+        for (int i = 0; i * PF_BM < c; i++) {
+            const int ti = s_tile[e] + i;
+            tile_expert[ti] = e; tile_row0[ti] = s_off[e] + i * PF_BM; tile_rows[ti] = (c - i * PF_BM) < PF_BM ? (c - i * PF_BM) : PF_BM;
+        }
+    }
+}
+
+__global__ void kr_pf_scatter_kernel(const int32_t* __restrict__ ids, int n_pairs, int E, const int* __restrict__ offsets, int* __restrict__ cursor,
+                                     int* __restrict__ row_pair, int* __restrict__ pair_row) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const int e = ids[i];
+    if (e < 0 || e >= E) { pair_row[i] = -1; return; }
+    const int r = offsets[e] + atomicAdd(&cursor[e], 1);
+    row_pair[r] = i; pair_row[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// activation digits: quantize_activation_int16 (avx2.rs:234) per token, stored as two int8 planes + per-group scale
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void kr_store_digits(int8_t* hi, int8_t* lo, const int (&q)[8]) {
+    u32x2 h, l;
+    h.x = kr_pack4(q[0] >> 8, q[1] >> 8, q[2] >> 8, q[3] >> 8); h.y = kr_pack4(q[4] >> 8, q[5] >> 8, q[6] >> 8, q[7] >> 8);
+    l.x = kr_pack4((q[0] & 255) - 128, (q[1] & 255) - 128, (q[2] & 255) - 128, (q[3] & 255) - 128);
+    l.y = kr_pack4((q[4] & 255) - 128, (q[5] & 255) - 128, (q[6] & 255) - 128, (q[7] & 255) - 128);
+    *reinterpret_cast<u32x2*>(hi) = h; *reinterpret_cast<u32x2*>(lo) = l;
+}
+
+// grid (M), block K/8 threads (<= 1024): thread = one 8-element chunk, 16 threads = one group
+__global__ void kr_pf_quant_x_kernel(const uint16_t* __restrict__ x, int K, int8_t* __restrict__ xh, int8_t* __restrict__ xl, float* __restrict__ xs) {
+    const int t = blockIdx.x;
+    for (int c = threadIdx.x; c < K / 8; c += blockDim.x) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(x + (size_t)t * K + (size_t)c * 8);
+        float v[8];
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u); v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
+        v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xFFFF0000u); v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xFFFF0000u);
+        float mx = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v[i]));
+        mx = kr_red16_max_f32(mx);
+        const float scale = mx > 0.0f ? mx / 32767.0f : 1.0f, inv = mx > 0.0f ? 32767.0f / mx : 0.0f;
+        int q[8];
+        kr_quant8<false>(v, inv, q);
+        kr_store_digits(xh + (size_t)t * K + c * 8, xl + (size_t)t * K + c * 8, q);
+        if ((c & 15) == 0) xs[(size_t)t * (K / 128) + (c >> 4)] = scale;
+    }
+}
+
+// hidden digits from gu rows: silu_quantize_int16_avx2 (avx2.rs:2310) or the GPT-OSS activation (moe.rs:268-287). grid (rows), block I/8
+template <int ACT>
+__global__ void kr_pf_act_kernel(const float* __restrict__ gu, int n, int gu_ld, float swiglu_limit, float alpha, int8_t* __restrict__ hh,
+                                 int8_t* __restrict__ hl, float* __restrict__ hs) {
+    const int row = blockIdx.x;
+    const float* g = gu + (size_t)row * gu_ld;
+    for (int c = threadIdx.x; c < n / 8; c += blockDim.x) {
+        const float4 g0 = *reinterpret_cast<const float4*>(g + c * 8), g1 = *reinterpret_cast<const float4*>(g + c * 8 + 4);
+        const float4 u0 = *reinterpret_cast<const float4*>(g + n + c * 8), u1 = *reinterpret_cast<const float4*>(g + n + c * 8 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        float h[8], mx = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (ACT == KR_ACT_GPTOSS) {
+                float gate = gg[i], up = uu[i];
+                if (gate > swiglu_limit) gate = swiglu_limit;
+                if (up > swiglu_limit) up = swiglu_limit;
+                if (up < -swiglu_limit) up = -swiglu_limit;
+                h[i] = (up + 1.0f) * (gate * kr_sigmoid_poly5_scalar(gate * alpha));
+            } else h[i] = (gg[i] * kr_sigmoid_poly5(gg[i])) * uu[i];
+            mx = fmaxf(mx, fabsf(h[i]));
+        }
+        mx = kr_red16_max_f32(mx);
+        const float scale = mx > 0.0f ? mx / 32767.0f : 1.0f, inv = mx > 0.0f ? 32767.0f / mx : 0.0f;
+        int q[8];
+        if (ACT == KR_ACT_SILU_FUSED) kr_quant8<true>(h, inv, q); else kr_quant8<false>(h, inv, q);
+        kr_store_digits(hh + (size_t)row * n + c * 8, hl + (size_t)row * n + c * 8, q);
+        if ((c & 15) == 0) hs[(size_t)row * (n / 128) + (c >> 4)] = scale;
+    }
+}
+
+// per (expert, column, group): sum_k (nibble - 8), packed as i16 pairs in the layout of the scale pairs.  grid (N/8 tiles, experts), 64 thr
+__global__ void __launch_bounds__(64) kr_pf_wsum_kernel(const KrMatDev m, uint32_t* __restrict__ wsum) {
+    const int tile = blockIdx.x, e = blockIdx.y, lane = threadIdx.x, col = lane >> 3;
+    const u32x4* q = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(m.q) + (size_t)e * m.q_stride) + (size_t)tile * m.ngp * 64 + lane;
+    uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(wsum) + (size_t)e * m.s_stride) + (size_t)tile * m.ngp * 8 + col;
+    for (int gp = 0; gp < m.ngp; gp++) {
+        const u32x4 w = q[(size_t)gp * 64];
+        int s0 = __builtin_amdgcn_sdot4((int)(w.x & 0x0F0F0F0Fu), 0x01010101, 0, false) + __builtin_amdgcn_sdot4((int)((w.x >> 4) & 0x0F0F0F0Fu), 0x01010101, 0, false) +
+                 __builtin_amdgcn_sdot4((int)(w.y & 0x0F0F0F0Fu), 0x01010101, 0, false) + __builtin_amdgcn_sdot4((int)((w.y >> 4) & 0x0F0F0F0Fu), 0x01010101, 0, false) - 128;
+        int s1 = __builtin_amdgcn_sdot4((int)(w.z & 0x0F0F0F0Fu), 0x01010101, 0, false) + __builtin_amdgcn_sdot4((int)((w.z >> 4) & 0x0F0F0F0Fu), 0x01010101, 0, false) +
+                 __builtin_amdgcn_sdot4((int)(w.w & 0x0F0F0F0Fu), 0x01010101, 0, false) + __builtin_amdgcn_sdot4((int)((w.w >> 4) & 0x0F0F0F0Fu), 0x01010101, 0, false) - 128;
+        s0 = kr_red8_add_i32(s0); s1 = kr_red8_add_i32(s1);
+        if ((lane & 7) == 0) out[gp * 8] = ((uint32_t)s0 & 0xFFFFu) | ((uint32_t)s1 << 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// grouped GEMM on int8 MFMA
+// ------------------------------------------------------------------------------------------
+struct KrPfGemmArgs {
+    KrMatDev m; const uint32_t* wsum;      // weights of the layer's experts (+ wsum in the scale-pair layout)
+    const int8_t* a_hi; const int8_t* a_lo; const float* a_scale;   // digits [rows_or_tokens][K], scales [..][K/128]
+    const int* row_pair; int topk; int gather_tokens;               // stage 1: A row = token of the pair; stage 2: A row = GEMM row
+    const int* tile_expert; const int* tile_row0; const int* tile_rows; const int* n_tiles;
+    float* out; int out_ld;                 // [rows][out_ld]
+    int single_expert;                      // shared expert: every tile uses expert 0 of `m`, rows are tokens 0..M-1 in order
+    int total_rows;
+};
+
+__device__ __forceinline__ uint32_t kr_unpack_lo4(uint32_t lo, uint32_t hi) {  // bytes k0,k1,k2,k3 as (q-8) i8
+    return ((__builtin_amdgcn_perm(hi, lo, 0x05010400u)) + 0x78787878u) ^ 0x80808080u;
+}
+__device__ __forceinline__ uint32_t kr_unpack_hi4(uint32_t lo, uint32_t hi) {  // bytes k4..k7
+    return ((__builtin_amdgcn_perm(hi, lo, 0x07030602u)) + 0x78787878u) ^ 0x80808080u;
+}
+
+__global__ void __launch_bounds__(256) kr_pf_gemm_kernel(const KrPfGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int8_t* As_hi = reinterpret_cast<int8_t*>(smem);                       // [64][PF_LDK]
+    int8_t* As_lo = As_hi + PF_BM * PF_LDK;                                 // [64][PF_LDK]
+    int8_t* Bs = As_lo + PF_BM * PF_LDK;                                    // [128][PF_LDK]
+    float* As_sc = reinterpret_cast<float*>(Bs + PF_BN * PF_LDK);           // [2][64]
+    int* row_src = reinterpret_cast<int*>(As_sc + 2 * PF_BM);               // [64]
+
+    const int mt = blockIdx.x;
+    int expert, row0, rows;
+    if (a.single_expert) { expert = 0; row0 = mt * PF_BM; rows = a.total_rows - row0 < PF_BM ? a.total_rows - row0 : PF_BM; if (rows <= 0) return; }
+    else { if (mt >= a.n_tiles[0]) return; expert = a.tile_expert[mt]; row0 = a.tile_row0[mt]; rows = a.tile_rows[mt]; }
+    const int n0 = blockIdx.y * PF_BN;
+    const KrMatDev& m = a.m;
+    const int K = m.ng * 128;
+    const u32x4* wq = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(m.q) + (size_t)expert * m.q_stride);
+    const uint32_t* wsc = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + (size_t)expert * m.s_stride);
+    const uint32_t* wsm = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.wsum) + (size_t)expert * m.s_stride);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < PF_BM) {
+        int src = -1;
+        if (tid < rows) {
+            if (a.single_expert) src = row0 + tid;
+            else { const int pair = a.row_pair[row0 + tid]; src = a.gather_tokens ? pair / a.topk : row0 + tid; }
+        }
+        row_src[tid] = src;
+    }
+    __syncthreads();
+
+    v16i zero16; for (int i = 0; i < 16; i++) zero16[i] = 0;
+    float outv[2][16];
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) outv[s][r] = 0.0f;
+    const int col = n0 + wave * 32 + (lane & 31);          // this lane's output column
+    const int ctile = col >> 3, cin = col & 7;
+    const int khalf = (lane >> 5) * 16;
+
+    for (int gp = 0; gp < m.ngp; gp++) {
+        // ---- stage A digits (64 rows x 256 k, two planes): thread -> (row = tid/4, 64-byte quarter)
+        {
+            const int r = tid >> 2, qtr = tid & 3;
+            const int src = row_src[r];
+            const size_t go = (size_t)(src < 0 ? 0 : src) * K + (size_t)gp * 256 + qtr * 64;
+            const int kvalid = K - gp * 256;   // 256, or 128 for a trailing odd group
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                u32x4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
+                if (src >= 0 && qtr * 64 + j * 16 < kvalid) {
+                    vh = *reinterpret_cast<const u32x4*>(a.a_hi + go + j * 16);
+                    vl = *reinterpret_cast<const u32x4*>(a.a_lo + go + j * 16);
+                }
+                *reinterpret_cast<u32x4*>(As_hi + r * PF_LDK + qtr * 64 + j * 16) = vh;
+                *reinterpret_cast<u32x4*>(As_lo + r * PF_LDK + qtr * 64 + j * 16) = vl;
+            }
+            if (tid < 2 * PF_BM) {
+                const int rr = tid & 63, g = 2 * gp + (tid >> 6), s2 = row_src[rr];
+                As_sc[tid] = (s2 >= 0 && g < m.ng) ? a.a_scale[(size_t)s2 * m.ng + g] : 0.0f;
+            }
+        }
+        // ---- stage B: 128 columns x 256 k nibbles -> (q-8) int8, natural k order.  16 column tiles x 64 lane records; 4 per thread
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int rec = tid + j * 256;                 // 0..1023
+            const int t8 = rec >> 6, ln = rec & 63;        // column tile within the block tile, lane record
+            const int c = ln >> 3, l8 = ln & 7;
+            const int gcol = n0 + t8 * 8 + c;
+            u32x4 w = {0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};
+            if (gcol < m.N) w = kr_ldg_nt(wq + ((size_t)(gcol >> 3) * m.ngp + gp) * 64 + ln);
+            int8_t* brow = Bs + (t8 * 8 + c) * PF_LDK;
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int h = 0; h < 2; h++)       // group g0 / g1 of the pair
+#pragma unroll
+                for (int i = 0; i < 2; i++) {  // the lane's two words of that group: k = 16*l8 + 8*i .. +8
+                    const uint32_t wd = ws[h * 2 + i];
+                    const uint32_t lo = wd & 0x0F0F0F0Fu, hi = (wd >> 4) & 0x0F0F0F0Fu;
+                    u32x2 o; o.x = kr_unpack_lo4(lo, hi); o.y = kr_unpack_hi4(lo, hi);
+                    *reinterpret_cast<u32x2*>(brow + h * 128 + l8 * 16 + i * 8) = o;
+                }
+        }
+        __syncthreads();
+        // ---- two quantization groups of this pair
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int g = 2 * gp + h;
+            if (g < m.ng) {
+                v16i acc_hi[2] = {zero16, zero16}, acc_lo[2] = {zero16, zero16};
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const int ko = h * 128 + ks * 32 + khalf;
+                    const v4i b = *reinterpret_cast<const v4i*>(Bs + (wave * 32 + (lane & 31)) * PF_LDK + ko);
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        const v4i ah = *reinterpret_cast<const v4i*>(As_hi + (s * 32 + (lane & 31)) * PF_LDK + ko);
+                        const v4i al = *reinterpret_cast<const v4i*>(As_lo + (s * 32 + (lane & 31)) * PF_LDK + ko);
+                        acc_hi[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, b, acc_hi[s], 0, 0, 0);
+                        acc_lo[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, b, acc_lo[s], 0, 0, 0);
+                    }
+                }
+                // group epilogue: exact i32 sum -> one fma per group (avx2.rs:1162-1176)
+                uint32_t sp = 0, sm2 = 0;
+                if (col < m.N) { sp = wsc[((size_t)ctile * m.ngp + gp) * 8 + cin]; sm2 = wsm[((size_t)ctile * m.ngp + gp) * 8 + cin]; }
+                const float wscale = __uint_as_float((h ? (sp >> 16) : (sp & 0xFFFFu)) << 16);
+                const int wsum128 = ((int)(int16_t)(h ? (sm2 >> 16) : (sm2 & 0xFFFFu))) << 7;
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int isum = (acc_hi[s][r] << 8) + acc_lo[s][r] + wsum128;
+                        const float comb = wscale * As_sc[h * PF_BM + row];
+                        outv[s][r] = __builtin_fmaf((float)isum, comb, outv[s][r]);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    if (col < m.N) {
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < rows) a.out[(size_t)(row0 + row) * a.out_ld + col] = outv[s][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// combine: out[t] = sum_s w[t][s] * eo[row(t,s)] in routing order (moe.rs:661-667); shared: rsf*out + shared (moe.rs:703-706)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kr_pf_combine_kernel(const float* __restrict__ eo, const int* __restrict__ pair_row, const float* __restrict__ wts,
+                                                           int topk, int H, const float* __restrict__ shared_eo, float rsf, void* out, int out_bf16) {
+    const int t = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= H) return;
+    float acc = 0.0f;
+    for (int s = 0; s < topk; s++) {
+        const int r = pair_row[(size_t)t * topk + s];
+        if (r < 0) continue;
+        acc += wts[(size_t)t * topk + s] * eo[(size_t)r * H + j];
+    }
+    if (shared_eo) acc = rsf * acc + shared_eo[(size_t)t * H + j];
+    if (out_bf16) reinterpret_cast<uint16_t*>(out)[(size_t)t * H + j] = kr_f32_to_bf16(acc);
+    else reinterpret_cast<float*>(out)[(size_t)t * H + j] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+size_t kr_pf_gemm_lds_bytes() { return (size_t)(2 * PF_BM + PF_BN) * PF_LDK + 2 * PF_BM * 4 + PF_BM * 4; }
+
+void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, hipStream_t st) {
+    const int n = M * topk;
+    hipMemsetAsync(s.counts, 0, (size_t)E * 4, st);
+    hipLaunchKernelGGL(kr_pf_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E, s.counts);
+    hipLaunchKernelGGL(kr_pf_scan_kernel, dim3(1), dim3(1024), 0, st, s.counts, E, s.offsets, s.cursor, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles);
+    hipLaunchKernelGGL(kr_pf_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E, s.offsets, s.cursor, s.row_pair, s.pair_row);
+}
+void kr_launch_pf_quant_x(const uint16_t* x, int M, int K, int8_t* xh, int8_t* xl, float* xs, hipStream_t st) {
+    const int thr = K / 8 < 1024 ? K / 8 : 1024;
+    hipLaunchKernelGGL(kr_pf_quant_x_kernel, dim3(M), dim3(thr), 0, st, x, K, xh, xl, xs);
+}
+void kr_launch_pf_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, int8_t* hh, int8_t* hl, float* hs, hipStream_t st) {
+    const int thr = n / 8 < 1024 ? n / 8 : 1024;
+    if (act_mode == KR_ACT_GPTOSS) hipLaunchKernelGGL(kr_pf_act_kernel<KR_ACT_GPTOSS>, dim3(rows), dim3(thr), 0, st, gu, n, gu_ld, swiglu_limit, alpha, hh, hl, hs);
+    else hipLaunchKernelGGL(kr_pf_act_kernel<KR_ACT_SILU_FUSED>, dim3(rows), dim3(thr), 0, st, gu, n, gu_ld, swiglu_limit, alpha, hh, hl, hs);
+}
+void kr_launch_pf_wsum(const KrMatDev& m, int n_experts, uint32_t* wsum, hipStream_t st) {
+    hipLaunchKernelGGL(kr_pf_wsum_kernel, dim3((m.N + 7) / 8, n_experts), dim3(64), 0, st, m, wsum);
+}
+void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_hi, const int8_t* a_lo, const float* a_scale, const KrPfSort* sort, int topk,
+                       int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, hipStream_t st) {
+    KrPfGemmArgs a{};
+    a.m = m; a.wsum = wsum; a.a_hi = a_hi; a.a_lo = a_lo; a.a_scale = a_scale; a.topk = topk; a.gather_tokens = gather_tokens;
+    if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
+    a.out = out; a.out_ld = out_ld; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
+    const int mt = single_expert_rows > 0 ? (single_expert_rows + PF_BM - 1) / PF_BM : max_tiles;
+    dim3 grid(mt, (m.N + PF_BN - 1) / PF_BN);
+    hipLaunchKernelGGL(kr_pf_gemm_kernel, grid, dim3(256), kr_pf_gemm_lds_bytes(), st, a);
+}
+void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
+                          int out_bf16, hipStream_t st) {
+    hipLaunchKernelGGL(kr_pf_combine_kernel, dim3((H + 255) / 256, M), dim3(256), 0, st, eo, pair_row, wts, topk, H, shared_eo, rsf, out, out_bf16);
+}
