@@ -535,7 +535,7 @@ extern "C" int kr_decode_set_use_graph(kr_decode_store* s, int enable) {
 extern "C" int kr_decode_step(kr_decode_store* s, int token_id, int position, float* logits_out, void* stream) {
     if (int rc = need_cfg(s)) return rc;
     KR_HIP(hipSetDevice(s->eng->device));
-    hipStream_t st = stream ? (hipStream_t)stream : s->eng->stream;
+    hipStream_t st = kr_pick_stream(s->eng, stream);
     // all scratch the MoE block needs must exist before capture (no allocation inside a capture)
     {
         kr_engine* e = s->eng; size_t gu = 0, eo = 0;
@@ -562,7 +562,7 @@ extern "C" int kr_decode_generate_greedy(kr_decode_store* s, int first_token, in
                                          int* tokens_out, int* n_out, void* stream) {
     if (int rc = need_cfg(s)) return rc;
     KR_HIP(hipSetDevice(s->eng->device));
-    hipStream_t st = stream ? (hipStream_t)stream : s->eng->stream;
+    hipStream_t st = kr_pick_stream(s->eng, stream);
     int tok = first_token, n = 0;
     for (int i = 0; i < max_tokens; i++) {
         if (int rc = kr_decode_step(s, tok, start_pos + i, nullptr, st)) return rc;

@@ -316,7 +316,7 @@ extern "C" int kr_moe_forward(kr_engine* e, int layer, const void* act, const in
     if (!L.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded -- call load() first (layer %d has no experts)", layer);
     std::lock_guard<std::mutex> lk(e->mu);
     KR_HIP(hipSetDevice(e->device));
-    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    hipStream_t st = kr_pick_stream(e, stream);
     if (stream && st != e->stream) { /* staging copies are issued on the caller's stream too */ }
     const int H = e->cfg.hidden_size;
     const bool use_shared = L.shared_present && !routed_only;
@@ -369,7 +369,7 @@ extern "C" int kr_reduce_sum_bf16(kr_engine* e, const void* const* inputs, int n
     if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
     if (n_inputs <= 0) return KR_OK;  // moe.rs:2511
     KR_HIP(hipSetDevice(e->device));
-    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    hipStream_t st = kr_pick_stream(e, stream);
     for (int i = 0; i < n_inputs; i++)
         if (!is_device_ptr(inputs[i])) return kr_fail(KR_ERR_VALUE, "kr_reduce_sum_bf16 expects device pointers");
     if (!is_device_ptr(out)) return kr_fail(KR_ERR_VALUE, "kr_reduce_sum_bf16 expects device pointers");
@@ -505,7 +505,7 @@ extern "C" int kr_route_topk(kr_engine* e, int layer, const void* x, int m, int 
     if (rule != KR_ROUTE_RULE_DECODE && rule != KR_ROUTE_RULE_ENGINE) return kr_fail(KR_ERR_VALUE, "unknown routing rule %d", rule);
     std::lock_guard<std::mutex> lk(e->mu);
     KR_HIP(hipSetDevice(e->device));
-    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    hipStream_t st = kr_pick_stream(e, stream);
     const size_t xb = (size_t)m * e->r_hidden * (rule == KR_ROUTE_RULE_DECODE ? 4 : 2);
     const void* d_x = x;
     if (!is_device_ptr(x)) {
@@ -528,7 +528,7 @@ extern "C" int kr_forward_moe_routed(kr_engine* e, int layer, const void* act_bf
     if (!L.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded");
     if (!e->routing_set) return kr_fail(KR_ERR_STATE, "Routing config not set");
     if (!L.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", layer);
-    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    hipStream_t st = kr_pick_stream(e, stream);
     const void* d_act = act_bf16;
     {
         std::lock_guard<std::mutex> lk(e->mu);
@@ -586,7 +586,7 @@ extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const
     if (e->cfg.hidden_size % 128 || L.inter % 128) return kr_fail(KR_ERR_VALUE, "prefill path needs dims divisible by 128");
     std::lock_guard<std::mutex> lk(e->mu);
     KR_HIP(hipSetDevice(e->device));
-    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    hipStream_t st = kr_pick_stream(e, stream);
     const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
     const bool use_shared = L.shared_present && !routed_only;
     const int SI = L.shared_inter;

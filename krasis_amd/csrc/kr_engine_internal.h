@@ -78,6 +78,14 @@ struct kr_engine {
 };
 
 bool is_device_ptr(const void* p);
+// ABI stream convention: NULL = the engine's own stream, (void*)1 = the legacy default (null) stream, else a hipStream_t
+static inline hipStream_t kr_pick_stream(kr_engine* e, void* stream);
 int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int count);
 int upload_mat(kr_engine* e, MatSet& ms, int idx, const void* w, const uint16_t* sc);
 int download_mat(kr_engine* e, MatSet& ms, int idx, void* w, uint16_t* sc);
+
+static inline hipStream_t kr_pick_stream(kr_engine* e, void* stream) {
+    if (!stream) return e->stream;
+    if (stream == (void*)1) return (hipStream_t)0;
+    return (hipStream_t)stream;
+}

@@ -37,7 +37,7 @@ class GpuPrefillManager:
         if ids.shape != w.shape or ids.shape[0] != M:
             raise ValueError("topk_ids / topk_weights shape mismatch")
         out = torch.empty((M, K), dtype=torch.bfloat16, device=hidden.device)
-        st = torch.cuda.current_stream(hidden.device).cuda_stream
+        st = torch.cuda.current_stream(hidden.device).cuda_stream or 1   # 1 = legacy default stream in the C ABI
         eng = self.engine
         fn = eng._lib.kr_moe_prefill if M >= PREFILL_MIN_TOKENS else eng._lib.kr_moe_forward
         check(fn(eng._h, moe_layer_idx, hidden.data_ptr(), ids.data_ptr(), w.data_ptr(), out.data_ptr(), M, ids.shape[1],
