@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--prefill-tokens", type=int, default=8192, help="tokens per prefill chunk for the experts-only prefill side measurement (0 = skip)")
     return ap.parse_args()
 
 
@@ -120,6 +121,34 @@ def build_qcn(rank, local_rank, L):
     st.finalize_decode()
     st.fill_state_synthetic(q["kv_max_seq"], seed=4242 + rank)
     return eng, st, keep
+
+
+def prefill_experts(eng, L, M, torch):
+    """Side measurement (NOT the headline value): the prefill expert path alone -- token sort + int8-MFMA grouped GEMM + combine of all
+    L MoE layers for one chunk of M tokens with uniform random routing (k distinct experts per token).  Attention / linear-attention
+    prefill kernels are not built yet, so this is an upper bound on prefill tok/s, reported with its MFMA roofline fraction."""
+    from krasis_amd import GpuPrefillManager
+    q = QCN; H, I, E, k = q["hidden"], q["inter"], q["experts"], q["topk"]
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = ((torch.rand((M, H), device="cuda", generator=g) - 0.5)).to(torch.bfloat16)
+    ids = torch.rand((M, E), device="cuda", generator=g).topk(k, dim=1).indices.to(torch.int32)
+    w = torch.softmax(torch.randn((M, k), device="cuda", generator=g), dim=1)
+    mgr = GpuPrefillManager(eng, k)
+    for l in range(min(L, 2)):
+        mgr.forward(l, x, ids, w, routed_only=True)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for l in range(L):
+        mgr.forward(l, x, ids, w, routed_only=True)
+    ev1.record(); torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1)
+    macs = M * k * 3 * H * I * L                       # routed experts only
+    tops = 2.0 * macs * 2 / (ms * 1e-3) / 1e12         # x2: two int8 MFMA passes (high / low activation digit) per MAC
+    return {"tokens": M, "layers": L, "ms": ms, "tok_s_experts_only": M / (ms * 1e-3), "int8_TOPS_issued": tops,
+            "mfma_i8_dense_peak_TOPS": 4400.0, "frac_of_i8_peak": tops / 4400.0,
+            "effective_TFLOPs_2MAC": 2.0 * macs / (ms * 1e-3) / 1e12,
+            "note": "experts only (sort + 2 grouped GEMMs + act + combine); attention prefill kernels not built in this round"}
 
 
 def cpu_baseline(max_seconds, L):
@@ -218,6 +247,10 @@ def main():
     per_kind_us = {KINDS[j]: (tot_ms[j] / P) * 1e3 for j in range(15)}            # us per step
     per_launch_us = {KINDS[j]: (tot_ms[j] / max(tot_n[j], 1)) * 1e3 for j in range(15)}
 
+    prefill = None
+    if args.prefill_tokens > 0:
+        prefill = prefill_experts(eng, L, args.prefill_tokens, torch)
+
     if rank == 0:
         ab = algorithmic_bytes(L)
         sym_us, sym_bytes, sym_n = {}, {}, {}
@@ -248,6 +281,8 @@ def main():
                          "per_kind_us_per_step": {k_: round(v, 2) for k_, v in per_kind_us.items()},
                          "per_kind_us_per_launch": {k_: round(v, 2) for k_, v in per_launch_us.items()}},
         }
+        if prefill is not None:
+            res["prefill_experts_only"] = prefill
         if not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L)
