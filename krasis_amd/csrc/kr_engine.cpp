@@ -200,6 +200,7 @@ extern "C" void kr_engine_destroy(kr_engine* e) {
         l.w13.q.release(); l.w13.s.release(); l.w2.q.release(); l.w2.s.release();
         l.sw13.q.release(); l.sw13.s.release(); l.sw2.q.release(); l.sw2.s.release();
         l.gate_cm.release(); l.gate_rm.release(); l.bias.release(); l.esc.release();
+        for (GgufSet* g : {&l.g_gate, &l.g_up, &l.g_down, &l.gs_gate, &l.gs_up, &l.gs_down}) { g->q.release(); g->h.release(); }
     }
     for (DevBuf* b : {&e->gu, &e->eo, &e->st_act, &e->st_ids, &e->st_w, &e->st_out, &e->ptr_table, &e->r_logits, &e->r_ids, &e->r_w, &e->r_x, &e->pf_i32, &e->pf_xh, &e->pf_xl, &e->pf_xs,
                        &e->pf_gu, &e->pf_hh, &e->pf_hl, &e->pf_hs, &e->pf_eo, &e->pf_sgu, &e->pf_shh, &e->pf_shl, &e->pf_shs, &e->pf_seo}) b->release();
@@ -293,8 +294,90 @@ extern "C" int kr_download_expert_unified(kr_engine* e, int layer, int expert, v
     return KR_OK;
 }
 
-extern "C" int kr_upload_expert_gguf(kr_engine*, int, int, int, const uint8_t*, const uint8_t*, int, const uint8_t*, int) {
-    return kr_fail(KR_ERR_STATE, "native GGUF block kernels are not built yet in this round (INT4/INT8-g128 only)");
+// ---- native GGUF blocks: raw row-major [rows][K/blk] -> lane-tiled records (kr_gguf.hip header comment) ----
+static size_t ggml_block_bytes(int t) { return t == GG_Q4_K ? 144 : t == GG_Q8_0 ? 34 : t == GG_Q4_0 ? 18 : t == GG_Q5_0 ? 22 : t == GG_Q6_K ? 210 : 0; }
+static int ggml_block_elems(int t) { return (t == GG_Q4_K || t == GG_Q6_K) ? 256 : 32; }
+
+static void retile_gguf(int type, const uint8_t* src, int K, int N, uint8_t* dq, uint8_t* dh) {
+    const int nt = (N + 7) / 8; const size_t bb = ggml_block_bytes(type); const int nb = K / ggml_block_elems(type);
+    const size_t row_bytes = (size_t)nb * bb;
+    if (type == GG_Q5_0 || type == GG_Q6_K) { memcpy(dq, src, (size_t)N * row_bytes); return; }
+    memset(dq, 0, gg_q_bytes(type, K, N)); memset(dh, 0, gg_h_bytes(type, K, N));
+    for (int t = 0; t < nt; t++) for (int r = 0; r < 8; r++) {
+        const int row = t * 8 + r; if (row >= N) continue;
+        const uint8_t* rp = src + (size_t)row * row_bytes;
+        if (type == GG_Q4_K) {
+            for (int b = 0; b < nb; b++) {
+                const uint8_t* blk = rp + (size_t)b * 144; const uint8_t* qs = blk + 16;
+                memcpy(dh + (((size_t)t * nb + b) * 8 + r) * 16, blk, 16);
+                for (int l = 0; l < 8; l++) {
+                    uint8_t* o = dq + (((size_t)t * nb + b) * 64 + r * 8 + l) * 16;
+                    for (int j = 0; j < 4; j++) { o[4 * j] = qs[32 * j + 2 * l]; o[4 * j + 1] = qs[32 * j + 2 * l + 1]; o[4 * j + 2] = qs[32 * j + 16 + 2 * l]; o[4 * j + 3] = qs[32 * j + 17 + 2 * l]; }
+                }
+            }
+        } else if (type == GG_Q8_0) {
+            const int nbg = (nb + 3) / 4;
+            for (int b = 0; b < nb; b++) {
+                const uint8_t* blk = rp + (size_t)b * 34; const uint8_t* qs = blk + 2; const int bg = b / 4, u = b % 4;
+                memcpy(dh + (((size_t)t * nbg + bg) * 8 + r) * 8 + u * 2, blk, 2);
+                for (int l = 0; l < 8; l++) {
+                    uint8_t* o = dq + (((size_t)t * nbg + bg) * 64 + r * 8 + l) * 16 + u * 4;
+                    o[0] = qs[2 * l]; o[1] = qs[2 * l + 1]; o[2] = qs[16 + 2 * l]; o[3] = qs[17 + 2 * l];
+                }
+            }
+        } else {  // Q4_0
+            const int nbg = (nb + 7) / 8;
+            for (int b = 0; b < nb; b++) {
+                const uint8_t* blk = rp + (size_t)b * 18; const uint8_t* qs = blk + 2; const int bg = b / 8, u = b % 8;
+                memcpy(dh + (((size_t)t * nbg + bg) * 8 + r) * 16 + u * 2, blk, 2);
+                for (int l = 0; l < 8; l++) {
+                    uint8_t* o = dq + (((size_t)t * nbg + bg) * 64 + r * 8 + l) * 16 + u * 2;
+                    o[0] = qs[2 * l]; o[1] = qs[2 * l + 1];
+                }
+            }
+        }
+    }
+}
+
+static int ggset_alloc(kr_engine* e, GgufSet& gs, int type, int K, int N, int count) {
+    if (gs.allocated()) {
+        if (gs.type != type || gs.K != K || gs.N != N) return kr_fail(KR_ERR_VALUE, "GGUF expert type/shape mismatch within layer");
+        return KR_OK;
+    }
+    if (!ggml_block_bytes(type)) return kr_fail(KR_ERR_VALUE, "GGUF matvec not implemented for type %d", type);
+    if (K % ggml_block_elems(type)) return kr_fail(KR_ERR_VALUE, "K=%d not a multiple of the block size of type %d", K, type);
+    gs.type = type; gs.K = K; gs.N = N; gs.count = count; gs.q_stride = gg_q_bytes(type, K, N); gs.h_stride = gg_h_bytes(type, K, N);
+    if (gs.q.ensure(gs.q_stride * count) || gs.h.ensure(gs.h_stride * count)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    e->weight_bytes += (gs.q_stride + gs.h_stride) * count;
+    return KR_OK;
+}
+static int ggset_upload(GgufSet& gs, int idx, const uint8_t* src) {
+    std::vector<uint8_t> dq(gs.q_stride), dh(gs.h_stride);
+    retile_gguf(gs.type, src, gs.K, gs.N, dq.data(), dh.data());
+    KR_HIP(hipMemcpy((char*)gs.q.p + (size_t)idx * gs.q_stride, dq.data(), gs.q_stride, hipMemcpyHostToDevice));
+    KR_HIP(hipMemcpy((char*)gs.h.p + (size_t)idx * gs.h_stride, dh.data(), gs.h_stride, hipMemcpyHostToDevice));
+    return KR_OK;
+}
+
+extern "C" int kr_upload_expert_gguf(kr_engine* e, int layer, int expert, int inter, const uint8_t* gate, const uint8_t* up, int gate_up_type,
+                                     const uint8_t* down, int down_type) {
+    if (int rc = check_layer(e, layer)) return rc;
+    if (!gate || !up || !down) return kr_fail(KR_ERR_VALUE, "null weight pointer");
+    KR_HIP(hipSetDevice(e->device));
+    Layer& L = e->layers[layer];
+    const int H = e->cfg.hidden_size;
+    const bool sh = expert == -1;
+    if (!sh && (expert < 0 || expert >= e->cfg.n_routed_experts)) return kr_fail(KR_ERR_VALUE, "expert index %d out of range", expert);
+    const int cnt = sh ? 1 : e->cfg.n_routed_experts, idx = sh ? 0 : expert;
+    GgufSet& G = sh ? L.gs_gate : L.g_gate; GgufSet& U = sh ? L.gs_up : L.g_up; GgufSet& D = sh ? L.gs_down : L.g_down;
+    if (int rc = ggset_alloc(e, G, gate_up_type, H, inter, cnt)) return rc;
+    if (int rc = ggset_alloc(e, U, gate_up_type, H, inter, cnt)) return rc;
+    if (int rc = ggset_alloc(e, D, down_type, inter, H, cnt)) return rc;
+    if (int rc = ggset_upload(G, idx, gate)) return rc;
+    if (int rc = ggset_upload(U, idx, up)) return rc;
+    if (int rc = ggset_upload(D, idx, down)) return rc;
+    if (sh) { L.gguf_shared = true; L.shared_inter = inter; } else { L.gguf = true; L.inter = inter; L.present[expert] = 1; }
+    return KR_OK;
 }
 
 // stage an argument that may live on the host
@@ -313,12 +396,42 @@ extern "C" int kr_moe_forward(kr_engine* e, int layer, const void* act, const in
     if (topk <= 0 || topk > KR_MAX_TOPK) return kr_fail(KR_ERR_VALUE, "topk %d exceeds MAX_TOPK %d", topk, KR_MAX_TOPK);
     if (batch > 65535) return kr_fail(KR_ERR_VALUE, "batch %d too large for the decode path (use the prefill entry point)", batch);
     Layer& L = e->layers[layer];
-    if (!L.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded -- call load() first (layer %d has no experts)", layer);
+    if (!L.w13.allocated() && !L.gguf) return kr_fail(KR_ERR_STATE, "Model not loaded -- call load() first (layer %d has no experts)", layer);
     std::lock_guard<std::mutex> lk(e->mu);
     KR_HIP(hipSetDevice(e->device));
     hipStream_t st = kr_pick_stream(e, stream);
     if (stream && st != e->stream) { /* staging copies are issued on the caller's stream too */ }
     const int H = e->cfg.hidden_size;
+    if (L.gguf) {
+        // moe_forward_gguf (moe.rs:990): native GGUF blocks, per-32 INT16 activations
+        const bool ush = L.gguf_shared && !routed_only;
+        GgMoeArgs g{};
+        g.B = batch; g.topk = topk; g.n_slots = topk + (ush ? 1 : 0); g.H = H;
+        g.gate = L.g_gate.view(); g.up = L.g_up.view(); g.down = L.g_down.view();
+        if (ush) { g.sgate = L.gs_gate.view(); g.sup = L.gs_up.view(); g.sdown = L.gs_down.view(); }
+        g.I_max = ush && L.shared_inter > L.inter ? L.shared_inter : L.inter; g.gu_ld = 2 * g.I_max;
+        if (e->gu.ensure((size_t)batch * g.n_slots * g.gu_ld * 4) || e->eo.ensure((size_t)batch * g.n_slots * H * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of MoE scratch failed");
+        g.gu = (float*)e->gu.p; g.eo = (float*)e->eo.p;
+        hipStream_t saved = e->stream; e->stream = st;
+        const void *d_act, *d_ids, *d_w;
+        int rc = stage_in(e, e->st_act, act, (size_t)batch * H * 2, &d_act);
+        if (!rc) rc = stage_in(e, e->st_ids, ids, (size_t)batch * topk * 4, &d_ids);
+        if (!rc) rc = stage_in(e, e->st_w, wts, (size_t)batch * topk * 4, &d_w);
+        e->stream = saved;
+        if (rc) return rc;
+        g.act = (const uint16_t*)d_act; g.ids = (const int32_t*)d_ids;
+        const size_t out_bytes = (size_t)batch * H * (out_dtype == KR_OUT_BF16 ? 2 : 4);
+        const bool out_dev = is_device_ptr(out);
+        if (!out_dev && e->st_out.ensure(out_bytes)) return kr_fail(KR_ERR_HIP, "hipMalloc of staging buffer failed");
+        kr_launch_gguf_moe(g, st);
+        KrMoeArgs c{};
+        c.B = batch; c.topk = topk; c.n_slots = g.n_slots; c.H = H; c.ids = g.ids; c.wts = (const float*)d_w; c.eo = g.eo;
+        c.out = out_dev ? out : e->st_out.p; c.out_bf16 = out_dtype == KR_OUT_BF16; c.rsf = e->cfg.routed_scaling_factor;
+        kr_launch_moe_combine(c, st);
+        KR_HIP(hipGetLastError());
+        if (!out_dev) { KR_HIP(hipMemcpyAsync(out, e->st_out.p, out_bytes, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }
+        return KR_OK;
+    }
     const bool use_shared = L.shared_present && !routed_only;
     KrMoeArgs a{};
     a.B = batch; a.topk = topk; a.n_slots = topk + (use_shared ? 1 : 0);

@@ -10,6 +10,7 @@
 
 #include "../../include/krasis_hip.h"
 #include "kr_kernels.h"
+#include "kr_gguf.h"
 
 int kr_fail(int code, const char* fmt, ...);
 #define KR_HIP(call)                                                                                   \
@@ -45,7 +46,15 @@ struct MatSet {            // all experts of one layer for one projection, conti
     }
 };
 
+struct GgufSet {          // native GGUF experts of one layer for one projection
+    DevBuf q, h; int type = 0, K = 0, N = 0, count = 0; size_t q_stride = 0, h_stride = 0;
+    bool allocated() const { return q.p != nullptr; }
+    GgMat view() const { GgMat m{}; m.q = q.p; m.h = h.p; m.type = type; m.K = K; m.N = N; m.q_stride = q_stride; m.h_stride = h_stride; return m; }
+};
+
 struct Layer {
+    GgufSet g_gate, g_up, g_down, gs_gate, gs_up, gs_down;   // native GGUF blocks (has_gguf)
+    bool gguf = false, gguf_shared = false;
     MatSet w13, w2;        // routed experts
     MatSet sw13, sw2;      // shared expert (count == 1)
     std::vector<uint8_t> present;

@@ -67,6 +67,7 @@ class KrasisEngine:
         self._gpu_bits = 4
         self._pending = None
         self._routing_cfg = None
+        self._has_gguf = False
 
     # ------------------------------------------------------------------ lifetime
     def __del__(self):
@@ -116,6 +117,16 @@ class KrasisEngine:
             assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
         check(self._lib.kr_upload_expert_unified(self._h, layer, expert, inter, _addr(w13), _addr(w13_scales), num_bits,
                                                  _addr(w2), _addr(w2_scales), w2_bits))
+
+    def load_gguf_expert(self, layer: int, expert: int, gate: np.ndarray, up: np.ndarray, down: np.ndarray, gate_up_type: int,
+                         down_type: int, inter: int) -> None:
+        """Upload one expert as raw GGUF blocks (GgufExpertWeights, weights/mod.rs:252): gate/up [inter, hidden], down [hidden, inter],
+        row-major blocks; expert = -1 is the shared expert.  This is the reference's `gguf_native=True` store."""
+        self._need()
+        for a in (gate, up, down):
+            assert isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+        check(self._lib.kr_upload_expert_gguf(self._h, layer, expert, inter, _addr(gate), _addr(up), gate_up_type, _addr(down), down_type))
+        self._has_gguf = True
 
     def fill_synthetic(self, bits: int = 4, seed: int = 0x12345678ABCDEF01, layers: Optional[Sequence[int]] = None) -> None:
         """Synthetic experts with bench_decode_synthetic's value distribution (decode.rs:4379-4392), generated on the GPU."""
@@ -280,7 +291,7 @@ class KrasisEngine:
         self._need("Model not loaded"); return True
 
     def has_gguf(self) -> bool:
-        self._need("Model not loaded"); return False
+        self._need("Model not loaded"); return self._has_gguf
 
     def marlin_w2_padded_n(self) -> int:
         """weights/mod.rs:942-949."""
