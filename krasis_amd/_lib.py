@@ -17,7 +17,7 @@ SYMBOLS = [
     "kr_last_error", "kr_version", "kr_engine_create", "kr_engine_destroy", "kr_engine_get_config",
     "kr_engine_device_bytes", "kr_upload_expert_unified", "kr_upload_expert_gguf", "kr_fill_layer_synthetic",
     "kr_download_expert_unified", "kr_moe_forward", "kr_moe_prefill", "kr_set_routing_config", "kr_set_routing_weights",
-    "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_synchronize", "kr_set_profiling",
+    "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_combine_rows", "kr_synchronize", "kr_set_profiling",
     "kr_get_profile", "kr_decode_create", "kr_decode_destroy", "kr_decode_store_weight_f32", "kr_decode_store_weight_synthetic",
     "kr_decode_download_weight", "kr_decode_store_norm_weight", "kr_decode_configure", "kr_decode_add_la_layer",
     "kr_decode_add_gqa_layer", "kr_decode_set_layer_moe", "kr_decode_set_layer_dense", "kr_decode_set_rope", "kr_decode_finalize",
@@ -81,6 +81,7 @@ def load_library() -> C.CDLL:
                                   C.c_void_p, C.c_void_p]
     lib.kr_forward_moe_routed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.kr_reduce_sum_bf16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.kr_combine_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.kr_synchronize.argtypes = [C.c_void_p]
     lib.kr_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.kr_get_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]

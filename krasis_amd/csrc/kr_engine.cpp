@@ -750,3 +750,15 @@ extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const
     KR_HIP(hipGetLastError());
     return KR_OK;
 }
+
+// Expert-parallel combine (krasis_amd/ep.py): rows returned by the owning ranks are summed per token in routing order with the routing
+// weights, exactly as the single-GPU combine does (moe.rs:661-667).  eo_rows f32 [n_rows,H]; pair_row i32 [M,k] (-1 = skipped slot).
+extern "C" int kr_combine_rows(kr_engine* e, const float* eo_rows, const int32_t* pair_row, const float* wts, void* out, int M, int topk,
+                               int out_dtype, void* stream) {
+    if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
+    if (!is_device_ptr(eo_rows) || !is_device_ptr(pair_row) || !is_device_ptr(wts) || !is_device_ptr(out)) return kr_fail(KR_ERR_VALUE, "kr_combine_rows expects device pointers");
+    KR_HIP(hipSetDevice(e->device));
+    kr_launch_pf_combine(eo_rows, pair_row, wts, M, topk, e->cfg.hidden_size, nullptr, 1.0f, out, out_dtype == KR_OUT_BF16, kr_pick_stream(e, stream));
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+}

@@ -245,12 +245,12 @@ class KrasisEngine:
         return (ids, w, lg) if want_logits else (ids, w)
 
     # ------------------------------------------------------------------ collectives helper (moe.rs:2505)
-    def reduce_sum_bf16(self, input_ptrs: Sequence[int], output_ptr: int, num_elements: int) -> None:
+    def reduce_sum_bf16(self, input_ptrs: Sequence[int], output_ptr: int, num_elements: int, stream: int = 0) -> None:
         if not input_ptrs:
             return
         self._need("Model not loaded")
         arr = (C.c_void_p * len(input_ptrs))(*input_ptrs)
-        check(self._lib.kr_reduce_sum_bf16(self._h, arr, len(input_ptrs), output_ptr, num_elements, None))
+        check(self._lib.kr_reduce_sum_bf16(self._h, arr, len(input_ptrs), output_ptr, num_elements, stream or None))
 
     def synchronize(self) -> None:
         self._need()
