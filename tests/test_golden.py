@@ -1,0 +1,104 @@
+"""Oracle pinned against golden vectors produced by the reference's importable Python operators (tests/golden/make_golden.py).
+
+The reference's Rust decode math and its Python/torch math are two statements of the same operators (HF-equivalent); they differ only in
+summation order / polynomial-vs-libm transcendentals, so these are tolerance tests (tolerances written per case); the GPU<->oracle tests are
+the bit-exact ones.  Together: reference(torch) ~ oracle == HIP.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _bf16_round(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return ((u + r) & 0xFFFF0000).view(np.float32)
+
+
+def test_la_recurrent_matches_reference_python():
+    d = np.load(os.path.join(G, "la_recurrent.npz"))
+    nk, nv, dk, dv, kd, steps = [int(x) for x in d["dims"]]
+    conv_state = np.zeros((2 * nk * dk + nv * dv) * kd, np.float32)
+    state = np.zeros(nv * dk * dv, np.float32)
+    norm_w = np.tile(d["norm_w"], nv)                       # decode_setup.py:855 expands [dv] -> [nv*dv]
+    for t in range(steps):
+        c = O.la_conv(d["qkvz"][t], d["ba"][t], conv_state, d["conv_w"], d["a_log"], d["dt_bias"], float(d["scale"]), nk, nv, dk, dv, kd)
+        conv_state = c["conv_state"]
+        ro, state = O.la_recurrent(state, c["q"], c["k"], c["v"], c["g"], c["beta"], nv, dk, dv)
+        out = O.gated_rmsnorm_silu(ro, c["z"], norm_w, nv, dv, float(d["eps"]))
+        ref = d["out"][t]                                   # bf16-rounded by the reference (linear_attention.py:566)
+        # tolerance: 1 bf16 ulp (2^-8 relative) + poly-sigmoid (5e-5) on values of O(1)
+        np.testing.assert_allclose(out, ref, rtol=2 ** -7, atol=2e-4, err_msg=f"step {t}")
+    # recurrent state: pure f32 on both sides, only summation order differs
+    ref_state = d["final_recur_state"]                      # [nv, dk, dv]
+    got = state.reshape(nv, dk, dv) if state.size == ref_state.size else None
+    alt = state.reshape(nv, dv, dk).transpose(0, 2, 1)
+    err = min(np.abs(got - ref_state).max(), np.abs(alt - ref_state).max())
+    assert err < 2e-5, err
+
+
+def test_la_recurrent_equals_chunked_reference():
+    """The oracle's token-by-token recurrence reproduces the reference's CHUNKED prefill form (linear_attention.py:695) on 150 tokens."""
+    d = np.load(os.path.join(G, "la_chunked.npz"))
+    nk, nv, dk, dv, kd, M = [int(x) for x in d["dims"]]
+    conv_state = np.zeros((2 * nk * dk + nv * dv) * kd, np.float32)
+    state = np.zeros(nv * dk * dv, np.float32)
+    norm_w = np.tile(d["norm_w"], nv)                       # decode_setup.py:855 expands [dv] -> [nv*dv]
+    worst = 0.0
+    for t in range(M):
+        c = O.la_conv(d["qkvz"][t], d["ba"][t], conv_state, d["conv_w"], d["a_log"], d["dt_bias"], float(d["scale"]), nk, nv, dk, dv, kd)
+        conv_state = c["conv_state"]
+        ro, state = O.la_recurrent(state, c["q"], c["k"], c["v"], c["g"], c["beta"], nv, dk, dv)
+        out = O.gated_rmsnorm_silu(ro, c["z"], norm_w, nv, dv, float(d["eps"]))
+        worst = max(worst, float(np.abs(out - d["out"][t]).max() / (np.abs(d["out"][t]).max() + 1e-6)))
+    assert worst < 2 ** -6, worst                            # bf16-rounded output + chunked-vs-sequential f32 order
+
+
+@pytest.mark.parametrize("case", ["softmax_norm", "softmax_raw", "sigmoid_corr", "gptoss"])
+def test_routing_matches_reference_python(case):
+    d = np.load(os.path.join(G, "routing.npz"))
+    g = lambda k: d[f"{case}.{k}"] if f"{case}.{k}" in d.files else None
+    gate, hidden, ids_ref, w_ref = g("gate"), g("hidden"), g("ids"), g("w")
+    k = int(g("k")); scoring = str(g("scoring")); norm = bool(g("norm")); swiglu = float(g("swiglu"))
+    for m in range(hidden.shape[0]):
+        if swiglu > 0:
+            lg = O.route_matmul(gate, hidden[m]) + g("bias")
+            ids, w, _ = O.route_score_topk(lg.astype(np.float32), k, scoring=2)
+        else:
+            ids, w, _ = O.route_decode(gate, hidden[m], k, scoring=0 if scoring == "sigmoid" else 1, norm_topk=norm, e_score_corr=g("corr"))
+        # same expert set; order may differ (heap order vs torch.topk's sorted order)
+        assert sorted(ids.tolist()) == sorted(ids_ref[m].tolist()), (case, m)
+        ref = dict(zip(ids_ref[m].tolist(), w_ref[m].tolist()))
+        tol = 1e-4 if scoring == "sigmoid" else 2e-6         # decode sigmoid is the degree-4 polynomial (decode.rs), ~5e-5 abs
+        for e, wt in zip(ids.tolist(), w.tolist()):
+            assert abs(wt - ref[e]) <= tol + 1e-5 * abs(ref[e]), (case, m, e, wt, ref[e])
+        # engine rule (moe.rs:3035): bf16 dot, iterative argmax -> sorted like torch.topk
+        gb = (np.ascontiguousarray(gate, np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        hb = (np.ascontiguousarray(hidden[m], np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        if swiglu > 0:
+            ids2, w2 = O.route_engine(gb, hb, k, corr_bias=g("bias"), swiglu_limit=swiglu)
+        else:
+            ids2, w2 = O.route_engine(gb, hb, k, sigmoid=(scoring == "sigmoid"), norm_topk=norm, corr_bias=g("corr"))
+        assert ids2.tolist() == ids_ref[m].tolist(), (case, m)
+        np.testing.assert_allclose(w2, w_ref[m], rtol=2e-5, atol=2e-7)
+
+
+def test_gqa_rope_and_attention_match_reference_python():
+    d = np.load(os.path.join(G, "gqa_rope.npz"))
+    nh, nkv, hd, rot, P = [int(x) for x in d["dims"]]
+    half = rot // 2
+    kc = np.zeros((16, nkv * hd), np.uint16); vc = np.zeros((16, nkv * hd), np.uint16)
+    out = None
+    for p in range(P):
+        out, kc, vc = O.gqa_step(d["q"][p].reshape(-1), d["k"][p].reshape(-1), d["v"][p].reshape(-1), None, None, False, nh, nkv, hd, 1e-6,
+                                 d["cos"][:, :half], d["sin"][:, :half], kc, vc, p, 1.0 / np.sqrt(hd))
+    # cached K at every position == reference's roped K, to fp16 storage precision
+    import ctypes as C
+    kf = np.array([O.lib().kro_f16_to_f32(int(x)) for x in kc[:P].reshape(-1)], np.float32).reshape(P, nkv, hd)
+    np.testing.assert_allclose(kf, d["k_rope"], rtol=2 ** -10, atol=2 ** -12)
+    np.testing.assert_allclose(out.reshape(nh, hd), d["attn_last"], rtol=2e-3, atol=2e-3)   # fp16 KV cache
