@@ -21,7 +21,7 @@
 
 struct DWeight { MatSet ms; int rows = 0, cols = 0; };
 
-enum { ATTN_NONE = 0, ATTN_LA = 1, ATTN_GQA = 2 };
+enum { ATTN_NONE = 0, ATTN_LA = 1, ATTN_GQA = 2, ATTN_MLA = 3 };
 enum { MLP_NONE = 0, MLP_MOE = 1, MLP_DENSE = 2 };
 
 struct DLayer {
@@ -33,6 +33,9 @@ struct DLayer {
     // GQA
     int q_wid = -1, k_wid = -1, v_wid = -1, o_wid = -1, gated = 0, nh = 0, nkv = 0, hd = 0; float sm_scale = 1.0f;
     DevBuf q_norm, k_norm, kv_k, kv_v; int q_norm_len = 0, k_norm_len = 0;
+    // MLA (kv_k = compressed-KV cache [max_seq, klr], kv_v = k_pe cache [max_seq, rd], both FP16)
+    int kva_wid = -1, mq_wid = -1, mqa_wid = -1, mqb_wid = -1, klr = 0, nd = 0, rd = 0, vhd = 0, q_a_norm_len = 0;
+    DevBuf w_kc, w_vc, kv_a_norm, q_a_norm, mla_cos, mla_sin; int mla_rope_seq = 0;
     // MLP
     int moe_layer = -1, sgu_wid = -1, sd_wid = -1, sg_wid = -1;
     int gate_wid = -1, up_wid = -1, down_wid = -1;
@@ -51,7 +54,7 @@ struct kr_decode_store {
     DevBuf rope_cos, rope_sin; int rope_half = 0, max_rope_seq = 0;
     int kv_max_seq = 0;
     // scratch
-    DevBuf hid, res, proj_a, proj_b, qbuf, kbuf, vbuf, zbuf, gbuf, betabuf, gatebuf, recur_out, attn_out, logits, gate_val, tok;
+    DevBuf hid, res, proj_a, proj_b, qbuf, kbuf, vbuf, zbuf, gbuf, betabuf, gatebuf, latbuf, recur_out, attn_out, logits, gate_val, tok;
     DevBuf dense_gu;  // [gate(K) | up(K)] of the dense MLP; only [0,inter) of each half is ever written, the padding stays 0
     DevBuf moe_gu, moe_eo, r_logits, r_ids, r_w;  // store-owned so a captured graph never sees them reallocated
     DevBuf step_dev; KrStep* step_host = nullptr;
@@ -99,9 +102,10 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
     for (auto& w : s->weights) { w->ms.q.release(); w->ms.s.release(); }
     for (auto& n : s->norms) n->release();
     for (auto& l : s->layers)
-        for (DevBuf* b : {&l.conv_w, &l.a_log, &l.dt_bias, &l.la_norm_w, &l.conv_state, &l.recur_state, &l.q_norm, &l.k_norm, &l.kv_k, &l.kv_v}) b->release();
+        for (DevBuf* b : {&l.conv_w, &l.a_log, &l.dt_bias, &l.la_norm_w, &l.conv_state, &l.recur_state, &l.q_norm, &l.k_norm, &l.kv_k, &l.kv_v,
+                           &l.w_kc, &l.w_vc, &l.kv_a_norm, &l.q_a_norm, &l.mla_cos, &l.mla_sin}) b->release();
     for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
-                      &s->gbuf, &s->betabuf, &s->gatebuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
+                      &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
                       &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     if (s->step_host) (void)hipHostFree(s->step_host);
     delete s;
@@ -273,6 +277,42 @@ extern "C" int kr_decode_add_gqa_layer(kr_decode_store* s, int input_norm_id, in
     return KR_OK;
 }
 
+// add_decode_mla_layer (decode.rs:2131): w_kc / w_vc arrive as bf16 [nh, nd, klr] / [nh, vhd, klr] and are widened to f32 like the
+// reference does (:2157-2160); q_proj_wid < 0 selects the LoRA query path (q_a_proj -> q_a_norm -> q_b_proj).
+extern "C" int kr_decode_add_mla_layer(kr_decode_store* s, int input_norm_id, int post_attn_norm_id, int kv_a_proj_wid, int o_proj_wid,
+                                       int q_proj_wid, int q_a_proj_wid, int q_b_proj_wid, const uint16_t* w_kc_bf16, size_t w_kc_len,
+                                       const uint16_t* w_vc_bf16, size_t w_vc_len, const float* kv_a_norm, int kv_a_norm_len,
+                                       const float* q_a_norm, int q_a_norm_len, const float* rope_cos, const float* rope_sin,
+                                       int rope_max_seq, int num_heads, int kv_lora_rank, int qk_nope_dim, int qk_rope_dim, int v_head_dim,
+                                       float sm_scale) {
+    if (int rc = need_cfg(s)) return rc;
+    if (!w_kc_bf16 || !w_vc_bf16 || !kv_a_norm || !rope_cos || !rope_sin) return kr_fail(KR_ERR_VALUE, "add_decode_mla_layer: null argument");
+    for (int id : {kv_a_proj_wid, o_proj_wid}) if (int rc = chk_wid(s, id, "add_decode_mla_layer")) return rc;
+    if (q_proj_wid >= 0) { if (int rc = chk_wid(s, q_proj_wid, "add_decode_mla_layer")) return rc; }
+    else for (int id : {q_a_proj_wid, q_b_proj_wid}) if (int rc = chk_wid(s, id, "add_decode_mla_layer (q LoRA)")) return rc;
+    const int nh = num_heads, klr = kv_lora_rank, nd = qk_nope_dim, rd = qk_rope_dim, vhd = v_head_dim;
+    if (klr % 64 || klr > 576 || nd > 640 || nd % 8 || rd % 16 || rd > 256 || nh <= 0 || vhd <= 0)
+        return kr_fail(KR_ERR_VALUE, "MLA geometry unsupported (kv_lora_rank %d, nope %d, rope %d)", klr, nd, rd);
+    if (w_kc_len != (size_t)nh * nd * klr || w_vc_len != (size_t)nh * vhd * klr || kv_a_norm_len != klr)
+        return kr_fail(KR_ERR_VALUE, "MLA weight lengths do not match the geometry");
+    if (s->weights[kv_a_proj_wid]->rows != klr + rd) return kr_fail(KR_ERR_VALUE, "kv_a_proj rows %d != kv_lora_rank + rope", s->weights[kv_a_proj_wid]->rows);
+    KR_HIP(hipSetDevice(s->eng->device));
+    DLayer L; L.input_norm = input_norm_id; L.post_norm = post_attn_norm_id; L.attn = ATTN_MLA;
+    L.kva_wid = kv_a_proj_wid; L.o_wid = o_proj_wid; L.mq_wid = q_proj_wid; L.mqa_wid = q_a_proj_wid; L.mqb_wid = q_b_proj_wid;
+    L.nh = nh; L.klr = klr; L.nd = nd; L.rd = rd; L.vhd = vhd; L.sm_scale = sm_scale; L.mla_rope_seq = rope_max_seq;
+    std::vector<float> tmp(w_kc_len > w_vc_len ? w_kc_len : w_vc_len);
+    auto widen = [&](const uint16_t* src, size_t n) { for (size_t i = 0; i < n; i++) { uint32_t b = (uint32_t)src[i] << 16; memcpy(&tmp[i], &b, 4); } };
+    widen(w_kc_bf16, w_kc_len); if (int rc = upload_f32(L.w_kc, tmp.data(), w_kc_len)) return rc;
+    widen(w_vc_bf16, w_vc_len); if (int rc = upload_f32(L.w_vc, tmp.data(), w_vc_len)) return rc;
+    if (int rc = upload_f32(L.kv_a_norm, kv_a_norm, klr)) return rc;
+    if (q_a_norm && q_a_norm_len > 0) { if (int rc = upload_f32(L.q_a_norm, q_a_norm, q_a_norm_len)) return rc; L.q_a_norm_len = q_a_norm_len; }
+    if (int rc = upload_f32(L.mla_cos, rope_cos, (size_t)rope_max_seq * (rd / 2))) return rc;
+    if (int rc = upload_f32(L.mla_sin, rope_sin, (size_t)rope_max_seq * (rd / 2))) return rc;
+    s->weight_bytes += (w_kc_len + w_vc_len) * 4;
+    s->layers.push_back(std::move(L)); s->graph_ok = false;
+    return KR_OK;
+}
+
 extern "C" int kr_decode_set_layer_moe(kr_decode_store* s, int layer, int moe_layer_idx, int shared_gate_up_wid, int shared_down_wid, int shared_gate_wid) {
     if (int rc = need_cfg(s)) return rc;
     if (layer < 0 || layer >= (int)s->layers.size()) return kr_fail(KR_ERR_VALUE, "layer %d out of range", layer);
@@ -311,7 +351,7 @@ extern "C" int kr_decode_finalize(kr_decode_store* s) {
     if (int rc = need_cfg(s)) return rc;
     if ((int)s->layers.size() != s->n_layers) return kr_fail(KR_ERR_STATE, "configured %d layers but %zu were added", s->n_layers, s->layers.size());
     KR_HIP(hipSetDevice(s->eng->device));
-    size_t pa = 0, pb = 0, qb = 0, kb = 0, vb = 0, zb = 0, ro = 0, ao = 0, gb = 0, dg = 0;
+    size_t pa = 0, pb = 0, qb = 0, kb = 0, vb = 0, zb = 0, ro = 0, ao = 0, gb = 0, dg = 0, lb = 0;
     for (auto& L : s->layers) {
         if (L.attn == ATTN_LA) {
             pa = maxz(pa, s->weights[L.qkvz_wid]->rows); pb = maxz(pb, s->weights[L.ba_wid]->rows);
@@ -321,16 +361,23 @@ extern "C" int kr_decode_finalize(kr_decode_store* s) {
             pa = maxz(pa, s->weights[L.q_wid]->rows); kb = maxz(kb, s->weights[L.k_wid]->rows); vb = maxz(vb, s->weights[L.v_wid]->rows);
             qb = maxz(qb, (size_t)L.nh * L.hd); zb = maxz(zb, (size_t)L.nh * L.hd); ao = maxz(ao, s->weights[L.o_wid]->cols);
         }
+        else if (L.attn == ATTN_MLA) {
+            const size_t hd = (size_t)L.nd + L.rd;
+            pa = maxz(pa, (size_t)L.nh * hd); kb = maxz(kb, (size_t)L.klr + L.rd); qb = maxz(qb, (size_t)L.nh * L.klr); zb = maxz(zb, (size_t)L.nh * L.rd);
+            lb = maxz(lb, (size_t)L.nh * L.klr); ao = maxz(ao, maxz((size_t)L.nh * L.vhd, s->weights[L.o_wid]->cols));
+            if (L.mq_wid < 0) pb = maxz(pb, maxz(s->weights[L.mqa_wid]->rows, s->weights[L.mqb_wid]->cols));
+        }
         if (L.mlp == MLP_DENSE) dg = maxz(dg, 2 * (size_t)s->weights[L.down_wid]->cols);
     }
     ao = maxz(ao, (size_t)s->hidden);
     if (s->proj_a.ensure(maxz(pa, 64) * 4) || s->proj_b.ensure(maxz(pb, 64) * 4) || s->qbuf.ensure(maxz(qb, 64) * 4) || s->kbuf.ensure(maxz(kb, 64) * 4) ||
         s->vbuf.ensure(maxz(vb, 64) * 4) || s->zbuf.ensure(maxz(zb, 64) * 4) || s->recur_out.ensure(maxz(ro, 64) * 4) ||
         s->attn_out.ensure(maxz(ao, 64) * 4) || s->gbuf.ensure(maxz(gb, 64) * 4) || s->betabuf.ensure(maxz(gb, 64) * 4) ||
-        s->gatebuf.ensure(maxz(zb, 64) * 4))
+        s->gatebuf.ensure(maxz(zb, 64) * 4) || s->latbuf.ensure(maxz(lb, 64) * 4))
         return kr_fail(KR_ERR_HIP, "hipMalloc of decode scratch failed");
     if (dg) { if (s->dense_gu.ensure(dg * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed"); KR_HIP(hipMemset(s->dense_gu.p, 0, s->dense_gu.bytes)); }
     KR_HIP(hipMemset(s->proj_a.p, 0, s->proj_a.bytes));
+    KR_HIP(hipMemset(s->proj_b.p, 0, s->proj_b.bytes));
     KR_HIP(hipMemset(s->attn_out.p, 0, s->attn_out.bytes));
     s->graph_ok = false;
     return KR_OK;
@@ -350,6 +397,11 @@ extern "C" int kr_decode_set_state(kr_decode_store* s, int seq_len, int kv_max_s
             if (L.kv_k.ensure(n) || L.kv_v.ensure(n)) return kr_fail(KR_ERR_HIP, "hipMalloc of KV cache failed");
             if (kv_k && kv_k[i]) KR_HIP(hipMemcpy(L.kv_k.p, kv_k[i], n, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_k.p, 0, n));
             if (kv_v && kv_v[i]) KR_HIP(hipMemcpy(L.kv_v.p, kv_v[i], n, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_v.p, 0, n));
+        } else if (L.attn == ATTN_MLA) {   // kv_k[i] = compressed-KV cache, kv_v[i] = k_pe cache (set_decode_state's mla_ckv_ptrs / mla_kpe_ptrs)
+            const size_t nc = (size_t)kv_max_seq * L.klr * 2, np = (size_t)kv_max_seq * L.rd * 2;
+            if (L.kv_k.ensure(nc) || L.kv_v.ensure(np)) return kr_fail(KR_ERR_HIP, "hipMalloc of MLA cache failed");
+            if (kv_k && kv_k[i]) KR_HIP(hipMemcpy(L.kv_k.p, kv_k[i], nc, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_k.p, 0, nc));
+            if (kv_v && kv_v[i]) KR_HIP(hipMemcpy(L.kv_v.p, kv_v[i], np, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_v.p, 0, np));
         } else if (L.attn == ATTN_LA) {
             const size_t cn = (size_t)(2 * L.nk * L.dk + L.nv * L.dv) * L.kd * 4, rn = (size_t)L.nv * L.dk * L.dv * 4;
             if (conv_state && conv_state[i]) KR_HIP(hipMemcpy(L.conv_state.p, conv_state[i], cn, hipMemcpyHostToDevice));
@@ -372,6 +424,11 @@ extern "C" int kr_decode_fill_state_synthetic(kr_decode_store* s, int kv_max_seq
             if (L.kv_k.ensure(n * 2) || L.kv_v.ensure(n * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc of KV cache failed");
             kr_launch_fill_fp16_kv((uint16_t*)L.kv_k.p, n, seed + i * 4 + 0, s->eng->stream);
             kr_launch_fill_fp16_kv((uint16_t*)L.kv_v.p, n, seed + i * 4 + 1, s->eng->stream);
+        } else if (L.attn == ATTN_MLA) {
+            const size_t nc = (size_t)kv_max_seq * L.klr, np = (size_t)kv_max_seq * L.rd;
+            if (L.kv_k.ensure(nc * 2) || L.kv_v.ensure(np * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc of MLA cache failed");
+            kr_launch_fill_fp16_kv((uint16_t*)L.kv_k.p, nc, seed + i * 4 + 0, s->eng->stream);
+            kr_launch_fill_fp16_kv((uint16_t*)L.kv_v.p, np, seed + i * 4 + 1, s->eng->stream);
         } else if (L.attn == ATTN_LA) {
             kr_launch_fill_uniform_f32((float*)L.conv_state.p, (size_t)(2 * L.nk * L.dk + L.nv * L.dv) * L.kd, 0.1f, seed + i * 4 + 2, s->eng->stream);
             kr_launch_fill_uniform_f32((float*)L.recur_state.p, (size_t)L.nv * L.dk * L.dv, 0.01f, seed + i * 4 + 3, s->eng->stream);
@@ -392,6 +449,9 @@ extern "C" int kr_decode_get_state(kr_decode_store* s, int layer, uint16_t* kv_k
         const size_t n = (size_t)s->kv_max_seq * L.nkv * L.hd * 2;
         if (kv_k) KR_HIP(hipMemcpy(kv_k, L.kv_k.p, n, hipMemcpyDeviceToHost));
         if (kv_v) KR_HIP(hipMemcpy(kv_v, L.kv_v.p, n, hipMemcpyDeviceToHost));
+    } else if (L.attn == ATTN_MLA) {
+        if (kv_k) KR_HIP(hipMemcpy(kv_k, L.kv_k.p, (size_t)s->kv_max_seq * L.klr * 2, hipMemcpyDeviceToHost));
+        if (kv_v) KR_HIP(hipMemcpy(kv_v, L.kv_v.p, (size_t)s->kv_max_seq * L.rd * 2, hipMemcpyDeviceToHost));
     } else if (L.attn == ATTN_LA) {
         if (conv_state) KR_HIP(hipMemcpy(conv_state, L.conv_state.p, (size_t)(2 * L.nk * L.dk + L.nv * L.dv) * L.kd * 4, hipMemcpyDeviceToHost));
         if (recur_state) KR_HIP(hipMemcpy(recur_state, L.recur_state.p, (size_t)L.nv * L.dk * L.dv * 4, hipMemcpyDeviceToHost));
@@ -452,6 +512,32 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.k_cache = (uint16_t*)L.kv_k.p; a.v_cache = (uint16_t*)L.kv_v.p; a.q_out = (float*)s->qbuf.p; a.gate = (float*)s->gatebuf.p;
             a.attn_out = (float*)s->attn_out.p; a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.eps = s->eps; a.sm_scale = L.sm_scale;
             PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
+        }
+        else if (L.attn == ATTN_MLA) {
+            if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no MLA cache for layer %zu)", li);
+            if (L.mla_rope_seq < s->kv_max_seq) return kr_fail(KR_ERR_VALUE, "MLA rope table (%d) shorter than kv_max_seq (%d)", L.mla_rope_seq, s->kv_max_seq);
+            float* kv_out = (float*)s->kbuf.p; float* q_full = (float*)s->proj_a.p;
+            if (L.mq_wid >= 0) {   // direct query projection shares the activation with kv_a_proj: one launch
+                const KrMatDev mats[2] = {mv(s, L.kva_wid), mv(s, L.mq_wid)};
+                float* ys[2] = {kv_out, q_full};
+                if (mats[0].bits == mats[1].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 2, hid, 1, st));
+                else { PROF(PK_MATVEC, kr_launch_matvec(mats[0], hid, 1, ys[0], st)); PROF(PK_MATVEC, kr_launch_matvec(mats[1], hid, 1, ys[1], st)); }
+            } else {               // LoRA: q_a_proj -> sequential RMSNorm -> q_b_proj (decode.rs:3036-3079)
+                const KrMatDev mats[2] = {mv(s, L.kva_wid), mv(s, L.mqa_wid)};
+                float* ys[2] = {kv_out, (float*)s->proj_b.p};
+                if (mats[0].bits == mats[1].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 2, hid, 1, st));
+                else { PROF(PK_MATVEC, kr_launch_matvec(mats[0], hid, 1, ys[0], st)); PROF(PK_MATVEC, kr_launch_matvec(mats[1], hid, 1, ys[1], st)); }
+                if (L.q_a_norm_len) PROF(PK_RMSNORM, kr_launch_rmsnorm_seq((float*)s->proj_b.p, (const float*)L.q_a_norm.p, s->weights[L.mqa_wid]->rows, s->eps, st));
+                PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.mqb_wid), s->proj_b.p, 1, q_full, st));
+            }
+            KrMlaArgs a{};
+            a.step = step; a.kv_out = kv_out; a.q_full = q_full; a.kv_a_norm = (const float*)L.kv_a_norm.p; a.w_kc = (const float*)L.w_kc.p;
+            a.w_vc = (const float*)L.w_vc.p; a.rope_cos = (const float*)L.mla_cos.p; a.rope_sin = (const float*)L.mla_sin.p;
+            a.ckv_cache = (uint16_t*)L.kv_k.p; a.kpe_cache = (uint16_t*)L.kv_v.p; a.q_abs = (float*)s->qbuf.p; a.q_pe = (float*)s->zbuf.p;
+            a.attn_lat = (float*)s->latbuf.p; a.v_proj = (float*)s->attn_out.p;
+            a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale;
+            PROF(PK_GQA, kr_launch_mla(a, s->kv_max_seq, st));
             PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }
         PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st));

@@ -19,6 +19,18 @@ struct KrGqaArgs {
     int gated, nh, nkv, hd; float eps, sm_scale;
 };
 
+struct KrMlaArgs {   // decode.rs:2993-3252
+    const KrStep* step;
+    const float* kv_out;      // kv_a_proj output [klr + rd]
+    const float* q_full;      // q (or q_b) projection output [nh * (nd + rd)]
+    const float *kv_a_norm, *w_kc, *w_vc, *rope_cos, *rope_sin;
+    uint16_t *ckv_cache, *kpe_cache;   // FP16 [max_seq, klr] / [max_seq, rd]
+    float *q_abs, *q_pe, *attn_lat, *v_proj;
+    int nh, klr, nd, rd, vhd; float eps, sm_scale;
+};
+void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s);
+void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s);
+
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s);
 struct KrNormSrc {   // where the value added to the residual comes from (see kr_fused_add_rmsnorm_kernel)
     int mode;        // 0 hidden buffer, 1 embedding row of the current token, 2 MoE epilogue of the previous layer

@@ -319,7 +319,7 @@ size_t kr_pf_gemm_lds_bytes() { return (size_t)(2 * PF_BM + PF_BN) * PF_LDK + 2 
 
 void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, hipStream_t st) {
     const int n = M * topk;
-    hipMemsetAsync(s.counts, 0, (size_t)E * 4, st);
+    (void)hipMemsetAsync(s.counts, 0, (size_t)E * 4, st);
     hipLaunchKernelGGL(kr_pf_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E, s.counts);
     hipLaunchKernelGGL(kr_pf_scan_kernel, dim3(1), dim3(1024), 0, st, s.counts, E, s.offsets, s.cursor, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles);
     hipLaunchKernelGGL(kr_pf_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E, s.offsets, s.cursor, s.row_pair, s.pair_row);

@@ -107,6 +107,17 @@ class CpuDecodeStore:
                                                 q_norm_ptr or None, q_norm_len, k_norm_ptr or None, k_norm_len, int(gated), num_heads,
                                                 num_kv_heads, head_dim, sm_scale))
 
+    def add_decode_mla_layer(self, input_norm_id, post_attn_norm_id, kv_a_proj_wid, o_proj_wid, q_proj_wid, q_a_proj_wid, q_b_proj_wid,
+                             w_kc_ptr, w_kc_len, w_vc_ptr, w_vc_len, kv_a_norm_ptr, kv_a_norm_len, q_a_norm_ptr, q_a_norm_len, rope_cos_ptr,
+                             rope_sin_ptr, rope_len, rope_max_seq, num_heads, kv_lora_rank, qk_nope_dim, qk_rope_dim, v_head_dim, sm_scale) -> None:
+        """decode.rs:2131 (same positional arguments; None for an absent projection id)."""
+        self._need()
+        f = lambda v: -1 if v is None else v
+        check(self._lib.kr_decode_add_mla_layer(self._h, input_norm_id, post_attn_norm_id, kv_a_proj_wid, o_proj_wid, f(q_proj_wid),
+                                                f(q_a_proj_wid), f(q_b_proj_wid), w_kc_ptr, w_kc_len, w_vc_ptr, w_vc_len, kv_a_norm_ptr,
+                                                kv_a_norm_len, q_a_norm_ptr or None, q_a_norm_len, rope_cos_ptr, rope_sin_ptr, rope_max_seq,
+                                                num_heads, kv_lora_rank, qk_nope_dim, qk_rope_dim, v_head_dim, sm_scale))
+
     def set_decode_layer_moe(self, layer_idx: int, route_id: int, moe_layer_idx: int, shared_gate_up_wid: Optional[int] = None,
                              shared_down_wid: Optional[int] = None, shared_gate_wid: Optional[int] = None) -> None:
         self._need()
@@ -130,6 +141,9 @@ class CpuDecodeStore:
         self._need()
         n = self._n_layers
         mk = lambda xs: (C.c_void_p * n)(*[(x or None) for x in xs])
+        if mla_ckv_ptrs is not None:   # MLA layers keep their caches in the kv_k / kv_v slots of the C ABI
+            kv_k_ptrs = [a or b for a, b in zip(list(kv_k_ptrs) + [0] * n, mla_ckv_ptrs)][:n]
+            kv_v_ptrs = [a or b for a, b in zip(list(kv_v_ptrs) + [0] * n, mla_kpe_ptrs)][:n]
         check(self._lib.kr_decode_set_state(self._h, seq_len, kv_max_seq, mk(kv_k_ptrs), mk(kv_v_ptrs), mk(conv_state_ptrs), mk(recur_state_ptrs)))
 
     def fill_state_synthetic(self, kv_max_seq: int, seed: int = 7) -> None:

@@ -1095,6 +1095,88 @@ void kro_gqa_step(const float* q_in, float* k, float* v, const float* q_norm, in
     free(q); free(gate); free(sc);
 }
 
+/* ---- G5: MLA decode attention (decode.rs:2993-3252) ---- */
+/* mla_attn_dot_fp16_avx2 (decode.rs:4286): two 8-lane fma accumulators over alternating 8-blocks, (acc0+acc1) then hsum, scalar tail */
+static float mla_dot_f32_f16(const float* q, const uint16_t* c, int dim) {
+    int n8 = dim / 8; float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int chunks = n8 / 2, i = 0;
+    for (int ch = 0; ch < chunks; ch++) {
+        for (int j = 0; j < 8; j++) a0[j] = fmaf(q[i * 8 + j], kro_f16_to_f32(c[i * 8 + j]), a0[j]);
+        for (int j = 0; j < 8; j++) a1[j] = fmaf(q[(i + 1) * 8 + j], kro_f16_to_f32(c[(i + 1) * 8 + j]), a1[j]);
+        i += 2;
+    }
+    if (n8 % 2) for (int j = 0; j < 8; j++) a0[j] = fmaf(q[i * 8 + j], kro_f16_to_f32(c[i * 8 + j]), a0[j]);
+    float s8[8]; for (int j = 0; j < 8; j++) s8[j] = a0[j] + a1[j];
+    float r = hsum8(s8);
+    for (int t = n8 * 8; t < dim; t++) r += q[t] * kro_f16_to_f32(c[t]);
+    return r;
+}
+
+/* plain sequential RMSNorm used for kv_a_norm / q_a_norm (decode.rs:3023-3032, 3053-3062): scalar sum, x *= rms * w */
+void kro_rmsnorm_seq(float* x, const float* w, int n, float eps) {
+    float ss = 0.0f; for (int i = 0; i < n; i++) ss += x[i] * x[i];
+    float rms = 1.0f / sqrtf(ss / (float)n + eps);
+    for (int i = 0; i < n; i++) x[i] *= rms * w[i];
+}
+
+/* kv_out = kv_a_proj output [klr + rd]; q_full = q (or q_b) projection output [nh * (nd + rd)] (modified in place like the reference);
+ * w_kc f32 [nh, nd, klr]; w_vc f32 [nh, vhd, klr]; caches FP16 [max_seq, klr] / [max_seq, rd]; out v_projected [nh * vhd]. */
+void kro_mla_step(float* kv_out, float* q_full, const float* kv_a_norm, const float* w_kc, const float* w_vc,
+                  const float* rope_cos, const float* rope_sin, int nh, int klr, int nd, int rd, int vhd, float eps, float sm_scale,
+                  uint16_t* ckv_cache, uint16_t* kpe_cache, int position, float* v_projected) {
+    int hd = nd + rd, half = rd / 2, seq = position + 1;
+    float* ckv = (float*)malloc(4 * (size_t)klr);
+    memcpy(ckv, kv_out, 4 * (size_t)klr);
+    kro_rmsnorm_seq(ckv, kv_a_norm, klr, eps);
+    float tmp[256];
+    /* de-interleave k_pe (decode.rs:3098-3107) */
+    for (int i = 0; i < half; i++) { tmp[i] = kv_out[klr + 2 * i]; tmp[half + i] = kv_out[klr + 2 * i + 1]; }
+    memcpy(kv_out + klr, tmp, 4 * (size_t)rd);
+    const float* cs = rope_cos + (size_t)position * half; const float* sn = rope_sin + (size_t)position * half;
+    for (int h = 0; h < nh; h++) { /* decode.rs:3113-3128 */
+        float* b = q_full + (size_t)h * hd + nd;
+        for (int i = 0; i < half; i++) { tmp[i] = b[2 * i]; tmp[half + i] = b[2 * i + 1]; }
+        for (int i = 0; i < half; i++) { float x1 = tmp[i], x2 = tmp[half + i]; b[i] = x1 * cs[i] - x2 * sn[i]; b[half + i] = x2 * cs[i] + x1 * sn[i]; }
+    }
+    { float* kpe = kv_out + klr; /* decode.rs:3131-3140 */
+      for (int i = 0; i < half; i++) { float x1 = kpe[i], x2 = kpe[half + i]; kpe[i] = x1 * cs[i] - x2 * sn[i]; kpe[half + i] = x2 * cs[i] + x1 * sn[i]; } }
+    /* absorb (decode.rs:4508): out[h][j] = fma(q[h][i], w_kc[h][i][j], out) for i ascending */
+    float* qabs = (float*)calloc((size_t)nh * klr, 4);
+    int klr8 = klr / 8;
+    for (int h = 0; h < nh; h++) for (int i = 0; i < nd; i++) {
+        float qv = q_full[(size_t)h * hd + i]; const float* wr = w_kc + ((size_t)h * nd + i) * klr; float* o = qabs + (size_t)h * klr;
+        for (int j = 0; j < klr8 * 8; j++) o[j] = fmaf(qv, wr[j], o[j]);
+    }
+    for (int i = 0; i < klr; i++) ckv_cache[(size_t)position * klr + i] = kro_f32_to_f16(ckv[i]);
+    for (int i = 0; i < rd; i++) kpe_cache[(size_t)position * rd + i] = kro_f32_to_f16(kv_out[klr + i]);
+    float* sc = (float*)malloc(4 * (size_t)seq); float* ao = (float*)malloc(4 * (size_t)klr);
+    for (int h = 0; h < nh; h++) {
+        float mx = -INFINITY;
+        for (int t = 0; t < seq; t++) {
+            float s = mla_dot_f32_f16(qabs + (size_t)h * klr, ckv_cache + (size_t)t * klr, klr);
+            s += mla_dot_f32_f16(q_full + (size_t)h * hd + nd, kpe_cache + (size_t)t * rd, rd);
+            s *= sm_scale; sc[t] = s; if (s > mx) mx = s;
+        }
+        float se = 0.0f; for (int t = 0; t < seq; t++) { float e = expf(sc[t] - mx); sc[t] = e; se += e; }
+        float inv = 1.0f / se; for (int t = 0; t < seq; t++) sc[t] *= inv;
+        for (int j = 0; j < klr; j++) ao[j] = 0.0f;   /* decode.rs:4326: only the klr8*8 prefix is touched; klr % 8 == 0 in every model */
+        for (int t = 0; t < seq; t++) { float w = sc[t]; const uint16_t* c = ckv_cache + (size_t)t * klr; for (int j = 0; j < klr8 * 8; j++) ao[j] = fmaf(w, kro_f16_to_f32(c[j]), ao[j]); }
+        /* w_vc projection (decode.rs:4555): two accumulators, (acc0+acc1), hsum */
+        for (int o = 0; o < vhd; o++) {
+            const float* wr = w_vc + ((size_t)h * vhd + o) * klr; float a0[8] = {0,0,0,0,0,0,0,0}, a1[8] = {0,0,0,0,0,0,0,0}; int chunks = klr8 / 2, j = 0;
+            for (int ch = 0; ch < chunks; ch++) {
+                for (int l = 0; l < 8; l++) a0[l] = fmaf(wr[j * 8 + l], ao[j * 8 + l], a0[l]);
+                for (int l = 0; l < 8; l++) a1[l] = fmaf(wr[(j + 1) * 8 + l], ao[(j + 1) * 8 + l], a1[l]);
+                j += 2;
+            }
+            if (klr8 % 2) for (int l = 0; l < 8; l++) a0[l] = fmaf(wr[j * 8 + l], ao[j * 8 + l], a0[l]);
+            float s8[8]; for (int l = 0; l < 8; l++) s8[l] = a0[l] + a1[l];
+            v_projected[(size_t)h * vhd + o] = hsum8(s8);
+        }
+    }
+    free(ckv); free(qabs); free(sc); free(ao);
+}
+
 int kro_sample_greedy(const float* logits, int n) { /* decode.rs:3718: first max wins */
     int best = 0; float bv = logits[0];
     for (int i = 1; i < n; i++) if (logits[i] > bv) { bv = logits[i]; best = i; }

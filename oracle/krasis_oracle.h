@@ -152,6 +152,11 @@ void kro_gqa_step(const float* q_in, float* k, float* v, const float* q_norm, in
                   int k_norm_len, int gated, int nh, int nkv, int hd, float eps, const float* rope_cos,
                   const float* rope_sin, int rope_half, uint16_t* k_cache, uint16_t* v_cache, int max_seq, int position,
                   float sm_scale, float* attn_out);
+/* G5 MLA (decode.rs:2993-3252 driver; :4286 dot, :4326 weighted sum, :4508 absorb, :4555 w_vc) */
+void kro_rmsnorm_seq(float* x, const float* w, int n, float eps);                                                     /* decode.rs:3023-3032 */
+void kro_mla_step(float* kv_out, float* q_full, const float* kv_a_norm, const float* w_kc, const float* w_vc,
+                  const float* rope_cos, const float* rope_sin, int nh, int klr, int nd, int rd, int vhd, float eps, float sm_scale,
+                  uint16_t* ckv_cache, uint16_t* kpe_cache, int position, float* v_projected);
 int  kro_sample_greedy(const float* logits, int n);                                                                   /* decode.rs:3718 */
 
 /* ---- H: GPU prefill semantics (third-party sglang fused_marlin_moe 0.5.9; parity unpinned) ---- */

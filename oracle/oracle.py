@@ -512,6 +512,23 @@ def gqa_step(q_in, k, v, q_norm, k_norm, gated, nh, nkv, hd, eps, rope_cos, rope
     return out, kc, vc
 
 
+def rmsnorm_seq(x, w, eps):
+    x = _c(x, np.float32).copy()
+    lib().kro_rmsnorm_seq(_p(x), _p(_c(w, np.float32)), x.size, C.c_float(eps))
+    return x
+
+
+def mla_step(kv_out, q_full, kv_a_norm, w_kc, w_vc, rope_cos, rope_sin, nh, klr, nd, rd, vhd, eps, sm_scale, ckv_cache, kpe_cache, position):
+    """Returns (v_projected [nh*vhd], ckv_cache, kpe_cache) with the caches updated at `position` (FP16 bits as u16)."""
+    kv = _c(kv_out, np.float32).copy(); q = _c(q_full, np.float32).copy()
+    ck = _c(ckv_cache, np.uint16).copy(); kp = _c(kpe_cache, np.uint16).copy()
+    out = np.empty(nh * vhd, np.float32)
+    lib().kro_mla_step(_p(kv), _p(q), _p(_c(kv_a_norm, np.float32)), _p(_c(w_kc, np.float32)), _p(_c(w_vc, np.float32)),
+                       _p(_c(rope_cos, np.float32)), _p(_c(rope_sin, np.float32)), nh, klr, nd, rd, vhd, C.c_float(eps), C.c_float(sm_scale),
+                       _p(ck), _p(kp), position, _p(out))
+    return out, ck, kp
+
+
 def sample_greedy(logits) -> int:
     lg = _c(logits, np.float32)
     return int(lib().kro_sample_greedy(_p(lg), lg.size))

@@ -151,6 +151,38 @@ def golden_gqa_rope(attn):
                         attn_last=out.numpy())
 
 
+def golden_mla(attn):
+    """MLA absorbed decode attention: the reference's own de-interleave + RoPE (attention.py:165-211) around the flashinfer MLA math
+    (scores = q_abs.ckv + q_pe.kpe, softmax, sum p.ckv, then w_vc), stated in plain torch f32."""
+    nh, klr, nd, rd, vhd, theta, P, eps = 4, 512, 128, 64, 128, 10000.0, 7, 1e-6
+    a = attn.MLAAttention.__new__(attn.MLAAttention)
+    a.device, a.qk_rope_dim, a.rope_theta, a._rope_cos_sin = torch.device("cpu"), rd, theta, None
+    a.cfg = types.SimpleNamespace(rope_scaling={"factor": 40.0, "original_max_position_embeddings": 4096, "beta_fast": 32.0, "beta_slow": 1.0,
+                                                "mscale_all_dim": 0.707})            # V2-Lite's YaRN settings
+    g = torch.Generator().manual_seed(17)
+    r = lambda *s, amp=1.0: (torch.rand(*s, generator=g) * 2 - 1) * amp
+    kv_out = r(P, klr + rd)                      # kv_a_proj outputs per position
+    q_full = r(P, nh, nd + rd)                   # q_proj outputs per position
+    kv_a_norm = r(klr) * 0.5 + 1.0
+    w_kc = r(nh, nd, klr, amp=0.1).to(torch.bfloat16).float()
+    w_vc = r(nh, vhd, klr, amp=0.1).to(torch.bfloat16).float()
+    cos, sin = a._get_rope_cos_sin(P)
+    pos = torch.arange(P)
+    q_pe, k_pe = a._apply_rope(q_full[:, :, nd:], kv_out[:, None, klr:], pos)
+    ckv = kv_out[:, :klr]
+    ckv = ckv * torch.rsqrt(ckv.pow(2).mean(-1, keepdim=True) + eps) * kv_a_norm
+    q_abs = torch.einsum("hi,hij->hj", q_full[P - 1, :, :nd], w_kc)                      # [nh, klr]
+    sm = 1.0 / ((nd + rd) ** 0.5)
+    s = (q_abs @ ckv.T + q_pe[P - 1] @ k_pe[:, 0, :].T) * sm                               # [nh, P]
+    p = torch.softmax(s, dim=-1)
+    ao = p @ ckv                                                                           # [nh, klr]
+    vp = torch.einsum("hoj,hj->ho", w_vc, ao)                                              # [nh, vhd]
+    np.savez_compressed(os.path.join(OUT, "mla.npz"), dims=np.array([nh, klr, nd, rd, vhd, P], np.int32), eps=np.float32(eps),
+                        sm_scale=np.float32(sm), kv_out=kv_out.numpy(), q_full=q_full.reshape(P, -1).numpy(), kv_a_norm=kv_a_norm.numpy(),
+                        w_kc=w_kc.numpy(), w_vc=w_vc.numpy(), cos=cos.float().numpy(), sin=sin.float().numpy(),
+                        k_pe_rope=k_pe[:, 0, :].float().numpy(), ckv_normed=ckv.numpy(), v_projected_last=vp.numpy())
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)
@@ -159,6 +191,7 @@ if __name__ == "__main__":
     golden_la_chunked(la)
     golden_routing(layer)
     golden_gqa_rope(attn)
+    golden_mla(attn)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

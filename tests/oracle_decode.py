@@ -51,6 +51,19 @@ class OracleDecode:
                 ao, L["kv_k"], L["kv_v"] = O.gqa_step(q, k, v, L["q_norm"], L["k_norm"], L["gated"], L["nh"], L["nkv"], L["hd"], self.eps,
                                                      self.rope[0], self.rope[1], L["kv_k"], L["kv_v"], pos, L["sm_scale"])
                 self.hidden = self.matvec(L["o"], ao)
+            elif L["attn"] == "mla":                                         # decode.rs:2993-3252
+                kv_out = self.matvec(L["kv_a"], self.hidden)
+                if L.get("q") is not None:
+                    q_full = self.matvec(L["q"], self.hidden)
+                else:
+                    qc = self.matvec(L["q_a"], self.hidden)
+                    if L.get("q_a_norm") is not None:
+                        qc = O.rmsnorm_seq(qc, L["q_a_norm"], self.eps)
+                    pad = np.zeros(self.weights[L["q_b"]][3], F); pad[: qc.size] = qc
+                    q_full = self.matvec(L["q_b"], pad)
+                vp, L["ckv"], L["kpe"] = O.mla_step(kv_out, q_full, L["kv_a_norm"], L["w_kc"], L["w_vc"], L["cos"], L["sin"], L["nh"], L["klr"],
+                                                   L["nd"], L["rd"], L["vhd"], self.eps, L["sm_scale"], L["ckv"], L["kpe"], pos)
+                self.hidden = self.matvec(L["o"], vp)
             self.hidden, self.residual = O.fused_add_rmsnorm(self.hidden, self.residual, self.norms[L["post_norm"]], self.eps, False, self.nbo)
             if L.get("mlp") == "moe":
                 ids, w, _ = O.route_decode(L["gate"], self.hidden, self.topk, self.scoring, self.norm_topk, L.get("bias"), L.get("esc"))

@@ -102,3 +102,17 @@ def test_gqa_rope_and_attention_match_reference_python():
     kf = np.array([O.lib().kro_f16_to_f32(int(x)) for x in kc[:P].reshape(-1)], np.float32).reshape(P, nkv, hd)
     np.testing.assert_allclose(kf, d["k_rope"], rtol=2 ** -10, atol=2 ** -12)
     np.testing.assert_allclose(out.reshape(nh, hd), d["attn_last"], rtol=2e-3, atol=2e-3)   # fp16 KV cache
+
+
+def test_mla_matches_reference_python():
+    d = np.load(os.path.join(G, "mla.npz"))
+    nh, klr, nd, rd, vhd, P = [int(x) for x in d["dims"]]
+    ck = np.zeros((8, klr), np.uint16); kp = np.zeros((8, rd), np.uint16)
+    out = None
+    for p in range(P):
+        out, ck, kp = O.mla_step(d["kv_out"][p], d["q_full"][p], d["kv_a_norm"], d["w_kc"], d["w_vc"], d["cos"], d["sin"], nh, klr, nd, rd, vhd,
+                                 float(d["eps"]), float(d["sm_scale"]), ck, kp, p)
+    f16 = lambda a: np.array([O.lib().kro_f16_to_f32(int(x)) for x in a.reshape(-1)], np.float32).reshape(a.shape)
+    np.testing.assert_allclose(f16(kp[:P]), d["k_pe_rope"], rtol=2 ** -10, atol=2 ** -12)     # fp16 cache of the reference's roped k_pe
+    np.testing.assert_allclose(f16(ck[:P]), d["ckv_normed"], rtol=2 ** -10, atol=2 ** -12)
+    np.testing.assert_allclose(out.reshape(nh, vhd), d["v_projected_last"], rtol=3e-3, atol=3e-3)   # fp16 KV cache

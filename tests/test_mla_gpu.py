@@ -1,0 +1,107 @@
+"""GPU parity of the MLA decode arm (DeepSeek-V2-Lite shape family: dense layer 0, MoE layers with an un-gated shared expert, MLA with
+the direct query projection; plus the V3-style LoRA query path) against the oracle driver -- logits and both FP16 caches BIT FOR BIT."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.oracle_decode import OracleDecode
+from tests.util import make_experts, upload
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _ptr(a):
+    return a.ctypes.data
+
+
+def build(seed=0, lora=False, klr=512, nh=4):
+    from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
+    rng = np.random.default_rng(seed)
+    H, V, E, k, I, SI = 256, 384, 8, 3, 128, 256           # shared expert = 2 x I like V2-Lite (n_shared_experts = 2)
+    nd, rd, vhd, qlr = 128, 64, 128, 384
+    kv_max, nL = 24, 2
+    emb = ((rng.random((V, H)) - 0.5) * 0.2).astype(F)
+    eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, nL, 2, 1.0))
+    eng.set_routing_config("softmax", False, k, E, H)       # V2-Lite: softmax, no top-k renormalisation
+    st = CpuDecodeStore(128, True, False); st.set_moe_store(eng)
+    orc = OracleDecode(H, 1e-6, False, k, 1, False, 1.0, emb, V)
+    keep = [emb]
+
+    def W(rows, cols, scale=0.05):
+        w = (rng.standard_normal((rows, cols)) * scale).astype(F); keep.append(w)
+        return st.store_weight_f32(_ptr(w), rows, cols, 4), orc.store_weight_f32(w, 4)
+
+    def N(n):
+        w = (rng.random(n) * 0.2 + 0.9).astype(F); keep.append(w)
+        return st.store_norm_weight(_ptr(w), n), orc.store_norm(w)
+
+    fin = N(H); lm = W(V, H)
+    st.configure_decode(H, nL, 1e-6, fin[0], lm[0], V, k, 1, False, 1.0, _ptr(emb))
+    orc.final_norm, orc.lm_head = fin[1], lm[1]
+    half = rd // 2
+    ang = np.arange(kv_max)[:, None] * (1.0 / 10000.0 ** (2 * np.arange(half) / rd))[None, :]
+    cos, sin = np.cos(ang).astype(F), np.sin(ang).astype(F); keep += [cos, sin]
+    state_k, state_v = [None] * nL, [None] * nL
+    for li in range(nL):
+        n_in, n_post = N(H), N(H)
+        kv_a = W(klr + rd, H, 0.08); o = W(H, nh * vhd)
+        if lora:
+            q_a = W(qlr, H, 0.08); q_b = W(nh * (nd + rd), qlr, 0.08); q = (None, None)
+            qan = (rng.random(qlr) + 0.5).astype(F); keep.append(qan)
+        else:
+            q = W(nh * (nd + rd), H, 0.08); q_a = q_b = (None, None); qan = None
+        w_kc = O.f32_to_bf16((rng.standard_normal((nh, nd, klr)) * 0.06).astype(F)); w_vc = O.f32_to_bf16((rng.standard_normal((nh, vhd, klr)) * 0.06).astype(F))
+        kvn = (rng.random(klr) + 0.5).astype(F); keep += [w_kc, w_vc, kvn]
+        sm = F(1.0 / np.sqrt(nd + rd))
+        st.add_decode_mla_layer(n_in[0], n_post[0], kv_a[0], o[0], q[0], q_a[0], q_b[0], _ptr(w_kc), w_kc.size, _ptr(w_vc), w_vc.size, _ptr(kvn), klr,
+                                _ptr(qan) if qan is not None else 0, qlr if qan is not None else 0, _ptr(cos), _ptr(sin), half, kv_max, nh, klr, nd, rd, vhd,
+                                float(sm))
+        ck = O.f32_to_f16_bits((rng.standard_normal((kv_max, klr)) * 0.5).astype(F)); kp = O.f32_to_f16_bits((rng.standard_normal((kv_max, rd)) * 0.5).astype(F))
+        state_k[li], state_v[li] = ck, kp
+        L = dict(in_norm=n_in[1], post_norm=n_post[1], attn="mla", kv_a=kv_a[1], o=o[1], q=q[1], q_a=q_a[1], q_b=q_b[1], q_a_norm=qan, kv_a_norm=kvn,
+                 w_kc=O.bf16_to_f32(w_kc), w_vc=O.bf16_to_f32(w_vc), cos=cos, sin=sin, nh=nh, klr=klr, nd=nd, rd=rd, vhd=vhd, sm_scale=sm,
+                 ckv=ck.copy(), kpe=kp.copy())
+        if li == 0:                                          # first_k_dense_replace = 1
+            DI = 384
+            gw = W(DI, H); uw = W(DI, H); dw = W(H, DI)
+            st.set_decode_layer_dense(li, gw[0], uw[0], dw[0]); L.update(mlp="dense", gate_w=gw[1], up_w=uw[1], down_w=dw[1])
+        else:
+            experts = make_experts(rng, E, H, I); upload(eng, li, experts)
+            gate = ((rng.random((E, H)) - 0.5) * 0.1).astype(F); keep.append(gate)
+            eng.set_route_weight_f32(li, gate, None, None)
+            sgu = W(2 * SI, H); sd = W(H, SI)
+            st.set_decode_layer_moe(li, li, li, sgu[0], sd[0], None)
+            L.update(mlp="moe", gate=gate, experts=experts, sgu=sgu[1], sd=sd[1])
+        orc.layers.append(L)
+    st.finalize_decode()
+    z = lambda xs: [(_ptr(x) if x is not None else 0) for x in xs]
+    st.set_decode_state(5, kv_max, [0] * nL, [0] * nL, [0] * nL, [0] * nL, z(state_k), z(state_v))
+    return st, eng, orc, keep, dict(V=V, nL=nL, kv_max=kv_max, klr=klr, rd=rd)
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(lora=True, seed=2), dict(klr=256, nh=3, seed=4)])
+@pytest.mark.parametrize("graph", [True, False])
+def test_mla_decode_step_bit_exact(cfg, graph):
+    st, eng, orc, keep, d = build(**cfg)
+    st.set_use_graph(graph)
+    tok = 9
+    for step, pos in enumerate([5, 6, 7]):
+        logits = np.empty(d["V"], F)
+        st.decode_step(tok, pos, logits.ctypes.data)
+        ref = orc.step(tok, pos)
+        assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (step, float(np.max(np.abs(logits - ref))))
+        tok = st.last_token()
+        assert tok == O.sample_greedy(ref)
+    for li in range(d["nL"]):
+        ck = np.empty((d["kv_max"], d["klr"]), np.uint16); kp = np.empty((d["kv_max"], d["rd"]), np.uint16)
+        st.get_decode_state(li, ck, kp, None, None)
+        assert np.array_equal(ck, orc.layers[li]["ckv"]) and np.array_equal(kp, orc.layers[li]["kpe"])
+
+
+def test_mla_geometry_errors():
+    from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
+    eng = KrasisEngine(); eng.configure(ModelConfig(256, 128, 8, 2, 1, 0, 1.0))
+    st = CpuDecodeStore(128, True, False); st.set_moe_store(eng)
+    with pytest.raises(RuntimeError):                        # configure_decode first (decode.rs:2153-2154)
+        st.add_decode_mla_layer(0, 0, 0, 0, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 512, 128, 64, 128, 0.1)
