@@ -56,6 +56,7 @@ struct kr_decode_store {
     // scratch
     DevBuf hid, res, proj_a, proj_b, qbuf, kbuf, vbuf, zbuf, gbuf, betabuf, gatebuf, latbuf, recur_out, attn_out, logits, gate_val, tok;
     DevBuf dense_gu;  // [gate(K) | up(K)] of the dense MLP; only [0,inter) of each half is ever written, the padding stays 0
+    DevBuf hid2, res2, r_counter, argmax_scratch; bool fuse_router = true;   // outputs of the fused norm+router launch (its inputs stay readable for every workgroup)
     DevBuf moe_gu, moe_eo, r_logits, r_ids, r_w;  // store-owned so a captured graph never sees them reallocated
     DevBuf step_dev; KrStep* step_host = nullptr;
     size_t weight_bytes = 0;
@@ -106,7 +107,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                            &l.w_kc, &l.w_vc, &l.kv_a_norm, &l.q_a_norm, &l.mla_cos, &l.mla_sin}) b->release();
     for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
-                      &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
+                      &s->hid2, &s->res2, &s->r_counter, &s->argmax_scratch, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     if (s->step_host) (void)hipHostFree(s->step_host);
     delete s;
 }
@@ -226,8 +227,10 @@ extern "C" int kr_decode_configure(kr_decode_store* s, int hidden, int n_layers,
         KR_HIP(hipStreamSynchronize(s->eng->stream));
     }
     if (s->hid.ensure((size_t)hidden * 4) || s->res.ensure((size_t)hidden * 4) || s->logits.ensure((size_t)vocab * 4) ||
-        s->gate_val.ensure(64) || s->tok.ensure(64))
+        s->gate_val.ensure(64) || s->tok.ensure(64) || s->hid2.ensure((size_t)hidden * 4) || s->res2.ensure((size_t)hidden * 4) || s->r_counter.ensure(64) || s->argmax_scratch.ensure(1024))
         return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    KR_HIP(hipMemset(s->r_counter.p, 0, 64));
+    KR_HIP(hipMemset(s->argmax_scratch.p, 0, 1024));
     s->configured = true; s->graph_ok = false;
     return KR_OK;
 }
@@ -473,10 +476,11 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
     KrNormSrc src{}; src.mode = 1; src.emb = (const float*)s->embedding.p; src.step = step;
     const KrNormSrc from_hidden{};  // mode 0
     bool first = true;
+    const float* res_cur = res;   // where the residual stream currently lives (res, or res2 after a fused norm+router launch)
     for (size_t li = 0; li < s->layers.size(); li++) {
         DLayer& L = s->layers[li];
-        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st));
-        first = false; src = from_hidden;
+        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st));
+        first = false; src = from_hidden; res_cur = res;
         if (L.attn == ATTN_LA) {
             {
                 const KrMatDev mats[2] = {mv(s, L.qkvz_wid), mv(s, L.ba_wid)};
@@ -540,19 +544,37 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             PROF(PK_GQA, kr_launch_mla(a, s->kv_max_seq, st));
             PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }
-        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st));
+        // post-attention fused add+RMSNorm: folded into the router launch of MoE layers, its own launch otherwise
+        const float* act = hid;   // normalised hidden the MLP block reads
+        bool routed = false;
         if (L.mlp == MLP_MOE) {
             Layer& EL = e->layers[L.moe_layer];
             if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
             if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
+            if (s->fuse_router) {
+                prof_mark(s, PK_ROUTE_LOGITS, st);
+                routed = 0 == kr_launch_route_fused_decode(EL.gate_cm.p, EL.gate_bf16_exact, EL.has_bias ? (const float*)EL.bias.p : nullptr, (float*)s->r_logits.p,
+                                                           (unsigned*)s->r_counter.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p,
+                                                           (float*)s->r_w.p, e->r_ne, H, s->topk, s->scoring, s->norm_topk, nullptr, hid, res,
+                                                           (const float*)s->norms[L.post_norm]->p, (float*)s->hid2.p, (float*)s->res2.p, s->eps,
+                                                           s->norm_bias_one, st);
+                prof_mark(s, -1, st);
+                if (routed) { act = (const float*)s->hid2.p; res_cur = (const float*)s->res2.p; }
+            }
+        }
+        if (!routed) PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res, res, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st));
+        if (L.mlp == MLP_MOE) {
+            Layer& EL = e->layers[L.moe_layer];
             const int E = e->r_ne, k = s->topk;
-            PROF(PK_ROUTE_LOGITS, kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, hid, EL.has_bias ? (const float*)EL.bias.p : nullptr, (float*)s->r_logits.p, 1, E, H, st));
-            PROF(PK_ROUTE_SELECT, kr_launch_route_select((const float*)s->r_logits.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p, (float*)s->r_w.p, 1, E, k,
-                                   s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st));
+            if (!routed) {
+                PROF(PK_ROUTE_LOGITS, kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, hid, EL.has_bias ? (const float*)EL.bias.p : nullptr, (float*)s->r_logits.p, 1, E, H, st));
+                PROF(PK_ROUTE_SELECT, kr_launch_route_select((const float*)s->r_logits.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p, (float*)s->r_w.p, 1, E, k,
+                                       s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st));
+            }
             const bool has_shared = L.sgu_wid >= 0;
             const bool has_gate = has_shared && L.sg_wid >= 0;
             KrMoeArgs a{};
-            a.act = nullptr; a.act_f32 = hid; a.shared_decode = 1;
+            a.act = nullptr; a.act_f32 = act; a.shared_decode = 1;
             a.ids = (const int32_t*)s->r_ids.p; a.wts = (const float*)s->r_w.p;
             a.B = 1; a.topk = k; a.n_slots = k + (has_shared ? 1 : 0); a.H = H; a.I = EL.inter;
             a.w13 = EL.w13.view(); a.w2 = EL.w2.view();
@@ -566,7 +588,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             const bool fuse_gate = has_gate && a.w13.bits == 4 && a.sw13.bits == 4 && mv(s, L.sg_wid).bits == 4;
             if (fuse_gate) { a.sgate = mv(s, L.sg_wid); a.gate_out = (float*)s->gate_val.p; }
             PROF(PK_MOE_W13, kr_launch_moe_w13(a, st));
-            if (has_gate && !fuse_gate) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), hid, 1, (float*)s->gate_val.p, st));
+            if (has_gate && !fuse_gate) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), act, 1, (float*)s->gate_val.p, st));
             PROF(PK_MOE_W2, kr_launch_moe_w2(a, st));
             // epilogue (weighted sum, rsf, shared * sigmoid(gate)) is folded into the next fused add+RMSNorm
             src = KrNormSrc{}; src.mode = 2; src.eo = a.eo; src.ids = a.ids; src.wts = a.wts; src.topk = k; src.has_shared = has_shared ? 1 : 0;
@@ -581,9 +603,9 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.down_wid), s->dense_gu.p, 1, hid, st, KR_ACT_SILU_MUL));
         }
     }
-    PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st));
+    PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st));
     PROF(PK_LM_HEAD, kr_launch_matvec(mv(s, s->lm_head), hid, 1, (float*)s->logits.p, st));
-    PROF(PK_ARGMAX, kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, st));
+    PROF(PK_ARGMAX, kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, st));
     KR_HIP(hipGetLastError());
     return KR_OK;
 }

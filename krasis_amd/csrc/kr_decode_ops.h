@@ -37,7 +37,7 @@ struct KrNormSrc {   // where the value added to the residual comes from (see kr
     const float* emb; const KrStep* step;
     const float* eo; const int32_t* ids; const float* wts; int topk; int has_shared; const float* gate_val; float rsf;
 };
-void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s);
+void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, const float* res_in, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s);
 void kr_launch_la_conv(const KrLaArgs& a, hipStream_t s);
 int kr_launch_la_recurrent_gnorm(float* state, const float* q, const float* k, const float* v, const float* g, const float* beta, const float* z,
                                  const float* w, float* out, int nv, int dk, int dv, float eps, hipStream_t s);
@@ -45,4 +45,4 @@ void kr_launch_gated_rmsnorm_silu(const float* recur, const float* z, const floa
 void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s);
 void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const float* wts, int topk, int has_shared, const float* gate_val,
                                   float rsf, float* hidden, int H, hipStream_t s);
-void kr_launch_argmax(const float* x, int n, int* out, hipStream_t s);
+void kr_launch_argmax(const float* x, int n, int* out, float* scratch, hipStream_t s);

@@ -45,7 +45,7 @@ __global__ void kr_embed_kernel(const float* __restrict__ emb, const KrStep* __r
 //   src.mode 2: the MoE epilogue of the previous layer, hidden = moe (*rsf) + shared * sigmoid(gate) (decode.rs:3343-3402),
 // so the embedding copy and the MoE combine need no launch of their own.
 #define KR_NORM_THREADS 1024
-__global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(const KrNormSrc src, float* hidden, float* residual, const float* __restrict__ w,
+__global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(const KrNormSrc src, float* hidden, const float* res_in, float* residual, const float* __restrict__ w,
                                                                               int n, float eps, int first, int bias_one) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* r = sm;                       // [n]
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(c
             }
             hv = acc;
         }
-        const float v = first ? hv : (hv + residual[i]);
+        const float v = first ? hv : (hv + res_in[i]);
         r[i] = v; residual[i] = v;
     }
     __syncthreads();
@@ -329,11 +329,14 @@ __global__ void __launch_bounds__(256) kr_moe_combine_decode_kernel(const float*
 
 // hidden = act(gu[0..n), gu[n..2n)) for the dense-MLP path is handled by the matvec prologue (KR_ACT_SILU_MUL).
 
-// greedy sampling: first maximum wins (decode.rs:3718)
-__global__ void __launch_bounds__(1024) kr_argmax_kernel(const float* __restrict__ x, int n, int* __restrict__ out) {
-    __shared__ float bv[16]; __shared__ int bi[16];
+// greedy sampling: first maximum wins (decode.rs:3718).  64 workgroups scan slices; the one that finishes last (device-scope
+// counter, reset for the next replay) reduces the 64 partials.  (value desc, index asc) is associative, so the split is exact.
+#define KR_ARGMAX_BLOCKS 64
+__global__ void __launch_bounds__(1024) kr_argmax_kernel(const float* __restrict__ x, int n, int* __restrict__ out, float* part_v, int* part_i,
+                                                         unsigned* counter) {
+    __shared__ float bv[16]; __shared__ int bi[16]; __shared__ int s_last;
     float v = -__builtin_inff(); int idx = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < n; i += 1024) { const float t = x[i]; if (t > v || (t == v && i < idx)) { v = t; idx = i; } }
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += KR_ARGMAX_BLOCKS * 1024) { const float t = x[i]; if (t > v || (t == v && i < idx)) { v = t; idx = i; } }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const float ov = __shfl_xor(v, off); const int oi = __shfl_xor(idx, off);
@@ -343,8 +346,22 @@ __global__ void __launch_bounds__(1024) kr_argmax_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; w++) if (bv[w] > v || (bv[w] == v && bi[w] < idx)) { v = bv[w]; idx = bi[w]; }
-        out[0] = idx;
+        __hip_atomic_store(part_v + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part_i + blockIdx.x, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == KR_ARGMAX_BLOCKS - 1;
+        if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    v = __hip_atomic_load(part_v + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    idx = __hip_atomic_load(part_i + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off); const int oi = __shfl_xor(idx, off);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    if (threadIdx.x == 0) out[0] = idx;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -353,8 +370,8 @@ __global__ void __launch_bounds__(1024) kr_argmax_kernel(const float* __restrict
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s) {
     hipLaunchKernelGGL(kr_embed_kernel, dim3((H + 255) / 256), dim3(256), 0, s, emb, st, hidden, H);
 }
-void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s) {
-    hipLaunchKernelGGL(kr_fused_add_rmsnorm_kernel, dim3(1), dim3(KR_NORM_THREADS), (size_t)(n + 4) * 4, s, src, hidden, residual, w, n, eps, first, bias_one);
+void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, const float* res_in, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s) {
+    hipLaunchKernelGGL(kr_fused_add_rmsnorm_kernel, dim3(1), dim3(KR_NORM_THREADS), (size_t)(n + 4) * 4, s, src, hidden, res_in, residual, w, n, eps, first, bias_one);
 }
 void kr_launch_la_conv(const KrLaArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kr_la_conv_kernel, dim3(a.nk), dim3(256), (size_t)(2 * a.dk + 4) * 4, s, a);
@@ -378,6 +395,6 @@ void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const flo
                                   float rsf, float* hidden, int H, hipStream_t s) {
     hipLaunchKernelGGL(kr_moe_combine_decode_kernel, dim3((H + 255) / 256), dim3(256), 0, s, eo, ids, wts, topk, has_shared, gate_val, rsf, hidden, H);
 }
-void kr_launch_argmax(const float* x, int n, int* out, hipStream_t s) {
-    hipLaunchKernelGGL(kr_argmax_kernel, dim3(1), dim3(1024), 0, s, x, n, out);
+void kr_launch_argmax(const float* x, int n, int* out, float* scratch /* >= 129 words, word 128 = counter (zeroed once) */, hipStream_t s) {
+    hipLaunchKernelGGL(kr_argmax_kernel, dim3(KR_ARGMAX_BLOCKS), dim3(1024), 0, s, x, n, out, scratch, (int*)(scratch + 64), (unsigned*)(scratch + 128));
 }

@@ -7,3 +7,9 @@ void kr_launch_route_logits_decode(const void* gate_cm, int gate_bf16, const flo
 void kr_launch_route_logits_engine(const void* gate_rm, const uint16_t* act, float* logits, int m, int E, int H, hipStream_t st);
 void kr_launch_route_select(const float* logits, const float* esc, int32_t* ids, float* w, int m, int E, int topk, int scoring,
                             int norm, int rule, int gptoss, hipStream_t st);
+/* decode graph, M = 1: [fused add+RMSNorm ->] gate GEMV -> scoring + top-k in one launch (norm_w == nullptr: x is already normalised).
+ * returns non-zero when the geometry is not covered (caller falls back to the separate launches) */
+int kr_launch_route_fused_decode(const void* gate_cm, int gate_bf16, const float* bias, float* logits, unsigned* counter, const float* esc,
+                                 int32_t* ids, float* w, int E, int H, int topk, int scoring, int norm_topk, const float* x,
+                                 const float* hid_in, const float* res_in, const float* norm_w, float* hid_out, float* res_out, float eps,
+                                 int bias_one, hipStream_t st);

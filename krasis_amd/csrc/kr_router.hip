@@ -15,6 +15,13 @@
 #include "kr_libm.h"
 #include "kr_router.h"
 
+#ifdef KR_TIMING   // tools/probes/route_timing.hip: wall-clock stamps (10 ns units) of one wave, no-op in the product build
+__device__ unsigned long long kr_stamps[32];
+#define KR_STAMP(i) do { if ((threadIdx.x & 63) == 0) kr_stamps[i] = wall_clock64(); } while (0)
+#else
+#define KR_STAMP(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // logits, rule DECODE
 // ------------------------------------------------------------------------------------------
@@ -160,49 +167,49 @@ __device__ void kr_topk_heap_serial(const float* v, int n, int k, float* hv, int
     for (int i = 0; i < k; i++) out[i] = hi[i];
 }
 
-// ---- wave-wide (value desc, index asc) arg-best over 64 lanes on packed 64-bit keys ----
-// key = orderable(value) << 32 | (0xFFFFFFFF - index); larger key == better; 0 == empty / already taken.
-__device__ __forceinline__ uint64_t kr_make_key(float v, int e) {
+// ---- wave-wide top-k in (value desc, index asc) order ----
+// Element e lives in lane e / NV, slot e % NV ("lane-major"), so index order == (lane asc, slot asc): a 32-bit orderable image of the
+// value is enough -- among equal values the first slot wins inside a lane (strict '>' scan) and the lowest lane wins across lanes (ballot + ffs).
+// key 0 == empty / already taken.
+__device__ __forceinline__ uint32_t kr_make_key(float v) {
     if (v == 0.0f) v = 0.0f;                       // -0 and +0 compare equal in the reference
     uint32_t u = __float_as_uint(v);
     u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;    // monotone map float -> uint
-    return ((uint64_t)u << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)e);
+    return u;
 }
-__device__ __forceinline__ float kr_key_value(uint64_t k) {
-    uint32_t u = (uint32_t)(k >> 32);
+__device__ __forceinline__ float kr_key_value(uint32_t u) {
     u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
     return __uint_as_float(u);
 }
-__device__ __forceinline__ int kr_key_index(uint64_t k) { return (int)(0xFFFFFFFFu - (uint32_t)k); }
-__device__ __forceinline__ uint64_t kr_key_max(uint64_t a, uint64_t b) { return a > b ? a : b; }
-#define KR_DPP64(k, ctrl) (((uint64_t)(uint32_t)KR_DPP((int)((k) >> 32), ctrl) << 32) | (uint32_t)KR_DPP((int)(uint32_t)(k), ctrl))
-__device__ __forceinline__ uint64_t kr_wave_key_max(uint64_t k) {
-    k = kr_key_max(k, KR_DPP64(k, KR_DPP_XOR1));
-    k = kr_key_max(k, KR_DPP64(k, KR_DPP_XOR2));
-    k = kr_key_max(k, KR_DPP64(k, KR_DPP_HALF_MIRROR));
-    k = kr_key_max(k, KR_DPP64(k, KR_DPP_MIRROR));    // every lane of a 16-lane row holds the row maximum
-    uint64_t r[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-        r[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(k >> 32), 16 * j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 16 * j);
-    return kr_key_max(kr_key_max(r[0], r[1]), kr_key_max(r[2], r[3]));
+__device__ __forceinline__ uint32_t kr_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t kr_wave_umax(uint32_t k) {
+    k = kr_umax(k, (uint32_t)KR_DPP((int)k, KR_DPP_XOR1));
+    k = kr_umax(k, (uint32_t)KR_DPP((int)k, KR_DPP_XOR2));
+    k = kr_umax(k, (uint32_t)KR_DPP((int)k, KR_DPP_HALF_MIRROR));
+    k = kr_umax(k, (uint32_t)KR_DPP((int)k, KR_DPP_MIRROR));    // every lane of a 16-lane row holds the row maximum
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)k, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)k, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)k, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)k, 48);
+    return kr_umax(kr_umax(r0, r1), kr_umax(r2, r3));
 }
 
-// first kp1 elements in (value desc, index asc) order; element e lives in lane e%64, slot e/64 (registers)
+// first kp1 elements in (value desc, index asc) order; element e = lane * NV + slot (registers)
 template <int NV>
 __device__ __forceinline__ void kr_topk_wave_reg(const float (&val)[NV], int n, int kp1, float* pv, int* pi) {
     const int lane = threadIdx.x & 63;
-    uint64_t key[NV];
+    uint32_t key[NV];
 #pragma unroll
-    for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; key[i] = e < n ? kr_make_key(val[i], e) : 0ull; }
+    for (int i = 0; i < NV; i++) { const int e = lane * NV + i; key[i] = e < n ? kr_make_key(val[i]) : 0u; }
     for (int t = 0; t < kp1; t++) {
-        uint64_t best = 0ull;
+        uint32_t hk = 0u; int hs = 0;
 #pragma unroll
-        for (int i = 0; i < NV; i++) best = kr_key_max(best, key[i]);
-        const uint64_t w = kr_wave_key_max(best);
+        for (int i = 0; i < NV; i++) if (key[i] > hk) { hk = key[i]; hs = i; }
+        const uint32_t wmax = kr_wave_umax(hk);
+        const uint64_t mask = __ballot(hk == wmax);
+        const int win = __builtin_ctzll(mask);
+        const int slot = __builtin_amdgcn_readlane(hs, win);
 #pragma unroll
-        for (int i = 0; i < NV; i++) if (key[i] == w) key[i] = 0ull;   // keys are unique (index embedded): removes exactly the winner
-        if (lane == 0) { pv[t] = kr_key_value(w); pi[t] = kr_key_index(w); }
+        for (int i = 0; i < NV; i++) if (lane == win && i == slot) key[i] = 0u;
+        if (lane == 0) { pv[t] = kr_key_value(wmax); pi[t] = win * NV + slot; }
     }
 }
 
@@ -214,19 +221,36 @@ struct KrRouteSelArgs {
     int gptoss;           // rule ENGINE: swiglu_limit > 0 branch (moe.rs:3101)
 };
 
-// strictly sequential f32 sum of x[0..n) (reference order), register-batched so LDS latency is paid once per 16 values
+// strictly sequential f32 sum of x[0..n) (reference order); the next 16 values are fetched from LDS (4 x ds_read_b128) while the
+// current 16 are being added, so the chain of dependent adds is the only latency left.  x must be 16-byte aligned.
+#define KR_ADD16(s, a0, a1, a2, a3) do { s += a0.x; s += a0.y; s += a0.z; s += a0.w; s += a1.x; s += a1.y; s += a1.z; s += a1.w; \
+                                           s += a2.x; s += a2.y; s += a2.z; s += a2.w; s += a3.x; s += a3.y; s += a3.z; s += a3.w; } while (0)
 __device__ __forceinline__ float kr_seq_sum(const float* x, int n) {
     float s = 0.0f; int e = 0;
-    for (; e + 16 <= n; e += 16) {
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = x[e + u];
-#pragma unroll
-        for (int u = 0; u < 16; u++) s += v[u];
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    if (n >= 32) {   // two register sets (A, B): B's ds_reads are in flight while A is added and vice versa
+        float4 a0 = x4[0], a1 = x4[1], a2 = x4[2], a3 = x4[3];
+        for (; e + 64 <= n; e += 32) {
+            const float4 b0 = x4[e / 4 + 4], b1 = x4[e / 4 + 5], b2 = x4[e / 4 + 6], b3 = x4[e / 4 + 7];
+            __builtin_amdgcn_sched_barrier(0);
+            KR_ADD16(s, a0, a1, a2, a3);
+            a0 = x4[e / 4 + 8]; a1 = x4[e / 4 + 9]; a2 = x4[e / 4 + 10]; a3 = x4[e / 4 + 11];
+            __builtin_amdgcn_sched_barrier(0);
+            KR_ADD16(s, b0, b1, b2, b3);
+        }
+        // a = block at e (loaded); at least 32 and fewer than 64 values remain
+        const float4 b0 = x4[e / 4 + 4], b1 = x4[e / 4 + 5], b2 = x4[e / 4 + 6], b3 = x4[e / 4 + 7];
+        KR_ADD16(s, a0, a1, a2, a3);
+        KR_ADD16(s, b0, b1, b2, b3);
+        e += 32;
     }
     for (; e < n; e++) s += x[e];
     return s;
 }
+
+// the selection is run by ONE wave (its own launch, or the last workgroup of the fused kernel whose other waves have left):
+// LDS traffic of a single wave is ordered by a fence, no workgroup barrier involved
+__device__ __forceinline__ void kr_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 template <int NV>
 __device__ __forceinline__ void kr_route_select_body(const KrRouteSelArgs& a, const float* lg, int32_t* ids, float* w, float* sm) {
@@ -241,26 +265,29 @@ __device__ __forceinline__ void kr_route_select_body(const KrRouteSelArgs& a, co
     const bool decode = a.rule == 1;
     const bool raw_topk = decode ? (a.scoring == 2) : (a.gptoss != 0);
     float sc[NV], sl[NV];
+    KR_STAMP(8);
 #pragma unroll
-    for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; sc[i] = e < E ? lg[e] : 0.0f; }
+    for (int i = 0; i < NV; i++) { const int e = lane * NV + i; sc[i] = e < E ? lg[e] : 0.0f; }
     if (raw_topk) {
 #pragma unroll
-        for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; if (e < E && !decode && a.esc) sc[i] += a.esc[e]; }
+        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; if (e < E && !decode && a.esc) sc[i] += a.esc[e]; }
     } else if (a.scoring == 0) {
         const int e8 = (E / 8) * 8;
 #pragma unroll
-        for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; if (e < E) sc[i] = (decode && e < e8) ? kr_sigmoid_poly4(sc[i]) : 1.0f / (1.0f + kr_expf(-sc[i])); }
+        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; if (e < E) sc[i] = (decode && e < e8) ? kr_sigmoid_poly4(sc[i]) : 1.0f / (1.0f + kr_expf(-sc[i])); }
     } else {
         float mx = -__builtin_inff();
 #pragma unroll
-        for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; if (e < E) mx = fmaxf(mx, sc[i]); }
+        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; if (e < E) mx = fmaxf(mx, sc[i]); }
         mx = kr_red16_max_f32(mx);
         mx = fmaxf(fmaxf(__shfl(mx, 0), __shfl(mx, 16)), fmaxf(__shfl(mx, 32), __shfl(mx, 48)));
 #pragma unroll
-        for (int i = 0; i < NV; i++) { const int e = i * 64 + lane; if (e < E) { sc[i] = kr_expf(sc[i] - mx); scores[e] = sc[i]; } }
-        __syncthreads();
+        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; if (e < E) { sc[i] = kr_expf(sc[i] - mx); scores[e] = sc[i]; } }
+        kr_wave_sync();
+        KR_STAMP(12);
         if (lane == 0) red[0] = kr_seq_sum(scores, E);   // decode.rs:4156 / moe.rs:3201: sum in index order
-        __syncthreads();
+        KR_STAMP(13);
+        kr_wave_sync();
         const float se = red[0];
         if (decode) { const float inv = 1.0f / se;
 #pragma unroll
@@ -271,34 +298,43 @@ __device__ __forceinline__ void kr_route_select_body(const KrRouteSelArgs& a, co
     }
 #pragma unroll
     for (int i = 0; i < NV; i++) {
-        const int e = i * 64 + lane;
+        const int e = lane * NV + i;
         sl[i] = (!raw_topk && a.esc && e < E) ? sc[i] + a.esc[e] : sc[i];
         if (e < E) { scores[e] = sc[i]; sel[e] = sl[i]; }
     }
     const int np = k + 1 <= E ? k + 1 : k;
+    KR_STAMP(9);
     kr_topk_wave_reg<NV>(sl, E, np, pv, pi);
-    __syncthreads();
-    if (lane == 0) {
-        bool tie = false;
-        if (decode) for (int i = 0; i + 1 < np; i++) tie |= (pv[i] == pv[i + 1]);
-        if (tie) kr_topk_heap_serial(sel, E, k, hv, hi, ids);  // heap order governs ties (decode.rs:1531)
-        else for (int i = 0; i < k; i++) ids[i] = pi[i];       // engine rule: lowest index wins == (value desc, index asc)
-        if (raw_topk) {
-            float mx = -__builtin_inff();
-            for (int i = 0; i < k; i++) mx = fmaxf(mx, scores[ids[i]]);
-            float se = 0.0f;
-            for (int i = 0; i < k; i++) { const float v = kr_expf(scores[ids[i]] - mx); w[i] = v; se += v; }
-            if (decode) { const float inv = 1.0f / se; for (int i = 0; i < k; i++) w[i] *= inv; }
-            else for (int i = 0; i < k; i++) w[i] /= se;
-        } else {
-            for (int i = 0; i < k; i++) w[i] = scores[ids[i]];
-            if (a.norm) {
-                float s = 0.0f;
-                for (int i = 0; i < k; i++) s += w[i];
-                if (s > 0.0f) for (int i = 0; i < k; i++) w[i] /= s;
-            }
-        }
+    KR_STAMP(10);
+    kr_wave_sync();
+    // ---- epilogue: lanes 0..k-1 each own one selected expert; only the (short) sums stay sequential ----
+    bool tie = false;
+    if (decode) {
+        const float pa = lane < np ? pv[lane] : 0.0f, pb = lane + 1 < np ? pv[lane + 1] : 0.0f;
+        tie = __ballot(lane + 1 < np && pa == pb) != 0ull;
     }
+    if (tie) {                                             // heap order governs ties (decode.rs:1531): exact serial emulation
+        if (lane == 0) kr_topk_heap_serial(sel, E, k, hv, hi, pi);
+        kr_wave_sync();
+    }
+    const int my = lane < k ? pi[lane] : 0;                // engine rule: lowest index wins == (value desc, index asc)
+    float wv = lane < k ? scores[my] : 0.0f;
+    if (raw_topk) {
+        float mx = lane < k ? wv : -__builtin_inff();
+        mx = kr_red16_max_f32(mx);
+        mx = fmaxf(fmaxf(__shfl(mx, 0), __shfl(mx, 16)), fmaxf(__shfl(mx, 32), __shfl(mx, 48)));
+        wv = lane < k ? kr_expf(wv - mx) : 0.0f;
+    }
+    if (raw_topk || a.norm) {
+        if (lane < k) hv[lane] = wv;
+        kr_wave_sync();
+        if (lane == 0) { float se = 0.0f; for (int i = 0; i < k; i++) se += hv[i]; red[1] = se; }   // sequential, routing order
+        kr_wave_sync();
+        const float se = red[1];
+        if (raw_topk) wv = decode ? wv * (1.0f / se) : wv / se;
+        else if (se > 0.0f) wv = wv / se;
+    }
+    if (lane < k) { ids[lane] = my; w[lane] = wv; }
 }
 
 __global__ void __launch_bounds__(64) kr_route_select_kernel(const KrRouteSelArgs a) {
@@ -314,6 +350,130 @@ __global__ void __launch_bounds__(64) kr_route_select_kernel(const KrRouteSelArg
     else if (nv <= 8) kr_route_select_body<8>(a, lg, ids, w, sm);
     else if (nv <= 16) kr_route_select_body<16>(a, lg, ids, w, sm);
     else kr_route_select_body<32>(a, lg, ids, w, sm);
+}
+
+// ------------------------------------------------------------------------------------------
+// decode graph, M = 1: [fused add + RMSNorm] -> gate GEMV (rule DECODE) -> scoring + top-k, ONE launch.
+//   * every workgroup rebuilds the normalised hidden vector itself (the reduction order is fixed -- 8 fma lanes + hsum,
+//     decode.rs:1235-1252 -- so all workgroups get identical bits); workgroup 0 publishes hidden/residual for the expert kernels.
+//     Inputs and outputs are different buffers because other workgroups may still be reading the inputs.
+//   * the workgroup that finishes last (device-scope counter) runs the selection, so the logits never wait for another launch.
+// ------------------------------------------------------------------------------------------
+struct KrRouteFusedArgs {
+    const void* gate_cm; const float* bias; float* logits; unsigned* counter;
+    KrRouteSelArgs sel;
+    const float* x;            // normalised hidden (norm_w == nullptr), else unused
+    const float *hid_in, *res_in, *norm_w; float *hid_out, *res_out; float eps; int bias_one;   // folded fused_add_rmsnorm (decode.rs:1199)
+    int H;
+};
+
+template <bool GATE_BF16, int NV>
+__global__ void __launch_bounds__(256) kr_route_fused_decode_kernel(const KrRouteFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ int s_last;
+    const int H = a.H, E = a.sel.E, ld = H / 16 + 4;
+    float* xs = sm;                  // [16][ld] chain-major copy of x
+    float* r = sm + 16 * ld;         // [H + 4] residual sum (norm fold) -- reused as selection scratch by the last workgroup
+    const int t = threadIdx.x;
+    KR_STAMP(0);
+    if (a.norm_w) {
+        for (int i = t; i < H; i += 256) { const float v = a.hid_in[i] + a.res_in[i]; r[i] = v; if (blockIdx.x == 0) a.res_out[i] = v; }
+        __syncthreads();
+        if (t < 8) {
+            float ss = 0.0f;
+            const int nb = H / 8; int b = 0;
+            for (; b + 8 <= nb; b += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = r[(b + u) * 8 + t];
+#pragma unroll
+                for (int u = 0; u < 8; u++) ss = __builtin_fmaf(v[u], v[u], ss);
+            }
+            for (; b < nb; b++) { const float v = r[b * 8 + t]; ss = __builtin_fmaf(v, v, ss); }
+            ss = ss + __shfl_xor(ss, 4); ss = ss + __shfl_xor(ss, 1); ss = ss + __shfl_xor(ss, 2);
+            if (t == 0) {
+                for (int q = (H / 8) * 8; q < H; q++) ss += r[q] * r[q];
+                r[H] = 1.0f / sqrtf(ss / (float)H + a.eps);
+            }
+        }
+        __syncthreads();
+        const float rms = r[H];
+        for (int i = t; i < H; i += 256) {
+            const float v = (r[i] * rms) * (a.bias_one ? (a.norm_w[i] + 1.0f) : a.norm_w[i]);
+            xs[(i & 15) * ld + (i >> 4)] = v;
+            if (blockIdx.x == 0) a.hid_out[i] = v;
+        }
+    } else {
+        for (int i = t; i < H; i += 256) xs[(i & 15) * ld + (i >> 4)] = a.x[i];
+    }
+    __syncthreads();
+    KR_STAMP(1);
+    const int wave = t >> 6, lane = t & 63;
+    const int eb = blockIdx.x * 4 + wave;  // block of 4 experts
+    if (eb * 4 < E) {
+        const int j = lane & 15;
+        float acc = 0.0f;
+        const float* xj = xs + j * ld;
+        if (GATE_BF16) {
+            const int nc = H / 128;
+            const u32x4* g = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)eb * nc * 64 + lane;
+            for (int c0 = 0; c0 < nc; c0 += 4) {
+                u32x4 w[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (c0 + u < nc) w[u] = kr_ldg_nt(g + (size_t)(c0 + u) * 64);
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (c0 + u < nc) {
+                    const float* xx = xj + (c0 + u) * 8;
+                    const uint32_t ww[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        acc = __builtin_fmaf(__uint_as_float(ww[p] << 16), xx[2 * p], acc);
+                        acc = __builtin_fmaf(__uint_as_float(ww[p] & 0xFFFF0000u), xx[2 * p + 1], acc);
+                    }
+                }
+            }
+        } else {
+            const int nc = H / 64;
+            const u32x4* g = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)eb * nc * 64 + lane;
+            for (int c0 = 0; c0 < nc; c0 += 8) {
+                u32x4 w[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (c0 + u < nc) w[u] = kr_ldg_nt(g + (size_t)(c0 + u) * 64);
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (c0 + u < nc) {
+                    const float* xx = xj + (c0 + u) * 4;
+                    acc = __builtin_fmaf(__uint_as_float(w[u].x), xx[0], acc);
+                    acc = __builtin_fmaf(__uint_as_float(w[u].y), xx[1], acc);
+                    acc = __builtin_fmaf(__uint_as_float(w[u].z), xx[2], acc);
+                    acc = __builtin_fmaf(__uint_as_float(w[u].w), xx[3], acc);
+                }
+            }
+        }
+        float v = acc;
+        v = v + __shfl_xor(v, 8);
+        v = v + __shfl_xor(v, 4);
+        v = v + __shfl_xor(v, 1);
+        v = v + __shfl_xor(v, 2);
+        const int e = eb * 4 + (lane >> 4);
+        if (j == 0 && e < E) {
+            if (a.bias) v += a.bias[e];
+            __hip_atomic_store(a.logits + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- last workgroup selects ----
+    KR_STAMP(2);
+    __syncthreads();
+    if (t == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == gridDim.x - 1;
+        if (s_last) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch / graph replay
+    }
+    __syncthreads();
+    if (!s_last || wave != 0) return;
+    KR_STAMP(3);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // every workgroup's logits are visible (released by its counter increment)
+    kr_route_select_body<NV>(a.sel, a.logits, a.sel.ids, a.sel.w, sm);
+    KR_STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -335,4 +495,24 @@ void kr_launch_route_select(const float* logits, const float* esc, int32_t* ids,
     KrRouteSelArgs a{logits, esc, ids, w, E, topk, scoring, norm, rule, gptoss};
     const size_t lds = (size_t)(2 * E + 33 + 33 + 32 + 32 + 4) * 4;
     hipLaunchKernelGGL(kr_route_select_kernel, dim3(m), dim3(64), lds, st, a);
+}
+
+int kr_launch_route_fused_decode(const void* gate_cm, int gate_bf16, const float* bias, float* logits, unsigned* counter, const float* esc,
+                                 int32_t* ids, float* w, int E, int H, int topk, int scoring, int norm_topk, const float* x,
+                                 const float* hid_in, const float* res_in, const float* norm_w, float* hid_out, float* res_out, float eps,
+                                 int bias_one, hipStream_t st) {
+    KrRouteFusedArgs a{};
+    a.gate_cm = gate_cm; a.bias = bias; a.logits = logits; a.counter = counter;
+    a.sel = KrRouteSelArgs{logits, esc, ids, w, E, topk, scoring, norm_topk, 1 /* KR_ROUTE_RULE_DECODE */, 0};
+    a.x = x; a.hid_in = hid_in; a.res_in = res_in; a.norm_w = norm_w; a.hid_out = hid_out; a.res_out = res_out; a.eps = eps; a.bias_one = bias_one; a.H = H;
+    const int nv = (E + 63) / 64;
+    if (H % 128 || topk > 32) return 1;
+    dim3 grid((E / 4 + 3) / 4);
+    const size_t sel_f = (size_t)(2 * E + 33 + 33 + 32 + 32 + 4);
+    const size_t lds = ((size_t)16 * (H / 16 + 4) + (size_t)H + 4 > sel_f ? (size_t)16 * (H / 16 + 4) + (size_t)H + 4 : sel_f) * 4;
+#define KR_RF(B, N) hipLaunchKernelGGL((kr_route_fused_decode_kernel<B, N>), grid, dim3(256), lds, st, a)
+    if (gate_bf16) { if (nv <= 1) KR_RF(true, 1); else if (nv <= 2) KR_RF(true, 2); else if (nv <= 4) KR_RF(true, 4); else if (nv <= 8) KR_RF(true, 8); else return 1; }
+    else { if (nv <= 1) KR_RF(false, 1); else if (nv <= 2) KR_RF(false, 2); else if (nv <= 4) KR_RF(false, 4); else if (nv <= 8) KR_RF(false, 8); else return 1; }
+#undef KR_RF
+    return 0;
 }
