@@ -19,55 +19,7 @@
 #include "kr_kernels.h"
 #include "kr_router.h"
 
-struct DWeight { MatSet ms; int rows = 0, cols = 0; };
-
-enum { ATTN_NONE = 0, ATTN_LA = 1, ATTN_GQA = 2, ATTN_MLA = 3 };
-enum { MLP_NONE = 0, MLP_MOE = 1, MLP_DENSE = 2 };
-
-struct DLayer {
-    int input_norm = -1, post_norm = -1;
-    int attn = ATTN_NONE, mlp = MLP_NONE;
-    // LA
-    int qkvz_wid = -1, ba_wid = -1, out_wid = -1, nk = 0, nv = 0, dk = 0, dv = 0, kd = 4; float la_scale = 1.0f;
-    DevBuf conv_w, a_log, dt_bias, la_norm_w, conv_state, recur_state;
-    // GQA
-    int q_wid = -1, k_wid = -1, v_wid = -1, o_wid = -1, gated = 0, nh = 0, nkv = 0, hd = 0; float sm_scale = 1.0f;
-    DevBuf q_norm, k_norm, kv_k, kv_v; int q_norm_len = 0, k_norm_len = 0;
-    // MLA (kv_k = compressed-KV cache [max_seq, klr], kv_v = k_pe cache [max_seq, rd], both FP16)
-    int kva_wid = -1, mq_wid = -1, mqa_wid = -1, mqb_wid = -1, klr = 0, nd = 0, rd = 0, vhd = 0, q_a_norm_len = 0;
-    DevBuf w_kc, w_vc, kv_a_norm, q_a_norm, mla_cos, mla_sin; int mla_rope_seq = 0;
-    // MLP
-    int moe_layer = -1, sgu_wid = -1, sd_wid = -1, sg_wid = -1;
-    int gate_wid = -1, up_wid = -1, down_wid = -1;
-};
-
-struct kr_decode_store {
-    kr_engine* eng = nullptr;
-    int group_size = 128; bool norm_bias_one = false;
-    std::vector<std::unique_ptr<DWeight>> weights;
-    std::vector<std::unique_ptr<DevBuf>> norms; std::vector<int> norm_len;
-    bool configured = false;
-    int hidden = 0, n_layers = 0, vocab = 0, topk = 0, scoring = 1, norm_topk = 1, final_norm = -1, lm_head = -1;
-    float eps = 1e-6f, rsf = 1.0f;
-    DevBuf embedding;
-    std::vector<DLayer> layers;
-    DevBuf rope_cos, rope_sin; int rope_half = 0, max_rope_seq = 0;
-    int kv_max_seq = 0;
-    // scratch
-    DevBuf hid, res, proj_a, proj_b, qbuf, kbuf, vbuf, zbuf, gbuf, betabuf, gatebuf, latbuf, recur_out, attn_out, logits, gate_val, tok;
-    DevBuf dense_gu;  // [gate(K) | up(K)] of the dense MLP; only [0,inter) of each half is ever written, the padding stays 0
-    DevBuf hid2, res2, r_counter, argmax_scratch; bool fuse_router = true;   // outputs of the fused norm+router launch (its inputs stay readable for every workgroup)
-    DevBuf moe_gu, moe_eo, r_logits, r_ids, r_w;  // store-owned so a captured graph never sees them reallocated
-    DevBuf step_dev; KrStep* step_host = nullptr;
-    size_t weight_bytes = 0;
-    // captured graph of one decode step
-    hipGraphExec_t graph_exec = nullptr; bool graph_ok = false; bool use_graph = true;
-    // profiling pass (kr_decode_profile_step): HIP events around every launch, accumulated per kernel kind
-    bool prof = false; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0; std::vector<int> ev_kind;
-};
-
-enum { PK_EMBED = 0, PK_RMSNORM, PK_MATVEC, PK_LA_CONV, PK_LA_RECUR, PK_GATED_NORM, PK_GQA, PK_ROUTE_LOGITS, PK_ROUTE_SELECT, PK_MOE_W13,
-       PK_MOE_W2, PK_MOE_COMBINE, PK_LM_HEAD, PK_ARGMAX, PK_SHARED_GATE, PK_COUNT };
+#include "kr_decode_internal.h"
 
 static void prof_mark(kr_decode_store* s, int kind, hipStream_t st) {
     if (!s->prof) return;
@@ -100,14 +52,14 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
     (void)hipSetDevice(s->eng->device);
     (void)hipStreamSynchronize(s->eng->stream);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
-    for (auto& w : s->weights) { w->ms.q.release(); w->ms.s.release(); }
+    for (auto& w : s->weights) { w->ms.q.release(); w->ms.s.release(); w->ms.wsum.release(); }
     for (auto& n : s->norms) n->release();
     for (auto& l : s->layers)
         for (DevBuf* b : {&l.conv_w, &l.a_log, &l.dt_bias, &l.la_norm_w, &l.conv_state, &l.recur_state, &l.q_norm, &l.k_norm, &l.kv_k, &l.kv_v,
                            &l.w_kc, &l.w_vc, &l.kv_a_norm, &l.q_a_norm, &l.mla_cos, &l.mla_sin}) b->release();
     for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
-                      &s->hid2, &s->res2, &s->r_counter, &s->argmax_scratch, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
+                      &s->hid2, &s->res2, &s->r_counter, &s->argmax_scratch, &s->pf_scratch, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     if (s->step_host) (void)hipHostFree(s->step_host);
     delete s;
 }
@@ -465,7 +417,6 @@ extern "C" int kr_decode_get_state(kr_decode_store* s, int layer, uint16_t* kv_k
 // ------------------------------------------------------------------------------------------------
 // one decode step: the launch sequence of decode_step (decode.rs:2690-3520)
 // ------------------------------------------------------------------------------------------------
-static KrMatDev mv(kr_decode_store* s, int wid) { return s->weights[wid]->ms.view(); }
 
 static int enqueue_step(kr_decode_store* s, hipStream_t st) {
     kr_engine* e = s->eng;

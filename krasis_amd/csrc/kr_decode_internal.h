@@ -1,0 +1,65 @@
+// kr_decode_internal.h -- the decode store's state, shared by kr_decode.cpp (single-token graph) and kr_decode_prefill.cpp (batched prompt)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <vector>
+
+#include "kr_decode_ops.h"
+#include "kr_engine_internal.h"
+
+struct DWeight { MatSet ms; int rows = 0, cols = 0; };
+
+enum { ATTN_NONE = 0, ATTN_LA = 1, ATTN_GQA = 2, ATTN_MLA = 3 };
+enum { MLP_NONE = 0, MLP_MOE = 1, MLP_DENSE = 2 };
+
+struct DLayer {
+    int input_norm = -1, post_norm = -1;
+    int attn = ATTN_NONE, mlp = MLP_NONE;
+    // LA
+    int qkvz_wid = -1, ba_wid = -1, out_wid = -1, nk = 0, nv = 0, dk = 0, dv = 0, kd = 4; float la_scale = 1.0f;
+    DevBuf conv_w, a_log, dt_bias, la_norm_w, conv_state, recur_state;
+    // GQA
+    int q_wid = -1, k_wid = -1, v_wid = -1, o_wid = -1, gated = 0, nh = 0, nkv = 0, hd = 0; float sm_scale = 1.0f;
+    DevBuf q_norm, k_norm, kv_k, kv_v; int q_norm_len = 0, k_norm_len = 0;
+    // MLA (kv_k = compressed-KV cache [max_seq, klr], kv_v = k_pe cache [max_seq, rd], both FP16)
+    int kva_wid = -1, mq_wid = -1, mqa_wid = -1, mqb_wid = -1, klr = 0, nd = 0, rd = 0, vhd = 0, q_a_norm_len = 0;
+    DevBuf w_kc, w_vc, kv_a_norm, q_a_norm, mla_cos, mla_sin; int mla_rope_seq = 0;
+    // MLP
+    int moe_layer = -1, sgu_wid = -1, sd_wid = -1, sg_wid = -1;
+    int gate_wid = -1, up_wid = -1, down_wid = -1;
+};
+
+struct kr_decode_store {
+    kr_engine* eng = nullptr;
+    int group_size = 128; bool norm_bias_one = false;
+    std::vector<std::unique_ptr<DWeight>> weights;
+    std::vector<std::unique_ptr<DevBuf>> norms; std::vector<int> norm_len;
+    bool configured = false;
+    int hidden = 0, n_layers = 0, vocab = 0, topk = 0, scoring = 1, norm_topk = 1, final_norm = -1, lm_head = -1;
+    float eps = 1e-6f, rsf = 1.0f;
+    DevBuf embedding;
+    std::vector<DLayer> layers;
+    DevBuf rope_cos, rope_sin; int rope_half = 0, max_rope_seq = 0;
+    int kv_max_seq = 0;
+    // scratch
+    DevBuf hid, res, proj_a, proj_b, qbuf, kbuf, vbuf, zbuf, gbuf, betabuf, gatebuf, latbuf, recur_out, attn_out, logits, gate_val, tok;
+    DevBuf dense_gu;  // [gate(K) | up(K)] of the dense MLP; only [0,inter) of each half is ever written, the padding stays 0
+    DevBuf hid2, res2, r_counter, argmax_scratch;
+    bool fuse_router = true;   // hid2/res2: outputs of the fused norm+router launch (its inputs stay readable for every workgroup)
+    DevBuf pf_scratch;         // kr_decode_prefill: one arena for the chunk buffers
+    DevBuf moe_gu, moe_eo, r_logits, r_ids, r_w;  // store-owned so a captured graph never sees them reallocated
+    DevBuf step_dev; KrStep* step_host = nullptr;
+    size_t weight_bytes = 0;
+    // captured graph of one decode step
+    hipGraphExec_t graph_exec = nullptr; bool graph_ok = false; bool use_graph = true;
+    // profiling pass (kr_decode_profile_step): HIP events around every launch, accumulated per kernel kind
+    bool prof = false; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0; std::vector<int> ev_kind;
+};
+
+enum { PK_EMBED = 0, PK_RMSNORM, PK_MATVEC, PK_LA_CONV, PK_LA_RECUR, PK_GATED_NORM, PK_GQA, PK_ROUTE_LOGITS, PK_ROUTE_SELECT, PK_MOE_W13,
+       PK_MOE_W2, PK_MOE_COMBINE, PK_LM_HEAD, PK_ARGMAX, PK_SHARED_GATE, PK_COUNT };
+
+
+static inline KrMatDev mv(kr_decode_store* s, int wid) { return s->weights[wid]->ms.view(); }
+int kr_ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st);   // kr_engine.cpp: per (group, column) nibble sums for the int8-MFMA GEMM

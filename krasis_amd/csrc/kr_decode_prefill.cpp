@@ -1,0 +1,196 @@
+// kr_decode_prefill.cpp -- the whole-model prompt pass on the GPU.
+//
+// The reference runs the prompt through third-party GPU kernels (flashinfer attention, sglang fused_marlin_moe, torch matmuls:
+// python/krasis/model.py forward_prefill_layer_grouped, layer.py:242-461, attention.py:496-687, linear_attention.py:695-845) and
+// then hands KV / recurrent state to the CPU decoder (decode_setup.py:232-278).  Here the prompt pass is defined as "what the
+// decode graph would have produced token by token": kr_decode_prefill(tokens[0..n)) leaves logits, FP16 KV caches, conv and
+// recurrent state bit-identical to n successive kr_decode_step calls (src/decode.rs:2690-3520), so there is one numerics story for
+// prefill and decode and no state hand-off.  GEMM-shaped work rides the int8-MFMA grouped GEMM (kr_prefill.hip); everything else
+// is the batched form of the decode operators (kr_prefill_ops.hip).  Tokens are processed in chunks through all layers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/krasis_hip.h"
+#include "kr_decode_internal.h"
+#include "kr_prefill.h"
+#include "kr_prefill_ops.h"
+#include "kr_router.h"
+
+#define KR_PFM_CHUNK 4096
+
+namespace {
+struct Scratch {   // carved from one allocation per store (grown on demand)
+    float *res, *hid, *normed, *pa, *pb, *pc, *q, *k, *v, *z, *gexp, *beta, *recur, *attn, *gate, *moe, *sh, *gv, *sgu, *logits;
+    int8_t *xh, *xl, *yh, *yl; float *xs, *ys;
+    uint16_t* xb; int32_t* ids; float* w; int* tok;
+};
+size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
+}  // namespace
+
+static int pf_gemm(kr_decode_store* s, int wid, const int8_t* xh, const int8_t* xl, const float* xs, int C, float* out, int ld, hipStream_t st) {
+    DWeight& W = *s->weights[wid];
+    if (W.ms.bits != 4) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: weight %d is INT%d; the MFMA projection path is built for INT4-g128", wid, W.ms.bits);
+    if (int rc = kr_ensure_wsum(s->eng, W.ms, st)) return rc;
+    kr_launch_pf_gemm(W.ms.view(), (const uint32_t*)W.ms.wsum.p, xh, xl, xs, nullptr, 1, 0, 0, C, out, ld, st);
+    return KR_OK;
+}
+
+extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int n_tokens, int start_pos, float* logits_out, void* stream) {
+    if (!s) return kr_fail(KR_ERR_VALUE, "null decode store");
+    if (!s->configured) return kr_fail(KR_ERR_STATE, "Call configure_decode first");
+    if (!tokens || n_tokens <= 0) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: empty prompt");
+    if ((int)s->layers.size() != s->n_layers) return kr_fail(KR_ERR_STATE, "finalize_decode was not called");
+    if (start_pos < 0 || (s->kv_max_seq > 0 && start_pos + n_tokens > s->kv_max_seq))
+        return kr_fail(KR_ERR_VALUE, "prompt [%d, %d) does not fit kv_max_seq %d", start_pos, start_pos + n_tokens, s->kv_max_seq);
+    for (int i = 0; i < n_tokens; i++) if (tokens[i] < 0 || tokens[i] >= s->vocab) return kr_fail(KR_ERR_VALUE, "token id %d out of range (vocab %d)", tokens[i], s->vocab);
+    kr_engine* e = s->eng;
+    KR_HIP(hipSetDevice(e->device));
+    hipStream_t st = kr_pick_stream(e, stream);
+    const int H = s->hidden, k = s->topk;
+    if (H % 128) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill needs hidden %% 128 == 0");
+    const int CH = std::min(n_tokens, KR_PFM_CHUNK);
+
+    // ---- geometry of the widest layer -> scratch sizes (floats per token)
+    size_t pa = H, pb = 64, pc = 64, qd = 64, kd = 64, vd = 64, zd = 64, nvmax = 1, ad = H, sid = 0, kmax = H;
+    bool any_moe = false;
+    for (auto& L : s->layers) {
+        if (L.attn == ATTN_LA) {
+            pa = std::max(pa, (size_t)s->weights[L.qkvz_wid]->rows); pb = std::max(pb, (size_t)s->weights[L.ba_wid]->rows);
+            qd = std::max(qd, (size_t)L.nv * L.dk); kd = std::max(kd, (size_t)L.nv * L.dk); vd = std::max(vd, (size_t)L.nv * L.dv); zd = std::max(zd, (size_t)L.nv * L.dv);
+            nvmax = std::max(nvmax, (size_t)L.nv); ad = std::max(ad, (size_t)s->weights[L.out_wid]->cols);
+        } else if (L.attn == ATTN_GQA) {
+            pa = std::max(pa, (size_t)s->weights[L.q_wid]->rows); pb = std::max(pb, (size_t)s->weights[L.k_wid]->rows); pc = std::max(pc, (size_t)s->weights[L.v_wid]->rows);
+            qd = std::max(qd, (size_t)L.nh * L.hd); zd = std::max(zd, (size_t)L.nh * L.hd); ad = std::max(ad, (size_t)s->weights[L.o_wid]->cols);
+            if (start_pos + n_tokens > 36000) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: GQA score row exceeds LDS (context > 36000)");
+        } else if (L.attn == ATTN_MLA) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: MLA layers are decode-only in this build (feed the prompt through decode_step)");
+        if (L.mlp == MLP_MOE) {
+            any_moe = true;
+            if (L.sgu_wid >= 0) { sid = std::max(sid, (size_t)s->weights[L.sgu_wid]->rows); kmax = std::max(kmax, (size_t)s->weights[L.sd_wid]->cols); }
+        } else if (L.mlp == MLP_DENSE) { sid = std::max(sid, 2 * (size_t)s->weights[L.down_wid]->cols); kmax = std::max(kmax, (size_t)s->weights[L.down_wid]->cols); }
+    }
+    kmax = std::max(kmax, ad);
+    const size_t C = CH;
+    size_t total = 0;
+    auto take = [&](size_t bytes) { const size_t o = total; total += al(bytes); return o; };
+    const size_t o_res = take(C * H * 4), o_hid = take(C * H * 4), o_nrm = take(C * H * 4), o_pa = take(C * pa * 4), o_pb = take(C * pb * 4), o_pc = take(C * pc * 4),
+                 o_q = take(C * qd * 4), o_k = take(C * kd * 4), o_v = take(C * vd * 4), o_z = take(C * zd * 4), o_ge = take(C * nvmax * 4), o_be = take(C * nvmax * 4),
+                 o_rec = take(C * vd * 4), o_att = take(C * ad * 4), o_gate = take(C * zd * 4), o_moe = take(C * H * 4), o_sh = take(C * H * 4), o_gv = take(C * 4),
+                 o_sgu = take(C * std::max(sid, (size_t)64) * 4), o_xh = take(C * H), o_xl = take(C * H), o_xs = take(C * (H / 128) * 4), o_yh = take(C * kmax),
+                 o_yl = take(C * kmax), o_ys = take(C * (kmax / 128 + 1) * 4), o_xb = take(C * H * 2), o_ids = take(C * 32 * 4), o_w = take(C * 32 * 4), o_tok = take(C * 4),
+                 o_lg = take(C * (size_t)std::max(e->r_ne, 64) * 4);
+    if (s->pf_scratch.ensure(total)) return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch (%zu MiB) failed", total >> 20);
+    char* base = (char*)s->pf_scratch.p;
+    Scratch B{};
+    B.res = (float*)(base + o_res); B.hid = (float*)(base + o_hid); B.normed = (float*)(base + o_nrm); B.pa = (float*)(base + o_pa); B.pb = (float*)(base + o_pb);
+    B.pc = (float*)(base + o_pc); B.q = (float*)(base + o_q); B.k = (float*)(base + o_k); B.v = (float*)(base + o_v); B.z = (float*)(base + o_z);
+    B.gexp = (float*)(base + o_ge); B.beta = (float*)(base + o_be); B.recur = (float*)(base + o_rec); B.attn = (float*)(base + o_att); B.gate = (float*)(base + o_gate);
+    B.moe = (float*)(base + o_moe); B.sh = (float*)(base + o_sh); B.gv = (float*)(base + o_gv); B.sgu = (float*)(base + o_sgu); B.xh = (int8_t*)(base + o_xh);
+    B.xl = (int8_t*)(base + o_xl); B.xs = (float*)(base + o_xs); B.yh = (int8_t*)(base + o_yh); B.yl = (int8_t*)(base + o_yl); B.ys = (float*)(base + o_ys);
+    B.xb = (uint16_t*)(base + o_xb); B.ids = (int32_t*)(base + o_ids); B.w = (float*)(base + o_w); B.tok = (int*)(base + o_tok); B.logits = (float*)(base + o_lg);
+    (void)any_moe;
+
+    for (int c0 = 0; c0 < n_tokens; c0 += CH) {
+        const int Cc = std::min(CH, n_tokens - c0), pos0 = start_pos + c0;
+        KR_HIP(hipMemcpyAsync(B.tok, tokens + c0, (size_t)Cc * 4, hipMemcpyHostToDevice, st));
+        bool first = true, add_is_emb = true;
+        for (size_t li = 0; li < s->layers.size(); li++) {
+            DLayer& L = s->layers[li];
+            // ---- input norm (+ digits for the projections)
+            KrPfmNormArgs na{};
+            na.mode = add_is_emb ? 1 : 0; na.add_in = B.hid; na.emb = (const float*)s->embedding.p; na.tokens = B.tok; na.res = B.res;
+            na.w = (const float*)s->norms[L.input_norm]->p; na.out = B.normed; na.xh = B.xh; na.xl = B.xl; na.xs = B.xs; na.H = H; na.first = first ? 1 : 0;
+            na.bias_one = s->norm_bias_one; na.eps = s->eps;
+            kr_launch_pfm_norm(na, Cc, st);
+            first = false; add_is_emb = false;
+            if (L.attn == ATTN_LA) {
+                const int nq = s->weights[L.qkvz_wid]->rows, nb = s->weights[L.ba_wid]->rows, oc = s->weights[L.out_wid]->cols;
+                if (int rc = pf_gemm(s, L.qkvz_wid, B.xh, B.xl, B.xs, Cc, B.pa, nq, st)) return rc;
+                if (int rc = pf_gemm(s, L.ba_wid, B.xh, B.xl, B.xs, Cc, B.pb, nb, st)) return rc;
+                KrPfmLaArgs a{};
+                a.qkvz = B.pa; a.ld_qkvz = nq; a.ba = B.pb; a.ld_ba = nb; a.conv_state = (float*)L.conv_state.p; a.conv_w = (const float*)L.conv_w.p;
+                a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale; a.q = B.q; a.k = B.k; a.v = B.v; a.z = B.z;
+                a.gexp = B.gexp; a.beta = B.beta; a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
+                if (kr_launch_pfm_la(a, (float*)L.recur_state.p, B.recur, (const float*)L.la_norm_w.p, B.attn, Cc, s->eps, st))
+                    return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
+                if (oc != L.nv * L.dv) return kr_fail(KR_ERR_VALUE, "out_proj cols %d != nv*dv", oc);
+                kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
+                if (int rc = pf_gemm(s, L.out_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+            } else if (L.attn == ATTN_GQA) {
+                if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
+                const int nq = s->weights[L.q_wid]->rows, nk_ = s->weights[L.k_wid]->rows, nv_ = s->weights[L.v_wid]->rows, oc = s->weights[L.o_wid]->cols;
+                if (int rc = pf_gemm(s, L.q_wid, B.xh, B.xl, B.xs, Cc, B.pa, nq, st)) return rc;
+                if (int rc = pf_gemm(s, L.k_wid, B.xh, B.xl, B.xs, Cc, B.pb, nk_, st)) return rc;
+                if (int rc = pf_gemm(s, L.v_wid, B.xh, B.xl, B.xs, Cc, B.pc, nv_, st)) return rc;
+                KrPfmGqaArgs a{};
+                a.q_in = B.pa; a.k_in = B.pb; a.v_in = B.pc; a.ld_q = nq; a.ld_k = nk_; a.ld_v = nv_;
+                a.q_norm = L.q_norm_len ? (const float*)L.q_norm.p : nullptr; a.k_norm = L.k_norm_len ? (const float*)L.k_norm.p : nullptr;
+                a.q_norm_per_head = L.q_norm_len == L.nh * L.hd; a.k_norm_per_head = L.k_norm_len == L.nkv * L.hd;
+                a.rope_cos = (const float*)s->rope_cos.p; a.rope_sin = (const float*)s->rope_sin.p; a.rope_half = s->rope_half;
+                a.k_cache = (uint16_t*)L.kv_k.p; a.v_cache = (uint16_t*)L.kv_v.p; a.q_out = B.q; a.gate = B.gate; a.attn_out = B.attn;
+                a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.pos0 = pos0; a.eps = s->eps; a.sm_scale = L.sm_scale;
+                if (s->max_rope_seq > 0 && pos0 + Cc > s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "prompt exceeds the rope table (%d)", s->max_rope_seq);
+                kr_launch_pfm_gqa(a, Cc, st);
+                if (oc != L.nh * L.hd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*hd", oc);
+                kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
+                if (int rc = pf_gemm(s, L.o_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+            }
+            // ---- post-attention norm: f32 hidden, digits (shared expert / dense MLP), bf16 copy (routed experts)
+            na.mode = 0; na.add_in = B.hid; na.first = 0; na.w = (const float*)s->norms[L.post_norm]->p; na.out_bf16 = L.mlp == MLP_MOE ? B.xb : nullptr;
+            kr_launch_pfm_norm(na, Cc, st);
+            if (L.mlp == MLP_MOE) {
+                Layer& EL = e->layers[L.moe_layer];
+                if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
+                if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
+                const int E = e->r_ne;
+                kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, B.normed, EL.has_bias ? (const float*)EL.bias.p : nullptr, B.logits, Cc, E, H, st);
+                kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
+                // routed experts: exact CPU-engine arithmetic on the matrix cores, f32 weighted sum in routing order
+                if (int rc = kr_moe_prefill(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, (void*)(st ? (void*)st : (void*)1))) return rc;
+                const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
+                if (has_shared) {   // decode-store numerics: f32 input digits, fast_silu_mul + f32::round digits (decode.rs:3356-3378)
+                    const int si2 = s->weights[L.sgu_wid]->rows, SI = si2 / 2;
+                    if (SI % 128) return kr_fail(KR_ERR_VALUE, "shared expert intermediate %d not a multiple of 128", SI);
+                    if (int rc = pf_gemm(s, L.sgu_wid, B.xh, B.xl, B.xs, Cc, B.sgu, si2, st)) return rc;
+                    kr_launch_pf_act(B.sgu, Cc, SI, si2, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yh, B.yl, B.ys, st);
+                    if (int rc = pf_gemm(s, L.sd_wid, B.yh, B.yl, B.ys, Cc, B.sh, H, st)) return rc;
+                    if (has_gate) if (int rc = pf_gemm(s, L.sg_wid, B.xh, B.xl, B.xs, Cc, B.gv, 1, st)) return rc;
+                }
+                kr_launch_pfm_moe_epilogue(B.moe, has_shared ? B.sh : nullptr, has_gate ? B.gv : nullptr, 1, s->rsf, B.hid, Cc, H, st);
+            } else if (L.mlp == MLP_DENSE) {
+                const int K = s->weights[L.down_wid]->cols, ng = s->weights[L.gate_wid]->rows, nu = s->weights[L.up_wid]->rows;
+                if (K % 128) return kr_fail(KR_ERR_VALUE, "dense MLP intermediate %d not a multiple of 128", K);
+                KR_HIP(hipMemsetAsync(B.sgu, 0, (size_t)Cc * 2 * K * 4, st));   // padding of gate | up stays 0 (decode.rs dense path)
+                {   // gate -> [0,K), up -> [K,2K) of each row
+                    DWeight& Wg = *s->weights[L.gate_wid]; DWeight& Wu = *s->weights[L.up_wid];
+                    if (Wg.ms.bits != 4 || Wu.ms.bits != 4) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: dense MLP weights must be INT4-g128");
+                    if (int rc = kr_ensure_wsum(e, Wg.ms, st)) return rc;
+                    if (int rc = kr_ensure_wsum(e, Wu.ms, st)) return rc;
+                    kr_launch_pf_gemm(Wg.ms.view(), (const uint32_t*)Wg.ms.wsum.p, B.xh, B.xl, B.xs, nullptr, 1, 0, 0, Cc, B.sgu, 2 * K, st);
+                    kr_launch_pf_gemm(Wu.ms.view(), (const uint32_t*)Wu.ms.wsum.p, B.xh, B.xl, B.xs, nullptr, 1, 0, 0, Cc, B.sgu + K, 2 * K, st);
+                    (void)ng; (void)nu;
+                }
+                kr_launch_pf_act(B.sgu, Cc, K, 2 * K, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yh, B.yl, B.ys, st);
+                if (int rc = pf_gemm(s, L.down_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+            } else {
+                KR_HIP(hipMemcpyAsync(B.hid, B.normed, (size_t)Cc * H * 4, hipMemcpyDeviceToDevice, st));   // no MLP: hidden stays the normalised value
+            }
+        }
+        if (c0 + Cc == n_tokens) {
+            // ---- final norm + lm_head + greedy sample for the LAST token only (the other positions' logits are never consumed)
+            KrPfmNormArgs na{};
+            na.mode = add_is_emb ? 1 : 0; na.add_in = B.hid; na.emb = (const float*)s->embedding.p; na.tokens = B.tok; na.res = B.res;
+            na.w = (const float*)s->norms[s->final_norm]->p; na.out = B.normed; na.H = H; na.first = first ? 1 : 0; na.bias_one = s->norm_bias_one; na.eps = s->eps;
+            kr_launch_pfm_norm(na, Cc, st);
+            kr_launch_matvec(mv(s, s->lm_head), B.normed + (size_t)(Cc - 1) * H, 1, (float*)s->logits.p, st);
+            kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, st);
+        }
+    }
+    KR_HIP(hipGetLastError());
+    if (logits_out) {
+        if (is_device_ptr(logits_out)) KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToDevice, st));
+        else { KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }
+    }
+    return KR_OK;
+}

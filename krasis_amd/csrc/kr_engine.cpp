@@ -675,7 +675,7 @@ extern "C" int kr_get_profile(kr_engine* e, int kind, double* total_ms, long* la
 // ------------------------------------------------------------------------------------------------
 // prefill: GpuPrefillManager.forward (python/krasis/gpu_prefill.py:4374-4484) on int8 MFMA, numerics == kr_moe_forward
 // ------------------------------------------------------------------------------------------------
-static int ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st) {
+int kr_ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st) {
     if (ms.wsum.p || !ms.allocated()) return KR_OK;
     if (ms.bits != 4) return kr_fail(KR_ERR_VALUE, "prefill MFMA path is built for INT4-g128 experts (got %d-bit)", ms.bits);
     if (ms.wsum.ensure(ms.s_stride * ms.count)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
@@ -703,9 +703,9 @@ extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const
     const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
     const bool use_shared = L.shared_present && !routed_only;
     const int SI = L.shared_inter;
-    if (int rc = ensure_wsum(e, L.w13, st)) return rc;
-    if (int rc = ensure_wsum(e, L.w2, st)) return rc;
-    if (use_shared) { if (int rc = ensure_wsum(e, L.sw13, st)) return rc; if (int rc = ensure_wsum(e, L.sw2, st)) return rc; }
+    if (int rc = kr_ensure_wsum(e, L.w13, st)) return rc;
+    if (int rc = kr_ensure_wsum(e, L.w2, st)) return rc;
+    if (use_shared) { if (int rc = kr_ensure_wsum(e, L.sw13, st)) return rc; if (int rc = kr_ensure_wsum(e, L.sw2, st)) return rc; }
     const int CH = M < KR_PF_CHUNK ? M : KR_PF_CHUNK;
     const size_t np = (size_t)CH * topk;
     const int max_tiles = (int)(np / 64) + E + 1;

@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(256) kr_pf_gemm_kernel(const KrPfGemmArgs a) {
     const int col = n0 + wave * 32 + (lane & 31);          // this lane's output column
     const int ctile = col >> 3, cin = col & 7;
     const int khalf = (lane >> 5) * 16;
+    const bool fused = col < m.n_fma;
 
     for (int gp = 0; gp < m.ngp; gp++) {
         // ---- stage A digits (64 rows x 256 k, two planes): thread -> (row = tid/4, 64-byte quarter)
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(256) kr_pf_gemm_kernel(const KrPfGemmArgs a) {
                         const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                         const int isum = (acc_hi[s][r] << 8) + acc_lo[s][r] + wsum128;
                         const float comb = wscale * As_sc[h * PF_BM + row];
-                        outv[s][r] = __builtin_fmaf((float)isum, comb, outv[s][r]);
+                        outv[s][r] = fused ? __builtin_fmaf((float)isum, comb, outv[s][r]) : (outv[s][r] + (float)isum * comb);   // avx2.rs:1175 / :1201
                     }
             }
         }
@@ -331,6 +332,7 @@ void kr_launch_pf_quant_x(const uint16_t* x, int M, int K, int8_t* xh, int8_t* x
 void kr_launch_pf_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, int8_t* hh, int8_t* hl, float* hs, hipStream_t st) {
     const int thr = n / 8 < 1024 ? n / 8 : 1024;
     if (act_mode == KR_ACT_GPTOSS) hipLaunchKernelGGL(kr_pf_act_kernel<KR_ACT_GPTOSS>, dim3(rows), dim3(thr), 0, st, gu, n, gu_ld, swiglu_limit, alpha, hh, hl, hs);
+    else if (act_mode == KR_ACT_SILU_MUL) hipLaunchKernelGGL(kr_pf_act_kernel<KR_ACT_SILU_MUL>, dim3(rows), dim3(thr), 0, st, gu, n, gu_ld, swiglu_limit, alpha, hh, hl, hs);
     else hipLaunchKernelGGL(kr_pf_act_kernel<KR_ACT_SILU_FUSED>, dim3(rows), dim3(thr), 0, st, gu, n, gu_ld, swiglu_limit, alpha, hh, hl, hs);
 }
 void kr_launch_pf_wsum(const KrMatDev& m, int n_experts, uint32_t* wsum, hipStream_t st) {

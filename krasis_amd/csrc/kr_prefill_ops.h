@@ -1,0 +1,34 @@
+// kr_prefill_ops.h -- launch wrappers of kr_prefill_ops.hip (batched decode-graph operators for kr_decode_prefill)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct KrPfmNormArgs {
+    int mode;                     // 0: add_in[t]; 1: embedding row of tokens[t]
+    const float* add_in; const float* emb; const int* tokens;
+    float* res;                   // [C,H] residual stream, updated in place
+    const float* w; float* out;   // norm weight [H]; normalised hidden f32 [C,H]
+    int8_t *xh, *xl; float* xs;   // optional INT16 digits of the normalised hidden (quantize_activation_int16_f32)
+    uint16_t* out_bf16;           // optional bf16 copy (input of the routed experts)
+    int H, first, bias_one; float eps;
+};
+struct KrPfmLaArgs {
+    const float* qkvz; int ld_qkvz; const float* ba; int ld_ba;
+    float* conv_state; const float* conv_w; const float* a_log; const float* dt_bias; float scale;
+    float *q, *k, *v, *z, *gexp, *beta;   // [C, nv*dk] x2, [C, nv*dv] x2, [C, nv] x2
+    int nk, nv, dk, dv, hr;
+};
+struct KrPfmGqaArgs {
+    const float *q_in, *k_in, *v_in; int ld_q, ld_k, ld_v;
+    const float *q_norm, *k_norm; int q_norm_per_head, k_norm_per_head;
+    const float *rope_cos, *rope_sin; int rope_half;
+    uint16_t *k_cache, *v_cache;
+    float *q_out, *gate, *attn_out;   // [C, nh*hd]
+    int gated, nh, nkv, hd, pos0; float eps, sm_scale;
+};
+void kr_launch_pfm_norm(const KrPfmNormArgs& a, int C, hipStream_t st);
+void kr_launch_pfm_quant_f32(const float* x, int rows, int ld, int K, int8_t* xh, int8_t* xl, float* xs, hipStream_t st);
+// conv + conv-state update + gated delta rule over the chunk + gated RMSNorm; non-zero = unsupported geometry
+int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out, const float* norm_w, float* gated_out, int C, float eps, hipStream_t st);
+void kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, hipStream_t st);
+void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st);

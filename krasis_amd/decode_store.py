@@ -160,6 +160,14 @@ class CpuDecodeStore:
         self._need()
         check(self._lib.kr_decode_step(self._h, token_id, position, output_ptr or None, stream or None))
 
+    def prefill(self, tokens: Sequence[int], start_pos: int = 0, output_ptr: int = 0, stream: int = 0) -> int:
+        """Whole-model prompt pass on the GPU (kr_decode_prefill): equivalent to calling decode_step for every prompt token, which is what
+        replaces model.server_prefill + CpuDecoder.prepare (decode_setup.py:232-278).  Returns the greedy sample of the last position."""
+        self._need()
+        arr = (C.c_int32 * len(tokens))(*tokens)
+        check(self._lib.kr_decode_prefill(self._h, arr, len(tokens), start_pos, output_ptr or None, stream or None))
+        return self.last_token()
+
     def generate_batch(self, first_token: int, start_pos: int, max_tokens: int, temperature: float = 0.0, top_k: int = 0, top_p: float = 1.0,
                        stop_ids: Sequence[int] = (), presence_penalty: float = 0.0) -> List[int]:
         self._need()

@@ -88,8 +88,10 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False):
     st.set_decode_rope(_ptr(cos), _ptr(sin), d2, kv_max)
     st.finalize_decode()
     z = lambda xs: [(_ptr(x) if x is not None else 0) for x in xs]
-    st.set_decode_state(5, kv_max, z(state["kv_k"]), z(state["kv_v"]), z(state["conv"]), z(state["recur"]))
-    return st, eng, orc, keep, dict(H=H, V=V, kinds=kinds, kv_max=kv_max, nkv=nkv, hd=hd, conv_dim=2 * nk * dk + nv * dv, nv=nv, dk=dk, dv=dv)
+    reset = lambda: st.set_decode_state(5, kv_max, z(state["kv_k"]), z(state["kv_v"]), z(state["conv"]), z(state["recur"]))
+    reset()
+    return st, eng, orc, keep, dict(H=H, V=V, kinds=kinds, kv_max=kv_max, nkv=nkv, hd=hd, conv_dim=2 * nk * dk + nv * dv, nv=nv, dk=dk, dv=dv, reset=reset,
+                                    state=state)
 
 
 @pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True)])

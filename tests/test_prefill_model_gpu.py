@@ -1,0 +1,59 @@
+"""Whole-model prompt pass (kr_decode_prefill) == token-by-token decode, BIT FOR BIT: last-position logits, greedy sample, FP16 KV caches,
+conv and recurrent state.  The decode path is itself bit-exact against the oracle (tests/test_decode_gpu.py), so prefill == decode == oracle."""
+import numpy as np
+import pytest
+
+from tests.test_decode_gpu import build
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _snapshot(st, d):
+    out = []
+    for li, kind in enumerate(d["kinds"]):
+        if kind == "la":
+            cs = np.empty(d["conv_dim"] * 4, F); rs = np.empty(d["nv"] * d["dk"] * d["dv"], F)
+            st.get_decode_state(li, None, None, cs, rs); out.append((cs, rs))
+        else:
+            kc = np.empty((d["kv_max"], d["nkv"] * d["hd"]), np.uint16); vc = np.empty_like(kc)
+            st.get_decode_state(li, kc, vc, None, None); out.append((kc, vc))
+    return out
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True)])
+@pytest.mark.parametrize("n_tok,start", [(1, 5), (3, 5), (9, 0), (20, 7)])
+def test_prefill_equals_sequential_decode(cfg, n_tok, start):
+    st, eng, orc, keep, d = build(**cfg)
+    rng = np.random.default_rng(n_tok * 31 + start)
+    toks = [int(x) for x in rng.integers(0, d["V"], n_tok)]
+    # reference: token-by-token decode from the same initial state
+    st.set_use_graph(True)
+    ref_logits = np.empty(d["V"], F)
+    for i, t in enumerate(toks):
+        st.decode_step(t, start + i, ref_logits.ctypes.data)
+    ref_tok = st.last_token()
+    ref_state = _snapshot(st, d)
+    # prompt pass from the same initial state
+    d["reset"]()
+    logits = np.empty(d["V"], F)
+    tok = st.prefill(toks, start, logits.ctypes.data)
+    assert np.array_equal(logits.view(np.uint32), ref_logits.view(np.uint32)), float(np.max(np.abs(logits - ref_logits)))
+    assert tok == ref_tok
+    for li, (a, b) in enumerate(zip(_snapshot(st, d), ref_state)):
+        assert np.array_equal(a[0].view(np.uint32) if a[0].dtype == F else a[0], b[0].view(np.uint32) if b[0].dtype == F else b[0]), ("state0", li)
+        assert np.array_equal(a[1].view(np.uint32) if a[1].dtype == F else a[1], b[1].view(np.uint32) if b[1].dtype == F else b[1]), ("state1", li)
+    # and decoding continues seamlessly after the prompt pass
+    nxt = np.empty(d["V"], F)
+    st.decode_step(tok, start + n_tok, nxt.ctypes.data)
+    assert np.isfinite(nxt).all()
+
+
+def test_prefill_argument_errors():
+    st, eng, orc, keep, d = build()
+    with pytest.raises(ValueError):
+        st.prefill([], 0)
+    with pytest.raises(ValueError):
+        st.prefill([1, 2, 3], d["kv_max"] - 1)            # does not fit kv_max_seq
+    with pytest.raises(ValueError):
+        st.prefill([d["V"] + 5], 0)                       # token id out of range
