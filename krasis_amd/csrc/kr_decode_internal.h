@@ -47,6 +47,7 @@ struct kr_decode_store {
     DevBuf dense_gu;  // [gate(K) | up(K)] of the dense MLP; only [0,inter) of each half is ever written, the padding stays 0
     DevBuf hid2, res2, r_counter, argmax_scratch;
     bool fuse_router = true;   // hid2/res2: outputs of the fused norm+router launch (its inputs stay readable for every workgroup)
+    DevBuf pf_scores;          // kr_decode_prefill: attention scores [chunk*nh rows][context] f32
     DevBuf pf_scratch;         // kr_decode_prefill: one arena for the chunk buffers
     DevBuf moe_gu, moe_eo, r_logits, r_ids, r_w;  // store-owned so a captured graph never sees them reallocated
     DevBuf step_dev; KrStep* step_host = nullptr;

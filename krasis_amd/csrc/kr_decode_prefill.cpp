@@ -63,7 +63,6 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
         } else if (L.attn == ATTN_GQA) {
             pa = std::max(pa, (size_t)s->weights[L.q_wid]->rows); pb = std::max(pb, (size_t)s->weights[L.k_wid]->rows); pc = std::max(pc, (size_t)s->weights[L.v_wid]->rows);
             qd = std::max(qd, (size_t)L.nh * L.hd); zd = std::max(zd, (size_t)L.nh * L.hd); ad = std::max(ad, (size_t)s->weights[L.o_wid]->cols);
-            if (start_pos + n_tokens > 36000) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: GQA score row exceeds LDS (context > 36000)");
         } else if (L.attn == ATTN_MLA) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: MLA layers are decode-only in this build (feed the prompt through decode_step)");
         if (L.mlp == MLP_MOE) {
             any_moe = true;
@@ -131,7 +130,10 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
                 a.k_cache = (uint16_t*)L.kv_k.p; a.v_cache = (uint16_t*)L.kv_v.p; a.q_out = B.q; a.gate = B.gate; a.attn_out = B.attn;
                 a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.pos0 = pos0; a.eps = s->eps; a.sm_scale = L.sm_scale;
                 if (s->max_rope_seq > 0 && pos0 + Cc > s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "prompt exceeds the rope table (%d)", s->max_rope_seq);
-                kr_launch_pfm_gqa(a, Cc, st);
+                const int sc_ld = (pos0 + Cc + 63) & ~63;
+                if (s->pf_scores.ensure((size_t)Cc * L.nh * ((size_t)sc_ld + 1) * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
+                float* scp = (float*)s->pf_scores.p;
+                if (kr_launch_pfm_gqa(a, Cc, scp, sc_ld, scp + (size_t)Cc * L.nh * sc_ld, st)) return kr_fail(KR_ERR_VALUE, "unsupported GQA geometry for the prompt pass");
                 if (oc != L.nh * L.hd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*hd", oc);
                 kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
                 if (int rc = pf_gemm(s, L.o_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;

@@ -30,5 +30,7 @@ void kr_launch_pfm_norm(const KrPfmNormArgs& a, int C, hipStream_t st);
 void kr_launch_pfm_quant_f32(const float* x, int rows, int ld, int K, int8_t* xh, int8_t* xl, float* xs, hipStream_t st);
 // conv + conv-state update + gated delta rule over the chunk + gated RMSNorm; non-zero = unsupported geometry
 int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out, const float* norm_w, float* gated_out, int C, float eps, hipStream_t st);
-void kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, hipStream_t st);
+// prep (norm, RoPE, KV append) + scores -> softmax -> P.V over the score scratch sc[C*nh rows][sc_ld] (sc_ld >= pos0 + C), inv[C*nh];
+// non-zero = unsupported geometry
+int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st);
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st);

@@ -165,6 +165,8 @@ __global__ void kr_pfm_la_conv_state_kernel(const KrPfmLaArgs a, int C) {
 
 // ---- gated delta rule over the chunk (decode.rs:1293): one thread per state column, the column lives in registers ------------
 // grid nv, dv threads.  Per token: kv = chain_i fma(S[i]*e^g, k[i]); delta = (v - kv)*beta; S[i] = fma(k[i], delta, S[i]*e^g); o = chain_i fma(S[i], q[i]).
+// The two DK-long fma chains per token are inherent to the reference order (measured alternatives -- LDS-staged token blocks, interleaving
+// the chains of consecutive tokens, scalar loads of k/q -- were all slower than this form on MI355X: the wave is issue/latency bound).
 template <int DK>
 __global__ void __launch_bounds__(256) kr_pfm_la_recur_kernel(float* __restrict__ state, const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, const float* __restrict__ gexp, const float* __restrict__ beta,
@@ -256,55 +258,174 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_prep_kernel(const KrPfmGqaArgs
     }
 }
 
-// causal attention of token t over cache positions 0..pos0+t (decode.rs:4194); grid (nh, C), 256 threads, LDS (max_seq + 8) floats
-__global__ void __launch_bounds__(256) kr_pfm_gqa_attn_kernel(const KrPfmGqaArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sc[];
-    __shared__ float qs[256]; __shared__ float red[8];
-    const int h = blockIdx.x, t = blockIdx.y, hd = a.hd, kvs = a.nkv * hd, seq = a.pos0 + t + 1;
-    const int kvh = h / (a.nh / a.nkv);
-    if (threadIdx.x < hd) qs[threadIdx.x] = a.q_out[(size_t)t * a.nh * hd + (size_t)h * hd + threadIdx.x];
-    __syncthreads();
-    const int l = threadIdx.x & 7;
-    for (int s = threadIdx.x >> 3; s < seq; s += 32) {
-        const uint16_t* kr = a.k_cache + (size_t)s * kvs + (size_t)kvh * hd;
-        float acc = 0.0f;
-        for (int b = 0; b < hd / 8; b++) acc = __builtin_fmaf(qs[b * 8 + l], __half2float(__ushort_as_half(kr[b * 8 + l])), acc);
-        acc = kr_pfm_hsum8(acc);
-        if (l == 0) sc[s] = acc * a.sm_scale;
+// ---- causal attention over the FP16 cache, exact decode order (decode.rs:4194-4281), three passes that share K / V across queries ----
+// A query is (token t, head h); the R = group * TT queries of one kv head and TT consecutive tokens form a tile.  Scores live in an
+// HBM scratch sc[row = t*nh + h][pos] (row stride sc_ld) so the softmax keeps the reference's max / exp / sequential-sum / scale
+// order over the WHOLE row, and P.V accumulates position by position.
+#define PFA_TT_MAX 32          // queries per tile (registers of pass C)
+#define PFA_LDB 36             // floats per lane record (32 + pad) in the transposed LDS images
+
+// pass A: scores.  grid (position tiles of 256, token tiles, nkv); 256 threads = 32 lane-groups of 8; a lane-group owns one position
+// per pass, keeps that K row in registers (lane l: elements 8b + l) and evaluates every query of the tile against it:
+//   s = hsum8( chain_b fma(q[8b+l], k[8b+l]) ) * sm_scale      (single accumulator, decode.rs:4229-4242)
+__global__ void __launch_bounds__(256) kr_pfm_gqa_scores_kernel(const KrPfmGqaArgs a, float* __restrict__ sc, int sc_ld, int TT, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int hd = a.hd, nb = hd / 8, group = a.nh / a.nkv, kvh = blockIdx.z, t0 = blockIdx.y * TT, kvs = a.nkv * hd;
+    const int tn = min(TT, C - t0), R = group * tn;
+    const int p_lo = blockIdx.x * 256, p_max = a.pos0 + t0 + tn - 1;     // last position any query of the tile may see
+    if (p_lo > p_max) return;
+    float* qT = lds;                              // [R][8 lanes][PFA_LDB]   q[r][8b + l] at (r*8 + l)*PFA_LDB + b
+    float* kT = lds + (size_t)group * TT * 8 * PFA_LDB;   // [32 positions][8 lanes][PFA_LDB]
+    const int tid = threadIdx.x, g = tid >> 3, l = tid & 7;
+    for (int i = tid; i < R * hd; i += 256) {
+        const int r = i / hd, d = i % hd, tt = r / group, hh = kvh * group + r % group;
+        qT[(r * 8 + (d & 7)) * PFA_LDB + (d >> 3)] = a.q_out[(size_t)(t0 + tt) * a.nh * hd + (size_t)hh * hd + d];
     }
-    __syncthreads();
+    for (int pass = 0; pass < 8; pass++) {
+        const int pb = p_lo + pass * 32;
+        if (pb > p_max) break;
+        __syncthreads();                          // q staged / previous K tile consumed
+        for (int i = tid; i < 32 * (hd / 8); i += 256) {   // 16-byte loads: 8 halves = one b-block of one position
+            const int pp = i / (hd / 8), b = i % (hd / 8), pos = pb + pp;
+            u32x4 w = {0, 0, 0, 0};
+            if (pos <= p_max) w = *reinterpret_cast<const u32x4*>(a.k_cache + (size_t)pos * kvs + (size_t)kvh * hd + b * 8);
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                kT[(pp * 8 + 2 * j) * PFA_LDB + b] = __half2float(__ushort_as_half((uint16_t)(ww[j] & 0xFFFFu)));
+                kT[(pp * 8 + 2 * j + 1) * PFA_LDB + b] = __half2float(__ushort_as_half((uint16_t)(ww[j] >> 16)));
+            }
+        }
+        __syncthreads();
+        const int pos = pb + g;
+        float kr[32];
+#pragma unroll
+        for (int b4 = 0; b4 < 8; b4++) {
+            if (b4 * 4 < nb) {
+                const float4 v = *reinterpret_cast<const float4*>(kT + (g * 8 + l) * PFA_LDB + b4 * 4);
+                kr[b4 * 4] = v.x; kr[b4 * 4 + 1] = v.y; kr[b4 * 4 + 2] = v.z; kr[b4 * 4 + 3] = v.w;
+            }
+        }
+        for (int r0 = 0; r0 < R; r0 += 4) {       // 4 queries at a time: 4 independent fma chains per lane
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float* qb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) qb[u] = qT + ((r0 + u < R ? r0 + u : R - 1) * 8 + l) * PFA_LDB;
+#pragma unroll
+            for (int b4 = 0; b4 < 8; b4++) {
+                if (b4 * 4 < nb) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float4 qv = *reinterpret_cast<const float4*>(qb[u] + b4 * 4);
+                        acc[u] = __builtin_fmaf(qv.x, kr[b4 * 4], acc[u]); acc[u] = __builtin_fmaf(qv.y, kr[b4 * 4 + 1], acc[u]);
+                        acc[u] = __builtin_fmaf(qv.z, kr[b4 * 4 + 2], acc[u]); acc[u] = __builtin_fmaf(qv.w, kr[b4 * 4 + 3], acc[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = r0 + u, tt = r / group, hh = kvh * group + r % group, qpos = a.pos0 + t0 + tt;
+                const float sv = kr_pfm_hsum8(acc[u]);
+                if (r < R && l == 0 && pos <= qpos) sc[((size_t)(t0 + tt) * a.nh + hh) * sc_ld + pos] = sv * a.sm_scale;
+            }
+        }
+    }
+}
+
+// pass B: per row  max -> e = exp(s - max) (libm) -> sequential sum in position order -> inv = 1 / sum  (decode.rs:4244-4262).
+// one wave per row: 64 positions at a time are exponentiated in parallel, lane 0 adds them in order.
+__global__ void __launch_bounds__(256) kr_pfm_gqa_softmax_kernel(float* __restrict__ sc, int sc_ld, float* __restrict__ inv, int nh, int pos0, int rows) {
+    __shared__ __attribute__((aligned(16))) float buf[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int seq = pos0 + row / nh + 1;
+    float* s = sc + (size_t)row * sc_ld;
     float mx = -__builtin_inff();
-    for (int s = threadIdx.x; s < seq; s += 256) mx = fmaxf(mx, sc[s]);
+    for (int p = lane; p < seq; p += 64) mx = fmaxf(mx, s[p]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    for (int s = threadIdx.x; s < seq; s += 256) sc[s] = kr_expf(sc[s] - mx);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float se = 0.0f; int s = 0;
-        for (; s + 8 <= seq; s += 8) {
-            float v[8];
+    float se = 0.0f;
+    for (int p0 = 0; p0 < seq; p0 += 64) {
+        const int p = p0 + lane;
+        float e = 0.0f;
+        if (p < seq) { e = kr_expf(s[p] - mx); s[p] = e; }
+        buf[wave][lane] = e;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const int n = min(64, seq - p0);
+            if (n == 64) {
+                const float4* b4 = reinterpret_cast<const float4*>(buf[wave]);
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = sc[s + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) se += v[u];
+                for (int u = 0; u < 16; u++) { const float4 v = b4[u]; se += v.x; se += v.y; se += v.z; se += v.w; }
+            } else for (int u = 0; u < n; u++) se += buf[wave][u];
         }
-        for (; s < seq; s++) se += sc[s];
-        red[4] = 1.0f / se;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    const float inv = red[4];
-    for (int s = threadIdx.x; s < seq; s += 256) sc[s] *= inv;
-    __syncthreads();
-    const int d = threadIdx.x;
+    if (lane == 0) inv[row] = 1.0f / se;
+}
+
+// pass C: out[t][h][d] = chain_pos fma(e[pos] * inv, V[pos][d]) (decode.rs:4264-4273), gated by sigmoid(gate) (:4277).
+// grid (token tiles, nkv); thread d keeps one accumulator per query of the tile; V rows are read once per tile.
+__global__ void __launch_bounds__(256) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a, const float* __restrict__ sc, int sc_ld, const float* __restrict__ inv, int TT, int C) {
+    __shared__ __attribute__((aligned(16))) float P[PFA_TT_MAX][64];
+    __shared__ float s_inv[PFA_TT_MAX];
+    const int hd = a.hd, group = a.nh / a.nkv, kvh = blockIdx.y, t0 = blockIdx.x * TT, kvs = a.nkv * hd;
+    const int tn = min(TT, C - t0), R = group * tn, d = threadIdx.x, p_max = a.pos0 + t0 + tn - 1;
+    if (d < R) { const int tt = d / group, hh = kvh * group + d % group; s_inv[d] = inv[(size_t)(t0 + tt) * a.nh + hh]; }
+    float acc[PFA_TT_MAX];
+#pragma unroll
+    for (int r = 0; r < PFA_TT_MAX; r++) acc[r] = 0.0f;
+    const uint16_t* vc = a.v_cache + (size_t)kvh * hd + (d < hd ? d : 0);
+    for (int p0 = 0; p0 <= p_max; p0 += 64) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < R * 64; i += 256) {
+            const int r = i >> 6, pp = i & 63, tt = r / group, hh = kvh * group + r % group, pos = p0 + pp;
+            P[r][pp] = pos <= a.pos0 + t0 + tt ? sc[((size_t)(t0 + tt) * a.nh + hh) * sc_ld + pos] * s_inv[r] : 0.0f;   // sc[s] *= inv (decode.rs:4260)
+        }
+        __syncthreads();
+        const int np = min(64, p_max + 1 - p0);
+        if (p0 + 63 <= a.pos0 + t0 && R == PFA_TT_MAX) {   // tile entirely below the diagonal, full query tile: no masks, no branches
+            for (int pp0 = 0; pp0 < 64; pp0 += 4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = __half2float(__ushort_as_half(vc[(size_t)(p0 + pp0 + u) * kvs]));
+#pragma unroll
+                for (int r = 0; r < PFA_TT_MAX; r++) {
+                    const float4 pr = *reinterpret_cast<const float4*>(&P[r][pp0]);
+                    acc[r] = __builtin_fmaf(pr.x, v[0], acc[r]); acc[r] = __builtin_fmaf(pr.y, v[1], acc[r]);
+                    acc[r] = __builtin_fmaf(pr.z, v[2], acc[r]); acc[r] = __builtin_fmaf(pr.w, v[3], acc[r]);
+                }
+            }
+            continue;
+        }
+        for (int pp0 = 0; pp0 < np; pp0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = (pp0 + u < np) ? __half2float(__ushort_as_half(vc[(size_t)(p0 + pp0 + u) * kvs])) : 0.0f;
+#pragma unroll
+            for (int r = 0; r < PFA_TT_MAX; r++) {
+                if (r < R) {
+                    const int lim = a.pos0 + t0 + r / group - (p0 + pp0);    // positions pp0 + u with u <= lim are visible to query r
+                    const float4 pr = *reinterpret_cast<const float4*>(&P[r][pp0]);
+                    if (lim >= 0) acc[r] = __builtin_fmaf(pr.x, v[0], acc[r]);
+                    if (lim >= 1 && pp0 + 1 < np) acc[r] = __builtin_fmaf(pr.y, v[1], acc[r]);
+                    if (lim >= 2 && pp0 + 2 < np) acc[r] = __builtin_fmaf(pr.z, v[2], acc[r]);
+                    if (lim >= 3 && pp0 + 3 < np) acc[r] = __builtin_fmaf(pr.w, v[3], acc[r]);
+                }
+            }
+        }
+    }
     if (d < hd) {
-        const uint16_t* vc = a.v_cache + (size_t)kvh * hd + d;
-        float o = 0.0f;
-        for (int s = 0; s < seq; s++) o = __builtin_fmaf(sc[s], __half2float(__ushort_as_half(vc[(size_t)s * kvs])), o);
-        if (a.gated) { const float gt = a.gate[(size_t)t * a.nh * hd + (size_t)h * hd + d]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
-        a.attn_out[(size_t)t * a.nh * hd + (size_t)h * hd + d] = o;
+#pragma unroll
+        for (int r = 0; r < PFA_TT_MAX; r++) {
+            if (r < R) {
+                const int tt = r / group, hh = kvh * group + r % group;
+                float o = acc[r];
+                const size_t oi = (size_t)(t0 + tt) * a.nh * hd + (size_t)hh * hd + d;
+                if (a.gated) { const float gt = a.gate[oi]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
+                a.attn_out[oi] = o;
+            }
+        }
     }
 }
 
@@ -344,9 +465,20 @@ int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out,
     hipLaunchKernelGGL(kr_pfm_gated_norm_kernel, dim3(a.nv, C), dim3(a.dv), 0, st, recur_out, a.z, norm_w, gated_out, a.nv, a.dv, eps);
     return 0;
 }
-void kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, hipStream_t st) {
+int kr_pfm_gqa_tile(int nh, int nkv) { const int group = nh / nkv; int tt = PFA_TT_MAX / group; return tt < 1 ? 0 : tt; }
+int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st) {
+    const int group = a.nh / a.nkv, TT = kr_pfm_gqa_tile(a.nh, a.nkv);
+    if (TT == 0 || a.hd > 256 || a.hd % 32 || a.nh % a.nkv) return 1;
     hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, C), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(kr_pfm_gqa_attn_kernel, dim3(a.nh, C), dim3(256), (size_t)(a.pos0 + C + 8) * 4, st, a);
+    const int ntt = (C + TT - 1) / TT, npt = (a.pos0 + C + 255) / 256;
+    const size_t lds = ((size_t)group * TT * 8 + 32 * 8) * PFA_LDB * 4;
+    static bool big_lds_set = false;   // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950)
+    if (!big_lds_set) { (void)hipFuncSetAttribute((const void*)kr_pfm_gqa_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); big_lds_set = true; }
+    hipLaunchKernelGGL(kr_pfm_gqa_scores_kernel, dim3(npt, ntt, a.nkv), dim3(256), lds, st, a, sc, sc_ld, TT, C);
+    const int rows = C * a.nh;
+    hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, a.nh, a.pos0, rows);
+    hipLaunchKernelGGL(kr_pfm_gqa_pv_kernel, dim3(ntt, a.nkv), dim3(256), 0, st, a, sc, sc_ld, inv, TT, C);
+    return 0;
 }
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st) {
     hipLaunchKernelGGL(kr_pfm_moe_epilogue_kernel, dim3((H + 255) / 256, C), dim3(256), 0, st, moe, shared, gate_val, gate_ld, rsf, hidden, H);
