@@ -26,8 +26,22 @@ KINDS = ["embed", "fused_add_rmsnorm", "proj_matvec", "la_conv", "la_recurrent",
          "route_select", "moe_w13", "moe_w2", "moe_combine", "lm_head", "argmax", "shared_gate"]
 SYMBOL = {"proj_matvec": "kr_matvec_kernel<float,4>", "lm_head": "kr_matvec_kernel<float,4>", "shared_gate": "kr_matvec_kernel<float,4>",
           "moe_w13": "kr_moe_w13_kernel<4>", "moe_w2": "kr_moe_w2_kernel<4,0>", "la_recurrent": "kr_la_recurrent_kernel<128>",
-          "route_logits": "kr_route_logits_decode_kernel<true>", "route_select": "kr_route_select_kernel",
+          "route_logits": "kr_route_fused_decode_kernel<true,8>", "route_select": "kr_route_select_kernel",
           "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
+
+
+def pmc_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 --pmc FETCH_SIZE pass (separate run, profiles/*pmc*.json; corrected as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes).  None when no PMC summary is committed for that kernel."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if symbol in d.get("kernels", {}):
+                return d["kernels"][symbol], os.path.basename(f)
+        except Exception:
+            pass
+    return None, None
 
 
 def parse():
@@ -184,9 +198,10 @@ def prefill_model(st, L, P, reps, torch):
 
 def cpu_baseline(max_seconds, L):
     """The reference's CPU decode arithmetic (AVX2 integer INT4 kernel on tiled weights, src/kernel/avx2.rs:1066, OpenMP over
-    256-column tiles like rayon) timed on this host on a BOUNDED sample: one MoE layer (10 routed + shared), the projections of one
-    LA and one GQA layer, lm_head once; then scaled to a full token.  Norms / recurrent state / attention are left out
-    (optimistic for the CPU).  Weights use the reference's xorshift generator."""
+    256-column tiles like rayon) timed on this host.  The sample is the weight set ONE decoded token touches -- L MoE layers (10 routed +
+    shared experts each, distinct per layer), the LA / GQA projections of every layer and lm_head, ~1.9 GB, so the pass streams from DRAM
+    like the real decode instead of living in the last-level cache -- run as whole-token passes for the time budget.  Norms, recurrent
+    state and attention are left out (optimistic for the CPU).  Weights use the reference's xorshift generator."""
     import numpy as np
     from oracle import oracle as O
     q = QCN; H, I, k = q["hidden"], q["inter"], q["topk"]
@@ -196,14 +211,20 @@ def cpu_baseline(max_seconds, L):
         p = rng.fill_u32(cols // 8 * rows).reshape(cols // 8, rows); s = rng.fill_scales_bf16(cols // 128 * rows).reshape(cols // 128, rows)
         return O.repack_tiled_u32(p), O.repack_tiled_u16(s), cols, rows
 
-    experts = []
-    for _ in range(k + 1):
-        e = O.UnifiedExpert(rng.fill_u32(H // 8 * 2 * I).reshape(H // 8, 2 * I), rng.fill_scales_bf16(H // 128 * 2 * I).reshape(H // 128, 2 * I),
-                            rng.fill_u32(I // 8 * H).reshape(I // 8, H), rng.fill_scales_bf16(I // 128 * H).reshape(I // 128, H), H, I)
-        experts.append(O.tile_expert(e))
+    def expert_set():
+        out = []
+        for _ in range(k + 1):
+            e = O.UnifiedExpert(rng.fill_u32(H // 8 * 2 * I).reshape(H // 8, 2 * I), rng.fill_scales_bf16(H // 128 * 2 * I).reshape(H // 128, 2 * I),
+                                rng.fill_u32(I // 8 * H).reshape(I // 8, H), rng.fill_scales_bf16(I // 128 * H).reshape(I // 128, H), H, I)
+            out.append(O.tile_expert(e))
+        return out
+
     group_dim = 2 * q["dk"] + 2 * q["dv"] * (q["nv"] // q["nk"])
-    la = [tiled(q["nk"] * group_dim, H), tiled(H, q["nv"] * q["dv"])]
-    gqa = [tiled(q["nh"] * q["hd"] * 2 + 2 * q["nkv"] * q["hd"], H), tiled(H, q["nh"] * q["hd"])]
+    layers = []
+    for l in range(L):
+        proj = ([tiled(q["nh"] * q["hd"] * 2 + 2 * q["nkv"] * q["hd"], H), tiled(H, q["nh"] * q["hd"])] if is_gqa(l)
+                else [tiled(q["nk"] * group_dim, H), tiled(H, q["nv"] * q["dv"])])
+        layers.append((expert_set(), proj))
     lm = tiled(q["vocab"], H)
     act = O.f32_to_bf16(rng.fill_f32(H, 0.5)); w = np.full(k + 1, 1.0 / (k + 1), np.float32)
     x2048 = rng.fill_f32(H, 0.5); x4096 = rng.fill_f32(4096, 0.5)
@@ -212,23 +233,33 @@ def cpu_baseline(max_seconds, L):
     def mv(t, qx, sx):
         O.matvec_int4_tiled_avx2(t[0], t[1], qx, sx, t[2], t[3])
 
+    def token():
+        for experts, proj in layers:
+            mv(proj[0], qa, sa); mv(proj[1], qb, sb)
+            O.moe_forward_unified_tiled_avx2(experts, w, act)
+        mv(lm, qa, sa)
+
     def timed(fn, budget):
         fn(); n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget:
+        while n == 0 or time.perf_counter() - t0 < budget:
             fn(); n += 1
-        return (time.perf_counter() - t0) / max(n, 1)
+        return (time.perf_counter() - t0) / n
 
-    per = max_seconds / 4.0
-    t_moe = timed(lambda: O.moe_forward_unified_tiled_avx2(experts, w, act), per)
-    t_la = timed(lambda: (mv(la[0], qa, sa), mv(la[1], qb, sb)), per)
-    t_gqa = timed(lambda: (mv(gqa[0], qa, sa), mv(gqa[1], qb, sb)), per)
-    t_lm = timed(lambda: mv(lm, qa, sa), per)
-    n_la = sum(1 for l in range(L) if not is_gqa(l)); n_gqa = L - n_la
-    tok_s = 1.0 / (L * t_moe + n_la * t_la + n_gqa * t_gqa + t_lm)
-    return dict(value=tok_s, unit="tok/s", cores=O.num_threads(), kind="port",
-                sample="1 MoE layer (10 routed + shared INT4 experts) + LA-layer and GQA-layer projections + lm_head, AVX2+OpenMP port of "
-                       "avx2.rs:1066 on tiled weights; scaled to %d layers; norms/attention/state omitted (optimistic for the CPU)" % L,
-                ms={"moe_layer": t_moe * 1e3, "la_proj": t_la * 1e3, "gqa_proj": t_gqa * 1e3, "lm_head": t_lm * 1e3})
+    # thread count: the reference warns that SMT / too many threads hurts (CHANGELOG.md:24); a quick sweep picks the team size
+    hw = O.num_threads()
+    cands = sorted({c for c in (8, 16, 32, 64, hw) if c <= hw})
+    best_c, best_t, sweep = hw, None, {}
+    for c in cands:
+        O.set_num_threads(c)
+        tt = timed(token, max_seconds * 0.4 / len(cands)); sweep[c] = round(1.0 / tt, 2)
+        if best_t is None or tt < best_t:
+            best_c, best_t = c, tt
+    O.set_num_threads(best_c)
+    t_tok = timed(token, max_seconds * 0.6)
+    return dict(value=1.0 / t_tok, unit="tok/s", cores=best_c, host_threads=hw, kind="port", tok_s_by_threads=sweep,
+                sample="whole-token passes over one token's weight set (%d MoE layers x (10 routed + shared INT4 experts) + LA/GQA projections + lm_head, "
+                       "~1.9 GB streamed from DRAM), AVX2+OpenMP port of avx2.rs:1066 on tiled weights; norms/attention/state omitted "
+                       "(optimistic for the CPU)" % L, ms_per_token=t_tok * 1e3)
 
 
 def main():
@@ -293,6 +324,7 @@ def main():
         dom = max(sym_us, key=lambda s: sym_us[s])
         achieved = sym_bytes[dom] / (sym_us[dom] * 1e-6) / 1e9 if sym_us[dom] > 0 else 0.0
         tok_s = world * args.steps / dt
+        traffic, traffic_src = pmc_traffic(dom)
         res = {
             "metric": "decode tok/s, Qwen3-Coder-Next Q4 @%d MI355X" % world,
             "value": tok_s, "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -305,7 +337,8 @@ def main():
                        "parallelism": "replica x%d (QCN fits one GPU; decode is not expert-parallel)" % world,
                        "hip_graph": not args.no_graph, "target_tok_s": 200},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM fetch bytes per launch (PMC FETCH_SIZE, separate pass)",
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": sym_bytes[dom] / max(sym_n[dom], 1), "us_per_launch": sym_us[dom] / max(sym_n[dom], 1),
                          "launches_per_step": sym_n[dom],
                          "step_algorithmic_bytes": ab["total"], "step_effective_GBs": ab["total"] * (args.steps / dt) / 1e9,

@@ -1364,6 +1364,14 @@ void kro_moe_forward_unified_tiled_avx2(const kro_unified_expert* const* ex, con
     free(q); free(qs); free(gu); free(eo); free(hq); free(hs);
 }
 
+void kro_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int kro_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

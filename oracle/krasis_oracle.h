@@ -184,6 +184,7 @@ void kro_matvec_int4_tiled_avx2(const uint32_t* packed_tiled, const uint16_t* sc
 void kro_moe_forward_unified_tiled_avx2(const kro_unified_expert* const* experts_tiled, const float* weights, int n_sel,
                                         const uint16_t* act_bf16, int sig_mode, float* out);
 int  kro_num_threads(void);
+void kro_set_num_threads(int n);   /* OpenMP team size of the AVX2 twins (rayon pool size in the reference, numa.rs:420) */
 
 #ifdef __cplusplus
 }

@@ -296,6 +296,10 @@ def moe_forward_unified_tiled_avx2(experts_tiled, weights, act_bf16, mode=SIG_PO
     return out
 
 
+def set_num_threads(n: int) -> None:
+    lib().kro_set_num_threads(int(n))
+
+
 def num_threads() -> int:
     return int(lib().kro_num_threads())
 
