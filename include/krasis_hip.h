@@ -85,6 +85,12 @@ int kr_upload_expert_unified(kr_engine* e, int layer, int expert, int inter,
 int kr_upload_expert_gguf(kr_engine* e, int layer, int expert, int inter,
                           const uint8_t* gate, const uint8_t* up, int gate_up_type,
                           const uint8_t* down, int down_type);
+/* load_from_hf (weights/mod.rs:1181 -> load_and_quantize_expert -> weights/marlin.rs:65,145): BF16 tensors of one expert in the HF
+ * checkpoint layout -- gate, up [inter, hidden], down [hidden, inter], row-major, host or device pointers -- quantized on the GPU with
+ * the reference's rule (scale = bf16(amax/7 | amax/127), q = clamp(round(v * (1/scale)))) and stored in the resident layout.
+ * expert = -1: the shared expert (inter = n_shared_experts * moe_intermediate_size). */
+int kr_upload_expert_bf16(kr_engine* e, int layer, int expert, int inter, const uint16_t* gate, const uint16_t* up, const uint16_t* down,
+                          int w13_bits, int w2_bits);
 /* Fill a layer's routed experts (and shared, if configured) with device-generated pseudo-random INT4/INT8
  * words and bf16 scales in [0.005,0.05] -- the distribution of bench_decode_synthetic (decode.rs:4379-4392),
  * generated by a counter hash on the GPU instead of one serial xorshift stream. */

@@ -256,6 +256,48 @@ extern "C" int kr_upload_expert_unified(kr_engine* e, int layer, int expert, int
     return KR_OK;
 }
 
+// load_from_hf path (weights/mod.rs:1181 -> load_and_quantize_expert -> marlin.rs:65,145): BF16 checkpoint tensors in the HF layout
+// (gate/up [inter, hidden], down [hidden, inter], row-major; host or device) are quantized ON THE GPU with the reference's rule and
+// written straight into the resident layout -- no host-side packing, one HtoD copy of the BF16 data.
+extern "C" int kr_upload_expert_bf16(kr_engine* e, int layer, int expert, int inter, const uint16_t* gate, const uint16_t* up, const uint16_t* down,
+                                     int w13_bits, int w2_bits) {
+    if (int rc = check_layer(e, layer)) return rc;
+    if (!gate || !up || !down) return kr_fail(KR_ERR_VALUE, "null weight pointer");
+    if ((w13_bits != 4 && w13_bits != 8) || (w2_bits != 4 && w2_bits != 8)) return kr_fail(KR_ERR_VALUE, "Unsupported num_bits: %d/%d", w13_bits, w2_bits);
+    if (inter <= 0 || inter % 128 != 0) return kr_fail(KR_ERR_VALUE, "intermediate size (%d) must be divisible by group_size (128)", inter);
+    KR_HIP(hipSetDevice(e->device));
+    Layer& L = e->layers[layer];
+    const int H = e->cfg.hidden_size;
+    const bool shared = expert == -1;
+    if (!shared && (expert < 0 || expert >= e->cfg.n_routed_experts)) return kr_fail(KR_ERR_VALUE, "expert index %d out of range (%d experts)", expert, e->cfg.n_routed_experts);
+    MatSet& a = shared ? L.sw13 : L.w13; MatSet& b = shared ? L.sw2 : L.w2;
+    const int count = shared ? 1 : e->cfg.n_routed_experts, idx = shared ? 0 : expert;
+    if (int rc = matset_alloc(e, a, H, 2 * inter, w13_bits, count)) return rc;
+    if (int rc = matset_alloc(e, b, inter, H, w2_bits, count)) return rc;
+    const size_t n_each = (size_t)inter * H;
+    const uint16_t *dg = gate, *du = up, *dd = down;
+    if (!is_device_ptr(gate) || !is_device_ptr(up) || !is_device_ptr(down)) {
+        if (e->st_act.ensure(3 * n_each * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc of the BF16 staging buffer failed");
+        uint16_t* st = (uint16_t*)e->st_act.p;
+        KR_HIP(hipMemcpyAsync(st, gate, n_each * 2, hipMemcpyDefault, e->stream));
+        KR_HIP(hipMemcpyAsync(st + n_each, up, n_each * 2, hipMemcpyDefault, e->stream));
+        KR_HIP(hipMemcpyAsync(st + 2 * n_each, down, n_each * 2, hipMemcpyDefault, e->stream));
+        dg = st; du = st + n_each; dd = st + 2 * n_each;
+    }
+    char* q13 = (char*)a.q.p + (size_t)idx * a.q_stride; uint32_t* s13 = (uint32_t*)((char*)a.s.p + (size_t)idx * a.s_stride);
+    char* q2 = (char*)b.q.p + (size_t)idx * b.q_stride; uint32_t* s2 = (uint32_t*)((char*)b.s.p + (size_t)idx * b.s_stride);
+    kr_launch_quant_bf16(dg, inter, H, w13_bits, q13, s13, 0, e->stream);            // gate -> columns [0, inter)
+    kr_launch_quant_bf16(du, inter, H, w13_bits, q13, s13, inter / 8, e->stream);    // up   -> columns [inter, 2 inter)
+    kr_launch_quant_bf16(dd, H, inter, w2_bits, q2, s2, 0, e->stream);
+    KR_HIP(hipStreamSynchronize(e->stream));   // the staging buffer is reused by the next call
+    KR_HIP(hipGetLastError());
+    if (a.wsum.p) { a.wsum.release(); }          // nibble sums are rebuilt on the next prefill call
+    if (b.wsum.p) { b.wsum.release(); }
+    if (shared) { L.shared_present = true; L.shared_inter = inter; }
+    else { L.present[expert] = 1; L.inter = inter; }
+    return KR_OK;
+}
+
 extern "C" int kr_fill_layer_synthetic(kr_engine* e, int layer, int bits, uint64_t seed) {
     if (int rc = check_layer(e, layer)) return rc;
     if (bits != 4 && bits != 8) return kr_fail(KR_ERR_VALUE, "Unsupported num_bits: %d", bits);

@@ -94,16 +94,20 @@ class KrasisEngine:
 
     def load(self, model_dir: str, group_size=None, max_layers=None, start_layer=None, num_bits=None,
              cpu_num_bits=None, gpu_num_bits=None, gguf_path=None, gguf_native: bool = False) -> None:
-        """KrasisEngine.load (moe.rs:1538): HF safetensors -> quantize_int4/int8 -> HBM (weight_store.py)."""
-        from .weight_store import load_from_hf  # host loader (SURVEY §8f rank 3)
-        if gguf_path is not None:
-            raise ValueError("GGUF loading is not built yet in this round")
-        bits = cpu_num_bits or num_bits or 4
-        if bits not in (4, 8):
-            raise ValueError(f"cpu_num_bits must be 4 or 8, got {bits}")
+        """KrasisEngine.load (moe.rs:1538).  BF16 safetensors -> GPU-side quantize_int4/int8 -> HBM, or GGUF blocks kept native
+        (`gguf_path`, `gguf_native=True`).  cpu_num_bits / gpu_num_bits collapse to ONE resident copy (there is no separate CPU store);
+        when both are given the decode (cpu) precision wins, as it determines the numerics of `moe_forward`."""
+        from .weight_store import load_from_gguf, load_from_hf
         if group_size not in (None, 128):
             raise ValueError(f"group_size {group_size} unsupported")
-        load_from_hf(self, model_dir, bits, max_layers=max_layers, start_layer=start_layer)
+        bits = cpu_num_bits or num_bits or gpu_num_bits or 4
+        if bits not in (4, 8):
+            raise ValueError(f"cpu_num_bits must be 4 or 8, got {bits}")
+        if gguf_path is not None:
+            import os
+            load_from_gguf(self, gguf_path, os.path.join(model_dir, "config.json"), gguf_native=gguf_native, max_layers=max_layers, start_layer=start_layer)
+        else:
+            load_from_hf(self, model_dir, bits, max_layers=max_layers, start_layer=start_layer)
 
     # ------------------------------------------------------------------ weights
     def load_unified_expert(self, layer: int, expert: int, w13, w13_scales, w2, w2_scales, num_bits: int = 4,
