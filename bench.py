@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--prefill-chunk", type=int, default=0, help="tokens per chunk of the prompt pass (0 = library default)")
     ap.add_argument("--prefill-reps", type=int, default=2, help="timed repetitions of the whole-model prompt pass")
     ap.add_argument("--prefill-tokens", type=int, default=8192, help="tokens per prefill chunk for the experts-only prefill side measurement (0 = skip)")
     return ap.parse_args()
@@ -312,7 +313,10 @@ def main():
     prefill = None; prefill_full = None
     if args.prefill_tokens > 0:
         prefill = prefill_experts(eng, L, args.prefill_tokens, torch)
+        if args.prefill_chunk:
+            st.set_prefill_chunk(args.prefill_chunk)
         prefill_full = prefill_model(st, L, args.prefill_tokens, args.prefill_reps, torch)
+        prefill_full["chunk"] = args.prefill_chunk or 2048
 
     if rank == 0:
         ab = algorithmic_bytes(L)

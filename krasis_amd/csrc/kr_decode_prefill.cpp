@@ -18,23 +18,127 @@
 #include "kr_prefill_ops.h"
 #include "kr_router.h"
 
-#define KR_PFM_CHUNK 4096
+#define KR_PFM_CHUNK 2048
 
 namespace {
-struct Scratch {   // carved from one allocation per store (grown on demand)
+struct Scratch {   // carved from one allocation per arena (grown on demand)
     float *res, *hid, *normed, *pa, *pb, *pc, *q, *k, *v, *z, *gexp, *beta, *recur, *attn, *gate, *moe, *sh, *gv, *sgu, *logits;
     int8_t *xh, *xl, *yh, *yl; float *xs, *ys;
-    uint16_t* xb; int32_t* ids; float* w; int* tok;
+    uint16_t* xb; int32_t* ids; float* w;
+};
+struct Chunk {      // one chunk of the prompt in flight: its arena, stream and running flags
+    Scratch B; float* scores; const int* tok; int Cc, pos0, set; bool first, add_is_emb; hipStream_t st;
 };
 size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
 }  // namespace
 
 static int pf_gemm(kr_decode_store* s, int wid, const int8_t* xh, const int8_t* xl, const float* xs, int C, float* out, int ld, hipStream_t st) {
     DWeight& W = *s->weights[wid];
-    if (W.ms.bits != 4) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: weight %d is INT%d; the MFMA projection path is built for INT4-g128", wid, W.ms.bits);
-    if (int rc = kr_ensure_wsum(s->eng, W.ms, st)) return rc;
+    if (!W.ms.wsum.p) return kr_fail(KR_ERR_STATE, "internal: nibble sums of weight %d were not prepared", wid);
     kr_launch_pf_gemm(W.ms.view(), (const uint32_t*)W.ms.wsum.p, xh, xl, xs, nullptr, 1, 0, 0, C, out, ld, st);
     return KR_OK;
+}
+
+// everything a layer launches, for one chunk, on the chunk's stream
+static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
+    kr_engine* e = s->eng;
+    const int H = s->hidden, k = s->topk, Cc = cx.Cc, pos0 = cx.pos0;
+    Scratch& B = cx.B; hipStream_t st = cx.st;
+    DLayer& L = s->layers[li];
+    // ---- input norm (+ digits for the projections)
+    KrPfmNormArgs na{};
+    na.mode = cx.add_is_emb ? 1 : 0; na.add_in = B.hid; na.emb = (const float*)s->embedding.p; na.tokens = cx.tok; na.res = B.res;
+    na.w = (const float*)s->norms[L.input_norm]->p; na.out = B.normed; na.xh = B.xh; na.xl = B.xl; na.xs = B.xs; na.H = H; na.first = cx.first ? 1 : 0;
+    na.bias_one = s->norm_bias_one; na.eps = s->eps;
+    kr_launch_pfm_norm(na, Cc, st);
+    cx.first = false; cx.add_is_emb = false;
+    if (L.attn == ATTN_LA) {
+        const int nq = s->weights[L.qkvz_wid]->rows, nb = s->weights[L.ba_wid]->rows, oc = s->weights[L.out_wid]->cols;
+        if (int rc = pf_gemm(s, L.qkvz_wid, B.xh, B.xl, B.xs, Cc, B.pa, nq, st)) return rc;
+        if (int rc = pf_gemm(s, L.ba_wid, B.xh, B.xl, B.xs, Cc, B.pb, nb, st)) return rc;
+        KrPfmLaArgs a{};
+        a.qkvz = B.pa; a.ld_qkvz = nq; a.ba = B.pb; a.ld_ba = nb; a.conv_state = (float*)L.conv_state.p; a.conv_w = (const float*)L.conv_w.p;
+        a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale; a.q = B.q; a.k = B.k; a.v = B.v; a.z = B.z;
+        a.gexp = B.gexp; a.beta = B.beta; a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
+        if (kr_launch_pfm_la(a, (float*)L.recur_state.p, B.recur, (const float*)L.la_norm_w.p, B.attn, Cc, s->eps, st))
+            return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
+        if (oc != L.nv * L.dv) return kr_fail(KR_ERR_VALUE, "out_proj cols %d != nv*dv", oc);
+        kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
+        if (int rc = pf_gemm(s, L.out_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+    } else if (L.attn == ATTN_GQA) {
+        if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
+        const int nq = s->weights[L.q_wid]->rows, nk_ = s->weights[L.k_wid]->rows, nv_ = s->weights[L.v_wid]->rows, oc = s->weights[L.o_wid]->cols;
+        if (int rc = pf_gemm(s, L.q_wid, B.xh, B.xl, B.xs, Cc, B.pa, nq, st)) return rc;
+        if (int rc = pf_gemm(s, L.k_wid, B.xh, B.xl, B.xs, Cc, B.pb, nk_, st)) return rc;
+        if (int rc = pf_gemm(s, L.v_wid, B.xh, B.xl, B.xs, Cc, B.pc, nv_, st)) return rc;
+        KrPfmGqaArgs a{};
+        a.q_in = B.pa; a.k_in = B.pb; a.v_in = B.pc; a.ld_q = nq; a.ld_k = nk_; a.ld_v = nv_;
+        a.q_norm = L.q_norm_len ? (const float*)L.q_norm.p : nullptr; a.k_norm = L.k_norm_len ? (const float*)L.k_norm.p : nullptr;
+        a.q_norm_per_head = L.q_norm_len == L.nh * L.hd; a.k_norm_per_head = L.k_norm_len == L.nkv * L.hd;
+        a.rope_cos = (const float*)s->rope_cos.p; a.rope_sin = (const float*)s->rope_sin.p; a.rope_half = s->rope_half;
+        a.k_cache = (uint16_t*)L.kv_k.p; a.v_cache = (uint16_t*)L.kv_v.p; a.q_out = B.q; a.gate = B.gate; a.attn_out = B.attn;
+        a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.pos0 = pos0; a.eps = s->eps; a.sm_scale = L.sm_scale;
+        if (s->max_rope_seq > 0 && pos0 + Cc > s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "prompt exceeds the rope table (%d)", s->max_rope_seq);
+        const int sc_ld = (pos0 + Cc + 63) & ~63;
+        if (s->pf_scores.ensure((size_t)Cc * L.nh * ((size_t)sc_ld + 1) * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
+        float* scp = (float*)s->pf_scores.p;
+        if (kr_launch_pfm_gqa(a, Cc, scp, sc_ld, scp + (size_t)Cc * L.nh * sc_ld, st)) return kr_fail(KR_ERR_VALUE, "unsupported GQA geometry for the prompt pass");
+        if (oc != L.nh * L.hd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*hd", oc);
+        kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
+        if (int rc = pf_gemm(s, L.o_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+    }
+    // ---- post-attention norm: f32 hidden, digits (shared expert / dense MLP), bf16 copy (routed experts)
+    na.mode = 0; na.add_in = B.hid; na.first = 0; na.w = (const float*)s->norms[L.post_norm]->p; na.out_bf16 = L.mlp == MLP_MOE ? B.xb : nullptr;
+    kr_launch_pfm_norm(na, Cc, st);
+    if (L.mlp == MLP_MOE) {
+        Layer& EL = e->layers[L.moe_layer];
+        if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
+        if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
+        const int E = e->r_ne;
+        kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, B.normed, EL.has_bias ? (const float*)EL.bias.p : nullptr, B.logits, Cc, E, H, st);
+        kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
+        // routed experts: exact CPU-engine arithmetic on the matrix cores, f32 weighted sum in routing order
+        if (int rc = kr_moe_prefill_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set, st)) return rc;
+        const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
+        if (has_shared) {   // decode-store numerics: f32 input digits, fast_silu_mul + f32::round digits (decode.rs:3356-3378)
+            const int si2 = s->weights[L.sgu_wid]->rows, SI = si2 / 2;
+            if (SI % 128) return kr_fail(KR_ERR_VALUE, "shared expert intermediate %d not a multiple of 128", SI);
+            if (int rc = pf_gemm(s, L.sgu_wid, B.xh, B.xl, B.xs, Cc, B.sgu, si2, st)) return rc;
+            kr_launch_pf_act(B.sgu, Cc, SI, si2, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yh, B.yl, B.ys, st);
+            if (int rc = pf_gemm(s, L.sd_wid, B.yh, B.yl, B.ys, Cc, B.sh, H, st)) return rc;
+            if (has_gate) if (int rc = pf_gemm(s, L.sg_wid, B.xh, B.xl, B.xs, Cc, B.gv, 1, st)) return rc;
+        }
+        kr_launch_pfm_moe_epilogue(B.moe, has_shared ? B.sh : nullptr, has_gate ? B.gv : nullptr, 1, s->rsf, B.hid, Cc, H, st);
+    } else if (L.mlp == MLP_DENSE) {
+        const int K = s->weights[L.down_wid]->cols, ng = s->weights[L.gate_wid]->rows, nu = s->weights[L.up_wid]->rows;
+        if (K % 128) return kr_fail(KR_ERR_VALUE, "dense MLP intermediate %d not a multiple of 128", K);
+        KR_HIP(hipMemsetAsync(B.sgu, 0, (size_t)Cc * 2 * K * 4, st));   // padding of gate | up stays 0 (decode.rs dense path)
+        {   // gate -> [0,K), up -> [K,2K) of each row
+            DWeight& Wg = *s->weights[L.gate_wid]; DWeight& Wu = *s->weights[L.up_wid];
+            if (Wg.ms.bits != 4 || Wu.ms.bits != 4) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: dense MLP weights must be INT4-g128");
+            if (int rc = kr_ensure_wsum(e, Wg.ms, st)) return rc;
+            if (int rc = kr_ensure_wsum(e, Wu.ms, st)) return rc;
+            kr_launch_pf_gemm(Wg.ms.view(), (const uint32_t*)Wg.ms.wsum.p, B.xh, B.xl, B.xs, nullptr, 1, 0, 0, Cc, B.sgu, 2 * K, st);
+            kr_launch_pf_gemm(Wu.ms.view(), (const uint32_t*)Wu.ms.wsum.p, B.xh, B.xl, B.xs, nullptr, 1, 0, 0, Cc, B.sgu + K, 2 * K, st);
+            (void)ng; (void)nu;
+        }
+        kr_launch_pf_act(B.sgu, Cc, K, 2 * K, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yh, B.yl, B.ys, st);
+        if (int rc = pf_gemm(s, L.down_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+    } else {
+        KR_HIP(hipMemcpyAsync(B.hid, B.normed, (size_t)Cc * H * 4, hipMemcpyDeviceToDevice, st));   // no MLP: hidden stays the normalised value
+    }
+    return KR_OK;
+}
+
+// final norm + lm_head + greedy sample for the LAST token only (the other positions' logits are never consumed)
+static void run_final(kr_decode_store* s, Chunk& cx) {
+    Scratch& B = cx.B; const int H = s->hidden;
+    KrPfmNormArgs na{};
+    na.mode = cx.add_is_emb ? 1 : 0; na.add_in = B.hid; na.emb = (const float*)s->embedding.p; na.tokens = cx.tok; na.res = B.res;
+    na.w = (const float*)s->norms[s->final_norm]->p; na.out = B.normed; na.H = H; na.first = cx.first ? 1 : 0; na.bias_one = s->norm_bias_one; na.eps = s->eps;
+    kr_launch_pfm_norm(na, cx.Cc, cx.st);
+    kr_launch_matvec(mv(s, s->lm_head), B.normed + (size_t)(cx.Cc - 1) * H, 1, (float*)s->logits.p, cx.st);
+    kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, cx.st);
 }
 
 extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int n_tokens, int start_pos, float* logits_out, void* stream) {
@@ -48,26 +152,42 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
     kr_engine* e = s->eng;
     KR_HIP(hipSetDevice(e->device));
     hipStream_t st = kr_pick_stream(e, stream);
-    const int H = s->hidden, k = s->topk;
+    const int H = s->hidden;
     if (H % 128) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill needs hidden %% 128 == 0");
-    const int CH = std::min(n_tokens, KR_PFM_CHUNK);
+    const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : KR_PFM_CHUNK);
+    const int n_chunks = (n_tokens + CH - 1) / CH, n_arenas = n_chunks > 1 ? 2 : 1;
+    const int L = (int)s->layers.size();
 
-    // ---- geometry of the widest layer -> scratch sizes (floats per token)
-    size_t pa = H, pb = 64, pc = 64, qd = 64, kd = 64, vd = 64, zd = 64, nvmax = 1, ad = H, sid = 0, kmax = H;
-    bool any_moe = false;
-    for (auto& L : s->layers) {
-        if (L.attn == ATTN_LA) {
-            pa = std::max(pa, (size_t)s->weights[L.qkvz_wid]->rows); pb = std::max(pb, (size_t)s->weights[L.ba_wid]->rows);
-            qd = std::max(qd, (size_t)L.nv * L.dk); kd = std::max(kd, (size_t)L.nv * L.dk); vd = std::max(vd, (size_t)L.nv * L.dv); zd = std::max(zd, (size_t)L.nv * L.dv);
-            nvmax = std::max(nvmax, (size_t)L.nv); ad = std::max(ad, (size_t)s->weights[L.out_wid]->cols);
-        } else if (L.attn == ATTN_GQA) {
-            pa = std::max(pa, (size_t)s->weights[L.q_wid]->rows); pb = std::max(pb, (size_t)s->weights[L.k_wid]->rows); pc = std::max(pc, (size_t)s->weights[L.v_wid]->rows);
-            qd = std::max(qd, (size_t)L.nh * L.hd); zd = std::max(zd, (size_t)L.nh * L.hd); ad = std::max(ad, (size_t)s->weights[L.o_wid]->cols);
-        } else if (L.attn == ATTN_MLA) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: MLA layers are decode-only in this build (feed the prompt through decode_step)");
-        if (L.mlp == MLP_MOE) {
-            any_moe = true;
-            if (L.sgu_wid >= 0) { sid = std::max(sid, (size_t)s->weights[L.sgu_wid]->rows); kmax = std::max(kmax, (size_t)s->weights[L.sd_wid]->cols); }
-        } else if (L.mlp == MLP_DENSE) { sid = std::max(sid, 2 * (size_t)s->weights[L.down_wid]->cols); kmax = std::max(kmax, (size_t)s->weights[L.down_wid]->cols); }
+    // ---- geometry of the widest layer -> scratch sizes (floats per token); nibble sums of every weight the GEMMs will touch
+    size_t pa = H, pb = 64, pc = 64, qd = 64, kd = 64, vd = 64, zd = 64, nvmax = 1, ad = H, sid = 0, kmax = H, sc_rows = 0;
+    std::vector<int> wids;
+    for (auto& Ly : s->layers) {
+        if (Ly.attn == ATTN_LA) {
+            pa = std::max(pa, (size_t)s->weights[Ly.qkvz_wid]->rows); pb = std::max(pb, (size_t)s->weights[Ly.ba_wid]->rows);
+            qd = std::max(qd, (size_t)Ly.nv * Ly.dk); kd = std::max(kd, (size_t)Ly.nv * Ly.dk); vd = std::max(vd, (size_t)Ly.nv * Ly.dv); zd = std::max(zd, (size_t)Ly.nv * Ly.dv);
+            nvmax = std::max(nvmax, (size_t)Ly.nv); ad = std::max(ad, (size_t)s->weights[Ly.out_wid]->cols);
+            for (int w : {Ly.qkvz_wid, Ly.ba_wid, Ly.out_wid}) wids.push_back(w);
+        } else if (Ly.attn == ATTN_GQA) {
+            pa = std::max(pa, (size_t)s->weights[Ly.q_wid]->rows); pb = std::max(pb, (size_t)s->weights[Ly.k_wid]->rows); pc = std::max(pc, (size_t)s->weights[Ly.v_wid]->rows);
+            qd = std::max(qd, (size_t)Ly.nh * Ly.hd); zd = std::max(zd, (size_t)Ly.nh * Ly.hd); ad = std::max(ad, (size_t)s->weights[Ly.o_wid]->cols);
+            sc_rows = std::max(sc_rows, (size_t)Ly.nh);
+            for (int w : {Ly.q_wid, Ly.k_wid, Ly.v_wid, Ly.o_wid}) wids.push_back(w);
+        } else if (Ly.attn == ATTN_MLA) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: MLA layers are decode-only in this build (feed the prompt through decode_step)");
+        if (Ly.mlp == MLP_MOE) {
+            if (Ly.sgu_wid >= 0) { sid = std::max(sid, (size_t)s->weights[Ly.sgu_wid]->rows); kmax = std::max(kmax, (size_t)s->weights[Ly.sd_wid]->cols); wids.push_back(Ly.sgu_wid); wids.push_back(Ly.sd_wid); }
+            if (Ly.sgu_wid >= 0 && Ly.sg_wid >= 0) wids.push_back(Ly.sg_wid);
+            Layer& EL = e->layers[Ly.moe_layer];
+            if (int rc = kr_ensure_wsum(e, EL.w13, st)) return rc;
+            if (int rc = kr_ensure_wsum(e, EL.w2, st)) return rc;
+        } else if (Ly.mlp == MLP_DENSE) {
+            sid = std::max(sid, 2 * (size_t)s->weights[Ly.down_wid]->cols); kmax = std::max(kmax, (size_t)s->weights[Ly.down_wid]->cols);
+            for (int w : {Ly.gate_wid, Ly.up_wid, Ly.down_wid}) wids.push_back(w);
+        }
+    }
+    for (int w : wids) {
+        DWeight& W = *s->weights[w];
+        if (W.ms.bits != 4) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: weight %d is INT%d; the MFMA projection path is built for INT4-g128", w, W.ms.bits);
+        if (int rc = kr_ensure_wsum(e, W.ms, st)) return rc;
     }
     kmax = std::max(kmax, ad);
     const size_t C = CH;
@@ -77,122 +197,79 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
                  o_q = take(C * qd * 4), o_k = take(C * kd * 4), o_v = take(C * vd * 4), o_z = take(C * zd * 4), o_ge = take(C * nvmax * 4), o_be = take(C * nvmax * 4),
                  o_rec = take(C * vd * 4), o_att = take(C * ad * 4), o_gate = take(C * zd * 4), o_moe = take(C * H * 4), o_sh = take(C * H * 4), o_gv = take(C * 4),
                  o_sgu = take(C * std::max(sid, (size_t)64) * 4), o_xh = take(C * H), o_xl = take(C * H), o_xs = take(C * (H / 128) * 4), o_yh = take(C * kmax),
-                 o_yl = take(C * kmax), o_ys = take(C * (kmax / 128 + 1) * 4), o_xb = take(C * H * 2), o_ids = take(C * 32 * 4), o_w = take(C * 32 * 4), o_tok = take(C * 4),
+                 o_yl = take(C * kmax), o_ys = take(C * (kmax / 128 + 1) * 4), o_xb = take(C * H * 2), o_ids = take(C * 32 * 4), o_w = take(C * 32 * 4),
                  o_lg = take(C * (size_t)std::max(e->r_ne, 64) * 4);
-    if (s->pf_scratch.ensure(total)) return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch (%zu MiB) failed", total >> 20);
-    char* base = (char*)s->pf_scratch.p;
-    Scratch B{};
-    B.res = (float*)(base + o_res); B.hid = (float*)(base + o_hid); B.normed = (float*)(base + o_nrm); B.pa = (float*)(base + o_pa); B.pb = (float*)(base + o_pb);
-    B.pc = (float*)(base + o_pc); B.q = (float*)(base + o_q); B.k = (float*)(base + o_k); B.v = (float*)(base + o_v); B.z = (float*)(base + o_z);
-    B.gexp = (float*)(base + o_ge); B.beta = (float*)(base + o_be); B.recur = (float*)(base + o_rec); B.attn = (float*)(base + o_att); B.gate = (float*)(base + o_gate);
-    B.moe = (float*)(base + o_moe); B.sh = (float*)(base + o_sh); B.gv = (float*)(base + o_gv); B.sgu = (float*)(base + o_sgu); B.xh = (int8_t*)(base + o_xh);
-    B.xl = (int8_t*)(base + o_xl); B.xs = (float*)(base + o_xs); B.yh = (int8_t*)(base + o_yh); B.yl = (int8_t*)(base + o_yl); B.ys = (float*)(base + o_ys);
-    B.xb = (uint16_t*)(base + o_xb); B.ids = (int32_t*)(base + o_ids); B.w = (float*)(base + o_w); B.tok = (int*)(base + o_tok); B.logits = (float*)(base + o_lg);
-    (void)any_moe;
+    const size_t sc_ld_max = (size_t)((start_pos + n_tokens + 63) & ~63), sc_bytes = al(C * sc_rows * (sc_ld_max + 1) * 4);
+    if (s->pf_scratch.ensure(total * n_arenas) || s->pf_tokens.ensure((size_t)n_tokens * 4) || (sc_rows && s->pf_scores.ensure(sc_bytes * n_arenas)))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch (%zu MiB) failed", (total * n_arenas + sc_bytes * n_arenas) >> 20);
+    KR_HIP(hipMemcpyAsync(s->pf_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice, st));
+    auto carve = [&](int arena) {
+        char* base = (char*)s->pf_scratch.p + (size_t)arena * total;
+        Scratch B{};
+        B.res = (float*)(base + o_res); B.hid = (float*)(base + o_hid); B.normed = (float*)(base + o_nrm); B.pa = (float*)(base + o_pa); B.pb = (float*)(base + o_pb);
+        B.pc = (float*)(base + o_pc); B.q = (float*)(base + o_q); B.k = (float*)(base + o_k); B.v = (float*)(base + o_v); B.z = (float*)(base + o_z);
+        B.gexp = (float*)(base + o_ge); B.beta = (float*)(base + o_be); B.recur = (float*)(base + o_rec); B.attn = (float*)(base + o_att); B.gate = (float*)(base + o_gate);
+        B.moe = (float*)(base + o_moe); B.sh = (float*)(base + o_sh); B.gv = (float*)(base + o_gv); B.sgu = (float*)(base + o_sgu); B.xh = (int8_t*)(base + o_xh);
+        B.xl = (int8_t*)(base + o_xl); B.xs = (float*)(base + o_xs); B.yh = (int8_t*)(base + o_yh); B.yl = (int8_t*)(base + o_yl); B.ys = (float*)(base + o_ys);
+        B.xb = (uint16_t*)(base + o_xb); B.ids = (int32_t*)(base + o_ids); B.w = (float*)(base + o_w); B.logits = (float*)(base + o_lg);
+        return B;
+    };
 
-    for (int c0 = 0; c0 < n_tokens; c0 += CH) {
-        const int Cc = std::min(CH, n_tokens - c0), pos0 = start_pos + c0;
-        KR_HIP(hipMemcpyAsync(B.tok, tokens + c0, (size_t)Cc * 4, hipMemcpyHostToDevice, st));
-        bool first = true, add_is_emb = true;
-        for (size_t li = 0; li < s->layers.size(); li++) {
-            DLayer& L = s->layers[li];
-            // ---- input norm (+ digits for the projections)
-            KrPfmNormArgs na{};
-            na.mode = add_is_emb ? 1 : 0; na.add_in = B.hid; na.emb = (const float*)s->embedding.p; na.tokens = B.tok; na.res = B.res;
-            na.w = (const float*)s->norms[L.input_norm]->p; na.out = B.normed; na.xh = B.xh; na.xl = B.xl; na.xs = B.xs; na.H = H; na.first = first ? 1 : 0;
-            na.bias_one = s->norm_bias_one; na.eps = s->eps;
-            kr_launch_pfm_norm(na, Cc, st);
-            first = false; add_is_emb = false;
-            if (L.attn == ATTN_LA) {
-                const int nq = s->weights[L.qkvz_wid]->rows, nb = s->weights[L.ba_wid]->rows, oc = s->weights[L.out_wid]->cols;
-                if (int rc = pf_gemm(s, L.qkvz_wid, B.xh, B.xl, B.xs, Cc, B.pa, nq, st)) return rc;
-                if (int rc = pf_gemm(s, L.ba_wid, B.xh, B.xl, B.xs, Cc, B.pb, nb, st)) return rc;
-                KrPfmLaArgs a{};
-                a.qkvz = B.pa; a.ld_qkvz = nq; a.ba = B.pb; a.ld_ba = nb; a.conv_state = (float*)L.conv_state.p; a.conv_w = (const float*)L.conv_w.p;
-                a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale; a.q = B.q; a.k = B.k; a.v = B.v; a.z = B.z;
-                a.gexp = B.gexp; a.beta = B.beta; a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
-                if (kr_launch_pfm_la(a, (float*)L.recur_state.p, B.recur, (const float*)L.la_norm_w.p, B.attn, Cc, s->eps, st))
-                    return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
-                if (oc != L.nv * L.dv) return kr_fail(KR_ERR_VALUE, "out_proj cols %d != nv*dv", oc);
-                kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
-                if (int rc = pf_gemm(s, L.out_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
-            } else if (L.attn == ATTN_GQA) {
-                if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
-                const int nq = s->weights[L.q_wid]->rows, nk_ = s->weights[L.k_wid]->rows, nv_ = s->weights[L.v_wid]->rows, oc = s->weights[L.o_wid]->cols;
-                if (int rc = pf_gemm(s, L.q_wid, B.xh, B.xl, B.xs, Cc, B.pa, nq, st)) return rc;
-                if (int rc = pf_gemm(s, L.k_wid, B.xh, B.xl, B.xs, Cc, B.pb, nk_, st)) return rc;
-                if (int rc = pf_gemm(s, L.v_wid, B.xh, B.xl, B.xs, Cc, B.pc, nv_, st)) return rc;
-                KrPfmGqaArgs a{};
-                a.q_in = B.pa; a.k_in = B.pb; a.v_in = B.pc; a.ld_q = nq; a.ld_k = nk_; a.ld_v = nv_;
-                a.q_norm = L.q_norm_len ? (const float*)L.q_norm.p : nullptr; a.k_norm = L.k_norm_len ? (const float*)L.k_norm.p : nullptr;
-                a.q_norm_per_head = L.q_norm_len == L.nh * L.hd; a.k_norm_per_head = L.k_norm_len == L.nkv * L.hd;
-                a.rope_cos = (const float*)s->rope_cos.p; a.rope_sin = (const float*)s->rope_sin.p; a.rope_half = s->rope_half;
-                a.k_cache = (uint16_t*)L.kv_k.p; a.v_cache = (uint16_t*)L.kv_v.p; a.q_out = B.q; a.gate = B.gate; a.attn_out = B.attn;
-                a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.pos0 = pos0; a.eps = s->eps; a.sm_scale = L.sm_scale;
-                if (s->max_rope_seq > 0 && pos0 + Cc > s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "prompt exceeds the rope table (%d)", s->max_rope_seq);
-                const int sc_ld = (pos0 + Cc + 63) & ~63;
-                if (s->pf_scores.ensure((size_t)Cc * L.nh * ((size_t)sc_ld + 1) * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
-                float* scp = (float*)s->pf_scores.p;
-                if (kr_launch_pfm_gqa(a, Cc, scp, sc_ld, scp + (size_t)Cc * L.nh * sc_ld, st)) return kr_fail(KR_ERR_VALUE, "unsupported GQA geometry for the prompt pass");
-                if (oc != L.nh * L.hd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*hd", oc);
-                kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
-                if (int rc = pf_gemm(s, L.o_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
-            }
-            // ---- post-attention norm: f32 hidden, digits (shared expert / dense MLP), bf16 copy (routed experts)
-            na.mode = 0; na.add_in = B.hid; na.first = 0; na.w = (const float*)s->norms[L.post_norm]->p; na.out_bf16 = L.mlp == MLP_MOE ? B.xb : nullptr;
-            kr_launch_pfm_norm(na, Cc, st);
-            if (L.mlp == MLP_MOE) {
-                Layer& EL = e->layers[L.moe_layer];
-                if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
-                if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
-                const int E = e->r_ne;
-                kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, B.normed, EL.has_bias ? (const float*)EL.bias.p : nullptr, B.logits, Cc, E, H, st);
-                kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
-                // routed experts: exact CPU-engine arithmetic on the matrix cores, f32 weighted sum in routing order
-                if (int rc = kr_moe_prefill(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, (void*)(st ? (void*)st : (void*)1))) return rc;
-                const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
-                if (has_shared) {   // decode-store numerics: f32 input digits, fast_silu_mul + f32::round digits (decode.rs:3356-3378)
-                    const int si2 = s->weights[L.sgu_wid]->rows, SI = si2 / 2;
-                    if (SI % 128) return kr_fail(KR_ERR_VALUE, "shared expert intermediate %d not a multiple of 128", SI);
-                    if (int rc = pf_gemm(s, L.sgu_wid, B.xh, B.xl, B.xs, Cc, B.sgu, si2, st)) return rc;
-                    kr_launch_pf_act(B.sgu, Cc, SI, si2, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yh, B.yl, B.ys, st);
-                    if (int rc = pf_gemm(s, L.sd_wid, B.yh, B.yl, B.ys, Cc, B.sh, H, st)) return rc;
-                    if (has_gate) if (int rc = pf_gemm(s, L.sg_wid, B.xh, B.xl, B.xs, Cc, B.gv, 1, st)) return rc;
-                }
-                kr_launch_pfm_moe_epilogue(B.moe, has_shared ? B.sh : nullptr, has_gate ? B.gv : nullptr, 1, s->rsf, B.hid, Cc, H, st);
-            } else if (L.mlp == MLP_DENSE) {
-                const int K = s->weights[L.down_wid]->cols, ng = s->weights[L.gate_wid]->rows, nu = s->weights[L.up_wid]->rows;
-                if (K % 128) return kr_fail(KR_ERR_VALUE, "dense MLP intermediate %d not a multiple of 128", K);
-                KR_HIP(hipMemsetAsync(B.sgu, 0, (size_t)Cc * 2 * K * 4, st));   // padding of gate | up stays 0 (decode.rs dense path)
-                {   // gate -> [0,K), up -> [K,2K) of each row
-                    DWeight& Wg = *s->weights[L.gate_wid]; DWeight& Wu = *s->weights[L.up_wid];
-                    if (Wg.ms.bits != 4 || Wu.ms.bits != 4) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: dense MLP weights must be INT4-g128");
-                    if (int rc = kr_ensure_wsum(e, Wg.ms, st)) return rc;
-                    if (int rc = kr_ensure_wsum(e, Wu.ms, st)) return rc;
-                    kr_launch_pf_gemm(Wg.ms.view(), (const uint32_t*)Wg.ms.wsum.p, B.xh, B.xl, B.xs, nullptr, 1, 0, 0, Cc, B.sgu, 2 * K, st);
-                    kr_launch_pf_gemm(Wu.ms.view(), (const uint32_t*)Wu.ms.wsum.p, B.xh, B.xl, B.xs, nullptr, 1, 0, 0, Cc, B.sgu + K, 2 * K, st);
-                    (void)ng; (void)nu;
-                }
-                kr_launch_pf_act(B.sgu, Cc, K, 2 * K, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yh, B.yl, B.ys, st);
-                if (int rc = pf_gemm(s, L.down_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
-            } else {
-                KR_HIP(hipMemcpyAsync(B.hid, B.normed, (size_t)Cc * H * 4, hipMemcpyDeviceToDevice, st));   // no MLP: hidden stays the normalised value
+    // ---- streams: chunk c runs on stream c % 2 with arena c % 2.  Cell (chunk c, layer l) needs (c, l-1) [same stream] and (c-1, l)
+    // [other stream: recurrent / conv state and the KV cache of layer l] -> one event per (parity, layer).  The serial, low-occupancy
+    // kernels of one chunk (gated-delta-rule recurrence, softmax sums, router top-k) overlap with the GEMMs and attention passes of
+    // its neighbour, which is one layer behind.
+    hipStream_t streams[2] = {st, st};
+    if (n_chunks > 1) {
+        if (!s->pf_side) KR_HIP(hipStreamCreateWithFlags(&s->pf_side, hipStreamNonBlocking));
+        streams[1] = s->pf_side;
+        while ((int)s->pf_events.size() < 2 * L + 2) { hipEvent_t ev; KR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); s->pf_events.push_back(ev); }
+        KR_HIP(hipEventRecord(s->pf_events[2 * L], st));                  // side stream starts after everything already queued on the main one
+        KR_HIP(hipStreamWaitEvent(streams[1], s->pf_events[2 * L], 0));
+    }
+    std::vector<Chunk> chunks(n_chunks);
+    for (int c = 0; c < n_chunks; c++) {
+        Chunk& cx = chunks[c];
+        cx.set = c & 1; cx.B = carve(cx.set); cx.scores = sc_rows ? (float*)((char*)s->pf_scores.p + (size_t)cx.set * sc_bytes) : nullptr;
+        cx.Cc = std::min(CH, n_tokens - c * CH); cx.pos0 = start_pos + c * CH; cx.tok = (const int*)s->pf_tokens.p + (size_t)c * CH;
+        cx.first = true; cx.add_is_emb = true; cx.st = streams[cx.set];
+    }
+    // two chunks in flight (one per stream / arena): pairs (2p, 2p+1) are enqueued layer-interleaved; chunk 2p+2 follows chunk 2p on the
+    // same stream, so its arena is free, and it waits layer by layer for chunk 2p+1 -- the pipeline never drains between pairs
+    for (int p0 = 0; p0 < n_chunks; p0 += 2) {
+        const int nb = std::min(2, n_chunks - p0);
+        for (int d = 0; d < L + nb - 1; d++) {
+            for (int j = 0; j < nb; j++) {
+                const int l = d - j, c = p0 + j;
+                if (l < 0 || l >= L) continue;
+                Chunk& cx = chunks[c];
+                if (c > 0) KR_HIP(hipStreamWaitEvent(cx.st, s->pf_events[(size_t)((c - 1) & 1) * L + l], 0));
+                if (int rc = run_layer(s, cx, (size_t)l)) return rc;
+                if (n_chunks > 1) KR_HIP(hipEventRecord(s->pf_events[(size_t)(c & 1) * L + l], cx.st));
             }
         }
-        if (c0 + Cc == n_tokens) {
-            // ---- final norm + lm_head + greedy sample for the LAST token only (the other positions' logits are never consumed)
-            KrPfmNormArgs na{};
-            na.mode = add_is_emb ? 1 : 0; na.add_in = B.hid; na.emb = (const float*)s->embedding.p; na.tokens = B.tok; na.res = B.res;
-            na.w = (const float*)s->norms[s->final_norm]->p; na.out = B.normed; na.H = H; na.first = first ? 1 : 0; na.bias_one = s->norm_bias_one; na.eps = s->eps;
-            kr_launch_pfm_norm(na, Cc, st);
-            kr_launch_matvec(mv(s, s->lm_head), B.normed + (size_t)(Cc - 1) * H, 1, (float*)s->logits.p, st);
-            kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, st);
-        }
+    }
+    Chunk& last = chunks[n_chunks - 1];
+    run_final(s, last);
+    if (last.st != st) {                                                   // results become visible on the caller's stream
+        KR_HIP(hipEventRecord(s->pf_events[2 * L + 1], last.st));
+        KR_HIP(hipStreamWaitEvent(st, s->pf_events[2 * L + 1], 0));
+    } else if (n_chunks > 1) {
+        KR_HIP(hipEventRecord(s->pf_events[2 * L + 1], streams[1]));
+        KR_HIP(hipStreamWaitEvent(st, s->pf_events[2 * L + 1], 0));
     }
     KR_HIP(hipGetLastError());
     if (logits_out) {
         if (is_device_ptr(logits_out)) KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToDevice, st));
         else { KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }
     }
+    return KR_OK;
+}
+
+// test / tuning hook: tokens per chunk of the prompt pass (0 = default 2048)
+extern "C" int kr_decode_set_prefill_chunk(kr_decode_store* s, int chunk) {
+    if (!s) return kr_fail(KR_ERR_VALUE, "null decode store");
+    if (chunk < 0 || chunk > 8192) return kr_fail(KR_ERR_VALUE, "prefill chunk %d out of range [0, 8192]", chunk);
+    s->pf_chunk = chunk;
     return KR_OK;
 }

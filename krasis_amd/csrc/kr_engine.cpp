@@ -202,8 +202,8 @@ extern "C" void kr_engine_destroy(kr_engine* e) {
         l.gate_cm.release(); l.gate_rm.release(); l.bias.release(); l.esc.release();
         for (GgufSet* g : {&l.g_gate, &l.g_up, &l.g_down, &l.gs_gate, &l.gs_up, &l.gs_down}) { g->q.release(); g->h.release(); }
     }
-    for (DevBuf* b : {&e->gu, &e->eo, &e->st_act, &e->st_ids, &e->st_w, &e->st_out, &e->ptr_table, &e->r_logits, &e->r_ids, &e->r_w, &e->r_x, &e->pf_i32, &e->pf_xh, &e->pf_xl, &e->pf_xs,
-                       &e->pf_gu, &e->pf_hh, &e->pf_hl, &e->pf_hs, &e->pf_eo, &e->pf_sgu, &e->pf_shh, &e->pf_shl, &e->pf_shs, &e->pf_seo}) b->release();
+    for (DevBuf* b : {&e->gu, &e->eo, &e->st_act, &e->st_ids, &e->st_w, &e->st_out, &e->ptr_table, &e->r_logits, &e->r_ids, &e->r_w, &e->r_x}) b->release();
+    for (auto& P : e->pf) for (DevBuf* b : {&P.i32, &P.xh, &P.xl, &P.xs, &P.gu, &P.hh, &P.hl, &P.hs, &P.eo, &P.sgu, &P.shh, &P.shl, &P.shs, &P.seo}) b->release();
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -728,8 +728,8 @@ int kr_ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st) {
 
 #define KR_PF_CHUNK 8192
 
-extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
-                              int out_dtype, int routed_only, void* stream) {
+int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
+                       int out_dtype, int routed_only, int set, hipStream_t st) {
     if (int rc = check_layer(e, layer)) return rc;
     if (!x_bf16 || !ids || !wts || !out) return kr_fail(KR_ERR_VALUE, "null pointer argument");
     if (M <= 0) return kr_fail(KR_ERR_VALUE, "M must be > 0");
@@ -741,7 +741,7 @@ extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const
     if (e->cfg.hidden_size % 128 || L.inter % 128) return kr_fail(KR_ERR_VALUE, "prefill path needs dims divisible by 128");
     std::lock_guard<std::mutex> lk(e->mu);
     KR_HIP(hipSetDevice(e->device));
-    hipStream_t st = kr_pick_stream(e, stream);
+    kr_engine::PfSet& P = e->pf[set & 1];
     const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
     const bool use_shared = L.shared_present && !routed_only;
     const int SI = L.shared_inter;
@@ -752,13 +752,13 @@ extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const
     const size_t np = (size_t)CH * topk;
     const int max_tiles = (int)(np / 64) + E + 1;
     const size_t n_i32 = 3 * (size_t)E + 3 * (size_t)max_tiles + 4 + 2 * np;
-    if (e->pf_i32.ensure(n_i32 * 4) || e->pf_xh.ensure((size_t)CH * H) || e->pf_xl.ensure((size_t)CH * H) || e->pf_xs.ensure((size_t)CH * (H / 128) * 4) ||
-        e->pf_gu.ensure(np * 2 * I * 4) || e->pf_hh.ensure(np * I) || e->pf_hl.ensure(np * I) || e->pf_hs.ensure(np * (I / 128) * 4) || e->pf_eo.ensure(np * H * 4))
+    if (P.i32.ensure(n_i32 * 4) || P.xh.ensure((size_t)CH * H) || P.xl.ensure((size_t)CH * H) || P.xs.ensure((size_t)CH * (H / 128) * 4) ||
+        P.gu.ensure(np * 2 * I * 4) || P.hh.ensure(np * I) || P.hl.ensure(np * I) || P.hs.ensure(np * (I / 128) * 4) || P.eo.ensure(np * H * 4))
         return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
-    if (use_shared && (e->pf_sgu.ensure((size_t)CH * 2 * SI * 4) || e->pf_shh.ensure((size_t)CH * SI) || e->pf_shl.ensure((size_t)CH * SI) ||
-                       e->pf_shs.ensure((size_t)CH * (SI / 128) * 4) || e->pf_seo.ensure((size_t)CH * H * 4)))
+    if (use_shared && (P.sgu.ensure((size_t)CH * 2 * SI * 4) || P.shh.ensure((size_t)CH * SI) || P.shl.ensure((size_t)CH * SI) ||
+                       P.shs.ensure((size_t)CH * (SI / 128) * 4) || P.seo.ensure((size_t)CH * H * 4)))
         return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
-    int* ib = (int*)e->pf_i32.p;
+    int* ib = (int*)P.i32.p;
     KrPfSort so{};
     so.counts = ib; so.offsets = ib + E; so.cursor = ib + 2 * E; ib += 3 * E;
     so.tile_expert = ib; so.tile_row0 = ib + max_tiles; so.tile_rows = ib + 2 * max_tiles; ib += 3 * max_tiles;
@@ -771,26 +771,32 @@ extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const
         const int32_t* idc = ids + (size_t)m0 * topk; const float* wc = wts + (size_t)m0 * topk;
         const int tiles_bound = (mc * topk) / 64 + E + 1;
         kr_launch_pf_sort(idc, mc, topk, E, so, st);
-        kr_launch_pf_quant_x(xc, mc, H, (int8_t*)e->pf_xh.p, (int8_t*)e->pf_xl.p, (float*)e->pf_xs.p, st);
-        kr_launch_pf_gemm(L.w13.view(), (const uint32_t*)L.w13.wsum.p, (const int8_t*)e->pf_xh.p, (const int8_t*)e->pf_xl.p, (const float*)e->pf_xs.p, &so, topk, 1,
-                          tiles_bound, 0, (float*)e->pf_gu.p, 2 * I, st);
-        kr_launch_pf_act((const float*)e->pf_gu.p, mc * topk, I, 2 * I, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (int8_t*)e->pf_hh.p, (int8_t*)e->pf_hl.p,
-                         (float*)e->pf_hs.p, st);
-        kr_launch_pf_gemm(L.w2.view(), (const uint32_t*)L.w2.wsum.p, (const int8_t*)e->pf_hh.p, (const int8_t*)e->pf_hl.p, (const float*)e->pf_hs.p, &so, topk, 0,
-                          tiles_bound, 0, (float*)e->pf_eo.p, H, st);
+        kr_launch_pf_quant_x(xc, mc, H, (int8_t*)P.xh.p, (int8_t*)P.xl.p, (float*)P.xs.p, st);
+        kr_launch_pf_gemm(L.w13.view(), (const uint32_t*)L.w13.wsum.p, (const int8_t*)P.xh.p, (const int8_t*)P.xl.p, (const float*)P.xs.p, &so, topk, 1,
+                          tiles_bound, 0, (float*)P.gu.p, 2 * I, st);
+        kr_launch_pf_act((const float*)P.gu.p, mc * topk, I, 2 * I, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (int8_t*)P.hh.p, (int8_t*)P.hl.p,
+                         (float*)P.hs.p, st);
+        kr_launch_pf_gemm(L.w2.view(), (const uint32_t*)L.w2.wsum.p, (const int8_t*)P.hh.p, (const int8_t*)P.hl.p, (const float*)P.hs.p, &so, topk, 0,
+                          tiles_bound, 0, (float*)P.eo.p, H, st);
         if (use_shared) {
-            kr_launch_pf_gemm(L.sw13.view(), (const uint32_t*)L.sw13.wsum.p, (const int8_t*)e->pf_xh.p, (const int8_t*)e->pf_xl.p, (const float*)e->pf_xs.p, nullptr, topk, 0,
-                              0, mc, (float*)e->pf_sgu.p, 2 * SI, st);
-            kr_launch_pf_act((const float*)e->pf_sgu.p, mc, SI, 2 * SI, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (int8_t*)e->pf_shh.p, (int8_t*)e->pf_shl.p,
-                             (float*)e->pf_shs.p, st);
-            kr_launch_pf_gemm(L.sw2.view(), (const uint32_t*)L.sw2.wsum.p, (const int8_t*)e->pf_shh.p, (const int8_t*)e->pf_shl.p, (const float*)e->pf_shs.p, nullptr, topk, 0,
-                              0, mc, (float*)e->pf_seo.p, H, st);
+            kr_launch_pf_gemm(L.sw13.view(), (const uint32_t*)L.sw13.wsum.p, (const int8_t*)P.xh.p, (const int8_t*)P.xl.p, (const float*)P.xs.p, nullptr, topk, 0,
+                              0, mc, (float*)P.sgu.p, 2 * SI, st);
+            kr_launch_pf_act((const float*)P.sgu.p, mc, SI, 2 * SI, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (int8_t*)P.shh.p, (int8_t*)P.shl.p,
+                             (float*)P.shs.p, st);
+            kr_launch_pf_gemm(L.sw2.view(), (const uint32_t*)L.sw2.wsum.p, (const int8_t*)P.shh.p, (const int8_t*)P.shl.p, (const float*)P.shs.p, nullptr, topk, 0,
+                              0, mc, (float*)P.seo.p, H, st);
         }
-        kr_launch_pf_combine((const float*)e->pf_eo.p, so.pair_row, wc, mc, topk, H, use_shared ? (const float*)e->pf_seo.p : nullptr, e->cfg.routed_scaling_factor,
+        kr_launch_pf_combine((const float*)P.eo.p, so.pair_row, wc, mc, topk, H, use_shared ? (const float*)P.seo.p : nullptr, e->cfg.routed_scaling_factor,
                              (char*)out + (size_t)m0 * H * ob, out_dtype == KR_OUT_BF16, st);
     }
     KR_HIP(hipGetLastError());
     return KR_OK;
+}
+
+extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
+                              int out_dtype, int routed_only, void* stream) {
+    if (int rc = check_layer(e, layer)) return rc;
+    return kr_moe_prefill_set(e, layer, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, 0, kr_pick_stream(e, stream));
 }
 
 // Expert-parallel combine (krasis_amd/ep.py): rows returned by the owning ranks are summed per token in routing order with the routing

@@ -80,7 +80,7 @@ struct kr_engine {
     bool routing_set = false; int r_scoring = 1, r_norm = 1, r_topk = 0, r_ne = 0, r_hidden = 0;
     DevBuf r_logits, r_ids, r_w, r_x;
     // prefill scratch (kr_moe_prefill)
-    DevBuf pf_i32, pf_xh, pf_xl, pf_xs, pf_gu, pf_hh, pf_hl, pf_hs, pf_eo, pf_sgu, pf_shh, pf_shl, pf_shs, pf_seo;
+    struct PfSet { DevBuf i32, xh, xl, xs, gu, hh, hl, hs, eo, sgu, shh, shl, shs, seo; } pf[2];   // two sets: the prompt pass runs two chunks concurrently
     // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
     bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};
     std::mutex mu;
@@ -92,6 +92,9 @@ static inline hipStream_t kr_pick_stream(kr_engine* e, void* stream);
 int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int count);
 int upload_mat(kr_engine* e, MatSet& ms, int idx, const void* w, const uint16_t* sc);
 int download_mat(kr_engine* e, MatSet& ms, int idx, void* w, uint16_t* sc);
+// kr_moe_prefill with an explicit scratch set (0/1) and stream; all pointers device.  out f32 or bf16 per out_dtype.
+int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
+                       int out_dtype, int routed_only, int set, hipStream_t st);
 
 static inline hipStream_t kr_pick_stream(kr_engine* e, void* stream) {
     if (!stream) return e->stream;

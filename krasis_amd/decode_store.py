@@ -168,6 +168,10 @@ class CpuDecodeStore:
         check(self._lib.kr_decode_prefill(self._h, arr, len(tokens), start_pos, output_ptr or None, stream or None))
         return self.last_token()
 
+    def set_prefill_chunk(self, chunk: int) -> None:
+        """Tokens per chunk of the prompt pass (0 = default); chunks alternate between two streams."""
+        self._need(); check(self._lib.kr_decode_set_prefill_chunk(self._h, chunk))
+
     def generate_batch(self, first_token: int, start_pos: int, max_tokens: int, temperature: float = 0.0, top_k: int = 0, top_p: float = 1.0,
                        stop_ids: Sequence[int] = (), presence_penalty: float = 0.0) -> List[int]:
         self._need()

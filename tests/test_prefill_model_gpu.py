@@ -22,9 +22,11 @@ def _snapshot(st, d):
 
 
 @pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True)])
-@pytest.mark.parametrize("n_tok,start", [(1, 5), (3, 5), (9, 0), (20, 7)])
-def test_prefill_equals_sequential_decode(cfg, n_tok, start):
+@pytest.mark.parametrize("n_tok,start,chunk", [(1, 5, 0), (3, 5, 0), (9, 0, 0), (20, 7, 0), (20, 7, 6), (23, 3, 1), (17, 0, 8)])
+def test_prefill_equals_sequential_decode(cfg, n_tok, start, chunk):
+    """chunk > 0 forces several chunks: they alternate between two streams / arenas in a (chunk, layer) wavefront."""
     st, eng, orc, keep, d = build(**cfg)
+    st.set_prefill_chunk(chunk)
     rng = np.random.default_rng(n_tok * 31 + start)
     toks = [int(x) for x in rng.integers(0, d["V"], n_tok)]
     # reference: token-by-token decode from the same initial state
