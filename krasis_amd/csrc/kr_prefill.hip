@@ -15,6 +15,7 @@
 #include "kr_device.h"
 #include "kr_kernels.h"
 #include "kr_prefill.h"
+#include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -295,6 +296,8 @@ __global__ void __launch_bounds__(256) kr_pf_gemm_kernel(const KrPfGemmArgs a) {
     }
 }
 
+#include "kr_prefill_gemm2.inc"
+
 // ------------------------------------------------------------------------------------------
 // combine: out[t] = sum_s w[t][s] * eo[row(t,s)] in routing order (moe.rs:661-667); shared: rsf*out + shared (moe.rs:703-706)
 // ------------------------------------------------------------------------------------------
@@ -345,8 +348,15 @@ void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_
     if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
     a.out = out; a.out_ld = out_ld; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
     const int mt = single_expert_rows > 0 ? (single_expert_rows + PF_BM - 1) / PF_BM : max_tiles;
-    dim3 grid(mt, (m.N + PF_BN - 1) / PF_BN);
-    hipLaunchKernelGGL(kr_pf_gemm_kernel, grid, dim3(256), kr_pf_gemm_lds_bytes(), st, a);
+    static int variant = -2;       // KR_PF_GEMM_VARIANT (tuning hook): -1 = first generation; 0 = (64 cols/wave, 2 groups/stage); 1 = (64,1); 2 = (32,1); 3 = (32,2) [default: measured best]
+    if (variant == -2) { const char* ev = getenv("KR_PF_GEMM_VARIANT"); variant = ev ? atoi(ev) : 3; }
+    if (variant == -1) {
+        dim3 grid(mt, (m.N + PF_BN - 1) / PF_BN);
+        hipLaunchKernelGGL(kr_pf_gemm_kernel, grid, dim3(256), kr_pf_gemm_lds_bytes(), st, a);
+    } else if (variant == 1) kr_pf_gemm2_launch<64, 1>(a, mt, st);
+    else if (variant == 2) kr_pf_gemm2_launch<32, 1>(a, mt, st);
+    else if (variant == 3) kr_pf_gemm2_launch<32, 2>(a, mt, st);
+    else kr_pf_gemm2_launch<64, 2>(a, mt, st);
 }
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                           int out_bf16, hipStream_t st) {
