@@ -115,7 +115,6 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         KR_HIP(hipMemsetAsync(B.sgu, 0, (size_t)Cc * 2 * K * 4, st));   // padding of gate | up stays 0 (decode.rs dense path)
         {   // gate -> [0,K), up -> [K,2K) of each row
             DWeight& Wg = *s->weights[L.gate_wid]; DWeight& Wu = *s->weights[L.up_wid];
-            if (Wg.ms.bits != 4 || Wu.ms.bits != 4) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: dense MLP weights must be INT4-g128");
             if (int rc = kr_ensure_wsum(e, Wg.ms, st)) return rc;
             if (int rc = kr_ensure_wsum(e, Wu.ms, st)) return rc;
             kr_launch_pf_gemm(Wg.ms.view(), (const uint32_t*)Wg.ms.wsum.p, B.xh, B.xl, B.xs, nullptr, 1, 0, 0, Cc, B.sgu, 2 * K, st);
@@ -186,7 +185,6 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
     }
     for (int w : wids) {
         DWeight& W = *s->weights[w];
-        if (W.ms.bits != 4) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: weight %d is INT%d; the MFMA projection path is built for INT4-g128", w, W.ms.bits);
         if (int rc = kr_ensure_wsum(e, W.ms, st)) return rc;
     }
     kmax = std::max(kmax, ad);

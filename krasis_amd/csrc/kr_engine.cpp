@@ -719,7 +719,7 @@ extern "C" int kr_get_profile(kr_engine* e, int kind, double* total_ms, long* la
 // ------------------------------------------------------------------------------------------------
 int kr_ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st) {
     if (ms.wsum.p || !ms.allocated()) return KR_OK;
-    if (ms.bits != 4) return kr_fail(KR_ERR_VALUE, "prefill MFMA path is built for INT4-g128 experts (got %d-bit)", ms.bits);
+    if (ms.bits != 4 && ms.bits != 8) return kr_fail(KR_ERR_VALUE, "prefill MFMA path needs INT4-g128 or INT8-g128 weights (got %d-bit)", ms.bits);
     if (ms.wsum.ensure(ms.s_stride * ms.count)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
     e->weight_bytes += ms.s_stride * ms.count;
     kr_launch_pf_wsum(ms.view(), ms.count, (uint32_t*)ms.wsum.p, st);

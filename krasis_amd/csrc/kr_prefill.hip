@@ -144,6 +144,28 @@ __global__ void __launch_bounds__(64) kr_pf_wsum_kernel(const KrMatDev m, uint32
     }
 }
 
+// INT8-g128 twin: per (expert, column, group) sum_k w, same i16-pair layout.  grid (N/8 tiles, experts), 64 thr
+__global__ void __launch_bounds__(64) kr_pf_wsum8_kernel(const KrMatDev m, uint32_t* __restrict__ wsum) {
+    const int tile = blockIdx.x, e = blockIdx.y, lane = threadIdx.x, col = lane >> 3;
+    const u32x4* q = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(m.q) + (size_t)e * m.q_stride) + (size_t)tile * m.ng * 64 + lane;
+    uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(wsum) + (size_t)e * m.s_stride) + (size_t)tile * m.ngp * 8 + col;
+    for (int gp = 0; gp < m.ngp; gp++) {
+        int sv[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int g = 2 * gp + h;
+            if (g < m.ng) {
+                const u32x4 w = q[(size_t)g * 64];
+                int t = __builtin_amdgcn_sdot4((int)w.x, 0x01010101, 0, false); t = __builtin_amdgcn_sdot4((int)w.y, 0x01010101, t, false);
+                t = __builtin_amdgcn_sdot4((int)w.z, 0x01010101, t, false); t = __builtin_amdgcn_sdot4((int)w.w, 0x01010101, t, false);
+                sv[h] = t;
+            }
+            sv[h] = kr_red8_add_i32(sv[h]);
+        }
+        if ((lane & 7) == 0) out[gp * 8] = ((uint32_t)sv[0] & 0xFFFFu) | ((uint32_t)sv[1] << 16);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // grouped GEMM on int8 MFMA
 // ------------------------------------------------------------------------------------------
@@ -339,6 +361,7 @@ void kr_launch_pf_act(const float* gu, int rows, int n, int gu_ld, int act_mode,
     else hipLaunchKernelGGL(kr_pf_act_kernel<KR_ACT_SILU_FUSED>, dim3(rows), dim3(thr), 0, st, gu, n, gu_ld, swiglu_limit, alpha, hh, hl, hs);
 }
 void kr_launch_pf_wsum(const KrMatDev& m, int n_experts, uint32_t* wsum, hipStream_t st) {
+    if (m.bits == 8) { hipLaunchKernelGGL(kr_pf_wsum8_kernel, dim3((m.N + 7) / 8, n_experts), dim3(64), 0, st, m, wsum); return; }
     hipLaunchKernelGGL(kr_pf_wsum_kernel, dim3((m.N + 7) / 8, n_experts), dim3(64), 0, st, m, wsum);
 }
 void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_hi, const int8_t* a_lo, const float* a_scale, const KrPfSort* sort, int topk,
@@ -350,13 +373,14 @@ void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_
     const int mt = single_expert_rows > 0 ? (single_expert_rows + PF_BM - 1) / PF_BM : max_tiles;
     static int variant = -2;       // KR_PF_GEMM_VARIANT (tuning hook): -1 = first generation; 0 = (64 cols/wave, 2 groups/stage); 1 = (64,1); 2 = (32,1); 3 = (32,2) [default: measured best]
     if (variant == -2) { const char* ev = getenv("KR_PF_GEMM_VARIANT"); variant = ev ? atoi(ev) : 3; }
-    if (variant == -1) {
+    if (variant == -1 && m.bits == 4) {
         dim3 grid(mt, (m.N + PF_BN - 1) / PF_BN);
         hipLaunchKernelGGL(kr_pf_gemm_kernel, grid, dim3(256), kr_pf_gemm_lds_bytes(), st, a);
-    } else if (variant == 1) kr_pf_gemm2_launch<64, 1>(a, mt, st);
-    else if (variant == 2) kr_pf_gemm2_launch<32, 1>(a, mt, st);
-    else if (variant == 3) kr_pf_gemm2_launch<32, 2>(a, mt, st);
-    else kr_pf_gemm2_launch<64, 2>(a, mt, st);
+    } else if (m.bits == 8) kr_pf_gemm2_launch<32, 2, 8>(a, mt, st);
+    else if (variant == 1) kr_pf_gemm2_launch<64, 1, 4>(a, mt, st);
+    else if (variant == 2) kr_pf_gemm2_launch<32, 1, 4>(a, mt, st);
+    else if (variant == 3) kr_pf_gemm2_launch<32, 2, 4>(a, mt, st);
+    else kr_pf_gemm2_launch<64, 2, 4>(a, mt, st);
 }
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                           int out_bf16, hipStream_t st) {

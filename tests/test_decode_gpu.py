@@ -15,7 +15,7 @@ def _ptr(a):
     return a.ctypes.data
 
 
-def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False):
+def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4):
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     rng = np.random.default_rng(seed)
     H, V, E, k, I, SI = 256, 512, 16, 4, 128, 128
@@ -33,7 +33,7 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False):
 
     def W(rows, cols, scale=0.05):
         w = (rng.standard_normal((rows, cols)) * scale).astype(F); keep.append(w)
-        return st.store_weight_f32(_ptr(w), rows, cols, 4), orc.store_weight_f32(w, 4)
+        return st.store_weight_f32(_ptr(w), rows, cols, wbits), orc.store_weight_f32(w, wbits)
 
     def N(n):
         w = (rng.random(n) * 0.2 + (0.0 if norm_bias_one else 0.9)).astype(F); keep.append(w)
@@ -74,10 +74,10 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False):
             DI = 384                                    # dense MLP with a padded intermediate (cols of down = 384)
             gw = W(DI - 40, H); uw = W(DI - 40, H)
             wd = (rng.standard_normal((H, DI)) * 0.05).astype(F); wd[:, DI - 40:] = 0; keep.append(wd)
-            dw = (st.store_weight_f32(_ptr(wd), H, DI, 4), orc.store_weight_f32(wd, 4))
+            dw = (st.store_weight_f32(_ptr(wd), H, DI, wbits), orc.store_weight_f32(wd, wbits))
             st.set_decode_layer_dense(li, gw[0], uw[0], dw[0]); L.update(mlp="dense", gate_w=gw[1], up_w=uw[1], down_w=dw[1])
         else:
-            experts = make_experts(rng, E, H, I); upload(eng, li, experts)
+            experts = make_experts(rng, E, H, I, wbits); upload(eng, li, experts)
             gate = ((rng.random((E, H)) - 0.5) * 0.1).astype(F); keep.append(gate)
             esc = ((rng.random(E) - 0.5) * 0.01).astype(F) if scoring == 0 else None
             eng.set_route_weight_f32(li, gate, None, esc)
@@ -94,7 +94,7 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False):
                                     state=state)
 
 
-@pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True)])
+@pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True), dict(wbits=8, with_dense=True)])
 @pytest.mark.parametrize("graph", [True, False])
 def test_decode_step_bit_exact(cfg, graph):
     st, eng, orc, keep, d = build(**cfg)

@@ -11,24 +11,26 @@ from tests.util import make_experts, rand_bf16, upload
 pytestmark = pytest.mark.gpu
 
 
-def _setup(H, I, E, k, n_shared=0, rsf=1.0, seed=0):
+def _setup(H, I, E, k, n_shared=0, rsf=1.0, seed=0, bits=4, w2_bits=None):
     import torch
     from krasis_amd import GpuPrefillManager, KrasisEngine, ModelConfig
     rng = np.random.default_rng(seed)
-    experts = make_experts(rng, E, H, I)
-    shared = make_experts(rng, 1, H, n_shared * I)[0] if n_shared else None
+    experts = make_experts(rng, E, H, I, bits, w2_bits)
+    shared = make_experts(rng, 1, H, n_shared * I, bits, w2_bits)[0] if n_shared else None
     eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, 1, n_shared, rsf))
     upload(eng, 0, experts, shared)
     return eng, GpuPrefillManager(eng, k), experts, shared, rng, torch
 
 
-@pytest.mark.parametrize("H,I,E,k,M,n_shared", [
-    (256, 128, 8, 2, 200, 0),
-    (512, 384, 16, 4, 333, 1),       # odd group count in w2, shared expert, ragged tiles
-    (2048, 512, 32, 10, 160, 1),     # QCN expert shape
+@pytest.mark.parametrize("H,I,E,k,M,n_shared,bits,w2_bits", [
+    (256, 128, 8, 2, 200, 0, 4, 4),
+    (512, 384, 16, 4, 333, 1, 4, 4),       # odd group count in w2, shared expert, ragged tiles
+    (2048, 512, 32, 10, 160, 1, 4, 4),     # QCN expert shape
+    (512, 384, 16, 4, 333, 1, 8, 8),       # INT8-g128 experts (Q8 configuration): the lane record is the MFMA fragment
+    (256, 128, 8, 2, 200, 0, 4, 8),        # mixed: INT4 gate/up, INT8 down
 ])
-def test_prefill_bit_exact_vs_cpu_engine_numerics(H, I, E, k, M, n_shared):
-    eng, mgr, experts, shared, rng, torch = _setup(H, I, E, k, n_shared, 2.0 if n_shared else 1.0)
+def test_prefill_bit_exact_vs_cpu_engine_numerics(H, I, E, k, M, n_shared, bits, w2_bits):
+    eng, mgr, experts, shared, rng, torch = _setup(H, I, E, k, n_shared, 2.0 if n_shared else 1.0, bits=bits, w2_bits=w2_bits)
     x = rand_bf16(rng, (M, H)); ids = np.stack([rng.choice(E, k, replace=False) for _ in range(M)]).astype(np.int32)
     ids[3, 1] = -1; ids[7, :] = -1                                  # skipped slots (moe.rs:2904)
     if E >= 16:

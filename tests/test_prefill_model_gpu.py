@@ -21,7 +21,7 @@ def _snapshot(st, d):
     return out
 
 
-@pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True)])
+@pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True), dict(wbits=8, with_dense=True)])
 @pytest.mark.parametrize("n_tok,start,chunk", [(1, 5, 0), (3, 5, 0), (9, 0, 0), (20, 7, 0), (20, 7, 6), (23, 3, 1), (17, 0, 8)])
 def test_prefill_equals_sequential_decode(cfg, n_tok, start, chunk):
     """chunk > 0 forces several chunks: they alternate between two streams / arenas in a (chunk, layer) wavefront."""
