@@ -200,6 +200,16 @@ int kr_decode_fill_state_synthetic(kr_decode_store* s, int kv_max_seq, uint64_t 
 int kr_decode_get_state(kr_decode_store* s, int layer, uint16_t* kv_k, uint16_t* kv_v, float* conv_state, float* recur_state);
 /* decode_step(token, pos, out_ptr) (decode.rs:2690): logits f32 [vocab] to a host or device pointer (NULL = keep on device) */
 int kr_decode_step(kr_decode_store* s, int token_id, int position, float* logits_out, void* stream);
+/* generate_batch (decode.rs:3525-3600) with the full sampler sample_from_logits (decode.rs:3718-3811): per step decode_step, presence
+ * penalty on already seen tokens, 1/temperature, top-k (k largest, sorted descending; ties by ascending token id), libm softmax with
+ * sequential sums in that order, top-p prefix, renormalisation, xorshift64 draw (x ^= x<<13; x ^= x>>7; x ^= x<<17; r = x / u64::MAX).
+ * temperature == 0 is greedy (first maximum).  The sampled token is appended before the stop test, so a stop id is the last element.
+ * rng_seed 0 = wall clock like the reference.  Everything runs on the GPU; one 4-byte DtoH per token returns the id. */
+int kr_decode_generate(kr_decode_store* s, int first_token, int start_pos, int max_tokens, float temperature, int top_k, float top_p,
+                       const int* stop_ids, int n_stop, float presence_penalty, uint64_t rng_seed, int* tokens_out, int* n_out, void* stream);
+/* sample_from_logits on the logits of the last decode_step / prefill (modifies them in place like the reference) */
+int kr_decode_sample(kr_decode_store* s, float temperature, int top_k, float top_p, float presence_penalty, uint64_t rng_seed, int reset_seen,
+                     int* token_out, void* stream);
 /* generate_batch (decode.rs:3525), greedy sampling only in this round */
 int kr_decode_generate_greedy(kr_decode_store* s, int first_token, int start_pos, int max_tokens, const int* stop_ids, int n_stop,
                               int* tokens_out, int* n_out, void* stream);

@@ -18,6 +18,8 @@
 #include "kr_engine_internal.h"
 #include "kr_kernels.h"
 #include "kr_router.h"
+#include "kr_sampler.h"
+#include <chrono>
 
 #include "kr_decode_internal.h"
 
@@ -59,7 +61,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                            &l.w_kc, &l.w_vc, &l.kv_a_norm, &l.q_a_norm, &l.mla_cos, &l.mla_sin}) b->release();
     for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
-                      &s->hid2, &s->res2, &s->r_counter, &s->argmax_scratch, &s->pf_scratch, &s->pf_scores, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
+                      &s->hid2, &s->res2, &s->r_counter, &s->argmax_scratch, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     for (hipEvent_t ev : s->pf_events) (void)hipEventDestroy(ev);
     if (s->pf_side) { (void)hipStreamSynchronize(s->pf_side); (void)hipStreamDestroy(s->pf_side); }
     if (s->step_host) (void)hipHostFree(s->step_host);
@@ -618,25 +620,85 @@ extern "C" int kr_decode_step(kr_decode_store* s, int token_id, int position, fl
     return KR_OK;
 }
 
-// generate_batch (decode.rs:3525), greedy only: next = argmax(logits) (first max wins); stop ids end generation
-extern "C" int kr_decode_generate_greedy(kr_decode_store* s, int first_token, int start_pos, int max_tokens, const int* stop_ids, int n_stop,
-                                         int* tokens_out, int* n_out, void* stream) {
+// ---- sampling state (generate_batch, decode.rs:3525-3600): seen-token bitmap, xorshift64 state, sort scratch -- all on the device
+static int sampler_prepare(kr_decode_store* s) {
+    const size_t vocab = (size_t)s->vocab;
+    if (s->smp_temp_bytes == 0) s->smp_temp_bytes = kr_sampler_temp_bytes(s->vocab);
+    if (s->smp_seen.ensure(((vocab + 31) / 32) * 4 + 64) || s->smp_keys.ensure(2 * vocab * 8) || s->smp_temp.ensure(s->smp_temp_bytes + 256) ||
+        s->smp_probs.ensure(vocab * 4) || s->smp_rng.ensure(64))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of sampler scratch failed");
+    return KR_OK;
+}
+
+// sample_from_logits (decode.rs:3718) applied to the logits of the last step; temperature 0 = greedy (first maximum).
+// rng_seed != 0 re-seeds the xorshift64 state (the reference seeds from the wall clock; 0xDEADBEEF if that is 0).
+extern "C" int kr_decode_sample(kr_decode_store* s, float temperature, int top_k, float top_p, float presence_penalty, uint64_t rng_seed,
+                                int reset_seen, int* token_out, void* stream) {
     if (int rc = need_cfg(s)) return rc;
+    if (temperature < 0.0f) return kr_fail(KR_ERR_VALUE, "temperature must be >= 0");
     KR_HIP(hipSetDevice(s->eng->device));
     hipStream_t st = kr_pick_stream(s->eng, stream);
+    if (int rc = sampler_prepare(s)) return rc;
+    if (reset_seen) KR_HIP(hipMemsetAsync(s->smp_seen.p, 0, s->smp_seen.bytes, st));
+    if (rng_seed) KR_HIP(hipMemcpyAsync(s->smp_rng.p, &rng_seed, 8, hipMemcpyHostToDevice, st));
+    if (temperature == 0.0f) {
+        if (presence_penalty != 0.0f) return kr_fail(KR_ERR_VALUE, "presence_penalty with greedy sampling goes through kr_decode_generate");
+        kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, st);
+    } else {
+        uint64_t* keys = (uint64_t*)s->smp_keys.p;
+        if (kr_launch_sample((float*)s->logits.p, s->vocab, temperature, top_k, top_p, presence_penalty, (uint32_t*)s->smp_seen.p, keys, keys + s->vocab,
+                             s->smp_temp.p, s->smp_temp_bytes, (float*)s->smp_probs.p, (uint64_t*)s->smp_rng.p, (int*)s->tok.p, st))
+            return kr_fail(KR_ERR_HIP, "device radix sort failed");
+    }
+    if (token_out) { KR_HIP(hipMemcpyAsync(token_out, s->tok.p, 4, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }
+    return KR_OK;
+}
+
+// generate_batch (decode.rs:3525): decode_step -> presence penalty on seen tokens -> sample_from_logits; the sampled token is appended
+// BEFORE the stop test (decode.rs:3587-3591), so a stop id is the last element of the result.
+extern "C" int kr_decode_generate(kr_decode_store* s, int first_token, int start_pos, int max_tokens, float temperature, int top_k, float top_p,
+                                  const int* stop_ids, int n_stop, float presence_penalty, uint64_t rng_seed, int* tokens_out, int* n_out, void* stream) {
+    if (int rc = need_cfg(s)) return rc;
+    if (!tokens_out || !n_out) return kr_fail(KR_ERR_VALUE, "null output pointer");
+    if (temperature < 0.0f) return kr_fail(KR_ERR_VALUE, "temperature must be >= 0");
+    KR_HIP(hipSetDevice(s->eng->device));
+    hipStream_t st = kr_pick_stream(s->eng, stream);
+    const bool sampled = temperature != 0.0f, penal = presence_penalty != 0.0f;
+    if (sampled || penal) {
+        if (int rc = sampler_prepare(s)) return rc;
+        KR_HIP(hipMemsetAsync(s->smp_seen.p, 0, s->smp_seen.bytes, st));
+        if (first_token >= 0 && first_token < s->vocab) kr_launch_mark_seen((uint32_t*)s->smp_seen.p, nullptr, first_token, st);
+        if (rng_seed == 0) { rng_seed = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count(); if (rng_seed == 0) rng_seed = 0xDEADBEEFull; }
+        KR_HIP(hipMemcpyAsync(s->smp_rng.p, &rng_seed, 8, hipMemcpyHostToDevice, st));
+    }
     int tok = first_token, n = 0;
     for (int i = 0; i < max_tokens; i++) {
-        if (int rc = kr_decode_step(s, tok, start_pos + i, nullptr, st)) return rc;
+        if (int rc = kr_decode_step(s, tok, start_pos + i, nullptr, st)) return rc;     // graph replay ends with the greedy argmax into s->tok
+        if (sampled) {
+            uint64_t* keys = (uint64_t*)s->smp_keys.p;
+            if (kr_launch_sample((float*)s->logits.p, s->vocab, temperature, top_k, top_p, presence_penalty, (uint32_t*)s->smp_seen.p, keys, keys + s->vocab,
+                                 s->smp_temp.p, s->smp_temp_bytes, (float*)s->smp_probs.p, (uint64_t*)s->smp_rng.p, (int*)s->tok.p, st))
+                return kr_fail(KR_ERR_HIP, "device radix sort failed");
+        } else if (penal) {   // greedy with a presence penalty: penalise, then first maximum
+            kr_launch_penalty((float*)s->logits.p, s->vocab, presence_penalty, (const uint32_t*)s->smp_seen.p, st);
+            kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, st);
+            kr_launch_mark_seen((uint32_t*)s->smp_seen.p, (const int*)s->tok.p, 0, st);
+        }
         int next = 0;
         KR_HIP(hipMemcpyAsync(&next, s->tok.p, 4, hipMemcpyDeviceToHost, st));
         KR_HIP(hipStreamSynchronize(st));
+        tokens_out[n++] = next; tok = next;
         bool stop = false;
         for (int j = 0; j < n_stop; j++) stop |= (stop_ids[j] == next);
         if (stop) break;
-        tokens_out[n++] = next; tok = next;
     }
     *n_out = n;
     return KR_OK;
+}
+
+extern "C" int kr_decode_generate_greedy(kr_decode_store* s, int first_token, int start_pos, int max_tokens, const int* stop_ids, int n_stop,
+                                         int* tokens_out, int* n_out, void* stream) {
+    return kr_decode_generate(s, first_token, start_pos, max_tokens, 0.0f, 0, 1.0f, stop_ids, n_stop, 0.0f, 0, tokens_out, n_out, stream);
 }
 
 extern "C" int kr_decode_last_token(kr_decode_store* s, int* tok) {

@@ -47,6 +47,7 @@ struct kr_decode_store {
     DevBuf dense_gu;  // [gate(K) | up(K)] of the dense MLP; only [0,inter) of each half is ever written, the padding stays 0
     DevBuf hid2, res2, r_counter, argmax_scratch;
     bool fuse_router = true;   // hid2/res2: outputs of the fused norm+router launch (its inputs stay readable for every workgroup)
+    DevBuf smp_seen, smp_keys, smp_temp, smp_probs, smp_rng; size_t smp_temp_bytes = 0;   // sampler: seen bitmap, sort keys / scratch, probabilities, xorshift64 state
     DevBuf pf_scores;          // kr_decode_prefill: attention scores [chunk*nh rows][context] f32
     DevBuf pf_tokens; int pf_chunk = 0; hipStream_t pf_side = nullptr; std::vector<hipEvent_t> pf_events;   // prompt pass: token ids, chunk size, second stream
     DevBuf pf_scratch;         // kr_decode_prefill: one arena for the chunk buffers

@@ -173,14 +173,21 @@ class CpuDecodeStore:
         self._need(); check(self._lib.kr_decode_set_prefill_chunk(self._h, chunk))
 
     def generate_batch(self, first_token: int, start_pos: int, max_tokens: int, temperature: float = 0.0, top_k: int = 0, top_p: float = 1.0,
-                       stop_ids: Sequence[int] = (), presence_penalty: float = 0.0) -> List[int]:
+                       stop_ids: Sequence[int] = (), presence_penalty: float = 0.0, rng_seed: int = 0) -> List[int]:
+        """decode.rs:3525 -- decode loop + sampler on the GPU; `rng_seed` (extra, 0 = wall clock like the reference) makes draws reproducible."""
         self._need()
-        if temperature > 0.0:
-            raise ValueError("only greedy sampling (temperature=0) is built in this round")
-        out = (C.c_int * max_tokens)(); n = C.c_int()
+        out = (C.c_int * max(max_tokens, 1))(); n = C.c_int()
         stops = (C.c_int * max(len(stop_ids), 1))(*stop_ids)
-        check(self._lib.kr_decode_generate_greedy(self._h, first_token, start_pos, max_tokens, stops, len(stop_ids), out, C.byref(n), None))
+        check(self._lib.kr_decode_generate(self._h, first_token, start_pos, max_tokens, temperature, top_k, top_p, stops, len(stop_ids),
+                                           presence_penalty, rng_seed, out, C.byref(n), None))
         return list(out[: n.value])
+
+    def sample(self, temperature: float, top_k: int = 0, top_p: float = 1.0, presence_penalty: float = 0.0, rng_seed: int = 0, reset_seen: bool = False) -> int:
+        """sample_from_logits (decode.rs:3718) on the logits of the last decode_step / prefill."""
+        self._need()
+        t = C.c_int()
+        check(self._lib.kr_decode_sample(self._h, temperature, top_k, top_p, presence_penalty, rng_seed, int(reset_seen), C.byref(t), None))
+        return t.value
 
     def last_token(self) -> int:
         t = C.c_int(); check(self._lib.kr_decode_last_token(self._h, C.byref(t))); return t.value

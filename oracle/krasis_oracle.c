@@ -1183,6 +1183,38 @@ int kro_sample_greedy(const float* logits, int n) { /* decode.rs:3718: first max
     return best;
 }
 
+/* sample_from_logits (decode.rs:3718-3811).  logits are modified in place (temperature) like the reference.  The reference orders the
+ * top-k with sort_unstable_by on the value only; equal logits are ordered here by ascending token id (one valid outcome of that sort). */
+static const float* g_sort_logits;
+static int cmp_logit_desc(const void* a, const void* b) {
+    int ia = *(const int*)a, ib = *(const int*)b; float va = g_sort_logits[ia], vb = g_sort_logits[ib];
+    if (va > vb) return -1; if (va < vb) return 1; return ia < ib ? -1 : (ia > ib ? 1 : 0);
+}
+uint64_t kro_xorshift64_next(uint64_t* st) { uint64_t x = *st; x ^= x << 13; x ^= x >> 7; x ^= x << 17; *st = x; return x; }
+int kro_sample_from_logits(float* logits, int vocab, float temperature, int top_k, float top_p, uint64_t* rng_state) {
+    if (temperature == 0.0f) return kro_sample_greedy(logits, vocab);
+    float inv_temp = 1.0f / temperature;
+    for (int i = 0; i < vocab; i++) logits[i] *= inv_temp;
+    int k = (top_k > 0 && top_k < vocab) ? top_k : vocab;
+    int* idx = (int*)malloc(sizeof(int) * (size_t)vocab);
+    for (int i = 0; i < vocab; i++) idx[i] = i;
+    g_sort_logits = logits; qsort(idx, (size_t)vocab, sizeof(int), cmp_logit_desc);
+    float* probs = (float*)malloc(4 * (size_t)k);
+    float mx = logits[idx[0]], sum = 0.0f;
+    for (int i = 0; i < k; i++) { probs[i] = expf(logits[idx[i]] - mx); sum += probs[i]; }
+    float inv_sum = 1.0f / sum;
+    for (int i = 0; i < k; i++) probs[i] *= inv_sum;
+    int cutoff = k;
+    if (top_p < 1.0f) { float cum = 0.0f; for (int i = 0; i < k; i++) { cum += probs[i]; if (cum >= top_p) { cutoff = i + 1; break; } } }
+    if (cutoff < k) { float ns = 0.0f; for (int i = 0; i < cutoff; i++) ns += probs[i]; float inv = 1.0f / ns; for (int i = 0; i < cutoff; i++) probs[i] *= inv; }
+    float r = (float)((double)kro_xorshift64_next(rng_state) / 18446744073709551615.0);
+    int pick = cutoff - 1; float cum = 0.0f;
+    for (int i = 0; i < cutoff; i++) { cum += probs[i]; if (r < cum) { pick = i; break; } }
+    int tok = idx[pick];
+    free(idx); free(probs);
+    return tok;
+}
+
 /* ------------------------------------------------------------------ */
 /* H: GPU prefill semantics (sglang fused_marlin_moe dataflow)          */
 /* ------------------------------------------------------------------ */

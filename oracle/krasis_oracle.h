@@ -157,7 +157,9 @@ void kro_rmsnorm_seq(float* x, const float* w, int n, float eps);               
 void kro_mla_step(float* kv_out, float* q_full, const float* kv_a_norm, const float* w_kc, const float* w_vc,
                   const float* rope_cos, const float* rope_sin, int nh, int klr, int nd, int rd, int vhd, float eps, float sm_scale,
                   uint16_t* ckv_cache, uint16_t* kpe_cache, int position, float* v_projected);
-int  kro_sample_greedy(const float* logits, int n);                                                                   /* decode.rs:3718 */
+int  kro_sample_greedy(const float* logits, int n);
+uint64_t kro_xorshift64_next(uint64_t* st);                                                                          /* decode.rs:3556-3561 */
+int  kro_sample_from_logits(float* logits, int vocab, float temperature, int top_k, float top_p, uint64_t* rng_state); /* decode.rs:3718 */                                                                   /* decode.rs:3718 */
 
 /* ---- H: GPU prefill semantics (third-party sglang fused_marlin_moe 0.5.9; parity unpinned) ---- */
 /* python/krasis/gpu_prefill.py:64-239 dataflow: bf16 act x dequant(INT4/8) weights, fp32 accumulate,

@@ -538,6 +538,15 @@ def sample_greedy(logits) -> int:
     return int(lib().kro_sample_greedy(_p(lg), lg.size))
 
 
+def sample_from_logits(logits, temperature, top_k, top_p, rng_state: int):
+    """Returns (token, new_rng_state); the logits copy is scaled in place like the reference."""
+    lg = _c(logits, np.float32).copy()
+    st = C.c_uint64(rng_state)
+    lib().kro_sample_from_logits.restype = C.c_int
+    tok = lib().kro_sample_from_logits(_p(lg), lg.size, C.c_float(temperature), int(top_k), C.c_float(top_p), C.byref(st))
+    return int(tok), int(st.value)
+
+
 def reduce_sum_bf16(inputs: Sequence[np.ndarray]) -> np.ndarray:
     ins = [_c(a, np.uint16) for a in inputs]
     n = ins[0].size

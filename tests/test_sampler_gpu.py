@@ -1,0 +1,56 @@
+"""Sampler (sample_from_logits, decode.rs:3718-3811) and generate_batch on the GPU vs the oracle restatement: same token for every draw."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.test_decode_gpu import build
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.mark.parametrize("temperature,top_k,top_p", [(0.7, 20, 0.9), (1.0, 0, 1.0), (1.3, 5, 0.5), (0.5, 50, 1.0), (2.0, 0, 0.8), (1.0, 1, 1.0)])
+def test_sample_matches_oracle(temperature, top_k, top_p):
+    st, eng, orc, keep, d = build()
+    lg = np.empty(d["V"], F)
+    seed = 0x9E3779B97F4A7C15
+    state = seed
+    tok = 11
+    for step in range(6):
+        st.decode_step(tok, 5 + step, lg.ctypes.data)
+        got = st.sample(temperature, top_k, top_p, rng_seed=seed if step == 0 else 0)
+        ref, state = O.sample_from_logits(lg, temperature, top_k, top_p, state)
+        assert got == ref, (step, got, ref)
+        tok = got
+
+
+def test_sample_ties_break_by_token_id():
+    st, eng, orc, keep, d = build()
+    lg = np.empty(d["V"], F)
+    st.decode_step(3, 5, lg.ctypes.data)
+    # top_k = 1 with temperature: the draw always returns the first of the sorted order = arg max with the lowest id
+    assert st.sample(0.8, 1, 1.0, rng_seed=123) == O.sample_greedy(lg)
+
+
+@pytest.mark.parametrize("temperature,top_k,top_p,penalty", [(0.0, 0, 1.0, 0.0), (0.0, 0, 1.0, 1.5), (0.9, 10, 0.95, 0.0), (0.9, 10, 0.95, 0.7)])
+def test_generate_batch_matches_oracle(temperature, top_k, top_p, penalty):
+    st, eng, orc, keep, d = build(seed=2)
+    seed = 0x1234567
+    toks = st.generate_batch(9, 5, 7, temperature, top_k, top_p, (), penalty, rng_seed=seed)
+    ref, tok, state, seen = [], 9, seed, {9}
+    for i in range(7):
+        lg = orc.step(tok, 5 + i).copy()
+        if penalty != 0.0:
+            for t in seen:
+                lg[t] -= F(penalty)
+        tok, state = O.sample_from_logits(lg, temperature, top_k, top_p, state) if temperature > 0 else (O.sample_greedy(lg), state)
+        seen.add(tok); ref.append(tok)
+    assert toks == ref
+
+
+def test_generate_stop_id_is_last_element():
+    st, eng, orc, keep, d = build(seed=3)
+    free = st.generate_batch(11, 5, 5)
+    d["reset"]()                                                     # same initial KV / recurrent state for the second run
+    stopped = st.generate_batch(11, 5, 5, stop_ids=(free[2],))      # decode.rs:3587-3591: push, then test
+    assert stopped == free[:free.index(free[2]) + 1]
