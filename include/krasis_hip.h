@@ -181,7 +181,13 @@ int kr_decode_set_layer_moe(kr_decode_store* s, int layer, int moe_layer_idx, in
                             int shared_gate_wid);
 int kr_decode_set_layer_dense(kr_decode_store* s, int layer, int gate_wid, int up_wid, int down_wid);              /* decode.rs:2215 */
 int kr_decode_set_rope(kr_decode_store* s, const float* cos_table, const float* sin_table, int half_dim, int max_seq);
-int kr_decode_finalize(kr_decode_store* s);                                                                        /* decode.rs:2471 */
+int kr_decode_finalize(kr_decode_store* s);
+/* element type of the GQA KV caches: KR_KV_FP16 = the reference's CPU-decode cache (decode.rs:4423-4478, default), KR_KV_FP8_E4M3 = the
+ * reference's GPU cache dtype (python/krasis/kv_cache.py:38-135, torch.float8_e4m3fn: RNE, no saturation).  Call before set_decode_state;
+ * kv_k / kv_v buffers of kr_decode_set_state / kr_decode_get_state then hold 1-byte elements. */
+#define KR_KV_FP16 0
+#define KR_KV_FP8_E4M3 1
+int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype);                                                                        /* decode.rs:2471 */
 /* Whole-model prompt pass.  Replaces the reference's GPU prefill (python/krasis/model.py forward_prefill_layer_grouped / server_prefill,
  * layer.py:242-461, attention.py:496-687, linear_attention.py:695-845 -- third-party kernels) AND the GPU->CPU state hand-off
  * (decode_setup.py:232-278): tokens[0..n) (host ints) at positions start_pos.. are run through every layer in chunks; afterwards the

@@ -352,7 +352,7 @@ extern "C" int kr_decode_set_state(kr_decode_store* s, int seq_len, int kv_max_s
     for (size_t i = 0; i < s->layers.size(); i++) {
         DLayer& L = s->layers[i];
         if (L.attn == ATTN_GQA) {
-            const size_t n = (size_t)kv_max_seq * L.nkv * L.hd * 2;
+            const size_t n = (size_t)kv_max_seq * L.nkv * L.hd * (s->kv_fp8 ? 1 : 2);
             if (L.kv_k.ensure(n) || L.kv_v.ensure(n)) return kr_fail(KR_ERR_HIP, "hipMalloc of KV cache failed");
             if (kv_k && kv_k[i]) KR_HIP(hipMemcpy(L.kv_k.p, kv_k[i], n, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_k.p, 0, n));
             if (kv_v && kv_v[i]) KR_HIP(hipMemcpy(L.kv_v.p, kv_v[i], n, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_v.p, 0, n));
@@ -380,6 +380,7 @@ extern "C" int kr_decode_fill_state_synthetic(kr_decode_store* s, int kv_max_seq
         DLayer& L = s->layers[i];
         if (L.attn == ATTN_GQA) {
             const size_t n = (size_t)kv_max_seq * L.nkv * L.hd;
+            if (s->kv_fp8) return kr_fail(KR_ERR_VALUE, "fill_state_synthetic generates the FP16 cache of bench_decode_synthetic (decode.rs:4402-4411); set FP8 caches through set_decode_state");
             if (L.kv_k.ensure(n * 2) || L.kv_v.ensure(n * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc of KV cache failed");
             kr_launch_fill_fp16_kv((uint16_t*)L.kv_k.p, n, seed + i * 4 + 0, s->eng->stream);
             kr_launch_fill_fp16_kv((uint16_t*)L.kv_v.p, n, seed + i * 4 + 1, s->eng->stream);
@@ -405,7 +406,7 @@ extern "C" int kr_decode_get_state(kr_decode_store* s, int layer, uint16_t* kv_k
     KR_HIP(hipStreamSynchronize(s->eng->stream));
     DLayer& L = s->layers[layer];
     if (L.attn == ATTN_GQA) {
-        const size_t n = (size_t)s->kv_max_seq * L.nkv * L.hd * 2;
+        const size_t n = (size_t)s->kv_max_seq * L.nkv * L.hd * (s->kv_fp8 ? 1 : 2);
         if (kv_k) KR_HIP(hipMemcpy(kv_k, L.kv_k.p, n, hipMemcpyDeviceToHost));
         if (kv_v) KR_HIP(hipMemcpy(kv_v, L.kv_v.p, n, hipMemcpyDeviceToHost));
     } else if (L.attn == ATTN_MLA) {
@@ -468,7 +469,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.q_norm = L.q_norm_len ? (const float*)L.q_norm.p : nullptr; a.k_norm = L.k_norm_len ? (const float*)L.k_norm.p : nullptr;
             a.q_norm_per_head = L.q_norm_len == L.nh * L.hd; a.k_norm_per_head = L.k_norm_len == L.nkv * L.hd;
             a.rope_cos = (const float*)s->rope_cos.p; a.rope_sin = (const float*)s->rope_sin.p; a.rope_half = s->rope_half;
-            a.k_cache = (uint16_t*)L.kv_k.p; a.v_cache = (uint16_t*)L.kv_v.p; a.q_out = (float*)s->qbuf.p; a.gate = (float*)s->gatebuf.p;
+            a.k_cache = L.kv_k.p; a.v_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_out = (float*)s->qbuf.p; a.gate = (float*)s->gatebuf.p;
             a.attn_out = (float*)s->attn_out.p; a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.eps = s->eps; a.sm_scale = L.sm_scale;
             PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
             PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
@@ -588,6 +589,16 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
         return KR_OK;
     }
     return enqueue_step(s, st);
+}
+
+// KV element type of the GQA caches: 0 = FP16 (reference CPU decode, decode.rs:4423-4478), 1 = FP8-E4M3 (reference GPU cache, kv_cache.py:38-135).
+// Call before set_decode_state; existing caches are dropped.
+extern "C" int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype) {
+    if (int rc = chk_store(s)) return rc;
+    if (kv_dtype != 0 && kv_dtype != 1) return kr_fail(KR_ERR_VALUE, "kv_dtype %d unknown (0 = FP16, 1 = FP8-E4M3)", kv_dtype);
+    if (s->kv_fp8 != kv_dtype) for (auto& L : s->layers) if (L.attn == ATTN_GQA) { L.kv_k.release(); L.kv_v.release(); }
+    s->kv_fp8 = kv_dtype; s->graph_ok = false;
+    return KR_OK;
 }
 
 extern "C" int kr_decode_set_use_graph(kr_decode_store* s, int enable) {

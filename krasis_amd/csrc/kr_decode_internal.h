@@ -46,6 +46,7 @@ struct kr_decode_store {
     DevBuf hid, res, proj_a, proj_b, qbuf, kbuf, vbuf, zbuf, gbuf, betabuf, gatebuf, latbuf, recur_out, attn_out, logits, gate_val, tok;
     DevBuf dense_gu;  // [gate(K) | up(K)] of the dense MLP; only [0,inter) of each half is ever written, the padding stays 0
     DevBuf hid2, res2, r_counter, argmax_scratch;
+    int kv_fp8 = 0;            // GQA KV element type: 0 FP16 (reference CPU decode), 1 FP8-E4M3 (reference GPU cache dtype)
     bool fuse_router = true;   // hid2/res2: outputs of the fused norm+router launch (its inputs stay readable for every workgroup)
     DevBuf smp_seen, smp_keys, smp_temp, smp_probs, smp_rng; size_t smp_temp_bytes = 0;   // sampler: seen bitmap, sort keys / scratch, probabilities, xorshift64 state
     DevBuf pf_scores;          // kr_decode_prefill: attention scores [chunk*nh rows][context] f32

@@ -14,7 +14,7 @@ struct KrGqaArgs {
     const float *q_in, *k_in, *v_in;
     const float *q_norm, *k_norm; int q_norm_per_head, k_norm_per_head;
     const float *rope_cos, *rope_sin; int rope_half;
-    uint16_t *k_cache, *v_cache;
+    void *k_cache, *v_cache; int kv_fp8;   // FP16 (reference CPU decode) or FP8-E4M3 (reference GPU cache dtype) elements
     float *q_out, *gate, *attn_out;
     int gated, nh, nkv, hd; float eps, sm_scale;
 };

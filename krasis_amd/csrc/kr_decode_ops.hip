@@ -248,8 +248,8 @@ __global__ void __launch_bounds__(256) kr_gqa_prep_kernel(const KrGqaArgs a) {
         if (is_q) a.q_out[(size_t)h * hd + d] = val;
         else {
             const size_t o = (size_t)pos * a.nkv * hd + (size_t)h * hd + d;
-            a.k_cache[o] = __half_as_ushort(__float2half_rn(val));
-            a.v_cache[o] = __half_as_ushort(__float2half_rn(a.v_in[(size_t)h * hd + d]));
+            kr_kv_store(a.k_cache, o, val, a.kv_fp8);
+            kr_kv_store(a.v_cache, o, a.v_in[(size_t)h * hd + d], a.kv_fp8);
         }
     }
 }
@@ -265,9 +265,9 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a) {
     // scores: 8 lanes per position
     const int l = threadIdx.x & 7;
     for (int s = threadIdx.x >> 3; s < seq; s += 32) {
-        const uint16_t* kr = a.k_cache + (size_t)s * kvs + (size_t)kvh * hd;
+        const size_t kb = (size_t)s * kvs + (size_t)kvh * hd;
         float acc = 0.0f;
-        for (int b = 0; b < hd / 8; b++) acc = __builtin_fmaf(qs[b * 8 + l], __half2float(__ushort_as_half(kr[b * 8 + l])), acc);
+        for (int b = 0; b < hd / 8; b++) acc = __builtin_fmaf(qs[b * 8 + l], kr_kv_load(a.k_cache, kb + b * 8 + l, a.kv_fp8), acc);
         acc = kr_hsum8(acc);
         if (l == 0) sc[s] = acc * a.sm_scale;
     }
@@ -299,9 +299,9 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a) {
     __syncthreads();
     const int d = threadIdx.x;
     if (d < hd) {
-        const uint16_t* vc = a.v_cache + (size_t)kvh * hd + d;
+        const size_t vb = (size_t)kvh * hd + d;
         float o = 0.0f;
-        for (int s = 0; s < seq; s++) o = __builtin_fmaf(sc[s], __half2float(__ushort_as_half(vc[(size_t)s * kvs])), o);
+        for (int s = 0; s < seq; s++) o = __builtin_fmaf(sc[s], kr_kv_load(a.v_cache, vb + (size_t)s * kvs, a.kv_fp8), o);
         if (a.gated) { const float gt = a.gate[(size_t)h * hd + d]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
         a.attn_out[(size_t)h * hd + d] = o;
     }

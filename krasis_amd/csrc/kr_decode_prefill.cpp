@@ -76,7 +76,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.q_norm = L.q_norm_len ? (const float*)L.q_norm.p : nullptr; a.k_norm = L.k_norm_len ? (const float*)L.k_norm.p : nullptr;
         a.q_norm_per_head = L.q_norm_len == L.nh * L.hd; a.k_norm_per_head = L.k_norm_len == L.nkv * L.hd;
         a.rope_cos = (const float*)s->rope_cos.p; a.rope_sin = (const float*)s->rope_sin.p; a.rope_half = s->rope_half;
-        a.k_cache = (uint16_t*)L.kv_k.p; a.v_cache = (uint16_t*)L.kv_v.p; a.q_out = B.q; a.gate = B.gate; a.attn_out = B.attn;
+        a.k_cache = L.kv_k.p; a.v_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_out = B.q; a.gate = B.gate; a.attn_out = B.attn;
         a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.pos0 = pos0; a.eps = s->eps; a.sm_scale = L.sm_scale;
         if (s->max_rope_seq > 0 && pos0 + Cc > s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "prompt exceeds the rope table (%d)", s->max_rope_seq);
         const int sc_ld = (pos0 + Cc + 63) & ~63;

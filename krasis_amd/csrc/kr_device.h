@@ -140,3 +140,38 @@ __device__ __forceinline__ void kr_store_chunk(const KrActLds& L, int chunk, con
         p[5] = kr_pack4((q[4] & 255) - 128, (q[5] & 255) - 128, (q[6] & 255) - 128, (q[7] & 255) - 128);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// KV-cache element codecs.  FP16 is the reference's CPU-decode cache (VCVTPS2PH RNE, decode.rs:4464-4478); FP8-E4M3 (OCP "fn": bias 7,
+// no infinities, 0x7F/0xFF = NaN, max 448) is the reference's GPU cache dtype (python/krasis/kv_cache.py:38-135, torch.float8_e4m3fn).
+// f32 -> e4m3 follows torch's conversion: round to nearest even, |x| beyond the largest finite value becomes NaN (no saturation).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t kr_f32_to_e4m3(float f) {
+    const uint32_t b = __float_as_uint(f), sign = (b >> 24) & 0x80u, a = b & 0x7FFFFFFFu;
+    if (a >= 0x43F00000u) return (uint8_t)(sign | 0x7Fu);              // |x| >= 480 (or NaN/inf): NaN, like c10::Float8_e4m3fn
+    if (a < 0x3C800000u) {                                             // |x| < 2^-6: subnormal result, RNE via the magic-add trick
+        const float t = __uint_as_float(a) + __uint_as_float(0x46800000u);   // + 2^14: mantissa LSB == 2^-9
+        return (uint8_t)(sign | ((__float_as_uint(t) - 0x46800000u) & 0xFFu));
+    }
+    uint32_t r = a + 0x7FFFFu + ((a >> 20) & 1u);                      // RNE at bit 20
+    r = (r - 0x3C000000u) >> 20;                                       // rebias 127 -> 7, keep 4+3 bits
+    return (uint8_t)(sign | (r & 0x7Fu));
+}
+__device__ __forceinline__ float kr_e4m3_to_f32(uint8_t x) {
+    const uint32_t m = (uint32_t)(x & 0x7Fu);
+    if (m == 0x7Fu) return __uint_as_float(0x7FC00000u | ((uint32_t)(x & 0x80u) << 24));
+    const float v = __uint_as_float(m << 20) * __uint_as_float(0x7B800000u);   // x 2^120: rebias 7 -> 127, subnormals come out exact
+    return (x & 0x80u) ? -v : v;
+}
+__device__ __forceinline__ float kr_kv_load(const void* base, size_t i, int fp8) {
+    if (fp8) return kr_e4m3_to_f32(reinterpret_cast<const uint8_t*>(base)[i]);
+    const uint16_t h = reinterpret_cast<const uint16_t*>(base)[i];
+    _Float16 hv; __builtin_memcpy(&hv, &h, 2);
+    return (float)hv;
+}
+__device__ __forceinline__ void kr_kv_store(void* base, size_t i, float v, int fp8) {
+    if (fp8) { reinterpret_cast<uint8_t*>(base)[i] = kr_f32_to_e4m3(v); return; }
+    const _Float16 hv = (_Float16)v;                                    // v_cvt_f16_f32: round to nearest even
+    uint16_t h; __builtin_memcpy(&h, &hv, 2);
+    reinterpret_cast<uint16_t*>(base)[i] = h;
+}

@@ -252,8 +252,8 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_prep_kernel(const KrPfmGqaArgs
         if (is_q) a.q_out[(size_t)t * a.nh * hd + (size_t)h * hd + d] = val;
         else {
             const size_t o = (size_t)pos * a.nkv * hd + (size_t)h * hd + d;
-            a.k_cache[o] = __half_as_ushort(__float2half_rn(val));
-            a.v_cache[o] = __half_as_ushort(__float2half_rn(v_in[(size_t)h * hd + d]));
+            kr_kv_store(a.k_cache, o, val, a.kv_fp8);
+            kr_kv_store(a.v_cache, o, v_in[(size_t)h * hd + d], a.kv_fp8);
         }
     }
 }
@@ -287,13 +287,21 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_scores_kernel(const KrPfmGqaAr
         __syncthreads();                          // q staged / previous K tile consumed
         for (int i = tid; i < 32 * (hd / 8); i += 256) {   // 16-byte loads: 8 halves = one b-block of one position
             const int pp = i / (hd / 8), b = i % (hd / 8), pos = pb + pp;
-            u32x4 w = {0, 0, 0, 0};
-            if (pos <= p_max) w = *reinterpret_cast<const u32x4*>(a.k_cache + (size_t)pos * kvs + (size_t)kvh * hd + b * 8);
-            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+            if (a.kv_fp8) {       // 8 bytes = 8 e4m3 values of one b-block
+                u32x2 w = {0, 0};
+                if (pos <= p_max) w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(a.k_cache) + (size_t)pos * kvs + (size_t)kvh * hd + b * 8);
+                const uint32_t ww[2] = {w.x, w.y};
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                kT[(pp * 8 + 2 * j) * PFA_LDB + b] = __half2float(__ushort_as_half((uint16_t)(ww[j] & 0xFFFFu)));
-                kT[(pp * 8 + 2 * j + 1) * PFA_LDB + b] = __half2float(__ushort_as_half((uint16_t)(ww[j] >> 16)));
+                for (int j = 0; j < 8; j++) kT[(pp * 8 + j) * PFA_LDB + b] = kr_e4m3_to_f32((uint8_t)(ww[j >> 2] >> (8 * (j & 3))));
+            } else {
+                u32x4 w = {0, 0, 0, 0};
+                if (pos <= p_max) w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(a.k_cache) + (size_t)pos * kvs + (size_t)kvh * hd + b * 8);
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    kT[(pp * 8 + 2 * j) * PFA_LDB + b] = __half2float(__ushort_as_half((uint16_t)(ww[j] & 0xFFFFu)));
+                    kT[(pp * 8 + 2 * j + 1) * PFA_LDB + b] = __half2float(__ushort_as_half((uint16_t)(ww[j] >> 16)));
+                }
             }
         }
         __syncthreads();
@@ -375,7 +383,7 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a
     float acc[PFA_TT_MAX];
 #pragma unroll
     for (int r = 0; r < PFA_TT_MAX; r++) acc[r] = 0.0f;
-    const uint16_t* vc = a.v_cache + (size_t)kvh * hd + (d < hd ? d : 0);
+    const size_t vcb = (size_t)kvh * hd + (d < hd ? d : 0);
     for (int p0 = 0; p0 <= p_max; p0 += 64) {
         __syncthreads();
         for (int i = threadIdx.x; i < R * 64; i += 256) {
@@ -388,7 +396,7 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a
             for (int pp0 = 0; pp0 < 64; pp0 += 4) {
                 float v[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = __half2float(__ushort_as_half(vc[(size_t)(p0 + pp0 + u) * kvs]));
+                for (int u = 0; u < 4; u++) v[u] = kr_kv_load(a.v_cache, vcb + (size_t)(p0 + pp0 + u) * kvs, a.kv_fp8);
 #pragma unroll
                 for (int r = 0; r < PFA_TT_MAX; r++) {
                     const float4 pr = *reinterpret_cast<const float4*>(&P[r][pp0]);
@@ -401,7 +409,7 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a
         for (int pp0 = 0; pp0 < np; pp0 += 4) {
             float v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = (pp0 + u < np) ? __half2float(__ushort_as_half(vc[(size_t)(p0 + pp0 + u) * kvs])) : 0.0f;
+            for (int u = 0; u < 4; u++) v[u] = (pp0 + u < np) ? kr_kv_load(a.v_cache, vcb + (size_t)(p0 + pp0 + u) * kvs, a.kv_fp8) : 0.0f;
 #pragma unroll
             for (int r = 0; r < PFA_TT_MAX; r++) {
                 if (r < R) {

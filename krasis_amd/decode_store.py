@@ -132,6 +132,10 @@ class CpuDecodeStore:
         self._need()
         check(self._lib.kr_decode_set_rope(self._h, cos_ptr, sin_ptr, half_dim, max_seq))
 
+    def set_kv_dtype(self, fp8_e4m3: bool) -> None:
+        """GQA KV cache element type: FP16 (reference CPU decode, default) or FP8-E4M3 (reference GPU cache, kv_cache.py:38)."""
+        self._need(); check(self._lib.kr_decode_set_kv_dtype(self._h, 1 if fp8_e4m3 else 0))
+
     def finalize_decode(self) -> None:
         self._need()
         check(self._lib.kr_decode_finalize(self._h))

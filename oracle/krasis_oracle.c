@@ -1050,9 +1050,33 @@ void kro_gated_rmsnorm_silu(const float* recur, const float* z, const float* w, 
     }
 }
 
+/* torch.float8_e4m3fn codecs (c10/util/Float8_e4m3fn.h: fp8e4m3fn_from_fp32_value / to_fp32): RNE, |x| >= 480 -> NaN (0x7F), no saturation;
+ * the reference's GPU KV cache dtype (python/krasis/kv_cache.py:38-135) */
+uint8_t kro_f32_to_e4m3(float f) {
+    uint32_t b; memcpy(&b, &f, 4);
+    uint32_t sign = (b >> 24) & 0x80u, a = b & 0x7FFFFFFFu;
+    if (a >= 0x43F00000u) return (uint8_t)(sign | 0x7Fu);
+    if (a < 0x3C800000u) { float x, m; uint32_t mb = 0x46800000u, tb; memcpy(&x, &a, 4); memcpy(&m, &mb, 4); float t = x + m; memcpy(&tb, &t, 4); return (uint8_t)(sign | ((tb - 0x46800000u) & 0xFFu)); }
+    uint32_t r = a + 0x7FFFFu + ((a >> 20) & 1u);
+    r = (r - 0x3C000000u) >> 20;
+    return (uint8_t)(sign | (r & 0x7Fu));
+}
+float kro_e4m3_to_f32(uint8_t x) {
+    uint32_t m = x & 0x7Fu; float v;
+    if (m == 0x7Fu) { uint32_t nb = 0x7FC00000u | ((uint32_t)(x & 0x80u) << 24); memcpy(&v, &nb, 4); return v; }
+    if ((m >> 3) == 0) v = ldexpf((float)(m & 7u), -9);                 /* subnormal: m * 2^-9 */
+    else v = ldexpf(1.0f + (float)(m & 7u) / 8.0f, (int)(m >> 3) - 7);
+    return (x & 0x80u) ? -v : v;
+}
+
+static int g_kv_fp8 = 0;   /* element type used by kro_gqa_step for the caches (uint16 slots hold the byte when FP8) */
+void kro_set_kv_fp8(int on) { g_kv_fp8 = on; }
+static inline float kv_ld(const uint16_t* c, size_t i) { return g_kv_fp8 ? kro_e4m3_to_f32((uint8_t)c[i]) : kro_f16_to_f32(c[i]); }
+static inline uint16_t kv_st(float v) { return g_kv_fp8 ? (uint16_t)kro_f32_to_e4m3(v) : kro_f32_to_f16(v); }
+
 static float dot_f32_f16_lanes(const float* q, const uint16_t* c, int dim) { /* decode.rs:4229-4242 (single accumulator) */
     int hd8 = dim / 8; float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < hd8; b++) for (int j = 0; j < 8; j++) l[j] = fmaf(q[b * 8 + j], kro_f16_to_f32(c[b * 8 + j]), l[j]);
+    for (int b = 0; b < hd8; b++) for (int j = 0; j < 8; j++) l[j] = fmaf(q[b * 8 + j], kv_ld(c, (size_t)(b * 8 + j)), l[j]);
     return hsum8(l);
 }
 
@@ -1079,17 +1103,17 @@ void kro_gqa_step(const float* q_in, float* k, float* v, const float* q_norm, in
     for (int h = 0; h < nh; h++) { float* b = q + h * hd; for (int i = 0; i < d2; i++) { float x1 = b[i], x2 = b[d2 + i]; b[i] = x1 * cs[i] - x2 * sn[i]; b[d2 + i] = x2 * cs[i] + x1 * sn[i]; } }
     for (int h = 0; h < nkv; h++) { float* b = k + h * hd; for (int i = 0; i < d2; i++) { float x1 = b[i], x2 = b[d2 + i]; b[i] = x1 * cs[i] - x2 * sn[i]; b[d2 + i] = x2 * cs[i] + x1 * sn[i]; } }
     int kvs = nkv * hd;
-    for (int i = 0; i < kvs; i++) { k_cache[(size_t)position * kvs + i] = kro_f32_to_f16(k[i]); v_cache[(size_t)position * kvs + i] = kro_f32_to_f16(v[i]); }
+    for (int i = 0; i < kvs; i++) { k_cache[(size_t)position * kvs + i] = kv_st(k[i]); v_cache[(size_t)position * kvs + i] = kv_st(v[i]); }
     int seq = position + 1; int groups = nh / nkv;
     float* sc = (float*)malloc(4 * (size_t)seq);
     for (int h = 0; h < nh; h++) {
         int kvh = h / groups;
-        for (int s = 0; s < seq; s++) sc[s] = dot_f32_f16_lanes(q + h * hd, k_cache + (size_t)s * kvs + kvh * hd, hd) * sm_scale;
+        for (int s = 0; s < seq; s++) sc[s] = dot_f32_f16_lanes(q + h * hd, k_cache + (size_t)s * kvs + kvh * hd, hd) * sm_scale;   /* cache element type: see kv_ld */
         float mx = -INFINITY; for (int s = 0; s < seq; s++) mx = maxf_rust(mx, sc[s]);
         float se = 0.0f; for (int s = 0; s < seq; s++) { sc[s] = expf(sc[s] - mx); se += sc[s]; }
         float inv = 1.0f / se; for (int s = 0; s < seq; s++) sc[s] *= inv;
         float* o = attn_out + h * hd; for (int d = 0; d < hd; d++) o[d] = 0.0f;
-        for (int s = 0; s < seq; s++) { const uint16_t* vv = v_cache + (size_t)s * kvs + kvh * hd; float w = sc[s]; for (int d = 0; d < hd; d++) o[d] = fmaf(w, kro_f16_to_f32(vv[d]), o[d]); }
+        for (int s = 0; s < seq; s++) { const uint16_t* vv = v_cache + (size_t)s * kvs + kvh * hd; float w = sc[s]; for (int d = 0; d < hd; d++) o[d] = fmaf(w, kv_ld(vv, (size_t)d), o[d]); }
     }
     if (gated) for (int i = 0; i < nh * hd; i++) { float sg = 1.0f / (1.0f + expf(-gate[i])); attn_out[i] *= sg; }
     free(q); free(gate); free(sc);

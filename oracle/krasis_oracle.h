@@ -152,6 +152,9 @@ void kro_gqa_step(const float* q_in, float* k, float* v, const float* q_norm, in
                   int k_norm_len, int gated, int nh, int nkv, int hd, float eps, const float* rope_cos,
                   const float* rope_sin, int rope_half, uint16_t* k_cache, uint16_t* v_cache, int max_seq, int position,
                   float sm_scale, float* attn_out);
+uint8_t kro_f32_to_e4m3(float f);   /* torch.float8_e4m3fn conversion (kv_cache.py:38-135 cache dtype) */
+float   kro_e4m3_to_f32(uint8_t x);
+void    kro_set_kv_fp8(int on);     /* kro_gqa_step cache element type: 0 FP16 (default), 1 FP8-E4M3 (one byte per uint16 slot) */
 /* G5 MLA (decode.rs:2993-3252 driver; :4286 dot, :4326 weighted sum, :4508 absorb, :4555 w_vc) */
 void kro_rmsnorm_seq(float* x, const float* w, int n, float eps);                                                     /* decode.rs:3023-3032 */
 void kro_mla_step(float* kv_out, float* q_full, const float* kv_a_norm, const float* w_kc, const float* w_vc,

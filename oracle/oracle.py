@@ -516,6 +516,20 @@ def gqa_step(q_in, k, v, q_norm, k_norm, gated, nh, nkv, hd, eps, rope_cos, rope
     return out, kc, vc
 
 
+def set_kv_fp8(on: bool) -> None:
+    lib().kro_set_kv_fp8(int(on))
+
+
+def f32_to_e4m3(x) -> np.ndarray:
+    x = _c(x, np.float32); L = lib(); L.kro_f32_to_e4m3.restype = C.c_uint8
+    return np.array([L.kro_f32_to_e4m3(C.c_float(float(v))) for v in x.reshape(-1)], np.uint8).reshape(x.shape)
+
+
+def e4m3_to_f32(b) -> np.ndarray:
+    b = _c(b, np.uint8); L = lib(); L.kro_e4m3_to_f32.restype = C.c_float
+    return np.array([L.kro_e4m3_to_f32(int(v)) for v in b.reshape(-1)], np.float32).reshape(b.shape)
+
+
 def rmsnorm_seq(x, w, eps):
     x = _c(x, np.float32).copy()
     lib().kro_rmsnorm_seq(_p(x), _p(_c(w, np.float32)), x.size, C.c_float(eps))
