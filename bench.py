@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--prefill-chunk", type=int, default=0, help="tokens per chunk of the prompt pass (0 = library default)")
+    ap.add_argument("--prefill-depth", type=int, default=0, help="chunks of the prompt pass in flight (0 = library default)")
     ap.add_argument("--prefill-reps", type=int, default=2, help="timed repetitions of the whole-model prompt pass")
     ap.add_argument("--prefill-tokens", type=int, default=8192, help="tokens per prefill chunk for the experts-only prefill side measurement (0 = skip)")
     return ap.parse_args()
@@ -315,6 +316,8 @@ def main():
         prefill = prefill_experts(eng, L, args.prefill_tokens, torch)
         if args.prefill_chunk:
             st.set_prefill_chunk(args.prefill_chunk)
+        if args.prefill_depth:
+            st.set_prefill_depth(args.prefill_depth)
         prefill_full = prefill_model(st, L, args.prefill_tokens, args.prefill_reps, torch)
         prefill_full["chunk"] = args.prefill_chunk or 2048
 

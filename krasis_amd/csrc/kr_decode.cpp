@@ -63,7 +63,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
                       &s->hid2, &s->res2, &s->r_counter, &s->argmax_scratch, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     for (hipEvent_t ev : s->pf_events) (void)hipEventDestroy(ev);
-    if (s->pf_side) { (void)hipStreamSynchronize(s->pf_side); (void)hipStreamDestroy(s->pf_side); }
+    for (hipStream_t ps : s->pf_side) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
     if (s->step_host) (void)hipHostFree(s->step_host);
     delete s;
 }

@@ -154,7 +154,8 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
     const int H = s->hidden;
     if (H % 128) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill needs hidden %% 128 == 0");
     const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : KR_PFM_CHUNK);
-    const int n_chunks = (n_tokens + CH - 1) / CH, n_arenas = n_chunks > 1 ? 2 : 1;
+    const int depth = s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : 2;        // chunks in flight (streams / arenas)
+    const int n_chunks = (n_tokens + CH - 1) / CH, n_arenas = std::min(n_chunks, depth), D = n_arenas;
     const int L = (int)s->layers.size();
 
     // ---- geometry of the widest layer -> scratch sizes (floats per token); nibble sums of every weight the GEMMs will touch
@@ -217,50 +218,56 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
     // [other stream: recurrent / conv state and the KV cache of layer l] -> one event per (parity, layer).  The serial, low-occupancy
     // kernels of one chunk (gated-delta-rule recurrence, softmax sums, router top-k) overlap with the GEMMs and attention passes of
     // its neighbour, which is one layer behind.
-    hipStream_t streams[2] = {st, st};
-    if (n_chunks > 1) {
-        if (!s->pf_side) KR_HIP(hipStreamCreateWithFlags(&s->pf_side, hipStreamNonBlocking));
-        streams[1] = s->pf_side;
-        while ((int)s->pf_events.size() < 2 * L + 2) { hipEvent_t ev; KR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); s->pf_events.push_back(ev); }
-        KR_HIP(hipEventRecord(s->pf_events[2 * L], st));                  // side stream starts after everything already queued on the main one
-        KR_HIP(hipStreamWaitEvent(streams[1], s->pf_events[2 * L], 0));
+    hipStream_t streams[KR_PF_MAX_DEPTH] = {st, st, st, st};
+    const size_t ev_start = (size_t)D * L, ev_end = ev_start + 1;     // + one end event per side stream
+    if (D > 1) {
+        while ((int)s->pf_side.size() < D - 1) { hipStream_t ns; KR_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking)); s->pf_side.push_back(ns); }
+        for (int i = 1; i < D; i++) streams[i] = s->pf_side[i - 1];
+        while (s->pf_events.size() < ev_end + D) { hipEvent_t ev; KR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); s->pf_events.push_back(ev); }
+        KR_HIP(hipEventRecord(s->pf_events[ev_start], st));               // side streams start after everything already queued on the main one
+        for (int i = 1; i < D; i++) KR_HIP(hipStreamWaitEvent(streams[i], s->pf_events[ev_start], 0));
     }
     std::vector<Chunk> chunks(n_chunks);
     for (int c = 0; c < n_chunks; c++) {
         Chunk& cx = chunks[c];
-        cx.set = c & 1; cx.B = carve(cx.set); cx.scores = sc_rows ? (float*)((char*)s->pf_scores.p + (size_t)cx.set * sc_bytes) : nullptr;
+        cx.set = c % D; cx.B = carve(cx.set); cx.scores = sc_rows ? (float*)((char*)s->pf_scores.p + (size_t)cx.set * sc_bytes) : nullptr;
         cx.Cc = std::min(CH, n_tokens - c * CH); cx.pos0 = start_pos + c * CH; cx.tok = (const int*)s->pf_tokens.p + (size_t)c * CH;
         cx.first = true; cx.add_is_emb = true; cx.st = streams[cx.set];
     }
-    // two chunks in flight (one per stream / arena): pairs (2p, 2p+1) are enqueued layer-interleaved; chunk 2p+2 follows chunk 2p on the
-    // same stream, so its arena is free, and it waits layer by layer for chunk 2p+1 -- the pipeline never drains between pairs
-    for (int p0 = 0; p0 < n_chunks; p0 += 2) {
-        const int nb = std::min(2, n_chunks - p0);
+    // D chunks in flight (one per stream / arena): groups of D chunks are enqueued layer-interleaved; chunk c + D follows chunk c on the same
+    // stream, so its arena is free, and it waits layer by layer for chunk c + D - 1 -- the pipeline never drains between groups
+    for (int p0 = 0; p0 < n_chunks; p0 += D) {
+        const int nb = std::min(D, n_chunks - p0);
         for (int d = 0; d < L + nb - 1; d++) {
             for (int j = 0; j < nb; j++) {
                 const int l = d - j, c = p0 + j;
                 if (l < 0 || l >= L) continue;
                 Chunk& cx = chunks[c];
-                if (c > 0) KR_HIP(hipStreamWaitEvent(cx.st, s->pf_events[(size_t)((c - 1) & 1) * L + l], 0));
+                if (c > 0 && D > 1) KR_HIP(hipStreamWaitEvent(cx.st, s->pf_events[(size_t)((c - 1) % D) * L + l], 0));
                 if (int rc = run_layer(s, cx, (size_t)l)) return rc;
-                if (n_chunks > 1) KR_HIP(hipEventRecord(s->pf_events[(size_t)(c & 1) * L + l], cx.st));
+                if (D > 1) KR_HIP(hipEventRecord(s->pf_events[(size_t)(c % D) * L + l], cx.st));
             }
         }
     }
     Chunk& last = chunks[n_chunks - 1];
     run_final(s, last);
-    if (last.st != st) {                                                   // results become visible on the caller's stream
-        KR_HIP(hipEventRecord(s->pf_events[2 * L + 1], last.st));
-        KR_HIP(hipStreamWaitEvent(st, s->pf_events[2 * L + 1], 0));
-    } else if (n_chunks > 1) {
-        KR_HIP(hipEventRecord(s->pf_events[2 * L + 1], streams[1]));
-        KR_HIP(hipStreamWaitEvent(st, s->pf_events[2 * L + 1], 0));
+    for (int i = 1; i < D; i++) {                                          // results become visible on the caller's stream
+        KR_HIP(hipEventRecord(s->pf_events[ev_end + i], streams[i]));
+        KR_HIP(hipStreamWaitEvent(st, s->pf_events[ev_end + i], 0));
     }
     KR_HIP(hipGetLastError());
     if (logits_out) {
         if (is_device_ptr(logits_out)) KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToDevice, st));
         else { KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }
     }
+    return KR_OK;
+}
+
+// tuning hook: chunks in flight (1..4, 0 = default 2)
+extern "C" int kr_decode_set_prefill_depth(kr_decode_store* s, int depth) {
+    if (!s) return kr_fail(KR_ERR_VALUE, "null decode store");
+    if (depth < 0 || depth > KR_PF_MAX_DEPTH) return kr_fail(KR_ERR_VALUE, "prefill depth %d out of range [0, %d]", depth, KR_PF_MAX_DEPTH);
+    s->pf_depth = depth;
     return KR_OK;
 }
 

@@ -741,7 +741,7 @@ int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_
     if (e->cfg.hidden_size % 128 || L.inter % 128) return kr_fail(KR_ERR_VALUE, "prefill path needs dims divisible by 128");
     std::lock_guard<std::mutex> lk(e->mu);
     KR_HIP(hipSetDevice(e->device));
-    kr_engine::PfSet& P = e->pf[set & 1];
+    kr_engine::PfSet& P = e->pf[set % KR_PF_MAX_DEPTH];
     const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
     const bool use_shared = L.shared_present && !routed_only;
     const int SI = L.shared_inter;

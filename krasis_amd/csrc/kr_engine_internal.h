@@ -12,6 +12,7 @@
 #include "kr_kernels.h"
 #include "kr_gguf.h"
 
+#define KR_PF_MAX_DEPTH 4
 int kr_fail(int code, const char* fmt, ...);
 #define KR_HIP(call)                                                                                   \
     do {                                                                                               \
@@ -80,7 +81,7 @@ struct kr_engine {
     bool routing_set = false; int r_scoring = 1, r_norm = 1, r_topk = 0, r_ne = 0, r_hidden = 0;
     DevBuf r_logits, r_ids, r_w, r_x;
     // prefill scratch (kr_moe_prefill)
-    struct PfSet { DevBuf i32, xh, xl, xs, gu, hh, hl, hs, eo, sgu, shh, shl, shs, seo; } pf[2];   // two sets: the prompt pass runs two chunks concurrently
+    struct PfSet { DevBuf i32, xh, xl, xs, gu, hh, hl, hs, eo, sgu, shh, shl, shs, seo; } pf[KR_PF_MAX_DEPTH];   // one set per chunk in flight of the prompt pass
     // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
     bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};
     std::mutex mu;

@@ -176,6 +176,10 @@ class CpuDecodeStore:
         """Tokens per chunk of the prompt pass (0 = default); chunks alternate between two streams."""
         self._need(); check(self._lib.kr_decode_set_prefill_chunk(self._h, chunk))
 
+    def set_prefill_depth(self, depth: int) -> None:
+        """Chunks of the prompt pass in flight (streams / scratch arenas), 1..4; 0 = default."""
+        self._need(); check(self._lib.kr_decode_set_prefill_depth(self._h, depth))
+
     def generate_batch(self, first_token: int, start_pos: int, max_tokens: int, temperature: float = 0.0, top_k: int = 0, top_p: float = 1.0,
                        stop_ids: Sequence[int] = (), presence_penalty: float = 0.0, rng_seed: int = 0) -> List[int]:
         """decode.rs:3525 -- decode loop + sampler on the GPU; `rng_seed` (extra, 0 = wall clock like the reference) makes draws reproducible."""

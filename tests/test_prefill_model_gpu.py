@@ -22,11 +22,12 @@ def _snapshot(st, d):
 
 
 @pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True), dict(wbits=8, with_dense=True)])
-@pytest.mark.parametrize("n_tok,start,chunk", [(1, 5, 0), (3, 5, 0), (9, 0, 0), (20, 7, 0), (20, 7, 6), (23, 3, 1), (17, 0, 8)])
-def test_prefill_equals_sequential_decode(cfg, n_tok, start, chunk):
-    """chunk > 0 forces several chunks: they alternate between two streams / arenas in a (chunk, layer) wavefront."""
+@pytest.mark.parametrize("n_tok,start,chunk,depth", [(1, 5, 0, 0), (3, 5, 0, 0), (9, 0, 0, 0), (20, 7, 0, 0), (20, 7, 6, 0), (23, 3, 1, 0), (17, 0, 8, 0),
+                                                     (23, 3, 2, 3), (23, 3, 1, 4), (20, 7, 6, 1)])
+def test_prefill_equals_sequential_decode(cfg, n_tok, start, chunk, depth):
+    """chunk > 0 forces several chunks: `depth` of them are in flight, one per stream / arena, in a (chunk, layer) wavefront."""
     st, eng, orc, keep, d = build(**cfg)
-    st.set_prefill_chunk(chunk)
+    st.set_prefill_chunk(chunk); st.set_prefill_depth(depth)
     rng = np.random.default_rng(n_tok * 31 + start)
     toks = [int(x) for x in rng.integers(0, d["V"], n_tok)]
     # reference: token-by-token decode from the same initial state
