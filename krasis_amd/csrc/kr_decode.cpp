@@ -61,7 +61,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                            &l.w_kc, &l.w_vc, &l.kv_a_norm, &l.q_a_norm, &l.mla_cos, &l.mla_sin}) b->release();
     for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
-                      &s->hid2, &s->res2, &s->r_counter, &s->argmax_scratch, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
+                      &s->hid2, &s->res2, &s->r_counter, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     for (hipEvent_t ev : s->pf_events) (void)hipEventDestroy(ev);
     for (hipStream_t ps : s->pf_side) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
     if (s->step_host) (void)hipHostFree(s->step_host);
@@ -329,6 +329,12 @@ extern "C" int kr_decode_finalize(kr_decode_store* s) {
         if (L.mlp == MLP_DENSE) dg = maxz(dg, 2 * (size_t)s->weights[L.down_wid]->cols);
     }
     ao = maxz(ao, (size_t)s->hidden);
+    {   // activation images: K = hidden for the norm outputs, K = widest attention output for img_attn
+        const size_t kh = ((size_t)s->hidden + 127) / 128 * 128, ka = (ao + 127) / 128 * 128;
+        if (s->img_in.ensure(kr_act_image_bytes((int)kh)) || s->img_post.ensure(kr_act_image_bytes((int)kh)) || s->img_post_bf16.ensure(kr_act_image_bytes((int)kh)) ||
+            s->img_attn.ensure(kr_act_image_bytes((int)ka)))
+            return kr_fail(KR_ERR_HIP, "hipMalloc of the activation images failed");
+    }
     if (s->proj_a.ensure(maxz(pa, 64) * 4) || s->proj_b.ensure(maxz(pb, 64) * 4) || s->qbuf.ensure(maxz(qb, 64) * 4) || s->kbuf.ensure(maxz(kb, 64) * 4) ||
         s->vbuf.ensure(maxz(vb, 64) * 4) || s->zbuf.ensure(maxz(zb, 64) * 4) || s->recur_out.ensure(maxz(ro, 64) * 4) ||
         s->attn_out.ensure(maxz(ao, 64) * 4) || s->gbuf.ensure(maxz(gb, 64) * 4) || s->betabuf.ensure(maxz(gb, 64) * 4) ||
@@ -435,13 +441,24 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
     const float* res_cur = res;   // where the residual stream currently lives (res, or res2 after a fused norm+router launch)
     for (size_t li = 0; li < s->layers.size(); li++) {
         DLayer& L = s->layers[li];
-        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st));
+        // INT16 activation images: built once by the kernel that produces an activation, copied by every workgroup of the
+        // matvec launch that consumes it (instead of being re-quantised per workgroup).  INT4 consumers only.
+        const bool img_ok = s->use_images && H % 128 == 0;
+        auto is4 = [&](int wid) { return wid >= 0 && s->weights[wid]->ms.bits == 4; };
+        bool in_img = false;
+        if (img_ok) {
+            if (L.attn == ATTN_LA) in_img = is4(L.qkvz_wid) && is4(L.ba_wid);
+            else if (L.attn == ATTN_GQA) in_img = is4(L.q_wid) && is4(L.k_wid) && is4(L.v_wid);
+        }
+        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st,
+                                                     in_img ? s->img_in.p : nullptr));
         first = false; src = from_hidden; res_cur = res;
+        const void* xin = in_img ? (const void*)s->img_in.p : (const void*)hid; const int xin_kind = in_img ? 2 : 1;
         if (L.attn == ATTN_LA) {
             {
                 const KrMatDev mats[2] = {mv(s, L.qkvz_wid), mv(s, L.ba_wid)};
                 float* ys[2] = {(float*)s->proj_a.p, (float*)s->proj_b.p};
-                if (mats[0].bits == mats[1].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 2, hid, 1, st));
+                if (mats[0].bits == mats[1].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 2, xin, xin_kind, st));
                 else { PROF(PK_MATVEC, kr_launch_matvec(mats[0], hid, 1, ys[0], st)); PROF(PK_MATVEC, kr_launch_matvec(mats[1], hid, 1, ys[1], st)); }
             }
             KrLaArgs a{};
@@ -452,16 +469,17 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             PROF(PK_LA_CONV, kr_launch_la_conv(a, st));
             prof_mark(s, PK_LA_RECUR, st);
             if (kr_launch_la_recurrent_gnorm((float*)L.recur_state.p, a.q, a.k, a.v, a.g, a.beta, a.z, (const float*)L.la_norm_w.p, (float*)s->attn_out.p,
-                                             L.nv, L.dk, L.dv, s->eps, st))
+                                             L.nv, L.dk, L.dv, s->eps, st, (img_ok && is4(L.out_wid) && L.dv == 128) ? s->img_attn.p : nullptr))
                 return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
             prof_mark(s, -1, st);
-            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->attn_out.p, 1, hid, st));
+            if (img_ok && is4(L.out_wid) && L.dv == 128) PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->img_attn.p, 2, hid, st));
+            else PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->attn_out.p, 1, hid, st));
         } else if (L.attn == ATTN_GQA) {
             if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
             {
                 const KrMatDev mats[3] = {mv(s, L.q_wid), mv(s, L.k_wid), mv(s, L.v_wid)};
                 float* ys[3] = {(float*)s->proj_a.p, (float*)s->kbuf.p, (float*)s->vbuf.p};
-                if (mats[0].bits == mats[1].bits && mats[0].bits == mats[2].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 3, hid, 1, st));
+                if (mats[0].bits == mats[1].bits && mats[0].bits == mats[2].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 3, xin, xin_kind, st));
                 else for (int i = 0; i < 3; i++) PROF(PK_MATVEC, kr_launch_matvec(mats[i], hid, 1, ys[i], st));
             }
             KrGqaArgs a{};
@@ -471,8 +489,11 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.rope_cos = (const float*)s->rope_cos.p; a.rope_sin = (const float*)s->rope_sin.p; a.rope_half = s->rope_half;
             a.k_cache = L.kv_k.p; a.v_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_out = (float*)s->qbuf.p; a.gate = (float*)s->gatebuf.p;
             a.attn_out = (float*)s->attn_out.p; a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.eps = s->eps; a.sm_scale = L.sm_scale;
+            const bool o_img = img_ok && is4(L.o_wid) && L.hd % 128 == 0 && s->weights[L.o_wid]->cols == L.nh * L.hd;
+            a.img_out = o_img ? s->img_attn.p : nullptr;
             PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
-            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
+            if (o_img) PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->img_attn.p, 2, hid, st));
+            else PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }
         else if (L.attn == ATTN_MLA) {
             if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no MLA cache for layer %zu)", li);
@@ -513,7 +534,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
                                                            (unsigned*)s->r_counter.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p,
                                                            (float*)s->r_w.p, e->r_ne, H, s->topk, s->scoring, s->norm_topk, nullptr, hid, res,
                                                            (const float*)s->norms[L.post_norm]->p, (float*)s->hid2.p, (float*)s->res2.p, s->eps,
-                                                           s->norm_bias_one, st);
+                                                           s->norm_bias_one, st, img_ok ? s->img_post.p : nullptr, img_ok ? s->img_post_bf16.p : nullptr);
                 prof_mark(s, -1, st);
                 if (routed) { act = (const float*)s->hid2.p; res_cur = (const float*)s->res2.p; }
             }
@@ -531,6 +552,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             const bool has_gate = has_shared && L.sg_wid >= 0;
             KrMoeArgs a{};
             a.act = nullptr; a.act_f32 = act; a.shared_decode = 1;
+            if (routed && img_ok) { a.act_img = s->img_post.p; a.act_img_bf16 = s->img_post_bf16.p; }
             a.ids = (const int32_t*)s->r_ids.p; a.wts = (const float*)s->r_w.p;
             a.B = 1; a.topk = k; a.n_slots = k + (has_shared ? 1 : 0); a.H = H; a.I = EL.inter;
             a.w13 = EL.w13.view(); a.w2 = EL.w2.view();
@@ -559,8 +581,11 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.down_wid), s->dense_gu.p, 1, hid, st, KR_ACT_SILU_MUL));
         }
     }
-    PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st));
-    PROF(PK_LM_HEAD, kr_launch_matvec(mv(s, s->lm_head), hid, 1, (float*)s->logits.p, st));
+    const bool lm_img = false;   // the vocabulary projection is wide enough that per-wave tiles beat the cooperative form (measured)
+    PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st,
+                                                 lm_img ? s->img_in.p : nullptr));
+    if (lm_img) PROF(PK_LM_HEAD, kr_launch_matvec(mv(s, s->lm_head), s->img_in.p, 2, (float*)s->logits.p, st));
+    else PROF(PK_LM_HEAD, kr_launch_matvec(mv(s, s->lm_head), hid, 1, (float*)s->logits.p, st));
     PROF(PK_ARGMAX, kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, st));
     KR_HIP(hipGetLastError());
     return KR_OK;

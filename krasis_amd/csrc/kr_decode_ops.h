@@ -17,6 +17,7 @@ struct KrGqaArgs {
     void *k_cache, *v_cache; int kv_fp8;   // FP16 (reference CPU decode) or FP8-E4M3 (reference GPU cache dtype) elements
     float *q_out, *gate, *attn_out;
     int gated, nh, nkv, hd; float eps, sm_scale;
+    void* img_out;   // optional: INT16 image of attn_out for the o-projection launch (hd % 128 == 0)
 };
 
 struct KrMlaArgs {   // decode.rs:2993-3252
@@ -37,10 +38,11 @@ struct KrNormSrc {   // where the value added to the residual comes from (see kr
     const float* emb; const KrStep* step;
     const float* eo; const int32_t* ids; const float* wts; int topk; int has_shared; const float* gate_val; float rsf;
 };
-void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, const float* res_in, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s);
+void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, const float* res_in, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s,
+                                 void* img_out = nullptr);   // img_out: optional INT16 image of the normalised hidden (n % 128 == 0)
 void kr_launch_la_conv(const KrLaArgs& a, hipStream_t s);
 int kr_launch_la_recurrent_gnorm(float* state, const float* q, const float* k, const float* v, const float* g, const float* beta, const float* z,
-                                 const float* w, float* out, int nv, int dk, int dv, float eps, hipStream_t s);
+                                 const float* w, float* out, int nv, int dk, int dv, float eps, hipStream_t s, void* img_out = nullptr);
 void kr_launch_gated_rmsnorm_silu(const float* recur, const float* z, const float* w, float* out, int nv, int dv, float eps, hipStream_t s);
 void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s);
 void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const float* wts, int topk, int has_shared, const float* gate_val,

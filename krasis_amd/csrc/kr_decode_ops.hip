@@ -46,7 +46,7 @@ __global__ void kr_embed_kernel(const float* __restrict__ emb, const KrStep* __r
 // so the embedding copy and the MoE combine need no launch of their own.
 #define KR_NORM_THREADS 1024
 __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(const KrNormSrc src, float* hidden, const float* res_in, float* residual, const float* __restrict__ w,
-                                                                              int n, float eps, int first, int bias_one) {
+                                                                              int n, float eps, int first, int bias_one, void* img_out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* r = sm;                       // [n]
     __shared__ float s_w[32]; __shared__ int s_id[32]; __shared__ float s_sig;
@@ -90,7 +90,12 @@ __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(c
     }
     __syncthreads();
     const float rms = sm[n];
-    for (int i = threadIdx.x; i < n; i += KR_NORM_THREADS) hidden[i] = (r[i] * rms) * (bias_one ? (w[i] + 1.0f) : w[i]);
+    for (int i = threadIdx.x; i < n; i += KR_NORM_THREADS) { const float hv = (r[i] * rms) * (bias_one ? (w[i] + 1.0f) : w[i]); hidden[i] = hv; r[i] = hv; }
+    if (img_out) {   // the INT16 image the next projection launches would otherwise each rebuild (quantize_activation_int16_f32, avx2.rs:274)
+        __syncthreads();
+        const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(img_out), n, false);
+        kr_quant_range_f32<false>(r, 0, n / 8, Lg, false);
+    }
 }
 
 // decode.rs:3815-3903 for kernel_dim == 4; one workgroup per key head.
@@ -158,7 +163,7 @@ template <int DK>
 __global__ void __launch_bounds__(256) kr_la_recurrent_gnorm_kernel(float* __restrict__ state, const float* __restrict__ q, const float* __restrict__ k,
                                                                    const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ beta,
                                                                    const float* __restrict__ z, const float* __restrict__ w, float* __restrict__ out,
-                                                                   int dv, float eps) {
+                                                                   int dv, float eps, void* img_out, int img_k) {
     __shared__ float ks[DK], qs[DK], r[256]; __shared__ float rms_s;
     const int h = blockIdx.x, j = threadIdx.x;
     for (int i = threadIdx.x; i < DK; i += blockDim.x) { ks[i] = k[(size_t)h * DK + i]; qs[i] = q[(size_t)h * DK + i]; }
@@ -193,7 +198,27 @@ __global__ void __launch_bounds__(256) kr_la_recurrent_gnorm_kernel(float* __res
     const size_t o = (size_t)h * dv + j;
     const float normed = (ob * rms_s) * w[o];
     const float zz = z[o];
-    out[o] = (zz * kr_sigmoid_poly5(zz)) * normed;
+    const float ov = (zz * kr_sigmoid_poly5(zz)) * normed;
+    out[o] = ov;
+    if (img_out) {   // dv == 128: this head is exactly one quantization group of the out-projection's input
+        __syncthreads();
+        r[j] = ov;
+        __syncthreads();
+        const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(img_out), img_k, false);
+        if (j < 16) {
+            float v8[8];
+            kr_load8(r, j, v8);
+            float mx = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v8[i]));
+            float scale, inv;
+            kr_group_scale(mx, scale, inv);
+            int q8[8];
+            kr_quant8<false>(v8, inv, q8);
+            kr_store_chunk<false>(Lg, h * 16 + j, q8);
+            if (j == 0) Lg.ascale[h] = scale;
+        }
+    }
 }
 
 // decode.rs:3979 (stand-alone form, kept for the per-op API gated_rmsnorm_silu, decode.rs:1062).  grid nv, dv threads
@@ -304,6 +329,26 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a) {
         for (int s = 0; s < seq; s++) o = __builtin_fmaf(sc[s], kr_kv_load(a.v_cache, vb + (size_t)s * kvs, a.kv_fp8), o);
         if (a.gated) { const float gt = a.gate[(size_t)h * hd + d]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
         a.attn_out[(size_t)h * hd + d] = o;
+        if (a.img_out) qs[d] = o;
+    }
+    if (a.img_out) {   // hd % 128 == 0: the head's output is hd/128 whole quantization groups of the o-projection's input
+        __syncthreads();
+        const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(a.img_out), a.nh * hd, false);
+        const int nch = hd / 8, c = threadIdx.x;
+        if (c < nch) {
+            float v8[8];
+            kr_load8(qs, c, v8);
+            float mx = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v8[i]));
+            float scale, inv;
+            kr_group_scale(mx, scale, inv);
+            int q8[8];
+            kr_quant8<false>(v8, inv, q8);
+            const int gc = h * nch + c;
+            kr_store_chunk<false>(Lg, gc, q8);
+            if ((gc & 15) == 0) Lg.ascale[gc >> 4] = scale;
+        }
     }
 }
 
@@ -370,17 +415,21 @@ __global__ void __launch_bounds__(1024) kr_argmax_kernel(const float* __restrict
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s) {
     hipLaunchKernelGGL(kr_embed_kernel, dim3((H + 255) / 256), dim3(256), 0, s, emb, st, hidden, H);
 }
-void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, const float* res_in, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s) {
-    hipLaunchKernelGGL(kr_fused_add_rmsnorm_kernel, dim3(1), dim3(KR_NORM_THREADS), (size_t)(n + 4) * 4, s, src, hidden, res_in, residual, w, n, eps, first, bias_one);
+void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, const float* res_in, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s,
+                                 void* img_out) {
+    if (n % 128) img_out = nullptr;
+    hipLaunchKernelGGL(kr_fused_add_rmsnorm_kernel, dim3(1), dim3(KR_NORM_THREADS), (size_t)(n + 4) * 4, s, src, hidden, res_in, residual, w, n, eps, first, bias_one, img_out);
 }
 void kr_launch_la_conv(const KrLaArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kr_la_conv_kernel, dim3(a.nk), dim3(256), (size_t)(2 * a.dk + 4) * 4, s, a);
 }
 int kr_launch_la_recurrent_gnorm(float* state, const float* q, const float* k, const float* v, const float* g, const float* beta, const float* z,
-                                 const float* w, float* out, int nv, int dk, int dv, float eps, hipStream_t s) {
+                                 const float* w, float* out, int nv, int dk, int dv, float eps, hipStream_t s, void* img_out) {
     if (dv > 256 || dv % 8 != 0) return 1;
-    if (dk == 128) hipLaunchKernelGGL(kr_la_recurrent_gnorm_kernel<128>, dim3(nv), dim3(dv), 0, s, state, q, k, v, g, beta, z, w, out, dv, eps);
-    else if (dk == 64) hipLaunchKernelGGL(kr_la_recurrent_gnorm_kernel<64>, dim3(nv), dim3(dv), 0, s, state, q, k, v, g, beta, z, w, out, dv, eps);
+    if (dv != 128) img_out = nullptr;
+    const int img_k = nv * dv;
+    if (dk == 128) hipLaunchKernelGGL(kr_la_recurrent_gnorm_kernel<128>, dim3(nv), dim3(dv), 0, s, state, q, k, v, g, beta, z, w, out, dv, eps, img_out, img_k);
+    else if (dk == 64) hipLaunchKernelGGL(kr_la_recurrent_gnorm_kernel<64>, dim3(nv), dim3(dv), 0, s, state, q, k, v, g, beta, z, w, out, dv, eps, img_out, img_k);
     else return 1;
     return 0;
 }

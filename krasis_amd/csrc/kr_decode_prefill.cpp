@@ -80,8 +80,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.pos0 = pos0; a.eps = s->eps; a.sm_scale = L.sm_scale;
         if (s->max_rope_seq > 0 && pos0 + Cc > s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "prompt exceeds the rope table (%d)", s->max_rope_seq);
         const int sc_ld = (pos0 + Cc + 63) & ~63;
-        if (s->pf_scores.ensure((size_t)Cc * L.nh * ((size_t)sc_ld + 1) * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
-        float* scp = (float*)s->pf_scores.p;
+        float* scp = cx.scores;   // this chunk's arena (chunks in flight on other streams have their own)
         if (kr_launch_pfm_gqa(a, Cc, scp, sc_ld, scp + (size_t)Cc * L.nh * sc_ld, st)) return kr_fail(KR_ERR_VALUE, "unsupported GQA geometry for the prompt pass");
         if (oc != L.nh * L.hd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*hd", oc);
         kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);

@@ -175,3 +175,67 @@ __device__ __forceinline__ void kr_kv_store(void* base, size_t i, float v, int f
     uint16_t h; __builtin_memcpy(&h, &hv, 2);
     reinterpret_cast<uint16_t*>(base)[i] = h;
 }
+
+// ---------------------------------------------------------------------------------------------
+// INT16 activation image: carving, and the f32 quantizer shared by every kernel that PRODUCES an image for a later matvec launch
+// (the image can live in LDS or, pre-built by the producer of the activation, in global memory with the identical byte layout).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ KrActLds kr_carve_lds(u32x4* smem, int K, bool want_i8) {
+    KrActLds L;
+    L.planes = smem;
+    L.asum16 = reinterpret_cast<int*>(smem + K / 8);
+    L.ascale = reinterpret_cast<float*>(L.asum16 + K / 16);
+    // keep the INT8 image 16-byte aligned: asum16 (K/16 ints) + ascale (K/128 floats) rounded up
+    const int tail_words = K / 16 + ((K / 128 + 3) & ~3);
+    L.planes8 = want_i8 ? (smem + K / 8 + (tail_words + 3) / 4) : nullptr;
+    return L;
+}
+__host__ __device__ static inline size_t kr_lds_bytes(int K, bool want_i8) {
+    const int tail_words = K / 16 + ((K / 128 + 3) & ~3);
+    size_t b = (size_t)(K / 8) * 16 + (size_t)((tail_words + 3) / 4) * 16;
+    if (want_i8) b += (size_t)(K / 16) * 32;
+    return b;
+}
+
+__device__ __forceinline__ void kr_load8(const uint16_t* x, int c, float (&v)[8]) {
+    const u32x4 r = *reinterpret_cast<const u32x4*>(x + (size_t)c * 8);
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xFFFF0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ void kr_load8(const float* x, int c, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(x + (size_t)c * 8);
+    const float4 b = *reinterpret_cast<const float4*>(x + (size_t)c * 8 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// group max (16 chunks = 16 consecutive lanes) -> scale / inverse scale, avx2.rs:257-258
+__device__ __forceinline__ void kr_group_scale(float mx_local, float& scale, float& inv) {
+    const float mx = kr_red16_max_f32(mx_local);
+    scale = mx > 0.0f ? mx / 32767.0f : 1.0f;
+    inv = mx > 0.0f ? 32767.0f / mx : 0.0f;
+}
+
+
+// quantize_activation_int16_f32 (avx2.rs:274) of chunks [c0, c1) (8 values each; c0, c1 multiples of 16 = whole 128-groups), optionally after
+// rounding to bf16 (decode.rs:3307-3309 feeds bf16(hidden) to the routed experts).  All threads of the workgroup take part (stride blockDim).
+template <bool I8>
+__device__ __forceinline__ void kr_quant_range_f32(const float* x, int c0, int c1, const KrActLds& L, bool round_bf16) {
+    for (int c = c0 + (int)threadIdx.x; c < c1; c += (int)blockDim.x) {
+        float v[8];
+        kr_load8(x, c, v);
+        float mx = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (round_bf16) v[i] = kr_bf16_to_f32(kr_f32_to_bf16(v[i]));
+            mx = fmaxf(mx, fabsf(v[i]));
+        }
+        float scale, inv;
+        kr_group_scale(mx, scale, inv);
+        int q[8];
+        kr_quant8<false>(v, inv, q);
+        kr_store_chunk<I8>(L, c, q);
+        if ((c & 15) == 0) L.ascale[c >> 4] = scale;
+    }
+}

@@ -29,6 +29,12 @@ static inline size_t kr_mat_s_bytes(int K, int N) {
     return (size_t)nt * ngp * 8 * 4;
 }
 
+// bytes of the INT16 activation image of a K-vector for INT4 weights (== kr_lds_bytes(K, false) in kr_device.h)
+static inline size_t kr_act_image_bytes(int K) {
+    const int tail_words = K / 16 + ((K / 128 + 3) & ~3);
+    return (size_t)(K / 8) * 16 + (size_t)((tail_words + 3) / 4) * 16;
+}
+
 // activation transform feeding the down projection
 enum { KR_ACT_SILU_FUSED = 0,  // silu_quantize_int16_avx2 (avx2.rs:2310): poly sigmoid, RNE quant
        KR_ACT_GPTOSS = 1,      // moe.rs:268-287: clamp, gate*sigmoid(alpha*gate)*(up+1), round-half-away quant
@@ -36,6 +42,8 @@ enum { KR_ACT_SILU_FUSED = 0,  // silu_quantize_int16_avx2 (avx2.rs:2310): poly 
 
 struct KrMoeArgs {
     const uint16_t* act;   // bf16 [B,H]
+    const void* act_img;      // optional pre-built INT16 image of the f32 activation (B == 1, INT4 weights): shared slot with decode numerics
+    const void* act_img_bf16; // optional pre-built image of bf16(activation): routed slots
     const float* act_f32;  // decode graph: f32 hidden [B,H]; routed experts see bf16(hidden) (decode.rs:3307), when set `act` is unused
     int shared_decode;     // shared slot follows the decode-store numerics: f32 input quant, fast_silu_mul + f32::round quant (decode.rs:3356-3378)
     const int32_t* ids;    // [B,topk]

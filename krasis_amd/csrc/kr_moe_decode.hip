@@ -16,6 +16,7 @@
 //     _mm256_fmadd_ps(group_f32, w_scale*a_scale, out) in the reference, hence bit-identical.
 #include "kr_device.h"
 #include "kr_kernels.h"
+#include <cstdio>
 
 #define KR_BLOCK 256
 #define KR_WAVES (KR_BLOCK / 64)
@@ -23,43 +24,6 @@
 // ------------------------------------------------------------------------------------------
 // prologues: build the INT16 activation image in LDS (whole workgroup cooperates)
 // ------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ KrActLds kr_carve_lds(u32x4* smem, int K, bool want_i8) {
-    KrActLds L;
-    L.planes = smem;
-    L.asum16 = reinterpret_cast<int*>(smem + K / 8);
-    L.ascale = reinterpret_cast<float*>(L.asum16 + K / 16);
-    // keep the INT8 image 16-byte aligned: asum16 (K/16 ints) + ascale (K/128 floats) rounded up
-    const int tail_words = K / 16 + ((K / 128 + 3) & ~3);
-    L.planes8 = want_i8 ? (smem + K / 8 + (tail_words + 3) / 4) : nullptr;
-    return L;
-}
-static inline size_t kr_lds_bytes(int K, bool want_i8) {
-    const int tail_words = K / 16 + ((K / 128 + 3) & ~3);
-    size_t b = (size_t)(K / 8) * 16 + (size_t)((tail_words + 3) / 4) * 16;
-    if (want_i8) b += (size_t)(K / 16) * 32;
-    return b;
-}
-
-__device__ __forceinline__ void kr_load8(const uint16_t* x, int c, float (&v)[8]) {
-    const u32x4 r = *reinterpret_cast<const u32x4*>(x + (size_t)c * 8);
-    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u);
-    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
-    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xFFFF0000u);
-    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xFFFF0000u);
-}
-__device__ __forceinline__ void kr_load8(const float* x, int c, float (&v)[8]) {
-    const float4 a = *reinterpret_cast<const float4*>(x + (size_t)c * 8);
-    const float4 b = *reinterpret_cast<const float4*>(x + (size_t)c * 8 + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-
-// group max (16 chunks = 16 consecutive lanes) -> scale / inverse scale, avx2.rs:257-258
-__device__ __forceinline__ void kr_group_scale(float mx_local, float& scale, float& inv) {
-    const float mx = kr_red16_max_f32(mx_local);
-    scale = mx > 0.0f ? mx / 32767.0f : 1.0f;
-    inv = mx > 0.0f ? 32767.0f / mx : 0.0f;
-}
 
 // quantize_activation_int16 / _f32 (avx2.rs:234,274): per-128 scale, round half away from zero
 template <typename T, bool I8>
@@ -232,6 +196,74 @@ __device__ __forceinline__ float kr_matvec_tile(KrPre& p, bool preloaded, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// Cooperative tile: the KR_WAVES waves of a workgroup SPLIT THE K RANGE of one 8-column tile.
+//
+// Measured on MI355X (tools/probes/launch_floor.hip, matvec_timing.hip): a dependent launch in a replayed graph costs ~1.55 us and
+// cold HBM loads add almost nothing, but every instruction on a wave's serial path costs ~3.5 ns -- a wave that walks all K/128 groups
+// of its tile executes ~1000 dependent instructions, which IS the kernel's duration.  The integer group sums are order-free, so wave w
+// computes the sums of groups [w*gw, (w+1)*gw) only; (f32(isum), bf16(w_scale)*a_scale) pairs go through LDS and 8 lanes replay the
+// reference's one-fma-per-group chain in group order (avx2.rs:1162-1176): bit-identical, a quarter of the serial path.
+// ------------------------------------------------------------------------------------------
+#define KR_GMAX 8        // groups per wave whose weights are requested up front (K <= 4096 with 4 waves; longer K loops)
+#define KR_NG_MAX 128    // groups per row the exchange buffer holds (K <= 16384)
+struct KrXch { float2 v[8][KR_NG_MAX + 2]; };   // [column][group] = (f32(isum), bf16(w_scale) * a_scale)
+
+template <int BITS> struct KrCo;
+template <> struct KrCo<4> { u32x2 w[KR_GMAX]; uint32_t sc[KR_GMAX]; int g0, g1; };
+template <> struct KrCo<8> { u32x4 w[KR_GMAX]; uint32_t sc[KR_GMAX]; int g0, g1; };
+
+template <int BITS>
+__device__ __forceinline__ void kr_co_fetch(KrCo<BITS>& p, const void* qbase, const uint32_t* sbase, const KrMatDev& m, int tile, int lane, int gb) {
+#pragma unroll
+    for (int u = 0; u < KR_GMAX; u++) {
+        const int g = gb + u;
+        if (g < p.g1) {
+            if constexpr (BITS == 4) p.w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(qbase) + (((size_t)tile * m.ngp + (g >> 1)) * 64 + lane) * 2 + (g & 1));
+            else p.w[u] = kr_ldg_nt(reinterpret_cast<const u32x4*>(qbase) + ((size_t)tile * m.ng + g) * 64 + lane);
+            p.sc[u] = kr_ldg_nt(sbase + ((size_t)tile * m.ngp + (g >> 1)) * 8 + (lane >> 3));
+        }
+    }
+}
+template <int BITS>
+__device__ __forceinline__ void kr_co_preload(KrCo<BITS>& p, const void* qbase, const uint32_t* sbase, const KrMatDev& m, int tile, int lane, int wave) {
+    const int gw = (m.ng + KR_WAVES - 1) / KR_WAVES;
+    p.g0 = wave * gw; p.g1 = p.g0 + gw < m.ng ? p.g0 + gw : m.ng;
+    kr_co_fetch<BITS>(p, qbase, sbase, m, tile, lane, p.g0);
+}
+
+// phase 1 (all waves): this wave's group sums -> LDS.  Call after the activation image is complete (workgroup barrier).
+template <int BITS>
+__device__ __forceinline__ void kr_co_sums(KrCo<BITS>& p, const void* qbase, const uint32_t* sbase, const KrMatDev& m, int tile, const KrActLds& L, KrXch& X, int lane) {
+    const int l8 = lane & 7, col = lane >> 3;
+    for (int gb = p.g0; gb < p.g1; gb += KR_GMAX) {
+        if (gb > p.g0) kr_co_fetch<BITS>(p, qbase, sbase, m, tile, lane, gb);
+#pragma unroll
+        for (int u = 0; u < KR_GMAX; u++) {
+            const int g = gb + u;
+            if (g < p.g1) {
+                int isum;
+                if constexpr (BITS == 4) isum = kr_red8_add_i32(kr_group_i4(p.w[u].x, p.w[u].y, g, l8, L));
+                else isum = kr_red8_add_i32(kr_group_i8(p.w[u], g, l8, L));
+                const uint32_t sbits = (g & 1) ? (p.sc[u] >> 16) : (p.sc[u] & 0xFFFFu);
+                if (l8 == 0) X.v[col][g] = make_float2((float)isum, __uint_as_float(sbits << 16) * L.ascale[g]);   // comb: avx2.rs:1171
+            }
+        }
+    }
+}
+// phase 2 (after a workgroup barrier): lane c < 8 of wave 0 folds column c in group order
+__device__ __forceinline__ float kr_co_chain(const KrXch& X, int ng, int col, bool fused) {
+    float acc = 0.0f;
+    int g = 0;
+    for (; g + 4 <= ng; g += 4) {
+        const float2 t0 = X.v[col][g], t1 = X.v[col][g + 1], t2 = X.v[col][g + 2], t3 = X.v[col][g + 3];
+        if (fused) { acc = __builtin_fmaf(t0.x, t0.y, acc); acc = __builtin_fmaf(t1.x, t1.y, acc); acc = __builtin_fmaf(t2.x, t2.y, acc); acc = __builtin_fmaf(t3.x, t3.y, acc); }
+        else { acc = acc + t0.x * t0.y; acc = acc + t1.x * t1.y; acc = acc + t2.x * t2.y; acc = acc + t3.x * t3.y; }      // avx2.rs:1201
+    }
+    for (; g < ng; g++) { const float2 t = X.v[col][g]; acc = fused ? __builtin_fmaf(t.x, t.y, acc) : (acc + t.x * t.y); }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
 
@@ -257,6 +289,13 @@ __device__ __forceinline__ KrSlot kr_resolve_slot(const KrMoeArgs& a, int b, int
     return r;
 }
 
+// pre-built activation image (global memory, byte layout == the LDS image for INT4 weights) -> LDS
+__device__ __forceinline__ void kr_image_copy(const void* img, int K, u32x4* smem) {
+    const int n16 = (int)(kr_lds_bytes(K, false) / 16);
+    const u32x4* src = reinterpret_cast<const u32x4*>(img);
+    for (int i = threadIdx.x; i < n16; i += KR_BLOCK) smem[i] = src[i];
+}
+
 // stage 1: gu[b][slot][0..2I) = W13 . q(act[b])      grid = (tile groups, n_slots, B)
 // The shared slot may carry one extra tile: the shared expert's sigmoid-gate row (decode.rs:3379-3390), N = 1.
 template <int BITS>
@@ -276,7 +315,10 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a,
     if (first < ntiles) kr_preload<BITS>(pre, sl.q13, sl.s13, m, first, lane, 0);
     else if (gate_wave) kr_preload<4>(pre, a.sgate.q, a.sgate.s, a.sgate, 0, lane, 0);
     const KrActLds L = kr_carve_lds(kr_smem, a.H, BITS == 8);
-    if (a.act_f32) kr_prologue_quant_f32<BITS == 8>(a.act_f32 + (size_t)b * a.H, a.H, L, !(sl.shared && a.shared_decode));
+    const bool round_bf16 = !(sl.shared && a.shared_decode);
+    const void* img = BITS == 4 && a.B == 1 ? (round_bf16 ? a.act_img_bf16 : a.act_img) : nullptr;   // pre-built by the router launch
+    if (img) kr_image_copy(img, a.H, kr_smem);
+    else if (a.act_f32) kr_prologue_quant_f32<BITS == 8>(a.act_f32 + (size_t)b * a.H, a.H, L, round_bf16);
     else kr_prologue_quant<uint16_t, BITS == 8>(a.act + (size_t)b * a.H, a.H, L);
     __syncthreads();
     float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
@@ -369,6 +411,49 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_matvec_kernel(const KrMultiMat mm
     }
 }
 
+// Cooperative form of the multi-matrix matvec (used for mid-sized projections fed by a pre-built activation image): the waves of a
+// workgroup split the K range of a tile (see "Cooperative tile" above); a workgroup walks `tpb` consecutive tiles.
+// x_kind: 0 bf16 vector, 1 f32 vector, 2 pre-built INT16 image in global memory (INT4 weights only)
+template <typename T, int BITS>
+__global__ void __launch_bounds__(KR_BLOCK) kr_matvec_coop_kernel(const KrMultiMat mm, const T* x, int tpb, int act_mode, int x_kind) {
+    __shared__ KrXch X[2];
+    const int total = mm.tile_end[mm.n - 1], gt0 = blockIdx.x * tpb;
+    if (gt0 >= total) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int mi = 0;
+    while (mi + 1 < mm.n && gt0 >= mm.tile_end[mi]) mi++;
+    KrCo<BITS> cur;
+    kr_co_preload<BITS>(cur, mm.m[mi].q, mm.m[mi].s, mm.m[mi], gt0 - (mi ? mm.tile_end[mi - 1] : 0), lane, wave);
+    const int K = mm.m[0].ng * 128;
+    const KrActLds L = kr_carve_lds(kr_smem, K, BITS == 8);
+    if (x_kind == 2) kr_image_copy(x, K, kr_smem);
+    else if (act_mode == KR_ACT_SILU_MUL) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(reinterpret_cast<const float*>(x), K, 0.0f, 0.0f, L);
+    else kr_prologue_quant<T, BITS == 8>(x, K, L);
+    __syncthreads();
+    for (int t = 0; t < tpb; t++) {
+        const int gt = gt0 + t;
+        if (gt >= total) break;
+        const KrMatDev& m = mm.m[mi];
+        const int tile = gt - (mi ? mm.tile_end[mi - 1] : 0);
+        int mn = mi;
+        KrCo<BITS> nxt;
+        const bool more = t + 1 < tpb && gt + 1 < total;
+        if (more) {   // the next tile's weights are requested before this tile's sums are formed
+            while (mn + 1 < mm.n && gt + 1 >= mm.tile_end[mn]) mn++;
+            kr_co_preload<BITS>(nxt, mm.m[mn].q, mm.m[mn].s, mm.m[mn], gt + 1 - (mn ? mm.tile_end[mn - 1] : 0), lane, wave);
+        }
+        KrXch& Xc = X[t & 1];
+        kr_co_sums<BITS>(cur, m.q, m.s, m, tile, L, Xc, lane);
+        __syncthreads();      // one barrier per tile: the exchange buffer alternates, so the chain of tile t overlaps the sums of tile t + 1
+        if (wave == (t & (KR_WAVES - 1)) && lane < 8) {
+            const int col = tile * 8 + lane;
+            const float acc = kr_co_chain(Xc, m.ng, lane, col < m.n_fma);
+            if (col < m.N) mm.y[mi][col] = acc;
+        }
+        if (more) { cur = nxt; mi = mn; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
@@ -423,14 +508,22 @@ void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st) {
 }
 
 void kr_launch_multi_matvec(const KrMatDev* mats, float* const* ys, int n, const void* x, int x_is_f32, hipStream_t st, int act_mode) {
+    // x_is_f32: 0 bf16 vector, 1 f32 vector, 2 pre-built INT16 image (kr_act_image_bytes(K) bytes; INT4 weights) -> cooperative kernel
     KrMultiMat mm{};
     mm.n = n;
     int total = 0;
     for (int i = 0; i < n; i++) { mm.m[i] = mats[i]; mm.y[i] = ys[i]; total += (mats[i].N + 7) / 8; mm.tile_end[i] = total; }
-    const int tpw = kr_pick_tpw(mats[0].K, total);
-    dim3 grid((total + KR_WAVES * tpw - 1) / (KR_WAVES * tpw));
     const int bits = mats[0].bits;
     const size_t lds = kr_lds_bytes(mats[0].ng * 128, bits == 8);
+    if (x_is_f32 == 2) {
+        if (bits != 4) { fprintf(stderr, "kr_launch_multi_matvec: pre-built image with INT8 weights\n"); return; }
+        int tpb = 1;
+        while ((total + tpb - 1) / tpb > 3072) tpb *= 2;
+        hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 4>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, mm, (const float*)x, tpb, act_mode, 2);
+        return;
+    }
+    const int tpw = kr_pick_tpw(mats[0].K, total);
+    dim3 grid((total + KR_WAVES * tpw - 1) / (KR_WAVES * tpw));
     if (x_is_f32) {
         if (bits == 4) hipLaunchKernelGGL((kr_matvec_kernel<float, 4>), grid, dim3(KR_BLOCK), lds, st, mm, (const float*)x, tpw, act_mode);
         else hipLaunchKernelGGL((kr_matvec_kernel<float, 8>), grid, dim3(KR_BLOCK), lds, st, mm, (const float*)x, tpw, act_mode);

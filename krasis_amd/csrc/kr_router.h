@@ -12,4 +12,4 @@ void kr_launch_route_select(const float* logits, const float* esc, int32_t* ids,
 int kr_launch_route_fused_decode(const void* gate_cm, int gate_bf16, const float* bias, float* logits, unsigned* counter, const float* esc,
                                  int32_t* ids, float* w, int E, int H, int topk, int scoring, int norm_topk, const float* x,
                                  const float* hid_in, const float* res_in, const float* norm_w, float* hid_out, float* res_out, float eps,
-                                 int bias_one, hipStream_t st);
+                                 int bias_one, hipStream_t st, void* img_f32 = nullptr, void* img_bf16 = nullptr);

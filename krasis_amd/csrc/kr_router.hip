@@ -364,6 +364,7 @@ struct KrRouteFusedArgs {
     KrRouteSelArgs sel;
     const float* x;            // normalised hidden (norm_w == nullptr), else unused
     const float *hid_in, *res_in, *norm_w; float *hid_out, *res_out; float eps; int bias_one;   // folded fused_add_rmsnorm (decode.rs:1199)
+    void *img_f32, *img_bf16;  // optional INT16 images of the normalised hidden for the expert launches (f32 quant: shared expert; bf16-rounded: routed)
     int H;
 };
 
@@ -401,7 +402,29 @@ __global__ void __launch_bounds__(256) kr_route_fused_decode_kernel(const KrRout
         for (int i = t; i < H; i += 256) {
             const float v = (r[i] * rms) * (a.bias_one ? (a.norm_w[i] + 1.0f) : a.norm_w[i]);
             xs[(i & 15) * ld + (i >> 4)] = v;
+            r[i] = v;
             if (blockIdx.x == 0) a.hid_out[i] = v;
+        }
+        if (a.img_f32) {   // every workgroup holds the normalised vector: (image, 128-group) pairs are dealt round-robin, 16 lanes each
+            __syncthreads();
+            const int ng = H / 128;
+            const KrActLds Lf = kr_carve_lds(reinterpret_cast<u32x4*>(a.img_f32), H, false), Lb = kr_carve_lds(reinterpret_cast<u32x4*>(a.img_bf16), H, false);
+            for (int u = blockIdx.x * 16 + (t >> 4); u < 2 * ng; u += gridDim.x * 16) {
+                const int g = u >> 1, c = g * 16 + (t & 15);
+                const bool rb = u & 1;
+                float v8[8];
+                kr_load8(r, c, v8);
+                float mx = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) { if (rb) v8[i] = kr_bf16_to_f32(kr_f32_to_bf16(v8[i])); mx = fmaxf(mx, fabsf(v8[i])); }
+                float scale, inv;
+                kr_group_scale(mx, scale, inv);
+                int q8[8];
+                kr_quant8<false>(v8, inv, q8);
+                const KrActLds& Lg = rb ? Lb : Lf;
+                kr_store_chunk<false>(Lg, c, q8);
+                if ((c & 15) == 0) Lg.ascale[c >> 4] = scale;
+            }
         }
     } else {
         for (int i = t; i < H; i += 256) xs[(i & 15) * ld + (i >> 4)] = a.x[i];
@@ -500,8 +523,9 @@ void kr_launch_route_select(const float* logits, const float* esc, int32_t* ids,
 int kr_launch_route_fused_decode(const void* gate_cm, int gate_bf16, const float* bias, float* logits, unsigned* counter, const float* esc,
                                  int32_t* ids, float* w, int E, int H, int topk, int scoring, int norm_topk, const float* x,
                                  const float* hid_in, const float* res_in, const float* norm_w, float* hid_out, float* res_out, float eps,
-                                 int bias_one, hipStream_t st) {
+                                 int bias_one, hipStream_t st, void* img_f32, void* img_bf16) {
     KrRouteFusedArgs a{};
+    a.img_f32 = (norm_w && img_f32 && img_bf16) ? img_f32 : nullptr; a.img_bf16 = a.img_f32 ? img_bf16 : nullptr;
     a.gate_cm = gate_cm; a.bias = bias; a.logits = logits; a.counter = counter;
     a.sel = KrRouteSelArgs{logits, esc, ids, w, E, topk, scoring, norm_topk, 1 /* KR_ROUTE_RULE_DECODE */, 0};
     a.x = x; a.hid_in = hid_in; a.res_in = res_in; a.norm_w = norm_w; a.hid_out = hid_out; a.res_out = res_out; a.eps = eps; a.bias_one = bias_one; a.H = H;
