@@ -596,6 +596,11 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
     if (s->kv_max_seq > 0 && pos >= s->kv_max_seq) return kr_fail(KR_ERR_VALUE, "position %d >= kv_max_seq %d", pos, s->kv_max_seq);
     if (s->max_rope_seq > 0 && pos >= s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "position %d >= rope table length %d", pos, s->max_rope_seq);
     s->step_host->token = token; s->step_host->pos = pos;
+    for (const DLayer& L : s->layers)            // outside capture: the attention kernel's LDS window (scores + one stage of cache rows)
+        if (L.hd > 0 && L.q_wid >= 0) {
+            const int pr = kr_gqa_attn_prepare(s->kv_max_seq, L.hd, s->kv_fp8);
+            if (pr) return kr_fail(pr == -1 ? KR_ERR_VALUE : KR_ERR_HIP, "GQA decode attention: kv_max_seq %d with head_dim %d does not fit the 160 KiB LDS window", s->kv_max_seq, L.hd);
+        }
     KR_HIP(hipMemcpyAsync(s->step_dev.p, s->step_host, sizeof(KrStep), hipMemcpyHostToDevice, st));
     if (s->use_graph) {
         if (!s->graph_ok) {

@@ -20,6 +20,8 @@ struct KrGqaArgs {
     void* img_out;   // optional: INT16 image of attn_out for the o-projection launch (hd % 128 == 0)
 };
 
+int kr_gqa_attn_prepare(int max_seq, int hd, int fp8);   // 0, -1 (scores + stage exceed 160 KiB of LDS), -2 (HIP refused)
+
 struct KrMlaArgs {   // decode.rs:2993-3252
     const KrStep* step;
     const float* kv_out;      // kv_a_proj output [klr + rd]

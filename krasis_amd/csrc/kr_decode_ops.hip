@@ -253,8 +253,15 @@ __global__ void __launch_bounds__(256) kr_gqa_prep_kernel(const KrGqaArgs a) {
     const float* nw = is_q ? a.q_norm : a.k_norm;
     if (nw) {
         if (d == 0) {
-            float ss = 0.0f;
-            for (int i = 0; i < hd; i++) ss += x[i] * x[i];
+            float ss = 0.0f; int i = 0;
+            for (; i + 32 <= hd; i += 32) {      // 32 LDS values in flight, then the scalar chain in element order
+                float v[32];
+#pragma unroll
+                for (int u = 0; u < 32; u++) { v[u] = x[i + u]; v[u] = v[u] * v[u]; }
+#pragma unroll
+                for (int u = 0; u < 32; u++) ss += v[u];
+            }
+            for (; i < hd; i++) ss += x[i] * x[i];
             rms_s = 1.0f / sqrtf(ss / (float)hd + a.eps);
         }
         __syncthreads();
@@ -279,34 +286,94 @@ __global__ void __launch_bounds__(256) kr_gqa_prep_kernel(const KrGqaArgs a) {
     }
 }
 
-// decode.rs:4194.  grid nh; 256 threads; dynamic LDS = (seq_len + 8) floats.
-__global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a) {
+// decode.rs:4194.  grid nh; 256 threads; dynamic LDS = (max_seq + 8) floats of scores + one stage of KR_GQA_ROWS cache rows.
+//
+// Both passes over the cache (q.k scores, then the p.v chain) are latency problems: 16 workgroups, and every output is a
+// sequential fma chain in the reference's order.  The rows are therefore staged: all 256 threads fetch KR_GQA_ROWS rows of the
+// head's K (then V) slice with 16-byte loads (up to 16 in flight per lane), the next stage's loads are issued before the current
+// stage is consumed from LDS, and the chains read 2-byte (FP16) / 1-byte (E4M3) elements from LDS.  One HBM/L2 latency per 128
+// positions instead of one per element.
+#define KR_GQA_ROWS 128
+#define KR_GQA_NL 16      // 16-byte loads per thread per stage at hd 256 / FP16 (fewer for smaller rows)
+template <bool FP8> __device__ __forceinline__ float kr_stage_elem(const unsigned char* row, int i) {
+    if (FP8) return kr_e4m3_to_f32(row[i]);
+    _Float16 hv; __builtin_memcpy(&hv, row + 2 * i, 2);
+    return (float)hv;
+}
+template <bool FP8>
+__global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int max_seq) {
     extern __shared__ __attribute__((aligned(16))) float sc[];
     __shared__ float qs[256]; __shared__ float red[8];
-    const int h = blockIdx.x, hd = a.hd, kvs = a.nkv * hd, seq = a.step->pos + 1;
+    const int h = blockIdx.x, hd = a.hd, kvs = a.nkv * hd, seq = a.step->pos + 1, t = threadIdx.x;
     const int kvh = h / (a.nh / a.nkv);
-    if (threadIdx.x < hd) qs[threadIdx.x] = a.q_out[(size_t)h * hd + threadIdx.x];
+    constexpr int esz = FP8 ? 1 : 2;
+    const int row_bytes = hd * esz, pitch = row_bytes + 16, cpr = row_bytes >> 4;      // 16-byte chunks per row
+    const int nl = (KR_GQA_ROWS * cpr + 255) >> 8;                                      // loads per thread per stage (<= KR_GQA_NL)
+    unsigned char* stage = reinterpret_cast<unsigned char*>(sc) + ((((size_t)max_seq + 8) * 4 + 15) & ~(size_t)15);
+    if (t < hd) qs[t] = a.q_out[(size_t)h * hd + t];
+    // chunk c = t + 256 i of a stage: row c / cpr, 16-byte column c % cpr
+    int crow[KR_GQA_NL], ccol[KR_GQA_NL];
+#pragma unroll
+    for (int i = 0; i < KR_GQA_NL; i++) { const int c = t + 256 * i; crow[i] = c / cpr; ccol[i] = (c % cpr) << 4; }
+    u32x4 rg[KR_GQA_NL];
+    auto issue = [&](const unsigned char* base, int s0) {
+#pragma unroll
+        for (int i = 0; i < KR_GQA_NL; i++) {
+            if (i < nl) {
+                const int sp = s0 + crow[i];
+                rg[i] = (crow[i] < KR_GQA_ROWS && sp < seq) ? *reinterpret_cast<const u32x4*>(base + (size_t)sp * kvs * esz + ccol[i]) : u32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < KR_GQA_NL; i++)
+            if (i < nl && crow[i] < KR_GQA_ROWS) *reinterpret_cast<u32x4*>(stage + crow[i] * pitch + ccol[i]) = rg[i];
+    };
+    const unsigned char* kbase = reinterpret_cast<const unsigned char*>(a.k_cache) + (size_t)kvh * hd * esz;
+    const unsigned char* vbase = reinterpret_cast<const unsigned char*>(a.v_cache) + (size_t)kvh * hd * esz;
+    const int nst = (seq + KR_GQA_ROWS - 1) / KR_GQA_ROWS;
+    // ---- scores: 8 lanes per position, lane l owns elements b*8 + l (the AVX2 lane), ascending b, then the 8-lane hsum
+    const int l = t & 7, g = t >> 3, nb = hd >> 3;
+    issue(kbase, 0);
     __syncthreads();
-    // scores: 8 lanes per position
-    const int l = threadIdx.x & 7;
-    for (int s = threadIdx.x >> 3; s < seq; s += 32) {
-        const size_t kb = (size_t)s * kvs + (size_t)kvh * hd;
-        float acc = 0.0f;
-        for (int b = 0; b < hd / 8; b++) acc = __builtin_fmaf(qs[b * 8 + l], kr_kv_load(a.k_cache, kb + b * 8 + l, a.kv_fp8), acc);
-        acc = kr_hsum8(acc);
-        if (l == 0) sc[s] = acc * a.sm_scale;
+    float qr[32];                                // the lane's 32 query elements (hd <= 256)
+#pragma unroll
+    for (int b = 0; b < 32; b++) qr[b] = b < nb ? qs[b * 8 + l] : 0.0f;
+    for (int st = 0; st < nst; st++) {
+        if (st) __syncthreads();                 // the previous stage's readers are done
+        commit();
+        if (st + 1 < nst) issue(kbase, (st + 1) * KR_GQA_ROWS); else issue(vbase, 0);   // V stage 0 rides under the softmax
+        __syncthreads();
+        const int s0 = st * KR_GQA_ROWS;
+#pragma unroll 1
+        for (int r = g; r < KR_GQA_ROWS; r += 32) {
+            const int sp = s0 + r;
+            if (sp >= seq) break;
+            const unsigned char* row = stage + r * pitch;
+            float acc = 0.0f;
+            for (int b = 0; b < nb; b += 16) {   // 16 LDS reads in flight, then the lane's chain (nb is uniform: scalar branches)
+                float kk[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) kk[u] = kr_stage_elem<FP8>(row, min(b + u, nb - 1) * 8 + l);
+#pragma unroll
+                for (int u = 0; u < 16; u++) if (b + u < nb) acc = __builtin_fmaf(qr[b + u], kk[u], acc);
+            }
+            acc = kr_hsum8(acc);
+            if (l == 0) sc[sp] = acc * a.sm_scale;
+        }
     }
     __syncthreads();
     float mx = -__builtin_inff();
-    for (int s = threadIdx.x; s < seq; s += 256) mx = fmaxf(mx, sc[s]);
+    for (int s = t; s < seq; s += 256) mx = fmaxf(mx, sc[s]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    if ((t & 63) == 0) red[t >> 6] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    for (int s = threadIdx.x; s < seq; s += 256) sc[s] = kr_expf(sc[s] - mx);
+    for (int s = t; s < seq; s += 256) sc[s] = kr_expf(sc[s] - mx);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (t == 0) {
         float se = 0.0f; int s = 0;
         for (; s + 8 <= seq; s += 8) {
             float v[8];
@@ -320,13 +387,28 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a) {
     }
     __syncthreads();
     const float inv = red[4];
-    for (int s = threadIdx.x; s < seq; s += 256) sc[s] *= inv;
-    __syncthreads();
-    const int d = threadIdx.x;
+    for (int s = t; s < seq; s += 256) sc[s] *= inv;
+    // ---- p.v: thread d owns output d, one fma per position in ascending order
+    float o = 0.0f;
+    for (int st = 0; st < nst; st++) {
+        __syncthreads();                         // previous stage consumed; the scaled scores are visible
+        commit();
+        if (st + 1 < nst) issue(vbase, (st + 1) * KR_GQA_ROWS);
+        __syncthreads();
+        if (t < hd) {
+            const int s0 = st * KR_GQA_ROWS, n = min(KR_GQA_ROWS, seq - s0);
+            const unsigned char* col = stage;
+            for (int r = 0; r < n; r += 16) {    // n <= 128 and r % 16 == 0: rows r..r+15 are inside the stage
+                float vv[16], pp[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { vv[u] = kr_stage_elem<FP8>(col + (r + u) * pitch, t); pp[u] = sc[s0 + r + u]; }
+#pragma unroll
+                for (int u = 0; u < 16; u++) if (r + u < n) o = __builtin_fmaf(pp[u], vv[u], o);
+            }
+        }
+    }
+    const int d = t;
     if (d < hd) {
-        const size_t vb = (size_t)kvh * hd + d;
-        float o = 0.0f;
-        for (int s = 0; s < seq; s++) o = __builtin_fmaf(sc[s], kr_kv_load(a.v_cache, vb + (size_t)s * kvs, a.kv_fp8), o);
         if (a.gated) { const float gt = a.gate[(size_t)h * hd + d]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
         a.attn_out[(size_t)h * hd + d] = o;
         if (a.img_out) qs[d] = o;
@@ -436,9 +518,27 @@ int kr_launch_la_recurrent_gnorm(float* state, const float* q, const float* k, c
 void kr_launch_gated_rmsnorm_silu(const float* recur, const float* z, const float* w, float* out, int nv, int dv, float eps, hipStream_t s) {
     hipLaunchKernelGGL(kr_gated_rmsnorm_silu_kernel, dim3(nv), dim3(256), 0, s, recur, z, w, out, dv, eps);
 }
+static size_t kr_gqa_attn_lds(int max_seq, int hd, int fp8) {
+    return ((((size_t)max_seq + 8) * 4 + 15) & ~(size_t)15) + (size_t)KR_GQA_ROWS * ((size_t)hd * (fp8 ? 1 : 2) + 16);
+}
+// Raises the kernel's dynamic-LDS window (gfx950: 160 KiB per workgroup).  Called outside graph capture, before the first launch.
+int kr_gqa_attn_prepare(int max_seq, int hd, int fp8) {
+    const size_t lds = kr_gqa_attn_lds(max_seq, hd, fp8);
+    if (lds > 160 * 1024) return -1;
+    static size_t lds_set[2] = {0, 0};
+    if (lds > lds_set[fp8 ? 1 : 0]) {
+        const hipError_t e = fp8 ? hipFuncSetAttribute((const void*)kr_gqa_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                 : hipFuncSetAttribute((const void*)kr_gqa_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -2;
+        lds_set[fp8 ? 1 : 0] = lds;
+    }
+    return 0;
+}
 void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
     hipLaunchKernelGGL(kr_gqa_prep_kernel, dim3(a.nh + a.nkv), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(kr_gqa_attn_kernel, dim3(a.nh), dim3(256), (size_t)(max_seq + 8) * 4, s, a);
+    const size_t lds = kr_gqa_attn_lds(max_seq, a.hd, a.kv_fp8);
+    if (a.kv_fp8) hipLaunchKernelGGL(kr_gqa_attn_kernel<true>, dim3(a.nh), dim3(256), lds, s, a, max_seq);
+    else hipLaunchKernelGGL(kr_gqa_attn_kernel<false>, dim3(a.nh), dim3(256), lds, s, a, max_seq);
 }
 void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const float* wts, int topk, int has_shared, const float* gate_val,
                                   float rsf, float* hidden, int H, hipStream_t s) {

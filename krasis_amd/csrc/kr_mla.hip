@@ -145,7 +145,15 @@ __global__ void __launch_bounds__(512) kr_mla_attn_kernel(const KrMlaArgs a) {
     for (int j = t; j < a.klr; j += 512) {
         const uint16_t* ck = a.ckv_cache + j;
         float o = 0.0f;
-        for (int s = 0; s < seq; s++) o = __builtin_fmaf(sc[s], kr_h2f(ck[(size_t)s * a.klr]), o);
+        int s = 0;
+        for (; s + 16 <= seq; s += 16) {      // 16 independent cache loads in flight, then the dependent fmas in position order
+            float vv[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) vv[u] = kr_h2f(ck[(size_t)(s + u) * a.klr]);
+#pragma unroll
+            for (int u = 0; u < 16; u++) o = __builtin_fmaf(sc[s + u], vv[u], o);
+        }
+        for (; s < seq; s++) o = __builtin_fmaf(sc[s], kr_h2f(ck[(size_t)s * a.klr]), o);
         a.attn_lat[(size_t)h * a.klr + j] = o;
     }
 }

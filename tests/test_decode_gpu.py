@@ -15,13 +15,12 @@ def _ptr(a):
     return a.ctypes.data
 
 
-def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4):
+def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64):
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     rng = np.random.default_rng(seed)
     H, V, E, k, I, SI = 256, 512, 16, 4, 128, 128
     nk, nv, dk, dv = 2, 4, 128, 128
-    nh, nkv, hd, d2 = 4, 2, 64, 8
-    kv_max = 32
+    nh, nkv, d2 = 4, 2, 8
     kinds = ["la", "gqa", "la"] + (["gqa"] if with_dense else [])
     nL = len(kinds)
     emb = ((rng.random((V, H)) - 0.5) * 0.2).astype(F)
@@ -119,6 +118,19 @@ def test_decode_step_bit_exact(cfg, graph):
             kc = np.empty((d["kv_max"], d["nkv"] * d["hd"]), np.uint16); vc = np.empty_like(kc)
             st.get_decode_state(li, kc, vc, None, None)
             assert np.array_equal(kc, L["kv_k"]) and np.array_equal(vc, L["kv_v"])
+
+
+@pytest.mark.parametrize("hd", [64, 128])
+def test_decode_step_long_positions_bit_exact(hd):
+    """positions past one / two 128-row stages of the attention kernel's K / V staging (decode.rs:4194 order kept across stages)"""
+    st, eng, orc, keep, d = build(seed=5, kv_max=300, hd=hd)
+    tok = 11
+    for pos in [126, 127, 128, 129, 255, 256, 257, 299]:
+        logits = np.empty(d["V"], F)
+        st.decode_step(tok, pos, logits.ctypes.data)
+        ref = orc.step(tok, pos)
+        assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (pos, float(np.max(np.abs(logits - ref))))
+        tok = O.sample_greedy(ref)
 
 
 def test_generate_batch_greedy_matches_oracle():

@@ -24,10 +24,10 @@ def test_e4m3_codecs_match_torch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("graph", [True, False])
-def test_decode_step_fp8_kv_bit_exact(graph):
+@pytest.mark.parametrize("graph,kv_max,positions", [(True, 32, [5, 6, 7]), (False, 32, [5, 6, 7]), (True, 300, [127, 128, 129, 257, 299])])
+def test_decode_step_fp8_kv_bit_exact(graph, kv_max, positions):
     from tests.test_decode_gpu import build
-    st, eng, orc, keep, d = build()
+    st, eng, orc, keep, d = build(kv_max=kv_max)
     st.set_kv_dtype(True); O.set_kv_fp8(True)
     try:
         rng = np.random.default_rng(5)
@@ -43,7 +43,7 @@ def test_decode_step_fp8_kv_bit_exact(graph):
                             [ptr(x) if x is not None else 0 for x in d["state"]["conv"]], [ptr(x) if x is not None else 0 for x in d["state"]["recur"]])
         st.set_use_graph(graph)
         tok = 7
-        for step, pos in enumerate([5, 6, 7]):
+        for step, pos in enumerate(positions):
             logits = np.empty(d["V"], F)
             st.decode_step(tok, pos, logits.ctypes.data)
             ref = orc.step(tok, pos)
