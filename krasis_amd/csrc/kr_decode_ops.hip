@@ -23,6 +23,13 @@ __device__ __forceinline__ float kr_sumsq_chain8(const float* x, int n, int l) {
     float acc = 0.0f;
     const int nb = n / 8;
     int b = 0;
+    for (; b + 32 <= nb; b += 32) {          // 32 LDS values in flight per lane, then the lane's fma chain
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++) v[u] = x[(b + u) * 8 + l];
+#pragma unroll
+        for (int u = 0; u < 32; u++) acc = __builtin_fmaf(v[u], v[u], acc);
+    }
     for (; b + 8 <= nb; b += 8) {
         float v[8];
 #pragma unroll
@@ -49,36 +56,64 @@ __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(c
                                                                               int n, float eps, int first, int bias_one, void* img_out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* r = sm;                       // [n]
-    __shared__ float s_w[32]; __shared__ int s_id[32]; __shared__ float s_sig;
-    if (src.mode == 2) {
-        if (threadIdx.x < src.topk) { s_w[threadIdx.x] = src.wts[threadIdx.x]; s_id[threadIdx.x] = src.ids[threadIdx.x]; }
-        if (threadIdx.x == 32) s_sig = (src.has_shared && src.gate_val) ? 1.0f / (1.0f + kr_expf(-src.gate_val[0])) : 1.0f;
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < n; i += KR_NORM_THREADS) {
-        float hv;
-        if (src.mode == 0) hv = hidden[i];
-        else if (src.mode == 1) hv = src.emb[(size_t)src.step->token * n + i];
-        else {
-            // MoE epilogue: sum_i w_i * eo_i in routing order (moe.rs:661-667), *rsf, + shared * sigmoid(gate)
-            float acc = 0.0f;
-            for (int s0 = 0; s0 < src.topk; s0 += 8) {
-                float e[8];
+    if (src.mode == 2 && src.topk <= 16) {
+        // MoE epilogue: sum_i w_i * eo_i in routing order (moe.rs:661-667), *rsf, + shared * sigmoid(gate).  Every load of the
+        // thread (slot rows, weights, ids, residual) is issued before the first use: one memory latency for the whole gather.
+        for (int i0 = threadIdx.x; i0 < n; i0 += 2 * KR_NORM_THREADS) {
+            const int i1 = i0 + KR_NORM_THREADS; const bool two = i1 < n;
+            float e0[16], e1[16], wv[16]; int idv[16];
 #pragma unroll
-                for (int u = 0; u < 8; u++) e[u] = (s0 + u < src.topk) ? src.eo[(size_t)(s0 + u) * n + i] : 0.0f;
-#pragma unroll
-                for (int u = 0; u < 8; u++) if (s0 + u < src.topk && s_id[s0 + u] >= 0) acc += s_w[s0 + u] * e[u];
+            for (int u = 0; u < 16; u++) if (u < src.topk) {
+                e0[u] = src.eo[(size_t)u * n + i0]; if (two) e1[u] = src.eo[(size_t)u * n + i1];
+                wv[u] = src.wts[u]; idv[u] = src.ids[u];
             }
-            if (src.rsf != 1.0f) acc *= src.rsf;
+            float sh0 = 0.0f, sh1 = 0.0f, gv = 0.0f;
+            if (src.has_shared) { sh0 = src.eo[(size_t)src.topk * n + i0]; if (two) sh1 = src.eo[(size_t)src.topk * n + i1]; if (src.gate_val) gv = src.gate_val[0]; }
+            const float r0 = first ? 0.0f : res_in[i0], r1 = (first || !two) ? 0.0f : res_in[i1];
+            const float sig = (src.has_shared && src.gate_val) ? 1.0f / (1.0f + kr_expf(-gv)) : 1.0f;
+            float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; u++) if (u < src.topk && idv[u] >= 0) { a0 += wv[u] * e0[u]; if (two) a1 += wv[u] * e1[u]; }
+            if (src.rsf != 1.0f) { a0 *= src.rsf; a1 *= src.rsf; }
             if (src.has_shared) {
-                float sh = src.eo[(size_t)src.topk * n + i];
-                if (src.gate_val) sh *= s_sig;
-                acc = acc + sh;
+                if (src.gate_val) { sh0 *= sig; sh1 *= sig; }
+                a0 = a0 + sh0; a1 = a1 + sh1;
             }
-            hv = acc;
+            const float v0 = first ? a0 : (a0 + r0);
+            r[i0] = v0; residual[i0] = v0;
+            if (two) { const float v1 = first ? a1 : (a1 + r1); r[i1] = v1; residual[i1] = v1; }
         }
-        const float v = first ? hv : (hv + res_in[i]);
-        r[i] = v; residual[i] = v;
+    } else {
+        __shared__ float s_w[32]; __shared__ int s_id[32]; __shared__ float s_sig;
+        if (src.mode == 2) {
+            if (threadIdx.x < src.topk) { s_w[threadIdx.x] = src.wts[threadIdx.x]; s_id[threadIdx.x] = src.ids[threadIdx.x]; }
+            if (threadIdx.x == 32) s_sig = (src.has_shared && src.gate_val) ? 1.0f / (1.0f + kr_expf(-src.gate_val[0])) : 1.0f;
+            __syncthreads();
+        }
+        for (int i = threadIdx.x; i < n; i += KR_NORM_THREADS) {
+            float hv;
+            if (src.mode == 0) hv = hidden[i];
+            else if (src.mode == 1) hv = src.emb[(size_t)src.step->token * n + i];
+            else {
+                float acc = 0.0f;
+                for (int s0 = 0; s0 < src.topk; s0 += 8) {
+                    float e[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) e[u] = (s0 + u < src.topk) ? src.eo[(size_t)(s0 + u) * n + i] : 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (s0 + u < src.topk && s_id[s0 + u] >= 0) acc += s_w[s0 + u] * e[u];
+                }
+                if (src.rsf != 1.0f) acc *= src.rsf;
+                if (src.has_shared) {
+                    float sh = src.eo[(size_t)src.topk * n + i];
+                    if (src.gate_val) sh *= s_sig;
+                    acc = acc + sh;
+                }
+                hv = acc;
+            }
+            const float v = first ? hv : (hv + res_in[i]);
+            r[i] = v; residual[i] = v;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 8) {

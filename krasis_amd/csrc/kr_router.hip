@@ -376,13 +376,45 @@ __global__ void __launch_bounds__(256) kr_route_fused_decode_kernel(const KrRout
     float* xs = sm;                  // [16][ld] chain-major copy of x
     float* r = sm + 16 * ld;         // [H + 4] residual sum (norm fold) -- reused as selection scratch by the last workgroup
     const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63;
+    const int eb = blockIdx.x * 4 + wave;  // block of 4 experts
     KR_STAMP(0);
+    // the wave's gate rows do not depend on the hidden vector: the first KR_GPF 16-byte chunks per lane are in flight while the norm runs
+    constexpr int KR_GPF = 16;
+    const int ncg = GATE_BF16 ? H / 128 : H / 64;
+    const u32x4* gp = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)eb * ncg * 64 + lane;
+    u32x4 gw[KR_GPF];
+    if (eb * 4 < E) {
+#pragma unroll
+        for (int u = 0; u < KR_GPF; u++) if (u < ncg) gw[u] = kr_ldg_nt(gp + (size_t)u * 64);
+    }
     if (a.norm_w) {
-        for (int i = t; i < H; i += 256) { const float v = a.hid_in[i] + a.res_in[i]; r[i] = v; if (blockIdx.x == 0) a.res_out[i] = v; }
+        if ((H & 1023) == 0) {   // float4 loads, all in flight before the first add
+            const float4* h4 = reinterpret_cast<const float4*>(a.hid_in); const float4* r4 = reinterpret_cast<const float4*>(a.res_in);
+            for (int i0 = 0; i0 < H / 4; i0 += 1024) {
+                float4 hv[4], rv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (i0 + u * 256 < H / 4) { hv[u] = h4[i0 + u * 256 + t]; rv[u] = r4[i0 + u * 256 + t]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (i0 + u * 256 < H / 4) {
+                    const float4 v = {hv[u].x + rv[u].x, hv[u].y + rv[u].y, hv[u].z + rv[u].z, hv[u].w + rv[u].w};
+                    reinterpret_cast<float4*>(r)[i0 + u * 256 + t] = v;
+                    if (blockIdx.x == 0) reinterpret_cast<float4*>(a.res_out)[i0 + u * 256 + t] = v;
+                }
+            }
+        } else
+            for (int i = t; i < H; i += 256) { const float v = a.hid_in[i] + a.res_in[i]; r[i] = v; if (blockIdx.x == 0) a.res_out[i] = v; }
         __syncthreads();
         if (t < 8) {
             float ss = 0.0f;
             const int nb = H / 8; int b = 0;
+            for (; b + 32 <= nb; b += 32) {      // 32 LDS values in flight per lane, then the lane's fma chain
+                float v[32];
+#pragma unroll
+                for (int u = 0; u < 32; u++) v[u] = r[(b + u) * 8 + t];
+#pragma unroll
+                for (int u = 0; u < 32; u++) ss = __builtin_fmaf(v[u], v[u], ss);
+            }
             for (; b + 8 <= nb; b += 8) {
                 float v[8];
 #pragma unroll
@@ -431,16 +463,24 @@ __global__ void __launch_bounds__(256) kr_route_fused_decode_kernel(const KrRout
     }
     __syncthreads();
     KR_STAMP(1);
-    const int wave = t >> 6, lane = t & 63;
-    const int eb = blockIdx.x * 4 + wave;  // block of 4 experts
     if (eb * 4 < E) {
         const int j = lane & 15;
         float acc = 0.0f;
         const float* xj = xs + j * ld;
         if (GATE_BF16) {
-            const int nc = H / 128;
-            const u32x4* g = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)eb * nc * 64 + lane;
-            for (int c0 = 0; c0 < nc; c0 += 4) {
+            const int nc = ncg;
+            const u32x4* g = gp;
+#pragma unroll
+            for (int u = 0; u < KR_GPF; u++) if (u < nc) {
+                const float* xx = xj + u * 8;
+                const uint32_t ww[4] = {gw[u].x, gw[u].y, gw[u].z, gw[u].w};
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    acc = __builtin_fmaf(__uint_as_float(ww[p] << 16), xx[2 * p], acc);
+                    acc = __builtin_fmaf(__uint_as_float(ww[p] & 0xFFFF0000u), xx[2 * p + 1], acc);
+                }
+            }
+            for (int c0 = KR_GPF; c0 < nc; c0 += 4) {
                 u32x4 w[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) if (c0 + u < nc) w[u] = kr_ldg_nt(g + (size_t)(c0 + u) * 64);
@@ -456,9 +496,17 @@ __global__ void __launch_bounds__(256) kr_route_fused_decode_kernel(const KrRout
                 }
             }
         } else {
-            const int nc = H / 64;
-            const u32x4* g = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)eb * nc * 64 + lane;
-            for (int c0 = 0; c0 < nc; c0 += 8) {
+            const int nc = ncg;
+            const u32x4* g = gp;
+#pragma unroll
+            for (int u = 0; u < KR_GPF; u++) if (u < nc) {
+                const float* xx = xj + u * 4;
+                acc = __builtin_fmaf(__uint_as_float(gw[u].x), xx[0], acc);
+                acc = __builtin_fmaf(__uint_as_float(gw[u].y), xx[1], acc);
+                acc = __builtin_fmaf(__uint_as_float(gw[u].z), xx[2], acc);
+                acc = __builtin_fmaf(__uint_as_float(gw[u].w), xx[3], acc);
+            }
+            for (int c0 = KR_GPF; c0 < nc; c0 += 8) {
                 u32x4 w[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) if (c0 + u < nc) w[u] = kr_ldg_nt(g + (size_t)(c0 + u) * 64);
