@@ -466,12 +466,21 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.conv_w = (const float*)L.conv_w.p; a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale;
             a.q = (float*)s->qbuf.p; a.k = (float*)s->kbuf.p; a.v = (float*)s->vbuf.p; a.z = (float*)s->zbuf.p; a.g = (float*)s->gbuf.p; a.beta = (float*)s->betabuf.p;
             a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
-            PROF(PK_LA_CONV, kr_launch_la_conv(a, st));
-            prof_mark(s, PK_LA_RECUR, st);
-            if (kr_launch_la_recurrent_gnorm((float*)L.recur_state.p, a.q, a.k, a.v, a.g, a.beta, a.z, (const float*)L.la_norm_w.p, (float*)s->attn_out.p,
-                                             L.nv, L.dk, L.dv, s->eps, st, (img_ok && is4(L.out_wid) && L.dv == 128) ? s->img_attn.p : nullptr))
-                return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
-            prof_mark(s, -1, st);
+            void* la_img = (img_ok && is4(L.out_wid) && L.dv == 128) ? s->img_attn.p : nullptr;
+            const int nt_la = a.hr * L.dv;
+            const bool la_fused = s->fuse_la && nt_la <= 256 && nt_la % 64 == 0 && (L.dv == 128 || L.dv == 64) && L.nv == L.nk * a.hr && (L.dk == 128 || L.dk == 64);
+            if (la_fused) {
+                prof_mark(s, PK_LA_RECUR, st);
+                (void)kr_launch_la_step(a, (float*)L.recur_state.p, (const float*)L.la_norm_w.p, (float*)s->attn_out.p, s->eps, st, la_img);
+                prof_mark(s, -1, st);
+            } else {
+                PROF(PK_LA_CONV, kr_launch_la_conv(a, st));
+                prof_mark(s, PK_LA_RECUR, st);
+                if (kr_launch_la_recurrent_gnorm((float*)L.recur_state.p, a.q, a.k, a.v, a.g, a.beta, a.z, (const float*)L.la_norm_w.p, (float*)s->attn_out.p,
+                                                 L.nv, L.dk, L.dv, s->eps, st, la_img))
+                    return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
+                prof_mark(s, -1, st);
+            }
             if (img_ok && is4(L.out_wid) && L.dv == 128) PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->img_attn.p, 2, hid, st));
             else PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->attn_out.p, 1, hid, st));
         } else if (L.attn == ATTN_GQA) {

@@ -256,6 +256,122 @@ __global__ void __launch_bounds__(256) kr_la_recurrent_gnorm_kernel(float* __res
     }
 }
 
+// Linear-attention decode step in ONE launch: conv1d + SiLU + gates + L2 norms (decode.rs:3815-3945), gated delta-rule
+// recurrence (decode.rs:1293) and the head's gated RMSNorm (decode.rs:3979).  One workgroup per KEY head, hr*dv threads: thread
+// (r, j) owns state column j of value head kh*hr + r.  A key head's conv channels (its q / k rows and the v rows of its hr value
+// heads) are read and shifted by this workgroup only, so the in-place conv-state update needs no cross-workgroup ordering.
+// The thread's whole state column (DK values) is requested before anything else and stays in registers for both passes: the
+// conv / gate / norm work runs under that one memory latency, and the second pass re-reads nothing.
+template <int DK, int DV>
+__global__ void __launch_bounds__(256) kr_la_step_kernel(const KrLaArgs a, float* __restrict__ state, const float* __restrict__ w, float* __restrict__ out,
+                                                        float eps, void* img_out, int img_k) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int dv = DV;       // compile-time row pitch: the column's 2 * DK loads / stores use immediate offsets from a few bases
+    const int kh = blockIdx.x, hr = a.hr, t = threadIdx.x, nt = hr * dv;
+    float* qc = sm; float* kc = qc + DK; float* vs = kc + DK; float* rr = vs + nt;
+    float* nrm = rr + nt; float* ge = nrm + 2; float* bt = ge + hr; float* rms = bt + hr;
+    const int r = t / dv, j = t - r * dv, vh = kh * hr + r;
+    // buffer addressing: descriptor = this key head's hr state slices (workgroup-uniform), voffset = the thread's column, rows by
+    // immediate offset (8 rows of DV floats per 4 KiB window) + a scalar window offset -- no per-row address registers
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(state + (size_t)kh * hr * DK * dv, 0, hr * DK * dv * 4, 0x00020000);
+    const int voff = (r * DK * dv + j) * 4;
+    constexpr int RW = 4096 / (dv * 4);     // rows per immediate-offset window
+    float c[DK];
+#pragma unroll
+    for (int u = 0; u < DK; u++)
+        c[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, voff + (u % RW) * dv * 4, (u / RW) * 4096, 0));
+    const int group_dim = 2 * DK + 2 * nt, key_dim = a.nk * DK;
+    const float* src = a.qkvz + (size_t)kh * group_dim;
+    const size_t o = (size_t)vh * dv + j;
+    const float zz = src[2 * DK + nt + t], wn = w[o];
+    // ---- conv1d (kernel 4) + SiLU; channel c of this key head's group: q [0,DK), k [DK,2DK), v [2DK, 2DK + hr*dv)
+    const int nch = 2 * DK + nt;
+    auto chan = [&](int cc) { return cc < DK ? kh * DK + cc : (cc < 2 * DK ? key_dim + kh * DK + (cc - DK) : 2 * key_dim + kh * nt + (cc - 2 * DK)); };
+    auto put = [&](int cc, float co) { if (cc < DK) qc[cc] = co; else if (cc < 2 * DK) kc[cc - DK] = co; else vs[cc - 2 * DK] = co; };
+    for (int c0 = t; c0 < nch; c0 += 2 * nt) {
+        const int c1 = c0 + nt; const bool two = c1 < nch;
+        const int ch0 = chan(c0), ch1 = two ? chan(c1) : ch0;
+        float4* cs0 = reinterpret_cast<float4*>(a.conv_state) + ch0; float4* cs1 = reinterpret_cast<float4*>(a.conv_state) + ch1;
+        const float4 s0 = *cs0, w0 = reinterpret_cast<const float4*>(a.conv_w)[ch0]; const float x0 = src[c0];
+        float4 s1 = s0, w1 = w0; float x1 = 0.0f;
+        if (two) { s1 = *cs1; w1 = reinterpret_cast<const float4*>(a.conv_w)[ch1]; x1 = src[c1]; }
+        *cs0 = float4{s0.y, s0.z, s0.w, x0};
+        float co = s0.y * w0.x + s0.z * w0.y + s0.w * w0.z + x0 * w0.w;
+        put(c0, co * kr_sigmoid_poly5(co));      // fast_silu_avx2 (conv_dim % 8 == 0)
+        if (two) {
+            *cs1 = float4{s1.y, s1.z, s1.w, x1};
+            co = s1.y * w1.x + s1.z * w1.y + s1.w * w1.z + x1 * w1.w;
+            put(c1, co * kr_sigmoid_poly5(co));
+        }
+    }
+    if (t < hr) {   // gates (decode.rs:3891-3901)
+        const int vg = kh * hr + t;
+        const float b_raw = a.ba[kh * 2 * hr + t], a_p = a.ba[kh * 2 * hr + hr + t];
+        bt[t] = 1.0f / (1.0f + kr_expf(-b_raw));
+        const float ap_dt = a_p + a.dt_bias[vg];
+        const float softplus = ap_dt > 20.0f ? ap_dt : kr_logf(1.0f + kr_expf(ap_dt));
+        const float g = -(kr_expf(a.a_log[vg])) * softplus;
+        ge[t] = kr_expf(g);
+    }
+    __syncthreads();
+    if (t < 16) {   // L2 norms: lanes 0-7 -> q, lanes 8-15 -> k (decode.rs:3909-3945)
+        const int which = t >> 3, l = t & 7;
+        const float ss = kr_sumsq_chain8(which ? kc : qc, DK, l);
+        if (l == 0) nrm[which] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+    }
+    __syncthreads();
+    {
+        const float inv_q = nrm[0] * a.scale, inv_k = nrm[1] * 1.0f;
+        for (int i = t; i < DK; i += nt) { qc[i] = qc[i] * inv_q; kc[i] = kc[i] * inv_k; }
+    }
+    __syncthreads();
+    // ---- recurrence: kv[j] = sum_i fma(S[i][j]*e^g, k[i]); delta = (v - kv) * beta; S' = fma(k, delta, S*e^g); o = sum_i fma(S', q)
+    // k and q are uniform across the workgroup: each wave keeps them in two registers per vector (lane l holds element l and
+    // 64 + l) and broadcasts element u with v_readlane, so the two fma chains read no LDS and only the state column occupies VGPRs
+    const float g_exp = ge[r], beta_h = bt[r];
+    const int ln = t & 63;
+    const float kr0 = kc[ln], qr0 = qc[ln], kr1 = DK > 64 ? kc[64 + ln] : 0.0f, qr1 = DK > 64 ? qc[64 + ln] : 0.0f;
+    auto bcast = [](float v, int u) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), u)); };
+    float kv = 0.0f;
+#pragma unroll
+    for (int u = 0; u < DK; u++) { c[u] = c[u] * g_exp; kv = __builtin_fmaf(c[u], bcast(u < 64 ? kr0 : kr1, u & 63), kv); }
+    const float delta = (vs[t] - kv) * beta_h;
+    float ob = 0.0f;
+#pragma unroll
+    for (int u = 0; u < DK; u++) {
+        const float sn = __builtin_fmaf(bcast(u < 64 ? kr0 : kr1, u & 63), delta, c[u]);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sn), srd, voff + (u % RW) * dv * 4, (u / RW) * 4096, 2 /* nt */);
+        ob = __builtin_fmaf(sn, bcast(u < 64 ? qr0 : qr1, u & 63), ob);
+    }
+    rr[t] = ob;
+    __syncthreads();
+    if (t < 8 * hr) { const int hh = t >> 3, l = t & 7; const float ss = kr_sumsq_chain8(rr + hh * dv, dv, l); if (l == 0) rms[hh] = 1.0f / sqrtf(ss / (float)dv + eps); }
+    __syncthreads();
+    const float normed = (ob * rms[r]) * wn;
+    const float ov = (zz * kr_sigmoid_poly5(zz)) * normed;
+    out[o] = ov;
+    if (img_out) {   // dv == 128: each value head is exactly one quantization group of the out-projection's input
+        __syncthreads();
+        rr[t] = ov;
+        __syncthreads();
+        const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(img_out), img_k, false);
+        if (t < 16 * hr) {
+            const int hh = t >> 4, jj = t & 15, vg = kh * hr + hh;
+            float v8[8];
+            kr_load8(rr + hh * dv, jj, v8);
+            float mx = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v8[i]));
+            float scale, inv;
+            kr_group_scale(mx, scale, inv);
+            int q8[8];
+            kr_quant8<false>(v8, inv, q8);
+            kr_store_chunk<false>(Lg, vg * 16 + jj, q8);
+            if (jj == 0) Lg.ascale[vg] = scale;
+        }
+    }
+}
+
 // decode.rs:3979 (stand-alone form, kept for the per-op API gated_rmsnorm_silu, decode.rs:1062).  grid nv, dv threads
 __global__ void __launch_bounds__(256) kr_gated_rmsnorm_silu_kernel(const float* __restrict__ recur, const float* __restrict__ z,
                                                                    const float* __restrict__ w, float* __restrict__ out, int dv, float eps) {
@@ -548,6 +664,18 @@ int kr_launch_la_recurrent_gnorm(float* state, const float* q, const float* k, c
     if (dk == 128) hipLaunchKernelGGL(kr_la_recurrent_gnorm_kernel<128>, dim3(nv), dim3(dv), 0, s, state, q, k, v, g, beta, z, w, out, dv, eps, img_out, img_k);
     else if (dk == 64) hipLaunchKernelGGL(kr_la_recurrent_gnorm_kernel<64>, dim3(nv), dim3(dv), 0, s, state, q, k, v, g, beta, z, w, out, dv, eps, img_out, img_k);
     else return 1;
+    return 0;
+}
+// fused conv + recurrence + gated norm (one launch); returns 1 when the geometry needs the two-launch path
+int kr_launch_la_step(const KrLaArgs& a, float* state, const float* w, float* out, float eps, hipStream_t s, void* img_out) {
+    const int nt = a.hr * a.dv;
+    if (nt > 256 || nt % 64 || a.nv != a.nk * a.hr || (a.dk != 128 && a.dk != 64) || (a.dv != 128 && a.dv != 64)) return 1;
+    if (a.dv != 128) img_out = nullptr;
+    const size_t lds = (size_t)(2 * a.dk + 2 * nt + 2 + 3 * a.hr + 4) * 4;
+#define KR_LA(DK_, DV_) hipLaunchKernelGGL((kr_la_step_kernel<DK_, DV_>), dim3(a.nk), dim3(nt), lds, s, a, state, w, out, eps, img_out, a.nv * a.dv)
+    if (a.dk == 128) { if (a.dv == 128) KR_LA(128, 128); else KR_LA(128, 64); }
+    else { if (a.dv == 128) KR_LA(64, 128); else KR_LA(64, 64); }
+#undef KR_LA
     return 0;
 }
 void kr_launch_gated_rmsnorm_silu(const float* recur, const float* z, const float* w, float* out, int nv, int dv, float eps, hipStream_t s) {
