@@ -465,7 +465,11 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
     // chunk c = t + 256 i of a stage: row c / cpr, 16-byte column c % cpr
     int crow[KR_GQA_NL], ccol[KR_GQA_NL];
 #pragma unroll
-    for (int i = 0; i < KR_GQA_NL; i++) { const int c = t + 256 * i; crow[i] = c / cpr; ccol[i] = (c % cpr) << 4; }
+    for (int i = 0; i < KR_GQA_NL; i++) {
+        const int c = t + 256 * i;
+        if ((cpr & (cpr - 1)) == 0) { const int sh = __builtin_ctz(cpr); crow[i] = c >> sh; ccol[i] = (c & (cpr - 1)) << 4; }   // hd 64 / 128 / 256
+        else { crow[i] = c / cpr; ccol[i] = (c % cpr) << 4; }
+    }
     u32x4 rg[KR_GQA_NL];
     auto issue = [&](const unsigned char* base, int s0) {
 #pragma unroll

@@ -252,7 +252,15 @@ __device__ __forceinline__ float kr_seq_sum(const float* x, int n) {
 // LDS traffic of a single wave is ordered by a fence, no workgroup barrier involved
 __device__ __forceinline__ void kr_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
-template <int NV>
+// softmax scoring without a correction bias: x -> fl(x * inv) is monotone, so the top-k of the exponentials is the top-k of the
+// probabilities unless rounding makes two of the leading k+1 equal.  With DUAL a second wave of the workgroup selects on the
+// exponentials while lane 0 of the first walks the 512-term sequential sum; equal scaled leaders fall back to the full selection.
+__device__ __forceinline__ bool kr_route_dual_ok(const KrRouteSelArgs& a) {
+    const bool decode = a.rule == 1;
+    const bool raw_topk = decode ? (a.scoring == 2) : (a.gptoss != 0);
+    return !raw_topk && a.scoring != 0 && a.esc == nullptr;
+}
+template <int NV, bool DUAL = false>
 __device__ __forceinline__ void kr_route_select_body(const KrRouteSelArgs& a, const float* lg, int32_t* ids, float* w, float* sm) {
     float* scores = sm;            // [E]
     float* sel = sm + a.E;         // [E]   (serial tie fallback only)
@@ -265,6 +273,7 @@ __device__ __forceinline__ void kr_route_select_body(const KrRouteSelArgs& a, co
     const bool decode = a.rule == 1;
     const bool raw_topk = decode ? (a.scoring == 2) : (a.gptoss != 0);
     float sc[NV], sl[NV];
+    bool pre_selected = false;
     KR_STAMP(8);
 #pragma unroll
     for (int i = 0; i < NV; i++) { const int e = lane * NV + i; sc[i] = e < E ? lg[e] : 0.0f; }
@@ -281,13 +290,28 @@ __device__ __forceinline__ void kr_route_select_body(const KrRouteSelArgs& a, co
         for (int i = 0; i < NV; i++) { const int e = lane * NV + i; if (e < E) mx = fmaxf(mx, sc[i]); }
         mx = kr_red16_max_f32(mx);
         mx = fmaxf(fmaxf(__shfl(mx, 0), __shfl(mx, 16)), fmaxf(__shfl(mx, 32), __shfl(mx, 48)));
+        const bool dual = DUAL && kr_route_dual_ok(a);
+        const int wv_id = threadIdx.x >> 6;
 #pragma unroll
-        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; if (e < E) { sc[i] = kr_expf(sc[i] - mx); scores[e] = sc[i]; } }
+        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; if (e < E) { sc[i] = kr_expf(sc[i] - mx); if (!dual || wv_id == 0) scores[e] = sc[i]; } }
+        if (dual) {
+            if (wv_id == 0) {
+                kr_wave_sync();
+                if (lane == 0) red[0] = kr_seq_sum(scores, E);
+            } else {
+                const int npu = a.topk + 1 <= E ? a.topk + 1 : a.topk;
+                kr_topk_wave_reg<NV>(sc, E, npu, pv, pi);        // on the exponentials
+            }
+            __syncthreads();                                     // the two surviving waves
+            if (wv_id != 0) return;
+            pre_selected = true;
+        } else {
         kr_wave_sync();
         KR_STAMP(12);
         if (lane == 0) red[0] = kr_seq_sum(scores, E);   // decode.rs:4156 / moe.rs:3201: sum in index order
         KR_STAMP(13);
         kr_wave_sync();
+        }
         const float se = red[0];
         if (decode) { const float inv = 1.0f / se;
 #pragma unroll
@@ -304,7 +328,18 @@ __device__ __forceinline__ void kr_route_select_body(const KrRouteSelArgs& a, co
     }
     const int np = k + 1 <= E ? k + 1 : k;
     KR_STAMP(9);
-    kr_topk_wave_reg<NV>(sl, E, np, pv, pi);
+    if (pre_selected) {   // scale the leaders found on the exponentials; they stand if strictly decreasing after rounding
+        kr_wave_sync();
+        const float se = red[0];
+        float cv = lane < np ? pv[lane] : 0.0f;
+        cv = decode ? cv * (1.0f / se) : cv / se;
+        const float nx = __shfl_down(cv, 1);
+        const bool strict = __ballot(lane + 1 < np && !(cv > nx)) == 0ull;
+        if (strict) { if (lane < np) pv[lane] = cv; }
+        else pre_selected = false;
+        kr_wave_sync();
+    }
+    if (!pre_selected) kr_topk_wave_reg<NV>(sl, E, np, pv, pi);
     KR_STAMP(10);
     kr_wave_sync();
     // ---- epilogue: lanes 0..k-1 each own one selected expert; only the (short) sums stay sequential ----
@@ -540,10 +575,11 @@ __global__ void __launch_bounds__(256) kr_route_fused_decode_kernel(const KrRout
         if (s_last) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch / graph replay
     }
     __syncthreads();
-    if (!s_last || wave != 0) return;
+    const bool dual = kr_route_dual_ok(a.sel);
+    if (!s_last || wave > (dual ? 1 : 0)) return;
     KR_STAMP(3);
     __atomic_thread_fence(__ATOMIC_ACQUIRE);   // every workgroup's logits are visible (released by its counter increment)
-    kr_route_select_body<NV>(a.sel, a.logits, a.sel.ids, a.sel.w, sm);
+    kr_route_select_body<NV, true>(a.sel, a.logits, a.sel.ids, a.sel.w, sm);
     KR_STAMP(11);
 }
 
