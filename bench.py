@@ -24,8 +24,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s ac
 B4 = 0.515625              # bytes per INT4-g128 weight incl. bf16 group scale
 KINDS = ["embed", "fused_add_rmsnorm", "proj_matvec", "la_conv", "la_recurrent", "gated_rmsnorm_silu", "gqa", "route_logits",
          "route_select", "moe_w13", "moe_w2", "moe_combine", "lm_head", "argmax", "shared_gate"]
-SYMBOL = {"proj_matvec": "kr_matvec_kernel<float,4>", "lm_head": "kr_matvec_kernel<float,4>", "shared_gate": "kr_matvec_kernel<float,4>",
-          "moe_w13": "kr_moe_w13_kernel<4>", "moe_w2": "kr_moe_w2_kernel<4,0>", "la_recurrent": "kr_la_recurrent_kernel<128>",
+SYMBOL = {"proj_matvec": "kr_matvec_coop_kernel<float,4>", "lm_head": "kr_matvec_kernel<float,4>", "shared_gate": "kr_matvec_kernel<float,4>",
+          "moe_w13": "kr_moe_w13_kernel<4>", "moe_w2": "kr_moe_w2_kernel<4,0>", "la_recurrent": "kr_la_step_kernel<128,128>",
           "route_logits": "kr_route_fused_decode_kernel<true,8>", "route_select": "kr_route_select_kernel",
           "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
 

@@ -10,6 +10,13 @@
 #include "kr_decode_ops.h"
 #include <hip/hip_fp16.h>
 
+#ifdef KR_TIMING   // tools/probes/gqa_timing.hip: wall-clock stamps (10 ns units) written by thread 0 of workgroup 0, no-op in the product build
+__device__ unsigned long long kr_dstamps[32];
+#define KR_DSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) kr_dstamps[i] = wall_clock64(); } while (0)
+#else
+#define KR_DSTAMP(i) do { } while (0)
+#endif
+
 // hsum over 8 consecutive lanes in the order of the reference's hsum (lo+hi, movehdup, movehl)
 __device__ __forceinline__ float kr_hsum8(float v) {
     v = v + __shfl_xor(v, 4);
@@ -437,7 +444,7 @@ __global__ void __launch_bounds__(256) kr_gqa_prep_kernel(const KrGqaArgs a) {
     }
 }
 
-// decode.rs:4194.  grid nh; 256 threads; dynamic LDS = (max_seq + 8) floats of scores + one stage of KR_GQA_ROWS cache rows.
+// decode.rs:4194.  grid nh; 256 threads; dynamic LDS = (max_seq + 40) floats of scores + one stage of KR_GQA_ROWS cache rows.
 //
 // Both passes over the cache (q.k scores, then the p.v chain) are latency problems: 16 workgroups, and every output is a
 // sequential fma chain in the reference's order.  The rows are therefore staged: all 256 threads fetch KR_GQA_ROWS rows of the
@@ -451,7 +458,9 @@ template <bool FP8> __device__ __forceinline__ float kr_stage_elem(const unsigne
     _Float16 hv; __builtin_memcpy(&hv, row + 2 * i, 2);
     return (float)hv;
 }
-template <bool FP8>
+// NB = head_dim / 8 as a compile-time constant (8 / 16 / 32): the per-lane loops unroll without the uniform guards that would put
+// every LDS read into its own basic block behind an s_waitcnt.  NB == 0: any head_dim % 8 == 0 up to 256, guarded (slow) form.
+template <bool FP8, int NB>
 __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int max_seq) {
     extern __shared__ __attribute__((aligned(16))) float sc[];
     __shared__ float qs[256]; __shared__ float red[8];
@@ -459,65 +468,77 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
     const int kvh = h / (a.nh / a.nkv);
     constexpr int esz = FP8 ? 1 : 2;
     const int row_bytes = hd * esz, pitch = row_bytes + 16, cpr = row_bytes >> 4;      // 16-byte chunks per row
-    const int nl = (KR_GQA_ROWS * cpr + 255) >> 8;                                      // loads per thread per stage (<= KR_GQA_NL)
-    unsigned char* stage = reinterpret_cast<unsigned char*>(sc) + ((((size_t)max_seq + 8) * 4 + 15) & ~(size_t)15);
+    unsigned char* stage = reinterpret_cast<unsigned char*>(sc) + ((((size_t)max_seq + 40) * 4 + 15) & ~(size_t)15);
+    KR_DSTAMP(0);
     if (t < hd) qs[t] = a.q_out[(size_t)h * hd + t];
-    // chunk c = t + 256 i of a stage: row c / cpr, 16-byte column c % cpr
-    int crow[KR_GQA_NL], ccol[KR_GQA_NL];
-#pragma unroll
-    for (int i = 0; i < KR_GQA_NL; i++) {
-        const int c = t + 256 * i;
-        if ((cpr & (cpr - 1)) == 0) { const int sh = __builtin_ctz(cpr); crow[i] = c >> sh; ccol[i] = (c & (cpr - 1)) << 4; }   // hd 64 / 128 / 256
-        else { crow[i] = c / cpr; ccol[i] = (c % cpr) << 4; }
-    }
+    // A stage is KR_GQA_ROWS rows; thread t fetches 16-byte column t % cprp (cprp = cpr rounded up to a power of two, <= 32) of rows
+    // t / cprp + i * (256 / cprp): a fixed row step per load, so one voffset + a uniform row term addresses every load.  Buffer
+    // addressing with num_records = seq rows: rows at or beyond the current length read as zero without a branch.
+    int lg = 2; while ((1 << lg) < cpr) lg++;
+    const int col = t & ((1 << lg) - 1), r0 = t >> lg, rstep = 256 >> lg, nl = KR_GQA_ROWS / rstep;   // nl = cprp / 2 <= KR_GQA_NL
+    const int grow = kvs * esz;                                                          // bytes per cache row
+    const int voff = col < cpr ? r0 * grow + kvh * hd * esz + col * 16 : 0x7FFFFFF0;     // idle columns: out of range -> zero
+    const int loff = r0 * pitch + (col < cpr ? col : 0) * 16;
+    const __amdgpu_buffer_rsrc_t srd_k = __builtin_amdgcn_make_buffer_rsrc(a.k_cache, 0, seq * grow, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc(a.v_cache, 0, seq * grow, 0x00020000);
     u32x4 rg[KR_GQA_NL];
-    auto issue = [&](const unsigned char* base, int s0) {
+    int rg_s0 = 0;
+    auto issue = [&](const __amdgpu_buffer_rsrc_t& srd, int s0) {
+        rg_s0 = s0;
 #pragma unroll
-        for (int i = 0; i < KR_GQA_NL; i++) {
-            if (i < nl) {
-                const int sp = s0 + crow[i];
-                rg[i] = (crow[i] < KR_GQA_ROWS && sp < seq) ? *reinterpret_cast<const u32x4*>(base + (size_t)sp * kvs * esz + ccol[i]) : u32x4{0, 0, 0, 0};
-            }
-        }
+        for (int i = 0; i < KR_GQA_NL; i++)
+            if (i < nl && s0 + i * rstep < seq) rg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, voff + (s0 + i * rstep) * grow, 0, 0);
     };
     auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < KR_GQA_NL; i++)
-            if (i < nl && crow[i] < KR_GQA_ROWS) *reinterpret_cast<u32x4*>(stage + crow[i] * pitch + ccol[i]) = rg[i];
+            if (i < nl && rg_s0 + i * rstep < seq && col < cpr) *reinterpret_cast<u32x4*>(stage + loff + i * rstep * pitch) = rg[i];
     };
-    const unsigned char* kbase = reinterpret_cast<const unsigned char*>(a.k_cache) + (size_t)kvh * hd * esz;
-    const unsigned char* vbase = reinterpret_cast<const unsigned char*>(a.v_cache) + (size_t)kvh * hd * esz;
+    const __amdgpu_buffer_rsrc_t& kbase = srd_k; const __amdgpu_buffer_rsrc_t& vbase = srd_v;
     const int nst = (seq + KR_GQA_ROWS - 1) / KR_GQA_ROWS;
     // ---- scores: 8 lanes per position, lane l owns elements b*8 + l (the AVX2 lane), ascending b, then the 8-lane hsum
-    const int l = t & 7, g = t >> 3, nb = hd >> 3;
+    const int l = t & 7, g = t >> 3, nb = NB ? NB : (hd >> 3);
+    constexpr int NBM = NB ? NB : 32;
     issue(kbase, 0);
     __syncthreads();
-    float qr[32];                                // the lane's 32 query elements (hd <= 256)
+    KR_DSTAMP(1);
+    float qr[NBM];                               // the lane's query elements (hd <= 256)
 #pragma unroll
-    for (int b = 0; b < 32; b++) qr[b] = b < nb ? qs[b * 8 + l] : 0.0f;
+    for (int b = 0; b < NBM; b++) qr[b] = (NB || b < nb) ? qs[b * 8 + l] : 0.0f;
     for (int st = 0; st < nst; st++) {
         if (st) __syncthreads();                 // the previous stage's readers are done
         commit();
         if (st + 1 < nst) issue(kbase, (st + 1) * KR_GQA_ROWS); else issue(vbase, 0);   // V stage 0 rides under the softmax
         __syncthreads();
+        KR_DSTAMP(2);
         const int s0 = st * KR_GQA_ROWS;
-#pragma unroll 1
-        for (int r = g; r < KR_GQA_ROWS; r += 32) {
-            const int sp = s0 + r;
-            if (sp >= seq) break;
+        // four passes of 32 rows (8 lanes per row); the next pass's elements are read from LDS while the current chain runs
+        float ka[NBM], kb[NBM];
+        auto loadk = [&](float (&X)[NBM], int r) {
             const unsigned char* row = stage + r * pitch;
+#pragma unroll
+            for (int b2 = 0; b2 < NBM; b2++) if (NB || b2 < nb) X[b2] = kr_stage_elem<FP8>(row, b2 * 8 + l);
+        };
+        auto chaink = [&](const float (&X)[NBM], int r) {
             float acc = 0.0f;
-            for (int b = 0; b < nb; b += 16) {   // 16 LDS reads in flight, then the lane's chain (nb is uniform: scalar branches)
-                float kk[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++) kk[u] = kr_stage_elem<FP8>(row, min(b + u, nb - 1) * 8 + l);
-#pragma unroll
-                for (int u = 0; u < 16; u++) if (b + u < nb) acc = __builtin_fmaf(qr[b + u], kk[u], acc);
-            }
+            for (int b2 = 0; b2 < NBM; b2++) if (NB || b2 < nb) acc = __builtin_fmaf(qr[b2], X[b2], acc);
             acc = kr_hsum8(acc);
-            if (l == 0) sc[sp] = acc * a.sm_scale;
+            if (l == 0) sc[s0 + r] = acc * a.sm_scale;
+        };
+        if (s0 + g < seq) loadk(ka, g);
+#pragma unroll
+        for (int k2 = 0; k2 < KR_GQA_ROWS / 32; k2 += 2) {
+            const int ra = g + 32 * k2, rb = ra + 32, rc = ra + 64;
+            if (s0 + rb < seq) loadk(kb, rb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + ra < seq) chaink(ka, ra);
+            if (rc < KR_GQA_ROWS && s0 + rc < seq) loadk(ka, rc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + rb < seq) chaink(kb, rb);
         }
     }
+    KR_DSTAMP(3);
     __syncthreads();
     float mx = -__builtin_inff();
     for (int s = t; s < seq; s += 256) mx = fmaxf(mx, sc[s]);
@@ -527,19 +548,12 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     for (int s = t; s < seq; s += 256) sc[s] = kr_expf(sc[s] - mx);
+    const int seq32 = (seq + 31) & ~31;          // zero padding: the exponentials are >= +0, so s + 0.0f == s bit for bit
+    if (t < seq32 - seq) sc[seq + t] = 0.0f;
     __syncthreads();
-    if (t == 0) {
-        float se = 0.0f; int s = 0;
-        for (; s + 8 <= seq; s += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = sc[s + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) se += v[u];
-        }
-        for (; s < seq; s++) se += sc[s];
-        red[4] = 1.0f / se;
-    }
+    KR_DSTAMP(4);
+    if (t == 0) red[4] = 1.0f / kr_seq_sum(sc, seq32);
+    KR_DSTAMP(5);   // position order (decode.rs:4194), LDS reads double-buffered under the add chain
     __syncthreads();
     const float inv = red[4];
     for (int s = t; s < seq; s += 256) sc[s] *= inv;
@@ -550,18 +564,44 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
         commit();
         if (st + 1 < nst) issue(vbase, (st + 1) * KR_GQA_ROWS);
         __syncthreads();
+        KR_DSTAMP(6);
         if (t < hd) {
             const int s0 = st * KR_GQA_ROWS, n = min(KR_GQA_ROWS, seq - s0);
             const unsigned char* col = stage;
-            for (int r = 0; r < n; r += 16) {    // n <= 128 and r % 16 == 0: rows r..r+15 are inside the stage
-                float vv[16], pp[16];
+            // batches of 16 rows, two register sets: the next batch's LDS reads are in flight under the current fma chain
+            float va[16], pa[16], vb[16], pb[16];
+            auto loadv = [&](float (&V)[16], float (&P)[16], int r) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) { vv[u] = kr_stage_elem<FP8>(col + (r + u) * pitch, t); pp[u] = sc[s0 + r + u]; }
+                for (int u = 0; u < 16; u++) { V[u] = kr_stage_elem<FP8>(col + (r + u) * pitch, t); P[u] = sc[s0 + r + u]; }
+            };
+            int r = 0;
+            if (n >= 32) {
+                loadv(va, pa, 0);
+                for (; r + 64 <= n; r += 32) {
+                    loadv(vb, pb, r + 16);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 16; u++) if (r + u < n) o = __builtin_fmaf(pp[u], vv[u], o);
+                    for (int u = 0; u < 16; u++) o = __builtin_fmaf(pa[u], va[u], o);
+                    loadv(va, pa, r + 32);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 16; u++) o = __builtin_fmaf(pb[u], vb[u], o);
+                }
+                loadv(vb, pb, r + 16);          // set a = rows r.., at least 32 and fewer than 64 rows remain
+#pragma unroll
+                for (int u = 0; u < 16; u++) o = __builtin_fmaf(pa[u], va[u], o);
+#pragma unroll
+                for (int u = 0; u < 16; u++) o = __builtin_fmaf(pb[u], vb[u], o);
+                r += 32;
+            }
+            for (; r < n; r += 16) {             // n <= 128 and r % 16 == 0: rows r..r+15 are inside the stage
+                loadv(va, pa, r);
+#pragma unroll
+                for (int u = 0; u < 16; u++) if (r + u < n) o = __builtin_fmaf(pa[u], va[u], o);
             }
         }
     }
+    KR_DSTAMP(7);
     const int d = t;
     if (d < hd) {
         if (a.gated) { const float gt = a.gate[(size_t)h * hd + d]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
@@ -686,7 +726,7 @@ void kr_launch_gated_rmsnorm_silu(const float* recur, const float* z, const floa
     hipLaunchKernelGGL(kr_gated_rmsnorm_silu_kernel, dim3(nv), dim3(256), 0, s, recur, z, w, out, dv, eps);
 }
 static size_t kr_gqa_attn_lds(int max_seq, int hd, int fp8) {
-    return ((((size_t)max_seq + 8) * 4 + 15) & ~(size_t)15) + (size_t)KR_GQA_ROWS * ((size_t)hd * (fp8 ? 1 : 2) + 16);
+    return ((((size_t)max_seq + 40) * 4 + 15) & ~(size_t)15) + (size_t)KR_GQA_ROWS * ((size_t)hd * (fp8 ? 1 : 2) + 16);
 }
 // Raises the kernel's dynamic-LDS window (gfx950: 160 KiB per workgroup).  Called outside graph capture, before the first launch.
 int kr_gqa_attn_prepare(int max_seq, int hd, int fp8) {
@@ -694,9 +734,10 @@ int kr_gqa_attn_prepare(int max_seq, int hd, int fp8) {
     if (lds > 160 * 1024) return -1;
     static size_t lds_set[2] = {0, 0};
     if (lds > lds_set[fp8 ? 1 : 0]) {
-        const hipError_t e = fp8 ? hipFuncSetAttribute((const void*)kr_gqa_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                                 : hipFuncSetAttribute((const void*)kr_gqa_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -2;
+        const void* fns[2][4] = {{(const void*)kr_gqa_attn_kernel<false, 8>, (const void*)kr_gqa_attn_kernel<false, 16>, (const void*)kr_gqa_attn_kernel<false, 32>, (const void*)kr_gqa_attn_kernel<false, 0>},
+                                 {(const void*)kr_gqa_attn_kernel<true, 8>, (const void*)kr_gqa_attn_kernel<true, 16>, (const void*)kr_gqa_attn_kernel<true, 32>, (const void*)kr_gqa_attn_kernel<true, 0>}};
+        for (int i = 0; i < 4; i++)
+            if (hipFuncSetAttribute(fns[fp8 ? 1 : 0][i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
         lds_set[fp8 ? 1 : 0] = lds;
     }
     return 0;
@@ -704,8 +745,10 @@ int kr_gqa_attn_prepare(int max_seq, int hd, int fp8) {
 void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
     hipLaunchKernelGGL(kr_gqa_prep_kernel, dim3(a.nh + a.nkv), dim3(256), 0, s, a);
     const size_t lds = kr_gqa_attn_lds(max_seq, a.hd, a.kv_fp8);
-    if (a.kv_fp8) hipLaunchKernelGGL(kr_gqa_attn_kernel<true>, dim3(a.nh), dim3(256), lds, s, a, max_seq);
-    else hipLaunchKernelGGL(kr_gqa_attn_kernel<false>, dim3(a.nh), dim3(256), lds, s, a, max_seq);
+#define KR_GQA(F_, N_) hipLaunchKernelGGL((kr_gqa_attn_kernel<F_, N_>), dim3(a.nh), dim3(256), lds, s, a, max_seq)
+    if (a.kv_fp8) { if (a.hd == 256) KR_GQA(true, 32); else if (a.hd == 128) KR_GQA(true, 16); else if (a.hd == 64) KR_GQA(true, 8); else KR_GQA(true, 0); }
+    else { if (a.hd == 256) KR_GQA(false, 32); else if (a.hd == 128) KR_GQA(false, 16); else if (a.hd == 64) KR_GQA(false, 8); else KR_GQA(false, 0); }
+#undef KR_GQA
 }
 void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const float* wts, int topk, int has_shared, const float* gate_val,
                                   float rsf, float* hidden, int H, hipStream_t s) {

@@ -176,6 +176,33 @@ __device__ __forceinline__ void kr_kv_store(void* base, size_t i, float v, int f
     reinterpret_cast<uint16_t*>(base)[i] = h;
 }
 
+// strictly sequential f32 sum of x[0..n) (reference order); the next 16 values are fetched from LDS (4 x ds_read_b128) while the
+// current 16 are being added, so the chain of dependent adds is the only latency left.  x must be 16-byte aligned.
+#define KR_ADD16(s, a0, a1, a2, a3) do { s += a0.x; s += a0.y; s += a0.z; s += a0.w; s += a1.x; s += a1.y; s += a1.z; s += a1.w; \
+                                           s += a2.x; s += a2.y; s += a2.z; s += a2.w; s += a3.x; s += a3.y; s += a3.z; s += a3.w; } while (0)
+__device__ __forceinline__ float kr_seq_sum(const float* x, int n) {
+    float s = 0.0f; int e = 0;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    if (n >= 32) {   // two register sets (A, B): B's ds_reads are in flight while A is added and vice versa
+        float4 a0 = x4[0], a1 = x4[1], a2 = x4[2], a3 = x4[3];
+        for (; e + 64 <= n; e += 32) {
+            const float4 b0 = x4[e / 4 + 4], b1 = x4[e / 4 + 5], b2 = x4[e / 4 + 6], b3 = x4[e / 4 + 7];
+            __builtin_amdgcn_sched_barrier(0);
+            KR_ADD16(s, a0, a1, a2, a3);
+            a0 = x4[e / 4 + 8]; a1 = x4[e / 4 + 9]; a2 = x4[e / 4 + 10]; a3 = x4[e / 4 + 11];
+            __builtin_amdgcn_sched_barrier(0);
+            KR_ADD16(s, b0, b1, b2, b3);
+        }
+        // a = block at e (loaded); at least 32 and fewer than 64 values remain
+        const float4 b0 = x4[e / 4 + 4], b1 = x4[e / 4 + 5], b2 = x4[e / 4 + 6], b3 = x4[e / 4 + 7];
+        KR_ADD16(s, a0, a1, a2, a3);
+        KR_ADD16(s, b0, b1, b2, b3);
+        e += 32;
+    }
+    for (; e < n; e++) s += x[e];
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // INT16 activation image: carving, and the f32 quantizer shared by every kernel that PRODUCES an image for a later matvec launch
 // (the image can live in LDS or, pre-built by the producer of the activation, in global memory with the identical byte layout).

@@ -2,6 +2,7 @@
 """Format rocprofv3 CSV outputs into the small text summaries committed under profiles/.
 
   rocprof_csv_summary.py stats <dir> <out.txt> [title]      # *_kernel_stats.csv   (--kernel-trace --stats)
+  rocprof_csv_summary.py statsdb <dir> <out.txt> [title]    # *_results.db (rocpd SQLite, the default output format)
   rocprof_csv_summary.py pmc   <dir> <out.txt> [title]      # *_counter_collection.csv (--pmc FETCH_SIZE): per-kernel HBM fetch bytes per launch
 
 FETCH_SIZE is reported in KiB of 64-B requests; on gfx950 wide streaming reads are tallied at half their size
@@ -20,6 +21,20 @@ def stats(d, out, title):
     for r in rows[:40]:
         lines.append(f"{int(r['Calls']):8d} {float(r['TotalDurationNs'])/1e6:11.3f} {float(r['AverageNs'])/1e3:10.2f} {float(r['Percentage']):6.2f} "
                      f"{float(r['MinNs'])/1e3:9.2f} {float(r['MaxNs'])/1e3:9.2f}  {r['Name'][:110]}")
+    open(out, "w").write("\n".join(lines) + "\n")
+
+
+def statsdb(d, out, title):
+    """same table from the rocpd SQLite output (rocprofv3 default output format): durations from the `kernels` view"""
+    import sqlite3
+    f = glob.glob(d + "/**/*results.db", recursive=True)[0]
+    c = sqlite3.connect(f)
+    rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    lines = [f"# {title}", f"# source: rocprofv3 --kernel-trace --stats ({f.split('gpurun_out/')[-1]}, kernels view: end - start per dispatch)",
+             f"{'calls':>8} {'total_ms':>11} {'avg_us':>10} {'pct':>6} {'min_us':>9} {'max_us':>9}  kernel"]
+    for r in rows[:40]:
+        lines.append(f"{r[1]:8d} {r[2]/1e6:11.3f} {r[3]/1e3:10.2f} {100*r[2]/tot:6.2f} {r[4]/1e3:9.2f} {r[5]/1e3:9.2f}  {r[0][:110]}")
     open(out, "w").write("\n".join(lines) + "\n")
 
 
@@ -44,4 +59,4 @@ def pmc(d, out, title):
 if __name__ == "__main__":
     mode, d, out = sys.argv[1:4]
     title = sys.argv[4] if len(sys.argv) > 4 else out
-    (stats if mode == "stats" else pmc)(d, out, title)
+    {"stats": stats, "statsdb": statsdb, "pmc": pmc}[mode](d, out, title)
