@@ -30,9 +30,12 @@ struct KrMlaArgs {   // decode.rs:2993-3252
     uint16_t *ckv_cache, *kpe_cache;   // FP16 [max_seq, klr] / [max_seq, rd]
     float *q_abs, *q_pe, *attn_lat, *v_proj;
     int nh, klr, nd, rd, vhd; float eps, sm_scale;
+    // prompt pass (step == nullptr): token t = blockIdx.y (blockIdx.z for the w_vc launch) sits at position pos0 + t; row t of the
+    // per-token buffers starts at t * ld_* floats (kv_out, q_full) or t * their natural size (q_abs, q_pe, attn_lat, v_proj)
+    int pos0; int ld_kv, ld_q;
 };
-void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s);
-void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s);
+void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok = 1);
+void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s, int rows = 1, int ld = 0);
 
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s);
 struct KrNormSrc {   // where the value added to the residual comes from (see kr_fused_add_rmsnorm_kernel)

@@ -85,6 +85,34 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         if (oc != L.nh * L.hd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*hd", oc);
         kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
         if (int rc = pf_gemm(s, L.o_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+    } else if (L.attn == ATTN_MLA) {
+        // MLA (decode.rs:2993-3252): batched projections on the GEMM, then the three decode launches with a token dimension.  The
+        // prep launch appends every token's latent / rope rows before the attention launch reads them, so token t of the chunk
+        // sees exactly the cache decode_step would have built.
+        if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no MLA cache for layer %zu)", li);
+        if (L.mla_rope_seq < pos0 + Cc) return kr_fail(KR_ERR_VALUE, "prompt exceeds the MLA rope table (%d)", L.mla_rope_seq);
+        const int nkv = s->weights[L.kva_wid]->rows, nq = L.nh * (L.nd + L.rd), oc = s->weights[L.o_wid]->cols;
+        if (int rc = pf_gemm(s, L.kva_wid, B.xh, B.xl, B.xs, Cc, B.pb, nkv, st)) return rc;
+        if (L.mq_wid >= 0) {
+            if (int rc = pf_gemm(s, L.mq_wid, B.xh, B.xl, B.xs, Cc, B.pa, nq, st)) return rc;
+        } else {   // LoRA query path: q_a_proj -> sequential RMSNorm -> q_b_proj (decode.rs:3036-3079)
+            const int qlr = s->weights[L.mqa_wid]->rows, qc = s->weights[L.mqb_wid]->cols;
+            if (qc != qlr || qlr % 128) return kr_fail(KR_ERR_VALUE, "q_b_proj cols %d != q_a_proj rows %d (multiple of 128)", qc, qlr);
+            if (int rc = pf_gemm(s, L.mqa_wid, B.xh, B.xl, B.xs, Cc, B.pc, qlr, st)) return rc;
+            if (L.q_a_norm_len) kr_launch_rmsnorm_seq(B.pc, (const float*)L.q_a_norm.p, qlr, s->eps, st, Cc, qlr);
+            kr_launch_pfm_quant_f32(B.pc, Cc, qlr, qlr, B.yh, B.yl, B.ys, st);
+            if (int rc = pf_gemm(s, L.mqb_wid, B.yh, B.yl, B.ys, Cc, B.pa, nq, st)) return rc;
+        }
+        KrMlaArgs a{};
+        a.step = nullptr; a.pos0 = pos0; a.kv_out = B.pb; a.ld_kv = nkv; a.q_full = B.pa; a.ld_q = nq;
+        a.kv_a_norm = (const float*)L.kv_a_norm.p; a.w_kc = (const float*)L.w_kc.p; a.w_vc = (const float*)L.w_vc.p;
+        a.rope_cos = (const float*)L.mla_cos.p; a.rope_sin = (const float*)L.mla_sin.p;
+        a.ckv_cache = (uint16_t*)L.kv_k.p; a.kpe_cache = (uint16_t*)L.kv_v.p; a.q_abs = B.q; a.q_pe = B.z; a.attn_lat = B.recur; a.v_proj = B.attn;
+        a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale;
+        kr_launch_mla(a, s->kv_max_seq, st, Cc);
+        if (oc != L.nh * L.vhd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*v_head_dim", oc);
+        kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
+        if (int rc = pf_gemm(s, L.o_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
     }
     // ---- post-attention norm: f32 hidden, digits (shared expert / dense MLP), bf16 copy (routed experts)
     na.mode = 0; na.add_in = B.hid; na.first = 0; na.w = (const float*)s->norms[L.post_norm]->p; na.out_bf16 = L.mlp == MLP_MOE ? B.xb : nullptr;
@@ -171,7 +199,15 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
             qd = std::max(qd, (size_t)Ly.nh * Ly.hd); zd = std::max(zd, (size_t)Ly.nh * Ly.hd); ad = std::max(ad, (size_t)s->weights[Ly.o_wid]->cols);
             sc_rows = std::max(sc_rows, (size_t)Ly.nh);
             for (int w : {Ly.q_wid, Ly.k_wid, Ly.v_wid, Ly.o_wid}) wids.push_back(w);
-        } else if (Ly.attn == ATTN_MLA) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: MLA layers are decode-only in this build (feed the prompt through decode_step)");
+        } else if (Ly.attn == ATTN_MLA) {
+            const size_t nq = (size_t)Ly.nh * (Ly.nd + Ly.rd);
+            pa = std::max(pa, nq); pb = std::max(pb, (size_t)s->weights[Ly.kva_wid]->rows);
+            qd = std::max(qd, (size_t)Ly.nh * Ly.klr); vd = std::max(vd, (size_t)Ly.nh * Ly.klr); zd = std::max(zd, (size_t)Ly.nh * Ly.rd);
+            ad = std::max(ad, (size_t)s->weights[Ly.o_wid]->cols);
+            wids.push_back(Ly.kva_wid); wids.push_back(Ly.o_wid);
+            if (Ly.mq_wid >= 0) wids.push_back(Ly.mq_wid);
+            else { pc = std::max(pc, (size_t)s->weights[Ly.mqa_wid]->rows); kmax = std::max(kmax, (size_t)s->weights[Ly.mqa_wid]->rows); wids.push_back(Ly.mqa_wid); wids.push_back(Ly.mqb_wid); }
+        }
         if (Ly.mlp == MLP_MOE) {
             if (Ly.sgu_wid >= 0) { sid = std::max(sid, (size_t)s->weights[Ly.sgu_wid]->rows); kmax = std::max(kmax, (size_t)s->weights[Ly.sd_wid]->cols); wids.push_back(Ly.sgu_wid); wids.push_back(Ly.sd_wid); }
             if (Ly.sgu_wid >= 0 && Ly.sg_wid >= 0) wids.push_back(Ly.sg_wid);

@@ -38,9 +38,17 @@ __device__ __forceinline__ float kr_dot2acc(const float* q, LoadB loadb, int dim
 // ---- launch 1: prep --------------------------------------------------------------------------------------------------
 // blocks [0, nh*klr/64): absorb tile (h, jt); the jt == 0 block of each head also de-interleaves + ropes q_pe[h].
 // last block: kv_a RMSNorm (sequential sum), k_pe de-interleave + RoPE, FP16 cache append at `pos`.
-__global__ void __launch_bounds__(64) kr_mla_prep_kernel(const KrMlaArgs a) {
+// per-token view of the argument block (decode: the single token; prompt pass: token blockIdx.y / .z of the chunk)
+__device__ __forceinline__ int kr_mla_token(KrMlaArgs& a, int tk) {
+    if (a.step) return a.step->pos;
+    a.kv_out += (size_t)tk * a.ld_kv; a.q_full += (size_t)tk * a.ld_q;
+    a.q_abs += (size_t)tk * a.nh * a.klr; a.q_pe += (size_t)tk * a.nh * a.rd; a.attn_lat += (size_t)tk * a.nh * a.klr; a.v_proj += (size_t)tk * a.nh * a.vhd;
+    return a.pos0 + tk;
+}
+__global__ void __launch_bounds__(64) kr_mla_prep_kernel(KrMlaArgs a) {
     __shared__ float sh[640];
-    const int tiles = a.klr / 64, nb_abs = a.nh * tiles, hd = a.nd + a.rd, half = a.rd / 2, pos = a.step->pos;
+    const int pos = kr_mla_token(a, blockIdx.y);
+    const int tiles = a.klr / 64, nb_abs = a.nh * tiles, hd = a.nd + a.rd, half = a.rd / 2;
     const int t = threadIdx.x;
     if ((int)blockIdx.x < nb_abs) {
         const int h = blockIdx.x / tiles, jt = blockIdx.x % tiles, j = jt * 64 + t;
@@ -98,11 +106,12 @@ __global__ void __launch_bounds__(64) kr_mla_prep_kernel(const KrMlaArgs a) {
 }
 
 // ---- launch 2: attention, one workgroup (512 threads) per head.  dynamic LDS: klr + rd + seq_max + 8 floats --------------
-__global__ void __launch_bounds__(512) kr_mla_attn_kernel(const KrMlaArgs a) {
+__global__ void __launch_bounds__(512) kr_mla_attn_kernel(KrMlaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[12];
+    const int seq = kr_mla_token(a, blockIdx.y) + 1;
     float* qa = lds; float* qp = qa + a.klr; float* sc = qp + a.rd;
-    const int h = blockIdx.x, seq = a.step->pos + 1, t = threadIdx.x;
+    const int h = blockIdx.x, t = threadIdx.x;
     for (int i = t; i < a.klr; i += 512) qa[i] = a.q_abs[(size_t)h * a.klr + i];
     for (int i = t; i < a.rd; i += 512) qp[i] = a.q_pe[(size_t)h * a.rd + i];
     __syncthreads();
@@ -159,8 +168,9 @@ __global__ void __launch_bounds__(512) kr_mla_attn_kernel(const KrMlaArgs a) {
 }
 
 // ---- launch 3: v_projected[h][o] = w_vc[h][o][:] . attn_lat[h][:]   grid (vhd/8, nh), 128 threads = 8 outputs x 16 lanes ----
-__global__ void __launch_bounds__(128) kr_mla_wvc_kernel(const KrMlaArgs a) {
+__global__ void __launch_bounds__(128) kr_mla_wvc_kernel(KrMlaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    (void)kr_mla_token(a, blockIdx.z);
     const int h = blockIdx.y, t = threadIdx.x, o = blockIdx.x * 8 + (t >> 4);
     for (int i = t; i < a.klr; i += 128) lds[i] = a.attn_lat[(size_t)h * a.klr + i];
     __syncthreads();
@@ -171,9 +181,10 @@ __global__ void __launch_bounds__(128) kr_mla_wvc_kernel(const KrMlaArgs a) {
 }
 
 // plain sequential RMSNorm (decode.rs:3053-3062, q_a_layernorm of the LoRA query path); one workgroup, in place
-__global__ void __launch_bounds__(256) kr_rmsnorm_seq_kernel(float* __restrict__ x, const float* __restrict__ w, int n, float eps) {
+__global__ void __launch_bounds__(256) kr_rmsnorm_seq_kernel(float* __restrict__ x, const float* __restrict__ w, int n, float eps, int ld) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x;
+    x += (size_t)blockIdx.x * ld;                // prompt pass: one workgroup per token row
     for (int i = t; i < n; i += 256) lds[i] = x[i];
     __syncthreads();
     if (t == 0) {
@@ -193,11 +204,11 @@ __global__ void __launch_bounds__(256) kr_rmsnorm_seq_kernel(float* __restrict__
     for (int i = t; i < n; i += 256) x[i] = lds[i] * (rms * w[i]);
 }
 
-void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s) {
-    hipLaunchKernelGGL(kr_mla_prep_kernel, dim3(a.nh * (a.klr / 64) + 1), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(kr_mla_attn_kernel, dim3(a.nh), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
-    hipLaunchKernelGGL(kr_mla_wvc_kernel, dim3((a.vhd + 7) / 8, a.nh), dim3(128), (size_t)a.klr * 4, s, a);
+void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {
+    hipLaunchKernelGGL(kr_mla_prep_kernel, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(kr_mla_attn_kernel, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
+    hipLaunchKernelGGL(kr_mla_wvc_kernel, dim3((a.vhd + 7) / 8, a.nh, n_tok), dim3(128), (size_t)a.klr * 4, s, a);
 }
-void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(kr_rmsnorm_seq_kernel, dim3(1), dim3(256), (size_t)(n + 4) * 4, s, x, w, n, eps);
+void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s, int rows, int ld) {
+    hipLaunchKernelGGL(kr_rmsnorm_seq_kernel, dim3(rows), dim3(256), (size_t)(n + 4) * 4, s, x, w, n, eps, ld);
 }

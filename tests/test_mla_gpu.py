@@ -99,6 +99,30 @@ def test_mla_decode_step_bit_exact(cfg, graph):
         assert np.array_equal(ck, orc.layers[li]["ckv"]) and np.array_equal(kp, orc.layers[li]["kpe"])
 
 
+@pytest.mark.parametrize("cfg,chunk,depth", [(dict(), 4, 2), (dict(lora=True, seed=2), 3, 1), (dict(klr=256, nh=3, seed=4), 16, 2)])
+def test_mla_prompt_pass_equals_sequential_decode(cfg, chunk, depth):
+    """kr_decode_prefill over MLA layers (batched projections + the decode launches with a token dimension) leaves logits and both
+    FP16 caches bit-identical to feeding the same tokens through decode_step one by one."""
+    toks = [3, 17, 99, 250, 7, 7, 41, 300, 12, 5, 64]
+    st, eng, orc, keep, d = build(**cfg)
+    seq = np.empty(d["V"], F)
+    for i, t in enumerate(toks):
+        st.decode_step(t, 5 + i, seq.ctypes.data)
+    caches = []
+    for li in range(d["nL"]):
+        ck = np.empty((d["kv_max"], d["klr"]), np.uint16); kp = np.empty((d["kv_max"], d["rd"]), np.uint16)
+        st.get_decode_state(li, ck, kp, None, None); caches.append((ck, kp))
+    st2, eng2, orc2, keep2, d2 = build(**cfg)                  # same seed -> same weights and initial caches
+    st2.set_prefill_chunk(chunk); st2.set_prefill_depth(depth)
+    pf = np.empty(d["V"], F); st2.prefill(toks, 5, pf.ctypes.data)
+    assert np.array_equal(pf.view(np.uint32), seq.view(np.uint32)), float(np.max(np.abs(pf - seq)))
+    assert st2.last_token() == st.last_token()
+    for li in range(d["nL"]):
+        ck = np.empty((d["kv_max"], d["klr"]), np.uint16); kp = np.empty((d["kv_max"], d["rd"]), np.uint16)
+        st2.get_decode_state(li, ck, kp, None, None)
+        assert np.array_equal(ck, caches[li][0]) and np.array_equal(kp, caches[li][1])
+
+
 def test_mla_geometry_errors():
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     eng = KrasisEngine(); eng.configure(ModelConfig(256, 128, 8, 2, 1, 0, 1.0))
