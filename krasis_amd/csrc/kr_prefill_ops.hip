@@ -165,8 +165,12 @@ __global__ void kr_pfm_la_conv_state_kernel(const KrPfmLaArgs a, int C) {
 
 // ---- gated delta rule over the chunk (decode.rs:1293): one thread per state column, the column lives in registers ------------
 // grid nv, dv threads.  Per token: kv = chain_i fma(S[i]*e^g, k[i]); delta = (v - kv)*beta; S[i] = fma(k[i], delta, S[i]*e^g); o = chain_i fma(S[i], q[i]).
-// The two DK-long fma chains per token are inherent to the reference order (measured alternatives -- LDS-staged token blocks, interleaving
-// the chains of consecutive tokens, scalar loads of k/q -- were all slower than this form on MI355X: the wave is issue/latency bound).
+// The two DK-long fma chains per token are inherent to the reference order and run at the dependent-issue latency (~8 cycles per
+// step, ~2 x DK x 8 cycles per token); what must NOT sit on the token loop is memory: every per-token scalar (e^g, beta, v) and the
+// next k / q rows are fetched one token ahead, and the state slice is addressed through a buffer descriptor (scalar row offsets)
+// so that no per-row 64-bit addresses stay live across the loop.  Measured alternatives (LDS-staged token blocks; one packed fma
+// advancing the kv chain of token t and the output chain of token t-1 on a {S*e^g, S} register pair -- needs 2 x DK registers; a
+// merged in-place loop -- the compiler hoists the decay into the previous update and spills) were slower on MI355X.
 template <int DK>
 __global__ void __launch_bounds__(256) kr_pfm_la_recur_kernel(float* __restrict__ state, const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, const float* __restrict__ gexp, const float* __restrict__ beta,
@@ -174,30 +178,74 @@ __global__ void __launch_bounds__(256) kr_pfm_la_recur_kernel(float* __restrict_
     __shared__ __attribute__((aligned(16))) float ks[2][DK], qs[2][DK];
     const int h = blockIdx.x, j = threadIdx.x, nvdk = nv * DK, nvdv = nv * dv;
     float S[DK];
-    float* Sg = state + (size_t)h * DK * dv + j;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(state + (size_t)h * DK * dv, 0, DK * dv * 4, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < DK; i++) S[i] = Sg[(size_t)i * dv];
-    for (int i = j; i < DK; i += blockDim.x) { ks[0][i] = k[(size_t)h * DK + i]; qs[0][i] = q[(size_t)h * DK + i]; }
+    for (int i = 0; i < DK; i++) S[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, j * 4, i * dv * 4, 0));
+    if (j < DK) { ks[0][j] = k[(size_t)h * DK + j]; qs[0][j] = q[(size_t)h * DK + j]; }   // DK <= blockDim (dv >= DK is checked by the launcher)
+    float ge = gexp[h], bt = beta[h], vj = v[(size_t)h * dv + j];
     __syncthreads();
     for (int t = 0; t < C; t++) {
         const int cur = t & 1;
-        float kn = 0.0f, qn = 0.0f;
-        const bool pre = t + 1 < C && j < DK;     // DK <= blockDim (dv >= DK is checked by the launcher)
-        if (pre) { kn = k[(size_t)(t + 1) * nvdk + (size_t)h * DK + j]; qn = q[(size_t)(t + 1) * nvdk + (size_t)h * DK + j]; }
-        const float ge = gexp[(size_t)t * nv + h], bt = beta[(size_t)t * nv + h], vj = v[(size_t)t * nvdv + (size_t)h * dv + j];
+        float kn = 0.0f, qn = 0.0f, ge_n = 1.0f, bt_n = 0.0f, vj_n = 0.0f;                 // token t + 1, in flight under this token's chains
+        const bool more = t + 1 < C;
+        if (more) {
+            if (j < DK) { kn = k[(size_t)(t + 1) * nvdk + (size_t)h * DK + j]; qn = q[(size_t)(t + 1) * nvdk + (size_t)h * DK + j]; }
+            ge_n = gexp[(size_t)(t + 1) * nv + h]; bt_n = beta[(size_t)(t + 1) * nv + h]; vj_n = v[(size_t)(t + 1) * nvdv + (size_t)h * dv + j];
+        }
+        // blocks of 16 elements: the next block's k (and q) rows leave LDS (4 / 8 x ds_read_b128) while the current block's chain
+        // steps run; the scheduling barriers stop the compiler from sinking each read next to its use (one exposed LDS latency per pair)
+        const float4* k4 = reinterpret_cast<const float4*>(ks[cur]); const float4* q4 = reinterpret_cast<const float4*>(qs[cur]);
         float kv = 0.0f;
+        float4 ka[4] = {k4[0], k4[1], k4[2], k4[3]};
 #pragma unroll
-        for (int i = 0; i < DK; i++) { S[i] = S[i] * ge; kv = __builtin_fmaf(S[i], ks[cur][i], kv); }
+        for (int b = 0; b < DK / 16; b++) {
+            float4 kb[4] = {ka[0], ka[1], ka[2], ka[3]};
+            if (b + 1 < DK / 16) { kb[0] = k4[4 * b + 4]; kb[1] = k4[4 * b + 5]; kb[2] = k4[4 * b + 6]; kb[3] = k4[4 * b + 7]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float* Sb = S + 16 * b + 4 * u;
+                Sb[0] = Sb[0] * ge; kv = __builtin_fmaf(Sb[0], ka[u].x, kv);
+                Sb[1] = Sb[1] * ge; kv = __builtin_fmaf(Sb[1], ka[u].y, kv);
+                Sb[2] = Sb[2] * ge; kv = __builtin_fmaf(Sb[2], ka[u].z, kv);
+                Sb[3] = Sb[3] * ge; kv = __builtin_fmaf(Sb[3], ka[u].w, kv);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) ka[u] = kb[u];
+        }
         const float delta = (vj - kv) * bt;
         float ob = 0.0f;
+        float4 qa[4] = {q4[0], q4[1], q4[2], q4[3]};
 #pragma unroll
-        for (int i = 0; i < DK; i++) { S[i] = __builtin_fmaf(ks[cur][i], delta, S[i]); ob = __builtin_fmaf(S[i], qs[cur][i], ob); }
+        for (int u = 0; u < 4; u++) ka[u] = k4[u];
+#pragma unroll
+        for (int b = 0; b < DK / 16; b++) {
+            float4 kb[4] = {ka[0], ka[1], ka[2], ka[3]}, qb[4] = {qa[0], qa[1], qa[2], qa[3]};
+            if (b + 1 < DK / 16) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) { kb[u] = k4[4 * b + 4 + u]; qb[u] = q4[4 * b + 4 + u]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float* Sb = S + 16 * b + 4 * u;
+                Sb[0] = __builtin_fmaf(ka[u].x, delta, Sb[0]); ob = __builtin_fmaf(Sb[0], qa[u].x, ob);
+                Sb[1] = __builtin_fmaf(ka[u].y, delta, Sb[1]); ob = __builtin_fmaf(Sb[1], qa[u].y, ob);
+                Sb[2] = __builtin_fmaf(ka[u].z, delta, Sb[2]); ob = __builtin_fmaf(Sb[2], qa[u].z, ob);
+                Sb[3] = __builtin_fmaf(ka[u].w, delta, Sb[3]); ob = __builtin_fmaf(Sb[3], qa[u].w, ob);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { ka[u] = kb[u]; qa[u] = qb[u]; }
+        }
         out[(size_t)t * nvdv + (size_t)h * dv + j] = ob;
-        if (pre) { ks[cur ^ 1][j] = kn; qs[cur ^ 1][j] = qn; }
+        if (more && j < DK) { ks[cur ^ 1][j] = kn; qs[cur ^ 1][j] = qn; }
+        ge = ge_n; bt = bt_n; vj = vj_n;
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < DK; i++) Sg[(size_t)i * dv] = S[i];
+    for (int i = 0; i < DK; i++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S[i]), srd, j * 4, i * dv * 4, 0);
 }
 
 // ---- gated RMSNorm + SiLU gate per (token, head) (decode.rs:3979); grid (nv, C), dv threads ----------------------------------
