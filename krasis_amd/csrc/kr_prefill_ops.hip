@@ -388,6 +388,92 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_scores_kernel(const KrPfmGqaAr
     }
 }
 
+// pass A, specialised: head_dim / 8 and the KV dtype are template parameters, so the per-lane loops carry no uniform guards (each
+// guarded LDS / global read would sit in its own basic block behind a wait), and the NEXT 32-position K tile is fetched into
+// registers while the current one is evaluated.  Same arithmetic, same order as the generic kernel above.
+template <bool FP8, int NB>
+__global__ void __launch_bounds__(256) kr_pfm_gqa_scores_t_kernel(const KrPfmGqaArgs a, float* __restrict__ sc, int sc_ld, int TT, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int hd = NB * 8, NCH = 32 * NB / 256;            // 16-byte (FP16) / 8-byte (E4M3) chunks of a K tile per thread
+    const int group = a.nh / a.nkv, kvh = blockIdx.z, t0 = blockIdx.y * TT, kvs = a.nkv * hd;
+    const int tn = min(TT, C - t0), R = group * tn;
+    const int p_lo = blockIdx.x * 256, p_max = a.pos0 + t0 + tn - 1;     // last position any query of the tile may see
+    if (p_lo > p_max) return;
+    float* qT = lds;                              // [R][8 lanes][PFA_LDB]   q[r][8b + l] at (r*8 + l)*PFA_LDB + b
+    float* kT = lds + (size_t)group * TT * 8 * PFA_LDB;   // [32 positions][8 lanes][PFA_LDB]
+    const int tid = threadIdx.x, g = tid >> 3, l = tid & 7;
+    u32x4 kw[NCH];
+    auto issue_k = [&](int pb) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int i = tid + 256 * c, pp = i / NB, b = i % NB, pos = pb + pp;
+            kw[c] = u32x4{0, 0, 0, 0};
+            if (pos <= p_max) {
+                if (FP8) { const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(a.k_cache) + (size_t)pos * kvs + (size_t)kvh * hd + b * 8); kw[c].x = w.x; kw[c].y = w.y; }
+                else kw[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(a.k_cache) + (size_t)pos * kvs + (size_t)kvh * hd + b * 8);
+            }
+        }
+    };
+    auto commit_k = [&]() {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int i = tid + 256 * c, pp = i / NB, b = i % NB;
+            const uint32_t ww[4] = {kw[c].x, kw[c].y, kw[c].z, kw[c].w};
+            if (FP8) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) kT[(pp * 8 + j) * PFA_LDB + b] = kr_e4m3_to_f32((uint8_t)(ww[j >> 2] >> (8 * (j & 3))));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    kT[(pp * 8 + 2 * j) * PFA_LDB + b] = __half2float(__ushort_as_half((uint16_t)(ww[j] & 0xFFFFu)));
+                    kT[(pp * 8 + 2 * j + 1) * PFA_LDB + b] = __half2float(__ushort_as_half((uint16_t)(ww[j] >> 16)));
+                }
+            }
+        }
+    };
+    issue_k(p_lo);
+    for (int i = tid; i < R * hd; i += 256) {
+        const int r = i / hd, d = i % hd, tt = r / group, hh = kvh * group + r % group;
+        qT[(r * 8 + (d & 7)) * PFA_LDB + (d >> 3)] = a.q_out[(size_t)(t0 + tt) * a.nh * hd + (size_t)hh * hd + d];
+    }
+    for (int pass = 0; pass < 8; pass++) {
+        const int pb = p_lo + pass * 32;
+        if (pb > p_max) break;
+        __syncthreads();                          // q staged / previous K tile consumed
+        commit_k();
+        if (pass + 1 < 8 && pb + 32 <= p_max) issue_k(pb + 32);
+        __syncthreads();
+        const int pos = pb + g;
+        float kr[NB];
+#pragma unroll
+        for (int b4 = 0; b4 < NB / 4; b4++) {
+            const float4 v = *reinterpret_cast<const float4*>(kT + (g * 8 + l) * PFA_LDB + b4 * 4);
+            kr[b4 * 4] = v.x; kr[b4 * 4 + 1] = v.y; kr[b4 * 4 + 2] = v.z; kr[b4 * 4 + 3] = v.w;
+        }
+        for (int r0 = 0; r0 < R; r0 += 4) {       // 4 queries at a time: 4 independent fma chains per lane
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float* qb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) qb[u] = qT + ((r0 + u < R ? r0 + u : R - 1) * 8 + l) * PFA_LDB;
+#pragma unroll
+            for (int b4 = 0; b4 < NB / 4; b4++) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float4 qv = *reinterpret_cast<const float4*>(qb[u] + b4 * 4);
+                    acc[u] = __builtin_fmaf(qv.x, kr[b4 * 4], acc[u]); acc[u] = __builtin_fmaf(qv.y, kr[b4 * 4 + 1], acc[u]);
+                    acc[u] = __builtin_fmaf(qv.z, kr[b4 * 4 + 2], acc[u]); acc[u] = __builtin_fmaf(qv.w, kr[b4 * 4 + 3], acc[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = r0 + u, tt = r / group, hh = kvh * group + r % group, qpos = a.pos0 + t0 + tt;
+                const float sv = kr_pfm_hsum8(acc[u]);
+                if (r < R && l == 0 && pos <= qpos) sc[((size_t)(t0 + tt) * a.nh + hh) * sc_ld + pos] = sv * a.sm_scale;
+            }
+        }
+    }
+}
+
 // pass B: per row  max -> e = exp(s - max) (libm) -> sequential sum in position order -> inv = 1 / sum  (decode.rs:4244-4262).
 // one wave per row: 64 positions at a time are exponentiated in parallel, lane 0 adds them in order.
 __global__ void __launch_bounds__(256) kr_pfm_gqa_softmax_kernel(float* __restrict__ sc, int sc_ld, float* __restrict__ inv, int nh, int pos0, int rows) {
@@ -422,8 +508,17 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_softmax_kernel(float* __restri
 
 // pass C: out[t][h][d] = chain_pos fma(e[pos] * inv, V[pos][d]) (decode.rs:4264-4273), gated by sigmoid(gate) (:4277).
 // grid (token tiles, nkv); thread d keeps one accumulator per query of the tile; V rows are read once per tile.
+// Memory never sits on the position loop: the KV dtype is a template parameter (a run-time branch around each V load would end
+// every load's basic block with a wait), the next 8 V rows are in flight while the current 8 are consumed, and the next 64-position
+// tile of probabilities is fetched into registers during the current tile and committed to the other half of a double-buffered
+// LDS image.  Every accumulator still sees its positions in ascending order.
+template <bool FP8> __device__ __forceinline__ float kr_pfm_v_load(const void* base, size_t i) {
+    if (FP8) return kr_e4m3_to_f32(reinterpret_cast<const uint8_t*>(base)[i]);
+    return __half2float(__ushort_as_half(reinterpret_cast<const uint16_t*>(base)[i]));
+}
+template <bool FP8>
 __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a, const float* __restrict__ sc, int sc_ld, const float* __restrict__ inv, int TT, int C) {
-    __shared__ __attribute__((aligned(16))) float P[PFA_TT_MAX][64];
+    __shared__ __attribute__((aligned(16))) float P[2][PFA_TT_MAX][64];
     __shared__ float s_inv[PFA_TT_MAX];
     const int hd = a.hd, group = a.nh / a.nkv, kvh = blockIdx.y, t0 = blockIdx.x * TT, kvs = a.nkv * hd;
     const int tn = min(TT, C - t0), R = group * tn, d = threadIdx.x, p_max = a.pos0 + t0 + tn - 1;
@@ -432,44 +527,64 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a
 #pragma unroll
     for (int r = 0; r < PFA_TT_MAX; r++) acc[r] = 0.0f;
     const size_t vcb = (size_t)kvh * hd + (d < hd ? d : 0);
-    for (int p0 = 0; p0 <= p_max; p0 += 64) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < R * 64; i += 256) {
-            const int r = i >> 6, pp = i & 63, tt = r / group, hh = kvh * group + r % group, pos = p0 + pp;
-            P[r][pp] = pos <= a.pos0 + t0 + tt ? sc[((size_t)(t0 + tt) * a.nh + hh) * sc_ld + pos] * s_inv[r] : 0.0f;   // sc[s] *= inv (decode.rs:4260)
-        }
-        __syncthreads();
-        const int np = min(64, p_max + 1 - p0);
-        if (p0 + 63 <= a.pos0 + t0 && R == PFA_TT_MAX) {   // tile entirely below the diagonal, full query tile: no masks, no branches
-            for (int pp0 = 0; pp0 < 64; pp0 += 4) {
-                float v[4];
+    // probability tile p0: element i = tid + 256 u  ->  query r = i / 64, position p0 + i % 64
+    constexpr int NPF = PFA_TT_MAX * 64 / 256;
+    float pf[NPF];
+    auto fetch_p = [&](int p0) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = kr_kv_load(a.v_cache, vcb + (size_t)(p0 + pp0 + u) * kvs, a.kv_fp8);
+        for (int u = 0; u < NPF; u++) {
+            const int i = d + 256 * u, r = i >> 6, pp = i & 63, tt = r / group, hh = kvh * group + r % group, pos = p0 + pp;
+            pf[u] = (r < R && pos <= a.pos0 + t0 + tt) ? sc[((size_t)(t0 + tt) * a.nh + hh) * sc_ld + pos] : 0.0f;
+        }
+    };
+    auto commit_p = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NPF; u++) { const int i = d + 256 * u, r = i >> 6, pp = i & 63; P[buf][r][pp] = r < R ? pf[u] * s_inv[r] : 0.0f; }   // sc[s] *= inv (decode.rs:4260)
+    };
+    fetch_p(0);
+    __syncthreads();                               // s_inv
+    commit_p(0);
+    float va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) va[u] = u <= p_max ? kr_pfm_v_load<FP8>(a.v_cache, vcb + (size_t)u * kvs) : 0.0f;
+    int cur = 0;
+    for (int p0 = 0; p0 <= p_max; p0 += 64, cur ^= 1) {
+        __syncthreads();                           // P[cur] committed; P[cur ^ 1] free
+        const bool more = p0 + 64 <= p_max;
+        if (more) fetch_p(p0 + 64);
+        const bool full = p0 + 63 <= a.pos0 + t0 && R == PFA_TT_MAX;   // tile entirely below the diagonal, full query tile: no masks
+        const int np = min(64, p_max + 1 - p0);
+#pragma unroll 1
+        for (int pp0 = 0; pp0 < 64; pp0 += 8) {
+            if (pp0 >= np) break;
+            const int nx = p0 + pp0 + 8;           // next batch of 8 rows (may belong to the next tile); rows past p_max are never used
+#pragma unroll
+            for (int u = 0; u < 8; u++) vb[u] = nx + u <= p_max ? kr_pfm_v_load<FP8>(a.v_cache, vcb + (size_t)(nx + u) * kvs) : 0.0f;
+            if (full) {
 #pragma unroll
                 for (int r = 0; r < PFA_TT_MAX; r++) {
-                    const float4 pr = *reinterpret_cast<const float4*>(&P[r][pp0]);
-                    acc[r] = __builtin_fmaf(pr.x, v[0], acc[r]); acc[r] = __builtin_fmaf(pr.y, v[1], acc[r]);
-                    acc[r] = __builtin_fmaf(pr.z, v[2], acc[r]); acc[r] = __builtin_fmaf(pr.w, v[3], acc[r]);
+                    const float4 p0v = *reinterpret_cast<const float4*>(&P[cur][r][pp0]), p1v = *reinterpret_cast<const float4*>(&P[cur][r][pp0 + 4]);
+                    acc[r] = __builtin_fmaf(p0v.x, va[0], acc[r]); acc[r] = __builtin_fmaf(p0v.y, va[1], acc[r]);
+                    acc[r] = __builtin_fmaf(p0v.z, va[2], acc[r]); acc[r] = __builtin_fmaf(p0v.w, va[3], acc[r]);
+                    acc[r] = __builtin_fmaf(p1v.x, va[4], acc[r]); acc[r] = __builtin_fmaf(p1v.y, va[5], acc[r]);
+                    acc[r] = __builtin_fmaf(p1v.z, va[6], acc[r]); acc[r] = __builtin_fmaf(p1v.w, va[7], acc[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < PFA_TT_MAX; r++) {
+                    if (r < R) {
+                        const int lim = min(a.pos0 + t0 + r / group - (p0 + pp0), np - 1 - pp0);   // positions pp0 + u with u <= lim are visible to query r
+                        const float4 p0v = *reinterpret_cast<const float4*>(&P[cur][r][pp0]), p1v = *reinterpret_cast<const float4*>(&P[cur][r][pp0 + 4]);
+                        const float pr[8] = {p0v.x, p0v.y, p0v.z, p0v.w, p1v.x, p1v.y, p1v.z, p1v.w};
+#pragma unroll
+                        for (int u = 0; u < 8; u++) if (u <= lim) acc[r] = __builtin_fmaf(pr[u], va[u], acc[r]);
+                    }
                 }
             }
-            continue;
-        }
-        for (int pp0 = 0; pp0 < np; pp0 += 4) {
-            float v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = (pp0 + u < np) ? kr_kv_load(a.v_cache, vcb + (size_t)(p0 + pp0 + u) * kvs, a.kv_fp8) : 0.0f;
-#pragma unroll
-            for (int r = 0; r < PFA_TT_MAX; r++) {
-                if (r < R) {
-                    const int lim = a.pos0 + t0 + r / group - (p0 + pp0);    // positions pp0 + u with u <= lim are visible to query r
-                    const float4 pr = *reinterpret_cast<const float4*>(&P[r][pp0]);
-                    if (lim >= 0) acc[r] = __builtin_fmaf(pr.x, v[0], acc[r]);
-                    if (lim >= 1 && pp0 + 1 < np) acc[r] = __builtin_fmaf(pr.y, v[1], acc[r]);
-                    if (lim >= 2 && pp0 + 2 < np) acc[r] = __builtin_fmaf(pr.z, v[2], acc[r]);
-                    if (lim >= 3 && pp0 + 3 < np) acc[r] = __builtin_fmaf(pr.w, v[3], acc[r]);
-                }
-            }
+            for (int u = 0; u < 8; u++) va[u] = vb[u];
         }
+        if (more) commit_p(cur ^ 1);
     }
     if (d < hd) {
 #pragma unroll
@@ -529,11 +644,23 @@ int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float*
     const int ntt = (C + TT - 1) / TT, npt = (a.pos0 + C + 255) / 256;
     const size_t lds = ((size_t)group * TT * 8 + 32 * 8) * PFA_LDB * 4;
     static bool big_lds_set = false;   // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950)
-    if (!big_lds_set) { (void)hipFuncSetAttribute((const void*)kr_pfm_gqa_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); big_lds_set = true; }
-    hipLaunchKernelGGL(kr_pfm_gqa_scores_kernel, dim3(npt, ntt, a.nkv), dim3(256), lds, st, a, sc, sc_ld, TT, C);
+    if (!big_lds_set) {
+        const void* fns[7] = {(const void*)kr_pfm_gqa_scores_kernel, (const void*)kr_pfm_gqa_scores_t_kernel<false, 8>, (const void*)kr_pfm_gqa_scores_t_kernel<false, 16>,
+                              (const void*)kr_pfm_gqa_scores_t_kernel<false, 32>, (const void*)kr_pfm_gqa_scores_t_kernel<true, 8>, (const void*)kr_pfm_gqa_scores_t_kernel<true, 16>,
+                              (const void*)kr_pfm_gqa_scores_t_kernel<true, 32>};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        big_lds_set = true;
+    }
+#define KR_SC(F_, N_) hipLaunchKernelGGL((kr_pfm_gqa_scores_t_kernel<F_, N_>), dim3(npt, ntt, a.nkv), dim3(256), lds, st, a, sc, sc_ld, TT, C)
+    if (a.hd == 256) { if (a.kv_fp8) KR_SC(true, 32); else KR_SC(false, 32); }
+    else if (a.hd == 128) { if (a.kv_fp8) KR_SC(true, 16); else KR_SC(false, 16); }
+    else if (a.hd == 64) { if (a.kv_fp8) KR_SC(true, 8); else KR_SC(false, 8); }
+    else hipLaunchKernelGGL(kr_pfm_gqa_scores_kernel, dim3(npt, ntt, a.nkv), dim3(256), lds, st, a, sc, sc_ld, TT, C);
+#undef KR_SC
     const int rows = C * a.nh;
     hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, a.nh, a.pos0, rows);
-    hipLaunchKernelGGL(kr_pfm_gqa_pv_kernel, dim3(ntt, a.nkv), dim3(256), 0, st, a, sc, sc_ld, inv, TT, C);
+    if (a.kv_fp8) hipLaunchKernelGGL(kr_pfm_gqa_pv_kernel<true>, dim3(ntt, a.nkv), dim3(256), 0, st, a, sc, sc_ld, inv, TT, C);
+    else hipLaunchKernelGGL(kr_pfm_gqa_pv_kernel<false>, dim3(ntt, a.nkv), dim3(256), 0, st, a, sc, sc_ld, inv, TT, C);
     return 0;
 }
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st) {
