@@ -503,88 +503,79 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_softmax_kernel(float* __restri
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0) inv[row] = 1.0f / se;
+    // sc[s] *= inv (decode.rs:4260): the row leaves this pass as probabilities, so pass C reads them as they are
+    const float iv = __shfl(1.0f / se, 0);
+    if (lane == 0) inv[row] = iv;
+    for (int p = lane; p < seq; p += 64) s[p] = s[p] * iv;
 }
 
-// pass C: out[t][h][d] = chain_pos fma(e[pos] * inv, V[pos][d]) (decode.rs:4264-4273), gated by sigmoid(gate) (:4277).
+// pass C: out[t][h][d] = chain_pos fma(p[pos], V[pos][d]) (decode.rs:4264-4273), gated by sigmoid(gate) (:4277).
 // grid (token tiles, nkv); thread d keeps one accumulator per query of the tile; V rows are read once per tile.
-// Memory never sits on the position loop: the KV dtype is a template parameter (a run-time branch around each V load would end
-// every load's basic block with a wait), the next 8 V rows are in flight while the current 8 are consumed, and the next 64-position
-// tile of probabilities is fetched into registers during the current tile and committed to the other half of a double-buffered
-// LDS image.  Every accumulator still sees its positions in ascending order.
+// The probabilities are the same for every thread of the workgroup, so they are SCALAR loads (constant address space ->
+// s_load_dwordx8 into SGPRs, consumed as the scalar operand of v_fmac): no LDS image, no barriers, and nothing competes with the VALU
+// for LDS return bandwidth (the LDS-staged form spent 8 LDS cycles per 16 fma cycles).  The KV dtype is a template parameter and the
+// next 8 V rows are in flight while the current 8 are consumed.  Every accumulator sees its positions in ascending order.
 template <bool FP8> __device__ __forceinline__ float kr_pfm_v_load(const void* base, size_t i) {
     if (FP8) return kr_e4m3_to_f32(reinterpret_cast<const uint8_t*>(base)[i]);
     return __half2float(__ushort_as_half(reinterpret_cast<const uint16_t*>(base)[i]));
 }
-template <bool FP8>
-__global__ void __launch_bounds__(256) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a, const float* __restrict__ sc, int sc_ld, const float* __restrict__ inv, int TT, int C) {
-    __shared__ __attribute__((aligned(16))) float P[2][PFA_TT_MAX][64];
-    __shared__ float s_inv[PFA_TT_MAX];
-    const int hd = a.hd, group = a.nh / a.nkv, kvh = blockIdx.y, t0 = blockIdx.x * TT, kvs = a.nkv * hd;
+typedef float kr_f8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) kr_f8* kr_cf8_ptr;
+template <bool FP8, int GROUP>     // GROUP = query heads per KV head as a constant (r / group, r % group fold away); 0 = run-time value
+__global__ void __launch_bounds__(256) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a, const float* __restrict__ sc, int sc_ld, int TT, int C) {
+    const int hd = a.hd, group = GROUP ? GROUP : a.nh / a.nkv, kvh = blockIdx.y, t0 = blockIdx.x * TT, kvs = a.nkv * hd;
     const int tn = min(TT, C - t0), R = group * tn, d = threadIdx.x, p_max = a.pos0 + t0 + tn - 1;
-    if (d < R) { const int tt = d / group, hh = kvh * group + d % group; s_inv[d] = inv[(size_t)(t0 + tt) * a.nh + hh]; }
     float acc[PFA_TT_MAX];
 #pragma unroll
     for (int r = 0; r < PFA_TT_MAX; r++) acc[r] = 0.0f;
     const size_t vcb = (size_t)kvh * hd + (d < hd ? d : 0);
-    // probability tile p0: element i = tid + 256 u  ->  query r = i / 64, position p0 + i % 64
-    constexpr int NPF = PFA_TT_MAX * 64 / 256;
-    float pf[NPF];
-    auto fetch_p = [&](int p0) {
-#pragma unroll
-        for (int u = 0; u < NPF; u++) {
-            const int i = d + 256 * u, r = i >> 6, pp = i & 63, tt = r / group, hh = kvh * group + r % group, pos = p0 + pp;
-            pf[u] = (r < R && pos <= a.pos0 + t0 + tt) ? sc[((size_t)(t0 + tt) * a.nh + hh) * sc_ld + pos] : 0.0f;
-        }
-    };
-    auto commit_p = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < NPF; u++) { const int i = d + 256 * u, r = i >> 6, pp = i & 63; P[buf][r][pp] = r < R ? pf[u] * s_inv[r] : 0.0f; }   // sc[s] *= inv (decode.rs:4260)
-    };
-    fetch_p(0);
-    __syncthreads();                               // s_inv
-    commit_p(0);
+    // query r of the tile = (token t0 + r / group, head kvh * group + r % group)
     float va[8], vb[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) va[u] = u <= p_max ? kr_pfm_v_load<FP8>(a.v_cache, vcb + (size_t)u * kvs) : 0.0f;
-    int cur = 0;
-    for (int p0 = 0; p0 <= p_max; p0 += 64, cur ^= 1) {
-        __syncthreads();                           // P[cur] committed; P[cur ^ 1] free
-        const bool more = p0 + 64 <= p_max;
-        if (more) fetch_p(p0 + 64);
-        const bool full = p0 + 63 <= a.pos0 + t0 && R == PFA_TT_MAX;   // tile entirely below the diagonal, full query tile: no masks
-        const int np = min(64, p_max + 1 - p0);
-#pragma unroll 1
-        for (int pp0 = 0; pp0 < 64; pp0 += 8) {
-            if (pp0 >= np) break;
-            const int nx = p0 + pp0 + 8;           // next batch of 8 rows (may belong to the next tile); rows past p_max are never used
+    const int tok_ld = a.nh * sc_ld;               // row (t, h) of the probabilities = t * tok_ld + h * sc_ld
+    for (int p0 = 0; p0 <= p_max; p0 += 8) {
+        // the 32 row addresses are recomputed per batch from an opaque zero (a handful of scalar ops per row, hidden behind the other
+        // waves' fma work): left loop-invariant they are hoisted, need 64 SGPRs and spill into VGPR lanes
+        int zo;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zo));
+        const float* scb = sc + (size_t)(t0 * tok_ld + kvh * group * sc_ld + zo) + p0;
+        auto prow = [&](int r) { return scb + (r / group) * tok_ld + (r % group) * sc_ld; };
+        const int nx = p0 + 8;                     // next 8 rows; rows past p_max are never used
 #pragma unroll
-            for (int u = 0; u < 8; u++) vb[u] = nx + u <= p_max ? kr_pfm_v_load<FP8>(a.v_cache, vcb + (size_t)(nx + u) * kvs) : 0.0f;
-            if (full) {
+        for (int u = 0; u < 8; u++) vb[u] = nx + u <= p_max ? kr_pfm_v_load<FP8>(a.v_cache, vcb + (size_t)(nx + u) * kvs) : 0.0f;
+        if (p0 + 7 <= a.pos0 + t0 && R == PFA_TT_MAX) {   // all 8 positions visible to every query of a full tile: no masks
+            // 4 queries per group: their scalar loads are issued together (scalar loads return out of order, so every wait drains
+            // all of them -- one wait per 32 fma steps; 32 SGPRs of probabilities live at a time)
 #pragma unroll
-                for (int r = 0; r < PFA_TT_MAX; r++) {
-                    const float4 p0v = *reinterpret_cast<const float4*>(&P[cur][r][pp0]), p1v = *reinterpret_cast<const float4*>(&P[cur][r][pp0 + 4]);
-                    acc[r] = __builtin_fmaf(p0v.x, va[0], acc[r]); acc[r] = __builtin_fmaf(p0v.y, va[1], acc[r]);
-                    acc[r] = __builtin_fmaf(p0v.z, va[2], acc[r]); acc[r] = __builtin_fmaf(p0v.w, va[3], acc[r]);
-                    acc[r] = __builtin_fmaf(p1v.x, va[4], acc[r]); acc[r] = __builtin_fmaf(p1v.y, va[5], acc[r]);
-                    acc[r] = __builtin_fmaf(p1v.z, va[6], acc[r]); acc[r] = __builtin_fmaf(p1v.w, va[7], acc[r]);
+            for (int r0 = 0; r0 < PFA_TT_MAX; r0 += 4) {
+                kr_f8 pv[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) pv[q4] = *(kr_cf8_ptr)(uintptr_t)prow(r0 + q4);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const int r = r0 + q4;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc[r] = __builtin_fmaf(pv[q4][u], va[u], acc[r]);
                 }
-            } else {
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
-                for (int r = 0; r < PFA_TT_MAX; r++) {
-                    if (r < R) {
-                        const int lim = min(a.pos0 + t0 + r / group - (p0 + pp0), np - 1 - pp0);   // positions pp0 + u with u <= lim are visible to query r
-                        const float4 p0v = *reinterpret_cast<const float4*>(&P[cur][r][pp0]), p1v = *reinterpret_cast<const float4*>(&P[cur][r][pp0 + 4]);
-                        const float pr[8] = {p0v.x, p0v.y, p0v.z, p0v.w, p1v.x, p1v.y, p1v.z, p1v.w};
+            for (int r = 0; r < PFA_TT_MAX; r++) {
+                if (r < R) {
+                    const int lim = a.pos0 + t0 + r / group - p0;            // positions p0 + u with u <= lim are visible to query r
+                    if (lim >= 0) {
+                        const kr_f8 pv = *(kr_cf8_ptr)(uintptr_t)prow(r);   // row stride is a multiple of 64 floats: in bounds
 #pragma unroll
-                        for (int u = 0; u < 8; u++) if (u <= lim) acc[r] = __builtin_fmaf(pr[u], va[u], acc[r]);
+                        for (int u = 0; u < 8; u++) if (u <= lim) acc[r] = __builtin_fmaf(pv[u], va[u], acc[r]);
                     }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 8; u++) va[u] = vb[u];
         }
-        if (more) commit_p(cur ^ 1);
+#pragma unroll
+        for (int u = 0; u < 8; u++) va[u] = vb[u];
     }
     if (d < hd) {
 #pragma unroll
@@ -659,8 +650,12 @@ int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float*
 #undef KR_SC
     const int rows = C * a.nh;
     hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, a.nh, a.pos0, rows);
-    if (a.kv_fp8) hipLaunchKernelGGL(kr_pfm_gqa_pv_kernel<true>, dim3(ntt, a.nkv), dim3(256), 0, st, a, sc, sc_ld, inv, TT, C);
-    else hipLaunchKernelGGL(kr_pfm_gqa_pv_kernel<false>, dim3(ntt, a.nkv), dim3(256), 0, st, a, sc, sc_ld, inv, TT, C);
+#define KR_PV(F_, G_) hipLaunchKernelGGL((kr_pfm_gqa_pv_kernel<F_, G_>), dim3(ntt, a.nkv), dim3(256), 0, st, a, sc, sc_ld, TT, C)
+#define KR_PVG(F_) do { switch (group) { case 1: KR_PV(F_, 1); break; case 2: KR_PV(F_, 2); break; case 4: KR_PV(F_, 4); break; case 8: KR_PV(F_, 8); break; \
+                                       case 16: KR_PV(F_, 16); break; default: KR_PV(F_, 0); } } while (0)
+    if (a.kv_fp8) KR_PVG(true); else KR_PVG(false);
+#undef KR_PVG
+#undef KR_PV
     return 0;
 }
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st) {
