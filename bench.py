@@ -166,7 +166,7 @@ def prefill_experts(eng, L, M, torch):
     return {"tokens": M, "layers": L, "ms": ms, "tok_s_experts_only": M / (ms * 1e-3), "int8_TOPS_issued": tops,
             "mfma_i8_dense_peak_TOPS": 4400.0, "frac_of_i8_peak": tops / 4400.0,
             "effective_TFLOPs_2MAC": 2.0 * macs / (ms * 1e-3) / 1e12,
-            "note": "experts only (sort + 2 grouped GEMMs + act + combine); attention prefill kernels not built in this round"}
+            "note": "experts only (sort + 2 grouped GEMMs + act + combine): the MFMA-bound part of the prompt pass in isolation"}
 
 
 def prefill_model(st, L, P, reps, torch):
