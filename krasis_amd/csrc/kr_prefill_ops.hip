@@ -510,80 +510,142 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_softmax_kernel(float* __restri
 }
 
 // pass C: out[t][h][d] = chain_pos fma(p[pos], V[pos][d]) (decode.rs:4264-4273), gated by sigmoid(gate) (:4277).
-// grid (token tiles, nkv); thread d keeps one accumulator per query of the tile; V rows are read once per tile.
-// The probabilities are the same for every thread of the workgroup, so they are SCALAR loads (constant address space ->
-// s_load_dwordx8 into SGPRs, consumed as the scalar operand of v_fmac): no LDS image, no barriers, and nothing competes with the VALU
-// for LDS return bandwidth (the LDS-staged form spent 8 LDS cycles per 16 fma cycles).  The KV dtype is a template parameter and the
-// next 8 V rows are in flight while the current 8 are consumed.  Every accumulator sees its positions in ascending order.
-template <bool FP8> __device__ __forceinline__ float kr_pfm_v_load(const void* base, size_t i) {
-    if (FP8) return kr_e4m3_to_f32(reinterpret_cast<const uint8_t*>(base)[i]);
-    return __half2float(__ushort_as_half(reinterpret_cast<const uint16_t*>(base)[i]));
+// grid (token tiles, nkv), ONE wave per workgroup; lane l owns CPL = head_dim / 64 adjacent value columns and keeps one accumulator
+// per (query of the tile, column).  The probabilities are the same for every lane, so each one read from the LDS image (a broadcast
+// ds_read_b128 carries 4 of them) feeds CPL fma per lane: with 4 columns per lane the LDS return path (1 KiB per wave64 b128 read,
+// 8 LDS cycles) stays at half the VALU time instead of twice it (the 1-column form), and the scalar-load form (3.4 ms per chunk) was
+// bound by the scalar cache streaming a 1 GB score scratch.  The next 64-position tile of probabilities is fetched into registers
+// during the current tile (double-buffered LDS image), the next 8 V rows are in flight while the current 8 are consumed, and the KV
+// dtype / GQA group / columns per lane are template parameters.  Every accumulator sees its positions in ascending order.
+template <bool FP8, int CPL> __device__ __forceinline__ void kr_pfm_v_load(const void* base, size_t i, float (&v)[CPL]) {
+    if (FP8) {
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(base) + i;
+        uint32_t w;
+        if (CPL == 4) w = *reinterpret_cast<const uint32_t*>(p); else if (CPL == 2) w = *reinterpret_cast<const uint16_t*>(p); else w = *p;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) v[c] = kr_e4m3_to_f32((uint8_t)(w >> (8 * c)));
+    } else {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + i;
+        uint32_t w0 = 0, w1 = 0;
+        if (CPL == 4) { const u32x2 w = *reinterpret_cast<const u32x2*>(p); w0 = w.x; w1 = w.y; }
+        else if (CPL == 2) w0 = *reinterpret_cast<const uint32_t*>(p);
+        else w0 = *p;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) { const uint32_t w = c < 2 ? w0 : w1; v[c] = __half2float(__ushort_as_half((uint16_t)(w >> (16 * (c & 1))))); }
+    }
 }
-typedef float kr_f8 __attribute__((ext_vector_type(8)));
-typedef const __attribute__((address_space(4))) kr_f8* kr_cf8_ptr;
-template <bool FP8, int GROUP>     // GROUP = query heads per KV head as a constant (r / group, r % group fold away); 0 = run-time value
-__global__ void __launch_bounds__(256) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a, const float* __restrict__ sc, int sc_ld, int TT, int C) {
+#define PFV_R 16               // queries per pass-C workgroup (one wave): 64 accumulators per lane at 4 columns, two waves per SIMD
+template <bool FP8, int GROUP, int CPL>     // GROUP = query heads per KV head (0 = run-time value); CPL = head_dim / 64
+__global__ void __launch_bounds__(64) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a, const float* __restrict__ sc, int sc_ld, int TT, int C) {
+    __shared__ __attribute__((aligned(16))) float P[2][PFV_R][64];
     const int hd = a.hd, group = GROUP ? GROUP : a.nh / a.nkv, kvh = blockIdx.y, t0 = blockIdx.x * TT, kvs = a.nkv * hd;
-    const int tn = min(TT, C - t0), R = group * tn, d = threadIdx.x, p_max = a.pos0 + t0 + tn - 1;
-    float acc[PFA_TT_MAX];
+    const int tn = min(TT, C - t0), R = group * tn, lane = threadIdx.x, p_max = a.pos0 + t0 + tn - 1;
+    float acc[PFV_R][CPL];
 #pragma unroll
-    for (int r = 0; r < PFA_TT_MAX; r++) acc[r] = 0.0f;
-    const size_t vcb = (size_t)kvh * hd + (d < hd ? d : 0);
-    // query r of the tile = (token t0 + r / group, head kvh * group + r % group)
-    float va[8], vb[8];
+    for (int r = 0; r < PFV_R; r++)
 #pragma unroll
-    for (int u = 0; u < 8; u++) va[u] = u <= p_max ? kr_pfm_v_load<FP8>(a.v_cache, vcb + (size_t)u * kvs) : 0.0f;
-    const int tok_ld = a.nh * sc_ld;               // row (t, h) of the probabilities = t * tok_ld + h * sc_ld
-    for (int p0 = 0; p0 <= p_max; p0 += 8) {
-        // the 32 row addresses are recomputed per batch from an opaque zero (a handful of scalar ops per row, hidden behind the other
-        // waves' fma work): left loop-invariant they are hoisted, need 64 SGPRs and spill into VGPR lanes
-        int zo;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(zo));
-        const float* scb = sc + (size_t)(t0 * tok_ld + kvh * group * sc_ld + zo) + p0;
-        auto prow = [&](int r) { return scb + (r / group) * tok_ld + (r % group) * sc_ld; };
-        const int nx = p0 + 8;                     // next 8 rows; rows past p_max are never used
+        for (int c = 0; c < CPL; c++) acc[r][c] = 0.0f;
+    const size_t vcb = (size_t)kvh * hd + (size_t)lane * CPL;
+    // probability tile p0: row r = query r of the tile, column = position p0 + lane
+    // buffer addressing: descriptor = this tile's rows, voffset = lane, soffset = row / tile offset (scalar) -- 32 row pointers would
+    // otherwise stay live in 64 VGPRs
+    const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc) + ((size_t)t0 * a.nh + (size_t)kvh * group) * sc_ld, 0,
+                                                                          (int)(((size_t)(tn - 1) * a.nh + group) * sc_ld * 4), 0x00020000);
+    float pf[PFV_R];
+    auto fetch_p = [&](int p0) {
+        const int pos = p0 + lane;
 #pragma unroll
-        for (int u = 0; u < 8; u++) vb[u] = nx + u <= p_max ? kr_pfm_v_load<FP8>(a.v_cache, vcb + (size_t)(nx + u) * kvs) : 0.0f;
-        if (p0 + 7 <= a.pos0 + t0 && R == PFA_TT_MAX) {   // all 8 positions visible to every query of a full tile: no masks
-            // 4 queries per group: their scalar loads are issued together (scalar loads return out of order, so every wait drains
-            // all of them -- one wait per 32 fma steps; 32 SGPRs of probabilities live at a time)
+        for (int r = 0; r < PFV_R; r++) {
+            const int tt = r / group, g = r % group;
+            const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(psrd, lane * 4, ((tt * a.nh + g) * sc_ld + p0) * 4, 0));   // rows past the tile: out of range -> 0
+            pf[r] = (r < R && pos <= a.pos0 + t0 + tt) ? v : 0.0f;
+        }
+    };
+    auto commit_p = [&](int buf) {
 #pragma unroll
-            for (int r0 = 0; r0 < PFA_TT_MAX; r0 += 4) {
-                kr_f8 pv[4];
+        for (int r = 0; r < PFV_R; r++) P[buf][r][lane] = pf[r];
+    };
+    fetch_p(0);
+    commit_p(0);
+    float va[8][CPL], vb[8][CPL];
+    // V rows are loaded UNCONDITIONALLY (row index clamped to p_max; rows past it are never consumed): a guard around a load + its
+    // conversion puts each load in its own basic block behind a wait -- one exposed memory latency per position
 #pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) pv[q4] = *(kr_cf8_ptr)(uintptr_t)prow(r0 + q4);
-                __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < 8; u++) kr_pfm_v_load<FP8, CPL>(a.v_cache, vcb + (size_t)min(u, p_max) * kvs, va[u]);
+    int cur = 0;
+    for (int p0 = 0; p0 <= p_max; p0 += 64, cur ^= 1) {
+        __syncthreads();                           // one wave: P[cur] committed, P[cur ^ 1] free
+        const bool more = p0 + 64 <= p_max;
+        if (more) fetch_p(p0 + 64);
+        const bool full = p0 + 63 <= a.pos0 + t0 && R == PFV_R;   // tile entirely below the diagonal, full query tile: no masks
+        const int np = min(64, p_max + 1 - p0);
+#pragma unroll 1
+        for (int pp0 = 0; pp0 < 64; pp0 += 8) {
+            if (pp0 >= np) break;
+            const int nx = p0 + pp0 + 8;           // next 8 rows (may belong to the next tile); rows past p_max are never used
 #pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const int r = r0 + q4;
+            for (int u = 0; u < 8; u++) kr_pfm_v_load<FP8, CPL>(a.v_cache, vcb + (size_t)min(nx + u, p_max) * kvs, vb[u]);
+            if (full) {
+                // rows in groups of 4, the next group's probabilities (8 broadcast ds_read_b128) in flight under the current group's
+                // 4 * 8 * CPL fma; the scheduling barriers keep the compiler from hoisting all 64 reads (256 registers) up front
+                float4 pa[8], pb[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) acc[r] = __builtin_fmaf(pv[q4][u], va[u], acc[r]);
+                for (int q4 = 0; q4 < 4; q4++) { pa[2 * q4] = *reinterpret_cast<const float4*>(&P[cur][q4][pp0]); pa[2 * q4 + 1] = *reinterpret_cast<const float4*>(&P[cur][q4][pp0 + 4]); }
+#pragma unroll
+                for (int r0 = 0; r0 < PFV_R; r0 += 4) {
+                    if (r0 + 4 < PFV_R) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) { pb[2 * q4] = *reinterpret_cast<const float4*>(&P[cur][r0 + 4 + q4][pp0]); pb[2 * q4 + 1] = *reinterpret_cast<const float4*>(&P[cur][r0 + 4 + q4][pp0 + 4]); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // position-major issue order: the 4 * CPL accumulators of the group advance one position at a time, so consecutive
+                    // instructions are independent (each accumulator still takes its 8 positions in ascending order)
+                    float pr[4][8];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        pr[q4][0] = pa[2 * q4].x; pr[q4][1] = pa[2 * q4].y; pr[q4][2] = pa[2 * q4].z; pr[q4][3] = pa[2 * q4].w;
+                        pr[q4][4] = pa[2 * q4 + 1].x; pr[q4][5] = pa[2 * q4 + 1].y; pr[q4][6] = pa[2 * q4 + 1].z; pr[q4][7] = pa[2 * q4 + 1].w;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++)
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) acc[r0 + q4][c] = __builtin_fmaf(pr[q4][u], va[u][c], acc[r0 + q4][c]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; q8++) pa[q8] = pb[q8];
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
+            } else {
 #pragma unroll
-            for (int r = 0; r < PFA_TT_MAX; r++) {
-                if (r < R) {
-                    const int lim = a.pos0 + t0 + r / group - p0;            // positions p0 + u with u <= lim are visible to query r
-                    if (lim >= 0) {
-                        const kr_f8 pv = *(kr_cf8_ptr)(uintptr_t)prow(r);   // row stride is a multiple of 64 floats: in bounds
+                for (int r = 0; r < PFV_R; r++) {
+                    if (r < R) {
+                        const int lim = min(a.pos0 + t0 + r / group - (p0 + pp0), np - 1 - pp0);   // positions pp0 + u with u <= lim are visible to query r
+                        const float4 p0v = *reinterpret_cast<const float4*>(&P[cur][r][pp0]), p1v = *reinterpret_cast<const float4*>(&P[cur][r][pp0 + 4]);
+                        const float pr[8] = {p0v.x, p0v.y, p0v.z, p0v.w, p1v.x, p1v.y, p1v.z, p1v.w};
 #pragma unroll
-                        for (int u = 0; u < 8; u++) if (u <= lim) acc[r] = __builtin_fmaf(pv[u], va[u], acc[r]);
+                        for (int u = 0; u < 8; u++)
+                            if (u <= lim)
+#pragma unroll
+                                for (int c = 0; c < CPL; c++) acc[r][c] = __builtin_fmaf(pr[u], va[u][c], acc[r][c]);
                     }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int c = 0; c < CPL; c++) va[u][c] = vb[u][c];
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) va[u] = vb[u];
+        if (more) commit_p(cur ^ 1);
     }
-    if (d < hd) {
 #pragma unroll
-        for (int r = 0; r < PFA_TT_MAX; r++) {
-            if (r < R) {
-                const int tt = r / group, hh = kvh * group + r % group;
-                float o = acc[r];
-                const size_t oi = (size_t)(t0 + tt) * a.nh * hd + (size_t)hh * hd + d;
+    for (int r = 0; r < PFV_R; r++) {
+        if (r < R) {
+            const int tt = r / group, hh = kvh * group + r % group;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                float o = acc[r][c];
+                const size_t oi = (size_t)(t0 + tt) * a.nh * hd + (size_t)hh * hd + (size_t)lane * CPL + c;
                 if (a.gated) { const float gt = a.gate[oi]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
                 a.attn_out[oi] = o;
             }
@@ -650,10 +712,15 @@ int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float*
 #undef KR_SC
     const int rows = C * a.nh;
     hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, a.nh, a.pos0, rows);
-#define KR_PV(F_, G_) hipLaunchKernelGGL((kr_pfm_gqa_pv_kernel<F_, G_>), dim3(ntt, a.nkv), dim3(256), 0, st, a, sc, sc_ld, TT, C)
-#define KR_PVG(F_) do { switch (group) { case 1: KR_PV(F_, 1); break; case 2: KR_PV(F_, 2); break; case 4: KR_PV(F_, 4); break; case 8: KR_PV(F_, 8); break; \
-                                       case 16: KR_PV(F_, 16); break; default: KR_PV(F_, 0); } } while (0)
-    if (a.kv_fp8) KR_PVG(true); else KR_PVG(false);
+    const int TTV = PFV_R / group < 1 ? 0 : PFV_R / group, nttv = TTV ? (C + TTV - 1) / TTV : 0;   // pass C has its own (smaller) token tile
+    if (!TTV) return 1;
+#define KR_PV(F_, G_, C_) hipLaunchKernelGGL((kr_pfm_gqa_pv_kernel<F_, G_, C_>), dim3(nttv, a.nkv), dim3(64), 0, st, a, sc, sc_ld, TTV, C)
+#define KR_PVG(F_, C_) do { switch (group) { case 1: KR_PV(F_, 1, C_); break; case 2: KR_PV(F_, 2, C_); break; case 4: KR_PV(F_, 4, C_); break; case 8: KR_PV(F_, 8, C_); break; \
+                                           case 16: KR_PV(F_, 16, C_); break; default: KR_PV(F_, 0, C_); } } while (0)
+    if (a.hd == 256) { if (a.kv_fp8) KR_PVG(true, 4); else KR_PVG(false, 4); }
+    else if (a.hd == 128) { if (a.kv_fp8) KR_PVG(true, 2); else KR_PVG(false, 2); }
+    else if (a.hd == 64) { if (a.kv_fp8) KR_PVG(true, 1); else KR_PVG(false, 1); }
+    else return 1;
 #undef KR_PVG
 #undef KR_PV
     return 0;
