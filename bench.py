@@ -319,7 +319,7 @@ def main():
         if args.prefill_depth:
             st.set_prefill_depth(args.prefill_depth)
         prefill_full = prefill_model(st, L, args.prefill_tokens, args.prefill_reps, torch)
-        prefill_full["chunk"] = args.prefill_chunk or 2048
+        prefill_full["chunk"] = args.prefill_chunk or 1024; prefill_full["chunks_in_flight"] = args.prefill_depth or 3
 
     if rank == 0:
         ab = algorithmic_bytes(L)

@@ -193,13 +193,12 @@ int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype);                   
  * (decode_setup.py:232-278): tokens[0..n) (host ints) at positions start_pos.. are run through every layer in chunks; afterwards the
  * logits of the LAST token (optional host/device f32 [vocab]), the greedy sample (kr_decode_last_token), the FP16 KV caches and the
  * conv / recurrent states are bit-identical to n successive kr_decode_step calls (decode.rs:2690-3520).  GEMM-shaped work runs on the
- * int8-MFMA grouped GEMM with the exact INT16-digit arithmetic.  INT4-g128 weights; LA and GQA layers (MLA prompts go through
- * kr_decode_step). */
+ * int8-MFMA grouped GEMM with the exact INT16-digit arithmetic.  INT4 / INT8-g128 weights; linear-attention, GQA and MLA layers. */
 int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int n_tokens, int start_pos, float* logits_out, void* stream);
-/* tokens per chunk of the prompt pass (0 = default 2048).  Chunks alternate between two HIP streams and two scratch arenas: layer l of
+/* tokens per chunk of the prompt pass (0 = default 1024).  Chunks rotate over `depth` HIP streams and scratch arenas: layer l of
  * chunk c+1 runs concurrently with layer l+1 of chunk c (per-layer events carry the state / KV dependencies). */
 int kr_decode_set_prefill_chunk(kr_decode_store* s, int chunk);
-int kr_decode_set_prefill_depth(kr_decode_store* s, int depth);   /* chunks in flight = streams = scratch arenas, 1..4 (0 = default 2) */
+int kr_decode_set_prefill_depth(kr_decode_store* s, int depth);   /* chunks in flight = streams = scratch arenas, 1..4 (0 = default 3) */
 /* set_decode_state (decode.rs:2640): per-layer host pointers (NULL = not applicable / zero-init) */
 int kr_decode_set_state(kr_decode_store* s, int seq_len, int kv_max_seq, const uint16_t* const* kv_k, const uint16_t* const* kv_v,
                         const float* const* conv_state, const float* const* recur_state);

@@ -18,7 +18,8 @@
 #include "kr_prefill_ops.h"
 #include "kr_router.h"
 
-#define KR_PFM_CHUNK 2048
+#define KR_PFM_CHUNK 1024     // tokens per chunk; with KR_PFM_DEPTH chunks in flight (sweep in tools/dbg/sweep_depth.sh: 1024 x 3 beats 2048 x 2 at 4k / 8k / 20k prompts)
+#define KR_PFM_DEPTH 3
 
 namespace {
 struct Scratch {   // carved from one allocation per arena (grown on demand)
@@ -181,7 +182,7 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
     const int H = s->hidden;
     if (H % 128) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill needs hidden %% 128 == 0");
     const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : KR_PFM_CHUNK);
-    const int depth = s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : 2;        // chunks in flight (streams / arenas)
+    const int depth = s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : KR_PFM_DEPTH;   // chunks in flight (streams / arenas)
     const int n_chunks = (n_tokens + CH - 1) / CH, n_arenas = std::min(n_chunks, depth), D = n_arenas;
     const int L = (int)s->layers.size();
 
@@ -306,7 +307,7 @@ extern "C" int kr_decode_set_prefill_depth(kr_decode_store* s, int depth) {
     return KR_OK;
 }
 
-// test / tuning hook: tokens per chunk of the prompt pass (0 = default 2048)
+// test / tuning hook: tokens per chunk of the prompt pass (0 = default 1024)
 extern "C" int kr_decode_set_prefill_chunk(kr_decode_store* s, int chunk) {
     if (!s) return kr_fail(KR_ERR_VALUE, "null decode store");
     if (chunk < 0 || chunk > 8192) return kr_fail(KR_ERR_VALUE, "prefill chunk %d out of range [0, 8192]", chunk);

@@ -1,1 +1,4 @@
-for dp in 2 3 4; do python bench.py --steps 2 --warmup 1 --no-cpu-baseline --prefill-tokens 20480 --prefill-reps 1 --prefill-depth $dp 2>&1 | tail -1 > gpurun_out/sw_$dp.json; done
+# prompt-pass sweep: prompt length x chunk size x chunks in flight (bench.py builds the model once per run)
+for tk in 4096 20480; do for cfg in "512 3" "512 4" "1024 3" "2048 2"; do set -- $cfg
+  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --prefill-tokens $tk --prefill-reps 2 --prefill-chunk $1 --prefill-depth $2 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('tokens $tk chunk $1 depth $2', round(d['prefill']['value']))"
+done; done
