@@ -15,12 +15,12 @@ def _ptr(a):
     return a.ctypes.data
 
 
-def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64):
+def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4):
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     rng = np.random.default_rng(seed)
     H, V, E, k, I, SI = 256, 512, 16, 4, 128, 128
     nk, nv, dk, dv = 2, 4, 128, 128
-    nh, nkv, d2 = 4, 2, 8
+    nkv, d2 = 2, 8
     kinds = ["la", "gqa", "la"] + (["gqa"] if with_dense else [])
     nL = len(kinds)
     emb = ((rng.random((V, H)) - 0.5) * 0.2).astype(F)
@@ -120,7 +120,7 @@ def test_decode_step_bit_exact(cfg, graph):
             assert np.array_equal(kc, L["kv_k"]) and np.array_equal(vc, L["kv_v"])
 
 
-@pytest.mark.parametrize("hd", [64, 128])
+@pytest.mark.parametrize("hd", [64, 128, 256])
 def test_decode_step_long_positions_bit_exact(hd):
     """positions past one / two 128-row stages of the attention kernel's K / V staging (decode.rs:4194 order kept across stages)"""
     st, eng, orc, keep, d = build(seed=5, kv_max=300, hd=hd)

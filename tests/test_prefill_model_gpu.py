@@ -52,6 +52,49 @@ def test_prefill_equals_sequential_decode(cfg, n_tok, start, chunk, depth):
     assert np.isfinite(nxt).all()
 
 
+@pytest.mark.parametrize("hd,nh,fp8", [(128, 8, False), (256, 16, False), (256, 16, True), (128, 4, True), (64, 16, False)])
+def test_prefill_wide_heads_long_prompt(hd, nh, fp8):
+    """the head-dim / GQA-group / KV-dtype specialisations of the prompt-pass attention (QCN: head_dim 256, 8 query heads per KV head)
+    on a prompt that spans several 64-position probability tiles, 32-position K tiles and chunks"""
+    from oracle import oracle as O
+    st, eng, orc, keep, d = build(seed=11, kv_max=260, hd=hd, nh=nh)
+    if fp8:
+        st.set_kv_dtype(True)
+        rng = np.random.default_rng(5)
+        kv = {li: (O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)), O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)))
+              for li, kind in enumerate(d["kinds"]) if kind == "gqa"}
+        n = len(d["kinds"]); ptr = lambda a: a.ctypes.data
+        reset = lambda: st.set_decode_state(5, d["kv_max"], [ptr(kv[i][0]) if i in kv else 0 for i in range(n)], [ptr(kv[i][1]) if i in kv else 0 for i in range(n)],
+                                            [ptr(x) if x is not None else 0 for x in d["state"]["conv"]], [ptr(x) if x is not None else 0 for x in d["state"]["recur"]])
+    else:
+        reset = d["reset"]
+    reset()
+    start, n_tok = 37, 170
+    rng = np.random.default_rng(hd + nh)
+    toks = [int(x) for x in rng.integers(0, d["V"], n_tok)]
+    ref_logits = np.empty(d["V"], F)
+    for i, t in enumerate(toks):
+        st.decode_step(t, start + i, ref_logits.ctypes.data)
+    ref_tok = st.last_token()
+    esz = np.uint8 if fp8 else np.uint16
+    def snap():
+        out = []
+        for li, kind in enumerate(d["kinds"]):
+            if kind == "gqa":
+                kc = np.empty((d["kv_max"], d["nkv"] * d["hd"]), esz); vc = np.empty_like(kc)
+                st.get_decode_state(li, kc, vc, None, None); out.append((kc, vc))
+        return out
+    ref_kv = snap()
+    reset()
+    st.set_prefill_chunk(48); st.set_prefill_depth(3)
+    logits = np.empty(d["V"], F)
+    tok = st.prefill(toks, start, logits.ctypes.data)
+    assert np.array_equal(logits.view(np.uint32), ref_logits.view(np.uint32)), float(np.max(np.abs(logits - ref_logits)))
+    assert tok == ref_tok
+    for a, b in zip(snap(), ref_kv):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_prefill_argument_errors():
     st, eng, orc, keep, d = build()
     with pytest.raises(ValueError):
