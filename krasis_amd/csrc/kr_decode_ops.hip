@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256) kr_la_recurrent_gnorm_kernel(float* __res
 // (r, j) owns state column j of value head kh*hr + r.  A key head's conv channels (its q / k rows and the v rows of its hr value
 // heads) are read and shifted by this workgroup only, so the in-place conv-state update needs no cross-workgroup ordering.
 // The thread's whole state column (DK values) is requested before anything else and stays in registers for both passes: the
-// conv / gate / norm work runs under that one memory latency, and the second pass re-reads nothing.
+// conv / gate / norm work runs under that one memory latency, and the second pass re-reads nothing (k / q are broadcast LDS reads).
 template <int DK, int DV>
 __global__ void __launch_bounds__(256) kr_la_step_kernel(const KrLaArgs a, float* __restrict__ state, const float* __restrict__ w, float* __restrict__ out,
                                                         float eps, void* img_out, int img_k) {
@@ -333,22 +333,58 @@ __global__ void __launch_bounds__(256) kr_la_step_kernel(const KrLaArgs a, float
     }
     __syncthreads();
     // ---- recurrence: kv[j] = sum_i fma(S[i][j]*e^g, k[i]); delta = (v - kv) * beta; S' = fma(k, delta, S*e^g); o = sum_i fma(S', q)
-    // k and q are uniform across the workgroup: each wave keeps them in two registers per vector (lane l holds element l and
-    // 64 + l) and broadcasts element u with v_readlane, so the two fma chains read no LDS and only the state column occupies VGPRs
+    // k and q are uniform across the workgroup and come out of LDS 4 at a time (broadcast ds_read_b128), one 16-element block ahead
+    // of the chain that consumes them; a lone wave issues about one instruction per 9 cycles whatever the dependencies, so the count
+    // matters: per 4 elements 1 read + 2 packed mul + 4 fma (pass 1), 2 reads + 2 packed fma + 4 stores + 4 fma (pass 2).  The
+    // scheduling barriers keep the compiler from hoisting all the reads (the column already holds DK registers).
     const float g_exp = ge[r], beta_h = bt[r];
-    const int ln = t & 63;
-    const float kr0 = kc[ln], qr0 = qc[ln], kr1 = DK > 64 ? kc[64 + ln] : 0.0f, qr1 = DK > 64 ? qc[64 + ln] : 0.0f;
-    auto bcast = [](float v, int u) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), u)); };
+    const float4* k4 = reinterpret_cast<const float4*>(kc); const float4* q4 = reinterpret_cast<const float4*>(qc);
     float kv = 0.0f;
+    float4 ka[4] = {k4[0], k4[1], k4[2], k4[3]};
 #pragma unroll
-    for (int u = 0; u < DK; u++) { c[u] = c[u] * g_exp; kv = __builtin_fmaf(c[u], bcast(u < 64 ? kr0 : kr1, u & 63), kv); }
+    for (int b = 0; b < DK / 16; b++) {
+        float4 kb[4] = {ka[0], ka[1], ka[2], ka[3]};
+        if (b + 1 < DK / 16) { kb[0] = k4[4 * b + 4]; kb[1] = k4[4 * b + 5]; kb[2] = k4[4 * b + 6]; kb[3] = k4[4 * b + 7]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float* cb = c + 16 * b + 4 * u;
+            cb[0] = cb[0] * g_exp; kv = __builtin_fmaf(cb[0], ka[u].x, kv);
+            cb[1] = cb[1] * g_exp; kv = __builtin_fmaf(cb[1], ka[u].y, kv);
+            cb[2] = cb[2] * g_exp; kv = __builtin_fmaf(cb[2], ka[u].z, kv);
+            cb[3] = cb[3] * g_exp; kv = __builtin_fmaf(cb[3], ka[u].w, kv);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) ka[u] = kb[u];
+    }
     const float delta = (vs[t] - kv) * beta_h;
     float ob = 0.0f;
+    float4 qa[4] = {q4[0], q4[1], q4[2], q4[3]};
 #pragma unroll
-    for (int u = 0; u < DK; u++) {
-        const float sn = __builtin_fmaf(bcast(u < 64 ? kr0 : kr1, u & 63), delta, c[u]);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sn), srd, voff + (u % RW) * dv * 4, (u / RW) * 4096, 2 /* nt */);
-        ob = __builtin_fmaf(sn, bcast(u < 64 ? qr0 : qr1, u & 63), ob);
+    for (int u = 0; u < 4; u++) ka[u] = k4[u];
+#pragma unroll
+    for (int b = 0; b < DK / 16; b++) {
+        float4 kb[4] = {ka[0], ka[1], ka[2], ka[3]}, qb[4] = {qa[0], qa[1], qa[2], qa[3]};
+        if (b + 1 < DK / 16) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { kb[u] = k4[4 * b + 4 + u]; qb[u] = q4[4 * b + 4 + u]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float kk[4] = {ka[u].x, ka[u].y, ka[u].z, ka[u].w}, qq[4] = {qa[u].x, qa[u].y, qa[u].z, qa[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = 16 * b + 4 * u + e;
+                const float sn = __builtin_fmaf(kk[e], delta, c[i]);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sn), srd, voff + (i % RW) * dv * 4, (i / RW) * 4096, 2 /* nt */);
+                ob = __builtin_fmaf(sn, qq[e], ob);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { ka[u] = kb[u]; qa[u] = qb[u]; }
     }
     rr[t] = ob;
     __syncthreads();
