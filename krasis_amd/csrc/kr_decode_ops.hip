@@ -62,7 +62,10 @@ __global__ void kr_embed_kernel(const float* __restrict__ emb, const KrStep* __r
 __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(const KrNormSrc src, float* hidden, const float* res_in, float* residual, const float* __restrict__ w,
                                                                               int n, float eps, int first, int bias_one, void* img_out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* r = sm;                       // [n]
+    float* r = sm;                       // [n + 4]
+    const int ldt = n / 8 + 4;
+    float* rt = sm + n + 4;              // [8][ldt] lane-major copy for the sum-of-squares chain (n % 8 == 0)
+    const bool tr = (n & 7) == 0;
     if (src.mode == 2 && src.topk <= 16) {
         // MoE epilogue: sum_i w_i * eo_i in routing order (moe.rs:661-667), *rsf, + shared * sigmoid(gate).  Every load of the
         // thread (slot rows, weights, ids, residual) is issued before the first use: one memory latency for the whole gather.
@@ -88,7 +91,8 @@ __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(c
             }
             const float v0 = first ? a0 : (a0 + r0);
             r[i0] = v0; residual[i0] = v0;
-            if (two) { const float v1 = first ? a1 : (a1 + r1); r[i1] = v1; residual[i1] = v1; }
+            if (tr) rt[(i0 & 7) * ldt + (i0 >> 3)] = v0;
+            if (two) { const float v1 = first ? a1 : (a1 + r1); r[i1] = v1; residual[i1] = v1; if (tr) rt[(i1 & 7) * ldt + (i1 >> 3)] = v1; }
         }
     } else {
         __shared__ float s_w[32]; __shared__ int s_id[32]; __shared__ float s_sig;
@@ -120,11 +124,12 @@ __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(c
             }
             const float v = first ? hv : (hv + res_in[i]);
             r[i] = v; residual[i] = v;
+            if (tr) rt[(i & 7) * ldt + (i >> 3)] = v;
         }
     }
     __syncthreads();
     if (threadIdx.x < 8) {
-        float ss = kr_sumsq_chain8(r, n, threadIdx.x);
+        float ss = tr ? kr_hsum8(kr_sumsq_lane_t(rt, ldt, n, threadIdx.x)) : kr_sumsq_chain8(r, n, threadIdx.x);
         if (threadIdx.x == 0) {
             for (int t = (n / 8) * 8; t < n; t++) ss += r[t] * r[t];
             sm[n] = 1.0f / sqrtf(ss / (float)n + eps);
@@ -731,7 +736,7 @@ void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, h
 void kr_launch_fused_add_rmsnorm(const KrNormSrc& src, float* hidden, const float* res_in, float* residual, const float* w, int n, float eps, int first, int bias_one, hipStream_t s,
                                  void* img_out) {
     if (n % 128) img_out = nullptr;
-    hipLaunchKernelGGL(kr_fused_add_rmsnorm_kernel, dim3(1), dim3(KR_NORM_THREADS), (size_t)(n + 4) * 4, s, src, hidden, res_in, residual, w, n, eps, first, bias_one, img_out);
+    hipLaunchKernelGGL(kr_fused_add_rmsnorm_kernel, dim3(1), dim3(KR_NORM_THREADS), (size_t)(n + 4 + 8 * (n / 8 + 4)) * 4, s, src, hidden, res_in, residual, w, n, eps, first, bias_one, img_out);
 }
 void kr_launch_la_conv(const KrLaArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kr_la_conv_kernel, dim3(a.nk), dim3(256), (size_t)(2 * a.dk + 4) * 4, s, a);

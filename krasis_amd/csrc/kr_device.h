@@ -203,6 +203,29 @@ __device__ __forceinline__ float kr_seq_sum(const float* x, int n) {
     return s;
 }
 
+// The reference's 8-lane sum of squares (lane l owns elements 8 b + l, b ascending; fused_add_rmsnorm_avx2, decode.rs:1235-1252) over
+// a LANE-MAJOR copy xt[l * ld + b] = x[8 b + l] (ld % 4 == 0; ld = n / 8 + 4 keeps the 8 lanes on distinct banks): the chain lane reads
+// its elements four at a time -- 64 ds_read_b128 instead of 256 ds_read_b32 for n = 2048, and a lone wave pays per instruction.
+// Call with the first 8 lanes of a wave; returns the lane's partial (the caller folds the 8 lanes with the reference's hsum tree).
+__device__ __forceinline__ float kr_sumsq_lane_t(const float* xt, int ld, int n, int l) {
+    const float4* p = reinterpret_cast<const float4*>(xt + l * ld);
+    const int nb = n / 8;
+    float acc = 0.0f;
+    int b = 0;
+    for (; b + 32 <= nb; b += 32) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(b >> 2) + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            acc = __builtin_fmaf(v[u].x, v[u].x, acc); acc = __builtin_fmaf(v[u].y, v[u].y, acc);
+            acc = __builtin_fmaf(v[u].z, v[u].z, acc); acc = __builtin_fmaf(v[u].w, v[u].w, acc);
+        }
+    }
+    for (; b < nb; b++) { const float v = xt[l * ld + b]; acc = __builtin_fmaf(v, v, acc); }
+    return acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // INT16 activation image: carving, and the f32 quantizer shared by every kernel that PRODUCES an image for a later matvec launch
 // (the image can live in LDS or, pre-built by the producer of the activation, in global memory with the identical byte layout).

@@ -383,6 +383,8 @@ __global__ void __launch_bounds__(256) kr_route_fused_decode_kernel(const KrRout
     const int H = a.H, E = a.sel.E, ld = H / 16 + 4;
     float* xs = sm;                  // [16][ld] chain-major copy of x
     float* r = sm + 16 * ld;         // [H + 4] residual sum (norm fold) -- reused as selection scratch by the last workgroup
+    const int ldt = H / 8 + 4;
+    float* rt = r + H + 4;           // [8][ldt] lane-major copy of the residual sum for the sum-of-squares chain
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int eb = blockIdx.x * 4 + wave;  // block of 4 experts
@@ -407,30 +409,16 @@ __global__ void __launch_bounds__(256) kr_route_fused_decode_kernel(const KrRout
                 for (int u = 0; u < 4; u++) if (i0 + u * 256 < H / 4) {
                     const float4 v = {hv[u].x + rv[u].x, hv[u].y + rv[u].y, hv[u].z + rv[u].z, hv[u].w + rv[u].w};
                     reinterpret_cast<float4*>(r)[i0 + u * 256 + t] = v;
+                    { const int e = (i0 + u * 256 + t) * 4, bb = e >> 3, l0 = e & 7;    // elements e .. e + 3: lanes l0 .. l0 + 3 of block bb
+                      rt[l0 * ldt + bb] = v.x; rt[(l0 + 1) * ldt + bb] = v.y; rt[(l0 + 2) * ldt + bb] = v.z; rt[(l0 + 3) * ldt + bb] = v.w; }
                     if (blockIdx.x == 0) reinterpret_cast<float4*>(a.res_out)[i0 + u * 256 + t] = v;
                 }
             }
         } else
-            for (int i = t; i < H; i += 256) { const float v = a.hid_in[i] + a.res_in[i]; r[i] = v; if (blockIdx.x == 0) a.res_out[i] = v; }
+            for (int i = t; i < H; i += 256) { const float v = a.hid_in[i] + a.res_in[i]; r[i] = v; rt[(i & 7) * ldt + (i >> 3)] = v; if (blockIdx.x == 0) a.res_out[i] = v; }
         __syncthreads();
         if (t < 8) {
-            float ss = 0.0f;
-            const int nb = H / 8; int b = 0;
-            for (; b + 32 <= nb; b += 32) {      // 32 LDS values in flight per lane, then the lane's fma chain
-                float v[32];
-#pragma unroll
-                for (int u = 0; u < 32; u++) v[u] = r[(b + u) * 8 + t];
-#pragma unroll
-                for (int u = 0; u < 32; u++) ss = __builtin_fmaf(v[u], v[u], ss);
-            }
-            for (; b + 8 <= nb; b += 8) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = r[(b + u) * 8 + t];
-#pragma unroll
-                for (int u = 0; u < 8; u++) ss = __builtin_fmaf(v[u], v[u], ss);
-            }
-            for (; b < nb; b++) { const float v = r[b * 8 + t]; ss = __builtin_fmaf(v, v, ss); }
+            float ss = kr_sumsq_lane_t(rt, ldt, H, t);
             ss = ss + __shfl_xor(ss, 4); ss = ss + __shfl_xor(ss, 1); ss = ss + __shfl_xor(ss, 2);
             if (t == 0) {
                 for (int q = (H / 8) * 8; q < H; q++) ss += r[q] * r[q];
@@ -590,7 +578,8 @@ int kr_launch_route_fused_decode(const void* gate_cm, int gate_bf16, const float
     if (H % 128 || topk > 32) return 1;
     dim3 grid((E / 4 + 3) / 4);
     const size_t sel_f = (size_t)(2 * E + 33 + 33 + 32 + 32 + 4);
-    const size_t lds = ((size_t)16 * (H / 16 + 4) + (size_t)H + 4 > sel_f ? (size_t)16 * (H / 16 + 4) + (size_t)H + 4 : sel_f) * 4;
+    const size_t norm_f = (size_t)16 * (H / 16 + 4) + (size_t)H + 4 + (size_t)8 * (H / 8 + 4);
+    const size_t lds = (norm_f > sel_f ? norm_f : sel_f) * 4;
 #define KR_RF(B, N) hipLaunchKernelGGL((kr_route_fused_decode_kernel<B, N>), grid, dim3(256), lds, st, a)
     if (gate_bf16) { if (nv <= 1) KR_RF(true, 1); else if (nv <= 2) KR_RF(true, 2); else if (nv <= 4) KR_RF(true, 4); else if (nv <= 8) KR_RF(true, 8); else return 1; }
     else { if (nv <= 1) KR_RF(false, 1); else if (nv <= 2) KR_RF(false, 2); else if (nv <= 4) KR_RF(false, 4); else if (nv <= 8) KR_RF(false, 8); else return 1; }
