@@ -94,8 +94,9 @@ class KrasisEngine:
 
     def load(self, model_dir: str, group_size=None, max_layers=None, start_layer=None, num_bits=None,
              cpu_num_bits=None, gpu_num_bits=None, gguf_path=None, gguf_native: bool = False) -> None:
-        """KrasisEngine.load (moe.rs:1538).  BF16 safetensors -> GPU-side quantize_int4/int8 -> HBM, or GGUF blocks kept native
-        (`gguf_path`, `gguf_native=True`).  cpu_num_bits / gpu_num_bits collapse to ONE resident copy (there is no separate CPU store);
+        """KrasisEngine.load (moe.rs:1538).  BF16 safetensors -> GPU-side quantize_int4/int8 -> HBM; with `gguf_path`: GGUF blocks
+        de-quantized and re-quantized to INT4 / INT8-g128 (`gguf_native=False`, the reference's default) or kept native
+        (`gguf_native=True`).  cpu_num_bits / gpu_num_bits collapse to ONE resident copy (there is no separate CPU store);
         when both are given the decode (cpu) precision wins, as it determines the numerics of `moe_forward`."""
         from .weight_store import load_from_gguf, load_from_hf
         if group_size not in (None, 128):

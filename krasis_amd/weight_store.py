@@ -258,13 +258,16 @@ class GgufFile:
 
 
 def load_from_gguf(engine, gguf_path: str, config_json: Optional[str] = None, gguf_native: bool = True, max_layers: Optional[int] = None,
-                   start_layer: Optional[int] = None, cfg: Optional[MoeConfig] = None) -> MoeConfig:
-    """KrasisEngine.load(gguf_path=...) (moe.rs:1538 -> weights/mod.rs:3251).  `gguf_native=True` keeps the file's blocks (Q4_K / Q8_0 / Q4_0 /
-    Q5_0 / Q6_K) and runs the native block kernels; the re-quantizing default of the reference (`gguf_native=False`, :3375-3420) needs a
-    de-quantizer for every ggml type on the host and is not built here -- use a BF16 checkpoint with `load_from_hf` for INT4-g128 experts."""
+                   start_layer: Optional[int] = None, cfg: Optional[MoeConfig] = None, group_size: int = 128) -> MoeConfig:
+    """KrasisEngine.load(gguf_path=...) (moe.rs:1538 -> weights/mod.rs:3251).
+    `gguf_native=True` keeps the file's blocks (Q4_K / Q8_0 / Q4_0 / Q5_0 / Q6_K) and runs the native block kernels.
+    `gguf_native=False` is the reference's default (the only GGUF mode its CLI reaches): every expert tensor is de-quantized to f32
+    (gguf.rs:872), rounded to bf16 and re-quantized to INT4 / INT8-g128 with the expert quantizer (weights/mod.rs:3592-3760, :4063-4113);
+    the width is chosen once for the whole file -- the widest mapping of any gate tensor for w13, of any down tensor for w2
+    (gguf_type_to_cpu_bits, weights/mod.rs:26-42, :3617-3646) -- so w13 / w2 may differ (mixed precision)."""
     from .engine import ModelConfig
     if not gguf_native:
-        raise ValueError("gguf_native=False (dequantize + requantize to INT4-g128) is not built; pass gguf_native=True or load the BF16 checkpoint")
+        return _load_from_gguf_requant(engine, gguf_path, config_json, max_layers, start_layer, cfg, group_size)
     g = GgufFile(gguf_path)
     try:
         if cfg is None:
@@ -302,6 +305,67 @@ def load_from_gguf(engine, gguf_path: str, config_json: Optional[str] = None, gg
                 tg, td = g.tensors[sh[0]], g.tensors[sh[2]]
                 engine.load_gguf_expert(m, -1, np.ascontiguousarray(g.tensor_bytes(sh[0])), np.ascontiguousarray(g.tensor_bytes(sh[1])),
                                         np.ascontiguousarray(g.tensor_bytes(sh[2])), tg.dtype, td.dtype, cfg.n_shared_experts * I)
+        return cfg
+    finally:
+        g.close()
+
+
+def _load_from_gguf_requant(engine, gguf_path, config_json, max_layers, start_layer, cfg, group_size) -> MoeConfig:
+    """the `gguf_native=False` arm of load_from_gguf: GGUF blocks -> f32 -> bf16 -> INT4 / INT8-g128 experts (quantized on the GPU)"""
+    from .engine import ModelConfig
+    from . import gguf_dequant as GD
+    from ._lib import check
+    if group_size != 128:
+        raise ValueError("group_size must be 128 (marlin.rs:12)")
+    g = GgufFile(gguf_path)
+    try:
+        if cfg is None:
+            if config_json is None:
+                raise ValueError("load_from_gguf needs the model's config.json (the reference reads it from model_dir) or an explicit MoeConfig")
+            cfg = MoeConfig.from_json(config_json)
+        n_moe = cfg.num_hidden_layers - cfg.first_k_dense_replace
+        start = start_layer or 0
+        count = min(max_layers, n_moe - start) if max_layers else n_moe - start
+        if count <= 0:
+            raise ValueError(f"start_layer {start} / max_layers {max_layers} select no MoE layer (model has {n_moe})")
+        H, I, E = cfg.hidden_size, cfg.moe_intermediate_size, cfg.n_routed_experts
+        # one width per file: scan EVERY MoE layer of the model (not only the selected range), as the reference's cache builder does
+        w13_bits, w2_bits = 4, 4
+        for li in range(cfg.first_k_dense_replace, cfg.num_hidden_layers):
+            names, merged = g.find_expert_tensors(li, 0)
+            if names is None:
+                continue
+            for e in range(1 if merged else E):
+                nm, _ = g.find_expert_tensors(li, e)
+                if nm is None:
+                    continue
+                w13_bits = max(w13_bits, GD.cpu_bits(g.tensors[nm[0]].dtype)); w2_bits = max(w2_bits, GD.cpu_bits(g.tensors[nm[2]].dtype))
+        engine.configure(ModelConfig(cfg.hidden_size, cfg.moe_intermediate_size, cfg.n_routed_experts, cfg.num_experts_per_tok, count,
+                                     cfg.n_shared_experts, cfg.routed_scaling_factor, swiglu_limit=cfg.swiglu_limit,
+                                     activation_alpha=cfg.activation_alpha))
+
+        def upload(layer_out, expert, inter, tn):
+            tg, tu, td = (g.tensors[n] for n in tn[0])
+            sl = tn[1]
+            if tg.dims[0] != H or td.dims[0] != inter:
+                raise ValueError(f"{tn[0][0]}: unexpected dims {tg.dims} / {td.dims} for hidden {H}, intermediate {inter}")
+            parts = []
+            for t, name, n_el in ((tg, tn[0][0], inter * H), (tu, tn[0][1], inter * H), (td, tn[0][2], H * inter)):
+                f = GD.dequantize_raw_data(t.dtype, np.ascontiguousarray(g.tensor_bytes(name, *sl)), n_el)
+                parts.append(np.ascontiguousarray(GD.f32_to_bf16(f)))
+            check(engine._lib.kr_upload_expert_bf16(engine._h, layer_out, expert, inter, parts[0].ctypes.data, parts[1].ctypes.data, parts[2].ctypes.data,
+                                                    w13_bits, w2_bits))
+
+        for m in range(count):
+            layer_idx = start + m + cfg.first_k_dense_replace
+            for e in range(E):
+                names, merged = g.find_expert_tensors(layer_idx, e)
+                if names is None:
+                    raise IOError(f"GGUF has no expert tensors for layer {layer_idx} expert {e}")
+                upload(m, e, I, (names, (e, E) if merged else (None, 1)))
+            sh = g.find_shared_expert_tensors(layer_idx)
+            if sh is not None and cfg.n_shared_experts > 0:
+                upload(m, -1, cfg.n_shared_experts * I, (sh, (None, 1)))
         return cfg
     finally:
         g.close()

@@ -96,6 +96,92 @@ def test_gguf_reader(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------------------ GPU
+_GGML = {"F32": (0, 1, 4), "F16": (1, 1, 2), "Q4_0": (2, 32, 18), "Q5_0": (6, 32, 22), "Q8_0": (8, 32, 34), "Q4_K": (12, 256, 144), "Q5_K": (13, 256, 176),
+         "Q6_K": (14, 256, 210), "BF16": (30, 1, 2)}
+
+
+def _random_blocks(rng, name, n):
+    """n elements of ggml type `name` as raw bytes with finite f16 scales"""
+    ty, qk, bb = _GGML[name]
+    nb = n // qk
+    raw = rng.integers(0, 256, (nb, bb), dtype=np.uint8)
+    f16 = lambda k: (rng.standard_normal((nb, k)) * 0.05).astype(np.float16).view(np.uint8).reshape(nb, 2 * k)
+    if name in ("Q4_0", "Q5_0", "Q8_0"): raw[:, 0:2] = f16(1)
+    elif name in ("Q4_K", "Q5_K"): raw[:, 0:4] = f16(2)
+    elif name == "Q6_K": raw[:, 208:210] = f16(1)
+    elif name == "F16": raw = (rng.standard_normal((nb, 1)) * 0.05).astype(np.float16).view(np.uint8).reshape(nb, 2)
+    elif name == "BF16": raw = ((rng.standard_normal((nb, 1)) * 0.05).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16).view(np.uint8).reshape(nb, 2)
+    elif name == "F32": raw = (rng.standard_normal((nb, 1)) * 0.05).astype(np.float32).view(np.uint8).reshape(nb, 4)
+    return ty, np.ascontiguousarray(raw.reshape(-1))
+
+
+@pytest.mark.parametrize("name", sorted(_GGML))
+def test_gguf_dequantizers_match_oracle(name):
+    """krasis_amd.gguf_dequant (the product's load-time de-quantizers, gguf_native=False) == the oracle's restatement of gguf.rs:872, bit for bit"""
+    from oracle import oracle as O
+    from krasis_amd import gguf_dequant as GD
+    rng = np.random.default_rng(len(name) * 7 + 1)
+    n = 256 * 12
+    ty, raw = _random_blocks(rng, name, n)
+    got = GD.dequantize_raw_data(ty, raw, n)
+    ref = O.dequantize(ty, raw, n)
+    assert got.dtype == np.float32 and got.shape == (n,)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), float(np.max(np.abs(got - ref)))
+    assert np.array_equal(GD.f32_to_bf16(got), O.f32_to_bf16(ref))
+
+
+def test_gguf_cpu_bits_mapping():
+    from krasis_amd import gguf_dequant as GD     # gguf_type_to_cpu_bits (weights/mod.rs:26-42)
+    assert [GD.cpu_bits(t) for t in (2, 12, 6, 13, 14, 8, 1, 30, 0)] == [4, 4, 4, 4, 8, 8, 8, 8, 8]
+    with pytest.raises(ValueError):
+        GD.cpu_bits(99)
+    with pytest.raises(ValueError):
+        GD.dequantize_raw_data(10, np.zeros(84, np.uint8), 256)          # Q2_K: no de-quantizer in the reference either
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gate_t,down_t,merged", [("Q4_K", "Q6_K", True), ("Q5_0", "Q4_0", False), ("Q8_0", "Q5_K", True)])
+def test_load_from_gguf_requantized(tmp_path, gate_t, down_t, merged):
+    """gguf_native=False: GGUF blocks -> f32 -> bf16 -> INT4 / INT8-g128 (file-wide widths, mixed precision allowed) == the oracle's
+    dequantize + unified_from_bf16, bit for bit (weights/mod.rs:3592-3760, :4063-4113)"""
+    from oracle import oracle as O
+    from krasis_amd import KrasisEngine, gguf_dequant as GD
+    rng = np.random.default_rng(3)
+    H, I, E, L = 256, 256, 3, 2                                  # layer 0 dense, layer 1 MoE; shared expert = 1 x I
+    tensors, raw = [], {}
+    def add(name, dims, tname, n):
+        ty, b = _random_blocks(rng, tname, n); tensors.append((name, dims, ty, b.tobytes())); raw[name] = (ty, b)
+    if merged:
+        add("blk.1.ffn_gate_exps.weight", (H, I, E), gate_t, E * I * H); add("blk.1.ffn_up_exps.weight", (H, I, E), gate_t, E * I * H)
+        add("blk.1.ffn_down_exps.weight", (I, H, E), down_t, E * H * I)
+    else:
+        for e in range(E):
+            add(f"blk.1.ffn_gate.{e}.weight", (H, I), gate_t, I * H); add(f"blk.1.ffn_up.{e}.weight", (H, I), gate_t, I * H); add(f"blk.1.ffn_down.{e}.weight", (I, H), down_t, H * I)
+    add("blk.1.ffn_gate_shexp.weight", (H, I), gate_t, I * H); add("blk.1.ffn_up_shexp.weight", (H, I), gate_t, I * H); add("blk.1.ffn_down_shexp.weight", (I, H), down_t, H * I)
+    write_gguf(str(tmp_path / "m.gguf"), tensors)
+    (tmp_path / "config.json").write_text(json.dumps({"hidden_size": H, "moe_intermediate_size": I, "n_routed_experts": E, "num_experts_per_tok": 2,
+                                                      "num_hidden_layers": L, "first_k_dense_replace": 1, "n_shared_experts": 1}))
+    eng = KrasisEngine()
+    eng.load(str(tmp_path), gguf_path=str(tmp_path / "m.gguf"), gguf_native=False)
+    b13, b2 = GD.cpu_bits(_GGML[gate_t][0]), GD.cpu_bits(_GGML[down_t][0])
+    def ref_expert(names, e):
+        out = []
+        for nm, n_el, shape in ((names[0], I * H, (I, H)), (names[1], I * H, (I, H)), (names[2], H * I, (H, I))):
+            ty, b = raw[nm]
+            per = b.size // (E if merged and "exps" in nm else 1)
+            blk = b[e * per:(e + 1) * per] if merged and "exps" in nm else b
+            out.append(O.f32_to_bf16(O.dequantize(ty, blk, n_el)).reshape(shape))
+        return O.unified_from_bf16(out[0], out[1], out[2], num_bits=b13, w2_bits=b2)
+    for e in range(E):
+        names = ("blk.1.ffn_gate_exps.weight", "blk.1.ffn_up_exps.weight", "blk.1.ffn_down_exps.weight") if merged else (f"blk.1.ffn_gate.{e}.weight", f"blk.1.ffn_up.{e}.weight", f"blk.1.ffn_down.{e}.weight")
+        ref = ref_expert(names, e)
+        w13, w13s, w2, w2s = eng.download_expert(0, e, b13, b2)
+        assert np.array_equal(w13, ref.w13) and np.array_equal(w13s, ref.w13_scales) and np.array_equal(w2, ref.w2) and np.array_equal(w2s, ref.w2_scales), e
+    ref = ref_expert(("blk.1.ffn_gate_shexp.weight", "blk.1.ffn_up_shexp.weight", "blk.1.ffn_down_shexp.weight"), 0)
+    w13, w13s, w2, w2s = eng.download_expert(0, -1, b13, b2)
+    assert np.array_equal(w13, ref.w13) and np.array_equal(w2, ref.w2) and np.array_equal(w2s, ref.w2_scales)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("bits,w2_bits", [(4, 4), (8, 8), (4, 8)])
 def test_gpu_quantizer_matches_reference_rule(bits, w2_bits):
