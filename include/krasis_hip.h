@@ -182,7 +182,7 @@ int kr_decode_set_layer_moe(kr_decode_store* s, int layer, int moe_layer_idx, in
 int kr_decode_set_layer_dense(kr_decode_store* s, int layer, int gate_wid, int up_wid, int down_wid);              /* decode.rs:2215 */
 int kr_decode_set_rope(kr_decode_store* s, const float* cos_table, const float* sin_table, int half_dim, int max_seq);
 int kr_decode_finalize(kr_decode_store* s);
-/* element type of the GQA KV caches: KR_KV_FP16 = the reference's CPU-decode cache (decode.rs:4423-4478, default), KR_KV_FP8_E4M3 = the
+/* element type of the GQA KV caches and of the MLA compressed-KV / rope caches: KR_KV_FP16 = the reference's CPU-decode cache (decode.rs:4423-4478, default), KR_KV_FP8_E4M3 = the
  * reference's GPU cache dtype (python/krasis/kv_cache.py:38-135, torch.float8_e4m3fn: RNE, no saturation).  Call before set_decode_state;
  * kv_k / kv_v buffers of kr_decode_set_state / kr_decode_get_state then hold 1-byte elements. */
 #define KR_KV_FP16 0

@@ -363,7 +363,7 @@ extern "C" int kr_decode_set_state(kr_decode_store* s, int seq_len, int kv_max_s
             if (kv_k && kv_k[i]) KR_HIP(hipMemcpy(L.kv_k.p, kv_k[i], n, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_k.p, 0, n));
             if (kv_v && kv_v[i]) KR_HIP(hipMemcpy(L.kv_v.p, kv_v[i], n, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_v.p, 0, n));
         } else if (L.attn == ATTN_MLA) {   // kv_k[i] = compressed-KV cache, kv_v[i] = k_pe cache (set_decode_state's mla_ckv_ptrs / mla_kpe_ptrs)
-            const size_t nc = (size_t)kv_max_seq * L.klr * 2, np = (size_t)kv_max_seq * L.rd * 2;
+            const size_t esz = s->kv_fp8 ? 1 : 2, nc = (size_t)kv_max_seq * L.klr * esz, np = (size_t)kv_max_seq * L.rd * esz;
             if (L.kv_k.ensure(nc) || L.kv_v.ensure(np)) return kr_fail(KR_ERR_HIP, "hipMalloc of MLA cache failed");
             if (kv_k && kv_k[i]) KR_HIP(hipMemcpy(L.kv_k.p, kv_k[i], nc, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_k.p, 0, nc));
             if (kv_v && kv_v[i]) KR_HIP(hipMemcpy(L.kv_v.p, kv_v[i], np, hipMemcpyHostToDevice)); else KR_HIP(hipMemset(L.kv_v.p, 0, np));
@@ -392,6 +392,7 @@ extern "C" int kr_decode_fill_state_synthetic(kr_decode_store* s, int kv_max_seq
             kr_launch_fill_fp16_kv((uint16_t*)L.kv_v.p, n, seed + i * 4 + 1, s->eng->stream);
         } else if (L.attn == ATTN_MLA) {
             const size_t nc = (size_t)kv_max_seq * L.klr, np = (size_t)kv_max_seq * L.rd;
+            if (s->kv_fp8) return kr_fail(KR_ERR_VALUE, "fill_state_synthetic generates FP16 caches (decode.rs:4402-4411); set FP8 caches through set_decode_state");
             if (L.kv_k.ensure(nc * 2) || L.kv_v.ensure(np * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc of MLA cache failed");
             kr_launch_fill_fp16_kv((uint16_t*)L.kv_k.p, nc, seed + i * 4 + 0, s->eng->stream);
             kr_launch_fill_fp16_kv((uint16_t*)L.kv_v.p, np, seed + i * 4 + 1, s->eng->stream);
@@ -416,8 +417,9 @@ extern "C" int kr_decode_get_state(kr_decode_store* s, int layer, uint16_t* kv_k
         if (kv_k) KR_HIP(hipMemcpy(kv_k, L.kv_k.p, n, hipMemcpyDeviceToHost));
         if (kv_v) KR_HIP(hipMemcpy(kv_v, L.kv_v.p, n, hipMemcpyDeviceToHost));
     } else if (L.attn == ATTN_MLA) {
-        if (kv_k) KR_HIP(hipMemcpy(kv_k, L.kv_k.p, (size_t)s->kv_max_seq * L.klr * 2, hipMemcpyDeviceToHost));
-        if (kv_v) KR_HIP(hipMemcpy(kv_v, L.kv_v.p, (size_t)s->kv_max_seq * L.rd * 2, hipMemcpyDeviceToHost));
+        const size_t esz = s->kv_fp8 ? 1 : 2;
+        if (kv_k) KR_HIP(hipMemcpy(kv_k, L.kv_k.p, (size_t)s->kv_max_seq * L.klr * esz, hipMemcpyDeviceToHost));
+        if (kv_v) KR_HIP(hipMemcpy(kv_v, L.kv_v.p, (size_t)s->kv_max_seq * L.rd * esz, hipMemcpyDeviceToHost));
     } else if (L.attn == ATTN_LA) {
         if (conv_state) KR_HIP(hipMemcpy(conv_state, L.conv_state.p, (size_t)(2 * L.nk * L.dk + L.nv * L.dv) * L.kd * 4, hipMemcpyDeviceToHost));
         if (recur_state) KR_HIP(hipMemcpy(recur_state, L.recur_state.p, (size_t)L.nv * L.dk * L.dv * 4, hipMemcpyDeviceToHost));
@@ -524,7 +526,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             KrMlaArgs a{};
             a.step = step; a.kv_out = kv_out; a.q_full = q_full; a.kv_a_norm = (const float*)L.kv_a_norm.p; a.w_kc = (const float*)L.w_kc.p;
             a.w_vc = (const float*)L.w_vc.p; a.rope_cos = (const float*)L.mla_cos.p; a.rope_sin = (const float*)L.mla_sin.p;
-            a.ckv_cache = (uint16_t*)L.kv_k.p; a.kpe_cache = (uint16_t*)L.kv_v.p; a.q_abs = (float*)s->qbuf.p; a.q_pe = (float*)s->zbuf.p;
+            a.ckv_cache = L.kv_k.p; a.kpe_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_abs = (float*)s->qbuf.p; a.q_pe = (float*)s->zbuf.p;
             a.attn_lat = (float*)s->latbuf.p; a.v_proj = (float*)s->attn_out.p;
             a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale;
             PROF(PK_GQA, kr_launch_mla(a, s->kv_max_seq, st));
@@ -635,7 +637,7 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
 extern "C" int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype) {
     if (int rc = chk_store(s)) return rc;
     if (kv_dtype != 0 && kv_dtype != 1) return kr_fail(KR_ERR_VALUE, "kv_dtype %d unknown (0 = FP16, 1 = FP8-E4M3)", kv_dtype);
-    if (s->kv_fp8 != kv_dtype) for (auto& L : s->layers) if (L.attn == ATTN_GQA) { L.kv_k.release(); L.kv_v.release(); }
+    if (s->kv_fp8 != kv_dtype) for (auto& L : s->layers) if (L.attn == ATTN_GQA || L.attn == ATTN_MLA) { L.kv_k.release(); L.kv_v.release(); }
     s->kv_fp8 = kv_dtype; s->graph_ok = false;
     return KR_OK;
 }

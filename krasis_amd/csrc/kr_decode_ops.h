@@ -27,7 +27,8 @@ struct KrMlaArgs {   // decode.rs:2993-3252
     const float* kv_out;      // kv_a_proj output [klr + rd]
     const float* q_full;      // q (or q_b) projection output [nh * (nd + rd)]
     const float *kv_a_norm, *w_kc, *w_vc, *rope_cos, *rope_sin;
-    uint16_t *ckv_cache, *kpe_cache;   // FP16 [max_seq, klr] / [max_seq, rd]
+    void *ckv_cache, *kpe_cache;       // [max_seq, klr] / [max_seq, rd], FP16 or (kv_fp8) E4M3 elements
+    int kv_fp8;
     float *q_abs, *q_pe, *attn_lat, *v_proj;
     int nh, klr, nd, rd, vhd; float eps, sm_scale;
     // prompt pass (step == nullptr): token t = blockIdx.y (blockIdx.z for the w_vc launch) sits at position pos0 + t; row t of the

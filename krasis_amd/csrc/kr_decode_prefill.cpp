@@ -108,7 +108,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.step = nullptr; a.pos0 = pos0; a.kv_out = B.pb; a.ld_kv = nkv; a.q_full = B.pa; a.ld_q = nq;
         a.kv_a_norm = (const float*)L.kv_a_norm.p; a.w_kc = (const float*)L.w_kc.p; a.w_vc = (const float*)L.w_vc.p;
         a.rope_cos = (const float*)L.mla_cos.p; a.rope_sin = (const float*)L.mla_sin.p;
-        a.ckv_cache = (uint16_t*)L.kv_k.p; a.kpe_cache = (uint16_t*)L.kv_v.p; a.q_abs = B.q; a.q_pe = B.z; a.attn_lat = B.recur; a.v_proj = B.attn;
+        a.ckv_cache = L.kv_k.p; a.kpe_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_abs = B.q; a.q_pe = B.z; a.attn_lat = B.recur; a.v_proj = B.attn;
         a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale;
         kr_launch_mla(a, s->kv_max_seq, st, Cc);
         if (oc != L.nh * L.vhd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*v_head_dim", oc);

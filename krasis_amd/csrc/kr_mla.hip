@@ -21,6 +21,15 @@ __device__ __forceinline__ float kr_mla_hsum8(float v) {   // lo+hi, movehdup, m
     return v;
 }
 __device__ __forceinline__ float kr_h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+// cache element i of a row / of the whole cache: FP16 (reference CPU decode) or E4M3 (the GPU cache dtype, extended to the latent cache)
+template <bool FP8> __device__ __forceinline__ float kr_mla_ld(const void* base, size_t i) {
+    if (FP8) return kr_e4m3_to_f32(reinterpret_cast<const uint8_t*>(base)[i]);
+    return kr_h2f(reinterpret_cast<const uint16_t*>(base)[i]);
+}
+template <bool FP8> __device__ __forceinline__ void kr_mla_st(void* base, size_t i, float v) {
+    if (FP8) reinterpret_cast<uint8_t*>(base)[i] = kr_f32_to_e4m3(v);
+    else reinterpret_cast<uint16_t*>(base)[i] = __half_as_ushort(__float2half_rn(v));
+}
 
 // 16 cooperating lanes (c = lane & 15) evaluate mla_attn_dot_fp16_avx2 / the w_vc row dot: chain (a = c >> 3, l = c & 7) owns the
 // 8-blocks i with i % 2 == a (an odd trailing block goes to accumulator 0), ascending.  Every lane of the 16 returns the result.
@@ -45,6 +54,7 @@ __device__ __forceinline__ int kr_mla_token(KrMlaArgs& a, int tk) {
     a.q_abs += (size_t)tk * a.nh * a.klr; a.q_pe += (size_t)tk * a.nh * a.rd; a.attn_lat += (size_t)tk * a.nh * a.klr; a.v_proj += (size_t)tk * a.nh * a.vhd;
     return a.pos0 + tk;
 }
+template <bool FP8>
 __global__ void __launch_bounds__(64) kr_mla_prep_kernel(KrMlaArgs a) {
     __shared__ float sh[640];
     const int pos = kr_mla_token(a, blockIdx.y);
@@ -95,17 +105,18 @@ __global__ void __launch_bounds__(64) kr_mla_prep_kernel(KrMlaArgs a) {
     const float rms = sh[639];
     for (int i = t; i < a.klr; i += 64) {
         const float v = x[i] * (rms * a.kv_a_norm[i]);                                     // x *= rms * w (decode.rs:3030)
-        a.ckv_cache[(size_t)pos * a.klr + i] = __half_as_ushort(__float2half_rn(v));
+        kr_mla_st<FP8>(a.ckv_cache, (size_t)pos * a.klr + i, v);
     }
     if (t < half) {                                                                        // decode.rs:3098-3107, 3131-3140
         const float x1 = a.kv_out[a.klr + 2 * t], x2 = a.kv_out[a.klr + 2 * t + 1];
         const float c = a.rope_cos[(size_t)pos * half + t], s = a.rope_sin[(size_t)pos * half + t];
-        a.kpe_cache[(size_t)pos * a.rd + t] = __half_as_ushort(__float2half_rn(x1 * c - x2 * s));
-        a.kpe_cache[(size_t)pos * a.rd + half + t] = __half_as_ushort(__float2half_rn(x2 * c + x1 * s));
+        kr_mla_st<FP8>(a.kpe_cache, (size_t)pos * a.rd + t, x1 * c - x2 * s);
+        kr_mla_st<FP8>(a.kpe_cache, (size_t)pos * a.rd + half + t, x2 * c + x1 * s);
     }
 }
 
 // ---- launch 2: attention, one workgroup (512 threads) per head.  dynamic LDS: klr + rd + seq_max + 8 floats --------------
+template <bool FP8>
 __global__ void __launch_bounds__(512) kr_mla_attn_kernel(KrMlaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[12];
@@ -117,9 +128,9 @@ __global__ void __launch_bounds__(512) kr_mla_attn_kernel(KrMlaArgs a) {
     __syncthreads();
     const int c = t & 15;
     for (int s = t >> 4; s < seq; s += 32) {
-        const uint16_t* ck = a.ckv_cache + (size_t)s * a.klr; const uint16_t* kp = a.kpe_cache + (size_t)s * a.rd;
-        float v = kr_dot2acc(qa, [&](int i) { return kr_h2f(ck[i]); }, a.klr, c);
-        v += kr_dot2acc(qp, [&](int i) { return kr_h2f(kp[i]); }, a.rd, c);
+        const size_t cko = (size_t)s * a.klr, kpo = (size_t)s * a.rd;
+        float v = kr_dot2acc(qa, [&](int i) { return kr_mla_ld<FP8>(a.ckv_cache, cko + i); }, a.klr, c);
+        v += kr_dot2acc(qp, [&](int i) { return kr_mla_ld<FP8>(a.kpe_cache, kpo + i); }, a.rd, c);
         v *= a.sm_scale;
         if (c == 0) sc[s] = v;
     }
@@ -152,17 +163,16 @@ __global__ void __launch_bounds__(512) kr_mla_attn_kernel(KrMlaArgs a) {
     for (int s = t; s < seq; s += 512) sc[s] *= inv;
     __syncthreads();
     for (int j = t; j < a.klr; j += 512) {
-        const uint16_t* ck = a.ckv_cache + j;
         float o = 0.0f;
         int s = 0;
         for (; s + 16 <= seq; s += 16) {      // 16 independent cache loads in flight, then the dependent fmas in position order
             float vv[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) vv[u] = kr_h2f(ck[(size_t)(s + u) * a.klr]);
+            for (int u = 0; u < 16; u++) vv[u] = kr_mla_ld<FP8>(a.ckv_cache, (size_t)(s + u) * a.klr + j);
 #pragma unroll
             for (int u = 0; u < 16; u++) o = __builtin_fmaf(sc[s + u], vv[u], o);
         }
-        for (; s < seq; s++) o = __builtin_fmaf(sc[s], kr_h2f(ck[(size_t)s * a.klr]), o);
+        for (; s < seq; s++) o = __builtin_fmaf(sc[s], kr_mla_ld<FP8>(a.ckv_cache, (size_t)s * a.klr + j), o);
         a.attn_lat[(size_t)h * a.klr + j] = o;
     }
 }
@@ -205,8 +215,13 @@ __global__ void __launch_bounds__(256) kr_rmsnorm_seq_kernel(float* __restrict__
 }
 
 void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {
-    hipLaunchKernelGGL(kr_mla_prep_kernel, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(kr_mla_attn_kernel, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
+    if (a.kv_fp8) {
+        hipLaunchKernelGGL(kr_mla_prep_kernel<true>, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(kr_mla_attn_kernel<true>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
+    } else {
+        hipLaunchKernelGGL(kr_mla_prep_kernel<false>, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(kr_mla_attn_kernel<false>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
+    }
     hipLaunchKernelGGL(kr_mla_wvc_kernel, dim3((a.vhd + 7) / 8, a.nh, n_tok), dim3(128), (size_t)a.klr * 4, s, a);
 }
 void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s, int rows, int ld) {

@@ -1125,14 +1125,14 @@ static float mla_dot_f32_f16(const float* q, const uint16_t* c, int dim) {
     int n8 = dim / 8; float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int chunks = n8 / 2, i = 0;
     for (int ch = 0; ch < chunks; ch++) {
-        for (int j = 0; j < 8; j++) a0[j] = fmaf(q[i * 8 + j], kro_f16_to_f32(c[i * 8 + j]), a0[j]);
-        for (int j = 0; j < 8; j++) a1[j] = fmaf(q[(i + 1) * 8 + j], kro_f16_to_f32(c[(i + 1) * 8 + j]), a1[j]);
+        for (int j = 0; j < 8; j++) a0[j] = fmaf(q[i * 8 + j], kv_ld(c, (size_t)(i * 8 + j)), a0[j]);
+        for (int j = 0; j < 8; j++) a1[j] = fmaf(q[(i + 1) * 8 + j], kv_ld(c, (size_t)((i + 1) * 8 + j)), a1[j]);
         i += 2;
     }
-    if (n8 % 2) for (int j = 0; j < 8; j++) a0[j] = fmaf(q[i * 8 + j], kro_f16_to_f32(c[i * 8 + j]), a0[j]);
+    if (n8 % 2) for (int j = 0; j < 8; j++) a0[j] = fmaf(q[i * 8 + j], kv_ld(c, (size_t)(i * 8 + j)), a0[j]);
     float s8[8]; for (int j = 0; j < 8; j++) s8[j] = a0[j] + a1[j];
     float r = hsum8(s8);
-    for (int t = n8 * 8; t < dim; t++) r += q[t] * kro_f16_to_f32(c[t]);
+    for (int t = n8 * 8; t < dim; t++) r += q[t] * kv_ld(c, (size_t)t);
     return r;
 }
 
@@ -1144,7 +1144,8 @@ void kro_rmsnorm_seq(float* x, const float* w, int n, float eps) {
 }
 
 /* kv_out = kv_a_proj output [klr + rd]; q_full = q (or q_b) projection output [nh * (nd + rd)] (modified in place like the reference);
- * w_kc f32 [nh, nd, klr]; w_vc f32 [nh, vhd, klr]; caches FP16 [max_seq, klr] / [max_seq, rd]; out v_projected [nh * vhd]. */
+ * w_kc f32 [nh, nd, klr]; w_vc f32 [nh, vhd, klr]; caches FP16 (or, after kro_set_kv_fp8(1), E4M3 bytes in the u16 slots -- an extension of the
+ * reference GPU cache dtype to the decode store, no counterpart in decode.rs) [max_seq, klr] / [max_seq, rd]; out v_projected [nh * vhd]. */
 void kro_mla_step(float* kv_out, float* q_full, const float* kv_a_norm, const float* w_kc, const float* w_vc,
                   const float* rope_cos, const float* rope_sin, int nh, int klr, int nd, int rd, int vhd, float eps, float sm_scale,
                   uint16_t* ckv_cache, uint16_t* kpe_cache, int position, float* v_projected) {
@@ -1171,8 +1172,8 @@ void kro_mla_step(float* kv_out, float* q_full, const float* kv_a_norm, const fl
         float qv = q_full[(size_t)h * hd + i]; const float* wr = w_kc + ((size_t)h * nd + i) * klr; float* o = qabs + (size_t)h * klr;
         for (int j = 0; j < klr8 * 8; j++) o[j] = fmaf(qv, wr[j], o[j]);
     }
-    for (int i = 0; i < klr; i++) ckv_cache[(size_t)position * klr + i] = kro_f32_to_f16(ckv[i]);
-    for (int i = 0; i < rd; i++) kpe_cache[(size_t)position * rd + i] = kro_f32_to_f16(kv_out[klr + i]);
+    for (int i = 0; i < klr; i++) ckv_cache[(size_t)position * klr + i] = kv_st(ckv[i]);
+    for (int i = 0; i < rd; i++) kpe_cache[(size_t)position * rd + i] = kv_st(kv_out[klr + i]);
     float* sc = (float*)malloc(4 * (size_t)seq); float* ao = (float*)malloc(4 * (size_t)klr);
     for (int h = 0; h < nh; h++) {
         float mx = -INFINITY;
@@ -1184,7 +1185,7 @@ void kro_mla_step(float* kv_out, float* q_full, const float* kv_a_norm, const fl
         float se = 0.0f; for (int t = 0; t < seq; t++) { float e = expf(sc[t] - mx); sc[t] = e; se += e; }
         float inv = 1.0f / se; for (int t = 0; t < seq; t++) sc[t] *= inv;
         for (int j = 0; j < klr; j++) ao[j] = 0.0f;   /* decode.rs:4326: only the klr8*8 prefix is touched; klr % 8 == 0 in every model */
-        for (int t = 0; t < seq; t++) { float w = sc[t]; const uint16_t* c = ckv_cache + (size_t)t * klr; for (int j = 0; j < klr8 * 8; j++) ao[j] = fmaf(w, kro_f16_to_f32(c[j]), ao[j]); }
+        for (int t = 0; t < seq; t++) { float w = sc[t]; const uint16_t* c = ckv_cache + (size_t)t * klr; for (int j = 0; j < klr8 * 8; j++) ao[j] = fmaf(w, kv_ld(c, (size_t)j), ao[j]); }
         /* w_vc projection (decode.rs:4555): two accumulators, (acc0+acc1), hsum */
         for (int o = 0; o < vhd; o++) {
             const float* wr = w_vc + ((size_t)h * vhd + o) * klr; float a0[8] = {0,0,0,0,0,0,0,0}, a1[8] = {0,0,0,0,0,0,0,0}; int chunks = klr8 / 2, j = 0;

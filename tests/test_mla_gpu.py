@@ -123,6 +123,45 @@ def test_mla_prompt_pass_equals_sequential_decode(cfg, chunk, depth):
         assert np.array_equal(ck, caches[li][0]) and np.array_equal(kp, caches[li][1])
 
 
+@pytest.mark.parametrize("cfg", [dict(), dict(lora=True, seed=2)])
+def test_mla_fp8_latent_cache_bit_exact(cfg):
+    """FP8-E4M3 compressed-KV / rope caches (set_kv_dtype): decode steps, both caches and the prompt pass against the oracle's E4M3 twin"""
+    st, eng, orc, keep, d = build(**cfg)
+    st.set_kv_dtype(True); O.set_kv_fp8(True)
+    try:
+        rng = np.random.default_rng(9)
+        nL = d["nL"]
+        ck = [O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["klr"])) * 0.5).astype(F)) for _ in range(nL)]
+        kp = [O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["rd"])) * 0.5).astype(F)) for _ in range(nL)]
+        for li in range(nL):
+            orc.layers[li]["ckv"] = ck[li].astype(np.uint16); orc.layers[li]["kpe"] = kp[li].astype(np.uint16)   # oracle keeps one byte per u16 slot
+        reset = lambda: st.set_decode_state(5, d["kv_max"], [0] * nL, [0] * nL, [0] * nL, [0] * nL, [_ptr(x) for x in ck], [_ptr(x) for x in kp])
+        reset()
+        tok = 9
+        for step, pos in enumerate([5, 6, 7]):
+            logits = np.empty(d["V"], F)
+            st.decode_step(tok, pos, logits.ctypes.data)
+            ref = orc.step(tok, pos)
+            assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (step, float(np.max(np.abs(logits - ref))))
+            tok = st.last_token()
+        for li in range(nL):
+            a = np.empty((d["kv_max"], d["klr"]), np.uint8); b = np.empty((d["kv_max"], d["rd"]), np.uint8)
+            st.get_decode_state(li, a, b, None, None)
+            assert np.array_equal(a, orc.layers[li]["ckv"].astype(np.uint8)) and np.array_equal(b, orc.layers[li]["kpe"].astype(np.uint8))
+        # prompt pass with FP8 latent caches == decoding the prompt token by token
+        toks = [3, 9, 27, 81, 5, 15, 200]
+        reset()
+        seq = np.empty(d["V"], F)
+        for i, t in enumerate(toks):
+            st.decode_step(t, 8 + i, seq.ctypes.data)
+        reset()
+        st.set_prefill_chunk(3)
+        pf = np.empty(d["V"], F); st.prefill(toks, 8, pf.ctypes.data)
+        assert np.array_equal(pf.view(np.uint32), seq.view(np.uint32))
+    finally:
+        O.set_kv_fp8(False)
+
+
 def test_mla_geometry_errors():
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     eng = KrasisEngine(); eng.configure(ModelConfig(256, 128, 8, 2, 1, 0, 1.0))
