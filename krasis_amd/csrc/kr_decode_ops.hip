@@ -62,6 +62,7 @@ __global__ void kr_embed_kernel(const float* __restrict__ emb, const KrStep* __r
 __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(const KrNormSrc src, float* hidden, const float* res_in, float* residual, const float* __restrict__ w,
                                                                               int n, float eps, int first, int bias_one, void* img_out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    KR_DSTAMP(10);
     float* r = sm;                       // [n + 4]
     const int ldt = n / 8 + 4;
     float* rt = sm + n + 4;              // [8][ldt] lane-major copy for the sum-of-squares chain (n % 8 == 0)
@@ -127,7 +128,9 @@ __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(c
             if (tr) rt[(i & 7) * ldt + (i >> 3)] = v;
         }
     }
+    KR_DSTAMP(11);
     __syncthreads();
+    KR_DSTAMP(12);
     if (threadIdx.x < 8) {
         float ss = tr ? kr_hsum8(kr_sumsq_lane_t(rt, ldt, n, threadIdx.x)) : kr_sumsq_chain8(r, n, threadIdx.x);
         if (threadIdx.x == 0) {
@@ -135,14 +138,17 @@ __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(c
             sm[n] = 1.0f / sqrtf(ss / (float)n + eps);
         }
     }
+    KR_DSTAMP(13);
     __syncthreads();
     const float rms = sm[n];
     for (int i = threadIdx.x; i < n; i += KR_NORM_THREADS) { const float hv = (r[i] * rms) * (bias_one ? (w[i] + 1.0f) : w[i]); hidden[i] = hv; r[i] = hv; }
+    KR_DSTAMP(14);
     if (img_out) {   // the INT16 image the next projection launches would otherwise each rebuild (quantize_activation_int16_f32, avx2.rs:274)
         __syncthreads();
         const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(img_out), n, false);
         kr_quant_range_f32<false>(r, 0, n / 8, Lg, false);
     }
+    KR_DSTAMP(15);
 }
 
 // decode.rs:3815-3903 for kernel_dim == 4; one workgroup per key head.
