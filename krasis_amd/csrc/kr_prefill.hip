@@ -371,7 +371,7 @@ void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_
     if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
     a.out = out; a.out_ld = out_ld; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
     const int mt = single_expert_rows > 0 ? (single_expert_rows + PF_BM - 1) / PF_BM : max_tiles;
-    static int variant = -2;       // KR_PF_GEMM_VARIANT (tuning hook): -1 = first generation; 0 = (64 cols/wave, 2 groups/stage); 1 = (64,1); 2 = (32,1); 3 = (32,2) [default: measured best]
+    static int variant = -2;       // KR_PF_GEMM_VARIANT (tuning hook): -1 = first generation; 0 = (64 cols/wave, 2 groups/stage); 1 = (64,1); 2 = (32,1); 3 = (32,2) [default: measured best]; 4 = (32,2) with the 2 x 2 row-split wave grid (a third less LDS read traffic, twice the B unpack work: 67k vs 92k tok/s experts-only -- the kernel is VALU-bound, not LDS-bound)
     if (variant == -2) { const char* ev = getenv("KR_PF_GEMM_VARIANT"); variant = ev ? atoi(ev) : 3; }
     if (variant == -1 && m.bits == 4) {
         dim3 grid(mt, (m.N + PF_BN - 1) / PF_BN);
@@ -380,6 +380,7 @@ void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_
     else if (variant == 1) kr_pf_gemm2_launch<64, 1, 4>(a, mt, st);
     else if (variant == 2) kr_pf_gemm2_launch<32, 1, 4>(a, mt, st);
     else if (variant == 3) kr_pf_gemm2_launch<32, 2, 4>(a, mt, st);
+    else if (variant == 4) kr_pf_gemm2_launch<32, 2, 4, true>(a, mt, st);
     else kr_pf_gemm2_launch<64, 2, 4>(a, mt, st);
 }
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
