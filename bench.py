@@ -312,7 +312,7 @@ def main():
     per_launch_us = {KINDS[j]: (tot_ms[j] / max(tot_n[j], 1)) * 1e3 for j in range(15)}
 
     prefill = None; prefill_full = None
-    if args.prefill_tokens > 0:
+    if args.prefill_tokens > 0 and world == 1:       # side measurements (prompt pass, CPU baseline) belong to the N = 1 line only
         prefill = prefill_experts(eng, L, args.prefill_tokens, torch)
         if args.prefill_chunk:
             st.set_prefill_chunk(args.prefill_chunk)
@@ -357,7 +357,7 @@ def main():
             res["prefill"] = prefill_full
         if prefill is not None:
             res["prefill_experts_only"] = prefill
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L)
             except Exception as ex:  # a reported side number, never the product path
