@@ -61,7 +61,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                            &l.w_kc, &l.w_vc, &l.kv_a_norm, &l.q_a_norm, &l.mla_cos, &l.mla_sin}) b->release();
     for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
-                      &s->hid2, &s->res2, &s->r_counter, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
+                      &s->hid2, &s->res2, &s->r_counter, &s->gqa_scores, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     for (hipEvent_t ev : s->pf_events) (void)hipEventDestroy(ev);
     for (hipStream_t ps : s->pf_side) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
     if (s->step_host) (void)hipHostFree(s->step_host);
@@ -502,6 +502,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.attn_out = (float*)s->attn_out.p; a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.eps = s->eps; a.sm_scale = L.sm_scale;
             const bool o_img = img_ok && is4(L.o_wid) && L.hd % 128 == 0 && s->weights[L.o_wid]->cols == L.nh * L.hd;
             a.img_out = o_img ? s->img_attn.p : nullptr;
+            a.sc_g = s->kv_max_seq > s->gqa_split_min ? (float*)s->gqa_scores.p : nullptr;
             PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
             if (o_img) PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->img_attn.p, 2, hid, st));
             else PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
@@ -609,6 +610,7 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
     s->step_host->token = token; s->step_host->pos = pos;
     for (const DLayer& L : s->layers)            // outside capture: the attention kernel's LDS window (scores + one stage of cache rows)
         if (L.hd > 0 && L.q_wid >= 0) {
+            if (s->kv_max_seq > s->gqa_split_min && s->gqa_scores.ensure((size_t)L.nh * s->kv_max_seq * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
             const int pr = kr_gqa_attn_prepare(s->kv_max_seq, L.hd, s->kv_fp8);
             if (pr) return kr_fail(pr == -1 ? KR_ERR_VALUE : KR_ERR_HIP, "GQA decode attention: kv_max_seq %d with head_dim %d does not fit the 160 KiB LDS window", s->kv_max_seq, L.hd);
         }

@@ -18,6 +18,7 @@ struct KrGqaArgs {
     float *q_out, *gate, *attn_out;
     int gated, nh, nkv, hd; float eps, sm_scale;
     void* img_out;   // optional: INT16 image of attn_out for the o-projection launch (hd % 128 == 0)
+    float* sc_g;     // long caches: [nh][max_seq] score scratch -- the scores are computed by (nh x max_seq/256) workgroups in their own launch
 };
 
 int kr_gqa_attn_prepare(int max_seq, int hd, int fp8);   // 0, -1 (scores + stage exceed 160 KiB of LDS), -2 (HIP refused)
@@ -51,7 +52,7 @@ int kr_launch_la_recurrent_gnorm(float* state, const float* q, const float* k, c
                                  const float* w, float* out, int nv, int dk, int dv, float eps, hipStream_t s, void* img_out = nullptr);
 int kr_launch_la_step(const KrLaArgs& a, float* state, const float* w, float* out, float eps, hipStream_t s, void* img_out = nullptr);
 void kr_launch_gated_rmsnorm_silu(const float* recur, const float* z, const float* w, float* out, int nv, int dv, float eps, hipStream_t s);
-void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s);
+void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s);   // a.sc_g != nullptr: prep, scores (many workgroups), softmax + p.v
 void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const float* wts, int topk, int has_shared, const float* gate_val,
                                   float rsf, float* hidden, int H, hipStream_t s);
 void kr_launch_argmax(const float* x, int n, int* out, float* scratch, hipStream_t s);

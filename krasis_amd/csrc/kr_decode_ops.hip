@@ -507,15 +507,20 @@ template <bool FP8> __device__ __forceinline__ float kr_stage_elem(const unsigne
 }
 // NB = head_dim / 8 as a compile-time constant (8 / 16 / 32): the per-lane loops unroll without the uniform guards that would put
 // every LDS read into its own basic block behind an s_waitcnt.  NB == 0: any head_dim % 8 == 0 up to 256, guarded (slow) form.
-template <bool FP8, int NB>
-__global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int max_seq) {
+// PHASE 0: the whole attention of one head in one workgroup (short caches).  Long caches split it: PHASE 1 = scores only, workgroup
+// (h, y) covers positions [256 y, 256 y + 256) and writes a.sc_g (the q.k work is independent per position, so it spreads over
+// nh x max_seq / 256 workgroups instead of crawling through one); PHASE 2 = softmax + p.v of head h reading those scores -- the part
+// whose order is sequential by definition (the reference's position-ordered sum and fma chain).  `lds_seq` sizes the LDS score window.
+template <bool FP8, int NB, int PHASE>
+__global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int max_seq, int lds_seq) {
     extern __shared__ __attribute__((aligned(16))) float sc[];
     __shared__ float qs[256]; __shared__ float red[8];
     const int h = blockIdx.x, hd = a.hd, kvs = a.nkv * hd, seq = a.step->pos + 1, t = threadIdx.x;
+    if (PHASE == 1 && (int)blockIdx.y * 256 >= seq) return;
     const int kvh = h / (a.nh / a.nkv);
     constexpr int esz = FP8 ? 1 : 2;
     const int row_bytes = hd * esz, pitch = row_bytes + 16, cpr = row_bytes >> 4;      // 16-byte chunks per row
-    unsigned char* stage = reinterpret_cast<unsigned char*>(sc) + ((((size_t)max_seq + 40) * 4 + 15) & ~(size_t)15);
+    unsigned char* stage = reinterpret_cast<unsigned char*>(sc) + ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15);
     KR_DSTAMP(0);
     if (t < hd) qs[t] = a.q_out[(size_t)h * hd + t];
     // A stage is KR_GQA_ROWS rows; thread t fetches 16-byte column t % cprp (cprp = cpr rounded up to a power of two, <= 32) of rows
@@ -546,16 +551,20 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
     // ---- scores: 8 lanes per position, lane l owns elements b*8 + l (the AVX2 lane), ascending b, then the 8-lane hsum
     const int l = t & 7, g = t >> 3, nb = NB ? NB : (hd >> 3);
     constexpr int NBM = NB ? NB : 32;
-    issue(kbase, 0);
+    const int st_lo = PHASE == 1 ? (int)blockIdx.y * 2 : 0, st_hi = PHASE == 1 ? min(nst, st_lo + 2) : (PHASE == 2 ? 0 : nst);
+    if (PHASE == 2) {                            // scores of this head come from the scores launch
+        for (int s = t; s < seq; s += 256) sc[s] = a.sc_g[(size_t)h * max_seq + s];
+        issue(vbase, 0);
+    } else issue(kbase, st_lo * KR_GQA_ROWS);
     __syncthreads();
     KR_DSTAMP(1);
     float qr[NBM];                               // the lane's query elements (hd <= 256)
 #pragma unroll
     for (int b = 0; b < NBM; b++) qr[b] = (NB || b < nb) ? qs[b * 8 + l] : 0.0f;
-    for (int st = 0; st < nst; st++) {
-        if (st) __syncthreads();                 // the previous stage's readers are done
+    for (int st = st_lo; st < st_hi; st++) {
+        if (st > st_lo) __syncthreads();         // the previous stage's readers are done
         commit();
-        if (st + 1 < nst) issue(kbase, (st + 1) * KR_GQA_ROWS); else issue(vbase, 0);   // V stage 0 rides under the softmax
+        if (st + 1 < st_hi) issue(kbase, (st + 1) * KR_GQA_ROWS); else if (PHASE == 0) issue(vbase, 0);   // V stage 0 rides under the softmax
         __syncthreads();
         KR_DSTAMP(2);
         const int s0 = st * KR_GQA_ROWS;
@@ -571,7 +580,7 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
 #pragma unroll
             for (int b2 = 0; b2 < NBM; b2++) if (NB || b2 < nb) acc = __builtin_fmaf(qr[b2], X[b2], acc);
             acc = kr_hsum8(acc);
-            if (l == 0) sc[s0 + r] = acc * a.sm_scale;
+            if (l == 0) { if (PHASE == 1) a.sc_g[(size_t)h * max_seq + s0 + r] = acc * a.sm_scale; else sc[s0 + r] = acc * a.sm_scale; }
         };
         if (s0 + g < seq) loadk(ka, g);
 #pragma unroll
@@ -586,6 +595,7 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
         }
     }
     KR_DSTAMP(3);
+    if (PHASE == 1) return;
     __syncthreads();
     float mx = -__builtin_inff();
     for (int s = t; s < seq; s += 256) mx = fmaxf(mx, sc[s]);
@@ -781,21 +791,30 @@ int kr_gqa_attn_prepare(int max_seq, int hd, int fp8) {
     if (lds > 160 * 1024) return -1;
     static size_t lds_set[2] = {0, 0};
     if (lds > lds_set[fp8 ? 1 : 0]) {
-        const void* fns[2][4] = {{(const void*)kr_gqa_attn_kernel<false, 8>, (const void*)kr_gqa_attn_kernel<false, 16>, (const void*)kr_gqa_attn_kernel<false, 32>, (const void*)kr_gqa_attn_kernel<false, 0>},
-                                 {(const void*)kr_gqa_attn_kernel<true, 8>, (const void*)kr_gqa_attn_kernel<true, 16>, (const void*)kr_gqa_attn_kernel<true, 32>, (const void*)kr_gqa_attn_kernel<true, 0>}};
-        for (int i = 0; i < 4; i++)
-            if (hipFuncSetAttribute(fns[fp8 ? 1 : 0][i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+#define KR_F(F_, N_) (const void*)kr_gqa_attn_kernel<F_, N_, 0>, (const void*)kr_gqa_attn_kernel<F_, N_, 1>, (const void*)kr_gqa_attn_kernel<F_, N_, 2>
+        const void* f16[12] = {KR_F(false, 8), KR_F(false, 16), KR_F(false, 32), KR_F(false, 0)};
+        const void* f8[12] = {KR_F(true, 8), KR_F(true, 16), KR_F(true, 32), KR_F(true, 0)};
+#undef KR_F
+        for (int i = 0; i < 12; i++)
+            if (hipFuncSetAttribute(fp8 ? f8[i] : f16[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
         lds_set[fp8 ? 1 : 0] = lds;
     }
     return 0;
 }
-void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
-    hipLaunchKernelGGL(kr_gqa_prep_kernel, dim3(a.nh + a.nkv), dim3(256), 0, s, a);
-    const size_t lds = kr_gqa_attn_lds(max_seq, a.hd, a.kv_fp8);
-#define KR_GQA(F_, N_) hipLaunchKernelGGL((kr_gqa_attn_kernel<F_, N_>), dim3(a.nh), dim3(256), lds, s, a, max_seq)
+template <int PHASE>
+static void kr_launch_gqa_phase(const KrGqaArgs& a, int max_seq, dim3 grid, int lds_seq, hipStream_t s) {
+    const size_t lds = kr_gqa_attn_lds(lds_seq, a.hd, a.kv_fp8);
+#define KR_GQA(F_, N_) hipLaunchKernelGGL((kr_gqa_attn_kernel<F_, N_, PHASE>), grid, dim3(256), lds, s, a, max_seq, lds_seq)
     if (a.kv_fp8) { if (a.hd == 256) KR_GQA(true, 32); else if (a.hd == 128) KR_GQA(true, 16); else if (a.hd == 64) KR_GQA(true, 8); else KR_GQA(true, 0); }
     else { if (a.hd == 256) KR_GQA(false, 32); else if (a.hd == 128) KR_GQA(false, 16); else if (a.hd == 64) KR_GQA(false, 8); else KR_GQA(false, 0); }
 #undef KR_GQA
+}
+void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
+    hipLaunchKernelGGL(kr_gqa_prep_kernel, dim3(a.nh + a.nkv), dim3(256), 0, s, a);
+    if (a.sc_g) {      // long cache: scores over nh x max_seq / 256 workgroups (those past the current length leave at once), then softmax + p.v
+        kr_launch_gqa_phase<1>(a, max_seq, dim3(a.nh, (max_seq + 255) / 256), 0, s);
+        kr_launch_gqa_phase<2>(a, max_seq, dim3(a.nh), max_seq, s);
+    } else kr_launch_gqa_phase<0>(a, max_seq, dim3(a.nh), max_seq, s);
 }
 void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const float* wts, int topk, int has_shared, const float* gate_val,
                                   float rsf, float* hidden, int H, hipStream_t s) {

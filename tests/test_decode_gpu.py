@@ -133,6 +133,20 @@ def test_decode_step_long_positions_bit_exact(hd):
         tok = O.sample_greedy(ref)
 
 
+@pytest.mark.parametrize("hd,graph", [(64, True), (256, False)])
+def test_decode_step_split_attention_bit_exact(hd, graph):
+    """kv_max_seq > 1024: decode attention runs as a scores launch over (heads x 256-position blocks) + a softmax / p.v launch; same bits"""
+    st, eng, orc, keep, d = build(seed=8, kv_max=1300, hd=hd)
+    st.set_use_graph(graph)
+    tok = 5
+    for pos in [3, 255, 256, 257, 700, 1023, 1024, 1299]:
+        logits = np.empty(d["V"], F)
+        st.decode_step(tok, pos, logits.ctypes.data)
+        ref = orc.step(tok, pos)
+        assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (pos, float(np.max(np.abs(logits - ref))))
+        tok = O.sample_greedy(ref)
+
+
 def test_generate_batch_greedy_matches_oracle():
     st, eng, orc, keep, d = build(seed=3)
     toks = st.generate_batch(11, 5, 4)

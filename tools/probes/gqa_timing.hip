@@ -30,7 +30,7 @@ int main() {
         KrStep hs{}; hs.token = 0; hs.pos = pos;
         CK(hipMemcpy(dstep, &hs, sizeof(hs), hipMemcpyHostToDevice));
         CK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL((kr_gqa_attn_kernel<false, 32>), dim3(nh), dim3(256), lds, st, a, max_seq);
+        hipLaunchKernelGGL((kr_gqa_attn_kernel<false, 32, 0>), dim3(nh), dim3(256), lds, st, a, max_seq, max_seq);
         CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         unsigned long long s[32]; CK(hipMemcpyFromSymbol(s, HIP_SYMBOL(kr_dstamps), sizeof(s)));
