@@ -530,6 +530,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.ckv_cache = L.kv_k.p; a.kpe_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_abs = (float*)s->qbuf.p; a.q_pe = (float*)s->zbuf.p;
             a.attn_lat = (float*)s->latbuf.p; a.v_proj = (float*)s->attn_out.p;
             a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale;
+            a.sc_g = s->kv_max_seq > s->mla_split_min ? (float*)s->gqa_scores.p : nullptr;
             PROF(PK_GQA, kr_launch_mla(a, s->kv_max_seq, st));
             PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }
@@ -613,6 +614,11 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
             if (s->kv_max_seq > s->gqa_split_min && s->gqa_scores.ensure((size_t)L.nh * s->kv_max_seq * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
             const int pr = kr_gqa_attn_prepare(s->kv_max_seq, L.hd, s->kv_fp8);
             if (pr) return kr_fail(pr == -1 ? KR_ERR_VALUE : KR_ERR_HIP, "GQA decode attention: kv_max_seq %d with head_dim %d does not fit the 160 KiB LDS window", s->kv_max_seq, L.hd);
+        }
+    for (const DLayer& L : s->layers)
+        if (L.attn == ATTN_MLA) {
+            KrMlaArgs pa{}; pa.klr = L.klr; pa.rd = L.rd; pa.kv_fp8 = s->kv_fp8; kr_mla_attn_prepare(pa, s->kv_max_seq);
+            if (s->kv_max_seq > s->mla_split_min && s->gqa_scores.ensure((size_t)L.nh * s->kv_max_seq * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
         }
     KR_HIP(hipMemcpyAsync(s->step_dev.p, s->step_host, sizeof(KrStep), hipMemcpyHostToDevice, st));
     if (s->use_graph) {

@@ -30,6 +30,7 @@ struct KrMlaArgs {   // decode.rs:2993-3252
     const float *kv_a_norm, *w_kc, *w_vc, *rope_cos, *rope_sin;
     void *ckv_cache, *kpe_cache;       // [max_seq, klr] / [max_seq, rd], FP16 or (kv_fp8) E4M3 elements
     int kv_fp8;
+    float* sc_g;                       // decode, long caches: [nh][max_seq] score scratch (scores in their own, head-shared launch)
     float *q_abs, *q_pe, *attn_lat, *v_proj;
     int nh, klr, nd, rd, vhd; float eps, sm_scale;
     // prompt pass (step == nullptr): token t = blockIdx.y (blockIdx.z for the w_vc launch) sits at position pos0 + t; row t of the
@@ -37,6 +38,7 @@ struct KrMlaArgs {   // decode.rs:2993-3252
     int pos0; int ld_kv, ld_q;
 };
 void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok = 1);
+void kr_mla_attn_prepare(const KrMlaArgs& a, int max_seq);   // outside graph capture: LDS window of the staged attention kernel
 void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s, int rows = 1, int ld = 0);
 
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s);

@@ -14,6 +14,13 @@
 #include "kr_decode_ops.h"
 #include <hip/hip_fp16.h>
 
+#ifdef KR_TIMING   // tools/probes/mla_timing.hip: wall-clock stamps (10 ns units) of thread 0 of workgroup 0, no-op in the product build
+__device__ unsigned long long kr_mstamps[32];
+#define KR_MSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) kr_mstamps[i] = wall_clock64(); } while (0)
+#else
+#define KR_MSTAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ float kr_mla_hsum8(float v) {   // lo+hi, movehdup, movehl (same tree as every hsum in decode.rs)
     v = v + __shfl_xor(v, 4);
     v = v + __shfl_xor(v, 1);
@@ -25,6 +32,11 @@ __device__ __forceinline__ float kr_h2f(uint16_t h) { return __half2float(__usho
 template <bool FP8> __device__ __forceinline__ float kr_mla_ld(const void* base, size_t i) {
     if (FP8) return kr_e4m3_to_f32(reinterpret_cast<const uint8_t*>(base)[i]);
     return kr_h2f(reinterpret_cast<const uint16_t*>(base)[i]);
+}
+template <bool FP8> __device__ __forceinline__ float kr_stage_val(const unsigned char* row, int i) {   // element i of a staged (LDS) row
+    if (FP8) return kr_e4m3_to_f32(row[i]);
+    _Float16 hv; __builtin_memcpy(&hv, row + 2 * i, 2);
+    return (float)hv;
 }
 template <bool FP8> __device__ __forceinline__ void kr_mla_st(void* base, size_t i, float v) {
     if (FP8) reinterpret_cast<uint8_t*>(base)[i] = kr_f32_to_e4m3(v);
@@ -177,6 +189,217 @@ __global__ void __launch_bounds__(512) kr_mla_attn_kernel(KrMlaArgs a) {
     }
 }
 
+// ---- launch 2, specialised: latent-cache rows staged through LDS ---------------------------------------------------------------
+// Same arithmetic and order as kr_mla_attn_kernel above; what changes is where the operands wait.  klr / 8, rd / 8 and the cache dtype
+// are template parameters (no run-time guards around the per-lane reads -- each would end a basic block with a wait), and the
+// compressed-KV + rope rows of 64 positions at a time are fetched by all 512 threads with 16-byte buffer loads (num_records = the
+// current length: rows past it read as zero) while the previous 64 are consumed from LDS.  The generic kernel issued one 2-byte global
+// load per element of every dot product and of every weighted-sum step: 215 ns per cached position per layer on a V2-Lite shape.
+#define KR_MLA_ROWS 64
+#define KR_MLA_HG 4          // heads that share a staged row in the decode scores launch
+// PHASE 0: scores + softmax + weighted sum of one head.  PHASE 2: softmax + weighted sum only, the scores come from a.sc_g (written by
+// kr_mla_scores_kernel, which shares every staged cache row between 8 heads and spreads over the position blocks).
+template <bool FP8, int NBC, int NBR, int PHASE>
+__global__ void __launch_bounds__(512) kr_mla_attn_staged_kernel(KrMlaArgs a, int max_seq) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[12];
+    constexpr int klr = NBC * 8, rd = NBR * 8, esz = FP8 ? 1 : 2;
+    constexpr int CPR_C = klr * esz / 16, CPR_R = rd * esz / 16;   // 16-byte chunks per staged row (latent part, rope part)
+    constexpr int pitch = (klr + rd) * esz + 16;
+    constexpr int NLC = KR_MLA_ROWS * CPR_C / 512;                                     // latent-row chunks per thread per stage (8 at klr 512 / FP16)
+    static_assert(KR_MLA_ROWS * CPR_C % 512 == 0 && KR_MLA_ROWS * CPR_R <= 512, "chunk split");
+    const int seq = kr_mla_token(a, blockIdx.y) + 1;
+    float* qa = lds; float* qp = qa + klr; float* sc = qp + rd;
+    unsigned char* stage = reinterpret_cast<unsigned char*>(sc) + ((((size_t)max_seq + 40) * 4 + 15) & ~(size_t)15);
+    const int h = blockIdx.x, t = threadIdx.x;
+    for (int i = t; i < klr; i += 512) qa[i] = a.q_abs[(size_t)h * klr + i];
+    for (int i = t; i < rd; i += 512) qp[i] = a.q_pe[(size_t)h * rd + i];
+    const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(a.ckv_cache, 0, seq * klr * esz, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(a.kpe_cache, 0, seq * rd * esz, 0x00020000);
+    // Every thread fetches NLC chunks of the latent rows and (threads below ROWS * CPR_R) one chunk of the rope rows: UNCONDITIONAL loads
+    // (a per-thread guard would put each load behind an exec-mask branch whose join waits for it) -- rows at or past the current length
+    // are outside the descriptors and read as zero.  Two stages are in flight (register sets r0 / r1): one stage's compute (~1.2 us)
+    // does not cover a memory round trip.
+    struct Regs { u32x4 c[NLC]; u32x4 r; };
+    const int rrow = t / CPR_R, rcol = t % CPR_R;
+    const bool has_r = t < KR_MLA_ROWS * CPR_R;
+    auto issue = [&](Regs& R, int s0) {
+#pragma unroll
+        for (int i = 0; i < NLC; i++) {
+            const int c = t + 512 * i, r = c / CPR_C, col = c % CPR_C;
+            R.c[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_c, (s0 + r) * klr * esz + col * 16, 0, 0);
+        }
+        R.r = __builtin_amdgcn_raw_buffer_load_b128(srd_r, has_r ? (s0 + rrow) * rd * esz + rcol * 16 : 0x7FFFFFF0, 0, 0);
+    };
+    auto commit = [&](const Regs& R) {
+#pragma unroll
+        for (int i = 0; i < NLC; i++) {
+            const int c = t + 512 * i, r = c / CPR_C, col = c % CPR_C;
+            *reinterpret_cast<u32x4*>(stage + r * pitch + col * 16) = R.c[i];
+        }
+        if (has_r) *reinterpret_cast<u32x4*>(stage + rrow * pitch + klr * esz + rcol * 16) = R.r;
+    };
+    Regs r0, r1;
+    const int nst = (seq + KR_MLA_ROWS - 1) / KR_MLA_ROWS;
+    KR_MSTAMP(0);
+    if (PHASE == 2) for (int s2 = t; s2 < seq; s2 += 512) sc[s2] = a.sc_g[(size_t)h * max_seq + s2];
+    else { issue(r0, 0); issue(r1, KR_MLA_ROWS); }
+    __syncthreads();
+    KR_MSTAMP(1);
+    // ---- scores: 16 lanes per position (mla_attn_dot_fp16_avx2): lane c = (accumulator a2 = c >> 3, AVX lane l = c & 7) owns the 8-blocks
+    // i % 2 == a2 (an odd trailing block goes to accumulator 0), ascending; (acc0 + acc1) then the 8-lane hsum; latent dot + rope dot
+    const int c16 = t & 15, a2 = c16 >> 3, l = c16 & 7, g = t >> 4;
+    constexpr int NQC = (NBC + 1) / 2, NQR = (NBR + 1) / 2;
+    float qc[NQC], qr[NQR];
+#pragma unroll
+    for (int u = 0; u < NQC; u++) { const int i = 2 * u + a2; qc[u] = (i < NBC && (i < (NBC & ~1) || a2 == 0)) ? qa[i * 8 + l] : 0.0f; }
+#pragma unroll
+    for (int u = 0; u < NQR; u++) { const int i = 2 * u + a2; qr[u] = (i < NBR && (i < (NBR & ~1) || a2 == 0)) ? qp[i * 8 + l] : 0.0f; }
+    static_assert(NBC % 2 == 0 && NBR % 2 == 0, "odd block counts take the generic kernel (a zero query element is not a skipped fma)");
+    for (int st = 0; st < (PHASE == 2 ? 0 : nst); st++) {
+        if (st) __syncthreads();
+        commit(r0);
+        r0 = r1;
+        issue(r1, (st + 2) * KR_MLA_ROWS);           // past the end: zeros, never committed
+        __syncthreads();
+        KR_MSTAMP(2);
+        const int s0 = st * KR_MLA_ROWS;
+#pragma unroll
+        for (int k2 = 0; k2 < KR_MLA_ROWS / 32; k2++) {
+            const int r = g + 32 * k2;
+            if (s0 + r < seq) {
+                const unsigned char* row = stage + r * pitch;
+                float kc[NQC], kr[NQR];
+#pragma unroll
+                for (int u = 0; u < NQC; u++) kc[u] = kr_stage_val<FP8>(row, (2 * u + a2) * 8 + l);
+#pragma unroll
+                for (int u = 0; u < NQR; u++) kr[u] = kr_stage_val<FP8>(row + klr * esz, (2 * u + a2) * 8 + l);
+                float acc = 0.0f;
+#pragma unroll
+                for (int u = 0; u < NQC; u++) acc = __builtin_fmaf(qc[u], kc[u], acc);
+                float oth = __shfl_xor(acc, 8);
+                float v = kr_mla_hsum8(a2 == 0 ? acc + oth : oth + acc);
+                acc = 0.0f;
+#pragma unroll
+                for (int u = 0; u < NQR; u++) acc = __builtin_fmaf(qr[u], kr[u], acc);
+                oth = __shfl_xor(acc, 8);
+                v += kr_mla_hsum8(a2 == 0 ? acc + oth : oth + acc);
+                v *= a.sm_scale;
+                if (c16 == 0) sc[s0 + r] = v;
+            }
+        }
+    }
+    KR_MSTAMP(3);
+    __syncthreads();
+    KR_MSTAMP(4);
+    float mx = -__builtin_inff();
+    for (int s = t; s < seq; s += 512) mx = fmaxf(mx, sc[s]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 8; w++) mx = fmaxf(mx, red[w]);
+    for (int s = t; s < seq; s += 512) sc[s] = kr_expf(sc[s] - mx);
+    const int seq32 = (seq + 31) & ~31;              // zero padding: the exponentials are >= +0, so s + 0.0f == s bit for bit
+    if (t < seq32 - seq) sc[seq + t] = 0.0f;
+    issue(r0, 0);                                    // the first stages of the weighted sum ride under the sequential sum
+    issue(r1, KR_MLA_ROWS);
+    __syncthreads();
+    KR_MSTAMP(5);
+    if (t == 0) red[8] = 1.0f / kr_seq_sum(sc, seq32);
+    KR_MSTAMP(6);
+    __syncthreads();
+    const float inv = red[8];
+    for (int s = t; s < seq; s += 512) sc[s] *= inv;
+    // ---- weighted sum (mla_weighted_sum_fp16_avx2): thread j owns latent element j, one fma per position in ascending order
+    float o = 0.0f;
+    for (int st = 0; st < nst; st++) {
+        __syncthreads();
+        commit(r0);
+        r0 = r1;
+        issue(r1, (st + 2) * KR_MLA_ROWS);
+        __syncthreads();
+        KR_MSTAMP(7);
+        if (t < klr) {
+            const int s0 = st * KR_MLA_ROWS, n = min(KR_MLA_ROWS, seq - s0);
+            for (int r = 0; r < n; r += 16) {        // n <= 64 and r % 16 == 0: rows r .. r + 15 are inside the stage
+                float vv[16], pp[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { vv[u] = kr_stage_val<FP8>(stage + (r + u) * pitch, t); pp[u] = sc[s0 + r + u]; }
+#pragma unroll
+                for (int u = 0; u < 16; u++) if (r + u < n) o = __builtin_fmaf(pp[u], vv[u], o);
+            }
+        }
+    }
+    KR_MSTAMP(8);
+    if (t < klr) a.attn_lat[(size_t)h * klr + t] = o;
+}
+
+// ---- decode, long caches: scores of 8 heads x 64 positions per workgroup ---------------------------------------------------------
+// The latent cache is shared by ALL heads, so a staged row should serve many of them: workgroup (position block x, head group y) stages
+// 64 rows once and evaluates them against KR_MLA_HG heads (16 lanes per (position, head) pair; a lane group keeps its head, so its
+// query slice stays in registers).  grid = (max_seq / 64, nh / KR_MLA_HG); blocks past the current length leave at once.  Same dot products,
+// same order as the per-head kernels.
+template <bool FP8, int NBC, int NBR>
+__global__ void __launch_bounds__(512) kr_mla_scores_kernel(KrMlaArgs a, int max_seq) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int klr = NBC * 8, rd = NBR * 8, esz = FP8 ? 1 : 2, HG = KR_MLA_HG;
+    constexpr int CPR_C = klr * esz / 16, CPR_R = rd * esz / 16, pitch = (klr + rd) * esz + 16, NLC = KR_MLA_ROWS * CPR_C / 512;
+    const int seq = a.step->pos + 1, s0 = blockIdx.x * KR_MLA_ROWS, t = threadIdx.x;
+    if (s0 >= seq) return;
+    const int hg0 = blockIdx.y * HG, nhg = min(HG, a.nh - hg0);
+    float* qa = lds; float* qp = qa + HG * klr;
+    unsigned char* stage = reinterpret_cast<unsigned char*>(qp + HG * rd);
+    const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(a.ckv_cache, 0, seq * klr * esz, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(a.kpe_cache, 0, seq * rd * esz, 0x00020000);
+    u32x4 rc[NLC];
+#pragma unroll
+    for (int i = 0; i < NLC; i++) { const int c = t + 512 * i, r = c / CPR_C, col = c % CPR_C; rc[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_c, (s0 + r) * klr * esz + col * 16, 0, 0); }
+    const int rrow = t / CPR_R, rcol = t % CPR_R;
+    const bool has_r = t < KR_MLA_ROWS * CPR_R;
+    const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(srd_r, has_r ? (s0 + rrow) * rd * esz + rcol * 16 : 0x7FFFFFF0, 0, 0);
+    for (int i = t; i < nhg * klr; i += 512) qa[i] = a.q_abs[(size_t)hg0 * klr + i];
+    for (int i = t; i < nhg * rd; i += 512) qp[i] = a.q_pe[(size_t)hg0 * rd + i];
+#pragma unroll
+    for (int i = 0; i < NLC; i++) { const int c = t + 512 * i, r = c / CPR_C, col = c % CPR_C; *reinterpret_cast<u32x4*>(stage + r * pitch + col * 16) = rc[i]; }
+    if (has_r) *reinterpret_cast<u32x4*>(stage + rrow * pitch + klr * esz + rcol * 16) = rr;
+    __syncthreads();
+    const int c16 = t & 15, a2 = c16 >> 3, l = c16 & 7, g = t >> 4, hh = g % HG, prow = g / HG;
+    if (hh >= nhg) return;
+    constexpr int NQC = NBC / 2, NQR = NBR / 2;
+    float qc[NQC], qr[NQR];
+#pragma unroll
+    for (int u = 0; u < NQC; u++) qc[u] = qa[hh * klr + (2 * u + a2) * 8 + l];
+#pragma unroll
+    for (int u = 0; u < NQR; u++) qr[u] = qp[hh * rd + (2 * u + a2) * 8 + l];
+    float* out = a.sc_g + (size_t)(hg0 + hh) * max_seq + s0;
+#pragma unroll 1
+    for (int pass = 0; pass < KR_MLA_ROWS / (32 / HG); pass++) {
+        const int r = prow + (32 / HG) * pass;
+        if (s0 + r >= seq) break;
+        const unsigned char* row = stage + r * pitch;
+        float kc[NQC], kr[NQR];
+#pragma unroll
+        for (int u = 0; u < NQC; u++) kc[u] = kr_stage_val<FP8>(row, (2 * u + a2) * 8 + l);
+#pragma unroll
+        for (int u = 0; u < NQR; u++) kr[u] = kr_stage_val<FP8>(row + klr * esz, (2 * u + a2) * 8 + l);
+        float acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NQC; u++) acc = __builtin_fmaf(qc[u], kc[u], acc);
+        float oth = __shfl_xor(acc, 8);
+        float v = kr_mla_hsum8(a2 == 0 ? acc + oth : oth + acc);
+        acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NQR; u++) acc = __builtin_fmaf(qr[u], kr[u], acc);
+        oth = __shfl_xor(acc, 8);
+        v += kr_mla_hsum8(a2 == 0 ? acc + oth : oth + acc);
+        v *= a.sm_scale;
+        if (c16 == 0) out[r] = v;
+    }
+}
+
 // ---- launch 3: v_projected[h][o] = w_vc[h][o][:] . attn_lat[h][:]   grid (vhd/8, nh), 128 threads = 8 outputs x 16 lanes ----
 __global__ void __launch_bounds__(128) kr_mla_wvc_kernel(KrMlaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -214,13 +437,44 @@ __global__ void __launch_bounds__(256) kr_rmsnorm_seq_kernel(float* __restrict__
     for (int i = t; i < n; i += 256) x[i] = lds[i] * (rms * w[i]);
 }
 
+static size_t kr_mla_staged_lds(const KrMlaArgs& a, int max_seq) {
+    const size_t esz = a.kv_fp8 ? 1 : 2;
+    return (size_t)(a.klr + a.rd) * 4 + ((((size_t)max_seq + 40) * 4 + 15) & ~(size_t)15) + (size_t)KR_MLA_ROWS * ((size_t)(a.klr + a.rd) * esz + 16);
+}
+template <bool FP8, int NBC>
+static bool kr_launch_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {
+    const size_t lds = kr_mla_staged_lds(a, max_seq);
+    const size_t esz = a.kv_fp8 ? 1 : 2;
+    const size_t lds_sc = (size_t)KR_MLA_HG * (a.klr + a.rd) * 4 + (size_t)KR_MLA_ROWS * ((size_t)(a.klr + a.rd) * esz + 16);
+    if (lds > 160 * 1024) return false;
+    static size_t lds_set = 0;                       // per instantiation; raised outside graph capture by kr_mla_attn_prepare
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute((const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void*)kr_mla_scores_kernel<FP8, NBC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess) return false;
+        lds_set = lds;
+    }
+    if (!s) return true;                             // prepare-only call
+    if (a.sc_g && n_tok == 1) {                      // decode with a long cache: head-shared scores launch, then softmax + weighted sum per head
+        hipLaunchKernelGGL((kr_mla_scores_kernel<FP8, NBC, 8>), dim3((max_seq + KR_MLA_ROWS - 1) / KR_MLA_ROWS, (a.nh + KR_MLA_HG - 1) / KR_MLA_HG), dim3(512), lds_sc, s, a, max_seq);
+        hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>), dim3(a.nh, 1), dim3(512), lds, s, a, max_seq);
+    } else hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 0>), dim3(a.nh, n_tok), dim3(512), lds, s, a, max_seq);
+    return true;
+}
+static bool kr_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {
+    if (a.rd != 64) return false;
+    if (a.klr == 512) return a.kv_fp8 ? kr_launch_mla_staged<true, 64>(a, max_seq, s, n_tok) : kr_launch_mla_staged<false, 64>(a, max_seq, s, n_tok);
+    if (a.klr == 256) return a.kv_fp8 ? kr_launch_mla_staged<true, 32>(a, max_seq, s, n_tok) : kr_launch_mla_staged<false, 32>(a, max_seq, s, n_tok);
+    return false;
+}
+// raises the staged kernel's dynamic-LDS window; called outside graph capture (hipFuncSetAttribute is not a stream operation)
+void kr_mla_attn_prepare(const KrMlaArgs& a, int max_seq) { (void)kr_mla_staged(a, max_seq, nullptr, 1); }
 void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {
-    if (a.kv_fp8) {
-        hipLaunchKernelGGL(kr_mla_prep_kernel<true>, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(kr_mla_attn_kernel<true>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
-    } else {
-        hipLaunchKernelGGL(kr_mla_prep_kernel<false>, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(kr_mla_attn_kernel<false>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
+    if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_prep_kernel<true>, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(kr_mla_prep_kernel<false>, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
+    if (!kr_mla_staged(a, max_seq, s, n_tok)) {      // other geometries: the generic kernel
+        if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_attn_kernel<true>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
+        else hipLaunchKernelGGL(kr_mla_attn_kernel<false>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
     }
     hipLaunchKernelGGL(kr_mla_wvc_kernel, dim3((a.vhd + 7) / 8, a.nh, n_tok), dim3(128), (size_t)a.klr * 4, s, a);
 }

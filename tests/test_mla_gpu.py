@@ -15,12 +15,12 @@ def _ptr(a):
     return a.ctypes.data
 
 
-def build(seed=0, lora=False, klr=512, nh=4):
+def build(seed=0, lora=False, klr=512, nh=4, kv_max=24):
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     rng = np.random.default_rng(seed)
     H, V, E, k, I, SI = 256, 384, 8, 3, 128, 256           # shared expert = 2 x I like V2-Lite (n_shared_experts = 2)
     nd, rd, vhd, qlr = 128, 64, 128, 384
-    kv_max, nL = 24, 2
+    nL = 2
     emb = ((rng.random((V, H)) - 0.5) * 0.2).astype(F)
     eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, nL, 2, 1.0))
     eng.set_routing_config("softmax", False, k, E, H)       # V2-Lite: softmax, no top-k renormalisation
@@ -158,6 +158,33 @@ def test_mla_fp8_latent_cache_bit_exact(cfg):
         st.set_prefill_chunk(3)
         pf = np.empty(d["V"], F); st.prefill(toks, 8, pf.ctypes.data)
         assert np.array_equal(pf.view(np.uint32), seq.view(np.uint32))
+    finally:
+        O.set_kv_fp8(False)
+
+
+@pytest.mark.parametrize("cfg,fp8", [(dict(kv_max=600, nh=11), False), (dict(kv_max=600, lora=True, seed=2, klr=256), False), (dict(kv_max=560, nh=9, seed=6), True)])
+def test_mla_long_cache_split_attention_bit_exact(cfg, fp8):
+    """kv_max_seq > 512: decode scores run in their own launch that shares every staged latent row between 8 heads (position blocks x head
+    groups, ragged last head group), softmax + weighted sum per head; positions around the 64-row stage boundaries"""
+    st, eng, orc, keep, d = build(**cfg)
+    if fp8:
+        st.set_kv_dtype(True); O.set_kv_fp8(True)
+    try:
+        nL = d["nL"]
+        if fp8:
+            rng = np.random.default_rng(4)
+            ck = [O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["klr"])) * 0.5).astype(F)) for _ in range(nL)]
+            kp = [O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["rd"])) * 0.5).astype(F)) for _ in range(nL)]
+            for li in range(nL):
+                orc.layers[li]["ckv"] = ck[li].astype(np.uint16); orc.layers[li]["kpe"] = kp[li].astype(np.uint16)
+            st.set_decode_state(5, d["kv_max"], [0] * nL, [0] * nL, [0] * nL, [0] * nL, [_ptr(x) for x in ck], [_ptr(x) for x in kp])
+        tok = 9
+        for pos in [5, 62, 63, 64, 65, 127, 128, 191, d["kv_max"] - 1]:
+            logits = np.empty(d["V"], F)
+            st.decode_step(tok, pos, logits.ctypes.data)
+            ref = orc.step(tok, pos)
+            assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (pos, float(np.max(np.abs(logits - ref))))
+            tok = O.sample_greedy(ref)
     finally:
         O.set_kv_fp8(False)
 
