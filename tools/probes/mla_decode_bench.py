@@ -45,3 +45,12 @@ for pos in (10, 100, 500, kv_max - 2):
     for i in range(20): st.decode_step(0, pos)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("pos %5d  %.3f ms/step  (%.1f tok/s)" % (pos, dt / 20 * 1e3, 20 / dt), flush=True)
+
+# prompt pass over the MLA arm (batched projections, per-token attention launches with a token dimension)
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if P:
+    st.fill_state_synthetic(kv_max, seed=9)
+    toks = [int(x) for x in np.random.default_rng(5).integers(0, V, P)]
+    st.prefill(toks, 0); torch.cuda.synchronize()
+    t0 = time.perf_counter(); st.prefill(toks, 0); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("prompt pass %d tokens: %.1f ms  (%.0f tok/s)" % (P, dt * 1e3, P / dt), flush=True)
