@@ -344,7 +344,7 @@ def main():
                        "parallelism": "replica x%d (QCN fits one GPU; decode is not expert-parallel)" % world,
                        "hip_graph": not args.no_graph, "target_tok_s": 200},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM fetch bytes per launch (PMC FETCH_SIZE, separate pass)",
+                         "frac": achieved / HBM_PEAK_GBS, "peak_measured_stream_read": 6996.0, "peak_measured_source": "tools/probes/hbm_stream.hip on this box type (8 GiB, 16-byte loads)", "traffic": traffic, "traffic_unit": "HBM fetch bytes per launch (PMC FETCH_SIZE, separate pass)",
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": sym_bytes[dom] / max(sym_n[dom], 1), "us_per_launch": sym_us[dom] / max(sym_n[dom], 1),
                          "launches_per_step": sym_n[dom],
