@@ -90,7 +90,8 @@ def build_qcn(rank, local_rank, L, rope_len=0):
     q = QCN; H, I, E, k, V = q["hidden"], q["inter"], q["experts"], q["topk"], q["vocab"]
     eng = KrasisEngine(device=local_rank)
     eng.configure(ModelConfig(H, I, E, k, L, 0, 1.0))
-    eng.fill_synthetic(4, seed=0x12345678ABCDEF01 + rank)
+    bits = int(os.environ.get("KR_BENCH_BITS", "4"))            # probe hook: 8 = INT8-g128 weights everywhere (not the headline configuration)
+    eng.fill_synthetic(bits, seed=0x12345678ABCDEF01 + rank)
     eng.set_routing_config("softmax", True, k, E, H)
     st = CpuDecodeStore(128, True, True)                       # norm_bias_one: qwen3_next (decode.rs:4701)
     st.set_moe_store(eng)
@@ -100,7 +101,7 @@ def build_qcn(rank, local_rank, L, rope_len=0):
 
     def W(rows, cols):
         seed[0] += 1
-        return st.store_weight_synthetic(rows, cols, 4, seed[0])
+        return st.store_weight_synthetic(rows, cols, bits, seed[0])
 
     def N(n):
         w = ((rng.random(n, dtype=np.float32) - 0.5) * 0.2).astype(np.float32); keep.append(w)

@@ -575,8 +575,8 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.gu = (float*)s->moe_gu.p; a.eo = (float*)s->moe_eo.p; a.out = nullptr; a.out_bf16 = 0;
             a.rsf = s->rsf; a.swiglu_limit = e->cfg.swiglu_limit; a.alpha = e->cfg.activation_alpha;
             a.act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
-            // the shared expert's sigmoid-gate row rides in the shared slot's w13 launch when both are INT4
-            const bool fuse_gate = has_gate && a.w13.bits == 4 && a.sw13.bits == 4 && mv(s, L.sg_wid).bits == 4;
+            // the shared expert's sigmoid-gate row rides in the shared slot's w13 launch when routed, shared and gate weights have one width
+            const bool fuse_gate = has_gate && a.w13.bits == a.sw13.bits && mv(s, L.sg_wid).bits == a.w13.bits;
             if (fuse_gate) { a.sgate = mv(s, L.sg_wid); a.gate_out = (float*)s->gate_val.p; }
             PROF(PK_MOE_W13, kr_launch_moe_w13(a, st));
             if (has_gate && !fuse_gate) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), act, 1, (float*)s->gate_val.p, st));

@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a,
     KrPre pre;
     const bool gate_wave = with_gate && first == ntiles;
     if (first < ntiles) kr_preload<BITS>(pre, sl.q13, sl.s13, m, first, lane, 0);
-    else if (gate_wave) kr_preload<4>(pre, a.sgate.q, a.sgate.s, a.sgate, 0, lane, 0);
+    else if (gate_wave) kr_preload<BITS>(pre, a.sgate.q, a.sgate.s, a.sgate, 0, lane, 0);   // the gate row has the width of the launch (host check)
     const KrActLds L = kr_carve_lds(kr_smem, a.H, BITS == 8);
     const bool round_bf16 = !(sl.shared && a.shared_decode);
     const void* img = BITS == 4 && a.B == 1 ? (round_bf16 ? a.act_img_bf16 : a.act_img) : nullptr;   // pre-built by the router launch
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a,
             const int col = tile * 8 + (lane >> 3);
             if ((lane & 7) == 0 && col < m.N) gu[col] = acc;
         } else if (with_gate && tile == ntiles) {
-            const float acc = kr_matvec_tile<4>(pre, t == 0, a.sgate.q, a.sgate.s, a.sgate, 0, L, lane);
+            const float acc = kr_matvec_tile<BITS>(pre, t == 0, a.sgate.q, a.sgate.s, a.sgate, 0, L, lane);
             if (lane == 0) a.gate_out[b] = acc;
         }
     }
