@@ -15,13 +15,13 @@ def _ptr(a):
     return a.ctypes.data
 
 
-def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4):
+def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4, dims=None, kinds=None):
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     rng = np.random.default_rng(seed)
-    H, V, E, k, I, SI = 256, 512, 16, 4, 128, 128
+    H, V, E, k, I, SI = dims or (256, 512, 16, 4, 128, 128)
     nk, nv, dk, dv = 2, 4, 128, 128
     nkv, d2 = 2, 8
-    kinds = ["la", "gqa", "la"] + (["gqa"] if with_dense else [])
+    kinds = kinds or (["la", "gqa", "la"] + (["gqa"] if with_dense else []))
     nL = len(kinds)
     emb = ((rng.random((V, H)) - 0.5) * 0.2).astype(F)
     eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, nL, 0, rsf))
@@ -140,6 +140,21 @@ def test_decode_step_split_attention_bit_exact(hd, graph):
     st.set_use_graph(graph)
     tok = 5
     for pos in [3, 255, 256, 257, 700, 1023, 1024, 1299]:
+        logits = np.empty(d["V"], F)
+        st.decode_step(tok, pos, logits.ctypes.data)
+        ref = orc.step(tok, pos)
+        assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (pos, float(np.max(np.abs(logits - ref))))
+        tok = O.sample_greedy(ref)
+
+
+@pytest.mark.parametrize("dims,hd,nh", [((2048, 512, 72, 10, 512, 512), 256, 16),      # Qwen3-Coder-Next widths (hidden 2048, I 512, top-10, head_dim 256, 8 q / kv head)
+                                         ((4096, 384, 72, 8, 1536, 1536), 128, 32)])     # Qwen3-235B widths (hidden 4096, I 1536, top-8, head_dim 128)
+def test_decode_step_production_widths_bit_exact(dims, hd, nh):
+    """one linear-attention + one GQA layer at the real models' widths (expert count reduced): the K = 2048 / 4096 paths of the
+    cooperative matvec, the 32-chunk gate rows and the NV > 1 selection of the fused router, the 256-wide heads"""
+    st, eng, orc, keep, d = build(seed=21, dims=dims, hd=hd, nh=nh, kv_max=48, kinds=["la", "gqa"])
+    tok = 3
+    for pos in [5, 6, 40]:
         logits = np.empty(d["V"], F)
         st.decode_step(tok, pos, logits.ctypes.data)
         ref = orc.step(tok, pos)
