@@ -95,6 +95,26 @@ def test_prefill_wide_heads_long_prompt(hd, nh, fp8):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_prefill_production_widths():
+    """prompt pass == sequential decode at Qwen3-Coder-Next widths (hidden 2048, I 512, top-10 of 72, head_dim 256, 8 q heads per KV head)"""
+    st, eng, orc, keep, d = build(seed=23, dims=(2048, 512, 72, 10, 512, 512), hd=256, nh=16, kv_max=160, kinds=["la", "gqa"])
+    rng = np.random.default_rng(2)
+    toks = [int(x) for x in rng.integers(0, d["V"], 90)]
+    ref_logits = np.empty(d["V"], F)
+    for i, t in enumerate(toks):
+        st.decode_step(t, 11 + i, ref_logits.ctypes.data)
+    ref_tok = st.last_token(); ref_state = _snapshot(st, d)
+    d["reset"]()
+    st.set_prefill_chunk(40); st.set_prefill_depth(3)
+    logits = np.empty(d["V"], F)
+    tok = st.prefill(toks, 11, logits.ctypes.data)
+    assert np.array_equal(logits.view(np.uint32), ref_logits.view(np.uint32)), float(np.max(np.abs(logits - ref_logits)))
+    assert tok == ref_tok
+    for li, (a, b) in enumerate(zip(_snapshot(st, d), ref_state)):
+        assert np.array_equal(a[0].view(np.uint32) if a[0].dtype == F else a[0], b[0].view(np.uint32) if b[0].dtype == F else b[0]), ("state0", li)
+        assert np.array_equal(a[1].view(np.uint32) if a[1].dtype == F else a[1], b[1].view(np.uint32) if b[1].dtype == F else b[1]), ("state1", li)
+
+
 def test_prefill_argument_errors():
     st, eng, orc, keep, d = build()
     with pytest.raises(ValueError):
