@@ -15,10 +15,10 @@ def _ptr(a):
     return a.ctypes.data
 
 
-def build(seed=0, lora=False, klr=512, nh=4, kv_max=24):
+def build(seed=0, lora=False, klr=512, nh=4, kv_max=24, dims=None):
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     rng = np.random.default_rng(seed)
-    H, V, E, k, I, SI = 256, 384, 8, 3, 128, 256           # shared expert = 2 x I like V2-Lite (n_shared_experts = 2)
+    H, V, E, k, I, SI = dims or (256, 384, 8, 3, 128, 256)   # shared expert = 2 x I like V2-Lite (n_shared_experts = 2)
     nd, rd, vhd, qlr = 128, 64, 128, 384
     nL = 2
     emb = ((rng.random((V, H)) - 0.5) * 0.2).astype(F)
@@ -187,6 +187,28 @@ def test_mla_long_cache_split_attention_bit_exact(cfg, fp8):
             tok = O.sample_greedy(ref)
     finally:
         O.set_kv_fp8(False)
+
+
+def test_mla_production_widths_bit_exact():
+    """DeepSeek-V2-Lite widths: hidden 2048, 16 heads, kv_lora 512, expert intermediate 1408 (11 quantization groups: the odd-group
+    padding of the lane-tiled layout), shared expert 2816, top-6 (expert count reduced to 12); decode steps + prompt pass"""
+    st, eng, orc, keep, d = build(seed=31, nh=16, kv_max=40, dims=(2048, 384, 12, 6, 1408, 2816))
+    tok = 4
+    for pos in [5, 6, 30]:
+        logits = np.empty(d["V"], F)
+        st.decode_step(tok, pos, logits.ctypes.data)
+        ref = orc.step(tok, pos)
+        assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (pos, float(np.max(np.abs(logits - ref))))
+        tok = O.sample_greedy(ref)
+    st2, eng2, orc2, keep2, d2 = build(seed=31, nh=16, kv_max=40, dims=(2048, 384, 12, 6, 1408, 2816))
+    toks = [3, 17, 99, 250, 7, 7, 41, 300, 12]
+    seq = np.empty(d["V"], F)
+    st2.set_prefill_chunk(4)
+    pf = np.empty(d["V"], F); st2.prefill(toks, 5, pf.ctypes.data)
+    st3, eng3, orc3, keep3, d3 = build(seed=31, nh=16, kv_max=40, dims=(2048, 384, 12, 6, 1408, 2816))
+    for i, t in enumerate(toks):
+        st3.decode_step(t, 5 + i, seq.ctypes.data)
+    assert np.array_equal(pf.view(np.uint32), seq.view(np.uint32)), float(np.max(np.abs(pf - seq)))
 
 
 def test_mla_geometry_errors():
