@@ -9,6 +9,7 @@
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 
 #ifdef KR_TIMING   // tools/probes/gqa_timing.hip: wall-clock stamps (10 ns units) written by thread 0 of workgroup 0, no-op in the product build
 __device__ unsigned long long kr_dstamps[32];
@@ -551,6 +552,76 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
     // ---- scores: 8 lanes per position, lane l owns elements b*8 + l (the AVX2 lane), ascending b, then the 8-lane hsum
     const int l = t & 7, g = t >> 3, nb = NB ? NB : (hd >> 3);
     constexpr int NBM = NB ? NB : 32;
+    if (PHASE == 3) {
+        // ---- caches too long for an LDS-resident score row: the row stays in a.sc_g and is streamed in tiles.  max -> exp (in place) ->
+        // position-ordered sum over 4096-value tiles (one thread, the running sum carried across tiles) -> p.v with the stage's 128
+        // probabilities scaled into a small LDS window.  Same operations, same order as the resident form.
+        constexpr int TILE = 4096;
+        float* tile = sc;                                    // [TILE + 32]; lds_seq == TILE for this phase
+        float* row = a.sc_g + (size_t)h * max_seq;
+        float mx = -__builtin_inff();
+        for (int s = t; s < seq; s += 256) mx = fmaxf(mx, row[s]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if ((t & 63) == 0) red[t >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        for (int s = t; s < seq; s += 256) row[s] = kr_expf(row[s] - mx);
+        issue(vbase, 0);
+        __syncthreads();
+        float se = 0.0f;
+        for (int s0 = 0; s0 < seq; s0 += TILE) {
+            const int n = min(TILE, seq - s0), n32 = (n + 31) & ~31;
+            for (int i = t; i < n32; i += 256) tile[i] = i < n ? row[s0 + i] : 0.0f;   // zero padding: s + 0.0f == s for sums of exponentials
+            __syncthreads();
+            if (t == 0) { se = kr_seq_sum(tile, n32, se); red[5] = se; }
+            __syncthreads();
+        }
+        const float inv3 = 1.0f / red[5];
+        float o = 0.0f;
+        for (int st = 0; st < nst; st++) {
+            __syncthreads();
+            commit();
+            if (st + 1 < nst) issue(vbase, (st + 1) * KR_GQA_ROWS);
+            const int s0 = st * KR_GQA_ROWS, n = min(KR_GQA_ROWS, seq - s0);
+            if (t < KR_GQA_ROWS) tile[t] = t < n ? row[s0 + t] * inv3 : 0.0f;          // sc[s] *= inv (decode.rs:4260)
+            __syncthreads();
+            if (t < hd) {
+                for (int r = 0; r < n; r += 16) {
+                    float vv[16], pp[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) { vv[u] = kr_stage_elem<FP8>(stage + (r + u) * pitch, t); pp[u] = tile[r + u]; }
+#pragma unroll
+                    for (int u = 0; u < 16; u++) if (r + u < n) o = __builtin_fmaf(pp[u], vv[u], o);
+                }
+            }
+        }
+        if (t < hd) {
+            if (a.gated) { const float gt = a.gate[(size_t)h * hd + t]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
+            a.attn_out[(size_t)h * hd + t] = o;
+            if (a.img_out) qs[t] = o;
+        }
+        if (a.img_out) {
+            __syncthreads();
+            const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(a.img_out), a.nh * hd, false);
+            const int nch = hd / 8, c = t;
+            if (c < nch) {
+                float v8[8];
+                kr_load8(qs, c, v8);
+                float mx8 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) mx8 = fmaxf(mx8, fabsf(v8[i]));
+                float scale, inv;
+                kr_group_scale(mx8, scale, inv);
+                int q8[8];
+                kr_quant8<false>(v8, inv, q8);
+                const int gc = h * nch + c;
+                kr_store_chunk<false>(Lg, gc, q8);
+                if ((gc & 15) == 0) Lg.ascale[gc >> 4] = scale;
+            }
+        }
+        return;
+    }
     const int st_lo = PHASE == 1 ? (int)blockIdx.y * 2 : 0, st_hi = PHASE == 1 ? min(nst, st_lo + 2) : (PHASE == 2 ? 0 : nst);
     if (PHASE == 2) {                            // scores of this head come from the scores launch
         for (int s = t; s < seq; s += 256) sc[s] = a.sc_g[(size_t)h * max_seq + s];
@@ -786,16 +857,17 @@ static size_t kr_gqa_attn_lds(int max_seq, int hd, int fp8) {
     return ((((size_t)max_seq + 40) * 4 + 15) & ~(size_t)15) + (size_t)KR_GQA_ROWS * ((size_t)hd * (fp8 ? 1 : 2) + 16);
 }
 // Raises the kernel's dynamic-LDS window (gfx950: 160 KiB per workgroup).  Called outside graph capture, before the first launch.
+// LDS-resident score rows fit up to ~23 k positions; beyond that the softmax / p.v launch streams the row from HBM (PHASE 3)
+static bool kr_gqa_resident(int max_seq, int hd, int fp8) { return kr_gqa_attn_lds(max_seq, hd, fp8) <= 160 * 1024; }
 int kr_gqa_attn_prepare(int max_seq, int hd, int fp8) {
-    const size_t lds = kr_gqa_attn_lds(max_seq, hd, fp8);
-    if (lds > 160 * 1024) return -1;
+    const size_t lds = kr_gqa_resident(max_seq, hd, fp8) ? kr_gqa_attn_lds(max_seq, hd, fp8) : kr_gqa_attn_lds(4096, hd, fp8);
     static size_t lds_set[2] = {0, 0};
     if (lds > lds_set[fp8 ? 1 : 0]) {
-#define KR_F(F_, N_) (const void*)kr_gqa_attn_kernel<F_, N_, 0>, (const void*)kr_gqa_attn_kernel<F_, N_, 1>, (const void*)kr_gqa_attn_kernel<F_, N_, 2>
-        const void* f16[12] = {KR_F(false, 8), KR_F(false, 16), KR_F(false, 32), KR_F(false, 0)};
-        const void* f8[12] = {KR_F(true, 8), KR_F(true, 16), KR_F(true, 32), KR_F(true, 0)};
+#define KR_F(F_, N_) (const void*)kr_gqa_attn_kernel<F_, N_, 0>, (const void*)kr_gqa_attn_kernel<F_, N_, 1>, (const void*)kr_gqa_attn_kernel<F_, N_, 2>, (const void*)kr_gqa_attn_kernel<F_, N_, 3>
+        const void* f16[16] = {KR_F(false, 8), KR_F(false, 16), KR_F(false, 32), KR_F(false, 0)};
+        const void* f8[16] = {KR_F(true, 8), KR_F(true, 16), KR_F(true, 32), KR_F(true, 0)};
 #undef KR_F
-        for (int i = 0; i < 12; i++)
+        for (int i = 0; i < 16; i++)
             if (hipFuncSetAttribute(fp8 ? f8[i] : f16[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
         lds_set[fp8 ? 1 : 0] = lds;
     }
@@ -813,7 +885,8 @@ void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
     hipLaunchKernelGGL(kr_gqa_prep_kernel, dim3(a.nh + a.nkv), dim3(256), 0, s, a);
     if (a.sc_g) {      // long cache: scores over nh x max_seq / 256 workgroups (those past the current length leave at once), then softmax + p.v
         kr_launch_gqa_phase<1>(a, max_seq, dim3(a.nh, (max_seq + 255) / 256), 0, s);
-        kr_launch_gqa_phase<2>(a, max_seq, dim3(a.nh), max_seq, s);
+        if (kr_gqa_resident(max_seq, a.hd, a.kv_fp8) && !getenv("KR_GQA_STREAM")) kr_launch_gqa_phase<2>(a, max_seq, dim3(a.nh), max_seq, s);   // (env: test hook)
+        else kr_launch_gqa_phase<3>(a, max_seq, dim3(a.nh), 4096, s);
     } else kr_launch_gqa_phase<0>(a, max_seq, dim3(a.nh), max_seq, s);
 }
 void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const float* wts, int topk, int has_shared, const float* gate_val,

@@ -180,8 +180,8 @@ __device__ __forceinline__ void kr_kv_store(void* base, size_t i, float v, int f
 // current 16 are being added, so the chain of dependent adds is the only latency left.  x must be 16-byte aligned.
 #define KR_ADD16(s, a0, a1, a2, a3) do { s += a0.x; s += a0.y; s += a0.z; s += a0.w; s += a1.x; s += a1.y; s += a1.z; s += a1.w; \
                                            s += a2.x; s += a2.y; s += a2.z; s += a2.w; s += a3.x; s += a3.y; s += a3.z; s += a3.w; } while (0)
-__device__ __forceinline__ float kr_seq_sum(const float* x, int n) {
-    float s = 0.0f; int e = 0;
+__device__ __forceinline__ float kr_seq_sum(const float* x, int n, float s = 0.0f) {   // s: the running sum so far (tiled callers)
+    int e = 0;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     if (n >= 32) {   // two register sets (A, B): B's ds_reads are in flight while A is added and vice versa
         float4 a0 = x4[0], a1 = x4[1], a2 = x4[2], a3 = x4[3];

@@ -147,6 +147,35 @@ def test_decode_step_split_attention_bit_exact(hd, graph):
         tok = O.sample_greedy(ref)
 
 
+@pytest.mark.parametrize("hd,fp8", [(64, False), (256, False), (128, True)])
+def test_decode_step_streamed_attention_bit_exact(hd, fp8, monkeypatch):
+    """caches too long for an LDS-resident score row (> ~23 k positions) stream it from HBM in tiles; KR_GQA_STREAM forces that form
+    on a cache the oracle can follow, positions across the 128-row stage and 4096-value tile boundaries"""
+    monkeypatch.setenv("KR_GQA_STREAM", "1")
+    st, eng, orc, keep, d = build(seed=12, kv_max=4400, hd=hd)
+    if fp8:
+        st.set_kv_dtype(True); O.set_kv_fp8(True)
+    try:
+        if fp8:
+            rng = np.random.default_rng(5)
+            kv = {li: (O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)), O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)))
+                  for li, kind in enumerate(d["kinds"]) if kind == "gqa"}
+            for li in kv:
+                orc.layers[li]["kv_k"] = kv[li][0].astype(np.uint16); orc.layers[li]["kv_v"] = kv[li][1].astype(np.uint16)
+            n = len(d["kinds"]); ptr = lambda a: a.ctypes.data
+            st.set_decode_state(5, d["kv_max"], [ptr(kv[i][0]) if i in kv else 0 for i in range(n)], [ptr(kv[i][1]) if i in kv else 0 for i in range(n)],
+                                [ptr(x) if x is not None else 0 for x in d["state"]["conv"]], [ptr(x) if x is not None else 0 for x in d["state"]["recur"]])
+        tok = 5
+        for pos in [3, 127, 128, 1500, 4095, 4096, 4399]:
+            logits = np.empty(d["V"], F)
+            st.decode_step(tok, pos, logits.ctypes.data)
+            ref = orc.step(tok, pos)
+            assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (pos, float(np.max(np.abs(logits - ref))))
+            tok = O.sample_greedy(ref)
+    finally:
+        O.set_kv_fp8(False)
+
+
 @pytest.mark.parametrize("dims,hd,nh", [((2048, 512, 72, 10, 512, 512), 256, 16),      # Qwen3-Coder-Next widths (hidden 2048, I 512, top-10, head_dim 256, 8 q / kv head)
                                          ((4096, 384, 72, 8, 1536, 1536), 128, 32)])     # Qwen3-235B widths (hidden 4096, I 1536, top-8, head_dim 128)
 def test_decode_step_production_widths_bit_exact(dims, hd, nh):
