@@ -13,6 +13,7 @@
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 
 #ifdef KR_TIMING   // tools/probes/mla_timing.hip: wall-clock stamps (10 ns units) of thread 0 of workgroup 0, no-op in the product build
 __device__ unsigned long long kr_mstamps[32];
@@ -199,8 +200,11 @@ __global__ void __launch_bounds__(512) kr_mla_attn_kernel(KrMlaArgs a) {
 #define KR_MLA_HG 4          // heads that share a staged row in the decode scores launch
 // PHASE 0: scores + softmax + weighted sum of one head.  PHASE 2: softmax + weighted sum only, the scores come from a.sc_g (written by
 // kr_mla_scores_kernel, which shares every staged cache row between 8 heads and spreads over the position blocks).
+// PHASE 3: as PHASE 2 for caches whose score row does not fit LDS (> ~21 k positions): the row stays in a.sc_g and is streamed in tiles
+// (max, exp in place, position-ordered sum over 4096-value tiles with the running sum carried, the stage's 64 probabilities scaled
+// into a small LDS window).  `lds_seq` sizes the LDS score window (max_seq, or the tile for PHASE 3).
 template <bool FP8, int NBC, int NBR, int PHASE>
-__global__ void __launch_bounds__(512) kr_mla_attn_staged_kernel(KrMlaArgs a, int max_seq) {
+__global__ void __launch_bounds__(512) kr_mla_attn_staged_kernel(KrMlaArgs a, int max_seq, int lds_seq) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[12];
     constexpr int klr = NBC * 8, rd = NBR * 8, esz = FP8 ? 1 : 2;
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(512) kr_mla_attn_staged_kernel(KrMlaArgs a, in
     static_assert(KR_MLA_ROWS * CPR_C % 512 == 0 && KR_MLA_ROWS * CPR_R <= 512, "chunk split");
     const int seq = kr_mla_token(a, blockIdx.y) + 1;
     float* qa = lds; float* qp = qa + klr; float* sc = qp + rd;
-    unsigned char* stage = reinterpret_cast<unsigned char*>(sc) + ((((size_t)max_seq + 40) * 4 + 15) & ~(size_t)15);
+    unsigned char* stage = reinterpret_cast<unsigned char*>(sc) + ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15);
     const int h = blockIdx.x, t = threadIdx.x;
     for (int i = t; i < klr; i += 512) qa[i] = a.q_abs[(size_t)h * klr + i];
     for (int i = t; i < rd; i += 512) qp[i] = a.q_pe[(size_t)h * rd + i];
@@ -242,6 +246,53 @@ __global__ void __launch_bounds__(512) kr_mla_attn_staged_kernel(KrMlaArgs a, in
     Regs r0, r1;
     const int nst = (seq + KR_MLA_ROWS - 1) / KR_MLA_ROWS;
     KR_MSTAMP(0);
+    if (PHASE == 3) {
+        constexpr int TILE = 4096;
+        float* tile = sc;
+        float* row = a.sc_g + (size_t)h * max_seq;
+        float mx = -__builtin_inff();
+        for (int s2 = t; s2 < seq; s2 += 512) mx = fmaxf(mx, row[s2]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if ((t & 63) == 0) red[t >> 6] = mx;
+        __syncthreads();
+        mx = red[0];
+#pragma unroll
+        for (int w = 1; w < 8; w++) mx = fmaxf(mx, red[w]);
+        for (int s2 = t; s2 < seq; s2 += 512) row[s2] = kr_expf(row[s2] - mx);
+        issue(r0, 0); issue(r1, KR_MLA_ROWS);
+        __syncthreads();
+        float se = 0.0f;
+        for (int s0 = 0; s0 < seq; s0 += TILE) {
+            const int n = min(TILE, seq - s0), n32 = (n + 31) & ~31;
+            for (int i = t; i < n32; i += 512) tile[i] = i < n ? row[s0 + i] : 0.0f;
+            __syncthreads();
+            if (t == 0) { se = kr_seq_sum(tile, n32, se); red[9] = se; }
+            __syncthreads();
+        }
+        const float inv3 = 1.0f / red[9];
+        float o3 = 0.0f;
+        for (int st = 0; st < nst; st++) {
+            __syncthreads();
+            commit(r0);
+            r0 = r1;
+            issue(r1, (st + 2) * KR_MLA_ROWS);
+            const int s0 = st * KR_MLA_ROWS, n = min(KR_MLA_ROWS, seq - s0);
+            if (t < KR_MLA_ROWS) tile[t] = t < n ? row[s0 + t] * inv3 : 0.0f;
+            __syncthreads();
+            if (t < klr) {
+                for (int r = 0; r < n; r += 16) {
+                    float vv[16], pp[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) { vv[u] = kr_stage_val<FP8>(stage + (r + u) * pitch, t); pp[u] = tile[r + u]; }
+#pragma unroll
+                    for (int u = 0; u < 16; u++) if (r + u < n) o3 = __builtin_fmaf(pp[u], vv[u], o3);
+                }
+            }
+        }
+        if (t < klr) a.attn_lat[(size_t)h * klr + t] = o3;
+        return;
+    }
     if (PHASE == 2) for (int s2 = t; s2 < seq; s2 += 512) sc[s2] = a.sc_g[(size_t)h * max_seq + s2];
     else { issue(r0, 0); issue(r1, KR_MLA_ROWS); }
     __syncthreads();
@@ -437,28 +488,32 @@ __global__ void __launch_bounds__(256) kr_rmsnorm_seq_kernel(float* __restrict__
     for (int i = t; i < n; i += 256) x[i] = lds[i] * (rms * w[i]);
 }
 
-static size_t kr_mla_staged_lds(const KrMlaArgs& a, int max_seq) {
+static size_t kr_mla_staged_lds(const KrMlaArgs& a, int lds_seq) {
     const size_t esz = a.kv_fp8 ? 1 : 2;
-    return (size_t)(a.klr + a.rd) * 4 + ((((size_t)max_seq + 40) * 4 + 15) & ~(size_t)15) + (size_t)KR_MLA_ROWS * ((size_t)(a.klr + a.rd) * esz + 16);
+    return (size_t)(a.klr + a.rd) * 4 + ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15) + (size_t)KR_MLA_ROWS * ((size_t)(a.klr + a.rd) * esz + 16);
 }
 template <bool FP8, int NBC>
 static bool kr_launch_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {
-    const size_t lds = kr_mla_staged_lds(a, max_seq);
+    const bool resident = kr_mla_staged_lds(a, max_seq) <= 160 * 1024 && !getenv("KR_MLA_STREAM");   // (env: test hook)
+    const bool split = a.sc_g && n_tok == 1;
+    if (!resident && !split) return false;          // the prompt pass keeps the score row in LDS: the generic kernel reports the limit
+    const int lds_seq = resident ? max_seq : 4096;
+    const size_t lds = kr_mla_staged_lds(a, lds_seq);
     const size_t esz = a.kv_fp8 ? 1 : 2;
     const size_t lds_sc = (size_t)KR_MLA_HG * (a.klr + a.rd) * 4 + (size_t)KR_MLA_ROWS * ((size_t)(a.klr + a.rd) * esz + 16);
-    if (lds > 160 * 1024) return false;
     static size_t lds_set = 0;                       // per instantiation; raised outside graph capture by kr_mla_attn_prepare
     if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        if (hipFuncSetAttribute((const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        const void* fns[3] = {(const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 0>, (const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>, (const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 3>};
+        for (const void* f : fns) if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         if (hipFuncSetAttribute((const void*)kr_mla_scores_kernel<FP8, NBC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess) return false;
         lds_set = lds;
     }
     if (!s) return true;                             // prepare-only call
-    if (a.sc_g && n_tok == 1) {                      // decode with a long cache: head-shared scores launch, then softmax + weighted sum per head
+    if (split) {                                     // decode with a long cache: head-shared scores launch, then softmax + weighted sum per head
         hipLaunchKernelGGL((kr_mla_scores_kernel<FP8, NBC, 8>), dim3((max_seq + KR_MLA_ROWS - 1) / KR_MLA_ROWS, (a.nh + KR_MLA_HG - 1) / KR_MLA_HG), dim3(512), lds_sc, s, a, max_seq);
-        hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>), dim3(a.nh, 1), dim3(512), lds, s, a, max_seq);
-    } else hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 0>), dim3(a.nh, n_tok), dim3(512), lds, s, a, max_seq);
+        if (resident) hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>), dim3(a.nh, 1), dim3(512), lds, s, a, max_seq, lds_seq);
+        else hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 3>), dim3(a.nh, 1), dim3(512), lds, s, a, max_seq, lds_seq);
+    } else hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 0>), dim3(a.nh, n_tok), dim3(512), lds, s, a, max_seq, lds_seq);
     return true;
 }
 static bool kr_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {

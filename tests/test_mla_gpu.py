@@ -189,6 +189,35 @@ def test_mla_long_cache_split_attention_bit_exact(cfg, fp8):
         O.set_kv_fp8(False)
 
 
+@pytest.mark.parametrize("cfg,fp8", [(dict(kv_max=9000, nh=5, seed=8), False), (dict(kv_max=8300, nh=3, seed=9, klr=256), True),
+                                     (dict(kv_max=24000, nh=2, seed=10), False)])
+def test_mla_streamed_score_row_bit_exact(cfg, fp8, monkeypatch):
+    """caches whose score row does not fit LDS (> ~21 k positions) keep it in HBM: max / exp / position-ordered sum stream over 4096-value
+    tiles.  Forced here at a length the oracle finishes quickly (KR_MLA_STREAM), over a randomly filled cache, around the tile edges"""
+    monkeypatch.setenv("KR_MLA_STREAM", "1")
+    st, eng, orc, keep, d = build(**cfg)
+    if fp8:
+        st.set_kv_dtype(True); O.set_kv_fp8(True)
+    try:
+        nL = d["nL"]
+        rng = np.random.default_rng(14)
+        conv = O.f32_to_e4m3 if fp8 else O.f32_to_bf16
+        ck = [conv((rng.standard_normal((d["kv_max"], d["klr"])) * 0.5).astype(F)) for _ in range(nL)]
+        kp = [conv((rng.standard_normal((d["kv_max"], d["rd"])) * 0.5).astype(F)) for _ in range(nL)]
+        for li in range(nL):
+            orc.layers[li]["ckv"] = ck[li].astype(np.uint16); orc.layers[li]["kpe"] = kp[li].astype(np.uint16)
+        st.set_decode_state(5, d["kv_max"], [0] * nL, [0] * nL, [0] * nL, [0] * nL, [_ptr(x) for x in ck], [_ptr(x) for x in kp])
+        tok = 9
+        for pos in [5, 63, 64, 4094, 4095, 4096, 4131, 8191, 8192, d["kv_max"] - 1]:   # 24000 positions: streamed without the hook
+            logits = np.empty(d["V"], F)
+            st.decode_step(tok, pos, logits.ctypes.data)
+            ref = orc.step(tok, pos)
+            assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (pos, float(np.max(np.abs(logits - ref))))
+            tok = O.sample_greedy(ref)
+    finally:
+        O.set_kv_fp8(False)
+
+
 def test_mla_production_widths_bit_exact():
     """DeepSeek-V2-Lite widths: hidden 2048, 16 heads, kv_lora 512, expert intermediate 1408 (11 quantization groups: the odd-group
     padding of the lane-tiled layout), shared expert 2816, top-6 (expert count reduced to 12); decode steps + prompt pass"""

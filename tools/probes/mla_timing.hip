@@ -24,7 +24,7 @@ int main() {
     for (int pos : {9, 63, 127, 511, 1023, 2047}) for (int rep = 0; rep < 2; rep++) {
         KrStep hs{}; hs.token = 0; hs.pos = pos; CK(hipMemcpy(dstep, &hs, sizeof(hs), hipMemcpyHostToDevice));
         CK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL((kr_mla_attn_staged_kernel<false, 64, 8, 0>), dim3(nh, 1), dim3(512), lds, st, a, max_seq);
+        hipLaunchKernelGGL((kr_mla_attn_staged_kernel<false, 64, 8, 0>), dim3(nh, 1), dim3(512), lds, st, a, max_seq, max_seq);
         CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         unsigned long long s[32]; CK(hipMemcpyFromSymbol(s, HIP_SYMBOL(kr_mstamps), sizeof(s)));
