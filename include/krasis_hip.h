@@ -195,6 +195,15 @@ int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype);                   
  * conv / recurrent states are bit-identical to n successive kr_decode_step calls (decode.rs:2690-3520).  GEMM-shaped work runs on the
  * int8-MFMA grouped GEMM with the exact INT16-digit arithmetic.  INT4 / INT8-g128 weights; linear-attention, GQA and MLA layers. */
 int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int n_tokens, int start_pos, float* logits_out, void* stream);
+/* Scoring prompt pass = the reference's model.forward(..., return_all_logits=True) + cross_entropy(logits[:-1], tokens[1:], reduction="none")
+ * (perplexity/measure_ppl.py:212-227): as kr_decode_prefill, plus final norm + lm_head for EVERY position (one [chunk, vocab] GEMM per
+ * chunk, never the [n, vocab] tensor) and nll_out[i] = logsumexp(logits_i) - logits_i[tokens[i+1]] for i in [0, n_tokens-1), f32, host or
+ * device.  The logits are the decode step's bit for bit; the log-sum-exp sums f32 expf terms in double and rounds once (within one f32 ulp of a
+ * float64 restatement; tests hold it to 4e-6 absolute at nll < 16). */
+int kr_decode_prefill_nll(kr_decode_store* s, const int32_t* tokens, int n_tokens, int start_pos, float* nll_out, float* logits_out, void* stream);
+/* fresh request state: zero caches / conv / recurrent states sized for kv_max_seq (measure_ppl.py:199-206: new SequenceKVState per window +
+ * linear-attention reset_state()) */
+int kr_decode_reset_state(kr_decode_store* s, int kv_max_seq);
 /* tokens per chunk of the prompt pass (0 = default 1024).  Chunks rotate over `depth` HIP streams and scratch arenas: layer l of
  * chunk c+1 runs concurrently with layer l+1 of chunk c (per-layer events carry the state / KV dependencies). */
 int kr_decode_set_prefill_chunk(kr_decode_store* s, int chunk);

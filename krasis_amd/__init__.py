@@ -8,5 +8,6 @@ from ._lib import KrasisHipError, lib_path, load_library  # noqa: F401
 from .engine import KrasisEngine, ModelConfig  # noqa: F401
 from .decode_store import CpuDecodeStore  # noqa: F401
 from .prefill import GpuPrefillManager  # noqa: F401
+from .perplexity import evaluate_perplexity  # noqa: F401
 
-__all__ = ["KrasisEngine", "ModelConfig", "CpuDecodeStore", "GpuPrefillManager", "KrasisHipError", "load_library", "lib_path"]
+__all__ = ["KrasisEngine", "ModelConfig", "CpuDecodeStore", "GpuPrefillManager", "evaluate_perplexity", "KrasisHipError", "load_library", "lib_path"]

@@ -61,7 +61,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                            &l.w_kc, &l.w_vc, &l.kv_a_norm, &l.q_a_norm, &l.mla_cos, &l.mla_sin}) b->release();
     for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
-                      &s->hid2, &s->res2, &s->r_counter, &s->gqa_scores, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
+                      &s->hid2, &s->res2, &s->r_counter, &s->gqa_scores, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_vlogits, &s->pf_nll, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     for (hipEvent_t ev : s->pf_events) (void)hipEventDestroy(ev);
     for (hipStream_t ps : s->pf_side) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
     if (s->step_host) (void)hipHostFree(s->step_host);
@@ -354,6 +354,7 @@ extern "C" int kr_decode_set_state(kr_decode_store* s, int seq_len, int kv_max_s
     if (int rc = need_cfg(s)) return rc;
     (void)seq_len;
     KR_HIP(hipSetDevice(s->eng->device));
+    KR_HIP(hipDeviceSynchronize());          // steps still in flight on the engine's (non-blocking) streams write these buffers
     s->kv_max_seq = kv_max_seq;
     for (size_t i = 0; i < s->layers.size(); i++) {
         DLayer& L = s->layers[i];
@@ -374,6 +375,20 @@ extern "C" int kr_decode_set_state(kr_decode_store* s, int seq_len, int kv_max_s
         }
     }
     s->graph_ok = false;
+    return KR_OK;
+}
+
+// fresh request: zero KV / latent caches, conv and recurrent states (what the perplexity harness does per window: new SequenceKVState +
+// layer.attention.reset_state(), perplexity/measure_ppl.py:199-206)
+extern "C" int kr_decode_reset_state(kr_decode_store* s, int kv_max_seq) {
+    if (int rc = need_cfg(s)) return rc;
+    if (kv_max_seq <= 0) return kr_fail(KR_ERR_VALUE, "kv_max_seq must be positive, got %d", kv_max_seq);
+    if (int rc = kr_decode_set_state(s, 0, kv_max_seq, nullptr, nullptr, nullptr, nullptr)) return rc;
+    for (auto& L : s->layers) {
+        if (L.attn != ATTN_LA) continue;
+        KR_HIP(hipMemset(L.conv_state.p, 0, (size_t)(2 * L.nk * L.dk + L.nv * L.dv) * L.kd * 4));
+        KR_HIP(hipMemset(L.recur_state.p, 0, (size_t)L.nv * L.dk * L.dv * 4));
+    }
     return KR_OK;
 }
 

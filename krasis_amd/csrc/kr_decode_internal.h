@@ -53,6 +53,7 @@ struct kr_decode_store {
     bool fuse_router = true;   // hid2/res2: outputs of the fused norm+router launch (its inputs stay readable for every workgroup)
     DevBuf smp_seen, smp_keys, smp_temp, smp_probs, smp_rng; size_t smp_temp_bytes = 0;   // sampler: seen bitmap, sort keys / scratch, probabilities, xorshift64 state
     DevBuf pf_scores;          // kr_decode_prefill: attention scores [chunk*nh rows][context] f32
+    DevBuf pf_vlogits, pf_nll; // kr_decode_prefill_nll: [chunk, vocab] logits per arena; per-position negative log-likelihoods
     DevBuf pf_tokens; int pf_chunk = 0; int pf_depth = 0; std::vector<hipStream_t> pf_side; std::vector<hipEvent_t> pf_events;   // prompt pass: token ids, chunk size, second stream
     DevBuf pf_scratch;         // kr_decode_prefill: one arena for the chunk buffers
     DevBuf moe_gu, moe_eo, r_logits, r_ids, r_w;  // store-owned so a captured graph never sees them reallocated

@@ -168,7 +168,26 @@ static void run_final(kr_decode_store* s, Chunk& cx) {
     kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, cx.st);
 }
 
-extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int n_tokens, int start_pos, float* logits_out, void* stream) {
+// scoring mode (kr_decode_prefill_nll): final norm + lm_head GEMM for EVERY token of the chunk, then the next-token negative log-likelihood
+// per row; the last chunk also leaves the last row's logits and greedy sample where run_final would
+static int run_final_all(kr_decode_store* s, Chunk& cx, float* vlogits, int first_tok, int n_tokens, bool last) {
+    Scratch& B = cx.B; const int H = s->hidden; const size_t V = (size_t)s->vocab;
+    KrPfmNormArgs na{};
+    na.mode = cx.add_is_emb ? 1 : 0; na.add_in = B.hid; na.emb = (const float*)s->embedding.p; na.tokens = cx.tok; na.res = B.res;
+    na.w = (const float*)s->norms[s->final_norm]->p; na.out = B.normed; na.xh = B.xh; na.xl = B.xl; na.xs = B.xs; na.H = H; na.first = cx.first ? 1 : 0;
+    na.bias_one = s->norm_bias_one; na.eps = s->eps;
+    kr_launch_pfm_norm(na, cx.Cc, cx.st);
+    if (int rc = pf_gemm(s, s->lm_head, B.xh, B.xl, B.xs, cx.Cc, vlogits, (int)V, cx.st)) return rc;
+    const int scored = std::min(cx.Cc, n_tokens - 1 - first_tok);      // the last prompt token has no label
+    kr_launch_pfm_nll(vlogits, V, cx.tok + 1, (float*)s->pf_nll.p + first_tok, scored, (int)V, cx.st);
+    if (last) {
+        KR_HIP(hipMemcpyAsync(s->logits.p, vlogits + (size_t)(cx.Cc - 1) * V, V * 4, hipMemcpyDeviceToDevice, cx.st));
+        kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, cx.st);
+    }
+    return KR_OK;
+}
+
+static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens, int start_pos, float* logits_out, float* nll_out, void* stream) {
     if (!s) return kr_fail(KR_ERR_VALUE, "null decode store");
     if (!s->configured) return kr_fail(KR_ERR_STATE, "Call configure_decode first");
     if (!tokens || n_tokens <= 0) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill: empty prompt");
@@ -220,6 +239,7 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
             for (int w : {Ly.gate_wid, Ly.up_wid, Ly.down_wid}) wids.push_back(w);
         }
     }
+    if (nll_out) wids.push_back(s->lm_head);
     for (int w : wids) {
         DWeight& W = *s->weights[w];
         if (int rc = kr_ensure_wsum(e, W.ms, st)) return rc;
@@ -237,6 +257,9 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
     const size_t sc_ld_max = (size_t)((start_pos + n_tokens + 63) & ~63), sc_bytes = al(C * sc_rows * (sc_ld_max + 1) * 4);
     if (s->pf_scratch.ensure(total * n_arenas) || s->pf_tokens.ensure((size_t)n_tokens * 4) || (sc_rows && s->pf_scores.ensure(sc_bytes * n_arenas)))
         return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch (%zu MiB) failed", (total * n_arenas + sc_bytes * n_arenas) >> 20);
+    const size_t vl_bytes = al(C * (size_t)s->vocab * 4);                 // scoring mode: logits of a whole chunk, one buffer per arena
+    if (nll_out && (s->pf_vlogits.ensure(vl_bytes * n_arenas) || s->pf_nll.ensure((size_t)n_tokens * 4)))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of the all-position logits (%zu MiB) failed", (vl_bytes * n_arenas) >> 20);
     KR_HIP(hipMemcpyAsync(s->pf_tokens.p, tokens, (size_t)n_tokens * 4, hipMemcpyHostToDevice, st));
     auto carve = [&](int arena) {
         char* base = (char*)s->pf_scratch.p + (size_t)arena * total;
@@ -282,11 +305,13 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
                 if (c > 0 && D > 1) KR_HIP(hipStreamWaitEvent(cx.st, s->pf_events[(size_t)((c - 1) % D) * L + l], 0));
                 if (int rc = run_layer(s, cx, (size_t)l)) return rc;
                 if (D > 1) KR_HIP(hipEventRecord(s->pf_events[(size_t)(c % D) * L + l], cx.st));
+                if (nll_out && l == L - 1)
+                    if (int rc = run_final_all(s, cx, (float*)((char*)s->pf_vlogits.p + (size_t)cx.set * vl_bytes), c * CH, n_tokens, c == n_chunks - 1)) return rc;
             }
         }
     }
     Chunk& last = chunks[n_chunks - 1];
-    run_final(s, last);
+    if (!nll_out) run_final(s, last);
     for (int i = 1; i < D; i++) {                                          // results become visible on the caller's stream
         KR_HIP(hipEventRecord(s->pf_events[ev_end + i], streams[i]));
         KR_HIP(hipStreamWaitEvent(st, s->pf_events[ev_end + i], 0));
@@ -296,7 +321,21 @@ extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int 
         if (is_device_ptr(logits_out)) KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToDevice, st));
         else { KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }
     }
+    if (nll_out && n_tokens > 1) {
+        if (is_device_ptr(nll_out)) KR_HIP(hipMemcpyAsync(nll_out, s->pf_nll.p, (size_t)(n_tokens - 1) * 4, hipMemcpyDeviceToDevice, st));
+        else { KR_HIP(hipMemcpyAsync(nll_out, s->pf_nll.p, (size_t)(n_tokens - 1) * 4, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }
+    }
     return KR_OK;
+}
+
+extern "C" int kr_decode_prefill(kr_decode_store* s, const int32_t* tokens, int n_tokens, int start_pos, float* logits_out, void* stream) {
+    return prefill_impl(s, tokens, n_tokens, start_pos, logits_out, nullptr, stream);
+}
+// prompt pass that also scores the prompt: nll_out[i] = -log softmax(logits at position i)[tokens[i + 1]], i in [0, n_tokens - 1)
+extern "C" int kr_decode_prefill_nll(kr_decode_store* s, const int32_t* tokens, int n_tokens, int start_pos, float* nll_out, float* logits_out, void* stream) {
+    if (!nll_out) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill_nll: null nll_out");
+    if (n_tokens < 2) return kr_fail(KR_ERR_VALUE, "Need at least 2 tokens, got %d", n_tokens);
+    return prefill_impl(s, tokens, n_tokens, start_pos, logits_out, nll_out, stream);
 }
 
 // tuning hook: chunks in flight (1..4, 0 = default 2)

@@ -27,6 +27,7 @@ struct KrPfmGqaArgs {
     int gated, nh, nkv, hd, pos0; float eps, sm_scale;
 };
 void kr_launch_pfm_norm(const KrPfmNormArgs& a, int C, hipStream_t st);
+void kr_launch_pfm_nll(const float* logits, size_t ld, const int* labels, float* nll, int rows, int V, hipStream_t st);
 void kr_launch_pfm_quant_f32(const float* x, int rows, int ld, int K, int8_t* xh, int8_t* xl, float* xs, hipStream_t st);
 // conv + conv-state update + gated delta rule over the chunk + gated RMSNorm; non-zero = unsupported geometry
 int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out, const float* norm_w, float* gated_out, int C, float eps, hipStream_t st);

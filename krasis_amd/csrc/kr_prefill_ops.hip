@@ -728,3 +728,36 @@ int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float*
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st) {
     hipLaunchKernelGGL(kr_pfm_moe_epilogue_kernel, dim3((H + 255) / 256, C), dim3(256), 0, st, moe, shared, gate_val, gate_ld, rsf, hidden, H);
 }
+
+// ---- negative log-likelihood of the next token per prompt position (perplexity/measure_ppl.py:218-227: cross_entropy(logits[:-1], tokens[1:],
+// reduction="none") in f32).  One workgroup per row: maximum, then sum of expf(x - max) accumulated in double (the order of a double sum
+// moves the f32 result by far less than one ulp), nll = log(sum) + max - x[label] rounded once.  HBM-bound: one read of the row.
+__global__ void __launch_bounds__(1024) kr_pfm_nll_kernel(const float* __restrict__ logits, size_t ld, const int* __restrict__ labels, float* __restrict__ nll, int V) {
+    __shared__ float redf[16];
+    __shared__ double redd[16];
+    const float* x = logits + (size_t)blockIdx.x * ld;
+    const int t = threadIdx.x;
+    float mx = -__builtin_inff();
+    for (int i = t; i < V; i += 1024) mx = fmaxf(mx, x[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((t & 63) == 0) redf[t >> 6] = mx;
+    __syncthreads();
+    mx = redf[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) mx = fmaxf(mx, redf[w]);
+    double sm = 0.0;
+    for (int i = t; i < V; i += 1024) sm += (double)kr_expf(x[i] - mx);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sm += __shfl_xor(sm, off);
+    if ((t & 63) == 0) redd[t >> 6] = sm;
+    __syncthreads();
+    if (t == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; w++) tot += redd[w];
+        nll[blockIdx.x] = (float)(log(tot) + (double)mx - (double)x[labels[blockIdx.x]]);
+    }
+}
+void kr_launch_pfm_nll(const float* logits, size_t ld, const int* labels, float* nll, int rows, int V, hipStream_t st) {
+    if (rows > 0) hipLaunchKernelGGL(kr_pfm_nll_kernel, dim3(rows), dim3(1024), 0, st, logits, ld, labels, nll, V);
+}

@@ -172,6 +172,23 @@ class CpuDecodeStore:
         check(self._lib.kr_decode_prefill(self._h, arr, len(tokens), start_pos, output_ptr or None, stream or None))
         return self.last_token()
 
+    def prefill_nll(self, tokens: Sequence[int], start_pos: int = 0, output_ptr: int = 0, stream: int = 0) -> np.ndarray:
+        """Scoring prompt pass (kr_decode_prefill_nll): the prompt pass plus, per position i < n-1, the next-token negative log-likelihood
+        -log softmax(logits_i)[tokens[i+1]] -- model.forward(return_all_logits=True) + cross_entropy(reduction="none") of the perplexity
+        harness (perplexity/measure_ppl.py:212-227) without materialising [n, vocab].  Returns f32 [n-1]."""
+        self._need()
+        if len(tokens) < 2:
+            raise ValueError(f"Need at least 2 tokens, got {len(tokens)}")
+        arr = (C.c_int32 * len(tokens))(*tokens)
+        nll = np.empty(len(tokens) - 1, np.float32)
+        check(self._lib.kr_decode_prefill_nll(self._h, arr, len(tokens), start_pos, nll.ctypes.data, output_ptr or None, stream or None))
+        return nll
+
+    def reset_decode_state(self, kv_max_seq: int) -> None:
+        """fresh request: zeroed KV / latent caches, conv and recurrent states (measure_ppl.py:199-206)"""
+        self._need()
+        check(self._lib.kr_decode_reset_state(self._h, kv_max_seq))
+
     def set_prefill_chunk(self, chunk: int) -> None:
         """Tokens per chunk of the prompt pass (0 = default); chunks alternate between two streams."""
         self._need(); check(self._lib.kr_decode_set_prefill_chunk(self._h, chunk))

@@ -547,6 +547,14 @@ def mla_step(kv_out, q_full, kv_a_norm, w_kc, w_vc, rope_cos, rope_sin, nh, klr,
     return out, ck, kp
 
 
+def cross_entropy_nll(logits, label: int) -> float:
+    """-log softmax(logits)[label]: torch.nn.functional.cross_entropy(reduction="none") of the perplexity harness
+    (perplexity/measure_ppl.py:218-227), restated in float64 (numpy); the HIP kernel is held to 4e-6 absolute against it"""
+    x = np.asarray(logits, np.float64)
+    mx = float(x.max())
+    return float(np.log(np.exp(x - mx).sum()) + mx - x[int(label)])
+
+
 def sample_greedy(logits) -> int:
     lg = _c(logits, np.float32)
     return int(lib().kro_sample_greedy(_p(lg), lg.size))
