@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--prefill-chunk", type=int, default=0, help="tokens per chunk of the prompt pass (0 = library default)")
     ap.add_argument("--prefill-depth", type=int, default=0, help="chunks of the prompt pass in flight (0 = library default)")
     ap.add_argument("--prefill-reps", type=int, default=2, help="timed repetitions of the whole-model prompt pass")
+    ap.add_argument("--no-ep", action="store_true", help="skip the expert-parallel prompt-pass leg of the N > 1 lines")
+    ap.add_argument("--ep-selftest", action="store_true", help="run the expert-parallel leg at N = 1 too (no collectives: checks the row path)")
     ap.add_argument("--prefill-tokens", type=int, default=8192, help="tokens per prefill chunk for the experts-only prefill side measurement (0 = skip)")
     return ap.parse_args()
 
@@ -170,6 +172,44 @@ def prefill_experts(eng, L, M, torch):
             "note": "experts only (sort + 2 grouped GEMMs + act + combine): the MFMA-bound part of the prompt pass in isolation"}
 
 
+def prefill_ep(eng, L, M, world, rank, torch, dist):
+    """Expert-parallel prompt-pass experts over RCCL (krasis_amd/ep.py, mode "alltoall"): every rank owns E/N experts and M
+    tokens; each (token, slot) row travels once to the rank that owns its expert (all_to_all over the xGMI mesh), runs through the int8-MFMA
+    expert GEMMs there, the f32 expert row comes back and the source rank combines its k rows in routing order -- bit-identical to one GPU
+    (tests/test_ep_cpu.py world 2 on gloo, tests/test_ep_gpu.py).  All L MoE layers, uniform random routing, weak scaling (M tokens per rank).
+    The bench engines are replicas, so a rank's slice is experts [0, E/N) of its resident synthetic set: same bytes, same arithmetic."""
+    from krasis_amd.ep import ExpertParallelMoE, engine_row_ops
+    q = QCN; H, I, E, k = q["hidden"], q["inter"], q["experts"], q["topk"]
+    g = torch.Generator(device="cuda").manual_seed(7 + rank)
+    x = ((torch.rand((M, H), device="cuda", generator=g) - 0.5)).to(torch.bfloat16)
+    ids = torch.rand((M, E), device="cuda", generator=g).topk(k, dim=1).indices.to(torch.int32)
+    w = torch.softmax(torch.randn((M, k), device="cuda", generator=g), dim=1)
+    ops, combine = engine_row_ops(eng)
+    ep = ExpertParallelMoE(ops, E, mode="alltoall")
+    for l in range(min(L, 2)):
+        ep.forward(l, x, ids, w, combine)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for l in range(L):
+        ep.forward(l, x, ids, w, combine)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    macs = world * M * k * 3 * H * I * L
+    off = (world - 1) / world                          # share of the rows that leave the GPU under uniform routing
+    return {"tokens_per_gpu": M, "tokens_total": world * M, "layers": L, "ms": dt * 1e3, "tok_s_experts_only": world * M / dt, "scaling": "weak",
+            "experts_per_gpu": E // world, "effective_TFLOPs_2MAC": 2.0 * macs / dt / 1e12,
+            "exchange_GB_per_gpu_per_layer": {"dispatch_bf16": M * k * H * 2 * off / 1e9, "combine_f32": M * k * H * 4 * off / 1e9},
+            "note": "sort by owner + all_to_all dispatch + expert GEMMs + all_to_all combine, per layer, no overlap between layers; "
+                    "compare with prefill_experts_only of the N = 1 line"}
+
+
 def prefill_model(st, L, P, reps, torch):
     """Whole-model prompt pass (kr_decode_prefill): P synthetic tokens through all L layers (projection + expert GEMMs on int8 MFMA, exact
     gated-delta-rule recurrence, exact causal GQA attention, router, norms), bit-identical to token-by-token decode.  tok/s = P / time."""
@@ -275,7 +315,8 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=5))
 
     from krasis_amd import _lib
     L = args.layers
@@ -322,6 +363,13 @@ def main():
         prefill_full = prefill_model(st, L, args.prefill_tokens, args.prefill_reps, torch)
         prefill_full["chunk"] = args.prefill_chunk or 1024; prefill_full["chunks_in_flight"] = args.prefill_depth or 3
 
+    ep_leg = None
+    if args.prefill_tokens > 0 and not args.no_ep and (world > 1 or args.ep_selftest):   # every rank takes part; same call sequence on all
+        try:
+            ep_leg = prefill_ep(eng, L, args.prefill_tokens, world, rank, torch, dist)
+        except Exception as ex:
+            ep_leg = {"error": repr(ex)}
+
     if rank == 0:
         ab = algorithmic_bytes(L)
         sym_us, sym_bytes, sym_n = {}, {}, {}
@@ -358,6 +406,8 @@ def main():
             res["prefill"] = prefill_full
         if prefill is not None:
             res["prefill_experts_only"] = prefill
+        if ep_leg is not None:
+            res["prefill_experts_ep_alltoall"] = ep_leg
         if not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L)

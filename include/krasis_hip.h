@@ -132,6 +132,9 @@ int kr_forward_moe_routed(kr_engine* e, int layer, const void* act_bf16, void* o
 /* ---- reduce_sum_bf16 (moe.rs:2505): N-way bf16 sum, f32 accumulate in input order, RNE ---- */
 int kr_reduce_sum_bf16(kr_engine* e, const void* const* inputs, int n_inputs, void* out, size_t n, void* stream);
 
+/* test / tuning hook: (token, slot) pairs per pass of kr_moe_prefill (0 = default 81 920: 8192 tokens of a top-10 model, 81 920 top-1 rows
+ * of the expert-parallel dispatch); larger batches are walked in passes of pairs / topk tokens */
+int kr_moe_set_prefill_pairs(kr_engine* e, int pairs);
 /* expert-parallel combine: out[t] = sum_s w[t][s] * eo_rows[pair_row[t][s]] in routing order (moe.rs:661-667); pair_row -1 = skip */
 int kr_combine_rows(kr_engine* e, const float* eo_rows, const int32_t* pair_row, const float* weights, void* out, int M, int topk,
                     int out_dtype, void* stream);

@@ -726,7 +726,10 @@ int kr_ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st) {
     return KR_OK;
 }
 
-#define KR_PF_CHUNK 8192
+// tokens per pass of the expert path are bounded by (token, slot) PAIRS, the unit the scratch and the GEMM row tiles are sized in: a
+// top-10 batch walks 8192 tokens at a time, the top-1 rows of the expert-parallel dispatch 81 920 -- so every expert's weights are
+// streamed once per ~80 k pairs either way
+#define KR_PF_PAIRS 81920
 
 int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
                        int out_dtype, int routed_only, int set, hipStream_t st) {
@@ -748,7 +751,9 @@ int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_
     if (int rc = kr_ensure_wsum(e, L.w13, st)) return rc;
     if (int rc = kr_ensure_wsum(e, L.w2, st)) return rc;
     if (use_shared) { if (int rc = kr_ensure_wsum(e, L.sw13, st)) return rc; if (int rc = kr_ensure_wsum(e, L.sw2, st)) return rc; }
-    const int CH = M < KR_PF_CHUNK ? M : KR_PF_CHUNK;
+    const int pairs = e->pf_pairs > 0 ? e->pf_pairs : KR_PF_PAIRS;
+    const int CHmax = pairs / topk > 64 ? pairs / topk : 64;
+    const int CH = M < CHmax ? M : CHmax;
     const size_t np = (size_t)CH * topk;
     const int max_tiles = (int)(np / 64) + E + 1;
     const size_t n_i32 = 3 * (size_t)E + 3 * (size_t)max_tiles + 4 + 2 * np;
@@ -797,6 +802,14 @@ extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const
                               int out_dtype, int routed_only, void* stream) {
     if (int rc = check_layer(e, layer)) return rc;
     return kr_moe_prefill_set(e, layer, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, 0, kr_pick_stream(e, stream));
+}
+
+// test / tuning hook: (token, slot) pairs per pass of kr_moe_prefill (0 = default 81 920)
+extern "C" int kr_moe_set_prefill_pairs(kr_engine* e, int pairs) {
+    if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
+    if (pairs < 0) return kr_fail(KR_ERR_VALUE, "pairs must be >= 0, got %d", pairs);
+    e->pf_pairs = pairs;
+    return KR_OK;
 }
 
 // Expert-parallel combine (krasis_amd/ep.py): rows returned by the owning ranks are summed per token in routing order with the routing

@@ -81,6 +81,7 @@ struct kr_engine {
     bool routing_set = false; int r_scoring = 1, r_norm = 1, r_topk = 0, r_ne = 0, r_hidden = 0;
     DevBuf r_logits, r_ids, r_w, r_x;
     // prefill scratch (kr_moe_prefill)
+    int pf_pairs = 0;          // kr_moe_set_prefill_pairs
     struct PfSet { DevBuf i32, xh, xl, xs, gu, hh, hl, hs, eo, sgu, shh, shl, shs, seo; } pf[KR_PF_MAX_DEPTH];   // one set per chunk in flight of the prompt pass
     // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
     bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};

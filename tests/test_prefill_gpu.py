@@ -49,6 +49,23 @@ def test_prefill_bit_exact_vs_cpu_engine_numerics(H, I, E, k, M, n_shared, bits,
     assert np.array_equal(got, out2)
 
 
+@pytest.mark.parametrize("pairs", [64, 200, 1000])
+def test_prefill_pass_loop_equals_single_pass(pairs):
+    """batches larger than the pair budget are walked in passes of pairs / topk tokens (kr_moe_set_prefill_pairs): same bits as one pass"""
+    from krasis_amd._lib import check
+    eng, mgr, experts, shared, rng, torch = _setup(512, 384, 16, 4, 1, 2.0, seed=3)
+    M = 333
+    x = rand_bf16(rng, (M, 512)); ids = np.stack([rng.choice(16, 4, replace=False) for _ in range(M)]).astype(np.int32); ids[9, 2] = -1
+    w = rng.random((M, 4)).astype(np.float32)
+    xt = torch.from_numpy(x.view(np.int16)).cuda().view(torch.bfloat16); it = torch.from_numpy(ids).cuda(); wt = torch.from_numpy(w).cuda()
+    one = mgr.forward(0, xt, it, wt).clone()
+    check(eng._lib.kr_moe_set_prefill_pairs(eng._h, pairs))
+    many = mgr.forward(0, xt, it, wt)
+    torch.cuda.synchronize()
+    assert torch.equal(one.view(torch.int16), many.view(torch.int16))
+    check(eng._lib.kr_moe_set_prefill_pairs(eng._h, 0))
+
+
 def test_prefill_routed_only_and_small_batch_dispatch():
     eng, mgr, experts, shared, rng, torch = _setup(256, 128, 8, 2, 1, 3.0)
     for M in (5, 100):
