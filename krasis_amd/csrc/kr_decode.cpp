@@ -461,11 +461,12 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
         // INT16 activation images: built once by the kernel that produces an activation, copied by every workgroup of the
         // matvec launch that consumes it (instead of being re-quantised per workgroup).  INT4 consumers only.
         const bool img_ok = s->use_images && H % 128 == 0;
-        auto is4 = [&](int wid) { return wid >= 0 && s->weights[wid]->ms.bits == 4; };
+        // a launch takes one weight width: the matrices that share an activation image must agree (INT4 or INT8)
+        auto img_w = [&](int wid, int like = -1) { return wid >= 0 && (like < 0 || s->weights[wid]->ms.bits == s->weights[like]->ms.bits); };
         bool in_img = false;
         if (img_ok) {
-            if (L.attn == ATTN_LA) in_img = is4(L.qkvz_wid) && is4(L.ba_wid);
-            else if (L.attn == ATTN_GQA) in_img = is4(L.q_wid) && is4(L.k_wid) && is4(L.v_wid);
+            if (L.attn == ATTN_LA) in_img = img_w(L.qkvz_wid) && img_w(L.ba_wid, L.qkvz_wid);
+            else if (L.attn == ATTN_GQA) in_img = img_w(L.q_wid) && img_w(L.k_wid, L.q_wid) && img_w(L.v_wid, L.q_wid);
         }
         PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st,
                                                      in_img ? s->img_in.p : nullptr));
@@ -483,7 +484,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.conv_w = (const float*)L.conv_w.p; a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale;
             a.q = (float*)s->qbuf.p; a.k = (float*)s->kbuf.p; a.v = (float*)s->vbuf.p; a.z = (float*)s->zbuf.p; a.g = (float*)s->gbuf.p; a.beta = (float*)s->betabuf.p;
             a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
-            void* la_img = (img_ok && is4(L.out_wid) && L.dv == 128) ? s->img_attn.p : nullptr;
+            void* la_img = (img_ok && img_w(L.out_wid) && L.dv == 128) ? s->img_attn.p : nullptr;
             const int nt_la = a.hr * L.dv;
             const bool la_fused = s->fuse_la && nt_la <= 256 && nt_la % 64 == 0 && (L.dv == 128 || L.dv == 64) && L.nv == L.nk * a.hr && (L.dk == 128 || L.dk == 64);
             if (la_fused) {
@@ -498,7 +499,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
                     return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
                 prof_mark(s, -1, st);
             }
-            if (img_ok && is4(L.out_wid) && L.dv == 128) PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->img_attn.p, 2, hid, st));
+            if (img_ok && img_w(L.out_wid) && L.dv == 128) PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->img_attn.p, 2, hid, st));
             else PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->attn_out.p, 1, hid, st));
         } else if (L.attn == ATTN_GQA) {
             if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
@@ -515,7 +516,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.rope_cos = (const float*)s->rope_cos.p; a.rope_sin = (const float*)s->rope_sin.p; a.rope_half = s->rope_half;
             a.k_cache = L.kv_k.p; a.v_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_out = (float*)s->qbuf.p; a.gate = (float*)s->gatebuf.p;
             a.attn_out = (float*)s->attn_out.p; a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.eps = s->eps; a.sm_scale = L.sm_scale;
-            const bool o_img = img_ok && is4(L.o_wid) && L.hd % 128 == 0 && s->weights[L.o_wid]->cols == L.nh * L.hd;
+            const bool o_img = img_ok && img_w(L.o_wid) && L.hd % 128 == 0 && s->weights[L.o_wid]->cols == L.nh * L.hd;
             a.img_out = o_img ? s->img_attn.p : nullptr;
             a.sc_g = s->kv_max_seq > s->gqa_split_min ? (float*)s->gqa_scores.p : nullptr;
             PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));

@@ -289,11 +289,25 @@ __device__ __forceinline__ KrSlot kr_resolve_slot(const KrMoeArgs& a, int b, int
     return r;
 }
 
-// pre-built activation image (global memory, byte layout == the LDS image for INT4 weights) -> LDS
-__device__ __forceinline__ void kr_image_copy(const void* img, int K, u32x4* smem) {
+// pre-built activation image (global memory, byte layout == the LDS image for INT4 weights) -> LDS.  INT8 weights read the same INT16
+// values in natural byte order (kr_store_chunk<true>): that second plane set is a byte permutation of the record, formed on the way in.
+template <int BITS>
+__device__ __forceinline__ void kr_image_copy(const void* img, int K, u32x4* smem, const KrActLds& L) {
     const int n16 = (int)(kr_lds_bytes(K, false) / 16);
     const u32x4* src = reinterpret_cast<const u32x4*>(img);
-    for (int i = threadIdx.x; i < n16; i += KR_BLOCK) smem[i] = src[i];
+    for (int i = threadIdx.x; i < n16; i += KR_BLOCK) {
+        const u32x4 r = src[i];
+        smem[i] = r;
+        if constexpr (BITS == 8) {
+            if (i < K / 8) {         // record of chunk i: x / y = high bytes of the even / odd values, z / w = low bytes
+                uint32_t* p = reinterpret_cast<uint32_t*>(L.planes8) + (i >> 1) * 8 + (i & 1) * 2;
+                p[0] = __builtin_amdgcn_perm(r.y, r.x, 0x05010400u);
+                p[1] = __builtin_amdgcn_perm(r.y, r.x, 0x07030602u);
+                p[4] = __builtin_amdgcn_perm(r.w, r.z, 0x05010400u) ^ 0x80808080u;    // (low byte) - 128 as i8
+                p[5] = __builtin_amdgcn_perm(r.w, r.z, 0x07030602u) ^ 0x80808080u;
+            }
+        }
+    }
 }
 
 // stage 1: gu[b][slot][0..2I) = W13 . q(act[b])      grid = (tile groups, n_slots, B)
@@ -316,8 +330,8 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a,
     else if (gate_wave) kr_preload<BITS>(pre, a.sgate.q, a.sgate.s, a.sgate, 0, lane, 0);   // the gate row has the width of the launch (host check)
     const KrActLds L = kr_carve_lds(kr_smem, a.H, BITS == 8);
     const bool round_bf16 = !(sl.shared && a.shared_decode);
-    const void* img = BITS == 4 && a.B == 1 ? (round_bf16 ? a.act_img_bf16 : a.act_img) : nullptr;   // pre-built by the router launch
-    if (img) kr_image_copy(img, a.H, kr_smem);
+    const void* img = a.B == 1 ? (round_bf16 ? a.act_img_bf16 : a.act_img) : nullptr;   // pre-built by the router launch
+    if (img) kr_image_copy<BITS>(img, a.H, kr_smem, L);
     else if (a.act_f32) kr_prologue_quant_f32<BITS == 8>(a.act_f32 + (size_t)b * a.H, a.H, L, round_bf16);
     else kr_prologue_quant<uint16_t, BITS == 8>(a.act + (size_t)b * a.H, a.H, L);
     __syncthreads();
@@ -413,7 +427,7 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_matvec_kernel(const KrMultiMat mm
 
 // Cooperative form of the multi-matrix matvec (used for mid-sized projections fed by a pre-built activation image): the waves of a
 // workgroup split the K range of a tile (see "Cooperative tile" above); a workgroup walks `tpb` consecutive tiles.
-// x_kind: 0 bf16 vector, 1 f32 vector, 2 pre-built INT16 image in global memory (INT4 weights only)
+// x_kind: 0 bf16 vector, 1 f32 vector, 2 pre-built INT16 image in global memory
 template <typename T, int BITS>
 __global__ void __launch_bounds__(KR_BLOCK) kr_matvec_coop_kernel(const KrMultiMat mm, const T* x, int tpb, int act_mode, int x_kind) {
     __shared__ KrXch X[2];
@@ -426,7 +440,7 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_matvec_coop_kernel(const KrMultiM
     kr_co_preload<BITS>(cur, mm.m[mi].q, mm.m[mi].s, mm.m[mi], gt0 - (mi ? mm.tile_end[mi - 1] : 0), lane, wave);
     const int K = mm.m[0].ng * 128;
     const KrActLds L = kr_carve_lds(kr_smem, K, BITS == 8);
-    if (x_kind == 2) kr_image_copy(x, K, kr_smem);
+    if (x_kind == 2) kr_image_copy<BITS>(x, K, kr_smem, L);
     else if (act_mode == KR_ACT_SILU_MUL) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(reinterpret_cast<const float*>(x), K, 0.0f, 0.0f, L);
     else kr_prologue_quant<T, BITS == 8>(x, K, L);
     __syncthreads();
@@ -508,7 +522,7 @@ void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st) {
 }
 
 void kr_launch_multi_matvec(const KrMatDev* mats, float* const* ys, int n, const void* x, int x_is_f32, hipStream_t st, int act_mode) {
-    // x_is_f32: 0 bf16 vector, 1 f32 vector, 2 pre-built INT16 image (kr_act_image_bytes(K) bytes; INT4 weights) -> cooperative kernel
+    // x_is_f32: 0 bf16 vector, 1 f32 vector, 2 pre-built INT16 image (kr_act_image_bytes(K) bytes) -> cooperative kernel
     KrMultiMat mm{};
     mm.n = n;
     int total = 0;
@@ -516,10 +530,10 @@ void kr_launch_multi_matvec(const KrMatDev* mats, float* const* ys, int n, const
     const int bits = mats[0].bits;
     const size_t lds = kr_lds_bytes(mats[0].ng * 128, bits == 8);
     if (x_is_f32 == 2) {
-        if (bits != 4) { fprintf(stderr, "kr_launch_multi_matvec: pre-built image with INT8 weights\n"); return; }
         int tpb = 1;
         while ((total + tpb - 1) / tpb > 3072) tpb *= 2;
-        hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 4>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, mm, (const float*)x, tpb, act_mode, 2);
+        if (bits == 4) hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 4>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, mm, (const float*)x, tpb, act_mode, 2);
+        else hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 8>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, mm, (const float*)x, tpb, act_mode, 2);
         return;
     }
     const int tpw = kr_pick_tpw(mats[0].K, total);
