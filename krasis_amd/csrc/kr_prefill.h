@@ -11,7 +11,6 @@ struct KrPfSort {
     int* row_pair;                                  // [n_pairs]  GEMM row -> (token*topk + slot)
     int* pair_row;                                  // [n_pairs]  inverse (-1 for skipped ids)
 };
-size_t kr_pf_gemm_lds_bytes();
 void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, hipStream_t st);
 void kr_launch_pf_quant_x(const uint16_t* x, int M, int K, int8_t* xh, int8_t* xl, float* xs, hipStream_t st);
 void kr_launch_pf_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, int8_t* hh, int8_t* hl, float* hs, hipStream_t st);

@@ -15,14 +15,11 @@
 #include "kr_device.h"
 #include "kr_kernels.h"
 #include "kr_prefill.h"
-#include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 #define PF_BM 64
-#define PF_BN 128
-#define PF_LDK 272          // bytes per LDS row: 256 k + 16 pad (keeps ds_read_b128 rows on distinct 16-B slots)
 
 // ------------------------------------------------------------------------------------------
 // token sort (moe_align_block_size equivalent): rows of the grouped GEMM = (token, slot) pairs grouped by expert
@@ -179,145 +176,6 @@ struct KrPfGemmArgs {
     int total_rows;
 };
 
-__device__ __forceinline__ uint32_t kr_unpack_lo4(uint32_t lo, uint32_t hi) {  // bytes k0,k1,k2,k3 as (q-8) i8
-    return ((__builtin_amdgcn_perm(hi, lo, 0x05010400u)) + 0x78787878u) ^ 0x80808080u;
-}
-__device__ __forceinline__ uint32_t kr_unpack_hi4(uint32_t lo, uint32_t hi) {  // bytes k4..k7
-    return ((__builtin_amdgcn_perm(hi, lo, 0x07030602u)) + 0x78787878u) ^ 0x80808080u;
-}
-
-__global__ void __launch_bounds__(256) kr_pf_gemm_kernel(const KrPfGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int8_t* As_hi = reinterpret_cast<int8_t*>(smem);                       // [64][PF_LDK]
-    int8_t* As_lo = As_hi + PF_BM * PF_LDK;                                 // [64][PF_LDK]
-    int8_t* Bs = As_lo + PF_BM * PF_LDK;                                    // [128][PF_LDK]
-    float* As_sc = reinterpret_cast<float*>(Bs + PF_BN * PF_LDK);           // [2][64]
-    int* row_src = reinterpret_cast<int*>(As_sc + 2 * PF_BM);               // [64]
-
-    const int mt = blockIdx.x;
-    int expert, row0, rows;
-    if (a.single_expert) { expert = 0; row0 = mt * PF_BM; rows = a.total_rows - row0 < PF_BM ? a.total_rows - row0 : PF_BM; if (rows <= 0) return; }
-    else { if (mt >= a.n_tiles[0]) return; expert = a.tile_expert[mt]; row0 = a.tile_row0[mt]; rows = a.tile_rows[mt]; }
-    const int n0 = blockIdx.y * PF_BN;
-    const KrMatDev& m = a.m;
-    const int K = m.ng * 128;
-    const u32x4* wq = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(m.q) + (size_t)expert * m.q_stride);
-    const uint32_t* wsc = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + (size_t)expert * m.s_stride);
-    const uint32_t* wsm = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.wsum) + (size_t)expert * m.s_stride);
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < PF_BM) {
-        int src = -1;
-        if (tid < rows) {
-            if (a.single_expert) src = row0 + tid;
-            else { const int pair = a.row_pair[row0 + tid]; src = a.gather_tokens ? pair / a.topk : row0 + tid; }
-        }
-        row_src[tid] = src;
-    }
-    __syncthreads();
-
-    v16i zero16; for (int i = 0; i < 16; i++) zero16[i] = 0;
-    float outv[2][16];
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) outv[s][r] = 0.0f;
-    const int col = n0 + wave * 32 + (lane & 31);          // this lane's output column
-    const int ctile = col >> 3, cin = col & 7;
-    const int khalf = (lane >> 5) * 16;
-    const bool fused = col < m.n_fma;
-
-    for (int gp = 0; gp < m.ngp; gp++) {
-        // ---- stage A digits (64 rows x 256 k, two planes): thread -> (row = tid/4, 64-byte quarter)
-        {
-            const int r = tid >> 2, qtr = tid & 3;
-            const int src = row_src[r];
-            const size_t go = (size_t)(src < 0 ? 0 : src) * K + (size_t)gp * 256 + qtr * 64;
-            const int kvalid = K - gp * 256;   // 256, or 128 for a trailing odd group
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                u32x4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
-                if (src >= 0 && qtr * 64 + j * 16 < kvalid) {
-                    vh = *reinterpret_cast<const u32x4*>(a.a_hi + go + j * 16);
-                    vl = *reinterpret_cast<const u32x4*>(a.a_lo + go + j * 16);
-                }
-                *reinterpret_cast<u32x4*>(As_hi + r * PF_LDK + qtr * 64 + j * 16) = vh;
-                *reinterpret_cast<u32x4*>(As_lo + r * PF_LDK + qtr * 64 + j * 16) = vl;
-            }
-            if (tid < 2 * PF_BM) {
-                const int rr = tid & 63, g = 2 * gp + (tid >> 6), s2 = row_src[rr];
-                As_sc[tid] = (s2 >= 0 && g < m.ng) ? a.a_scale[(size_t)s2 * m.ng + g] : 0.0f;
-            }
-        }
-        // ---- stage B: 128 columns x 256 k nibbles -> (q-8) int8, natural k order.  16 column tiles x 64 lane records; 4 per thread
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int rec = tid + j * 256;                 // 0..1023
-            const int t8 = rec >> 6, ln = rec & 63;        // column tile within the block tile, lane record
-            const int c = ln >> 3, l8 = ln & 7;
-            const int gcol = n0 + t8 * 8 + c;
-            u32x4 w = {0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};
-            if (gcol < m.N) w = kr_ldg_nt(wq + ((size_t)(gcol >> 3) * m.ngp + gp) * 64 + ln);
-            int8_t* brow = Bs + (t8 * 8 + c) * PF_LDK;
-            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int h = 0; h < 2; h++)       // group g0 / g1 of the pair
-#pragma unroll
-                for (int i = 0; i < 2; i++) {  // the lane's two words of that group: k = 16*l8 + 8*i .. +8
-                    const uint32_t wd = ws[h * 2 + i];
-                    const uint32_t lo = wd & 0x0F0F0F0Fu, hi = (wd >> 4) & 0x0F0F0F0Fu;
-                    u32x2 o; o.x = kr_unpack_lo4(lo, hi); o.y = kr_unpack_hi4(lo, hi);
-                    *reinterpret_cast<u32x2*>(brow + h * 128 + l8 * 16 + i * 8) = o;
-                }
-        }
-        __syncthreads();
-        // ---- two quantization groups of this pair
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int g = 2 * gp + h;
-            if (g < m.ng) {
-                v16i acc_hi[2] = {zero16, zero16}, acc_lo[2] = {zero16, zero16};
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    const int ko = h * 128 + ks * 32 + khalf;
-                    const v4i b = *reinterpret_cast<const v4i*>(Bs + (wave * 32 + (lane & 31)) * PF_LDK + ko);
-#pragma unroll
-                    for (int s = 0; s < 2; s++) {
-                        const v4i ah = *reinterpret_cast<const v4i*>(As_hi + (s * 32 + (lane & 31)) * PF_LDK + ko);
-                        const v4i al = *reinterpret_cast<const v4i*>(As_lo + (s * 32 + (lane & 31)) * PF_LDK + ko);
-                        acc_hi[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, b, acc_hi[s], 0, 0, 0);
-                        acc_lo[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, b, acc_lo[s], 0, 0, 0);
-                    }
-                }
-                // group epilogue: exact i32 sum -> one fma per group (avx2.rs:1162-1176)
-                uint32_t sp = 0, sm2 = 0;
-                if (col < m.N) { sp = wsc[((size_t)ctile * m.ngp + gp) * 8 + cin]; sm2 = wsm[((size_t)ctile * m.ngp + gp) * 8 + cin]; }
-                const float wscale = __uint_as_float((h ? (sp >> 16) : (sp & 0xFFFFu)) << 16);
-                const int wsum128 = ((int)(int16_t)(h ? (sm2 >> 16) : (sm2 & 0xFFFFu))) << 7;
-#pragma unroll
-                for (int s = 0; s < 2; s++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        const int isum = (acc_hi[s][r] << 8) + acc_lo[s][r] + wsum128;
-                        const float comb = wscale * As_sc[h * PF_BM + row];
-                        outv[s][r] = fused ? __builtin_fmaf((float)isum, comb, outv[s][r]) : (outv[s][r] + (float)isum * comb);   // avx2.rs:1175 / :1201
-                    }
-            }
-        }
-        __syncthreads();
-    }
-    if (col < m.N) {
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < rows) a.out[(size_t)(row0 + row) * a.out_ld + col] = outv[s][r];
-            }
-    }
-}
-
 #include "kr_prefill_gemm2.inc"
 
 // ------------------------------------------------------------------------------------------
@@ -341,8 +199,6 @@ __global__ void __launch_bounds__(256) kr_pf_combine_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-size_t kr_pf_gemm_lds_bytes() { return (size_t)(2 * PF_BM + PF_BN) * PF_LDK + 2 * PF_BM * 4 + PF_BM * 4; }
-
 void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, hipStream_t st) {
     const int n = M * topk;
     (void)hipMemsetAsync(s.counts, 0, (size_t)E * 4, st);
@@ -371,17 +227,10 @@ void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_
     if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
     a.out = out; a.out_ld = out_ld; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
     const int mt = single_expert_rows > 0 ? (single_expert_rows + PF_BM - 1) / PF_BM : max_tiles;
-    static int variant = -2;       // KR_PF_GEMM_VARIANT (tuning hook): -1 = first generation; 0 = (64 cols/wave, 2 groups/stage); 1 = (64,1); 2 = (32,1); 3 = (32,2) [default: measured best]; 4 = (32,2) with the 2 x 2 row-split wave grid (a third less LDS read traffic, twice the B unpack work: 67k vs 92k tok/s experts-only -- the kernel is VALU-bound, not LDS-bound)
-    if (variant == -2) { const char* ev = getenv("KR_PF_GEMM_VARIANT"); variant = ev ? atoi(ev) : 3; }
-    if (variant == -1 && m.bits == 4) {
-        dim3 grid(mt, (m.N + PF_BN - 1) / PF_BN);
-        hipLaunchKernelGGL(kr_pf_gemm_kernel, grid, dim3(256), kr_pf_gemm_lds_bytes(), st, a);
-    } else if (m.bits == 8) kr_pf_gemm2_launch<32, 2, 8>(a, mt, st);
-    else if (variant == 1) kr_pf_gemm2_launch<64, 1, 4>(a, mt, st);
-    else if (variant == 2) kr_pf_gemm2_launch<32, 1, 4>(a, mt, st);
-    else if (variant == 3) kr_pf_gemm2_launch<32, 2, 4>(a, mt, st);
-    else if (variant == 4) kr_pf_gemm2_launch<32, 2, 4, true>(a, mt, st);
-    else kr_pf_gemm2_launch<64, 2, 4>(a, mt, st);
+    // 32 columns per wave, two quantization groups per k stage: the best of the (64|32 columns) x (1|2 groups) shapes and of a 2 x 2 row-split
+    // wave grid that were measured
+    if (m.bits == 8) kr_pf_gemm2_launch<32, 2, 8>(a, mt, st);
+    else kr_pf_gemm2_launch<32, 2, 4>(a, mt, st);
 }
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                           int out_bf16, hipStream_t st) {
