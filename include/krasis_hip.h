@@ -210,7 +210,7 @@ int kr_decode_reset_state(kr_decode_store* s, int kv_max_seq);
 /* tokens per chunk of the prompt pass (0 = default 1024).  Chunks rotate over `depth` HIP streams and scratch arenas: layer l of
  * chunk c+1 runs concurrently with layer l+1 of chunk c (per-layer events carry the state / KV dependencies). */
 int kr_decode_set_prefill_chunk(kr_decode_store* s, int chunk);
-int kr_decode_set_prefill_depth(kr_decode_store* s, int depth);   /* chunks in flight = streams = scratch arenas, 1..4 (0 = default 3) */
+int kr_decode_set_prefill_depth(kr_decode_store* s, int depth);   /* chunks in flight = streams = scratch arenas, 1..8 (0 = default 3) */
 /* set_decode_state (decode.rs:2640): per-layer host pointers (NULL = not applicable / zero-init) */
 int kr_decode_set_state(kr_decode_store* s, int seq_len, int kv_max_seq, const uint16_t* const* kv_k, const uint16_t* const* kv_v,
                         const float* const* conv_state, const float* const* recur_state);

@@ -277,7 +277,8 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     // [other stream: recurrent / conv state and the KV cache of layer l] -> one event per (parity, layer).  The serial, low-occupancy
     // kernels of one chunk (gated-delta-rule recurrence, softmax sums, router top-k) overlap with the GEMMs and attention passes of
     // its neighbour, which is one layer behind.
-    hipStream_t streams[KR_PF_MAX_DEPTH] = {st, st, st, st};
+    hipStream_t streams[KR_PF_MAX_DEPTH];
+    for (auto& x : streams) x = st;
     const size_t ev_start = (size_t)D * L, ev_end = ev_start + 1;     // + one end event per side stream
     if (D > 1) {
         while ((int)s->pf_side.size() < D - 1) { hipStream_t ns; KR_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking)); s->pf_side.push_back(ns); }
@@ -338,7 +339,7 @@ extern "C" int kr_decode_prefill_nll(kr_decode_store* s, const int32_t* tokens, 
     return prefill_impl(s, tokens, n_tokens, start_pos, logits_out, nll_out, stream);
 }
 
-// tuning hook: chunks in flight (1..4, 0 = default 2)
+// tuning hook: chunks in flight (1..8, 0 = default 3)
 extern "C" int kr_decode_set_prefill_depth(kr_decode_store* s, int depth) {
     if (!s) return kr_fail(KR_ERR_VALUE, "null decode store");
     if (depth < 0 || depth > KR_PF_MAX_DEPTH) return kr_fail(KR_ERR_VALUE, "prefill depth %d out of range [0, %d]", depth, KR_PF_MAX_DEPTH);

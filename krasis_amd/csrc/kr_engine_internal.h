@@ -12,7 +12,7 @@
 #include "kr_kernels.h"
 #include "kr_gguf.h"
 
-#define KR_PF_MAX_DEPTH 4
+#define KR_PF_MAX_DEPTH 8
 int kr_fail(int code, const char* fmt, ...);
 #define KR_HIP(call)                                                                                   \
     do {                                                                                               \

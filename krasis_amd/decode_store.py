@@ -194,7 +194,7 @@ class CpuDecodeStore:
         self._need(); check(self._lib.kr_decode_set_prefill_chunk(self._h, chunk))
 
     def set_prefill_depth(self, depth: int) -> None:
-        """Chunks of the prompt pass in flight (streams / scratch arenas), 1..4; 0 = default."""
+        """Chunks of the prompt pass in flight (streams / scratch arenas), 1..8; 0 = default."""
         self._need(); check(self._lib.kr_decode_set_prefill_depth(self._h, depth))
 
     def generate_batch(self, first_token: int, start_pos: int, max_tokens: int, temperature: float = 0.0, top_k: int = 0, top_p: float = 1.0,
