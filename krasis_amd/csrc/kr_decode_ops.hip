@@ -547,8 +547,101 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
         for (int i = 0; i < KR_GQA_NL; i++)
             if (i < nl && rg_s0 + i * rstep < seq && col < cpr) *reinterpret_cast<u32x4*>(stage + loff + i * rstep * pitch) = rg[i];
     };
-    const __amdgpu_buffer_rsrc_t& kbase = srd_k; const __amdgpu_buffer_rsrc_t& vbase = srd_v;
+    const __amdgpu_buffer_rsrc_t& kbase = srd_k;
     const int nst = (seq + KR_GQA_ROWS - 1) / KR_GQA_ROWS;
+    // ---- V stages, FP16 with head_dim 128 / 256: COLUMN-major in LDS.  The p.v chain of output d is one fma per position in position
+    // order, and a lone wave pays per instruction, so the instructions around that fma are what can be saved: with the stage stored as
+    // [d][128 positions] one 16-byte LDS read hands thread d its next 8 positions (the row-major stage costs a 2-byte read and a convert
+    // per position), the probabilities come four per broadcast read, and the half -> float widening rides inside the fma (v_fma_mix).
+    // A thread fetches 8 CONSECUTIVE rows of its 16-byte column (two such blocks at head_dim 256), transposes the 8 x 8 halves in
+    // registers (one v_perm per output dword) and writes eight 16-byte position groups.  Row d starts at d * 272 bytes (8 consecutive d
+    // on distinct bank groups for the readers) and its 16 position groups are XOR-swizzled by (d / 8) % 8 (the 8 writers of one
+    // instruction, d = 8 col + j, land on distinct bank groups).
+    constexpr bool VT = !FP8 && NB >= 16;
+    constexpr int pitchT = KR_GQA_ROWS * 2 + 16;
+    constexpr int LGT = NB == 32 ? 5 : 4, RST = 256 >> LGT, NLT = VT ? KR_GQA_ROWS / RST : 0;     // the staging geometry above as constants
+    const int voffT = r0 * 8 * grow + kvh * hd * esz + col * 16;
+    auto issue_v = [&](int s0) {
+        if constexpr (VT) {      // unguarded: rows at or past the current length are outside the descriptor and read as zero
+#pragma unroll
+            for (int i = 0; i < NLT; i++) rg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, voffT + (s0 + (i >> 3) * RST * 8 + (i & 7)) * grow, 0, 0);
+        } else issue(srd_v, s0);
+    };
+    auto commit_v = [&]() {
+        if constexpr (VT) {
+#pragma unroll
+            for (int blk = 0; blk < NLT / 8; blk++) {
+                const int pb = blk * RST + r0;                                        // position group of these 8 rows inside the stage
+                unsigned char* base = stage + (size_t)(col * 8) * pitchT + ((pb ^ (col & 7)) << 4);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                    u32x4 o4;
+                    o4.x = __builtin_amdgcn_perm(rg[blk * 8 + 1][j >> 1], rg[blk * 8 + 0][j >> 1], sel);
+                    o4.y = __builtin_amdgcn_perm(rg[blk * 8 + 3][j >> 1], rg[blk * 8 + 2][j >> 1], sel);
+                    o4.z = __builtin_amdgcn_perm(rg[blk * 8 + 5][j >> 1], rg[blk * 8 + 4][j >> 1], sel);
+                    o4.w = __builtin_amdgcn_perm(rg[blk * 8 + 7][j >> 1], rg[blk * 8 + 6][j >> 1], sel);
+                    *reinterpret_cast<u32x4*>(base + j * pitchT) = o4;
+                }
+            }
+        } else commit();
+    };
+    // one stage of the p.v chain for output t: n positions, probabilities P[0..n)
+    const unsigned char* rowT = stage + (size_t)t * pitchT;
+    const int swz = (t >> 3) & 7;
+    auto chain8 = [&](float o, const u32x4 v, const float4 pa, const float4 pb) {
+        auto lo = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); };
+        auto hi = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); };
+        o = __builtin_fmaf(pa.x, lo(v.x), o); o = __builtin_fmaf(pa.y, hi(v.x), o);
+        o = __builtin_fmaf(pa.z, lo(v.y), o); o = __builtin_fmaf(pa.w, hi(v.y), o);
+        o = __builtin_fmaf(pb.x, lo(v.z), o); o = __builtin_fmaf(pb.y, hi(v.z), o);
+        o = __builtin_fmaf(pb.z, lo(v.w), o); o = __builtin_fmaf(pb.w, hi(v.w), o);
+        return o;
+    };
+    auto pv_stage_t = [&](float o, const float* P, int n) {
+        const int nfull = n >> 3;
+        u32x4 va[4], vb[4]; float4 pa[8], pbv[8];
+        auto loadg = [&](u32x4 (&V)[4], float4 (&Pq)[8], int g0) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) V[u] = *reinterpret_cast<const u32x4*>(rowT + (((g0 + u) ^ swz) << 4));
+#pragma unroll
+            for (int u = 0; u < 8; u++) Pq[u] = *reinterpret_cast<const float4*>(P + g0 * 8 + u * 4);
+        };
+        auto chain32 = [&](const u32x4 (&V)[4], const float4 (&Pq)[8]) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) o = chain8(o, V[u], Pq[2 * u], Pq[2 * u + 1]);
+        };
+        int g0 = 0;
+        if (nfull >= 8) {                        // two register sets: the next 32 positions are read from LDS under the current chain
+            loadg(va, pa, 0);
+            for (; g0 + 16 <= nfull; g0 += 8) {
+                loadg(vb, pbv, g0 + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                chain32(va, pa);
+                loadg(va, pa, g0 + 8);
+                __builtin_amdgcn_sched_barrier(0);
+                chain32(vb, pbv);
+            }
+            loadg(vb, pbv, g0 + 4);
+            chain32(va, pa);
+            chain32(vb, pbv);
+            g0 += 8;
+        }
+        for (; g0 < nfull; g0++) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(rowT + ((g0 ^ swz) << 4));
+            o = chain8(o, v, *reinterpret_cast<const float4*>(P + g0 * 8), *reinterpret_cast<const float4*>(P + g0 * 8 + 4));
+        }
+        const int rem = n & 7;
+        if (rem) {                               // last, partial group of the cache (once per launch)
+            const u32x4 v = *reinterpret_cast<const u32x4*>(rowT + ((nfull ^ swz) << 4));
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int k2 = 0; k2 < rem; k2++) {
+                const uint16_t hb = (uint16_t)((k2 & 1) ? (w[k2 >> 1] >> 16) : (w[k2 >> 1] & 0xFFFFu));
+                o = __builtin_fmaf(P[nfull * 8 + k2], (float)__builtin_bit_cast(_Float16, hb), o);
+            }
+        }
+        return o;
+    };
     // ---- scores: 8 lanes per position, lane l owns elements b*8 + l (the AVX2 lane), ascending b, then the 8-lane hsum
     const int l = t & 7, g = t >> 3, nb = NB ? NB : (hd >> 3);
     constexpr int NBM = NB ? NB : 32;
@@ -567,7 +660,7 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
         __syncthreads();
         mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         for (int s = t; s < seq; s += 256) row[s] = kr_expf(row[s] - mx);
-        issue(vbase, 0);
+        issue_v(0);
         __syncthreads();
         float se = 0.0f;
         for (int s0 = 0; s0 < seq; s0 += TILE) {
@@ -581,12 +674,13 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
         float o = 0.0f;
         for (int st = 0; st < nst; st++) {
             __syncthreads();
-            commit();
-            if (st + 1 < nst) issue(vbase, (st + 1) * KR_GQA_ROWS);
+            commit_v();
+            if (st + 1 < nst) issue_v((st + 1) * KR_GQA_ROWS);
             const int s0 = st * KR_GQA_ROWS, n = min(KR_GQA_ROWS, seq - s0);
             if (t < KR_GQA_ROWS) tile[t] = t < n ? row[s0 + t] * inv3 : 0.0f;          // sc[s] *= inv (decode.rs:4260)
             __syncthreads();
-            if (t < hd) {
+            if (VT) { if (t < hd) o = pv_stage_t(o, tile, n); }
+            else if (t < hd) {
                 for (int r = 0; r < n; r += 16) {
                     float vv[16], pp[16];
 #pragma unroll
@@ -625,7 +719,7 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
     const int st_lo = PHASE == 1 ? (int)blockIdx.y * 2 : 0, st_hi = PHASE == 1 ? min(nst, st_lo + 2) : (PHASE == 2 ? 0 : nst);
     if (PHASE == 2) {                            // scores of this head come from the scores launch
         for (int s = t; s < seq; s += 256) sc[s] = a.sc_g[(size_t)h * max_seq + s];
-        issue(vbase, 0);
+        issue_v(0);
     } else issue(kbase, st_lo * KR_GQA_ROWS);
     __syncthreads();
     KR_DSTAMP(1);
@@ -635,7 +729,7 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
     for (int st = st_lo; st < st_hi; st++) {
         if (st > st_lo) __syncthreads();         // the previous stage's readers are done
         commit();
-        if (st + 1 < st_hi) issue(kbase, (st + 1) * KR_GQA_ROWS); else if (PHASE == 0) issue(vbase, 0);   // V stage 0 rides under the softmax
+        if (st + 1 < st_hi) issue(kbase, (st + 1) * KR_GQA_ROWS); else if (PHASE == 0) issue_v(0);   // V stage 0 rides under the softmax
         __syncthreads();
         KR_DSTAMP(2);
         const int s0 = st * KR_GQA_ROWS;
@@ -689,11 +783,12 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
     float o = 0.0f;
     for (int st = 0; st < nst; st++) {
         __syncthreads();                         // previous stage consumed; the scaled scores are visible
-        commit();
-        if (st + 1 < nst) issue(vbase, (st + 1) * KR_GQA_ROWS);
+        commit_v();
+        if (st + 1 < nst) issue_v((st + 1) * KR_GQA_ROWS);
         __syncthreads();
         KR_DSTAMP(6);
-        if (t < hd) {
+        if (VT) { if (t < hd) o = pv_stage_t(o, sc + st * KR_GQA_ROWS, min(KR_GQA_ROWS, seq - st * KR_GQA_ROWS)); }
+        else if (t < hd) {
             const int s0 = st * KR_GQA_ROWS, n = min(KR_GQA_ROWS, seq - s0);
             const unsigned char* col = stage;
             // batches of 16 rows, two register sets: the next batch's LDS reads are in flight under the current fma chain
@@ -756,6 +851,177 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
         }
     }
 }
+
+// ---- long caches, FP16, head_dim 128 / 256: softmax + p.v of one head with PRODUCER and CONSUMER waves -------------------------------------
+// The p.v chain is one fma per position in position order, and a wave issues roughly one instruction per 9 cycles whatever it is doing,
+// so everything that is not that fma is moved OFF the chain's waves: waves 0-3 (thread d owns output d) only read the staged values and run
+// the chain; waves 4-7 fetch the next 64 cache rows, transpose them to column-major in registers and write them to the other half of a
+// double-buffered LDS stage (and, when the score row is streamed, scale the next 64 probabilities into a small window).  Two waves share
+// a SIMD, so the producer's instructions fill issue slots the chain leaves empty.  One workgroup barrier per 64 positions.
+// STREAM = the score row stays in a.sc_g (caches past ~22 k positions): max / exp / position-ordered sum over 4096-value tiles.
+// Same operations in the same order as kr_gqa_attn_kernel PHASE 2 / 3 (decode.rs:4194-4281).
+#define KR_PV_ROWS 64
+#define KR_PV_DEPTH 4
+template <int NB, bool STREAM>
+__global__ void __launch_bounds__(512) kr_gqa_pv_kernel(const KrGqaArgs a, int max_seq, int lds_seq) {
+    extern __shared__ __attribute__((aligned(16))) float sc[];
+    __shared__ float qs[256]; __shared__ float red[12]; __shared__ __attribute__((aligned(16))) float pw[2][KR_PV_ROWS];
+    constexpr int hd = NB * 8, pitchT = KR_PV_ROWS * 2 + 16, stage_bytes = hd * pitchT;
+    const int h = blockIdx.x, kvs = a.nkv * hd, seq = a.step->pos + 1, t = threadIdx.x, kvh = h / (a.nh / a.nkv);
+    unsigned char* stage = reinterpret_cast<unsigned char*>(sc) + ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15);
+    const int nst = (seq + KR_PV_ROWS - 1) / KR_PV_ROWS;
+    float* row = a.sc_g + (size_t)h * max_seq;
+    // ---- producer state: thread pt fetches rows rb * 8 .. + 7 of 16-byte column `col` (NB columns x 8 row blocks = NB * 8 pieces per stage)
+    const bool producer = t >= 256;
+    const int pt = t - 256, col = pt & (NB - 1), rb = pt / NB;
+    const bool pactive = producer && rb < 8;
+    const int grow = kvs * 2;
+    const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc(a.v_cache, 0, seq * grow, 0x00020000);
+    const int voff = pactive ? rb * 8 * grow + kvh * hd * 2 + col * 16 : 0x7FFFFFF0;
+    // KR_PV_DEPTH register sets: the rows of stage k are requested KR_PV_DEPTH stages (~2 us) before they are transposed into LDS
+    u32x4 rg[KR_PV_DEPTH][8];
+    auto issue_v = [&](u32x4 (&R)[8], int s0) {      // unguarded: rows at or past the current length are outside the descriptor and read as zero
+#pragma unroll
+        for (int i = 0; i < 8; i++) R[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, voff + (s0 + i) * grow, 0, 0);
+    };
+    auto commit_v = [&](const u32x4 (&R)[8], int buf) {
+        if (!pactive) return;
+        unsigned char* base = stage + buf * stage_bytes + (size_t)(col * 8) * pitchT + ((rb ^ (col & 7)) << 4);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+            u32x4 o4;
+            o4.x = __builtin_amdgcn_perm(R[1][j >> 1], R[0][j >> 1], sel);
+            o4.y = __builtin_amdgcn_perm(R[3][j >> 1], R[2][j >> 1], sel);
+            o4.z = __builtin_amdgcn_perm(R[5][j >> 1], R[4][j >> 1], sel);
+            o4.w = __builtin_amdgcn_perm(R[7][j >> 1], R[6][j >> 1], sel);
+            *reinterpret_cast<u32x4*>(base + j * pitchT) = o4;
+        }
+    };
+    if (producer) {
+#pragma unroll
+        for (int u = 0; u < KR_PV_DEPTH; u++) issue_v(rg[u], u * KR_PV_ROWS);
+    }
+    // ---- softmax: maximum, exponentials, position-ordered sum (one lane), scale
+    float mx = -__builtin_inff();
+    if (STREAM) { for (int s = t; s < seq; s += 512) mx = fmaxf(mx, row[s]); }
+    else { for (int s = t; s < seq; s += 512) { const float v = row[s]; sc[s] = v; mx = fmaxf(mx, v); } }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 8; w++) mx = fmaxf(mx, red[w]);
+    float inv;
+    if (STREAM) {
+        constexpr int TILE = 4096;
+        for (int s = t; s < seq; s += 512) row[s] = kr_expf(row[s] - mx);
+        if (producer) { commit_v(rg[0], 0); issue_v(rg[0], KR_PV_DEPTH * KR_PV_ROWS); }
+        __syncthreads();
+        float se = 0.0f;
+        for (int s0 = 0; s0 < seq; s0 += TILE) {
+            const int n = min(TILE, seq - s0), n32 = (n + 31) & ~31;
+            for (int i = t; i < n32; i += 512) sc[i] = i < n ? row[s0 + i] : 0.0f;     // zero padding: s + 0.0f == s for sums of exponentials
+            __syncthreads();
+            if (t == 0) { se = kr_seq_sum(sc, n32, se); red[9] = se; }
+            __syncthreads();
+        }
+        inv = 1.0f / red[9];
+        if (t < KR_PV_ROWS) pw[0][t] = t < seq ? row[t] * inv : 0.0f;                  // sc[s] *= inv (decode.rs:4260), stage 0
+    } else {
+        for (int s = t; s < seq; s += 512) sc[s] = kr_expf(sc[s] - mx);
+        const int seq32 = (seq + 31) & ~31;
+        if (t < seq32 - seq) sc[seq + t] = 0.0f;
+        if (producer) { commit_v(rg[0], 0); issue_v(rg[0], KR_PV_DEPTH * KR_PV_ROWS); }
+        __syncthreads();
+        if (t == 0) red[8] = 1.0f / kr_seq_sum(sc, seq32);
+        __syncthreads();
+        inv = red[8];
+        for (int s = t; s < seq; s += 512) sc[s] *= inv;
+    }
+    __syncthreads();
+    // ---- p.v
+    const unsigned char* rowT = stage + (size_t)(t & 255) * pitchT;
+    const int swz = (t >> 3) & 7;
+    float o = 0.0f;
+    auto chain8 = [&](float acc, const u32x4 v, const float4 pa, const float4 pb) {
+        auto lo = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); };
+        auto hi = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); };
+        acc = __builtin_fmaf(pa.x, lo(v.x), acc); acc = __builtin_fmaf(pa.y, hi(v.x), acc);
+        acc = __builtin_fmaf(pa.z, lo(v.y), acc); acc = __builtin_fmaf(pa.w, hi(v.y), acc);
+        acc = __builtin_fmaf(pb.x, lo(v.z), acc); acc = __builtin_fmaf(pb.y, hi(v.z), acc);
+        acc = __builtin_fmaf(pb.z, lo(v.w), acc); acc = __builtin_fmaf(pb.w, hi(v.w), acc);
+        return acc;
+    };
+    for (int st0 = 0; st0 < nst; st0 += KR_PV_DEPTH) {
+#pragma unroll
+      for (int u = 0; u < KR_PV_DEPTH; u++) {           // stage st0 + u lives in register set u (st0 % KR_PV_DEPTH == 0)
+        const int st = st0 + u;
+        if (st >= nst) break;
+        const int buf = st & 1, s0 = st * KR_PV_ROWS;
+        if (producer) {
+            if (st + 1 < nst) {
+                constexpr int DN = KR_PV_DEPTH;
+                commit_v(rg[(u + 1) % DN], buf ^ 1);
+                issue_v(rg[(u + 1) % DN], (st + 1 + DN) * KR_PV_ROWS);
+                if (STREAM && pt < KR_PV_ROWS) { const int sn = s0 + KR_PV_ROWS + pt; pw[buf ^ 1][pt] = sn < seq ? row[sn] * inv : 0.0f; }
+            }
+        } else if (t < hd) {
+            const float* P = STREAM ? pw[buf] : sc + s0;
+            const unsigned char* rT = rowT + buf * stage_bytes;
+            const int n = min(KR_PV_ROWS, seq - s0);
+            if (n == KR_PV_ROWS) {               // full stage: both halves' reads are issued before the first chain
+                u32x4 v[8]; float4 pq[16];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const u32x4*>(rT + ((u ^ swz) << 4));
+#pragma unroll
+                for (int u = 0; u < 16; u++) pq[u] = *reinterpret_cast<const float4*>(P + u * 4);
+#pragma unroll
+                for (int u = 0; u < 8; u++) o = chain8(o, v[u], pq[2 * u], pq[2 * u + 1]);
+            } else {                             // last, partial stage of the cache (once per launch)
+                const int nfull = n >> 3, rem = n & 7;
+                for (int g0 = 0; g0 < nfull; g0++)
+                    o = chain8(o, *reinterpret_cast<const u32x4*>(rT + ((g0 ^ swz) << 4)), *reinterpret_cast<const float4*>(P + g0 * 8), *reinterpret_cast<const float4*>(P + g0 * 8 + 4));
+                if (rem) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(rT + ((nfull ^ swz) << 4));
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                    for (int k2 = 0; k2 < rem; k2++) {
+                        const uint16_t hb = (uint16_t)((k2 & 1) ? (w[k2 >> 1] >> 16) : (w[k2 >> 1] & 0xFFFFu));
+                        o = __builtin_fmaf(P[nfull * 8 + k2], (float)__builtin_bit_cast(_Float16, hb), o);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+      }
+    }
+    if (t < hd) {
+        if (a.gated) { const float gt = a.gate[(size_t)h * hd + t]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
+        a.attn_out[(size_t)h * hd + t] = o;
+        if (a.img_out) qs[t] = o;
+    }
+    if (a.img_out) {   // hd % 128 == 0: the head's output is hd/128 whole quantization groups of the o-projection's input
+        __syncthreads();
+        const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(a.img_out), a.nh * hd, false);
+        constexpr int nch = hd / 8;
+        if (t < nch) {
+            float v8[8];
+            kr_load8(qs, t, v8);
+            float mx8 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) mx8 = fmaxf(mx8, fabsf(v8[i]));
+            float scale, qinv;
+            kr_group_scale(mx8, scale, qinv);
+            int q8[8];
+            kr_quant8<false>(v8, qinv, q8);
+            const int gc = h * nch + t;
+            kr_store_chunk<false>(Lg, gc, q8);
+            if ((gc & 15) == 0) Lg.ascale[gc >> 4] = scale;
+        }
+    }
+}
+static size_t kr_gqa_pv_lds(int lds_seq, int hd) { return ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15) + 2 * (size_t)hd * (KR_PV_ROWS * 2 + 16); }
 
 // decode-step MoE epilogue (decode.rs:3343-3345, 3391-3402): hidden = moe (*rsf) + shared (*sigmoid(gate))
 __global__ void __launch_bounds__(256) kr_moe_combine_decode_kernel(const float* __restrict__ eo, const int32_t* __restrict__ ids,
@@ -854,7 +1120,8 @@ void kr_launch_gated_rmsnorm_silu(const float* recur, const float* z, const floa
     hipLaunchKernelGGL(kr_gated_rmsnorm_silu_kernel, dim3(nv), dim3(256), 0, s, recur, z, w, out, dv, eps);
 }
 static size_t kr_gqa_attn_lds(int max_seq, int hd, int fp8) {
-    return ((((size_t)max_seq + 40) * 4 + 15) & ~(size_t)15) + (size_t)KR_GQA_ROWS * ((size_t)hd * (fp8 ? 1 : 2) + 16);
+    const size_t row_major = (size_t)KR_GQA_ROWS * ((size_t)hd * (fp8 ? 1 : 2) + 16), col_major = (size_t)hd * (KR_GQA_ROWS * 2 + 16);   // K stage / FP16 V stage
+    return ((((size_t)max_seq + 40) * 4 + 15) & ~(size_t)15) + (row_major > col_major || fp8 ? row_major : col_major);
 }
 // Raises the kernel's dynamic-LDS window (gfx950: 160 KiB per workgroup).  Called outside graph capture, before the first launch.
 // LDS-resident score rows fit up to ~23 k positions; beyond that the softmax / p.v launch streams the row from HBM (PHASE 3)
@@ -871,6 +1138,16 @@ int kr_gqa_attn_prepare(int max_seq, int hd, int fp8) {
             if (hipFuncSetAttribute(fp8 ? f8[i] : f16[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
         lds_set[fp8 ? 1 : 0] = lds;
     }
+    if (!fp8 && (hd == 128 || hd == 256)) {      // the producer / consumer softmax + p.v kernel of long FP16 caches
+        const bool res = kr_gqa_pv_lds(max_seq, hd) <= 160 * 1024;
+        const size_t lp = kr_gqa_pv_lds(res ? max_seq : 4096, hd);
+        static size_t lp_set = 0;
+        if (lp > lp_set) {
+            const void* f[4] = {(const void*)kr_gqa_pv_kernel<16, false>, (const void*)kr_gqa_pv_kernel<16, true>, (const void*)kr_gqa_pv_kernel<32, false>, (const void*)kr_gqa_pv_kernel<32, true>};
+            for (const void* fn : f) if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp) != hipSuccess) return -2;
+            lp_set = lp;
+        }
+    }
     return 0;
 }
 template <int PHASE>
@@ -885,7 +1162,16 @@ void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
     hipLaunchKernelGGL(kr_gqa_prep_kernel, dim3(a.nh + a.nkv), dim3(256), 0, s, a);
     if (a.sc_g) {      // long cache: scores over nh x max_seq / 256 workgroups (those past the current length leave at once), then softmax + p.v
         kr_launch_gqa_phase<1>(a, max_seq, dim3(a.nh, (max_seq + 255) / 256), 0, s);
-        if (kr_gqa_resident(max_seq, a.hd, a.kv_fp8) && !getenv("KR_GQA_STREAM")) kr_launch_gqa_phase<2>(a, max_seq, dim3(a.nh), max_seq, s);   // (env: test hook)
+        const bool stream_hook = getenv("KR_GQA_STREAM") != nullptr;                   // (env: test hook)
+        if (!a.kv_fp8 && (a.hd == 128 || a.hd == 256)) {
+            const bool res = kr_gqa_pv_lds(max_seq, a.hd) <= 160 * 1024 && !stream_hook;
+            const int lds_seq = res ? max_seq : 4096;
+            const size_t lds = kr_gqa_pv_lds(lds_seq, a.hd);
+            if (a.hd == 256) { if (res) hipLaunchKernelGGL((kr_gqa_pv_kernel<32, false>), dim3(a.nh), dim3(512), lds, s, a, max_seq, lds_seq);
+                               else hipLaunchKernelGGL((kr_gqa_pv_kernel<32, true>), dim3(a.nh), dim3(512), lds, s, a, max_seq, lds_seq); }
+            else { if (res) hipLaunchKernelGGL((kr_gqa_pv_kernel<16, false>), dim3(a.nh), dim3(512), lds, s, a, max_seq, lds_seq);
+                   else hipLaunchKernelGGL((kr_gqa_pv_kernel<16, true>), dim3(a.nh), dim3(512), lds, s, a, max_seq, lds_seq); }
+        } else if (kr_gqa_resident(max_seq, a.hd, a.kv_fp8) && !stream_hook) kr_launch_gqa_phase<2>(a, max_seq, dim3(a.nh), max_seq, s);
         else kr_launch_gqa_phase<3>(a, max_seq, dim3(a.nh), 4096, s);
     } else kr_launch_gqa_phase<0>(a, max_seq, dim3(a.nh), max_seq, s);
 }

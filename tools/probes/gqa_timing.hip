@@ -38,5 +38,32 @@ int main() {
         if (rep) printf("seq %3d: event %5.1f us | K latency %.2f q->regs+commit %.2f scores(last stage) %.2f max+exp %.2f seqsum %.2f scale+V commit %.2f pv(last stage) %.2f | in-kernel %.2f us\n",
                         pos + 1, ms * 1e3, d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(5, 6), d(6, 7), d(0, 7));
     }
+    // ---- long cache: scores launch (PHASE 1) + softmax / p.v per head (PHASE 2)
+    {
+        const int ms2 = 8192; const size_t n2 = (size_t)ms2 * nkv * hd;
+        std::vector<uint16_t> k2(n2), v2(n2);
+        for (size_t i = 0; i < n2; i++) { k2[i] = 0x3000 + (rand() & 0x7FF) + ((rand() & 1) << 15); v2[i] = 0x3000 + (rand() & 0x7FF) + ((rand() & 1) << 15); }
+        void *dk2, *dv2; float* dsc;
+        CK(hipMalloc(&dk2, n2 * 2)); CK(hipMalloc(&dv2, n2 * 2)); CK(hipMalloc(&dsc, (size_t)nh * ms2 * 4));
+        CK(hipMemcpy(dk2, k2.data(), n2 * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dv2, v2.data(), n2 * 2, hipMemcpyHostToDevice));
+        if (kr_gqa_attn_prepare(ms2, hd, 0)) { printf("prepare failed\n"); return 1; }
+        a.k_cache = dk2; a.v_cache = dv2; a.sc_g = dsc;
+        const size_t lds2 = kr_gqa_attn_lds(ms2, hd, 0), lds1 = kr_gqa_attn_lds(0, hd, 0);
+        for (int pos : {1023, 4095, 8190}) for (int rep = 0; rep < 2; rep++) {
+            KrStep hs{}; hs.token = 0; hs.pos = pos;
+            CK(hipMemcpy(dstep, &hs, sizeof(hs), hipMemcpyHostToDevice));
+            CK(hipEventRecord(e0, st));
+            hipLaunchKernelGGL((kr_gqa_attn_kernel<false, 32, 1>), dim3(nh, ms2 / 256), dim3(256), lds1, st, a, ms2, 0);
+            CK(hipEventRecord(e1, st));
+            hipEvent_t e2; CK(hipEventCreate(&e2));
+            hipLaunchKernelGGL((kr_gqa_pv_kernel<32, false>), dim3(nh), dim3(512), kr_gqa_pv_lds(ms2, hd), st, a, ms2, ms2);
+            CK(hipEventRecord(e2, st)); CK(hipStreamSynchronize(st));
+            float m1, m2; CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e1, e2));
+            unsigned long long s[32]; CK(hipMemcpyFromSymbol(s, HIP_SYMBOL(kr_dstamps), sizeof(s)));
+            auto d = [&](int x, int y) { return (double)(long long)(s[y] - s[x]) * 0.01; };
+            if (rep) printf("seq %4d split: scores launch %6.1f us | softmax+pv launch %6.1f us: load scores %.1f max+exp %.1f seqsum %.1f scale + p.v (all stages) %.1f\n",
+                            pos + 1, m1 * 1e3, m2 * 1e3, d(0, 3), d(3, 4), d(4, 5), d(5, 7));
+        }
+    }
     return 0;
 }
