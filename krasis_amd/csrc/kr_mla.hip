@@ -488,6 +488,156 @@ __global__ void __launch_bounds__(256) kr_rmsnorm_seq_kernel(float* __restrict__
     for (int i = t; i < n; i += 256) x[i] = lds[i] * (rms * w[i]);
 }
 
+// ---- decode, long FP16 caches: softmax + weighted sum of one head with PRODUCER and CONSUMER waves (the MLA twin of kr_gqa_pv_kernel) --------
+// The weighted sum (mla_weighted_sum_fp16_avx2, decode.rs:4326) is one fma per position in position order for every latent element, and a
+// wave issues roughly one instruction per 9 cycles whatever it does -- so the chain's waves should issue nothing but the chain.  Threads
+// 0 .. klr-1 (consumers, thread j owns latent element j) read a COLUMN-major stage [j][64 positions] from LDS: one 16-byte read = 8 positions,
+// probabilities four per broadcast read, the half -> float widening inside v_fma_mix_f32.  The last 256 threads (producers) fetch the next
+// 64 latent rows a stage ahead, transpose 8 x 8 halves in registers (v_perm_b32) and write the other half of the double-buffered stage;
+// they also scale the stage's 64 probabilities into a small window.  One workgroup barrier per 64 positions.  The score row stays in
+// a.sc_g (written by kr_mla_scores_kernel): max, exp in place, position-ordered sum over 1024-value tiles with the running sum carried.
+// Same operations in the same order as kr_mla_attn_staged_kernel PHASE 2 / 3.
+#define KR_MPV_ROWS 64
+#define KR_MPV_EPT 1        // latent elements per consumer thread; 2 (half the probability reads, two chains per thread) measured 5 % slower
+template <int NBC>
+__global__ void __launch_bounds__(NBC * 8 / KR_MPV_EPT + 256) kr_mla_pv_kernel(KrMlaArgs a, int max_seq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_mem[];
+    __shared__ float red[16];
+    __shared__ __attribute__((aligned(16))) float pw[2][KR_MPV_ROWS];
+    __shared__ __attribute__((aligned(16))) float tile[1024 + 32];
+    constexpr int klr = NBC * 8, pitchT = KR_MPV_ROWS * 2 + 16, stage_bytes = klr * pitchT;
+    constexpr int EPT = KR_MPV_EPT, NC = klr / EPT, NT = NC + 256, NW = NT / 64;     // NC consumer threads, thread j owns elements j + e * NC
+    constexpr int NBLK = NBC / 32, RBS = 256 / NBC;      // 8 x 8 blocks per producer thread; row-block step between them
+    const int h = blockIdx.x, t = threadIdx.x, seq = a.step->pos + 1;
+    const int nst = (seq + KR_MPV_ROWS - 1) / KR_MPV_ROWS;
+    float* row = a.sc_g + (size_t)h * max_seq;
+    const bool producer = t >= NC;
+    const int pt = t - NC, col = pt & (NBC - 1), rb0 = pt / NBC;
+    const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.ckv_cache), 0, seq * klr * 2, 0x00020000);
+    const int voff = producer ? rb0 * 8 * klr * 2 + col * 16 : 0x7FFFFFF0;
+    u32x4 rg[NBLK * 8];          // one register set: the rows of stage k+2 are requested while stage k is consumed
+    auto issue_v = [&](u32x4 (&R)[NBLK * 8], int s0) {      // unguarded: rows at or past the current length are outside the descriptor and read as zero
+#pragma unroll
+        for (int i = 0; i < NBLK * 8; i++) R[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_c, voff + (s0 + (i >> 3) * RBS * 8 + (i & 7)) * klr * 2, 0, 0);
+    };
+    auto commit_v = [&](const u32x4 (&R)[NBLK * 8], int buf) {
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            const int rb = rb0 + b * RBS;                    // position group (8 rows) inside the stage
+            unsigned char* base = stage_mem + buf * stage_bytes + (size_t)(col * 8) * pitchT + ((rb ^ (col & 7)) << 4);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                u32x4 o4;
+                o4.x = __builtin_amdgcn_perm(R[b * 8 + 1][j >> 1], R[b * 8 + 0][j >> 1], sel);
+                o4.y = __builtin_amdgcn_perm(R[b * 8 + 3][j >> 1], R[b * 8 + 2][j >> 1], sel);
+                o4.z = __builtin_amdgcn_perm(R[b * 8 + 5][j >> 1], R[b * 8 + 4][j >> 1], sel);
+                o4.w = __builtin_amdgcn_perm(R[b * 8 + 7][j >> 1], R[b * 8 + 6][j >> 1], sel);
+                *reinterpret_cast<u32x4*>(base + j * pitchT) = o4;
+            }
+        }
+    };
+    if (producer) issue_v(rg, 0);
+    // ---- softmax over the streamed score row
+    float mx = -__builtin_inff();
+    for (int s2 = t; s2 < seq; s2 += NT) mx = fmaxf(mx, row[s2]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) mx = fmaxf(mx, red[w]);
+    for (int s2 = t; s2 < seq; s2 += NT) row[s2] = kr_expf(row[s2] - mx);
+    if (producer) { commit_v(rg, 0); issue_v(rg, KR_MPV_ROWS); }
+    __syncthreads();
+    float se = 0.0f;
+    for (int s0 = 0; s0 < seq; s0 += 1024) {
+        const int n = min(1024, seq - s0), n32 = (n + 31) & ~31;
+        for (int i = t; i < n32; i += NT) tile[i] = i < n ? row[s0 + i] : 0.0f;        // zero padding: s + 0.0f == s for sums of exponentials
+        __syncthreads();
+        if (t == 0) { se = kr_seq_sum(tile, n32, se); red[15] = se; }
+        __syncthreads();
+    }
+    const float inv = 1.0f / red[15];
+    if (t < KR_MPV_ROWS) pw[0][t] = t < seq ? row[t] * inv : 0.0f;                      // sc[s] *= inv, stage 0
+    __syncthreads();
+    // ---- weighted sum
+    const unsigned char* rowT = stage_mem + (size_t)(t & (NC - 1)) * pitchT;
+    const int swz = (t >> 3) & 7;
+    float o[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) o[e] = 0.0f;
+    auto lo = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); };
+    auto hi = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); };
+    auto chain8 = [&](float acc, const u32x4 v, const float4 pa, const float4 pb) {
+        acc = __builtin_fmaf(pa.x, lo(v.x), acc); acc = __builtin_fmaf(pa.y, hi(v.x), acc);
+        acc = __builtin_fmaf(pa.z, lo(v.y), acc); acc = __builtin_fmaf(pa.w, hi(v.y), acc);
+        acc = __builtin_fmaf(pb.x, lo(v.z), acc); acc = __builtin_fmaf(pb.y, hi(v.z), acc);
+        acc = __builtin_fmaf(pb.z, lo(v.w), acc); acc = __builtin_fmaf(pb.w, hi(v.w), acc);
+        return acc;
+    };
+    for (int st0 = 0; st0 < nst; st0 += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {                  // stage st0 + u: LDS buffer u
+        const int st = st0 + u;
+        if (st >= nst) break;
+        const int s0 = st * KR_MPV_ROWS;
+        if (producer) {
+            if (st + 1 < nst) {
+                commit_v(rg, u ^ 1);
+                issue_v(rg, (st + 2) * KR_MPV_ROWS);
+                if (pt < KR_MPV_ROWS) { const int sn = s0 + KR_MPV_ROWS + pt; pw[u ^ 1][pt] = sn < seq ? row[sn] * inv : 0.0f; }
+            }
+        } else {
+            const float* P = pw[u];
+            const unsigned char* rT = rowT + u * stage_bytes;
+            const int n = min(KR_MPV_ROWS, seq - s0);
+            if (n == KR_MPV_ROWS) {
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {     // 32 positions at a time: the values up front, the probabilities 16 positions ahead of their use
+                    u32x4 v[EPT][4]; float4 pq[2][4];
+#pragma unroll
+                    for (int e = 0; e < EPT; e++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) v[e][g] = *reinterpret_cast<const u32x4*>(rT + (size_t)e * NC * pitchT + (((hf * 4 + g) ^ swz) << 4));
+#pragma unroll
+                    for (int q = 0; q < 2; q++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) pq[q][g] = *reinterpret_cast<const float4*>(P + hf * 32 + q * 16 + g * 4);
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int e = 0; e < EPT; e++) o[e] = chain8(o[e], v[e][g], pq[g >> 1][2 * (g & 1)], pq[g >> 1][2 * (g & 1) + 1]);
+                }
+            } else {                                 // last, partial stage (once per launch)
+                const int nfull = n >> 3, rem = n & 7;
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    const unsigned char* rE = rT + (size_t)e * NC * pitchT;
+                    for (int g0 = 0; g0 < nfull; g0++)
+                        o[e] = chain8(o[e], *reinterpret_cast<const u32x4*>(rE + ((g0 ^ swz) << 4)), *reinterpret_cast<const float4*>(P + g0 * 8), *reinterpret_cast<const float4*>(P + g0 * 8 + 4));
+                    if (rem) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(rE + ((nfull ^ swz) << 4));
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                        for (int k2 = 0; k2 < rem; k2++) {
+                            const uint16_t hb = (uint16_t)((k2 & 1) ? (w[k2 >> 1] >> 16) : (w[k2 >> 1] & 0xFFFFu));
+                            o[e] = __builtin_fmaf(P[nfull * 8 + k2], (float)__builtin_bit_cast(_Float16, hb), o[e]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+      }
+    }
+    if (!producer) {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) a.attn_lat[(size_t)h * klr + e * NC + t] = o[e];
+    }
+}
+template <int NBC> static size_t kr_mla_pv_lds() { return 2 * (size_t)NBC * 8 * (KR_MPV_ROWS * 2 + 16); }
+
 static size_t kr_mla_staged_lds(const KrMlaArgs& a, int lds_seq) {
     const size_t esz = a.kv_fp8 ? 1 : 2;
     return (size_t)(a.klr + a.rd) * 4 + ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15) + (size_t)KR_MLA_ROWS * ((size_t)(a.klr + a.rd) * esz + 16);
@@ -506,12 +656,14 @@ static bool kr_launch_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s,
         const void* fns[3] = {(const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 0>, (const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>, (const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 3>};
         for (const void* f : fns) if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         if (hipFuncSetAttribute((const void*)kr_mla_scores_kernel<FP8, NBC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess) return false;
+        if (!FP8 && hipFuncSetAttribute((const void*)kr_mla_pv_kernel<NBC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kr_mla_pv_lds<NBC>()) != hipSuccess) return false;
         lds_set = lds;
     }
     if (!s) return true;                             // prepare-only call
     if (split) {                                     // decode with a long cache: head-shared scores launch, then softmax + weighted sum per head
         hipLaunchKernelGGL((kr_mla_scores_kernel<FP8, NBC, 8>), dim3((max_seq + KR_MLA_ROWS - 1) / KR_MLA_ROWS, (a.nh + KR_MLA_HG - 1) / KR_MLA_HG), dim3(512), lds_sc, s, a, max_seq);
-        if (resident) hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>), dim3(a.nh, 1), dim3(512), lds, s, a, max_seq, lds_seq);
+        if (!FP8) hipLaunchKernelGGL((kr_mla_pv_kernel<NBC>), dim3(a.nh), dim3(NBC * 8 / KR_MPV_EPT + 256), kr_mla_pv_lds<NBC>(), s, a, max_seq);
+        else if (resident) hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>), dim3(a.nh, 1), dim3(512), lds, s, a, max_seq, lds_seq);
         else hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 3>), dim3(a.nh, 1), dim3(512), lds, s, a, max_seq, lds_seq);
     } else hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 0>), dim3(a.nh, n_tok), dim3(512), lds, s, a, max_seq, lds_seq);
     return true;

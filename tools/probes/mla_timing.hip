@@ -32,5 +32,31 @@ int main() {
         if (rep) printf("seq %4d: event %6.1f us | first load %.2f  scores (all stages, start of last) %.2f  last scores %.2f  barrier %.2f  max+exp %.2f  seqsum %.2f  wsum to last stage %.2f  last wsum %.2f | in-kernel %.2f\n",
                         pos + 1, ms * 1e3, d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(5, 6), d(6, 7), d(7, 8), d(0, 8));
     }
+    // ---- long cache: head-shared scores launch + softmax / weighted sum per head (old PHASE 2 vs the producer / consumer kernel)
+    {
+        const int ms2 = 8192;
+        std::vector<uint16_t> c2((size_t)ms2 * klr), k2((size_t)ms2 * rd);
+        for (auto& x : c2) x = 0x3000 + (rand() & 0x7FF) + ((rand() & 1) << 15);
+        for (auto& x : k2) x = 0x3000 + (rand() & 0x7FF) + ((rand() & 1) << 15);
+        void *dc2, *dk2; float* dsc;
+        CK(hipMalloc(&dc2, c2.size() * 2)); CK(hipMalloc(&dk2, k2.size() * 2)); CK(hipMalloc(&dsc, (size_t)nh * ms2 * 4));
+        CK(hipMemcpy(dc2, c2.data(), c2.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dk2, k2.data(), k2.size() * 2, hipMemcpyHostToDevice));
+        a.ckv_cache = dc2; a.kpe_cache = dk2; a.sc_g = dsc;
+        kr_mla_attn_prepare(a, ms2);
+        const size_t lds_sc = (size_t)KR_MLA_HG * (klr + rd) * 4 + (size_t)KR_MLA_ROWS * ((size_t)(klr + rd) * 2 + 16);
+        const size_t lds2 = kr_mla_staged_lds(a, ms2);
+        hipEvent_t e2; CK(hipEventCreate(&e2));
+        for (int pos : {1023, 4095, 8190}) for (int variant = 0; variant < 2; variant++) for (int rep = 0; rep < 2; rep++) {
+            KrStep hs{}; hs.token = 0; hs.pos = pos; CK(hipMemcpy(dstep, &hs, sizeof(hs), hipMemcpyHostToDevice));
+            CK(hipEventRecord(e0, st));
+            hipLaunchKernelGGL((kr_mla_scores_kernel<false, 64, 8>), dim3((ms2 + KR_MLA_ROWS - 1) / KR_MLA_ROWS, (nh + KR_MLA_HG - 1) / KR_MLA_HG), dim3(512), lds_sc, st, a, ms2);
+            CK(hipEventRecord(e1, st));
+            if (variant == 0) hipLaunchKernelGGL((kr_mla_attn_staged_kernel<false, 64, 8, 2>), dim3(nh, 1), dim3(512), lds2, st, a, ms2, ms2);
+            else hipLaunchKernelGGL((kr_mla_pv_kernel<64>), dim3(nh), dim3(512 / KR_MPV_EPT + 256), kr_mla_pv_lds<64>(), st, a, ms2);
+            CK(hipEventRecord(e2, st)); CK(hipStreamSynchronize(st));
+            float m1, m2; CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e1, e2));
+            if (rep) printf("seq %4d split: scores launch %6.1f us | softmax + weighted sum (%s) %6.1f us\n", pos + 1, m1 * 1e3, variant ? "producer/consumer" : "staged PHASE 2", m2 * 1e3);
+        }
+    }
     return 0;
 }
