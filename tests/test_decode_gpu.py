@@ -133,7 +133,7 @@ def test_decode_step_long_positions_bit_exact(hd):
         tok = O.sample_greedy(ref)
 
 
-@pytest.mark.parametrize("hd,graph", [(64, True), (256, False)])
+@pytest.mark.parametrize("hd,graph", [(64, True), (256, False), (128, True)])
 def test_decode_step_split_attention_bit_exact(hd, graph):
     """kv_max_seq > 1024: decode attention runs as a scores launch over (heads x 256-position blocks) + a softmax / p.v launch; same bits"""
     st, eng, orc, keep, d = build(seed=8, kv_max=1300, hd=hd)
@@ -147,7 +147,7 @@ def test_decode_step_split_attention_bit_exact(hd, graph):
         tok = O.sample_greedy(ref)
 
 
-@pytest.mark.parametrize("hd,fp8", [(64, False), (256, False), (128, True)])
+@pytest.mark.parametrize("hd,fp8", [(64, False), (256, False), (128, True), (128, False)])
 def test_decode_step_streamed_attention_bit_exact(hd, fp8, monkeypatch):
     """caches too long for an LDS-resident score row (> ~23 k positions) stream it from HBM in tiles; KR_GQA_STREAM forces that form
     on a cache the oracle can follow, positions across the 128-row stage and 4096-value tile boundaries"""
