@@ -852,7 +852,7 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
     }
 }
 
-// ---- long caches, FP16, head_dim 128 / 256: softmax + p.v of one head with PRODUCER and CONSUMER waves -------------------------------------
+// ---- long caches, head_dim 128 / 256 (FP16 or E4M3): softmax + p.v of one head with PRODUCER and CONSUMER waves -------------------------------------
 // The p.v chain is one fma per position in position order, and a wave issues roughly one instruction per 9 cycles whatever it is doing,
 // so everything that is not that fma is moved OFF the chain's waves: waves 0-3 (thread d owns output d) only read the staged values and run
 // the chain; waves 4-7 fetch the next 64 cache rows, transpose them to column-major in registers and write them to the other half of a
@@ -862,40 +862,63 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
 // Same operations in the same order as kr_gqa_attn_kernel PHASE 2 / 3 (decode.rs:4194-4281).
 #define KR_PV_ROWS 64
 #define KR_PV_DEPTH 4
-template <int NB, bool STREAM>
+template <int NB, bool STREAM, bool FP8>
 __global__ void __launch_bounds__(512) kr_gqa_pv_kernel(const KrGqaArgs a, int max_seq, int lds_seq) {
     extern __shared__ __attribute__((aligned(16))) float sc[];
     __shared__ float qs[256]; __shared__ float red[12]; __shared__ __attribute__((aligned(16))) float pw[2][KR_PV_ROWS];
-    constexpr int hd = NB * 8, pitchT = KR_PV_ROWS * 2 + 16, stage_bytes = hd * pitchT;
+    constexpr int hd = NB * 8, esz = FP8 ? 1 : 2, pitchT = KR_PV_ROWS * esz + 16, stage_bytes = hd * pitchT;
     const int h = blockIdx.x, kvs = a.nkv * hd, seq = a.step->pos + 1, t = threadIdx.x, kvh = h / (a.nh / a.nkv);
     unsigned char* stage = reinterpret_cast<unsigned char*>(sc) + ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15);
     const int nst = (seq + KR_PV_ROWS - 1) / KR_PV_ROWS;
     float* row = a.sc_g + (size_t)h * max_seq;
-    // ---- producer state: thread pt fetches rows rb * 8 .. + 7 of 16-byte column `col` (NB columns x 8 row blocks = NB * 8 pieces per stage)
+    // ---- producer state.  FP16: thread pt fetches rows rb * 8 .. + 7 of 16-byte column `col` (NB columns x 8 row blocks = NB * 8 pieces per
+    // stage).  E4M3: rows rb * 16 .. + 15 of the 4-byte column `col` (hd / 4 columns x 4 row blocks): a 16 x 4 byte block becomes four
+    // 16-position groups with 8 v_perm per four rows; row d of the stage is 64 bytes + 16, position groups swizzled by (d / 8) % 4.
     const bool producer = t >= 256;
-    const int pt = t - 256, col = pt & (NB - 1), rb = pt / NB;
-    const bool pactive = producer && rb < 8;
-    const int grow = kvs * 2;
+    constexpr int NCOL = FP8 ? hd / 4 : NB, NRB = FP8 ? 4 : 8, RPB = KR_PV_ROWS / NRB, CB = FP8 ? 4 : 16;   // columns, row blocks, rows per block, column bytes
+    const int pt = t - 256, col = pt & (NCOL - 1), rb = pt / NCOL;
+    const bool pactive = producer && rb < NRB;
+    const int grow = kvs * esz;
     const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc(a.v_cache, 0, seq * grow, 0x00020000);
-    const int voff = pactive ? rb * 8 * grow + kvh * hd * 2 + col * 16 : 0x7FFFFFF0;
+    const int voff = pactive ? rb * RPB * grow + kvh * hd * esz + col * CB : 0x7FFFFFF0;
     // KR_PV_DEPTH register sets: the rows of stage k are requested KR_PV_DEPTH stages (~2 us) before they are transposed into LDS
-    u32x4 rg[KR_PV_DEPTH][8];
-    auto issue_v = [&](u32x4 (&R)[8], int s0) {      // unguarded: rows at or past the current length are outside the descriptor and read as zero
+    constexpr int NRG = FP8 ? 4 : 8;
+    u32x4 rg[KR_PV_DEPTH][NRG];
+    auto issue_v = [&](u32x4 (&R)[NRG], int s0) {      // unguarded: rows at or past the current length are outside the descriptor and read as zero
+        if constexpr (FP8) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) R[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, voff + (s0 + i) * grow, 0, 0);
+            for (int i = 0; i < 16; i++) R[i >> 2][i & 3] = __builtin_amdgcn_raw_buffer_load_b32(srd_v, voff + (s0 + i) * grow, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) R[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, voff + (s0 + i) * grow, 0, 0);
+        }
     };
-    auto commit_v = [&](const u32x4 (&R)[8], int buf) {
+    auto commit_v = [&](const u32x4 (&R)[NRG], int buf) {
         if (!pactive) return;
-        unsigned char* base = stage + buf * stage_bytes + (size_t)(col * 8) * pitchT + ((rb ^ (col & 7)) << 4);
+        if constexpr (FP8) {
+            u32x4 o4[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
-            u32x4 o4;
-            o4.x = __builtin_amdgcn_perm(R[1][j >> 1], R[0][j >> 1], sel);
-            o4.y = __builtin_amdgcn_perm(R[3][j >> 1], R[2][j >> 1], sel);
-            o4.z = __builtin_amdgcn_perm(R[5][j >> 1], R[4][j >> 1], sel);
-            o4.w = __builtin_amdgcn_perm(R[7][j >> 1], R[6][j >> 1], sel);
-            *reinterpret_cast<u32x4*>(base + j * pitchT) = o4;
+            for (int m = 0; m < 4; m++) {              // rows 4m .. 4m+3 of the block: byte j of each -> dword m of output j
+                const uint32_t ta = __builtin_amdgcn_perm(R[m].y, R[m].x, 0x05010400u), tb = __builtin_amdgcn_perm(R[m].y, R[m].x, 0x07030602u);
+                const uint32_t tc = __builtin_amdgcn_perm(R[m].w, R[m].z, 0x05010400u), td = __builtin_amdgcn_perm(R[m].w, R[m].z, 0x07030602u);
+                o4[0][m] = __builtin_amdgcn_perm(tc, ta, 0x05040100u); o4[1][m] = __builtin_amdgcn_perm(tc, ta, 0x07060302u);
+                o4[2][m] = __builtin_amdgcn_perm(td, tb, 0x05040100u); o4[3][m] = __builtin_amdgcn_perm(td, tb, 0x07060302u);
+            }
+            unsigned char* base = stage + buf * stage_bytes + (size_t)(col * 4) * pitchT + ((rb ^ ((col >> 1) & 3)) << 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) *reinterpret_cast<u32x4*>(base + j * pitchT) = o4[j];
+        } else {
+            unsigned char* base = stage + buf * stage_bytes + (size_t)(col * 8) * pitchT + ((rb ^ (col & 7)) << 4);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                u32x4 o4;
+                o4.x = __builtin_amdgcn_perm(R[1][j >> 1], R[0][j >> 1], sel);
+                o4.y = __builtin_amdgcn_perm(R[3][j >> 1], R[2][j >> 1], sel);
+                o4.z = __builtin_amdgcn_perm(R[5][j >> 1], R[4][j >> 1], sel);
+                o4.w = __builtin_amdgcn_perm(R[7][j >> 1], R[6][j >> 1], sel);
+                *reinterpret_cast<u32x4*>(base + j * pitchT) = o4;
+            }
         }
     };
     if (producer) {
@@ -943,7 +966,7 @@ __global__ void __launch_bounds__(512) kr_gqa_pv_kernel(const KrGqaArgs a, int m
     __syncthreads();
     // ---- p.v
     const unsigned char* rowT = stage + (size_t)(t & 255) * pitchT;
-    const int swz = (t >> 3) & 7;
+    const int swz = FP8 ? (t >> 3) & 3 : (t >> 3) & 7;
     float o = 0.0f;
     auto chain8 = [&](float acc, const u32x4 v, const float4 pa, const float4 pb) {
         auto lo = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); };
@@ -952,6 +975,12 @@ __global__ void __launch_bounds__(512) kr_gqa_pv_kernel(const KrGqaArgs a, int m
         acc = __builtin_fmaf(pa.z, lo(v.y), acc); acc = __builtin_fmaf(pa.w, hi(v.y), acc);
         acc = __builtin_fmaf(pb.x, lo(v.z), acc); acc = __builtin_fmaf(pb.y, hi(v.z), acc);
         acc = __builtin_fmaf(pb.z, lo(v.w), acc); acc = __builtin_fmaf(pb.w, hi(v.w), acc);
+        return acc;
+    };
+    // E4M3: one dword = 4 positions; the hardware widening (v_cvt_f32_fp8, OCP E4M3 on gfx950 == torch.float8_e4m3fn for every finite code)
+    auto chain4f8 = [&](float acc, const uint32_t w, const float4 p4) {
+        acc = __builtin_fmaf(p4.x, __builtin_amdgcn_cvt_f32_fp8((int)w, 0), acc); acc = __builtin_fmaf(p4.y, __builtin_amdgcn_cvt_f32_fp8((int)w, 1), acc);
+        acc = __builtin_fmaf(p4.z, __builtin_amdgcn_cvt_f32_fp8((int)w, 2), acc); acc = __builtin_fmaf(p4.w, __builtin_amdgcn_cvt_f32_fp8((int)w, 3), acc);
         return acc;
     };
     for (int st0 = 0; st0 < nst; st0 += KR_PV_DEPTH) {
@@ -971,14 +1000,32 @@ __global__ void __launch_bounds__(512) kr_gqa_pv_kernel(const KrGqaArgs a, int m
             const float* P = STREAM ? pw[buf] : sc + s0;
             const unsigned char* rT = rowT + buf * stage_bytes;
             const int n = min(KR_PV_ROWS, seq - s0);
-            if (n == KR_PV_ROWS) {               // full stage: both halves' reads are issued before the first chain
+            if (FP8) {
+                if (n == KR_PV_ROWS) {
+                    u32x4 v[4]; float4 pq[16];
+#pragma unroll
+                    for (int u2 = 0; u2 < 4; u2++) v[u2] = *reinterpret_cast<const u32x4*>(rT + ((u2 ^ swz) << 4));
+#pragma unroll
+                    for (int u2 = 0; u2 < 16; u2++) pq[u2] = *reinterpret_cast<const float4*>(P + u2 * 4);
+#pragma unroll
+                    for (int u2 = 0; u2 < 16; u2++) o = chain4f8(o, v[u2 >> 2][u2 & 3], pq[u2]);
+                } else {                         // last, partial stage of the cache (once per launch)
+                    for (int k2 = 0; k2 < n; k2++) {
+                        const uint32_t w = *reinterpret_cast<const uint32_t*>(rT + (((k2 >> 4) ^ swz) << 4) + ((k2 >> 2) & 3) * 4);
+                        const int bs = k2 & 3;
+                        const float vv = bs == 0 ? __builtin_amdgcn_cvt_f32_fp8((int)w, 0) : bs == 1 ? __builtin_amdgcn_cvt_f32_fp8((int)w, 1)
+                                       : bs == 2 ? __builtin_amdgcn_cvt_f32_fp8((int)w, 2) : __builtin_amdgcn_cvt_f32_fp8((int)w, 3);
+                        o = __builtin_fmaf(P[k2], vv, o);
+                    }
+                }
+            } else if (n == KR_PV_ROWS) {        // full stage: both halves' reads are issued before the first chain
                 u32x4 v[8]; float4 pq[16];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const u32x4*>(rT + ((u ^ swz) << 4));
+                for (int u2 = 0; u2 < 8; u2++) v[u2] = *reinterpret_cast<const u32x4*>(rT + ((u2 ^ swz) << 4));
 #pragma unroll
-                for (int u = 0; u < 16; u++) pq[u] = *reinterpret_cast<const float4*>(P + u * 4);
+                for (int u2 = 0; u2 < 16; u2++) pq[u2] = *reinterpret_cast<const float4*>(P + u2 * 4);
 #pragma unroll
-                for (int u = 0; u < 8; u++) o = chain8(o, v[u], pq[2 * u], pq[2 * u + 1]);
+                for (int u2 = 0; u2 < 8; u2++) o = chain8(o, v[u2], pq[2 * u2], pq[2 * u2 + 1]);
             } else {                             // last, partial stage of the cache (once per launch)
                 const int nfull = n >> 3, rem = n & 7;
                 for (int g0 = 0; g0 < nfull; g0++)
@@ -1021,7 +1068,7 @@ __global__ void __launch_bounds__(512) kr_gqa_pv_kernel(const KrGqaArgs a, int m
         }
     }
 }
-static size_t kr_gqa_pv_lds(int lds_seq, int hd) { return ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15) + 2 * (size_t)hd * (KR_PV_ROWS * 2 + 16); }
+static size_t kr_gqa_pv_lds(int lds_seq, int hd, int fp8) { return ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15) + 2 * (size_t)hd * (KR_PV_ROWS * (fp8 ? 1 : 2) + 16); }
 
 // decode-step MoE epilogue (decode.rs:3343-3345, 3391-3402): hidden = moe (*rsf) + shared (*sigmoid(gate))
 __global__ void __launch_bounds__(256) kr_moe_combine_decode_kernel(const float* __restrict__ eo, const int32_t* __restrict__ ids,
@@ -1138,14 +1185,15 @@ int kr_gqa_attn_prepare(int max_seq, int hd, int fp8) {
             if (hipFuncSetAttribute(fp8 ? f8[i] : f16[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
         lds_set[fp8 ? 1 : 0] = lds;
     }
-    if (!fp8 && (hd == 128 || hd == 256)) {      // the producer / consumer softmax + p.v kernel of long FP16 caches
-        const bool res = kr_gqa_pv_lds(max_seq, hd) <= 160 * 1024;
-        const size_t lp = kr_gqa_pv_lds(res ? max_seq : 4096, hd);
-        static size_t lp_set = 0;
-        if (lp > lp_set) {
-            const void* f[4] = {(const void*)kr_gqa_pv_kernel<16, false>, (const void*)kr_gqa_pv_kernel<16, true>, (const void*)kr_gqa_pv_kernel<32, false>, (const void*)kr_gqa_pv_kernel<32, true>};
-            for (const void* fn : f) if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp) != hipSuccess) return -2;
-            lp_set = lp;
+    if (hd == 128 || hd == 256) {                // the producer / consumer softmax + p.v kernel of long caches
+        const bool res = kr_gqa_pv_lds(max_seq, hd, fp8) <= 160 * 1024;
+        const size_t lp = kr_gqa_pv_lds(res ? max_seq : 4096, hd, fp8);
+        static size_t lp_set[2] = {0, 0};
+        if (lp > lp_set[fp8 ? 1 : 0]) {
+            const void* f16[4] = {(const void*)kr_gqa_pv_kernel<16, false, false>, (const void*)kr_gqa_pv_kernel<16, true, false>, (const void*)kr_gqa_pv_kernel<32, false, false>, (const void*)kr_gqa_pv_kernel<32, true, false>};
+            const void* f8[4] = {(const void*)kr_gqa_pv_kernel<16, false, true>, (const void*)kr_gqa_pv_kernel<16, true, true>, (const void*)kr_gqa_pv_kernel<32, false, true>, (const void*)kr_gqa_pv_kernel<32, true, true>};
+            for (int i = 0; i < 4; i++) if (hipFuncSetAttribute(fp8 ? f8[i] : f16[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp) != hipSuccess) return -2;
+            lp_set[fp8 ? 1 : 0] = lp;
         }
     }
     return 0;
@@ -1163,14 +1211,16 @@ void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
     if (a.sc_g) {      // long cache: scores over nh x max_seq / 256 workgroups (those past the current length leave at once), then softmax + p.v
         kr_launch_gqa_phase<1>(a, max_seq, dim3(a.nh, (max_seq + 255) / 256), 0, s);
         const bool stream_hook = getenv("KR_GQA_STREAM") != nullptr;                   // (env: test hook)
-        if (!a.kv_fp8 && (a.hd == 128 || a.hd == 256)) {
-            const bool res = kr_gqa_pv_lds(max_seq, a.hd) <= 160 * 1024 && !stream_hook;
+        if (a.hd == 128 || a.hd == 256) {
+            const bool res = kr_gqa_pv_lds(max_seq, a.hd, a.kv_fp8) <= 160 * 1024 && !stream_hook;
             const int lds_seq = res ? max_seq : 4096;
-            const size_t lds = kr_gqa_pv_lds(lds_seq, a.hd);
-            if (a.hd == 256) { if (res) hipLaunchKernelGGL((kr_gqa_pv_kernel<32, false>), dim3(a.nh), dim3(512), lds, s, a, max_seq, lds_seq);
-                               else hipLaunchKernelGGL((kr_gqa_pv_kernel<32, true>), dim3(a.nh), dim3(512), lds, s, a, max_seq, lds_seq); }
-            else { if (res) hipLaunchKernelGGL((kr_gqa_pv_kernel<16, false>), dim3(a.nh), dim3(512), lds, s, a, max_seq, lds_seq);
-                   else hipLaunchKernelGGL((kr_gqa_pv_kernel<16, true>), dim3(a.nh), dim3(512), lds, s, a, max_seq, lds_seq); }
+            const size_t lds = kr_gqa_pv_lds(lds_seq, a.hd, a.kv_fp8);
+#define KR_PVK(N_, S_, F_) hipLaunchKernelGGL((kr_gqa_pv_kernel<N_, S_, F_>), dim3(a.nh), dim3(512), lds, s, a, max_seq, lds_seq)
+#define KR_PVS(N_, F_) do { if (res) KR_PVK(N_, false, F_); else KR_PVK(N_, true, F_); } while (0)
+            if (a.hd == 256) { if (a.kv_fp8) KR_PVS(32, true); else KR_PVS(32, false); }
+            else { if (a.kv_fp8) KR_PVS(16, true); else KR_PVS(16, false); }
+#undef KR_PVS
+#undef KR_PVK
         } else if (kr_gqa_resident(max_seq, a.hd, a.kv_fp8) && !stream_hook) kr_launch_gqa_phase<2>(a, max_seq, dim3(a.nh), max_seq, s);
         else kr_launch_gqa_phase<3>(a, max_seq, dim3(a.nh), 4096, s);
     } else kr_launch_gqa_phase<0>(a, max_seq, dim3(a.nh), max_seq, s);

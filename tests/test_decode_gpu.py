@@ -147,18 +147,27 @@ def test_decode_step_split_attention_bit_exact(hd, graph):
         tok = O.sample_greedy(ref)
 
 
-@pytest.mark.parametrize("hd,fp8", [(64, False), (256, False), (128, True), (128, False)])
-def test_decode_step_streamed_attention_bit_exact(hd, fp8, monkeypatch):
+@pytest.mark.parametrize("hd,fp8,stream", [(64, False, True), (256, False, True), (128, True, True), (128, False, True), (256, True, True),
+                                           (256, True, False), (128, True, False), (64, True, False), (256, "codes", False)])
+def test_decode_step_streamed_attention_bit_exact(hd, fp8, stream, monkeypatch):
     """caches too long for an LDS-resident score row (> ~23 k positions) stream it from HBM in tiles; KR_GQA_STREAM forces that form
-    on a cache the oracle can follow, positions across the 128-row stage and 4096-value tile boundaries"""
-    monkeypatch.setenv("KR_GQA_STREAM", "1")
+    on a cache the oracle can follow, positions across the 128-row stage and 4096-value tile boundaries.  stream=False: the same long
+    random E4M3 cache through the LDS-resident form (hardware FP8 widening in the p.v chain at head_dim 128 / 256)"""
+    if stream:
+        monkeypatch.setenv("KR_GQA_STREAM", "1")
     st, eng, orc, keep, d = build(seed=12, kv_max=4400, hd=hd)
     if fp8:
         st.set_kv_dtype(True); O.set_kv_fp8(True)
     try:
         if fp8:
             rng = np.random.default_rng(5)
-            kv = {li: (O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)), O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)))
+            def cache():
+                if fp8 == "codes":      # V: every finite E4M3 code (subnormals, +-448, both zeros) through the hardware widening; K stays small so the softmax spreads
+                    b = rng.integers(0, 256, (d["kv_max"], d["nkv"] * d["hd"])).astype(np.uint8)
+                    b[(b & 0x7F) == 0x7F] = 0x3C
+                    return b
+                return O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F))
+            kv = {li: (O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)), cache())
                   for li, kind in enumerate(d["kinds"]) if kind == "gqa"}
             for li in kv:
                 orc.layers[li]["kv_k"] = kv[li][0].astype(np.uint16); orc.layers[li]["kv_v"] = kv[li][1].astype(np.uint16)

@@ -56,13 +56,37 @@ int main() {
             hipLaunchKernelGGL((kr_gqa_attn_kernel<false, 32, 1>), dim3(nh, ms2 / 256), dim3(256), lds1, st, a, ms2, 0);
             CK(hipEventRecord(e1, st));
             hipEvent_t e2; CK(hipEventCreate(&e2));
-            hipLaunchKernelGGL((kr_gqa_pv_kernel<32, false>), dim3(nh), dim3(512), kr_gqa_pv_lds(ms2, hd), st, a, ms2, ms2);
+            hipLaunchKernelGGL((kr_gqa_pv_kernel<32, false, false>), dim3(nh), dim3(512), kr_gqa_pv_lds(ms2, hd, 0), st, a, ms2, ms2);
             CK(hipEventRecord(e2, st)); CK(hipStreamSynchronize(st));
             float m1, m2; CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e1, e2));
             unsigned long long s[32]; CK(hipMemcpyFromSymbol(s, HIP_SYMBOL(kr_dstamps), sizeof(s)));
             auto d = [&](int x, int y) { return (double)(long long)(s[y] - s[x]) * 0.01; };
             if (rep) printf("seq %4d split: scores launch %6.1f us | softmax+pv launch %6.1f us: load scores %.1f max+exp %.1f seqsum %.1f scale + p.v (all stages) %.1f\n",
                             pos + 1, m1 * 1e3, m2 * 1e3, d(0, 3), d(3, 4), d(4, 5), d(5, 7));
+        }
+    }
+    // ---- the same long cache as FP8-E4M3 bytes: scores launch + producer / consumer softmax + p.v
+    {
+        const int ms2 = 8192; const size_t n2 = (size_t)ms2 * nkv * hd;
+        std::vector<uint8_t> k8(n2), v8(n2);
+        for (size_t i = 0; i < n2; i++) { k8[i] = (uint8_t)(0x28 + (rand() & 0x1F) + ((rand() & 1) << 7)); v8[i] = (uint8_t)(0x28 + (rand() & 0x1F) + ((rand() & 1) << 7)); }
+        void *dk8, *dv8; float* dsc;
+        CK(hipMalloc(&dk8, n2)); CK(hipMalloc(&dv8, n2)); CK(hipMalloc(&dsc, (size_t)nh * ms2 * 4));
+        CK(hipMemcpy(dk8, k8.data(), n2, hipMemcpyHostToDevice)); CK(hipMemcpy(dv8, v8.data(), n2, hipMemcpyHostToDevice));
+        if (kr_gqa_attn_prepare(ms2, hd, 1)) { printf("prepare failed\n"); return 1; }
+        a.k_cache = dk8; a.v_cache = dv8; a.sc_g = dsc; a.kv_fp8 = 1;
+        const size_t lds2 = kr_gqa_attn_lds(ms2, hd, 1), lds1 = kr_gqa_attn_lds(0, hd, 1);
+        hipEvent_t e2; CK(hipEventCreate(&e2));
+        for (int pos : {1023, 8190}) for (int rep = 0; rep < 2; rep++) {
+            KrStep hs{}; hs.token = 0; hs.pos = pos;
+            CK(hipMemcpy(dstep, &hs, sizeof(hs), hipMemcpyHostToDevice));
+            CK(hipEventRecord(e0, st));
+            hipLaunchKernelGGL((kr_gqa_attn_kernel<true, 32, 1>), dim3(nh, ms2 / 256), dim3(256), lds1, st, a, ms2, 0);
+            CK(hipEventRecord(e1, st));
+            hipLaunchKernelGGL((kr_gqa_pv_kernel<32, false, true>), dim3(nh), dim3(512), kr_gqa_pv_lds(ms2, hd, 1), st, a, ms2, ms2);
+            CK(hipEventRecord(e2, st)); CK(hipStreamSynchronize(st));
+            float m1, m2; CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e1, e2));
+            if (rep) printf("seq %4d FP8 split: scores launch %6.1f us | softmax+pv launch %6.1f us\n", pos + 1, m1 * 1e3, m2 * 1e3);
         }
     }
     return 0;
