@@ -158,10 +158,9 @@ __device__ __forceinline__ uint8_t kr_f32_to_e4m3(float f) {
     return (uint8_t)(sign | (r & 0x7Fu));
 }
 __device__ __forceinline__ float kr_e4m3_to_f32(uint8_t x) {
-    const uint32_t m = (uint32_t)(x & 0x7Fu);
-    if (m == 0x7Fu) return __uint_as_float(0x7FC00000u | ((uint32_t)(x & 0x80u) << 24));
-    const float v = __uint_as_float(m << 20) * __uint_as_float(0x7B800000u);   // x 2^120: rebias 7 -> 127, subnormals come out exact
-    return (x & 0x80u) ? -v : v;
+    // gfx950's v_cvt_f32_fp8 reads OCP E4M3 (the "fn" format of torch.float8_e4m3fn): exact for all 254 finite codes (subnormals, both zeros,
+    // +-448; tests/test_decode_gpu.py runs every one through it), NaN for 0x7F / 0xFF
+    return __builtin_amdgcn_cvt_f32_fp8((int)x, 0);
 }
 __device__ __forceinline__ float kr_kv_load(const void* base, size_t i, int fp8) {
     if (fp8) return kr_e4m3_to_f32(reinterpret_cast<const uint8_t*>(base)[i]);
