@@ -13,7 +13,6 @@
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
 #include <hip/hip_fp16.h>
-#include <cstdlib>
 
 #ifdef KR_TIMING   // tools/probes/mla_timing.hip: wall-clock stamps (10 ns units) of thread 0 of workgroup 0, no-op in the product build
 __device__ unsigned long long kr_mstamps[32];
@@ -198,13 +197,11 @@ __global__ void __launch_bounds__(512) kr_mla_attn_kernel(KrMlaArgs a) {
 // load per element of every dot product and of every weighted-sum step: 215 ns per cached position per layer on a V2-Lite shape.
 #define KR_MLA_ROWS 64
 #define KR_MLA_HG 4          // heads that share a staged row in the decode scores launch
-// PHASE 0: scores + softmax + weighted sum of one head.  PHASE 2: softmax + weighted sum only, the scores come from a.sc_g (written by
-// kr_mla_scores_kernel, which shares every staged cache row between 8 heads and spreads over the position blocks).
-// PHASE 3: as PHASE 2 for caches whose score row does not fit LDS (> ~21 k positions): the row stays in a.sc_g and is streamed in tiles
-// (max, exp in place, position-ordered sum over 4096-value tiles with the running sum carried, the stage's 64 probabilities scaled
-// into a small LDS window).  `lds_seq` sizes the LDS score window (max_seq, or the tile for PHASE 3).
-template <bool FP8, int NBC, int NBR, int PHASE>
-__global__ void __launch_bounds__(512) kr_mla_attn_staged_kernel(KrMlaArgs a, int max_seq, int lds_seq) {
+// Scores + softmax + weighted sum of one head in one workgroup: short caches of the decode step (the score row is LDS-resident) and the prompt
+// pass (grid y = token).  Long decode caches split the work: kr_mla_scores_kernel + kr_mla_pv_kernel below.
+template <bool FP8, int NBC, int NBR>
+__global__ void __launch_bounds__(512) kr_mla_attn_staged_kernel(KrMlaArgs a, int max_seq) {
+    const int lds_seq = max_seq;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[12];
     constexpr int klr = NBC * 8, rd = NBR * 8, esz = FP8 ? 1 : 2;
@@ -246,55 +243,7 @@ __global__ void __launch_bounds__(512) kr_mla_attn_staged_kernel(KrMlaArgs a, in
     Regs r0, r1;
     const int nst = (seq + KR_MLA_ROWS - 1) / KR_MLA_ROWS;
     KR_MSTAMP(0);
-    if (PHASE == 3) {
-        constexpr int TILE = 4096;
-        float* tile = sc;
-        float* row = a.sc_g + (size_t)h * max_seq;
-        float mx = -__builtin_inff();
-        for (int s2 = t; s2 < seq; s2 += 512) mx = fmaxf(mx, row[s2]);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        if ((t & 63) == 0) red[t >> 6] = mx;
-        __syncthreads();
-        mx = red[0];
-#pragma unroll
-        for (int w = 1; w < 8; w++) mx = fmaxf(mx, red[w]);
-        for (int s2 = t; s2 < seq; s2 += 512) row[s2] = kr_expf(row[s2] - mx);
-        issue(r0, 0); issue(r1, KR_MLA_ROWS);
-        __syncthreads();
-        float se = 0.0f;
-        for (int s0 = 0; s0 < seq; s0 += TILE) {
-            const int n = min(TILE, seq - s0), n32 = (n + 31) & ~31;
-            for (int i = t; i < n32; i += 512) tile[i] = i < n ? row[s0 + i] : 0.0f;
-            __syncthreads();
-            if (t == 0) { se = kr_seq_sum(tile, n32, se); red[9] = se; }
-            __syncthreads();
-        }
-        const float inv3 = 1.0f / red[9];
-        float o3 = 0.0f;
-        for (int st = 0; st < nst; st++) {
-            __syncthreads();
-            commit(r0);
-            r0 = r1;
-            issue(r1, (st + 2) * KR_MLA_ROWS);
-            const int s0 = st * KR_MLA_ROWS, n = min(KR_MLA_ROWS, seq - s0);
-            if (t < KR_MLA_ROWS) tile[t] = t < n ? row[s0 + t] * inv3 : 0.0f;
-            __syncthreads();
-            if (t < klr) {
-                for (int r = 0; r < n; r += 16) {
-                    float vv[16], pp[16];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) { vv[u] = kr_stage_val<FP8>(stage + (r + u) * pitch, t); pp[u] = tile[r + u]; }
-#pragma unroll
-                    for (int u = 0; u < 16; u++) if (r + u < n) o3 = __builtin_fmaf(pp[u], vv[u], o3);
-                }
-            }
-        }
-        if (t < klr) a.attn_lat[(size_t)h * klr + t] = o3;
-        return;
-    }
-    if (PHASE == 2) for (int s2 = t; s2 < seq; s2 += 512) sc[s2] = a.sc_g[(size_t)h * max_seq + s2];
-    else { issue(r0, 0); issue(r1, KR_MLA_ROWS); }
+    issue(r0, 0); issue(r1, KR_MLA_ROWS);
     __syncthreads();
     KR_MSTAMP(1);
     // ---- scores: 16 lanes per position (mla_attn_dot_fp16_avx2): lane c = (accumulator a2 = c >> 3, AVX lane l = c & 7) owns the 8-blocks
@@ -307,7 +256,7 @@ __global__ void __launch_bounds__(512) kr_mla_attn_staged_kernel(KrMlaArgs a, in
 #pragma unroll
     for (int u = 0; u < NQR; u++) { const int i = 2 * u + a2; qr[u] = (i < NBR && (i < (NBR & ~1) || a2 == 0)) ? qp[i * 8 + l] : 0.0f; }
     static_assert(NBC % 2 == 0 && NBR % 2 == 0, "odd block counts take the generic kernel (a zero query element is not a skipped fma)");
-    for (int st = 0; st < (PHASE == 2 ? 0 : nst); st++) {
+    for (int st = 0; st < nst; st++) {
         if (st) __syncthreads();
         commit(r0);
         r0 = r1;
@@ -488,7 +437,7 @@ __global__ void __launch_bounds__(256) kr_rmsnorm_seq_kernel(float* __restrict__
     for (int i = t; i < n; i += 256) x[i] = lds[i] * (rms * w[i]);
 }
 
-// ---- decode, long FP16 caches: softmax + weighted sum of one head with PRODUCER and CONSUMER waves (the MLA twin of kr_gqa_pv_kernel) --------
+// ---- decode, long caches (FP16 or E4M3): softmax + weighted sum of one head with PRODUCER and CONSUMER waves (the MLA twin of kr_gqa_pv_kernel) --------
 // The weighted sum (mla_weighted_sum_fp16_avx2, decode.rs:4326) is one fma per position in position order for every latent element, and a
 // wave issues roughly one instruction per 9 cycles whatever it does -- so the chain's waves should issue nothing but the chain.  Threads
 // 0 .. klr-1 (consumers, thread j owns latent element j) read a COLUMN-major stage [j][64 positions] from LDS: one 16-byte read = 8 positions,
@@ -496,44 +445,70 @@ __global__ void __launch_bounds__(256) kr_rmsnorm_seq_kernel(float* __restrict__
 // 64 latent rows a stage ahead, transpose 8 x 8 halves in registers (v_perm_b32) and write the other half of the double-buffered stage;
 // they also scale the stage's 64 probabilities into a small window.  One workgroup barrier per 64 positions.  The score row stays in
 // a.sc_g (written by kr_mla_scores_kernel): max, exp in place, position-ordered sum over 1024-value tiles with the running sum carried.
-// Same operations in the same order as kr_mla_attn_staged_kernel PHASE 2 / 3.
+// Same operations in the same order as the softmax / weighted-sum half of kr_mla_attn_staged_kernel.
 #define KR_MPV_ROWS 64
 #define KR_MPV_EPT 1        // latent elements per consumer thread; 2 (half the probability reads, two chains per thread) measured 5 % slower
-template <int NBC>
+template <int NBC, bool FP8>
 __global__ void __launch_bounds__(NBC * 8 / KR_MPV_EPT + 256) kr_mla_pv_kernel(KrMlaArgs a, int max_seq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_mem[];
     __shared__ float red[16];
     __shared__ __attribute__((aligned(16))) float pw[2][KR_MPV_ROWS];
     __shared__ __attribute__((aligned(16))) float tile[1024 + 32];
-    constexpr int klr = NBC * 8, pitchT = KR_MPV_ROWS * 2 + 16, stage_bytes = klr * pitchT;
+    constexpr int klr = NBC * 8, esz = FP8 ? 1 : 2, pitchT = KR_MPV_ROWS * esz + 16, stage_bytes = klr * pitchT;
     constexpr int EPT = KR_MPV_EPT, NC = klr / EPT, NT = NC + 256, NW = NT / 64;     // NC consumer threads, thread j owns elements j + e * NC
-    constexpr int NBLK = NBC / 32, RBS = 256 / NBC;      // 8 x 8 blocks per producer thread; row-block step between them
+    // producer pieces.  FP16: 8 rows x one 16-byte column (NBC columns x 8 row blocks).  E4M3: 16 rows x one 4-byte column (klr / 4 columns x 4
+    // row blocks; 8 v_perm per four rows turn byte j of 16 rows into a 16-position group; position groups swizzled by (j / 8) % 4).
+    constexpr int NCOL = FP8 ? klr / 4 : NBC, NRB = FP8 ? 4 : 8, RPB = KR_MPV_ROWS / NRB, CB = FP8 ? 4 : 16;
+    constexpr int NBLK = NCOL * NRB / 256, RBS = 256 / NCOL, NRG = FP8 ? 4 : 8;       // blocks per producer thread, row-block step, 16-byte registers per block
     const int h = blockIdx.x, t = threadIdx.x, seq = a.step->pos + 1;
     const int nst = (seq + KR_MPV_ROWS - 1) / KR_MPV_ROWS;
     float* row = a.sc_g + (size_t)h * max_seq;
     const bool producer = t >= NC;
-    const int pt = t - NC, col = pt & (NBC - 1), rb0 = pt / NBC;
-    const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.ckv_cache), 0, seq * klr * 2, 0x00020000);
-    const int voff = producer ? rb0 * 8 * klr * 2 + col * 16 : 0x7FFFFFF0;
-    u32x4 rg[NBLK * 8];          // one register set: the rows of stage k+2 are requested while stage k is consumed
-    auto issue_v = [&](u32x4 (&R)[NBLK * 8], int s0) {      // unguarded: rows at or past the current length are outside the descriptor and read as zero
-#pragma unroll
-        for (int i = 0; i < NBLK * 8; i++) R[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_c, voff + (s0 + (i >> 3) * RBS * 8 + (i & 7)) * klr * 2, 0, 0);
-    };
-    auto commit_v = [&](const u32x4 (&R)[NBLK * 8], int buf) {
+    const int pt = t - NC, col = pt & (NCOL - 1), rb0 = pt / NCOL;
+    const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.ckv_cache), 0, seq * klr * esz, 0x00020000);
+    const int voff = producer ? rb0 * RPB * klr * esz + col * CB : 0x7FFFFFF0;
+    u32x4 rg[NBLK * NRG];        // one register set: the rows of stage k+2 are requested while stage k is consumed
+    auto issue_v = [&](u32x4 (&R)[NBLK * NRG], int s0) {    // unguarded: rows at or past the current length are outside the descriptor and read as zero
 #pragma unroll
         for (int b = 0; b < NBLK; b++) {
-            const int rb = rb0 + b * RBS;                    // position group (8 rows) inside the stage
-            unsigned char* base = stage_mem + buf * stage_bytes + (size_t)(col * 8) * pitchT + ((rb ^ (col & 7)) << 4);
+            if constexpr (FP8) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
-                u32x4 o4;
-                o4.x = __builtin_amdgcn_perm(R[b * 8 + 1][j >> 1], R[b * 8 + 0][j >> 1], sel);
-                o4.y = __builtin_amdgcn_perm(R[b * 8 + 3][j >> 1], R[b * 8 + 2][j >> 1], sel);
-                o4.z = __builtin_amdgcn_perm(R[b * 8 + 5][j >> 1], R[b * 8 + 4][j >> 1], sel);
-                o4.w = __builtin_amdgcn_perm(R[b * 8 + 7][j >> 1], R[b * 8 + 6][j >> 1], sel);
-                *reinterpret_cast<u32x4*>(base + j * pitchT) = o4;
+                for (int i = 0; i < 16; i++) R[b * 4 + (i >> 2)][i & 3] = __builtin_amdgcn_raw_buffer_load_b32(srd_c, voff + (s0 + b * RBS * 16 + i) * klr, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) R[b * 8 + i] = __builtin_amdgcn_raw_buffer_load_b128(srd_c, voff + (s0 + b * RBS * 8 + i) * klr * 2, 0, 0);
+            }
+        }
+    };
+    auto commit_v = [&](const u32x4 (&R)[NBLK * NRG], int buf) {
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            const int rb = rb0 + b * RBS;                    // position group inside the stage
+            if constexpr (FP8) {
+                u32x4 o4[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const u32x4 q = R[b * 4 + m];
+                    const uint32_t ta = __builtin_amdgcn_perm(q.y, q.x, 0x05010400u), tb = __builtin_amdgcn_perm(q.y, q.x, 0x07030602u);
+                    const uint32_t tc = __builtin_amdgcn_perm(q.w, q.z, 0x05010400u), td = __builtin_amdgcn_perm(q.w, q.z, 0x07030602u);
+                    o4[0][m] = __builtin_amdgcn_perm(tc, ta, 0x05040100u); o4[1][m] = __builtin_amdgcn_perm(tc, ta, 0x07060302u);
+                    o4[2][m] = __builtin_amdgcn_perm(td, tb, 0x05040100u); o4[3][m] = __builtin_amdgcn_perm(td, tb, 0x07060302u);
+                }
+                unsigned char* base = stage_mem + buf * stage_bytes + (size_t)(col * 4) * pitchT + ((rb ^ ((col >> 1) & 3)) << 4);
+#pragma unroll
+                for (int j = 0; j < 4; j++) *reinterpret_cast<u32x4*>(base + j * pitchT) = o4[j];
+            } else {
+                unsigned char* base = stage_mem + buf * stage_bytes + (size_t)(col * 8) * pitchT + ((rb ^ (col & 7)) << 4);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                    u32x4 o4;
+                    o4.x = __builtin_amdgcn_perm(R[b * 8 + 1][j >> 1], R[b * 8 + 0][j >> 1], sel);
+                    o4.y = __builtin_amdgcn_perm(R[b * 8 + 3][j >> 1], R[b * 8 + 2][j >> 1], sel);
+                    o4.z = __builtin_amdgcn_perm(R[b * 8 + 5][j >> 1], R[b * 8 + 4][j >> 1], sel);
+                    o4.w = __builtin_amdgcn_perm(R[b * 8 + 7][j >> 1], R[b * 8 + 6][j >> 1], sel);
+                    *reinterpret_cast<u32x4*>(base + j * pitchT) = o4;
+                }
             }
         }
     };
@@ -564,7 +539,7 @@ __global__ void __launch_bounds__(NBC * 8 / KR_MPV_EPT + 256) kr_mla_pv_kernel(K
     __syncthreads();
     // ---- weighted sum
     const unsigned char* rowT = stage_mem + (size_t)(t & (NC - 1)) * pitchT;
-    const int swz = (t >> 3) & 7;
+    const int swz = FP8 ? (t >> 3) & 3 : (t >> 3) & 7;
     float o[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; e++) o[e] = 0.0f;
@@ -575,6 +550,11 @@ __global__ void __launch_bounds__(NBC * 8 / KR_MPV_EPT + 256) kr_mla_pv_kernel(K
         acc = __builtin_fmaf(pa.z, lo(v.y), acc); acc = __builtin_fmaf(pa.w, hi(v.y), acc);
         acc = __builtin_fmaf(pb.x, lo(v.z), acc); acc = __builtin_fmaf(pb.y, hi(v.z), acc);
         acc = __builtin_fmaf(pb.z, lo(v.w), acc); acc = __builtin_fmaf(pb.w, hi(v.w), acc);
+        return acc;
+    };
+    auto chain4f8 = [&](float acc, const uint32_t w, const float4 p4) {     // one dword = 4 positions, hardware E4M3 widening
+        acc = __builtin_fmaf(p4.x, __builtin_amdgcn_cvt_f32_fp8((int)w, 0), acc); acc = __builtin_fmaf(p4.y, __builtin_amdgcn_cvt_f32_fp8((int)w, 1), acc);
+        acc = __builtin_fmaf(p4.z, __builtin_amdgcn_cvt_f32_fp8((int)w, 2), acc); acc = __builtin_fmaf(p4.w, __builtin_amdgcn_cvt_f32_fp8((int)w, 3), acc);
         return acc;
     };
     for (int st0 = 0; st0 < nst; st0 += 2) {
@@ -593,7 +573,29 @@ __global__ void __launch_bounds__(NBC * 8 / KR_MPV_EPT + 256) kr_mla_pv_kernel(K
             const float* P = pw[u];
             const unsigned char* rT = rowT + u * stage_bytes;
             const int n = min(KR_MPV_ROWS, seq - s0);
-            if (n == KR_MPV_ROWS) {
+            if (FP8) {
+                static_assert(!FP8 || EPT == 1, "E4M3 form: one element per consumer thread");
+                if (n == KR_MPV_ROWS) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) {
+                        u32x4 v[2]; float4 pq[8];
+#pragma unroll
+                        for (int g = 0; g < 2; g++) v[g] = *reinterpret_cast<const u32x4*>(rT + (((hf * 2 + g) ^ swz) << 4));
+#pragma unroll
+                        for (int g = 0; g < 8; g++) pq[g] = *reinterpret_cast<const float4*>(P + hf * 32 + g * 4);
+#pragma unroll
+                        for (int g = 0; g < 8; g++) o[0] = chain4f8(o[0], v[g >> 2][g & 3], pq[g]);
+                    }
+                } else {
+                    for (int k2 = 0; k2 < n; k2++) {
+                        const uint32_t w = *reinterpret_cast<const uint32_t*>(rT + (((k2 >> 4) ^ swz) << 4) + ((k2 >> 2) & 3) * 4);
+                        const int bs = k2 & 3;
+                        const float vv = bs == 0 ? __builtin_amdgcn_cvt_f32_fp8((int)w, 0) : bs == 1 ? __builtin_amdgcn_cvt_f32_fp8((int)w, 1)
+                                       : bs == 2 ? __builtin_amdgcn_cvt_f32_fp8((int)w, 2) : __builtin_amdgcn_cvt_f32_fp8((int)w, 3);
+                        o[0] = __builtin_fmaf(P[k2], vv, o[0]);
+                    }
+                }
+            } else if (n == KR_MPV_ROWS) {
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {     // 32 positions at a time: the values up front, the probabilities 16 positions ahead of their use
                     u32x4 v[EPT][4]; float4 pq[2][4];
@@ -636,7 +638,7 @@ __global__ void __launch_bounds__(NBC * 8 / KR_MPV_EPT + 256) kr_mla_pv_kernel(K
         for (int e = 0; e < EPT; e++) a.attn_lat[(size_t)h * klr + e * NC + t] = o[e];
     }
 }
-template <int NBC> static size_t kr_mla_pv_lds() { return 2 * (size_t)NBC * 8 * (KR_MPV_ROWS * 2 + 16); }
+template <int NBC, bool FP8> static size_t kr_mla_pv_lds() { return 2 * (size_t)NBC * 8 * (KR_MPV_ROWS * (FP8 ? 1 : 2) + 16); }
 
 static size_t kr_mla_staged_lds(const KrMlaArgs& a, int lds_seq) {
     const size_t esz = a.kv_fp8 ? 1 : 2;
@@ -644,28 +646,29 @@ static size_t kr_mla_staged_lds(const KrMlaArgs& a, int lds_seq) {
 }
 template <bool FP8, int NBC>
 static bool kr_launch_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {
-    const bool resident = kr_mla_staged_lds(a, max_seq) <= 160 * 1024 && !getenv("KR_MLA_STREAM");   // (env: test hook)
-    const bool split = a.sc_g && n_tok == 1;
-    if (!resident && !split) return false;          // the prompt pass keeps the score row in LDS: the generic kernel reports the limit
-    const int lds_seq = resident ? max_seq : 4096;
-    const size_t lds = kr_mla_staged_lds(a, lds_seq);
+    const bool split = a.sc_g && n_tok == 1;          // decode with a long cache: head-shared scores launch, then softmax + weighted sum per head
+    const size_t lds = kr_mla_staged_lds(a, max_seq);
+    const bool prep = !s;                             // prepare-only call (outside graph capture): raise the windows of both forms
+    if (!prep && !split && lds > 160 * 1024) return false;     // one-launch form: the score row is LDS-resident (the generic kernel reports the limit)
     const size_t esz = a.kv_fp8 ? 1 : 2;
     const size_t lds_sc = (size_t)KR_MLA_HG * (a.klr + a.rd) * 4 + (size_t)KR_MLA_ROWS * ((size_t)(a.klr + a.rd) * esz + 16);
+    const size_t lds_pv = kr_mla_pv_lds<NBC, FP8>();
     static size_t lds_set = 0;                       // per instantiation; raised outside graph capture by kr_mla_attn_prepare
-    if (lds > lds_set) {
-        const void* fns[3] = {(const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 0>, (const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>, (const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8, 3>};
-        for (const void* f : fns) if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        if (hipFuncSetAttribute((const void*)kr_mla_scores_kernel<FP8, NBC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess) return false;
-        if (!FP8 && hipFuncSetAttribute((const void*)kr_mla_pv_kernel<NBC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kr_mla_pv_lds<NBC>()) != hipSuccess) return false;
+    if ((prep || !split) && lds <= 160 * 1024 && lds > lds_set) {
+        if (hipFuncSetAttribute((const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         lds_set = lds;
     }
-    if (!s) return true;                             // prepare-only call
-    if (split) {                                     // decode with a long cache: head-shared scores launch, then softmax + weighted sum per head
+    static bool split_set = false;
+    if ((prep || split) && !split_set) {
+        if (hipFuncSetAttribute((const void*)kr_mla_scores_kernel<FP8, NBC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void*)kr_mla_pv_kernel<NBC, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pv) != hipSuccess) return false;
+        split_set = true;
+    }
+    if (prep) return true;
+    if (split) {
         hipLaunchKernelGGL((kr_mla_scores_kernel<FP8, NBC, 8>), dim3((max_seq + KR_MLA_ROWS - 1) / KR_MLA_ROWS, (a.nh + KR_MLA_HG - 1) / KR_MLA_HG), dim3(512), lds_sc, s, a, max_seq);
-        if (!FP8) hipLaunchKernelGGL((kr_mla_pv_kernel<NBC>), dim3(a.nh), dim3(NBC * 8 / KR_MPV_EPT + 256), kr_mla_pv_lds<NBC>(), s, a, max_seq);
-        else if (resident) hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 2>), dim3(a.nh, 1), dim3(512), lds, s, a, max_seq, lds_seq);
-        else hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 3>), dim3(a.nh, 1), dim3(512), lds, s, a, max_seq, lds_seq);
-    } else hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8, 0>), dim3(a.nh, n_tok), dim3(512), lds, s, a, max_seq, lds_seq);
+        hipLaunchKernelGGL((kr_mla_pv_kernel<NBC, FP8>), dim3(a.nh), dim3(NBC * 8 / KR_MPV_EPT + 256), lds_pv, s, a, max_seq);
+    } else hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8>), dim3(a.nh, n_tok), dim3(512), lds, s, a, max_seq);
     return true;
 }
 static bool kr_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {

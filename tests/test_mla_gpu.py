@@ -191,10 +191,10 @@ def test_mla_long_cache_split_attention_bit_exact(cfg, fp8):
 
 @pytest.mark.parametrize("cfg,fp8", [(dict(kv_max=9000, nh=5, seed=8), False), (dict(kv_max=8300, nh=3, seed=9, klr=256), True),
                                      (dict(kv_max=24000, nh=2, seed=10), False)])
-def test_mla_streamed_score_row_bit_exact(cfg, fp8, monkeypatch):
-    """caches whose score row does not fit LDS (> ~21 k positions) keep it in HBM: max / exp / position-ordered sum stream over 4096-value
-    tiles.  Forced here at a length the oracle finishes quickly (KR_MLA_STREAM), over a randomly filled cache, around the tile edges"""
-    monkeypatch.setenv("KR_MLA_STREAM", "1")
+def test_mla_streamed_score_row_bit_exact(cfg, fp8):
+    """long decode caches: the score row stays in HBM (written by the head-shared scores launch); the softmax streams it -- max, exp in place,
+    position-ordered sum over 1024-value tiles -- and the weighted sum runs on producer / consumer waves over column-major latent stages
+    (FP16 and E4M3).  A randomly filled cache, positions around the 64-row stages and the tile edges, up to 24 000 positions"""
     st, eng, orc, keep, d = build(**cfg)
     if fp8:
         st.set_kv_dtype(True); O.set_kv_fp8(True)

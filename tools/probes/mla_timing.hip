@@ -24,7 +24,7 @@ int main() {
     for (int pos : {9, 63, 127, 511, 1023, 2047}) for (int rep = 0; rep < 2; rep++) {
         KrStep hs{}; hs.token = 0; hs.pos = pos; CK(hipMemcpy(dstep, &hs, sizeof(hs), hipMemcpyHostToDevice));
         CK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL((kr_mla_attn_staged_kernel<false, 64, 8, 0>), dim3(nh, 1), dim3(512), lds, st, a, max_seq, max_seq);
+        hipLaunchKernelGGL((kr_mla_attn_staged_kernel<false, 64, 8>), dim3(nh, 1), dim3(512), lds, st, a, max_seq);
         CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         unsigned long long s[32]; CK(hipMemcpyFromSymbol(s, HIP_SYMBOL(kr_mstamps), sizeof(s)));
@@ -44,15 +44,14 @@ int main() {
         a.ckv_cache = dc2; a.kpe_cache = dk2; a.sc_g = dsc;
         kr_mla_attn_prepare(a, ms2);
         const size_t lds_sc = (size_t)KR_MLA_HG * (klr + rd) * 4 + (size_t)KR_MLA_ROWS * ((size_t)(klr + rd) * 2 + 16);
-        const size_t lds2 = kr_mla_staged_lds(a, ms2);
         hipEvent_t e2; CK(hipEventCreate(&e2));
-        for (int pos : {1023, 4095, 8190}) for (int variant = 0; variant < 2; variant++) for (int rep = 0; rep < 2; rep++) {
+        const size_t lds_pv = kr_mla_pv_lds<64, false>();
+        for (int pos : {1023, 4095, 8190}) for (int variant = 1; variant < 2; variant++) for (int rep = 0; rep < 2; rep++) {
             KrStep hs{}; hs.token = 0; hs.pos = pos; CK(hipMemcpy(dstep, &hs, sizeof(hs), hipMemcpyHostToDevice));
             CK(hipEventRecord(e0, st));
             hipLaunchKernelGGL((kr_mla_scores_kernel<false, 64, 8>), dim3((ms2 + KR_MLA_ROWS - 1) / KR_MLA_ROWS, (nh + KR_MLA_HG - 1) / KR_MLA_HG), dim3(512), lds_sc, st, a, ms2);
             CK(hipEventRecord(e1, st));
-            if (variant == 0) hipLaunchKernelGGL((kr_mla_attn_staged_kernel<false, 64, 8, 2>), dim3(nh, 1), dim3(512), lds2, st, a, ms2, ms2);
-            else hipLaunchKernelGGL((kr_mla_pv_kernel<64>), dim3(nh), dim3(512 / KR_MPV_EPT + 256), kr_mla_pv_lds<64>(), st, a, ms2);
+            hipLaunchKernelGGL((kr_mla_pv_kernel<64, false>), dim3(nh), dim3(512 / KR_MPV_EPT + 256), lds_pv, st, a, ms2);
             CK(hipEventRecord(e2, st)); CK(hipStreamSynchronize(st));
             float m1, m2; CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e1, e2));
             if (rep) printf("seq %4d split: scores launch %6.1f us | softmax + weighted sum (%s) %6.1f us\n", pos + 1, m1 * 1e3, variant ? "producer/consumer" : "staged PHASE 2", m2 * 1e3);
