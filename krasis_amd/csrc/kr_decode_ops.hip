@@ -852,7 +852,7 @@ __global__ void __launch_bounds__(256) kr_gqa_attn_kernel(const KrGqaArgs a, int
     }
 }
 
-// ---- long caches, head_dim 128 / 256 (FP16 or E4M3): softmax + p.v of one head with PRODUCER and CONSUMER waves -------------------------------------
+// ---- long caches, head_dim 64 / 128 / 256 (FP16 or E4M3): softmax + p.v of one head with PRODUCER and CONSUMER waves -------------------------------------
 // The p.v chain is one fma per position in position order, and a wave issues roughly one instruction per 9 cycles whatever it is doing,
 // so everything that is not that fma is moved OFF the chain's waves: waves 0-3 (thread d owns output d) only read the staged values and run
 // the chain; waves 4-7 fetch the next 64 cache rows, transpose them to column-major in registers and write them to the other half of a
@@ -1185,14 +1185,16 @@ int kr_gqa_attn_prepare(int max_seq, int hd, int fp8) {
             if (hipFuncSetAttribute(fp8 ? f8[i] : f16[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
         lds_set[fp8 ? 1 : 0] = lds;
     }
-    if (hd == 128 || hd == 256) {                // the producer / consumer softmax + p.v kernel of long caches
+    if (hd == 64 || hd == 128 || hd == 256) {    // the producer / consumer softmax + p.v kernel of long caches
         const bool res = kr_gqa_pv_lds(max_seq, hd, fp8) <= 160 * 1024;
         const size_t lp = kr_gqa_pv_lds(res ? max_seq : 4096, hd, fp8);
         static size_t lp_set[2] = {0, 0};
         if (lp > lp_set[fp8 ? 1 : 0]) {
-            const void* f16[4] = {(const void*)kr_gqa_pv_kernel<16, false, false>, (const void*)kr_gqa_pv_kernel<16, true, false>, (const void*)kr_gqa_pv_kernel<32, false, false>, (const void*)kr_gqa_pv_kernel<32, true, false>};
-            const void* f8[4] = {(const void*)kr_gqa_pv_kernel<16, false, true>, (const void*)kr_gqa_pv_kernel<16, true, true>, (const void*)kr_gqa_pv_kernel<32, false, true>, (const void*)kr_gqa_pv_kernel<32, true, true>};
-            for (int i = 0; i < 4; i++) if (hipFuncSetAttribute(fp8 ? f8[i] : f16[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp) != hipSuccess) return -2;
+#define KR_F(N_, F_) (const void*)kr_gqa_pv_kernel<N_, false, F_>, (const void*)kr_gqa_pv_kernel<N_, true, F_>
+            const void* f16[6] = {KR_F(8, false), KR_F(16, false), KR_F(32, false)};
+            const void* f8[6] = {KR_F(8, true), KR_F(16, true), KR_F(32, true)};
+#undef KR_F
+            for (int i = 0; i < 6; i++) if (hipFuncSetAttribute(fp8 ? f8[i] : f16[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp) != hipSuccess) return -2;
             lp_set[fp8 ? 1 : 0] = lp;
         }
     }
@@ -1211,14 +1213,15 @@ void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
     if (a.sc_g) {      // long cache: scores over nh x max_seq / 256 workgroups (those past the current length leave at once), then softmax + p.v
         kr_launch_gqa_phase<1>(a, max_seq, dim3(a.nh, (max_seq + 255) / 256), 0, s);
         const bool stream_hook = getenv("KR_GQA_STREAM") != nullptr;                   // (env: test hook)
-        if (a.hd == 128 || a.hd == 256) {
+        if (a.hd == 64 || a.hd == 128 || a.hd == 256) {
             const bool res = kr_gqa_pv_lds(max_seq, a.hd, a.kv_fp8) <= 160 * 1024 && !stream_hook;
             const int lds_seq = res ? max_seq : 4096;
             const size_t lds = kr_gqa_pv_lds(lds_seq, a.hd, a.kv_fp8);
 #define KR_PVK(N_, S_, F_) hipLaunchKernelGGL((kr_gqa_pv_kernel<N_, S_, F_>), dim3(a.nh), dim3(512), lds, s, a, max_seq, lds_seq)
 #define KR_PVS(N_, F_) do { if (res) KR_PVK(N_, false, F_); else KR_PVK(N_, true, F_); } while (0)
             if (a.hd == 256) { if (a.kv_fp8) KR_PVS(32, true); else KR_PVS(32, false); }
-            else { if (a.kv_fp8) KR_PVS(16, true); else KR_PVS(16, false); }
+            else if (a.hd == 128) { if (a.kv_fp8) KR_PVS(16, true); else KR_PVS(16, false); }
+            else { if (a.kv_fp8) KR_PVS(8, true); else KR_PVS(8, false); }
 #undef KR_PVS
 #undef KR_PVK
         } else if (kr_gqa_resident(max_seq, a.hd, a.kv_fp8) && !stream_hook) kr_launch_gqa_phase<2>(a, max_seq, dim3(a.nh), max_seq, s);
