@@ -1,4 +1,4 @@
-"""Expert parallelism (krasis_amd/ep.py) on CPU: world_size 2 over gloo, arithmetic supplied by the oracle.
+"""Expert parallelism (krasis_amd/ep.py) on CPU: world_size 2 and 3 over gloo, arithmetic supplied by the oracle.
 Checks the dataflow logic (expert slicing, all_to_all bookkeeping, routing-order combine, rank-order bf16 reduction):
   * all-to-all mode is BIT-IDENTICAL to single-device execution,
   * replicated mode equals the reference's CPU-hub reduction of the per-rank partial sums."""
@@ -98,8 +98,9 @@ def test_expert_slice_rule():
     assert [expert_slice(512, 8, r) for r in (0, 7)] == [(0, 64), (448, 512)]
 
 
-def test_ep_two_ranks_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 3])      # 3: 8 experts -> slices of 2, 2 and 4 (remainder on the last rank), token shards of 3, 3 and 4
+def test_ep_ranks_gloo(world):
+    port = _free_port()
     ctx = mp.get_context("spawn"); q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs: p.start()
@@ -113,7 +114,7 @@ def test_ep_two_ranks_gloo():
     # all-to-all == single device, bit for bit
     for rank, lo, hi, got, rep in res:
         assert np.array_equal(got, single[lo:hi]), rank
-    # replicated == CPU-hub reduction of the two partial sums (rank order), identical on both ranks
+    # replicated == CPU-hub reduction of the per-rank partial sums (rank order), identical on every rank
     from krasis_amd.ep import expert_slice
     parts = []
     for r in range(world):
@@ -123,6 +124,7 @@ def test_ep_two_ranks_gloo():
             part[t] = O.f32_to_bf16(O.moe_forward_unified([a for a, _ in sel], [b for _, b in sel], x[t]) if sel else np.zeros(H, np.float32))
         parts.append(part)
     expect = O.reduce_sum_bf16(parts)
-    assert np.array_equal(res[0][4], res[1][4])
+    for r in range(1, world):
+        assert np.array_equal(res[0][4], res[r][4])
     assert np.array_equal(res[0][4], expect)
     assert np.max(np.abs(O.bf16_to_f32(expect) - O.bf16_to_f32(single))) < 0.05
