@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(c
     } else {
         __shared__ float s_w[32]; __shared__ int s_id[32]; __shared__ float s_sig;
         if (src.mode == 2) {
-            if (threadIdx.x < src.topk) { s_w[threadIdx.x] = src.wts[threadIdx.x]; s_id[threadIdx.x] = src.ids[threadIdx.x]; }
+            if ((int)threadIdx.x < src.topk) { s_w[threadIdx.x] = src.wts[threadIdx.x]; s_id[threadIdx.x] = src.ids[threadIdx.x]; }
             if (threadIdx.x == 32) s_sig = (src.has_shared && src.gate_val) ? 1.0f / (1.0f + kr_expf(-src.gate_val[0])) : 1.0f;
             __syncthreads();
         }
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) kr_la_conv_kernel(const KrLaArgs a) {
         a.z[(size_t)(kh * hr + r) * dv + i] = src[2 * dk + hr * dv + r * dv + i];
     }
     // gates (decode.rs:3891-3901)
-    if (threadIdx.x < hr) {
+    if ((int)threadIdx.x < hr) {
         const int r = threadIdx.x, vh = kh * hr + r;
         const float b_raw = a.ba[kh * 2 * hr + r], a_p = a.ba[kh * 2 * hr + hr + r];
         a.beta[vh] = 1.0f / (1.0f + kr_expf(-b_raw));

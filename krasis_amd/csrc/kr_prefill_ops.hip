@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) kr_pfm_la_conv_kernel(const KrPfmLaArgs a
         const int r = c / dv, i = c % dv;
         a.z[(size_t)t * nvdv + (size_t)(kh * hr + r) * dv + i] = src[2 * dk + hr * dv + r * dv + i];
     }
-    if (threadIdx.x < hr) {   // decode.rs:3891-3901
+    if ((int)threadIdx.x < hr) {   // decode.rs:3891-3901
         const int r = threadIdx.x, vh = kh * hr + r;
         const float* ba = a.ba + (size_t)t * a.ld_ba;
         const float b_raw = ba[kh * 2 * hr + r], a_p = ba[kh * 2 * hr + hr + r];
