@@ -44,7 +44,6 @@ extern "C" int kr_decode_create(kr_engine* eng, int group_size, int norm_bias_on
     std::unique_ptr<kr_decode_store> s(new kr_decode_store);
     s->eng = eng; s->group_size = group_size; s->norm_bias_one = norm_bias_one != 0;
     if (s->step_dev.ensure(sizeof(KrStep))) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
-    KR_HIP(hipHostMalloc((void**)&s->step_host, sizeof(KrStep), hipHostMallocDefault));
     *out = s.release();
     return KR_OK;
 }
@@ -64,7 +63,6 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                       &s->hid2, &s->res2, &s->r_counter, &s->gqa_scores, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_vlogits, &s->pf_nll, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     for (hipEvent_t ev : s->pf_events) (void)hipEventDestroy(ev);
     for (hipStream_t ps : s->pf_side) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
-    if (s->step_host) (void)hipHostFree(s->step_host);
     delete s;
 }
 
@@ -583,7 +581,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.act = nullptr; a.act_f32 = act; a.shared_decode = 1;
             if (routed && img_ok) { a.act_img = s->img_post.p; a.act_img_bf16 = s->img_post_bf16.p; }
             a.ids = (const int32_t*)s->r_ids.p; a.wts = (const float*)s->r_w.p;
-            a.B = 1; a.topk = k; a.n_slots = k + (has_shared ? 1 : 0); a.H = H; a.I = EL.inter;
+            a.B = 1; a.topk = k; a.n_slots = k + (has_shared ? 1 : 0); a.E = E; a.H = H; a.I = EL.inter;
             a.w13 = EL.w13.view(); a.w2 = EL.w2.view();
             if (has_shared) { a.sw13 = mv(s, L.sgu_wid); a.sw2 = mv(s, L.sd_wid); a.I_shared = s->weights[L.sgu_wid]->rows / 2; }
             const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
@@ -622,9 +620,9 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
 
 static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
     if (token < 0 || token >= s->vocab) return kr_fail(KR_ERR_VALUE, "token id %d out of range (vocab %d)", token, s->vocab);
+    if (pos < 0) return kr_fail(KR_ERR_VALUE, "position %d must be >= 0", pos);
     if (s->kv_max_seq > 0 && pos >= s->kv_max_seq) return kr_fail(KR_ERR_VALUE, "position %d >= kv_max_seq %d", pos, s->kv_max_seq);
     if (s->max_rope_seq > 0 && pos >= s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "position %d >= rope table length %d", pos, s->max_rope_seq);
-    s->step_host->token = token; s->step_host->pos = pos;
     for (const DLayer& L : s->layers)            // outside capture: the attention kernel's LDS window (scores + one stage of cache rows)
         if (L.hd > 0 && L.q_wid >= 0) {
             if (s->kv_max_seq > s->gqa_split_min && s->gqa_scores.ensure((size_t)L.nh * s->kv_max_seq * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
@@ -636,7 +634,8 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
             KrMlaArgs pa{}; pa.klr = L.klr; pa.rd = L.rd; pa.kv_fp8 = s->kv_fp8; kr_mla_attn_prepare(pa, s->kv_max_seq);
             if (s->kv_max_seq > s->mla_split_min && s->gqa_scores.ensure((size_t)L.nh * s->kv_max_seq * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
         }
-    KR_HIP(hipMemcpyAsync(s->step_dev.p, s->step_host, sizeof(KrStep), hipMemcpyHostToDevice, st));
+    kr_launch_set_step((KrStep*)s->step_dev.p, token, pos, st);   // by-value kernel arguments: no host slot shared between queued steps
+    s->last_stream = st;
     if (s->use_graph) {
         if (!s->graph_ok) {
             if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
@@ -780,7 +779,10 @@ extern "C" int kr_decode_generate_greedy(kr_decode_store* s, int first_token, in
 extern "C" int kr_decode_last_token(kr_decode_store* s, int* tok) {
     if (int rc = need_cfg(s)) return rc;
     KR_HIP(hipSetDevice(s->eng->device));
-    KR_HIP(hipMemcpy(tok, s->tok.p, 4, hipMemcpyDeviceToHost));
+    // the engine / caller streams are non-blocking: a legacy-stream hipMemcpy would not wait for the step that writes s->tok
+    hipStream_t st = s->last_stream ? s->last_stream : s->eng->stream;
+    KR_HIP(hipMemcpyAsync(tok, s->tok.p, 4, hipMemcpyDeviceToHost, st));
+    KR_HIP(hipStreamSynchronize(st));
     return KR_OK;
 }
 

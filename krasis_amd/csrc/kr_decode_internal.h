@@ -57,7 +57,7 @@ struct kr_decode_store {
     DevBuf pf_tokens; int pf_chunk = 0; int pf_depth = 0; std::vector<hipStream_t> pf_side; std::vector<hipEvent_t> pf_events;   // prompt pass: token ids, chunk size, second stream
     DevBuf pf_scratch;         // kr_decode_prefill: one arena for the chunk buffers
     DevBuf moe_gu, moe_eo, r_logits, r_ids, r_w;  // store-owned so a captured graph never sees them reallocated
-    DevBuf step_dev; KrStep* step_host = nullptr;
+    DevBuf step_dev; hipStream_t last_stream = nullptr;   // stream of the most recent step / prompt pass (kr_decode_last_token waits on it)
     size_t weight_bytes = 0;
     // captured graph of one decode step
     hipGraphExec_t graph_exec = nullptr; bool graph_ok = false; bool use_graph = true;

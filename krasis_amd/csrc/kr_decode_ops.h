@@ -41,6 +41,7 @@ void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok = 1
 void kr_mla_attn_prepare(const KrMlaArgs& a, int max_seq);   // outside graph capture: LDS window of the staged attention kernel
 void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s, int rows = 1, int ld = 0);
 
+void kr_launch_set_step(KrStep* dst, int token, int pos, hipStream_t s);   // (token, pos) by value: safe with many steps queued
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s);
 struct KrNormSrc {   // where the value added to the residual comes from (see kr_fused_add_rmsnorm_kernel)
     int mode;        // 0 hidden buffer, 1 embedding row of the current token, 2 MoE epilogue of the previous layer

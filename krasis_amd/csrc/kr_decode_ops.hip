@@ -1130,6 +1130,12 @@ __global__ void __launch_bounds__(1024) kr_argmax_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+// (token, position) of a step are KERNEL ARGUMENTS of this one-thread launch: they are captured by value when the call is queued, so any
+// number of steps may be in flight without a shared host-side slot (a pinned slot + async copy let a later step overwrite an earlier one's
+// parameters before its DMA ran)
+__global__ void kr_set_step_kernel(KrStep* dst, int token, int pos) { dst->token = token; dst->pos = pos; }
+void kr_launch_set_step(KrStep* dst, int token, int pos, hipStream_t s) { hipLaunchKernelGGL(kr_set_step_kernel, dim3(1), dim3(1), 0, s, dst, token, pos); }
+
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s) {
     hipLaunchKernelGGL(kr_embed_kernel, dim3((H + 255) / 256), dim3(256), 0, s, emb, st, hidden, H);
 }

@@ -318,6 +318,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
         KR_HIP(hipStreamWaitEvent(st, s->pf_events[ev_end + i], 0));
     }
     KR_HIP(hipGetLastError());
+    s->last_stream = st;
     if (logits_out) {
         if (is_device_ptr(logits_out)) KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToDevice, st));
         else { KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }

@@ -146,7 +146,12 @@ int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int count) {
     return KR_OK;
 }
 
+// the prefill nibble sums (MatSet.wsum) are built lazily for ALL matrices of a set: any upload / fill that changes a matrix drops them so
+// the next prefill call rebuilds them (their bytes are counted once, when first built)
+static void drop_wsum(MatSet& ms) { if (ms.wsum.p) ms.wsum.release(); }
+
 int upload_mat(kr_engine* e, MatSet& ms, int idx, const void* w, const uint16_t* sc) {
+    drop_wsum(ms);
     std::vector<uint32_t> dq(ms.q_stride / 4), ds(ms.s_stride / 4);
     if (ms.bits == 4) retile_int4((const uint32_t*)w, sc, ms.K, ms.N, dq.data(), ds.data());
     else retile_int8((const int8_t*)w, sc, ms.K, ms.N, dq.data(), ds.data());
@@ -291,8 +296,7 @@ extern "C" int kr_upload_expert_bf16(kr_engine* e, int layer, int expert, int in
     kr_launch_quant_bf16(dd, H, inter, w2_bits, q2, s2, 0, e->stream);
     KR_HIP(hipStreamSynchronize(e->stream));   // the staging buffer is reused by the next call
     KR_HIP(hipGetLastError());
-    if (a.wsum.p) { a.wsum.release(); }          // nibble sums are rebuilt on the next prefill call
-    if (b.wsum.p) { b.wsum.release(); }
+    drop_wsum(a); drop_wsum(b);                 // nibble sums are rebuilt on the next prefill call
     if (shared) { L.shared_present = true; L.shared_inter = inter; }
     else { L.present[expert] = 1; L.inter = inter; }
     return KR_OK;
@@ -306,6 +310,7 @@ extern "C" int kr_fill_layer_synthetic(kr_engine* e, int layer, int bits, uint64
     const int H = e->cfg.hidden_size, I = e->cfg.moe_intermediate_size, E = e->cfg.n_routed_experts;
     if (int rc = matset_alloc(e, L.w13, H, 2 * I, bits, E)) return rc;
     if (int rc = matset_alloc(e, L.w2, I, H, bits, E)) return rc;
+    for (MatSet* ms : {&L.w13, &L.w2, &L.sw13, &L.sw2}) drop_wsum(*ms);
     kr_launch_fill_synth(L.w13.q.p, L.w13.q_stride * E, (uint32_t*)L.w13.s.p, L.w13.s_stride * E / 4, seed * 4 + 0, e->stream);
     kr_launch_fill_synth(L.w2.q.p, L.w2.q_stride * E, (uint32_t*)L.w2.s.p, L.w2.s_stride * E / 4, seed * 4 + 1, e->stream);
     std::fill(L.present.begin(), L.present.end(), 1); L.inter = I;
@@ -430,8 +435,23 @@ static int stage_in(kr_engine* e, DevBuf& buf, const void* p, size_t bytes, cons
     *dev = buf.p; return KR_OK;
 }
 
-extern "C" int kr_moe_forward(kr_engine* e, int layer, const void* act, const int32_t* ids, const float* wts,
-                              void* out, int batch, int topk, int out_dtype, int routed_only, void* stream) {
+// expert ids handed over in HOST memory are checked here the way the reference's indexing would fail (a panic on an out-of-range or
+// unloaded expert, moe.rs:2904-2932): ValueError instead of an out-of-bounds device read.  Device-resident ids are clamped to "skip"
+// by the kernels (kr_resolve_slot, the prefill sort).
+static int check_host_ids(kr_engine* e, const Layer& L, const int32_t* ids, size_t n) {
+    const int E = e->cfg.n_routed_experts;
+    for (size_t i = 0; i < n; i++) {
+        const int id = ids[i];
+        if (id < 0) continue;                                  // -1 = skip (moe.rs:2904)
+        if (id >= E) return kr_fail(KR_ERR_VALUE, "expert id %d out of range (%d experts)", id, E);
+        if (!L.present.empty() && !L.present[id]) return kr_fail(KR_ERR_STATE, "expert %d is not loaded", id);
+    }
+    return KR_OK;
+}
+
+// body of kr_moe_forward on a resolved stream; the caller holds e->mu
+static int moe_forward_locked(kr_engine* e, int layer, const void* act, const int32_t* ids, const float* wts,
+                              void* out, int batch, int topk, int out_dtype, int routed_only, hipStream_t st) {
     if (int rc = check_layer(e, layer)) return rc;
     if (!act || !ids || !wts || !out) return kr_fail(KR_ERR_VALUE, "null pointer argument");
     if (batch <= 0) return kr_fail(KR_ERR_VALUE, "batch_size must be > 0");
@@ -439,16 +459,14 @@ extern "C" int kr_moe_forward(kr_engine* e, int layer, const void* act, const in
     if (batch > 65535) return kr_fail(KR_ERR_VALUE, "batch %d too large for the decode path (use the prefill entry point)", batch);
     Layer& L = e->layers[layer];
     if (!L.w13.allocated() && !L.gguf) return kr_fail(KR_ERR_STATE, "Model not loaded -- call load() first (layer %d has no experts)", layer);
-    std::lock_guard<std::mutex> lk(e->mu);
     KR_HIP(hipSetDevice(e->device));
-    hipStream_t st = kr_pick_stream(e, stream);
-    if (stream && st != e->stream) { /* staging copies are issued on the caller's stream too */ }
+    if (!is_device_ptr(ids)) if (int rc = check_host_ids(e, L, ids, (size_t)batch * topk)) return rc;
     const int H = e->cfg.hidden_size;
     if (L.gguf) {
         // moe_forward_gguf (moe.rs:990): native GGUF blocks, per-32 INT16 activations
         const bool ush = L.gguf_shared && !routed_only;
         GgMoeArgs g{};
-        g.B = batch; g.topk = topk; g.n_slots = topk + (ush ? 1 : 0); g.H = H;
+        g.B = batch; g.topk = topk; g.n_slots = topk + (ush ? 1 : 0); g.H = H; g.E = e->cfg.n_routed_experts;
         g.gate = L.g_gate.view(); g.up = L.g_up.view(); g.down = L.g_down.view();
         if (ush) { g.sgate = L.gs_gate.view(); g.sup = L.gs_up.view(); g.sdown = L.gs_down.view(); }
         g.I_max = ush && L.shared_inter > L.inter ? L.shared_inter : L.inter; g.gu_ld = 2 * g.I_max;
@@ -467,7 +485,7 @@ extern "C" int kr_moe_forward(kr_engine* e, int layer, const void* act, const in
         if (!out_dev && e->st_out.ensure(out_bytes)) return kr_fail(KR_ERR_HIP, "hipMalloc of staging buffer failed");
         kr_launch_gguf_moe(g, st);
         KrMoeArgs c{};
-        c.B = batch; c.topk = topk; c.n_slots = g.n_slots; c.H = H; c.ids = g.ids; c.wts = (const float*)d_w; c.eo = g.eo;
+        c.B = batch; c.topk = topk; c.n_slots = g.n_slots; c.H = H; c.E = e->cfg.n_routed_experts; c.ids = g.ids; c.wts = (const float*)d_w; c.eo = g.eo;
         c.out = out_dev ? out : e->st_out.p; c.out_bf16 = out_dtype == KR_OUT_BF16; c.rsf = e->cfg.routed_scaling_factor;
         kr_launch_moe_combine(c, st);
         KR_HIP(hipGetLastError());
@@ -476,7 +494,7 @@ extern "C" int kr_moe_forward(kr_engine* e, int layer, const void* act, const in
     }
     const bool use_shared = L.shared_present && !routed_only;
     KrMoeArgs a{};
-    a.B = batch; a.topk = topk; a.n_slots = topk + (use_shared ? 1 : 0);
+    a.B = batch; a.topk = topk; a.n_slots = topk + (use_shared ? 1 : 0); a.E = e->cfg.n_routed_experts;
     a.H = H; a.I = L.inter; a.I_shared = L.shared_inter;
     a.w13 = L.w13.view(); a.w2 = L.w2.view();
     if (use_shared) { a.sw13 = L.sw13.view(); a.sw2 = L.sw2.view(); }
@@ -518,6 +536,13 @@ extern "C" int kr_moe_forward(kr_engine* e, int layer, const void* act, const in
         KR_HIP(hipStreamSynchronize(st));
     }
     return KR_OK;
+}
+
+extern "C" int kr_moe_forward(kr_engine* e, int layer, const void* act, const int32_t* ids, const float* wts,
+                              void* out, int batch, int topk, int out_dtype, int routed_only, void* stream) {
+    if (int rc = check_layer(e, layer)) return rc;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return moe_forward_locked(e, layer, act, ids, wts, out, batch, topk, out_dtype, routed_only, kr_pick_stream(e, stream));
 }
 
 extern "C" int kr_reduce_sum_bf16(kr_engine* e, const void* const* inputs, int n_inputs, void* out, size_t n, void* stream) {
@@ -680,23 +705,23 @@ extern "C" int kr_route_topk(kr_engine* e, int layer, const void* x, int m, int 
 extern "C" int kr_forward_moe_routed(kr_engine* e, int layer, const void* act_bf16, void* out_bf16, void* stream) {
     if (int rc = check_layer(e, layer)) return rc;
     Layer& L = e->layers[layer];
-    if (!L.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded");
+    if (!L.w13.allocated() && !L.gguf) return kr_fail(KR_ERR_STATE, "Model not loaded");
     if (!e->routing_set) return kr_fail(KR_ERR_STATE, "Routing config not set");
     if (!L.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", layer);
+    if (!act_bf16 || !out_bf16) return kr_fail(KR_ERR_VALUE, "null pointer argument");
+    // ONE resolved stream for the router and the experts (re-encoding a resolved legacy stream 0 as the ABI's NULL would move the experts
+    // onto the engine stream, unordered against the router), and the lock held across both: r_ids / r_w are engine scratch
     hipStream_t st = kr_pick_stream(e, stream);
+    std::lock_guard<std::mutex> lk(e->mu);
+    KR_HIP(hipSetDevice(e->device));
     const void* d_act = act_bf16;
-    {
-        std::lock_guard<std::mutex> lk(e->mu);
-        KR_HIP(hipSetDevice(e->device));
-        if (!is_device_ptr(act_bf16)) {
-            if (e->r_x.ensure((size_t)e->r_hidden * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
-            KR_HIP(hipMemcpyAsync(e->r_x.p, act_bf16, (size_t)e->r_hidden * 2, hipMemcpyHostToDevice, st));
-            d_act = e->r_x.p;
-        }
-        if (int rc = route_device(e, L, d_act, 1, KR_ROUTE_RULE_ENGINE, st)) return rc;
+    if (!is_device_ptr(act_bf16)) {
+        if (e->r_x.ensure((size_t)e->r_hidden * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+        KR_HIP(hipMemcpyAsync(e->r_x.p, act_bf16, (size_t)e->r_hidden * 2, hipMemcpyHostToDevice, st));
+        d_act = e->r_x.p;
     }
-    return kr_moe_forward(e, layer, d_act, (const int32_t*)e->r_ids.p, (const float*)e->r_w.p, out_bf16, 1, e->r_topk,
-                          KR_OUT_BF16, 0, st);
+    if (int rc = route_device(e, L, d_act, 1, KR_ROUTE_RULE_ENGINE, st)) return rc;
+    return moe_forward_locked(e, layer, d_act, (const int32_t*)e->r_ids.p, (const float*)e->r_w.p, out_bf16, 1, e->r_topk, KR_OUT_BF16, 0, st);
 }
 
 // ---- profiling hooks used by bench.py (HIP events on the launch stream, per kernel kind) ----
@@ -721,7 +746,7 @@ int kr_ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st) {
     if (ms.wsum.p || !ms.allocated()) return KR_OK;
     if (ms.bits != 4 && ms.bits != 8) return kr_fail(KR_ERR_VALUE, "prefill MFMA path needs INT4-g128 or INT8-g128 weights (got %d-bit)", ms.bits);
     if (ms.wsum.ensure(ms.s_stride * ms.count)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
-    e->weight_bytes += ms.s_stride * ms.count;
+    if (!ms.wsum_counted) { e->weight_bytes += ms.s_stride * ms.count; ms.wsum_counted = true; }
     kr_launch_pf_wsum(ms.view(), ms.count, (uint32_t*)ms.wsum.p, st);
     return KR_OK;
 }

@@ -35,6 +35,7 @@ struct DevBuf {
 struct MatSet {            // all experts of one layer for one projection, contiguous in HBM
     DevBuf q, s;
     DevBuf wsum;           // prefill: per (group, column) sum of (nibble-8), i16 pairs in the scale-pair layout (built on first use)
+    bool wsum_counted = false;   // its bytes are added to weight_bytes once, however often it is rebuilt
     int K = 0, N = 0, bits = 0, count = 0;
     size_t q_stride = 0, s_stride = 0;
     bool allocated() const { return q.p != nullptr; }

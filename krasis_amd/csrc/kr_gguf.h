@@ -10,7 +10,7 @@ struct GgMat {          // one projection [K -> N rows] of one (or all) expert(s
     const void* q; const void* h; int type, K, N; size_t q_stride, h_stride;
 };
 struct GgMoeArgs {
-    const uint16_t* act; const int32_t* ids; int B, topk, n_slots, H, I_max;
+    const uint16_t* act; const int32_t* ids; int B, topk, n_slots, H, I_max; int E;   // ids outside [0, E) are skipped
     GgMat gate, up, down;        // routed experts: expert e at q + e*q_stride
     GgMat sgate, sup, sdown;     // shared expert (n_slots > topk)
     float* gu; float* eo; int gu_ld;

@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(GG_BLOCK) kr_gguf_w13_kernel(const GgMoeArgs a
     const int slot = blockIdx.y, b = blockIdx.z;
     const bool shared = slot >= a.topk;
     const int e = shared ? 0 : a.ids[(size_t)b * a.topk + slot];
-    if (e < 0) return;
+    if (e < 0 || (!shared && e >= a.E)) return;
     const GgMat gate = shared ? a.sgate : gg_expert_mat(a.gate, e), up = shared ? a.sup : gg_expert_mat(a.up, e);
     const int I = gate.N, nt = (I + 7) / 8;
     const int t0 = blockIdx.x * tiles_per_wg;
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(GG_BLOCK) kr_gguf_w2_kernel(const GgMoeArgs a,
     const int slot = blockIdx.y, b = blockIdx.z;
     const bool shared = slot >= a.topk;
     const int e = shared ? 0 : a.ids[(size_t)b * a.topk + slot];
-    if (e < 0) return;
+    if (e < 0 || (!shared && e >= a.E)) return;
     const GgMat down = shared ? a.sdown : gg_expert_mat(a.down, e);
     const int I = down.K, nt = (down.N + 7) / 8;
     const int t0 = blockIdx.x * tiles_per_wg;

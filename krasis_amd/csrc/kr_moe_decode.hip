@@ -279,8 +279,8 @@ __device__ __forceinline__ KrSlot kr_resolve_slot(const KrMoeArgs& a, int b, int
         r.q13 = a.sw13.q; r.s13 = a.sw13.s; r.q2 = a.sw2.q; r.s2 = a.sw2.s;
     } else {
         const int e = a.ids[(size_t)b * a.topk + slot];
-        r.valid = e >= 0; r.inter = a.I;
-        const size_t ee = (size_t)(e < 0 ? 0 : e);
+        r.valid = e >= 0 && e < a.E; r.inter = a.I;
+        const size_t ee = (size_t)(r.valid ? e : 0);
         r.q13 = reinterpret_cast<const char*>(a.w13.q) + ee * a.w13.q_stride;
         r.s13 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.w13.s) + ee * a.w13.s_stride);
         r.q2 = reinterpret_cast<const char*>(a.w2.q) + ee * a.w2.q_stride;
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_combine_kernel(const KrMoeArg
     const float* eo = a.eo + (size_t)b * a.n_slots * a.H;
     float acc = 0.0f;
     for (int s = 0; s < a.topk; s++) {
-        if (a.ids[(size_t)b * a.topk + s] < 0) continue;
+        { const int id = a.ids[(size_t)b * a.topk + s]; if (id < 0 || id >= a.E) continue; }
         const float w = a.wts[(size_t)b * a.topk + s];
         acc += w * eo[(size_t)s * a.H + j];
     }

@@ -227,9 +227,10 @@ class KrasisEngine:
         b = None if correction_bias_f32 is None else np.frombuffer(correction_bias_f32, np.float32).copy()
         check(self._lib.kr_set_routing_weights(self._h, moe_layer_idx, _addr(g), 0, None, _addr(b) or None))
 
-    def forward_moe_routed(self, moe_layer_idx: int, activation_ptr: int, output_ptr: int) -> None:
+    def forward_moe_routed(self, moe_layer_idx: int, activation_ptr: int, output_ptr: int, stream: int = 0) -> None:
+        """moe.rs:3050 -- router + experts for one token; `stream` (extra): 0 = engine stream, 1 = legacy default stream, else a hipStream_t."""
         self._need("Model not loaded")
-        check(self._lib.kr_forward_moe_routed(self._h, moe_layer_idx, activation_ptr, output_ptr, None))
+        check(self._lib.kr_forward_moe_routed(self._h, moe_layer_idx, activation_ptr, output_ptr, stream or None))
 
     # decode-graph router (CpuDecodeStore.store_route_weight + moe_route, decode.rs:895,1086)
     def set_route_weight_f32(self, moe_layer_idx: int, gate_f32: np.ndarray, bias: Optional[np.ndarray] = None,

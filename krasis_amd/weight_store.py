@@ -54,7 +54,8 @@ class MoeConfig:
     @staticmethod
     def from_json(cfg_path: str, weight_map: Optional[Dict[str, str]] = None) -> "MoeConfig":
         raw = json.load(open(cfg_path))
-        cfg = raw.get("text_config", raw)                       # VL wrappers nest the language model config
+        # VL wrappers nest the language-model config: text_config (Kimi K2.5) or language_config (DeepSeek-VL2), weights/mod.rs:82-92
+        cfg = raw.get("text_config") or raw.get("language_config") or raw
         def need(*keys):
             for k in keys:
                 if cfg.get(k) is not None:
