@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- decode tok/s of Qwen3-Coder-Next (QCN) Q4 on MI355X, the reference's headline metric (BASELINE.json).
+"""bench.py -- decode tok/s of Qwen3-Coder-Next (QCN) Q4 on MI355X, the reference's headline metric (BASELINE.json, config 3).
 
 One "step" = one full decode token through the GPU decode graph (the reference's `decode_step`, src/decode.rs:2690):
-embedding -> 48 x [fused add+RMSNorm -> gated-delta-net linear attention (36 layers) | gated GQA with FP16 KV (12 layers)
+embedding -> 48 x [fused add+RMSNorm -> gated-delta-net linear attention (36 layers) | gated GQA with an FP8-E4M3 KV cache (12 layers)
 -> fused add+RMSNorm -> router (512 experts, softmax, top-10) -> 10 routed INT4-g128 experts + shared expert with sigmoid
 gate] -> final norm -> lm_head (151936 x 2048 INT4) -> greedy argmax.  Same protocol as the reference's synthetic benchmark
 (bench_decode_synthetic, decode.rs:4618): token 0, positions 10.., kv_max_seq 256, random weights / state with the reference's
-value distributions, generated on the GPU.  Everything is resident in HBM before the timed region.
+value distributions (router gate from the reference's xorshift64 stream), generated on the GPU.  Everything is resident in HBM before
+the timed region.
+
+Side measurements on the N = 1 line (never the headline `value`): the whole-model prompt pass at the reference benchmark's prompt
+lengths (--prefill-tokens, default 8192,20434,35139,49863: benchmark.py:434-505 / SURVEY 8d), the expert path alone, the same decode
+step late in a long cache, the other BASELINE configurations that fit one GPU (--side-configs: V2-Lite-shaped MLA model = config 2,
+QCN with INT8-g128 weights = config 5), and the CPU baseline (oracle port, incl. the V2-Lite Q4_K CPU expert pass = config 1).
+On N > 1 lines: the expert-parallel prompt-pass experts over RCCL (QCN and the Qwen3-235B expert shape = config 4).
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -20,21 +28,30 @@ sys.path.insert(0, ROOT)
 
 QCN = dict(hidden=2048, inter=512, experts=512, topk=10, layers=48, shared_inter=512, vocab=151936, nk=16, nv=32, dk=128, dv=128,
            nh=16, nkv=2, hd=256, full_attn_interval=4, kv_max_seq=256, eps=1e-6)
+# DeepSeek-V2-Lite (H 2048, I 1408, 64 experts top-6, 2 shared, 27 layers = 1 dense + 26 MoE, MLA 16 heads, kv_lora 512, nope 128, rope 64, v 128)
+V2L = dict(hidden=2048, inter=1408, experts=64, topk=6, layers=27, n_shared=2, vocab=102400, nh=16, klr=512, nd=128, rd=64, vhd=128, dense_inter=10944,
+           kv_max_seq=256, eps=1e-6)
+Q235 = dict(hidden=4096, inter=1536, experts=128, topk=8, layers=94)      # Qwen3-235B-A22B expert shape (config 4; 16 experts per GPU at EP-8)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable with a float4 copy)
+I8_PEAK_TOPS = 4400.0      # dense int8 MFMA peak the roofline is priced against (MI355X_MICROARCH.md: >= 3944 TOP/s reached by a 16x16x64 microbenchmark)
 B4 = 0.515625              # bytes per INT4-g128 weight incl. bf16 group scale
+B8 = 1.015625              # INT8-g128
 KINDS = ["embed", "fused_add_rmsnorm", "proj_matvec", "la_conv", "la_recurrent", "gated_rmsnorm_silu", "gqa", "route_logits",
          "route_select", "moe_w13", "moe_w2", "moe_combine", "lm_head", "argmax", "shared_gate"]
 SYMBOL = {"proj_matvec": "kr_matvec_coop_kernel<float,4>", "lm_head": "kr_matvec_kernel<float,4>", "shared_gate": "kr_matvec_kernel<float,4>",
           "moe_w13": "kr_moe_w13_kernel<4>", "moe_w2": "kr_moe_w2_kernel<4,0>", "la_recurrent": "kr_la_step_kernel<128,128>",
           "route_logits": "kr_route_fused_decode_kernel<true,8>", "route_select": "kr_route_select_kernel",
           "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
+WORKLOAD = {"qcn-q4": "Qwen3-Coder-Next Q4 int4gpu on 1×MI355X (512-expert top-10, hybrid linear+GQA, FP8 KV)",
+            "qcn-q8": "Qwen3-Coder-Next Q8 int8gpu on 1×MI355X (int8 MFMA path, Q8_0 dequant)",
+            "v2lite-q4": "DeepSeek-V2-Lite Q4 int4gpu on 1×MI355X (MLA + 64-expert top-6)"}
 
 
 def pmc_traffic(symbol):
     """HBM bytes per launch of `symbol` from the committed rocprofv3 --pmc FETCH_SIZE pass (separate run, profiles/*pmc*.json; corrected as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes).  None when no PMC summary is committed for that kernel."""
     import glob
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc*.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
         try:
             d = json.load(open(f))
             if symbol in d.get("kernels", {}):
@@ -49,17 +66,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--layers", type=int, default=QCN["layers"])
+    ap.add_argument("--config", default="qcn-q4", choices=sorted(WORKLOAD), help="which BASELINE configuration the headline line measures")
+    ap.add_argument("--kv", default="fp8", choices=["fp8", "fp16"], help="KV cache element type of the headline run (BASELINE config 3 names FP8 KV)")
+    ap.add_argument("--layers", type=int, default=0, help="0 = the model's layer count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=5.0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--prefill-chunk", type=int, default=0, help="tokens per chunk of the prompt pass (0 = library default)")
     ap.add_argument("--prefill-depth", type=int, default=0, help="chunks of the prompt pass in flight (0 = library default)")
-    ap.add_argument("--prefill-reps", type=int, default=2, help="timed repetitions of the whole-model prompt pass")
+    ap.add_argument("--prefill-reps", type=int, default=1, help="timed repetitions of the whole-model prompt pass per prompt length")
     ap.add_argument("--no-long-context", action="store_true", help="skip the long-cache decode side measurement of the N = 1 line")
     ap.add_argument("--no-ep", action="store_true", help="skip the expert-parallel prompt-pass leg of the N > 1 lines")
-    ap.add_argument("--ep-selftest", action="store_true", help="run the expert-parallel leg at N = 1 too (no collectives: checks the row path)")
-    ap.add_argument("--prefill-tokens", type=int, default=8192, help="tokens per prefill chunk for the experts-only prefill side measurement (0 = skip)")
+    ap.add_argument("--ep-selftest", action="store_true", help="run the expert-parallel leg at N = 1 too (no peer traffic: checks the row path)")
+    ap.add_argument("--prefill-tokens", default="8192,20434,35139,49863",
+                    help="prompt lengths of the prompt-pass side measurement (benchmark.py:434-505: 20 434 / 35 139 / 49 863 tokens; 0 = skip)")
+    ap.add_argument("--side-configs", default="v2lite-q4,qcn-q8", help="other single-GPU BASELINE configurations measured as side legs of the N = 1 line ('' = none)")
     return ap.parse_args()
 
 
@@ -67,33 +88,45 @@ def is_gqa(l):
     return (l + 1) % QCN["full_attn_interval"] == 0
 
 
-def algorithmic_bytes(L):
-    """Bytes a decode token must touch, each weight/state byte once, per kernel kind."""
+def algorithmic_bytes(L, bw=B4):
+    """Bytes a QCN decode token must touch, each weight/state byte once, per kernel kind."""
     q = QCN; H, I, E, k = q["hidden"], q["inter"], q["experts"], q["topk"]
     n_la = sum(1 for l in range(L) if not is_gqa(l)); n_gqa = L - n_la
     group_dim = 2 * q["dk"] + 2 * q["dv"] * (q["nv"] // q["nk"])
     la_w = (q["nk"] * group_dim + q["nk"] * 2 * (q["nv"] // q["nk"])) * H + H * (q["nv"] * q["dv"])
     gqa_w = (q["nh"] * q["hd"] * 2 + 2 * q["nkv"] * q["hd"]) * H + H * (q["nh"] * q["hd"])
     b = {
-        "proj_matvec": (n_la * la_w + n_gqa * gqa_w) * B4,
-        "moe_w13": L * (k + 1) * H * 2 * I * B4,          # 10 routed + shared expert
-        "moe_w2": L * (k + 1) * I * H * B4,
-        "lm_head": q["vocab"] * H * B4,
+        "proj_matvec": (n_la * la_w + n_gqa * gqa_w) * bw,
+        "moe_w13": L * (k + 1) * H * 2 * I * bw,          # 10 routed + shared expert
+        "moe_w2": L * (k + 1) * I * H * bw,
+        "lm_head": q["vocab"] * H * bw,
         "route_logits": L * E * H * 2,                      # gate stored as bf16 in HBM
         "la_recurrent": n_la * 2 * q["nv"] * q["dk"] * q["dv"] * 4,   # state read + write
-        "shared_gate": L * H * B4,
+        "shared_gate": L * H * bw,
     }
     b["total"] = sum(b.values())
     return b
 
 
-def build_qcn(rank, local_rank, L, rope_len=0):
+def algorithmic_bytes_v2lite(L, bw=B4):
+    """routed + shared experts of the 26 MoE layers, MLA projections, absorbed w_kc / w_vc (f32 in HBM like the
+    reference's decode store, decode.rs:2157-2160), the dense layer-0 MLP, lm_head, router gate (bf16)."""
+    v = V2L; H, I = v["hidden"], v["inter"]
+    n_moe = max(L - 1, 0)
+    mla_w = ((v["klr"] + v["rd"]) + v["nh"] * (v["nd"] + v["rd"])) * H + H * v["nh"] * v["vhd"]
+    b = {"moe_w13": n_moe * (v["topk"] + v["n_shared"]) * H * 2 * I * bw, "moe_w2": n_moe * (v["topk"] + v["n_shared"]) * I * H * bw,
+         "proj_matvec": L * mla_w * bw + 3 * H * v["dense_inter"] * bw, "gqa": L * 2 * v["nh"] * v["nd"] * v["klr"] * 4,
+         "lm_head": v["vocab"] * H * bw, "route_logits": n_moe * v["experts"] * H * 2}
+    b["total"] = sum(b.values())
+    return b
+
+
+def build_qcn(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
     import numpy as np
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     q = QCN; H, I, E, k, V = q["hidden"], q["inter"], q["experts"], q["topk"], q["vocab"]
     eng = KrasisEngine(device=local_rank)
     eng.configure(ModelConfig(H, I, E, k, L, 0, 1.0))
-    bits = int(os.environ.get("KR_BENCH_BITS", "4"))            # probe hook: 8 = INT8-g128 weights everywhere (not the headline configuration)
     eng.fill_synthetic(bits, seed=0x12345678ABCDEF01 + rank)
     eng.set_routing_config("softmax", True, k, E, H)
     st = CpuDecodeStore(128, True, True)                       # norm_bias_one: qwen3_next (decode.rs:4701)
@@ -128,10 +161,9 @@ def build_qcn(rank, local_rank, L, rope_len=0):
             nw = (rng.random(nv * dv, dtype=np.float32) + 0.5).astype(np.float32); keep += [cw, a_log, dtb, nw]
             st.add_decode_la_layer(n_in, n_post, qkvz, ba, out, cw.ctypes.data, a_log.ctypes.data, dtb.ctypes.data, nw.ctypes.data,
                                    nk, nv, dk, dv, 4, 1.0 / dk ** 0.5)
-        # router gate +-0.02 (decode.rs:5181), rounded to bf16 like a real checkpoint -> stored as bf16 in HBM
-        gate = ((rng.random((E, H), dtype=np.float32) - 0.5) * 0.04).astype(np.float32)
-        gate = (gate.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
-        eng.set_route_weight_f32(l, gate)
+        # router gate: the reference's xorshift64 stream, uniform +-0.02 (decode.rs:5181, :4356-4376), truncated to bf16 like a real
+        # checkpoint's gate tensor -> stored as bf16 in HBM
+        eng.set_route_weight_synthetic(l, 0x12345678ABCDEF01 + rank, 0.02, True)
         sgu, sd, sg = W(2 * q["shared_inter"], H), W(H, q["shared_inter"]), W(1, H)
         st.set_decode_layer_moe(l, l, l, sgu, sd, sg)
     half = hd // 2                                                    # decode.rs:5379: full rotary in the synthetic bench
@@ -141,16 +173,59 @@ def build_qcn(rank, local_rank, L, rope_len=0):
     cos, sin = np.cos(pos * freq).astype(np.float32), np.sin(pos * freq).astype(np.float32); keep += [cos, sin]
     st.set_decode_rope(cos.ctypes.data, sin.ctypes.data, half, rope_len)
     st.finalize_decode()
+    st.set_kv_dtype(kv_fp8)
     st.fill_state_synthetic(q["kv_max_seq"], seed=4242 + rank)
     return eng, st, keep
 
 
-def prefill_experts(eng, L, M, torch):
+def build_v2lite(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
+    """DeepSeek-V2-Lite-shaped decode graph (BASELINE config 2): MLA attention (direct q projection), layer 0 dense, 64 experts top-6 + 2 shared."""
+    import numpy as np
+    from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
+    v = V2L; H, I, E, k, V = v["hidden"], v["inter"], v["experts"], v["topk"], v["vocab"]
+    nh, klr, nd, rd, vhd = v["nh"], v["klr"], v["nd"], v["rd"], v["vhd"]
+    eng = KrasisEngine(device=local_rank); eng.configure(ModelConfig(H, I, E, k, L, v["n_shared"], 1.0))
+    eng.fill_synthetic(bits, seed=11 + rank); eng.set_routing_config("softmax", False, k, E, H)
+    st = CpuDecodeStore(128, True, False); st.set_moe_store(eng)
+    rng = np.random.default_rng(3 + rank); keep = []; seed = [50 + rank * 100000]
+
+    def W(r, c):
+        seed[0] += 1; return st.store_weight_synthetic(r, c, bits, seed[0])
+
+    def N(n):
+        w = (rng.random(n, dtype=np.float32) * 0.2 + 0.9).astype(np.float32); keep.append(w); return st.store_norm_weight(w.ctypes.data, n)
+
+    fin, lm = N(H), W(V, H)
+    st.configure_decode(H, L, v["eps"], fin, lm, V, k, 1, False, 1.0, 0, synth_seed=5 + rank)
+    half = rd // 2; rope_len = max(rope_len, v["kv_max_seq"])
+    ang = np.arange(rope_len)[:, None] * (1.0 / 10000.0 ** (2 * np.arange(half) / rd))[None, :]
+    cos, sin = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32); keep += [cos, sin]
+    DI = (v["dense_inter"] + 127) // 128 * 128                   # non-MoE weights pad cols to a multiple of 128 (decode_setup.py:586-597)
+    for l in range(L):
+        n_in, n_post = N(H), N(H)
+        kv_a, o, q = W(klr + rd, H), W(H, nh * vhd), W(nh * (nd + rd), H)
+        w_kc = ((rng.standard_normal((nh, nd, klr)) * 0.06).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        w_vc = ((rng.standard_normal((nh, vhd, klr)) * 0.06).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        kvn = (rng.random(klr) + 0.5).astype(np.float32); keep += [w_kc, w_vc, kvn]
+        st.add_decode_mla_layer(n_in, n_post, kv_a, o, q, None, None, w_kc.ctypes.data, w_kc.size, w_vc.ctypes.data, w_vc.size, kvn.ctypes.data, klr, 0, 0,
+                                cos.ctypes.data, sin.ctypes.data, half, rope_len, nh, klr, nd, rd, vhd, float(1.0 / np.sqrt(nd + rd)))
+        if l == 0:
+            st.set_decode_layer_dense(l, W(DI, H), W(DI, H), W(H, DI))
+        else:
+            eng.set_route_weight_synthetic(l, 0x12345678ABCDEF01 + rank, 0.02, True)
+            st.set_decode_layer_moe(l, l, l, W(2 * v["n_shared"] * I, H), W(H, v["n_shared"] * I), None)
+    st.finalize_decode()
+    st.set_kv_dtype(kv_fp8)
+    st.fill_state_synthetic(v["kv_max_seq"], seed=9 + rank)
+    return eng, st, keep
+
+
+def prefill_experts(eng, dims, L, M, torch):
     """Side measurement (NOT the headline value): the prefill expert path alone -- token sort + int8-MFMA grouped GEMM + combine of all
-    L MoE layers for one chunk of M tokens with uniform random routing (k distinct experts per token).  Attention / linear-attention
-    prefill kernels are not built yet, so this is an upper bound on prefill tok/s, reported with its MFMA roofline fraction."""
+    L MoE layers for one chunk of M tokens with uniform random routing (k distinct experts per token).  Roofline per SURVEY 8(d):
+    achieved = 2 * T * k * 3 * H * I / t (useful MACs x 2); `int8_TOPS_issued` counts both INT16-digit passes the exact arithmetic issues."""
     from krasis_amd import GpuPrefillManager
-    q = QCN; H, I, E, k = q["hidden"], q["inter"], q["experts"], q["topk"]
+    H, I, E, k = dims["hidden"], dims["inter"], dims["experts"], dims["topk"]
     g = torch.Generator(device="cuda").manual_seed(7)
     x = ((torch.rand((M, H), device="cuda", generator=g) - 0.5)).to(torch.bfloat16)
     ids = torch.rand((M, E), device="cuda", generator=g).topk(k, dim=1).indices.to(torch.int32)
@@ -166,37 +241,38 @@ def prefill_experts(eng, L, M, torch):
     ev1.record(); torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1)
     macs = M * k * 3 * H * I * L                       # routed experts only
-    tops = 2.0 * macs * 2 / (ms * 1e-3) / 1e12         # x2: two int8 MFMA passes (high / low activation digit) per MAC
-    return {"tokens": M, "layers": L, "ms": ms, "tok_s_experts_only": M / (ms * 1e-3), "int8_TOPS_issued": tops,
-            "mfma_i8_dense_peak_TOPS": 4400.0, "frac_of_i8_peak": tops / 4400.0,
-            "effective_TFLOPs_2MAC": 2.0 * macs / (ms * 1e-3) / 1e12,
-            "note": "experts only (sort + 2 grouped GEMMs + act + combine): the MFMA-bound part of the prompt pass in isolation"}
+    useful = 2.0 * macs / (ms * 1e-3) / 1e12
+    return {"tokens": M, "layers": L, "ms": ms, "tok_s_experts_only": M / (ms * 1e-3),
+            "roofline": {"bound": "mfma", "achieved": useful, "peak": I8_PEAK_TOPS, "unit": "TOP/s (int8; 2 x useful MACs / s, SURVEY 8d)", "frac": useful / I8_PEAK_TOPS,
+                         "peak_measured_ubench": 3944.0},
+            "int8_TOPS_issued": 2.0 * useful, "frac_of_i8_peak_issued": 2.0 * useful / I8_PEAK_TOPS,
+            "note": "experts only (sort + 2 grouped GEMMs + act + combine): the MFMA-bound part of the prompt pass in isolation; every MAC is issued "
+                    "twice (high / low INT16 activation digit) to reproduce the reference's integer arithmetic exactly"}
 
 
-def prefill_ep(eng, L, M, world, rank, torch, dist):
-    """Expert-parallel prompt-pass experts over RCCL (krasis_amd/ep.py, mode "alltoall"): every rank owns E/N experts and M
-    tokens; each (token, slot) row travels once to the rank that owns its expert (all_to_all over the xGMI mesh), runs through the int8-MFMA
-    expert GEMMs there, the f32 expert row comes back and the source rank combines its k rows in routing order -- bit-identical to one GPU
-    (tests/test_ep_cpu.py world 2 on gloo, tests/test_ep_gpu.py).  All L MoE layers, uniform random routing, weak scaling (M tokens per rank).
-    The bench engines are replicas, so a rank's slice is experts [0, E/N) of its resident synthetic set: same bytes, same arithmetic."""
-    from krasis_amd.ep import ExpertParallelMoE, engine_row_ops
-    q = QCN; H, I, E, k = q["hidden"], q["inter"], q["experts"], q["topk"]
+def prefill_ep(eng, dims, L, M, world, rank, torch, dist, experts_local=None):
+    """Expert-parallel prompt-pass experts over RCCL inside libkrasis_hip.so (kr_ep_init / kr_moe_prefill_ep): every rank owns
+    E/N experts and M tokens; each (token, slot) row travels once to the rank that owns its expert (ncclSend/ncclRecv groups over the xGMI
+    mesh), runs through the int8-MFMA expert GEMMs there, the bf16-of-f32... row comes back and the source rank combines its k rows in
+    routing order.  All L MoE layers, uniform random routing, weak scaling (M tokens per rank)."""
+    from krasis_amd.ep import ExpertParallel
+    H, I, E, k = dims["hidden"], dims["inter"], dims["experts"], dims["topk"]
     g = torch.Generator(device="cuda").manual_seed(7 + rank)
     x = ((torch.rand((M, H), device="cuda", generator=g) - 0.5)).to(torch.bfloat16)
     ids = torch.rand((M, E), device="cuda", generator=g).topk(k, dim=1).indices.to(torch.int32)
     w = torch.softmax(torch.randn((M, k), device="cuda", generator=g), dim=1)
-    ops, combine = engine_row_ops(eng)
-    ep = ExpertParallelMoE(ops, E, mode="alltoall")
+    ep = ExpertParallel(eng, E, world, rank, dist if world > 1 else None)
+    out = torch.empty((M, H), dtype=torch.bfloat16, device="cuda")
     for l in range(min(L, 2)):
-        ep.forward(l, x, ids, w, combine)
-    torch.cuda.synchronize()
+        ep.forward(l, x, ids, w, out)
+    ep.synchronize(); torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for l in range(L):
-        ep.forward(l, x, ids, w, combine)
-    torch.cuda.synchronize()
+        ep.forward(l, x, ids, w, out)
+    ep.synchronize(); torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -204,40 +280,121 @@ def prefill_ep(eng, L, M, world, rank, torch, dist):
         t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     macs = world * M * k * 3 * H * I * L
     off = (world - 1) / world                          # share of the rows that leave the GPU under uniform routing
+    useful = 2.0 * macs / dt / 1e12
     return {"tokens_per_gpu": M, "tokens_total": world * M, "layers": L, "ms": dt * 1e3, "tok_s_experts_only": world * M / dt, "scaling": "weak",
-            "experts_per_gpu": E // world, "effective_TFLOPs_2MAC": 2.0 * macs / dt / 1e12,
-            "exchange_GB_per_gpu_per_layer": {"dispatch_bf16": M * k * H * 2 * off / 1e9, "combine_f32": M * k * H * 4 * off / 1e9},
-            "note": "sort by owner + all_to_all dispatch + expert GEMMs + all_to_all combine, per layer, no overlap between layers; "
-                    "compare with prefill_experts_only of the N = 1 line"}
+            "experts_per_gpu": E // world, "roofline": {"bound": "mfma", "achieved": useful, "peak": I8_PEAK_TOPS * world, "unit": "TOP/s (int8, useful)", "frac": useful / (I8_PEAK_TOPS * world)},
+            "exchange_GB_per_gpu_per_layer": {"dispatch_bf16": M * k * H * 2 * off / 1e9, "combine_bf16": M * k * H * 2 * off / 1e9},
+            "note": "owner sort (kr_pf_count/scan/scatter) + RCCL send/recv dispatch + expert GEMMs + RCCL send/recv return + f32 combine, per layer; "
+                    "the next layer's dispatch overlaps the current layer's GEMMs; compare with prefill_experts_only of the N = 1 line"}
 
 
-def prefill_model(st, L, P, reps, torch):
-    """Whole-model prompt pass (kr_decode_prefill): P synthetic tokens through all L layers (projection + expert GEMMs on int8 MFMA, exact
-    gated-delta-rule recurrence, exact causal GQA attention, router, norms), bit-identical to token-by-token decode.  tok/s = P / time."""
+def prefill_model(st, dims, gemm_macs_per_token, L, P, reps, torch):
+    """Whole-model prompt pass (kr_decode_prefill): P synthetic tokens through all L layers.  tok/s = P / time.  Roofline per SURVEY 8(d):
+    useful GEMM MACs x 2 / t against the int8 MFMA peak."""
     import numpy as np
-    q = QCN
-    st.fill_state_synthetic(P + 64, 7)                      # FP16 KV caches / states sized for the prompt
-    toks = [int(x) for x in np.random.default_rng(5).integers(0, q["vocab"], P)]
-    st.prefill(toks, 0)                                     # warm-up: scratch arena, per-weight nibble sums
+    st.fill_state_synthetic(P + 64, 7)                      # KV caches / states sized for the prompt
+    toks = [int(x) for x in np.random.default_rng(5).integers(0, dims["vocab"], P)]
+    st.prefill(toks[: min(P, 2048)], 0)                     # warm-up: scratch arena, per-weight nibble sums
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         st.prefill(toks, 0)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    H, I, k = q["hidden"], q["inter"], q["topk"]
+    useful = 2.0 * P * gemm_macs_per_token / dt / 1e12
+    return {"value": P / dt, "unit": "tok/s", "tokens": P, "ms": dt * 1e3, "reps": reps, "layers": L, "target_tok_s": 3300,
+            "roofline": {"bound": "mfma", "achieved": useful, "peak": I8_PEAK_TOPS, "unit": "TOP/s (int8; 2 x useful GEMM MACs / s, SURVEY 8d)",
+                         "frac": useful / I8_PEAK_TOPS, "int8_TOPS_issued": 2.0 * useful}}
+
+
+def qcn_gemm_macs_per_token(L):
+    q = QCN; H, I, k = q["hidden"], q["inter"], q["topk"]
     n_la = sum(1 for l in range(L) if not is_gqa(l)); n_gqa = L - n_la
     hr = q["nv"] // q["nk"]; gd = 2 * q["dk"] + 2 * q["dv"] * hr
     w_la = q["nk"] * gd * H + q["nk"] * 2 * hr * H + H * q["nv"] * q["dv"]
     w_gqa = (q["nh"] * q["hd"] * 2 + 2 * q["nkv"] * q["hd"]) * H + H * q["nh"] * q["hd"]
     w_moe = (k + 1) * 3 * H * I + H                          # routed + shared expert (+ its gate row)
-    macs = P * (n_la * w_la + n_gqa * w_gqa + L * w_moe)     # GEMM MACs (lm_head runs for the last token only)
-    tops = 2.0 * macs * 2 / dt / 1e12                        # two int8 MFMA passes (high / low activation digit) per MAC
-    return {"value": P / dt, "unit": "tok/s", "tokens": P, "ms": dt * 1e3, "reps": reps, "layers": L, "target_tok_s": 3300,
-            "roofline": {"bound": "mfma", "achieved": tops, "peak": 4400.0, "unit": "TOP/s (int8, 2 digit passes per MAC)", "frac": tops / 4400.0,
-                         "effective_TFLOPs_2MAC": 2.0 * macs / dt / 1e12},
-            "note": "bit-identical to decoding the prompt token by token (tests/test_prefill_model_gpu.py); attention and the gated delta rule are "
-                    "evaluated in the decode order on the vector ALUs, GEMM-shaped work on the matrix cores"}
+    return n_la * w_la + n_gqa * w_gqa + L * w_moe           # GEMM MACs per prompt token (lm_head runs for the last token only)
+
+
+def v2l_gemm_macs_per_token(L):
+    v = V2L; H, I = v["hidden"], v["inter"]
+    mla = ((v["klr"] + v["rd"]) + v["nh"] * (v["nd"] + v["rd"])) * H + H * v["nh"] * v["vhd"]
+    return L * mla + 3 * H * v["dense_inter"] + max(L - 1, 0) * (v["topk"] + v["n_shared"]) * 3 * H * I
+
+
+def time_decode(st, steps, warmup, kvm, torch, dist, world):
+    def step(i):
+        st.decode_step(0, (10 + i) % (kvm - 1))
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    return dt
+
+
+def profile_kinds(st, kvm, P=5):
+    from krasis_amd import _lib
+    ms = (C.c_double * 16)(); cnt = (C.c_long * 16)()
+    tot_ms = [0.0] * 16; tot_n = [0] * 16
+    for i in range(P):
+        _lib.check(st._lib.kr_decode_profile_step(st._h, 0, (10 + i) % (kvm - 1), ms, cnt, 16))
+        for j in range(15):
+            tot_ms[j] += ms[j]; tot_n[j] += cnt[j]
+    per_kind_us = {KINDS[j]: (tot_ms[j] / P) * 1e3 for j in range(15)}            # us per step
+    per_launch_us = {KINDS[j]: (tot_ms[j] / max(tot_n[j], 1)) * 1e3 for j in range(15)}
+    n_per_step = {KINDS[j]: tot_n[j] / P for j in range(15)}
+    return per_kind_us, per_launch_us, n_per_step
+
+
+def long_context(st, kv_long, torch, kv_name):
+    st.fill_state_synthetic(kv_long, 7)
+    for i in range(3):
+        st.decode_step(0, kv_long - 6 + i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(20):
+        st.decode_step(0, kv_long - 2)
+    torch.cuda.synchronize()
+    d1 = (time.perf_counter() - t1) / 20
+    return {"kv_max_seq": kv_long, "position": kv_long - 2, "kv": kv_name, "ms_per_step": d1 * 1e3, "tok_s": 1.0 / d1}
+
+
+def side_config(name, rank, local_rank, args, torch):
+    """Another single-GPU BASELINE configuration as a side leg: decode tok/s (same protocol, fewer steps) + prompt pass at 8192 tokens."""
+    qcn = name.startswith("qcn")
+    bits = 8 if name.endswith("q8") else 4
+    dims = QCN if qcn else V2L
+    L = dims["layers"]
+    build = build_qcn if qcn else build_v2lite
+    eng, st, keep = build(rank, local_rank, L, 8192 + 64, bits, kv_fp8=True)
+    st.set_use_graph(not args.no_graph)
+    steps = min(args.steps, 50)
+    dt = time_decode(st, steps, args.warmup, dims["kv_max_seq"], torch, None, 1)
+    bw = B8 if bits == 8 else B4
+    ab = algorithmic_bytes(L, bw) if qcn else algorithmic_bytes_v2lite(L, bw)
+    res = {"workload": WORKLOAD[name], "decode_tok_s": steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "kv": "FP8-E4M3", "weights": "INT%d-g128" % bits,
+           "step_algorithmic_bytes": ab["total"], "step_frac_of_hbm_peak": ab["total"] * (steps / dt) / 1e9 / HBM_PEAK_GBS}
+    try:
+        macs = qcn_gemm_macs_per_token(L) if qcn else v2l_gemm_macs_per_token(L)
+        res["prefill"] = prefill_model(st, dims, macs, L, 8192, 1, torch)
+        res["prefill_experts_only"] = prefill_experts(eng, dims, L if qcn else L, 8192, torch)
+    except Exception as ex:
+        res["prefill"] = {"error": repr(ex)}
+    del st, eng, keep
+    gc.collect(); torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline(max_seconds, L):
@@ -300,10 +457,55 @@ def cpu_baseline(max_seconds, L):
             best_c, best_t = c, tt
     O.set_num_threads(best_c)
     t_tok = timed(token, max_seconds * 0.6)
-    return dict(value=1.0 / t_tok, unit="tok/s", cores=best_c, host_threads=hw, kind="port", tok_s_by_threads=sweep,
-                sample="whole-token passes over one token's weight set (%d MoE layers x (10 routed + shared INT4 experts) + LA/GQA projections + lm_head, "
-                       "~1.9 GB streamed from DRAM), AVX2+OpenMP port of avx2.rs:1066 on tiled weights; norms/attention/state omitted "
-                       "(optimistic for the CPU)" % L, ms_per_token=t_tok * 1e3)
+    res = dict(value=1.0 / t_tok, unit="tok/s", cores=best_c, host_threads=hw, kind="port", tok_s_by_threads=sweep,
+               sample="whole-token passes over one token's weight set (%d MoE layers x (10 routed + shared INT4 experts) + LA/GQA projections + lm_head, "
+                      "~1.9 GB streamed from DRAM), AVX2+OpenMP port of avx2.rs:1066 on tiled weights; norms/attention/state omitted "
+                      "(optimistic for the CPU)" % L, ms_per_token=t_tok * 1e3)
+    try:
+        res["v2lite_q4k_cpu"] = cpu_v2lite_q4k(min(2.0, max_seconds * 0.4), best_c)
+    except Exception as ex:
+        res["v2lite_q4k_cpu"] = {"error": repr(ex)}
+    return res
+
+
+def cpu_v2lite_q4k(budget, threads):
+    """BASELINE config 1 (DeepSeek-V2-Lite Q4_K int4cpu pure-CPU decode): the MoE part of one token through the oracle's restatement of
+    moe_forward_gguf (moe.rs:990 -> gguf_kernels.rs:690: Q4_K gate/up, Q8_0 down since 1408 is not a multiple of 256), 26 layers x (6 routed
+    + 2 shared-width experts).  Experts only, scalar single-thread port (cores = 1); synthetic blocks per SURVEY 8d
+    (d = f16((0.005 + u * 0.045) / 63), dmin = f16(8 d), raw scale / quant bytes; Q8_0: d = f16((0.005 + u * 0.045) / 127))."""
+    import numpy as np
+    from oracle import oracle as O
+    v = V2L; H, I, k = v["hidden"], v["inter"], v["topk"]
+    rng = np.random.default_rng(0x1234)
+
+    def blocks(t, rows, K):
+        be, bb = (256, 144) if t == O.Q4_K else (32, 34)
+        nb = K // be
+        raw = rng.integers(0, 256, size=(rows, nb, bb), dtype=np.uint8)
+        u = rng.random((rows, nb)).astype(np.float32)
+        d = ((0.005 + u * 0.045) / (63.0 if t == O.Q4_K else 127.0)).astype(np.float16)
+        dv = d.view(np.uint16)
+        raw[:, :, 0] = dv & 0xFF; raw[:, :, 1] = dv >> 8
+        if t == O.Q4_K:
+            dm = (d.astype(np.float32) * 8.0).astype(np.float16).view(np.uint16)
+            raw[:, :, 2] = dm & 0xFF; raw[:, :, 3] = dm >> 8
+        return np.ascontiguousarray(raw.reshape(rows, nb * bb))
+
+    n_layers = 26
+    experts = [O.GgufExpert(blocks(O.Q4_K, I, H), blocks(O.Q4_K, I, H), blocks(O.Q8_0, H, I), O.Q4_K, O.Q8_0, H, I) for _ in range((k + 2) * 2)]
+    act = O.f32_to_bf16(((rng.random(H) - 0.5)).astype(np.float32)); w = np.full(k + 2, 1.0 / (k + 2), np.float32)
+
+    def token():
+        for l in range(n_layers):          # two layers' worth of distinct experts, alternated
+            O.moe_forward_gguf(experts[(l % 2) * (k + 2): (l % 2 + 1) * (k + 2)], w, act)
+
+    token(); n, t0 = 0, time.perf_counter()
+    while n == 0 or time.perf_counter() - t0 < budget:
+        token(); n += 1
+    t = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / t, "unit": "tok/s (MoE experts of one token only)", "ms_per_token": t * 1e3, "cores": 1, "kind": "port",
+            "workload": "DeepSeek-V2-Lite Q4_K int4cpu pure-CPU decode (testconfigs/v2lite-4-4.conf, no GPU)",
+            "sample": "26 MoE layers x 8 native-GGUF experts (Q4_K gate/up, Q8_0 down) through kro_moe_forward_gguf (scalar restatement of gguf_kernels.rs:690)"}
 
 
 def main():
@@ -319,98 +521,119 @@ def main():
         import datetime
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=5))
 
-    from krasis_amd import _lib
-    L = args.layers
-    eng, st, keep = build_qcn(rank, local_rank, L, max(args.prefill_tokens + 64, 8192))      # rope table: prompt pass and the long-cache side measurement
+    name = args.config
+    qcn = name.startswith("qcn")
+    dims = QCN if qcn else V2L
+    bits = 8 if name.endswith("q8") else 4
+    bw = B8 if bits == 8 else B4
+    L = args.layers or dims["layers"]
+    pf_list = [int(x) for x in str(args.prefill_tokens).split(",") if x.strip() and int(x) > 0]
+    rope_len = max([8192] + pf_list) + 64
+    kv_fp8 = args.kv == "fp8"
+    build = build_qcn if qcn else build_v2lite
+    eng, st, keep = build(rank, local_rank, L, rope_len, bits, kv_fp8)      # rope table: prompt pass and the long-cache side measurement
     st.set_use_graph(not args.no_graph)
-    kvm = QCN["kv_max_seq"]
-
-    def step(i):
-        st.decode_step(0, (10 + i) % (kvm - 1))
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    kvm = dims["kv_max_seq"]
+    dt = time_decode(st, args.steps, args.warmup, kvm, torch, dist, world)
 
     # per-kernel durations: un-graphed steps with HIP events around every launch on the launch stream
-    ms = (C.c_double * 16)(); cnt = (C.c_long * 16)()
-    tot_ms = [0.0] * 16; tot_n = [0] * 16; P = 5
-    for i in range(P):
-        _lib.check(st._lib.kr_decode_profile_step(st._h, 0, (10 + i) % (kvm - 1), ms, cnt, 16))
-        for j in range(15):
-            tot_ms[j] += ms[j]; tot_n[j] += cnt[j]
-    per_kind_us = {KINDS[j]: (tot_ms[j] / P) * 1e3 for j in range(15)}            # us per step
-    per_launch_us = {KINDS[j]: (tot_ms[j] / max(tot_n[j], 1)) * 1e3 for j in range(15)}
+    per_kind_us, per_launch_us, n_per_step = profile_kinds(st, kvm)
 
-    prefill = None; prefill_full = None
-    if args.prefill_tokens > 0 and world == 1:       # side measurements (prompt pass, CPU baseline) belong to the N = 1 line only
-        prefill = prefill_experts(eng, L, args.prefill_tokens, torch)
-        if args.prefill_chunk:
-            st.set_prefill_chunk(args.prefill_chunk)
-        if args.prefill_depth:
-            st.set_prefill_depth(args.prefill_depth)
-        prefill_full = prefill_model(st, L, args.prefill_tokens, args.prefill_reps, torch)
-        prefill_full["chunk"] = args.prefill_chunk or 1024; prefill_full["chunks_in_flight"] = args.prefill_depth or 3
-
-    long_ctx = None
-    if world == 1 and not args.no_long_context:          # side measurement: the same decode step late in a long cache (split attention launches)
+    side = {}
+    if world == 1:       # side measurements belong to the N = 1 line only
+        # the same decode step with the other KV element type (the headline follows BASELINE config 3: FP8 KV)
         try:
-            kv_long = 8192
-            st.fill_state_synthetic(kv_long, 7)
-            for i in range(3):
-                st.decode_step(0, kv_long - 6 + i)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(20):
-                st.decode_step(0, kv_long - 2)
-            torch.cuda.synchronize()
-            d1 = (time.perf_counter() - t1) / 20
-            long_ctx = {"kv_max_seq": kv_long, "position": kv_long - 2, "ms_per_step": d1 * 1e3, "tok_s": 1.0 / d1,
-                        "note": "GQA layers read 8190 cached positions per head: scores over (heads x 256-position blocks) workgroups, then softmax + p.v "
-                                "with a column-major V stage on producer / consumer waves; the headline value follows the reference protocol (positions 10..)"}
+            st.set_kv_dtype(not kv_fp8); st.fill_state_synthetic(kvm, seed=4242)
+            d2 = time_decode(st, min(args.steps, 50), 3, kvm, torch, None, 1)
+            side["decode_other_kv"] = {"kv": "FP16" if kv_fp8 else "FP8-E4M3", "tok_s": min(args.steps, 50) / d2, "ms_per_step": d2 / min(args.steps, 50) * 1e3}
+            st.set_kv_dtype(kv_fp8); st.fill_state_synthetic(kvm, seed=4242)
         except Exception as ex:
-            long_ctx = {"error": repr(ex)}
+            side["decode_other_kv"] = {"error": repr(ex)}
+        if pf_list:
+            try:
+                side["prefill_experts_only"] = prefill_experts(eng, dims, L, 8192, torch)
+            except Exception as ex:
+                side["prefill_experts_only"] = {"error": repr(ex)}
+            if args.prefill_chunk:
+                st.set_prefill_chunk(args.prefill_chunk)
+            if args.prefill_depth:
+                st.set_prefill_depth(args.prefill_depth)
+            macs = qcn_gemm_macs_per_token(L) if qcn else v2l_gemm_macs_per_token(L)
+            runs = []
+            for P in pf_list:
+                try:
+                    r = prefill_model(st, dims, macs, L, P, args.prefill_reps, torch)
+                    r["chunk"] = args.prefill_chunk or 1024; r["chunks_in_flight"] = args.prefill_depth or 3
+                except Exception as ex:
+                    r = {"tokens": P, "error": repr(ex)}
+                runs.append(r)
+            ok = [r for r in runs if "value" in r]
+            if ok:
+                side["prefill"] = dict(ok[0]); side["prefill"]["by_prompt_length"] = {str(r["tokens"]): round(r["value"], 1) for r in ok}
+                side["prefill"]["note"] = ("whole-model prompt pass; `value` is the first listed length, by_prompt_length holds every length of "
+                                           "--prefill-tokens (the reference benchmark's 20 434 / 35 139 / 49 863-token prompts, benchmark.py:434-505)")
+            else:
+                side["prefill"] = runs[0]
+        if not args.no_long_context:          # the same decode step late in a long cache
+            try:
+                side["decode_long_context"] = long_context(st, 8192, torch, "FP8-E4M3" if kv_fp8 else "FP16")
+                side["decode_long_context_32k"] = long_context(st, 32768, torch, "FP8-E4M3" if kv_fp8 else "FP16")
+            except Exception as ex:
+                side["decode_long_context"] = {"error": repr(ex)}
 
-    ep_leg = None
-    if args.prefill_tokens > 0 and not args.no_ep and (world > 1 or args.ep_selftest):   # every rank takes part; same call sequence on all
+    ep_legs = {}
+    if pf_list and not args.no_ep and (world > 1 or args.ep_selftest):   # every rank takes part; same call sequence on all
         try:
-            ep_leg = prefill_ep(eng, L, args.prefill_tokens, world, rank, torch, dist)
+            ep_legs["prefill_experts_ep_alltoall"] = prefill_ep(eng, dims, L, 8192, world, rank, torch, dist)
         except Exception as ex:
-            ep_leg = {"error": repr(ex)}
+            ep_legs["prefill_experts_ep_alltoall"] = {"error": repr(ex)}
+
+    ab = (algorithmic_bytes(L, bw) if qcn else algorithmic_bytes_v2lite(L, bw))
+    del st, eng, keep
+    gc.collect(); torch.cuda.empty_cache()
+
+    if pf_list and not args.no_ep and (world > 1 or args.ep_selftest):
+        # BASELINE config 4: Qwen3-235B-A22B expert shape, E/N experts per GPU (16 at N = 8), a few layers' worth of resident experts
+        try:
+            from krasis_amd import KrasisEngine, ModelConfig
+            d4 = Q235; L4 = 4
+            e4 = KrasisEngine(device=local_rank); e4.configure(ModelConfig(d4["hidden"], d4["inter"], d4["experts"] // world, d4["topk"], L4, 0, 1.0))
+            e4.fill_synthetic(4, seed=99 + rank)
+            r = prefill_ep(e4, d4, L4, 8192, world, rank, torch, dist)
+            r["workload"] = "Qwen3-235B-A22B Q4 expert-parallel on %d×MI355X via RCCL all-to-all over xGMI (expert GEMMs of %d of 94 MoE layers)" % (world, L4)
+            ep_legs["prefill_experts_ep_235b"] = r
+            del e4; gc.collect(); torch.cuda.empty_cache()
+        except Exception as ex:
+            ep_legs["prefill_experts_ep_235b"] = {"error": repr(ex)}
+
+    if world == 1 and args.side_configs:
+        side["configs"] = {}
+        for sc in [s for s in args.side_configs.split(",") if s.strip() and s.strip() != name]:
+            try:
+                side["configs"][sc] = side_config(sc.strip(), rank, local_rank, args, torch)
+            except Exception as ex:
+                side["configs"][sc] = {"error": repr(ex)}
 
     if rank == 0:
-        ab = algorithmic_bytes(L)
         sym_us, sym_bytes, sym_n = {}, {}, {}
         for j in range(15):
             kname = KINDS[j]; sym = SYMBOL.get(kname, kname)
             sym_us[sym] = sym_us.get(sym, 0.0) + per_kind_us[kname]; sym_bytes[sym] = sym_bytes.get(sym, 0.0) + ab.get(kname, 0.0)
-            sym_n[sym] = sym_n.get(sym, 0) + tot_n[j] / P
+            sym_n[sym] = sym_n.get(sym, 0) + n_per_step[kname]
         dom = max(sym_us, key=lambda s: sym_us[s])
         achieved = sym_bytes[dom] / (sym_us[dom] * 1e-6) / 1e9 if sym_us[dom] > 0 else 0.0
         tok_s = world * args.steps / dt
         traffic, traffic_src = pmc_traffic(dom)
         res = {
-            "metric": "decode tok/s, Qwen3-Coder-Next Q4 @%d MI355X" % world,
+            "metric": "decode tok/s, %s @%d MI355X" % ("Qwen3-Coder-Next Q%d" % bits if qcn else "DeepSeek-V2-Lite Q4", world),
             "value": tok_s, "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int4-g128 weights x int16 activations -> i32, f32 scale chain (reference CPU-decode numerics, bit-exact)",
+            "dtype": "int%d-g128 weights x int16 activations -> i32, f32 scale chain (reference CPU-decode numerics, bit-exact)" % bits,
             "data": "synthetic",
-            "config": {"workload": "Qwen3-Coder-Next Q4 int4gpu on 1xMI355X (512-expert top-10, hybrid linear+GQA)",
-                       "scope": "full decode_step: embedding, %d layers (LA/GQA + MoE + shared expert), final norm, lm_head, greedy sample" % L,
-                       "kv": "FP16 KV cache (reference CPU-decode numerics), kv_max_seq %d" % kvm, "layers": L,
-                       "parallelism": "replica x%d (QCN fits one GPU; decode is not expert-parallel)" % world,
+            "config": {"workload": WORKLOAD[name],
+                       "scope": "full decode_step: embedding, %d layers (attention + MoE + shared expert), final norm, lm_head, greedy sample" % L,
+                       "kv": ("FP8-E4M3" if kv_fp8 else "FP16") + " KV cache, kv_max_seq %d" % kvm, "layers": L,
+                       "parallelism": "replica x%d (the model fits one GPU; decode is not expert-parallel)" % world,
                        "hip_graph": not args.no_graph, "target_tok_s": 200},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "peak_measured_stream_read": 6996.0, "peak_measured_source": "tools/probes/hbm_stream.hip on this box type (8 GiB, 16-byte loads)", "traffic": traffic, "traffic_unit": "HBM fetch bytes per launch (PMC FETCH_SIZE, separate pass)",
@@ -422,17 +645,11 @@ def main():
                          "per_kind_us_per_step": {k_: round(v, 2) for k_, v in per_kind_us.items()},
                          "per_kind_us_per_launch": {k_: round(v, 2) for k_, v in per_launch_us.items()}},
         }
-        if prefill_full is not None:
-            res["prefill"] = prefill_full
-        if prefill is not None:
-            res["prefill_experts_only"] = prefill
-        if ep_leg is not None:
-            res["prefill_experts_ep_alltoall"] = ep_leg
-        if long_ctx is not None:
-            res["decode_long_context"] = long_ctx
+        res.update(side)
+        res.update(ep_legs)
         if not args.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L)
+                res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, QCN["layers"])
             except Exception as ex:  # a reported side number, never the product path
                 res["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(res))

@@ -123,6 +123,9 @@ int kr_set_routing_config(kr_engine* e, int scoring, int norm_topk_prob, int top
 /* gate: bf16 [E,H] when gate_is_f32 == 0 else f32 [E,H]; bias / e_score_corr f32 [E] or NULL (host pointers) */
 int kr_set_routing_weights(kr_engine* e, int layer, const void* gate, int gate_is_f32, const float* bias,
                            const float* e_score_corr);
+/* bench_decode_synthetic's router gate (decode.rs:5181: fill_random_f32(route_data, rng, 0.02) over Xorshift64, decode.rs:4356-4376), generated
+ * by the library's host side; round_bf16 != 0 truncates each value to bf16 like a checkpoint's gate tensor (stored as bf16 in HBM) */
+int kr_set_routing_weights_synthetic(kr_engine* e, int layer, uint64_t seed, float amp, int round_bf16);
 /* x: bf16 [m,H] (rule ENGINE) or f32 [m,H] (rule DECODE); ids_out i32 [m,topk]; w_out f32 [m,topk] */
 int kr_route_topk(kr_engine* e, int layer, const void* x, int m, int rule, int32_t* ids_out, float* w_out,
                   float* logits_out /* optional f32 [m,E] */, void* stream);

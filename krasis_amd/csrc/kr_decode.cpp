@@ -397,18 +397,20 @@ extern "C" int kr_decode_fill_state_synthetic(kr_decode_store* s, int kv_max_seq
     s->kv_max_seq = kv_max_seq;
     for (size_t i = 0; i < s->layers.size(); i++) {
         DLayer& L = s->layers[i];
-        if (L.attn == ATTN_GQA) {
-            const size_t n = (size_t)kv_max_seq * L.nkv * L.hd;
-            if (s->kv_fp8) return kr_fail(KR_ERR_VALUE, "fill_state_synthetic generates the FP16 cache of bench_decode_synthetic (decode.rs:4402-4411); set FP8 caches through set_decode_state");
-            if (L.kv_k.ensure(n * 2) || L.kv_v.ensure(n * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc of KV cache failed");
-            kr_launch_fill_fp16_kv((uint16_t*)L.kv_k.p, n, seed + i * 4 + 0, s->eng->stream);
-            kr_launch_fill_fp16_kv((uint16_t*)L.kv_v.p, n, seed + i * 4 + 1, s->eng->stream);
-        } else if (L.attn == ATTN_MLA) {
-            const size_t nc = (size_t)kv_max_seq * L.klr, np = (size_t)kv_max_seq * L.rd;
-            if (s->kv_fp8) return kr_fail(KR_ERR_VALUE, "fill_state_synthetic generates FP16 caches (decode.rs:4402-4411); set FP8 caches through set_decode_state");
-            if (L.kv_k.ensure(nc * 2) || L.kv_v.ensure(np * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc of MLA cache failed");
-            kr_launch_fill_fp16_kv((uint16_t*)L.kv_k.p, nc, seed + i * 4 + 0, s->eng->stream);
-            kr_launch_fill_fp16_kv((uint16_t*)L.kv_v.p, np, seed + i * 4 + 1, s->eng->stream);
+        if (L.attn == ATTN_GQA || L.attn == ATTN_MLA) {
+            // GQA: K / V [kv_max_seq, nkv*hd]; MLA: compressed KV [kv_max_seq, klr] / rope keys [kv_max_seq, rd].  FP16 pattern of
+            // bench_decode_synthetic (decode.rs:4402-4411) or its E4M3 twin when the caches hold the reference's GPU dtype
+            const size_t nk_ = L.attn == ATTN_GQA ? (size_t)kv_max_seq * L.nkv * L.hd : (size_t)kv_max_seq * L.klr;
+            const size_t nv_ = L.attn == ATTN_GQA ? nk_ : (size_t)kv_max_seq * L.rd;
+            const size_t esz = s->kv_fp8 ? 1 : 2;
+            if (L.kv_k.ensure(nk_ * esz) || L.kv_v.ensure(nv_ * esz)) return kr_fail(KR_ERR_HIP, "hipMalloc of KV cache failed");
+            if (s->kv_fp8) {
+                kr_launch_fill_e4m3_kv((uint8_t*)L.kv_k.p, nk_, seed + i * 4 + 0, s->eng->stream);
+                kr_launch_fill_e4m3_kv((uint8_t*)L.kv_v.p, nv_, seed + i * 4 + 1, s->eng->stream);
+            } else {
+                kr_launch_fill_fp16_kv((uint16_t*)L.kv_k.p, nk_, seed + i * 4 + 0, s->eng->stream);
+                kr_launch_fill_fp16_kv((uint16_t*)L.kv_v.p, nv_, seed + i * 4 + 1, s->eng->stream);
+            }
         } else if (L.attn == ATTN_LA) {
             kr_launch_fill_uniform_f32((float*)L.conv_state.p, (size_t)(2 * L.nk * L.dk + L.nv * L.dv) * L.kd, 0.1f, seed + i * 4 + 2, s->eng->stream);
             kr_launch_fill_uniform_f32((float*)L.recur_state.p, (size_t)L.nv * L.dk * L.dv, 0.01f, seed + i * 4 + 3, s->eng->stream);

@@ -631,6 +631,24 @@ extern "C" int kr_set_routing_weights(kr_engine* e, int layer, const void* gate,
     return KR_OK;
 }
 
+// bench_decode_synthetic's router gate (decode.rs:5181 fill_random_f32(route_data, rng, 0.02) with Xorshift64, decode.rs:4356-4376):
+// x ^= x<<13; x ^= x>>7; x ^= x<<17; value = (x as i64 / i64::MAX) as f32 * amp.  round_bf16 != 0 truncates to bf16 the way a checkpoint's
+// gate is stored (the gate is then kept as bf16 in HBM).  One stream per layer: seed + layer (seed 0 -> 0xDEADBEEF like the reference).
+extern "C" int kr_set_routing_weights_synthetic(kr_engine* e, int layer, uint64_t seed, float amp, int round_bf16) {
+    if (int rc = check_layer(e, layer)) return rc;
+    if (!e->routing_set) return kr_fail(KR_ERR_STATE, "Routing config not set");
+    const size_t n = (size_t)e->r_ne * e->r_hidden;
+    std::vector<float> g(n);
+    uint64_t x = seed + (uint64_t)layer * 0x9E3779B97F4A7C15ull; if (x == 0) x = 0xDEADBEEFull;
+    for (size_t i = 0; i < n; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        float v = (float)((double)(int64_t)x / 9223372036854775807.0) * amp;
+        if (round_bf16) { uint32_t b; memcpy(&b, &v, 4); b &= 0xFFFF0000u; memcpy(&v, &b, 4); }
+        g[i] = v;
+    }
+    return kr_set_routing_weights(e, layer, g.data(), 1, nullptr, nullptr);
+}
+
 static int build_gate_rm(kr_engine* e, Layer& L) {
     if (L.gate_rm.p) return KR_OK;
     if (!L.gate_bf16_exact) return kr_fail(KR_ERR_VALUE, "engine routing rule needs a bf16 gate (moe.rs:2990); this layer's gate is not bf16-exact");

@@ -81,6 +81,7 @@ void kr_launch_multi_matvec(const KrMatDev* mats, float* const* ys, int n, const
 void kr_launch_fill_synth(void* q, size_t q_bytes, uint32_t* s, size_t s_words, uint64_t seed, hipStream_t st);
 void kr_launch_fill_uniform_f32(float* x, size_t n, float amp, uint64_t seed, hipStream_t st);
 void kr_launch_fill_fp16_kv(uint16_t* x, size_t n, uint64_t seed, hipStream_t st);
+void kr_launch_fill_e4m3_kv(uint8_t* x, size_t n, uint64_t seed, hipStream_t st);
 void kr_launch_reduce_sum_bf16(const uint16_t* const* dev_ptr_table, int n_inputs, uint16_t* out, size_t n, hipStream_t st);
 
 // marlin.rs:65,145 quantizers on the GPU: bf16 W[rows][K] (HF row-major) -> lane-tiled records of column tiles [tile0, tile0 + rows/8)

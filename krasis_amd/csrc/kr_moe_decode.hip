@@ -595,6 +595,18 @@ __global__ void kr_fill_fp16_kv_kernel(uint16_t* x, size_t n, uint64_t seed) {
         x[i] = (uint16_t)((sign << 15) | (ex << 10) | mant);
     }
 }
+// E4M3 twin of the FP16 pattern (decode.rs:4402-4411 draws sign / exponent in [8,23] / mantissa for FP16 = magnitudes 2^-7 .. 2^8): sign,
+// exponent field in [3,10] (2^-4 .. 2^3 with bias 7), 3 mantissa bits -- finite by construction (the only NaN code has exponent 15)
+__global__ void kr_fill_e4m3_kv_kernel(uint8_t* x, size_t n, uint64_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t bits = kr_splitmix(seed * 0x100000001B3ull + i);
+        const uint8_t sign = (uint8_t)((bits >> 15) & 1), ex = (uint8_t)(((bits >> 5) & 0x7) + 3), mant = (uint8_t)(bits & 0x7);
+        x[i] = (uint8_t)((sign << 7) | (ex << 3) | mant);
+    }
+}
+void kr_launch_fill_e4m3_kv(uint8_t* x, size_t n, uint64_t seed, hipStream_t st) {
+    hipLaunchKernelGGL(kr_fill_e4m3_kv_kernel, dim3(1024), dim3(256), 0, st, x, n, seed);
+}
 void kr_launch_fill_uniform_f32(float* x, size_t n, float amp, uint64_t seed, hipStream_t st) {
     hipLaunchKernelGGL(kr_fill_uniform_f32_kernel, dim3(2048), dim3(256), 0, st, x, n, amp, seed);
 }

@@ -241,6 +241,11 @@ class KrasisEngine:
         c = None if e_score_corr is None else np.ascontiguousarray(e_score_corr, np.float32)
         check(self._lib.kr_set_routing_weights(self._h, moe_layer_idx, _addr(g), 1, _addr(b) or None, _addr(c) or None))
 
+    def set_route_weight_synthetic(self, moe_layer_idx: int, seed: int = 0x12345678ABCDEF01, amp: float = 0.02, round_bf16: bool = True) -> None:
+        """Router gate of bench_decode_synthetic (decode.rs:5181): xorshift64 uniform +-amp, optionally truncated to bf16 like a checkpoint."""
+        self._need("Model not loaded")
+        check(self._lib.kr_set_routing_weights_synthetic(self._h, moe_layer_idx, seed & (2**64 - 1), amp, int(round_bf16)))
+
     def route(self, moe_layer_idx: int, x, m: int, rule: int = _lib.KR_ROUTE_RULE_DECODE, want_logits: bool = False):
         """Returns (ids int32 [m,k], weights f32 [m,k][, logits f32 [m,E]]) as numpy arrays."""
         self._need("Model not loaded")

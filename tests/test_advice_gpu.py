@@ -119,8 +119,8 @@ def test_device_ids_out_of_range_are_skipped():
     act = rand_bf16(rng, (2, H)); w = rng.random((2, k)).astype(F)
     ids = np.array([[1, E + 5, 3], [2, 4, 1 << 20]], np.int32)
     out = torch.empty((2, H), dtype=torch.int16, device="cuda")
-    eng.forward_moe_direct(0, torch.from_numpy(act.view(np.int16)).cuda().data_ptr(), torch.from_numpy(ids).cuda().data_ptr(), torch.from_numpy(w).cuda().data_ptr(),
-                           out.data_ptr(), 2, k)
+    ad, idd, wd = torch.from_numpy(act.view(np.int16)).cuda(), torch.from_numpy(ids).cuda(), torch.from_numpy(w).cuda()
+    eng.forward_moe_direct(0, ad.data_ptr(), idd.data_ptr(), wd.data_ptr(), out.data_ptr(), 2, k)
     eng.synchronize(); torch.cuda.synchronize()
     got = out.cpu().numpy().view(np.uint16)
     for b in range(2):
