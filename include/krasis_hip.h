@@ -99,6 +99,19 @@ int kr_fill_layer_synthetic(kr_engine* e, int layer, int bits, uint64_t seed);
 int kr_download_expert_unified(kr_engine* e, int layer, int expert, void* w13, uint16_t* w13_scales,
                                void* w2, uint16_t* w2_scales);
 
+/* ---- the reference's Marlin GPU layout: marlin_repack / marlin_repack_int8 (src/weights/marlin.rs:256-491, :587-758), undone
+ *      in the reference by inverse_marlin_repack / inverse_scale_permute (python/krasis/triton_moe.py:71-170).  Host-side conversions only -- no
+ *      CDNA kernel consumes this layout.  row-major: packed [N, K/8] u32 (INT4, nibble = q + 8, LSB = lowest k) or [N, K] i8 (INT8), scales bf16
+ *      [N, K/gs];  Marlin: packed [K/16, 2N] (INT4) / [K/16, 4N] (INT8) u32, scales bf16 [K/gs, N] permuted.  N % 64 == 0, K % 16 == 0. ---- */
+int kr_marlin_repack(const void* rowmajor, const uint16_t* scales, int N, int K, int group_size, int bits, uint32_t* out_packed, uint16_t* out_scales);
+int kr_marlin_unpack(const uint32_t* marlin_packed, const uint16_t* marlin_scales, int N, int K, int group_size, int bits, void* out_rowmajor, uint16_t* out_scales);
+/* one expert in the Marlin GPU format of UnifiedExpertWeights::from_expert_weights_marlin_* (weights/mod.rs:506-640): w13 = repack(gate rows || up
+ * rows), w2 = repack(down) with N padded per marlin_w2_padded_n (weights/mod.rs:942-949); what the reference's disk cache holds (:856-934) and
+ * what KrasisEngine.get_expert_w13_packed / _scales / get_expert_w2_packed / _scales return (moe.rs:1972-2090) */
+int kr_upload_expert_marlin(kr_engine* e, int layer, int expert, int inter, const uint32_t* w13_packed, const uint16_t* w13_scales,
+                            const uint32_t* w2_packed, const uint16_t* w2_scales, int bits);
+int kr_download_expert_marlin(kr_engine* e, int layer, int expert, uint32_t* w13_packed, uint16_t* w13_scales, uint32_t* w2_packed, uint16_t* w2_scales);
+
 /* ---- MoE forward: moe_forward_unified / moe_forward_gguf (moe.rs:572, 990) behind
  *      KrasisEngine.moe_forward (moe.rs:1775), forward_moe_direct (moe.rs:2843), submit/sync_forward (:2723).
  *   act  bf16 [batch, hidden]; ids i32 [batch, topk] (-1 = skip, moe.rs:2904); w f32 [batch, topk]

@@ -16,11 +16,6 @@ def make_experts(rng, E, H, I, bits=4, w2_bits=None, scale=0.05):
     return out
 
 
-def synth_expert(rng_u32, H, I, bits=4):
-    """Expert with the reference's synthetic distribution (random packed words, scales in [0.005,0.05])."""
-    raise NotImplementedError
-
-
 def upload(engine, layer, experts, shared=None):
     for e, ex in enumerate(experts):
         engine.load_unified_expert(layer, e, ex.w13, ex.w13_scales, ex.w2, ex.w2_scales, ex.num_bits, ex.w2_bits)
