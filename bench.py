@@ -160,7 +160,7 @@ def build_qcn(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
             a_log = ((rng.random(nv, dtype=np.float32) - 0.5) * 2.0).astype(np.float32); dtb = ((rng.random(nv, dtype=np.float32) - 0.5)).astype(np.float32)
             nw = (rng.random(nv * dv, dtype=np.float32) + 0.5).astype(np.float32); keep += [cw, a_log, dtb, nw]
             st.add_decode_la_layer(n_in, n_post, qkvz, ba, out, cw.ctypes.data, a_log.ctypes.data, dtb.ctypes.data, nw.ctypes.data,
-                                   nk, nv, dk, dv, 4, 1.0 / dk ** 0.5)
+                                   nk, nv, dk, dv, nv // nk, 4, 1.0 / dk ** 0.5)
         # router gate: the reference's xorshift64 stream, uniform +-0.02 (decode.rs:5181, :4356-4376), truncated to bf16 like a real
         # checkpoint's gate tensor -> stored as bf16 in HBM
         eng.set_route_weight_synthetic(l, 0x12345678ABCDEF01 + rank, 0.02, True)

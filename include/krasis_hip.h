@@ -163,8 +163,11 @@ int kr_synchronize(kr_engine* e);
  * copied to the device).  decode_step is a fixed launch sequence replayed as a hipGraph.
  * ================================================================================================ */
 typedef struct kr_decode_store kr_decode_store;
-/* CpuDecodeStore(group_size=128, parallel=True, norm_bias_one=False)  decode.rs:229 */
+/* CpuDecodeStore(group_size=128, parallel=True, norm_bias_one=False)  decode.rs:229.  e may be NULL: the reference constructs the store first
+ * and binds the engine LAST (set_moe_store, decode.rs:2250; decode_setup.py:1010); the store then runs on the current HIP device until
+ * kr_decode_set_moe_store hands it the engine that owns the routed experts and routers (same device). */
 int kr_decode_create(kr_engine* e, int group_size, int norm_bias_one, kr_decode_store** out);
+int kr_decode_set_moe_store(kr_decode_store* s, kr_engine* e);
 void kr_decode_destroy(kr_decode_store* s);
 /* store_weight_f32(ptr, rows, cols, bits) -> id (decode.rs:280): f32 [rows, cols] -> quantize_f32_to_transposed_int4/8
  * (decode.rs:46,115; scale = amax/7, q = round(v * 7/amax)) -> HBM */

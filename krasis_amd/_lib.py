@@ -18,7 +18,7 @@ SYMBOLS = [
     "kr_engine_device_bytes", "kr_upload_expert_unified", "kr_upload_expert_bf16", "kr_upload_expert_gguf", "kr_fill_layer_synthetic",
     "kr_download_expert_unified", "kr_marlin_repack", "kr_marlin_unpack", "kr_upload_expert_marlin", "kr_download_expert_marlin", "kr_moe_forward", "kr_moe_prefill", "kr_set_routing_config", "kr_set_routing_weights", "kr_set_routing_weights_synthetic",
     "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_combine_rows", "kr_moe_set_prefill_pairs", "kr_synchronize", "kr_set_profiling",
-    "kr_get_profile", "kr_decode_create", "kr_decode_destroy", "kr_decode_store_weight_f32", "kr_decode_store_weight_synthetic",
+    "kr_get_profile", "kr_decode_create", "kr_decode_set_moe_store", "kr_decode_destroy", "kr_decode_store_weight_f32", "kr_decode_store_weight_synthetic",
     "kr_decode_download_weight", "kr_decode_store_norm_weight", "kr_decode_configure", "kr_decode_add_la_layer",
     "kr_decode_add_gqa_layer", "kr_decode_add_mla_layer", "kr_decode_prefill", "kr_decode_prefill_nll", "kr_decode_reset_state", "kr_decode_generate", "kr_decode_sample", "kr_decode_set_prefill_chunk", "kr_decode_set_prefill_depth", "kr_decode_set_layer_moe", "kr_decode_set_layer_dense", "kr_decode_set_rope", "kr_decode_finalize", "kr_decode_set_kv_dtype",
     "kr_decode_set_state", "kr_decode_fill_state_synthetic", "kr_decode_get_state", "kr_decode_step", "kr_decode_generate_greedy",
@@ -94,6 +94,7 @@ def load_library() -> C.CDLL:
     lib.kr_get_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     lib.kr_decode_create.argtypes = [vp, ci, ci, C.POINTER(vp)]
+    lib.kr_decode_set_moe_store.argtypes = [vp, vp]
     lib.kr_decode_destroy.argtypes = [vp]; lib.kr_decode_destroy.restype = None
     lib.kr_decode_store_weight_f32.argtypes = [vp, vp, ci, ci, ci, C.POINTER(ci)]
     lib.kr_decode_store_weight_synthetic.argtypes = [vp, ci, ci, ci, C.c_uint64, C.POINTER(ci)]

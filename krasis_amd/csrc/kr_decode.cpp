@@ -38,11 +38,19 @@ static int chk_wid(kr_decode_store* s, int id, const char* what) {
 }
 
 extern "C" int kr_decode_create(kr_engine* eng, int group_size, int norm_bias_one, kr_decode_store** out) {
-    if (!eng || !out) return kr_fail(KR_ERR_VALUE, "null argument");
+    if (!out) return kr_fail(KR_ERR_VALUE, "null argument");
     if (group_size != 128) return kr_fail(KR_ERR_VALUE, "group_size %d unsupported", group_size);
+    bool own = false;
+    if (!eng) {   // CpuDecodeStore::new comes before set_moe_store in the reference (decode.rs:229, :2250): run on a bare engine of the current device
+        int ndev = 0, dev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); return kr_fail(KR_ERR_HIP, "no HIP device available: libkrasis_hip.so has no CPU fallback"); }
+        KR_HIP(hipGetDevice(&dev));
+        eng = kr_engine_new_bare(dev); own = true;
+        if (!eng) return kr_fail(KR_ERR_HIP, "could not create a stream on device %d", dev);
+    }
     KR_HIP(hipSetDevice(eng->device));
     std::unique_ptr<kr_decode_store> s(new kr_decode_store);
-    s->eng = eng; s->group_size = group_size; s->norm_bias_one = norm_bias_one != 0;
+    s->eng = eng; s->own_eng = own; s->group_size = group_size; s->norm_bias_one = norm_bias_one != 0;
     if (s->step_dev.ensure(sizeof(KrStep))) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
     *out = s.release();
     return KR_OK;
@@ -63,6 +71,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                       &s->hid2, &s->res2, &s->r_counter, &s->gqa_scores, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_vlogits, &s->pf_nll, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     for (hipEvent_t ev : s->pf_events) (void)hipEventDestroy(ev);
     for (hipStream_t ps : s->pf_side) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
+    if (s->own_eng) kr_engine_destroy(s->eng);
     delete s;
 }
 
@@ -270,10 +279,26 @@ extern "C" int kr_decode_add_mla_layer(kr_decode_store* s, int input_norm_id, in
     return KR_OK;
 }
 
+// set_moe_store (decode.rs:2250-2266): bind the engine that owns the routed experts and routers.  May come before or after the builder calls.
+extern "C" int kr_decode_set_moe_store(kr_decode_store* s, kr_engine* eng) {
+    if (int rc = chk_store(s)) return rc;
+    if (!eng) return kr_fail(KR_ERR_VALUE, "null engine");
+    if (eng == s->eng) return KR_OK;
+    if (!s->own_eng) return kr_fail(KR_ERR_STATE, "MoE store already set");
+    if (eng->device != s->eng->device) return kr_fail(KR_ERR_VALUE, "engine lives on device %d, the decode store on device %d", eng->device, s->eng->device);
+    KR_HIP(hipSetDevice(eng->device));
+    KR_HIP(hipDeviceSynchronize());
+    for (auto& L : s->layers) if (L.mlp == MLP_MOE && L.moe_layer >= (int)eng->layers.size())
+        return kr_fail(KR_ERR_VALUE, "moe_layer_idx %d out of range (engine has %zu MoE layers)", L.moe_layer, eng->layers.size());
+    kr_engine_destroy(s->eng);
+    s->eng = eng; s->own_eng = false; s->graph_ok = false; s->last_stream = nullptr;
+    return KR_OK;
+}
+
 extern "C" int kr_decode_set_layer_moe(kr_decode_store* s, int layer, int moe_layer_idx, int shared_gate_up_wid, int shared_down_wid, int shared_gate_wid) {
     if (int rc = need_cfg(s)) return rc;
     if (layer < 0 || layer >= (int)s->layers.size()) return kr_fail(KR_ERR_VALUE, "layer %d out of range", layer);
-    if (moe_layer_idx < 0 || moe_layer_idx >= (int)s->eng->layers.size()) return kr_fail(KR_ERR_VALUE, "moe_layer_idx %d out of range", moe_layer_idx);
+    if (moe_layer_idx < 0 || (!s->own_eng && moe_layer_idx >= (int)s->eng->layers.size())) return kr_fail(KR_ERR_VALUE, "moe_layer_idx %d out of range", moe_layer_idx);
     if ((shared_gate_up_wid >= 0) != (shared_down_wid >= 0)) return kr_fail(KR_ERR_VALUE, "shared gate_up and down weights must be set together");
     for (int id : {shared_gate_up_wid, shared_down_wid, shared_gate_wid}) if (id >= 0) if (int rc = chk_wid(s, id, "set_decode_layer_moe")) return rc;
     DLayer& L = s->layers[layer];
@@ -554,6 +579,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
         const float* act = hid;   // normalised hidden the MLP block reads
         bool routed = false;
         if (L.mlp == MLP_MOE) {
+            if (s->own_eng || L.moe_layer >= (int)e->layers.size()) return kr_fail(KR_ERR_STATE, "set_moe_store was not called (MoE layer %d has no engine)", L.moe_layer);
             Layer& EL = e->layers[L.moe_layer];
             if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
             if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
@@ -680,6 +706,7 @@ extern "C" int kr_decode_step(kr_decode_store* s, int token_id, int position, fl
     {
         kr_engine* e = s->eng; size_t gu = 0, eo = 0;
         for (auto& L : s->layers) if (L.mlp == MLP_MOE) {
+            if (s->own_eng || L.moe_layer >= (int)e->layers.size()) return kr_fail(KR_ERR_STATE, "set_moe_store was not called (MoE layer %d has no engine)", L.moe_layer);
             Layer& EL = e->layers[L.moe_layer];
             const int sI = L.sgu_wid >= 0 ? s->weights[L.sgu_wid]->rows / 2 : 0;
             const int imax = sI > EL.inter ? sI : EL.inter; const int ns = s->topk + (L.sgu_wid >= 0 ? 1 : 0);

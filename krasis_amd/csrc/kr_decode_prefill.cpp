@@ -231,6 +231,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
         if (Ly.mlp == MLP_MOE) {
             if (Ly.sgu_wid >= 0) { sid = std::max(sid, (size_t)s->weights[Ly.sgu_wid]->rows); kmax = std::max(kmax, (size_t)s->weights[Ly.sd_wid]->cols); wids.push_back(Ly.sgu_wid); wids.push_back(Ly.sd_wid); }
             if (Ly.sgu_wid >= 0 && Ly.sg_wid >= 0) wids.push_back(Ly.sg_wid);
+            if (s->own_eng || Ly.moe_layer >= (int)e->layers.size()) return kr_fail(KR_ERR_STATE, "set_moe_store was not called (MoE layer %d has no engine)", Ly.moe_layer);
             Layer& EL = e->layers[Ly.moe_layer];
             if (int rc = kr_ensure_wsum(e, EL.w13, st)) return rc;
             if (int rc = kr_ensure_wsum(e, EL.w2, st)) return rc;

@@ -196,6 +196,16 @@ extern "C" int kr_engine_create(int device, const kr_model_config* cfg, kr_engin
     return KR_OK;
 }
 
+// A decode store created before its MoE engine exists (the reference builds CpuDecodeStore first and calls set_moe_store last,
+// decode_setup.py:824-1018) runs on a bare engine: device + stream, no MoE layers.  kr_decode_set_moe_store swaps the real one in.
+kr_engine* kr_engine_new_bare(int device) {
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::unique_ptr<kr_engine> e(new kr_engine);
+    e->device = device; e->cfg = kr_model_config{}; e->cfg.group_size = 128; e->cfg.routed_scaling_factor = 1.0f;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e.release();
+}
+
 extern "C" void kr_engine_destroy(kr_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);

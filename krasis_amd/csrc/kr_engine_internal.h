@@ -90,6 +90,7 @@ struct kr_engine {
 };
 
 bool is_device_ptr(const void* p);
+kr_engine* kr_engine_new_bare(int device);   // device + stream only (a decode store created before its MoE engine)
 // ABI stream convention: NULL = the engine's own stream, (void*)1 = the legacy default (null) stream, else a hipStream_t
 static inline hipStream_t kr_pick_stream(kr_engine* e, void* stream);
 int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int count);

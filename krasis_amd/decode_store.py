@@ -18,15 +18,22 @@ from .engine import KrasisEngine, _addr
 
 class CpuDecodeStore:
     def __init__(self, group_size: int = 128, parallel: bool = True, norm_bias_one: bool = False):
+        # Like the reference (decode.rs:229) the store exists BEFORE an engine is bound: weights, norms and router gates can be stored first and
+        # set_moe_store(engine) may come last (decode_setup.py:1010) -- or first, as the synthetic benchmark does.  Until then the store runs on
+        # the current HIP device with a bare engine inside the library.
         self._lib = load_library()
         self._group_size = group_size
         self._norm_bias_one = norm_bias_one
         self._h = C.c_void_p()
+        check(self._lib.kr_decode_create(None, group_size, int(norm_bias_one), C.byref(self._h)))
         self._engine: Optional[KrasisEngine] = None
-        self._keep: list = []
         self._vocab = 0
         self._n_layers = 0
-        self._pending = []      # weights stored before set_moe_store() binds an engine
+        self._n_weights = 0
+        self._routes: list = []          # route_id -> (gate f32 [E,H], bias | None, e_score_corr | None)   (store_route_weight)
+        self._route_layer: dict = {}     # route_id -> engine MoE layer (set_decode_layer_moe)
+        self._route_cfg = None           # (scoring code, norm_topk_prob, topk) from configure_decode
+        self._routes_pushed: set = set()
 
     def __del__(self):
         try:
@@ -35,18 +42,36 @@ class CpuDecodeStore:
         except Exception:
             pass
 
-    # the reference shares its WeightStore with the engine via set_moe_store (decode.rs:2250); here the engine also owns the
-    # device/stream, so it must be bound before weights are stored.
+    # set_moe_store (decode.rs:2250): the engine owns the routed experts and the routers; bound at any point of the build
     def set_moe_store(self, engine: KrasisEngine) -> None:
         engine._need("Model not loaded")
-        if self._h.value:
+        if self._engine is not None and self._engine is not engine:
             raise RuntimeError("MoE store already set")
+        check(self._lib.kr_decode_set_moe_store(self._h, engine._h))
         self._engine = engine
-        check(self._lib.kr_decode_create(engine._h, self._group_size, int(self._norm_bias_one), C.byref(self._h)))
+        self._push_routes()
+
+    def _push_routes(self) -> None:
+        """router gates handed to store_route_weight live in the engine's router store (one per MoE layer): pushed once the engine, the routing
+        configuration (configure_decode) and the route_id -> moe_layer_idx mapping (set_decode_layer_moe) are all known"""
+        eng = self._engine
+        if eng is None or self._route_cfg is None:
+            return
+        for rid, layer in self._route_layer.items():
+            if rid in self._routes_pushed or rid >= len(self._routes):
+                continue
+            gate, bias, esc = self._routes[rid]
+            E, H = gate.shape
+            if eng._routing_cfg is None:
+                sf, norm, topk = self._route_cfg
+                check(self._lib.kr_set_routing_config(eng._h, sf, int(norm), topk, E, H))
+                eng._routing_cfg = ({0: "sigmoid", 1: "softmax", 2: "swiglu"}[sf], norm, topk, E, H)
+            eng.set_route_weight_f32(layer, gate, bias, esc)
+            self._routes_pushed.add(rid)
 
     def _need(self):
         if not self._h.value:
-            raise RuntimeError("Call set_moe_store(engine) first")
+            raise RuntimeError("decode store was destroyed")
 
     # ------------------------------------------------------------------ weights
     def store_weight_f32(self, data_ptr: int, rows: int, cols: int, num_bits: int = 4) -> int:
@@ -55,12 +80,14 @@ class CpuDecodeStore:
             raise ValueError(f"num_bits must be 4 or 8, got {num_bits}")
         wid = C.c_int()
         check(self._lib.kr_decode_store_weight_f32(self._h, data_ptr, rows, cols, num_bits, C.byref(wid)))
+        self._n_weights += 1
         return wid.value
 
     def store_weight_synthetic(self, rows: int, cols: int, num_bits: int = 4, seed: int = 1) -> int:
         self._need()
         wid = C.c_int()
         check(self._lib.kr_decode_store_weight_synthetic(self._h, rows, cols, num_bits, seed, C.byref(wid)))
+        self._n_weights += 1
         return wid.value
 
     def download_weight(self, wid: int, rows: int, cols: int, num_bits: int = 4):
@@ -76,14 +103,31 @@ class CpuDecodeStore:
         check(self._lib.kr_decode_store_norm_weight(self._h, data_ptr, size, C.byref(nid)))
         return nid.value
 
-    def store_route_weight(self, data_ptr: int, num_experts: int, hidden_dim: int, bias_ptr: int = 0, e_score_corr_ptr: int = 0,
-                           moe_layer_idx: Optional[int] = None) -> int:
-        """decode.rs:895 -- f32 gate [E, H] (+ optional bias / e_score_correction).  Routed through the engine's router store."""
+    def store_route_weight(self, data_ptr: int, num_experts: int, hidden_dim: int, bias_ptr: Optional[int] = None, bias_len: int = 0,
+                           e_score_corr_ptr: Optional[int] = None, e_score_corr_len: int = 0) -> int:
+        """decode.rs:895 -- f32 gate [E, H] (+ optional bias / e_score_correction [E]) -> route_id.  The data is copied (the caller may free
+        its tensors, decode_setup.py:563-567)."""
         self._need()
-        idx = moe_layer_idx if moe_layer_idx is not None else len(self._keep)
-        check(self._lib.kr_set_routing_weights(self._engine._h, idx, data_ptr, 1, bias_ptr or None, e_score_corr_ptr or None))
-        self._keep.append(idx)
-        return idx
+        if not data_ptr:
+            raise ValueError("null gate pointer")
+        rd = lambda p, n: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).copy()
+        gate = rd(data_ptr, num_experts * hidden_dim).reshape(num_experts, hidden_dim)
+        bias = rd(bias_ptr, bias_len) if bias_ptr and bias_len else None
+        esc = rd(e_score_corr_ptr, e_score_corr_len) if e_score_corr_ptr and e_score_corr_len else None
+        self._routes.append((gate, bias, esc))
+        return len(self._routes) - 1
+
+    def num_weights(self) -> int:
+        return self._n_weights
+
+    def num_route_weights(self) -> int:
+        return len(self._routes)
+
+    def total_bytes(self) -> int:
+        return self.device_bytes()
+
+    def repack_to_tiled(self) -> None:
+        """decode.rs repack_to_tiled: the CPU engine re-tiles its weights for bandwidth; the HBM layout is already lane-tiled."""
 
     # ------------------------------------------------------------------ graph
     def configure_decode(self, hidden_size: int, num_layers: int, eps: float, final_norm_id: int, lm_head_wid: int, vocab_size: int,
@@ -93,10 +137,14 @@ class CpuDecodeStore:
         check(self._lib.kr_decode_configure(self._h, hidden_size, num_layers, eps, final_norm_id, lm_head_wid, vocab_size, topk,
                                             scoring_func, int(norm_topk_prob), routed_scaling_factor, embedding_ptr or None, synth_seed))
         self._vocab, self._n_layers = vocab_size, num_layers
+        self._route_cfg = (scoring_func, bool(norm_topk_prob), topk)
 
     def add_decode_la_layer(self, input_norm_id, post_attn_norm_id, in_proj_qkvz_wid, in_proj_ba_wid, out_proj_wid, conv_weight_ptr,
-                            a_log_ptr, dt_bias_ptr, norm_weight_ptr, nk, nv, dk, dv, kernel_dim, scale) -> None:
+                            a_log_ptr, dt_bias_ptr, norm_weight_ptr, nk, nv, dk, dv, hr, kernel_dim, scale) -> None:
+        """decode.rs:2036 (same positional arguments; hr = value heads per key head)"""
         self._need()
+        if hr * nk != nv:
+            raise ValueError(f"head ratio {hr} does not match {nv} value / {nk} key heads")
         check(self._lib.kr_decode_add_la_layer(self._h, input_norm_id, post_attn_norm_id, in_proj_qkvz_wid, in_proj_ba_wid, out_proj_wid,
                                                conv_weight_ptr, a_log_ptr, dt_bias_ptr, norm_weight_ptr, nk, nv, dk, dv, kernel_dim, scale))
 
@@ -123,6 +171,8 @@ class CpuDecodeStore:
         self._need()
         f = lambda v: -1 if v is None else v
         check(self._lib.kr_decode_set_layer_moe(self._h, layer_idx, moe_layer_idx, f(shared_gate_up_wid), f(shared_down_wid), f(shared_gate_wid)))
+        self._route_layer[route_id] = moe_layer_idx
+        self._push_routes()
 
     def set_decode_layer_dense(self, layer_idx: int, gate_proj_wid: int, up_proj_wid: int, down_proj_wid: int) -> None:
         self._need()
@@ -138,6 +188,7 @@ class CpuDecodeStore:
 
     def finalize_decode(self) -> None:
         self._need()
+        self._push_routes()
         check(self._lib.kr_decode_finalize(self._h))
 
     def set_decode_state(self, seq_len: int, kv_max_seq: int, kv_k_ptrs: Sequence[int], kv_v_ptrs: Sequence[int],

@@ -56,7 +56,7 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbit
             keep += [conv_w, a_log, dt_bias, norm_w]
             scale = F(1.0 / np.sqrt(dk))
             st.add_decode_la_layer(n_in[0], n_post[0], qkvz[0], ba[0], out[0], _ptr(conv_w), _ptr(a_log), _ptr(dt_bias), _ptr(norm_w),
-                                   nk, nv, dk, dv, 4, float(scale))
+                                   nk, nv, dk, dv, nv // nk, 4, float(scale))
             cs = ((rng.random(conv_dim * 4) - 0.5) * 0.2).astype(F); rs = ((rng.random(nv * dk * dv) - 0.5) * 0.02).astype(F)
             state["conv"][li] = cs; state["recur"][li] = rs
             L.update(qkvz=qkvz[1], ba=ba[1], out=out[1], conv_w=conv_w, a_log=a_log, dt_bias=dt_bias, norm_w=norm_w, nk=nk, nv=nv, dk=dk, dv=dv,
