@@ -250,6 +250,22 @@ def prefill_experts(eng, dims, L, M, torch):
                     "twice (high / low INT16 activation digit) to reproduce the reference's integer arithmetic exactly"}
 
 
+def prefill_experts_gguf(local_rank, torch, gate_up_type=12, down_type=12, L=8):
+    """Side measurement: the expert path of the prompt pass on NATIVE GGUF blocks (QCN shape, Q4_K gate / up / down): raw super-blocks staged
+    in LDS feeding the int8 MFMA (kr_gguf_prefill.hip), L layers of 512 synthetic experts."""
+    from krasis_amd import KrasisEngine, ModelConfig
+    q = QCN
+    eng = KrasisEngine(device=local_rank); eng.configure(ModelConfig(q["hidden"], q["inter"], q["experts"], q["topk"], L, 0, 1.0))
+    eng.fill_synthetic_gguf(gate_up_type, down_type, seed=77)
+    r = prefill_experts(eng, q, L, 8192, torch)
+    r["weights"] = "native GGUF blocks, gate/up ggml type %d, down type %d (Q4_K = 12: 0.5625 B / weight, Q8_0 = 8)" % (gate_up_type, down_type)
+    r["note"] = ("sort + 3 grouped GEMMs (gate, up, down) + libm-SiLU act + combine; raw Q4_K super-blocks in LDS, one int8 MFMA per 32-wide sub-block and "
+                 "activation digit, per-sub-block scale / min epilogue (one f32 chain per output: ~1e-6 relative to the streaming kernels)")
+    del eng
+    gc.collect(); torch.cuda.empty_cache()
+    return r
+
+
 def prefill_ep(eng, dims, L, M, world, rank, torch, dist, experts_local=None):
     """Expert-parallel prompt-pass experts over RCCL inside libkrasis_hip.so (kr_ep_init / kr_moe_prefill_ep): every rank owns
     E/N experts and M tokens; each (token, slot) row travels once to the rank that owns its expert (ncclSend/ncclRecv groups over the xGMI
@@ -606,6 +622,11 @@ def main():
         except Exception as ex:
             ep_legs["prefill_experts_ep_235b"] = {"error": repr(ex)}
 
+    if world == 1 and pf_list:
+        try:
+            side["prefill_experts_only_q4k_gguf"] = prefill_experts_gguf(local_rank, torch)
+        except Exception as ex:
+            side["prefill_experts_only_q4k_gguf"] = {"error": repr(ex)}
     if world == 1 and args.side_configs:
         side["configs"] = {}
         for sc in [s for s in args.side_configs.split(",") if s.strip() and s.strip() != name]:

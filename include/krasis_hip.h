@@ -95,6 +95,9 @@ int kr_upload_expert_bf16(kr_engine* e, int layer, int expert, int inter, const 
  * words and bf16 scales in [0.005,0.05] -- the distribution of bench_decode_synthetic (decode.rs:4379-4392),
  * generated by a counter hash on the GPU instead of one serial xorshift stream. */
 int kr_fill_layer_synthetic(kr_engine* e, int layer, int bits, uint64_t seed);
+/* the native-GGUF twin: every routed expert of the layer as Q4_K (12) / Q8_0 (8) blocks with the block distribution SURVEY 8d defines
+ * (raw quant / scale bytes, d = f16((0.005 + u * 0.045) / 63), dmin = f16(8 d); Q8_0: d = f16((0.005 + u * 0.045) / 127)) */
+int kr_fill_layer_synthetic_gguf(kr_engine* e, int layer, int gate_up_type, int down_type, uint64_t seed);
 /* Read one expert back in the reference layout (inverse re-tiling); used by parity tests at full size. */
 int kr_download_expert_unified(kr_engine* e, int layer, int expert, void* w13, uint16_t* w13_scales,
                                void* w2, uint16_t* w2_scales);
@@ -122,7 +125,11 @@ int kr_moe_forward(kr_engine* e, int layer, const void* act_bf16, const int32_t*
 /* ---- prefill: GpuPrefillManager.forward(moe_layer_idx, hidden[M,H] bf16, topk_ids[M,k] i32, topk_weights[M,k] f32, routed_only)
  *      (python/krasis/gpu_prefill.py:4374-4394).  All pointers are device pointers.  Token sort + int8-MFMA grouped GEMM; every row
  *      carries the arithmetic of expert_forward_unified (moe.rs:184), so the result equals kr_moe_forward on the same batch bit for bit.
- *      out = rsf*routed + shared unless routed_only (gpu_prefill.py:4467-4484). ---- */
+ *      out = rsf*routed + shared unless routed_only (gpu_prefill.py:4467-4484).
+ *      Native-GGUF layers (kr_upload_expert_gguf): Q4_K / Q8_0 blocks run on the same matrix cores -- raw super-blocks staged in LDS, one
+ *      int8 MFMA per 32-wide sub-block and activation digit, the per-sub-block scale / min epilogue of gguf_kernels.rs:271-432 -- with ONE
+ *      f32 chain per output instead of the AVX2 kernel's eight lane chains: equal to kr_moe_forward within ~1e-6 relative (stated in
+ *      tests/test_gguf_gpu.py), not bit for bit; Q4_0 / Q5_0 / Q6_K layers walk the batch through the bit-exact streaming kernels. ---- */
 int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* weights, void* out, int M, int topk,
                    int out_dtype, int routed_only, void* stream);
 

@@ -15,7 +15,7 @@ KR_ROUTE_RULE_ENGINE, KR_ROUTE_RULE_DECODE = 0, 1
 # every symbol include/krasis_hip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
     "kr_last_error", "kr_version", "kr_engine_create", "kr_engine_destroy", "kr_engine_get_config",
-    "kr_engine_device_bytes", "kr_upload_expert_unified", "kr_upload_expert_bf16", "kr_upload_expert_gguf", "kr_fill_layer_synthetic",
+    "kr_engine_device_bytes", "kr_upload_expert_unified", "kr_upload_expert_bf16", "kr_upload_expert_gguf", "kr_fill_layer_synthetic", "kr_fill_layer_synthetic_gguf",
     "kr_download_expert_unified", "kr_marlin_repack", "kr_marlin_unpack", "kr_upload_expert_marlin", "kr_download_expert_marlin", "kr_moe_forward", "kr_moe_prefill", "kr_set_routing_config", "kr_set_routing_weights", "kr_set_routing_weights_synthetic",
     "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_combine_rows", "kr_moe_set_prefill_pairs", "kr_synchronize", "kr_set_profiling",
     "kr_get_profile", "kr_decode_create", "kr_decode_set_moe_store", "kr_decode_destroy", "kr_decode_store_weight_f32", "kr_decode_store_weight_synthetic",
@@ -72,6 +72,7 @@ def load_library() -> C.CDLL:
     lib.kr_upload_expert_gguf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_void_p, C.c_int]
     lib.kr_fill_layer_synthetic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64]
+    lib.kr_fill_layer_synthetic_gguf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
     lib.kr_download_expert_unified.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.kr_marlin_repack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.kr_marlin_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

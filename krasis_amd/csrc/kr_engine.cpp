@@ -215,10 +215,10 @@ extern "C" void kr_engine_destroy(kr_engine* e) {
         l.w13.q.release(); l.w13.s.release(); l.w2.q.release(); l.w2.s.release();
         l.sw13.q.release(); l.sw13.s.release(); l.sw2.q.release(); l.sw2.s.release();
         l.gate_cm.release(); l.gate_rm.release(); l.bias.release(); l.esc.release();
-        for (GgufSet* g : {&l.g_gate, &l.g_up, &l.g_down, &l.gs_gate, &l.gs_up, &l.gs_down}) { g->q.release(); g->h.release(); }
+        for (GgufSet* g : {&l.g_gate, &l.g_up, &l.g_down, &l.gs_gate, &l.gs_up, &l.gs_down}) { g->q.release(); g->h.release(); g->ws.release(); }
     }
     for (DevBuf* b : {&e->gu, &e->eo, &e->st_act, &e->st_ids, &e->st_w, &e->st_out, &e->ptr_table, &e->r_logits, &e->r_ids, &e->r_w, &e->r_x}) b->release();
-    for (auto& P : e->pf) for (DevBuf* b : {&P.i32, &P.xh, &P.xl, &P.xs, &P.gu, &P.hh, &P.hl, &P.hs, &P.eo, &P.sgu, &P.shh, &P.shl, &P.shs, &P.seo}) b->release();
+    for (auto& P : e->pf) for (DevBuf* b : {&P.i32, &P.xh, &P.xl, &P.xs, &P.xm, &P.gu, &P.hh, &P.hl, &P.hs, &P.hm, &P.eo, &P.sgu, &P.shh, &P.shl, &P.shs, &P.shm, &P.seo}) b->release();
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -409,6 +409,7 @@ static int ggset_alloc(kr_engine* e, GgufSet& gs, int type, int K, int N, int co
     return KR_OK;
 }
 static int ggset_upload(GgufSet& gs, int idx, const uint8_t* src) {
+    gs.ws.release();                                  // prompt-pass quant sums are rebuilt on the next kr_moe_prefill
     std::vector<uint8_t> dq(gs.q_stride), dh(gs.h_stride);
     retile_gguf(gs.type, src, gs.K, gs.N, dq.data(), dh.data());
     KR_HIP(hipMemcpy((char*)gs.q.p + (size_t)idx * gs.q_stride, dq.data(), gs.q_stride, hipMemcpyHostToDevice));
@@ -434,6 +435,27 @@ extern "C" int kr_upload_expert_gguf(kr_engine* e, int layer, int expert, int in
     if (int rc = ggset_upload(U, idx, up)) return rc;
     if (int rc = ggset_upload(D, idx, down)) return rc;
     if (sh) { L.gguf_shared = true; L.shared_inter = inter; } else { L.gguf = true; L.inter = inter; L.present[expert] = 1; }
+    return KR_OK;
+}
+
+// synthetic native-GGUF experts for a whole layer (Q4_K or Q8_0 blocks, both projections), generated on the GPU -- the GGUF twin of
+// kr_fill_layer_synthetic with the block distribution SURVEY 8d defines
+extern "C" int kr_fill_layer_synthetic_gguf(kr_engine* e, int layer, int gate_up_type, int down_type, uint64_t seed) {
+    if (int rc = check_layer(e, layer)) return rc;
+    for (int t : {gate_up_type, down_type}) if (t != GG_Q4_K && t != GG_Q8_0) return kr_fail(KR_ERR_VALUE, "synthetic GGUF fill supports Q4_K (12) and Q8_0 (8), got %d", t);
+    KR_HIP(hipSetDevice(e->device));
+    Layer& L = e->layers[layer];
+    const int H = e->cfg.hidden_size, I = e->cfg.moe_intermediate_size, E = e->cfg.n_routed_experts;
+    if (int rc = ggset_alloc(e, L.g_gate, gate_up_type, H, I, E)) return rc;
+    if (int rc = ggset_alloc(e, L.g_up, gate_up_type, H, I, E)) return rc;
+    if (int rc = ggset_alloc(e, L.g_down, down_type, I, H, E)) return rc;
+    int k = 0;
+    for (GgufSet* g : {&L.g_gate, &L.g_up, &L.g_down}) {
+        g->ws.release();
+        kr_launch_gpf_fill_synth(g->q.p, g->q_stride * E, g->h.p, g->h_stride * E, g->type, seed * 8 + (uint64_t)(k++), e->stream);
+    }
+    KR_HIP(hipStreamSynchronize(e->stream));
+    L.gguf = true; L.inter = I; std::fill(L.present.begin(), L.present.end(), 1);
     return KR_OK;
 }
 
@@ -784,6 +806,83 @@ int kr_ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st) {
 // streamed once per ~80 k pairs either way
 #define KR_PF_PAIRS 81920
 
+// ---- native GGUF layers (moe_forward_gguf, moe.rs:990): Q4_K / Q8_0 blocks on the int8-MFMA grouped GEMM (kr_gguf_prefill.hip); layers
+//      whose block types have no MFMA form (Q4_0 / Q5_0 / Q6_K) walk the batch through the streaming kernels.  The caller holds e->mu.
+static int gg_ensure_ws(kr_engine* e, GgufSet& g, hipStream_t st) {
+    if (g.ws.p || !g.allocated()) return KR_OK;
+    g.ws_stride = kr_gpf_ws_bytes(g.type, g.K, g.N);
+    if (g.ws.ensure(g.ws_stride * g.count)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    kr_launch_gpf_wsum(g.view(), g.count, g.ws.p, g.ws_stride, st);
+    (void)e;
+    return KR_OK;
+}
+
+static int moe_prefill_gguf(kr_engine* e, Layer& L, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
+                            int out_dtype, int routed_only, int set, hipStream_t st) {
+    const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
+    const bool use_shared = L.gguf_shared && !routed_only;
+    const int SI = L.shared_inter;
+    bool mfma = kr_gpf_type_supported(L.g_gate.type, H) && kr_gpf_type_supported(L.g_down.type, I);
+    if (use_shared) mfma = mfma && kr_gpf_type_supported(L.gs_gate.type, H) && kr_gpf_type_supported(L.gs_down.type, SI);
+    const size_t ob = out_dtype == KR_OUT_BF16 ? 2 : 4;
+    if (!mfma) {   // streaming kernels, 16 384 tokens per pass (grid z limit 65 535)
+        for (int m0 = 0; m0 < M; m0 += 16384) {
+            const int mc = M - m0 < 16384 ? M - m0 : 16384;
+            if (int rc = moe_forward_locked(e, layer, (const uint16_t*)x_bf16 + (size_t)m0 * H, ids + (size_t)m0 * topk, wts + (size_t)m0 * topk,
+                                            (char*)out + (size_t)m0 * H * ob, mc, topk, out_dtype, routed_only, st)) return rc;
+        }
+        return KR_OK;
+    }
+    kr_engine::PfSet& P = e->pf[set % KR_PF_MAX_DEPTH];
+    for (GgufSet* g : {&L.g_gate, &L.g_up, &L.g_down}) if (int rc = gg_ensure_ws(e, *g, st)) return rc;
+    if (use_shared) for (GgufSet* g : {&L.gs_gate, &L.gs_up, &L.gs_down}) if (int rc = gg_ensure_ws(e, *g, st)) return rc;
+    const int pairs = e->pf_pairs > 0 ? e->pf_pairs : KR_PF_PAIRS;
+    const int CHmax = pairs / topk > 64 ? pairs / topk : 64;
+    const int CH = M < CHmax ? M : CHmax;
+    const size_t np = (size_t)CH * topk;
+    const int max_tiles = (int)(np / 64) + E + 1;
+    const size_t n_i32 = 3 * (size_t)E + 3 * (size_t)max_tiles + 4 + 2 * np;
+    if (P.i32.ensure(n_i32 * 4) || P.xh.ensure((size_t)CH * H) || P.xl.ensure((size_t)CH * H) || P.xs.ensure((size_t)CH * (H / 32) * 4) || P.xm.ensure((size_t)CH * (H / 32) * 4) ||
+        P.gu.ensure(np * 2 * I * 4) || P.hh.ensure(np * I) || P.hl.ensure(np * I) || P.hs.ensure(np * (I / 32) * 4) || P.hm.ensure(np * (I / 32) * 4) || P.eo.ensure(np * H * 4))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
+    if (use_shared && (P.sgu.ensure((size_t)CH * 2 * SI * 4) || P.shh.ensure((size_t)CH * SI) || P.shl.ensure((size_t)CH * SI) || P.shs.ensure((size_t)CH * (SI / 32) * 4) ||
+                       P.shm.ensure((size_t)CH * (SI / 32) * 4) || P.seo.ensure((size_t)CH * H * 4)))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
+    int* ib = (int*)P.i32.p;
+    KrPfSort so{};
+    so.counts = ib; so.offsets = ib + E; so.cursor = ib + 2 * E; ib += 3 * E;
+    so.tile_expert = ib; so.tile_row0 = ib + max_tiles; so.tile_rows = ib + 2 * max_tiles; ib += 3 * max_tiles;
+    so.n_tiles = ib; ib += 4; so.row_pair = ib; so.pair_row = ib + np;
+    for (int m0 = 0; m0 < M; m0 += CH) {
+        const int mc = M - m0 < CH ? M - m0 : CH;
+        const uint16_t* xc = (const uint16_t*)x_bf16 + (size_t)m0 * H;
+        const int32_t* idc = ids + (size_t)m0 * topk; const float* wc = wts + (size_t)m0 * topk;
+        const int tiles_bound = (mc * topk) / 64 + E + 1;
+        kr_launch_pf_sort(idc, mc, topk, E, so, st);
+        kr_launch_gpf_quant_x(xc, mc, H, (int8_t*)P.xh.p, (int8_t*)P.xl.p, (float*)P.xs.p, (float*)P.xm.p, st);
+        kr_launch_gpf_gemm(L.g_gate.view(), L.g_gate.ws.p, L.g_gate.ws_stride, (const int8_t*)P.xh.p, (const int8_t*)P.xl.p, (const float*)P.xs.p, (const float*)P.xm.p, &so,
+                           topk, 1, tiles_bound, 0, (float*)P.gu.p, 2 * I, 0, st);
+        kr_launch_gpf_gemm(L.g_up.view(), L.g_up.ws.p, L.g_up.ws_stride, (const int8_t*)P.xh.p, (const int8_t*)P.xl.p, (const float*)P.xs.p, (const float*)P.xm.p, &so,
+                           topk, 1, tiles_bound, 0, (float*)P.gu.p, 2 * I, I, st);
+        kr_launch_gpf_act((const float*)P.gu.p, mc * topk, I, 2 * I, (int8_t*)P.hh.p, (int8_t*)P.hl.p, (float*)P.hs.p, (float*)P.hm.p, st);
+        kr_launch_gpf_gemm(L.g_down.view(), L.g_down.ws.p, L.g_down.ws_stride, (const int8_t*)P.hh.p, (const int8_t*)P.hl.p, (const float*)P.hs.p, (const float*)P.hm.p, &so,
+                           topk, 0, tiles_bound, 0, (float*)P.eo.p, H, 0, st);
+        if (use_shared) {
+            kr_launch_gpf_gemm(L.gs_gate.view(), L.gs_gate.ws.p, L.gs_gate.ws_stride, (const int8_t*)P.xh.p, (const int8_t*)P.xl.p, (const float*)P.xs.p, (const float*)P.xm.p,
+                               nullptr, topk, 0, 0, mc, (float*)P.sgu.p, 2 * SI, 0, st);
+            kr_launch_gpf_gemm(L.gs_up.view(), L.gs_up.ws.p, L.gs_up.ws_stride, (const int8_t*)P.xh.p, (const int8_t*)P.xl.p, (const float*)P.xs.p, (const float*)P.xm.p,
+                               nullptr, topk, 0, 0, mc, (float*)P.sgu.p, 2 * SI, SI, st);
+            kr_launch_gpf_act((const float*)P.sgu.p, mc, SI, 2 * SI, (int8_t*)P.shh.p, (int8_t*)P.shl.p, (float*)P.shs.p, (float*)P.shm.p, st);
+            kr_launch_gpf_gemm(L.gs_down.view(), L.gs_down.ws.p, L.gs_down.ws_stride, (const int8_t*)P.shh.p, (const int8_t*)P.shl.p, (const float*)P.shs.p,
+                               (const float*)P.shm.p, nullptr, topk, 0, 0, mc, (float*)P.seo.p, H, 0, st);
+        }
+        kr_launch_pf_combine((const float*)P.eo.p, so.pair_row, wc, mc, topk, H, use_shared ? (const float*)P.seo.p : nullptr, e->cfg.routed_scaling_factor,
+                             (char*)out + (size_t)m0 * H * ob, out_dtype == KR_OUT_BF16, st);
+    }
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
 int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
                        int out_dtype, int routed_only, int set, hipStream_t st) {
     if (int rc = check_layer(e, layer)) return rc;
@@ -791,12 +890,13 @@ int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_
     if (M <= 0) return kr_fail(KR_ERR_VALUE, "M must be > 0");
     if (topk <= 0 || topk > KR_MAX_TOPK) return kr_fail(KR_ERR_VALUE, "topk %d exceeds MAX_TOPK %d", topk, KR_MAX_TOPK);
     Layer& L = e->layers[layer];
-    if (!L.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded -- call load() first (layer %d has no experts)", layer);
+    if (!L.w13.allocated() && !L.gguf) return kr_fail(KR_ERR_STATE, "Model not loaded -- call load() first (layer %d has no experts)", layer);
     if (!is_device_ptr(x_bf16) || !is_device_ptr(ids) || !is_device_ptr(wts) || !is_device_ptr(out))
         return kr_fail(KR_ERR_VALUE, "kr_moe_prefill expects device pointers (hidden/topk tensors live in HBM during prefill)");
-    if (e->cfg.hidden_size % 128 || L.inter % 128) return kr_fail(KR_ERR_VALUE, "prefill path needs dims divisible by 128");
     std::lock_guard<std::mutex> lk(e->mu);
     KR_HIP(hipSetDevice(e->device));
+    if (L.gguf) return moe_prefill_gguf(e, L, layer, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, set, st);
+    if (e->cfg.hidden_size % 128 || L.inter % 128) return kr_fail(KR_ERR_VALUE, "prefill path needs dims divisible by 128");
     kr_engine::PfSet& P = e->pf[set % KR_PF_MAX_DEPTH];
     const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
     const bool use_shared = L.shared_present && !routed_only;

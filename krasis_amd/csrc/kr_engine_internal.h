@@ -50,6 +50,7 @@ struct MatSet {            // all experts of one layer for one projection, conti
 
 struct GgufSet {          // native GGUF experts of one layer for one projection
     DevBuf q, h; int type = 0, K = 0, N = 0, count = 0; size_t q_stride = 0, h_stride = 0;
+    DevBuf ws; size_t ws_stride = 0;   // prompt pass: per (row, sub-block) sums of the quants (kr_gguf_prefill.hip), built on first use
     bool allocated() const { return q.p != nullptr; }
     GgMat view() const { GgMat m{}; m.q = q.p; m.h = h.p; m.type = type; m.K = K; m.N = N; m.q_stride = q_stride; m.h_stride = h_stride; return m; }
 };
@@ -83,7 +84,7 @@ struct kr_engine {
     DevBuf r_logits, r_ids, r_w, r_x;
     // prefill scratch (kr_moe_prefill)
     int pf_pairs = 0;          // kr_moe_set_prefill_pairs
-    struct PfSet { DevBuf i32, xh, xl, xs, gu, hh, hl, hs, eo, sgu, shh, shl, shs, seo; } pf[KR_PF_MAX_DEPTH];   // one set per chunk in flight of the prompt pass
+    struct PfSet { DevBuf i32, xh, xl, xs, xm, gu, hh, hl, hs, hm, eo, sgu, shh, shl, shs, shm, seo; } pf[KR_PF_MAX_DEPTH];   // one set per chunk in flight of the prompt pass
     // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
     bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};
     std::mutex mu;

@@ -18,3 +18,15 @@ struct GgMoeArgs {
 void kr_launch_gguf_moe(const GgMoeArgs& a, hipStream_t st);
 size_t gg_q_bytes(int type, int K, int N);
 size_t gg_h_bytes(int type, int K, int N);
+
+// ---- prompt pass: GGUF blocks on the int8-MFMA grouped GEMM (kr_gguf_prefill.hip) ----
+struct KrPfSort;
+bool kr_gpf_type_supported(int type, int K);
+size_t kr_gpf_ws_bytes(int type, int K, int N);
+void kr_launch_gpf_wsum(const GgMat& m, int n_experts, void* ws, size_t ws_stride, hipStream_t st);
+void kr_launch_gpf_quant_x(const uint16_t* x, int M, int K, int8_t* xh, int8_t* xl, float* xs, float* xm, hipStream_t st);
+void kr_launch_gpf_act(const float* gu, int rows, int n, int gu_ld, int8_t* hh, int8_t* hl, float* hs, float* hm, hipStream_t st);
+void kr_launch_gpf_gemm(const GgMat& m, const void* ws, size_t ws_stride, const int8_t* a_hi, const int8_t* a_lo, const float* a_scale, const float* a_sum,
+                        const KrPfSort* sort, int topk, int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, int col_off,
+                        hipStream_t st);
+void kr_launch_gpf_fill_synth(void* q, size_t q_bytes, void* h, size_t h_bytes, int type, uint64_t seed, hipStream_t st);

@@ -140,6 +140,13 @@ class KrasisEngine:
             check(self._lib.kr_fill_layer_synthetic(self._h, layer, bits, (seed + layer * 0x9E3779B97F4A7C15) & (2**64 - 1)))
         self._cpu_bits = self._gpu_bits = bits
 
+    def fill_synthetic_gguf(self, gate_up_type: int = 12, down_type: int = 12, seed: int = 0x12345678ABCDEF01, layers: Optional[Sequence[int]] = None) -> None:
+        """Synthetic native-GGUF experts (ggml type ids: Q4_K = 12, Q8_0 = 8) with the block distribution SURVEY 8d defines, generated on the GPU."""
+        self._need()
+        for layer in (layers if layers is not None else range(self._cfg.num_moe_layers)):
+            check(self._lib.kr_fill_layer_synthetic_gguf(self._h, layer, gate_up_type, down_type, (seed + layer * 0x9E3779B97F4A7C15) & (2**64 - 1)))
+        self._has_gguf = True
+
     def download_expert(self, layer: int, expert: int, bits: int = 4, w2_bits: Optional[int] = None):
         """Read an expert back in the reference layout (inverse re-tiling)."""
         self._need()

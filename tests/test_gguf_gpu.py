@@ -62,3 +62,83 @@ def test_moe_forward_gguf_bit_exact(H, I, gu_t, dn_t):
         sel = [(experts[i], wi) for i, wi in zip(ids[b], w[b]) if i >= 0]
         ref = O.moe_forward_gguf([s[0] for s in sel], [s[1] for s in sel], act[b], shared, 1.5)
         assert np.array_equal(out[b], O.f32_to_bf16(ref)), b
+
+
+@pytest.mark.parametrize("H,I,gu_t,dn_t,shared", [
+    (2048, 512, O.Q4_K, O.Q4_K, True),      # QCN expert shape, Q4_K super-blocks on the MFMA GEMM
+    (512, 192, O.Q4_K, O.Q8_0, True),       # V2-Lite situation: intermediate not a multiple of 256 -> Q8_0 down, K % 256 != 0 tail stage
+    (2048, 512, O.Q8_0, O.Q8_0, False),     # QCN Q8 config
+    (512, 224, O.Q4_0, O.Q4_0, True),       # no MFMA form: the batch walks the bit-exact streaming kernels
+])
+def test_moe_prefill_gguf_mfma(H, I, gu_t, dn_t, shared):
+    """kr_moe_prefill on a native-GGUF layer (M >= 64): Q4_K / Q8_0 blocks staged raw in LDS, int8 MFMA per 32-wide sub-block and activation
+    digit, per-sub-block scale / min epilogue.  The integer sums are exact; the f32 chain runs once per output over the sub-blocks instead of
+    the AVX2 kernel's 8 lane chains + hsum (kr_gguf_prefill.hip header), so the result is compared with the bit-exact kr_moe_forward on the
+    same layer at a STATED TOLERANCE: |diff| <= 2e-5 * max|ref| (measured ~1e-6; Q4_K's out - corr cancellation is the widest case).
+    Types without an MFMA form must stay bit-identical."""
+    import os
+    import torch
+    from krasis_amd import GpuPrefillManager, KrasisEngine, ModelConfig, _lib
+    from krasis_amd._lib import check
+    rng = np.random.default_rng(H * 3 + I + gu_t + dn_t)
+    E, k, M = 6, 3, 200
+    experts = [make(rng, H, I, gu_t, dn_t) for _ in range(E)]
+    sh = make(rng, H, I, gu_t, dn_t) if shared else None
+    eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, 1, 1 if shared else 0, 1.5))
+    for e, ex in enumerate(experts):
+        eng.load_gguf_expert(0, e, ex.gate, ex.up, ex.down, gu_t, dn_t, I)
+    if shared:
+        eng.load_gguf_expert(0, -1, sh.gate, sh.up, sh.down, gu_t, dn_t, I)
+    act = rand_bf16(rng, (M, H)); ids = np.stack([rng.choice(E, k, replace=False) for _ in range(M)]).astype(np.int32)
+    ids[5, 1] = -1; ids[77, :] = -1
+    w = rng.random((M, k)).astype(np.float32)
+    xd = torch.from_numpy(act.view(np.int16)).cuda(); idd = torch.from_numpy(ids).cuda(); wd = torch.from_numpy(w).cuda()
+    ref = torch.empty((M, H), dtype=torch.float32, device="cuda"); got = torch.empty_like(ref)
+    st = torch.cuda.current_stream().cuda_stream or 1
+    check(eng._lib.kr_moe_forward(eng._h, 0, xd.data_ptr(), idd.data_ptr(), wd.data_ptr(), ref.data_ptr(), M, k, _lib.KR_OUT_F32, 0, st))
+    check(eng._lib.kr_moe_prefill(eng._h, 0, xd.data_ptr(), idd.data_ptr(), wd.data_ptr(), got.data_ptr(), M, k, _lib.KR_OUT_F32, 0, st))
+    torch.cuda.synchronize()
+    r, g = ref.cpu().numpy(), got.cpu().numpy()
+    # the streaming reference itself against the oracle on a few rows (bit for bit)
+    for b in (0, 5, 77, M - 1):
+        sel = [(experts[i], wi) for i, wi in zip(ids[b], w[b]) if i >= 0]
+        orc = O.moe_forward_gguf([s[0] for s in sel], [s[1] for s in sel], act[b], sh, 1.5)
+        assert np.array_equal(r[b].view(np.uint32), orc.view(np.uint32)), b
+    err = float(np.abs(g - r).max()); scale = float(np.abs(r).max())
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/r02_gguf_prefill_err.txt", "a") as f:
+            f.write(f"H={H} I={I} types=({gu_t},{dn_t}) max|diff|={err:.3e} max|ref|={scale:.3e} rel={err / scale:.3e} rms_rel={float(np.sqrt(((g - r) ** 2).mean()) / np.sqrt((r ** 2).mean())):.3e}\n")
+    if gu_t == O.Q4_0:
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+    else:
+        assert np.isfinite(g).all() and err <= 2e-5 * scale, (err, scale)
+    # bf16 output + routed_only through the operator class
+    mgr = GpuPrefillManager(eng, k)
+    ob = mgr.forward(0, xd.view(torch.bfloat16), idd, wd, routed_only=True)
+    rb = torch.empty((M, H), dtype=torch.float32, device="cuda")
+    check(eng._lib.kr_moe_forward(eng._h, 0, xd.data_ptr(), idd.data_ptr(), wd.data_ptr(), rb.data_ptr(), M, k, _lib.KR_OUT_F32, 1, st))
+    torch.cuda.synchronize()
+    d2 = (ob.float() - rb).abs().max().item()
+    assert d2 <= 2 ** -7 * rb.abs().max().item() + 2e-5 * scale       # one bf16 rounding on top
+
+
+def test_synthetic_gguf_fill_and_prefill_runs():
+    """kr_fill_layer_synthetic_gguf (bench leg): finite outputs, decode and prompt-pass forms agree at the stated tolerance"""
+    import torch
+    from krasis_amd import KrasisEngine, ModelConfig, _lib
+    from krasis_amd._lib import check
+    H, I, E, k, M = 2048, 512, 16, 4, 96
+    eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, 1))
+    eng.fill_synthetic_gguf(O.Q4_K, O.Q4_K, seed=5)
+    rng = np.random.default_rng(2)
+    act = rand_bf16(rng, (M, H), 0.5); ids = np.stack([rng.choice(E, k, replace=False) for _ in range(M)]).astype(np.int32)
+    w = rng.random((M, k)).astype(np.float32)
+    xd = torch.from_numpy(act.view(np.int16)).cuda(); idd = torch.from_numpy(ids).cuda(); wd = torch.from_numpy(w).cuda()
+    ref = torch.empty((M, H), dtype=torch.float32, device="cuda"); got = torch.empty_like(ref)
+    st = torch.cuda.current_stream().cuda_stream or 1
+    check(eng._lib.kr_moe_forward(eng._h, 0, xd.data_ptr(), idd.data_ptr(), wd.data_ptr(), ref.data_ptr(), M, k, _lib.KR_OUT_F32, 0, st))
+    check(eng._lib.kr_moe_prefill(eng._h, 0, xd.data_ptr(), idd.data_ptr(), wd.data_ptr(), got.data_ptr(), M, k, _lib.KR_OUT_F32, 0, st))
+    torch.cuda.synchronize()
+    r, g = ref.cpu().numpy(), got.cpu().numpy()
+    assert np.isfinite(r).all() and np.abs(r).max() > 0
+    assert np.abs(g - r).max() <= 2e-5 * np.abs(r).max()
