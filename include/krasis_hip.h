@@ -162,6 +162,19 @@ int kr_moe_set_prefill_pairs(kr_engine* e, int pairs);
 int kr_combine_rows(kr_engine* e, const float* eo_rows, const int32_t* pair_row, const float* weights, void* out, int M, int topk,
                     int out_dtype, void* stream);
 
+/* ---- expert parallelism over RCCL inside the library (reference dataflow python/krasis/gpu_prefill.py:353-359,4140-4148 +
+ *      python/krasis/model.py:3131-3241).  One process per GPU; rank r's engine is configured with ITS experts only (contiguous slice
+ *      [r * floor(E/R), ...), the last rank takes the remainder) as local experts 0..n_local-1.  kr_moe_prefill_ep takes this rank's SHARD of
+ *      the tokens with GLOBAL expert ids: every (token, slot) row travels once to the rank that owns its expert (ncclSend / ncclRecv groups
+ *      -- xGMI is a full mesh, no ring), runs through that rank's expert GEMMs and returns; the source rank combines its rows in routing
+ *      order.  With f32 return rows the result equals single-GPU kr_moe_prefill bit for bit; return_bf16 halves the return bytes for one
+ *      extra rounding per row.  Bootstrap: rank 0 calls kr_ep_unique_id, the host carries the 128 bytes to the other ranks. ---- */
+int kr_ep_unique_id(void* id_out128);
+int kr_ep_init(kr_engine* e, int world, int rank, int n_experts_total, const void* id128 /* NULL when world == 1 */, int return_bf16);
+int kr_ep_destroy(kr_engine* e);
+int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids_global, const float* weights, void* out, int M, int topk,
+                      int out_dtype, int routed_only, void* stream);
+
 int kr_synchronize(kr_engine* e);
 
 /* ================================================================================================

@@ -208,6 +208,7 @@ kr_engine* kr_engine_new_bare(int device) {
 
 extern "C" void kr_engine_destroy(kr_engine* e) {
     if (!e) return;
+    (void)kr_ep_destroy(e);
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& l : e->layers) {

@@ -88,7 +88,9 @@ struct kr_engine {
     // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
     bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};
     std::mutex mu;
+    struct kr_ep_state* ep = nullptr;   // expert parallelism (kr_ep.cpp): communicator, exchange buffers
 };
+extern "C" int kr_ep_destroy(kr_engine* e);
 
 bool is_device_ptr(const void* p);
 kr_engine* kr_engine_new_bare(int device);   // device + stream only (a decode store created before its MoE engine)

@@ -19,3 +19,10 @@ void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_
                        int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, hipStream_t st);
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                           int out_bf16, hipStream_t st);
+void kr_launch_pf_combine_bf16rows(const uint16_t* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
+                                   int out_bf16, hipStream_t st);
+// expert parallelism helpers (kr_ep.cpp)
+void kr_launch_ep_dest(const int32_t* ids, int n, int E_total, int per, int world, int32_t* dest, int32_t* lid, hipStream_t st);
+void kr_launch_ep_gather(const uint16_t* x, const int* row_pair, const int32_t* lid, int topk, int H, const int* n_rows, int max_rows, uint16_t* rows, int32_t* row_lid,
+                         hipStream_t st);
+void kr_launch_ep_rows_bf16(const float* in, uint16_t* out, size_t n, hipStream_t st);

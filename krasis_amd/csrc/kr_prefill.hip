@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(1024) kr_pf_scan_kernel(const int* __restrict_
     if (t == 0) {
         int o = 0, tl = 0;
         for (int e = 0; e < E; e++) { s_off[e] = o; s_tile[e] = tl; o += counts[e]; tl += (counts[e] + PF_BM - 1) / PF_BM; }
-        s_off[E] = o; s_tile[E] = tl; n_tiles_out[0] = tl;
+        s_off[E] = o; s_tile[E] = tl; n_tiles_out[0] = tl; n_tiles_out[1] = o;   // [1]: rows in total (valid pairs)
     }
     __syncthreads();
     for (int e = t; e < E; e += 1024) {
@@ -181,7 +181,8 @@ struct KrPfGemmArgs {
 // ------------------------------------------------------------------------------------------
 // combine: out[t] = sum_s w[t][s] * eo[row(t,s)] in routing order (moe.rs:661-667); shared: rsf*out + shared (moe.rs:703-706)
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) kr_pf_combine_kernel(const float* __restrict__ eo, const int* __restrict__ pair_row, const float* __restrict__ wts,
+template <bool ROWS_BF16>
+__global__ void __launch_bounds__(256) kr_pf_combine_kernel(const void* __restrict__ eo_v, const int* __restrict__ pair_row, const float* __restrict__ wts,
                                                            int topk, int H, const float* __restrict__ shared_eo, float rsf, void* out, int out_bf16) {
     const int t = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (j >= H) return;
@@ -189,7 +190,8 @@ __global__ void __launch_bounds__(256) kr_pf_combine_kernel(const float* __restr
     for (int s = 0; s < topk; s++) {
         const int r = pair_row[(size_t)t * topk + s];
         if (r < 0) continue;
-        acc += wts[(size_t)t * topk + s] * eo[(size_t)r * H + j];
+        const float v = ROWS_BF16 ? kr_bf16_to_f32(reinterpret_cast<const uint16_t*>(eo_v)[(size_t)r * H + j]) : reinterpret_cast<const float*>(eo_v)[(size_t)r * H + j];
+        acc += wts[(size_t)t * topk + s] * v;
     }
     if (shared_eo) acc = rsf * acc + shared_eo[(size_t)t * H + j];
     if (out_bf16) reinterpret_cast<uint16_t*>(out)[(size_t)t * H + j] = kr_f32_to_bf16(acc);
@@ -234,5 +236,48 @@ void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_
 }
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                           int out_bf16, hipStream_t st) {
-    hipLaunchKernelGGL(kr_pf_combine_kernel, dim3((H + 255) / 256, M), dim3(256), 0, st, eo, pair_row, wts, topk, H, shared_eo, rsf, out, out_bf16);
+    hipLaunchKernelGGL(kr_pf_combine_kernel<false>, dim3((H + 255) / 256, M), dim3(256), 0, st, (const void*)eo, pair_row, wts, topk, H, shared_eo, rsf, out, out_bf16);
+}
+void kr_launch_pf_combine_bf16rows(const uint16_t* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
+                                   int out_bf16, hipStream_t st) {
+    hipLaunchKernelGGL(kr_pf_combine_kernel<true>, dim3((H + 255) / 256, M), dim3(256), 0, st, (const void*)eo, pair_row, wts, topk, H, shared_eo, rsf, out, out_bf16);
+}
+
+// ------------------------------------------------------------------------------------------
+// expert parallelism (kr_ep.cpp): destination rank + local expert id of every (token, slot) pair; rows gathered in destination order
+// ------------------------------------------------------------------------------------------
+__global__ void kr_ep_dest_kernel(const int32_t* __restrict__ ids, int n, int E_total, int per, int world, int32_t* __restrict__ dest, int32_t* __restrict__ lid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = ids[i];
+    if (e < 0 || e >= E_total) { dest[i] = -1; lid[i] = -1; return; }
+    int d = e / per; if (d > world - 1) d = world - 1;          // the last rank takes the remainder (gpu_prefill.py:353-359)
+    dest[i] = d; lid[i] = e - d * per;
+}
+// send row r = x[token of pair row_pair[r]] (bf16 [H]) and its local expert id; grid (n_rows), H/8 threads
+__global__ void kr_ep_gather_kernel(const uint16_t* __restrict__ x, const int* __restrict__ row_pair, const int32_t* __restrict__ lid, int topk, int H,
+                                    const int* __restrict__ n_rows, uint16_t* __restrict__ rows, int32_t* __restrict__ row_lid) {
+    const int r = blockIdx.x;
+    if (r >= n_rows[0]) return;
+    const int pair = row_pair[r];
+    const u32x4* src = reinterpret_cast<const u32x4*>(x + (size_t)(pair / topk) * H);
+    u32x4* dst = reinterpret_cast<u32x4*>(rows + (size_t)r * H);
+    for (int c = threadIdx.x; c < H / 8; c += blockDim.x) dst[c] = src[c];
+    if (threadIdx.x == 0) row_lid[r] = lid[pair];
+}
+// f32 rows -> bf16 rows (RNE) for the return leg
+__global__ void kr_ep_rows_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = kr_f32_to_bf16(in[i]);
+}
+void kr_launch_ep_dest(const int32_t* ids, int n, int E_total, int per, int world, int32_t* dest, int32_t* lid, hipStream_t st) {
+    hipLaunchKernelGGL(kr_ep_dest_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E_total, per, world, dest, lid);
+}
+void kr_launch_ep_gather(const uint16_t* x, const int* row_pair, const int32_t* lid, int topk, int H, const int* n_rows, int max_rows, uint16_t* rows, int32_t* row_lid,
+                         hipStream_t st) {
+    if (max_rows <= 0) return;
+    hipLaunchKernelGGL(kr_ep_gather_kernel, dim3(max_rows), dim3(H / 8 < 256 ? H / 8 : 256), 0, st, x, row_pair, lid, topk, H, n_rows, rows, row_lid);
+}
+void kr_launch_ep_rows_bf16(const float* in, uint16_t* out, size_t n, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(kr_ep_rows_bf16_kernel, dim3(2048), dim3(256), 0, st, in, out, n);
 }

@@ -111,6 +111,52 @@ class ExpertParallelMoE:
         return self.forward_alltoall(layer, x, ids, w, combine)
 
 
+class ExpertParallel:
+    """Expert parallelism INSIDE libkrasis_hip.so over RCCL (kr_ep_init / kr_moe_prefill_ep, csrc/kr_ep.cpp): the product path.  `engine` is this
+    rank's engine, configured with its own expert slice as local experts 0..n_local-1; tokens are sharded over the ranks and carry GLOBAL expert
+    ids.  The RCCL unique id of rank 0 travels over the caller's torch.distributed group (any backend) -- the only use of torch here.
+    `ExpertParallelMoE` above is the same dataflow written against torch.distributed collectives; it exists so the sharding / ownership /
+    combine logic can be exercised on CPU with gloo."""
+
+    def __init__(self, engine, num_experts_total: int, world: int = 1, rank: int = 0, dist_module=None, return_bf16: bool = True, group=None):
+        import ctypes as C
+        from ._lib import check
+        self.engine, self.world, self.rank = engine, world, rank
+        lib = engine._lib
+        idbuf = (C.c_char * 128)()
+        if world > 1:
+            if dist_module is None:
+                raise ValueError("world > 1 needs a torch.distributed module to carry the RCCL unique id")
+            if rank == 0:
+                check(lib.kr_ep_unique_id(idbuf))
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist_module.get_backend(group) == "nccl" else torch.device("cpu")
+            t = torch.frombuffer(bytearray(bytes(idbuf)), dtype=torch.uint8).clone().to(dev)
+            dist_module.broadcast(t, src=0, group=group)
+            raw = bytes(t.cpu().numpy().tobytes())
+            idbuf = (C.c_char * 128).from_buffer_copy(raw)
+        check(lib.kr_ep_init(engine._h, world, rank, num_experts_total, idbuf if world > 1 else None, int(return_bf16)))
+
+    def forward(self, layer: int, x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, out: torch.Tensor = None, routed_only: bool = True) -> torch.Tensor:
+        """x bf16 [M, H] (this rank's tokens), ids i32 [M, k] global expert ids, w f32 [M, k] -> bf16 (or f32, by out.dtype) [M, H]"""
+        from . import _lib
+        from ._lib import check
+        M, H = x.shape
+        if out is None:
+            out = torch.empty((M, H), dtype=torch.bfloat16, device=x.device)
+        od = _lib.KR_OUT_BF16 if out.dtype == torch.bfloat16 else _lib.KR_OUT_F32
+        st = torch.cuda.current_stream(x.device).cuda_stream or 1
+        check(self.engine._lib.kr_moe_prefill_ep(self.engine._h, layer, x.data_ptr(), ids.data_ptr(), w.data_ptr(), out.data_ptr(), M, ids.shape[1], od,
+                                                 int(routed_only), st))
+        return out
+
+    def synchronize(self) -> None:
+        self.engine.synchronize()
+
+    def close(self) -> None:
+        from ._lib import check
+        check(self.engine._lib.kr_ep_destroy(self.engine._h))
+
+
 def engine_row_ops(engine) -> Tuple[RowOps, Callable]:
     """Bind the row operators to libkrasis_hip.so (GPU).  `engine` holds this rank's expert slice as experts 0..n_local-1."""
     from . import _lib

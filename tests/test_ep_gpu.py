@@ -29,3 +29,36 @@ def test_alltoall_path_equals_single_gpu(M):
     rep = ExpertParallelMoE(ops, E, mode="replicated").forward(0, xt, it, wt)
     torch.cuda.synchronize()
     assert torch.equal(rep.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("M,ret_bf16,shared", [(7, False, False), (130, False, True), (130, True, False), (300, True, True)])
+def test_library_expert_parallel_world1(M, ret_bf16, shared):
+    """kr_ep_init / kr_moe_prefill_ep (csrc/kr_ep.cpp) at world 1: owner sort on the device, row gather, expert GEMMs on top-1 rows, combine in routing
+    order.  f32 return rows: bit-identical to kr_moe_prefill / kr_moe_forward; bf16 return rows: one extra bf16 rounding per expert row."""
+    import torch
+    from krasis_amd import KrasisEngine, ModelConfig, _lib
+    from krasis_amd._lib import check
+    from krasis_amd.ep import ExpertParallel
+    H, I, E, k = 256, 128, 8, 3
+    rng = np.random.default_rng(M + 17)
+    experts = make_experts(rng, E, H, I)
+    sh = make_experts(rng, 1, H, I)[0] if shared else None
+    eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, 1, 1 if shared else 0, 2.0)); upload(eng, 0, experts, sh)
+    x = rand_bf16(rng, (M, H)); ids = np.stack([rng.choice(E, k, replace=False) for _ in range(M)]).astype(np.int32); ids[1, 2] = -1; ids[3, :] = -1
+    w = rng.random((M, k)).astype(np.float32)
+    xt = torch.from_numpy(x.view(np.int16)).cuda().view(torch.bfloat16); it = torch.from_numpy(ids).cuda(); wt = torch.from_numpy(w).cuda()
+    ep = ExpertParallel(eng, E, 1, 0, None, return_bf16=ret_bf16)
+    got = torch.empty((M, H), dtype=torch.float32, device="cuda")
+    ep.forward(0, xt, it, wt, got, routed_only=not shared)
+    ref = torch.empty((M, H), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream or 1
+    check(eng._lib.kr_moe_forward(eng._h, 0, xt.data_ptr(), it.data_ptr(), wt.data_ptr(), ref.data_ptr(), M, k, _lib.KR_OUT_F32, int(not shared), st))
+    torch.cuda.synchronize(); eng.synchronize()
+    if not ret_bf16:
+        assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+    else:
+        assert (got - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    got2 = ep.forward(0, xt, it, wt, routed_only=not shared)          # bf16 output, second call reuses the buffers
+    torch.cuda.synchronize(); eng.synchronize()
+    assert (got2.float() - ref).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+    ep.close()
