@@ -374,7 +374,8 @@ def profile_kinds(st, kvm, P=5):
     return per_kind_us, per_launch_us, n_per_step
 
 
-def long_context(st, kv_long, torch, kv_name):
+def long_context(st, kv_long, torch, kv_name, fast=False):
+    st.set_attention_mode(fast)
     st.fill_state_synthetic(kv_long, 7)
     for i in range(3):
         st.decode_step(0, kv_long - 6 + i)
@@ -384,7 +385,10 @@ def long_context(st, kv_long, torch, kv_name):
         st.decode_step(0, kv_long - 2)
     torch.cuda.synchronize()
     d1 = (time.perf_counter() - t1) / 20
-    return {"kv_max_seq": kv_long, "position": kv_long - 2, "kv": kv_name, "ms_per_step": d1 * 1e3, "tok_s": 1.0 / d1}
+    st.set_attention_mode(False)
+    return {"kv_max_seq": kv_long, "position": kv_long - 2, "kv": kv_name, "ms_per_step": d1 * 1e3, "tok_s": 1.0 / d1,
+            "attention": "fast: split-KV softmax + p.v, log-sum-exp merge (~1e-6 relative to the exact order)" if fast else
+                         "exact: the reference's sequential softmax sum / p.v order (bit-identical to the CPU decode)"}
 
 
 def side_config(name, rank, local_rank, args, torch):
@@ -592,8 +596,11 @@ def main():
                 side["prefill"] = runs[0]
         if not args.no_long_context:          # the same decode step late in a long cache
             try:
-                side["decode_long_context"] = long_context(st, 8192, torch, "FP8-E4M3" if kv_fp8 else "FP16")
-                side["decode_long_context_32k"] = long_context(st, 32768, torch, "FP8-E4M3" if kv_fp8 else "FP16")
+                kvn = "FP8-E4M3" if kv_fp8 else "FP16"
+                side["decode_long_context"] = long_context(st, 8192, torch, kvn)
+                side["decode_long_context_32k"] = long_context(st, 32768, torch, kvn)
+                side["decode_long_context_fast"] = long_context(st, 8192, torch, kvn, fast=True)
+                side["decode_long_context_32k_fast"] = long_context(st, 32768, torch, kvn, fast=True)
             except Exception as ex:
                 side["decode_long_context"] = {"error": repr(ex)}
 

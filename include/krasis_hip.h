@@ -229,7 +229,14 @@ int kr_decode_finalize(kr_decode_store* s);
  * kv_k / kv_v buffers of kr_decode_set_state / kr_decode_get_state then hold 1-byte elements. */
 #define KR_KV_FP16 0
 #define KR_KV_FP8_E4M3 1
-int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype);                                                                        /* decode.rs:2471 */
+int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype);
+/* numerics of attention over LONG caches / long prompts (north_star: fp tolerance outside the router ids).  KR_ATTN_EXACT (default): the
+ * reference's sequential softmax sum and p.v order, bit-identical to decode.rs:4194-4281.  KR_ATTN_FAST: decode caches longer than 1024
+ * positions are split over (256-position chunk x KV head) workgroups and merged by log-sum-exp (same products and exponentials, another
+ * summation order: ~1e-6 relative).  Call before the first step (a captured graph is rebuilt). */
+#define KR_ATTN_EXACT 0
+#define KR_ATTN_FAST 1
+int kr_decode_set_attention_mode(kr_decode_store* s, int mode);                                                                        /* decode.rs:2471 */
 /* Whole-model prompt pass.  Replaces the reference's GPU prefill (python/krasis/model.py forward_prefill_layer_grouped / server_prefill,
  * layer.py:242-461, attention.py:496-687, linear_attention.py:695-845 -- third-party kernels) AND the GPU->CPU state hand-off
  * (decode_setup.py:232-278): tokens[0..n) (host ints) at positions start_pos.. are run through every layer in chunks; afterwards the

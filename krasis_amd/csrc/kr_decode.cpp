@@ -68,7 +68,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                            &l.w_kc, &l.w_vc, &l.kv_a_norm, &l.q_a_norm, &l.mla_cos, &l.mla_sin}) b->release();
     for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
-                      &s->hid2, &s->res2, &s->r_counter, &s->gqa_scores, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_vlogits, &s->pf_nll, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
+                      &s->hid2, &s->res2, &s->r_counter, &s->gqa_scores, &s->fd_o, &s->fd_ml, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_vlogits, &s->pf_nll, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     for (hipEvent_t ev : s->pf_events) (void)hipEventDestroy(ev);
     for (hipStream_t ps : s->pf_side) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
     if (s->own_eng) kr_engine_destroy(s->eng);
@@ -544,6 +544,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             const bool o_img = img_ok && img_w(L.o_wid) && L.hd % 128 == 0 && s->weights[L.o_wid]->cols == L.nh * L.hd;
             a.img_out = o_img ? s->img_attn.p : nullptr;
             a.sc_g = s->kv_max_seq > s->gqa_split_min ? (float*)s->gqa_scores.p : nullptr;
+            if (s->attn_fast && a.sc_g) { a.fd_o = (float*)s->fd_o.p; a.fd_ml = (float*)s->fd_ml.p; }
             PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
             if (o_img) PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->img_attn.p, 2, hid, st));
             else PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
@@ -654,6 +655,10 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
     for (const DLayer& L : s->layers)            // outside capture: the attention kernel's LDS window (scores + one stage of cache rows)
         if (L.hd > 0 && L.q_wid >= 0) {
             if (s->kv_max_seq > s->gqa_split_min && s->gqa_scores.ensure((size_t)L.nh * s->kv_max_seq * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
+            if (s->attn_fast && s->kv_max_seq > s->gqa_split_min) {
+                const size_t nch = ((size_t)s->kv_max_seq + 255) / 256;
+                if (s->fd_o.ensure((size_t)L.nh * L.hd * nch * 4) || s->fd_ml.ensure((size_t)L.nh * nch * 8)) return kr_fail(KR_ERR_HIP, "hipMalloc of the split-KV partials failed");
+            }
             const int pr = kr_gqa_attn_prepare(s->kv_max_seq, L.hd, s->kv_fp8);
             if (pr) return kr_fail(pr == -1 ? KR_ERR_VALUE : KR_ERR_HIP, "GQA decode attention: kv_max_seq %d with head_dim %d does not fit the 160 KiB LDS window", s->kv_max_seq, L.hd);
         }
@@ -690,6 +695,16 @@ extern "C" int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype) {
     if (kv_dtype != 0 && kv_dtype != 1) return kr_fail(KR_ERR_VALUE, "kv_dtype %d unknown (0 = FP16, 1 = FP8-E4M3)", kv_dtype);
     if (s->kv_fp8 != kv_dtype) for (auto& L : s->layers) if (L.attn == ATTN_GQA || L.attn == ATTN_MLA) { L.kv_k.release(); L.kv_v.release(); }
     s->kv_fp8 = kv_dtype; s->graph_ok = false;
+    return KR_OK;
+}
+
+// attention numerics of LONG caches: KR_ATTN_EXACT (default) keeps the reference's sequential softmax sum and p.v order (bit-identical to
+// decode.rs:4194-4281); KR_ATTN_FAST splits the cache over many workgroups and merges the partials (log-sum-exp) -- same products, another
+// summation order, ~1e-6 relative.  Router ids, every matvec and the short-cache kernels are unaffected.
+extern "C" int kr_decode_set_attention_mode(kr_decode_store* s, int mode) {
+    if (int rc = chk_store(s)) return rc;
+    if (mode != 0 && mode != 1) return kr_fail(KR_ERR_VALUE, "attention mode %d unknown (0 = exact order, 1 = fast split-KV)", mode);
+    s->attn_fast = mode; s->graph_ok = false;
     return KR_OK;
 }
 

@@ -19,6 +19,7 @@ struct KrGqaArgs {
     int gated, nh, nkv, hd; float eps, sm_scale;
     void* img_out;   // optional: INT16 image of attn_out for the o-projection launch (hd % 128 == 0)
     float* sc_g;     // long caches: [nh][max_seq] score scratch -- the scores are computed by (nh x max_seq/256) workgroups in their own launch
+    float *fd_o, *fd_ml;   // fast (tolerance) mode: split-KV partials [nkv][chunks][G][hd] and (max, sum) [nh][chunks][2]; null = exact order
 };
 
 int kr_gqa_attn_prepare(int max_seq, int hd, int fp8);   // 0, -1 (scores + stage exceed 160 KiB of LDS), -2 (HIP refused)

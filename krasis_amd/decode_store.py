@@ -186,6 +186,11 @@ class CpuDecodeStore:
         """GQA KV cache element type: FP16 (reference CPU decode, default) or FP8-E4M3 (reference GPU cache, kv_cache.py:38)."""
         self._need(); check(self._lib.kr_decode_set_kv_dtype(self._h, 1 if fp8_e4m3 else 0))
 
+    def set_attention_mode(self, fast: bool) -> None:
+        """False (default): the reference's sequential softmax / p.v order (bit-exact).  True: split-KV attention with a log-sum-exp merge for
+        long caches -- tolerance mode (~1e-6 relative), many workgroups instead of one per head."""
+        self._need(); check(self._lib.kr_decode_set_attention_mode(self._h, 1 if fast else 0))
+
     def finalize_decode(self) -> None:
         self._need()
         self._push_routes()

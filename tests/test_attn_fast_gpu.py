@@ -1,0 +1,58 @@
+"""Tolerance-mode attention for long caches (kr_decode_set_attention_mode, KR_ATTN_FAST): split-KV softmax + p.v with a log-sum-exp merge.
+The exact kernels (reference order, bit-identical to decode.rs:4194-4281) are the yardstick: the same decode steps are run in both modes and
+the logits compared at a STATED tolerance -- same products and libm exponentials, another f32 summation order:
+    max |logits_fast - logits_exact| <= 2e-4 * max |logits_exact|          (measured ~1e-6 .. 1e-5; INT16 re-quantisation of the attention output
+                                                                            in the o-projection can move a value by one quantisation step)
+and the greedy token is unchanged.  Router top-k ids must be identical (north_star: bit-exact ids)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.test_decode_gpu import build
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.mark.parametrize("hd,fp8,kv_max", [(256, False, 1300), (128, True, 1300), (64, False, 2100), (256, True, 4400)])
+def test_fast_attention_matches_exact_within_tolerance(hd, fp8, kv_max):
+    outs = {}
+    for mode in (False, True):
+        st, eng, orc, keep, d = build(seed=31, kv_max=kv_max, hd=hd)
+        if fp8:
+            st.set_kv_dtype(True)
+            rng = np.random.default_rng(5)
+            kv = {li: (O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)),
+                       O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F))) for li, kind in enumerate(d["kinds"]) if kind == "gqa"}
+            n = len(d["kinds"]); ptr = lambda a: a.ctypes.data
+            st.set_decode_state(5, d["kv_max"], [ptr(kv[i][0]) if i in kv else 0 for i in range(n)], [ptr(kv[i][1]) if i in kv else 0 for i in range(n)],
+                                [ptr(x) if x is not None else 0 for x in d["state"]["conv"]], [ptr(x) if x is not None else 0 for x in d["state"]["recur"]])
+        st.set_attention_mode(mode)
+        res = []
+        tok = 5
+        for pos in [3, 255, 256, 700, 1023, 1024, kv_max - 1]:
+            lg = np.empty(d["V"], F); st.decode_step(tok, pos, lg.ctypes.data); res.append(lg.copy())
+            tok = int(np.argmax(res[-1])) if mode is False else outs[False][1][len(res) - 1]      # both runs are fed the exact run's tokens
+        outs[mode] = (res, [int(np.argmax(r)) for r in res])
+    worst = 0.0
+    for a, b in zip(outs[False][0], outs[True][0]):
+        worst = max(worst, float(np.abs(a - b).max() / np.abs(a).max()))
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/r02_attn_fast_err.txt", "a") as f:
+            f.write(f"hd={hd} fp8={fp8} kv_max={kv_max} worst_rel={worst:.3e}\n")
+    assert worst <= 2e-4, worst
+    assert outs[False][1] == outs[True][1]
+
+
+def test_fast_mode_leaves_short_caches_bit_exact():
+    """caches up to 1024 positions never take the split path: fast mode must be bit-identical there"""
+    st, eng, orc, keep, d = build(seed=3, kv_max=300)
+    st.set_attention_mode(True)
+    tok = 7
+    for pos in [5, 128, 299]:
+        lg = np.empty(d["V"], F); st.decode_step(tok, pos, lg.ctypes.data)
+        ref = orc.step(tok, pos)
+        assert np.array_equal(lg.view(np.uint32), ref.view(np.uint32)), pos
+        tok = O.sample_greedy(ref)
