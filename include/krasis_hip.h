@@ -233,7 +233,7 @@ int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype);
 /* numerics of attention over LONG caches / long prompts (north_star: fp tolerance outside the router ids).  KR_ATTN_EXACT (default): the
  * reference's sequential softmax sum and p.v order, bit-identical to decode.rs:4194-4281.  KR_ATTN_FAST: decode caches longer than 1024
  * positions are split over (256-position chunk x KV head) workgroups and merged by log-sum-exp (same products and exponentials, another
- * summation order: ~1e-6 relative).  Call before the first step (a captured graph is rebuilt). */
+ * summation order: logits within ~1e-4 relative, tests state 5e-4).  Call before the first step (a captured graph is rebuilt). */
 #define KR_ATTN_EXACT 0
 #define KR_ATTN_FAST 1
 int kr_decode_set_attention_mode(kr_decode_store* s, int mode);                                                                        /* decode.rs:2471 */

@@ -700,7 +700,7 @@ extern "C" int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype) {
 
 // attention numerics of LONG caches: KR_ATTN_EXACT (default) keeps the reference's sequential softmax sum and p.v order (bit-identical to
 // decode.rs:4194-4281); KR_ATTN_FAST splits the cache over many workgroups and merges the partials (log-sum-exp) -- same products, another
-// summation order, ~1e-6 relative.  Router ids, every matvec and the short-cache kernels are unaffected.
+// summation order; logits within ~1e-4 relative.  Router ids, every matvec and the short-cache kernels are unaffected.
 extern "C" int kr_decode_set_attention_mode(kr_decode_store* s, int mode) {
     if (int rc = chk_store(s)) return rc;
     if (mode != 0 && mode != 1) return kr_fail(KR_ERR_VALUE, "attention mode %d unknown (0 = exact order, 1 = fast split-KV)", mode);

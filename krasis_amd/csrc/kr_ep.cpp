@@ -79,7 +79,7 @@ extern "C" int kr_ep_unique_id(void* id_out128) {
 // (world == 1: may be NULL, no communicator is created).  return_bf16 != 0: expert rows come back as bf16 instead of f32.
 extern "C" int kr_ep_init(kr_engine* e, int world, int rank, int n_experts_total, const void* id128, int return_bf16) {
     if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
-    if (world < 1 || rank < 0 || rank >= world) return kr_fail(KR_ERR_VALUE, "bad world / rank (%d / %d)", world, rank);
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return kr_fail(KR_ERR_VALUE, "bad world / rank (%d / %d; at most 64 ranks)", world, rank);
     if (n_experts_total < world) return kr_fail(KR_ERR_VALUE, "%d experts cannot be split over %d ranks", n_experts_total, world);
     const int per = n_experts_total / world, n_local = rank == world - 1 ? n_experts_total - per * (world - 1) : per;
     if (e->cfg.n_routed_experts < n_local)      // a replica that holds more experts than its slice serves the first n_local of them
@@ -141,7 +141,7 @@ extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, co
     so.tile_expert = ib; so.tile_row0 = ib + max_tiles; so.tile_rows = ib + 2 * max_tiles; ib += 3 * max_tiles;
     so.n_tiles = ib; ib += 4; so.row_pair = ib; so.pair_row = ib + np;
     kr_launch_ep_dest(ids, np, s->E_total, s->per, W, (int32_t*)s->dest.p, (int32_t*)s->lid.p, st);
-    kr_launch_pf_sort((const int32_t*)s->dest.p, M, topk, W, so, st);
+    kr_launch_ep_sort((const int32_t*)s->dest.p, np, W, so, st);
     kr_launch_ep_gather((const uint16_t*)x_bf16, so.row_pair, (const int32_t*)s->lid.p, topk, H, so.n_tiles + 1, np, (uint16_t*)s->rows.p, (int32_t*)s->row_lid.p, st);
     // ---- send counts of every rank: cnt[src][dst]
     if (W > 1) KR_NCCL(g_rccl.AllGather(so.counts, s->cnt_all.p, W, ncclInt32, s->comm, st));

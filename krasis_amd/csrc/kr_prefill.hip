@@ -254,6 +254,43 @@ __global__ void kr_ep_dest_kernel(const int32_t* __restrict__ ids, int n, int E_
     int d = e / per; if (d > world - 1) d = world - 1;          // the last rank takes the remainder (gpu_prefill.py:353-359)
     dest[i] = d; lid[i] = e - d * per;
 }
+// Owner sort for a handful of destinations (world <= 64): the token sort's count / scatter kernels issue one global atomic per pair on
+// counts[dest] / cursor[dest] -- with 8 destinations that is ~10 k atomics per address and layer (the same-address rate is ~90 per us).  Here a
+// workgroup counts its 256 pairs per destination in LDS and touches each global counter ONCE.
+__global__ void __launch_bounds__(256) kr_ep_count_kernel(const int32_t* __restrict__ dest, int n, int W, int* __restrict__ counts) {
+    __shared__ int c[64];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < 64) c[threadIdx.x] = 0;
+    __syncthreads();
+    const int d = i < n ? dest[i] : -1;
+    if (d >= 0) atomicAdd(&c[d], 1);
+    __syncthreads();
+    if ((int)threadIdx.x < W && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], c[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) kr_ep_scatter_kernel(const int32_t* __restrict__ dest, int n, int W, const int* __restrict__ offsets, int* __restrict__ cursor,
+                                                           int* __restrict__ row_pair, int* __restrict__ pair_row) {
+    __shared__ int c[64], base[64];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < 64) c[threadIdx.x] = 0;
+    __syncthreads();
+    const int d = i < n ? dest[i] : -1;
+    int r = 0;
+    if (d >= 0) r = atomicAdd(&c[d], 1);
+    __syncthreads();
+    if ((int)threadIdx.x < W) base[threadIdx.x] = c[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], c[threadIdx.x]) : 0;
+    __syncthreads();
+    if (i >= n) return;
+    if (d < 0) { pair_row[i] = -1; return; }
+    const int row = offsets[d] + base[d] + r;
+    row_pair[row] = i; pair_row[i] = row;
+}
+void kr_launch_ep_sort(const int32_t* dest, int n, int W, KrPfSort s, hipStream_t st) {
+    (void)hipMemsetAsync(s.counts, 0, (size_t)W * 4, st);
+    hipLaunchKernelGGL(kr_ep_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dest, n, W, s.counts);
+    hipLaunchKernelGGL(kr_pf_scan_kernel, dim3(1), dim3(1024), 0, st, s.counts, W, s.offsets, s.cursor, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles);
+    hipLaunchKernelGGL(kr_ep_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dest, n, W, s.offsets, s.cursor, s.row_pair, s.pair_row);
+}
+
 // send row r = x[token of pair row_pair[r]] (bf16 [H]) and its local expert id; grid (n_rows), H/8 threads
 __global__ void kr_ep_gather_kernel(const uint16_t* __restrict__ x, const int* __restrict__ row_pair, const int32_t* __restrict__ lid, int topk, int H,
                                     const int* __restrict__ n_rows, uint16_t* __restrict__ rows, int32_t* __restrict__ row_lid) {

@@ -188,7 +188,7 @@ class CpuDecodeStore:
 
     def set_attention_mode(self, fast: bool) -> None:
         """False (default): the reference's sequential softmax / p.v order (bit-exact).  True: split-KV attention with a log-sum-exp merge for
-        long caches -- tolerance mode (~1e-6 relative), many workgroups instead of one per head."""
+        long caches -- tolerance mode (logits within ~1e-4 relative), many workgroups instead of one per head."""
         self._need(); check(self._lib.kr_decode_set_attention_mode(self._h, 1 if fast else 0))
 
     def finalize_decode(self) -> None:

@@ -74,7 +74,7 @@ def test_moe_prefill_gguf_mfma(H, I, gu_t, dn_t, shared):
     """kr_moe_prefill on a native-GGUF layer (M >= 64): Q4_K / Q8_0 blocks staged raw in LDS, int8 MFMA per 32-wide sub-block and activation
     digit, per-sub-block scale / min epilogue.  The integer sums are exact; the f32 chain runs once per output over the sub-blocks instead of
     the AVX2 kernel's 8 lane chains + hsum (kr_gguf_prefill.hip header), so the result is compared with the bit-exact kr_moe_forward on the
-    same layer at a STATED TOLERANCE: |diff| <= 2e-5 * max|ref| (measured ~1e-6; Q4_K's out - corr cancellation is the widest case).
+    same layer at a STATED TOLERANCE: |diff| <= 2e-5 * max|ref| (measured on MI355X: 4.6e-7 Q4_K/Q4_K at the QCN shape, 2.5e-6 Q4_K + Q8_0 down).
     Types without an MFMA form must stay bit-identical."""
     import os
     import torch
@@ -102,6 +102,9 @@ def test_moe_prefill_gguf_mfma(H, I, gu_t, dn_t, shared):
     # the streaming reference itself against the oracle on a few rows (bit for bit)
     for b in (0, 5, 77, M - 1):
         sel = [(experts[i], wi) for i, wi in zip(ids[b], w[b]) if i >= 0]
+        if not sel and sh is None:
+            assert not r[b].any() and not g[b].any()          # every slot skipped, no shared expert: zeros
+            continue
         orc = O.moe_forward_gguf([s[0] for s in sel], [s[1] for s in sel], act[b], sh, 1.5)
         assert np.array_equal(r[b].view(np.uint32), orc.view(np.uint32)), b
     err = float(np.abs(g - r).max()); scale = float(np.abs(r).max())
