@@ -80,9 +80,17 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.k_cache = L.kv_k.p; a.v_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_out = B.q; a.gate = B.gate; a.attn_out = B.attn;
         a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.pos0 = pos0; a.eps = s->eps; a.sm_scale = L.sm_scale;
         if (s->max_rope_seq > 0 && pos0 + Cc > s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "prompt exceeds the rope table (%d)", s->max_rope_seq);
-        const int sc_ld = (pos0 + Cc + 63) & ~63;
-        float* scp = cx.scores;   // this chunk's arena (chunks in flight on other streams have their own)
-        if (kr_launch_pfm_gqa(a, Cc, scp, sc_ld, scp + (size_t)Cc * L.nh * sc_ld, st)) return kr_fail(KR_ERR_VALUE, "unsupported GQA geometry for the prompt pass");
+        bool flash = false;
+        if (s->attn_fast && L.hd <= 256 && L.hd % 8 == 0) {      // tolerance mode: flash attention on the matrix cores (same prep launch)
+            kr_launch_pfm_gqa_prep(a, Cc, st);
+            flash = 0 == kr_launch_pfm_gqa_flash(a, Cc, st);
+        }
+        if (!flash) {
+            if (!cx.scores) return kr_fail(KR_ERR_STATE, "internal: no score scratch for the exact attention passes");
+            const int sc_ld = (pos0 + Cc + 63) & ~63;
+            float* scp = cx.scores;   // this chunk's arena (chunks in flight on other streams have their own)
+            if (kr_launch_pfm_gqa(a, Cc, scp, sc_ld, scp + (size_t)Cc * L.nh * sc_ld, st)) return kr_fail(KR_ERR_VALUE, "unsupported GQA geometry for the prompt pass");
+        }
         if (oc != L.nh * L.hd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*hd", oc);
         kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
         if (int rc = pf_gemm(s, L.o_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;

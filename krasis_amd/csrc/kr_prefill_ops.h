@@ -35,3 +35,6 @@ int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out,
 // non-zero = unsupported geometry
 int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st);
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st);
+// FAST mode (kr_attn_flash.hip): causal flash attention on f16 MFMA after the same prep launch; non-zero = geometry not covered
+int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st);
+void kr_launch_pfm_gqa_prep(const KrPfmGqaArgs& a, int C, hipStream_t st);

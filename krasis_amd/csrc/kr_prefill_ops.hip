@@ -690,6 +690,9 @@ int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out,
     return 0;
 }
 int kr_pfm_gqa_tile(int nh, int nkv) { const int group = nh / nkv; int tt = PFA_TT_MAX / group; return tt < 1 ? 0 : tt; }
+void kr_launch_pfm_gqa_prep(const KrPfmGqaArgs& a, int C, hipStream_t st) {
+    hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, C), dim3(256), 0, st, a);
+}
 int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st) {
     const int group = a.nh / a.nkv, TT = kr_pfm_gqa_tile(a.nh, a.nkv);
     if (TT == 0 || a.hd > 256 || a.hd % 32 || a.nh % a.nkv) return 1;

@@ -57,3 +57,41 @@ def test_fast_mode_leaves_short_caches_bit_exact():
         ref = orc.step(tok, pos)
         assert np.array_equal(lg.view(np.uint32), ref.view(np.uint32)), pos
         tok = O.sample_greedy(ref)
+
+
+@pytest.mark.parametrize("hd,nh,fp8,n_tok,start,chunk", [(256, 16, False, 170, 37, 0), (256, 16, True, 170, 37, 64), (128, 8, False, 200, 0, 0), (128, 4, True, 130, 5, 50),
+                                                         (64, 16, False, 170, 37, 0), (64, 4, True, 90, 3, 0)])
+def test_flash_prompt_pass_matches_exact_within_tolerance(hd, nh, fp8, n_tok, start, chunk):
+    """prompt pass in FAST mode: causal flash attention on f16 MFMA (kr_attn_flash.hip: S^T = K Q^T, online softmax in f32, O^T += V^T P^T; q and
+    the probabilities rounded to f16) against the exact prompt pass (== token-by-token decode, bit for bit) of the same model and prompt.
+    STATED TOLERANCE on the last-position logits: max |fast - exact| <= 3e-3 * max |exact| (f16 q / p: 2^-11 per product, eight times finer than the
+    bf16 flash attention the reference's own GPU prefill uses); same greedy token.  Cache starts from random FP16 / E4M3 rows below `start`."""
+    outs = {}
+    for mode in (False, True):
+        st, eng, orc, keep, d = build(seed=11, kv_max=260, hd=hd, nh=nh)
+        if fp8:
+            st.set_kv_dtype(True)
+            rng = np.random.default_rng(5)
+            kv = {li: (O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)), O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)))
+                  for li, kind in enumerate(d["kinds"]) if kind == "gqa"}
+            n = len(d["kinds"]); ptr = lambda a: a.ctypes.data
+            st.set_decode_state(5, d["kv_max"], [ptr(kv[i][0]) if i in kv else 0 for i in range(n)], [ptr(kv[i][1]) if i in kv else 0 for i in range(n)],
+                                [ptr(x) if x is not None else 0 for x in d["state"]["conv"]], [ptr(x) if x is not None else 0 for x in d["state"]["recur"]])
+        st.set_attention_mode(mode)
+        if chunk:
+            st.set_prefill_chunk(chunk)
+        rng = np.random.default_rng(hd + nh)
+        toks = [int(x) for x in rng.integers(0, d["V"], n_tok)]
+        lg = np.empty(d["V"], F)
+        tok = st.prefill(toks, start, lg.ctypes.data)
+        nxt = np.empty(d["V"], F); st.decode_step(tok, start + n_tok, nxt.ctypes.data)      # decoding continues on the state the prompt pass left
+        outs[mode] = (lg.copy(), tok, nxt.copy())
+    a, b = outs[False][0], outs[True][0]
+    rel = float(np.abs(a - b).max() / np.abs(a).max())
+    rel2 = float(np.abs(outs[False][2] - outs[True][2]).max() / np.abs(outs[False][2]).max())
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/r02_attn_fast_err.txt", "a") as f:
+            f.write(f"flash prefill hd={hd} nh={nh} fp8={fp8} n={n_tok} chunk={chunk} rel={rel:.3e} next-step rel={rel2:.3e}\n")
+    assert np.isfinite(b).all() and rel <= 3e-3, rel
+    assert outs[False][1] == outs[True][1]
+    assert rel2 <= 3e-3, rel2
