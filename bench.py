@@ -579,21 +579,26 @@ def main():
             if args.prefill_depth:
                 st.set_prefill_depth(args.prefill_depth)
             macs = qcn_gemm_macs_per_token(L) if qcn else v2l_gemm_macs_per_token(L)
-            runs = []
-            for P in pf_list:
-                try:
-                    r = prefill_model(st, dims, macs, L, P, args.prefill_reps, torch)
-                    r["chunk"] = args.prefill_chunk or 1024; r["chunks_in_flight"] = args.prefill_depth or 3
-                except Exception as ex:
-                    r = {"tokens": P, "error": repr(ex)}
-                runs.append(r)
-            ok = [r for r in runs if "value" in r]
-            if ok:
-                side["prefill"] = dict(ok[0]); side["prefill"]["by_prompt_length"] = {str(r["tokens"]): round(r["value"], 1) for r in ok}
-                side["prefill"]["note"] = ("whole-model prompt pass; `value` is the first listed length, by_prompt_length holds every length of "
-                                           "--prefill-tokens (the reference benchmark's 20 434 / 35 139 / 49 863-token prompts, benchmark.py:434-505)")
-            else:
-                side["prefill"] = runs[0]
+            for key, fast in (("prefill", False), ("prefill_fast", True)):
+                st.set_attention_mode(fast)
+                runs = []
+                for P in pf_list:
+                    try:
+                        r = prefill_model(st, dims, macs, L, P, args.prefill_reps, torch)
+                        r["chunk"] = args.prefill_chunk or 1024; r["chunks_in_flight"] = args.prefill_depth or 3
+                    except Exception as ex:
+                        r = {"tokens": P, "error": repr(ex)}
+                    runs.append(r)
+                ok = [r for r in runs if "value" in r]
+                if ok:
+                    side[key] = dict(ok[0]); side[key]["by_prompt_length"] = {str(r["tokens"]): round(r["value"], 1) for r in ok}
+                    side[key]["attention"] = ("fast: causal flash attention on f16 MFMA (f32 online softmax; logits within ~1e-3 relative of the exact pass)" if fast else
+                                              "exact: the CPU decode's operation order per query (bit-identical to token-by-token decode), vector ALUs")
+                    side[key]["note"] = ("whole-model prompt pass; `value` is the first listed length, by_prompt_length holds every length of "
+                                         "--prefill-tokens (the reference benchmark's 20 434 / 35 139 / 49 863-token prompts, benchmark.py:434-505)")
+                else:
+                    side[key] = runs[0]
+            st.set_attention_mode(False)
         if not args.no_long_context:          # the same decode step late in a long cache
             try:
                 kvn = "FP8-E4M3" if kv_fp8 else "FP16"
