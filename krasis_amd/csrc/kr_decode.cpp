@@ -573,6 +573,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.attn_lat = (float*)s->latbuf.p; a.v_proj = (float*)s->attn_out.p;
             a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale;
             a.sc_g = s->kv_max_seq > s->mla_split_min ? (float*)s->gqa_scores.p : nullptr;
+            if (s->attn_fast && a.sc_g) { a.fast = 1; a.fd_o = (float*)s->fd_o.p; a.fd_ml = (float*)s->fd_ml.p; }
             PROF(PK_GQA, kr_launch_mla(a, s->kv_max_seq, st));
             PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }
@@ -666,6 +667,10 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
         if (L.attn == ATTN_MLA) {
             KrMlaArgs pa{}; pa.klr = L.klr; pa.rd = L.rd; pa.kv_fp8 = s->kv_fp8; kr_mla_attn_prepare(pa, s->kv_max_seq);
             if (s->kv_max_seq > s->mla_split_min && s->gqa_scores.ensure((size_t)L.nh * s->kv_max_seq * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
+            if (s->attn_fast && s->kv_max_seq > s->mla_split_min) {
+                const size_t nch = ((size_t)s->kv_max_seq + 255) / 256;
+                if (s->fd_o.ensure((size_t)L.nh * L.klr * nch * 4) || s->fd_ml.ensure((size_t)L.nh * nch * 8)) return kr_fail(KR_ERR_HIP, "hipMalloc of the split-KV partials failed");
+            }
         }
     kr_launch_set_step((KrStep*)s->step_dev.p, token, pos, st);   // by-value kernel arguments: no host slot shared between queued steps
     s->last_stream = st;

@@ -32,6 +32,7 @@ struct KrMlaArgs {   // decode.rs:2993-3252
     void *ckv_cache, *kpe_cache;       // [max_seq, klr] / [max_seq, rd], FP16 or (kv_fp8) E4M3 elements
     int kv_fp8;
     float* sc_g;                       // decode, long caches: [nh][max_seq] score scratch (scores in their own, head-shared launch)
+    float *fd_o, *fd_ml; int fast;     // FAST (tolerance) mode: split-KV partials (decode, long caches) / flash attention (prompt pass); fast = 0: exact order
     float *q_abs, *q_pe, *attn_lat, *v_proj;
     int nh, klr, nd, rd, vhd; float eps, sm_scale;
     // prompt pass (step == nullptr): token t = blockIdx.y (blockIdx.z for the w_vc launch) sits at position pos0 + t; row t of the

@@ -8,6 +8,7 @@
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
+#include "kr_attn_fd.h"
 #include <hip/hip_fp16.h>
 #include <cstdlib>
 
@@ -1070,178 +1071,15 @@ __global__ void __launch_bounds__(512) kr_gqa_pv_kernel(const KrGqaArgs a, int m
 }
 static size_t kr_gqa_pv_lds(int lds_seq, int hd, int fp8) { return ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15) + 2 * (size_t)hd * (KR_PV_ROWS * (fp8 ? 1 : 2) + 16); }
 
-// ---- FAST (tolerance) mode for long caches: split-KV softmax + p.v -------------------------------------------------------------------
-// The exact kernels above keep the reference's sequential order (sum of exponentials and p.v one position after the other, decode.rs:4236-
-// 4270), so the second launch is ONE workgroup per head walking the whole cache.  north_star asks for fp TOLERANCE outside the router, so
-// a second numerics mode (kr_decode_set_attention_mode) keeps the exact per-position scores (the scores launch is parallel already) and
-// replaces that launch by
-//   kr_gqa_fd_partial_kernel : one workgroup per (256-position chunk, KV head): local maximum, exponentials, local sum and the chunk's
-//                              sum_p p * v for ALL query heads that share the KV head (a V row is read once per G heads), f32 throughout;
-//   kr_gqa_fd_merge_kernel   : per head, the log-sum-exp merge of the chunk partials, the sigmoid gate and the o-projection image.
-// Same products, same exp (the libm twin), a different summation order: the attention output differs in its last bits; after the INT16
-// re-quantisation of the o-projection input the logits move by ~1e-4 relative (tests/test_attn_fast_gpu.py states 5e-4).
-#define KR_FD_CH 256
-template <int HD, bool FP8>
-__global__ void __launch_bounds__(256) kr_gqa_fd_partial_kernel(const KrGqaArgs a, int max_seq, int n_chunks) {
-    constexpr int NDG = HD / 4, NPL = 256 / NDG, GMAX = 8;           // 4 dims per thread; NPL position lanes
-    __shared__ __attribute__((aligned(16))) float P[KR_FD_CH][GMAX];   // probabilities (relative to the chunk maximum), [position][head of the group]
-    __shared__ float red[4][GMAX];
-    extern __shared__ __attribute__((aligned(16))) float ored[];       // [NPL][G][HD] partial outputs of the position lanes
-    const int c = blockIdx.x, kvh = blockIdx.y, t = threadIdx.x, G = a.nh / a.nkv;
-    const int seq = a.step->pos + 1, p0 = c * KR_FD_CH;
-    if (p0 >= seq) return;
-    const int n = min(KR_FD_CH, seq - p0);
-    // ---- probabilities of the chunk: thread t = position p0 + t, all G heads
-    float sv[GMAX];
-#pragma unroll
-    for (int g = 0; g < GMAX; g++) sv[g] = (g < G && t < n) ? a.sc_g[(size_t)(kvh * G + g) * max_seq + p0 + t] : -__builtin_inff();
-#pragma unroll
-    for (int g = 0; g < GMAX; g++) {
-        float m = sv[g];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if ((t & 63) == 0) red[t >> 6][g] = m;
-    }
-    __syncthreads();
-    float mx[GMAX], ls[GMAX];
-#pragma unroll
-    for (int g = 0; g < GMAX; g++) {
-        mx[g] = fmaxf(fmaxf(red[0][g], red[1][g]), fmaxf(red[2][g], red[3][g]));
-        const float pv = (g < G && t < n) ? kr_expf(sv[g] - mx[g]) : 0.0f;
-        P[t][g] = pv; ls[g] = pv;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < GMAX; g++) {
-        float v = ls[g];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if ((t & 63) == 0) red[t >> 6][g] = v;
-    }
-    __syncthreads();
-    if (t < G) {
-        const float l = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-        float* ml = a.fd_ml + ((size_t)(kvh * G + t) * n_chunks + c) * 2;
-        ml[0] = mx[t]; ml[1] = l;     // (mx[] is uniform across threads)
-    }
-    // ---- sum_p p * v: thread = (4 dims dg, position lane pl); positions pl, pl + NPL, ...
-    const int dg = t % NDG, pl = t / NDG, esz = FP8 ? 1 : 2, kvs = a.nkv * HD;
-    const unsigned char* vb = reinterpret_cast<const unsigned char*>(a.v_cache) + ((size_t)p0 * kvs + (size_t)kvh * HD + dg * 4) * esz;
-    float acc[GMAX][4];
-#pragma unroll
-    for (int g = 0; g < GMAX; g++) { acc[g][0] = 0.0f; acc[g][1] = 0.0f; acc[g][2] = 0.0f; acc[g][3] = 0.0f; }
-    constexpr int UN = 4;
-    for (int i0 = pl; i0 < n; i0 += NPL * UN) {
-        float v[UN][4];
-#pragma unroll
-        for (int u = 0; u < UN; u++) {
-            const int i = i0 + u * NPL;
-            if (i < n) {
-                if (FP8) {
-                    const uint32_t w = *reinterpret_cast<const uint32_t*>(vb + (size_t)i * kvs);
-                    v[u][0] = __builtin_amdgcn_cvt_f32_fp8((int)w, 0); v[u][1] = __builtin_amdgcn_cvt_f32_fp8((int)w, 1);
-                    v[u][2] = __builtin_amdgcn_cvt_f32_fp8((int)w, 2); v[u][3] = __builtin_amdgcn_cvt_f32_fp8((int)w, 3);
-                } else {
-                    const u32x2 w = *reinterpret_cast<const u32x2*>(vb + (size_t)i * kvs * 2);
-                    v[u][0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w.x & 0xFFFFu)); v[u][1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w.x >> 16));
-                    v[u][2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w.y & 0xFFFFu)); v[u][3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w.y >> 16));
-                }
-            } else { v[u][0] = 0.0f; v[u][1] = 0.0f; v[u][2] = 0.0f; v[u][3] = 0.0f; }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; u++) {
-            const int i = min(i0 + u * NPL, KR_FD_CH - 1);
-#pragma unroll
-            for (int g4 = 0; g4 < GMAX / 4; g4++) {
-                if (g4 * 4 < G) {
-                    const float4 pq = *reinterpret_cast<const float4*>(&P[i][g4 * 4]);
-                    const float pp[4] = {pq.x, pq.y, pq.z, pq.w};
-#pragma unroll
-                    for (int gg = 0; gg < 4; gg++)
-#pragma unroll
-                        for (int d = 0; d < 4; d++) acc[g4 * 4 + gg][d] = __builtin_fmaf(pp[gg], v[u][d], acc[g4 * 4 + gg][d]);
-                }
-            }
-        }
-    }
-    // ---- position lanes -> one partial per (head, dim)
-#pragma unroll
-    for (int g = 0; g < GMAX; g++)
-        if (g < G) *reinterpret_cast<float4*>(ored + ((size_t)(pl * G + g) * HD + dg * 4)) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
-    __syncthreads();
-    float* po = a.fd_o + ((size_t)(kvh * n_chunks + c) * G) * HD;
-    for (int o = t; o < G * HD; o += 256) {
-        float sum = 0.0f;
-#pragma unroll
-        for (int q = 0; q < NPL; q++) sum += ored[(size_t)q * G * HD + o];
-        po[o] = sum;
-    }
-}
-
-template <int HD>
-__global__ void __launch_bounds__(256) kr_gqa_fd_merge_kernel(const KrGqaArgs a, int n_chunks) {
-    __shared__ float wc[512]; __shared__ float qs[256]; __shared__ float red[2];
-    const int h = blockIdx.x, t = threadIdx.x, G = a.nh / a.nkv, kvh = h / G, g = h % G;
-    const int seq = a.step->pos + 1, nc = (seq + KR_FD_CH - 1) / KR_FD_CH;
-    const float* ml = a.fd_ml + (size_t)h * n_chunks * 2;
-    float mx = -__builtin_inff();
-    for (int c = t; c < nc; c += 256) mx = fmaxf(mx, ml[c * 2]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((t & 63) == 0) wc[t >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(wc[0], wc[1]), fmaxf(wc[2], wc[3]));
-    __syncthreads();
-    float l = 0.0f;
-    for (int c = t; c < nc; c += 256) { const float w = kr_expf(ml[c * 2] - mx); if (c < 512) wc[c] = w; l += w * ml[c * 2 + 1]; }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) l += __shfl_xor(l, off);
-    __shared__ float lred[4];
-    if ((t & 63) == 0) lred[t >> 6] = l;
-    __syncthreads();
-    const float inv = 1.0f / ((lred[0] + lred[1]) + (lred[2] + lred[3]));
-    if (t < HD) {
-        float o = 0.0f;
-        for (int c = 0; c < nc; c++) {
-            const float w = c < 512 ? wc[c] : kr_expf(ml[c * 2] - mx);
-            o = __builtin_fmaf(w, a.fd_o[((size_t)(kvh * n_chunks + c) * G + g) * HD + t], o);
-        }
-        o *= inv;
-        if (a.gated) { const float gt = a.gate[(size_t)h * HD + t]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
-        a.attn_out[(size_t)h * HD + t] = o;
-        if (a.img_out) qs[t] = o;
-    }
-    if (a.img_out) {   // hd % 128 == 0: the head's output is hd/128 whole quantization groups of the o-projection's input
-        __syncthreads();
-        const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(a.img_out), a.nh * HD, false);
-        constexpr int nch = HD / 8;
-        if (t < nch) {
-            float v8[8];
-            kr_load8(qs, t, v8);
-            float mx8 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; i++) mx8 = fmaxf(mx8, fabsf(v8[i]));
-            float scale, qinv;
-            kr_group_scale(mx8, scale, qinv);
-            int q8[8];
-            kr_quant8<false>(v8, qinv, q8);
-            const int gc = h * nch + t;
-            kr_store_chunk<false>(Lg, gc, q8);
-            if ((gc & 15) == 0) Lg.ascale[gc >> 4] = scale;
-        }
-    }
-    (void)red;
-}
+// ---- FAST (tolerance) mode for long caches: split-KV softmax + p.v (kr_attn_fd.h) ----
 static bool kr_gqa_fast_ok(const KrGqaArgs& a) { return a.fd_o && a.fd_ml && a.sc_g && (a.hd == 64 || a.hd == 128 || a.hd == 256) && a.nh % a.nkv == 0 && a.nh / a.nkv <= 8; }
 static void kr_launch_gqa_fast(const KrGqaArgs& a, int max_seq, hipStream_t s) {
-    const int nchunks = (max_seq + KR_FD_CH - 1) / KR_FD_CH, G = a.nh / a.nkv;
-    const size_t lds = (size_t)256 * G * 4 * 4;      // [NPL][G][HD] floats with NPL * HD == 1024
-    dim3 grid(nchunks, a.nkv);
-#define KR_FDP(H_, F_) hipLaunchKernelGGL((kr_gqa_fd_partial_kernel<H_, F_>), grid, dim3(256), lds, s, a, max_seq, nchunks)
-    if (a.hd == 256) { if (a.kv_fp8) KR_FDP(256, true); else KR_FDP(256, false); hipLaunchKernelGGL(kr_gqa_fd_merge_kernel<256>, dim3(a.nh), dim3(256), 0, s, a, nchunks); }
-    else if (a.hd == 128) { if (a.kv_fp8) KR_FDP(128, true); else KR_FDP(128, false); hipLaunchKernelGGL(kr_gqa_fd_merge_kernel<128>, dim3(a.nh), dim3(256), 0, s, a, nchunks); }
-    else { if (a.kv_fp8) KR_FDP(64, true); else KR_FDP(64, false); hipLaunchKernelGGL(kr_gqa_fd_merge_kernel<64>, dim3(a.nh), dim3(256), 0, s, a, nchunks); }
-#undef KR_FDP
+    KrFdArgs f{};
+    f.step = a.step; f.sc_g = a.sc_g; f.v_cache = a.v_cache; f.v_ld = a.nkv * a.hd; f.fd_o = a.fd_o; f.fd_ml = a.fd_ml; f.nh = a.nh; f.nkv = a.nkv;
+    f.gate = a.gate; f.gated = a.gated; f.out = a.attn_out; f.img_out = a.img_out;
+    if (a.hd == 256) kr_launch_fd<256, 8>(f, a.kv_fp8, max_seq, s);
+    else if (a.hd == 128) kr_launch_fd<128, 8>(f, a.kv_fp8, max_seq, s);
+    else kr_launch_fd<64, 8>(f, a.kv_fp8, max_seq, s);
 }
 
 // decode-step MoE epilogue (decode.rs:3343-3345, 3391-3402): hidden = moe (*rsf) + shared (*sigmoid(gate))

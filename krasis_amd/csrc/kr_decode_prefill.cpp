@@ -117,7 +117,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.kv_a_norm = (const float*)L.kv_a_norm.p; a.w_kc = (const float*)L.w_kc.p; a.w_vc = (const float*)L.w_vc.p;
         a.rope_cos = (const float*)L.mla_cos.p; a.rope_sin = (const float*)L.mla_sin.p;
         a.ckv_cache = L.kv_k.p; a.kpe_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_abs = B.q; a.q_pe = B.z; a.attn_lat = B.recur; a.v_proj = B.attn;
-        a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale;
+        a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale; a.fast = s->attn_fast;
         kr_launch_mla(a, s->kv_max_seq, st, Cc);
         if (oc != L.nh * L.vhd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*v_head_dim", oc);
         kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);

@@ -12,6 +12,7 @@
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
+#include "kr_attn_fd.h"
 #include <hip/hip_fp16.h>
 
 #ifdef KR_TIMING   // tools/probes/mla_timing.hip: wall-clock stamps (10 ns units) of thread 0 of workgroup 0, no-op in the product build
@@ -664,9 +665,15 @@ static bool kr_launch_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s,
         if (hipFuncSetAttribute((const void*)kr_mla_pv_kernel<NBC, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pv) != hipSuccess) return false;
         split_set = true;
     }
-    if (prep) return true;
+    if (prep) { kr_fd_prepare<NBC * 8, 16>(); return true; }
     if (split) {
         hipLaunchKernelGGL((kr_mla_scores_kernel<FP8, NBC, 8>), dim3((max_seq + KR_MLA_ROWS - 1) / KR_MLA_ROWS, (a.nh + KR_MLA_HG - 1) / KR_MLA_HG), dim3(512), lds_sc, s, a, max_seq);
+        if (a.fast && a.fd_o && a.fd_ml && a.nh <= 16) {     // tolerance mode: split-KV softmax + weighted sum over (chunk) workgroups, all heads share a latent row
+            KrFdArgs f{};
+            f.step = a.step; f.sc_g = a.sc_g; f.v_cache = a.ckv_cache; f.v_ld = a.klr; f.fd_o = a.fd_o; f.fd_ml = a.fd_ml; f.nh = a.nh; f.nkv = 1;
+            f.gate = nullptr; f.gated = 0; f.out = a.attn_lat; f.img_out = nullptr;
+            kr_launch_fd<NBC * 8, 16>(f, FP8 ? 1 : 0, max_seq, s);
+        } else
         hipLaunchKernelGGL((kr_mla_pv_kernel<NBC, FP8>), dim3(a.nh), dim3(NBC * 8 / KR_MPV_EPT + 256), lds_pv, s, a, max_seq);
     } else hipLaunchKernelGGL((kr_mla_attn_staged_kernel<FP8, NBC, 8>), dim3(a.nh, n_tok), dim3(512), lds, s, a, max_seq);
     return true;
@@ -679,10 +686,13 @@ static bool kr_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_
 }
 // raises the staged kernel's dynamic-LDS window; called outside graph capture (hipFuncSetAttribute is not a stream operation)
 void kr_mla_attn_prepare(const KrMlaArgs& a, int max_seq) { (void)kr_mla_staged(a, max_seq, nullptr, 1); }
+int kr_launch_mla_flash(const KrMlaArgs& a, int n_tok, hipStream_t st);   // kr_mla_flash.hip
 void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {
     if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_prep_kernel<true>, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(kr_mla_prep_kernel<false>, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
-    if (!kr_mla_staged(a, max_seq, s, n_tok)) {      // other geometries: the generic kernel
+    if (a.fast && !a.step && kr_launch_mla_flash(a, n_tok, s) == 0) {
+        // prompt pass, tolerance mode: one flash-attention launch streams the latent cache once per 64 (token, head) rows
+    } else if (!kr_mla_staged(a, max_seq, s, n_tok)) {      // other geometries: the generic kernel
         if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_attn_kernel<true>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
         else hipLaunchKernelGGL(kr_mla_attn_kernel<false>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
     }

@@ -95,3 +95,42 @@ def test_flash_prompt_pass_matches_exact_within_tolerance(hd, nh, fp8, n_tok, st
     assert np.isfinite(b).all() and rel <= 3e-3, rel
     assert outs[False][1] == outs[True][1]
     assert rel2 <= 3e-3, rel2
+
+
+@pytest.mark.parametrize("cfg", [dict(kv_max=700), dict(klr=256, nh=3, seed=4, kv_max=900), dict(lora=True, seed=2, kv_max=640)])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_mla_fast_decode_and_flash_prompt_pass(cfg, fp8):
+    """MLA in FAST mode: (a) decode over a long latent cache: split-KV softmax + weighted sum shared by all heads (kr_attn_fd.h with nkv = 1),
+    (b) prompt pass: flash attention over [ckv | kpe] rows on f16 MFMA (kr_mla_flash.hip).  Same stated tolerances as the GQA tests:
+    decode 5e-4, prompt pass 3e-3 relative on the logits; greedy tokens equal."""
+    from tests.test_mla_gpu import build as build_mla
+    res = {}
+    for mode in (False, True):
+        st, eng, orc, keep, d = build_mla(**cfg)
+        if fp8:
+            st.set_kv_dtype(True)
+            rng = np.random.default_rng(9)
+            n = d["nL"]
+            ck = [O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["klr"])) * 0.5).astype(F)) for _ in range(n)]
+            kp = [O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["rd"])) * 0.5).astype(F)) for _ in range(n)]
+            st.set_decode_state(5, d["kv_max"], [0] * n, [0] * n, [0] * n, [0] * n, [x.ctypes.data for x in ck], [x.ctypes.data for x in kp])
+        st.set_attention_mode(mode)
+        outs = []
+        tok = 9
+        for pos in [5, 300, 511, 512, d["kv_max"] - 200]:
+            lg = np.empty(d["V"], F); st.decode_step(tok, pos, lg.ctypes.data); outs.append(lg.copy())
+            tok = int(np.argmax(lg)) if mode is False else res[False][1][len(outs) - 1]
+        toks = [int(x) for x in np.random.default_rng(3).integers(0, d["V"], 150)]
+        st.set_prefill_chunk(64)
+        pl = np.empty(d["V"], F)
+        ptok = st.prefill(toks, d["kv_max"] - 180, pl.ctypes.data)
+        res[mode] = (outs, [int(np.argmax(o)) for o in outs], pl.copy(), ptok)
+    worst = max(float(np.abs(a - b).max() / np.abs(a).max()) for a, b in zip(res[False][0], res[True][0]))
+    relp = float(np.abs(res[False][2] - res[True][2]).max() / np.abs(res[False][2]).max())
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/r02_attn_fast_err.txt", "a") as f:
+            f.write(f"mla cfg={cfg} fp8={fp8} decode worst_rel={worst:.3e} prompt rel={relp:.3e}\n")
+    assert worst <= 5e-4, worst
+    assert res[False][1] == res[True][1]
+    assert np.isfinite(res[True][2]).all() and relp <= 3e-3, relp
+    assert res[False][3] == res[True][3]
