@@ -50,7 +50,7 @@ extern "C" int kr_decode_create(kr_engine* eng, int group_size, int norm_bias_on
     }
     KR_HIP(hipSetDevice(eng->device));
     std::unique_ptr<kr_decode_store> s(new kr_decode_store);
-    s->eng = eng; s->own_eng = own; s->group_size = group_size; s->norm_bias_one = norm_bias_one != 0;
+    s->eng = eng; s->device = eng->device; s->own_eng = own; s->group_size = group_size; s->norm_bias_one = norm_bias_one != 0;
     if (s->step_dev.ensure(sizeof(KrStep))) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
     *out = s.release();
     return KR_OK;
@@ -58,8 +58,10 @@ extern "C" int kr_decode_create(kr_engine* eng, int group_size, int norm_bias_on
 
 extern "C" void kr_decode_destroy(kr_decode_store* s) {
     if (!s) return;
-    (void)hipSetDevice(s->eng->device);
-    (void)hipStreamSynchronize(s->eng->stream);
+    // the engine may already be gone (a garbage collector finalises an engine and its store in any order): only the store's own copy of the
+    // device ordinal is used, and the device is drained instead of the engine's stream
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
     for (auto& w : s->weights) { w->ms.q.release(); w->ms.s.release(); w->ms.wsum.release(); }
     for (auto& n : s->norms) n->release();
@@ -73,6 +75,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
     for (hipStream_t ps : s->pf_side) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
     if (s->own_eng) kr_engine_destroy(s->eng);
     delete s;
+    (void)hipGetLastError();      // a failure while tearing down must not surface as the "last error" of an unrelated later call
 }
 
 // ---- host-side weight quantizers (decode.rs:46-178): f32 [N,K] -> transposed INT4/INT8 + bf16 scales ----

@@ -31,7 +31,7 @@ struct DLayer {
 };
 
 struct kr_decode_store {
-    kr_engine* eng = nullptr; bool own_eng = false;   // own_eng: a bare engine made by kr_decode_create(NULL, ...), replaced by kr_decode_set_moe_store
+    kr_engine* eng = nullptr; int device = 0; bool own_eng = false;   // own_eng: a bare engine made by kr_decode_create(NULL, ...), replaced by kr_decode_set_moe_store
     int group_size = 128; bool norm_bias_one = false;
     std::vector<std::unique_ptr<DWeight>> weights;
     std::vector<std::unique_ptr<DevBuf>> norms; std::vector<int> norm_len;

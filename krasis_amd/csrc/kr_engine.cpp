@@ -222,6 +222,7 @@ extern "C" void kr_engine_destroy(kr_engine* e) {
     for (auto& P : e->pf) for (DevBuf* b : {&P.i32, &P.xh, &P.xl, &P.xs, &P.xm, &P.gu, &P.hh, &P.hl, &P.hs, &P.hm, &P.eo, &P.sgu, &P.shh, &P.shl, &P.shs, &P.shm, &P.seo}) b->release();
     (void)hipStreamDestroy(e->stream);
     delete e;
+    (void)hipGetLastError();
 }
 
 extern "C" int kr_engine_get_config(const kr_engine* e, kr_model_config* out) {
