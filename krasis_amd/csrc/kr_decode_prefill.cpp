@@ -23,6 +23,7 @@
 
 namespace {
 struct Scratch {   // carved from one allocation per arena (grown on demand)
+    float* lac;
     float *res, *hid, *normed, *pa, *pb, *pc, *q, *k, *v, *z, *gexp, *beta, *recur, *attn, *gate, *moe, *sh, *gv, *sgu, *logits;
     int8_t *xh, *xl, *yh, *yl; float *xs, *ys;
     uint16_t* xb; int32_t* ids; float* w;
@@ -61,6 +62,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.qkvz = B.pa; a.ld_qkvz = nq; a.ba = B.pb; a.ld_ba = nb; a.conv_state = (float*)L.conv_state.p; a.conv_w = (const float*)L.conv_w.p;
         a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale; a.q = B.q; a.k = B.k; a.v = B.v; a.z = B.z;
         a.gexp = B.gexp; a.beta = B.beta; a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
+        a.lac = B.lac; a.fast = s->attn_fast;
         if (kr_launch_pfm_la(a, (float*)L.recur_state.p, B.recur, (const float*)L.la_norm_w.p, B.attn, Cc, s->eps, st))
             return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
         if (oc != L.nv * L.dv) return kr_fail(KR_ERR_VALUE, "out_proj cols %d != nv*dv", oc);
@@ -255,14 +257,16 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     }
     kmax = std::max(kmax, ad);
     const size_t C = CH;
-    size_t total = 0;
+    size_t total = 0, lac_floats = 0;
+    if (s->attn_fast)
+        for (auto& Ly : s->layers) if (Ly.attn == ATTN_LA && kr_pfm_la_chunk_ok(Ly.dk, Ly.dv, CH)) lac_floats = std::max(lac_floats, kr_pfm_la_chunk_scratch_floats(CH, Ly.nv));
     auto take = [&](size_t bytes) { const size_t o = total; total += al(bytes); return o; };
     const size_t o_res = take(C * H * 4), o_hid = take(C * H * 4), o_nrm = take(C * H * 4), o_pa = take(C * pa * 4), o_pb = take(C * pb * 4), o_pc = take(C * pc * 4),
                  o_q = take(C * qd * 4), o_k = take(C * kd * 4), o_v = take(C * vd * 4), o_z = take(C * zd * 4), o_ge = take(C * nvmax * 4), o_be = take(C * nvmax * 4),
                  o_rec = take(C * vd * 4), o_att = take(C * ad * 4), o_gate = take(C * zd * 4), o_moe = take(C * H * 4), o_sh = take(C * H * 4), o_gv = take(C * 4),
                  o_sgu = take(C * std::max(sid, (size_t)64) * 4), o_xh = take(C * H), o_xl = take(C * H), o_xs = take(C * (H / 128) * 4), o_yh = take(C * kmax),
                  o_yl = take(C * kmax), o_ys = take(C * (kmax / 128 + 1) * 4), o_xb = take(C * H * 2), o_ids = take(C * 32 * 4), o_w = take(C * 32 * 4),
-                 o_lg = take(C * (size_t)std::max(e->r_ne, 64) * 4);
+                 o_lg = take(C * (size_t)std::max(e->r_ne, 64) * 4), o_lac = take(lac_floats * 4);
     const size_t sc_ld_max = (size_t)((start_pos + n_tokens + 63) & ~63), sc_bytes = al(C * sc_rows * (sc_ld_max + 1) * 4);
     if (s->pf_scratch.ensure(total * n_arenas) || s->pf_tokens.ensure((size_t)n_tokens * 4) || (sc_rows && s->pf_scores.ensure(sc_bytes * n_arenas)))
         return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch (%zu MiB) failed", (total * n_arenas + sc_bytes * n_arenas) >> 20);
@@ -279,6 +283,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
         B.moe = (float*)(base + o_moe); B.sh = (float*)(base + o_sh); B.gv = (float*)(base + o_gv); B.sgu = (float*)(base + o_sgu); B.xh = (int8_t*)(base + o_xh);
         B.xl = (int8_t*)(base + o_xl); B.xs = (float*)(base + o_xs); B.yh = (int8_t*)(base + o_yh); B.yl = (int8_t*)(base + o_yl); B.ys = (float*)(base + o_ys);
         B.xb = (uint16_t*)(base + o_xb); B.ids = (int32_t*)(base + o_ids); B.w = (float*)(base + o_w); B.logits = (float*)(base + o_lg);
+        B.lac = lac_floats ? (float*)(base + o_lac) : nullptr;
         return B;
     };
 

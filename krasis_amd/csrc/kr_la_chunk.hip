@@ -1,0 +1,318 @@
+// kr_la_chunk.hip -- FAST-mode prompt pass of the gated delta rule (linear-attention layers): sub-chunks of 64 tokens in closed form.
+//
+// The reference recurrence (src/decode.rs:1293 restated per token in kr_pfm_la_recur_kernel, which stays the exact / default path) is
+//     S <- a_t S;  d = b_t (v_t - S^T k_t);  S <- S + k_t d^T;  o_t = S^T q_t            (a_t = e^{g_t}, b_t = beta_t, S is [dk][dv])
+// i.e. S_t = (I - b_t k_t k_t^T) a_t S_{t-1} + b_t k_t v_t^T: two dk-long dependent fma chains per token, 1.67 ms per 1024-token launch on
+// MI355X (52.6 % of the FAST prompt pass, profiles/r02_prefill_fast_8192_kernel_stats.txt).  Over a sub-chunk of T = 64 tokens with
+// G_t = sum_{r<=t} g_r the same map is (WY form):
+//     (I + L) [W | Y] = [diag(b e^G) K | diag(b) V],   L[t][j] = b_t e^{G_t - G_j} (k_t . k_j)   (j < t)          -> forward substitution
+//     U  = Y - W S_0                                                                                            (the 64 "delta" rows)
+//     O  = (diag(e^G) Q - B W) S_0 + B Y,          B[t][j] = e^{G_t - G_j} (q_t . k_j)   (j <= t)
+//     S' = e^{G_T} S_0 + (diag(e^{G_T - G}) K)^T U
+// Only the two products with S_0 are sequential over sub-chunks.  Two launches:
+//   kr_lac_prep_kernel  grid (sub-chunks, heads): everything that does not need the state -- K K^T, Q K^T on the f32 MFMA, the triangular
+//                       solve in registers (one column of [W | Y] per thread, L rows broadcast from LDS), Q' = e^G Q - B W and O_0 = B Y.
+//   kr_lac_scan_kernel  grid (heads x 4 column slices of the state): walks the sub-chunks; per step U = Y - W S, O = O_0 + Q' S (four 32x32
+//                       blocks, one per wave) and S <- e^{G_T} S + K'^T U (four blocks), the next sub-chunk's tiles in flight in registers.
+// f32 MFMA (v_mfma_f32_32x32x2_f32) keeps f32 products and f32 accumulation; the result differs from the per-token order only by summation
+// order (tolerance mode: tests/test_attn_fast_gpu.py states it).  All exponents are differences G_t - G_j <= 0: nothing overflows, and a
+// decay that underflows gives 0, not NaN (g is clamped at -80 per token).
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include "kr_prefill_ops.h"
+
+#ifdef KR_TIMING   // tools/probes/lac_timing.hip: wall-clock stamps (10 ns units) by thread 0 of workgroup (0, 0); no-op in the product build
+__device__ unsigned long long kr_lstamps[64];
+#define LC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) kr_lstamps[i] = wall_clock64(); } while (0)
+#else
+#define LC_STAMP(i) do { } while (0)
+#endif
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+// e^x for x <= 0 on the transcendental unit (v_exp_f32 of x * log2 e, ~1 ulp of 2^-22 relative): the precise expf costs ~40 VALU instructions,
+// 1.1 us per 16 values on a lone wave -- more than the epilogue it sits in
+__device__ __forceinline__ float lc_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+#define LC_T 64
+#define LC_D 128
+#define LC_LD 132      // LDS row stride (floats) of the 64 x 128 tiles: rows 4 banks apart -> the float4 k-contiguous reads are conflict-free
+#define LC_LS 68       // row stride of the 64 x 64 matrices
+#define LC_SS 40       // row stride of the 32-column state / delta slices: rows k and k+4 are 32 banks apart
+#define LC_PREP_LDS ((3 * LC_T * LC_LD + 2 * LC_T * LC_LS + 3 * LC_T) * 4)
+#define LC_SCAN_LDS ((3 * LC_T * LC_LD + LC_D * LC_SS + LC_T * LC_SS + LC_T) * 4)
+
+struct KrLacArgs {
+    const float *q, *k, *v, *gexp, *beta;   // [C][nv*128] x3, [C][nv] x2
+    float *W, *Y, *Qp, *G;                  // [n_sub*nv][64][128] x3, [n_sub*nv][64]
+    float *out, *state;                     // [C][nv*128]; [nv][128][128]
+    int nv, C, n_sub;
+};
+
+// acc(32x32) += A(32 x K) . B(K x 32).  One v_mfma_f32_32x32x2_f32 takes k = lane>>5 from each lane; four steps share one 16-byte read, so the
+// lane half h supplies k = kb + 4h + s at step s -- on BOTH operands, which is all the instruction needs.
+//   A_ROWS: A[m][k] = A[m*lda + k] (k contiguous) else A[m][k] = A[k*lda + m];   B_ROWS: B[k][n] = B[n*ldb + k] (k contiguous) else B[k*ldb + n]
+struct LcNone { __device__ __forceinline__ void operator()(int) const {} };
+template <bool A_ROWS, bool B_ROWS, int K, typename F = LcNone>
+__device__ __forceinline__ void lc_blk(v16f& acc, const float* A, int lda, const float* B, int ldb, int lane, F&& between = LcNone()) {
+    const int r = lane & 31, h = lane >> 5;
+    float a[2][4], b[2][4];
+    auto fetch = [&](int kb, float* a_, float* b_) {
+        if (A_ROWS) { const f4 t = *reinterpret_cast<const f4*>(A + r * lda + kb + 4 * h); a_[0] = t.x; a_[1] = t.y; a_[2] = t.z; a_[3] = t.w; }
+        else {
+#pragma unroll
+            for (int s = 0; s < 4; s++) a_[s] = A[(kb + 4 * h + s) * lda + r];
+        }
+        if (B_ROWS) { const f4 t = *reinterpret_cast<const f4*>(B + r * ldb + kb + 4 * h); b_[0] = t.x; b_[1] = t.y; b_[2] = t.z; b_[3] = t.w; }
+        else {
+#pragma unroll
+            for (int s = 0; s < 4; s++) b_[s] = B[(kb + 4 * h + s) * ldb + r];
+        }
+    };
+    fetch(0, a[0], b[0]);
+#pragma unroll
+    for (int it = 0; it < K / 8; it++) {          // operands of step it + 1 leave LDS, and `between` issues its global loads, under the 4 MFMAs of step it
+        if (it + 1 < K / 8) fetch((it + 1) * 8, a[(it + 1) & 1], b[(it + 1) & 1]);
+        between(it);
+#pragma unroll
+        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[it & 1][s], b[it & 1][s], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);         // keep each step's requests in its step (the scheduler otherwise bunches them at the loop end)
+    }
+}
+__device__ __forceinline__ int lc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }   // accumulator register r -> block row
+
+__global__ void __launch_bounds__(256) kr_lac_prep_kernel(KrLacArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Kt = lds; float* Qt = Kt + LC_T * LC_LD; float* Vt = Qt + LC_T * LC_LD; float* Lm = Vt + LC_T * LC_LD; float* Bm = Lm + LC_T * LC_LS;
+    float* Gs = Bm + LC_T * LC_LS; float* bs = Gs + LC_T; float* bg = bs + LC_T;
+    const int sub = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = sub * LC_T, n = min(LC_T, a.C - c0);
+    const size_t ld = (size_t)a.nv * LC_D, tile = ((size_t)sub * a.nv + h) * LC_T;
+    LC_STAMP(0);
+    // ---- tiles (rows past the chunk end are zero: b = 0, g = 0 make them inert)
+    for (int u = tid; u < LC_T * 32; u += 256) {
+        const int t = u >> 5, c4 = (u & 31) * 4;
+        float4 kk = make_float4(0, 0, 0, 0), qq = kk, vv = kk;
+        if (t < n) {
+            const size_t o = (size_t)(c0 + t) * ld + (size_t)h * LC_D + c4;
+            kk = *reinterpret_cast<const float4*>(a.k + o); qq = *reinterpret_cast<const float4*>(a.q + o); vv = *reinterpret_cast<const float4*>(a.v + o);
+        }
+        *reinterpret_cast<float4*>(Kt + t * LC_LD + c4) = kk; *reinterpret_cast<float4*>(Qt + t * LC_LD + c4) = qq; *reinterpret_cast<float4*>(Vt + t * LC_LD + c4) = vv;
+    }
+    if (wave == 0) {
+        const int t = lane;
+        float g = t < n ? fmaxf(logf(fmaxf(a.gexp[(size_t)(c0 + t) * a.nv + h], 1e-37f)), -80.0f) : 0.0f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(g, o); if (lane >= o) g += y; }
+        const float b = t < n ? a.beta[(size_t)(c0 + t) * a.nv + h] : 0.0f;
+        Gs[t] = g; bs[t] = b; bg[t] = b * lc_exp(g);
+        a.G[tile + t] = g;
+    }
+    __syncthreads();
+    LC_STAMP(1);
+    // ---- K K^T -> L (strictly lower, decayed, row-scaled by b) and Q K^T -> B (lower incl. diagonal, decayed); the (0,1) blocks are zero
+    if (wave < 3) {
+        v16f acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+        // wave 0: L(0,0), L(1,1);  wave 1: B(0,0), B(1,1);  wave 2: L(1,0), B(1,0)
+        const float* A0 = wave == 1 ? Qt : Kt; const float* A1 = wave == 0 ? Kt : Qt;
+        const int rb0 = wave == 2 ? 1 : 0, cb0 = 0, rb1 = 1, cb1 = wave == 2 ? 0 : 1;
+        lc_blk<true, true, LC_D>(acc0, A0 + rb0 * 32 * LC_LD, LC_LD, Kt + cb0 * 32 * LC_LD, LC_LD, lane);
+        lc_blk<true, true, LC_D>(acc1, A1 + rb1 * 32 * LC_LD, LC_LD, Kt + cb1 * 32 * LC_LD, LC_LD, lane);
+        const bool l0 = wave != 1, l1 = wave == 0;   // which result is an L block (else a B block)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            { const int row = rb0 * 32 + lc_row(r, lane), col = cb0 * 32 + (lane & 31);
+              const float d = lc_exp(Gs[row] - Gs[col]) * acc0[r];
+              if (l0) Lm[row * LC_LS + col] = col < row ? bs[row] * d : 0.0f; else Bm[row * LC_LS + col] = col <= row ? d : 0.0f; }
+            { const int row = rb1 * 32 + lc_row(r, lane), col = cb1 * 32 + (lane & 31);
+              const float d = lc_exp(Gs[row] - Gs[col]) * acc1[r];
+              if (l1) Lm[row * LC_LS + col] = col < row ? bs[row] * d : 0.0f; else Bm[row * LC_LS + col] = col <= row ? d : 0.0f; }
+        }
+    } else {
+        for (int u = lane; u < 32 * 32; u += 64) { const int row = u >> 5, col = 32 + (u & 31); Lm[row * LC_LS + col] = 0.0f; Bm[row * LC_LS + col] = 0.0f; }
+    }
+    __syncthreads();
+    LC_STAMP(2);
+    // ---- (I + L) X = [diag(b e^G) K | diag(b) V]: thread c owns column c of X = [W | Y] in registers; row t of L is a broadcast read
+    {
+        f2 x[LC_T / 2];                                    // pairs of rows: the two fma chains of a row run as one v_pk_fma_f32
+        float* Xt = tid < LC_D ? Kt + tid : Vt + (tid - LC_D);
+        const float* sc = tid < LC_D ? bg : bs;
+#pragma unroll
+        for (int t = 0; t < LC_T; t += 2) { x[t / 2].x = sc[t] * Xt[t * LC_LD]; x[t / 2].y = sc[t + 1] * Xt[(t + 1) * LC_LD]; }
+        // row t + 1 of L leaves LDS (broadcast reads) while row t's chains run: with one wave per SIMD nothing else hides that latency
+        f4 cur[LC_T / 4], nx[LC_T / 4];
+        cur[0] = *reinterpret_cast<const f4*>(Lm + LC_LS);
+#pragma unroll
+        for (int t = 1; t < LC_T; t++) {
+            if (t + 1 < LC_T) {
+#pragma unroll
+                for (int j4 = 0; j4 < (t + 4) / 4; j4++) nx[j4] = *reinterpret_cast<const f4*>(Lm + (t + 1) * LC_LS + 4 * j4);
+            }
+            f2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
+#pragma unroll
+            for (int j4 = 0; j4 < (t + 3) / 4; j4++) {        // entries at j >= t are stored zeros
+                const f4 l = cur[j4];
+                sa = __builtin_elementwise_fma((f2){l.x, l.y}, x[2 * j4], sa);
+                sb = __builtin_elementwise_fma((f2){l.z, l.w}, x[2 * j4 + 1], sb);
+            }
+            const float sum = (sa.x + sa.y) + (sb.x + sb.y);
+            if (t & 1) x[t / 2].y -= sum; else x[t / 2].x -= sum;
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < LC_T) {
+#pragma unroll
+                for (int j4 = 0; j4 < (t + 4) / 4; j4++) cur[j4] = nx[j4];
+            }
+        }
+        float* Xg = (tid < LC_D ? a.W : a.Y) + tile * LC_D + (tid & (LC_D - 1));
+#pragma unroll
+        for (int t = 0; t < LC_T; t++) { const float xv = (t & 1) ? x[t / 2].y : x[t / 2].x; Xt[t * LC_LD] = xv; Xg[(size_t)t * LC_D] = xv; }   // W over K, Y over V: element (t, c) is read and written by thread c only
+    }
+    __syncthreads();
+    LC_STAMP(4);
+    // ---- Q' = diag(e^G) Q - B W  and  O_0 = B Y: wave w takes the 32 columns [32w, 32w+32) of both, both row halves (row half 0 only needs j < 32)
+    {
+        v16f q0, q1, o0, o1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { q0[i] = 0.0f; q1[i] = 0.0f; o0[i] = 0.0f; o1[i] = 0.0f; }
+        lc_blk<true, false, 32>(q0, Bm, LC_LS, Kt + wave * 32, LC_LD, lane);
+        lc_blk<true, false, 32>(o0, Bm, LC_LS, Vt + wave * 32, LC_LD, lane);
+        lc_blk<true, false, 64>(q1, Bm + 32 * LC_LS, LC_LS, Kt + wave * 32, LC_LD, lane);
+        lc_blk<true, false, 64>(o1, Bm + 32 * LC_LS, LC_LS, Vt + wave * 32, LC_LD, lane);
+        const int col = wave * 32 + (lane & 31);
+        LC_STAMP(5);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int r0 = lc_row(r, lane), r1 = 32 + r0;
+            a.Qp[(tile + r0) * LC_D + col] = lc_exp(Gs[r0]) * Qt[r0 * LC_LD + col] - q0[r];
+            a.Qp[(tile + r1) * LC_D + col] = lc_exp(Gs[r1]) * Qt[r1 * LC_LD + col] - q1[r];
+            if (r0 < n) a.out[(size_t)(c0 + r0) * ld + (size_t)h * LC_D + col] = o0[r];
+            if (r1 < n) a.out[(size_t)(c0 + r1) * ld + (size_t)h * LC_D + col] = o1[r];
+        }
+        LC_STAMP(6);
+    }
+}
+
+__global__ void __launch_bounds__(256) kr_lac_scan_kernel(KrLacArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wt = lds; float* Qt = Wt + LC_T * LC_LD; float* Kt = Qt + LC_T * LC_LD; float* Ss = Kt + LC_T * LC_LD; float* Us = Ss + LC_D * LC_SS; float* Gs = Us + LC_T * LC_SS;
+    const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the 4 column slices of one head read the same W / Q' / K tiles: keep them on one XCD (workgroup id % 8) so the re-reads hit its L2
+    int h, slice;
+    if (a.nv % 8 == 0) { h = (bid & 7) + 8 * (bid >> 5); slice = (bid >> 3) & 3; } else { h = bid >> 2; slice = bid & 3; }
+    const size_t ld = (size_t)a.nv * LC_D;
+    const int col = slice * 32 + (lane & 31);
+    float* Sg = a.state + (size_t)h * LC_D * LC_D;
+    v16f S;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const int d = wave * 32 + lc_row(r, lane); S[r] = Sg[(size_t)d * LC_D + col]; Ss[d * LC_SS + (lane & 31)] = S[r]; }
+    // tile element u = tid + 256 i (i < 8): token row t = (tid >> 5) + 8 i, 16-byte column group tid & 31.  Running pointers: one add per sub-chunk.
+    const int t0 = tid >> 5, c4 = (tid & 31) * 4;
+    const size_t tile_stride = (size_t)a.nv * LC_T * LC_D;
+    const f4* Wp = reinterpret_cast<const f4*>(a.W + (size_t)h * LC_T * LC_D) + tid;
+    const f4* Qp = reinterpret_cast<const f4*>(a.Qp + (size_t)h * LC_T * LC_D) + tid;
+    const float* Kp = a.k + (size_t)h * LC_D + c4;
+    f4 pw[8], pq[8], pk[8]; float pg = 0.0f;
+    const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    // part i of sub-chunk SUB's tiles (W and Q' rows, or the K rows: rows past the chunk end read the last row and are zeroed when they are
+    // written to LDS -- no branch, and no wait at the request)
+#define LC_FETCH_WQ(SUB, I) { pw[I] = Wp[(size_t)(SUB) * (tile_stride / 4) + 256 * (I)]; pq[I] = Qp[(size_t)(SUB) * (tile_stride / 4) + 256 * (I)]; }
+#define LC_FETCH_K(SUB, I)  { pk[I] = *reinterpret_cast<const f4*>(Kp + (size_t)min((SUB) * LC_T + t0 + 8 * (I), a.C - 1) * ld); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { LC_FETCH_WQ(0, i) LC_FETCH_K(0, i) }
+    if (tid < LC_T) pg = a.G[(size_t)h * LC_T + tid];
+    for (int sub = 0; sub < a.n_sub; sub++) {
+        const size_t tile = ((size_t)sub * a.nv + h) * LC_T;
+        const int c0 = sub * LC_T, n = min(LC_T, a.C - c0);
+        const int nxt = min(sub + 1, a.n_sub - 1);     // the last step re-requests its own tiles: no branch in the product loop
+        if (sub == 1) LC_STAMP(10);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int t = t0 + 8 * i;
+            *reinterpret_cast<f4*>(Wt + t * LC_LD + c4) = pw[i]; *reinterpret_cast<f4*>(Qt + t * LC_LD + c4) = pq[i]; *reinterpret_cast<f4*>(Kt + t * LC_LD + c4) = c0 + t < a.C ? pk[i] : zero4;
+        }
+        if (tid < LC_T) Gs[tid] = pg;
+        __syncthreads();
+        if (sub == 1) LC_STAMP(11);
+        // ---- waves 0,1: U = Y - W S (row halves);  waves 2,3: O = O_0 + Q' S.  The Y / O_0 values are requested FIRST (the memory counter is in
+        // order: waiting for them must not wait for the prefetch), then the next sub-chunk's tiles are requested from inside the product loop
+        {
+            const int rb = wave & 1;
+            float y[16];
+            if (wave < 2) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) y[r] = a.Y[(tile + rb * 32 + lc_row(r, lane)) * LC_D + col];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { const int row = min(rb * 32 + lc_row(r, lane), n - 1); y[r] = a.out[(size_t)(c0 + row) * ld + (size_t)h * LC_D + col]; }
+            }
+            if (tid < LC_T) pg = a.G[((size_t)nxt * a.nv + h) * LC_T + tid];
+            v16f acc;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+            if (sub == 1) LC_STAMP(12);
+            lc_blk<true, false, LC_D>(acc, (wave < 2 ? Wt : Qt) + rb * 32 * LC_LD, LC_LD, Ss, LC_SS, lane, [&](int it) {
+                if (it & 1) LC_FETCH_K(nxt, it >> 1) else LC_FETCH_WQ(nxt, it >> 1)
+            });
+            if (sub == 1) LC_STAMP(13);
+            const float gT = Gs[LC_T - 1];
+            if (wave < 2) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { const int row = rb * 32 + lc_row(r, lane); Us[row * LC_SS + (lane & 31)] = (y[r] - acc[r]) * lc_exp(gT - Gs[row]); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { const int row = rb * 32 + lc_row(r, lane); if (row < n) a.out[(size_t)(c0 + row) * ld + (size_t)h * LC_D + col] = y[r] + acc[r]; }
+            }
+        }
+        if (sub == 1) LC_STAMP(14);
+        __syncthreads();
+        if (sub == 1) LC_STAMP(15);
+        // ---- S <- e^{G_T} S + K^T U'   (U' rows already carry e^{G_T - G_t}); wave w owns state rows [32w, 32w+32)
+        {
+            const float gam = lc_exp(Gs[LC_T - 1]);
+#pragma unroll
+            for (int r = 0; r < 16; r++) S[r] *= gam;
+            lc_blk<false, false, LC_T>(S, Kt + wave * 32, LC_LD, Us, LC_SS, lane);
+        }
+        if (sub == 1) LC_STAMP(16);
+        __syncthreads();
+        if (sub == 1) LC_STAMP(17);
+#pragma unroll
+        for (int r = 0; r < 16; r++) Ss[(wave * 32 + lc_row(r, lane)) * LC_SS + (lane & 31)] = S[r];
+        if (sub == 1) LC_STAMP(18);
+        if (sub == 2) LC_STAMP(19);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) Sg[(size_t)(wave * 32 + lc_row(r, lane)) * LC_D + col] = S[r];
+}
+
+// floats of scratch per padded token (a multiple of 64 tokens) and head: W, Y, Q' rows + one G
+size_t kr_pfm_la_chunk_scratch_floats(int C, int nv) { const size_t c64 = ((size_t)C + LC_T - 1) / LC_T * LC_T; return c64 * nv * (3 * LC_D + 1); }
+bool kr_pfm_la_chunk_ok(int dk, int dv, int C) { return dk == LC_D && dv == LC_D && C >= LC_T; }
+
+// > 64 KB of dynamic LDS is an opt-in per device (and not allowed inside a stream capture: the prompt pass is never captured)
+static int lac_prepare() {
+    static std::mutex mu; static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    std::lock_guard<std::mutex> g(mu);
+    if (done[dev]) return 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kr_lac_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LC_PREP_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kr_lac_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LC_SCAN_LDS) != hipSuccess) return 1;
+    done[dev] = true;
+    return 0;
+}
+
+int kr_launch_pfm_la_chunked(const KrPfmLaArgs& p, float* state, float* out, float* scratch, int C, hipStream_t st) {
+    if (!kr_pfm_la_chunk_ok(p.dk, p.dv, C) || !scratch) return 1;
+    if (lac_prepare()) return 1;
+    KrLacArgs a{};
+    a.q = p.q; a.k = p.k; a.v = p.v; a.gexp = p.gexp; a.beta = p.beta; a.nv = p.nv; a.C = C; a.n_sub = (C + LC_T - 1) / LC_T;
+    const size_t tiles = (size_t)a.n_sub * p.nv * LC_T;
+    a.W = scratch; a.Y = a.W + tiles * LC_D; a.Qp = a.Y + tiles * LC_D; a.G = a.Qp + tiles * LC_D;
+    a.out = out; a.state = state;
+    hipLaunchKernelGGL(kr_lac_prep_kernel, dim3(a.n_sub, p.nv), dim3(256), LC_PREP_LDS, st, a);
+    hipLaunchKernelGGL(kr_lac_scan_kernel, dim3(p.nv * 4), dim3(256), LC_SCAN_LDS, st, a);
+    return 0;
+}

@@ -17,6 +17,7 @@ struct KrPfmLaArgs {
     float* conv_state; const float* conv_w; const float* a_log; const float* dt_bias; float scale;
     float *q, *k, *v, *z, *gexp, *beta;   // [C, nv*dk] x2, [C, nv*dv] x2, [C, nv] x2
     int nk, nv, dk, dv, hr;
+    float* lac; int fast;                 // FAST mode: scratch of the 64-token closed form (kr_la_chunk.hip), kr_pfm_la_chunk_scratch_floats(C, nv) floats
 };
 struct KrPfmGqaArgs {
     const float *q_in, *k_in, *v_in; int ld_q, ld_k, ld_v;
@@ -38,3 +39,7 @@ void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const flo
 // FAST mode (kr_attn_flash.hip): causal flash attention on f16 MFMA after the same prep launch; non-zero = geometry not covered
 int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st);
 void kr_launch_pfm_gqa_prep(const KrPfmGqaArgs& a, int C, hipStream_t st);
+// FAST mode (kr_la_chunk.hip): the gated delta rule over the chunk in sub-chunks of 64 tokens on the f32 MFMA; non-zero = geometry not covered
+int kr_launch_pfm_la_chunked(const KrPfmLaArgs& a, float* recur_state, float* recur_out, float* scratch, int C, hipStream_t st);
+size_t kr_pfm_la_chunk_scratch_floats(int C, int nv);
+bool kr_pfm_la_chunk_ok(int dk, int dv, int C);

@@ -683,7 +683,8 @@ int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out,
     hipLaunchKernelGGL(kr_pfm_la_conv_kernel, dim3(a.nk, C), dim3(256), (size_t)(2 * a.dk + 4) * 4, st, a);
     const int conv_dim = 2 * a.nk * a.dk + a.nv * a.dv;
     hipLaunchKernelGGL(kr_pfm_la_conv_state_kernel, dim3((conv_dim + 255) / 256), dim3(256), 0, st, a, C);
-    if (a.dk == 128) hipLaunchKernelGGL(kr_pfm_la_recur_kernel<128>, dim3(a.nv), dim3(a.dv), 0, st, recur_state, a.q, a.k, a.v, a.gexp, a.beta, recur_out, a.nv, a.dv, C);
+    if (a.fast && a.lac && kr_pfm_la_chunk_ok(a.dk, a.dv, C) && kr_launch_pfm_la_chunked(a, recur_state, recur_out, a.lac, C, st) == 0) {}
+    else if (a.dk == 128) hipLaunchKernelGGL(kr_pfm_la_recur_kernel<128>, dim3(a.nv), dim3(a.dv), 0, st, recur_state, a.q, a.k, a.v, a.gexp, a.beta, recur_out, a.nv, a.dv, C);
     else if (a.dk == 64) hipLaunchKernelGGL(kr_pfm_la_recur_kernel<64>, dim3(a.nv), dim3(a.dv), 0, st, recur_state, a.q, a.k, a.v, a.gexp, a.beta, recur_out, a.nv, a.dv, C);
     else return 1;
     hipLaunchKernelGGL(kr_pfm_gated_norm_kernel, dim3(a.nv, C), dim3(a.dv), 0, st, recur_out, a.z, norm_w, gated_out, a.nv, a.dv, eps);

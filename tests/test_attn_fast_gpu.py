@@ -97,6 +97,36 @@ def test_flash_prompt_pass_matches_exact_within_tolerance(hd, nh, fp8, n_tok, st
     assert rel2 <= 3e-3, rel2
 
 
+@pytest.mark.parametrize("la_heads,n_tok,chunk", [((2, 4), 300, 0), ((2, 4), 333, 128), ((4, 16), 200, 0), ((1, 8), 64, 0)])
+def test_chunked_delta_rule_matches_exact_within_tolerance(la_heads, n_tok, chunk):
+    """linear-attention layers only, so the ONLY difference between the two modes is kr_la_chunk.hip: the gated delta rule over sub-chunks of 64
+    tokens in closed form (triangular solve + f32 MFMA products) against the per-token recurrence (bit-identical to decode.rs:1293).  Same f32
+    products, another summation order.  STATED TOLERANCE: max |fast - exact| <= 1e-3 * max |exact| on the last-position logits AND on the logits of
+    the next decode step (which runs on the recurrent state the prompt pass left); same greedy token.  (Measured on MI355X: 0.6e-4 .. 3.7e-4 -- as
+    with the attention fast mode, last-bit differences of the layer output move single INT16 digits of the next projection's input by one step.)  Covers a partial last sub-chunk, chunks
+    that fall back to the exact kernel (< 64 tokens), and the head counts of both workgroup mappings (nv % 8 == 0 or not)."""
+    outs = {}
+    for mode in (False, True):
+        st, eng, orc, keep, d = build(seed=13, kv_max=400, kinds=["la", "la", "la"], la_heads=la_heads)
+        st.set_attention_mode(mode)
+        if chunk:
+            st.set_prefill_chunk(chunk)
+        rng = np.random.default_rng(n_tok)
+        toks = [int(x) for x in rng.integers(0, d["V"], n_tok)]
+        lg = np.empty(d["V"], F)
+        tok = st.prefill(toks, 0, lg.ctypes.data)
+        nxt = np.empty(d["V"], F); st.decode_step(tok, n_tok, nxt.ctypes.data)
+        outs[mode] = (lg.copy(), tok, nxt.copy())
+    rel = float(np.abs(outs[False][0] - outs[True][0]).max() / np.abs(outs[False][0]).max())
+    rel2 = float(np.abs(outs[False][2] - outs[True][2]).max() / np.abs(outs[False][2]).max())
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/r02_attn_fast_err.txt", "a") as f:
+            f.write(f"chunked delta rule heads={la_heads} n={n_tok} chunk={chunk} rel={rel:.3e} next-step rel={rel2:.3e}\n")
+    assert np.isfinite(outs[True][0]).all() and rel <= 1e-3, rel
+    assert rel2 <= 1e-3, rel2
+    assert outs[False][1] == outs[True][1]
+
+
 @pytest.mark.parametrize("cfg", [dict(kv_max=700), dict(klr=256, nh=3, seed=4, kv_max=900), dict(lora=True, seed=2, kv_max=640)])
 @pytest.mark.parametrize("fp8", [False, True])
 def test_mla_fast_decode_and_flash_prompt_pass(cfg, fp8):

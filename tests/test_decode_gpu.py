@@ -15,11 +15,11 @@ def _ptr(a):
     return a.ctypes.data
 
 
-def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4, dims=None, kinds=None):
+def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4, dims=None, kinds=None, la_heads=(2, 4)):
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     rng = np.random.default_rng(seed)
     H, V, E, k, I, SI = dims or (256, 512, 16, 4, 128, 128)
-    nk, nv, dk, dv = 2, 4, 128, 128
+    (nk, nv), dk, dv = la_heads, 128, 128
     nkv, d2 = 2, 8
     kinds = kinds or (["la", "gqa", "la"] + (["gqa"] if with_dense else []))
     nL = len(kinds)
