@@ -277,6 +277,41 @@ int kr_decode_sample(kr_decode_store* s, float temperature, int top_k, float top
 /* generate_batch (decode.rs:3525), greedy sampling only in this round */
 int kr_decode_generate_greedy(kr_decode_store* s, int first_token, int start_pos, int max_tokens, const int* stop_ids, int n_stop,
                               int* tokens_out, int* n_out, void* stream);
+/* generate_stream (decode.rs:3611): the cancellable loop of the reference's Rust server.  on_token(token, finish_reason, user) is called once per
+ * generated token -- finish_reason 0 none, 1 "stop" (a stop id, reported last), 2 "length" (max_tokens reached), 3 "cancelled" (cancel flag seen
+ * before the step; token = the last token) -- and returns non-zero to continue.  Text decoding (tokenizers::Tokenizer in the reference) stays
+ * with the host language.  *n_out = tokens generated (the return value of the reference method). */
+typedef int (*kr_token_cb)(int token, int finish_reason, void* user);
+int kr_decode_generate_stream(kr_decode_store* s, int first_token, int start_pos, int max_tokens, float temperature, int top_k, float top_p,
+                              const int* stop_ids, int n_stop, float presence_penalty, uint64_t rng_seed, kr_token_cb on_token, void* user, int* n_out,
+                              void* stream);
+/* cancel / reset_cancel / last_decode_elapsed_s (decode.rs:253-265): the flag is read by generate_stream before every step; the elapsed time
+ * is the wall time of the last generate / generate_stream loop */
+int kr_decode_cancel(kr_decode_store* s);
+int kr_decode_reset_cancel(kr_decode_store* s);
+double kr_decode_last_elapsed_s(kr_decode_store* s);
+
+/* ---- stand-alone CpuDecodeStore operators (decode.rs:328-1086).  Every pointer may be a host or a device pointer; host buffers are staged and
+ * the call returns after the results are back.  Bit-identical to the reference methods (tests/test_standalone_ops_gpu.py against the oracle's
+ * kro_op_* restatements); several differ from the decode graph's arithmetic exactly as they do in the reference (scalar loops, libm exp). */
+int kr_decode_matmul(kr_decode_store* s, int weight_id, const float* input, float* output);                                   /* decode.rs:328 */
+int kr_decode_matmul_batch(kr_decode_store* s, const int* weight_ids, int n, const float* input, float* const* outputs);      /* decode.rs:364 */
+/* fused_add_rmsnorm (weight != NULL, decode.rs:406) / fused_add_rmsnorm_id (weight == NULL, stored norm `norm_id`, decode.rs:447) */
+int kr_decode_fused_add_rmsnorm(kr_decode_store* s, float* hidden, float* residual, const float* weight, int norm_id, float eps, int size, int first_call);
+int kr_decode_rmsnorm(kr_decode_store* s, const float* input, const float* weight, float eps, float* output, int size);      /* decode.rs:473 */
+int kr_decode_silu_mul(kr_decode_store* s, const float* gate, const float* up, float* output, int size);                      /* decode.rs:511 */
+int kr_decode_fused_shared_expert(kr_decode_store* s, int gate_up_wid, int down_wid, const float* input, float* output);      /* decode.rs:542 */
+int kr_decode_linear_attention_recurrent(kr_decode_store* s, float* state, const float* q, const float* k, const float* v, const float* g, const float* beta,
+                                         float* output, int nv, int dk, int dv);                                              /* decode.rs:609 */
+int kr_decode_gated_rmsnorm_silu(kr_decode_store* s, const float* x, const float* z, const float* norm_weight, float* output, float eps, int nv, int dv); /* decode.rs:650 */
+int kr_decode_linear_attention_conv(kr_decode_store* s, const float* qkvz, const float* ba, float* conv_state, const float* conv_weight, const float* a_log,
+                                    const float* dt_bias, float scale, float* q_out, float* k_out, float* v_out, float* z_out, float* g_out, float* beta_out,
+                                    int nk, int nv, int dk, int dv, int hr, int kernel_dim);                                  /* decode.rs:713 */
+/* store_route_weight (decode.rs:895) / moe_route (decode.rs:955): f32 gate [E, H], optional bias / e_score_correction [E] (NULL = none) */
+int kr_decode_store_route_weight(kr_decode_store* s, const float* gate, int num_experts, int hidden_dim, const float* bias, const float* e_score_corr, int* route_id_out);
+int kr_decode_moe_route(kr_decode_store* s, int route_id, const float* hidden, int32_t* topk_ids_out, float* topk_weights_out, int topk, int scoring_func, int norm_topk_prob);
+int kr_decode_num_route_weights(kr_decode_store* s);                                                                          /* decode.rs:1113 */
+size_t kr_decode_weight_bytes(kr_decode_store* s, int weight_id);                                                             /* decode.rs:1107 */
 int kr_decode_last_token(kr_decode_store* s, int* token);
 int kr_decode_set_use_graph(kr_decode_store* s, int enable);
 int kr_decode_read_buffer(kr_decode_store* s, int which /*0 hidden, 1 residual*/, float* out, int n);

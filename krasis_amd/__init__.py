@@ -9,5 +9,6 @@ from .engine import KrasisEngine, ModelConfig  # noqa: F401
 from .decode_store import CpuDecodeStore  # noqa: F401
 from .prefill import GpuPrefillManager  # noqa: F401
 from .perplexity import evaluate_perplexity  # noqa: F401
+from .synthetic import bench_decode_synthetic  # noqa: F401
 
-__all__ = ["KrasisEngine", "ModelConfig", "CpuDecodeStore", "GpuPrefillManager", "evaluate_perplexity", "KrasisHipError", "load_library", "lib_path"]
+__all__ = ["KrasisEngine", "ModelConfig", "CpuDecodeStore", "GpuPrefillManager", "evaluate_perplexity", "bench_decode_synthetic", "KrasisHipError", "load_library", "lib_path"]

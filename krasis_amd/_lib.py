@@ -23,7 +23,12 @@ SYMBOLS = [
     "kr_decode_add_gqa_layer", "kr_decode_add_mla_layer", "kr_decode_prefill", "kr_decode_prefill_nll", "kr_decode_reset_state", "kr_decode_generate", "kr_decode_sample", "kr_decode_set_prefill_chunk", "kr_decode_set_prefill_depth", "kr_decode_set_layer_moe", "kr_decode_set_layer_dense", "kr_decode_set_rope", "kr_decode_finalize", "kr_decode_set_kv_dtype", "kr_decode_set_attention_mode",
     "kr_decode_set_state", "kr_decode_fill_state_synthetic", "kr_decode_get_state", "kr_decode_step", "kr_decode_generate_greedy",
     "kr_decode_last_token", "kr_decode_set_use_graph", "kr_decode_read_buffer", "kr_decode_device_bytes", "kr_decode_profile_step",
+    "kr_decode_generate_stream", "kr_decode_cancel", "kr_decode_reset_cancel", "kr_decode_last_elapsed_s", "kr_decode_matmul", "kr_decode_matmul_batch",
+    "kr_decode_fused_add_rmsnorm", "kr_decode_rmsnorm", "kr_decode_silu_mul", "kr_decode_fused_shared_expert", "kr_decode_linear_attention_recurrent",
+    "kr_decode_gated_rmsnorm_silu", "kr_decode_linear_attention_conv", "kr_decode_store_route_weight", "kr_decode_moe_route", "kr_decode_num_route_weights",
+    "kr_decode_weight_bytes",
 ]
+TOKEN_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.c_void_p)      # kr_token_cb(token, finish_reason, user) -> continue?
 
 
 class KrasisHipError(RuntimeError):
@@ -133,6 +138,22 @@ def load_library() -> C.CDLL:
     lib.kr_decode_read_buffer.argtypes = [vp, ci, vp, ci]
     lib.kr_decode_profile_step.argtypes = [vp, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_long), ci]
     lib.kr_decode_device_bytes.argtypes = [vp]; lib.kr_decode_device_bytes.restype = C.c_size_t
+    lib.kr_decode_generate_stream.argtypes = [vp, ci, ci, ci, cf, ci, cf, vp, ci, cf, C.c_uint64, TOKEN_CB, vp, vp, vp]
+    lib.kr_decode_cancel.argtypes = [vp]; lib.kr_decode_reset_cancel.argtypes = [vp]
+    lib.kr_decode_last_elapsed_s.argtypes = [vp]; lib.kr_decode_last_elapsed_s.restype = C.c_double
+    lib.kr_decode_matmul.argtypes = [vp, ci, vp, vp]
+    lib.kr_decode_matmul_batch.argtypes = [vp, vp, ci, vp, vp]
+    lib.kr_decode_fused_add_rmsnorm.argtypes = [vp, vp, vp, vp, ci, cf, ci, ci]
+    lib.kr_decode_rmsnorm.argtypes = [vp, vp, vp, cf, vp, ci]
+    lib.kr_decode_silu_mul.argtypes = [vp, vp, vp, vp, ci]
+    lib.kr_decode_fused_shared_expert.argtypes = [vp, ci, ci, vp, vp]
+    lib.kr_decode_linear_attention_recurrent.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci]
+    lib.kr_decode_gated_rmsnorm_silu.argtypes = [vp, vp, vp, vp, vp, cf, ci, ci]
+    lib.kr_decode_linear_attention_conv.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci]
+    lib.kr_decode_store_route_weight.argtypes = [vp, vp, ci, ci, vp, vp, vp]
+    lib.kr_decode_moe_route.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci]
+    lib.kr_decode_num_route_weights.argtypes = [vp]
+    lib.kr_decode_weight_bytes.argtypes = [vp, ci]; lib.kr_decode_weight_bytes.restype = C.c_size_t
     _lib = lib
     return lib
 

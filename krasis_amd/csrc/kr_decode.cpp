@@ -63,6 +63,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    kr_standalone_release(s);
     for (auto& w : s->weights) { w->ms.q.release(); w->ms.s.release(); w->ms.wsum.release(); }
     for (auto& n : s->norms) n->release();
     for (auto& l : s->layers)
@@ -783,10 +784,14 @@ extern "C" int kr_decode_sample(kr_decode_store* s, float temperature, int top_k
 
 // generate_batch (decode.rs:3525): decode_step -> presence penalty on seen tokens -> sample_from_logits; the sampled token is appended
 // BEFORE the stop test (decode.rs:3587-3591), so a stop id is the last element of the result.
-extern "C" int kr_decode_generate(kr_decode_store* s, int first_token, int start_pos, int max_tokens, float temperature, int top_k, float top_p,
-                                  const int* stop_ids, int n_stop, float presence_penalty, uint64_t rng_seed, int* tokens_out, int* n_out, void* stream) {
+// generate_batch (decode.rs:3525) and generate_stream (decode.rs:3611) share one loop.  on_token != nullptr is the streaming form: the cancel
+// flag is polled before every step (a cancelled run reports the last token with reason 3), and the callback gets (token, finish_reason:
+// 0 none, 1 stop, 2 length, 3 cancelled); returning 0 ends the run.  Both forms record the wall time of the loop (last_decode_elapsed_s).
+static int generate_core(kr_decode_store* s, int first_token, int start_pos, int max_tokens, float temperature, int top_k, float top_p,
+                         const int* stop_ids, int n_stop, float presence_penalty, uint64_t rng_seed, int* tokens_out, int* n_out, void* stream,
+                         kr_token_cb on_token, void* user) {
     if (int rc = need_cfg(s)) return rc;
-    if (!tokens_out || !n_out) return kr_fail(KR_ERR_VALUE, "null output pointer");
+    if (!n_out || (!tokens_out && !on_token)) return kr_fail(KR_ERR_VALUE, "null output pointer");
     if (temperature < 0.0f) return kr_fail(KR_ERR_VALUE, "temperature must be >= 0");
     KR_HIP(hipSetDevice(s->eng->device));
     hipStream_t st = kr_pick_stream(s->eng, stream);
@@ -799,8 +804,11 @@ extern "C" int kr_decode_generate(kr_decode_store* s, int first_token, int start
         KR_HIP(hipMemcpyAsync(s->smp_rng.p, &rng_seed, 8, hipMemcpyHostToDevice, st));
     }
     int tok = first_token, n = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto stamp = [&]() { kr_standalone_set_elapsed(s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
     for (int i = 0; i < max_tokens; i++) {
-        if (int rc = kr_decode_step(s, tok, start_pos + i, nullptr, st)) return rc;     // graph replay ends with the greedy argmax into s->tok
+        if (on_token && kr_standalone_cancelled(s)) { on_token(tok, 3, user); break; }
+        if (int rc = kr_decode_step(s, tok, start_pos + i, nullptr, st)) { stamp(); return rc; }     // graph replay ends with the greedy argmax into s->tok
         if (sampled) {
             uint64_t* keys = (uint64_t*)s->smp_keys.p;
             if (kr_launch_sample((float*)s->logits.p, s->vocab, temperature, top_k, top_p, presence_penalty, (uint32_t*)s->smp_seen.p, keys, keys + s->vocab,
@@ -814,13 +822,32 @@ extern "C" int kr_decode_generate(kr_decode_store* s, int first_token, int start
         int next = 0;
         KR_HIP(hipMemcpyAsync(&next, s->tok.p, 4, hipMemcpyDeviceToHost, st));
         KR_HIP(hipStreamSynchronize(st));
-        tokens_out[n++] = next; tok = next;
+        if (tokens_out) tokens_out[n] = next;
+        n++; tok = next;
         bool stop = false;
         for (int j = 0; j < n_stop; j++) stop |= (stop_ids[j] == next);
-        if (stop) break;
+        if (on_token) {
+            const int reason = stop ? 1 : (n >= max_tokens ? 2 : 0);
+            const int cont = on_token(next, reason, user);
+            if (reason || !cont) break;
+        } else if (stop) break;
     }
+    stamp();
     *n_out = n;
     return KR_OK;
+}
+
+extern "C" int kr_decode_generate(kr_decode_store* s, int first_token, int start_pos, int max_tokens, float temperature, int top_k, float top_p,
+                                  const int* stop_ids, int n_stop, float presence_penalty, uint64_t rng_seed, int* tokens_out, int* n_out, void* stream) {
+    if (!tokens_out) return kr_fail(KR_ERR_VALUE, "null output pointer");
+    return generate_core(s, first_token, start_pos, max_tokens, temperature, top_k, top_p, stop_ids, n_stop, presence_penalty, rng_seed, tokens_out, n_out, stream, nullptr, nullptr);
+}
+
+extern "C" int kr_decode_generate_stream(kr_decode_store* s, int first_token, int start_pos, int max_tokens, float temperature, int top_k, float top_p,
+                                         const int* stop_ids, int n_stop, float presence_penalty, uint64_t rng_seed, kr_token_cb on_token, void* user, int* n_out,
+                                         void* stream) {
+    if (!on_token) return kr_fail(KR_ERR_VALUE, "generate_stream needs a token callback");
+    return generate_core(s, first_token, start_pos, max_tokens, temperature, top_k, top_p, stop_ids, n_stop, presence_penalty, rng_seed, nullptr, n_out, stream, on_token, user);
 }
 
 extern "C" int kr_decode_generate_greedy(kr_decode_store* s, int first_token, int start_pos, int max_tokens, const int* stop_ids, int n_stop,

@@ -30,7 +30,9 @@ struct DLayer {
     int gate_wid = -1, up_wid = -1, down_wid = -1;
 };
 
+struct kr_standalone_state;   // kr_decode_standalone.cpp: staging buffers, stand-alone router gates, cancel flag, elapsed time
 struct kr_decode_store {
+    kr_standalone_state* standalone = nullptr;
     kr_engine* eng = nullptr; int device = 0; bool own_eng = false;   // own_eng: a bare engine made by kr_decode_create(NULL, ...), replaced by kr_decode_set_moe_store
     int group_size = 128; bool norm_bias_one = false;
     std::vector<std::unique_ptr<DWeight>> weights;
@@ -71,4 +73,7 @@ enum { PK_EMBED = 0, PK_RMSNORM, PK_MATVEC, PK_LA_CONV, PK_LA_RECUR, PK_GATED_NO
 
 
 static inline KrMatDev mv(kr_decode_store* s, int wid) { return s->weights[wid]->ms.view(); }
-int kr_ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st);   // kr_engine.cpp: per (group, column) nibble sums for the int8-MFMA GEMM
+int kr_ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st);
+void kr_standalone_release(kr_decode_store* s);
+int kr_standalone_cancelled(kr_decode_store* s);
+void kr_standalone_set_elapsed(kr_decode_store* s, double sec);   // kr_engine.cpp: per (group, column) nibble sums for the int8-MFMA GEMM

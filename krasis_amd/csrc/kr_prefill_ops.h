@@ -39,6 +39,7 @@ void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const flo
 // FAST mode (kr_attn_flash.hip): causal flash attention on f16 MFMA after the same prep launch; non-zero = geometry not covered
 int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st);
 void kr_launch_pfm_gqa_prep(const KrPfmGqaArgs& a, int C, hipStream_t st);
+int kr_launch_pfm_la_recur(float* state, const float* q, const float* k, const float* v, const float* gexp, const float* beta, float* out, int nv, int dk, int dv, int C, hipStream_t st);
 // FAST mode (kr_la_chunk.hip): the gated delta rule over the chunk in sub-chunks of 64 tokens on the f32 MFMA; non-zero = geometry not covered
 int kr_launch_pfm_la_chunked(const KrPfmLaArgs& a, float* recur_state, float* recur_out, float* scratch, int C, hipStream_t st);
 size_t kr_pfm_la_chunk_scratch_floats(int C, int nv);

@@ -690,6 +690,14 @@ int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out,
     hipLaunchKernelGGL(kr_pfm_gated_norm_kernel, dim3(a.nv, C), dim3(a.dv), 0, st, recur_out, a.z, norm_w, gated_out, a.nv, a.dv, eps);
     return 0;
 }
+// the recurrence alone (stand-alone operator linear_attention_recurrent, decode.rs:609): gexp = e^g per (token, head); non-zero = unsupported geometry
+int kr_launch_pfm_la_recur(float* state, const float* q, const float* k, const float* v, const float* gexp, const float* beta, float* out, int nv, int dk, int dv, int C, hipStream_t st) {
+    if (dv > 256 || dv % 8 || dv < dk) return 1;
+    if (dk == 128) hipLaunchKernelGGL(kr_pfm_la_recur_kernel<128>, dim3(nv), dim3(dv), 0, st, state, q, k, v, gexp, beta, out, nv, dv, C);
+    else if (dk == 64) hipLaunchKernelGGL(kr_pfm_la_recur_kernel<64>, dim3(nv), dim3(dv), 0, st, state, q, k, v, gexp, beta, out, nv, dv, C);
+    else return 1;
+    return 0;
+}
 int kr_pfm_gqa_tile(int nh, int nkv) { const int group = nh / nkv; int tt = PFA_TT_MAX / group; return tt < 1 ? 0 : tt; }
 void kr_launch_pfm_gqa_prep(const KrPfmGqaArgs& a, int C, hipStream_t st) {
     hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, C), dim3(256), 0, st, a);

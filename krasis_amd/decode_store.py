@@ -115,7 +115,12 @@ class CpuDecodeStore:
         bias = rd(bias_ptr, bias_len) if bias_ptr and bias_len else None
         esc = rd(e_score_corr_ptr, e_score_corr_len) if e_score_corr_ptr and e_score_corr_len else None
         self._routes.append((gate, bias, esc))
-        return len(self._routes) - 1
+        # the device copy serves the stand-alone moe_route (decode.rs:955); the engine's routers get theirs through _push_routes
+        rid = C.c_int()
+        check(self._lib.kr_decode_store_route_weight(self._h, _addr(gate), num_experts, hidden_dim, _addr(bias) if bias is not None else None,
+                                                     _addr(esc) if esc is not None else None, C.byref(rid)))
+        assert rid.value == len(self._routes) - 1
+        return rid.value
 
     def num_weights(self) -> int:
         return self._n_weights
@@ -125,6 +130,75 @@ class CpuDecodeStore:
 
     def total_bytes(self) -> int:
         return self.device_bytes()
+
+    def weight_bytes(self, weight_id: int) -> int:
+        """decode.rs:1107 -- packed words * 4 + bf16 scales * 2 of one stored weight"""
+        return int(self._lib.kr_decode_weight_bytes(self._h, weight_id))
+
+    def self_addr(self) -> int:
+        """decode.rs:269 -- raw address of the store for GIL-free callers: here the kr_decode_store* handle of the C ABI"""
+        return int(self._h.value or 0)
+
+    def consolidate_weights_mmap(self) -> None:
+        """decode.rs:2341 consolidates the CPU engine's weights into one NUMA-interleaved mmap; HBM allocations need no such step."""
+
+    # ------------------------------------------------------------------ stand-alone operators (decode.rs:328-1086)
+    # Pointers are plain addresses like the reference's (tensor.data_ptr()); host AND device addresses are accepted.  The arithmetic runs on
+    # the GPU (csrc/kr_decode_standalone.cpp); results are bit-identical to the reference methods.
+    def matmul(self, weight_id: int, input_ptr: int, output_ptr: int) -> None:
+        check(self._lib.kr_decode_matmul(self._h, weight_id, input_ptr, output_ptr))
+
+    def matmul_batch(self, weight_ids: Sequence[int], input_ptr: int, output_ptrs: Sequence[int]) -> None:
+        if len(weight_ids) != len(output_ptrs):
+            raise ValueError("weight_ids and output_ptrs must have same length")          # decode.rs:370
+        n = len(weight_ids)
+        ids = (C.c_int * max(n, 1))(*weight_ids); outs = (C.c_void_p * max(n, 1))(*output_ptrs)
+        check(self._lib.kr_decode_matmul_batch(self._h, ids, n, input_ptr, outs))
+
+    def fused_add_rmsnorm(self, hidden_ptr: int, residual_ptr: int, weight_ptr: int, eps: float, size: int, first_call: bool) -> None:
+        if not weight_ptr:
+            raise ValueError("null weight pointer")
+        check(self._lib.kr_decode_fused_add_rmsnorm(self._h, hidden_ptr, residual_ptr, weight_ptr, -1, eps, size, int(first_call)))
+
+    def fused_add_rmsnorm_id(self, hidden_ptr: int, residual_ptr: int, norm_id: int, eps: float, size: int, first_call: bool) -> None:
+        check(self._lib.kr_decode_fused_add_rmsnorm(self._h, hidden_ptr, residual_ptr, None, norm_id, eps, size, int(first_call)))
+
+    def rmsnorm(self, input_ptr: int, weight_ptr: int, eps: float, output_ptr: int, size: int) -> None:
+        check(self._lib.kr_decode_rmsnorm(self._h, input_ptr, weight_ptr, eps, output_ptr, size))
+
+    def silu_mul(self, gate_ptr: int, up_ptr: int, output_ptr: int, size: int) -> None:
+        check(self._lib.kr_decode_silu_mul(self._h, gate_ptr, up_ptr, output_ptr, size))
+
+    def fused_shared_expert(self, gate_up_wid: int, down_wid: int, input_ptr: int, output_ptr: int) -> None:
+        check(self._lib.kr_decode_fused_shared_expert(self._h, gate_up_wid, down_wid, input_ptr, output_ptr))
+
+    def linear_attention_recurrent(self, state_ptr: int, q_ptr: int, k_ptr: int, v_ptr: int, g_ptr: int, beta_ptr: int, output_ptr: int,
+                                   nv: int, dk: int, dv: int) -> None:
+        check(self._lib.kr_decode_linear_attention_recurrent(self._h, state_ptr, q_ptr, k_ptr, v_ptr, g_ptr, beta_ptr, output_ptr, nv, dk, dv))
+
+    def gated_rmsnorm_silu(self, x_ptr: int, z_ptr: int, norm_weight_ptr: int, output_ptr: int, eps: float, nv: int, dv: int) -> None:
+        check(self._lib.kr_decode_gated_rmsnorm_silu(self._h, x_ptr, z_ptr, norm_weight_ptr, output_ptr, eps, nv, dv))
+
+    def linear_attention_conv(self, qkvz_ptr: int, ba_ptr: int, conv_state_ptr: int, conv_weight_ptr: int, a_log_ptr: int, dt_bias_ptr: int, scale: float,
+                              q_out_ptr: int, k_out_ptr: int, v_out_ptr: int, z_out_ptr: int, g_out_ptr: int, beta_out_ptr: int,
+                              nk: int, nv: int, dk: int, dv: int, hr: int, kernel_dim: int) -> None:
+        check(self._lib.kr_decode_linear_attention_conv(self._h, qkvz_ptr, ba_ptr, conv_state_ptr, conv_weight_ptr, a_log_ptr, dt_bias_ptr, scale,
+                                                        q_out_ptr, k_out_ptr, v_out_ptr, z_out_ptr, g_out_ptr, beta_out_ptr, nk, nv, dk, dv, hr, kernel_dim))
+
+    def moe_route(self, route_id: int, hidden_ptr: int, topk_ids_out_ptr: int, topk_weights_out_ptr: int, topk: int, scoring_func: int,
+                  norm_topk_prob: bool) -> None:
+        check(self._lib.kr_decode_moe_route(self._h, route_id, hidden_ptr, topk_ids_out_ptr, topk_weights_out_ptr, topk, scoring_func, int(norm_topk_prob)))
+
+    # ------------------------------------------------------------------ cancellation / timing (decode.rs:253-265)
+    @property
+    def last_decode_elapsed_s(self) -> float:
+        return float(self._lib.kr_decode_last_elapsed_s(self._h))
+
+    def cancel(self) -> None:
+        check(self._lib.kr_decode_cancel(self._h))
+
+    def reset_cancel(self) -> None:
+        check(self._lib.kr_decode_reset_cancel(self._h))
 
     def repack_to_tiled(self) -> None:
         """decode.rs repack_to_tiled: the CPU engine re-tiles its weights for bandwidth; the HBM layout is already lane-tiled."""
@@ -263,6 +337,38 @@ class CpuDecodeStore:
                                            presence_penalty, rng_seed, out, C.byref(n), None))
         return list(out[: n.value])
 
+    def generate_stream(self, first_token: int, start_position: int, max_tokens: int, temperature: float, top_k: int, top_p: float,
+                        stop_ids: Sequence[int], tokenizer, presence_penalty: float, on_token, rng_seed: int = 0) -> int:
+        """decode.rs:3611 -- the cancellable loop of the reference's Rust server.  on_token(token_id, text, finish_reason) -> bool (False cancels);
+        finish_reason is None, "stop", "length" or "cancelled".  `tokenizer` is anything with decode(ids, skip_special_tokens=...) (tokenizers /
+        transformers) or None (text = "").  Returns the number of generated tokens."""
+        self._need()
+        from ._lib import TOKEN_CB
+        reasons = {0: None, 1: "stop", 2: "length", 3: "cancelled"}
+        err: list = []
+
+        def cb(token, reason, _user):
+            try:
+                text = ""
+                if tokenizer is not None and reason != 3:
+                    try:
+                        text = tokenizer.decode([int(token)], skip_special_tokens=True)
+                    except TypeError:
+                        text = tokenizer.decode([int(token)])
+                return 1 if on_token(int(token), text or "", reasons[reason]) else 0
+            except BaseException as e:        # an exception must not unwind through the C frame
+                err.append(e)
+                return 0
+
+        cfn = TOKEN_CB(cb)
+        n = C.c_int()
+        stops = (C.c_int * max(len(stop_ids), 1))(*stop_ids)
+        check(self._lib.kr_decode_generate_stream(self._h, first_token, start_position, max_tokens, temperature, top_k, top_p, stops, len(stop_ids),
+                                                  presence_penalty, rng_seed, cfn, None, C.byref(n), None))
+        if err:
+            raise err[0]
+        return n.value
+
     def sample(self, temperature: float, top_k: int = 0, top_p: float = 1.0, presence_penalty: float = 0.0, rng_seed: int = 0, reset_seen: bool = False) -> int:
         """sample_from_logits (decode.rs:3718) on the logits of the last decode_step / prefill."""
         self._need()
@@ -281,3 +387,11 @@ class CpuDecodeStore:
 
     def device_bytes(self) -> int:
         self._need(); return int(self._lib.kr_decode_device_bytes(self._h))
+
+    def profile_step(self, token_id: int, position: int):
+        """one un-graphed decode step with HIP events around every launch -> [(ms, launches)] per kernel kind (include/krasis_hip.h lists the kinds);
+        the stand-in for KRASIS_CPU_DECODE_TIMING's per-op buckets (decode.rs:3477-3517)"""
+        self._need()
+        ms = (C.c_double * 16)(); cnt = (C.c_long * 16)()
+        check(self._lib.kr_decode_profile_step(self._h, token_id, position, ms, cnt, 16))
+        return [(ms[i], cnt[i]) for i in range(15)]

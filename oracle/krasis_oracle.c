@@ -1050,6 +1050,78 @@ void kro_gated_rmsnorm_silu(const float* recur, const float* z, const float* w, 
     }
 }
 
+/* ---- the stand-alone CpuDecodeStore operators (src/decode.rs:473-890): plain scalar loops and libm exp, NOT the decode graph's AVX2 forms
+ * above.  Restated operation for operation (the oracle is built with -ffp-contract=off: `a += b * c` is a multiply and an add, as in rustc). */
+void kro_op_rmsnorm(const float* x, const float* w, float* out, int n, float eps, int bias_one) { /* decode.rs:473-507 */
+    float ss = 0.0f; for (int i = 0; i < n; i++) ss += x[i] * x[i];
+    float rms = 1.0f / sqrtf(ss / (float)n + eps);
+    if (bias_one) for (int i = 0; i < n; i++) out[i] = x[i] * rms * (1.0f + w[i]);
+    else for (int i = 0; i < n; i++) out[i] = x[i] * rms * w[i];
+}
+void kro_op_silu_mul(const float* gate, const float* up, float* out, int n) { /* decode.rs:511-538 */
+    for (int i = 0; i < n; i++) { float x = gate[i]; float sg = 1.0f / (1.0f + expf(-x)); out[i] = x * sg * up[i]; }
+}
+void kro_op_gated_rmsnorm_silu(const float* x, const float* z, const float* w, float* out, float eps, int nv, int dv) { /* decode.rs:650-695 */
+    for (int h = 0; h < nv; h++) {
+        int base = h * dv; float ss = 0.0f;
+        for (int j = 0; j < dv; j++) ss += x[base + j] * x[base + j];
+        float rms = 1.0f / sqrtf(ss / (float)dv + eps);
+        for (int j = 0; j < dv; j++) {
+            float normed = x[base + j] * rms * w[base + j]; float zv = z[base + j];
+            float silu_z = zv / (1.0f + expf(-zv));
+            out[base + j] = silu_z * normed;
+        }
+    }
+}
+void kro_op_la_conv(const float* qkvz, const float* ba, float* conv_state, const float* conv_w, const float* a_log, const float* dt_bias, float scale,
+                    float* q, float* k, float* v, float* z, float* g, float* beta, int nk, int nv, int dk, int dv, int hr, int kd) { /* decode.rs:713-890 */
+    int conv_dim = nk * dk * 2 + nv * dv, group_dim = 2 * dk + 2 * dv * hr, key_dim = nk * dk;
+    float* mixed = (float*)calloc((size_t)conv_dim, 4); float* co = (float*)calloc((size_t)conv_dim, 4);
+    float* b_raw = (float*)calloc((size_t)nv, 4); float* a_param = (float*)calloc((size_t)nv, 4);
+    for (int h = 0; h < nk; h++) {
+        int src = h * group_dim;
+        memcpy(mixed + h * dk, qkvz + src, 4 * (size_t)dk);
+        memcpy(mixed + key_dim + h * dk, qkvz + src + dk, 4 * (size_t)dk);
+        for (int r = 0; r < hr; r++) {
+            int vh = h * hr + r;
+            memcpy(mixed + 2 * key_dim + vh * dv, qkvz + src + 2 * dk + r * dv, 4 * (size_t)dv);
+            memcpy(z + vh * dv, qkvz + src + 2 * dk + hr * dv + r * dv, 4 * (size_t)dv);
+        }
+    }
+    for (int h = 0; h < nk; h++) for (int r = 0; r < hr; r++) { b_raw[h * hr + r] = ba[h * 2 * hr + r]; a_param[h * hr + r] = ba[h * 2 * hr + hr + r]; }
+    for (int ch = 0; ch < conv_dim; ch++) {
+        int base = ch * kd;
+        for (int t = 0; t < kd - 1; t++) conv_state[base + t] = conv_state[base + t + 1];
+        conv_state[base + kd - 1] = mixed[ch];
+    }
+    for (int ch = 0; ch < conv_dim; ch++) {
+        float dot = 0.0f;
+        for (int t = 0; t < kd; t++) dot += conv_state[ch * kd + t] * conv_w[ch * kd + t];
+        float sg = 1.0f / (1.0f + expf(-dot));
+        co[ch] = dot * sg;
+    }
+    for (int vh = 0; vh < nv; vh++) {
+        int kh = vh / hr, sb = kh * dk, db = vh * dk; float ss = 0.0f;
+        for (int i = 0; i < dk; i++) { float val = co[sb + i]; ss += val * val; }
+        float inv = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        for (int i = 0; i < dk; i++) q[db + i] = co[sb + i] * inv * scale;
+    }
+    for (int vh = 0; vh < nv; vh++) {
+        int kh = vh / hr, sb = key_dim + kh * dk, db = vh * dk; float ss = 0.0f;
+        for (int i = 0; i < dk; i++) { float val = co[sb + i]; ss += val * val; }
+        float inv = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        for (int i = 0; i < dk; i++) k[db + i] = co[sb + i] * inv;
+    }
+    memcpy(v, co + 2 * key_dim, 4 * (size_t)(nv * dv));
+    for (int h = 0; h < nv; h++) {
+        beta[h] = 1.0f / (1.0f + expf(-b_raw[h]));
+        float ap_dt = a_param[h] + dt_bias[h];
+        float softplus = ap_dt > 20.0f ? ap_dt : logf(1.0f + expf(ap_dt));
+        g[h] = -(expf(a_log[h])) * softplus;
+    }
+    free(mixed); free(co); free(b_raw); free(a_param);
+}
+
 /* torch.float8_e4m3fn codecs (c10/util/Float8_e4m3fn.h: fp8e4m3fn_from_fp32_value / to_fp32): RNE, |x| >= 480 -> NaN (0x7F), no saturation;
  * the reference's GPU KV cache dtype (python/krasis/kv_cache.py:38-135) */
 uint8_t kro_f32_to_e4m3(float f) {

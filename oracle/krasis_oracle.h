@@ -147,6 +147,12 @@ void kro_la_recurrent(float* state, const float* q, const float* k, const float*
                       float* out, int nv, int dk, int dv);                                                            /* decode.rs:1293 */
 void kro_gated_rmsnorm_silu(const float* recur, const float* z, const float* w, float* out, int nv, int dv, float eps,
                             int sig_mode);                                                                            /* decode.rs:3979 */
+/* stand-alone CpuDecodeStore operators (decode.rs:473-890): scalar loops + libm exp, not the decode graph's AVX2 forms */
+void kro_op_rmsnorm(const float* x, const float* w, float* out, int n, float eps, int bias_one);
+void kro_op_silu_mul(const float* gate, const float* up, float* out, int n);
+void kro_op_gated_rmsnorm_silu(const float* x, const float* z, const float* w, float* out, float eps, int nv, int dv);
+void kro_op_la_conv(const float* qkvz, const float* ba, float* conv_state, const float* conv_w, const float* a_log, const float* dt_bias, float scale,
+                    float* q, float* k, float* v, float* z, float* g, float* beta, int nk, int nv, int dk, int dv, int hr, int kd);
 /* decode.rs:2873-2975 + :4194 ; q_in = q_proj output ([nh*hd] or [nh*2*hd] if gated); writes k/v fp16 at position */
 void kro_gqa_step(const float* q_in, float* k, float* v, const float* q_norm, int q_norm_len, const float* k_norm,
                   int k_norm_len, int gated, int nh, int nkv, int hd, float eps, const float* rope_cos,

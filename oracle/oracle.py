@@ -502,6 +502,36 @@ def gated_rmsnorm_silu(recur, z, w, nv, dv, eps, mode=SIG_POLY5_DIV):
     return out
 
 
+
+# ---- stand-alone CpuDecodeStore operators (decode.rs:473-890): scalar loops + libm exp (kro_op_*) ----
+def op_rmsnorm(x, w, eps, bias_one=False):
+    x = _c(x, np.float32); out = np.empty_like(x)
+    lib().kro_op_rmsnorm(_p(x), _p(_c(w, np.float32)), _p(out), x.size, C.c_float(eps), int(bias_one))
+    return out
+
+
+def op_silu_mul(gate, up):
+    gate = _c(gate, np.float32); out = np.empty_like(gate)
+    lib().kro_op_silu_mul(_p(gate), _p(_c(up, np.float32)), _p(out), gate.size)
+    return out
+
+
+def op_gated_rmsnorm_silu(x, z, w, eps, nv, dv):
+    out = np.empty(nv * dv, np.float32)
+    lib().kro_op_gated_rmsnorm_silu(_p(_c(x, np.float32)), _p(_c(z, np.float32)), _p(_c(w, np.float32)), _p(out), C.c_float(eps), nv, dv)
+    return out
+
+
+def op_la_conv(qkvz, ba, conv_state, conv_w, a_log, dt_bias, scale, nk, nv, dk, dv, hr, kd):
+    """-> (q, k, v, z, g, beta, conv_state_new); conv_state [conv_dim, kd] is copied, the copy is updated"""
+    cs = _c(conv_state, np.float32).copy()
+    q = np.empty(nv * dk, np.float32); k = np.empty(nv * dk, np.float32); v = np.empty(nv * dv, np.float32); z = np.empty(nv * dv, np.float32)
+    g = np.empty(nv, np.float32); beta = np.empty(nv, np.float32)
+    lib().kro_op_la_conv(_p(_c(qkvz, np.float32)), _p(_c(ba, np.float32)), _p(cs), _p(_c(conv_w, np.float32)), _p(_c(a_log, np.float32)), _p(_c(dt_bias, np.float32)),
+                         C.c_float(scale), _p(q), _p(k), _p(v), _p(z), _p(g), _p(beta), nk, nv, dk, dv, hr, kd)
+    return q, k, v, z, g, beta, cs
+
+
 def gqa_step(q_in, k, v, q_norm, k_norm, gated, nh, nkv, hd, eps, rope_cos, rope_sin, k_cache, v_cache, position, sm_scale):
     """Returns (attn_out, k_cache, v_cache) with caches updated at `position`."""
     q_in = _c(q_in, np.float32); k = _c(k, np.float32).copy(); v = _c(v, np.float32).copy()
