@@ -12,6 +12,7 @@
 // Same products, same exp (the libm twin), a different summation order: the attention output differs in its last bits; after the INT16
 // re-quantisation of the o-projection input the logits move by ~1e-4 relative (tests/test_attn_fast_gpu.py states 5e-4).
 #pragma once
+#include "kr_lds_optin.h"
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
@@ -183,13 +184,8 @@ __global__ void __launch_bounds__(256) kr_fd_merge_kernel(const KrFdArgs a, int 
 // set OUTSIDE graph capture (kr_mla_attn_prepare)
 template <int HD, int GMAX>
 static void kr_fd_prepare() {
-    int dev = 0; (void)hipGetDevice(&dev);
-    static bool attr_set[16] = {};
-    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)kr_fd_partial_kernel<HD, false, GMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute((const void*)kr_fd_partial_kernel<HD, true, GMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set[dev] = true;
-    }
+    (void)kr_lds_optin((const void*)kr_fd_partial_kernel<HD, false, GMAX>, 96 * 1024);
+    (void)kr_lds_optin((const void*)kr_fd_partial_kernel<HD, true, GMAX>, 96 * 1024);
 }
 // G <= GMAX is the caller's check
 template <int HD, int GMAX>

@@ -18,6 +18,7 @@
 // The V tile of the current 64 positions is fetched while S^T and the softmax run, the next K tile while O^T accumulates (two barriers per tile).
 #include "kr_device.h"
 #include "kr_libm.h"
+#include "kr_lds_optin.h"
 #include "kr_prefill_ops.h"
 
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
@@ -226,13 +227,11 @@ int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st) {
     if (a.nh % a.nkv || G < 1 || G > FA_ROWS || (FA_ROWS % G) || (a.hd != 64 && a.hd != 128 && a.hd != 256)) return 1;
     const int TQ = FA_ROWS / G;
     const size_t lds = (size_t)FA_TK * (a.hd * 2 + 16) + (size_t)a.hd * (FA_TK * 2 + 16);
-    int dev = 0; (void)hipGetDevice(&dev);
-    static bool attr_set[16] = {};
-    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        const void* fns[6] = {(const void*)kr_pfm_gqa_flash_kernel<256, false>, (const void*)kr_pfm_gqa_flash_kernel<256, true>, (const void*)kr_pfm_gqa_flash_kernel<128, false>,
-                              (const void*)kr_pfm_gqa_flash_kernel<128, true>, (const void*)kr_pfm_gqa_flash_kernel<64, false>, (const void*)kr_pfm_gqa_flash_kernel<64, true>};
-        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set[dev] = true;
+    {
+        const void* fn = a.hd == 256 ? (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash_kernel<256, true> : (const void*)kr_pfm_gqa_flash_kernel<256, false>)
+                       : a.hd == 128 ? (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash_kernel<128, true> : (const void*)kr_pfm_gqa_flash_kernel<128, false>)
+                                     : (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash_kernel<64, true> : (const void*)kr_pfm_gqa_flash_kernel<64, false>);
+        if (kr_lds_optin(fn, 96 * 1024)) return 1;
     }
     dim3 grid((C + TQ - 1) / TQ, a.nkv);
 #define KR_FA(H_, F_) hipLaunchKernelGGL((kr_pfm_gqa_flash_kernel<H_, F_>), grid, dim3(256), lds, st, a, C)

@@ -5,6 +5,7 @@
 //
 // Every reduction that the reference performs with 8 AVX lanes + hsum is performed here by 8 GPU lanes walking the
 // same fma chains and combined with the same tree, so each f32 result carries the same bits.
+#include "kr_lds_optin.h"
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
@@ -1193,27 +1194,23 @@ static size_t kr_gqa_attn_lds(int max_seq, int hd, int fp8) {
 static bool kr_gqa_resident(int max_seq, int hd, int fp8) { return kr_gqa_attn_lds(max_seq, hd, fp8) <= 160 * 1024; }
 int kr_gqa_attn_prepare(int max_seq, int hd, int fp8) {
     const size_t lds = kr_gqa_resident(max_seq, hd, fp8) ? kr_gqa_attn_lds(max_seq, hd, fp8) : kr_gqa_attn_lds(4096, hd, fp8);
-    static size_t lds_set[2] = {0, 0};
-    if (lds > lds_set[fp8 ? 1 : 0]) {
+    {
 #define KR_F(F_, N_) (const void*)kr_gqa_attn_kernel<F_, N_, 0>, (const void*)kr_gqa_attn_kernel<F_, N_, 1>, (const void*)kr_gqa_attn_kernel<F_, N_, 2>, (const void*)kr_gqa_attn_kernel<F_, N_, 3>
         const void* f16[16] = {KR_F(false, 8), KR_F(false, 16), KR_F(false, 32), KR_F(false, 0)};
         const void* f8[16] = {KR_F(true, 8), KR_F(true, 16), KR_F(true, 32), KR_F(true, 0)};
 #undef KR_F
         for (int i = 0; i < 16; i++)
-            if (hipFuncSetAttribute(fp8 ? f8[i] : f16[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        lds_set[fp8 ? 1 : 0] = lds;
+            if (kr_lds_optin(fp8 ? f8[i] : f16[i], lds)) return -2;
     }
     if (hd == 64 || hd == 128 || hd == 256) {    // the producer / consumer softmax + p.v kernel of long caches
         const bool res = kr_gqa_pv_lds(max_seq, hd, fp8) <= 160 * 1024;
         const size_t lp = kr_gqa_pv_lds(res ? max_seq : 4096, hd, fp8);
-        static size_t lp_set[2] = {0, 0};
-        if (lp > lp_set[fp8 ? 1 : 0]) {
+        {
 #define KR_F(N_, F_) (const void*)kr_gqa_pv_kernel<N_, false, F_>, (const void*)kr_gqa_pv_kernel<N_, true, F_>
             const void* f16[6] = {KR_F(8, false), KR_F(16, false), KR_F(32, false)};
             const void* f8[6] = {KR_F(8, true), KR_F(16, true), KR_F(32, true)};
 #undef KR_F
-            for (int i = 0; i < 6; i++) if (hipFuncSetAttribute(fp8 ? f8[i] : f16[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp) != hipSuccess) return -2;
-            lp_set[fp8 ? 1 : 0] = lp;
+            for (int i = 0; i < 6; i++) if (kr_lds_optin(fp8 ? f8[i] : f16[i], lp)) return -2;
         }
     }
     return 0;

@@ -953,6 +953,49 @@ int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_
     return KR_OK;
 }
 
+// Expert-parallel receive side (kr_ep.cpp): `n` rows, each for ONE local expert `lid[r]` (all valid), weight 1, no shared expert.  The rows are
+// sorted by expert like a prompt pass with topk = 1, but the w2 GEMM writes row r's result straight to out[r] (caller's order) in the dtype the
+// rows travel back in: no expert-output buffer, no combine pass, no conversion pass.  The bf16 rounding is the one kr_launch_ep_rows_bf16 applied.
+int kr_moe_prefill_rows(kr_engine* e, int layer, const void* rows_bf16, const int32_t* lid, void* out, int n, int out_bf16, int set, hipStream_t st) {
+    if (int rc = check_layer(e, layer)) return rc;
+    Layer& L = e->layers[layer];
+    if (L.gguf || !L.w13.allocated() || e->cfg.hidden_size % 128 || L.inter % 128) return -1;     // caller falls back to kr_moe_prefill_set
+    std::lock_guard<std::mutex> lk(e->mu);
+    KR_HIP(hipSetDevice(e->device));
+    kr_engine::PfSet& P = e->pf[set % KR_PF_MAX_DEPTH];
+    const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
+    if (int rc = kr_ensure_wsum(e, L.w13, st)) return rc;
+    if (int rc = kr_ensure_wsum(e, L.w2, st)) return rc;
+    const int pairs = e->pf_pairs > 0 ? e->pf_pairs : KR_PF_PAIRS;
+    const int CH = n < pairs ? n : pairs;
+    const size_t np = (size_t)CH;
+    const int max_tiles = (int)(np / 64) + E + 1;
+    const size_t n_i32 = 3 * (size_t)E + 3 * (size_t)max_tiles + 4 + 2 * np;
+    if (P.i32.ensure(n_i32 * 4) || P.xh.ensure((size_t)CH * H) || P.xl.ensure((size_t)CH * H) || P.xs.ensure((size_t)CH * (H / 128) * 4) ||
+        P.gu.ensure(np * 2 * I * 4) || P.hh.ensure(np * I) || P.hl.ensure(np * I) || P.hs.ensure(np * (I / 128) * 4))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
+    int* ib = (int*)P.i32.p;
+    KrPfSort so{};
+    so.counts = ib; so.offsets = ib + E; so.cursor = ib + 2 * E; ib += 3 * E;
+    so.tile_expert = ib; so.tile_row0 = ib + max_tiles; so.tile_rows = ib + 2 * max_tiles; ib += 3 * max_tiles;
+    so.n_tiles = ib; ib += 4; so.row_pair = ib; so.pair_row = ib + np;
+    const int act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
+    const size_t ob = out_bf16 ? 2 : 4;
+    for (int m0 = 0; m0 < n; m0 += CH) {
+        const int mc = n - m0 < CH ? n - m0 : CH;
+        const int tiles_bound = mc / 64 + E + 1;
+        kr_launch_pf_sort(lid + m0, mc, 1, E, so, st);
+        kr_launch_pf_quant_x((const uint16_t*)rows_bf16 + (size_t)m0 * H, mc, H, (int8_t*)P.xh.p, (int8_t*)P.xl.p, (float*)P.xs.p, st);
+        kr_launch_pf_gemm(L.w13.view(), (const uint32_t*)L.w13.wsum.p, (const int8_t*)P.xh.p, (const int8_t*)P.xl.p, (const float*)P.xs.p, &so, 1, 1,
+                          tiles_bound, 0, (float*)P.gu.p, 2 * I, st);
+        kr_launch_pf_act((const float*)P.gu.p, mc, I, 2 * I, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (int8_t*)P.hh.p, (int8_t*)P.hl.p, (float*)P.hs.p, st);
+        kr_launch_pf_gemm(L.w2.view(), (const uint32_t*)L.w2.wsum.p, (const int8_t*)P.hh.p, (const int8_t*)P.hl.p, (const float*)P.hs.p, &so, 1, 0,
+                          tiles_bound, 0, (float*)((char*)out + (size_t)m0 * H * ob), H, st, 1, out_bf16);
+    }
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
 extern "C" int kr_moe_prefill(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
                               int out_dtype, int routed_only, void* stream) {
     if (int rc = check_layer(e, layer)) return rc;

@@ -100,6 +100,7 @@ int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int count);
 int upload_mat(kr_engine* e, MatSet& ms, int idx, const void* w, const uint16_t* sc);
 int download_mat(kr_engine* e, MatSet& ms, int idx, void* w, uint16_t* sc);
 // kr_moe_prefill with an explicit scratch set (0/1) and stream; all pointers device.  out f32 or bf16 per out_dtype.
+int kr_moe_prefill_rows(kr_engine* e, int layer, const void* rows_bf16, const int32_t* lid, void* out, int n, int out_bf16, int set, hipStream_t st);
 int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
                        int out_dtype, int routed_only, int set, hipStream_t st);
 

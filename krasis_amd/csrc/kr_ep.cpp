@@ -144,13 +144,16 @@ extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, co
     kr_launch_ep_sort((const int32_t*)s->dest.p, np, W, so, st);
     kr_launch_ep_gather((const uint16_t*)x_bf16, so.row_pair, (const int32_t*)s->lid.p, topk, H, so.n_tiles + 1, np, (uint16_t*)s->rows.p, (int32_t*)s->row_lid.p, st);
     // ---- send counts of every rank: cnt[src][dst]
-    if (W > 1) KR_NCCL(g_rccl.AllGather(so.counts, s->cnt_all.p, W, ncclInt32, s->comm, st));
-    else KR_HIP(hipMemcpyAsync(s->cnt_all.p, so.counts, 4, hipMemcpyDeviceToDevice, st));
-    KR_HIP(hipMemcpyAsync(s->cnt_host, s->cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st));
-    KR_HIP(hipEventRecord(s->ev, st));
-    KR_HIP(hipEventSynchronize(s->ev));
+    // The host needs the split sizes to post the sends / receives: one small DtoH and an event wait per call.  A world of one posts nothing:
+    // it takes every pair slot as a row (rows past the last routed pair carry local id -1 and belong to no expert tile) and never waits.
     std::vector<size_t> soff(W + 1, 0), roff(W + 1, 0);
-    for (int r = 0; r < W; r++) { soff[r + 1] = soff[r] + (size_t)s->cnt_host[s->rank * W + r]; roff[r + 1] = roff[r] + (size_t)s->cnt_host[r * W + s->rank]; }
+    if (W > 1) {
+        KR_NCCL(g_rccl.AllGather(so.counts, s->cnt_all.p, W, ncclInt32, s->comm, st));
+        KR_HIP(hipMemcpyAsync(s->cnt_host, s->cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st));
+        KR_HIP(hipEventRecord(s->ev, st));
+        KR_HIP(hipEventSynchronize(s->ev));
+        for (int r = 0; r < W; r++) { soff[r + 1] = soff[r] + (size_t)s->cnt_host[s->rank * W + r]; roff[r + 1] = roff[r] + (size_t)s->cnt_host[r * W + s->rank]; }
+    } else { soff[1] = roff[1] = (size_t)np; }
     const size_t n_send = soff[W], n_recv = roff[W];
     // ---- dispatch
     const uint16_t* rrows = (const uint16_t*)s->rows.p; const int32_t* rlid = (const int32_t*)s->row_lid.p;
@@ -174,13 +177,20 @@ extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, co
         if (s->ones.ensure(n_ones * 4 * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
         KR_HIP(hipMemsetD32Async((hipDeviceptr_t)s->ones.p, 0x3F800000, s->ones.bytes / 4, st));      // f32 1.0
     }
-    if (n_recv) if (int rc = kr_moe_prefill_set(e, layer, rrows, rlid, (const float*)s->ones.p, s->eo.p, (int)n_recv, 1, KR_OUT_F32, 1, 0, st)) return rc;
-    // ---- return
+    // the w2 GEMM writes every row at its place, in the dtype it travels back in (kr_moe_prefill_rows); native-GGUF layers take the generic
+    // prompt-pass entry (combine with weight 1 = a copy) and a conversion pass
     const void* back = s->eo.p;
-    if (s->ret_bf16) {
-        if (s->eo16.ensure((n_recv ? n_recv : 1) * (size_t)H * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
-        kr_launch_ep_rows_bf16((const float*)s->eo.p, (uint16_t*)s->eo16.p, n_recv * (size_t)H, st);
-        back = s->eo16.p;
+    if (n_recv) {
+        const int rc = kr_moe_prefill_rows(e, layer, rrows, rlid, s->eo.p, (int)n_recv, s->ret_bf16 ? 1 : 0, 0, st);
+        if (rc > 0) return rc;
+        if (rc < 0) {
+            if (int rc2 = kr_moe_prefill_set(e, layer, rrows, rlid, (const float*)s->ones.p, s->eo.p, (int)n_recv, 1, KR_OUT_F32, 1, 0, st)) return rc2;
+            if (s->ret_bf16) {
+                if (s->eo16.ensure(n_recv * (size_t)H * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+                kr_launch_ep_rows_bf16((const float*)s->eo.p, (uint16_t*)s->eo16.p, n_recv * (size_t)H, st);
+                back = s->eo16.p;
+            }
+        }
     }
     if (W > 1) {
         const size_t esz = s->ret_bf16 ? 2 : 4;

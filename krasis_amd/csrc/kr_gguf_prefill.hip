@@ -18,6 +18,7 @@
 // k order inside a sub-block: the HBM lane records (kr_gguf.hip header) hold bytes {2l, 2l+1, 16+2l, 17+2l} for l = 0..7, i.e. position
 // p = 4l + i <-> element e(p); the activation digit planes are written in the same order by the quantizers below, so records are copied
 // to LDS without a byte shuffle (the MFMA sums over k in any order as long as A and B agree).
+#include "kr_lds_optin.h"
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_gguf.h"
@@ -398,13 +399,7 @@ void kr_launch_gpf_gemm(const GgMat& m, const void* ws, size_t ws_stride, const 
     const int mt = single_expert_rows > 0 ? (single_expert_rows + GPF_BM - 1) / GPF_BM : max_tiles;
     const bool q4k = m.type == GG_Q4_K;
     const size_t lds = (size_t)2 * GPF_BM * GPF_LDA + (size_t)GPF_BN * ((q4k ? 128 : 256) + 16) + (size_t)(2 * 8 * GPF_BM + 3 * 8 * GPF_BN + GPF_BM) * 4;
-    int dev = 0; (void)hipGetDevice(&dev);
-    static bool attr_set[2][16] = {};      // per (type, device): the dynamic-LDS opt-in is a per-device function attribute
-    if (dev >= 0 && dev < 16 && !attr_set[q4k ? 0 : 1][dev]) {
-        if (q4k) (void)hipFuncSetAttribute((const void*)kr_gpf_gemm_kernel<GG_Q4_K>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        else (void)hipFuncSetAttribute((const void*)kr_gpf_gemm_kernel<GG_Q8_0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set[q4k ? 0 : 1][dev] = true;
-    }
+    (void)kr_lds_optin(q4k ? (const void*)kr_gpf_gemm_kernel<GG_Q4_K> : (const void*)kr_gpf_gemm_kernel<GG_Q8_0>, 96 * 1024);   // per (kernel, device)
     dim3 grid(((mt + 7) / 8) * 8 * ((m.N + GPF_BN - 1) / GPF_BN));
     if (q4k) hipLaunchKernelGGL(kr_gpf_gemm_kernel<GG_Q4_K>, grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL(kr_gpf_gemm_kernel<GG_Q8_0>, grid, dim3(256), lds, st, a);

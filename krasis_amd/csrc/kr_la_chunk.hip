@@ -18,7 +18,7 @@
 // order (tolerance mode: tests/test_attn_fast_gpu.py states it).  All exponents are differences G_t - G_j <= 0: nothing overflows, and a
 // decay that underflows gives 0, not NaN (g is clamped at -80 per token).
 #include <hip/hip_runtime.h>
-#include <mutex>
+#include "kr_lds_optin.h"
 #include "kr_prefill_ops.h"
 
 #ifdef KR_TIMING   // tools/probes/lac_timing.hip: wall-clock stamps (10 ns units) by thread 0 of workgroup (0, 0); no-op in the product build
@@ -293,15 +293,7 @@ bool kr_pfm_la_chunk_ok(int dk, int dv, int C) { return dk == LC_D && dv == LC_D
 
 // > 64 KB of dynamic LDS is an opt-in per device (and not allowed inside a stream capture: the prompt pass is never captured)
 static int lac_prepare() {
-    static std::mutex mu; static bool done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
-    std::lock_guard<std::mutex> g(mu);
-    if (done[dev]) return 0;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kr_lac_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LC_PREP_LDS) != hipSuccess) return 1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kr_lac_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LC_SCAN_LDS) != hipSuccess) return 1;
-    done[dev] = true;
-    return 0;
+    return kr_lds_optin(reinterpret_cast<const void*>(kr_lac_prep_kernel), LC_PREP_LDS) || kr_lds_optin(reinterpret_cast<const void*>(kr_lac_scan_kernel), LC_SCAN_LDS);
 }
 
 int kr_launch_pfm_la_chunked(const KrPfmLaArgs& p, float* state, float* out, float* scratch, int C, hipStream_t st) {

@@ -9,6 +9,7 @@
 //
 // Three launches per layer: prep (norm, RoPE, FP16 cache append, w_kc absorption spread over nh*klr/64 workgroups so the 4 MiB of
 // w_kc streams from many CUs), attention (one workgroup per head), w_vc projection (nh*vhd/8 workgroups, 4 MiB of w_vc).
+#include "kr_lds_optin.h"
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
@@ -654,16 +655,11 @@ static bool kr_launch_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s,
     const size_t esz = a.kv_fp8 ? 1 : 2;
     const size_t lds_sc = (size_t)KR_MLA_HG * (a.klr + a.rd) * 4 + (size_t)KR_MLA_ROWS * ((size_t)(a.klr + a.rd) * esz + 16);
     const size_t lds_pv = kr_mla_pv_lds<NBC, FP8>();
-    static size_t lds_set = 0;                       // per instantiation; raised outside graph capture by kr_mla_attn_prepare
-    if ((prep || !split) && lds <= 160 * 1024 && lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        lds_set = lds;
-    }
-    static bool split_set = false;
-    if ((prep || split) && !split_set) {
-        if (hipFuncSetAttribute((const void*)kr_mla_scores_kernel<FP8, NBC, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess) return false;
-        if (hipFuncSetAttribute((const void*)kr_mla_pv_kernel<NBC, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pv) != hipSuccess) return false;
-        split_set = true;
+    // windows are per (kernel, device) and raised outside graph capture by kr_mla_attn_prepare; inside a capture the table already covers them
+    if ((prep || !split) && lds <= 160 * 1024 && kr_lds_optin((const void*)kr_mla_attn_staged_kernel<FP8, NBC, 8>, lds)) return false;
+    if (prep || split) {
+        if (kr_lds_optin((const void*)kr_mla_scores_kernel<FP8, NBC, 8>, lds_sc)) return false;
+        if (kr_lds_optin((const void*)kr_mla_pv_kernel<NBC, FP8>, lds_pv)) return false;
     }
     if (prep) { kr_fd_prepare<NBC * 8, 16>(); return true; }
     if (split) {

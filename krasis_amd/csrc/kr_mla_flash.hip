@@ -13,6 +13,7 @@
 //   * O^T += V^T P^T: A = the same latent rows written TRANSPOSED ([dim][position], two positions per dword) while the tile is staged --
 //     one global fetch feeds both operands --, B = P^T from the S^T accumulators.
 // q, p rounded to f16; ckv / kpe exact in f16 (FP16 or E4M3 caches).  f32 accumulation and softmax.
+#include "kr_lds_optin.h"
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
@@ -196,14 +197,10 @@ template <int KLR> static size_t kr_mla_flash_lds() { return (size_t)(MF_ROWS + 
 
 // raise the dynamic-LDS window (per device, outside graph capture / before the first launch)
 void kr_mla_flash_prepare() {
-    int dev = 0; (void)hipGetDevice(&dev);
-    static bool attr_set[16] = {};
-    if (dev < 0 || dev >= 16 || attr_set[dev]) return;
-    (void)hipFuncSetAttribute((const void*)kr_mla_flash_kernel<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kr_mla_flash_lds<512>());
-    (void)hipFuncSetAttribute((const void*)kr_mla_flash_kernel<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kr_mla_flash_lds<512>());
-    (void)hipFuncSetAttribute((const void*)kr_mla_flash_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kr_mla_flash_lds<256>());
-    (void)hipFuncSetAttribute((const void*)kr_mla_flash_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kr_mla_flash_lds<256>());
-    attr_set[dev] = true;
+    (void)kr_lds_optin((const void*)kr_mla_flash_kernel<512, false>, kr_mla_flash_lds<512>());
+    (void)kr_lds_optin((const void*)kr_mla_flash_kernel<512, true>, kr_mla_flash_lds<512>());
+    (void)kr_lds_optin((const void*)kr_mla_flash_kernel<256, false>, kr_mla_flash_lds<256>());
+    (void)kr_lds_optin((const void*)kr_mla_flash_kernel<256, true>, kr_mla_flash_lds<256>());
 }
 // prompt pass, n_tok tokens: a.q_abs / a.q_pe / a.attn_lat are the chunk's [n_tok][nh][.] buffers.  non-zero = geometry not covered
 int kr_launch_mla_flash(const KrMlaArgs& a, int n_tok, hipStream_t st) {

@@ -12,6 +12,7 @@
 // one-fma-per-group f32 chain as the reference: out = fma(f32(isum), bf16(w_scale) * a_scale, out).
 //
 // Tile: 64 rows (tokens routed to one expert) x 128 columns per workgroup of 4 waves; one group PAIR (256 k) per LDS stage.
+#include "kr_lds_optin.h"
 #include "kr_device.h"
 #include "kr_kernels.h"
 #include "kr_prefill.h"
@@ -174,6 +175,8 @@ struct KrPfGemmArgs {
     float* out; int out_ld;                 // [rows][out_ld]
     int single_expert;                      // shared expert: every tile uses expert 0 of `m`, rows are tokens 0..M-1 in order
     int total_rows;
+    int scatter_rows;                       // expert-parallel rows: GEMM row r is written to out row row_pair[r] (its place in the caller's order) -- no combine pass
+    int out_bf16;                           // ... as bf16 (RNE), the dtype the rows travel back in
 };
 
 #include "kr_prefill_gemm2.inc"
@@ -223,8 +226,9 @@ void kr_launch_pf_wsum(const KrMatDev& m, int n_experts, uint32_t* wsum, hipStre
     hipLaunchKernelGGL(kr_pf_wsum_kernel, dim3((m.N + 7) / 8, n_experts), dim3(64), 0, st, m, wsum);
 }
 void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_hi, const int8_t* a_lo, const float* a_scale, const KrPfSort* sort, int topk,
-                       int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, hipStream_t st) {
+                       int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows, int out_bf16) {
     KrPfGemmArgs a{};
+    a.scatter_rows = scatter_rows; a.out_bf16 = out_bf16;
     a.m = m; a.wsum = wsum; a.a_hi = a_hi; a.a_lo = a_lo; a.a_scale = a_scale; a.topk = topk; a.gather_tokens = gather_tokens;
     if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
     a.out = out; a.out_ld = out_ld; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
@@ -295,7 +299,7 @@ void kr_launch_ep_sort(const int32_t* dest, int n, int W, KrPfSort s, hipStream_
 __global__ void kr_ep_gather_kernel(const uint16_t* __restrict__ x, const int* __restrict__ row_pair, const int32_t* __restrict__ lid, int topk, int H,
                                     const int* __restrict__ n_rows, uint16_t* __restrict__ rows, int32_t* __restrict__ row_lid) {
     const int r = blockIdx.x;
-    if (r >= n_rows[0]) return;
+    if (r >= n_rows[0]) { if (threadIdx.x == 0) row_lid[r] = -1; return; }     // past the last routed pair: a row no expert takes
     const int pair = row_pair[r];
     const u32x4* src = reinterpret_cast<const u32x4*>(x + (size_t)(pair / topk) * H);
     u32x4* dst = reinterpret_cast<u32x4*>(rows + (size_t)r * H);

@@ -5,6 +5,7 @@
 // keeps the decode kernel's order (8 fma lanes + hsum for the norms, one sequential chain per state column for the gated delta rule,
 // sequential softmax sums); tokens only add independent parallel work.  The GEMM-shaped work (projections, experts) runs on the
 // int8-MFMA grouped GEMM of kr_prefill.hip with the exact INT16-digit arithmetic.
+#include "kr_lds_optin.h"
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_prefill_ops.h"
@@ -708,13 +709,11 @@ int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float*
     hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, C), dim3(256), 0, st, a);
     const int ntt = (C + TT - 1) / TT, npt = (a.pos0 + C + 255) / 256;
     const size_t lds = ((size_t)group * TT * 8 + 32 * 8) * PFA_LDB * 4;
-    static bool big_lds_set = false;   // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950)
-    if (!big_lds_set) {
+    {                                  // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950), per (kernel, device)
         const void* fns[7] = {(const void*)kr_pfm_gqa_scores_kernel, (const void*)kr_pfm_gqa_scores_t_kernel<false, 8>, (const void*)kr_pfm_gqa_scores_t_kernel<false, 16>,
                               (const void*)kr_pfm_gqa_scores_t_kernel<false, 32>, (const void*)kr_pfm_gqa_scores_t_kernel<true, 8>, (const void*)kr_pfm_gqa_scores_t_kernel<true, 16>,
                               (const void*)kr_pfm_gqa_scores_t_kernel<true, 32>};
-        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        big_lds_set = true;
+        for (const void* f : fns) (void)kr_lds_optin(f, 96 * 1024);
     }
 #define KR_SC(F_, N_) hipLaunchKernelGGL((kr_pfm_gqa_scores_t_kernel<F_, N_>), dim3(npt, ntt, a.nkv), dim3(256), lds, st, a, sc, sc_ld, TT, C)
     if (a.hd == 256) { if (a.kv_fp8) KR_SC(true, 32); else KR_SC(false, 32); }
