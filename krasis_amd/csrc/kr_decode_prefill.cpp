@@ -133,7 +133,9 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
         if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
         const int E = e->r_ne;
-        kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, B.normed, EL.has_bias ? (const float*)EL.bias.p : nullptr, B.logits, Cc, E, H, st);
+        const float* rbias = EL.has_bias ? (const float*)EL.bias.p : nullptr;
+        if (!(Cc >= 32 && EL.gate_row.p && 0 == kr_launch_route_logits_mfma(EL.gate_row.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st)))
+            kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st);
         kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
         // routed experts: exact CPU-engine arithmetic on the matrix cores, f32 weighted sum in routing order
         if (int rc = kr_moe_prefill_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set, st)) return rc;
@@ -243,6 +245,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
             if (Ly.sgu_wid >= 0 && Ly.sg_wid >= 0) wids.push_back(Ly.sg_wid);
             if (s->own_eng || Ly.moe_layer >= (int)e->layers.size()) return kr_fail(KR_ERR_STATE, "set_moe_store was not called (MoE layer %d has no engine)", Ly.moe_layer);
             Layer& EL = e->layers[Ly.moe_layer];
+            if (int rc = kr_ensure_gate_row(e, Ly.moe_layer)) return rc;
             if (int rc = kr_ensure_wsum(e, EL.w13, st)) return rc;
             if (int rc = kr_ensure_wsum(e, EL.w2, st)) return rc;
         } else if (Ly.mlp == MLP_DENSE) {

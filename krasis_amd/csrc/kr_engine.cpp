@@ -215,7 +215,7 @@ extern "C" void kr_engine_destroy(kr_engine* e) {
         for (MatSet* ms : {&l.w13, &l.w2, &l.sw13, &l.sw2}) ms->wsum.release();
         l.w13.q.release(); l.w13.s.release(); l.w2.q.release(); l.w2.s.release();
         l.sw13.q.release(); l.sw13.s.release(); l.sw2.q.release(); l.sw2.s.release();
-        l.gate_cm.release(); l.gate_rm.release(); l.bias.release(); l.esc.release();
+        l.gate_cm.release(); l.gate_rm.release(); l.gate_row.release(); l.bias.release(); l.esc.release();
         for (GgufSet* g : {&l.g_gate, &l.g_up, &l.g_down, &l.gs_gate, &l.gs_up, &l.gs_down}) { g->q.release(); g->h.release(); g->ws.release(); }
     }
     for (DevBuf* b : {&e->gu, &e->eo, &e->st_act, &e->st_ids, &e->st_w, &e->st_out, &e->ptr_table, &e->r_logits, &e->r_ids, &e->r_w, &e->r_x}) b->release();
@@ -657,7 +657,7 @@ extern "C" int kr_set_routing_weights(kr_engine* e, int layer, const void* gate,
         if (L.gate_cm.ensure(cm.size() * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
         KR_HIP(hipMemcpy(L.gate_cm.p, cm.data(), cm.size() * 4, hipMemcpyHostToDevice));
     }
-    L.gate_rm.release();
+    L.gate_rm.release(); L.gate_row.release();
     L.has_bias = bias != nullptr; L.has_esc = e_score_corr != nullptr;
     if (bias) { if (L.bias.ensure((size_t)E * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed"); KR_HIP(hipMemcpy(L.bias.p, bias, (size_t)E * 4, hipMemcpyHostToDevice)); }
     if (e_score_corr) { if (L.esc.ensure((size_t)E * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed"); KR_HIP(hipMemcpy(L.esc.p, e_score_corr, (size_t)E * 4, hipMemcpyHostToDevice)); }
@@ -701,6 +701,22 @@ static int build_gate_rm(kr_engine* e, Layer& L) {
     return KR_OK;
 }
 
+int kr_ensure_gate_row(kr_engine* e, int layer) {
+    Layer& L = e->layers[layer];
+    if (L.gate_row.p || L.gate_host.empty()) return KR_OK;
+    const size_t n = L.gate_host.size();
+    if (L.gate_bf16_exact) {
+        std::vector<uint16_t> g(n);
+        for (size_t i = 0; i < n; i++) { uint32_t b; memcpy(&b, &L.gate_host[i], 4); g[i] = (uint16_t)(b >> 16); }
+        if (L.gate_row.ensure(n * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+        KR_HIP(hipMemcpy(L.gate_row.p, g.data(), n * 2, hipMemcpyHostToDevice));
+    } else {
+        if (L.gate_row.ensure(n * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+        KR_HIP(hipMemcpy(L.gate_row.p, L.gate_host.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    return KR_OK;
+}
+
 // routes m tokens; results stay on the device in e->r_ids / e->r_w (and e->r_logits)
 static int route_device(kr_engine* e, Layer& L, const void* d_x, int m, int rule, hipStream_t st) {
     const int E = e->r_ne, H = e->r_hidden, k = e->r_topk;
@@ -708,8 +724,13 @@ static int route_device(kr_engine* e, Layer& L, const void* d_x, int m, int rule
         return kr_fail(KR_ERR_HIP, "hipMalloc of routing scratch failed");
     const int gptoss = e->cfg.swiglu_limit > 0.0f;
     if (rule == KR_ROUTE_RULE_DECODE) {
-        kr_launch_route_logits_decode(L.gate_cm.p, L.gate_bf16_exact, (const float*)d_x, L.has_bias ? (const float*)L.bias.p : nullptr,
-                                      (float*)e->r_logits.p, m, E, H, st);
+        const float* bias = L.has_bias ? (const float*)L.bias.p : nullptr;
+        bool done = false;
+        if (m >= 32) {      // batches: the same chains on the f32 MFMA
+            if (int rc = kr_ensure_gate_row(e, (int)(&L - e->layers.data()))) return rc;
+            done = L.gate_row.p && 0 == kr_launch_route_logits_mfma(L.gate_row.p, L.gate_bf16_exact, (const float*)d_x, bias, (float*)e->r_logits.p, m, E, H, st);
+        }
+        if (!done) kr_launch_route_logits_decode(L.gate_cm.p, L.gate_bf16_exact, (const float*)d_x, bias, (float*)e->r_logits.p, m, E, H, st);
     } else {
         if (int rc = build_gate_rm(e, L)) return rc;
         kr_launch_route_logits_engine(L.gate_rm.p, (const uint16_t*)d_x, (float*)e->r_logits.p, m, E, H, st);

@@ -68,6 +68,7 @@ struct Layer {
     bool gate_bf16_exact = false;          // every value representable in bf16 -> stored as bf16 in HBM
     DevBuf gate_cm;                        // chain-major layout for rule DECODE
     DevBuf gate_rm;                        // row-lane layout for rule ENGINE (built on first use)
+    DevBuf gate_row;                       // plain row-major [E][H] (bf16 when exact, else f32) for the MFMA logits of the prompt pass (built on first use)
     DevBuf bias, esc; bool has_bias = false, has_esc = false, routing_present = false;
 };
 
@@ -100,6 +101,7 @@ int matset_alloc(kr_engine* e, MatSet& ms, int K, int N, int bits, int count);
 int upload_mat(kr_engine* e, MatSet& ms, int idx, const void* w, const uint16_t* sc);
 int download_mat(kr_engine* e, MatSet& ms, int idx, void* w, uint16_t* sc);
 // kr_moe_prefill with an explicit scratch set (0/1) and stream; all pointers device.  out f32 or bf16 per out_dtype.
+int kr_ensure_gate_row(kr_engine* e, int layer);   // kr_engine.cpp: uploads Layer::gate_row on first use (synchronous copy: call before enqueueing the pass)
 int kr_moe_prefill_rows(kr_engine* e, int layer, const void* rows_bf16, const int32_t* lid, void* out, int n, int out_bf16, int set, hipStream_t st);
 int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
                        int out_dtype, int routed_only, int set, hipStream_t st);

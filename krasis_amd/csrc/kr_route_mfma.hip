@@ -1,0 +1,143 @@
+// kr_route_mfma.hip -- router logits of the prompt pass (rule DECODE, moe_route_matmul_avx2, src/decode.rs:1385) on the f32 matrix cores,
+// BIT-IDENTICAL to the 16-chain GEMV of kr_router.hip (the ids that follow must stay bit-exact).
+//
+// The reference keeps two 8-lane fma accumulators per expert row: logit(t, e) is 16 independent chains
+//     a_j <- fma(w[e][16 s + j], x[t][16 s + j], a_j),   s = 0 .. H/16 - 1 in order,   j = 0 .. 15
+// folded by a fixed tree ((a0+a8)+(a4+a12) + (a1+a9)+(a5+a13)) + ((a2+a10)+(a6+a14) + (a3+a11)+(a7+a15)), then + bias.
+// v_mfma_f32_32x32x2_f32 computes D = fma(A[.][1], B[1][.], fma(A[.][0], B[0][.], C)) -- two fused steps in k order (checked bit for bit
+// against the GEMV by tests/test_router_gpu.py and by every prompt-pass == decode test) -- so chain j over a 32-token x 32-expert block is ONE
+// accumulator fed with (s, s+1) pairs: A[t][k] = x[t][16 (2m + k) + j], B[k][e] = w[e][16 (2m + k) + j].  A wave owns a block and all 16
+// chains (16 accumulators = 256 AGPRs); per 32 consecutive k it reads 16 floats of x and 16 gate values per lane (4 + 2 LDS reads) for 16
+// MFMAs.  The kernel runs at the f32-MFMA rate (2.1 GFLOP per 1024-token chunk and layer): 131 us as a GEMV -> see DESIGN.md 5b.
+// Workgroup: 4 waves = 64 tokens x 64 experts, 128-k stages double-buffered in LDS (next stage's global loads in flight during the MFMAs).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kr_lds_optin.h"
+#include "kr_router.h"
+
+typedef float rm_v16f __attribute__((ext_vector_type(16)));
+typedef float rm_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t rm_u4 __attribute__((ext_vector_type(4)));
+#define RM_KS 128                  // k per stage
+#define RM_LDA (RM_KS + 4)         // floats per x row in LDS
+#define RM_LDB16 (RM_KS + 8)       // bf16 per gate row in LDS (272 B: rows 4 banks apart)
+#define RM_LDB32 (RM_KS + 4)       // f32 gate row
+
+template <bool GATE_BF16>
+__global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* __restrict__ gate_row, const float* __restrict__ x, const float* __restrict__ bias,
+                                                                   float* __restrict__ logits, int T, int E, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_BYTES = 64 * RM_LDA * 4, B_BYTES = GATE_BF16 ? 64 * RM_LDB16 * 2 : 64 * RM_LDB32 * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.y * 64, e0 = blockIdx.x * 64;
+    const int tb = (wave >> 1) * 32, eb = (wave & 1) * 32;         // this wave's block inside the tile
+    // ---- global -> register staging: x tile 64 rows x 128 floats (8 float4 per thread), gate tile 64 rows x 128 values
+    rm_f4 pa[8]; rm_u4 pb[GATE_BF16 ? 4 : 8];
+    auto load_stage = [&](int st) {
+        const int k0 = st * RM_KS;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int u = tid + 256 * i, row = u >> 5, c4 = (u & 31) * 4;
+            const int tr = min(t0 + row, T - 1);
+            pa[i] = *reinterpret_cast<const rm_f4*>(x + (size_t)tr * H + k0 + c4);
+        }
+        if (GATE_BF16) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int u = tid + 256 * i, row = u >> 4, c8 = (u & 15) * 8;
+                const int er = min(e0 + row, E - 1);
+                pb[i] = *reinterpret_cast<const rm_u4*>(reinterpret_cast<const uint16_t*>(gate_row) + (size_t)er * H + k0 + c8);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int u = tid + 256 * i, row = u >> 5, c4 = (u & 31) * 4;
+                const int er = min(e0 + row, E - 1);
+                pb[i] = *reinterpret_cast<const rm_u4*>(reinterpret_cast<const float*>(gate_row) + (size_t)er * H + k0 + c4);
+            }
+        }
+    };
+    auto commit_stage = [&](int buf) {
+        float* As = reinterpret_cast<float*>(smem + buf * (A_BYTES + B_BYTES));
+        char* Bs = smem + buf * (A_BYTES + B_BYTES) + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int u = tid + 256 * i, row = u >> 5, c4 = (u & 31) * 4; *reinterpret_cast<rm_f4*>(As + row * RM_LDA + c4) = pa[i]; }
+        if (GATE_BF16) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int u = tid + 256 * i, row = u >> 4, c8 = (u & 15) * 8; *reinterpret_cast<rm_u4*>(Bs + (row * RM_LDB16 + c8) * 2) = pb[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int u = tid + 256 * i, row = u >> 5, c4 = (u & 31) * 4; *reinterpret_cast<rm_u4*>(Bs + (row * RM_LDB32 + c4) * 4) = pb[i]; }
+        }
+    };
+    rm_v16f acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[j][i] = 0.0f;
+    const int nst = H / RM_KS;
+    load_stage(0);
+    commit_stage(0);
+    __syncthreads();
+    for (int st = 0; st < nst; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nst) load_stage(st + 1);
+        const float* As = reinterpret_cast<const float*>(smem + buf * (A_BYTES + B_BYTES)) + (tb + r) * RM_LDA + 16 * h;
+        const char* Bs = smem + buf * (A_BYTES + B_BYTES) + A_BYTES;
+#pragma unroll
+        for (int m = 0; m < RM_KS / 32; m++) {            // 32 consecutive k: the (s, s+1) pair of every chain
+            float a[16], b[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const rm_f4 v = *reinterpret_cast<const rm_f4*>(As + 32 * m + 4 * q); a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w; }
+            if (GATE_BF16) {
+                const uint16_t* bp = reinterpret_cast<const uint16_t*>(Bs) + (eb + r) * RM_LDB16 + 32 * m + 16 * h;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const rm_u4 v = *reinterpret_cast<const rm_u4*>(bp + 8 * q);
+                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int p = 0; p < 4; p++) { b[8 * q + 2 * p] = __uint_as_float(w4[p] << 16); b[8 * q + 2 * p + 1] = __uint_as_float(w4[p] & 0xFFFF0000u); }
+                }
+            } else {
+                const float* bp = reinterpret_cast<const float*>(Bs) + (eb + r) * RM_LDB32 + 32 * m + 16 * h;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const rm_f4 v = *reinterpret_cast<const rm_f4*>(bp + 4 * q); b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w; }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[j], 0, 0, 0);
+        }
+        if (st + 1 < nst) commit_stage(buf ^ 1);          // the other buffer: its readers finished before the barrier that ended stage st - 1
+        __syncthreads();
+    }
+    // ---- the reference's tree over the 16 chains (decode.rs:1419-1427), then + bias (decode.rs:3292)
+    const int e = e0 + eb + r;
+    const float bv = (bias && e < E) ? bias[e] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float c0 = (acc[0][i] + acc[8][i]) + (acc[4][i] + acc[12][i]);
+        const float c1 = (acc[1][i] + acc[9][i]) + (acc[5][i] + acc[13][i]);
+        const float c2 = (acc[2][i] + acc[10][i]) + (acc[6][i] + acc[14][i]);
+        const float c3 = (acc[3][i] + acc[11][i]) + (acc[7][i] + acc[15][i]);
+        float v = (c0 + c1) + (c2 + c3);
+        if (bias) v += bv;
+        const int t = t0 + tb + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (t < T && e < E) logits[(size_t)t * E + e] = v;
+    }
+}
+
+// non-zero = geometry not covered (caller keeps the GEMV)
+int kr_launch_route_logits_mfma(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* logits, int T, int E, int H, hipStream_t st) {
+    if (H % RM_KS || T < 1 || E < 1) return 1;
+    const dim3 grid((E + 63) / 64, (T + 63) / 64);
+    if (gate_bf16) {
+        const size_t lds = 2 * (size_t)(64 * RM_LDA * 4 + 64 * RM_LDB16 * 2);
+        if (kr_lds_optin(reinterpret_cast<const void*>(kr_route_logits_mfma_kernel<true>), lds)) return 1;
+        hipLaunchKernelGGL(kr_route_logits_mfma_kernel<true>, grid, dim3(256), lds, st, gate_row, x, bias, logits, T, E, H);
+    } else {
+        const size_t lds = 2 * (size_t)(64 * RM_LDA * 4 + 64 * RM_LDB32 * 4);
+        if (kr_lds_optin(reinterpret_cast<const void*>(kr_route_logits_mfma_kernel<false>), lds)) return 1;
+        hipLaunchKernelGGL(kr_route_logits_mfma_kernel<false>, grid, dim3(256), lds, st, gate_row, x, bias, logits, T, E, H);
+    }
+    return 0;
+}

@@ -40,6 +40,26 @@ def test_decode_rule_bit_exact(E, H, k, scoring, bf16_gate):
         assert np.array_equal(w[t].view(np.uint32), r_w.view(np.uint32)), "weights"
 
 
+@pytest.mark.parametrize("E,H,m,bf16_gate,use_bias", [(512, 2048, 100, True, False), (72, 256, 70, False, True), (64, 2048, 33, True, True), (200, 512, 64, False, False)])
+def test_decode_rule_batch_logits_on_mfma_bit_exact(E, H, m, bf16_gate, use_bias):
+    """batches of >= 32 tokens take the f32-MFMA logits kernel (kr_route_mfma.hip): 16 chains per (token, expert) as 16 accumulators, the
+    reference's fold tree afterwards -- the same bits as the GEMV, hence as moe_route_matmul_avx2 (partial token / expert tiles included)"""
+    rng = np.random.default_rng(E + m)
+    gate = ((rng.random((E, H), dtype=np.float32) - 0.5) * 0.04).astype(np.float32)
+    if bf16_gate:
+        gate = O.bf16_to_f32(O.f32_to_bf16(gate)).reshape(E, H)
+    bias = ((rng.random(E, dtype=np.float32) - 0.5) * 0.1).astype(np.float32) if use_bias else None
+    k = 6
+    eng = _engine(E, H, k, "softmax")
+    eng.set_route_weight_f32(0, gate, bias, None)
+    x = ((rng.random((m, H), dtype=np.float32) - 0.5) * 2).astype(np.float32)
+    ids, w, lg = eng.route(0, x, m, RULE_DECODE, want_logits=True)
+    for t in range(m):
+        r_ids, r_w, r_lg = O.route_decode(gate, x[t], k, 1, True, bias, None)
+        assert np.array_equal(lg[t].view(np.uint32), r_lg.view(np.uint32)), ("logits", t)
+        assert np.array_equal(ids[t], r_ids) and np.array_equal(w[t].view(np.uint32), r_w.view(np.uint32)), t
+
+
 def test_decode_rule_ties_follow_heap_order():
     E, H, k = 64, 128, 4
     gate = np.zeros((E, H), np.float32)
