@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--prefill-reps", type=int, default=1, help="timed repetitions of the whole-model prompt pass per prompt length")
     ap.add_argument("--no-long-context", action="store_true", help="skip the long-cache decode side measurement of the N = 1 line")
     ap.add_argument("--no-ep", action="store_true", help="skip the expert-parallel prompt-pass leg of the N > 1 lines")
+    ap.add_argument("--ep-timeout", type=int, default=420, help="seconds the multi-GPU expert-parallel side legs may take before every rank gives up (rank 0 still prints the line)")
     ap.add_argument("--ep-selftest", action="store_true", help="run the expert-parallel leg at N = 1 too (no peer traffic: checks the row path)")
     ap.add_argument("--prefill-tokens", default="8192,20434,35139,49863",
                     help="prompt lengths of the prompt-pass side measurement (benchmark.py:434-505: 20 434 / 35 139 / 49 863 tokens; 0 = skip)")
@@ -269,8 +270,8 @@ def prefill_experts_gguf(local_rank, torch, gate_up_type=12, down_type=12, L=8):
 def prefill_ep(eng, dims, L, M, world, rank, torch, dist, experts_local=None):
     """Expert-parallel prompt-pass experts over RCCL inside libkrasis_hip.so (kr_ep_init / kr_moe_prefill_ep): every rank owns
     E/N experts and M tokens; each (token, slot) row travels once to the rank that owns its expert (ncclSend/ncclRecv groups over the xGMI
-    mesh), runs through the int8-MFMA expert GEMMs there, the bf16-of-f32... row comes back and the source rank combines its k rows in
-    routing order.  All L MoE layers, uniform random routing, weak scaling (M tokens per rank)."""
+    mesh), runs through the int8-MFMA expert GEMMs there (the w2 GEMM writes the row in bf16 at its return slot), comes back, and the source
+    rank combines its k rows in routing order.  All L MoE layers, uniform random routing, weak scaling (M tokens per rank)."""
     from krasis_amd.ep import ExpertParallel
     H, I, E, k = dims["hidden"], dims["inter"], dims["experts"], dims["topk"]
     g = torch.Generator(device="cuda").manual_seed(7 + rank)
@@ -300,8 +301,8 @@ def prefill_ep(eng, dims, L, M, world, rank, torch, dist, experts_local=None):
     return {"tokens_per_gpu": M, "tokens_total": world * M, "layers": L, "ms": dt * 1e3, "tok_s_experts_only": world * M / dt, "scaling": "weak",
             "experts_per_gpu": E // world, "roofline": {"bound": "mfma", "achieved": useful, "peak": I8_PEAK_TOPS * world, "unit": "TOP/s (int8, useful)", "frac": useful / (I8_PEAK_TOPS * world)},
             "exchange_GB_per_gpu_per_layer": {"dispatch_bf16": M * k * H * 2 * off / 1e9, "combine_bf16": M * k * H * 2 * off / 1e9},
-            "note": "owner sort (kr_pf_count/scan/scatter) + RCCL send/recv dispatch + expert GEMMs + RCCL send/recv return + f32 combine, per layer; "
-                    "the next layer's dispatch overlaps the current layer's GEMMs; compare with prefill_experts_only of the N = 1 line"}
+            "note": "owner sort + RCCL send/recv dispatch (bf16 rows) + expert GEMMs (w2 scatters bf16 rows to their return slots) + RCCL send/recv return + combine in "
+                    "routing order, per layer, inside libkrasis_hip.so (kr_moe_prefill_ep); compare with prefill_experts_only of the N = 1 line"}
 
 
 def prefill_model(st, dims, gemm_macs_per_token, L, P, reps, torch):
@@ -609,45 +610,15 @@ def main():
             except Exception as ex:
                 side["decode_long_context"] = {"error": repr(ex)}
 
-    ep_legs = {}
-    if pf_list and not args.no_ep and (world > 1 or args.ep_selftest):   # every rank takes part; same call sequence on all
-        try:
-            ep_legs["prefill_experts_ep_alltoall"] = prefill_ep(eng, dims, L, 8192, world, rank, torch, dist)
-        except Exception as ex:
-            ep_legs["prefill_experts_ep_alltoall"] = {"error": repr(ex)}
-
     ab = (algorithmic_bytes(L, bw) if qcn else algorithmic_bytes_v2lite(L, bw))
-    del st, eng, keep
-    gc.collect(); torch.cuda.empty_cache()
+    ep_legs = {}
+    emitted = []
 
-    if pf_list and not args.no_ep and (world > 1 or args.ep_selftest):
-        # BASELINE config 4: Qwen3-235B-A22B expert shape, E/N experts per GPU (16 at N = 8), a few layers' worth of resident experts
-        try:
-            from krasis_amd import KrasisEngine, ModelConfig
-            d4 = Q235; L4 = 4
-            e4 = KrasisEngine(device=local_rank); e4.configure(ModelConfig(d4["hidden"], d4["inter"], d4["experts"] // world, d4["topk"], L4, 0, 1.0))
-            e4.fill_synthetic(4, seed=99 + rank)
-            r = prefill_ep(e4, d4, L4, 8192, world, rank, torch, dist)
-            r["workload"] = "Qwen3-235B-A22B Q4 expert-parallel on %d×MI355X via RCCL all-to-all over xGMI (expert GEMMs of %d of 94 MoE layers)" % (world, L4)
-            ep_legs["prefill_experts_ep_235b"] = r
-            del e4; gc.collect(); torch.cuda.empty_cache()
-        except Exception as ex:
-            ep_legs["prefill_experts_ep_235b"] = {"error": repr(ex)}
-
-    if world == 1 and pf_list:
-        try:
-            side["prefill_experts_only_q4k_gguf"] = prefill_experts_gguf(local_rank, torch)
-        except Exception as ex:
-            side["prefill_experts_only_q4k_gguf"] = {"error": repr(ex)}
-    if world == 1 and args.side_configs:
-        side["configs"] = {}
-        for sc in [s for s in args.side_configs.split(",") if s.strip() and s.strip() != name]:
-            try:
-                side["configs"][sc] = side_config(sc.strip(), rank, local_rank, args, torch)
-            except Exception as ex:
-                side["configs"][sc] = {"error": repr(ex)}
-
-    if rank == 0:
+    def emit():
+        """rank 0's ONE JSON line.  Also called by the watchdog below if a collective of the multi-GPU side legs does not come back."""
+        if emitted or rank != 0:
+            emitted.append(1); return
+        emitted.append(1)
         sym_us, sym_bytes, sym_n = {}, {}, {}
         for j in range(15):
             kname = KINDS[j]; sym = SYMBOL.get(kname, kname)
@@ -685,7 +656,60 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, QCN["layers"])
             except Exception as ex:  # a reported side number, never the product path
                 res["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
+
+    watchdog = None
+    if world > 1 and pf_list and not args.no_ep:
+        # the expert-parallel side legs are collectives over RCCL: if one rank fails to join, the others would wait forever and the headline
+        # line (already measured) would be lost.  After `--ep-timeout` seconds every rank gives up; rank 0 prints the line first.
+        import threading
+
+        def bail():
+            ep_legs.setdefault("prefill_experts_ep_alltoall", {"error": "timeout after %d s (a rank did not join the RCCL exchange)" % args.ep_timeout})
+            try:
+                emit()
+            finally:
+                os._exit(0)
+        watchdog = threading.Timer(args.ep_timeout, bail); watchdog.daemon = True; watchdog.start()
+    if pf_list and not args.no_ep and (world > 1 or args.ep_selftest):   # every rank takes part; same call sequence on all
+        try:
+            ep_legs["prefill_experts_ep_alltoall"] = prefill_ep(eng, dims, L, 8192, world, rank, torch, dist)
+        except Exception as ex:
+            ep_legs["prefill_experts_ep_alltoall"] = {"error": repr(ex)}
+
+    del st, eng, keep
+    gc.collect(); torch.cuda.empty_cache()
+
+    if pf_list and not args.no_ep and (world > 1 or args.ep_selftest):
+        # BASELINE config 4: Qwen3-235B-A22B expert shape, E/N experts per GPU (16 at N = 8), a few layers' worth of resident experts
+        try:
+            from krasis_amd import KrasisEngine, ModelConfig
+            d4 = Q235; L4 = 4
+            e4 = KrasisEngine(device=local_rank); e4.configure(ModelConfig(d4["hidden"], d4["inter"], d4["experts"] // world, d4["topk"], L4, 0, 1.0))
+            e4.fill_synthetic(4, seed=99 + rank)
+            r = prefill_ep(e4, d4, L4, 8192, world, rank, torch, dist)
+            r["workload"] = "Qwen3-235B-A22B Q4 expert-parallel on %d×MI355X via RCCL all-to-all over xGMI (expert GEMMs of %d of 94 MoE layers)" % (world, L4)
+            ep_legs["prefill_experts_ep_235b"] = r
+            del e4; gc.collect(); torch.cuda.empty_cache()
+        except Exception as ex:
+            ep_legs["prefill_experts_ep_235b"] = {"error": repr(ex)}
+
+    if world == 1 and pf_list:
+        try:
+            side["prefill_experts_only_q4k_gguf"] = prefill_experts_gguf(local_rank, torch)
+        except Exception as ex:
+            side["prefill_experts_only_q4k_gguf"] = {"error": repr(ex)}
+    if world == 1 and args.side_configs:
+        side["configs"] = {}
+        for sc in [s for s in args.side_configs.split(",") if s.strip() and s.strip() != name]:
+            try:
+                side["configs"][sc] = side_config(sc.strip(), rank, local_rank, args, torch)
+            except Exception as ex:
+                side["configs"][sc] = {"error": repr(ex)}
+
+    if watchdog is not None:
+        watchdog.cancel()
+    emit()
     if world > 1:
         dist.destroy_process_group()
 

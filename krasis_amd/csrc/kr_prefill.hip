@@ -54,6 +54,47 @@ __global__ void __launch_bounds__(1024) kr_pf_scan_kernel(const int* __restrict_
     }
 }
 
+// One workgroup sorts a chunk's (token, slot) pairs by expert: count (LDS atomics) -> exclusive scans of rows and 64-row tiles -> scatter, in ONE
+// launch.  The three-launch form above costs 19 + 32 + 22 us per MoE layer of a 1024-token chunk (the scan walked the experts on one thread,
+// one dependent global load each) -- 5 % of the FAST prompt pass; this form is used up to KR_PF_SORT1_MAX pairs and 1024 experts.
+// The row order INSIDE an expert is the order in which the LDS atomics land: any order gives the same results (rows are independent; the
+// combine goes through pair_row).
+#define KR_PF_SORT1_MAX 32768
+__global__ void __launch_bounds__(1024) kr_pf_sort1_kernel(const int32_t* __restrict__ ids, int n_pairs, int E, int* __restrict__ counts, int* __restrict__ offsets,
+                                                          int* __restrict__ tile_expert, int* __restrict__ tile_row0, int* __restrict__ tile_rows,
+                                                          int* __restrict__ n_tiles_out, int* __restrict__ row_pair, int* __restrict__ pair_row) {
+    __shared__ int s_cnt[1024], s_off[1024], s_til[1024], s_cur[1024];
+    const int t = threadIdx.x;
+    s_cnt[t] = 0; s_cur[t] = 0;
+    __syncthreads();
+    for (int i = t; i < n_pairs; i += 1024) { const int e = ids[i]; if (e >= 0 && e < E) atomicAdd(&s_cnt[e], 1); }
+    __syncthreads();
+    const int c = t < E ? s_cnt[t] : 0, nt = (c + PF_BM - 1) / PF_BM;
+    s_off[t] = c; s_til[t] = nt;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {             // inclusive Hillis-Steele scans of rows and tiles
+        const int a = t >= d ? s_off[t - d] : 0, b = t >= d ? s_til[t - d] : 0;
+        __syncthreads();
+        s_off[t] += a; s_til[t] += b;
+        __syncthreads();
+    }
+    const int off = s_off[t] - c, til = s_til[t] - nt;   // exclusive
+    if (t == 1023) { n_tiles_out[0] = s_til[t]; n_tiles_out[1] = s_off[t]; }
+    __syncthreads();
+    s_off[t] = off;
+    if (t < E) {
+        counts[t] = c; offsets[t] = off;
+        for (int i = 0; i < nt; i++) { tile_expert[til + i] = t; tile_row0[til + i] = off + i * PF_BM; tile_rows[til + i] = (c - i * PF_BM) < PF_BM ? (c - i * PF_BM) : PF_BM; }
+    }
+    __syncthreads();
+    for (int i = t; i < n_pairs; i += 1024) {
+        const int e = ids[i];
+        if (e < 0 || e >= E) { pair_row[i] = -1; continue; }
+        const int r = s_off[e] + atomicAdd(&s_cur[e], 1);
+        row_pair[r] = i; pair_row[i] = r;
+    }
+}
+
 __global__ void kr_pf_scatter_kernel(const int32_t* __restrict__ ids, int n_pairs, int E, const int* __restrict__ offsets, int* __restrict__ cursor,
                                      int* __restrict__ row_pair, int* __restrict__ pair_row) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,6 +247,10 @@ __global__ void __launch_bounds__(256) kr_pf_combine_kernel(const void* __restri
 // ------------------------------------------------------------------------------------------
 void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, hipStream_t st) {
     const int n = M * topk;
+    if (n <= KR_PF_SORT1_MAX && E <= 1024) {
+        hipLaunchKernelGGL(kr_pf_sort1_kernel, dim3(1), dim3(1024), 0, st, ids, n, E, s.counts, s.offsets, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles, s.row_pair, s.pair_row);
+        return;
+    }
     (void)hipMemsetAsync(s.counts, 0, (size_t)E * 4, st);
     hipLaunchKernelGGL(kr_pf_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E, s.counts);
     hipLaunchKernelGGL(kr_pf_scan_kernel, dim3(1), dim3(1024), 0, st, s.counts, E, s.offsets, s.cursor, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles);
