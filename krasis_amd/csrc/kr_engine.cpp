@@ -953,12 +953,13 @@ int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_
         const int tiles_bound = (mc * topk) / 64 + E + 1;
         kr_launch_pf_sort(idc, mc, topk, E, so, st);
         kr_launch_pf_quant_x(xc, mc, H, (int8_t*)P.xh.p, (int8_t*)P.xl.p, (float*)P.xs.p, st);
+        const int var_rows = (long)mc * topk < 48L * E;     // fewer than ~48 rows per expert: most 64-row tiles have an empty second half
         kr_launch_pf_gemm(L.w13.view(), (const uint32_t*)L.w13.wsum.p, (const int8_t*)P.xh.p, (const int8_t*)P.xl.p, (const float*)P.xs.p, &so, topk, 1,
-                          tiles_bound, 0, (float*)P.gu.p, 2 * I, st);
+                          tiles_bound, 0, (float*)P.gu.p, 2 * I, st, 0, 0, var_rows);
         kr_launch_pf_act((const float*)P.gu.p, mc * topk, I, 2 * I, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (int8_t*)P.hh.p, (int8_t*)P.hl.p,
                          (float*)P.hs.p, st);
         kr_launch_pf_gemm(L.w2.view(), (const uint32_t*)L.w2.wsum.p, (const int8_t*)P.hh.p, (const int8_t*)P.hl.p, (const float*)P.hs.p, &so, topk, 0,
-                          tiles_bound, 0, (float*)P.eo.p, H, st);
+                          tiles_bound, 0, (float*)P.eo.p, H, st, 0, 0, var_rows);
         if (use_shared) {
             kr_launch_pf_gemm(L.sw13.view(), (const uint32_t*)L.sw13.wsum.p, (const int8_t*)P.xh.p, (const int8_t*)P.xl.p, (const float*)P.xs.p, nullptr, topk, 0,
                               0, mc, (float*)P.sgu.p, 2 * SI, st);
@@ -1007,11 +1008,12 @@ int kr_moe_prefill_rows(kr_engine* e, int layer, const void* rows_bf16, const in
         const int tiles_bound = mc / 64 + E + 1;
         kr_launch_pf_sort(lid + m0, mc, 1, E, so, st);
         kr_launch_pf_quant_x((const uint16_t*)rows_bf16 + (size_t)m0 * H, mc, H, (int8_t*)P.xh.p, (int8_t*)P.xl.p, (float*)P.xs.p, st);
+        const int var_rows = (long)mc < 48L * E;
         kr_launch_pf_gemm(L.w13.view(), (const uint32_t*)L.w13.wsum.p, (const int8_t*)P.xh.p, (const int8_t*)P.xl.p, (const float*)P.xs.p, &so, 1, 1,
-                          tiles_bound, 0, (float*)P.gu.p, 2 * I, st);
+                          tiles_bound, 0, (float*)P.gu.p, 2 * I, st, 0, 0, var_rows);
         kr_launch_pf_act((const float*)P.gu.p, mc, I, 2 * I, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (int8_t*)P.hh.p, (int8_t*)P.hl.p, (float*)P.hs.p, st);
         kr_launch_pf_gemm(L.w2.view(), (const uint32_t*)L.w2.wsum.p, (const int8_t*)P.hh.p, (const int8_t*)P.hl.p, (const float*)P.hs.p, &so, 1, 0,
-                          tiles_bound, 0, (float*)((char*)out + (size_t)m0 * H * ob), H, st, 1, out_bf16);
+                          tiles_bound, 0, (float*)((char*)out + (size_t)m0 * H * ob), H, st, 1, out_bf16, var_rows);
     }
     KR_HIP(hipGetLastError());
     return KR_OK;

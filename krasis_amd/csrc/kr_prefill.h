@@ -16,7 +16,8 @@ void kr_launch_pf_quant_x(const uint16_t* x, int M, int K, int8_t* xh, int8_t* x
 void kr_launch_pf_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, int8_t* hh, int8_t* hl, float* hs, hipStream_t st);
 void kr_launch_pf_wsum(const KrMatDev& m, int n_experts, uint32_t* wsum, hipStream_t st);
 void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_hi, const int8_t* a_lo, const float* a_scale, const KrPfSort* sort, int topk,
-                       int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows = 0, int out_bf16 = 0);
+                       int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows = 0, int out_bf16 = 0,
+                       int var_rows = 0 /* expert tiles mostly <= 32 rows: kernel variant that skips empty 32-row blocks */);
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                           int out_bf16, hipStream_t st);
 void kr_launch_pf_combine_bf16rows(const uint16_t* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,

@@ -218,6 +218,7 @@ struct KrPfGemmArgs {
     int total_rows;
     int scatter_rows;                       // expert-parallel rows: GEMM row r is written to out row row_pair[r] (its place in the caller's order) -- no combine pass
     int out_bf16;                           // ... as bf16 (RNE), the dtype the rows travel back in
+    int var_rows;                           // sorted expert tiles with fewer than 64 rows per expert on average: take the kernel that skips empty 32-row blocks
 };
 
 #include "kr_prefill_gemm2.inc"
@@ -271,9 +272,10 @@ void kr_launch_pf_wsum(const KrMatDev& m, int n_experts, uint32_t* wsum, hipStre
     hipLaunchKernelGGL(kr_pf_wsum_kernel, dim3((m.N + 7) / 8, n_experts), dim3(64), 0, st, m, wsum);
 }
 void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_hi, const int8_t* a_lo, const float* a_scale, const KrPfSort* sort, int topk,
-                       int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows, int out_bf16) {
+                       int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows, int out_bf16, int var_rows) {
     KrPfGemmArgs a{};
     a.scatter_rows = scatter_rows; a.out_bf16 = out_bf16;
+    a.var_rows = sort != nullptr && single_expert_rows <= 0 && var_rows;
     a.m = m; a.wsum = wsum; a.a_hi = a_hi; a.a_lo = a_lo; a.a_scale = a_scale; a.topk = topk; a.gather_tokens = gather_tokens;
     if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
     a.out = out; a.out_ld = out_ld; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
