@@ -71,6 +71,15 @@ def main():
     out["gemv.dims"] = np.array([N, K, gs], np.int32)
     out["gemv.w_std"] = w_std.numpy().view(np.uint32).copy(); out["gemv.scales"] = bf16_bits(scale)
     out["gemv.x"] = x.float().numpy(); out["gemv.dequant"] = wf.float().numpy(); out["gemv.y"] = y.float().numpy()
+    # ---- attention="int8" quantizer of the reference's loader (weight_loader.py:25-43): per-channel symmetric INT8 + bf16 scale
+    try:
+        wl = importlib.import_module("krasis.weight_loader")
+        wb = (torch.randn((48, 320), generator=g) * 0.07).to(torch.bfloat16)
+        wb[5] = 0.0                                                     # an all-zero row: amax clamps at 1e-10
+        q8, sc8 = wl.quantize_to_int8(wb)
+        out["q8.w_bf16"] = bf16_bits(wb); out["q8.q"] = q8.numpy().copy(); out["q8.scale_bf16"] = bf16_bits(sc8)
+    except Exception as ex:                                             # heavy optional imports of weight_loader missing in this image
+        print("quantize_to_int8 golden skipped:", repr(ex))
     np.savez_compressed(os.path.join(OUT, "marlin_int4.npz"), **out)
     print("marlin_int4.npz", os.path.getsize(os.path.join(OUT, "marlin_int4.npz")))
 
