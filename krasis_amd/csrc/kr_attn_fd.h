@@ -128,36 +128,57 @@ __global__ void __launch_bounds__(256) kr_fd_partial_kernel(const KrFdArgs a, in
 }
 
 template <int HD>
-__global__ void __launch_bounds__(256) kr_fd_merge_kernel(const KrFdArgs a, int n_chunks) {
-    __shared__ float wc[512]; __shared__ float qs[HD > 256 ? HD : 256]; __shared__ float lred[4];
+__global__ void __launch_bounds__(1024) kr_fd_merge_kernel(const KrFdArgs a, int n_chunks) {
+    // thread = (dim d, chunk phase): 1024 / HD phases walk interleaved chunks with independent partial sums (the first version's single
+    // dependent fma per chunk made this launch as long as the partial launch: 38 us at 128 chunks)
+    __shared__ float wc[1024]; __shared__ float qs[1024]; __shared__ float red[32];
     const int h = blockIdx.x, t = threadIdx.x, G = a.nh / a.nkv, kvh = h / G, g = h % G;
-    const int seq = a.step->pos + 1, nc = (seq + KR_FD_CH - 1) / KR_FD_CH;
+    const int seq = a.step->pos + 1, nc = min((seq + KR_FD_CH - 1) / KR_FD_CH, 1024);
     const float* ml = a.fd_ml + (size_t)h * n_chunks * 2;
-    float mx = -__builtin_inff();
-    for (int c = t; c < nc; c += 256) mx = fmaxf(mx, ml[c * 2]);
+    const float mv = t < nc ? ml[t * 2] : -__builtin_inff(), lv = t < nc ? ml[t * 2 + 1] : 0.0f;
+    float mx = mv;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((t & 63) == 0) wc[t >> 6] = mx;
+    if ((t & 63) == 0) red[t >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(wc[0], wc[1]), fmaxf(wc[2], wc[3]));
-    __syncthreads();
-    float l = 0.0f;
-    for (int c = t; c < nc; c += 256) { const float w = kr_expf(ml[c * 2] - mx); if (c < 512) wc[c] = w; l += w * ml[c * 2 + 1]; }
+    mx = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, red[i]);
+    const float wv = t < nc ? kr_expf(mv - mx) : 0.0f;
+    wc[t] = wv;
+    float l = wv * lv;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) l += __shfl_xor(l, off);
-    if ((t & 63) == 0) lred[t >> 6] = l;
+    if ((t & 63) == 0) red[16 + (t >> 6)] = l;
     __syncthreads();
-    const float inv = 1.0f / ((lred[0] + lred[1]) + (lred[2] + lred[3]));
-    for (int d = t; d < HD; d += 256) {
-        float o = 0.0f;
-        for (int c = 0; c < nc; c++) {
-            const float w = c < 512 ? wc[c] : kr_expf(ml[c * 2] - mx);
-            o = __builtin_fmaf(w, a.fd_o[((size_t)(kvh * n_chunks + c) * G + g) * HD + d], o);
-        }
+    float lt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) lt += red[16 + i];
+    const float inv = 1.0f / lt;
+    constexpr int NPH = 1024 / HD;
+    const int d = t % HD, ph = t / HD;
+    const float* ob = a.fd_o + ((size_t)kvh * n_chunks * G + g) * HD + d;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int c = ph;
+    for (; c + 3 * NPH < nc; c += 4 * NPH) {
+        const float v0 = ob[(size_t)c * G * HD], v1 = ob[(size_t)(c + NPH) * G * HD], v2 = ob[(size_t)(c + 2 * NPH) * G * HD], v3 = ob[(size_t)(c + 3 * NPH) * G * HD];
+        s0 = __builtin_fmaf(wc[c], v0, s0); s1 = __builtin_fmaf(wc[c + NPH], v1, s1); s2 = __builtin_fmaf(wc[c + 2 * NPH], v2, s2); s3 = __builtin_fmaf(wc[c + 3 * NPH], v3, s3);
+    }
+    for (; c < nc; c += NPH) s0 = __builtin_fmaf(wc[c], ob[(size_t)c * G * HD], s0);
+    float o = (s0 + s1) + (s2 + s3);
+    if (NPH > 1) {
+        __syncthreads();
+        qs[t] = o;
+        __syncthreads();
+        o = 0.0f;
+        if (t < HD) for (int p = 0; p < NPH; p++) o += qs[p * HD + t];
+        __syncthreads();
+    }
+    if (t < HD) {
         o *= inv;
-        if (a.gated) { const float gt = a.gate[(size_t)h * HD + d]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
-        a.out[(size_t)h * HD + d] = o;
-        if (a.img_out) qs[d] = o;
+        if (a.gated) { const float gt = a.gate[(size_t)h * HD + t]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
+        a.out[(size_t)h * HD + t] = o;
+        if (a.img_out) qs[t] = o;
     }
     if (a.img_out) {   // hd % 128 == 0: the head's output is hd/128 whole quantization groups of the o-projection's input
         __syncthreads();
@@ -195,5 +216,5 @@ static void kr_launch_fd(const KrFdArgs& a, int fp8, int max_seq, hipStream_t s)
     dim3 grid(nchunks, a.nkv);
     if (fp8) hipLaunchKernelGGL((kr_fd_partial_kernel<HD, true, GMAX>), grid, dim3(256), lds, s, a, max_seq, nchunks);
     else hipLaunchKernelGGL((kr_fd_partial_kernel<HD, false, GMAX>), grid, dim3(256), lds, s, a, max_seq, nchunks);
-    hipLaunchKernelGGL(kr_fd_merge_kernel<HD>, dim3(a.nh), dim3(256), 0, s, a, nchunks);
+    hipLaunchKernelGGL(kr_fd_merge_kernel<HD>, dim3(a.nh), dim3(1024), 0, s, a, nchunks);
 }

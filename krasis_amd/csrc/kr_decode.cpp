@@ -5,6 +5,7 @@
 // against the oracle restatement), but every weight, KV page, recurrent state and scratch buffer lives in HBM and one
 // decode_step is a fixed sequence of kernel launches that reads (token, position) from device memory, i.e. it is
 // hipGraph-capturable and replayable per token.
+#include <algorithm>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -661,8 +662,9 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
         if (L.hd > 0 && L.q_wid >= 0) {
             if (s->kv_max_seq > s->gqa_split_min && s->gqa_scores.ensure((size_t)L.nh * s->kv_max_seq * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
             if (s->attn_fast && s->kv_max_seq > s->gqa_split_min) {
-                const size_t nch = ((size_t)s->kv_max_seq + 255) / 256;
+                const size_t nch = std::max(((size_t)s->kv_max_seq + 255) / 256, kr_fd_flash_chunks(s->kv_max_seq));
                 if (s->fd_o.ensure((size_t)L.nh * L.hd * nch * 4) || s->fd_ml.ensure((size_t)L.nh * nch * 8)) return kr_fail(KR_ERR_HIP, "hipMalloc of the split-KV partials failed");
+                if ((L.hd == 64 || L.hd == 128 || L.hd == 256) && kr_fd_flash_prepare(L.hd, s->kv_fp8)) return kr_fail(KR_ERR_HIP, "LDS window of the flash-decode kernel refused");
             }
             const int pr = kr_gqa_attn_prepare(s->kv_max_seq, L.hd, s->kv_fp8);
             if (pr) return kr_fail(pr == -1 ? KR_ERR_VALUE : KR_ERR_HIP, "GQA decode attention: kv_max_seq %d with head_dim %d does not fit the 160 KiB LDS window", s->kv_max_seq, L.hd);

@@ -22,6 +22,18 @@ struct KrGqaArgs {
     float *fd_o, *fd_ml;   // fast (tolerance) mode: split-KV partials [nkv][chunks][G][hd] and (max, sum) [nh][chunks][2]; null = exact order
 };
 
+// FAST decode attention over long caches, second generation (kr_attn_flash.hip): split-KV flash-decode on the f16 MFMA + log-sum-exp merge
+struct KrFdFlashArgs {
+    const KrStep* step; const float* q;          // q [nh][hd] after QK-norm / RoPE (kr_gqa_prep_kernel)
+    const void *k_cache, *v_cache;               // [max_seq][nkv * hd], FP16 or E4M3 elements
+    float *fd_o, *fd_ml;                         // partials [nkv][chunks][G][hd], (max in log2 units, sum) [nh][chunks][2]
+    int nh, nkv; float sm_scale;
+    const float* gate; int gated; float* out; void* img_out;
+};
+int kr_fd_flash_chunk(int max_seq);
+size_t kr_fd_flash_chunks(int max_seq);
+int kr_fd_flash_prepare(int hd, int fp8);        // outside graph capture
+int kr_launch_fd_flash(const KrFdFlashArgs& a, int hd, int fp8, int max_seq, hipStream_t st);   // non-zero = geometry not covered
 int kr_gqa_attn_prepare(int max_seq, int hd, int fp8);   // 0, -1 (scores + stage exceed 160 KiB of LDS), -2 (HIP refused)
 
 struct KrMlaArgs {   // decode.rs:2993-3252

@@ -1225,6 +1225,12 @@ static void kr_launch_gqa_phase(const KrGqaArgs& a, int max_seq, dim3 grid, int 
 }
 void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
     hipLaunchKernelGGL(kr_gqa_prep_kernel, dim3(a.nh + a.nkv), dim3(256), 0, s, a);
+    if (a.sc_g && a.fd_o && a.fd_ml) {      // FAST mode, long cache: one split-KV flash-decode launch + merge (no score scratch)
+        KrFdFlashArgs f{};
+        f.step = a.step; f.q = a.q_out; f.k_cache = a.k_cache; f.v_cache = a.v_cache; f.fd_o = a.fd_o; f.fd_ml = a.fd_ml; f.nh = a.nh; f.nkv = a.nkv;
+        f.sm_scale = a.sm_scale; f.gate = a.gate; f.gated = a.gated; f.out = a.attn_out; f.img_out = a.img_out;
+        if (kr_launch_fd_flash(f, a.hd, a.kv_fp8, max_seq, s) == 0) return;
+    }
     if (a.sc_g) {      // long cache: scores over nh x max_seq / 256 workgroups (those past the current length leave at once), then softmax + p.v
         kr_launch_gqa_phase<1>(a, max_seq, dim3(a.nh, (max_seq + 255) / 256), 0, s);
         if (kr_gqa_fast_ok(a)) { kr_launch_gqa_fast(a, max_seq, s); return; }      // tolerance mode: split-KV softmax + p.v, log-sum-exp merge

@@ -1,8 +1,9 @@
 """Tolerance-mode attention for long caches (kr_decode_set_attention_mode, KR_ATTN_FAST): split-KV softmax + p.v with a log-sum-exp merge.
 The exact kernels (reference order, bit-identical to decode.rs:4194-4281) are the yardstick: the same decode steps are run in both modes and
-the logits compared at a STATED tolerance -- same products and libm exponentials, another f32 summation order:
-    max |logits_fast - logits_exact| <= 5e-4 * max |logits_exact|          (measured on MI355X: 0.9e-4 .. 1.3e-4 -- the attention output differs in
-                                                                            its last bits, its INT16 re-quantisation for the o-projection then
+the logits compared at a STATED tolerance.  GQA runs split-KV flash-decode on the f16 MFMA (kr_attn_flash.hip: q and the probabilities rounded to
+f16 = 2^-11, K / V exact in f16, f32 accumulation, exp2 on the transcendental unit); MLA keeps exact f32 scores with a split softmax + p.v:
+    max |logits_fast - logits_exact| <= 1e-3 * max |logits_exact|          (measured on MI355X: 1.8e-4 .. 4.2e-4 -- the attention output differs in
+                                                                            its low bits, its INT16 re-quantisation for the o-projection then
                                                                             moves single values by one step, and that step is what the logits see)
 and the greedy token is unchanged.  Router top-k ids must be identical (north_star: bit-exact ids)."""
 import os
@@ -43,7 +44,7 @@ def test_fast_attention_matches_exact_within_tolerance(hd, fp8, kv_max):
     if os.path.isdir("gpurun_out"):
         with open("gpurun_out/r02_attn_fast_err.txt", "a") as f:
             f.write(f"hd={hd} fp8={fp8} kv_max={kv_max} worst_rel={worst:.3e}\n")
-    assert worst <= 5e-4, worst
+    assert worst <= 1e-3, worst
     assert outs[False][1] == outs[True][1]
 
 
