@@ -167,3 +167,30 @@ def test_mla_fast_decode_and_flash_prompt_pass(cfg, fp8):
     assert np.isfinite(res[True][2]).all() and relp <= (2e-2 if fp8 else 3e-3), relp
     if not fp8:
         assert res[False][1] == res[True][1] and res[False][3] == res[True][3]
+
+
+@pytest.mark.parametrize("kinds,fp8", [(["la", "gqa", "la", "gqa"], False), (["la", "gqa", "la", "gqa"], True), (["gqa", "gqa"], True)])
+def test_fast_mode_perplexity_delta_on_the_synthetic_model(kinds, fp8):
+    """the perplexity harness (krasis_amd.evaluate_perplexity == perplexity/measure_ppl.py:154-297) over a synthetic hybrid model, windows of 256
+    tokens (4 sub-chunks of the closed-form delta rule, flash attention over the FP16 / E4M3 cache) in both modes.  STATED TOLERANCE on the
+    result the reference reports: |PPL_fast / PPL_exact - 1| <= 1e-3 and |mean NLL difference| <= 1e-3 nats (measured on MI355X: see
+    profiles/r02_fast_mode_errors.txt).  The exact mode is the reference CPU-decode arithmetic bit for bit (tests/test_perplexity.py)."""
+    from krasis_amd.perplexity import evaluate_perplexity
+    res = {}
+    rng = np.random.default_rng(99)
+    toks = None
+    for mode in (False, True):
+        st, eng, orc, keep, d = build(seed=17, kv_max=320, kinds=kinds, hd=128, nh=8)
+        if fp8:
+            st.set_kv_dtype(True)
+        st.set_attention_mode(mode)
+        if toks is None:
+            toks = [int(x) for x in rng.integers(0, d["V"], 700)]
+        res[mode] = evaluate_perplexity(st, toks, 256, 128)
+    a, b = res[False], res[True]
+    assert a["num_tokens_scored"] == b["num_tokens_scored"] == len(toks) - 1
+    rel = abs(b["perplexity"] / a["perplexity"] - 1.0); dn = abs(b["mean_loss"] - a["mean_loss"])
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/r02_attn_fast_err.txt", "a") as f:
+            f.write(f"ppl delta kinds={'+'.join(kinds)} fp8={fp8}: exact {a['perplexity']:.6f} fast {b['perplexity']:.6f} rel {rel:.3e} mean-nll diff {dn:.3e}\n")
+    assert rel <= 1e-3 and dn <= 1e-3, (rel, dn)
