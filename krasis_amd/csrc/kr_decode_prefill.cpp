@@ -7,6 +7,9 @@
 // recurrent state bit-identical to n successive kr_decode_step calls (src/decode.rs:2690-3520), so there is one numerics story for
 // prefill and decode and no state hand-off.  GEMM-shaped work rides the int8-MFMA grouped GEMM (kr_prefill.hip); everything else
 // is the batched form of the decode operators (kr_prefill_ops.hip).  Tokens are processed in chunks through all layers.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -138,7 +141,10 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
             kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st);
         kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
         // routed experts: exact CPU-engine arithmetic on the matrix cores, f32 weighted sum in routing order
-        if (int rc = kr_moe_prefill_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set, st)) return rc;
+        // expert parallelism (kr_ep_init on the engine): this rank's chunk exchanges its (token, slot) rows with the owners over RCCL; every rank
+        // must run the same number of chunks and layers (equal prompt lengths).  One chunk in flight: the exchange buffers are per engine.
+        if (e->ep) { if (int rc = kr_moe_prefill_ep(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, st ? (void*)st : (void*)1)) return rc; }
+        else if (int rc = kr_moe_prefill_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set, st)) return rc;
         const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
         if (has_shared) {   // decode-store numerics: f32 input digits, fast_silu_mul + f32::round digits (decode.rs:3356-3378)
             const int si2 = s->weights[L.sgu_wid]->rows, SI = si2 / 2;
@@ -213,7 +219,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     const int H = s->hidden;
     if (H % 128) return kr_fail(KR_ERR_VALUE, "kr_decode_prefill needs hidden %% 128 == 0");
     const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : KR_PFM_CHUNK);
-    const int depth = s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : KR_PFM_DEPTH;   // chunks in flight (streams / arenas)
+    const int depth = e->ep ? 1 : (s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : KR_PFM_DEPTH);   // chunks in flight (streams / arenas)
     const int n_chunks = (n_tokens + CH - 1) / CH, n_arenas = std::min(n_chunks, depth), D = n_arenas;
     const int L = (int)s->layers.size();
 
@@ -304,6 +310,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
         KR_HIP(hipEventRecord(s->pf_events[ev_start], st));               // side streams start after everything already queued on the main one
         for (int i = 1; i < D; i++) KR_HIP(hipStreamWaitEvent(streams[i], s->pf_events[ev_start], 0));
     }
+    const auto t_enqueue = std::chrono::steady_clock::now();
     std::vector<Chunk> chunks(n_chunks);
     for (int c = 0; c < n_chunks; c++) {
         Chunk& cx = chunks[c];
@@ -336,6 +343,12 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     }
     KR_HIP(hipGetLastError());
     s->last_stream = st;
+    if (getenv("KR_PFM_TIMING")) {      // tuning aid: how long the host took to enqueue the pass vs how long the GPU needs to drain it
+        const double enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enqueue).count();
+        (void)hipStreamSynchronize(st);
+        const double tot = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enqueue).count();
+        fprintf(stderr, "[kr_decode_prefill] %d tokens: host enqueue %.1f ms, GPU drained after %.1f ms\n", n_tokens, enq, tot);
+    }
     if (logits_out) {
         if (is_device_ptr(logits_out)) KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToDevice, st));
         else { KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }

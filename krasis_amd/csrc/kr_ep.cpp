@@ -58,7 +58,7 @@ int load_rccl() {
 }  // namespace
 
 struct kr_ep_state {
-    int world = 1, rank = 0, E_total = 0, per = 0, ret_bf16 = 0;
+    int world = 1, rank = 0, E_total = 0, per = 0, ret_bf16 = 0, full = 0;   // full: the engine holds ALL experts of the model (a replica that can also decode): local id = global id
     ncclComm_t comm = nullptr;
     DevBuf dest, lid, i32, rows, row_lid, rrows, rlid, eo, eo16, back, ones, cnt_all, shared_out, neg_ids;
     int* cnt_host = nullptr;          // pinned [world * world]
@@ -82,12 +82,13 @@ extern "C" int kr_ep_init(kr_engine* e, int world, int rank, int n_experts_total
     if (world < 1 || world > 64 || rank < 0 || rank >= world) return kr_fail(KR_ERR_VALUE, "bad world / rank (%d / %d; at most 64 ranks)", world, rank);
     if (n_experts_total < world) return kr_fail(KR_ERR_VALUE, "%d experts cannot be split over %d ranks", n_experts_total, world);
     const int per = n_experts_total / world, n_local = rank == world - 1 ? n_experts_total - per * (world - 1) : per;
-    if (e->cfg.n_routed_experts < n_local)      // a replica that holds more experts than its slice serves the first n_local of them
+    if (e->cfg.n_routed_experts < n_local)      // an engine that holds the WHOLE model (>= n_experts_total experts) serves its slice under the global ids; otherwise experts 0 .. n_local-1 are the slice
         return kr_fail(KR_ERR_VALUE, "rank %d of %d owns %d of %d experts but the engine holds only %d", rank, world, n_local, n_experts_total, e->cfg.n_routed_experts);
     if (e->ep) return kr_fail(KR_ERR_STATE, "expert parallelism is already initialised");
     KR_HIP(hipSetDevice(e->device));
     std::unique_ptr<kr_ep_state> s(new kr_ep_state);
     s->world = world; s->rank = rank; s->E_total = n_experts_total; s->per = per; s->ret_bf16 = return_bf16 != 0;
+    s->full = e->cfg.n_routed_experts >= n_experts_total && world > 0 ? 1 : 0;
     if (world > 1) {
         if (!id128) return kr_fail(KR_ERR_VALUE, "kr_ep_init needs the unique id of rank 0 when world > 1");
         if (int rc = load_rccl()) return rc;
@@ -140,7 +141,7 @@ extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, co
     so.counts = ib; so.offsets = ib + W; so.cursor = ib + 2 * W; ib += 3 * W;
     so.tile_expert = ib; so.tile_row0 = ib + max_tiles; so.tile_rows = ib + 2 * max_tiles; ib += 3 * max_tiles;
     so.n_tiles = ib; ib += 4; so.row_pair = ib; so.pair_row = ib + np;
-    kr_launch_ep_dest(ids, np, s->E_total, s->per, W, (int32_t*)s->dest.p, (int32_t*)s->lid.p, st);
+    kr_launch_ep_dest(ids, np, s->E_total, s->per, W, s->full, (int32_t*)s->dest.p, (int32_t*)s->lid.p, st);
     kr_launch_ep_sort((const int32_t*)s->dest.p, np, W, so, st);
     kr_launch_ep_gather((const uint16_t*)x_bf16, so.row_pair, (const int32_t*)s->lid.p, topk, H, so.n_tiles + 1, np, (uint16_t*)s->rows.p, (int32_t*)s->row_lid.p, st);
     // ---- send counts of every rank: cnt[src][dst]

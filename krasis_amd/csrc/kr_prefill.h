@@ -24,7 +24,7 @@ void kr_launch_pf_combine_bf16rows(const uint16_t* eo, const int* pair_row, cons
                                    int out_bf16, hipStream_t st);
 // expert parallelism helpers (kr_ep.cpp)
 void kr_launch_ep_sort(const int32_t* dest, int n, int W, KrPfSort s, hipStream_t st);   // owner sort, world <= 64 destinations
-void kr_launch_ep_dest(const int32_t* ids, int n, int E_total, int per, int world, int32_t* dest, int32_t* lid, hipStream_t st);
+void kr_launch_ep_dest(const int32_t* ids, int n, int E_total, int per, int world, int full, int32_t* dest, int32_t* lid, hipStream_t st);
 void kr_launch_ep_gather(const uint16_t* x, const int* row_pair, const int32_t* lid, int topk, int H, const int* n_rows, int max_rows, uint16_t* rows, int32_t* row_lid,
                          hipStream_t st);
 void kr_launch_ep_rows_bf16(const float* in, uint16_t* out, size_t n, hipStream_t st);

@@ -297,13 +297,13 @@ void kr_launch_pf_combine_bf16rows(const uint16_t* eo, const int* pair_row, cons
 // ------------------------------------------------------------------------------------------
 // expert parallelism (kr_ep.cpp): destination rank + local expert id of every (token, slot) pair; rows gathered in destination order
 // ------------------------------------------------------------------------------------------
-__global__ void kr_ep_dest_kernel(const int32_t* __restrict__ ids, int n, int E_total, int per, int world, int32_t* __restrict__ dest, int32_t* __restrict__ lid) {
+__global__ void kr_ep_dest_kernel(const int32_t* __restrict__ ids, int n, int E_total, int per, int world, int full, int32_t* __restrict__ dest, int32_t* __restrict__ lid) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int e = ids[i];
     if (e < 0 || e >= E_total) { dest[i] = -1; lid[i] = -1; return; }
     int d = e / per; if (d > world - 1) d = world - 1;          // the last rank takes the remainder (gpu_prefill.py:353-359)
-    dest[i] = d; lid[i] = e - d * per;
+    dest[i] = d; lid[i] = full ? e : e - d * per;        // full: the owner holds every expert of the model under its global id
 }
 // Owner sort for a handful of destinations (world <= 64): the token sort's count / scatter kernels issue one global atomic per pair on
 // counts[dest] / cursor[dest] -- with 8 destinations that is ~10 k atomics per address and layer (the same-address rate is ~90 per us).  Here a
@@ -357,8 +357,8 @@ __global__ void kr_ep_gather_kernel(const uint16_t* __restrict__ x, const int* _
 __global__ void kr_ep_rows_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = kr_f32_to_bf16(in[i]);
 }
-void kr_launch_ep_dest(const int32_t* ids, int n, int E_total, int per, int world, int32_t* dest, int32_t* lid, hipStream_t st) {
-    hipLaunchKernelGGL(kr_ep_dest_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E_total, per, world, dest, lid);
+void kr_launch_ep_dest(const int32_t* ids, int n, int E_total, int per, int world, int full, int32_t* dest, int32_t* lid, hipStream_t st) {
+    hipLaunchKernelGGL(kr_ep_dest_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E_total, per, world, full, dest, lid);
 }
 void kr_launch_ep_gather(const uint16_t* x, const int* row_pair, const int32_t* lid, int topk, int H, const int* n_rows, int max_rows, uint16_t* rows, int32_t* row_lid,
                          hipStream_t st) {

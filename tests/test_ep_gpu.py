@@ -62,3 +62,29 @@ def test_library_expert_parallel_world1(M, ret_bf16, shared):
     torch.cuda.synchronize(); eng.synchronize()
     assert (got2.float() - ref).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
     ep.close()
+
+
+def test_prompt_pass_through_the_ep_exchange_is_bit_identical():
+    """kr_decode_prefill with expert parallelism initialised on the engine (kr_ep_init, world 1: the whole row path -- owner sort, gather, experts on
+    the received rows with the scatter epilogue, combine in routing order -- without peer traffic) against the plain prompt pass of the same model:
+    f32 return rows, so logits, greedy token and the state the next decode step runs on are bit-identical."""
+    import numpy as np
+    from krasis_amd.ep import ExpertParallel
+    from tests.test_decode_gpu import build
+    F = np.float32
+    outs = []
+    for use_ep in (False, True):
+        st, eng, orc, keep, d = build(seed=23, kv_max=200)
+        ep = ExpertParallel(eng, eng.num_experts(), 1, 0, return_bf16=False) if use_ep else None
+        rng = np.random.default_rng(4)
+        toks = [int(x) for x in rng.integers(0, d["V"], 150)]
+        st.set_prefill_chunk(64)
+        lg = np.empty(d["V"], F)
+        tok = st.prefill(toks, 3, lg.ctypes.data)
+        nxt = np.empty(d["V"], F); st.decode_step(tok, 153, nxt.ctypes.data)
+        outs.append((lg.copy(), tok, nxt.copy()))
+        if ep is not None:
+            ep.close()
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32))
