@@ -43,6 +43,20 @@ static int pf_gemm(kr_decode_store* s, int wid, const int8_t* xh, const int8_t* 
     kr_launch_pf_gemm(W.ms.view(), (const uint32_t*)W.ms.wsum.p, xh, xl, xs, nullptr, 1, 0, 0, C, out, ld, st);
     return KR_OK;
 }
+// up to three projections of the same input in ONE launch (q | k | v, qkvz | ba, shared gate_up | shared gate); falls back to one launch each
+// when the weight widths or K differ
+static int pf_gemm_multi(kr_decode_store* s, const int* wids, float* const* outs, const int* lds, int n, const int8_t* xh, const int8_t* xl, const float* xs, int C, hipStream_t st) {
+    KrMatDev mats[3]; const uint32_t* ws[3];
+    bool same = n <= 3;
+    for (int i = 0; i < n; i++) {
+        DWeight& W = *s->weights[wids[i]];
+        if (!W.ms.wsum.p) return kr_fail(KR_ERR_STATE, "internal: nibble sums of weight %d were not prepared", wids[i]);
+        if (i < 3) { mats[i] = W.ms.view(); ws[i] = (const uint32_t*)W.ms.wsum.p; same = same && mats[i].bits == mats[0].bits && mats[i].ng == mats[0].ng; }
+    }
+    if (same && n > 1) { kr_launch_pf_gemm_multi(mats, ws, outs, lds, n, xh, xl, xs, C, st); return KR_OK; }
+    for (int i = 0; i < n; i++) if (int rc = pf_gemm(s, wids[i], xh, xl, xs, C, outs[i], lds[i], st)) return rc;
+    return KR_OK;
+}
 
 // everything a layer launches, for one chunk, on the chunk's stream
 static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
@@ -59,8 +73,8 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
     cx.first = false; cx.add_is_emb = false;
     if (L.attn == ATTN_LA) {
         const int nq = s->weights[L.qkvz_wid]->rows, nb = s->weights[L.ba_wid]->rows, oc = s->weights[L.out_wid]->cols;
-        if (int rc = pf_gemm(s, L.qkvz_wid, B.xh, B.xl, B.xs, Cc, B.pa, nq, st)) return rc;
-        if (int rc = pf_gemm(s, L.ba_wid, B.xh, B.xl, B.xs, Cc, B.pb, nb, st)) return rc;
+        { const int wids[2] = {L.qkvz_wid, L.ba_wid}; float* outs[2] = {B.pa, B.pb}; const int lds[2] = {nq, nb};
+          if (int rc = pf_gemm_multi(s, wids, outs, lds, 2, B.xh, B.xl, B.xs, Cc, st)) return rc; }
         KrPfmLaArgs a{};
         a.qkvz = B.pa; a.ld_qkvz = nq; a.ba = B.pb; a.ld_ba = nb; a.conv_state = (float*)L.conv_state.p; a.conv_w = (const float*)L.conv_w.p;
         a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale; a.q = B.q; a.k = B.k; a.v = B.v; a.z = B.z;
@@ -74,9 +88,8 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
     } else if (L.attn == ATTN_GQA) {
         if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
         const int nq = s->weights[L.q_wid]->rows, nk_ = s->weights[L.k_wid]->rows, nv_ = s->weights[L.v_wid]->rows, oc = s->weights[L.o_wid]->cols;
-        if (int rc = pf_gemm(s, L.q_wid, B.xh, B.xl, B.xs, Cc, B.pa, nq, st)) return rc;
-        if (int rc = pf_gemm(s, L.k_wid, B.xh, B.xl, B.xs, Cc, B.pb, nk_, st)) return rc;
-        if (int rc = pf_gemm(s, L.v_wid, B.xh, B.xl, B.xs, Cc, B.pc, nv_, st)) return rc;
+        { const int wids[3] = {L.q_wid, L.k_wid, L.v_wid}; float* outs[3] = {B.pa, B.pb, B.pc}; const int lds[3] = {nq, nk_, nv_};
+          if (int rc = pf_gemm_multi(s, wids, outs, lds, 3, B.xh, B.xl, B.xs, Cc, st)) return rc; }
         KrPfmGqaArgs a{};
         a.q_in = B.pa; a.k_in = B.pb; a.v_in = B.pc; a.ld_q = nq; a.ld_k = nk_; a.ld_v = nv_;
         a.q_norm = L.q_norm_len ? (const float*)L.q_norm.p : nullptr; a.k_norm = L.k_norm_len ? (const float*)L.k_norm.p : nullptr;
@@ -149,10 +162,10 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         if (has_shared) {   // decode-store numerics: f32 input digits, fast_silu_mul + f32::round digits (decode.rs:3356-3378)
             const int si2 = s->weights[L.sgu_wid]->rows, SI = si2 / 2;
             if (SI % 128) return kr_fail(KR_ERR_VALUE, "shared expert intermediate %d not a multiple of 128", SI);
-            if (int rc = pf_gemm(s, L.sgu_wid, B.xh, B.xl, B.xs, Cc, B.sgu, si2, st)) return rc;
+            { const int wids[2] = {L.sgu_wid, L.sg_wid}; float* outs[2] = {B.sgu, B.gv}; const int lds[2] = {si2, 1};       // gate_up (| the 1-column gate)
+              if (int rc = pf_gemm_multi(s, wids, outs, lds, has_gate ? 2 : 1, B.xh, B.xl, B.xs, Cc, st)) return rc; }
             kr_launch_pf_act(B.sgu, Cc, SI, si2, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yh, B.yl, B.ys, st);
             if (int rc = pf_gemm(s, L.sd_wid, B.yh, B.yl, B.ys, Cc, B.sh, H, st)) return rc;
-            if (has_gate) if (int rc = pf_gemm(s, L.sg_wid, B.xh, B.xl, B.xs, Cc, B.gv, 1, st)) return rc;
         }
         kr_launch_pfm_moe_epilogue(B.moe, has_shared ? B.sh : nullptr, has_gate ? B.gv : nullptr, 1, s->rsf, B.hid, Cc, H, st);
     } else if (L.mlp == MLP_DENSE) {

@@ -18,6 +18,8 @@ void kr_launch_pf_wsum(const KrMatDev& m, int n_experts, uint32_t* wsum, hipStre
 void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_hi, const int8_t* a_lo, const float* a_scale, const KrPfSort* sort, int topk,
                        int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows = 0, int out_bf16 = 0,
                        int var_rows = 0 /* expert tiles mostly <= 32 rows: kernel variant that skips empty 32-row blocks */);
+void kr_launch_pf_gemm_multi(const KrMatDev* mats, const uint32_t* const* wsums, float* const* outs, const int* out_lds, int n, const int8_t* a_hi, const int8_t* a_lo,
+                             const float* a_scale, int M, hipStream_t st);
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                           int out_bf16, hipStream_t st);
 void kr_launch_pf_combine_bf16rows(const uint16_t* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,

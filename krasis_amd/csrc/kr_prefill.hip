@@ -219,6 +219,9 @@ struct KrPfGemmArgs {
     int scatter_rows;                       // expert-parallel rows: GEMM row r is written to out row row_pair[r] (its place in the caller's order) -- no combine pass
     int out_bf16;                           // ... as bf16 (RNE), the dtype the rows travel back in
     int var_rows;                           // sorted expert tiles with fewer than 64 rows per expert on average: take the kernel that skips empty 32-row blocks
+    // up to two MORE matrices that consume the same A rows (same K, same width): their column blocks follow those of `m` in the same launch
+    // (q | k | v, qkvz | ba, shared gate_up | shared gate: a 64- or 1-column GEMM of its own is one latency-bound launch per chunk and layer)
+    int n_extra; KrMatDev mx[2]; const uint32_t* wsumx[2]; float* outx[2]; int out_ldx[2];
 };
 
 #include "kr_prefill_gemm2.inc"
@@ -283,6 +286,17 @@ void kr_launch_pf_gemm(const KrMatDev& m, const uint32_t* wsum, const int8_t* a_
     // 32 columns per wave, two quantization groups per k stage: the best of the (64|32 columns) x (1|2 groups) shapes and of a 2 x 2 row-split
     // wave grid that were measured
     if (m.bits == 8) kr_pf_gemm2_launch<32, 2, 8>(a, mt, st);
+    else kr_pf_gemm2_launch<32, 2, 4>(a, mt, st);
+}
+// dense GEMMs of up to three matrices over the same A rows (rows 0..M-1 in order), one launch; all matrices share K and the weight width
+void kr_launch_pf_gemm_multi(const KrMatDev* mats, const uint32_t* const* wsums, float* const* outs, const int* out_lds, int n, const int8_t* a_hi, const int8_t* a_lo,
+                             const float* a_scale, int M, hipStream_t st) {
+    KrPfGemmArgs a{};
+    a.m = mats[0]; a.wsum = wsums[0]; a.out = outs[0]; a.out_ld = out_lds[0]; a.a_hi = a_hi; a.a_lo = a_lo; a.a_scale = a_scale; a.topk = 1;
+    a.single_expert = 1; a.total_rows = M; a.n_extra = n - 1;
+    for (int i = 1; i < n; i++) { a.mx[i - 1] = mats[i]; a.wsumx[i - 1] = wsums[i]; a.outx[i - 1] = outs[i]; a.out_ldx[i - 1] = out_lds[i]; }
+    const int mt = (M + PF_BM - 1) / PF_BM;
+    if (mats[0].bits == 8) kr_pf_gemm2_launch<32, 2, 8>(a, mt, st);
     else kr_pf_gemm2_launch<32, 2, 4>(a, mt, st);
 }
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
