@@ -524,3 +524,10 @@ int kr_launch_fd_flash(const KrFdFlashArgs& a, int hd, int fp8, int max_seq, hip
 #undef KR_FF
     return 0;
 }
+
+void kr_launch_fd_merge2(const KrFdFlashArgs& a, int hd, int nch, int chunk, hipStream_t st) {     // also used by the MLA flash-decode (hd = kv_lora_rank)
+    if (hd == 512) hipLaunchKernelGGL(kr_fd_merge2_kernel<512>, dim3(a.nh), dim3(1024), 0, st, a, nch, chunk);
+    else if (hd == 256) hipLaunchKernelGGL(kr_fd_merge2_kernel<256>, dim3(a.nh), dim3(1024), 0, st, a, nch, chunk);
+    else if (hd == 128) hipLaunchKernelGGL(kr_fd_merge2_kernel<128>, dim3(a.nh), dim3(1024), 0, st, a, nch, chunk);
+    else hipLaunchKernelGGL(kr_fd_merge2_kernel<64>, dim3(a.nh), dim3(1024), 0, st, a, nch, chunk);
+}

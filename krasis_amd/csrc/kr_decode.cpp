@@ -674,7 +674,7 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
             KrMlaArgs pa{}; pa.klr = L.klr; pa.rd = L.rd; pa.kv_fp8 = s->kv_fp8; kr_mla_attn_prepare(pa, s->kv_max_seq);
             if (s->kv_max_seq > s->mla_split_min && s->gqa_scores.ensure((size_t)L.nh * s->kv_max_seq * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the attention score scratch failed");
             if (s->attn_fast && s->kv_max_seq > s->mla_split_min) {
-                const size_t nch = ((size_t)s->kv_max_seq + 255) / 256;
+                const size_t nch = std::max(((size_t)s->kv_max_seq + 255) / 256, kr_mla_flash_decode_chunks(s->kv_max_seq));
                 if (s->fd_o.ensure((size_t)L.nh * L.klr * nch * 4) || s->fd_ml.ensure((size_t)L.nh * nch * 8)) return kr_fail(KR_ERR_HIP, "hipMalloc of the split-KV partials failed");
             }
         }

@@ -52,6 +52,7 @@ struct KrMlaArgs {   // decode.rs:2993-3252
     int pos0; int ld_kv, ld_q;
 };
 void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok = 1);
+size_t kr_mla_flash_decode_chunks(int max_seq);   // chunks of the FAST split-KV decode (sizes the partial buffers)
 void kr_mla_attn_prepare(const KrMlaArgs& a, int max_seq);   // outside graph capture: LDS window of the staged attention kernel
 void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s, int rows = 1, int ld = 0);
 

@@ -646,6 +646,8 @@ static size_t kr_mla_staged_lds(const KrMlaArgs& a, int lds_seq) {
     const size_t esz = a.kv_fp8 ? 1 : 2;
     return (size_t)(a.klr + a.rd) * 4 + ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15) + (size_t)KR_MLA_ROWS * ((size_t)(a.klr + a.rd) * esz + 16);
 }
+int kr_launch_mla_flash_decode(const KrMlaArgs& a, int max_seq, hipStream_t st);   // kr_mla_flash.hip
+void kr_mla_flash_prepare();
 template <bool FP8, int NBC>
 static bool kr_launch_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {
     const bool split = a.sc_g && n_tok == 1;          // decode with a long cache: head-shared scores launch, then softmax + weighted sum per head
@@ -661,7 +663,8 @@ static bool kr_launch_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s,
         if (kr_lds_optin((const void*)kr_mla_scores_kernel<FP8, NBC, 8>, lds_sc)) return false;
         if (kr_lds_optin((const void*)kr_mla_pv_kernel<NBC, FP8>, lds_pv)) return false;
     }
-    if (prep) { kr_fd_prepare<NBC * 8, 16>(); return true; }
+    if (prep) { kr_fd_prepare<NBC * 8, 16>(); kr_mla_flash_prepare(); return true; }
+    if (split && a.fast && kr_launch_mla_flash_decode(a, max_seq, s) == 0) return true;      // FAST: split-KV flash-decode on the f16 MFMA + merge
     if (split) {
         hipLaunchKernelGGL((kr_mla_scores_kernel<FP8, NBC, 8>), dim3((max_seq + KR_MLA_ROWS - 1) / KR_MLA_ROWS, (a.nh + KR_MLA_HG - 1) / KR_MLA_HG), dim3(512), lds_sc, s, a, max_seq);
         if (a.fast && a.fd_o && a.fd_ml && a.nh <= 16) {     // tolerance mode: split-KV softmax + weighted sum over (chunk) workgroups, all heads share a latent row

@@ -32,8 +32,10 @@ __device__ __forceinline__ uint32_t mf_fp8x2_to_h2(uint32_t w, bool hi) {
 __device__ __forceinline__ uint32_t mf_f2h2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 
 // grid (row tiles of 64 query rows); q_abs [C][nh][KLR], q_pe [C][nh][64] (f32, kr_mla_prep_kernel), caches [position][KLR] / [position][64]
-template <int KLR, bool FP8>
-__global__ void __launch_bounds__(256) kr_mla_flash_kernel(const KrMlaArgs a, int C) {
+// SPLIT (decode over a long cache, one token): grid (row tiles, chunks); a workgroup walks `chunk_tiles` tiles of the cache and leaves the
+// un-normalised O rows and (max in log2 units, sum) per head for kr_fd_merge2_kernel (kr_attn_flash.hip); the position comes from a.step.
+template <int KLR, bool FP8, bool SPLIT = false>
+__global__ void __launch_bounds__(256) kr_mla_flash_kernel(const KrMlaArgs a, int C, int n_chunks = 0, int chunk_tiles = 0) {
     constexpr int RD = 64, DK = KLR + RD, KSTEPS = DK / 16, LDK = DK * 2 + 16, LDV = MF_TK * 2 + 16;
     constexpr int DBW = KLR / 64;                               // 32-dim output blocks per d-wave (two d-waves)
     constexpr int CB = FP8 ? 16 : 8;                            // dims per 16-byte global chunk
@@ -45,12 +47,15 @@ __global__ void __launch_bounds__(256) kr_mla_flash_kernel(const KrMlaArgs a, in
     char* Vt = Ks + MF_TK * LDK;                                // [KLR dims][LDV]       f16, positions contiguous
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n31 = lane & 31, khalf = lane >> 5, wq = wave & 1, wd = wave >> 1;
     const int nrows = C * a.nh, row0 = blockIdx.x * MF_ROWS;
+    const int pos0 = SPLIT ? a.step->pos : a.pos0;
     const int tok_first = row0 / a.nh, tok_last = min(C - 1, (row0 + MF_ROWS - 1) / a.nh);
-    const int kv_end = a.pos0 + tok_last + 1, full_vis = a.pos0 + tok_first;
-    const int n_tiles = (kv_end + MF_TK - 1) / MF_TK;
+    const int kv_end = pos0 + tok_last + 1, full_vis = pos0 + tok_first;
+    const int n_tiles_all = (kv_end + MF_TK - 1) / MF_TK;
+    const int tile_beg = SPLIT ? (int)blockIdx.y * chunk_tiles : 0, n_tiles = SPLIT ? min(n_tiles_all, tile_beg + chunk_tiles) : n_tiles_all;
+    if (SPLIT && tile_beg >= n_tiles_all) return;               // chunk past the current length (the grid is sized for the whole cache)
     const int myrow = row0 + wq * 32 + n31;
     const bool row_ok = myrow < nrows;
-    const int p_q = a.pos0 + (row_ok ? myrow / a.nh : 0);
+    const int p_q = pos0 + (row_ok ? myrow / a.nh : 0);
 
     // ---- query tile -> LDS (f16, sm_scale * log2 e folded in); rows past the end are zero
     {
@@ -123,8 +128,8 @@ __global__ void __launch_bounds__(256) kr_mla_flash_kernel(const KrMlaArgs a, in
         }
     };
 
-    load_tile(0);
-    for (int tile = 0; tile < n_tiles; tile++) {
+    load_tile(tile_beg * MF_TK);
+    for (int tile = tile_beg; tile < n_tiles; tile++) {
         const int p0 = tile * MF_TK;
         commit_tile();
         if (tile + 1 < n_tiles) load_tile(p0 + MF_TK);
@@ -181,6 +186,18 @@ __global__ void __launch_bounds__(256) kr_mla_flash_kernel(const KrMlaArgs a, in
             }
         __syncthreads();
     }
+    if (SPLIT) {
+        if (row_ok) {
+            float* out = a.fd_o + ((size_t)blockIdx.y * a.nh + myrow) * KLR + wd * (KLR / 2);          // [chunk][head][KLR]
+#pragma unroll
+            for (int db = 0; db < DBW; db++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++)
+                    *reinterpret_cast<float4*>(out + 32 * db + 8 * g4 + 4 * khalf) = make_float4(oacc[db][4 * g4], oacc[db][4 * g4 + 1], oacc[db][4 * g4 + 2], oacc[db][4 * g4 + 3]);
+            if (wd == 0 && khalf == 0) { float* ml = a.fd_ml + ((size_t)myrow * n_chunks + blockIdx.y) * 2; ml[0] = m_run; ml[1] = l_run; }
+        }
+        return;
+    }
     if (row_ok) {
         const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
         float* out = a.attn_lat + (size_t)myrow * KLR + wd * (KLR / 2);
@@ -197,6 +214,10 @@ template <int KLR> static size_t kr_mla_flash_lds() { return (size_t)(MF_ROWS + 
 
 // raise the dynamic-LDS window (per device, outside graph capture / before the first launch)
 void kr_mla_flash_prepare() {
+    (void)kr_lds_optin((const void*)kr_mla_flash_kernel<512, false, true>, kr_mla_flash_lds<512>());
+    (void)kr_lds_optin((const void*)kr_mla_flash_kernel<512, true, true>, kr_mla_flash_lds<512>());
+    (void)kr_lds_optin((const void*)kr_mla_flash_kernel<256, false, true>, kr_mla_flash_lds<256>());
+    (void)kr_lds_optin((const void*)kr_mla_flash_kernel<256, true, true>, kr_mla_flash_lds<256>());
     (void)kr_lds_optin((const void*)kr_mla_flash_kernel<512, false>, kr_mla_flash_lds<512>());
     (void)kr_lds_optin((const void*)kr_mla_flash_kernel<512, true>, kr_mla_flash_lds<512>());
     (void)kr_lds_optin((const void*)kr_mla_flash_kernel<256, false>, kr_mla_flash_lds<256>());
@@ -214,5 +235,28 @@ int kr_launch_mla_flash(const KrMlaArgs& a, int n_tok, hipStream_t st) {
         if (a.kv_fp8) hipLaunchKernelGGL((kr_mla_flash_kernel<256, true>), grid, dim3(256), kr_mla_flash_lds<256>(), st, a, n_tok);
         else hipLaunchKernelGGL((kr_mla_flash_kernel<256, false>), grid, dim3(256), kr_mla_flash_lds<256>(), st, a, n_tok);
     }
+    return 0;
+}
+
+// decode over a long cache, FAST mode: split-KV form of the kernel above + the log-sum-exp merge of kr_attn_flash.hip.  nh <= 64 heads (one row
+// tile).  non-zero = geometry not covered.  kr_mla_flash_prepare() must have run outside graph capture.
+int kr_mla_flash_decode_chunk(int max_seq) { return max_seq > 16384 ? 128 : 64; }
+size_t kr_mla_flash_decode_chunks(int max_seq) { const int ch = kr_mla_flash_decode_chunk(max_seq); return ((size_t)max_seq + ch - 1) / ch; }
+void kr_launch_fd_merge2(const KrFdFlashArgs& a, int hd, int nch, int chunk, hipStream_t st);   // kr_attn_flash.hip
+int kr_launch_mla_flash_decode(const KrMlaArgs& a, int max_seq, hipStream_t st) {
+    if (a.rd != 64 || (a.klr != 512 && a.klr != 256) || !a.step || !a.fd_o || !a.fd_ml || a.nh > MF_ROWS) return 1;
+    const int chunk = kr_mla_flash_decode_chunk(max_seq), nch = (int)kr_mla_flash_decode_chunks(max_seq);
+    if (nch > 1024) return 1;
+    dim3 grid(1, nch);
+    if (a.klr == 512) {
+        if (a.kv_fp8) hipLaunchKernelGGL((kr_mla_flash_kernel<512, true, true>), grid, dim3(256), kr_mla_flash_lds<512>(), st, a, 1, nch, chunk / MF_TK);
+        else hipLaunchKernelGGL((kr_mla_flash_kernel<512, false, true>), grid, dim3(256), kr_mla_flash_lds<512>(), st, a, 1, nch, chunk / MF_TK);
+    } else {
+        if (a.kv_fp8) hipLaunchKernelGGL((kr_mla_flash_kernel<256, true, true>), grid, dim3(256), kr_mla_flash_lds<256>(), st, a, 1, nch, chunk / MF_TK);
+        else hipLaunchKernelGGL((kr_mla_flash_kernel<256, false, true>), grid, dim3(256), kr_mla_flash_lds<256>(), st, a, 1, nch, chunk / MF_TK);
+    }
+    KrFdFlashArgs m{};
+    m.step = a.step; m.fd_o = a.fd_o; m.fd_ml = a.fd_ml; m.nh = a.nh; m.nkv = 1; m.gated = 0; m.out = a.attn_lat; m.img_out = nullptr;
+    kr_launch_fd_merge2(m, a.klr, nch, chunk, st);
     return 0;
 }

@@ -131,9 +131,10 @@ def test_chunked_delta_rule_matches_exact_within_tolerance(la_heads, n_tok, chun
 @pytest.mark.parametrize("cfg", [dict(kv_max=700), dict(klr=256, nh=3, seed=4, kv_max=900), dict(lora=True, seed=2, kv_max=640)])
 @pytest.mark.parametrize("fp8", [False, True])
 def test_mla_fast_decode_and_flash_prompt_pass(cfg, fp8):
-    """MLA in FAST mode: (a) decode over a long latent cache: split-KV softmax + weighted sum shared by all heads (kr_attn_fd.h with nkv = 1),
-    (b) prompt pass: flash attention over [ckv | kpe] rows on f16 MFMA (kr_mla_flash.hip).  Stated tolerances on the logits, FP16 caches: decode
-    5e-4, prompt pass 3e-3 relative (measured 1.1e-4 .. 2.5e-4 and 1.0e-3 .. 2.1e-3).  E4M3 caches: the latent rows the steps APPEND are
+    """MLA in FAST mode: (a) decode over a long latent cache: split-KV flash-decode over [ckv | kpe] rows on the f16 MFMA, all heads share a
+    chunk (kr_mla_flash.hip, SPLIT form) + log-sum-exp merge, (b) prompt pass: the same kernel over 64 (token, head) rows.  q and the
+    probabilities are rounded to f16 in both.  Stated tolerances on the logits, FP16 caches: decode 3e-3, prompt pass 3e-3 relative (measured
+    5.7e-4 .. 1.0e-3 and 1.0e-3 .. 2.2e-3).  E4M3 caches: the latent rows the steps APPEND are
     re-quantised to 3 mantissa bits, so a last-bit difference upstream can flip a stored code by 6 % of that element and the two runs' caches
     diverge -- the comparison then bounds that sensitivity, not the kernels: decode 5e-3, prompt pass 2e-2 (measured up to 1.9e-3 / 9.3e-3)."""
     from tests.test_mla_gpu import build as build_mla
@@ -163,7 +164,7 @@ def test_mla_fast_decode_and_flash_prompt_pass(cfg, fp8):
     if os.path.isdir("gpurun_out"):
         with open("gpurun_out/r02_attn_fast_err.txt", "a") as f:
             f.write(f"mla cfg={cfg} fp8={fp8} decode worst_rel={worst:.3e} prompt rel={relp:.3e}\n")
-    assert worst <= (5e-3 if fp8 else 5e-4), worst
+    assert worst <= (5e-3 if fp8 else 3e-3), worst
     assert np.isfinite(res[True][2]).all() and relp <= (2e-2 if fp8 else 3e-3), relp
     if not fp8:
         assert res[False][1] == res[True][1] and res[False][3] == res[True][3]
