@@ -28,6 +28,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define FA_TK 64
 #define FA_ROWS 128
+#ifdef KR_TIMING   // tools/probes/flash_timing.hip: wall-clock stamps (10 ns units) of wave 0 of workgroup (0, 0) at one tile; no-op in the product build
+__device__ unsigned long long kr_fstamps[32];
+#define FA_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && tile == 40) kr_fstamps[i] = wall_clock64(); } while (0)
+#else
+#define FA_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint32_t fa_fp8x2_to_h2(uint32_t w, bool hi) {      // two E4M3 bytes -> packed f16 pair (exact)
     const v2f f = hi ? __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
@@ -136,12 +142,18 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_flash_kernel(const KrPfmGqaArg
 
     // per tile: [K -> LDS] barrier [V loads in flight | S^T, softmax] [V -> LDS, next K loads in flight] barrier [O^T += V^T P^T]
     // (only one of the K / V register sets is live at a time: 512 registers hold Q^T, O^T, S^T and one prefetch set without spilling)
+    // E4M3 caches (16 + 16 prefetch registers) keep BOTH sets in flight: K and V of tile t + 1 are requested as soon as tile t went to LDS, a
+    // whole tile ahead of their use.  FP16 caches (32 + 32) would spill: there only one set is live (V of the current tile, then K of the next).
     load_k(0);
+    if (FP8) load_v(0);
     for (int tile = 0; tile < n_tiles; tile++) {
         const int p0 = tile * FA_TK;
+        FA_STAMP(0);
         commit_k();
+        if (FP8 && tile + 1 < n_tiles) load_k(p0 + FA_TK);
         __syncthreads();
-        load_v(p0);
+        if (!FP8) load_v(p0);
+        FA_STAMP(1);
         // ---- S^T = K Q^T  (two 32-position blocks)
         v16f sacc[2];
 #pragma unroll
@@ -155,6 +167,7 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_flash_kernel(const KrPfmGqaArg
                 if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the LDS fragment loads a few MFMAs ahead, not a whole tile (registers)
             }
         }
+        FA_STAMP(2);
         // ---- online softmax of this lane's row (32 of the tile's 64 positions live here, the rest in lane ^ 32)
         const bool need_mask = p0 + FA_TK - 1 > full_vis;
         float mloc = -__builtin_inff();
@@ -188,9 +201,12 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_flash_kernel(const KrPfmGqaArg
 #pragma unroll
                 for (int i = 0; i < 16; i++) oacc[db][i] *= alpha;
         }
+        FA_STAMP(3);
         commit_v();
-        if (tile + 1 < n_tiles) load_k(p0 + FA_TK);
+        if (tile + 1 < n_tiles) { if (FP8) load_v(p0 + FA_TK); else load_k(p0 + FA_TK); }
+        FA_STAMP(4);
         __syncthreads();
+        FA_STAMP(5);
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int db = 0; db < DB; db++)
@@ -202,6 +218,7 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_flash_kernel(const KrPfmGqaArg
                 oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, vv), pf[kt >> 1][kt & 1], oacc[db], 0, 0, 0);
                 if (kt == 3) __builtin_amdgcn_sched_barrier(0);
             }
+        FA_STAMP(6);
     }
     // ---- normalise, gate (attention.py:664-666 / decode.rs:4272-4280), store: accumulator rows 4g .. 4g+3 are dims 32 db + 8 g + 4 khalf + 0..3
     if (row_ok) {
