@@ -35,9 +35,10 @@ __device__ unsigned long long kr_fstamps[32];
 #define FA_STAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ uint32_t fa_fp8x2_to_h2(uint32_t w, bool hi) {      // two E4M3 bytes -> packed f16 pair (exact)
-    const v2f f = hi ? __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
-    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f.x, f.y));
+__device__ __forceinline__ uint32_t fa_fp8x2_to_h2(uint32_t w, bool hi) {      // two E4M3 bytes -> packed f16 pair (exact): ONE v_cvt_scalef32_pk_f16_fp8 (scale 1)
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t h = hi ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true) : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false);
+    return __builtin_bit_cast(uint32_t, h);
 }
 
 template <int HD, bool FP8>
