@@ -240,11 +240,229 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_flash_kernel(const KrPfmGqaArg
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Eight-wave form (head_dim 128 / 256): the phase probe of the four-wave kernel (tools/probes/flash_timing.hip) shows S^T 0.9 / softmax 1.1 /
+// staging 1.2 / PV 1.1 us per 64-position tile, strictly one after the other -- with 471 registers there is ONE wave per SIMD and nothing
+// overlaps the matrix core with the vector ALU.  Here the query tile lives in LDS instead of registers and the work of a tile is split over
+// wave PAIRS by position: wave (rg, ph) takes query rows [32 rg, +32) and the positions [32 ph, +32) of every tile, with its OWN online-softmax
+// state (max, sum, O) -- two independent flash streams over disjoint position subsets, merged once at the end (the split-KV merge, inside the
+// workgroup).  Half the MFMAs, half the softmax and half the registers per wave: two waves per SIMD, the one's softmax under the other's MFMAs.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int HD, bool FP8>
+__global__ void __launch_bounds__(512, 2) kr_pfm_gqa_flash8_kernel(const KrPfmGqaArgs a, int C) {
+    constexpr int KSTEPS = HD / 16, DB = HD / 32, LDK = HD * 2 + 16, LDV = FA_TK * 2 + 16;
+    constexpr int CPR = FP8 ? HD / 16 : HD / 8;                 // 16-byte global chunks per cache row
+    constexpr int KCH = FA_TK * CPR / 512;                      // K chunks per thread per tile
+    constexpr int VUN = (FA_TK / 2) * CPR, VPT = (VUN + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char fa_smem[];
+    char* Qs = fa_smem;                                         // [128 rows][LDK]       f16, scale and log2 e folded in
+    char* Ks = Qs + FA_ROWS * LDK;                              // [64 positions][LDK]   f16
+    char* Vt = Ks + FA_TK * LDK;                                // [HD dims][LDV]        f16, positions contiguous
+    const int G = a.nh / a.nkv, TQ = FA_ROWS / G;
+    const int kvh = blockIdx.y, t0 = blockIdx.x * TQ;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n31 = lane & 31, khalf = lane >> 5, rg = wave & 3, ph = wave >> 2;
+    const int r = rg * 32 + n31, hl = r / TQ, ti = r % TQ, tok = t0 + ti;
+    const bool row_ok = tok < C;
+    const int h = kvh * G + hl, p_q = a.pos0 + tok;
+    const int kvs = a.nkv * HD, esz = FP8 ? 1 : 2;
+    const int kv_end = a.pos0 + (t0 + TQ < C ? t0 + TQ : C);
+    const int n_tiles = (kv_end + FA_TK - 1) / FA_TK;
+    const int full_vis = a.pos0 + t0;
+    // ---- query tile -> LDS
+    {
+        const float sc = a.sm_scale * 1.4426950408889634f;
+        for (int i = tid; i < FA_ROWS * (HD / 8); i += 512) {
+            const int rr = i / (HD / 8), c8 = i % (HD / 8), hh = rr / TQ, tt = t0 + rr % TQ;
+            u32x4 o = {0, 0, 0, 0};
+            if (tt < C) {
+                const float* src = a.q_out + ((size_t)tt * a.nh + kvh * G + hh) * HD + c8 * 8;
+                const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+                o = u32x4{__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x0.x * sc, x0.y * sc)), __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x0.z * sc, x0.w * sc)),
+                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x1.x * sc, x1.y * sc)), __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x1.z * sc, x1.w * sc))};
+            }
+            *reinterpret_cast<u32x4*>(Qs + rr * LDK + c8 * 16) = o;
+        }
+    }
+    v16f oacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; db++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) oacc[db][i] = 0.0f;
+    float m_run = -__builtin_inff(), l_run = 0.0f;
+    const unsigned char* kc = reinterpret_cast<const unsigned char*>(a.k_cache) + (size_t)kvh * HD * esz;
+    const unsigned char* vc = reinterpret_cast<const unsigned char*>(a.v_cache) + (size_t)kvh * HD * esz;
+    u32x4 pk[KCH], pva[VPT], pvb[VPT];
+    auto load_k = [&](int p0) {
+#pragma unroll
+        for (int j = 0; j < KCH; j++) {
+            const int c = tid + j * 512, row = c / CPR, dc = c % CPR, p = min(p0 + row, kv_end - 1);      // rows past the end are masked below
+            pk[j] = *reinterpret_cast<const u32x4*>(kc + (size_t)p * kvs * esz + dc * 16);
+        }
+    };
+    auto load_v = [&](int p0) {
+#pragma unroll
+        for (int j = 0; j < VPT; j++) {
+            const int u = tid + j * 512, pp = u & 31, dc = u >> 5, p = p0 + 2 * pp;
+            pva[j] = u32x4{0, 0, 0, 0}; pvb[j] = u32x4{0, 0, 0, 0};
+            if (u < VUN) {
+                const u32x4 va = *reinterpret_cast<const u32x4*>(vc + (size_t)min(p, kv_end - 1) * kvs * esz + dc * 16);
+                const u32x4 vb = *reinterpret_cast<const u32x4*>(vc + (size_t)min(p + 1, kv_end - 1) * kvs * esz + dc * 16);
+                if (p < kv_end) pva[j] = va;
+                if (p + 1 < kv_end) pvb[j] = vb;
+            }
+        }
+    };
+    auto commit_k = [&]() {
+#pragma unroll
+        for (int j = 0; j < KCH; j++) {
+            const int c = tid + j * 512, row = c / CPR, dc = c % CPR;
+            if (FP8) {
+                const u32x4 w = pk[j];
+                u32x4 lo = {fa_fp8x2_to_h2(w.x, false), fa_fp8x2_to_h2(w.x, true), fa_fp8x2_to_h2(w.y, false), fa_fp8x2_to_h2(w.y, true)};
+                u32x4 hi = {fa_fp8x2_to_h2(w.z, false), fa_fp8x2_to_h2(w.z, true), fa_fp8x2_to_h2(w.w, false), fa_fp8x2_to_h2(w.w, true)};
+                *reinterpret_cast<u32x4*>(Ks + row * LDK + dc * 32) = lo; *reinterpret_cast<u32x4*>(Ks + row * LDK + dc * 32 + 16) = hi;
+            } else *reinterpret_cast<u32x4*>(Ks + row * LDK + dc * 16) = pk[j];
+        }
+    };
+    auto commit_v = [&]() {
+#pragma unroll
+        for (int j = 0; j < VPT; j++) {
+            const int u = tid + j * 512, pp = u & 31, dc = u >> 5;
+            if (u < VUN) {
+                uint32_t ha[8], hb[8];
+                constexpr int NW = FP8 ? 8 : 4;
+                if (FP8) {
+                    const uint32_t wa[4] = {pva[j].x, pva[j].y, pva[j].z, pva[j].w}, wb[4] = {pvb[j].x, pvb[j].y, pvb[j].z, pvb[j].w};
+#pragma unroll
+                    for (int m = 0; m < 4; m++) { ha[2 * m] = fa_fp8x2_to_h2(wa[m], false); ha[2 * m + 1] = fa_fp8x2_to_h2(wa[m], true);
+                                                  hb[2 * m] = fa_fp8x2_to_h2(wb[m], false); hb[2 * m + 1] = fa_fp8x2_to_h2(wb[m], true); }
+                } else {
+                    ha[0] = pva[j].x; ha[1] = pva[j].y; ha[2] = pva[j].z; ha[3] = pva[j].w; hb[0] = pvb[j].x; hb[1] = pvb[j].y; hb[2] = pvb[j].z; hb[3] = pvb[j].w;
+                }
+                char* base = Vt + (size_t)(dc * (FP8 ? 16 : 8)) * LDV + pp * 4;
+#pragma unroll
+                for (int m = 0; m < NW; m++) {
+                    *reinterpret_cast<uint32_t*>(base + (2 * m) * LDV) = __builtin_amdgcn_perm(hb[m], ha[m], 0x05040100u);
+                    *reinterpret_cast<uint32_t*>(base + (2 * m + 1) * LDV) = __builtin_amdgcn_perm(hb[m], ha[m], 0x07060302u);
+                }
+            }
+        }
+    };
+    load_k(0); load_v(0);
+    for (int tile = 0; tile < n_tiles; tile++) {
+        const int p0 = tile * FA_TK;
+        commit_k();
+        if (tile + 1 < n_tiles) load_k(p0 + FA_TK);
+        __syncthreads();                                  // K tile (and, in the first round, the query tile) is complete
+        // ---- S^T of this wave's 32 positions
+        v16f sacc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) sacc[i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+            const v8h kf = *reinterpret_cast<const v8h*>(Ks + (32 * ph + n31) * LDK + (16 * ks + 8 * khalf) * 2);
+            const v8h qf = *reinterpret_cast<const v8h*>(Qs + r * LDK + (16 * ks + 8 * khalf) * 2);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, sacc, 0, 0, 0);
+        }
+        const bool need_mask = p0 + FA_TK - 1 > full_vis || p0 + FA_TK > kv_end;
+        float mloc = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (need_mask) { const int p = p0 + 32 * ph + (i & 3) + 8 * (i >> 2) + 4 * khalf; if (p > p_q || !row_ok) sacc[i] = -__builtin_inff(); }
+            mloc = fmaxf(mloc, sacc[i]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float m_use = m_new == -__builtin_inff() ? 0.0f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float lsum = 0.0f;
+        v8h pf[2];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float pv = __builtin_amdgcn_exp2f(sacc[i] - m_use);
+            lsum += pv;
+            pf[i >> 3][i & 7] = (_Float16)pv;
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+            for (int db = 0; db < DB; db++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) oacc[db][i] *= alpha;
+        }
+        commit_v();
+        if (tile + 1 < n_tiles) load_v(p0 + FA_TK);
+        __syncthreads();
+        // ---- O^T += V^T P^T over this wave's 32 positions
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) {
+                const char* vr = Vt + (size_t)(32 * db + n31) * LDV + (32 * ph + 16 * kt + 4 * khalf) * 2;
+                const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr), v1 = *reinterpret_cast<const u32x2*>(vr + 16);
+                const u32x4 vv = {v0.x, v0.y, v1.x, v1.y};
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, vv), pf[kt], oacc[db], 0, 0, 0);
+            }
+    }
+    // ---- merge the two position streams of a row group: the ph = 1 waves hand (m, l, O) over through LDS (everything staged there is dead now)
+    __syncthreads();
+    float* Ox = reinterpret_cast<float*>(fa_smem);              // [4 row groups][HD dims][32 rows] f32 + [4][2][32] (m, l)   (HD = 256: 128 KiB + 1 KiB)
+    float* MLx = Ox + 4 * HD * 32;
+    if (ph == 1) {
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) Ox[((size_t)rg * HD + 32 * db + (i & 3) + 8 * (i >> 2) + 4 * khalf) * 32 + n31] = oacc[db][i];
+        if (khalf == 0) { MLx[(rg * 2 + 0) * 32 + n31] = m_run; MLx[(rg * 2 + 1) * 32 + n31] = l_run; }
+    }
+    __syncthreads();
+    if (ph == 0 && row_ok) {
+        const float m1 = MLx[(rg * 2 + 0) * 32 + n31], l1 = MLx[(rg * 2 + 1) * 32 + n31];
+        const float M = fmaxf(m_run, m1), Mu = M == -__builtin_inff() ? 0.0f : M;
+        const float w0 = __builtin_amdgcn_exp2f(m_run - Mu), w1 = __builtin_amdgcn_exp2f(m1 - Mu);
+        const float lt = l_run * w0 + l1 * w1;
+        const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+        const size_t ob = ((size_t)tok * a.nh + h) * HD;
+#pragma unroll
+        for (int db = 0; db < DB; db++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const int d = 32 * db + 8 * g4 + 4 * khalf;
+                float o4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) o4[u] = (oacc[db][4 * g4 + u] * w0 + Ox[((size_t)rg * HD + d + u) * 32 + n31] * w1) * inv;
+                float4 o = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                if (a.gated) {
+                    const float4 gt = *reinterpret_cast<const float4*>(a.gate + ob + d);
+                    o.x *= 1.0f / (1.0f + kr_expf(-gt.x)); o.y *= 1.0f / (1.0f + kr_expf(-gt.y)); o.z *= 1.0f / (1.0f + kr_expf(-gt.z)); o.w *= 1.0f / (1.0f + kr_expf(-gt.w));
+                }
+                *reinterpret_cast<float4*>(a.attn_out + ob + d) = o;
+            }
+    }
+}
+
 // non-zero = geometry not covered (the caller falls back to the exact passes)
 int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st) {
     const int G = a.nkv > 0 ? a.nh / a.nkv : 0;
     if (a.nh % a.nkv || G < 1 || G > FA_ROWS || (FA_ROWS % G) || (a.hd != 64 && a.hd != 128 && a.hd != 256)) return 1;
     const int TQ = FA_ROWS / G;
+    dim3 grid((C + TQ - 1) / TQ, a.nkv);
+    if (a.hd >= 128 && !getenv("KR_FLASH4")) {      // eight waves, query tile in LDS, wave pairs split the positions of a tile (KR_FLASH4: A/B hook for the four-wave form)
+        const size_t l8 = (size_t)(FA_ROWS + FA_TK) * (a.hd * 2 + 16) + (size_t)a.hd * (FA_TK * 2 + 16);
+        const size_t lm = (size_t)(4 * a.hd * 32 + 4 * 2 * 32) * 4;
+        const size_t lds8 = l8 > lm ? l8 : lm;
+        const void* fn8 = a.hd == 256 ? (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash8_kernel<256, true> : (const void*)kr_pfm_gqa_flash8_kernel<256, false>)
+                                      : (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash8_kernel<128, true> : (const void*)kr_pfm_gqa_flash8_kernel<128, false>);
+        if (lds8 <= 160 * 1024 && kr_lds_optin(fn8, lds8) == 0) {
+#define KR_FA8(H_, F_) hipLaunchKernelGGL((kr_pfm_gqa_flash8_kernel<H_, F_>), grid, dim3(512), lds8, st, a, C)
+            if (a.hd == 256) { if (a.kv_fp8) KR_FA8(256, true); else KR_FA8(256, false); }
+            else { if (a.kv_fp8) KR_FA8(128, true); else KR_FA8(128, false); }
+#undef KR_FA8
+            return 0;
+        }
+    }
     const size_t lds = (size_t)FA_TK * (a.hd * 2 + 16) + (size_t)a.hd * (FA_TK * 2 + 16);
     {
         const void* fn = a.hd == 256 ? (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash_kernel<256, true> : (const void*)kr_pfm_gqa_flash_kernel<256, false>)
@@ -252,7 +470,6 @@ int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st) {
                                      : (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash_kernel<64, true> : (const void*)kr_pfm_gqa_flash_kernel<64, false>);
         if (kr_lds_optin(fn, 96 * 1024)) return 1;
     }
-    dim3 grid((C + TQ - 1) / TQ, a.nkv);
 #define KR_FA(H_, F_) hipLaunchKernelGGL((kr_pfm_gqa_flash_kernel<H_, F_>), grid, dim3(256), lds, st, a, C)
     if (a.hd == 256) { if (a.kv_fp8) KR_FA(256, true); else KR_FA(256, false); }
     else if (a.hd == 128) { if (a.kv_fp8) KR_FA(128, true); else KR_FA(128, false); }
