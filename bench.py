@@ -311,7 +311,9 @@ def prefill_model(st, dims, gemm_macs_per_token, L, P, reps, torch):
     import numpy as np
     st.fill_state_synthetic(P + 64, 7)                      # KV caches / states sized for the prompt
     toks = [int(x) for x in np.random.default_rng(5).integers(0, dims["vocab"], P)]
-    st.prefill(toks[: min(P, 2048)], 0)                     # warm-up: scratch arena, per-weight nibble sums
+    st.prefill(toks[: min(P, 2048)], 0)                     # warm-up: scratch arena, per-weight nibble sums, router gate copies
+    if P > 2048:
+        st.prefill(toks[:64], P - 64)                       # ... and the buffers that grow with the context (score scratch of the exact mode)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
