@@ -50,6 +50,7 @@ struct KrMlaArgs {   // decode.rs:2993-3252
     // prompt pass (step == nullptr): token t = blockIdx.y (blockIdx.z for the w_vc launch) sits at position pos0 + t; row t of the
     // per-token buffers starts at t * ld_* floats (kv_out, q_full) or t * their natural size (q_abs, q_pe, attn_lat, v_proj)
     int pos0; int ld_kv, ld_q;
+    int absorb_done;   // prompt pass: q_abs of the chunk was produced by kr_launch_mla_absorb_mfma -- the prep launch skips its absorption loop
 };
 void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok = 1);
 size_t kr_mla_flash_decode_chunks(int max_seq);   // chunks of the FAST split-KV decode (sizes the partial buffers)

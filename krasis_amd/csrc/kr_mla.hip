@@ -10,6 +10,7 @@
 // Three launches per layer: prep (norm, RoPE, FP16 cache append, w_kc absorption spread over nh*klr/64 workgroups so the 4 MiB of
 // w_kc streams from many CUs), attention (one workgroup per head), w_vc projection (nh*vhd/8 workgroups, 4 MiB of w_vc).
 #include "kr_lds_optin.h"
+#include "kr_router.h"
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
@@ -72,11 +73,12 @@ template <bool FP8>
 __global__ void __launch_bounds__(64) kr_mla_prep_kernel(KrMlaArgs a) {
     __shared__ float sh[640];
     const int pos = kr_mla_token(a, blockIdx.y);
-    const int tiles = a.klr / 64, nb_abs = a.nh * tiles, hd = a.nd + a.rd, half = a.rd / 2;
+    const int tiles = a.absorb_done ? 1 : a.klr / 64, nb_abs = a.nh * tiles, hd = a.nd + a.rd, half = a.rd / 2;      // absorb_done: one workgroup per head (rope of q_pe only)
     const int t = threadIdx.x;
     if ((int)blockIdx.x < nb_abs) {
         const int h = blockIdx.x / tiles, jt = blockIdx.x % tiles, j = jt * 64 + t;
         const float* qh = a.q_full + (size_t)h * hd;
+        if (!a.absorb_done) {
         for (int i = t; i < a.nd; i += 64) sh[i] = qh[i];
         __syncthreads();
         const float* w = a.w_kc + (size_t)h * a.nd * a.klr + j;
@@ -91,6 +93,7 @@ __global__ void __launch_bounds__(64) kr_mla_prep_kernel(KrMlaArgs a) {
         }
         for (; i < a.nd; i++) o = __builtin_fmaf(sh[i], w[(size_t)i * a.klr], o);
         a.q_abs[(size_t)h * a.klr + j] = o;
+        }
         if (jt == 0 && t < half) {   // decode.rs:3113-3128
             const float x1 = qh[a.nd + 2 * t], x2 = qh[a.nd + 2 * t + 1];
             const float c = a.rope_cos[(size_t)pos * half + t], s = a.rope_sin[(size_t)pos * half + t];
@@ -686,15 +689,23 @@ static bool kr_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_
 // raises the staged kernel's dynamic-LDS window; called outside graph capture (hipFuncSetAttribute is not a stream operation)
 void kr_mla_attn_prepare(const KrMlaArgs& a, int max_seq) { (void)kr_mla_staged(a, max_seq, nullptr, 1); }
 int kr_launch_mla_flash(const KrMlaArgs& a, int n_tok, hipStream_t st);   // kr_mla_flash.hip
-void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok) {
-    if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_prep_kernel<true>, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(kr_mla_prep_kernel<false>, dim3(a.nh * (a.klr / 64) + 1, n_tok), dim3(64), 0, s, a);
+void kr_launch_mla(const KrMlaArgs& a_in, int max_seq, hipStream_t s, int n_tok) {
+    KrMlaArgs a = a_in;
+    // prompt pass: the w_kc absorption of the whole chunk on the f32 MFMA (one fma chain per output, bit-identical); the prep launch then only
+    // ropes q_pe (one workgroup per head) and appends the latent / rope rows
+    if (!a.step && n_tok >= 32 && kr_launch_mla_absorb_mfma(a.q_full, a.ld_q, a.nd + a.rd, a.nd, a.w_kc, a.klr, a.q_abs, n_tok, a.nh, s) == 0) a.absorb_done = 1;
+    const int prep_blocks = a.nh * (a.absorb_done ? 1 : a.klr / 64) + 1;
+    if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_prep_kernel<true>, dim3(prep_blocks, n_tok), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(kr_mla_prep_kernel<false>, dim3(prep_blocks, n_tok), dim3(64), 0, s, a);
     if (a.fast && !a.step && kr_launch_mla_flash(a, n_tok, s) == 0) {
         // prompt pass, tolerance mode: one flash-attention launch streams the latent cache once per 64 (token, head) rows
     } else if (!kr_mla_staged(a, max_seq, s, n_tok)) {      // other geometries: the generic kernel
         if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_attn_kernel<true>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
         else hipLaunchKernelGGL(kr_mla_attn_kernel<false>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
     }
+    // prompt pass: the w_vc projection of the whole chunk on the f32 MFMA (its two-accumulator dot is the router's 16-chain structure:
+    // kr_route_mfma.hip), bit-identical to the per-token launch below
+    if (!a.step && n_tok >= 32 && kr_launch_mla_wvc_mfma(a.w_vc, a.attn_lat, a.v_proj, n_tok, a.nh, a.vhd, a.klr, s) == 0) return;
     hipLaunchKernelGGL(kr_mla_wvc_kernel, dim3((a.vhd + 7) / 8, a.nh, n_tok), dim3(128), (size_t)a.klr * 4, s, a);
 }
 void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s, int rows, int ld) {

@@ -24,9 +24,15 @@ typedef uint32_t rm_u4 __attribute__((ext_vector_type(4)));
 #define RM_LDB16 (RM_KS + 8)       // bf16 per gate row in LDS (272 B: rows 4 banks apart)
 #define RM_LDB32 (RM_KS + 4)       // f32 gate row
 
+// Batched form (blockIdx.z): the same 16-chain dot + fold tree is the reference's w_vc projection of MLA (mla_project_wvc_avx2, decode.rs:4555: two
+// 8-lane accumulators over alternating 8-blocks = chains j = 8 a + l over elements 16 m + j, then acc0 + acc1 and the hsum tree) -- head h reads
+// x + h * x_bs with row stride ldx, gate + h * g_bs, and writes logits + h * o_bs with row stride ldo.
 template <bool GATE_BF16>
-__global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* __restrict__ gate_row, const float* __restrict__ x, const float* __restrict__ bias,
-                                                                   float* __restrict__ logits, int T, int E, int H) {
+__global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* __restrict__ gate_row_, const float* __restrict__ x_, const float* __restrict__ bias,
+                                                                   float* __restrict__ logits_, int T, int E, int H, int ldx, int ldo, size_t x_bs, size_t g_bs, size_t o_bs) {
+    const float* x = x_ + (size_t)blockIdx.z * x_bs; float* logits = logits_ + (size_t)blockIdx.z * o_bs;
+    const void* gate_row = GATE_BF16 ? (const void*)(reinterpret_cast<const uint16_t*>(gate_row_) + (size_t)blockIdx.z * g_bs)
+                                     : (const void*)(reinterpret_cast<const float*>(gate_row_) + (size_t)blockIdx.z * g_bs);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int A_BYTES = 64 * RM_LDA * 4, B_BYTES = GATE_BF16 ? 64 * RM_LDB16 * 2 : 64 * RM_LDB32 * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -40,7 +46,7 @@ __global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* _
         for (int i = 0; i < 8; i++) {
             const int u = tid + 256 * i, row = u >> 5, c4 = (u & 31) * 4;
             const int tr = min(t0 + row, T - 1);
-            pa[i] = *reinterpret_cast<const rm_f4*>(x + (size_t)tr * H + k0 + c4);
+            pa[i] = *reinterpret_cast<const rm_f4*>(x + (size_t)tr * ldx + k0 + c4);
         }
         if (GATE_BF16) {
 #pragma unroll
@@ -122,22 +128,82 @@ __global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* _
         float v = (c0 + c1) + (c2 + c3);
         if (bias) v += bv;
         const int t = t0 + tb + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (t < T && e < E) logits[(size_t)t * E + e] = v;
+        if (t < T && e < E) logits[(size_t)t * ldo + e] = v;
     }
 }
 
 // non-zero = geometry not covered (caller keeps the GEMV)
-int kr_launch_route_logits_mfma(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* logits, int T, int E, int H, hipStream_t st) {
-    if (H % RM_KS || T < 1 || E < 1) return 1;
-    const dim3 grid((E + 63) / 64, (T + 63) / 64);
+static int rm_launch(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* out, int T, int E, int H, int ldx, int ldo, int batch, size_t x_bs,
+                     size_t g_bs, size_t o_bs, hipStream_t st) {
+    if (H % RM_KS || T < 1 || E < 1 || batch < 1) return 1;
+    const dim3 grid((E + 63) / 64, (T + 63) / 64, batch);
     if (gate_bf16) {
         const size_t lds = 2 * (size_t)(64 * RM_LDA * 4 + 64 * RM_LDB16 * 2);
         if (kr_lds_optin(reinterpret_cast<const void*>(kr_route_logits_mfma_kernel<true>), lds)) return 1;
-        hipLaunchKernelGGL(kr_route_logits_mfma_kernel<true>, grid, dim3(256), lds, st, gate_row, x, bias, logits, T, E, H);
+        hipLaunchKernelGGL(kr_route_logits_mfma_kernel<true>, grid, dim3(256), lds, st, gate_row, x, bias, out, T, E, H, ldx, ldo, x_bs, g_bs, o_bs);
     } else {
         const size_t lds = 2 * (size_t)(64 * RM_LDA * 4 + 64 * RM_LDB32 * 4);
         if (kr_lds_optin(reinterpret_cast<const void*>(kr_route_logits_mfma_kernel<false>), lds)) return 1;
-        hipLaunchKernelGGL(kr_route_logits_mfma_kernel<false>, grid, dim3(256), lds, st, gate_row, x, bias, logits, T, E, H);
+        hipLaunchKernelGGL(kr_route_logits_mfma_kernel<false>, grid, dim3(256), lds, st, gate_row, x, bias, out, T, E, H, ldx, ldo, x_bs, g_bs, o_bs);
     }
+    return 0;
+}
+int kr_launch_route_logits_mfma(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* logits, int T, int E, int H, hipStream_t st) {
+    return rm_launch(gate_row, gate_bf16, x, bias, logits, T, E, H, H, E, 1, 0, 0, 0, st);
+}
+// MLA prompt pass: v_proj[t][h][o] = w_vc[h][o][:] . attn_lat[t][h][:] for all tokens and heads (bit-identical to kr_mla_wvc_kernel)
+int kr_launch_mla_wvc_mfma(const float* w_vc, const float* attn_lat, float* v_proj, int T, int nh, int vhd, int klr, hipStream_t st) {
+    return rm_launch(w_vc, 0, attn_lat, nullptr, v_proj, T, vhd, klr, nh * klr, nh * vhd, nh, (size_t)klr, (size_t)vhd * klr, (size_t)vhd, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// MLA prompt pass: the w_kc absorption of a chunk (mla_absorb_wkc_avx2, decode.rs:4508): q_abs[t][h][j] = chain over i ascending of
+// fma(q[t][h][i], w_kc[h][i][j], acc) -- ONE chain per output, so one accumulator per 32 x 32 block and the k pairs (2m, 2m+1) in order.
+// Workgroup: 64 tokens x 64 latent columns of one head, K = nd in one stage.  The q tile is stored with the k of every 8-group de-interleaved
+// (even k first), so the lane half that supplies k = 2m + h reads four consecutive floats.  Bit-identical to kr_mla_prep_kernel's loop.
+// ------------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kr_mla_absorb_mfma_kernel(const float* __restrict__ q_full, int ld_q, int hd, int nd, const float* __restrict__ w_kc, int klr,
+                                                                 float* __restrict__ q_abs, int T, int nh) {
+    extern __shared__ __attribute__((aligned(16))) float ab_smem[];
+    const int lda = nd + 4, ldb = 68;
+    float* As = ab_smem; float* Bs = As + 64 * lda;
+    const int j0 = blockIdx.x * 64, t0 = blockIdx.y * 64, h = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    for (int i = tid; i < 64 * (nd / 4); i += 256) {
+        const int row = i / (nd / 4), c4 = (i % (nd / 4)) * 4, t = min(t0 + row, T - 1);
+        const rm_f4 v = *reinterpret_cast<const rm_f4*>(q_full + (size_t)t * ld_q + (size_t)h * hd + c4);
+        float* d = As + row * lda + (c4 & ~7);                   // k = c4 .. c4 + 3 of the 8-group: even k -> slots 0..3, odd k -> slots 4..7
+        const int e0 = (c4 & 7) >> 1;
+        d[e0] = v.x; d[4 + e0] = v.y; d[e0 + 1] = v.z; d[4 + e0 + 1] = v.w;
+    }
+    for (int i = tid; i < nd * 16; i += 256) {
+        const int k = i >> 4, c4 = (i & 15) * 4;
+        *reinterpret_cast<rm_f4*>(Bs + k * ldb + c4) = *reinterpret_cast<const rm_f4*>(w_kc + ((size_t)h * nd + k) * klr + j0 + c4);
+    }
+    __syncthreads();
+    const int tb = (wave >> 1) * 32, jb = (wave & 1) * 32;
+    rm_v16f acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    for (int q8 = 0; q8 < nd; q8 += 8) {
+        const rm_f4 a4 = *reinterpret_cast<const rm_f4*>(As + (tb + r) * lda + q8 + 4 * hh);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+        float bv[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) bv[s2] = Bs[(q8 + 2 * s2 + hh) * ldb + jb + r];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int t = t0 + tb + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (t < T) q_abs[((size_t)t * nh + h) * klr + j0 + jb + r] = acc[i];
+    }
+}
+int kr_launch_mla_absorb_mfma(const float* q_full, int ld_q, int hd, int nd, const float* w_kc, int klr, float* q_abs, int T, int nh, hipStream_t st) {
+    if (nd % 8 || klr % 64 || T < 1) return 1;
+    const size_t lds = (size_t)(64 * (nd + 4) + nd * 68) * 4;
+    if (lds > 160 * 1024 || kr_lds_optin(reinterpret_cast<const void*>(kr_mla_absorb_mfma_kernel), lds)) return 1;
+    hipLaunchKernelGGL(kr_mla_absorb_mfma_kernel, dim3(klr / 64, (T + 63) / 64, nh), dim3(256), lds, st, q_full, ld_q, hd, nd, w_kc, klr, q_abs, T, nh);
     return 0;
 }
