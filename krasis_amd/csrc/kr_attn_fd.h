@@ -1,6 +1,6 @@
-// kr_attn_fd.h -- FAST (tolerance) mode of decode attention over long caches: split-KV softmax + weighted sum, shared by the GQA path
-// (kr_decode_ops.hip: V rows [position][nkv * hd], G = nh / nkv query heads per KV head) and the MLA path (kr_mla.hip: the latent cache
-// [position][klr] is the value stream of ALL heads, nkv = 1, G = nh).
+// kr_attn_fd.h -- FAST (tolerance) mode of decode attention over long caches, first form: exact scores + split-KV softmax / weighted sum.
+// Since the flash-decode kernels (kr_attn_flash.hip for GQA, the SPLIT form of kr_mla_flash.hip for MLA) this is the FALLBACK of the MLA path
+// for geometries those do not cover (kr_mla.hip: the latent cache [position][klr] is the value stream of ALL heads, nkv = 1, G = nh <= 16).
 //
 // The exact kernels keep the reference's sequential order (sum of exponentials and p.v one position after the other, decode.rs:4236-4270 /
 // :4326-4351), so their second launch is ONE workgroup per head walking the whole cache.  north_star asks for fp TOLERANCE outside the

@@ -9,7 +9,6 @@
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
-#include "kr_attn_fd.h"
 #include <hip/hip_fp16.h>
 #include <cstdlib>
 
@@ -1072,17 +1071,7 @@ __global__ void __launch_bounds__(512) kr_gqa_pv_kernel(const KrGqaArgs a, int m
 }
 static size_t kr_gqa_pv_lds(int lds_seq, int hd, int fp8) { return ((((size_t)lds_seq + 40) * 4 + 15) & ~(size_t)15) + 2 * (size_t)hd * (KR_PV_ROWS * (fp8 ? 1 : 2) + 16); }
 
-// ---- FAST (tolerance) mode for long caches: split-KV softmax + p.v (kr_attn_fd.h) ----
-static bool kr_gqa_fast_ok(const KrGqaArgs& a) { return a.fd_o && a.fd_ml && a.sc_g && (a.hd == 64 || a.hd == 128 || a.hd == 256) && a.nh % a.nkv == 0 && a.nh / a.nkv <= 8; }
-static void kr_launch_gqa_fast(const KrGqaArgs& a, int max_seq, hipStream_t s) {
-    KrFdArgs f{};
-    f.step = a.step; f.sc_g = a.sc_g; f.v_cache = a.v_cache; f.v_ld = a.nkv * a.hd; f.fd_o = a.fd_o; f.fd_ml = a.fd_ml; f.nh = a.nh; f.nkv = a.nkv;
-    f.gate = a.gate; f.gated = a.gated; f.out = a.attn_out; f.img_out = a.img_out;
-    if (a.hd == 256) kr_launch_fd<256, 8>(f, a.kv_fp8, max_seq, s);
-    else if (a.hd == 128) kr_launch_fd<128, 8>(f, a.kv_fp8, max_seq, s);
-    else kr_launch_fd<64, 8>(f, a.kv_fp8, max_seq, s);
-}
-
+// FAST (tolerance) mode for long caches: kr_launch_fd_flash (kr_attn_flash.hip), dispatched at the top of kr_launch_gqa
 // decode-step MoE epilogue (decode.rs:3343-3345, 3391-3402): hidden = moe (*rsf) + shared (*sigmoid(gate))
 __global__ void __launch_bounds__(256) kr_moe_combine_decode_kernel(const float* __restrict__ eo, const int32_t* __restrict__ ids,
                                                                    const float* __restrict__ wts, int topk, int has_shared,
@@ -1233,7 +1222,6 @@ void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
     }
     if (a.sc_g) {      // long cache: scores over nh x max_seq / 256 workgroups (those past the current length leave at once), then softmax + p.v
         kr_launch_gqa_phase<1>(a, max_seq, dim3(a.nh, (max_seq + 255) / 256), 0, s);
-        if (kr_gqa_fast_ok(a)) { kr_launch_gqa_fast(a, max_seq, s); return; }      // tolerance mode: split-KV softmax + p.v, log-sum-exp merge
         const bool stream_hook = getenv("KR_GQA_STREAM") != nullptr;                   // (env: test hook)
         if (a.hd == 64 || a.hd == 128 || a.hd == 256) {
             const bool res = kr_gqa_pv_lds(max_seq, a.hd, a.kv_fp8) <= 160 * 1024 && !stream_hook;
