@@ -158,6 +158,10 @@ int kr_reduce_sum_bf16(kr_engine* e, const void* const* inputs, int n_inputs, vo
 /* test / tuning hook: (token, slot) pairs per pass of kr_moe_prefill (0 = default 81 920: 8192 tokens of a top-10 model, 81 920 top-1 rows
  * of the expert-parallel dispatch); larger batches are walked in passes of pairs / topk tokens */
 int kr_moe_set_prefill_pairs(kr_engine* e, int pairs);
+/* numerics of the prompt-pass expert GEMMs of kr_moe_prefill: 0 (default) = the CPU engine's arithmetic (INT16 activation digits, one f32 fma per
+ * 128-group: bit-identical to kr_moe_forward, moe.rs:184); 1 = tolerance form: f16 activations x weights de-quantized in registers, f32 accumulation
+ * over the whole k range -- the dataflow of the reference's GPU prompt pass (gpu_prefill.py:64-239, Marlin).  Native GGUF layers stay exact. */
+int kr_moe_set_gemm_mode(kr_engine* e, int fast);
 /* expert-parallel combine: out[t] = sum_s w[t][s] * eo_rows[pair_row[t][s]] in routing order (moe.rs:661-667); pair_row -1 = skip */
 int kr_combine_rows(kr_engine* e, const float* eo_rows, const int32_t* pair_row, const float* weights, void* out, int M, int topk,
                     int out_dtype, void* stream);
@@ -236,6 +240,7 @@ int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype);
  * summation order: logits within ~1e-4 relative, tests state 5e-4).  Call before the first step (a captured graph is rebuilt). */
 #define KR_ATTN_EXACT 0
 #define KR_ATTN_FAST 1
+#define KR_GEMM_FAST 2   /* or-ed into the mode: every GEMM of kr_decode_prefill (projections, shared expert, routed experts, lm_head of the scoring pass) in the tolerance form of kr_moe_set_gemm_mode; decode steps are unaffected */
 int kr_decode_set_attention_mode(kr_decode_store* s, int mode);                                                                        /* decode.rs:2471 */
 /* Whole-model prompt pass.  Replaces the reference's GPU prefill (python/krasis/model.py forward_prefill_layer_grouped / server_prefill,
  * layer.py:242-461, attention.py:496-687, linear_attention.py:695-845 -- third-party kernels) AND the GPU->CPU state hand-off

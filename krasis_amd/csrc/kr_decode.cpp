@@ -714,8 +714,8 @@ extern "C" int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype) {
 // summation order; logits within ~1e-4 relative.  Router ids, every matvec and the short-cache kernels are unaffected.
 extern "C" int kr_decode_set_attention_mode(kr_decode_store* s, int mode) {
     if (int rc = chk_store(s)) return rc;
-    if (mode != 0 && mode != 1) return kr_fail(KR_ERR_VALUE, "attention mode %d unknown (0 = exact order, 1 = fast split-KV)", mode);
-    s->attn_fast = mode; s->graph_ok = false;
+    if (mode < 0 || mode > 3) return kr_fail(KR_ERR_VALUE, "numerics mode %d unknown (bit 0 = KR_ATTN_FAST, bit 1 = KR_GEMM_FAST)", mode);
+    s->attn_fast = mode & 1; s->gemm_fast = (mode >> 1) & 1; s->graph_ok = false;
     return KR_OK;
 }
 

@@ -29,33 +29,51 @@ struct Scratch {   // carved from one allocation per arena (grown on demand)
     float* lac;
     float *res, *hid, *normed, *pa, *pb, *pc, *q, *k, *v, *z, *gexp, *beta, *recur, *attn, *gate, *moe, *sh, *gv, *sgu, *logits;
     int8_t *xh, *xl, *yh, *yl; float *xs, *ys;
+    uint16_t *xf, *yf; float *xfm, *yfm;     // KR_GEMM_FAST: the same two activation slots as f16 rows + row multipliers (kr_prefill_h.hip)
     uint16_t* xb; int32_t* ids; float* w;
 };
+struct Act { const int8_t* h; const int8_t* l; const float* s; const uint16_t* f; const float* fm; };   // one GEMM input: INT16 digits or f16 rows
+Act X(const Scratch& B) { return Act{B.xh, B.xl, B.xs, B.xf, B.xfm}; }
+Act Y(const Scratch& B) { return Act{B.yh, B.yl, B.ys, B.yf, B.yfm}; }
 struct Chunk {      // one chunk of the prompt in flight: its arena, stream and running flags
     Scratch B; float* scores; const int* tok; int Cc, pos0, set; bool first, add_is_emb; hipStream_t st;
 };
 size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
 }  // namespace
 
-static int pf_gemm(kr_decode_store* s, int wid, const int8_t* xh, const int8_t* xl, const float* xs, int C, float* out, int ld, hipStream_t st) {
+static int pf_gemm(kr_decode_store* s, int wid, const Act& A, int C, float* out, int ld, hipStream_t st) {
     DWeight& W = *s->weights[wid];
+    if (s->gemm_fast) { kr_launch_pfh_gemm(W.ms.view(), A.f, A.fm, nullptr, 1, 0, 0, C, out, ld, st); return KR_OK; }
     if (!W.ms.wsum.p) return kr_fail(KR_ERR_STATE, "internal: nibble sums of weight %d were not prepared", wid);
-    kr_launch_pf_gemm(W.ms.view(), (const uint32_t*)W.ms.wsum.p, xh, xl, xs, nullptr, 1, 0, 0, C, out, ld, st);
+    kr_launch_pf_gemm(W.ms.view(), (const uint32_t*)W.ms.wsum.p, A.h, A.l, A.s, nullptr, 1, 0, 0, C, out, ld, st);
     return KR_OK;
 }
 // up to three projections of the same input in ONE launch (q | k | v, qkvz | ba, shared gate_up | shared gate); falls back to one launch each
 // when the weight widths or K differ
-static int pf_gemm_multi(kr_decode_store* s, const int* wids, float* const* outs, const int* lds, int n, const int8_t* xh, const int8_t* xl, const float* xs, int C, hipStream_t st) {
+static int pf_gemm_multi(kr_decode_store* s, const int* wids, float* const* outs, const int* lds, int n, const Act& A, int C, hipStream_t st) {
     KrMatDev mats[3]; const uint32_t* ws[3];
     bool same = n <= 3;
     for (int i = 0; i < n; i++) {
         DWeight& W = *s->weights[wids[i]];
-        if (!W.ms.wsum.p) return kr_fail(KR_ERR_STATE, "internal: nibble sums of weight %d were not prepared", wids[i]);
+        if (!s->gemm_fast && !W.ms.wsum.p) return kr_fail(KR_ERR_STATE, "internal: nibble sums of weight %d were not prepared", wids[i]);
         if (i < 3) { mats[i] = W.ms.view(); ws[i] = (const uint32_t*)W.ms.wsum.p; same = same && mats[i].bits == mats[0].bits && mats[i].ng == mats[0].ng; }
     }
-    if (same && n > 1) { kr_launch_pf_gemm_multi(mats, ws, outs, lds, n, xh, xl, xs, C, st); return KR_OK; }
-    for (int i = 0; i < n; i++) if (int rc = pf_gemm(s, wids[i], xh, xl, xs, C, outs[i], lds[i], st)) return rc;
+    if (same && n > 1) {
+        if (s->gemm_fast) kr_launch_pfh_gemm_multi(mats, outs, lds, n, A.f, A.fm, C, st);
+        else kr_launch_pf_gemm_multi(mats, ws, outs, lds, n, A.h, A.l, A.s, C, st);
+        return KR_OK;
+    }
+    for (int i = 0; i < n; i++) if (int rc = pf_gemm(s, wids[i], A, C, outs[i], lds[i], st)) return rc;
     return KR_OK;
+}
+// the producers of a GEMM input: INT16 digits (exact) or f16 rows (KR_GEMM_FAST)
+static void pf_rows(kr_decode_store* s, const float* x, int C, int ld, int K, Scratch& B, bool slot_y, hipStream_t st) {
+    if (s->gemm_fast) kr_launch_pfh_rows_f32(x, C, ld, K, slot_y ? B.yf : B.xf, slot_y ? B.yfm : B.xfm, st);
+    else kr_launch_pfm_quant_f32(x, C, ld, K, slot_y ? B.yh : B.xh, slot_y ? B.yl : B.xl, slot_y ? B.ys : B.xs, st);
+}
+static void pf_act(kr_decode_store* s, const float* gu, int C, int n, int gu_ld, Scratch& B, hipStream_t st) {
+    if (s->gemm_fast) kr_launch_pfh_act(gu, C, n, gu_ld, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yf, B.yfm, st);
+    else kr_launch_pf_act(gu, C, n, gu_ld, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yh, B.yl, B.ys, st);
 }
 
 // everything a layer launches, for one chunk, on the chunk's stream
@@ -69,12 +87,14 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
     na.mode = cx.add_is_emb ? 1 : 0; na.add_in = B.hid; na.emb = (const float*)s->embedding.p; na.tokens = cx.tok; na.res = B.res;
     na.w = (const float*)s->norms[L.input_norm]->p; na.out = B.normed; na.xh = B.xh; na.xl = B.xl; na.xs = B.xs; na.H = H; na.first = cx.first ? 1 : 0;
     na.bias_one = s->norm_bias_one; na.eps = s->eps;
+    if (s->gemm_fast) { na.xh = nullptr; na.xl = nullptr; na.xs = nullptr; }      // tolerance GEMMs take f16 rows of the normalised value instead of the digits
     kr_launch_pfm_norm(na, Cc, st);
+    if (s->gemm_fast) kr_launch_pfh_rows_f32(B.normed, Cc, H, H, B.xf, B.xfm, st);
     cx.first = false; cx.add_is_emb = false;
     if (L.attn == ATTN_LA) {
         const int nq = s->weights[L.qkvz_wid]->rows, nb = s->weights[L.ba_wid]->rows, oc = s->weights[L.out_wid]->cols;
         { const int wids[2] = {L.qkvz_wid, L.ba_wid}; float* outs[2] = {B.pa, B.pb}; const int lds[2] = {nq, nb};
-          if (int rc = pf_gemm_multi(s, wids, outs, lds, 2, B.xh, B.xl, B.xs, Cc, st)) return rc; }
+          if (int rc = pf_gemm_multi(s, wids, outs, lds, 2, X(B), Cc, st)) return rc; }
         KrPfmLaArgs a{};
         a.qkvz = B.pa; a.ld_qkvz = nq; a.ba = B.pb; a.ld_ba = nb; a.conv_state = (float*)L.conv_state.p; a.conv_w = (const float*)L.conv_w.p;
         a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale; a.q = B.q; a.k = B.k; a.v = B.v; a.z = B.z;
@@ -83,13 +103,13 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         if (kr_launch_pfm_la(a, (float*)L.recur_state.p, B.recur, (const float*)L.la_norm_w.p, B.attn, Cc, s->eps, st))
             return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
         if (oc != L.nv * L.dv) return kr_fail(KR_ERR_VALUE, "out_proj cols %d != nv*dv", oc);
-        kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
-        if (int rc = pf_gemm(s, L.out_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+        pf_rows(s, B.attn, Cc, oc, oc, B, true, st);
+        if (int rc = pf_gemm(s, L.out_wid, Y(B), Cc, B.hid, H, st)) return rc;
     } else if (L.attn == ATTN_GQA) {
         if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
         const int nq = s->weights[L.q_wid]->rows, nk_ = s->weights[L.k_wid]->rows, nv_ = s->weights[L.v_wid]->rows, oc = s->weights[L.o_wid]->cols;
         { const int wids[3] = {L.q_wid, L.k_wid, L.v_wid}; float* outs[3] = {B.pa, B.pb, B.pc}; const int lds[3] = {nq, nk_, nv_};
-          if (int rc = pf_gemm_multi(s, wids, outs, lds, 3, B.xh, B.xl, B.xs, Cc, st)) return rc; }
+          if (int rc = pf_gemm_multi(s, wids, outs, lds, 3, X(B), Cc, st)) return rc; }
         KrPfmGqaArgs a{};
         a.q_in = B.pa; a.k_in = B.pb; a.v_in = B.pc; a.ld_q = nq; a.ld_k = nk_; a.ld_v = nv_;
         a.q_norm = L.q_norm_len ? (const float*)L.q_norm.p : nullptr; a.k_norm = L.k_norm_len ? (const float*)L.k_norm.p : nullptr;
@@ -110,8 +130,8 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
             if (kr_launch_pfm_gqa(a, Cc, scp, sc_ld, scp + (size_t)Cc * L.nh * sc_ld, st)) return kr_fail(KR_ERR_VALUE, "unsupported GQA geometry for the prompt pass");
         }
         if (oc != L.nh * L.hd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*hd", oc);
-        kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
-        if (int rc = pf_gemm(s, L.o_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+        pf_rows(s, B.attn, Cc, oc, oc, B, true, st);
+        if (int rc = pf_gemm(s, L.o_wid, Y(B), Cc, B.hid, H, st)) return rc;
     } else if (L.attn == ATTN_MLA) {
         // MLA (decode.rs:2993-3252): batched projections on the GEMM, then the three decode launches with a token dimension.  The
         // prep launch appends every token's latent / rope rows before the attention launch reads them, so token t of the chunk
@@ -119,16 +139,16 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no MLA cache for layer %zu)", li);
         if (L.mla_rope_seq < pos0 + Cc) return kr_fail(KR_ERR_VALUE, "prompt exceeds the MLA rope table (%d)", L.mla_rope_seq);
         const int nkv = s->weights[L.kva_wid]->rows, nq = L.nh * (L.nd + L.rd), oc = s->weights[L.o_wid]->cols;
-        if (int rc = pf_gemm(s, L.kva_wid, B.xh, B.xl, B.xs, Cc, B.pb, nkv, st)) return rc;
+        if (int rc = pf_gemm(s, L.kva_wid, X(B), Cc, B.pb, nkv, st)) return rc;
         if (L.mq_wid >= 0) {
-            if (int rc = pf_gemm(s, L.mq_wid, B.xh, B.xl, B.xs, Cc, B.pa, nq, st)) return rc;
+            if (int rc = pf_gemm(s, L.mq_wid, X(B), Cc, B.pa, nq, st)) return rc;
         } else {   // LoRA query path: q_a_proj -> sequential RMSNorm -> q_b_proj (decode.rs:3036-3079)
             const int qlr = s->weights[L.mqa_wid]->rows, qc = s->weights[L.mqb_wid]->cols;
             if (qc != qlr || qlr % 128) return kr_fail(KR_ERR_VALUE, "q_b_proj cols %d != q_a_proj rows %d (multiple of 128)", qc, qlr);
-            if (int rc = pf_gemm(s, L.mqa_wid, B.xh, B.xl, B.xs, Cc, B.pc, qlr, st)) return rc;
+            if (int rc = pf_gemm(s, L.mqa_wid, X(B), Cc, B.pc, qlr, st)) return rc;
             if (L.q_a_norm_len) kr_launch_rmsnorm_seq(B.pc, (const float*)L.q_a_norm.p, qlr, s->eps, st, Cc, qlr);
-            kr_launch_pfm_quant_f32(B.pc, Cc, qlr, qlr, B.yh, B.yl, B.ys, st);
-            if (int rc = pf_gemm(s, L.mqb_wid, B.yh, B.yl, B.ys, Cc, B.pa, nq, st)) return rc;
+            pf_rows(s, B.pc, Cc, qlr, qlr, B, true, st);
+            if (int rc = pf_gemm(s, L.mqb_wid, Y(B), Cc, B.pa, nq, st)) return rc;
         }
         KrMlaArgs a{};
         a.step = nullptr; a.pos0 = pos0; a.kv_out = B.pb; a.ld_kv = nkv; a.q_full = B.pa; a.ld_q = nq;
@@ -138,12 +158,13 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale; a.fast = s->attn_fast;
         kr_launch_mla(a, s->kv_max_seq, st, Cc);
         if (oc != L.nh * L.vhd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*v_head_dim", oc);
-        kr_launch_pfm_quant_f32(B.attn, Cc, oc, oc, B.yh, B.yl, B.ys, st);
-        if (int rc = pf_gemm(s, L.o_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+        pf_rows(s, B.attn, Cc, oc, oc, B, true, st);
+        if (int rc = pf_gemm(s, L.o_wid, Y(B), Cc, B.hid, H, st)) return rc;
     }
     // ---- post-attention norm: f32 hidden, digits (shared expert / dense MLP), bf16 copy (routed experts)
     na.mode = 0; na.add_in = B.hid; na.first = 0; na.w = (const float*)s->norms[L.post_norm]->p; na.out_bf16 = L.mlp == MLP_MOE ? B.xb : nullptr;
     kr_launch_pfm_norm(na, Cc, st);
+    if (s->gemm_fast && (L.mlp == MLP_DENSE || (L.mlp == MLP_MOE && L.sgu_wid >= 0))) kr_launch_pfh_rows_f32(B.normed, Cc, H, H, B.xf, B.xfm, st);
     if (L.mlp == MLP_MOE) {
         Layer& EL = e->layers[L.moe_layer];
         if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
@@ -157,15 +178,15 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         // expert parallelism (kr_ep_init on the engine): this rank's chunk exchanges its (token, slot) rows with the owners over RCCL; every rank
         // must run the same number of chunks and layers (equal prompt lengths).  One chunk in flight: the exchange buffers are per engine.
         if (e->ep) { if (int rc = kr_moe_prefill_ep(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, st ? (void*)st : (void*)1)) return rc; }
-        else if (int rc = kr_moe_prefill_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set, st)) return rc;
+        else if (int rc = kr_moe_prefill_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set | (s->gemm_fast ? KR_PF_SET_FAST : 0), st)) return rc;
         const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
         if (has_shared) {   // decode-store numerics: f32 input digits, fast_silu_mul + f32::round digits (decode.rs:3356-3378)
             const int si2 = s->weights[L.sgu_wid]->rows, SI = si2 / 2;
             if (SI % 128) return kr_fail(KR_ERR_VALUE, "shared expert intermediate %d not a multiple of 128", SI);
             { const int wids[2] = {L.sgu_wid, L.sg_wid}; float* outs[2] = {B.sgu, B.gv}; const int lds[2] = {si2, 1};       // gate_up (| the 1-column gate)
-              if (int rc = pf_gemm_multi(s, wids, outs, lds, has_gate ? 2 : 1, B.xh, B.xl, B.xs, Cc, st)) return rc; }
-            kr_launch_pf_act(B.sgu, Cc, SI, si2, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yh, B.yl, B.ys, st);
-            if (int rc = pf_gemm(s, L.sd_wid, B.yh, B.yl, B.ys, Cc, B.sh, H, st)) return rc;
+              if (int rc = pf_gemm_multi(s, wids, outs, lds, has_gate ? 2 : 1, X(B), Cc, st)) return rc; }
+            pf_act(s, B.sgu, Cc, SI, si2, B, st);
+            if (int rc = pf_gemm(s, L.sd_wid, Y(B), Cc, B.sh, H, st)) return rc;
         }
         kr_launch_pfm_moe_epilogue(B.moe, has_shared ? B.sh : nullptr, has_gate ? B.gv : nullptr, 1, s->rsf, B.hid, Cc, H, st);
     } else if (L.mlp == MLP_DENSE) {
@@ -176,12 +197,12 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
             DWeight& Wg = *s->weights[L.gate_wid]; DWeight& Wu = *s->weights[L.up_wid];
             if (int rc = kr_ensure_wsum(e, Wg.ms, st)) return rc;
             if (int rc = kr_ensure_wsum(e, Wu.ms, st)) return rc;
-            kr_launch_pf_gemm(Wg.ms.view(), (const uint32_t*)Wg.ms.wsum.p, B.xh, B.xl, B.xs, nullptr, 1, 0, 0, Cc, B.sgu, 2 * K, st);
-            kr_launch_pf_gemm(Wu.ms.view(), (const uint32_t*)Wu.ms.wsum.p, B.xh, B.xl, B.xs, nullptr, 1, 0, 0, Cc, B.sgu + K, 2 * K, st);
+            if (int rc = pf_gemm(s, L.gate_wid, X(B), Cc, B.sgu, 2 * K, st)) return rc;
+            if (int rc = pf_gemm(s, L.up_wid, X(B), Cc, B.sgu + K, 2 * K, st)) return rc;
             (void)ng; (void)nu;
         }
-        kr_launch_pf_act(B.sgu, Cc, K, 2 * K, KR_ACT_SILU_MUL, 0.0f, 0.0f, B.yh, B.yl, B.ys, st);
-        if (int rc = pf_gemm(s, L.down_wid, B.yh, B.yl, B.ys, Cc, B.hid, H, st)) return rc;
+        pf_act(s, B.sgu, Cc, K, 2 * K, B, st);
+        if (int rc = pf_gemm(s, L.down_wid, Y(B), Cc, B.hid, H, st)) return rc;
     } else {
         KR_HIP(hipMemcpyAsync(B.hid, B.normed, (size_t)Cc * H * 4, hipMemcpyDeviceToDevice, st));   // no MLP: hidden stays the normalised value
     }
@@ -207,8 +228,10 @@ static int run_final_all(kr_decode_store* s, Chunk& cx, float* vlogits, int firs
     na.mode = cx.add_is_emb ? 1 : 0; na.add_in = B.hid; na.emb = (const float*)s->embedding.p; na.tokens = cx.tok; na.res = B.res;
     na.w = (const float*)s->norms[s->final_norm]->p; na.out = B.normed; na.xh = B.xh; na.xl = B.xl; na.xs = B.xs; na.H = H; na.first = cx.first ? 1 : 0;
     na.bias_one = s->norm_bias_one; na.eps = s->eps;
+    if (s->gemm_fast) { na.xh = nullptr; na.xl = nullptr; na.xs = nullptr; }
     kr_launch_pfm_norm(na, cx.Cc, cx.st);
-    if (int rc = pf_gemm(s, s->lm_head, B.xh, B.xl, B.xs, cx.Cc, vlogits, (int)V, cx.st)) return rc;
+    if (s->gemm_fast) kr_launch_pfh_rows_f32(B.normed, cx.Cc, H, H, B.xf, B.xfm, cx.st);
+    if (int rc = pf_gemm(s, s->lm_head, X(B), cx.Cc, vlogits, (int)V, cx.st)) return rc;
     const int scored = std::min(cx.Cc, n_tokens - 1 - first_tok);      // the last prompt token has no label
     kr_launch_pfm_nll(vlogits, V, cx.tok + 1, (float*)s->pf_nll.p + first_tok, scored, (int)V, cx.st);
     if (last) {
@@ -288,7 +311,8 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
                  o_rec = take(C * vd * 4), o_att = take(C * ad * 4), o_gate = take(C * zd * 4), o_moe = take(C * H * 4), o_sh = take(C * H * 4), o_gv = take(C * 4),
                  o_sgu = take(C * std::max(sid, (size_t)64) * 4), o_xh = take(C * H), o_xl = take(C * H), o_xs = take(C * (H / 128) * 4), o_yh = take(C * kmax),
                  o_yl = take(C * kmax), o_ys = take(C * (kmax / 128 + 1) * 4), o_xb = take(C * H * 2), o_ids = take(C * 32 * 4), o_w = take(C * 32 * 4),
-                 o_lg = take(C * (size_t)std::max(e->r_ne, 64) * 4), o_lac = take(lac_floats * 4);
+                 o_lg = take(C * (size_t)std::max(e->r_ne, 64) * 4), o_lac = take(lac_floats * 4),
+                 o_xf = take(C * H * 2), o_xfm = take(C * 4), o_yf = take(C * kmax * 2), o_yfm = take(C * 4);
     const size_t sc_ld_max = (size_t)((start_pos + n_tokens + 63) & ~63), sc_bytes = al(C * sc_rows * (sc_ld_max + 1) * 4);
     if (s->pf_scratch.ensure(total * n_arenas) || s->pf_tokens.ensure((size_t)n_tokens * 4) || (sc_rows && s->pf_scores.ensure(sc_bytes * n_arenas)))
         return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch (%zu MiB) failed", (total * n_arenas + sc_bytes * n_arenas) >> 20);
@@ -306,6 +330,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
         B.xl = (int8_t*)(base + o_xl); B.xs = (float*)(base + o_xs); B.yh = (int8_t*)(base + o_yh); B.yl = (int8_t*)(base + o_yl); B.ys = (float*)(base + o_ys);
         B.xb = (uint16_t*)(base + o_xb); B.ids = (int32_t*)(base + o_ids); B.w = (float*)(base + o_w); B.logits = (float*)(base + o_lg);
         B.lac = lac_floats ? (float*)(base + o_lac) : nullptr;
+        B.xf = (uint16_t*)(base + o_xf); B.xfm = (float*)(base + o_xfm); B.yf = (uint16_t*)(base + o_yf); B.yfm = (float*)(base + o_yfm);
         return B;
     };
 

@@ -906,6 +906,57 @@ static int moe_prefill_gguf(kr_engine* e, Layer& L, int layer, const void* x_bf1
     return KR_OK;
 }
 
+// kr_moe_prefill in the tolerance form (kr_moe_set_gemm_mode(e, 1)): same launches, the activations travel as f16 rows and the GEMMs run on the
+// f16 matrix cores with f32 accumulation over the whole k range (kr_prefill_h.hip).  Sort, combine, routing weights and skip rules are the exact path's.
+static int moe_prefill_fast(kr_engine* e, Layer& L, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
+                            int out_dtype, int routed_only, int set, hipStream_t st) {
+    kr_engine::PfSet& P = e->pf[set % KR_PF_MAX_DEPTH];
+    const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
+    const bool use_shared = L.shared_present && !routed_only;
+    const int SI = L.shared_inter;
+    const int pairs = e->pf_pairs > 0 ? e->pf_pairs : KR_PF_PAIRS;
+    const int CHmax = pairs / topk > 64 ? pairs / topk : 64;
+    const int CH = M < CHmax ? M : CHmax;
+    const size_t np = (size_t)CH * topk;
+    const int max_tiles = (int)(np / 64) + E + 1;
+    const size_t n_i32 = 3 * (size_t)E + 3 * (size_t)max_tiles + 4 + 2 * np;
+    if (P.i32.ensure(n_i32 * 4) || P.xf.ensure((size_t)CH * H * 2) || P.xfm.ensure((size_t)CH * 4) || P.gu.ensure(np * 2 * I * 4) || P.hf.ensure(np * I * 2) ||
+        P.hfm.ensure(np * 4) || P.eo.ensure(np * H * 4))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
+    if (use_shared && (P.sgu.ensure((size_t)CH * 2 * SI * 4) || P.shf.ensure((size_t)CH * SI * 2) || P.shfm.ensure((size_t)CH * 4) || P.seo.ensure((size_t)CH * H * 4)))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
+    int* ib = (int*)P.i32.p;
+    KrPfSort so{};
+    so.counts = ib; so.offsets = ib + E; so.cursor = ib + 2 * E; ib += 3 * E;
+    so.tile_expert = ib; so.tile_row0 = ib + max_tiles; so.tile_rows = ib + 2 * max_tiles; ib += 3 * max_tiles;
+    so.n_tiles = ib; ib += 4; so.row_pair = ib; so.pair_row = ib + np;
+    const int act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
+    const size_t ob = out_dtype == KR_OUT_BF16 ? 2 : 4;
+    for (int m0 = 0; m0 < M; m0 += CH) {
+        const int mc = M - m0 < CH ? M - m0 : CH;
+        const uint16_t* xc = (const uint16_t*)x_bf16 + (size_t)m0 * H;
+        const int32_t* idc = ids + (size_t)m0 * topk; const float* wc = wts + (size_t)m0 * topk;
+        const int tiles_bound = (mc * topk) / 64 + E + 1;
+        const int bm = kr_pfh_expert_bm((long)mc * topk, E, L.w13.view(), L.w2.view());
+        int run = (int)(((long)mc * topk / E + bm - 1) / bm);       // row tiles of an average expert: they share an XCD (one L2 fill of its weights)
+        run = run < 1 ? 1 : (run > 4 ? 4 : run);
+        kr_launch_pf_sort(idc, mc, topk, E, so, st, bm);
+        kr_launch_pfh_rows_bf16(xc, mc, H, H, (uint16_t*)P.xf.p, (float*)P.xfm.p, st);
+        kr_launch_pfh_gemm(L.w13.view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, &so, topk, 1, tiles_bound, 0, (float*)P.gu.p, 2 * I, st, 0, 0, run, bm);
+        kr_launch_pfh_act((const float*)P.gu.p, mc * topk, I, 2 * I, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (uint16_t*)P.hf.p, (float*)P.hfm.p, st);
+        kr_launch_pfh_gemm(L.w2.view(), (const uint16_t*)P.hf.p, (const float*)P.hfm.p, &so, topk, 0, tiles_bound, 0, (float*)P.eo.p, H, st, 0, 0, run, bm);
+        if (use_shared) {
+            kr_launch_pfh_gemm(L.sw13.view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, nullptr, topk, 0, 0, mc, (float*)P.sgu.p, 2 * SI, st);
+            kr_launch_pfh_act((const float*)P.sgu.p, mc, SI, 2 * SI, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (uint16_t*)P.shf.p, (float*)P.shfm.p, st);
+            kr_launch_pfh_gemm(L.sw2.view(), (const uint16_t*)P.shf.p, (const float*)P.shfm.p, nullptr, topk, 0, 0, mc, (float*)P.seo.p, H, st);
+        }
+        kr_launch_pf_combine((const float*)P.eo.p, so.pair_row, wc, mc, topk, H, use_shared ? (const float*)P.seo.p : nullptr, e->cfg.routed_scaling_factor,
+                             (char*)out + (size_t)m0 * H * ob, out_dtype == KR_OUT_BF16, st);
+    }
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
 int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
                        int out_dtype, int routed_only, int set, hipStream_t st) {
     if (int rc = check_layer(e, layer)) return rc;
@@ -918,8 +969,12 @@ int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_
         return kr_fail(KR_ERR_VALUE, "kr_moe_prefill expects device pointers (hidden/topk tensors live in HBM during prefill)");
     std::lock_guard<std::mutex> lk(e->mu);
     KR_HIP(hipSetDevice(e->device));
-    if (L.gguf) return moe_prefill_gguf(e, L, layer, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, set, st);
+    const bool fast = e->gemm_fast || (set & KR_PF_SET_FAST);
+    set &= 0xFF;
+    if (L.gguf) return moe_prefill_gguf(e, L, layer, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, set, st);      // native GGUF blocks: exact form only
     if (e->cfg.hidden_size % 128 || L.inter % 128) return kr_fail(KR_ERR_VALUE, "prefill path needs dims divisible by 128");
+    if (fast && (!L.shared_present || routed_only || L.shared_inter % 128 == 0))
+        return moe_prefill_fast(e, L, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, set, st);
     kr_engine::PfSet& P = e->pf[set % KR_PF_MAX_DEPTH];
     const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
     const bool use_shared = L.shared_present && !routed_only;
@@ -1030,6 +1085,16 @@ extern "C" int kr_moe_set_prefill_pairs(kr_engine* e, int pairs) {
     if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
     if (pairs < 0) return kr_fail(KR_ERR_VALUE, "pairs must be >= 0, got %d", pairs);
     e->pf_pairs = pairs;
+    return KR_OK;
+}
+
+// numerics of the prompt-pass expert GEMMs (kr_moe_prefill, kr_decode_prefill): 0 = the CPU engine's arithmetic, bit-identical to kr_moe_forward
+// (default); 1 = tolerance form (f16 activations, f32 accumulation over the whole k range -- the dataflow of the reference's GPU prompt pass)
+extern "C" int kr_moe_set_gemm_mode(kr_engine* e, int fast) {
+    if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
+    if (fast != 0 && fast != 1) return kr_fail(KR_ERR_VALUE, "gemm mode %d unknown (0 = exact, 1 = fast)", fast);
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->gemm_fast = fast;
     return KR_OK;
 }
 

@@ -85,7 +85,8 @@ struct kr_engine {
     DevBuf r_logits, r_ids, r_w, r_x;
     // prefill scratch (kr_moe_prefill)
     int pf_pairs = 0;          // kr_moe_set_prefill_pairs
-    struct PfSet { DevBuf i32, xh, xl, xs, xm, gu, hh, hl, hs, hm, eo, sgu, shh, shl, shs, shm, seo; } pf[KR_PF_MAX_DEPTH];   // one set per chunk in flight of the prompt pass
+    int gemm_fast = 0;         // kr_moe_set_gemm_mode: prompt-pass expert GEMMs in the tolerance form (kr_prefill_h.hip)
+    struct PfSet { DevBuf i32, xh, xl, xs, xm, gu, hh, hl, hs, hm, eo, sgu, shh, shl, shs, shm, seo, xf, xfm, hf, hfm, shf, shfm; } pf[KR_PF_MAX_DEPTH];   // one set per chunk in flight of the prompt pass
     // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
     bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};
     std::mutex mu;
@@ -103,6 +104,7 @@ int download_mat(kr_engine* e, MatSet& ms, int idx, void* w, uint16_t* sc);
 // kr_moe_prefill with an explicit scratch set (0/1) and stream; all pointers device.  out f32 or bf16 per out_dtype.
 int kr_ensure_gate_row(kr_engine* e, int layer);   // kr_engine.cpp: uploads Layer::gate_row on first use (synchronous copy: call before enqueueing the pass)
 int kr_moe_prefill_rows(kr_engine* e, int layer, const void* rows_bf16, const int32_t* lid, void* out, int n, int out_bf16, int set, hipStream_t st);
+#define KR_PF_SET_FAST 0x100   // or-ed into `set`: this call takes the tolerance GEMMs whatever kr_moe_set_gemm_mode says (the decode store's KR_GEMM_FAST)
 int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
                        int out_dtype, int routed_only, int set, hipStream_t st);
 

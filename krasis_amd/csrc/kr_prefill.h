@@ -11,7 +11,7 @@ struct KrPfSort {
     int* row_pair;                                  // [n_pairs]  GEMM row -> (token*topk + slot)
     int* pair_row;                                  // [n_pairs]  inverse (-1 for skipped ids)
 };
-void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, hipStream_t st);
+void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, hipStream_t st, int bm = 64 /* rows per tile of the tile table */);
 void kr_launch_pf_quant_x(const uint16_t* x, int M, int K, int8_t* xh, int8_t* xl, float* xs, hipStream_t st);
 void kr_launch_pf_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, int8_t* hh, int8_t* hl, float* hs, hipStream_t st);
 void kr_launch_pf_wsum(const KrMatDev& m, int n_experts, uint32_t* wsum, hipStream_t st);
@@ -30,3 +30,14 @@ void kr_launch_ep_dest(const int32_t* ids, int n, int E_total, int per, int worl
 void kr_launch_ep_gather(const uint16_t* x, const int* row_pair, const int32_t* lid, int topk, int H, const int* n_rows, int max_rows, uint16_t* rows, int32_t* row_lid,
                          hipStream_t st);
 void kr_launch_ep_rows_bf16(const float* in, uint16_t* out, size_t n, hipStream_t st);
+
+// FAST (tolerance) form, kr_prefill_h.hip: f16 rows with a power-of-two row multiplier x weights de-quantized in registers, f32 accumulation
+void kr_launch_pfh_rows_f32(const float* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st);
+void kr_launch_pfh_rows_bf16(const uint16_t* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st);
+void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, uint16_t* out, float* mul, hipStream_t st);
+// rows per tile the tolerance GEMMs of an expert layer want from kr_launch_pf_sort: 128 (the one-wave-per-SIMD form) when the average expert has
+// enough rows and both matrices are INT4, else 64
+int kr_pfh_expert_bm(long pairs, int E, const KrMatDev& w13, const KrMatDev& w2);
+void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
+                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows = 0, int out_bf16 = 0, int run = 1, int bm = 64);
+void kr_launch_pfh_gemm_multi(const KrMatDev* mats, float* const* outs, const int* out_lds, int n, const uint16_t* a_h, const float* a_mul, int M, hipStream_t st);

@@ -35,21 +35,21 @@ __global__ void kr_pf_count_kernel(const int32_t* __restrict__ ids, int n_pairs,
 // one block: exclusive scan of counts -> row offsets; tile table (expert, first row, rows) for every 64-row tile
 __global__ void __launch_bounds__(1024) kr_pf_scan_kernel(const int* __restrict__ counts, int E, int* __restrict__ offsets, int* __restrict__ cursor,
                                                          int* __restrict__ tile_expert, int* __restrict__ tile_row0, int* __restrict__ tile_rows,
-                                                         int* __restrict__ n_tiles_out) {
+                                                         int* __restrict__ n_tiles_out, int bm) {
     __shared__ int s_off[1025], s_tile[1025];
     const int t = threadIdx.x;
     if (t == 0) {
         int o = 0, tl = 0;
-        for (int e = 0; e < E; e++) { s_off[e] = o; s_tile[e] = tl; o += counts[e]; tl += (counts[e] + PF_BM - 1) / PF_BM; }
+        for (int e = 0; e < E; e++) { s_off[e] = o; s_tile[e] = tl; o += counts[e]; tl += (counts[e] + bm - 1) / bm; }
         s_off[E] = o; s_tile[E] = tl; n_tiles_out[0] = tl; n_tiles_out[1] = o;   // [1]: rows in total (valid pairs)
     }
     __syncthreads();
     for (int e = t; e < E; e += 1024) {
         offsets[e] = s_off[e]; cursor[e] = 0;
         const int c = counts[e];
-        for (int i = 0; i * PF_BM < c; i++) {
+        for (int i = 0; i * bm < c; i++) {
             const int ti = s_tile[e] + i;
-            tile_expert[ti] = e; tile_row0[ti] = s_off[e] + i * PF_BM; tile_rows[ti] = (c - i * PF_BM) < PF_BM ? (c - i * PF_BM) : PF_BM;
+            tile_expert[ti] = e; tile_row0[ti] = s_off[e] + i * bm; tile_rows[ti] = (c - i * bm) < bm ? (c - i * bm) : bm;
         }
     }
 }
@@ -62,14 +62,14 @@ __global__ void __launch_bounds__(1024) kr_pf_scan_kernel(const int* __restrict_
 #define KR_PF_SORT1_MAX 32768
 __global__ void __launch_bounds__(1024) kr_pf_sort1_kernel(const int32_t* __restrict__ ids, int n_pairs, int E, int* __restrict__ counts, int* __restrict__ offsets,
                                                           int* __restrict__ tile_expert, int* __restrict__ tile_row0, int* __restrict__ tile_rows,
-                                                          int* __restrict__ n_tiles_out, int* __restrict__ row_pair, int* __restrict__ pair_row) {
+                                                          int* __restrict__ n_tiles_out, int* __restrict__ row_pair, int* __restrict__ pair_row, int bm) {
     __shared__ int s_cnt[1024], s_off[1024], s_til[1024], s_cur[1024];
     const int t = threadIdx.x;
     s_cnt[t] = 0; s_cur[t] = 0;
     __syncthreads();
     for (int i = t; i < n_pairs; i += 1024) { const int e = ids[i]; if (e >= 0 && e < E) atomicAdd(&s_cnt[e], 1); }
     __syncthreads();
-    const int c = t < E ? s_cnt[t] : 0, nt = (c + PF_BM - 1) / PF_BM;
+    const int c = t < E ? s_cnt[t] : 0, nt = (c + bm - 1) / bm;
     s_off[t] = c; s_til[t] = nt;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {             // inclusive Hillis-Steele scans of rows and tiles
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(1024) kr_pf_sort1_kernel(const int32_t* __rest
     s_off[t] = off;
     if (t < E) {
         counts[t] = c; offsets[t] = off;
-        for (int i = 0; i < nt; i++) { tile_expert[til + i] = t; tile_row0[til + i] = off + i * PF_BM; tile_rows[til + i] = (c - i * PF_BM) < PF_BM ? (c - i * PF_BM) : PF_BM; }
+        for (int i = 0; i < nt; i++) { tile_expert[til + i] = t; tile_row0[til + i] = off + i * bm; tile_rows[til + i] = (c - i * bm) < bm ? (c - i * bm) : bm; }
     }
     __syncthreads();
     for (int i = t; i < n_pairs; i += 1024) {
@@ -249,15 +249,15 @@ __global__ void __launch_bounds__(256) kr_pf_combine_kernel(const void* __restri
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, hipStream_t st) {
+void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, hipStream_t st, int bm) {
     const int n = M * topk;
     if (n <= KR_PF_SORT1_MAX && E <= 1024) {
-        hipLaunchKernelGGL(kr_pf_sort1_kernel, dim3(1), dim3(1024), 0, st, ids, n, E, s.counts, s.offsets, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles, s.row_pair, s.pair_row);
+        hipLaunchKernelGGL(kr_pf_sort1_kernel, dim3(1), dim3(1024), 0, st, ids, n, E, s.counts, s.offsets, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles, s.row_pair, s.pair_row, bm);
         return;
     }
     (void)hipMemsetAsync(s.counts, 0, (size_t)E * 4, st);
     hipLaunchKernelGGL(kr_pf_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E, s.counts);
-    hipLaunchKernelGGL(kr_pf_scan_kernel, dim3(1), dim3(1024), 0, st, s.counts, E, s.offsets, s.cursor, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles);
+    hipLaunchKernelGGL(kr_pf_scan_kernel, dim3(1), dim3(1024), 0, st, s.counts, E, s.offsets, s.cursor, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles, bm);
     hipLaunchKernelGGL(kr_pf_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E, s.offsets, s.cursor, s.row_pair, s.pair_row);
 }
 void kr_launch_pf_quant_x(const uint16_t* x, int M, int K, int8_t* xh, int8_t* xl, float* xs, hipStream_t st) {
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) kr_ep_scatter_kernel(const int32_t* __res
 void kr_launch_ep_sort(const int32_t* dest, int n, int W, KrPfSort s, hipStream_t st) {
     (void)hipMemsetAsync(s.counts, 0, (size_t)W * 4, st);
     hipLaunchKernelGGL(kr_ep_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dest, n, W, s.counts);
-    hipLaunchKernelGGL(kr_pf_scan_kernel, dim3(1), dim3(1024), 0, st, s.counts, W, s.offsets, s.cursor, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles);
+    hipLaunchKernelGGL(kr_pf_scan_kernel, dim3(1), dim3(1024), 0, st, s.counts, W, s.offsets, s.cursor, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles, PF_BM);
     hipLaunchKernelGGL(kr_ep_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dest, n, W, s.offsets, s.cursor, s.row_pair, s.pair_row);
 }
 

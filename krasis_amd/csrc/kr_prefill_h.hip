@@ -1,0 +1,686 @@
+// kr_prefill_h.hip -- FAST (tolerance) form of the prompt-pass GEMMs: f16 activations x INT4 / INT8 weights de-quantized in registers on
+// v_mfma_f32_32x32x16_f16, f32 accumulation over the WHOLE k range.
+//
+// Why a second GEMM.  The exact kernel (kr_prefill_gemm2.inc) reproduces the CPU engine's arithmetic: INT16 activation digits on the int8
+// matrix cores, i32 sums reset every 128-wide quantization group and one f32 fma per (output, group).  That per-group epilogue is 4 VALU
+// instructions per output per group -- 626 VALU per 32 MFMA in the main loop (ISA count), so the matrix pipe idles >= 60 % of the time whatever the
+// tiling.  The reference's own GPU prompt pass (gpu_prefill.py:64-239, moe_wna16_marlin_gemm) does not have that epilogue: it de-quantizes the
+// weight to the activation type, folds the group scale into the fragment and accumulates in f32.  This kernel is that dataflow, written for
+// gfx950: tolerance mode (KR_GEMM_FAST of kr_decode_set_attention_mode / kr_moe_set_gemm_mode), checked against the exact kernel.
+//
+// Numerics.  A row is scaled by a power of two so that its largest |value| is in [1, 2) and rounded to f16 (RNE, 11 significant bits, vs 15
+// bits per 128-group of the INT16 digits); the row multiplier comes back in the final store (exact).  An INT4 weight becomes the f16 value
+// (nibble - 8) * s * 16 EXACTLY (3 x 8 significant bits; s = the bf16 group scale): the nibble is placed at mantissa bits 6..9 of 1024.0
+// (0x6400 | n << 6 = 1024 + 64 n) and one packed fma (1024 + 64 n) * (s / 4) - 1536 * (s / 4) lands on (n - 8) * 16 s with a single rounding of
+// an 11-bit exact value; the constant 1536 * s / 4 is exact in f16 because 1536 has two significant bits (with the nibble at bits 0..3 the
+// constant 1032 * s would need 16 bits and its rounding would bias every weight of the group by up to a quarter of a quantization step).
+// An INT8 weight: (0x6400 | b ^ 0x80) - 1152 = b exactly, times s * 16 (one rounding to 11 bits).  Products are accumulated by the MFMA in f32.
+// The factor 16 keeps small scales out of the f16 subnormals; scales above 132 (INT4) would overflow -- two orders of magnitude beyond any weight
+// a checkpoint holds.
+//
+// Tile: 64 rows x (128 | 256) columns per workgroup of 4 waves, each wave 64 rows x (32 | 64) columns = 2 x (1 | 2) accumulators of 32 x 32;
+// one group PAIR (256 k) per LDS stage; every global load of stage st + 1 is issued before the MFMA loop of stage st (registers), as in the
+// exact kernel.  Per 16-k step a wave reads 2 x 2 A fragments (b128) and NC packed words of B for 4 * NC MFMA: 80 B per lane per 8 MFMA at NC = 2,
+// 62 % of the LDS bandwidth at full matrix rate (the exact kernel's 64 x 32 wave tile needs 112 %).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "kr_lds_optin.h"
+#include "kr_device.h"
+#include "kr_kernels.h"
+#include "kr_prefill.h"
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define PFH_BM 64
+#ifdef KR_TIMING   // tools/probes/gemm_h_timing.hip: shader-clock stamps of wave 0 of one mid-grid workgroup at stage 3; no-op in the product build
+__device__ unsigned long long kr_hstamps[16];
+#define PFH_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && st == 3) kr_hstamps[i] = clock64(); } while (0)
+#else
+#define PFH_STAMP(i) do { } while (0)
+#endif
+#define PFH_KS 256
+#define PFH_LDA (PFH_KS * 2 + 16)       // bytes per A row of a stage (f16)
+#define PFH_LDB4 136                    // bytes per B column, INT4: 8 lane records x 16 B + 8 pad
+#define PFH_LDB8 (PFH_KS + 16)          // bytes per B column, INT8
+
+// ------------------------------------------------------------------------------------------
+// A operand: rows -> f16 with a power-of-two row multiplier
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pfh_row_scale(float mx, float& scl, float& inv) {    // mx >= 0: scl = 2^-e, inv = 2^e, e = exponent of mx
+    uint32_t E = __float_as_uint(mx) >> 23;
+    if (E == 0 || E > 253) { scl = 1.0f; inv = 1.0f; return; }       // zero row (or not finite): unscaled
+    scl = __uint_as_float((254u - E) << 23); inv = __uint_as_float(E << 23);
+}
+__device__ __forceinline__ uint32_t pfh_pack_h2(float a, float b) {
+    const v2h h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float pfh_block_max(float mx, uint32_t* slot) {   // slot: LDS word zeroed before the call + barrier
+    mx = kr_red16_max_f32(mx);
+    if ((threadIdx.x & 15) == 0) atomicMax(slot, __float_as_uint(mx));        // non-negative floats order like their bit patterns
+    __syncthreads();
+    return __uint_as_float(*slot);
+}
+
+// SRC 0: f32 rows (ld floats apart), SRC 1: bf16 rows (ld elements apart).  grid (rows), 256 threads, K % 8 == 0
+template <int SRC>
+__global__ void __launch_bounds__(256) kr_pfh_rows_kernel(const void* __restrict__ x, int ld, int K, uint16_t* __restrict__ out, float* __restrict__ mul) {
+    __shared__ uint32_t smax;
+    const int t = blockIdx.x;
+    if (threadIdx.x == 0) smax = 0;
+    __syncthreads();
+    auto load8 = [&](int c, float (&v)[8]) {
+        if (SRC == 0) {
+            const float* p = reinterpret_cast<const float*>(x) + (size_t)t * ld + (size_t)c * 8;
+            const float4 p0 = *reinterpret_cast<const float4*>(p), p1 = *reinterpret_cast<const float4*>(p + 4);
+            v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+        } else {
+            const u32x4 r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(x) + (size_t)t * ld + (size_t)c * 8);
+            v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u); v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
+            v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xFFFF0000u); v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xFFFF0000u);
+        }
+    };
+    float mx = 0.0f;
+    for (int c = threadIdx.x; c < K / 8; c += 256) {
+        float v[8]; load8(c, v);
+#pragma unroll
+        for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v[i]));
+    }
+    mx = pfh_block_max(mx, &smax);
+    float scl, inv; pfh_row_scale(mx, scl, inv);
+    for (int c = threadIdx.x; c < K / 8; c += 256) {
+        float v[8]; load8(c, v);
+        u32x4 o;
+        o.x = pfh_pack_h2(v[0] * scl, v[1] * scl); o.y = pfh_pack_h2(v[2] * scl, v[3] * scl);
+        o.z = pfh_pack_h2(v[4] * scl, v[5] * scl); o.w = pfh_pack_h2(v[6] * scl, v[7] * scl);
+        *reinterpret_cast<u32x4*>(out + (size_t)t * K + (size_t)c * 8) = o;
+    }
+    if (threadIdx.x == 0) mul[t] = inv * 0.0625f;       // 2^e / 16: undoes the row scaling and the weight factor 16
+}
+
+// hidden rows from gate | up rows: h = silu(g) * u with the exact kernel's sigmoid (avx2.rs:2310) or the GPT-OSS activation (moe.rs:268-287),
+// then the same f16 row form.  grid (rows), 256 threads; the row is computed twice (max, then store) -- the inputs come from L2.
+template <int ACT>
+__global__ void __launch_bounds__(256) kr_pfh_act_kernel(const float* __restrict__ gu, int n, int gu_ld, float swiglu_limit, float alpha, uint16_t* __restrict__ out,
+                                                        float* __restrict__ mul) {
+    __shared__ uint32_t smax;
+    const int row = blockIdx.x;
+    const float* g = gu + (size_t)row * gu_ld;
+    if (threadIdx.x == 0) smax = 0;
+    __syncthreads();
+    auto act8 = [&](int c, float (&h)[8]) {
+        const float4 g0 = *reinterpret_cast<const float4*>(g + c * 8), g1 = *reinterpret_cast<const float4*>(g + c * 8 + 4);
+        const float4 u0 = *reinterpret_cast<const float4*>(g + n + c * 8), u1 = *reinterpret_cast<const float4*>(g + n + c * 8 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (ACT == KR_ACT_GPTOSS) {
+                float gate = gg[i], up = uu[i];
+                if (gate > swiglu_limit) gate = swiglu_limit;
+                if (up > swiglu_limit) up = swiglu_limit;
+                if (up < -swiglu_limit) up = -swiglu_limit;
+                h[i] = (up + 1.0f) * (gate * kr_sigmoid_poly5_scalar(gate * alpha));
+            } else h[i] = (gg[i] * kr_sigmoid_poly5(gg[i])) * uu[i];
+        }
+    };
+    float mx = 0.0f;
+    for (int c = threadIdx.x; c < n / 8; c += 256) {
+        float h[8]; act8(c, h);
+#pragma unroll
+        for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(h[i]));
+    }
+    mx = pfh_block_max(mx, &smax);
+    float scl, inv; pfh_row_scale(mx, scl, inv);
+    for (int c = threadIdx.x; c < n / 8; c += 256) {
+        float h[8]; act8(c, h);
+        u32x4 o;
+        o.x = pfh_pack_h2(h[0] * scl, h[1] * scl); o.y = pfh_pack_h2(h[2] * scl, h[3] * scl);
+        o.z = pfh_pack_h2(h[4] * scl, h[5] * scl); o.w = pfh_pack_h2(h[6] * scl, h[7] * scl);
+        *reinterpret_cast<u32x4*>(out + (size_t)row * n + (size_t)c * 8) = o;
+    }
+    if (threadIdx.x == 0) mul[row] = inv * 0.0625f;
+}
+
+// ------------------------------------------------------------------------------------------
+// the GEMM
+// ------------------------------------------------------------------------------------------
+struct KrPfGemmHArgs {
+    KrMatDev m;
+    const uint16_t* a; const float* a_mul;   // f16 rows [rows_or_tokens][K], row multipliers
+    const int* row_pair; int topk; int gather_tokens;
+    const int* tile_expert; const int* tile_row0; const int* tile_rows; const int* n_tiles;
+    float* out; int out_ld;
+    int single_expert; int total_rows; int scatter_rows; int out_bf16;
+    int run;                                 // consecutive row tiles given to one XCD (1: the exact kernel's mapping; > 1: the tiles of one expert share an L2)
+    int n_extra; KrMatDev mx[2]; float* outx[2]; int out_ldx[2];
+};
+
+// one packed INT4 word (nibbles k .. k + 7 of a column) -> 8 f16 in the order (0,4,1,5,2,6,3,7); sq = s / 4 (both halves), cq = -1536 * sq.
+// 12 VALU: and + (shift | or) for the two low pairs, shift + and-or for the two high pairs, 4 packed fma.  M0 / M1 / M2 / Kc are held in registers by the
+// caller (opaque to the compiler): VOP3 takes no literal on gfx9, with literals the compiler falls back to separate v_and / v_or (16 VALU).
+__device__ __forceinline__ v8h pfh_dq4(uint32_t w, v2h sq, v2h cq, uint32_t M0, uint32_t M1, uint32_t MH, uint32_t Kc) {
+    const uint32_t t0 = ((w & M0) << 6) | Kc;                  // v_and, v_lshl_or       (n0, n4) at mantissa bits 6..9
+    const uint32_t t1 = ((w & M1) << 2) | Kc;                  // v_and, v_lshl_or       (n1, n5)
+    const uint32_t t2 = ((w >> 2) & MH) | Kc;                  // v_lshrrev, v_and_or    (n2, n6)
+    const uint32_t t3 = ((w >> 6) & MH) | Kc;                  // v_lshrrev, v_and_or    (n3, n7)
+    const v2h r0 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, t0), sq, cq), r1 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, t1), sq, cq);
+    const v2h r2 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, t2), sq, cq), r3 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, t3), sq, cq);
+    return v8h{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
+}
+// 8 INT8 weights (two words, natural k order) -> 8 f16: (1024 + (b ^ 0x80)) - 1152 = b, times sb = s * 16
+__device__ __forceinline__ v8h pfh_dq8(uint32_t w0, uint32_t w1, v2h sb) {
+    const uint32_t x0 = w0 ^ 0x80808080u, x1 = w1 ^ 0x80808080u, Kc = 0x64646464u;
+    const v2h off = {(_Float16)-1152.0f, (_Float16)-1152.0f};
+    // v_perm: selector bytes 0-3 pick from the second operand, 4-7 from the first
+    const uint32_t t0 = __builtin_amdgcn_perm(Kc, x0, 0x04010400u), t1 = __builtin_amdgcn_perm(Kc, x0, 0x04030402u);
+    const uint32_t t2 = __builtin_amdgcn_perm(Kc, x1, 0x04010400u), t3 = __builtin_amdgcn_perm(Kc, x1, 0x04030402u);
+    const v2h r0 = (__builtin_bit_cast(v2h, t0) + off) * sb, r1 = (__builtin_bit_cast(v2h, t1) + off) * sb;
+    const v2h r2 = (__builtin_bit_cast(v2h, t2) + off) * sb, r3 = (__builtin_bit_cast(v2h, t3) + off) * sb;
+    return v8h{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
+}
+
+template <int NC, int BITS>
+__global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs a) {
+    constexpr int BN = 128 * NC, LDA = PFH_LDA, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4, NS = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                                               // [64][LDA]  f16; BITS == 4: k permuted (0,4,1,5,2,6,3,7) inside every 8
+    char* Bs = As + PFH_BM * LDA;                                  // [BN][LDB]  packed lane records, copied verbatim
+    float* rmul = reinterpret_cast<float*>(Bs + BN * LDB);         // [64]
+    int* row_src = reinterpret_cast<int*>(rmul + PFH_BM);          // [64]
+    int* row_dst = row_src + PFH_BM;                               // [64]
+
+    const int ncb0 = (a.m.N + BN - 1) / BN, ncb1 = a.n_extra > 0 ? (a.mx[0].N + BN - 1) / BN : 0, ncb2 = a.n_extra > 1 ? (a.mx[1].N + BN - 1) / BN : 0;
+    const int ncb = ncb0 + ncb1 + ncb2, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per = ncb * a.run, grp = slot / per, local = slot - grp * per;
+    const int mt = (grp * 8 + xcd) * a.run + local / ncb;
+    int cb = local % ncb;
+    int expert, row0, rows;
+    if (a.single_expert) { expert = 0; row0 = mt * PFH_BM; rows = a.total_rows - row0 < PFH_BM ? a.total_rows - row0 : PFH_BM; if (rows <= 0) return; }
+    else { if (mt >= a.n_tiles[0]) return; expert = a.tile_expert[mt]; row0 = a.tile_row0[mt]; rows = a.tile_rows[mt]; }
+    KrMatDev m = a.m; float* out_p = a.out; int out_ld = a.out_ld;
+    if (cb >= ncb0 + ncb1) { cb -= ncb0 + ncb1; m = a.mx[1]; out_p = a.outx[1]; out_ld = a.out_ldx[1]; }
+    else if (cb >= ncb0) { cb -= ncb0; m = a.mx[0]; out_p = a.outx[0]; out_ld = a.out_ldx[0]; }
+    const int n0 = cb * BN;
+    const bool two = rows > 32;                                     // tiles of a short chunk: skip the empty second 32-row block (uniform)
+    const int K = m.ng * 128;
+    const char* wq = reinterpret_cast<const char*>(m.q) + (size_t)expert * m.q_stride;
+    const uint32_t* wsc = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + (size_t)expert * m.s_stride);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < PFH_BM) {
+        int src = -1;
+        if (tid < rows) {
+            if (a.single_expert) src = row0 + tid;
+            else { const int pair = a.row_pair[row0 + tid]; src = a.gather_tokens ? pair / a.topk : row0 + tid; }
+        }
+        row_src[tid] = src;
+        row_dst[tid] = (a.scatter_rows && !a.single_expert && tid < rows) ? a.row_pair[row0 + tid] : row0 + tid;
+        rmul[tid] = src >= 0 ? a.a_mul[src] : 0.0f;
+    }
+    __syncthreads();
+
+    v16f acc[NS][NC];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[s][c][r] = 0.0f;
+    const int n31 = lane & 31, khalf = lane >> 5;
+    uint32_t M0 = 0x000F000Fu, M1 = 0x00F000F0u, MH = 0x03C003C0u, Kc = 0x64006400u;      // de-quantization masks, kept in registers (see pfh_dq4)
+    asm volatile("" : "+v"(M0), "+v"(M1), "+v"(MH), "+v"(Kc));
+    const int cbase = wave * (32 * NC);
+    int col[NC], ctile[NC], cin[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) { col[c] = n0 + cbase + c * 32 + n31; const int cc = col[c] < m.N ? col[c] : m.N - 1; ctile[c] = cc >> 3; cin[c] = cc & 7; }
+
+    constexpr int APT = 8;                         // 16-byte A chunks per thread per stage (4 threads per row, 128 B each)
+    constexpr int RPT = BN * 8 / 256;              // B lane records per thread (per group for INT8)
+    constexpr int NBW = BITS == 8 ? 2 * RPT : RPT;
+    const int ar = tid >> 2, aq = tid & 3;
+    const int nst = m.ngp;
+    u32x4 pa[APT], pbw[NBW];
+    uint32_t pspv[NC];
+    // Loads are never masked: a tile row past `rows` reads row 0 / token 0, a column tile past the last one re-reads the last tile, a thread whose
+    // 64 k lie past K re-reads the last valid 64 of the row -- all finite or irrelevant: rows and columns are independent in a GEMM, the stores are
+    // guarded and a group past ng gets scale 0.  One address per thread for A (its 8 chunks are contiguous: immediate offsets), a wave-uniform
+    // record base per B load (the 64 lanes of a wave copy one 1-KiB tile record row: scalar base + lane * 16).
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int last_tile = (m.N - 1) >> 3;
+    auto load_stage = [&](int st) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) pspv[c] = wsc[((size_t)ctile[c] * m.ngp + st) * 8 + cin[c]];
+        {
+            const int src = row_src[ar];
+            const int kvalid = K - st * PFH_KS;
+            const int k0 = aq * 64 < kvalid ? aq * 64 : kvalid - 64;
+            const u32x4* ap = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.a) + ((size_t)(src < 0 ? 0 : src) * K + (size_t)st * PFH_KS + k0) * 2);
+#pragma unroll
+            for (int j = 0; j < APT; j++) pa[j] = ap[j];
+        }
+        if (BITS == 8) {
+#pragma unroll
+            for (int gg = 0; gg < 2; gg++) {
+                int g = 2 * st + gg; g = g < m.ng ? g : m.ng - 1;
+#pragma unroll
+                for (int j = 0; j < RPT; j++) {
+                    int tile = (n0 >> 3) + wv + 4 * j; tile = tile < last_tile ? tile : last_tile;
+                    pbw[(BITS == 8 ? gg * RPT : 0) + j] = kr_ldg_nt(reinterpret_cast<const u32x4*>(wq + ((size_t)tile * m.ng + g) * 1024) + lane);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPT; j++) {
+                int tile = (n0 >> 3) + wv + 4 * j; tile = tile < last_tile ? tile : last_tile;
+                pbw[j] = kr_ldg_nt(reinterpret_cast<const u32x4*>(wq + ((size_t)tile * m.ngp + st) * 1024) + lane);
+            }
+        }
+    };
+    uint32_t spv[NC];
+    auto commit_stage = [&]() {
+#pragma unroll
+        for (int c = 0; c < NC; c++) spv[c] = pspv[c];
+#pragma unroll
+        for (int j = 0; j < APT; j++) {
+            u32x4 v = pa[j];
+            if (BITS == 4)      // (a0,a1 | a2,a3 | a4,a5 | a6,a7) -> (a0,a4 | a1,a5 | a2,a6 | a3,a7)
+                v = u32x4{__builtin_amdgcn_perm(v.z, v.x, 0x05040100u), __builtin_amdgcn_perm(v.z, v.x, 0x07060302u),
+                          __builtin_amdgcn_perm(v.w, v.y, 0x05040100u), __builtin_amdgcn_perm(v.w, v.y, 0x07060302u)};
+            *reinterpret_cast<u32x4*>(As + ar * LDA + aq * 128 + j * 16) = v;
+        }
+        if (BITS == 8) {
+#pragma unroll
+            for (int gg = 0; gg < 2; gg++)
+#pragma unroll
+                for (int j = 0; j < RPT; j++) {
+                    const int rec = tid + j * 256, t8 = rec >> 6, ln = rec & 63, c = ln >> 3, l8 = ln & 7;
+                    *reinterpret_cast<u32x4*>(Bs + (t8 * 8 + c) * LDB + gg * 128 + l8 * 16) = pbw[(BITS == 8 ? gg * RPT : 0) + j];
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPT; j++) {
+                const int rec = tid + j * 256, t8 = rec >> 6, ln = rec & 63, c = ln >> 3, l8 = ln & 7;
+                const u32x4 w = pbw[j];
+                const u32x2 h0 = {w.x, w.y}, h1 = {w.z, w.w};     // 8-byte stores: the padded column stride is 8-byte aligned only
+                *reinterpret_cast<u32x2*>(Bs + (t8 * 8 + c) * LDB + l8 * 16) = h0;
+                *reinterpret_cast<u32x2*>(Bs + (t8 * 8 + c) * LDB + l8 * 16 + 8) = h1;
+            }
+        }
+    };
+    // The MFMA loop of one stage for NSA active 32-row blocks (compile-time: the whole stage is ONE basic block), software-pipelined over its
+    // 8 k-steps of 16: while the 4 * NSA... MFMAs of step t run, the wave de-quantizes the B words of step t + 1 and the LDS reads of step t + 2 are
+    // issued (a wave issues in order: an LDS wait or a dependent MFMA in front of the VALU work would idle the matrix pipe -- SQ_WAIT_INST_ANY was
+    // 45 % and SQ_WAIT_ANY 23 % of the wave cycles of the unpipelined form).  Consecutive MFMAs go to different accumulators.
+    auto stage_mfma = [&](int st, auto nsa) {
+        constexpr int NSA = decltype(nsa)::value;
+        v2h sq[2][NC], cq[2][NC];
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float sc = __uint_as_float((hh ? (spv[c] >> 16) : (spv[c] & 0xFFFFu)) << 16);
+                if (2 * st + hh >= m.ng) sc = 0.0f;                      // the missing second group of an odd group count contributes 0
+                const _Float16 s1 = (_Float16)(BITS == 8 ? sc * 16.0f : sc * 0.25f);
+                sq[hh][c] = v2h{s1, s1};
+                const _Float16 c1 = (_Float16)(-1536.0f * (float)s1);
+                cq[hh][c] = v2h{c1, c1};
+            }
+        v8h af[2][NSA][2], bf[2][NC][2];
+        u32x4 br[2][NC];          // raw B words of a step (INT4 uses .x .y)
+        auto rd = [&](int t, int buf) {
+            const int hh = t >> 2, lp = 2 * (t & 3) + khalf;             // lane record of this lane half: k = 16 lp .. 16 lp + 16 of group hh
+#pragma unroll
+            for (int s2 = 0; s2 < NSA; s2++) {
+                af[buf][s2][0] = *reinterpret_cast<const v8h*>(As + (s2 * 32 + n31) * LDA + hh * 256 + lp * 32);
+                af[buf][s2][1] = *reinterpret_cast<const v8h*>(As + (s2 * 32 + n31) * LDA + hh * 256 + lp * 32 + 16);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (BITS == 8) br[buf][c] = *reinterpret_cast<const u32x4*>(Bs + (cbase + c * 32 + n31) * LDB + hh * 128 + lp * 16);
+                else { const u32x2 pk = *reinterpret_cast<const u32x2*>(Bs + (cbase + c * 32 + n31) * LDB + lp * 16 + hh * 8); br[buf][c].x = pk.x; br[buf][c].y = pk.y; }
+            }
+        };
+        auto dq = [&](int t, int buf) {
+            const int hh = t >> 2;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (BITS == 8) { bf[buf][c][0] = pfh_dq8(br[buf][c].x, br[buf][c].y, sq[hh][c]); bf[buf][c][1] = pfh_dq8(br[buf][c].z, br[buf][c].w, sq[hh][c]); }
+                else { bf[buf][c][0] = pfh_dq4(br[buf][c].x, sq[hh][c], cq[hh][c], M0, M1, MH, Kc); bf[buf][c][1] = pfh_dq4(br[buf][c].y, sq[hh][c], cq[hh][c], M0, M1, MH, Kc); }
+            }
+        };
+        rd(0, 0); rd(1, 1); dq(0, 0);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int cur = t & 1, nxt = cur ^ 1;
+            if (t + 1 < 8) dq(t + 1, nxt);
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int s2 = 0; s2 < NSA; s2++) acc[s2][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][s2][h], bf[cur][c][h], acc[s2][c], 0, 0, 0);
+            if (t + 2 < 8) rd(t + 2, cur);
+            // issue order of the step: one MFMA, then a share of the de-quantization VALU, ...; the LDS reads of step t + 2 last
+            constexpr int NM = 2 * NC * NSA, VPM = (BITS == 8 ? 30 : 24) * NC / NM + 1;
+#pragma unroll
+            for (int i = 0; i < NM; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);     // VPM VALU
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NSA + NC, 0);   // DS reads
+        }
+    };
+    load_stage(0);
+    for (int st = 0; st < nst; st++) {
+        PFH_STAMP(0);
+        commit_stage();
+        PFH_STAMP(1);
+        if (st + 1 < nst) load_stage(st + 1);
+        PFH_STAMP(2);
+        __syncthreads();
+        PFH_STAMP(3);
+        if (two) stage_mfma(st, std::integral_constant<int, 2>{}); else stage_mfma(st, std::integral_constant<int, 1>{});
+        PFH_STAMP(4);
+        __syncthreads();
+        PFH_STAMP(5);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+        if (col[c] < m.N) {
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+                if (s == 0 || two) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (row < rows) {
+                            const float v = acc[s][c][r] * rmul[row];
+                            const size_t o = (size_t)row_dst[row] * out_ld + col[c];
+                            if (a.out_bf16) reinterpret_cast<uint16_t*>(out_p)[o] = kr_f32_to_bf16(v);
+                            else out_p[o] = v;
+                        }
+                    }
+                }
+        }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// second form for large problems (INT4): 128 rows x 256 columns per workgroup, ONE wave per SIMD with the 128 accumulator registers of its
+// 128 x 64 tile in the AGPR half of the register file.  Why: a wave issues in order and a SIMD has ~8 issue slots of 4 cycles under one
+// 32-cycle MFMA (MI355X_MICROARCH.md: <= 5 fillers hidden per MFMA).  The 64 x 64 wave tile above needs 8.5 VALU + 1 LDS per MFMA (6 of them the
+// de-quantization: every B fragment feeds only two row blocks) -- PMC: 25 % matrix-pipe busy, VALU and MFMA time simply add up.  With four row
+// blocks per B fragment the de-quantization is 3 VALU per MFMA and the whole stream ~5 issues per MFMA.
+//   * one quantization group (128 k) per stage, two LDS stages (2 x 52 KiB): while stage st is multiplied, the registers holding stage st + 1
+//     are committed to the other buffer inside the same basic block, then stage st + 2 is requested from HBM; one barrier per stage.
+//   * per 16-k step: 8 b128 A fragments + 2 packed B words for 16 MFMA on 8 different accumulators; LDS reads of step t + 2 and the
+//     de-quantization of step t + 1 are interleaved with the MFMAs of step t (sched_group_barrier).
+// Row tiles hold 128 rows (kr_launch_pf_sort with bm = 128); tiles with fewer rows run the variant with 1..3 active row blocks.
+#define PH2_BM 128
+#define PH2_BN 256
+#define PH2_KS 128
+#define PH2_LDA (PH2_KS * 2 + 16)
+#define PH2_LDB 72
+#define PH2_STAGE (PH2_BM * PH2_LDA + PH2_BN * PH2_LDB)
+
+__global__ void __launch_bounds__(256, 1) kr_pfh2_gemm_kernel(const KrPfGemmHArgs a) {
+    constexpr int BN = PH2_BN, LDA = PH2_LDA, LDB = PH2_LDB, NC = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rmul = reinterpret_cast<float*>(smem + 2 * PH2_STAGE);      // [128]
+    int* row_src = reinterpret_cast<int*>(rmul + PH2_BM);              // [128]
+    int* row_dst = row_src + PH2_BM;                                   // [128]
+
+    const int ncb0 = (a.m.N + BN - 1) / BN, ncb1 = a.n_extra > 0 ? (a.mx[0].N + BN - 1) / BN : 0, ncb2 = a.n_extra > 1 ? (a.mx[1].N + BN - 1) / BN : 0;
+    const int ncb = ncb0 + ncb1 + ncb2, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per = ncb * a.run, grp = slot / per, local = slot - grp * per;
+    const int mt = (grp * 8 + xcd) * a.run + local / ncb;
+    int cb = local % ncb;
+    int expert, row0, rows;
+    if (a.single_expert) { expert = 0; row0 = mt * PH2_BM; rows = a.total_rows - row0 < PH2_BM ? a.total_rows - row0 : PH2_BM; if (rows <= 0) return; }
+    else { if (mt >= a.n_tiles[0]) return; expert = a.tile_expert[mt]; row0 = a.tile_row0[mt]; rows = a.tile_rows[mt]; }
+    KrMatDev m = a.m; float* out_p = a.out; int out_ld = a.out_ld;
+    if (cb >= ncb0 + ncb1) { cb -= ncb0 + ncb1; m = a.mx[1]; out_p = a.outx[1]; out_ld = a.out_ldx[1]; }
+    else if (cb >= ncb0) { cb -= ncb0; m = a.mx[0]; out_p = a.outx[0]; out_ld = a.out_ldx[0]; }
+    const int n0 = cb * BN;
+    const int nsb = (rows + 31) >> 5;                                   // active 32-row blocks, 1..4 (uniform)
+    const int K = m.ng * 128, nst = m.ng;
+    const char* wq = reinterpret_cast<const char*>(m.q) + (size_t)expert * m.q_stride;
+    const uint32_t* wsc = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + (size_t)expert * m.s_stride);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < PH2_BM) {
+        int src = -1;
+        if (tid < rows) {
+            if (a.single_expert) src = row0 + tid;
+            else { const int pair = a.row_pair[row0 + tid]; src = a.gather_tokens ? pair / a.topk : row0 + tid; }
+        }
+        row_src[tid] = src;
+        row_dst[tid] = (a.scatter_rows && !a.single_expert && tid < rows) ? a.row_pair[row0 + tid] : row0 + tid;
+        rmul[tid] = src >= 0 ? a.a_mul[src] : 0.0f;
+    }
+    __syncthreads();
+
+    v16f acc[4][NC];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[s][c][r] = 0.0f;
+    const int n31 = lane & 31, khalf = lane >> 5;
+    uint32_t MH = 0x03C003C0u, M0 = 0x000F000Fu, M1 = 0x00F000F0u, Kc = 0x64006400u;
+    asm volatile("" : "+v"(M0), "+v"(M1), "+v"(MH), "+v"(Kc));
+    const int cbase = wave * 64;
+    int col[NC], ctile[NC], cin[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) { col[c] = n0 + cbase + c * 32 + n31; const int cc = col[c] < m.N ? col[c] : m.N - 1; ctile[c] = cc >> 3; cin[c] = cc & 7; }
+
+    // loads (never masked: see the first form): A 2 threads per row x 128 B contiguous, B one 8-byte half record per lane of 8 wave-uniform tiles
+    const int ar = tid >> 1, aq = tid & 1;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int last_tile = (m.N - 1) >> 3;
+    const int asrc = row_src[ar] < 0 ? 0 : row_src[ar];
+    const char* abase = reinterpret_cast<const char*>(a.a) + ((size_t)asrc * K + aq * 64) * 2;
+    u32x4 pa[8]; u32x2 pb[8]; uint32_t pspv[NC], spv[NC];
+    auto load_stage = [&](int st) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) pspv[c] = wsc[((size_t)ctile[c] * m.ngp + (st >> 1)) * 8 + cin[c]];
+        const u32x4* ap = reinterpret_cast<const u32x4*>(abase + (size_t)st * (PH2_KS * 2));
+#pragma unroll
+        for (int j = 0; j < 8; j++) pa[j] = ap[j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int tile = (n0 >> 3) + wv + 4 * j; tile = tile < last_tile ? tile : last_tile;
+            pb[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wq + ((size_t)tile * m.ngp + (st >> 1)) * 1024 + (st & 1) * 8) + 2 * lane);
+        }
+    };
+    auto commit_stage = [&](int buf) {
+        char* As = smem + buf * PH2_STAGE; char* Bs = As + PH2_BM * LDA;
+#pragma unroll
+        for (int c = 0; c < NC; c++) spv[c] = pspv[c];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32x4 v = pa[j];       // (a0,a1 | a2,a3 | a4,a5 | a6,a7) -> (a0,a4 | a1,a5 | a2,a6 | a3,a7)
+            *reinterpret_cast<u32x4*>(As + ar * LDA + aq * 128 + j * 16) =
+                u32x4{__builtin_amdgcn_perm(v.z, v.x, 0x05040100u), __builtin_amdgcn_perm(v.z, v.x, 0x07060302u),
+                      __builtin_amdgcn_perm(v.w, v.y, 0x05040100u), __builtin_amdgcn_perm(v.w, v.y, 0x07060302u)};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) *reinterpret_cast<u32x2*>(Bs + ((wv + 4 * j) * 8 + (lane >> 3)) * LDB + (lane & 7) * 8) = pb[j];
+    };
+    // one stage: MFMAs of buffer st & 1 for NSA active row blocks, with the commit of the registers (stage st + 1) to the other buffer in the same block
+    auto stage = [&](int st, auto nsa) {
+        constexpr int NSA = decltype(nsa)::value;
+        const char* As = smem + (st & 1) * PH2_STAGE; const char* Bs = As + PH2_BM * LDA;
+        v2h sq[NC], cq[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float sc = __uint_as_float(((st & 1) ? (spv[c] >> 16) : (spv[c] & 0xFFFFu)) << 16);
+            const _Float16 s1 = (_Float16)(sc * 0.25f);
+            sq[c] = v2h{s1, s1};
+            const _Float16 c1 = (_Float16)(-1536.0f * (float)s1);
+            cq[c] = v2h{c1, c1};
+        }
+        v8h af[2][NSA][2], bf[2][NC][2];
+        u32x2 br[2][NC];
+        auto rd = [&](int t, int buf) {
+            const int lp = 2 * t + khalf;
+#pragma unroll
+            for (int s2 = 0; s2 < NSA; s2++) {
+                af[buf][s2][0] = *reinterpret_cast<const v8h*>(As + (s2 * 32 + n31) * LDA + lp * 32);
+                af[buf][s2][1] = *reinterpret_cast<const v8h*>(As + (s2 * 32 + n31) * LDA + lp * 32 + 16);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) br[buf][c] = *reinterpret_cast<const u32x2*>(Bs + (cbase + c * 32 + n31) * LDB + lp * 8);
+        };
+        auto dq = [&](int buf) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) { bf[buf][c][0] = pfh_dq4(br[buf][c].x, sq[c], cq[c], M0, M1, MH, Kc); bf[buf][c][1] = pfh_dq4(br[buf][c].y, sq[c], cq[c], M0, M1, MH, Kc); }
+        };
+        rd(0, 0); rd(1, 1); dq(0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int cur = t & 1, nxt = cur ^ 1;
+            if (t + 1 < 4) dq(nxt);
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int s2 = 0; s2 < NSA; s2++) acc[s2][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][s2][h], bf[cur][c][h], acc[s2][c], 0, 0, 0);
+            if (t + 2 < 4) rd(t + 2, cur);
+            if (t == 1) commit_stage((st + 1) & 1);              // registers of stage st + 1 (past the last stage: stale data into a buffer nobody reads)
+            constexpr int NM = 2 * NC * NSA;
+            constexpr int VPM = (48 + (NM - 1)) / NM + (NSA >= 3 ? 1 : 2);
+#pragma unroll
+            for (int i = 0; i < NM; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                if (t == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // the 16 LDS writes of the commit, one per MFMA
+                if (t + 2 < 4 && i >= NM - (2 * NSA + NC)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // LDS reads of step t + 2 behind the last MFMAs
+            }
+        }
+    };
+    load_stage(0);
+    commit_stage(0);
+    if (nst > 1) load_stage(1);
+    __syncthreads();
+    // the main loop, one copy per number of active row blocks (the choice is made once per workgroup, outside the loop: the accumulators of
+    // each copy live in the AGPRs from its first MFMA to the store)
+    auto main_loop = [&](auto nsa) {
+        for (int st = 0; st < nst; st++) {
+            PFH_STAMP(0);
+            stage(st, nsa);
+            PFH_STAMP(1);
+            if (st + 2 < nst) load_stage(st + 2);
+            PFH_STAMP(2);
+            __syncthreads();
+            PFH_STAMP(3);
+        }
+    };
+    if (nsb == 4) main_loop(std::integral_constant<int, 4>{});
+    else if (nsb == 3) main_loop(std::integral_constant<int, 3>{});
+    else if (nsb == 2) main_loop(std::integral_constant<int, 2>{});
+    else main_loop(std::integral_constant<int, 1>{});
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+        if (col[c] < m.N) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+                if (s < nsb) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (row < rows) {
+                            const float v = acc[s][c][r] * rmul[row];
+                            const size_t o = (size_t)row_dst[row] * out_ld + col[c];
+                            if (a.out_bf16) reinterpret_cast<uint16_t*>(out_p)[o] = kr_f32_to_bf16(v);
+                            else out_p[o] = v;
+                        }
+                    }
+                }
+        }
+}
+static void pfh2_launch(const KrPfGemmHArgs& a, int mt128, hipStream_t st) {
+    const size_t lds = (size_t)2 * PH2_STAGE + 3 * PH2_BM * 4;
+    (void)kr_lds_optin((const void*)kr_pfh2_gemm_kernel, 112 * 1024);
+    int ncb = (a.m.N + PH2_BN - 1) / PH2_BN;
+    for (int i = 0; i < a.n_extra; i++) ncb += (a.mx[i].N + PH2_BN - 1) / PH2_BN;
+    const int span = 8 * a.run;
+    dim3 grid(((mt128 + span - 1) / span) * span * ncb);
+    hipLaunchKernelGGL(kr_pfh2_gemm_kernel, grid, dim3(256), lds, st, a);
+}
+
+template <int NC, int BITS>
+static void pfh_launch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
+    constexpr int BN = 128 * NC, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4;
+    const size_t lds = (size_t)PFH_BM * PFH_LDA + (size_t)BN * LDB + 3 * PFH_BM * 4;
+    (void)kr_lds_optin((const void*)kr_pfh_gemm_kernel<NC, BITS>, 80 * 1024);
+    int ncb = (a.m.N + BN - 1) / BN;
+    for (int i = 0; i < a.n_extra; i++) ncb += (a.mx[i].N + BN - 1) / BN;
+    const int span = 8 * a.run;
+    dim3 grid(((mt + span - 1) / span) * span * ncb);
+    hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS>), grid, dim3(256), lds, st, a);
+}
+static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
+    if (a.m.bits == 8) { pfh_launch<1, 8>(a, mt, st); return; }
+    // 256-column tiles when they still fill the chip (>= 2 workgroups per CU), else 128-column tiles
+    long n128 = (a.m.N + 127) / 128;
+    for (int i = 0; i < a.n_extra; i++) n128 += (a.mx[i].N + 127) / 128;
+    if ((long)mt * n128 >= 2048) pfh_launch<2, 4>(a, mt, st); else pfh_launch<1, 4>(a, mt, st);
+}
+
+void kr_launch_pfh_rows_f32(const float* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(kr_pfh_rows_kernel<0>, dim3(rows), dim3(256), 0, st, (const void*)x, ld, K, out, mul);
+}
+void kr_launch_pfh_rows_bf16(const uint16_t* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(kr_pfh_rows_kernel<1>, dim3(rows), dim3(256), 0, st, (const void*)x, ld, K, out, mul);
+}
+void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, uint16_t* out, float* mul, hipStream_t st) {
+    if (rows <= 0) return;
+    if (act_mode == KR_ACT_GPTOSS) hipLaunchKernelGGL(kr_pfh_act_kernel<KR_ACT_GPTOSS>, dim3(rows), dim3(256), 0, st, gu, n, gu_ld, swiglu_limit, alpha, out, mul);
+    else hipLaunchKernelGGL(kr_pfh_act_kernel<KR_ACT_SILU_MUL>, dim3(rows), dim3(256), 0, st, gu, n, gu_ld, swiglu_limit, alpha, out, mul);
+}
+// tuning hook: KR_PFH_FORM=1 forces the 64-row form, =2 the 128-row form wherever it applies (default: by problem size)
+static int pfh_form() { static int f = -1; if (f < 0) { const char* e = getenv("KR_PFH_FORM"); f = e ? atoi(e) : 0; } return f; }
+// the 128 x 256 form needs INT4 weights and enough workgroups to fill 256 CUs at one workgroup per CU
+static bool pfh2_dense_ok(const KrPfGemmHArgs& a, int rows) {
+    if (a.m.bits != 4 || pfh_form() == 1) return false;
+    if (pfh_form() == 2) return true;
+    long ncb = (a.m.N + PH2_BN - 1) / PH2_BN;
+    for (int i = 0; i < a.n_extra; i++) ncb += (a.mx[i].N + PH2_BN - 1) / PH2_BN;
+    return (long)((rows + PH2_BM - 1) / PH2_BM) * ncb >= 192;
+}
+int kr_pfh_expert_bm(long pairs, int E, const KrMatDev& w13, const KrMatDev& w2) {
+    if (w13.bits != 4 || w2.bits != 4 || pfh_form() == 1) return PFH_BM;
+    if (pfh_form() == 2) return PH2_BM;
+    return pairs >= 64L * E ? PH2_BM : PFH_BM;
+}
+void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
+                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows, int out_bf16, int run, int bm) {
+    KrPfGemmHArgs a{};
+    a.m = m; a.a = a_h; a.a_mul = a_mul; a.topk = topk; a.gather_tokens = gather_tokens; a.scatter_rows = scatter_rows; a.out_bf16 = out_bf16;
+    if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
+    a.out = out; a.out_ld = out_ld; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
+    a.run = (single_expert_rows > 0 || run < 1) ? 1 : run;
+    if (single_expert_rows > 0) {
+        if (pfh2_dense_ok(a, single_expert_rows)) pfh2_launch(a, (single_expert_rows + PH2_BM - 1) / PH2_BM, st);
+        else pfh_dispatch(a, (single_expert_rows + PFH_BM - 1) / PFH_BM, st);
+        return;
+    }
+    if (bm == PH2_BM && m.bits == 4) pfh2_launch(a, max_tiles, st); else pfh_dispatch(a, max_tiles, st);
+}
+void kr_launch_pfh_gemm_multi(const KrMatDev* mats, float* const* outs, const int* out_lds, int n, const uint16_t* a_h, const float* a_mul, int M, hipStream_t st) {
+    KrPfGemmHArgs a{};
+    a.m = mats[0]; a.out = outs[0]; a.out_ld = out_lds[0]; a.a = a_h; a.a_mul = a_mul; a.topk = 1; a.single_expert = 1; a.total_rows = M; a.n_extra = n - 1; a.run = 1;
+    for (int i = 1; i < n; i++) { a.mx[i - 1] = mats[i]; a.outx[i - 1] = outs[i]; a.out_ldx[i - 1] = out_lds[i]; }
+    if (pfh2_dense_ok(a, M)) pfh2_launch(a, (M + PH2_BM - 1) / PH2_BM, st);
+    else pfh_dispatch(a, (M + PFH_BM - 1) / PFH_BM, st);
+}

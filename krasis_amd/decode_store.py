@@ -260,10 +260,11 @@ class CpuDecodeStore:
         """GQA KV cache element type: FP16 (reference CPU decode, default) or FP8-E4M3 (reference GPU cache, kv_cache.py:38)."""
         self._need(); check(self._lib.kr_decode_set_kv_dtype(self._h, 1 if fp8_e4m3 else 0))
 
-    def set_attention_mode(self, fast: bool) -> None:
-        """False (default): the reference's sequential softmax / p.v order (bit-exact).  True: split-KV attention with a log-sum-exp merge for
-        long caches -- tolerance mode (logits within ~1e-4 relative), many workgroups instead of one per head."""
-        self._need(); check(self._lib.kr_decode_set_attention_mode(self._h, 1 if fast else 0))
+    def set_attention_mode(self, fast: bool, gemm_fast: bool = False) -> None:
+        """fast False (default): the reference's sequential softmax / p.v order (bit-exact).  True: split-KV / flash attention and the chunked
+        delta rule -- tolerance mode (logits within ~1e-4 relative).  gemm_fast True: the GEMMs of the prompt pass in the tolerance form as well
+        (f16 activations, f32 accumulation over the whole k range: the dataflow of the reference's GPU prompt pass); decode steps are unaffected."""
+        self._need(); check(self._lib.kr_decode_set_attention_mode(self._h, (1 if fast else 0) | (2 if gemm_fast else 0)))
 
     def finalize_decode(self) -> None:
         self._need()
