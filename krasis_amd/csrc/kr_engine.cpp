@@ -937,14 +937,13 @@ static int moe_prefill_fast(kr_engine* e, Layer& L, const void* x_bf16, const in
         const uint16_t* xc = (const uint16_t*)x_bf16 + (size_t)m0 * H;
         const int32_t* idc = ids + (size_t)m0 * topk; const float* wc = wts + (size_t)m0 * topk;
         const int tiles_bound = (mc * topk) / 64 + E + 1;
-        const int bm = kr_pfh_expert_bm((long)mc * topk, E, L.w13.view(), L.w2.view());
-        int run = (int)(((long)mc * topk / E + bm - 1) / bm);       // row tiles of an average expert: they share an XCD (one L2 fill of its weights)
+        int run = (int)(((long)mc * topk / E + 63) / 64);           // row tiles of an average expert: they share an XCD (one L2 fill of its weights)
         run = run < 1 ? 1 : (run > 4 ? 4 : run);
-        kr_launch_pf_sort(idc, mc, topk, E, so, st, bm);
+        kr_launch_pf_sort(idc, mc, topk, E, so, st);
         kr_launch_pfh_rows_bf16(xc, mc, H, H, (uint16_t*)P.xf.p, (float*)P.xfm.p, st);
-        kr_launch_pfh_gemm(L.w13.view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, &so, topk, 1, tiles_bound, 0, (float*)P.gu.p, 2 * I, st, 0, 0, run, bm);
+        kr_launch_pfh_gemm(L.w13.view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, &so, topk, 1, tiles_bound, 0, (float*)P.gu.p, 2 * I, st, 0, 0, run);
         kr_launch_pfh_act((const float*)P.gu.p, mc * topk, I, 2 * I, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (uint16_t*)P.hf.p, (float*)P.hfm.p, st);
-        kr_launch_pfh_gemm(L.w2.view(), (const uint16_t*)P.hf.p, (const float*)P.hfm.p, &so, topk, 0, tiles_bound, 0, (float*)P.eo.p, H, st, 0, 0, run, bm);
+        kr_launch_pfh_gemm(L.w2.view(), (const uint16_t*)P.hf.p, (const float*)P.hfm.p, &so, topk, 0, tiles_bound, 0, (float*)P.eo.p, H, st, 0, 0, run);
         if (use_shared) {
             kr_launch_pfh_gemm(L.sw13.view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, nullptr, topk, 0, 0, mc, (float*)P.sgu.p, 2 * SI, st);
             kr_launch_pfh_act((const float*)P.sgu.p, mc, SI, 2 * SI, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (uint16_t*)P.shf.p, (float*)P.shfm.p, st);
@@ -1104,6 +1103,7 @@ extern "C" int kr_combine_rows(kr_engine* e, const float* eo_rows, const int32_t
                                int out_dtype, void* stream) {
     if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
     if (!is_device_ptr(eo_rows) || !is_device_ptr(pair_row) || !is_device_ptr(wts) || !is_device_ptr(out)) return kr_fail(KR_ERR_VALUE, "kr_combine_rows expects device pointers");
+    if (e->cfg.hidden_size % 4) return kr_fail(KR_ERR_VALUE, "kr_combine_rows needs hidden_size %% 4 == 0 (got %d)", e->cfg.hidden_size);
     KR_HIP(hipSetDevice(e->device));
     kr_launch_pf_combine(eo_rows, pair_row, wts, M, topk, e->cfg.hidden_size, nullptr, 1.0f, out, out_dtype == KR_OUT_BF16, kr_pick_stream(e, stream));
     KR_HIP(hipGetLastError());

@@ -35,9 +35,6 @@ void kr_launch_ep_rows_bf16(const float* in, uint16_t* out, size_t n, hipStream_
 void kr_launch_pfh_rows_f32(const float* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st);
 void kr_launch_pfh_rows_bf16(const uint16_t* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st);
 void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, uint16_t* out, float* mul, hipStream_t st);
-// rows per tile the tolerance GEMMs of an expert layer want from kr_launch_pf_sort: 128 (the one-wave-per-SIMD form) when the average expert has
-// enough rows and both matrices are INT4, else 64
-int kr_pfh_expert_bm(long pairs, int E, const KrMatDev& w13, const KrMatDev& w2);
 void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
-                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows = 0, int out_bf16 = 0, int run = 1, int bm = 64);
+                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows = 0, int out_bf16 = 0, int run = 1);
 void kr_launch_pfh_gemm_multi(const KrMatDev* mats, float* const* outs, const int* out_lds, int n, const uint16_t* a_h, const float* a_mul, int M, hipStream_t st);

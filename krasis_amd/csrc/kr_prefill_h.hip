@@ -40,8 +40,10 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifdef KR_TIMING   // tools/probes/gemm_h_timing.hip: shader-clock stamps of wave 0 of one mid-grid workgroup at stage 3; no-op in the product build
 __device__ unsigned long long kr_hstamps[16];
 #define PFH_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && st == 3) kr_hstamps[i] = clock64(); } while (0)
+#define PFH_STAMPW(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) kr_hstamps[i] = clock64(); } while (0)
 #else
 #define PFH_STAMP(i) do { } while (0)
+#define PFH_STAMPW(i) do { } while (0)
 #endif
 #define PFH_KS 256
 #define PFH_LDA (PFH_KS * 2 + 16)       // bytes per A row of a stage (f16)
@@ -146,6 +148,55 @@ __global__ void __launch_bounds__(256) kr_pfh_act_kernel(const float* __restrict
     if (threadIdx.x == 0) mul[row] = inv * 0.0625f;
 }
 
+// the same for rows of up to 2048 values (expert intermediates): one WAVE per row, the row's values stay in registers between the max and the store
+// (no second evaluation, no LDS, no barrier); 4 rows per workgroup.  CPL = 8-value chunks per lane.
+template <int ACT, int CPL>
+__global__ void __launch_bounds__(256) kr_pfh_act_wave_kernel(const float* __restrict__ gu, int rows, int n, int gu_ld, float swiglu_limit, float alpha,
+                                                             uint16_t* __restrict__ out, float* __restrict__ mul) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* g = gu + (size_t)row * gu_ld;
+    float h[CPL][8];
+    float mx = 0.0f;
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + 64 * q;
+        if (c * 8 < n) {
+            const float4 g0 = *reinterpret_cast<const float4*>(g + c * 8), g1 = *reinterpret_cast<const float4*>(g + c * 8 + 4);
+            const float4 u0 = *reinterpret_cast<const float4*>(g + n + c * 8), u1 = *reinterpret_cast<const float4*>(g + n + c * 8 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (ACT == KR_ACT_GPTOSS) {
+                    float gate = gg[i], up = uu[i];
+                    if (gate > swiglu_limit) gate = swiglu_limit;
+                    if (up > swiglu_limit) up = swiglu_limit;
+                    if (up < -swiglu_limit) up = -swiglu_limit;
+                    h[q][i] = (up + 1.0f) * (gate * kr_sigmoid_poly5_scalar(gate * alpha));
+                } else h[q][i] = (gg[i] * kr_sigmoid_poly5(gg[i])) * uu[i];
+                mx = fmaxf(mx, fabsf(h[q][i]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) h[q][i] = 0.0f;
+        }
+    }
+    mx = kr_red16_max_f32(mx);
+    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float scl, inv; pfh_row_scale(mx, scl, inv);
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+        const int c = lane + 64 * q;
+        if (c * 8 < n) {
+            u32x4 o;
+            o.x = pfh_pack_h2(h[q][0] * scl, h[q][1] * scl); o.y = pfh_pack_h2(h[q][2] * scl, h[q][3] * scl);
+            o.z = pfh_pack_h2(h[q][4] * scl, h[q][5] * scl); o.w = pfh_pack_h2(h[q][6] * scl, h[q][7] * scl);
+            *reinterpret_cast<u32x4*>(out + (size_t)row * n + (size_t)c * 8) = o;
+        }
+    }
+    if (lane == 0) mul[row] = inv * 0.0625f;
+}
+
 // ------------------------------------------------------------------------------------------
 // the GEMM
 // ------------------------------------------------------------------------------------------
@@ -184,6 +235,55 @@ __device__ __forceinline__ v8h pfh_dq8(uint32_t w0, uint32_t w1, v2h sb) {
     return v8h{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
 }
 
+
+// Stores of a 32 x 32 accumulator block set: lane (n31, khalf) holds column n31 of 16 rows (r & 3) + 8 (r >> 2) + 4 khalf.  FULL: every row and column
+// of the tile is valid and rows are stored in GEMM order (no scatter): the row base is wave-uniform (scalar), the lane part one 32-bit offset, no
+// exec-mask branches -- the guarded form costs ~20 instructions and two branches per store.  BF16: round to bf16 (RNE) on the way out.
+template <int NSB, int NC, bool FULL, bool BF16, typename ACC>
+__device__ __forceinline__ void pfh_store_tile(const ACC& acc, int nsb, int rows, int row0, const float* rmul, const int* row_dst, void* out_p, int out_ld,
+                                               const int (&col)[NC], int N, int lane) {
+    const int khalf = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < NSB; s++) {
+        if (s >= nsb) break;
+#pragma unroll
+        for (int rq = 0; rq < 4; rq++) {
+            const int rowb = s * 32 + 8 * rq + 4 * khalf;
+            const float4 rm4 = *reinterpret_cast<const float4*>(rmul + rowb);
+            const float rm[4] = {rm4.x, rm4.y, rm4.z, rm4.w};
+            if (FULL) {
+                const uint32_t lane_off = (uint32_t)(4 * khalf) * (uint32_t)out_ld;      // elements; + col below
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    char* rb = reinterpret_cast<char*>(out_p) + (size_t)(row0 + s * 32 + 8 * rq + i) * out_ld * (BF16 ? 2 : 4);     // wave-uniform
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const float v = acc[s][c][rq * 4 + i] * rm[i];
+                        const uint32_t eo = lane_off + (uint32_t)col[c];
+                        if (BF16) *reinterpret_cast<uint16_t*>(rb + (size_t)eo * 2) = kr_f32_to_bf16(v);
+                        else *reinterpret_cast<float*>(rb + (size_t)eo * 4) = v;
+                    }
+                }
+            } else {
+                const int4 rd4 = *reinterpret_cast<const int4*>(row_dst + rowb);
+                const int rd[4] = {rd4.x, rd4.y, rd4.z, rd4.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (rowb + i < rows) {
+#pragma unroll
+                        for (int c = 0; c < NC; c++)
+                            if (col[c] < N) {
+                                const float v = acc[s][c][rq * 4 + i] * rm[i];
+                                const size_t o = (size_t)rd[i] * out_ld + col[c];
+                                if (BF16) reinterpret_cast<uint16_t*>(out_p)[o] = kr_f32_to_bf16(v);
+                                else reinterpret_cast<float*>(out_p)[o] = v;
+                            }
+                    }
+            }
+        }
+    }
+}
+
 template <int NC, int BITS>
 __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs a) {
     constexpr int BN = 128 * NC, LDA = PFH_LDA, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4, NS = 2;
@@ -194,6 +294,7 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     int* row_src = reinterpret_cast<int*>(rmul + PFH_BM);          // [64]
     int* row_dst = row_src + PFH_BM;                               // [64]
 
+    PFH_STAMPW(6);
     const int ncb0 = (a.m.N + BN - 1) / BN, ncb1 = a.n_extra > 0 ? (a.mx[0].N + BN - 1) / BN : 0, ncb2 = a.n_extra > 1 ? (a.mx[1].N + BN - 1) / BN : 0;
     const int ncb = ncb0 + ncb1 + ncb2, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int per = ncb * a.run, grp = slot / per, local = slot - grp * per;
@@ -218,7 +319,7 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
             if (a.single_expert) src = row0 + tid;
             else { const int pair = a.row_pair[row0 + tid]; src = a.gather_tokens ? pair / a.topk : row0 + tid; }
         }
-        row_src[tid] = src;
+        row_src[tid] = (int)((uint32_t)(src < 0 ? 0 : src) * (uint32_t)(K * 2));      // byte offset of the row in the A matrix (rows past `rows`: row 0)
         row_dst[tid] = (a.scatter_rows && !a.single_expert && tid < rows) ? a.row_pair[row0 + tid] : row0 + tid;
         rmul[tid] = src >= 0 ? a.a_mul[src] : 0.0f;
     }
@@ -242,7 +343,12 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     constexpr int APT = 8;                         // 16-byte A chunks per thread per stage (4 threads per row, 128 B each)
     constexpr int RPT = BN * 8 / 256;              // B lane records per thread (per group for INT8)
     constexpr int NBW = BITS == 8 ? 2 * RPT : RPT;
-    const int ar = tid >> 2, aq = tid & 3;
+    // A requests cover WHOLE 128-byte lines: a wave-instruction takes 8 lines (8 lanes x 16 B each) = 2 rows x 4 lines of the 512-byte row segment of
+    // the stage.  (4 threads per row x 128 contiguous bytes per thread, the mapping of the exact kernel, puts the 64 lanes of one instruction on 64
+    // different lines, each line re-requested by 8 instructions: the wave sat ~150 cycles in the issue of every load.)
+    // load j of thread tid: row 8 j + (tid >> 5), line (tid >> 3) & 3 of the segment, chunk tid & 7 of the line
+    const int arow = tid >> 5, aseg = (tid >> 3) & 3, achk = tid & 7;
+    const uint32_t* rofs = reinterpret_cast<const uint32_t*>(row_src);      // byte offset of every tile row in the A matrix
     const int nst = m.ngp;
     u32x4 pa[APT], pbw[NBW];
     uint32_t pspv[NC];
@@ -256,12 +362,10 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
 #pragma unroll
         for (int c = 0; c < NC; c++) pspv[c] = wsc[((size_t)ctile[c] * m.ngp + st) * 8 + cin[c]];
         {
-            const int src = row_src[ar];
-            const int kvalid = K - st * PFH_KS;
-            const int k0 = aq * 64 < kvalid ? aq * 64 : kvalid - 64;
-            const u32x4* ap = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.a) + ((size_t)(src < 0 ? 0 : src) * K + (size_t)st * PFH_KS + k0) * 2);
+            const int kvalid = K - st * PFH_KS;                  // 256, or 128 in the last stage of an odd group count: lines 2, 3 re-read lines 0, 1
+            const char* ab = reinterpret_cast<const char*>(a.a) + (size_t)st * (PFH_KS * 2) + (aseg * 64 < kvalid ? aseg : aseg - 2) * 128;
 #pragma unroll
-            for (int j = 0; j < APT; j++) pa[j] = ap[j];
+            for (int j = 0; j < APT; j++) pa[j] = *reinterpret_cast<const u32x4*>(ab + achk * 16 + rofs[arow + 8 * j]);
         }
         if (BITS == 8) {
 #pragma unroll
@@ -291,7 +395,7 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
             if (BITS == 4)      // (a0,a1 | a2,a3 | a4,a5 | a6,a7) -> (a0,a4 | a1,a5 | a2,a6 | a3,a7)
                 v = u32x4{__builtin_amdgcn_perm(v.z, v.x, 0x05040100u), __builtin_amdgcn_perm(v.z, v.x, 0x07060302u),
                           __builtin_amdgcn_perm(v.w, v.y, 0x05040100u), __builtin_amdgcn_perm(v.w, v.y, 0x07060302u)};
-            *reinterpret_cast<u32x4*>(As + ar * LDA + aq * 128 + j * 16) = v;
+            *reinterpret_cast<u32x4*>(As + (arow + 8 * j) * LDA + aseg * 128 + achk * 16) = v;
         }
         if (BITS == 8) {
 #pragma unroll
@@ -376,245 +480,35 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
         }
     };
     load_stage(0);
-    for (int st = 0; st < nst; st++) {
-        PFH_STAMP(0);
-        commit_stage();
-        PFH_STAMP(1);
-        if (st + 1 < nst) load_stage(st + 1);
-        PFH_STAMP(2);
-        __syncthreads();
-        PFH_STAMP(3);
-        if (two) stage_mfma(st, std::integral_constant<int, 2>{}); else stage_mfma(st, std::integral_constant<int, 1>{});
-        PFH_STAMP(4);
-        __syncthreads();
-        PFH_STAMP(5);
-    }
-#pragma unroll
-    for (int c = 0; c < NC; c++)
-        if (col[c] < m.N) {
-#pragma unroll
-            for (int s = 0; s < NS; s++)
-                if (s == 0 || two) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (row < rows) {
-                            const float v = acc[s][c][r] * rmul[row];
-                            const size_t o = (size_t)row_dst[row] * out_ld + col[c];
-                            if (a.out_bf16) reinterpret_cast<uint16_t*>(out_p)[o] = kr_f32_to_bf16(v);
-                            else out_p[o] = v;
-                        }
-                    }
-                }
-        }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// second form for large problems (INT4): 128 rows x 256 columns per workgroup, ONE wave per SIMD with the 128 accumulator registers of its
-// 128 x 64 tile in the AGPR half of the register file.  Why: a wave issues in order and a SIMD has ~8 issue slots of 4 cycles under one
-// 32-cycle MFMA (MI355X_MICROARCH.md: <= 5 fillers hidden per MFMA).  The 64 x 64 wave tile above needs 8.5 VALU + 1 LDS per MFMA (6 of them the
-// de-quantization: every B fragment feeds only two row blocks) -- PMC: 25 % matrix-pipe busy, VALU and MFMA time simply add up.  With four row
-// blocks per B fragment the de-quantization is 3 VALU per MFMA and the whole stream ~5 issues per MFMA.
-//   * one quantization group (128 k) per stage, two LDS stages (2 x 52 KiB): while stage st is multiplied, the registers holding stage st + 1
-//     are committed to the other buffer inside the same basic block, then stage st + 2 is requested from HBM; one barrier per stage.
-//   * per 16-k step: 8 b128 A fragments + 2 packed B words for 16 MFMA on 8 different accumulators; LDS reads of step t + 2 and the
-//     de-quantization of step t + 1 are interleaved with the MFMAs of step t (sched_group_barrier).
-// Row tiles hold 128 rows (kr_launch_pf_sort with bm = 128); tiles with fewer rows run the variant with 1..3 active row blocks.
-#define PH2_BM 128
-#define PH2_BN 256
-#define PH2_KS 128
-#define PH2_LDA (PH2_KS * 2 + 16)
-#define PH2_LDB 72
-#define PH2_STAGE (PH2_BM * PH2_LDA + PH2_BN * PH2_LDB)
-
-__global__ void __launch_bounds__(256, 1) kr_pfh2_gemm_kernel(const KrPfGemmHArgs a) {
-    constexpr int BN = PH2_BN, LDA = PH2_LDA, LDB = PH2_LDB, NC = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* rmul = reinterpret_cast<float*>(smem + 2 * PH2_STAGE);      // [128]
-    int* row_src = reinterpret_cast<int*>(rmul + PH2_BM);              // [128]
-    int* row_dst = row_src + PH2_BM;                                   // [128]
-
-    const int ncb0 = (a.m.N + BN - 1) / BN, ncb1 = a.n_extra > 0 ? (a.mx[0].N + BN - 1) / BN : 0, ncb2 = a.n_extra > 1 ? (a.mx[1].N + BN - 1) / BN : 0;
-    const int ncb = ncb0 + ncb1 + ncb2, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per = ncb * a.run, grp = slot / per, local = slot - grp * per;
-    const int mt = (grp * 8 + xcd) * a.run + local / ncb;
-    int cb = local % ncb;
-    int expert, row0, rows;
-    if (a.single_expert) { expert = 0; row0 = mt * PH2_BM; rows = a.total_rows - row0 < PH2_BM ? a.total_rows - row0 : PH2_BM; if (rows <= 0) return; }
-    else { if (mt >= a.n_tiles[0]) return; expert = a.tile_expert[mt]; row0 = a.tile_row0[mt]; rows = a.tile_rows[mt]; }
-    KrMatDev m = a.m; float* out_p = a.out; int out_ld = a.out_ld;
-    if (cb >= ncb0 + ncb1) { cb -= ncb0 + ncb1; m = a.mx[1]; out_p = a.outx[1]; out_ld = a.out_ldx[1]; }
-    else if (cb >= ncb0) { cb -= ncb0; m = a.mx[0]; out_p = a.outx[0]; out_ld = a.out_ldx[0]; }
-    const int n0 = cb * BN;
-    const int nsb = (rows + 31) >> 5;                                   // active 32-row blocks, 1..4 (uniform)
-    const int K = m.ng * 128, nst = m.ng;
-    const char* wq = reinterpret_cast<const char*>(m.q) + (size_t)expert * m.q_stride;
-    const uint32_t* wsc = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + (size_t)expert * m.s_stride);
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < PH2_BM) {
-        int src = -1;
-        if (tid < rows) {
-            if (a.single_expert) src = row0 + tid;
-            else { const int pair = a.row_pair[row0 + tid]; src = a.gather_tokens ? pair / a.topk : row0 + tid; }
-        }
-        row_src[tid] = src;
-        row_dst[tid] = (a.scatter_rows && !a.single_expert && tid < rows) ? a.row_pair[row0 + tid] : row0 + tid;
-        rmul[tid] = src >= 0 ? a.a_mul[src] : 0.0f;
-    }
-    __syncthreads();
-
-    v16f acc[4][NC];
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[s][c][r] = 0.0f;
-    const int n31 = lane & 31, khalf = lane >> 5;
-    uint32_t MH = 0x03C003C0u, M0 = 0x000F000Fu, M1 = 0x00F000F0u, Kc = 0x64006400u;
-    asm volatile("" : "+v"(M0), "+v"(M1), "+v"(MH), "+v"(Kc));
-    const int cbase = wave * 64;
-    int col[NC], ctile[NC], cin[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) { col[c] = n0 + cbase + c * 32 + n31; const int cc = col[c] < m.N ? col[c] : m.N - 1; ctile[c] = cc >> 3; cin[c] = cc & 7; }
-
-    // loads (never masked: see the first form): A 2 threads per row x 128 B contiguous, B one 8-byte half record per lane of 8 wave-uniform tiles
-    const int ar = tid >> 1, aq = tid & 1;
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int last_tile = (m.N - 1) >> 3;
-    const int asrc = row_src[ar] < 0 ? 0 : row_src[ar];
-    const char* abase = reinterpret_cast<const char*>(a.a) + ((size_t)asrc * K + aq * 64) * 2;
-    u32x4 pa[8]; u32x2 pb[8]; uint32_t pspv[NC], spv[NC];
-    auto load_stage = [&](int st) {
-#pragma unroll
-        for (int c = 0; c < NC; c++) pspv[c] = wsc[((size_t)ctile[c] * m.ngp + (st >> 1)) * 8 + cin[c]];
-        const u32x4* ap = reinterpret_cast<const u32x4*>(abase + (size_t)st * (PH2_KS * 2));
-#pragma unroll
-        for (int j = 0; j < 8; j++) pa[j] = ap[j];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int tile = (n0 >> 3) + wv + 4 * j; tile = tile < last_tile ? tile : last_tile;
-            pb[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wq + ((size_t)tile * m.ngp + (st >> 1)) * 1024 + (st & 1) * 8) + 2 * lane);
-        }
-    };
-    auto commit_stage = [&](int buf) {
-        char* As = smem + buf * PH2_STAGE; char* Bs = As + PH2_BM * LDA;
-#pragma unroll
-        for (int c = 0; c < NC; c++) spv[c] = pspv[c];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const u32x4 v = pa[j];       // (a0,a1 | a2,a3 | a4,a5 | a6,a7) -> (a0,a4 | a1,a5 | a2,a6 | a3,a7)
-            *reinterpret_cast<u32x4*>(As + ar * LDA + aq * 128 + j * 16) =
-                u32x4{__builtin_amdgcn_perm(v.z, v.x, 0x05040100u), __builtin_amdgcn_perm(v.z, v.x, 0x07060302u),
-                      __builtin_amdgcn_perm(v.w, v.y, 0x05040100u), __builtin_amdgcn_perm(v.w, v.y, 0x07060302u)};
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) *reinterpret_cast<u32x2*>(Bs + ((wv + 4 * j) * 8 + (lane >> 3)) * LDB + (lane & 7) * 8) = pb[j];
-    };
-    // one stage: MFMAs of buffer st & 1 for NSA active row blocks, with the commit of the registers (stage st + 1) to the other buffer in the same block
-    auto stage = [&](int st, auto nsa) {
-        constexpr int NSA = decltype(nsa)::value;
-        const char* As = smem + (st & 1) * PH2_STAGE; const char* Bs = As + PH2_BM * LDA;
-        v2h sq[NC], cq[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const float sc = __uint_as_float(((st & 1) ? (spv[c] >> 16) : (spv[c] & 0xFFFFu)) << 16);
-            const _Float16 s1 = (_Float16)(sc * 0.25f);
-            sq[c] = v2h{s1, s1};
-            const _Float16 c1 = (_Float16)(-1536.0f * (float)s1);
-            cq[c] = v2h{c1, c1};
-        }
-        v8h af[2][NSA][2], bf[2][NC][2];
-        u32x2 br[2][NC];
-        auto rd = [&](int t, int buf) {
-            const int lp = 2 * t + khalf;
-#pragma unroll
-            for (int s2 = 0; s2 < NSA; s2++) {
-                af[buf][s2][0] = *reinterpret_cast<const v8h*>(As + (s2 * 32 + n31) * LDA + lp * 32);
-                af[buf][s2][1] = *reinterpret_cast<const v8h*>(As + (s2 * 32 + n31) * LDA + lp * 32 + 16);
-            }
-#pragma unroll
-            for (int c = 0; c < NC; c++) br[buf][c] = *reinterpret_cast<const u32x2*>(Bs + (cbase + c * 32 + n31) * LDB + lp * 8);
-        };
-        auto dq = [&](int buf) {
-#pragma unroll
-            for (int c = 0; c < NC; c++) { bf[buf][c][0] = pfh_dq4(br[buf][c].x, sq[c], cq[c], M0, M1, MH, Kc); bf[buf][c][1] = pfh_dq4(br[buf][c].y, sq[c], cq[c], M0, M1, MH, Kc); }
-        };
-        rd(0, 0); rd(1, 1); dq(0);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int cur = t & 1, nxt = cur ^ 1;
-            if (t + 1 < 4) dq(nxt);
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int c = 0; c < NC; c++)
-#pragma unroll
-                    for (int s2 = 0; s2 < NSA; s2++) acc[s2][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][s2][h], bf[cur][c][h], acc[s2][c], 0, 0, 0);
-            if (t + 2 < 4) rd(t + 2, cur);
-            if (t == 1) commit_stage((st + 1) & 1);              // registers of stage st + 1 (past the last stage: stale data into a buffer nobody reads)
-            constexpr int NM = 2 * NC * NSA;
-            constexpr int VPM = (48 + (NM - 1)) / NM + (NSA >= 3 ? 1 : 2);
-#pragma unroll
-            for (int i = 0; i < NM; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                if (t == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // the 16 LDS writes of the commit, one per MFMA
-                if (t + 2 < 4 && i >= NM - (2 * NSA + NC)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // LDS reads of step t + 2 behind the last MFMAs
-            }
-        }
-    };
-    load_stage(0);
-    commit_stage(0);
-    if (nst > 1) load_stage(1);
-    __syncthreads();
-    // the main loop, one copy per number of active row blocks (the choice is made once per workgroup, outside the loop: the accumulators of
-    // each copy live in the AGPRs from its first MFMA to the store)
-    auto main_loop = [&](auto nsa) {
+    PFH_STAMPW(7);
+    auto main_loop = [&](auto nsa) {          // one copy of the loop per number of active row blocks (chosen once per workgroup)
         for (int st = 0; st < nst; st++) {
             PFH_STAMP(0);
-            stage(st, nsa);
+            commit_stage();
             PFH_STAMP(1);
-            if (st + 2 < nst) load_stage(st + 2);
+            if (st + 1 < nst) load_stage(st + 1);
             PFH_STAMP(2);
             __syncthreads();
             PFH_STAMP(3);
+            stage_mfma(st, nsa);
+            PFH_STAMP(4);
+            __syncthreads();
+            PFH_STAMP(5);
         }
     };
-    if (nsb == 4) main_loop(std::integral_constant<int, 4>{});
-    else if (nsb == 3) main_loop(std::integral_constant<int, 3>{});
-    else if (nsb == 2) main_loop(std::integral_constant<int, 2>{});
-    else main_loop(std::integral_constant<int, 1>{});
-#pragma unroll
-    for (int c = 0; c < NC; c++)
-        if (col[c] < m.N) {
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-                if (s < nsb) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (row < rows) {
-                            const float v = acc[s][c][r] * rmul[row];
-                            const size_t o = (size_t)row_dst[row] * out_ld + col[c];
-                            if (a.out_bf16) reinterpret_cast<uint16_t*>(out_p)[o] = kr_f32_to_bf16(v);
-                            else out_p[o] = v;
-                        }
-                    }
-                }
-        }
+    if (two) main_loop(std::integral_constant<int, 2>{}); else main_loop(std::integral_constant<int, 1>{});
+    PFH_STAMPW(8);
+    {
+        const bool full = rows == (two ? 64 : 32) && n0 + BN <= m.N && !(a.scatter_rows && !a.single_expert);     // uniform
+        const int nsb = two ? 2 : 1;
+        if (full) { if (a.out_bf16) pfh_store_tile<NS, NC, true, true>(acc, nsb, rows, row0, rmul, row_dst, out_p, out_ld, col, m.N, lane);
+                    else pfh_store_tile<NS, NC, true, false>(acc, nsb, rows, row0, rmul, row_dst, out_p, out_ld, col, m.N, lane); }
+        else { if (a.out_bf16) pfh_store_tile<NS, NC, false, true>(acc, nsb, rows, row0, rmul, row_dst, out_p, out_ld, col, m.N, lane);
+               else pfh_store_tile<NS, NC, false, false>(acc, nsb, rows, row0, rmul, row_dst, out_p, out_ld, col, m.N, lane); }
+    }
+    PFH_STAMPW(9);
 }
-static void pfh2_launch(const KrPfGemmHArgs& a, int mt128, hipStream_t st) {
-    const size_t lds = (size_t)2 * PH2_STAGE + 3 * PH2_BM * 4;
-    (void)kr_lds_optin((const void*)kr_pfh2_gemm_kernel, 112 * 1024);
-    int ncb = (a.m.N + PH2_BN - 1) / PH2_BN;
-    for (int i = 0; i < a.n_extra; i++) ncb += (a.mx[i].N + PH2_BN - 1) / PH2_BN;
-    const int span = 8 * a.run;
-    dim3 grid(((mt128 + span - 1) / span) * span * ncb);
-    hipLaunchKernelGGL(kr_pfh2_gemm_kernel, grid, dim3(256), lds, st, a);
-}
+
 
 template <int NC, int BITS>
 static void pfh_launch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
@@ -645,42 +539,29 @@ void kr_launch_pfh_rows_bf16(const uint16_t* x, int rows, int ld, int K, uint16_
 }
 void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, uint16_t* out, float* mul, hipStream_t st) {
     if (rows <= 0) return;
-    if (act_mode == KR_ACT_GPTOSS) hipLaunchKernelGGL(kr_pfh_act_kernel<KR_ACT_GPTOSS>, dim3(rows), dim3(256), 0, st, gu, n, gu_ld, swiglu_limit, alpha, out, mul);
+    const bool oss = act_mode == KR_ACT_GPTOSS;
+#define KR_ACTW(C_) do { if (oss) hipLaunchKernelGGL((kr_pfh_act_wave_kernel<KR_ACT_GPTOSS, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, gu, rows, n, gu_ld, swiglu_limit, alpha, out, mul); \
+                         else hipLaunchKernelGGL((kr_pfh_act_wave_kernel<KR_ACT_SILU_MUL, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, gu, rows, n, gu_ld, swiglu_limit, alpha, out, mul); } while (0)
+    if (n <= 512) { KR_ACTW(1); return; }
+    if (n <= 1024) { KR_ACTW(2); return; }
+    if (n <= 2048) { KR_ACTW(4); return; }
+#undef KR_ACTW
+    if (oss) hipLaunchKernelGGL(kr_pfh_act_kernel<KR_ACT_GPTOSS>, dim3(rows), dim3(256), 0, st, gu, n, gu_ld, swiglu_limit, alpha, out, mul);
     else hipLaunchKernelGGL(kr_pfh_act_kernel<KR_ACT_SILU_MUL>, dim3(rows), dim3(256), 0, st, gu, n, gu_ld, swiglu_limit, alpha, out, mul);
 }
-// tuning hook: KR_PFH_FORM=1 forces the 64-row form, =2 the 128-row form wherever it applies (default: by problem size)
-static int pfh_form() { static int f = -1; if (f < 0) { const char* e = getenv("KR_PFH_FORM"); f = e ? atoi(e) : 0; } return f; }
-// the 128 x 256 form needs INT4 weights and enough workgroups to fill 256 CUs at one workgroup per CU
-static bool pfh2_dense_ok(const KrPfGemmHArgs& a, int rows) {
-    if (a.m.bits != 4 || pfh_form() == 1) return false;
-    if (pfh_form() == 2) return true;
-    long ncb = (a.m.N + PH2_BN - 1) / PH2_BN;
-    for (int i = 0; i < a.n_extra; i++) ncb += (a.mx[i].N + PH2_BN - 1) / PH2_BN;
-    return (long)((rows + PH2_BM - 1) / PH2_BM) * ncb >= 192;
-}
-int kr_pfh_expert_bm(long pairs, int E, const KrMatDev& w13, const KrMatDev& w2) {
-    if (w13.bits != 4 || w2.bits != 4 || pfh_form() == 1) return PFH_BM;
-    if (pfh_form() == 2) return PH2_BM;
-    return pairs >= 64L * E ? PH2_BM : PFH_BM;
-}
 void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
-                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows, int out_bf16, int run, int bm) {
+                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows, int out_bf16, int run) {
     KrPfGemmHArgs a{};
     a.m = m; a.a = a_h; a.a_mul = a_mul; a.topk = topk; a.gather_tokens = gather_tokens; a.scatter_rows = scatter_rows; a.out_bf16 = out_bf16;
     if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
     a.out = out; a.out_ld = out_ld; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
     a.run = (single_expert_rows > 0 || run < 1) ? 1 : run;
-    if (single_expert_rows > 0) {
-        if (pfh2_dense_ok(a, single_expert_rows)) pfh2_launch(a, (single_expert_rows + PH2_BM - 1) / PH2_BM, st);
-        else pfh_dispatch(a, (single_expert_rows + PFH_BM - 1) / PFH_BM, st);
-        return;
-    }
-    if (bm == PH2_BM && m.bits == 4) pfh2_launch(a, max_tiles, st); else pfh_dispatch(a, max_tiles, st);
+    const int mt = single_expert_rows > 0 ? (single_expert_rows + PFH_BM - 1) / PFH_BM : max_tiles;
+    pfh_dispatch(a, mt, st);
 }
 void kr_launch_pfh_gemm_multi(const KrMatDev* mats, float* const* outs, const int* out_lds, int n, const uint16_t* a_h, const float* a_mul, int M, hipStream_t st) {
     KrPfGemmHArgs a{};
     a.m = mats[0]; a.out = outs[0]; a.out_ld = out_lds[0]; a.a = a_h; a.a_mul = a_mul; a.topk = 1; a.single_expert = 1; a.total_rows = M; a.n_extra = n - 1; a.run = 1;
     for (int i = 1; i < n; i++) { a.mx[i - 1] = mats[i]; a.outx[i - 1] = outs[i]; a.out_ldx[i - 1] = out_lds[i]; }
-    if (pfh2_dense_ok(a, M)) pfh2_launch(a, (M + PH2_BM - 1) / PH2_BM, st);
-    else pfh_dispatch(a, (M + PFH_BM - 1) / PFH_BM, st);
+    pfh_dispatch(a, (M + PFH_BM - 1) / PFH_BM, st);
 }

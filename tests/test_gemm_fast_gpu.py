@@ -51,10 +51,11 @@ def _deq_t(w, sc, bits, gs=128):
 @pytest.mark.parametrize("H,I,E,k,M,n_shared,bits,w2_bits", [
     (256, 128, 8, 2, 200, 0, 4, 4),
     (512, 384, 16, 4, 333, 1, 4, 4),       # odd group count in w2 (half-empty last stage), shared expert, ragged tiles
-    (2048, 512, 32, 10, 700, 1, 4, 4),     # QCN expert shape; ~220 rows per expert: 128-row tiles (full and ragged), tiles of one expert share an XCD run
+    (2048, 512, 32, 10, 700, 1, 4, 4),     # QCN expert shape; ~220 rows per expert: full and ragged tiles, the tiles of one expert share an XCD run
     (512, 384, 16, 4, 333, 1, 8, 8),       # INT8-g128 experts (Q8 configuration)
     (256, 128, 8, 2, 200, 0, 4, 8),        # mixed: INT4 gate/up, INT8 down
-    (256, 768, 8, 2, 4096, 1, 4, 4),       # enough rows for the 128 x 256 one-wave-per-SIMD form: experts (128-row tiles) and the shared gate_up GEMM
+    (256, 768, 8, 2, 4096, 1, 4, 4),       # many full 64-row tiles (unguarded store path), rows of 768 intermediates (two chunks per lane in the activation kernel)
+    (256, 2304, 4, 2, 150, 0, 4, 4),       # intermediate rows longer than 2048: the block-per-row activation kernel
 ])
 def test_fast_expert_gemm_vs_exact(H, I, E, k, M, n_shared, bits, w2_bits):
     """STATED TOLERANCE: relative RMS error of the f32 outputs <= 1e-3 against the exact kernel, worst element <= 5e-3 of the largest output

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
         const double flop = 2.0 * M * (double)K * N;
         printf("rep %d: %.1f us, %.0f TFLOP/s | stage 3 of a mid-grid workgroup, shader clocks: ", rep, ms * 1e3, flop / (ms * 1e-3) / 1e12);
         if (getenv("KR_PFH_FORM") && atoi(getenv("KR_PFH_FORM")) == 2) printf("stage (MFMA + commit) %lld | load issue %lld | barrier %lld | total %lld\n", d(0, 1), d(1, 2), d(2, 3), d(0, 3));
-        else printf("commit %lld | load issue %lld | barrier %lld | MFMA block %lld | barrier %lld | total %lld\n", d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(0, 5));
+        else printf("commit %lld | load issue %lld | barrier %lld | MFMA block %lld | barrier %lld | total %lld || workgroup: prologue %lld | main loop %lld | epilogue %lld\n", d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(0, 5), d(6, 7), d(7, 8), d(8, 9));
     }
     return 0;
 }
