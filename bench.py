@@ -34,6 +34,7 @@ V2L = dict(hidden=2048, inter=1408, experts=64, topk=6, layers=27, n_shared=2, v
 Q235 = dict(hidden=4096, inter=1536, experts=128, topk=8, layers=94)      # Qwen3-235B-A22B expert shape (config 4; 16 experts per GPU at EP-8)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable with a float4 copy)
 I8_PEAK_TOPS = 4400.0      # dense int8 MFMA peak the roofline is priced against (MI355X_MICROARCH.md: >= 3944 TOP/s reached by a 16x16x64 microbenchmark)
+F16_PEAK_TFLOPS = 2500.0            # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 B4 = 0.515625              # bytes per INT4-g128 weight incl. bf16 group scale
 B8 = 1.015625              # INT8-g128
 KINDS = ["embed", "fused_add_rmsnorm", "proj_matvec", "la_conv", "la_recurrent", "gated_rmsnorm_silu", "gqa", "route_logits",
@@ -221,28 +222,37 @@ def build_v2lite(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
     return eng, st, keep
 
 
-def prefill_experts(eng, dims, L, M, torch):
+def prefill_experts(eng, dims, L, M, torch, gemm_fast=False):
     """Side measurement (NOT the headline value): the prefill expert path alone -- token sort + int8-MFMA grouped GEMM + combine of all
     L MoE layers for one chunk of M tokens with uniform random routing (k distinct experts per token).  Roofline per SURVEY 8(d):
     achieved = 2 * T * k * 3 * H * I / t (useful MACs x 2); `int8_TOPS_issued` counts both INT16-digit passes the exact arithmetic issues."""
-    from krasis_amd import GpuPrefillManager
+    from krasis_amd import GpuPrefillManager, _lib
     H, I, E, k = dims["hidden"], dims["inter"], dims["experts"], dims["topk"]
     g = torch.Generator(device="cuda").manual_seed(7)
     x = ((torch.rand((M, H), device="cuda", generator=g) - 0.5)).to(torch.bfloat16)
     ids = torch.rand((M, E), device="cuda", generator=g).topk(k, dim=1).indices.to(torch.int32)
     w = torch.softmax(torch.randn((M, k), device="cuda", generator=g), dim=1)
     mgr = GpuPrefillManager(eng, k)
-    for l in range(min(L, 2)):
-        mgr.forward(l, x, ids, w, routed_only=True)
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for l in range(L):
-        mgr.forward(l, x, ids, w, routed_only=True)
-    ev1.record(); torch.cuda.synchronize()
+    _lib.check(eng._lib.kr_moe_set_gemm_mode(eng._h, 1 if gemm_fast else 0))
+    try:
+        for l in range(min(L, 2)):
+            mgr.forward(l, x, ids, w, routed_only=True)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for l in range(L):
+            mgr.forward(l, x, ids, w, routed_only=True)
+        ev1.record(); torch.cuda.synchronize()
+    finally:
+        _lib.check(eng._lib.kr_moe_set_gemm_mode(eng._h, 0))
     ms = ev0.elapsed_time(ev1)
     macs = M * k * 3 * H * I * L                       # routed experts only
     useful = 2.0 * macs / (ms * 1e-3) / 1e12
+    if gemm_fast:
+        return {"tokens": M, "layers": L, "ms": ms, "tok_s_experts_only": M / (ms * 1e-3),
+                "roofline": {"bound": "mfma", "achieved": useful, "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s (f16 MFMA; 2 x useful MACs / s)", "frac": useful / F16_PEAK_TFLOPS},
+                "note": "experts only, tolerance form (kr_moe_set_gemm_mode 1): f16 rows x INT4 weights de-quantized in registers, one MFMA pass per MAC, f32 accumulation over "
+                        "the whole k range; outputs within 2-4e-4 relative RMS of the exact kernel (tests/test_gemm_fast_gpu.py)"}
     return {"tokens": M, "layers": L, "ms": ms, "tok_s_experts_only": M / (ms * 1e-3),
             "roofline": {"bound": "mfma", "achieved": useful, "peak": I8_PEAK_TOPS, "unit": "TOP/s (int8; 2 x useful MACs / s, SURVEY 8d)", "frac": useful / I8_PEAK_TOPS,
                          "peak_measured_ubench": 3944.0},
@@ -412,6 +422,10 @@ def side_config(name, rank, local_rank, args, torch):
     try:
         macs = qcn_gemm_macs_per_token(L) if qcn else v2l_gemm_macs_per_token(L)
         res["prefill"] = prefill_model(st, dims, macs, L, 8192, 1, torch)
+        for key, gfast in (("prefill_fast", False), ("prefill_fast_gemm", True)):       # tolerance modes: attention (+ delta rule), then the GEMMs as well
+            st.set_attention_mode(True, gemm_fast=gfast)
+            res[key] = prefill_model(st, dims, macs, L, 8192, 1, torch)
+        st.set_attention_mode(False)
         res["prefill_experts_only"] = prefill_experts(eng, dims, L if qcn else L, 8192, torch)
     except Exception as ex:
         res["prefill"] = {"error": repr(ex)}
@@ -575,6 +589,7 @@ def main():
         if pf_list:
             try:
                 side["prefill_experts_only"] = prefill_experts(eng, dims, L, 8192, torch)
+                side["prefill_experts_only_fast_gemm"] = prefill_experts(eng, dims, L, 8192, torch, gemm_fast=True)
             except Exception as ex:
                 side["prefill_experts_only"] = {"error": repr(ex)}
             if args.prefill_chunk:
@@ -582,8 +597,8 @@ def main():
             if args.prefill_depth:
                 st.set_prefill_depth(args.prefill_depth)
             macs = qcn_gemm_macs_per_token(L) if qcn else v2l_gemm_macs_per_token(L)
-            for key, fast in (("prefill", False), ("prefill_fast", True)):
-                st.set_attention_mode(fast)
+            for key, fast, gfast in (("prefill", False, False), ("prefill_fast", True, False), ("prefill_fast_gemm", True, True)):
+                st.set_attention_mode(fast, gemm_fast=gfast)
                 runs = []
                 for P in pf_list:
                     try:
@@ -597,6 +612,14 @@ def main():
                     side[key] = dict(ok[0]); side[key]["by_prompt_length"] = {str(r["tokens"]): round(r["value"], 1) for r in ok}
                     side[key]["attention"] = ("fast: causal flash attention on f16 MFMA (f32 online softmax; logits within ~1e-3 relative of the exact pass)" if fast else
                                               "exact: the CPU decode's operation order per query (bit-identical to token-by-token decode), vector ALUs")
+                    side[key]["gemm"] = ("tolerance form (KR_GEMM_FAST): f16 activation rows x weights de-quantized in registers on the f16 MFMA, f32 accumulation over the "
+                                         "whole k range -- the dataflow of the reference's GPU prompt pass; expert outputs within 2-4e-4 relative RMS of the exact kernel, "
+                                         "PPL within 1e-3 (tests/test_gemm_fast_gpu.py)" if gfast else
+                                         "exact: INT16 activation digits on the int8 MFMA, one f32 fma per 128-group -- bit-identical to the reference's CPU engine")
+                    if gfast:     # the useful-flop rate of the same GEMM MACs against the f16 matrix peak (one pass per MAC in this form)
+                        r0 = side[key]["roofline"]
+                        side[key]["roofline"] = {"bound": "mfma", "achieved": r0["achieved"], "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s (f16 MFMA; 2 x useful GEMM MACs / s)",
+                                                 "frac": r0["achieved"] / F16_PEAK_TFLOPS}
                     side[key]["note"] = ("whole-model prompt pass; `value` is the first listed length, by_prompt_length holds every length of "
                                          "--prefill-tokens (the reference benchmark's 20 434 / 35 139 / 49 863-token prompts, benchmark.py:434-505)")
                 else:

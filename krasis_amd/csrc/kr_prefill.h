@@ -4,6 +4,15 @@
 #include <stdint.h>
 #include "kr_kernels.h"
 
+// dense GEMMs: shape of the (row tile x column block) super-tile one XCD works on at a time (see kr_prefill_h.hip): up to 8 x 8, shrunk until there
+// are at least 3 super-tiles per XCD to balance
+static inline void kr_pf_super_tile(int nrt, int ncb, int* sr, int* sc, int* n_super) {
+    int r = nrt < 8 ? nrt : 8, c = ncb < 8 ? ncb : 8;
+    auto count = [&]() { return ((nrt + r - 1) / r) * ((ncb + c - 1) / c); };
+    while (count() < 24 && (r > 1 || c > 1)) { if (r >= c && r > 1) r = (r + 1) / 2; else c = (c + 1) / 2; }
+    *sr = r; *sc = c; *n_super = count();
+}
+
 struct KrPfSort {
     int* counts; int* offsets; int* cursor;        // [E]
     int* tile_expert; int* tile_row0; int* tile_rows;  // [max_tiles]

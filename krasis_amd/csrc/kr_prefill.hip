@@ -222,6 +222,7 @@ struct KrPfGemmArgs {
     // up to two MORE matrices that consume the same A rows (same K, same width): their column blocks follow those of `m` in the same launch
     // (q | k | v, qkvz | ba, shared gate_up | shared gate: a 64- or 1-column GEMM of its own is one latency-bound launch per chunk and layer)
     int n_extra; KrMatDev mx[2]; const uint32_t* wsumx[2]; float* outx[2]; int out_ldx[2];
+    int sr, sc;                             // dense launches: super-tile shape per XCD (kr_pf_super_tile), set by the launcher
 };
 
 #include "kr_prefill_gemm2.inc"

@@ -207,7 +207,8 @@ struct KrPfGemmHArgs {
     const int* tile_expert; const int* tile_row0; const int* tile_rows; const int* n_tiles;
     float* out; int out_ld;
     int single_expert; int total_rows; int scatter_rows; int out_bf16;
-    int run;                                 // consecutive row tiles given to one XCD (1: the exact kernel's mapping; > 1: the tiles of one expert share an L2)
+    int run;                                 // experts: consecutive row tiles given to one XCD (> 1: the tiles of one expert share an L2)
+    int sr, sc;                              // dense: super-tile of sr row tiles x sc column blocks per XCD (kr_pf_super_tile)
     int n_extra; KrMatDev mx[2]; float* outx[2]; int out_ldx[2];
 };
 
@@ -297,9 +298,19 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     PFH_STAMPW(6);
     const int ncb0 = (a.m.N + BN - 1) / BN, ncb1 = a.n_extra > 0 ? (a.mx[0].N + BN - 1) / BN : 0, ncb2 = a.n_extra > 1 ? (a.mx[1].N + BN - 1) / BN : 0;
     const int ncb = ncb0 + ncb1 + ncb2, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per = ncb * a.run, grp = slot / per, local = slot - grp * per;
-    const int mt = (grp * 8 + xcd) * a.run + local / ncb;
-    int cb = local % ncb;
+    int mt, cb;
+    if (a.single_expert) {
+        // dense: an XCD works on one SUPER-TILE of sr x sc (row tile, column block) pairs at a time -- its 32 CUs hold ~64 of them: sr A tiles and sc B
+        // slices (256 KiB each at K = 2048) serve sr * sc workgroups from one L2.  Row-tile-major order streams a fresh B slice from the Infinity
+        // Cache / HBM for every workgroup (half of all operand bytes; a CU pulls only ~10-13 B/clk from beyond its L2).
+        const int nrt = (a.total_rows + PFH_BM - 1) / PFH_BM, nsc = (ncb + a.sc - 1) / a.sc, ssz = a.sr * a.sc;
+        const int sup = (slot / ssz) * 8 + xcd, w = slot % ssz;
+        mt = (sup / nsc) * a.sr + w % a.sr; cb = (sup % nsc) * a.sc + w / a.sr;
+        if (mt >= nrt || cb >= ncb) return;
+    } else {
+        const int per = ncb * a.run, grp = slot / per, local = slot - grp * per;
+        mt = (grp * 8 + xcd) * a.run + local / ncb; cb = local % ncb;
+    }
     int expert, row0, rows;
     if (a.single_expert) { expert = 0; row0 = mt * PFH_BM; rows = a.total_rows - row0 < PFH_BM ? a.total_rows - row0 : PFH_BM; if (rows <= 0) return; }
     else { if (mt >= a.n_tiles[0]) return; expert = a.tile_expert[mt]; row0 = a.tile_row0[mt]; rows = a.tile_rows[mt]; }
@@ -517,9 +528,11 @@ static void pfh_launch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     (void)kr_lds_optin((const void*)kr_pfh_gemm_kernel<NC, BITS>, 80 * 1024);
     int ncb = (a.m.N + BN - 1) / BN;
     for (int i = 0; i < a.n_extra; i++) ncb += (a.mx[i].N + BN - 1) / BN;
-    const int span = 8 * a.run;
-    dim3 grid(((mt + span - 1) / span) * span * ncb);
-    hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS>), grid, dim3(256), lds, st, a);
+    KrPfGemmHArgs b = a;
+    dim3 grid;
+    if (a.single_expert) { int n_super; kr_pf_super_tile(mt, ncb, &b.sr, &b.sc, &n_super); grid = dim3(((n_super + 7) / 8) * 8 * b.sr * b.sc); }
+    else { const int span = 8 * a.run; grid = dim3(((mt + span - 1) / span) * span * ncb); }
+    hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS>), grid, dim3(256), lds, st, b);
 }
 static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     if (a.m.bits == 8) { pfh_launch<1, 8>(a, mt, st); return; }

@@ -12,10 +12,10 @@ python - <<'P'
 import json
 d=json.load(open('gpurun_out/r02_bench_final.json'))
 print({k:d[k] for k in ['value','ms_per_step']}, d['roofline']['step_frac_of_hbm_peak'], d['roofline']['kernel'], round(d['roofline']['frac'],4), d['roofline']['traffic_source'])
-for k in ['prefill','prefill_fast','prefill_experts_only','decode_long_context','decode_long_context_32k','decode_long_context_fast','decode_long_context_32k_fast','cpu_baseline']:
+for k in ['prefill','prefill_fast','prefill_fast_gemm','prefill_experts_only','prefill_experts_only_fast_gemm','decode_long_context','decode_long_context_32k','decode_long_context_fast','decode_long_context_32k_fast','cpu_baseline']:
     v=d.get(k)
     if isinstance(v,dict): v={kk:vv for kk,vv in v.items() if kk in('value','by_prompt_length','tok_s','ms','tok_s_experts_only','unit','cores','error')}
     print(k, v)
 for n,c in (d.get('configs') or {}).items():
-    print(n, {kk:(vv if not isinstance(vv,dict) else {a:b for a,b in vv.items() if a in ('value','by_prompt_length','tok_s')}) for kk,vv in c.items() if kk in ('value','prefill','prefill_fast','decode_long_context_fast','decode_long_context_32k_fast','error')})
+    print(n, {kk:(vv if not isinstance(vv,dict) else {a:b for a,b in vv.items() if a in ('value','by_prompt_length','tok_s')}) for kk,vv in c.items() if kk in ('value','decode_tok_s','prefill','prefill_fast','prefill_fast_gemm','decode_long_context_fast','decode_long_context_32k_fast','error')})
 P
