@@ -302,6 +302,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     }
     kmax = std::max(kmax, ad);
     const size_t C = CH;
+    if (s->gemm_fast && C * std::max(kmax, (size_t)H) * 2 >= (1ull << 32)) return kr_fail(KR_ERR_VALUE, "KR_GEMM_FAST: chunk of %d tokens x %zu values exceeds 4 GiB of f16 activations; lower the chunk", CH, std::max(kmax, (size_t)H));
     size_t total = 0, lac_floats = 0;
     if (s->attn_fast)
         for (auto& Ly : s->layers) if (Ly.attn == ATTN_LA && kr_pfm_la_chunk_ok(Ly.dk, Ly.dv, CH)) lac_floats = std::max(lac_floats, kr_pfm_la_chunk_scratch_floats(CH, Ly.nv));

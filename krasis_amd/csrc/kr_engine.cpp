@@ -920,6 +920,9 @@ static int moe_prefill_fast(kr_engine* e, Layer& L, const void* x_bf16, const in
     const size_t np = (size_t)CH * topk;
     const int max_tiles = (int)(np / 64) + E + 1;
     const size_t n_i32 = 3 * (size_t)E + 3 * (size_t)max_tiles + 4 + 2 * np;
+    // the tolerance GEMM addresses its A rows with 32-bit byte offsets (kr_prefill_h.hip): a pass holds at most 4 GiB of f16 rows
+    if ((size_t)CH * H * 2 >= (1ull << 32) || np * I * 2 >= (1ull << 32))
+        return kr_fail(KR_ERR_VALUE, "tolerance GEMM: %zu rows x %d values per pass exceed 4 GiB of f16 activations; lower kr_moe_set_prefill_pairs", np, H > I ? H : I);
     if (P.i32.ensure(n_i32 * 4) || P.xf.ensure((size_t)CH * H * 2) || P.xfm.ensure((size_t)CH * 4) || P.gu.ensure(np * 2 * I * 4) || P.hf.ensure(np * I * 2) ||
         P.hfm.ensure(np * 4) || P.eo.ensure(np * H * 4))
         return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");

@@ -24,7 +24,6 @@
 // 62 % of the LDS bandwidth at full matrix rate (the exact kernel's 64 x 32 wave tile needs 112 %).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <type_traits>
 
 #include "kr_lds_optin.h"
@@ -363,10 +362,10 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     const int nst = m.ngp;
     u32x4 pa[APT], pbw[NBW];
     uint32_t pspv[NC];
-    // Loads are never masked: a tile row past `rows` reads row 0 / token 0, a column tile past the last one re-reads the last tile, a thread whose
-    // 64 k lie past K re-reads the last valid 64 of the row -- all finite or irrelevant: rows and columns are independent in a GEMM, the stores are
-    // guarded and a group past ng gets scale 0.  One address per thread for A (its 8 chunks are contiguous: immediate offsets), a wave-uniform
-    // record base per B load (the 64 lanes of a wave copy one 1-KiB tile record row: scalar base + lane * 16).
+    // Loads are never masked: a tile row past `rows` reads row 0 / token 0, a column tile past the last one re-reads the last tile, a line past K
+    // re-reads a valid line of the row -- all finite or irrelevant: rows and columns are independent in a GEMM, the stores are guarded and a group
+    // past ng gets scale 0.  A: whole 128-byte lines per request, row offsets from the LDS table (above); B: a wave-uniform record base per load
+    // (the 64 lanes of a wave copy one 1-KiB tile record row: scalar base + lane * 16).
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int last_tile = (m.N - 1) >> 3;
     auto load_stage = [&](int st) {

@@ -1,4 +1,4 @@
-"""probe: one whole-model prompt pass of QCN (synthetic) for rocprofv3 --kernel-trace --stats.  argv: tokens [fast=1] [layers] [chunk] [depth]"""
+"""probe: one whole-model prompt pass of QCN (synthetic) for rocprofv3 --kernel-trace --stats.  argv: tokens [fast=1 (2: + GEMM tolerance form)] [layers] [chunk] [depth]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -7,7 +7,7 @@ P = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 fast = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 48
 eng, st, keep = bench.build_qcn(0, 0, L, P + 64, 4, True)
-st.set_attention_mode(bool(fast))
+st.set_attention_mode(bool(fast), gemm_fast=(fast == 2))
 if len(sys.argv) > 4 and int(sys.argv[4]): st.set_prefill_chunk(int(sys.argv[4]))
 if len(sys.argv) > 5 and int(sys.argv[5]): st.set_prefill_depth(int(sys.argv[5]))
 st.fill_state_synthetic(P + 64, 7)
