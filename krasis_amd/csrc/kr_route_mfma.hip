@@ -27,23 +27,29 @@ typedef uint32_t rm_u4 __attribute__((ext_vector_type(4)));
 // Batched form (blockIdx.z): the same 16-chain dot + fold tree is the reference's w_vc projection of MLA (mla_project_wvc_avx2, decode.rs:4555: two
 // 8-lane accumulators over alternating 8-blocks = chains j = 8 a + l over elements 16 m + j, then acc0 + acc1 and the hsum tree) -- head h reads
 // x + h * x_bs with row stride ldx, gate + h * g_bs, and writes logits + h * o_bs with row stride ldo.
-template <bool GATE_BF16>
+// SPLIT: the problem has too few 64 x 64 tiles to fill the chip (the router of a 1024-token chunk: 128 workgroups of 256-register waves on 256 CUs).
+// A workgroup then takes 32 tokens x 64 experts and its four waves are (expert block, CHAIN HALF): wave half c owns the 8 chains
+// j = {0,1,4,5,8,9,12,13} + 2 c, i.e. the sub-trees (c0 + c1) or (c2 + c3) of the fold; the halves meet through LDS and the last add is the
+// tree's root -- the same 15 adds in the same order.  Twice the workgroups, half the accumulators (two waves per SIMD).
+template <bool GATE_BF16, bool SPLIT>
 __global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* __restrict__ gate_row_, const float* __restrict__ x_, const float* __restrict__ bias,
                                                                    float* __restrict__ logits_, int T, int E, int H, int ldx, int ldo, size_t x_bs, size_t g_bs, size_t o_bs) {
     const float* x = x_ + (size_t)blockIdx.z * x_bs; float* logits = logits_ + (size_t)blockIdx.z * o_bs;
     const void* gate_row = GATE_BF16 ? (const void*)(reinterpret_cast<const uint16_t*>(gate_row_) + (size_t)blockIdx.z * g_bs)
                                      : (const void*)(reinterpret_cast<const float*>(gate_row_) + (size_t)blockIdx.z * g_bs);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int A_BYTES = 64 * RM_LDA * 4, B_BYTES = GATE_BF16 ? 64 * RM_LDB16 * 2 : 64 * RM_LDB32 * 4;
+    constexpr int TT = SPLIT ? 32 : 64, NJ = SPLIT ? 8 : 16, NA = TT / 8;
+    constexpr int A_BYTES = TT * RM_LDA * 4, B_BYTES = GATE_BF16 ? 64 * RM_LDB16 * 2 : 64 * RM_LDB32 * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int t0 = blockIdx.y * 64, e0 = blockIdx.x * 64;
-    const int tb = (wave >> 1) * 32, eb = (wave & 1) * 32;         // this wave's block inside the tile
-    // ---- global -> register staging: x tile 64 rows x 128 floats (8 float4 per thread), gate tile 64 rows x 128 values
-    rm_f4 pa[8]; rm_u4 pb[GATE_BF16 ? 4 : 8];
+    const int t0 = blockIdx.y * TT, e0 = blockIdx.x * 64;
+    const int tb = SPLIT ? 0 : (wave >> 1) * 32, eb = (wave & 1) * 32;         // this wave's block inside the tile
+    const int ch = SPLIT ? (wave >> 1) : 0;                                       // its chain half
+    // ---- global -> register staging: x tile TT rows x 128 floats, gate tile 64 rows x 128 values
+    rm_f4 pa[NA]; rm_u4 pb[GATE_BF16 ? 4 : 8];
     auto load_stage = [&](int st) {
         const int k0 = st * RM_KS;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < NA; i++) {
             const int u = tid + 256 * i, row = u >> 5, c4 = (u & 31) * 4;
             const int tr = min(t0 + row, T - 1);
             pa[i] = *reinterpret_cast<const rm_f4*>(x + (size_t)tr * ldx + k0 + c4);
@@ -68,7 +74,7 @@ __global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* _
         float* As = reinterpret_cast<float*>(smem + buf * (A_BYTES + B_BYTES));
         char* Bs = smem + buf * (A_BYTES + B_BYTES) + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < 8; i++) { const int u = tid + 256 * i, row = u >> 5, c4 = (u & 31) * 4; *reinterpret_cast<rm_f4*>(As + row * RM_LDA + c4) = pa[i]; }
+        for (int i = 0; i < NA; i++) { const int u = tid + 256 * i, row = u >> 5, c4 = (u & 31) * 4; *reinterpret_cast<rm_f4*>(As + row * RM_LDA + c4) = pa[i]; }
         if (GATE_BF16) {
 #pragma unroll
             for (int i = 0; i < 4; i++) { const int u = tid + 256 * i, row = u >> 4, c8 = (u & 15) * 8; *reinterpret_cast<rm_u4*>(Bs + (row * RM_LDB16 + c8) * 2) = pb[i]; }
@@ -77,9 +83,9 @@ __global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* _
             for (int i = 0; i < 8; i++) { const int u = tid + 256 * i, row = u >> 5, c4 = (u & 31) * 4; *reinterpret_cast<rm_u4*>(Bs + (row * RM_LDB32 + c4) * 4) = pb[i]; }
         }
     };
-    rm_v16f acc[16];
+    rm_v16f acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 16; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[j][i] = 0.0f;
     const int nst = H / RM_KS;
@@ -93,25 +99,40 @@ __global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* _
         const char* Bs = smem + buf * (A_BYTES + B_BYTES) + A_BYTES;
 #pragma unroll
         for (int m = 0; m < RM_KS / 32; m++) {            // 32 consecutive k: the (s, s+1) pair of every chain
-            float a[16], b[16];
+            float a[NJ], b[NJ];
+            if (SPLIT) {      // local chain 2 q + i = chain 4 q + 2 ch + i: two consecutive values per group of four
+                typedef float rm_f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int q = 0; q < 4; q++) { const rm_f4 v = *reinterpret_cast<const rm_f4*>(As + 32 * m + 4 * q); a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w; }
-            if (GATE_BF16) {
-                const uint16_t* bp = reinterpret_cast<const uint16_t*>(Bs) + (eb + r) * RM_LDB16 + 32 * m + 16 * h;
+                for (int q = 0; q < 4; q++) { const rm_f2 v = *reinterpret_cast<const rm_f2*>(As + 32 * m + 4 * q + 2 * ch); a[2 * q] = v.x; a[2 * q + 1] = v.y; }
+                if (GATE_BF16) {
+                    const uint16_t* bp = reinterpret_cast<const uint16_t*>(Bs) + (eb + r) * RM_LDB16 + 32 * m + 16 * h + 2 * ch;
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const rm_u4 v = *reinterpret_cast<const rm_u4*>(bp + 8 * q);
-                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+                    for (int q = 0; q < 4; q++) { const uint32_t w = *reinterpret_cast<const uint32_t*>(bp + 4 * q); b[2 * q] = __uint_as_float(w << 16); b[2 * q + 1] = __uint_as_float(w & 0xFFFF0000u); }
+                } else {
+                    const float* bp = reinterpret_cast<const float*>(Bs) + (eb + r) * RM_LDB32 + 32 * m + 16 * h + 2 * ch;
 #pragma unroll
-                    for (int p = 0; p < 4; p++) { b[8 * q + 2 * p] = __uint_as_float(w4[p] << 16); b[8 * q + 2 * p + 1] = __uint_as_float(w4[p] & 0xFFFF0000u); }
+                    for (int q = 0; q < 4; q++) { const rm_f2 v = *reinterpret_cast<const rm_f2*>(bp + 4 * q); b[2 * q] = v.x; b[2 * q + 1] = v.y; }
                 }
             } else {
-                const float* bp = reinterpret_cast<const float*>(Bs) + (eb + r) * RM_LDB32 + 32 * m + 16 * h;
 #pragma unroll
-                for (int q = 0; q < 4; q++) { const rm_f4 v = *reinterpret_cast<const rm_f4*>(bp + 4 * q); b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w; }
+                for (int q = 0; q < 4; q++) { const rm_f4 v = *reinterpret_cast<const rm_f4*>(As + 32 * m + 4 * q); a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w; }
+                if (GATE_BF16) {
+                    const uint16_t* bp = reinterpret_cast<const uint16_t*>(Bs) + (eb + r) * RM_LDB16 + 32 * m + 16 * h;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const rm_u4 v = *reinterpret_cast<const rm_u4*>(bp + 8 * q);
+                        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int p = 0; p < 4; p++) { b[8 * q + 2 * p] = __uint_as_float(w4[p] << 16); b[8 * q + 2 * p + 1] = __uint_as_float(w4[p] & 0xFFFF0000u); }
+                    }
+                } else {
+                    const float* bp = reinterpret_cast<const float*>(Bs) + (eb + r) * RM_LDB32 + 32 * m + 16 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const rm_f4 v = *reinterpret_cast<const rm_f4*>(bp + 4 * q); b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w; }
+                }
             }
 #pragma unroll
-            for (int j = 0; j < 16; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[j], 0, 0, 0);
         }
         if (st + 1 < nst) commit_stage(buf ^ 1);          // the other buffer: its readers finished before the barrier that ended stage st - 1
         __syncthreads();
@@ -119,12 +140,44 @@ __global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* _
     // ---- the reference's tree over the 16 chains (decode.rs:1419-1427), then + bias (decode.rs:3292)
     const int e = e0 + eb + r;
     const float bv = (bias && e < E) ? bias[e] : 0.0f;
+    if (SPLIT) {
+        // local chains l = 2 q + i <-> chain 4 q + 2 ch + i: (l0 + l4) + (l2 + l6) is (a0 + a8) + (a4 + a12) for half 0 and (a2 + a10) + (a6 + a14) for half 1
+        float* xch = reinterpret_cast<float*>(smem) + ((wave & 1) * 64 + lane) * 16;      // the stage buffers are free after the last barrier
+        float half[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float ca = (acc[0][i] + acc[4][i]) + (acc[2][i] + acc[6][i]);
+            const float cb = (acc[1][i] + acc[5][i]) + (acc[3][i] + acc[7][i]);
+            half[i] = ca + cb;
+        }
+        if (ch == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) *reinterpret_cast<rm_f4*>(xch + 4 * q) = rm_f4{half[4 * q], half[4 * q + 1], half[4 * q + 2], half[4 * q + 3]};
+        }
+        __syncthreads();
+        if (ch == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const rm_f4 o = *reinterpret_cast<const rm_f4*>(xch + 4 * q);
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int i = 4 * q + p;
+                    float v = half[i] + ov[p];
+                    if (bias) v += bv;
+                    const int t = t0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (t < T && e < E) logits[(size_t)t * ldo + e] = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const float c0 = (acc[0][i] + acc[8][i]) + (acc[4][i] + acc[12][i]);
-        const float c1 = (acc[1][i] + acc[9][i]) + (acc[5][i] + acc[13][i]);
-        const float c2 = (acc[2][i] + acc[10][i]) + (acc[6][i] + acc[14][i]);
-        const float c3 = (acc[3][i] + acc[11][i]) + (acc[7][i] + acc[15][i]);
+        const float c0 = (acc[0][i] + acc[SPLIT ? 0 : 8][i]) + (acc[4][i] + acc[SPLIT ? 0 : 12][i]);
+        const float c1 = (acc[1][i] + acc[SPLIT ? 0 : 9][i]) + (acc[5][i] + acc[SPLIT ? 0 : 13][i]);
+        const float c2 = (acc[2][i] + acc[SPLIT ? 0 : 10][i]) + (acc[6][i] + acc[SPLIT ? 0 : 14][i]);
+        const float c3 = (acc[3][i] + acc[SPLIT ? 0 : 11][i]) + (acc[7][i] + acc[SPLIT ? 0 : 15][i]);
         float v = (c0 + c1) + (c2 + c3);
         if (bias) v += bv;
         const int t = t0 + tb + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -136,16 +189,16 @@ __global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* _
 static int rm_launch(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* out, int T, int E, int H, int ldx, int ldo, int batch, size_t x_bs,
                      size_t g_bs, size_t o_bs, hipStream_t st) {
     if (H % RM_KS || T < 1 || E < 1 || batch < 1) return 1;
-    const dim3 grid((E + 63) / 64, (T + 63) / 64, batch);
-    if (gate_bf16) {
-        const size_t lds = 2 * (size_t)(64 * RM_LDA * 4 + 64 * RM_LDB16 * 2);
-        if (kr_lds_optin(reinterpret_cast<const void*>(kr_route_logits_mfma_kernel<true>), lds)) return 1;
-        hipLaunchKernelGGL(kr_route_logits_mfma_kernel<true>, grid, dim3(256), lds, st, gate_row, x, bias, out, T, E, H, ldx, ldo, x_bs, g_bs, o_bs);
-    } else {
-        const size_t lds = 2 * (size_t)(64 * RM_LDA * 4 + 64 * RM_LDB32 * 4);
-        if (kr_lds_optin(reinterpret_cast<const void*>(kr_route_logits_mfma_kernel<false>), lds)) return 1;
-        hipLaunchKernelGGL(kr_route_logits_mfma_kernel<false>, grid, dim3(256), lds, st, gate_row, x, bias, out, T, E, H, ldx, ldo, x_bs, g_bs, o_bs);
-    }
+    // too few 64 x 64 tiles for the chip: 32-token tiles with the chains split over wave pairs (bit-identical, see the kernel)
+    const bool split = (long)((E + 63) / 64) * ((T + 63) / 64) * batch < 256;
+    const int tt = split ? 32 : 64;
+    const dim3 grid((E + 63) / 64, (T + tt - 1) / tt, batch);
+    const size_t lds = 2 * ((size_t)tt * RM_LDA * 4 + (gate_bf16 ? (size_t)64 * RM_LDB16 * 2 : (size_t)64 * RM_LDB32 * 4));
+#define KR_RM(B_, S_) do { if (kr_lds_optin(reinterpret_cast<const void*>(kr_route_logits_mfma_kernel<B_, S_>), lds)) return 1; \
+        hipLaunchKernelGGL((kr_route_logits_mfma_kernel<B_, S_>), grid, dim3(256), lds, st, gate_row, x, bias, out, T, E, H, ldx, ldo, x_bs, g_bs, o_bs); } while (0)
+    if (gate_bf16) { if (split) KR_RM(true, true); else KR_RM(true, false); }
+    else { if (split) KR_RM(false, true); else KR_RM(false, false); }
+#undef KR_RM
     return 0;
 }
 int kr_launch_route_logits_mfma(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* logits, int T, int E, int H, hipStream_t st) {
