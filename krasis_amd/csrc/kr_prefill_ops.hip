@@ -93,13 +93,18 @@ __global__ void kr_pfm_quant_f32_kernel(const float* __restrict__ x, int ld, int
 }
 
 // ---- linear attention: causal conv + SiLU + L2 norms + gates for every token (decode.rs:3815-3945) -------------------------
-// grid (nk, C).  Tap j of token t is X(t-3+j): a chunk row for >= 0, the carried conv state slot 4+i for i < 0.
-__global__ void __launch_bounds__(256) kr_pfm_la_conv_kernel(const KrPfmLaArgs a) {
+// grid (nk, ceil(C / 8)): a workgroup takes one key head and EIGHT consecutive tokens.  Tap j of token t is X(t-3+j): a chunk row for >= 0, the carried
+// conv state slot 4+i for i < 0.  A thread walks its channel down the 8 tokens with the 4-tap window in registers (11 row reads instead of 32; the
+// one-token form launched 16 384 workgroups per chunk whose whole life was one load -> barrier -> 16-step norm chain -> barrier -> store sequence:
+// 85 us per 1024-token chunk).  Per value the arithmetic is unchanged: the tap products are added left to right, SiLU with the degree-5 sigmoid,
+// the two L2 norms as 8-lane fma chains over the head's 128 conv outputs.
+#define PFC_TT 8
+__global__ void __launch_bounds__(256) kr_pfm_la_conv_kernel(const KrPfmLaArgs a, int C) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int kh = blockIdx.x, t = blockIdx.y, dk = a.dk, dv = a.dv, hr = a.hr, nk = a.nk;
+    const int kh = blockIdx.x, t0 = blockIdx.y * PFC_TT, dk = a.dk, dv = a.dv, hr = a.hr, nk = a.nk;
+    const int nt = C - t0 < PFC_TT ? C - t0 : PFC_TT;
     const int group_dim = 2 * dk + 2 * dv * hr, key_dim = nk * dk, nvdk = a.nv * dk, nvdv = a.nv * dv;
-    float* qc = sm; float* kc = sm + dk; float* nrm = sm + 2 * dk;
-    const float* src = a.qkvz + (size_t)t * a.ld_qkvz + (size_t)kh * group_dim;
+    float* qc = sm; float* kc = sm + PFC_TT * dk; float* nrm = sm + 2 * PFC_TT * dk;       // [8][dk], [8][dk], [8][2]
     const int nch = 2 * dk + hr * dv;
     for (int c = threadIdx.x; c < nch; c += 256) {
         int ch, off;
@@ -107,22 +112,27 @@ __global__ void __launch_bounds__(256) kr_pfm_la_conv_kernel(const KrPfmLaArgs a
         else if (c < 2 * dk) { ch = key_dim + kh * dk + (c - dk); off = c; }
         else { const int r = (c - 2 * dk) / dv, i = (c - 2 * dk) % dv; ch = 2 * key_dim + (kh * hr + r) * dv + i; off = 2 * dk + r * dv + i; }
         const float* cs = a.conv_state + (size_t)ch * 4;
-        const float* cw = a.conv_w + (size_t)ch * 4;
-        float s[4];
+        const float4 cw = *reinterpret_cast<const float4*>(a.conv_w + (size_t)ch * 4);
+        const float* col = a.qkvz + (size_t)kh * group_dim + off;
+        float x[PFC_TT + 3];                       // X(t0 - 3) .. X(t0 + 7) of this channel, all requested before the first use
 #pragma unroll
-        for (int j = 0; j < 4; j++) { const int i = t - 3 + j; s[j] = i >= 0 ? a.qkvz[(size_t)i * a.ld_qkvz + (size_t)kh * group_dim + off] : cs[4 + i]; }
-        float co = s[0] * cw[0] + s[1] * cw[1] + s[2] * cw[2] + s[3] * cw[3];
-        co = co * kr_sigmoid_poly5(co);
-        if (c < dk) qc[c] = co;
-        else if (c < 2 * dk) kc[c - dk] = co;
-        else a.v[(size_t)t * nvdv + (ch - 2 * key_dim)] = co;
+        for (int j = 0; j < PFC_TT + 3; j++) { const int i = t0 - 3 + j; x[j] = i < 0 ? cs[4 + i] : (i < C ? col[(size_t)i * a.ld_qkvz] : 0.0f); }
+#pragma unroll
+        for (int tt = 0; tt < PFC_TT; tt++)
+            if (tt < nt) {
+                float co = x[tt] * cw.x + x[tt + 1] * cw.y + x[tt + 2] * cw.z + x[tt + 3] * cw.w;
+                co = co * kr_sigmoid_poly5(co);
+                if (c < dk) qc[tt * dk + c] = co;
+                else if (c < 2 * dk) kc[tt * dk + (c - dk)] = co;
+                else a.v[(size_t)(t0 + tt) * nvdv + (ch - 2 * key_dim)] = co;
+            }
     }
-    for (int c = threadIdx.x; c < hr * dv; c += 256) {
-        const int r = c / dv, i = c % dv;
-        a.z[(size_t)t * nvdv + (size_t)(kh * hr + r) * dv + i] = src[2 * dk + hr * dv + r * dv + i];
+    for (int c = threadIdx.x; c < nt * hr * dv; c += 256) {
+        const int tt = c / (hr * dv), rem = c % (hr * dv), r = rem / dv, i = rem % dv;
+        a.z[(size_t)(t0 + tt) * nvdv + (size_t)(kh * hr + r) * dv + i] = a.qkvz[(size_t)(t0 + tt) * a.ld_qkvz + (size_t)kh * group_dim + 2 * dk + hr * dv + r * dv + i];
     }
-    if ((int)threadIdx.x < hr) {   // decode.rs:3891-3901
-        const int r = threadIdx.x, vh = kh * hr + r;
+    if ((int)threadIdx.x < nt * hr) {   // decode.rs:3891-3901
+        const int tt = threadIdx.x / hr, r = threadIdx.x % hr, vh = kh * hr + r, t = t0 + tt;
         const float* ba = a.ba + (size_t)t * a.ld_ba;
         const float b_raw = ba[kh * 2 * hr + r], a_p = ba[kh * 2 * hr + hr + r];
         a.beta[(size_t)t * a.nv + vh] = 1.0f / (1.0f + kr_expf(-b_raw));
@@ -132,17 +142,17 @@ __global__ void __launch_bounds__(256) kr_pfm_la_conv_kernel(const KrPfmLaArgs a
         a.gexp[(size_t)t * a.nv + vh] = kr_expf(g);   // decode.rs:1293 decays the state by exp(g)
     }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        const int which = threadIdx.x >> 3, l = threadIdx.x & 7;
-        const float ss = kr_pfm_sumsq8(which ? kc : qc, dk, l);
-        if (l == 0) nrm[which] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+    if (threadIdx.x < 16 * PFC_TT) {            // 8 lanes per (token, q | k) chain
+        const int tt = threadIdx.x >> 4, which = (threadIdx.x >> 3) & 1, l = threadIdx.x & 7;
+        const float ss = kr_pfm_sumsq8((which ? kc : qc) + tt * dk, dk, l);
+        if (l == 0) nrm[tt * 2 + which] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
     }
     __syncthreads();
-    const float inv_q = nrm[0] * a.scale, inv_k = nrm[1] * 1.0f;
-    for (int c = threadIdx.x; c < hr * dk; c += 256) {
-        const int r = c / dk, i = c % dk, vh = kh * hr + r;
-        a.q[(size_t)t * nvdk + (size_t)vh * dk + i] = qc[i] * inv_q;
-        a.k[(size_t)t * nvdk + (size_t)vh * dk + i] = kc[i] * inv_k;
+    for (int c = threadIdx.x; c < nt * hr * dk; c += 256) {
+        const int tt = c / (hr * dk), rem = c % (hr * dk), r = rem / dk, i = rem % dk, vh = kh * hr + r;
+        const float inv_q = nrm[tt * 2] * a.scale, inv_k = nrm[tt * 2 + 1] * 1.0f;
+        a.q[(size_t)(t0 + tt) * nvdk + (size_t)vh * dk + i] = qc[tt * dk + i] * inv_q;
+        a.k[(size_t)(t0 + tt) * nvdk + (size_t)vh * dk + i] = kc[tt * dk + i] * inv_k;
     }
 }
 
@@ -681,7 +691,7 @@ void kr_launch_pfm_quant_f32(const float* x, int rows, int ld, int K, int8_t* xh
 }
 int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out, const float* norm_w, float* gated_out, int C, float eps, hipStream_t st) {
     if (a.dv > 256 || a.dv % 8 || a.dv < a.dk || a.dk % 8) return 1;
-    hipLaunchKernelGGL(kr_pfm_la_conv_kernel, dim3(a.nk, C), dim3(256), (size_t)(2 * a.dk + 4) * 4, st, a);
+    hipLaunchKernelGGL(kr_pfm_la_conv_kernel, dim3(a.nk, (C + PFC_TT - 1) / PFC_TT), dim3(256), (size_t)(2 * PFC_TT * a.dk + 2 * PFC_TT) * 4, st, a, C);
     const int conv_dim = 2 * a.nk * a.dk + a.nv * a.dv;
     hipLaunchKernelGGL(kr_pfm_la_conv_state_kernel, dim3((conv_dim + 255) / 256), dim3(256), 0, st, a, C);
     if (a.fast && a.lac && kr_pfm_la_chunk_ok(a.dk, a.dv, C) && kr_launch_pfm_la_chunked(a, recur_state, recur_out, a.lac, C, st) == 0) {}
