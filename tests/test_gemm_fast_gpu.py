@@ -152,6 +152,28 @@ def test_gemm_fast_prompt_pass_logits_and_perplexity(kinds, fp8):
     assert lrel <= 1e-2, lrel
 
 
+@pytest.mark.parametrize("cfg", [dict(kv_max=700), dict(lora=True, seed=2, kv_max=640)])
+def test_gemm_fast_mla_prompt_pass(cfg):
+    """MLA layers (direct and LoRA query paths: kv_a / q_a / q_b / o projections, dense MLP or experts) with both FAST bits against the exact pass.
+    STATED TOLERANCE: last-position logits within 1e-2 of the largest logit (FP16 latent cache), greedy token unchanged."""
+    from tests.test_mla_gpu import build as build_mla
+    res = {}
+    for mode in (False, True):
+        st, eng, orc, keep, d = build_mla(**cfg)
+        st.set_attention_mode(mode, gemm_fast=mode)
+        toks = [int(x) for x in np.random.default_rng(3).integers(0, d["V"], 150)]
+        st.set_prefill_chunk(64)
+        pl = np.empty(d["V"], F)
+        ptok = st.prefill(toks, 0, pl.ctypes.data)
+        res[mode] = (pl.copy(), ptok)
+    rel = float(np.abs(res[False][0] - res[True][0]).max() / np.abs(res[False][0]).max())
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/r02_gemm_fast_err.txt", "a") as f:
+            f.write(f"mla prompt pass cfg={cfg}: logits rel {rel:.3e}\n")
+    assert np.isfinite(res[True][0]).all() and rel <= 1e-2, rel
+    assert res[False][1] == res[True][1]
+
+
 def test_gemm_mode_validation():
     from krasis_amd._lib import check
     eng, experts, shared, rng, torch = _setup(256, 128, 8, 2)
