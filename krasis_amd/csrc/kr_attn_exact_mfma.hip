@@ -1,0 +1,208 @@
+// kr_attn_exact_mfma.hip -- passes A (scores) and C (P.V) of the EXACT prompt-pass attention (decode.rs:4194-4281 order) on the f32 matrix
+// cores, BIT-IDENTICAL to the vector-ALU kernels kr_pfm_gqa_scores*_kernel / kr_pfm_gqa_pv_kernel of kr_prefill_ops.hip (which stay as the
+// fallback for group sizes that do not divide 32, and are what these were checked against: every prompt-pass == decode test runs them).
+//
+// v_mfma_f32_32x32x2_f32 computes D = fma(A[.][1], B[1][.], fma(A[.][0], B[0][.], C)): two fused multiply-adds in k order, no intermediate
+// rounding beyond the fma's own -- a sequential f32 fma chain IS an accumulator fed with consecutive pairs (the router logits and the MLA
+// projections of this round use the same fact, kr_route_mfma.hip).
+//   * scores: the reference keeps 8 fma lanes per (query, position): lane l walks q[8b + l] * k[8b + l] over b ascending, then
+//     ((l0 + l4) + (l1 + l5)) + ((l2 + l6) + (l3 + l7)), then * sm_scale.  Lane l of a 32-query x 32-position block is accumulator l fed with
+//     the pairs (b, b + 1): A[q][k] = q[8 (2m + k) + l], B[k][p] = K[p][8 (2m + k) + l] -- 8 accumulators per block, hd / 16 MFMAs each.
+//   * P.V: out[q][d] = chain over positions ascending of fma(p[q][pos], V[pos][d]): ONE accumulator per 32 x 32 (query, dim) block with the
+//     positions as k.  A position a query must not see enters with p = 0: fma(0, v, acc) = acc exactly (v is finite: cache rows past the
+//     last position of the tile are never read).
+// Both run at the f32-MFMA rate, which is the vector fma rate on CDNA4 -- the gain is structural: operands staged once in LDS for 32 x 32
+// outputs, no per-lane broadcast traffic (the vector P.V pass was bound by the LDS return path, the scores pass by 4 LDS reads per 4 fma).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "kr_device.h"
+#include "kr_libm.h"
+#include "kr_prefill_ops.h"
+
+typedef float xm_v16f __attribute__((ext_vector_type(16)));
+typedef float xm_f4 __attribute__((ext_vector_type(4)));
+
+#define XM_LDF 68          // floats per 64-float LDS row (272 B: consecutive rows 4 banks apart)
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// pass A.  grid (position tiles of 64, row tiles of 64 queries, nkv), 4 waves = 2 x 2 blocks of 32 queries x 32 positions.
+// A query row r of the tile is (token t0 + r / group, head kvh * group + r % group), t0 = tile * (64 / group).
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <bool FP8>
+__global__ void __launch_bounds__(256) kr_pfm_gqa_scores_mfma_kernel(const KrPfmGqaArgs a, float* __restrict__ sc, int sc_ld, int C) {
+    __shared__ __attribute__((aligned(16))) float Qs[64 * XM_LDF];
+    __shared__ __attribute__((aligned(16))) float Ks[64 * XM_LDF];
+    const int hd = a.hd, group = a.nh / a.nkv, kvh = blockIdx.z, TT = 64 / group, t0 = blockIdx.y * TT, kvs = a.nkv * hd;
+    const int tn = min(TT, C - t0), R = group * tn;
+    const int p_lo = blockIdx.x * 64, p_max = a.pos0 + t0 + tn - 1;          // last position any query of the tile may see
+    if (p_lo > p_max) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, kh = lane >> 5;
+    const int rb = (wave >> 1) * 32, pb = (wave & 1) * 32;                    // this wave's block inside the tile
+    xm_v16f acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[j][i] = 0.0f;
+    for (int d0 = 0; d0 < hd; d0 += 64) {
+        __syncthreads();                                                      // the previous stage's readers are done
+        // q: 64 rows x 64 floats, 16 float4 per row, 4 per thread
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+            const int rr = row < R ? row : R - 1, tt = rr / group, hh = kvh * group + rr % group;
+            *reinterpret_cast<xm_f4*>(Qs + row * XM_LDF + c4) = *reinterpret_cast<const xm_f4*>(a.q_out + (size_t)(t0 + tt) * a.nh * hd + (size_t)hh * hd + d0 + c4);
+        }
+        // K: 64 positions x 64 values (positions past p_max re-read p_max: their scores are never stored)
+        if (FP8) {
+            const int pos = min(p_lo + (tid >> 2), p_max), c16 = (tid & 3) * 16;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(a.k_cache) + (size_t)pos * kvs + (size_t)kvh * hd + d0 + c16);
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+            float* dst = Ks + (tid >> 2) * XM_LDF + c16;
+#pragma unroll
+            for (int j = 0; j < 16; j++) dst[j] = kr_e4m3_to_f32((uint8_t)(ww[j >> 2] >> (8 * (j & 3))));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int u = tid + 256 * i, prow = u >> 3, c8 = (u & 7) * 8;
+                const int pos = min(p_lo + prow, p_max);
+                const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(a.k_cache) + (size_t)pos * kvs + (size_t)kvh * hd + d0 + c8);
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+                float* dst = Ks + prow * XM_LDF + c8;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    dst[2 * j] = __half2float(__ushort_as_half((uint16_t)(ww[j] & 0xFFFFu)));
+                    dst[2 * j + 1] = __half2float(__ushort_as_half((uint16_t)(ww[j] >> 16)));
+                }
+            }
+        }
+        __syncthreads();
+        const float* qp = Qs + (rb + r31) * XM_LDF + 8 * kh;
+        const float* kp = Ks + (pb + r31) * XM_LDF + 8 * kh;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {                                         // 16 consecutive d: the (b, b + 1) pair of every lane chain
+            const xm_f4 q0 = *reinterpret_cast<const xm_f4*>(qp + 16 * m), q1 = *reinterpret_cast<const xm_f4*>(qp + 16 * m + 4);
+            const xm_f4 k0 = *reinterpret_cast<const xm_f4*>(kp + 16 * m), k1 = *reinterpret_cast<const xm_f4*>(kp + 16 * m + 4);
+            const float qa[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w}, ka[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j], ka[j], acc[j], 0, 0, 0);
+        }
+    }
+    // hsum8 of the reference (kr_pfm_hsum8: xor 4, xor 1, xor 2), * sm_scale, causal store
+    const int pos = p_lo + pb + r31;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int r = rb + (i & 3) + 8 * (i >> 2) + 4 * kh;
+        const float sv = ((acc[0][i] + acc[4][i]) + (acc[1][i] + acc[5][i])) + ((acc[2][i] + acc[6][i]) + (acc[3][i] + acc[7][i]));
+        if (r < R) {
+            const int tt = r / group, hh = kvh * group + r % group;
+            if (pos <= a.pos0 + t0 + tt) sc[((size_t)(t0 + tt) * a.nh + hh) * sc_ld + pos] = sv * a.sm_scale;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// pass C.  grid (row tiles of 32 queries, nkv), 4 waves; wave w owns the 32-dim blocks w * NB .. w * NB + NB - 1 of the head (NB = hd / 128,
+// head_dim 64: waves 0 and 1 one block each).  64 positions per stage: probabilities (masked) as f32 and the raw V rows in LDS.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <bool FP8, int HD>
+__global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaArgs a, const float* __restrict__ sc, int sc_ld, int C) {
+    constexpr int ESZ = FP8 ? 1 : 2, VROW = HD * ESZ + 64;                    // bytes per V row in LDS (+ 64: the two k halves land 16 banks apart)
+    constexpr int NB = HD >= 128 ? HD / 128 : 1, NW = HD >= 128 ? 4 : HD / 32;   // blocks per wave, waves that own blocks
+    constexpr int VCH = 64 * HD * ESZ / 16 / 256;                             // 16-byte V chunks per thread per stage (8 / 4 / 2 for f16, 4 / 2 / 1 for e4m3)
+    __shared__ __attribute__((aligned(16))) float Ps[32 * XM_LDF];
+    __shared__ __attribute__((aligned(16))) char Vs[64 * VROW];
+    const int group = a.nh / a.nkv, kvh = blockIdx.y, TT = 32 / group, t0 = blockIdx.x * TT, kvs = a.nkv * HD;
+    const int tn = min(TT, C - t0), R = group * tn, p_max = a.pos0 + t0 + tn - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, kh = lane >> 5;
+    xm_v16f acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[b][i] = 0.0f;
+    // staging maps: P row = tid >> 3 (32 rows), 8 positions per thread; V chunk u = tid + 256 i: row u / (HD * ESZ / 16), 16-byte chunk u % (...)
+    const int prow = tid >> 3, pseg = (tid & 7) * 8;
+    const int ptt = (prow < R ? prow : 0) / group, pg = (prow < R ? prow : 0) % group, qpos = a.pos0 + t0 + ptt;
+    const float* prow_p = sc + ((size_t)(t0 + ptt) * a.nh + (size_t)kvh * group + pg) * sc_ld;
+    constexpr int CPR = HD * ESZ / 16;                                        // chunks per V row
+    xm_f4 pp[2]; u32x4 pv[VCH > 0 ? VCH : 1];
+    auto load_stage = [&](int p0) {
+        pp[0] = *reinterpret_cast<const xm_f4*>(prow_p + p0 + pseg); pp[1] = *reinterpret_cast<const xm_f4*>(prow_p + p0 + pseg + 4);
+#pragma unroll
+        for (int i = 0; i < VCH; i++) {
+            const int u = tid + 256 * i, vr = u / CPR, vc = u % CPR;
+            const int pos = min(p0 + vr, p_max);
+            pv[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.v_cache) + ((size_t)pos * kvs + (size_t)kvh * HD) * ESZ + vc * 16);
+        }
+    };
+    auto commit_stage = [&](int p0) {
+        const float e[8] = {pp[0].x, pp[0].y, pp[0].z, pp[0].w, pp[1].x, pp[1].y, pp[1].z, pp[1].w};
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) m[j] = (prow < R && p0 + pseg + j <= qpos) ? e[j] : 0.0f;      // select, never multiply: the scratch past qpos is not initialised
+        *reinterpret_cast<xm_f4*>(Ps + prow * XM_LDF + pseg) = xm_f4{m[0], m[1], m[2], m[3]};
+        *reinterpret_cast<xm_f4*>(Ps + prow * XM_LDF + pseg + 4) = xm_f4{m[4], m[5], m[6], m[7]};
+#pragma unroll
+        for (int i = 0; i < VCH; i++) { const int u = tid + 256 * i, vr = u / CPR, vc = u % CPR; *reinterpret_cast<u32x4*>(Vs + vr * VROW + vc * 16) = pv[i]; }
+    };
+    load_stage(0);
+    for (int p0 = 0; p0 <= p_max; p0 += 64) {
+        __syncthreads();                                                      // the previous stage's readers are done
+        commit_stage(p0);
+        if (p0 + 64 <= p_max) load_stage(p0 + 64);                            // in flight during the MFMAs below
+        __syncthreads();
+        if (wave < NW) {
+            const int np = min(64, p_max + 1 - p0);                           // positions of this stage any query may see
+            const float* pr = Ps + r31 * XM_LDF + kh;
+            const char* vb = Vs + kh * VROW + (size_t)(wave * NB * 32 + r31) * ESZ;
+#pragma unroll 4
+            for (int s2 = 0; s2 < 32; s2++) {                                 // k = positions 2 s2 (lane half 0) and 2 s2 + 1 (lane half 1), ascending
+                if (2 * s2 >= np) break;
+                const float pa = pr[2 * s2];
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    float v;
+                    if (FP8) v = kr_e4m3_to_f32(*reinterpret_cast<const uint8_t*>(vb + 2 * s2 * VROW + b * 32));
+                    else v = __half2float(__ushort_as_half(*reinterpret_cast<const uint16_t*>(vb + 2 * s2 * VROW + b * 64)));
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, v, acc[b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (wave >= NW) return;
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int r = (i & 3) + 8 * (i >> 2) + 4 * kh;
+            if (r < R) {
+                const int tt = r / group, hh = kvh * group + r % group;
+                float o = acc[b][i];
+                const size_t oi = (size_t)(t0 + tt) * a.nh * HD + (size_t)hh * HD + (size_t)(wave * NB + b) * 32 + r31;
+                if (a.gated) { const float gt = a.gate[oi]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
+                a.attn_out[oi] = o;
+            }
+        }
+}
+
+// scores + P.V of the exact prompt pass on the matrix cores; non-zero = geometry not covered (the caller keeps the vector kernels)
+int kr_pfm_gqa_exact_mfma_ok(const KrPfmGqaArgs& a) {
+    const int group = a.nkv > 0 ? a.nh / a.nkv : 0;
+    return group >= 1 && group <= 32 && (32 % group) == 0 && a.nh % a.nkv == 0 && (a.hd == 64 || a.hd == 128 || a.hd == 256);
+}
+void kr_launch_pfm_gqa_scores_mfma(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, hipStream_t st) {
+    const int group = a.nh / a.nkv, TT = 64 / group;
+    const dim3 grid((a.pos0 + C + 63) / 64, (C + TT - 1) / TT, a.nkv);
+    if (a.kv_fp8) hipLaunchKernelGGL(kr_pfm_gqa_scores_mfma_kernel<true>, grid, dim3(256), 0, st, a, sc, sc_ld, C);
+    else hipLaunchKernelGGL(kr_pfm_gqa_scores_mfma_kernel<false>, grid, dim3(256), 0, st, a, sc, sc_ld, C);
+}
+void kr_launch_pfm_gqa_pv_mfma(const KrPfmGqaArgs& a, int C, const float* sc, int sc_ld, hipStream_t st) {
+    const int group = a.nh / a.nkv, TT = 32 / group;
+    const dim3 grid((C + TT - 1) / TT, a.nkv);
+#define KR_XPV(F_, H_) hipLaunchKernelGGL((kr_pfm_gqa_pv_mfma_kernel<F_, H_>), grid, dim3(256), 0, st, a, sc, sc_ld, C)
+    if (a.hd == 256) { if (a.kv_fp8) KR_XPV(true, 256); else KR_XPV(false, 256); }
+    else if (a.hd == 128) { if (a.kv_fp8) KR_XPV(true, 128); else KR_XPV(false, 128); }
+    else { if (a.kv_fp8) KR_XPV(true, 64); else KR_XPV(false, 64); }
+#undef KR_XPV
+}

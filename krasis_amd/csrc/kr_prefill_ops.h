@@ -35,6 +35,10 @@ int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out,
 // prep (norm, RoPE, KV append) + scores -> softmax -> P.V over the score scratch sc[C*nh rows][sc_ld] (sc_ld >= pos0 + C), inv[C*nh];
 // non-zero = unsupported geometry
 int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st);
+// passes A and C of the above on the f32 matrix cores, bit-identical (kr_attn_exact_mfma.hip); *_ok: the geometry is covered (group divides 32, head_dim 64 / 128 / 256)
+int kr_pfm_gqa_exact_mfma_ok(const KrPfmGqaArgs& a);
+void kr_launch_pfm_gqa_scores_mfma(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, hipStream_t st);
+void kr_launch_pfm_gqa_pv_mfma(const KrPfmGqaArgs& a, int C, const float* sc, int sc_ld, hipStream_t st);
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st);
 // FAST mode (kr_attn_flash.hip): causal flash attention on f16 MFMA after the same prep launch; non-zero = geometry not covered
 int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st);

@@ -10,6 +10,7 @@
 #include "kr_libm.h"
 #include "kr_prefill_ops.h"
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 __device__ __forceinline__ float kr_pfm_hsum8(float v) { v = v + __shfl_xor(v, 4); v = v + __shfl_xor(v, 1); v = v + __shfl_xor(v, 2); return v; }
 
@@ -717,6 +718,14 @@ int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float*
     const int group = a.nh / a.nkv, TT = kr_pfm_gqa_tile(a.nh, a.nkv);
     if (TT == 0 || a.hd > 256 || a.hd % 32 || a.nh % a.nkv) return 1;
     hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, C), dim3(256), 0, st, a);
+    static const bool no_mfma = getenv("KR_EXACT_ATTN_VALU") != nullptr;       // tuning / A-B hook: keep the vector-ALU passes
+    if (!no_mfma && kr_pfm_gqa_exact_mfma_ok(a)) {                              // scores and P.V on the f32 matrix cores, same bits (kr_attn_exact_mfma.hip)
+        kr_launch_pfm_gqa_scores_mfma(a, C, sc, sc_ld, st);
+        const int rows = C * a.nh;
+        hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, a.nh, a.pos0, rows);
+        kr_launch_pfm_gqa_pv_mfma(a, C, sc, sc_ld, st);
+        return 0;
+    }
     const int ntt = (C + TT - 1) / TT, npt = (a.pos0 + C + 255) / 256;
     const size_t lds = ((size_t)group * TT * 8 + 32 * 8) * PFA_LDB * 4;
     {                                  // > 64 KiB of dynamic LDS needs the opt-in (160 KiB per CU on gfx950), per (kernel, device)
