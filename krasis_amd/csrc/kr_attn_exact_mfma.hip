@@ -31,7 +31,7 @@ typedef float xm_f4 __attribute__((ext_vector_type(4)));
 // A query row r of the tile is (token t0 + r / group, head kvh * group + r % group), t0 = tile * (64 / group).
 // ------------------------------------------------------------------------------------------------------------------------------------
 template <bool FP8>
-__global__ void __launch_bounds__(256) kr_pfm_gqa_scores_mfma_kernel(const KrPfmGqaArgs a, float* __restrict__ sc, int sc_ld, int C) {
+__global__ void __launch_bounds__(256, 2) kr_pfm_gqa_scores_mfma_kernel(const KrPfmGqaArgs a, float* __restrict__ sc, int sc_ld, int C) {
     __shared__ __attribute__((aligned(16))) float Qs[64 * XM_LDF];
     __shared__ __attribute__((aligned(16))) float Ks[64 * XM_LDF];
     const int hd = a.hd, group = a.nh / a.nkv, kvh = blockIdx.z, TT = 64 / group, t0 = blockIdx.y * TT, kvs = a.nkv * hd;
@@ -45,38 +45,57 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_scores_mfma_kernel(const KrPfm
     for (int j = 0; j < 8; j++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[j][i] = 0.0f;
-    for (int d0 = 0; d0 < hd; d0 += 64) {
-        __syncthreads();                                                      // the previous stage's readers are done
-        // q: 64 rows x 64 floats, 16 float4 per row, 4 per thread
+    // staging: q 64 rows x 64 floats per stage (16 float4 per row, 4 per thread), K 64 positions x 64 values (positions past p_max re-read p_max:
+    // their scores are never stored).  The next stage's requests are in flight during the MFMAs of the current one.
+    const float* qsrc[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-            const int rr = row < R ? row : R - 1, tt = rr / group, hh = kvh * group + rr % group;
-            *reinterpret_cast<xm_f4*>(Qs + row * XM_LDF + c4) = *reinterpret_cast<const xm_f4*>(a.q_out + (size_t)(t0 + tt) * a.nh * hd + (size_t)hh * hd + d0 + c4);
-        }
-        // K: 64 positions x 64 values (positions past p_max re-read p_max: their scores are never stored)
+    for (int i = 0; i < 4; i++) {
+        const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+        const int rr = row < R ? row : R - 1, tt = rr / group, hh = kvh * group + rr % group;
+        qsrc[i] = a.q_out + (size_t)(t0 + tt) * a.nh * hd + (size_t)hh * hd + c4;
+    }
+    constexpr int KCH = FP8 ? 1 : 2;
+    const char* ksrc[KCH];
+#pragma unroll
+    for (int i = 0; i < KCH; i++) {
+        const int u = tid + 256 * i, prow = FP8 ? (u >> 2) : (u >> 3), off = FP8 ? (u & 3) * 16 : (u & 7) * 16;       // bytes inside the 64-value segment
+        ksrc[i] = reinterpret_cast<const char*>(a.k_cache) + ((size_t)min(p_lo + prow, p_max) * kvs + (size_t)kvh * hd) * (FP8 ? 1 : 2) + off;
+    }
+    xm_f4 qreg[4]; u32x4 kreg[KCH];
+    auto load_stage = [&](int d0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) qreg[i] = *reinterpret_cast<const xm_f4*>(qsrc[i] + d0);
+#pragma unroll
+        for (int i = 0; i < KCH; i++) kreg[i] = *reinterpret_cast<const u32x4*>(ksrc[i] + (size_t)d0 * (FP8 ? 1 : 2));
+    };
+    auto commit_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4; *reinterpret_cast<xm_f4*>(Qs + row * XM_LDF + c4) = qreg[i]; }
         if (FP8) {
-            const int pos = min(p_lo + (tid >> 2), p_max), c16 = (tid & 3) * 16;
-            const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(a.k_cache) + (size_t)pos * kvs + (size_t)kvh * hd + d0 + c16);
-            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-            float* dst = Ks + (tid >> 2) * XM_LDF + c16;
+            const uint32_t ww[4] = {kreg[0].x, kreg[0].y, kreg[0].z, kreg[0].w};
+            float* dst = Ks + (tid >> 2) * XM_LDF + (tid & 3) * 16;
 #pragma unroll
-            for (int j = 0; j < 16; j++) dst[j] = kr_e4m3_to_f32((uint8_t)(ww[j >> 2] >> (8 * (j & 3))));
+            for (int q4 = 0; q4 < 4; q4++)
+                *reinterpret_cast<xm_f4*>(dst + 4 * q4) = xm_f4{kr_e4m3_to_f32((uint8_t)ww[q4]), kr_e4m3_to_f32((uint8_t)(ww[q4] >> 8)),
+                                                              kr_e4m3_to_f32((uint8_t)(ww[q4] >> 16)), kr_e4m3_to_f32((uint8_t)(ww[q4] >> 24))};
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < KCH; i++) {
                 const int u = tid + 256 * i, prow = u >> 3, c8 = (u & 7) * 8;
-                const int pos = min(p_lo + prow, p_max);
-                const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(a.k_cache) + (size_t)pos * kvs + (size_t)kvh * hd + d0 + c8);
-                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-                float* dst = Ks + prow * XM_LDF + c8;
+                const uint32_t ww[4] = {kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w};
+                float f[8];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    dst[2 * j] = __half2float(__ushort_as_half((uint16_t)(ww[j] & 0xFFFFu)));
-                    dst[2 * j + 1] = __half2float(__ushort_as_half((uint16_t)(ww[j] >> 16)));
-                }
+                for (int j = 0; j < 4; j++) { f[2 * j] = __half2float(__ushort_as_half((uint16_t)(ww[j] & 0xFFFFu))); f[2 * j + 1] = __half2float(__ushort_as_half((uint16_t)(ww[j] >> 16))); }
+                *reinterpret_cast<xm_f4*>(Ks + prow * XM_LDF + c8) = xm_f4{f[0], f[1], f[2], f[3]};
+                *reinterpret_cast<xm_f4*>(Ks + prow * XM_LDF + c8 + 4) = xm_f4{f[4], f[5], f[6], f[7]};
             }
         }
+    };
+    load_stage(0);
+    for (int d0 = 0; d0 < hd; d0 += 64) {
+        __syncthreads();                                                      // the previous stage's readers are done
+        commit_stage();
+        if (d0 + 64 < hd) load_stage(d0 + 64);
         __syncthreads();
         const float* qp = Qs + (rb + r31) * XM_LDF + 8 * kh;
         const float* kp = Ks + (pb + r31) * XM_LDF + 8 * kh;
