@@ -31,7 +31,7 @@ typedef float xm_f4 __attribute__((ext_vector_type(4)));
 // A query row r of the tile is (token t0 + r / group, head kvh * group + r % group), t0 = tile * (64 / group).
 // ------------------------------------------------------------------------------------------------------------------------------------
 template <bool FP8>
-__global__ void __launch_bounds__(256, 2) kr_pfm_gqa_scores_mfma_kernel(const KrPfmGqaArgs a, float* __restrict__ sc, int sc_ld, int C) {
+__global__ void __launch_bounds__(256, 2) kr_pfm_gqa_scores_mfma_kernel(const KrPfmGqaArgs a, float* __restrict__ sc, int sc_ld, int C, float* __restrict__ tmax) {
     __shared__ __attribute__((aligned(16))) float Qs[64 * XM_LDF];
     __shared__ __attribute__((aligned(16))) float Ks[64 * XM_LDF];
     const int hd = a.hd, group = a.nh / a.nkv, kvh = blockIdx.z, TT = 64 / group, t0 = blockIdx.y * TT, kvs = a.nkv * hd;
@@ -108,15 +108,25 @@ __global__ void __launch_bounds__(256, 2) kr_pfm_gqa_scores_mfma_kernel(const Kr
             for (int j = 0; j < 8; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j], ka[j], acc[j], 0, 0, 0);
         }
     }
-    // hsum8 of the reference (kr_pfm_hsum8: xor 4, xor 1, xor 2), * sm_scale, causal store
+    // hsum8 of the reference (kr_pfm_hsum8: xor 4, xor 1, xor 2), * sm_scale, causal store; the maximum of every row over this block's 32
+    // positions goes to tmax[row][32-position block] so that pass B finds the row maximum without another walk over the score scratch (the
+    // scratch is the traffic of the exact attention: a 20 k-token context is 1.3 GB of scores per chunk and layer)
     const int pos = p_lo + pb + r31;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int r = rb + (i & 3) + 8 * (i >> 2) + 4 * kh;
         const float sv = ((acc[0][i] + acc[4][i]) + (acc[1][i] + acc[5][i])) + ((acc[2][i] + acc[6][i]) + (acc[3][i] + acc[7][i]));
+        float mv = -__builtin_inff();
+        size_t rowi = 0;
         if (r < R) {
             const int tt = r / group, hh = kvh * group + r % group;
-            if (pos <= a.pos0 + t0 + tt) sc[((size_t)(t0 + tt) * a.nh + hh) * sc_ld + pos] = sv * a.sm_scale;
+            rowi = (size_t)(t0 + tt) * a.nh + hh;
+            if (pos <= a.pos0 + t0 + tt) { mv = sv * a.sm_scale; sc[rowi * sc_ld + pos] = mv; }
+        }
+        if (tmax) {        // maximum over the 32 lanes of this lane half (the other half holds other rows)
+            mv = fmaxf(mv, __shfl_xor(mv, 16)); mv = fmaxf(mv, __shfl_xor(mv, 8)); mv = fmaxf(mv, __shfl_xor(mv, 4));
+            mv = fmaxf(mv, __shfl_xor(mv, 2)); mv = fmaxf(mv, __shfl_xor(mv, 1));
+            if (r31 == 0 && r < R) tmax[rowi * (size_t)(sc_ld >> 5) + ((p_lo + pb) >> 5)] = mv;
         }
     }
 }
@@ -126,7 +136,7 @@ __global__ void __launch_bounds__(256, 2) kr_pfm_gqa_scores_mfma_kernel(const Kr
 // head_dim 64: waves 0 and 1 one block each).  64 positions per stage: probabilities (masked) as f32 and the raw V rows in LDS.
 // ------------------------------------------------------------------------------------------------------------------------------------
 template <bool FP8, int HD>
-__global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaArgs a, const float* __restrict__ sc, int sc_ld, int C) {
+__global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaArgs a, const float* __restrict__ sc, int sc_ld, int C, const float* __restrict__ inv) {
     constexpr int ESZ = FP8 ? 1 : 2, VROW = HD * ESZ + 64;                    // bytes per V row in LDS (+ 64: the two k halves land 16 banks apart)
     constexpr int NB = HD >= 128 ? HD / 128 : 1, NW = HD >= 128 ? 4 : HD / 32;   // blocks per wave, waves that own blocks
     constexpr int VCH = 64 * HD * ESZ / 16 / 256;                             // 16-byte V chunks per thread per stage (8 / 4 / 2 for f16, 4 / 2 / 1 for e4m3)
@@ -144,6 +154,8 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaA
     const int prow = tid >> 3, pseg = (tid & 7) * 8;
     const int ptt = (prow < R ? prow : 0) / group, pg = (prow < R ? prow : 0) % group, qpos = a.pos0 + t0 + ptt;
     const float* prow_p = sc + ((size_t)(t0 + ptt) * a.nh + (size_t)kvh * group + pg) * sc_ld;
+    // pass B left the exponentials unscaled (inv != nullptr): p = e * (1 / sum) is formed here, the multiply the reference does in place (decode.rs:4260)
+    const float iv = inv ? inv[(size_t)(t0 + ptt) * a.nh + (size_t)kvh * group + pg] : 1.0f;
     constexpr int CPR = HD * ESZ / 16;                                        // chunks per V row
     xm_f4 pp[2]; u32x4 pv[VCH > 0 ? VCH : 1];
     auto load_stage = [&](int p0) {
@@ -159,7 +171,7 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaA
         const float e[8] = {pp[0].x, pp[0].y, pp[0].z, pp[0].w, pp[1].x, pp[1].y, pp[1].z, pp[1].w};
         float m[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) m[j] = (prow < R && p0 + pseg + j <= qpos) ? e[j] : 0.0f;      // select, never multiply: the scratch past qpos is not initialised
+        for (int j = 0; j < 8; j++) m[j] = (prow < R && p0 + pseg + j <= qpos) ? (inv ? e[j] * iv : e[j]) : 0.0f;      // select first: the scratch past qpos is not initialised
         *reinterpret_cast<xm_f4*>(Ps + prow * XM_LDF + pseg) = xm_f4{m[0], m[1], m[2], m[3]};
         *reinterpret_cast<xm_f4*>(Ps + prow * XM_LDF + pseg + 4) = xm_f4{m[4], m[5], m[6], m[7]};
 #pragma unroll
@@ -210,16 +222,16 @@ int kr_pfm_gqa_exact_mfma_ok(const KrPfmGqaArgs& a) {
     const int group = a.nkv > 0 ? a.nh / a.nkv : 0;
     return group >= 1 && group <= 32 && (32 % group) == 0 && a.nh % a.nkv == 0 && (a.hd == 64 || a.hd == 128 || a.hd == 256);
 }
-void kr_launch_pfm_gqa_scores_mfma(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, hipStream_t st) {
+void kr_launch_pfm_gqa_scores_mfma(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* tmax, hipStream_t st) {
     const int group = a.nh / a.nkv, TT = 64 / group;
     const dim3 grid((a.pos0 + C + 63) / 64, (C + TT - 1) / TT, a.nkv);
-    if (a.kv_fp8) hipLaunchKernelGGL(kr_pfm_gqa_scores_mfma_kernel<true>, grid, dim3(256), 0, st, a, sc, sc_ld, C);
-    else hipLaunchKernelGGL(kr_pfm_gqa_scores_mfma_kernel<false>, grid, dim3(256), 0, st, a, sc, sc_ld, C);
+    if (a.kv_fp8) hipLaunchKernelGGL(kr_pfm_gqa_scores_mfma_kernel<true>, grid, dim3(256), 0, st, a, sc, sc_ld, C, tmax);
+    else hipLaunchKernelGGL(kr_pfm_gqa_scores_mfma_kernel<false>, grid, dim3(256), 0, st, a, sc, sc_ld, C, tmax);
 }
-void kr_launch_pfm_gqa_pv_mfma(const KrPfmGqaArgs& a, int C, const float* sc, int sc_ld, hipStream_t st) {
+void kr_launch_pfm_gqa_pv_mfma(const KrPfmGqaArgs& a, int C, const float* sc, int sc_ld, const float* inv, hipStream_t st) {
     const int group = a.nh / a.nkv, TT = 32 / group;
     const dim3 grid((C + TT - 1) / TT, a.nkv);
-#define KR_XPV(F_, H_) hipLaunchKernelGGL((kr_pfm_gqa_pv_mfma_kernel<F_, H_>), grid, dim3(256), 0, st, a, sc, sc_ld, C)
+#define KR_XPV(F_, H_) hipLaunchKernelGGL((kr_pfm_gqa_pv_mfma_kernel<F_, H_>), grid, dim3(256), 0, st, a, sc, sc_ld, C, inv)
     if (a.hd == 256) { if (a.kv_fp8) KR_XPV(true, 256); else KR_XPV(false, 256); }
     else if (a.hd == 128) { if (a.kv_fp8) KR_XPV(true, 128); else KR_XPV(false, 128); }
     else { if (a.kv_fp8) KR_XPV(true, 64); else KR_XPV(false, 64); }

@@ -314,7 +314,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
                  o_yl = take(C * kmax), o_ys = take(C * (kmax / 128 + 1) * 4), o_xb = take(C * H * 2), o_ids = take(C * 32 * 4), o_w = take(C * 32 * 4),
                  o_lg = take(C * (size_t)std::max(e->r_ne, 64) * 4), o_lac = take(lac_floats * 4),
                  o_xf = take(C * H * 2), o_xfm = take(C * 4), o_yf = take(C * kmax * 2), o_yfm = take(C * 4);
-    const size_t sc_ld_max = (size_t)((start_pos + n_tokens + 63) & ~63), sc_bytes = al(C * sc_rows * (sc_ld_max + 1) * 4);
+    const size_t sc_ld_max = (size_t)((start_pos + n_tokens + 63) & ~63), sc_bytes = al(C * sc_rows * (sc_ld_max + 1 + sc_ld_max / 32) * 4);     // scores + 1 / sum per row + row maxima per 32 positions
     if (s->pf_scratch.ensure(total * n_arenas) || s->pf_tokens.ensure((size_t)n_tokens * 4) || (sc_rows && s->pf_scores.ensure(sc_bytes * n_arenas)))
         return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch (%zu MiB) failed", (total * n_arenas + sc_bytes * n_arenas) >> 20);
     const size_t vl_bytes = al(C * (size_t)s->vocab * 4);                 // scoring mode: logits of a whole chunk, one buffer per arena

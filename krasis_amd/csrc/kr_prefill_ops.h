@@ -32,13 +32,14 @@ void kr_launch_pfm_nll(const float* logits, size_t ld, const int* labels, float*
 void kr_launch_pfm_quant_f32(const float* x, int rows, int ld, int K, int8_t* xh, int8_t* xl, float* xs, hipStream_t st);
 // conv + conv-state update + gated delta rule over the chunk + gated RMSNorm; non-zero = unsupported geometry
 int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out, const float* norm_w, float* gated_out, int C, float eps, hipStream_t st);
-// prep (norm, RoPE, KV append) + scores -> softmax -> P.V over the score scratch sc[C*nh rows][sc_ld] (sc_ld >= pos0 + C), inv[C*nh];
+// prep (norm, RoPE, KV append) + scores -> softmax -> P.V over the score scratch sc[C*nh rows][sc_ld] (sc_ld >= pos0 + C, multiple of 64),
+// inv[C*nh * (1 + sc_ld/32)] (1 / sum per row, then the per-32-position row maxima of the matrix-core passes);
 // non-zero = unsupported geometry
 int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st);
 // passes A and C of the above on the f32 matrix cores, bit-identical (kr_attn_exact_mfma.hip); *_ok: the geometry is covered (group divides 32, head_dim 64 / 128 / 256)
 int kr_pfm_gqa_exact_mfma_ok(const KrPfmGqaArgs& a);
-void kr_launch_pfm_gqa_scores_mfma(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, hipStream_t st);
-void kr_launch_pfm_gqa_pv_mfma(const KrPfmGqaArgs& a, int C, const float* sc, int sc_ld, hipStream_t st);
+void kr_launch_pfm_gqa_scores_mfma(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* tmax /* [C*nh][sc_ld/32] row maxima per 32 positions, or null */, hipStream_t st);
+void kr_launch_pfm_gqa_pv_mfma(const KrPfmGqaArgs& a, int C, const float* sc, int sc_ld, const float* inv /* null: sc holds probabilities; else exponentials, scaled here */, hipStream_t st);
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st);
 // FAST mode (kr_attn_flash.hip): causal flash attention on f16 MFMA after the same prep launch; non-zero = geometry not covered
 int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st);

@@ -488,14 +488,18 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_scores_t_kernel(const KrPfmGqa
 
 // pass B: per row  max -> e = exp(s - max) (libm) -> sequential sum in position order -> inv = 1 / sum  (decode.rs:4244-4262).
 // one wave per row: 64 positions at a time are exponentiated in parallel, lane 0 adds them in order.
-__global__ void __launch_bounds__(256) kr_pfm_gqa_softmax_kernel(float* __restrict__ sc, int sc_ld, float* __restrict__ inv, int nh, int pos0, int rows) {
+__global__ void __launch_bounds__(256) kr_pfm_gqa_softmax_kernel(float* __restrict__ sc, int sc_ld, float* __restrict__ inv, int nh, int pos0, int rows,
+                                                                 const float* __restrict__ tmax) {
     __shared__ __attribute__((aligned(16))) float buf[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const int seq = pos0 + row / nh + 1;
     float* s = sc + (size_t)row * sc_ld;
     float mx = -__builtin_inff();
-    for (int p = lane; p < seq; p += 64) mx = fmaxf(mx, s[p]);
+    if (tmax) {            // pass A left the maximum of every 32 positions (the maximum is the same whatever the order it is taken in)
+        const float* tm = tmax + (size_t)row * (sc_ld >> 5);
+        for (int b = lane; b < (seq + 31) >> 5; b += 64) mx = fmaxf(mx, tm[b]);
+    } else for (int p = lane; p < seq; p += 64) mx = fmaxf(mx, s[p]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     float se = 0.0f;
@@ -515,10 +519,11 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_softmax_kernel(float* __restri
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
     }
-    // sc[s] *= inv (decode.rs:4260): the row leaves this pass as probabilities, so pass C reads them as they are
+    // sc[s] *= inv (decode.rs:4260): the row leaves this pass as probabilities, so the vector pass C reads them as they are; with tmax (matrix-core
+    // passes) the row stays as exponentials and pass C forms e * inv itself -- one read and one write of the scratch less
     const float iv = __shfl(1.0f / se, 0);
     if (lane == 0) inv[row] = iv;
-    for (int p = lane; p < seq; p += 64) s[p] = s[p] * iv;
+    if (!tmax) for (int p = lane; p < seq; p += 64) s[p] = s[p] * iv;
 }
 
 // pass C: out[t][h][d] = chain_pos fma(p[pos], V[pos][d]) (decode.rs:4264-4273), gated by sigmoid(gate) (:4277).
@@ -720,10 +725,11 @@ int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float*
     hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, C), dim3(256), 0, st, a);
     static const bool no_mfma = getenv("KR_EXACT_ATTN_VALU") != nullptr;       // tuning / A-B hook: keep the vector-ALU passes
     if (!no_mfma && kr_pfm_gqa_exact_mfma_ok(a)) {                              // scores and P.V on the f32 matrix cores, same bits (kr_attn_exact_mfma.hip)
-        kr_launch_pfm_gqa_scores_mfma(a, C, sc, sc_ld, st);
         const int rows = C * a.nh;
-        hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, a.nh, a.pos0, rows);
-        kr_launch_pfm_gqa_pv_mfma(a, C, sc, sc_ld, st);
+        float* tmax = inv + rows;                                                // [rows][sc_ld / 32]
+        kr_launch_pfm_gqa_scores_mfma(a, C, sc, sc_ld, tmax, st);
+        hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, a.nh, a.pos0, rows, (const float*)tmax);
+        kr_launch_pfm_gqa_pv_mfma(a, C, sc, sc_ld, inv, st);
         return 0;
     }
     const int ntt = (C + TT - 1) / TT, npt = (a.pos0 + C + 255) / 256;
@@ -741,7 +747,7 @@ int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float*
     else hipLaunchKernelGGL(kr_pfm_gqa_scores_kernel, dim3(npt, ntt, a.nkv), dim3(256), lds, st, a, sc, sc_ld, TT, C);
 #undef KR_SC
     const int rows = C * a.nh;
-    hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, a.nh, a.pos0, rows);
+    hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, a.nh, a.pos0, rows, (const float*)nullptr);
     const int TTV = PFV_R / group < 1 ? 0 : PFV_R / group, nttv = TTV ? (C + TTV - 1) / TTV : 0;   // pass C has its own (smaller) token tile
     if (!TTV) return 1;
 #define KR_PV(F_, G_, C_) hipLaunchKernelGGL((kr_pfm_gqa_pv_kernel<F_, G_, C_>), dim3(nttv, a.nkv), dim3(64), 0, st, a, sc, sc_ld, TTV, C)
