@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "kr_device.h"
+#include "kr_lds_optin.h"
 #include "kr_libm.h"
 #include "kr_prefill_ops.h"
 
@@ -135,13 +136,15 @@ __global__ void __launch_bounds__(256, 2) kr_pfm_gqa_scores_mfma_kernel(const Kr
 // pass C.  grid (row tiles of 32 queries, nkv), 4 waves; wave w owns the 32-dim blocks w * NB .. w * NB + NB - 1 of the head (NB = hd / 128,
 // head_dim 64: waves 0 and 1 one block each).  64 positions per stage: probabilities (masked) as f32 and the raw V rows in LDS.
 // ------------------------------------------------------------------------------------------------------------------------------------
-template <bool FP8, int HD>
+template <bool FP8, int HD, int PS>      // PS = positions per stage (64; 32 for the 512-wide latent rows of MLA: the V tile must fit the static LDS window)
 __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaArgs a, const float* __restrict__ sc, int sc_ld, int C, const float* __restrict__ inv) {
     constexpr int ESZ = FP8 ? 1 : 2, VROW = HD * ESZ + 64;                    // bytes per V row in LDS (+ 64: the two k halves land 16 banks apart)
     constexpr int NB = HD >= 128 ? HD / 128 : 1, NW = HD >= 128 ? 4 : HD / 32;   // blocks per wave, waves that own blocks
-    constexpr int VCH = 64 * HD * ESZ / 16 / 256;                             // 16-byte V chunks per thread per stage (8 / 4 / 2 for f16, 4 / 2 / 1 for e4m3)
-    __shared__ __attribute__((aligned(16))) float Ps[32 * XM_LDF];
-    __shared__ __attribute__((aligned(16))) char Vs[64 * VROW];
+    constexpr int VCH = PS * HD * ESZ / 16 / 256;                             // 16-byte V chunks per thread per stage
+    constexpr int PLD = PS + 4, PPT = PS / 8;                                 // floats per P row in LDS; probabilities per thread (8 threads per row)
+    static_assert(VCH >= 1 && (PPT == 4 || PPT == 8), "stage shape");
+    __shared__ __attribute__((aligned(16))) float Ps[32 * PLD];
+    __shared__ __attribute__((aligned(16))) char Vs[PS * VROW];
     const int group = a.nh / a.nkv, kvh = blockIdx.y, TT = 32 / group, t0 = blockIdx.x * TT, kvs = a.nkv * HD;
     const int tn = min(TT, C - t0), R = group * tn, p_max = a.pos0 + t0 + tn - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, kh = lane >> 5;
@@ -150,16 +153,17 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaA
     for (int b = 0; b < NB; b++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[b][i] = 0.0f;
-    // staging maps: P row = tid >> 3 (32 rows), 8 positions per thread; V chunk u = tid + 256 i: row u / (HD * ESZ / 16), 16-byte chunk u % (...)
-    const int prow = tid >> 3, pseg = (tid & 7) * 8;
+    // staging maps: P row = tid >> 3 (32 rows), PPT positions per thread; V chunk u = tid + 256 i: row u / CPR, 16-byte chunk u % CPR
+    const int prow = tid >> 3, pseg = (tid & 7) * PPT;
     const int ptt = (prow < R ? prow : 0) / group, pg = (prow < R ? prow : 0) % group, qpos = a.pos0 + t0 + ptt;
     const float* prow_p = sc + ((size_t)(t0 + ptt) * a.nh + (size_t)kvh * group + pg) * sc_ld;
     // pass B left the exponentials unscaled (inv != nullptr): p = e * (1 / sum) is formed here, the multiply the reference does in place (decode.rs:4260)
     const float iv = inv ? inv[(size_t)(t0 + ptt) * a.nh + (size_t)kvh * group + pg] : 1.0f;
     constexpr int CPR = HD * ESZ / 16;                                        // chunks per V row
-    xm_f4 pp[2]; u32x4 pv[VCH > 0 ? VCH : 1];
+    xm_f4 pp[PPT / 4]; u32x4 pv[VCH];
     auto load_stage = [&](int p0) {
-        pp[0] = *reinterpret_cast<const xm_f4*>(prow_p + p0 + pseg); pp[1] = *reinterpret_cast<const xm_f4*>(prow_p + p0 + pseg + 4);
+#pragma unroll
+        for (int q = 0; q < PPT / 4; q++) pp[q] = *reinterpret_cast<const xm_f4*>(prow_p + p0 + pseg + 4 * q);
 #pragma unroll
         for (int i = 0; i < VCH; i++) {
             const int u = tid + 256 * i, vr = u / CPR, vc = u % CPR;
@@ -168,27 +172,29 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaA
         }
     };
     auto commit_stage = [&](int p0) {
-        const float e[8] = {pp[0].x, pp[0].y, pp[0].z, pp[0].w, pp[1].x, pp[1].y, pp[1].z, pp[1].w};
-        float m[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) m[j] = (prow < R && p0 + pseg + j <= qpos) ? (inv ? e[j] * iv : e[j]) : 0.0f;      // select first: the scratch past qpos is not initialised
-        *reinterpret_cast<xm_f4*>(Ps + prow * XM_LDF + pseg) = xm_f4{m[0], m[1], m[2], m[3]};
-        *reinterpret_cast<xm_f4*>(Ps + prow * XM_LDF + pseg + 4) = xm_f4{m[4], m[5], m[6], m[7]};
+        for (int q = 0; q < PPT / 4; q++) {
+            const float e[4] = {pp[q].x, pp[q].y, pp[q].z, pp[q].w};
+            float m[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[j] = (prow < R && p0 + pseg + 4 * q + j <= qpos) ? (inv ? e[j] * iv : e[j]) : 0.0f;      // select first: the scratch past qpos is not initialised
+            *reinterpret_cast<xm_f4*>(Ps + prow * PLD + pseg + 4 * q) = xm_f4{m[0], m[1], m[2], m[3]};
+        }
 #pragma unroll
         for (int i = 0; i < VCH; i++) { const int u = tid + 256 * i, vr = u / CPR, vc = u % CPR; *reinterpret_cast<u32x4*>(Vs + vr * VROW + vc * 16) = pv[i]; }
     };
     load_stage(0);
-    for (int p0 = 0; p0 <= p_max; p0 += 64) {
+    for (int p0 = 0; p0 <= p_max; p0 += PS) {
         __syncthreads();                                                      // the previous stage's readers are done
         commit_stage(p0);
-        if (p0 + 64 <= p_max) load_stage(p0 + 64);                            // in flight during the MFMAs below
+        if (p0 + PS <= p_max) load_stage(p0 + PS);                            // in flight during the MFMAs below
         __syncthreads();
         if (wave < NW) {
-            const int np = min(64, p_max + 1 - p0);                           // positions of this stage any query may see
-            const float* pr = Ps + r31 * XM_LDF + kh;
+            const int np = min(PS, p_max + 1 - p0);                           // positions of this stage any query may see
+            const float* pr = Ps + r31 * PLD + kh;
             const char* vb = Vs + kh * VROW + (size_t)(wave * NB * 32 + r31) * ESZ;
 #pragma unroll 4
-            for (int s2 = 0; s2 < 32; s2++) {                                 // k = positions 2 s2 (lane half 0) and 2 s2 + 1 (lane half 1), ascending
+            for (int s2 = 0; s2 < PS / 2; s2++) {                             // k = positions 2 s2 (lane half 0) and 2 s2 + 1 (lane half 1), ascending
                 if (2 * s2 >= np) break;
                 const float pa = pr[2 * s2];
 #pragma unroll
@@ -217,6 +223,120 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaA
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// MLA prompt pass, exact scores (decode.rs mla_attn_dot_fp16_avx2 twice: kr_dot2acc of kr_mla.hip): per (token, head) row and position
+//     v = dot16(q_abs[row], ckv[pos]) + dot16(q_pe[row], kpe[pos]);  v *= sm_scale
+// where dot16 keeps 16 fma chains (chain j over elements 16 s + j, s ascending) and folds them with the AVX2 tree -- the router's structure
+// (kr_route_mfma.hip): 16 accumulators of a 32 x 32 block fed with (s, s + 1) pairs, tree (c0 + c1) + (c2 + c3), c0 = (a0 + a8) + (a4 + a12) ...
+// grid (position tiles of 64, row tiles of 64, 1); rows are (token, head) pairs in token-major order; 64 k per LDS stage.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <bool FP8>
+__global__ void __launch_bounds__(256) kr_mla_scores_mfma_kernel(const float* __restrict__ q_abs, const float* __restrict__ q_pe, const void* __restrict__ ckv,
+                                                                 const void* __restrict__ kpe, int nh, int klr, int rd, int pos0, int rows, float sm_scale,
+                                                                 float* __restrict__ sc, int sc_ld, float* __restrict__ tmax) {
+    __shared__ __attribute__((aligned(16))) float As[64 * XM_LDF];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * XM_LDF];
+    const int row0 = blockIdx.y * 64, R = min(64, rows - row0);
+    const int p_lo = blockIdx.x * 64, p_max = pos0 + (row0 + R - 1) / nh;     // last position any row of the tile may see
+    if (p_lo > p_max) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, kh = lane >> 5;
+    const int rb = (wave >> 1) * 32, pb = (wave & 1) * 32;
+    constexpr int ESZ = FP8 ? 1 : 2, KCH = FP8 ? 1 : 2;                       // 16-byte cache chunks per thread per 64-k stage
+    // staging maps of a 64-k stage: q 64 rows x 64 floats (4 float4 per thread), cache 64 positions x 64 values (rows past p_max re-read p_max)
+    int qrow[4], qc4[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int u = tid + 256 * i, row = u >> 4; qc4[i] = (u & 15) * 4; qrow[i] = row0 + (row < R ? row : R - 1); }
+    int kpos[KCH], koff[KCH];
+#pragma unroll
+    for (int i = 0; i < KCH; i++) { const int u = tid + 256 * i, prow = FP8 ? (u >> 2) : (u >> 3); koff[i] = FP8 ? (u & 3) * 16 : (u & 7) * 16; kpos[i] = min(p_lo + prow, p_max); }
+    xm_f4 qreg[4]; u32x4 kreg[KCH];
+    auto load_stage = [&](const float* qb, const char* kb, int K, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) qreg[i] = *reinterpret_cast<const xm_f4*>(qb + (size_t)qrow[i] * K + k0 + qc4[i]);
+#pragma unroll
+        for (int i = 0; i < KCH; i++) kreg[i] = *reinterpret_cast<const u32x4*>(kb + ((size_t)kpos[i] * K + k0) * ESZ + koff[i]);
+    };
+    auto commit_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int u = tid + 256 * i, row = u >> 4; *reinterpret_cast<xm_f4*>(As + row * XM_LDF + qc4[i]) = qreg[i]; }
+        if (FP8) {
+            const uint32_t ww[4] = {kreg[0].x, kreg[0].y, kreg[0].z, kreg[0].w};
+            float* dst = Bs + (tid >> 2) * XM_LDF + (tid & 3) * 16;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++)
+                *reinterpret_cast<xm_f4*>(dst + 4 * q4) = xm_f4{kr_e4m3_to_f32((uint8_t)ww[q4]), kr_e4m3_to_f32((uint8_t)(ww[q4] >> 8)),
+                                                              kr_e4m3_to_f32((uint8_t)(ww[q4] >> 16)), kr_e4m3_to_f32((uint8_t)(ww[q4] >> 24))};
+        } else {
+#pragma unroll
+            for (int i = 0; i < KCH; i++) {
+                const int u = tid + 256 * i, prow = u >> 3, c8 = (u & 7) * 8;
+                const uint32_t ww[4] = {kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w};
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { f[2 * j] = __half2float(__ushort_as_half((uint16_t)(ww[j] & 0xFFFFu))); f[2 * j + 1] = __half2float(__ushort_as_half((uint16_t)(ww[j] >> 16))); }
+                *reinterpret_cast<xm_f4*>(Bs + prow * XM_LDF + c8) = xm_f4{f[0], f[1], f[2], f[3]};
+                *reinterpret_cast<xm_f4*>(Bs + prow * XM_LDF + c8 + 4) = xm_f4{f[4], f[5], f[6], f[7]};
+            }
+        }
+    };
+    xm_v16f acc[16];
+    // one segment (K values of q rows against K values of cache rows): 16 chains, 64 k per stage, next stage requested under the MFMAs
+    auto segment = [&](const float* qb, const char* kb, int K) {
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[j][i] = 0.0f;
+        load_stage(qb, kb, K, 0);
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            __syncthreads();
+            commit_stage();
+            if (k0 + 64 < K) load_stage(qb, kb, K, k0 + 64);
+            __syncthreads();
+            const float* ap = As + (rb + r31) * XM_LDF + 16 * kh;
+            const float* bp = Bs + (pb + r31) * XM_LDF + 16 * kh;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {                                     // 32 consecutive k: the (s, s + 1) pair of every chain
+                float av[16], bv[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const xm_f4 x = *reinterpret_cast<const xm_f4*>(ap + 32 * m + 4 * q), y = *reinterpret_cast<const xm_f4*>(bp + 32 * m + 4 * q);
+                    av[4 * q] = x.x; av[4 * q + 1] = x.y; av[4 * q + 2] = x.z; av[4 * q + 3] = x.w;
+                    bv[4 * q] = y.x; bv[4 * q + 1] = y.y; bv[4 * q + 2] = y.z; bv[4 * q + 3] = y.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[j], 0, 0, 0);
+            }
+        }
+    };
+    auto fold = [&](int i) {
+        const float c0 = (acc[0][i] + acc[8][i]) + (acc[4][i] + acc[12][i]);
+        const float c1 = (acc[1][i] + acc[9][i]) + (acc[5][i] + acc[13][i]);
+        const float c2 = (acc[2][i] + acc[10][i]) + (acc[6][i] + acc[14][i]);
+        const float c3 = (acc[3][i] + acc[11][i]) + (acc[7][i] + acc[15][i]);
+        return (c0 + c1) + (c2 + c3);
+    };
+    float s1[16];
+    segment(q_abs, reinterpret_cast<const char*>(ckv), klr);                  // v = dot16(q_abs, ckv)
+#pragma unroll
+    for (int i = 0; i < 16; i++) s1[i] = fold(i);
+    segment(q_pe, reinterpret_cast<const char*>(kpe), rd);                    // v += dot16(q_pe, kpe)
+#pragma unroll
+    for (int i = 0; i < 16; i++) s1[i] = s1[i] + fold(i);
+    const int pos = p_lo + pb + r31;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int r = rb + (i & 3) + 8 * (i >> 2) + 4 * kh;
+        float mv = -__builtin_inff();
+        const size_t rowi = (size_t)row0 + (r < R ? r : 0);
+        if (r < R && pos <= pos0 + (int)(rowi / nh)) { mv = s1[i] * sm_scale; sc[rowi * sc_ld + pos] = mv; }
+        if (tmax) {
+            mv = fmaxf(mv, __shfl_xor(mv, 16)); mv = fmaxf(mv, __shfl_xor(mv, 8)); mv = fmaxf(mv, __shfl_xor(mv, 4));
+            mv = fmaxf(mv, __shfl_xor(mv, 2)); mv = fmaxf(mv, __shfl_xor(mv, 1));
+            if (r31 == 0 && r < R) tmax[rowi * (size_t)(sc_ld >> 5) + ((p_lo + pb) >> 5)] = mv;
+        }
+    }
+}
+
 // scores + P.V of the exact prompt pass on the matrix cores; non-zero = geometry not covered (the caller keeps the vector kernels)
 int kr_pfm_gqa_exact_mfma_ok(const KrPfmGqaArgs& a) {
     const int group = a.nkv > 0 ? a.nh / a.nkv : 0;
@@ -231,9 +351,23 @@ void kr_launch_pfm_gqa_scores_mfma(const KrPfmGqaArgs& a, int C, float* sc, int 
 void kr_launch_pfm_gqa_pv_mfma(const KrPfmGqaArgs& a, int C, const float* sc, int sc_ld, const float* inv, hipStream_t st) {
     const int group = a.nh / a.nkv, TT = 32 / group;
     const dim3 grid((C + TT - 1) / TT, a.nkv);
-#define KR_XPV(F_, H_) hipLaunchKernelGGL((kr_pfm_gqa_pv_mfma_kernel<F_, H_>), grid, dim3(256), 0, st, a, sc, sc_ld, C, inv)
-    if (a.hd == 256) { if (a.kv_fp8) KR_XPV(true, 256); else KR_XPV(false, 256); }
-    else if (a.hd == 128) { if (a.kv_fp8) KR_XPV(true, 128); else KR_XPV(false, 128); }
-    else { if (a.kv_fp8) KR_XPV(true, 64); else KR_XPV(false, 64); }
+#define KR_XPV(F_, H_, P_) hipLaunchKernelGGL((kr_pfm_gqa_pv_mfma_kernel<F_, H_, P_>), grid, dim3(256), 0, st, a, sc, sc_ld, C, inv)
+    if (a.hd == 512) { if (a.kv_fp8) KR_XPV(true, 512, 32); else KR_XPV(false, 512, 32); }      // MLA latent rows (kr_launch_mla_exact_mfma)
+    else if (a.hd == 256) { if (a.kv_fp8) KR_XPV(true, 256, 64); else KR_XPV(false, 256, 64); }
+    else if (a.hd == 128) { if (a.kv_fp8) KR_XPV(true, 128, 64); else KR_XPV(false, 128, 64); }
+    else { if (a.kv_fp8) KR_XPV(true, 64, 64); else KR_XPV(false, 64, 64); }
 #undef KR_XPV
+}
+// MLA prompt pass: scores of n_tok tokens x nh heads against the latent + rope caches -> score scratch sc[n_tok * nh][sc_ld] + row maxima per 32
+// positions; non-zero = geometry not covered (klr % 128, rd != 64, nh does not divide 32)
+int kr_mla_exact_mfma_ok(int nh, int klr, int rd) { return nh >= 1 && nh <= 32 && (32 % nh) == 0 && (klr == 512 || klr == 256) && rd == 64; }
+int kr_launch_mla_scores_mfma(const float* q_abs, const float* q_pe, const void* ckv, const void* kpe, int kv_fp8, int nh, int klr, int rd, int pos0, int n_tok,
+                              float sm_scale, float* sc, int sc_ld, float* tmax, hipStream_t st) {
+    if (!kr_mla_exact_mfma_ok(nh, klr, rd)) return 1;
+    const int rows = n_tok * nh;
+    const dim3 grid((pos0 + n_tok + 63) / 64, (rows + 63) / 64);
+    if (klr % 64 || rd % 64) return 1;
+    if (kv_fp8) hipLaunchKernelGGL(kr_mla_scores_mfma_kernel<true>, grid, dim3(256), 0, st, q_abs, q_pe, ckv, kpe, nh, klr, rd, pos0, rows, sm_scale, sc, sc_ld, tmax);
+    else hipLaunchKernelGGL(kr_mla_scores_mfma_kernel<false>, grid, dim3(256), 0, st, q_abs, q_pe, ckv, kpe, nh, klr, rd, pos0, rows, sm_scale, sc, sc_ld, tmax);
+    return 0;
 }

@@ -51,6 +51,7 @@ struct KrMlaArgs {   // decode.rs:2993-3252
     // per-token buffers starts at t * ld_* floats (kv_out, q_full) or t * their natural size (q_abs, q_pe, attn_lat, v_proj)
     int pos0; int ld_kv, ld_q;
     int absorb_done;   // prompt pass: q_abs of the chunk was produced by kr_launch_mla_absorb_mfma -- the prep launch skips its absorption loop
+    float* pf_sc; int pf_sc_ld;   // prompt pass, exact mode: score scratch [n_tok * nh][pf_sc_ld] + n_tok * nh * (1 + pf_sc_ld / 32) floats (1 / sum, row maxima) for the matrix-core passes; null: per-token launches
 };
 void kr_launch_mla(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_tok = 1);
 size_t kr_mla_flash_decode_chunks(int max_seq);   // chunks of the FAST split-KV decode (sizes the partial buffers)

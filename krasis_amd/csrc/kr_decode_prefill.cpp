@@ -156,6 +156,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.rope_cos = (const float*)L.mla_cos.p; a.rope_sin = (const float*)L.mla_sin.p;
         a.ckv_cache = L.kv_k.p; a.kpe_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_abs = B.q; a.q_pe = B.z; a.attn_lat = B.recur; a.v_proj = B.attn;
         a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale; a.fast = s->attn_fast;
+        if (!s->attn_fast && cx.scores) { a.pf_sc = cx.scores; a.pf_sc_ld = (pos0 + Cc + 63) & ~63; }      // exact mode: this chunk's score scratch for the matrix-core passes
         kr_launch_mla(a, s->kv_max_seq, st, Cc);
         if (oc != L.nh * L.vhd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*v_head_dim", oc);
         pf_rows(s, B.attn, Cc, oc, oc, B, true, st);
@@ -278,6 +279,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
             pa = std::max(pa, nq); pb = std::max(pb, (size_t)s->weights[Ly.kva_wid]->rows);
             qd = std::max(qd, (size_t)Ly.nh * Ly.klr); vd = std::max(vd, (size_t)Ly.nh * Ly.klr); zd = std::max(zd, (size_t)Ly.nh * Ly.rd);
             ad = std::max(ad, (size_t)s->weights[Ly.o_wid]->cols);
+            if (kr_mla_exact_mfma_ok(Ly.nh, Ly.klr, Ly.rd)) sc_rows = std::max(sc_rows, (size_t)Ly.nh);     // score scratch of the exact matrix-core passes
             wids.push_back(Ly.kva_wid); wids.push_back(Ly.o_wid);
             if (Ly.mq_wid >= 0) wids.push_back(Ly.mq_wid);
             else { pc = std::max(pc, (size_t)s->weights[Ly.mqa_wid]->rows); kmax = std::max(kmax, (size_t)s->weights[Ly.mqa_wid]->rows); wids.push_back(Ly.mqa_wid); wids.push_back(Ly.mqb_wid); }

@@ -14,6 +14,7 @@
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
+#include "kr_prefill_ops.h"
 #include "kr_attn_fd.h"
 #include <hip/hip_fp16.h>
 
@@ -689,6 +690,7 @@ static bool kr_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s, int n_
 // raises the staged kernel's dynamic-LDS window; called outside graph capture (hipFuncSetAttribute is not a stream operation)
 void kr_mla_attn_prepare(const KrMlaArgs& a, int max_seq) { (void)kr_mla_staged(a, max_seq, nullptr, 1); }
 int kr_launch_mla_flash(const KrMlaArgs& a, int n_tok, hipStream_t st);   // kr_mla_flash.hip
+static bool mla_no_mfma() { static const bool v = getenv("KR_EXACT_ATTN_VALU") != nullptr; return v; }     // A-B hook: keep the per-token exact launches
 void kr_launch_mla(const KrMlaArgs& a_in, int max_seq, hipStream_t s, int n_tok) {
     KrMlaArgs a = a_in;
     // prompt pass: the w_kc absorption of the whole chunk on the f32 MFMA (one fma chain per output, bit-identical); the prep launch then only
@@ -699,6 +701,17 @@ void kr_launch_mla(const KrMlaArgs& a_in, int max_seq, hipStream_t s, int n_tok)
     else hipLaunchKernelGGL(kr_mla_prep_kernel<false>, dim3(prep_blocks, n_tok), dim3(64), 0, s, a);
     if (a.fast && !a.step && kr_launch_mla_flash(a, n_tok, s) == 0) {
         // prompt pass, tolerance mode: one flash-attention launch streams the latent cache once per 64 (token, head) rows
+    } else if (!a.step && n_tok >= 32 && a.pf_sc && !mla_no_mfma() && kr_mla_exact_mfma_ok(a.nh, a.klr, a.rd)) {
+        // prompt pass, exact mode: scores and the weighted sum of the latent rows on the f32 matrix cores, bit-identical to the per-token launches
+        // (kr_attn_exact_mfma.hip: each kr_dot2acc is 16 accumulators with the AVX2 fold tree, the weighted sum one accumulator chain over positions);
+        // the softmax pass is the GQA one (max, libm exp, sum in position order)
+        const int rows = n_tok * a.nh;
+        float* inv = a.pf_sc + (size_t)rows * a.pf_sc_ld; float* tmax = inv + rows;
+        (void)kr_launch_mla_scores_mfma(a.q_abs, a.q_pe, a.ckv_cache, a.kpe_cache, a.kv_fp8, a.nh, a.klr, a.rd, a.pos0, n_tok, a.sm_scale, a.pf_sc, a.pf_sc_ld, tmax, s);
+        kr_launch_pfm_softmax_rows(a.pf_sc, a.pf_sc_ld, inv, a.nh, a.pos0, rows, tmax, s);
+        KrPfmGqaArgs g{};
+        g.v_cache = a.ckv_cache; g.kv_fp8 = a.kv_fp8; g.nh = a.nh; g.nkv = 1; g.hd = a.klr; g.pos0 = a.pos0; g.gated = 0; g.attn_out = a.attn_lat;
+        kr_launch_pfm_gqa_pv_mfma(g, n_tok, a.pf_sc, a.pf_sc_ld, inv, s);
     } else if (!kr_mla_staged(a, max_seq, s, n_tok)) {      // other geometries: the generic kernel
         if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_attn_kernel<true>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
         else hipLaunchKernelGGL(kr_mla_attn_kernel<false>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);

@@ -40,6 +40,13 @@ int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float*
 int kr_pfm_gqa_exact_mfma_ok(const KrPfmGqaArgs& a);
 void kr_launch_pfm_gqa_scores_mfma(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* tmax /* [C*nh][sc_ld/32] row maxima per 32 positions, or null */, hipStream_t st);
 void kr_launch_pfm_gqa_pv_mfma(const KrPfmGqaArgs& a, int C, const float* sc, int sc_ld, const float* inv /* null: sc holds probabilities; else exponentials, scaled here */, hipStream_t st);
+// pass B alone (exact softmax of score rows: max -> libm exp -> sum in position order -> 1 / sum in inv[row]); tmax != null: row maxima per 32 positions are
+// given and the rows stay as exponentials (the matrix-core pass C scales them)
+void kr_launch_pfm_softmax_rows(float* sc, int sc_ld, float* inv, int nh, int pos0, int rows, const float* tmax, hipStream_t st);
+// MLA prompt pass, exact scores on the f32 matrix cores (kr_attn_exact_mfma.hip)
+int kr_mla_exact_mfma_ok(int nh, int klr, int rd);
+int kr_launch_mla_scores_mfma(const float* q_abs, const float* q_pe, const void* ckv, const void* kpe, int kv_fp8, int nh, int klr, int rd, int pos0, int n_tok,
+                              float sm_scale, float* sc, int sc_ld, float* tmax, hipStream_t st);
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st);
 // FAST mode (kr_attn_flash.hip): causal flash attention on f16 MFMA after the same prep launch; non-zero = geometry not covered
 int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st);

@@ -761,6 +761,9 @@ int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float*
 #undef KR_PV
     return 0;
 }
+void kr_launch_pfm_softmax_rows(float* sc, int sc_ld, float* inv, int nh, int pos0, int rows, const float* tmax, hipStream_t st) {
+    hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, nh, pos0, rows, tmax);
+}
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st) {
     hipLaunchKernelGGL(kr_pfm_moe_epilogue_kernel, dim3((H + 255) / 256, C), dim3(256), 0, st, moe, shared, gate_val, gate_ld, rsf, hidden, H);
 }
