@@ -230,9 +230,11 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaA
 // (kr_route_mfma.hip): 16 accumulators of a 32 x 32 block fed with (s, s + 1) pairs, tree (c0 + c1) + (c2 + c3), c0 = (a0 + a8) + (a4 + a12) ...
 // grid (position tiles of 64, row tiles of 64, 1); rows are (token, head) pairs in token-major order; 64 k per LDS stage.
 // ------------------------------------------------------------------------------------------------------------------------------------
-template <bool FP8>
-__global__ void __launch_bounds__(256) kr_mla_scores_mfma_kernel(const float* __restrict__ q_abs, const float* __restrict__ q_pe, const void* __restrict__ ckv,
-                                                                 const void* __restrict__ kpe, int nh, int klr, int rd, int pos0, int rows, float sm_scale,
+// Two launches, one dot each (holding the first dot's 16 folded values across a second 256-register accumulation made the register allocator spill
+// accumulators to scratch, and a kernel with a scratch segment runs with a fraction of the waves: 7.8 ms instead of ~1): ROPE = true writes
+// dot16(q_pe, kpe) of every visible (row, position) to the scratch; ROPE = false reads it back as the second addend: v = dot16(q_abs, ckv) + that; v *= sm_scale.
+template <bool FP8, bool ROPE>
+__global__ void __launch_bounds__(256) kr_mla_scores_mfma_kernel(const float* __restrict__ qb, const void* __restrict__ kbv, int nh, int K, int pos0, int rows, float sm_scale,
                                                                  float* __restrict__ sc, int sc_ld, float* __restrict__ tmax) {
     __shared__ __attribute__((aligned(16))) float As[64 * XM_LDF];
     __shared__ __attribute__((aligned(16))) float Bs[64 * XM_LDF];
@@ -279,57 +281,50 @@ __global__ void __launch_bounds__(256) kr_mla_scores_mfma_kernel(const float* __
             }
         }
     };
+    const char* kb = reinterpret_cast<const char*>(kbv);
     xm_v16f acc[16];
-    // one segment (K values of q rows against K values of cache rows): 16 chains, 64 k per stage, next stage requested under the MFMAs
-    auto segment = [&](const float* qb, const char* kb, int K) {
 #pragma unroll
-        for (int j = 0; j < 16; j++)
+    for (int j = 0; j < 16; j++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc[j][i] = 0.0f;
-        load_stage(qb, kb, K, 0);
-        for (int k0 = 0; k0 < K; k0 += 64) {
-            __syncthreads();
-            commit_stage();
-            if (k0 + 64 < K) load_stage(qb, kb, K, k0 + 64);
-            __syncthreads();
-            const float* ap = As + (rb + r31) * XM_LDF + 16 * kh;
-            const float* bp = Bs + (pb + r31) * XM_LDF + 16 * kh;
+        for (int i = 0; i < 16; i++) acc[j][i] = 0.0f;
+    // 16 chains, 64 k per stage, next stage requested under the MFMAs
+    load_stage(qb, kb, K, 0);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        __syncthreads();
+        commit_stage();
+        if (k0 + 64 < K) load_stage(qb, kb, K, k0 + 64);
+        __syncthreads();
+        const float* ap = As + (rb + r31) * XM_LDF + 16 * kh;
+        const float* bp = Bs + (pb + r31) * XM_LDF + 16 * kh;
 #pragma unroll
-            for (int m = 0; m < 2; m++) {                                     // 32 consecutive k: the (s, s + 1) pair of every chain
-                float av[16], bv[16];
+        for (int m = 0; m < 2; m++) {                                         // 32 consecutive k: the (s, s + 1) pair of every chain
+            float av[16], bv[16];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const xm_f4 x = *reinterpret_cast<const xm_f4*>(ap + 32 * m + 4 * q), y = *reinterpret_cast<const xm_f4*>(bp + 32 * m + 4 * q);
-                    av[4 * q] = x.x; av[4 * q + 1] = x.y; av[4 * q + 2] = x.z; av[4 * q + 3] = x.w;
-                    bv[4 * q] = y.x; bv[4 * q + 1] = y.y; bv[4 * q + 2] = y.z; bv[4 * q + 3] = y.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 16; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[j], 0, 0, 0);
+            for (int q = 0; q < 4; q++) {
+                const xm_f4 x = *reinterpret_cast<const xm_f4*>(ap + 32 * m + 4 * q), y = *reinterpret_cast<const xm_f4*>(bp + 32 * m + 4 * q);
+                av[4 * q] = x.x; av[4 * q + 1] = x.y; av[4 * q + 2] = x.z; av[4 * q + 3] = x.w;
+                bv[4 * q] = y.x; bv[4 * q + 1] = y.y; bv[4 * q + 2] = y.z; bv[4 * q + 3] = y.w;
             }
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[j], 0, 0, 0);
         }
-    };
-    auto fold = [&](int i) {
-        const float c0 = (acc[0][i] + acc[8][i]) + (acc[4][i] + acc[12][i]);
-        const float c1 = (acc[1][i] + acc[9][i]) + (acc[5][i] + acc[13][i]);
-        const float c2 = (acc[2][i] + acc[10][i]) + (acc[6][i] + acc[14][i]);
-        const float c3 = (acc[3][i] + acc[11][i]) + (acc[7][i] + acc[15][i]);
-        return (c0 + c1) + (c2 + c3);
-    };
-    float s1[16];
-    segment(q_abs, reinterpret_cast<const char*>(ckv), klr);                  // v = dot16(q_abs, ckv)
-#pragma unroll
-    for (int i = 0; i < 16; i++) s1[i] = fold(i);
-    segment(q_pe, reinterpret_cast<const char*>(kpe), rd);                    // v += dot16(q_pe, kpe)
-#pragma unroll
-    for (int i = 0; i < 16; i++) s1[i] = s1[i] + fold(i);
+    }
     const int pos = p_lo + pb + r31;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int r = rb + (i & 3) + 8 * (i >> 2) + 4 * kh;
+        const float c0 = (acc[0][i] + acc[8][i]) + (acc[4][i] + acc[12][i]);
+        const float c1 = (acc[1][i] + acc[9][i]) + (acc[5][i] + acc[13][i]);
+        const float c2 = (acc[2][i] + acc[10][i]) + (acc[6][i] + acc[14][i]);
+        const float c3 = (acc[3][i] + acc[11][i]) + (acc[7][i] + acc[15][i]);
+        const float d = (c0 + c1) + (c2 + c3);
         float mv = -__builtin_inff();
         const size_t rowi = (size_t)row0 + (r < R ? r : 0);
-        if (r < R && pos <= pos0 + (int)(rowi / nh)) { mv = s1[i] * sm_scale; sc[rowi * sc_ld + pos] = mv; }
-        if (tmax) {
+        if (r < R && pos <= pos0 + (int)(rowi / nh)) {
+            if (ROPE) sc[rowi * sc_ld + pos] = d;                             // the second addend, picked up by the latent launch
+            else { mv = (d + sc[rowi * sc_ld + pos]) * sm_scale; sc[rowi * sc_ld + pos] = mv; }      // v = dot(latent) + dot(rope); v *= sm_scale
+        }
+        if (!ROPE && tmax) {
             mv = fmaxf(mv, __shfl_xor(mv, 16)); mv = fmaxf(mv, __shfl_xor(mv, 8)); mv = fmaxf(mv, __shfl_xor(mv, 4));
             mv = fmaxf(mv, __shfl_xor(mv, 2)); mv = fmaxf(mv, __shfl_xor(mv, 1));
             if (r31 == 0 && r < R) tmax[rowi * (size_t)(sc_ld >> 5) + ((p_lo + pb) >> 5)] = mv;
@@ -367,7 +362,9 @@ int kr_launch_mla_scores_mfma(const float* q_abs, const float* q_pe, const void*
     const int rows = n_tok * nh;
     const dim3 grid((pos0 + n_tok + 63) / 64, (rows + 63) / 64);
     if (klr % 64 || rd % 64) return 1;
-    if (kv_fp8) hipLaunchKernelGGL(kr_mla_scores_mfma_kernel<true>, grid, dim3(256), 0, st, q_abs, q_pe, ckv, kpe, nh, klr, rd, pos0, rows, sm_scale, sc, sc_ld, tmax);
-    else hipLaunchKernelGGL(kr_mla_scores_mfma_kernel<false>, grid, dim3(256), 0, st, q_abs, q_pe, ckv, kpe, nh, klr, rd, pos0, rows, sm_scale, sc, sc_ld, tmax);
+#define KR_MS(F_, R_, Q_, C_, K_) hipLaunchKernelGGL((kr_mla_scores_mfma_kernel<F_, R_>), grid, dim3(256), 0, st, Q_, C_, nh, K_, pos0, rows, sm_scale, sc, sc_ld, tmax)
+    if (kv_fp8) { KR_MS(true, true, q_pe, kpe, rd); KR_MS(true, false, q_abs, ckv, klr); }
+    else { KR_MS(false, true, q_pe, kpe, rd); KR_MS(false, false, q_abs, ckv, klr); }
+#undef KR_MS
     return 0;
 }
