@@ -35,7 +35,9 @@ template <bool FP8>
 __global__ void __launch_bounds__(256, 2) kr_pfm_gqa_scores_mfma_kernel(const KrPfmGqaArgs a, float* __restrict__ sc, int sc_ld, int C, float* __restrict__ tmax) {
     __shared__ __attribute__((aligned(16))) float Qs[64 * XM_LDF];
     __shared__ __attribute__((aligned(16))) float Ks[64 * XM_LDF];
-    const int hd = a.hd, group = a.nh / a.nkv, kvh = blockIdx.z, TT = 64 / group, t0 = blockIdx.y * TT, kvs = a.nkv * hd;
+    // group divides 32: a power of two -- tokens and heads of a row by shift and mask (a run-time integer division is ~50 instructions, and a lone wave
+    // issues one per ~8 cycles: 16 rows x 2 divisions per lane were a third of a workgroup's life)
+    const int hd = a.hd, group = a.nh / a.nkv, lg = __builtin_ctz(group), gm = group - 1, kvh = blockIdx.z, TT = 64 >> lg, t0 = blockIdx.y * TT, kvs = a.nkv * hd;
     const int tn = min(TT, C - t0), R = group * tn;
     const int p_lo = blockIdx.x * 64, p_max = a.pos0 + t0 + tn - 1;          // last position any query of the tile may see
     if (p_lo > p_max) return;
@@ -52,7 +54,7 @@ __global__ void __launch_bounds__(256, 2) kr_pfm_gqa_scores_mfma_kernel(const Kr
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-        const int rr = row < R ? row : R - 1, tt = rr / group, hh = kvh * group + rr % group;
+        const int rr = row < R ? row : R - 1, tt = rr >> lg, hh = kvh * group + (rr & gm);
         qsrc[i] = a.q_out + (size_t)(t0 + tt) * a.nh * hd + (size_t)hh * hd + c4;
     }
     constexpr int KCH = FP8 ? 1 : 2;
@@ -120,13 +122,13 @@ __global__ void __launch_bounds__(256, 2) kr_pfm_gqa_scores_mfma_kernel(const Kr
         float mv = -__builtin_inff();
         size_t rowi = 0;
         if (r < R) {
-            const int tt = r / group, hh = kvh * group + r % group;
+            const int tt = r >> lg, hh = kvh * group + (r & gm);
             rowi = (size_t)(t0 + tt) * a.nh + hh;
             if (pos <= a.pos0 + t0 + tt) { mv = sv * a.sm_scale; sc[rowi * sc_ld + pos] = mv; }
         }
         if (tmax) {        // maximum over the 32 lanes of this lane half (the other half holds other rows)
-            mv = fmaxf(mv, __shfl_xor(mv, 16)); mv = fmaxf(mv, __shfl_xor(mv, 8)); mv = fmaxf(mv, __shfl_xor(mv, 4));
-            mv = fmaxf(mv, __shfl_xor(mv, 2)); mv = fmaxf(mv, __shfl_xor(mv, 1));
+            mv = kr_red16_max_f32(mv);                            // 4 DPP steps inside each 16-lane row, then one exchange between the two rows of the lane half
+            mv = fmaxf(mv, __shfl_xor(mv, 16));
             if (r31 == 0 && r < R) tmax[rowi * (size_t)(sc_ld >> 5) + ((p_lo + pb) >> 5)] = mv;
         }
     }
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaA
     static_assert(VCH >= 1 && (PPT == 4 || PPT == 8), "stage shape");
     __shared__ __attribute__((aligned(16))) float Ps[32 * PLD];
     __shared__ __attribute__((aligned(16))) char Vs[PS * VROW];
-    const int group = a.nh / a.nkv, kvh = blockIdx.y, TT = 32 / group, t0 = blockIdx.x * TT, kvs = a.nkv * HD;
+    const int group = a.nh / a.nkv, lg = __builtin_ctz(group), gm = group - 1, kvh = blockIdx.y, TT = 32 >> lg, t0 = blockIdx.x * TT, kvs = a.nkv * HD;      // group: a power of two
     const int tn = min(TT, C - t0), R = group * tn, p_max = a.pos0 + t0 + tn - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, kh = lane >> 5;
     xm_v16f acc[NB];
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaA
         for (int i = 0; i < 16; i++) acc[b][i] = 0.0f;
     // staging maps: P row = tid >> 3 (32 rows), PPT positions per thread; V chunk u = tid + 256 i: row u / CPR, 16-byte chunk u % CPR
     const int prow = tid >> 3, pseg = (tid & 7) * PPT;
-    const int ptt = (prow < R ? prow : 0) / group, pg = (prow < R ? prow : 0) % group, qpos = a.pos0 + t0 + ptt;
+    const int ptt = (prow < R ? prow : 0) >> lg, pg = (prow < R ? prow : 0) & gm, qpos = a.pos0 + t0 + ptt;
     const float* prow_p = sc + ((size_t)(t0 + ptt) * a.nh + (size_t)kvh * group + pg) * sc_ld;
     // pass B left the exponentials unscaled (inv != nullptr): p = e * (1 / sum) is formed here, the multiply the reference does in place (decode.rs:4260)
     const float iv = inv ? inv[(size_t)(t0 + ptt) * a.nh + (size_t)kvh * group + pg] : 1.0f;
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_pv_mfma_kernel(const KrPfmGqaA
         for (int i = 0; i < 16; i++) {
             const int r = (i & 3) + 8 * (i >> 2) + 4 * kh;
             if (r < R) {
-                const int tt = r / group, hh = kvh * group + r % group;
+                const int tt = r >> lg, hh = kvh * group + (r & gm);
                 float o = acc[b][i];
                 const size_t oi = (size_t)(t0 + tt) * a.nh * HD + (size_t)hh * HD + (size_t)(wave * NB + b) * 32 + r31;
                 if (a.gated) { const float gt = a.gate[oi]; o *= 1.0f / (1.0f + kr_expf(-gt)); }
@@ -239,7 +241,8 @@ __global__ void __launch_bounds__(256) kr_mla_scores_mfma_kernel(const float* __
     __shared__ __attribute__((aligned(16))) float As[64 * XM_LDF];
     __shared__ __attribute__((aligned(16))) float Bs[64 * XM_LDF];
     const int row0 = blockIdx.y * 64, R = min(64, rows - row0);
-    const int p_lo = blockIdx.x * 64, p_max = pos0 + (row0 + R - 1) / nh;     // last position any row of the tile may see
+    const int lnh = __builtin_ctz(nh);                                        // nh divides 32: a power of two
+    const int p_lo = blockIdx.x * 64, p_max = pos0 + ((row0 + R - 1) >> lnh);  // last position any row of the tile may see
     if (p_lo > p_max) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, kh = lane >> 5;
     const int rb = (wave >> 1) * 32, pb = (wave & 1) * 32;
@@ -320,13 +323,13 @@ __global__ void __launch_bounds__(256) kr_mla_scores_mfma_kernel(const float* __
         const float d = (c0 + c1) + (c2 + c3);
         float mv = -__builtin_inff();
         const size_t rowi = (size_t)row0 + (r < R ? r : 0);
-        if (r < R && pos <= pos0 + (int)(rowi / nh)) {
+        if (r < R && pos <= pos0 + (int)(rowi >> lnh)) {
             if (ROPE) sc[rowi * sc_ld + pos] = d;                             // the second addend, picked up by the latent launch
             else { mv = (d + sc[rowi * sc_ld + pos]) * sm_scale; sc[rowi * sc_ld + pos] = mv; }      // v = dot(latent) + dot(rope); v *= sm_scale
         }
         if (!ROPE && tmax) {
-            mv = fmaxf(mv, __shfl_xor(mv, 16)); mv = fmaxf(mv, __shfl_xor(mv, 8)); mv = fmaxf(mv, __shfl_xor(mv, 4));
-            mv = fmaxf(mv, __shfl_xor(mv, 2)); mv = fmaxf(mv, __shfl_xor(mv, 1));
+            mv = kr_red16_max_f32(mv);                            // 4 DPP steps inside each 16-lane row, then one exchange between the two rows of the lane half
+            mv = fmaxf(mv, __shfl_xor(mv, 16));
             if (r31 == 0 && r < R) tmax[rowi * (size_t)(sc_ld >> 5) + ((p_lo + pb) >> 5)] = mv;
         }
     }
