@@ -179,24 +179,26 @@ __global__ void __launch_bounds__(256, 2) kr_gpf_gemm_kernel(const GpfGemmArgs a
 #pragma unroll
         for (int r = 0; r < 16; r++) { outv[s][r] = 0.0f; corr[s][r] = 0.0f; }
     const int n31 = lane & 31, khalf = lane >> 5, cw = wave * 32 + n31;     // this lane's column inside the tile
-    const int ar = tid >> 2, aq = tid & 3;
+    const int ar = tid >> 2, aq = tid & 3;                                  // activation scales / sums: 4 threads per row
+    const int arow = tid >> 4, aseg = (tid >> 3) & 1, achk = tid & 7;       // activation digits: whole lines (below)
     const int nst = (K + GPF_KS - 1) / GPF_KS;
 
     u32x4 pvh[4], pvl[4], pbw[Q4K ? 4 : 8], phd, pws;
     float2 pasc, pasm;
     auto load_stage = [&](int st) {
-        {   // A digits: 4 threads per row, 64 bytes each per plane
-            const int src = row_src[ar];
-            const size_t go = (size_t)(src < 0 ? 0 : src) * K + (size_t)st * GPF_KS + aq * 64;
+        {   // A digits: whole 128-byte lines per request (8 lanes x 16 B; load j of thread tid = row (tid >> 4) + 16 j, line (tid >> 3) & 1, chunk tid & 7 --
+            // the grouped INT4 GEMM's finding, kr_prefill_gemm2.inc), never masked: a tile row past `rows` reads row 0 and is not stored, a line past K
+            // re-reads line 0 of the segment and meets activation scale 0 / weight blocks that are zero (the scale / sum loads below keep their guards)
             const int kvalid = K - st * GPF_KS;
+            const int so = aseg * 128 + achk * 16 < kvalid ? aseg * 128 + achk * 16 : 0;     // (per chunk: K % 128 may be 64, nothing is read past a row's end)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                pvh[j] = u32x4{0, 0, 0, 0}; pvl[j] = u32x4{0, 0, 0, 0};
-                if (src >= 0 && aq * 64 + j * 16 < kvalid) {
-                    pvh[j] = *reinterpret_cast<const u32x4*>(a.a_hi + go + j * 16);
-                    pvl[j] = *reinterpret_cast<const u32x4*>(a.a_lo + go + j * 16);
-                }
+                const int srcj = row_src[arow + 16 * j];
+                const size_t go = (size_t)(srcj < 0 ? 0 : srcj) * K + (size_t)st * GPF_KS + so;
+                pvh[j] = *reinterpret_cast<const u32x4*>(a.a_hi + go);
+                pvl[j] = *reinterpret_cast<const u32x4*>(a.a_lo + go);
             }
+            const int src = row_src[ar];
             pasc = make_float2(0.0f, 0.0f); pasm = make_float2(0.0f, 0.0f);
             const int sb0 = st * 8 + aq * 2;
             if (src >= 0 && sb0 < nsub) {      // nsub is even for every supported K (K % 64 == 0 is checked on the host)
@@ -237,8 +239,8 @@ __global__ void __launch_bounds__(256, 2) kr_gpf_gemm_kernel(const GpfGemmArgs a
     auto commit_stage = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            *reinterpret_cast<u32x4*>(As_hi + ar * GPF_LDA + aq * 64 + j * 16) = pvh[j];
-            *reinterpret_cast<u32x4*>(As_lo + ar * GPF_LDA + aq * 64 + j * 16) = pvl[j];
+            *reinterpret_cast<u32x4*>(As_hi + (arow + 16 * j) * GPF_LDA + aseg * 128 + achk * 16) = pvh[j];
+            *reinterpret_cast<u32x4*>(As_lo + (arow + 16 * j) * GPF_LDA + aseg * 128 + achk * 16) = pvl[j];
         }
         As_sc[(aq * 2) * GPF_BM + ar] = pasc.x; As_sc[(aq * 2 + 1) * GPF_BM + ar] = pasc.y;
         As_sm[(aq * 2) * GPF_BM + ar] = pasm.x; As_sm[(aq * 2 + 1) * GPF_BM + ar] = pasm.y;
