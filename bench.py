@@ -611,7 +611,8 @@ def main():
                 if ok:
                     side[key] = dict(ok[0]); side[key]["by_prompt_length"] = {str(r["tokens"]): round(r["value"], 1) for r in ok}
                     side[key]["attention"] = ("fast: causal flash attention on f16 MFMA (f32 online softmax; logits within ~1e-3 relative of the exact pass)" if fast else
-                                              "exact: the CPU decode's operation order per query (bit-identical to token-by-token decode), vector ALUs")
+                                              "exact: the CPU decode's operation order per query (bit-identical to token-by-token decode); scores and P.V as f32 fma chains on the matrix cores, "
+                                              "sequential softmax sum, per-token delta rule")
                     side[key]["gemm"] = ("tolerance form (KR_GEMM_FAST): f16 activation rows x weights de-quantized in registers on the f16 MFMA, f32 accumulation over the "
                                          "whole k range -- the dataflow of the reference's GPU prompt pass; expert outputs within 2-4e-4 relative RMS of the exact kernel, "
                                          "PPL within 1e-3 (tests/test_gemm_fast_gpu.py)" if gfast else
