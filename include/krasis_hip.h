@@ -241,6 +241,7 @@ int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype);
 #define KR_ATTN_EXACT 0
 #define KR_ATTN_FAST 1
 #define KR_GEMM_FAST 2   /* or-ed into the mode: every GEMM of kr_decode_prefill (projections, shared expert, routed experts, lm_head of the scoring pass) in the tolerance form of kr_moe_set_gemm_mode; decode steps are unaffected */
+#define KR_DECODE_FAST 4 /* or-ed into the mode: decode steps run the tolerance-mode kernels of kr_decode_fast.hip -- the reference's products (INT16 activation digits, exact integer group sums, its sigmoid / libm functions), but every f32 reduction as a lane / wave / workgroup TREE instead of the reference's sequential chain, the norms folded into the launches that consume them, top-k + silu*up + the expert combine inside the expert launches (6 launches per linear-attention MoE layer).  Router ids are those of the exact kernels for identical logits (ties fall back to the reference's heap order); logits agree with the exact mode to the tolerance stated in tests/test_decode_fast_gpu.py.  Layers / geometries the kernels do not cover (MLA, dense MLP, GPT-OSS activation, E > 512, hidden > 4096) silently keep the exact kernels.  The prompt pass is unaffected. */
 int kr_decode_set_attention_mode(kr_decode_store* s, int mode);                                                                        /* decode.rs:2471 */
 /* Whole-model prompt pass.  Replaces the reference's GPU prefill (python/krasis/model.py forward_prefill_layer_grouped / server_prefill,
  * layer.py:242-461, attention.py:496-687, linear_attention.py:695-845 -- third-party kernels) AND the GPU->CPU state hand-off

@@ -23,6 +23,7 @@
 #include <chrono>
 
 #include "kr_decode_internal.h"
+#include "kr_decode_fast.h"
 
 static void prof_mark(kr_decode_store* s, int kind, hipStream_t st) {
     if (!s->prof) return;
@@ -72,7 +73,7 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                            &l.w_kc, &l.w_vc, &l.kv_a_norm, &l.q_a_norm, &l.mla_cos, &l.mla_sin}) b->release();
     for (DevBuf* b : {&s->embedding, &s->rope_cos, &s->rope_sin, &s->hid, &s->res, &s->proj_a, &s->proj_b, &s->qbuf, &s->kbuf, &s->vbuf, &s->zbuf,
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
-                      &s->hid2, &s->res2, &s->r_counter, &s->gqa_scores, &s->fd_o, &s->fd_ml, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_vlogits, &s->pf_nll, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
+                      &s->hid2, &s->res2, &s->f_qk, &s->r_counter, &s->gqa_scores, &s->fd_o, &s->fd_ml, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_vlogits, &s->pf_nll, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     for (hipEvent_t ev : s->pf_events) (void)hipEventDestroy(ev);
     for (hipStream_t ps : s->pf_side) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
     if (s->own_eng) kr_engine_destroy(s->eng);
@@ -338,12 +339,12 @@ extern "C" int kr_decode_finalize(kr_decode_store* s) {
     if (int rc = need_cfg(s)) return rc;
     if ((int)s->layers.size() != s->n_layers) return kr_fail(KR_ERR_STATE, "configured %d layers but %zu were added", s->n_layers, s->layers.size());
     KR_HIP(hipSetDevice(s->eng->device));
-    size_t pa = 0, pb = 0, qb = 0, kb = 0, vb = 0, zb = 0, ro = 0, ao = 0, gb = 0, dg = 0, lb = 0;
+    size_t pa = 0, pb = 0, qb = 0, kb = 0, vb = 0, zb = 0, ro = 0, ao = 0, gb = 0, dg = 0, lb = 0, fq = 64;
     for (auto& L : s->layers) {
         if (L.attn == ATTN_LA) {
             pa = maxz(pa, s->weights[L.qkvz_wid]->rows); pb = maxz(pb, s->weights[L.ba_wid]->rows);
             qb = maxz(qb, (size_t)L.nv * L.dk); kb = maxz(kb, (size_t)L.nv * L.dk); vb = maxz(vb, (size_t)L.nv * L.dv); zb = maxz(zb, (size_t)L.nv * L.dv);
-            ro = maxz(ro, (size_t)L.nv * L.dv); ao = maxz(ao, s->weights[L.out_wid]->cols); gb = maxz(gb, L.nv);
+            ro = maxz(ro, (size_t)L.nv * L.dv); ao = maxz(ao, s->weights[L.out_wid]->cols); gb = maxz(gb, L.nv); fq = maxz(fq, (size_t)L.nk * 2 * L.dk);
         } else if (L.attn == ATTN_GQA) {
             pa = maxz(pa, s->weights[L.q_wid]->rows); kb = maxz(kb, s->weights[L.k_wid]->rows); vb = maxz(vb, s->weights[L.v_wid]->rows);
             qb = maxz(qb, (size_t)L.nh * L.hd); zb = maxz(zb, (size_t)L.nh * L.hd); ao = maxz(ao, s->weights[L.o_wid]->cols);
@@ -366,7 +367,7 @@ extern "C" int kr_decode_finalize(kr_decode_store* s) {
     if (s->proj_a.ensure(maxz(pa, 64) * 4) || s->proj_b.ensure(maxz(pb, 64) * 4) || s->qbuf.ensure(maxz(qb, 64) * 4) || s->kbuf.ensure(maxz(kb, 64) * 4) ||
         s->vbuf.ensure(maxz(vb, 64) * 4) || s->zbuf.ensure(maxz(zb, 64) * 4) || s->recur_out.ensure(maxz(ro, 64) * 4) ||
         s->attn_out.ensure(maxz(ao, 64) * 4) || s->gbuf.ensure(maxz(gb, 64) * 4) || s->betabuf.ensure(maxz(gb, 64) * 4) ||
-        s->gatebuf.ensure(maxz(zb, 64) * 4) || s->latbuf.ensure(maxz(lb, 64) * 4))
+        s->gatebuf.ensure(maxz(zb, 64) * 4) || s->latbuf.ensure(maxz(lb, 64) * 4) || s->f_qk.ensure(fq * 4))
         return kr_fail(KR_ERR_HIP, "hipMalloc of decode scratch failed");
     if (dg) { if (s->dense_gu.ensure(dg * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed"); KR_HIP(hipMemset(s->dense_gu.p, 0, s->dense_gu.bytes)); }
     KR_HIP(hipMemset(s->proj_a.p, 0, s->proj_a.bytes));
@@ -485,7 +486,11 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
     KrNormSrc src{}; src.mode = 1; src.emb = (const float*)s->embedding.p; src.step = step;
     const KrNormSrc from_hidden{};  // mode 0
     bool first = true;
-    const float* res_cur = res;   // where the residual stream currently lives (res, or res2 after a fused norm+router launch)
+    float* res_cur = res;   // where the residual stream currently lives: a launch whose workgroups all read the residual writes the OTHER buffer
+    float* const res_b = (float*)s->res2.p;
+    auto other = [&](float* r) { return r == res ? res_b : res; };
+    // KR_DECODE_FAST (kr_decode_fast.hip): tolerance-mode kernels for the pieces whose geometry they cover; everything else stays exact
+    const bool fast = s->decode_fast && s->use_images && H % 128 == 0 && H <= 4096 && s->f_qk.p;
     for (size_t li = 0; li < s->layers.size(); li++) {
         DLayer& L = s->layers[li];
         // INT16 activation images: built once by the kernel that produces an activation, copied by every workgroup of the
@@ -498,12 +503,58 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             if (L.attn == ATTN_LA) in_img = img_w(L.qkvz_wid) && img_w(L.ba_wid, L.qkvz_wid);
             else if (L.attn == ATTN_GQA) in_img = img_w(L.q_wid) && img_w(L.k_wid, L.q_wid) && img_w(L.v_wid, L.q_wid);
         }
-        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st,
-                                                     in_img ? s->img_in.p : nullptr));
-        first = false; src = from_hidden; res_cur = res;
+        // FAST: the input add+RMSNorm folded into the first projection launch (every workgroup rebuilds the normalised vector with tree sums)
+        bool did_in = false, la_conv_done = false;
+        if (fast && in_img && src.mode != 2) {
+            KrFdmArgs fa{};
+            fa.mode = 1; fa.hid_in = hid; fa.res_in = res_cur; fa.res_out = other(res_cur); fa.norm_w = (const float*)s->norms[L.input_norm]->p;
+            fa.first = first ? 1 : 0; fa.eps = s->eps; fa.bias_one = s->norm_bias_one;
+            if (src.mode == 1) { fa.emb = src.emb; fa.step = src.step; }
+            int total = 0;
+            auto add = [&](int wid, float* y) { fa.mm.m[fa.mm.n] = mv(s, wid); fa.mm.y[fa.mm.n] = y; total += (fa.mm.m[fa.mm.n].N + 7) / 8; fa.mm.tile_end[fa.mm.n] = total; fa.mm.n++; };
+            if (L.attn == ATTN_LA) {
+                add(L.qkvz_wid, (float*)s->proj_a.p); add(L.ba_wid, (float*)s->proj_b.p);
+                const int hr = L.nv / L.nk;
+                if (L.dv == 128 && (L.dk == 128 || L.dk == 64) && L.nv == L.nk * hr && L.kd == 4 && img_w(L.out_wid)) {
+                    fa.conv_state = (float*)L.conv_state.p; fa.conv_w = (const float*)L.conv_w.p; fa.qk_out = (float*)s->f_qk.p; fa.v_out = (float*)s->vbuf.p; fa.z_out = (float*)s->zbuf.p;
+                    fa.nk = L.nk; fa.dk = L.dk; fa.hr = hr; fa.dv = L.dv;
+                }
+            } else { add(L.q_wid, (float*)s->proj_a.p); add(L.k_wid, (float*)s->kbuf.p); add(L.v_wid, (float*)s->vbuf.p); }
+            prof_mark(s, PK_MATVEC, st);
+            did_in = 0 == kr_launch_fdm(fa, st);
+            prof_mark(s, -1, st);
+            if (did_in) { la_conv_done = fa.conv_state != nullptr; res_cur = other(res_cur); }
+        }
+        if (!did_in) {
+            PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[L.input_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st,
+                                                         in_img ? s->img_in.p : nullptr));
+            res_cur = res;
+        }
+        first = false; src = from_hidden;
         const void* xin = in_img ? (const void*)s->img_in.p : (const void*)hid; const int xin_kind = in_img ? 2 : 1;
-        if (L.attn == ATTN_LA) {
-            {
+        // FAST out / o projection from the attention output's INT16 image: K split over the waves of a workgroup, tree sums
+        auto out_proj = [&](int wid) {
+            if (fast) {
+                KrFdmArgs fo{}; fo.mode = 0; fo.img = s->img_attn.p; fo.mm.n = 1; fo.mm.m[0] = mv(s, wid); fo.mm.y[0] = hid; fo.mm.tile_end[0] = (fo.mm.m[0].N + 7) / 8;
+                prof_mark(s, PK_MATVEC, st);
+                const int rc = kr_launch_fdm(fo, st);
+                prof_mark(s, -1, st);
+                if (rc == 0) return;
+            }
+            PROF(PK_MATVEC, kr_launch_matvec(mv(s, wid), s->img_attn.p, 2, hid, st));
+        };
+        if (L.attn == ATTN_LA && la_conv_done) {
+            KrFlaArgs a{};
+            a.qk = (const float*)s->f_qk.p; a.v = (const float*)s->vbuf.p; a.z = (const float*)s->zbuf.p; a.ba = (const float*)s->proj_b.p;
+            a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale; a.state = (float*)L.recur_state.p;
+            a.norm_w = (const float*)L.la_norm_w.p; a.out = (float*)s->attn_out.p; a.img_out = s->img_attn.p; a.img_k = s->weights[L.out_wid]->ms.view().ng * 128;
+            a.nk = L.nk; a.nv = L.nv; a.hr = L.nv / L.nk; a.dk = L.dk; a.dv = L.dv; a.eps = s->eps;
+            prof_mark(s, PK_LA_RECUR, st);
+            if (kr_launch_fla(a, st)) return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry (fast mode)");
+            prof_mark(s, -1, st);
+            out_proj(L.out_wid);
+        } else if (L.attn == ATTN_LA) {
+            if (!did_in) {
                 const KrMatDev mats[2] = {mv(s, L.qkvz_wid), mv(s, L.ba_wid)};
                 float* ys[2] = {(float*)s->proj_a.p, (float*)s->proj_b.p};
                 if (mats[0].bits == mats[1].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 2, xin, xin_kind, st));
@@ -529,11 +580,11 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
                     return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
                 prof_mark(s, -1, st);
             }
-            if (img_ok && img_w(L.out_wid) && L.dv == 128) PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->img_attn.p, 2, hid, st));
+            if (img_ok && img_w(L.out_wid) && L.dv == 128) out_proj(L.out_wid);
             else PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.out_wid), s->attn_out.p, 1, hid, st));
         } else if (L.attn == ATTN_GQA) {
             if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no KV cache for layer %zu)", li);
-            {
+            if (!did_in) {
                 const KrMatDev mats[3] = {mv(s, L.q_wid), mv(s, L.k_wid), mv(s, L.v_wid)};
                 float* ys[3] = {(float*)s->proj_a.p, (float*)s->kbuf.p, (float*)s->vbuf.p};
                 if (mats[0].bits == mats[1].bits && mats[0].bits == mats[2].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 3, xin, xin_kind, st));
@@ -551,7 +602,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.sc_g = s->kv_max_seq > s->gqa_split_min ? (float*)s->gqa_scores.p : nullptr;
             if (s->attn_fast && a.sc_g) { a.fd_o = (float*)s->fd_o.p; a.fd_ml = (float*)s->fd_ml.p; }
             PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
-            if (o_img) PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->img_attn.p, 2, hid, st));
+            if (o_img) out_proj(L.o_wid);
             else PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }
         else if (L.attn == ATTN_MLA) {
@@ -584,24 +635,59 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
         }
         // post-attention fused add+RMSNorm: folded into the router launch of MoE layers, its own launch otherwise
         const float* act = hid;   // normalised hidden the MLP block reads
-        bool routed = false;
+        bool routed = false, moe_done = false;
         if (L.mlp == MLP_MOE) {
             if (s->own_eng || L.moe_layer >= (int)e->layers.size()) return kr_fail(KR_ERR_STATE, "set_moe_store was not called (MoE layer %d has no engine)", L.moe_layer);
             Layer& EL = e->layers[L.moe_layer];
             if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
             if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
-            if (s->fuse_router) {
+            if (fast) {   // norm + gate GEMV | select + gate|up + silu*up | down + combine: three launches, the MoE output lands in `hid`
+                const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
+                KrFmoeArgs fa{}; KrMoeArgs& a = fa.m;
+                a.shared_decode = 1; a.act_img = s->img_post.p; a.act_img_bf16 = s->img_post_bf16.p;
+                a.ids = (const int32_t*)s->r_ids.p; a.wts = (const float*)s->r_w.p;
+                a.B = 1; a.topk = s->topk; a.n_slots = s->topk + (has_shared ? 1 : 0); a.E = e->r_ne; a.H = H; a.I = EL.inter;
+                a.w13 = EL.w13.view(); a.w2 = EL.w2.view();
+                if (has_shared) { a.sw13 = mv(s, L.sgu_wid); a.sw2 = mv(s, L.sd_wid); a.I_shared = s->weights[L.sgu_wid]->rows / 2; }
+                const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
+                a.gu_ld = 2 * imax; a.gu = (float*)s->moe_gu.p; a.eo = (float*)s->moe_eo.p;
+                a.rsf = s->rsf; a.swiglu_limit = e->cfg.swiglu_limit; a.alpha = e->cfg.activation_alpha;
+                a.act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
+                bool ok = true;
+                if (has_gate) {
+                    if (a.w13.bits == a.sw13.bits && mv(s, L.sg_wid).bits == a.w13.bits) { a.sgate = mv(s, L.sg_wid); a.gate_out = (float*)s->gate_val.p; }
+                    else ok = false;
+                }
+                fa.logits = (const float*)s->r_logits.p; fa.esc = EL.has_esc ? (const float*)EL.esc.p : nullptr; fa.scoring = s->scoring; fa.norm_topk = s->norm_topk;
+                fa.hid_out = hid;
+                if (ok && kr_fmoe_check(fa) == 0) {
+                    KrFrtArgs ra{};
+                    ra.gate_cm = EL.gate_cm.p; ra.gate_bf16 = EL.gate_bf16_exact; ra.bias = EL.has_bias ? (const float*)EL.bias.p : nullptr; ra.logits = (float*)s->r_logits.p;
+                    ra.E = e->r_ne; ra.H = H; ra.hid_in = hid; ra.res_in = res_cur; ra.norm_w = (const float*)s->norms[L.post_norm]->p; ra.hid_out = (float*)s->hid2.p;
+                    ra.res_out = other(res_cur); ra.eps = s->eps; ra.bias_one = s->norm_bias_one; ra.img_f32 = s->img_post.p; ra.img_bf16 = s->img_post_bf16.p;
+                    prof_mark(s, PK_ROUTE_LOGITS, st);
+                    const int rc = kr_launch_frt(ra, st);
+                    prof_mark(s, -1, st);
+                    if (rc == 0) {
+                        prof_mark(s, PK_MOE_W13, st); (void)kr_launch_fw13(fa, st); prof_mark(s, -1, st);
+                        prof_mark(s, PK_MOE_W2, st); (void)kr_launch_fw2(fa, st); prof_mark(s, -1, st);
+                        res_cur = other(res_cur); src = from_hidden; moe_done = true;
+                    }
+                }
+            }
+            if (!moe_done && s->fuse_router) {
                 prof_mark(s, PK_ROUTE_LOGITS, st);
                 routed = 0 == kr_launch_route_fused_decode(EL.gate_cm.p, EL.gate_bf16_exact, EL.has_bias ? (const float*)EL.bias.p : nullptr, (float*)s->r_logits.p,
                                                            (unsigned*)s->r_counter.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p,
-                                                           (float*)s->r_w.p, e->r_ne, H, s->topk, s->scoring, s->norm_topk, nullptr, hid, res,
-                                                           (const float*)s->norms[L.post_norm]->p, (float*)s->hid2.p, (float*)s->res2.p, s->eps,
+                                                           (float*)s->r_w.p, e->r_ne, H, s->topk, s->scoring, s->norm_topk, nullptr, hid, res_cur,
+                                                           (const float*)s->norms[L.post_norm]->p, (float*)s->hid2.p, other(res_cur), s->eps,
                                                            s->norm_bias_one, st, img_ok ? s->img_post.p : nullptr, img_ok ? s->img_post_bf16.p : nullptr);
                 prof_mark(s, -1, st);
-                if (routed) { act = (const float*)s->hid2.p; res_cur = (const float*)s->res2.p; }
+                if (routed) { act = (const float*)s->hid2.p; res_cur = other(res_cur); }
             }
         }
-        if (!routed) PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res, res, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st));
+        if (moe_done) continue;
+        if (!routed) PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res_cur, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st));
         if (L.mlp == MLP_MOE) {
             Layer& EL = e->layers[L.moe_layer];
             const int E = e->r_ne, k = s->topk;
@@ -714,8 +800,8 @@ extern "C" int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype) {
 // summation order; logits within ~1e-4 relative.  Router ids, every matvec and the short-cache kernels are unaffected.
 extern "C" int kr_decode_set_attention_mode(kr_decode_store* s, int mode) {
     if (int rc = chk_store(s)) return rc;
-    if (mode < 0 || mode > 3) return kr_fail(KR_ERR_VALUE, "numerics mode %d unknown (bit 0 = KR_ATTN_FAST, bit 1 = KR_GEMM_FAST)", mode);
-    s->attn_fast = mode & 1; s->gemm_fast = (mode >> 1) & 1; s->graph_ok = false;
+    if (mode < 0 || mode > 7) return kr_fail(KR_ERR_VALUE, "numerics mode %d unknown (bit 0 = KR_ATTN_FAST, bit 1 = KR_GEMM_FAST, bit 2 = KR_DECODE_FAST)", mode);
+    s->attn_fast = mode & 1; s->gemm_fast = (mode >> 1) & 1; s->decode_fast = (mode >> 2) & 1; s->graph_ok = false;
     return KR_OK;
 }
 
@@ -872,7 +958,10 @@ extern "C" int kr_decode_read_buffer(kr_decode_store* s, int which, float* out, 
     if (int rc = need_cfg(s)) return rc;
     KR_HIP(hipSetDevice(s->eng->device));
     KR_HIP(hipStreamSynchronize(s->eng->stream));
-    DevBuf* b = which == 0 ? &s->hid : &s->res;
+    // 0 hidden, 1 residual, 2 router ids (int32 bits), 3 router weights, 4 router logits of the LAST MoE layer of the last step, 5 second residual buffer
+    DevBuf* b = which == 0 ? &s->hid : which == 1 ? &s->res : which == 2 ? &s->r_ids : which == 3 ? &s->r_w : which == 4 ? &s->r_logits : which == 5 ? &s->res2 : nullptr;
+    if (!b || !b->p || (size_t)n * 4 > b->bytes) return kr_fail(KR_ERR_VALUE, "read_buffer: buffer %d unknown or shorter than %d words", which, n);
+    if (s->last_stream) KR_HIP(hipStreamSynchronize(s->last_stream));
     KR_HIP(hipMemcpy(out, b->p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return KR_OK;
 }

@@ -1,0 +1,748 @@
+// kr_decode_fast.hip -- the decode step in TOLERANCE mode (mode bit KR_DECODE_FAST of kr_decode_set_attention_mode) for gfx950.
+//
+// Same operators as the exact decode graph (kr_decode_ops.hip, kr_moe_decode.hip, kr_router.hip; reference src/decode.rs:2690-3520,
+// src/moe.rs:572-715, src/kernel/avx2.rs:1066-1206), same products: INT16 activation digits per 128-group (avx2.rs:234-304), exact integer
+// group sums (v_dot4), bf16(w_scale) * a_scale per group, the reference's polynomial sigmoid / libm functions.  What changes is the ORDER OF
+// THE f32 SUMS: a lane accumulates its own groups and lanes / waves are combined by trees, the norm and softmax sums are wave trees, the
+// state chains of the gated delta rule are split over 16 row slices.  That removes the serial chains that set the duration of the exact
+// launches and lets the launch structure follow the data dependences instead of the reference's call structure:
+// 6 launches per linear-attention MoE layer (7 before), none of them a single-workgroup kernel.
+// The exact kernels stay the default and the yardstick: tests/test_decode_fast_gpu.py states and checks the tolerances.
+#include "kr_decode_fast.h"
+
+#include "kr_device.h"
+#include "kr_libm.h"
+#include "kr_matvec_dev.h"
+#include "kr_topk.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+extern __shared__ __attribute__((aligned(16))) u32x4 kr_fsm[];
+
+#define KR_FU 16   // 16-byte weight records a lane keeps in flight per tile in the generic (guarded) form
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// reductions (all 64 lanes active at every call site that spans rows)
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float kr_f_red8(float v) {
+    v += __int_as_float(KR_DPP(__float_as_int(v), KR_DPP_XOR1));
+    v += __int_as_float(KR_DPP(__float_as_int(v), KR_DPP_XOR2));
+    v += __int_as_float(KR_DPP(__float_as_int(v), KR_DPP_HALF_MIRROR));
+    return v;
+}
+__device__ __forceinline__ float kr_f_red16(float v) {
+    v = kr_f_red8(v);
+    v += __int_as_float(KR_DPP(__float_as_int(v), KR_DPP_MIRROR));
+    return v;
+}
+__device__ __forceinline__ float kr_f_rl(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float kr_f_wave_sum(float v) {
+    v = kr_f_red16(v);
+    return (kr_f_rl(v, 0) + kr_f_rl(v, 16)) + (kr_f_rl(v, 32) + kr_f_rl(v, 48));
+}
+__device__ __forceinline__ float kr_f_wave_max(float v) {
+    v = kr_red16_max_f32(v);
+    return fmaxf(fmaxf(kr_f_rl(v, 0), kr_f_rl(v, 16)), fmaxf(kr_f_rl(v, 32), kr_f_rl(v, 48)));
+}
+__device__ __forceinline__ void kr_f_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// weight records of one 8-column tile: NU > 0 = exactly NU units per wave (no guards: one basic block), NU == 0 = guarded, up to KR_FU per pass
+// unit = group pair (INT4) / group (INT8), as in kr_moe_decode.hip
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int BITS, int NU, int FU = KR_FU> struct KrFw { u32x4 w[NU > 0 ? NU : FU]; uint32_t sc[NU > 0 ? NU : FU]; };
+
+template <int BITS, int NU, int FU = KR_FU>
+__device__ __forceinline__ void kr_f_fetch(KrFw<BITS, NU, FU>& p, const KrMatDev& m, const void* qbase, const uint32_t* sbase, int tile, int lane, int ub, int u1) {
+    const int units = BITS == 4 ? m.ngp : m.ng;
+    const u32x4* q = reinterpret_cast<const u32x4*>(qbase) + (size_t)tile * units * 64 + lane;
+    const uint32_t* s = sbase + (size_t)tile * m.ngp * 8 + (lane >> 3);
+    if constexpr (NU > 0) {
+#pragma unroll
+        for (int u = 0; u < NU; u++) { p.w[u] = kr_ldg_nt(q + (size_t)(ub + u) * 64); p.sc[u] = kr_ldg_nt(s + (BITS == 4 ? (ub + u) : ((ub + u) >> 1)) * 8); }
+    } else {
+#pragma unroll
+        for (int u = 0; u < FU; u++)
+            if (ub + u < u1) { p.w[u] = kr_ldg_nt(q + (size_t)(ub + u) * 64); p.sc[u] = kr_ldg_nt(s + (BITS == 4 ? (ub + u) : ((ub + u) >> 1)) * 8); }
+    }
+}
+
+// the lane's f32 partial over units [ub, u1): exact integer sum of each group times bf16(w_scale) * a_scale (avx2.rs:1171), accumulated per lane
+template <int BITS, int NU, int FU = KR_FU>
+__device__ __forceinline__ float kr_f_dot(const KrFw<BITS, NU, FU>& p, const KrMatDev& m, int ub, int u1, int l8, const KrActLds& L, float acc) {
+    constexpr int N = NU > 0 ? NU : FU;
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        const int un = ub + u;
+        if (NU > 0 || un < u1) {
+            if constexpr (BITS == 4) {
+                const int g0 = 2 * un, g1 = g0 + 1;
+                const int i0 = kr_group_i4(p.w[u].x, p.w[u].y, g0, l8, L);
+                acc = __builtin_fmaf((float)i0, __uint_as_float(p.sc[u] << 16) * L.ascale[g0], acc);
+                if (NU > 0 || g1 < m.ng) {   // NU > 0 is only launched for an even group count
+                    const int i1 = kr_group_i4(p.w[u].z, p.w[u].w, g1, l8, L);
+                    acc = __builtin_fmaf((float)i1, __uint_as_float(p.sc[u] & 0xFFFF0000u) * L.ascale[g1], acc);
+                }
+            } else {
+                const int i0 = kr_group_i8(p.w[u], un, l8, L);
+                const uint32_t sb = (un & 1) ? (p.sc[u] & 0xFFFF0000u) : (p.sc[u] << 16);
+                acc = __builtin_fmaf((float)i0, __uint_as_float(sb) * L.ascale[un], acc);
+            }
+        }
+    }
+    return acc;
+}
+
+// whole tile for one wave's unit range [u0, u1); `p` holds the first pass (already requested)
+template <int BITS, int NU, int FU = KR_FU>
+__device__ __forceinline__ float kr_f_tile(KrFw<BITS, NU, FU>& p, const KrMatDev& m, const void* qbase, const uint32_t* sbase, int tile, int lane, int u0, int u1, const KrActLds& L) {
+    float acc = kr_f_dot<BITS, NU, FU>(p, m, u0, u1, lane & 7, L, 0.0f);
+    if constexpr (NU == 0) {
+        for (int ub = u0 + FU; ub < u1; ub += FU) {
+            kr_f_fetch<BITS, NU, FU>(p, m, qbase, sbase, tile, lane, ub, u1);
+            acc = kr_f_dot<BITS, NU, FU>(p, m, ub, u1, lane & 7, L, acc);
+        }
+    }
+    return kr_f_red8(acc);
+}
+
+// pre-built activation image (global memory, byte layout == the LDS image for INT4 weights) -> LDS by threads [t0, t0 + nthr) of the workgroup
+template <int BITS>
+__device__ __forceinline__ void kr_f_image_copy(const void* img, int K, u32x4* smem, const KrActLds& L, int tt, int nthr) {
+    const int n16 = (int)(kr_lds_bytes(K, false) / 16);
+    const u32x4* src = reinterpret_cast<const u32x4*>(img);
+    for (int i = tt; i < n16; i += nthr) {
+        const u32x4 r = src[i];
+        smem[i] = r;
+        if constexpr (BITS == 8) {
+            if (i < K / 8) {
+                uint32_t* p = reinterpret_cast<uint32_t*>(L.planes8) + (i >> 1) * 8 + (i & 1) * 2;
+                p[0] = __builtin_amdgcn_perm(r.y, r.x, 0x05010400u);
+                p[1] = __builtin_amdgcn_perm(r.y, r.x, 0x07030602u);
+                p[4] = __builtin_amdgcn_perm(r.w, r.z, 0x05010400u) ^ 0x80808080u;
+                p[5] = __builtin_amdgcn_perm(r.w, r.z, 0x07030602u) ^ 0x80808080u;
+            }
+        }
+    }
+}
+
+// fused add + RMSNorm (decode.rs:1199) of a vector of n <= 4096 values by a 256-thread workgroup: thread t owns chunks t and t + 256 (8 values
+// each).  Returns the normalised values in x[u][*]; the caller quantises / stores them.  The sum of squares is a tree (lane, wave, workgroup).
+struct KrFNormIn { const float *hid, *res, *w; float* res_out; int first; float eps; int bias_one; int n; };
+__device__ __forceinline__ void kr_f_norm(const KrFNormIn& in, float (&x)[2][8], float* s_red, bool write_res) {
+    const int t = threadIdx.x, nch = in.n / 8;
+    float wv[2][8];
+    float ss = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int c = t + 256 * u;
+        if (c < nch) {
+            float h[8], r[8];
+            kr_load8(in.hid, c, h);
+            kr_load8(in.w, c, wv[u]);
+            if (!in.first) kr_load8(in.res, c, r);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { x[u][i] = in.first ? h[i] : (h[i] + r[i]); ss = __builtin_fmaf(x[u][i], x[u][i], ss); }
+            if (write_res) {
+                float4* ro = reinterpret_cast<float4*>(in.res_out + (size_t)c * 8);
+                ro[0] = float4{x[u][0], x[u][1], x[u][2], x[u][3]}; ro[1] = float4{x[u][4], x[u][5], x[u][6], x[u][7]};
+            }
+        }
+    }
+    ss = kr_f_wave_sum(ss);
+    if ((t & 63) == 0) s_red[t >> 6] = ss;
+    __syncthreads();
+    const float tot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    const float rms = 1.0f / sqrtf(tot / (float)in.n + in.eps);
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[u][i] = (x[u][i] * rms) * (in.bias_one ? (wv[u][i] + 1.0f) : wv[u][i]);
+}
+
+// quantize_activation_int16_f32 (avx2.rs:274) of the thread's chunk straight from registers (its 128-group = its 16-lane row)
+template <bool I8>
+__device__ __forceinline__ void kr_f_quant_chunk(const float (&v)[8], int c, const KrActLds& L, bool round_bf16) {
+    float y[8];
+    float mx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { y[i] = round_bf16 ? kr_bf16_to_f32(kr_f32_to_bf16(v[i])) : v[i]; mx = fmaxf(mx, fabsf(y[i])); }
+    float scale, inv;
+    kr_group_scale(mx, scale, inv);
+    int q[8];
+    kr_quant8<false>(y, inv, q);
+    kr_store_chunk<I8>(L, c, q);
+    if ((c & 15) == 0) L.ascale[c >> 4] = scale;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K1 / K3: multi-matrix dequant-matvec.  KS waves split the K range of a tile, 4 / KS tiles per workgroup.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int BITS, int KS, int NU>
+__global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
+    constexpr int TW = 4 / KS;
+    __shared__ float s_red[4];
+    __shared__ float s_x[TW][KS][8];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
+    const int tw = wave / KS, ks = wave - tw * KS;
+    const int total = a.mm.tile_end[a.mm.n - 1];
+    const int gt = blockIdx.x * TW + tw;
+    const bool active = gt < total;
+    int mi = 0;
+    while (mi + 1 < a.mm.n && gt >= a.mm.tile_end[mi]) mi++;
+    const KrMatDev m = a.mm.m[mi];
+    const int tile = active ? gt - (mi ? a.mm.tile_end[mi - 1] : 0) : 0;
+    const int units = BITS == 4 ? m.ngp : m.ng;
+    int u0, u1;
+    if (NU > 0) { u0 = ks * NU; u1 = u0 + NU; }
+    else { const int uw = (units + KS - 1) / KS; u0 = ks * uw; u1 = u0 + uw < units ? u0 + uw : units; }
+    KrFw<BITS, NU> W;
+    if (active) kr_f_fetch<BITS, NU>(W, m, m.q, m.s, tile, lane, u0, u1);
+    // the lane that will hold column `col` asks for its conv state / taps now (linear-attention epilogue)
+    const int col = tile * 8 + cl;
+    const bool out_lane = active && ks == 0 && l8 == 0 && col < m.N;
+    int kind = -1, dst = 0, ch = 0;
+    float4 cs = float4{0.0f, 0.0f, 0.0f, 0.0f}, cw = cs;
+    if (a.conv_state && mi == 0 && out_lane) {
+        const int nt = a.hr * a.dv, gd = 2 * a.dk + 2 * nt, key_dim = a.nk * a.dk;
+        const int kh = col / gd, cc = col - kh * gd;
+        if (cc < a.dk) { kind = 0; ch = kh * a.dk + cc; dst = kh * 2 * a.dk + cc; }
+        else if (cc < 2 * a.dk) { kind = 1; ch = key_dim + kh * a.dk + (cc - a.dk); dst = kh * 2 * a.dk + cc; }
+        else if (cc < 2 * a.dk + nt) { kind = 2; ch = 2 * key_dim + kh * nt + (cc - 2 * a.dk); dst = kh * nt + (cc - 2 * a.dk); }
+        else { kind = 3; dst = kh * nt + (cc - 2 * a.dk - nt); }
+        if (kind < 3) { cs = reinterpret_cast<const float4*>(a.conv_state)[ch]; cw = reinterpret_cast<const float4*>(a.conv_w)[ch]; }
+    }
+    const int K = a.mm.m[0].ng * 128;
+    const KrActLds L = kr_carve_lds(kr_fsm, K, BITS == 8);
+    if (a.mode == 0) kr_f_image_copy<BITS>(a.img, K, kr_fsm, L, t, 256);
+    else {
+        KrFNormIn in{a.emb ? a.emb + (size_t)a.step->token * K : a.hid_in, a.res_in, a.norm_w, a.res_out, a.first, a.eps, a.bias_one, K};
+        float x[2][8];
+        kr_f_norm(in, x, s_red, blockIdx.x == 0);
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int c = t + 256 * u; if (c < K / 8) kr_f_quant_chunk<BITS == 8>(x[u], c, L, false); }
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    if (active) acc = kr_f_tile<BITS, NU>(W, m, m.q, m.s, tile, lane, u0, u1, L);
+    if constexpr (KS > 1) {
+        if (l8 == 0) s_x[tw][ks][cl] = acc;
+        __syncthreads();
+        if (ks == 0) {
+            acc = s_x[tw][0][cl];
+#pragma unroll
+            for (int k = 1; k < KS; k++) acc += s_x[tw][k][cl];
+        }
+    }
+    if (out_lane) {
+        if (kind < 0) a.mm.y[mi][col] = acc;
+        else if (kind == 3) a.z_out[dst] = acc;
+        else {   // decode.rs:3815-3890: depthwise conv1d (kernel 4) over the shifted state, SiLU; the state shift is this lane's alone
+            reinterpret_cast<float4*>(a.conv_state)[ch] = float4{cs.y, cs.z, cs.w, acc};
+            float co = cs.y * cw.x + cs.z * cw.y + cs.w * cw.z + acc * cw.w;
+            co = co * kr_sigmoid_poly5(co);
+            if (kind == 2) a.v_out[dst] = co; else a.qk_out[dst] = co;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K2: gated delta-rule step of one VALUE head (decode.rs:3891-3945, 1293, 3979).  512 threads: NS slices of RPS state rows x DV / 4 column quads.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int DK, int DV>
+__global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
+    constexpr int JQ = DV / 4, NS = 512 / JQ, RPS = DK / NS, WQ = DK / 64;
+    static_assert(RPS >= 1 && NS * RPS == DK, "geometry");
+    __shared__ float s_qk[2 * DK];
+    __shared__ float s_red[8];
+    __shared__ float s_gate[2];
+    __shared__ __attribute__((aligned(16))) float s_part[NS][DV];
+    __shared__ __attribute__((aligned(16))) float s_vec[DV];
+    const int vh = blockIdx.x, kh = vh / a.hr, r = vh - kh * a.hr;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int slice = t / JQ, jq = t - slice * JQ;
+    f32x4* S4 = reinterpret_cast<f32x4*>(a.state + (size_t)vh * DK * DV);
+    f32x4 c[RPS];
+#pragma unroll
+    for (int u = 0; u < RPS; u++) c[u] = __builtin_nontemporal_load(S4 + (size_t)(slice * RPS + u) * JQ + jq);
+    float qv = 0.0f;
+    if (t < 2 * DK) { qv = a.qk[(size_t)kh * 2 * DK + t]; s_qk[t] = qv; }
+    float zz = 0.0f, vv = 0.0f, wn = 0.0f;
+    if (t < DV) { const size_t o = (size_t)vh * DV + t; zz = a.z[o]; vv = a.v[o]; wn = a.norm_w[o]; }
+    const float sq = kr_f_wave_sum(qv * qv);
+    if (lane == 0) s_red[wave] = sq;
+    if (t == 448) {   // gates (decode.rs:3891-3901) on a wave that has nothing else to do before the barrier
+        const float b_raw = a.ba[kh * 2 * a.hr + r], a_p = a.ba[kh * 2 * a.hr + a.hr + r];
+        s_gate[1] = 1.0f / (1.0f + kr_expf(-b_raw));
+        const float ap_dt = a_p + a.dt_bias[vh];
+        const float softplus = ap_dt > 20.0f ? ap_dt : kr_logf(1.0f + kr_expf(ap_dt));
+        const float g = -(kr_expf(a.a_log[vh])) * softplus;
+        s_gate[0] = kr_expf(g);
+    }
+    __syncthreads();
+    float ssq = s_red[0], ssk = s_red[WQ];
+#pragma unroll
+    for (int w = 1; w < WQ; w++) { ssq += s_red[w]; ssk += s_red[WQ + w]; }
+    const float inv_q = (ssq > 0.0f ? 1.0f / sqrtf(ssq) : 0.0f) * a.scale, inv_k = ssk > 0.0f ? 1.0f / sqrtf(ssk) : 0.0f;
+    const float g_exp = s_gate[0], beta = s_gate[1];
+    float kk[RPS], qq[RPS];
+#pragma unroll
+    for (int u = 0; u < RPS; u++) { kk[u] = s_qk[DK + slice * RPS + u] * inv_k; qq[u] = s_qk[slice * RPS + u] * inv_q; }
+    f32x4 kvp = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < RPS; u++) {
+        c[u] = c[u] * g_exp;
+        kvp.x = __builtin_fmaf(c[u].x, kk[u], kvp.x); kvp.y = __builtin_fmaf(c[u].y, kk[u], kvp.y);
+        kvp.z = __builtin_fmaf(c[u].z, kk[u], kvp.z); kvp.w = __builtin_fmaf(c[u].w, kk[u], kvp.w);
+    }
+    reinterpret_cast<f32x4*>(s_part[slice])[jq] = kvp;
+    __syncthreads();
+    if (t < DV) {
+        float kv = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; s++) kv += s_part[s][t];
+        s_vec[t] = (vv - kv) * beta;
+    }
+    __syncthreads();
+    const f32x4 d4 = reinterpret_cast<const f32x4*>(s_vec)[jq];
+    f32x4 op = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < RPS; u++) {
+        f32x4 sn;
+        sn.x = __builtin_fmaf(kk[u], d4.x, c[u].x); sn.y = __builtin_fmaf(kk[u], d4.y, c[u].y);
+        sn.z = __builtin_fmaf(kk[u], d4.z, c[u].z); sn.w = __builtin_fmaf(kk[u], d4.w, c[u].w);
+        __builtin_nontemporal_store(sn, S4 + (size_t)(slice * RPS + u) * JQ + jq);
+        op.x = __builtin_fmaf(sn.x, qq[u], op.x); op.y = __builtin_fmaf(sn.y, qq[u], op.y);
+        op.z = __builtin_fmaf(sn.z, qq[u], op.z); op.w = __builtin_fmaf(sn.w, qq[u], op.w);
+    }
+    reinterpret_cast<f32x4*>(s_part[slice])[jq] = op;    // every read of the first partials happened before the previous barrier
+    __syncthreads();
+    float ob = 0.0f;
+    if (t < DV) {
+#pragma unroll
+        for (int s = 0; s < NS; s++) ob += s_part[s][t];
+        const float so = kr_f_wave_sum(ob * ob);
+        if (lane == 0) s_red[wave] = so;
+    }
+    __syncthreads();
+    float ov = 0.0f;
+    if (t < DV) {
+        float ss = s_red[0];
+#pragma unroll
+        for (int w = 1; w < DV / 64; w++) ss += s_red[w];
+        const float rms = 1.0f / sqrtf(ss / (float)DV + a.eps);
+        const float normed = (ob * rms) * wn;
+        ov = (zz * kr_sigmoid_poly5(zz)) * normed;
+        a.out[(size_t)vh * DV + t] = ov;
+        s_vec[t] = ov;
+    }
+    if (a.img_out && DV == 128) {   // the head is one quantization group of the out-projection's input
+        __syncthreads();
+        if (t < 16) {
+            const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(a.img_out), a.img_k, false);
+            float v8[8];
+            kr_load8(s_vec, t, v8);
+            float mx = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v8[i]));
+            float scale, inv;
+            kr_group_scale(mx, scale, inv);
+            int q8[8];
+            kr_quant8<false>(v8, inv, q8);
+            kr_store_chunk<false>(Lg, vh * 16 + t, q8);
+            if (t == 0) Lg.ascale[vh] = scale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K4: post-attention add + RMSNorm folded into the router gate GEMV (decode.rs:1385-1429).  One workgroup per block of 4 experts, its 4 waves
+// split the K range of the chain-major gate rows.  Workgroups 0 / 1 also publish the residual and the two INT16 images.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool GATE_BF16>
+__global__ void __launch_bounds__(256) kr_frt_kernel(const KrFrtArgs a) {
+    constexpr int CPW = 16;   // 16-byte gate chunks per lane and wave kept in flight (H <= 4096: bf16 8, f32 16)
+    float* xs = reinterpret_cast<float*>(kr_fsm);   // [16][ld] chain-major copy of the normalised hidden
+    __shared__ float s_red[4];
+    __shared__ float s_part[4][4];
+    const int H = a.H, ld = H / 16 + 4;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int eb = blockIdx.x;
+    const int ncg = GATE_BF16 ? H / 128 : H / 64;
+    const int cpw = (ncg + 3) / 4, c0 = wave * cpw, c1 = c0 + cpw < ncg ? c0 + cpw : ncg;
+    const u32x4* gp = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)eb * ncg * 64 + lane;
+    u32x4 gw[CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; u++) if (c0 + u < c1) gw[u] = kr_ldg_nt(gp + (size_t)(c0 + u) * 64);
+    KrFNormIn in{a.hid_in, a.res_in, a.norm_w, a.res_out, 0, a.eps, a.bias_one, H};
+    float x[2][8];
+    kr_f_norm(in, x, s_red, blockIdx.x == 0);
+    const bool img_f = a.img_f32 && blockIdx.x == 0, img_b = a.img_bf16 && blockIdx.x == (gridDim.x > 1 ? 1 : 0);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int c = t + 256 * u;
+        if (c < H / 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int e = c * 8 + i; xs[(e & 15) * ld + (e >> 4)] = x[u][i]; }
+            if (blockIdx.x == 0 && a.hid_out) {
+                float4* ho = reinterpret_cast<float4*>(a.hid_out + (size_t)c * 8);
+                ho[0] = float4{x[u][0], x[u][1], x[u][2], x[u][3]}; ho[1] = float4{x[u][4], x[u][5], x[u][6], x[u][7]};
+            }
+            if (img_f) kr_f_quant_chunk<false>(x[u], c, kr_carve_lds(reinterpret_cast<u32x4*>(a.img_f32), H, false), false);
+            if (img_b) kr_f_quant_chunk<false>(x[u], c, kr_carve_lds(reinterpret_cast<u32x4*>(a.img_bf16), H, false), true);
+        }
+    }
+    __syncthreads();
+    const int j = lane & 15;
+    const float* xj = xs + j * ld;
+    float acc = 0.0f;
+#pragma unroll
+    for (int u = 0; u < CPW; u++) if (c0 + u < c1) {
+        if (GATE_BF16) {
+            const float* xx = xj + (c0 + u) * 8;
+            const uint32_t ww[4] = {gw[u].x, gw[u].y, gw[u].z, gw[u].w};
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                acc = __builtin_fmaf(__uint_as_float(ww[p] << 16), xx[2 * p], acc);
+                acc = __builtin_fmaf(__uint_as_float(ww[p] & 0xFFFF0000u), xx[2 * p + 1], acc);
+            }
+        } else {
+            const float* xx = xj + (c0 + u) * 4;
+            acc = __builtin_fmaf(__uint_as_float(gw[u].x), xx[0], acc);
+            acc = __builtin_fmaf(__uint_as_float(gw[u].y), xx[1], acc);
+            acc = __builtin_fmaf(__uint_as_float(gw[u].z), xx[2], acc);
+            acc = __builtin_fmaf(__uint_as_float(gw[u].w), xx[3], acc);
+        }
+    }
+    acc = kr_f_red16(acc);
+    if (j == 0) s_part[wave][lane >> 4] = acc;
+    __syncthreads();
+    if (t < 4) {
+        const int e = eb * 4 + t;
+        if (e < a.E) {
+            float v = (s_part[0][t] + s_part[1][t]) + (s_part[2][t] + s_part[3][t]);
+            if (a.bias) v += a.bias[e];   // decode.rs:3292-3294
+            a.logits[e] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// scoring + top-k by ONE wave (moe_route_score_topk + topk_indices, decode.rs:4088-4186, 1495-1535): the scores and the renormalisation are
+// wave trees; the selection is the (value desc, index asc) wave top-k of kr_topk.h; softmax without a correction bias selects on the LOGITS
+// (softmax is monotone), so for identical logits the ids are those of the exact kernel unless two of the leading k + 1 are EQUAL -- then the
+// reference's heap order decides and is emulated serially, as in the exact kernel.
+// sm: [E] scores, [E] selection values, [33] pv, [33] pi, [32] hv, [32] hi
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void kr_f_select(const float* logits, const float* esc, int E, int k, int scoring, int norm, float* sm, int* s_ids, float* s_w) {
+    float* scores = sm; float* sel = sm + E; float* pv = sel + E; int* pi = reinterpret_cast<int*>(pv + 33);
+    float* hv = reinterpret_cast<float*>(pi + 33); int* hi = reinterpret_cast<int*>(hv + 32);
+    const int lane = threadIdx.x & 63;
+    const bool raw = scoring == 2;
+    float lg[NV], sc[NV], sl[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) { const int e = lane * NV + i; lg[i] = e < E ? logits[e] : -__builtin_inff(); }
+    if (raw) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) sc[i] = lg[i];
+    } else if (scoring == 0) {
+        const int e8 = (E / 8) * 8;
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; sc[i] = e < E ? (e < e8 ? kr_sigmoid_poly4(lg[i]) : 1.0f / (1.0f + kr_expf(-lg[i]))) : 0.0f; }
+    } else {
+        float mx = lg[0];
+#pragma unroll
+        for (int i = 1; i < NV; i++) mx = fmaxf(mx, lg[i]);
+        mx = kr_f_wave_max(mx);
+        float se = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; sc[i] = e < E ? __builtin_amdgcn_exp2f((lg[i] - mx) * 1.4426950408889634f) : 0.0f; se += sc[i]; }
+        se = kr_f_wave_sum(se);
+        const float inv = 1.0f / se;
+#pragma unroll
+        for (int i = 0; i < NV; i++) sc[i] *= inv;
+    }
+    const bool on_logits = scoring == 1 && esc == nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int e = lane * NV + i;
+        sl[i] = on_logits ? lg[i] : ((!raw && esc && e < E) ? sc[i] + esc[e] : sc[i]);
+        if (e < E) { scores[e] = sc[i]; sel[e] = sl[i]; }
+    }
+    const int np = k + 1 <= E ? k + 1 : k;
+    kr_topk_wave_reg<NV>(sl, E, np, pv, pi);
+    kr_f_wave_sync();
+    {
+        const float pa = lane < np ? pv[lane] : 0.0f, pb = lane + 1 < np ? pv[lane + 1] : 0.0f;
+        const bool tie = __ballot(lane + 1 < np && pa == pb) != 0ull;
+        if (tie) {   // heap order governs ties (decode.rs:1531)
+            if (lane == 0) kr_topk_heap_serial(sel, E, k, hv, hi, pi);
+            kr_f_wave_sync();
+        }
+    }
+    const int my = lane < k ? pi[lane] : 0;
+    float wv = lane < k ? scores[my] : 0.0f;
+    if (raw) {
+        const float mx = kr_f_wave_max(lane < k ? wv : -__builtin_inff());
+        wv = lane < k ? kr_expf(wv - mx) : 0.0f;
+    }
+    if (raw || norm) {
+        const float se = kr_f_wave_sum(wv);
+        if (raw) wv = wv * (1.0f / se);
+        else if (se > 0.0f) wv = wv / se;
+    }
+    if (lane < k) { s_ids[lane] = my; s_w[lane] = wv; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K5: gate | up of the k routed experts + the shared expert (+ its sigmoid-gate row).  grid (units, n_slots); 2 tile PAIRS per workgroup
+// (gate tile t and up tile t + I / 8 of the same hidden column), 2 waves split K; epilogue h = silu(g) * u (avx2.rs:2331-2333, decode.rs:1731-1733).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int BITS, int NU>
+__global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
+    const KrMoeArgs& a = fa.m;
+    constexpr int KS = 2, TW = 2;
+    __shared__ int s_ids[32];
+    __shared__ float s_w[32];
+    __shared__ float s_x[TW][KS][2][8];
+    const int slot = blockIdx.y;
+    const bool shared = slot >= a.topk;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
+    const int tw = wave >> 1, ks = wave & 1;
+    const KrActLds L = kr_carve_lds(kr_fsm, a.H, BITS == 8);
+    if (shared) kr_f_image_copy<BITS>(a.act_img, a.H, kr_fsm, L, t, 256);
+    else if (wave > 0) kr_f_image_copy<BITS>(a.act_img_bf16, a.H, kr_fsm, L, t - 64, 192);
+    else {
+        float* selsm = reinterpret_cast<float*>(reinterpret_cast<char*>(kr_fsm) + kr_lds_bytes(a.H, BITS == 8));
+        const int nv = (a.E + 63) / 64;
+        if (nv <= 1) kr_f_select<1>(fa.logits, fa.esc, a.E, a.topk, fa.scoring, fa.norm_topk, selsm, s_ids, s_w);
+        else if (nv <= 2) kr_f_select<2>(fa.logits, fa.esc, a.E, a.topk, fa.scoring, fa.norm_topk, selsm, s_ids, s_w);
+        else if (nv <= 4) kr_f_select<4>(fa.logits, fa.esc, a.E, a.topk, fa.scoring, fa.norm_topk, selsm, s_ids, s_w);
+        else kr_f_select<8>(fa.logits, fa.esc, a.E, a.topk, fa.scoring, fa.norm_topk, selsm, s_ids, s_w);
+        if (blockIdx.x == 0 && slot == 0 && lane < a.topk) {   // the routing of this token, for the w2 launch (and anyone who asks)
+            const_cast<int32_t*>(a.ids)[lane] = s_ids[lane]; const_cast<float*>(a.wts)[lane] = s_w[lane];
+        }
+    }
+    __syncthreads();
+    const KrMatDev& m = shared ? a.sw13 : a.w13;
+    const void* qb = m.q; const uint32_t* sb = m.s;
+    const int inter = shared ? a.I_shared : a.I;
+    if (!shared) {
+        const int e = s_ids[slot];
+        qb = reinterpret_cast<const char*>(m.q) + (size_t)e * m.q_stride;
+        sb = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + (size_t)e * m.s_stride);
+    }
+    const int ntp = inter / 8;
+    const int unit = blockIdx.x * TW + tw;
+    const bool pair = unit < ntp;
+    const bool gate_row = shared && a.sgate.q != nullptr && unit == ntp;
+    const int units = BITS == 4 ? m.ngp : m.ng;
+    int u0, u1;
+    if (NU > 0) { u0 = ks * NU; u1 = u0 + NU; }
+    else { const int uw = (units + KS - 1) / KS; u0 = ks * uw; u1 = u0 + uw < units ? u0 + uw : units; }
+    KrFw<BITS, NU> Wg, Wu;
+    float ag = 0.0f, au = 0.0f;
+    if (pair) {
+        kr_f_fetch<BITS, NU>(Wg, m, qb, sb, unit, lane, u0, u1);
+        kr_f_fetch<BITS, NU>(Wu, m, qb, sb, unit + ntp, lane, u0, u1);
+        ag = kr_f_tile<BITS, NU>(Wg, m, qb, sb, unit, lane, u0, u1, L);
+        au = kr_f_tile<BITS, NU>(Wu, m, qb, sb, unit + ntp, lane, u0, u1, L);
+    } else if (gate_row) {
+        kr_f_fetch<BITS, NU>(Wg, a.sgate, a.sgate.q, a.sgate.s, 0, lane, u0, u1);
+        ag = kr_f_tile<BITS, NU>(Wg, a.sgate, a.sgate.q, a.sgate.s, 0, lane, u0, u1, L);
+    }
+    if (l8 == 0) { s_x[tw][ks][0][cl] = ag; s_x[tw][ks][1][cl] = au; }
+    __syncthreads();
+    if (ks == 0 && l8 == 0) {
+        const float g = s_x[tw][0][0][cl] + s_x[tw][1][0][cl], u = s_x[tw][0][1][cl] + s_x[tw][1][1][cl];
+        if (pair) a.gu[(size_t)slot * a.gu_ld + unit * 8 + cl] = (g * kr_sigmoid_poly5(g)) * u;
+        else if (gate_row && cl == 0) a.gate_out[0] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K6: down projection of ALL slots for one 8-column tile + the weighted combine.  One wave per slot: it quantises its expert's hidden
+// (silu_quantize_int16_avx2's cvtps rounding for routed experts, avx2.rs:2357; f32::round for the decode-store shared expert,
+// decode.rs:3364-3374) into its own LDS region, walks the I / 128 groups and leaves 8 column values; 8 lanes then form
+// rsf * sum_i w_i y_i (routing order, moe.rs:661-667) + shared * sigmoid(gate) (decode.rs:3379-3402).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int BITS, int NU>
+__global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int slot_lds) {
+    const KrMoeArgs& a = fa.m;
+    __shared__ float s_y[16][8];
+    __shared__ float s_wt[16];
+    __shared__ int s_ok[16];
+    __shared__ float s_sig;
+    const int t = threadIdx.x, slot = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
+    const int tile = blockIdx.x;
+    const bool shared = slot >= a.topk;
+    const KrMatDev& m = shared ? a.sw2 : a.w2;
+    const int inter = shared ? a.I_shared : a.I;
+    const void* qb = m.q; const uint32_t* sb = m.s;
+    bool valid = true; float wt = 1.0f;
+    if (!shared) {
+        const int e = a.ids[slot];
+        valid = e >= 0 && e < a.E; wt = a.wts[slot];
+        const size_t ee = valid ? (size_t)e : 0;
+        qb = reinterpret_cast<const char*>(m.q) + ee * m.q_stride;
+        sb = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + ee * m.s_stride);
+    }
+    const int units = BITS == 4 ? m.ngp : m.ng;
+    KrFw<BITS, NU, 8> W;     // 16 waves per workgroup leave 128 registers per lane: the guarded form keeps 8 records in flight
+    kr_f_fetch<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units);
+    const KrActLds L = kr_carve_lds(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(kr_fsm) + (size_t)slot * slot_lds), inter, BITS == 8);
+    const float* h = a.gu + (size_t)slot * a.gu_ld;
+    const bool half_away = shared && a.shared_decode;
+    for (int c = lane; c < inter / 8; c += 64) {
+        float v[8];
+        kr_load8(h, c, v);
+        float mx = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v[i]));
+        float scale, inv;
+        kr_group_scale(mx, scale, inv);
+        int q[8];
+        if (half_away) kr_quant8<false>(v, inv, q); else kr_quant8<true>(v, inv, q);
+        kr_store_chunk<BITS == 8>(L, c, q);
+        if ((c & 15) == 0) L.ascale[c >> 4] = scale;
+    }
+    if (shared && lane == 0) s_sig = a.gate_out ? 1.0f / (1.0f + kr_expf(-a.gate_out[0])) : 1.0f;
+    kr_f_wave_sync();
+    const float acc = kr_f_tile<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units, L);
+    if (l8 == 0) s_y[slot][cl] = acc;
+    if (lane == 0) { s_wt[slot] = wt; s_ok[slot] = valid ? 1 : 0; }
+    __syncthreads();
+    if (t < 8) {
+        float o = 0.0f;
+        for (int s = 0; s < a.topk; s++) if (s_ok[s]) o += s_wt[s] * s_y[s][t];
+        if (a.rsf != 1.0f) o *= a.rsf;
+        if (a.n_slots > a.topk) {
+            float sh = s_y[a.topk][t];
+            if (a.gate_out) sh *= s_sig;
+            o = o + sh;
+        }
+        const int col = tile * 8 + t;
+        if (col < a.H) fa.hid_out[col] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int BITS, int KS>
+static int kr_fdm_launch_nu(const KrFdmArgs& a, int nu, dim3 grid, size_t lds, hipStream_t st) {
+#define KR_FDM(N_) hipLaunchKernelGGL((kr_fdm_kernel<BITS, KS, N_>), grid, dim3(256), lds, st, a)
+    switch (nu) {
+        case 2: KR_FDM(2); break;
+        case 4: KR_FDM(4); break;
+        case 8: KR_FDM(8); break;
+        case 16: KR_FDM(16); break;
+        default: KR_FDM(0); break;
+    }
+#undef KR_FDM
+    return 0;
+}
+
+int kr_launch_fdm(const KrFdmArgs& a, hipStream_t st) {
+    const KrMatDev& m0 = a.mm.m[0];
+    const int bits = m0.bits, K = m0.ng * 128;
+    for (int i = 1; i < a.mm.n; i++) if (a.mm.m[i].bits != bits || a.mm.m[i].ng != m0.ng) return 1;
+    if (a.mode == 1 && (K > 4096 || K != m0.K)) return 1;
+    if (a.conv_state && (a.mm.m[0].N != a.nk * (2 * a.dk + 2 * a.hr * a.dv))) return 1;
+    const int total = a.mm.tile_end[a.mm.n - 1];
+    const int units = bits == 4 ? m0.ngp : m0.ng;
+    // K split: near one or two workgroups per CU, and a wave's chain no longer than 8 units
+    int ks = total >= 1024 ? 1 : (total >= 512 ? 2 : 4);
+    while (ks < 4 && units / ks > 8) ks *= 2;
+    const int tw = 4 / ks;
+    const bool even = (bits == 8 || (m0.ng % 2) == 0) && units % ks == 0;
+    const int nu_exact = even ? units / ks : 0;
+    const int nu = (nu_exact == 2 || nu_exact == 4 || nu_exact == 8 || nu_exact == 16) ? nu_exact : 0;
+    dim3 grid((total + tw - 1) / tw);
+    const size_t lds = kr_lds_bytes(K, bits == 8);
+    if (bits == 4) {
+        if (ks == 1) return kr_fdm_launch_nu<4, 1>(a, nu, grid, lds, st);
+        if (ks == 2) return kr_fdm_launch_nu<4, 2>(a, nu, grid, lds, st);
+        return kr_fdm_launch_nu<4, 4>(a, nu, grid, lds, st);
+    }
+    if (ks == 1) return kr_fdm_launch_nu<8, 1>(a, nu, grid, lds, st);
+    if (ks == 2) return kr_fdm_launch_nu<8, 2>(a, nu, grid, lds, st);
+    return kr_fdm_launch_nu<8, 4>(a, nu, grid, lds, st);
+}
+
+int kr_launch_fla(const KrFlaArgs& a, hipStream_t st) {
+    if (a.nv != a.nk * a.hr) return 1;
+#define KR_FLA(DK_, DV_) hipLaunchKernelGGL((kr_fla_kernel<DK_, DV_>), dim3(a.nv), dim3(512), 0, st, a)
+    if (a.dk == 128 && a.dv == 128) KR_FLA(128, 128);
+    else if (a.dk == 64 && a.dv == 128) KR_FLA(64, 128);
+    else return 1;
+#undef KR_FLA
+    return 0;
+}
+
+int kr_launch_frt(const KrFrtArgs& a, hipStream_t st) {
+    if (a.H % 128 || a.H > 4096 || a.H < 256) return 1;
+    const size_t lds = (size_t)16 * (a.H / 16 + 4) * 4;
+    dim3 grid((a.E + 3) / 4);
+    if (a.gate_bf16) hipLaunchKernelGGL(kr_frt_kernel<true>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(kr_frt_kernel<false>, grid, dim3(256), lds, st, a);
+    return 0;
+}
+
+static bool kr_fmoe_ok(const KrFmoeArgs& fa) {
+    const KrMoeArgs& a = fa.m;
+    const bool has_shared = a.n_slots > a.topk;
+    if (a.B != 1 || a.n_slots > 16 || a.topk > 15 || a.E > 512 || a.act_mode != KR_ACT_SILU_FUSED) return false;
+    if (!a.act_img || !a.act_img_bf16 || a.H % 128 || a.I % 128) return false;
+    if (a.w13.ng * 128 != a.H || a.w2.ng * 128 != a.I) return false;
+    if (has_shared) {
+        if (a.sw13.bits != a.w13.bits || a.sw2.bits != a.w2.bits || a.I_shared % 128 || a.sw13.ng != a.w13.ng || a.sw2.ng * 128 != a.I_shared) return false;
+        if (a.sgate.q && (a.sgate.bits != a.w13.bits || a.sgate.ng != a.w13.ng || !a.gate_out)) return false;
+    }
+    return true;
+}
+
+int kr_fmoe_check(const KrFmoeArgs& fa) {
+    if (!kr_fmoe_ok(fa)) return 1;
+    const KrMoeArgs& a = fa.m;
+    const bool has_shared = a.n_slots > a.topk;
+    const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
+    return kr_lds_bytes(imax, a.w2.bits == 8) * a.n_slots > 150 * 1024 ? 1 : 0;
+}
+
+int kr_launch_fw13(const KrFmoeArgs& fa, hipStream_t st) {
+    if (!kr_fmoe_ok(fa)) return 1;
+    const KrMoeArgs& a = fa.m;
+    const bool has_shared = a.n_slots > a.topk;
+    int ntp = a.I / 8;
+    if (has_shared && a.I_shared / 8 + (a.sgate.q ? 1 : 0) > ntp) ntp = a.I_shared / 8 + (a.sgate.q ? 1 : 0);
+    dim3 grid((ntp + 1) / 2, a.n_slots);
+    const size_t lds = kr_lds_bytes(a.H, a.w13.bits == 8) + (size_t)(2 * a.E + 33 + 33 + 32 + 32 + 4) * 4;
+    const int units = a.w13.bits == 4 ? a.w13.ngp : a.w13.ng;
+    const bool even = (a.w13.bits == 8 || (a.w13.ng % 2) == 0) && units % 2 == 0;
+    const int nu = even ? units / 2 : 0;
+#define KR_FW13(B_, N_) hipLaunchKernelGGL((kr_fw13_kernel<B_, N_>), grid, dim3(256), lds, st, fa)
+    if (a.w13.bits == 4) { if (nu == 4) KR_FW13(4, 4); else if (nu == 8) KR_FW13(4, 8); else KR_FW13(4, 0); }
+    else { if (nu == 8) KR_FW13(8, 8); else KR_FW13(8, 0); }
+#undef KR_FW13
+    return 0;
+}
+
+int kr_launch_fw2(const KrFmoeArgs& fa, hipStream_t st) {
+    if (!kr_fmoe_ok(fa)) return 1;
+    const KrMoeArgs& a = fa.m;
+    const bool has_shared = a.n_slots > a.topk;
+    const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
+    const size_t slot_lds = kr_lds_bytes(imax, a.w2.bits == 8);
+    if (slot_lds * a.n_slots > 150 * 1024) return 1;
+    dim3 grid((a.H + 7) / 8);
+    // exact unit count (no guards) when every slot has the same, even, group count
+    const int units = a.w2.bits == 4 ? a.w2.ngp : a.w2.ng;
+    const bool uniform = (!has_shared || a.I_shared == a.I) && (a.w2.bits == 8 || a.w2.ng % 2 == 0);
+    const int nu = uniform && (units == 2 || units == 4 || units == 8) ? units : 0;
+#define KR_FW2(B_, N_) hipLaunchKernelGGL((kr_fw2_kernel<B_, N_>), grid, dim3(64 * a.n_slots), slot_lds * a.n_slots, st, fa, (int)slot_lds)
+    if (a.w2.bits == 4) { if (nu == 2) KR_FW2(4, 2); else if (nu == 4) KR_FW2(4, 4); else if (nu == 8) KR_FW2(4, 8); else KR_FW2(4, 0); }
+    else { if (nu == 4) KR_FW2(8, 4); else if (nu == 8) KR_FW2(8, 8); else KR_FW2(8, 0); }
+#undef KR_FW2
+    return 0;
+}

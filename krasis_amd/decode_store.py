@@ -260,11 +260,13 @@ class CpuDecodeStore:
         """GQA KV cache element type: FP16 (reference CPU decode, default) or FP8-E4M3 (reference GPU cache, kv_cache.py:38)."""
         self._need(); check(self._lib.kr_decode_set_kv_dtype(self._h, 1 if fp8_e4m3 else 0))
 
-    def set_attention_mode(self, fast: bool, gemm_fast: bool = False) -> None:
+    def set_attention_mode(self, fast: bool, gemm_fast: bool = False, decode_fast: bool = False) -> None:
         """fast False (default): the reference's sequential softmax / p.v order (bit-exact).  True: split-KV / flash attention and the chunked
         delta rule -- tolerance mode (logits within ~1e-4 relative).  gemm_fast True: the GEMMs of the prompt pass in the tolerance form as well
-        (f16 activations, f32 accumulation over the whole k range: the dataflow of the reference's GPU prompt pass); decode steps are unaffected."""
-        self._need(); check(self._lib.kr_decode_set_attention_mode(self._h, (1 if fast else 0) | (2 if gemm_fast else 0)))
+        (f16 activations, f32 accumulation over the whole k range: the dataflow of the reference's GPU prompt pass); decode steps are unaffected.
+        decode_fast True (KR_DECODE_FAST): decode steps on the tolerance-mode kernels -- the reference's products, tree reductions instead of its
+        sequential chains, norms / top-k / activation / combine folded into the matvec launches; the prompt pass is unaffected."""
+        self._need(); check(self._lib.kr_decode_set_attention_mode(self._h, (1 if fast else 0) | (2 if gemm_fast else 0) | (4 if decode_fast else 0)))
 
     def finalize_decode(self) -> None:
         self._need()
@@ -385,6 +387,14 @@ class CpuDecodeStore:
 
     def read_hidden(self, n: int) -> np.ndarray:
         out = np.empty(n, np.float32); check(self._lib.kr_decode_read_buffer(self._h, 0, _addr(out), n)); return out
+
+    def read_router(self, n_experts: int, topk: int):
+        """(logits [E], ids [k], weights [k]) the router of the LAST MoE layer produced in the most recent decode step (test / debug aid)"""
+        lg = np.empty(n_experts, np.float32); ids = np.empty(topk, np.int32); w = np.empty(topk, np.float32)
+        check(self._lib.kr_decode_read_buffer(self._h, 4, _addr(lg), n_experts))
+        check(self._lib.kr_decode_read_buffer(self._h, 2, _addr(ids), topk))
+        check(self._lib.kr_decode_read_buffer(self._h, 3, _addr(w), topk))
+        return lg, ids, w
 
     def device_bytes(self) -> int:
         self._need(); return int(self._lib.kr_decode_device_bytes(self._h))
