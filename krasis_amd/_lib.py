@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libkrasis_hip.so")
+_LIB = os.environ.get("KRASIS_HIP_LIB") or os.path.join(_HERE, "libkrasis_hip.so")   # KRASIS_HIP_LIB: probe builds of the same library (tools/probes), never a fallback
 
 KR_OK, KR_ERR_STATE, KR_ERR_VALUE, KR_ERR_IO, KR_ERR_HIP = 0, 1, 2, 3, 4
 KR_OUT_F32, KR_OUT_BF16 = 0, 1

@@ -18,6 +18,14 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 extern __shared__ __attribute__((aligned(16))) u32x4 kr_fsm[];
 
+#ifdef KR_FTIMING   // libkrasis_hip_timing.so (make timing): wall-clock stamps (10 ns units) of wave 0 of the middle workgroup, read back by tools/probes/decode_fast_stamps.py
+__device__ unsigned long long kr_fstamps[8][16];
+#define KR_FSTAMP(k, i) do { if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) kr_fstamps[k][i] = wall_clock64(); } while (0)
+extern "C" int kr_debug_fstamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kr_fstamps), sizeof(kr_fstamps)); }
+#else
+#define KR_FSTAMP(k, i) do { } while (0)
+#endif
+
 #define KR_FU 16   // 16-byte weight records a lane keeps in flight per tile in the generic (guarded) form
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -184,6 +192,8 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
     __shared__ float s_x[TW][KS][8];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
     const int tw = wave / KS, ks = wave - tw * KS;
+    [[maybe_unused]] const int sk = a.mode == 1 ? 0 : 2;
+    KR_FSTAMP(sk, 0);
     const int total = a.mm.tile_end[a.mm.n - 1];
     const int gt = blockIdx.x * TW + tw;
     const bool active = gt < total;
@@ -213,6 +223,7 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
     }
     const int K = a.mm.m[0].ng * 128;
     const KrActLds L = kr_carve_lds(kr_fsm, K, BITS == 8);
+    KR_FSTAMP(sk, 1);
     if (a.mode == 0) kr_f_image_copy<BITS>(a.img, K, kr_fsm, L, t, 256);
     else {
         KrFNormIn in{a.emb ? a.emb + (size_t)a.step->token * K : a.hid_in, a.res_in, a.norm_w, a.res_out, a.first, a.eps, a.bias_one, K};
@@ -221,9 +232,12 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
 #pragma unroll
         for (int u = 0; u < 2; u++) { const int c = t + 256 * u; if (c < K / 8) kr_f_quant_chunk<BITS == 8>(x[u], c, L, false); }
     }
+    KR_FSTAMP(sk, 2);
     __syncthreads();
+    KR_FSTAMP(sk, 3);
     float acc = 0.0f;
     if (active) acc = kr_f_tile<BITS, NU>(W, m, m.q, m.s, tile, lane, u0, u1, L);
+    KR_FSTAMP(sk, 4);
     if constexpr (KS > 1) {
         if (l8 == 0) s_x[tw][ks][cl] = acc;
         __syncthreads();
@@ -243,6 +257,7 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
             if (kind == 2) a.v_out[dst] = co; else a.qk_out[dst] = co;
         }
     }
+    KR_FSTAMP(sk, 5);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -261,6 +276,7 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int slice = t / JQ, jq = t - slice * JQ;
     f32x4* S4 = reinterpret_cast<f32x4*>(a.state + (size_t)vh * DK * DV);
+    KR_FSTAMP(1, 0);
     f32x4 c[RPS];
 #pragma unroll
     for (int u = 0; u < RPS; u++) c[u] = __builtin_nontemporal_load(S4 + (size_t)(slice * RPS + u) * JQ + jq);
@@ -278,7 +294,9 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
         const float g = -(kr_expf(a.a_log[vh])) * softplus;
         s_gate[0] = kr_expf(g);
     }
+    KR_FSTAMP(1, 1);
     __syncthreads();
+    KR_FSTAMP(1, 2);
     float ssq = s_red[0], ssk = s_red[WQ];
 #pragma unroll
     for (int w = 1; w < WQ; w++) { ssq += s_red[w]; ssk += s_red[WQ + w]; }
@@ -295,6 +313,7 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
         kvp.z = __builtin_fmaf(c[u].z, kk[u], kvp.z); kvp.w = __builtin_fmaf(c[u].w, kk[u], kvp.w);
     }
     reinterpret_cast<f32x4*>(s_part[slice])[jq] = kvp;
+    KR_FSTAMP(1, 3);
     __syncthreads();
     if (t < DV) {
         float kv = 0.0f;
@@ -303,6 +322,7 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
         s_vec[t] = (vv - kv) * beta;
     }
     __syncthreads();
+    KR_FSTAMP(1, 4);
     const f32x4 d4 = reinterpret_cast<const f32x4*>(s_vec)[jq];
     f32x4 op = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -315,6 +335,7 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
         op.z = __builtin_fmaf(sn.z, qq[u], op.z); op.w = __builtin_fmaf(sn.w, qq[u], op.w);
     }
     reinterpret_cast<f32x4*>(s_part[slice])[jq] = op;    // every read of the first partials happened before the previous barrier
+    KR_FSTAMP(1, 5);
     __syncthreads();
     float ob = 0.0f;
     if (t < DV) {
@@ -324,6 +345,7 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
         if (lane == 0) s_red[wave] = so;
     }
     __syncthreads();
+    KR_FSTAMP(1, 6);
     float ov = 0.0f;
     if (t < DV) {
         float ss = s_red[0];
@@ -352,6 +374,7 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
             if (t == 0) Lg.ascale[vh] = scale;
         }
     }
+    KR_FSTAMP(1, 7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -367,6 +390,7 @@ __global__ void __launch_bounds__(256) kr_frt_kernel(const KrFrtArgs a) {
     const int H = a.H, ld = H / 16 + 4;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int eb = blockIdx.x;
+    KR_FSTAMP(3, 0);
     const int ncg = GATE_BF16 ? H / 128 : H / 64;
     const int cpw = (ncg + 3) / 4, c0 = wave * cpw, c1 = c0 + cpw < ncg ? c0 + cpw : ncg;
     const u32x4* gp = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)eb * ncg * 64 + lane;
@@ -376,6 +400,7 @@ __global__ void __launch_bounds__(256) kr_frt_kernel(const KrFrtArgs a) {
     KrFNormIn in{a.hid_in, a.res_in, a.norm_w, a.res_out, 0, a.eps, a.bias_one, H};
     float x[2][8];
     kr_f_norm(in, x, s_red, blockIdx.x == 0);
+    KR_FSTAMP(3, 1);
     const bool img_f = a.img_f32 && blockIdx.x == 0, img_b = a.img_bf16 && blockIdx.x == (gridDim.x > 1 ? 1 : 0);
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -392,6 +417,7 @@ __global__ void __launch_bounds__(256) kr_frt_kernel(const KrFrtArgs a) {
         }
     }
     __syncthreads();
+    KR_FSTAMP(3, 2);
     const int j = lane & 15;
     const float* xj = xs + j * ld;
     float acc = 0.0f;
@@ -414,6 +440,7 @@ __global__ void __launch_bounds__(256) kr_frt_kernel(const KrFrtArgs a) {
         }
     }
     acc = kr_f_red16(acc);
+    KR_FSTAMP(3, 3);
     if (j == 0) s_part[wave][lane >> 4] = acc;
     __syncthreads();
     if (t < 4) {
@@ -424,6 +451,7 @@ __global__ void __launch_bounds__(256) kr_frt_kernel(const KrFrtArgs a) {
             a.logits[e] = v;
         }
     }
+    KR_FSTAMP(3, 4);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -510,6 +538,7 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
     const int tw = wave >> 1, ks = wave & 1;
     const KrActLds L = kr_carve_lds(kr_fsm, a.H, BITS == 8);
+    KR_FSTAMP(4, 0);
     if (shared) kr_f_image_copy<BITS>(a.act_img, a.H, kr_fsm, L, t, 256);
     else if (wave > 0) kr_f_image_copy<BITS>(a.act_img_bf16, a.H, kr_fsm, L, t - 64, 192);
     else {
@@ -523,7 +552,9 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
             const_cast<int32_t*>(a.ids)[lane] = s_ids[lane]; const_cast<float*>(a.wts)[lane] = s_w[lane];
         }
     }
+    KR_FSTAMP(4, 1);
     __syncthreads();
+    KR_FSTAMP(4, 2);
     const KrMatDev& m = shared ? a.sw13 : a.w13;
     const void* qb = m.q; const uint32_t* sb = m.s;
     const int inter = shared ? a.I_shared : a.I;
@@ -545,12 +576,14 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
     if (pair) {
         kr_f_fetch<BITS, NU>(Wg, m, qb, sb, unit, lane, u0, u1);
         kr_f_fetch<BITS, NU>(Wu, m, qb, sb, unit + ntp, lane, u0, u1);
+        KR_FSTAMP(4, 3);
         ag = kr_f_tile<BITS, NU>(Wg, m, qb, sb, unit, lane, u0, u1, L);
         au = kr_f_tile<BITS, NU>(Wu, m, qb, sb, unit + ntp, lane, u0, u1, L);
     } else if (gate_row) {
         kr_f_fetch<BITS, NU>(Wg, a.sgate, a.sgate.q, a.sgate.s, 0, lane, u0, u1);
         ag = kr_f_tile<BITS, NU>(Wg, a.sgate, a.sgate.q, a.sgate.s, 0, lane, u0, u1, L);
     }
+    KR_FSTAMP(4, 4);
     if (l8 == 0) { s_x[tw][ks][0][cl] = ag; s_x[tw][ks][1][cl] = au; }
     __syncthreads();
     if (ks == 0 && l8 == 0) {
@@ -558,6 +591,7 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
         if (pair) a.gu[(size_t)slot * a.gu_ld + unit * 8 + cl] = (g * kr_sigmoid_poly5(g)) * u;
         else if (gate_row && cl == 0) a.gate_out[0] = g;
     }
+    KR_FSTAMP(4, 5);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -575,6 +609,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     __shared__ float s_sig;
     const int t = threadIdx.x, slot = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
     const int tile = blockIdx.x;
+    KR_FSTAMP(5, 0);
     const bool shared = slot >= a.topk;
     const KrMatDev& m = shared ? a.sw2 : a.w2;
     const int inter = shared ? a.I_shared : a.I;
@@ -592,6 +627,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     kr_f_fetch<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units);
     const KrActLds L = kr_carve_lds(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(kr_fsm) + (size_t)slot * slot_lds), inter, BITS == 8);
     const float* h = a.gu + (size_t)slot * a.gu_ld;
+    KR_FSTAMP(5, 1);
     const bool half_away = shared && a.shared_decode;
     for (int c = lane; c < inter / 8; c += 64) {
         float v[8];
@@ -608,10 +644,13 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     }
     if (shared && lane == 0) s_sig = a.gate_out ? 1.0f / (1.0f + kr_expf(-a.gate_out[0])) : 1.0f;
     kr_f_wave_sync();
+    KR_FSTAMP(5, 2);
     const float acc = kr_f_tile<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units, L);
+    KR_FSTAMP(5, 3);
     if (l8 == 0) s_y[slot][cl] = acc;
     if (lane == 0) { s_wt[slot] = wt; s_ok[slot] = valid ? 1 : 0; }
     __syncthreads();
+    KR_FSTAMP(5, 4);
     if (t < 8) {
         float o = 0.0f;
         for (int s = 0; s < a.topk; s++) if (s_ok[s]) o += s_wt[s] * s_y[s][t];
@@ -624,6 +663,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
         const int col = tile * 8 + t;
         if (col < a.H) fa.hid_out[col] = o;
     }
+    KR_FSTAMP(5, 5);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -29,6 +29,15 @@ fastbench)  # only the bench probe (+ trace)
     kstats r03_decode_fast "QCN Q4 decode step, KR_DECODE_FAST, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only fast --steps 30)" -- \
         python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r03_decode_fast_prof
     ;;
+fast2)      # remaining FAST tests, in-kernel phase stamps (probe build), then the whole GPU suite
+    timeout 900 python -m pytest tests/test_decode_fast_gpu.py -q -k "router or generate" 2>&1 | tail -8
+    cat $R/r03_decode_fast_err.txt 2>/dev/null | tail -4
+    KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
+    timeout 2400 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -6
+    ;;
+stamps)
+    KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
+    ;;
 tests)      # the whole GPU suite, as the driver runs it
     timeout 2400 python -m pytest tests/ -x -q -m gpu "$@" 2>&1 | tail -15
     ;;
