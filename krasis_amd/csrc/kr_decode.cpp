@@ -513,11 +513,12 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             int total = 0;
             auto add = [&](int wid, float* y) { fa.mm.m[fa.mm.n] = mv(s, wid); fa.mm.y[fa.mm.n] = y; total += (fa.mm.m[fa.mm.n].N + 7) / 8; fa.mm.tile_end[fa.mm.n] = total; fa.mm.n++; };
             if (L.attn == ATTN_LA) {
-                add(L.qkvz_wid, (float*)s->proj_a.p); add(L.ba_wid, (float*)s->proj_b.p);
+                add(L.ba_wid, (float*)s->proj_b.p); add(L.qkvz_wid, (float*)s->proj_a.p);   // the ba tiles first: their lanes carry the libm gate epilogue, the first workgroups start earliest
                 const int hr = L.nv / L.nk;
                 if (L.dv == 128 && (L.dk == 128 || L.dk == 64) && L.nv == L.nk * hr && L.kd == 4 && img_w(L.out_wid)) {
                     fa.conv_state = (float*)L.conv_state.p; fa.conv_w = (const float*)L.conv_w.p; fa.qk_out = (float*)s->f_qk.p; fa.v_out = (float*)s->vbuf.p; fa.z_out = (float*)s->zbuf.p;
-                    fa.nk = L.nk; fa.dk = L.dk; fa.hr = hr; fa.dv = L.dv;
+                    fa.nk = L.nk; fa.dk = L.dk; fa.hr = hr; fa.dv = L.dv; fa.conv_mi = 1; fa.gate_mi = 0;
+                    fa.a_log = (const float*)L.a_log.p; fa.dt_bias = (const float*)L.dt_bias.p; fa.ge_out = (float*)s->gbuf.p; fa.beta_out = (float*)s->betabuf.p;
                 }
             } else { add(L.q_wid, (float*)s->proj_a.p); add(L.k_wid, (float*)s->kbuf.p); add(L.v_wid, (float*)s->vbuf.p); }
             prof_mark(s, PK_MATVEC, st);
@@ -545,8 +546,8 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
         };
         if (L.attn == ATTN_LA && la_conv_done) {
             KrFlaArgs a{};
-            a.qk = (const float*)s->f_qk.p; a.v = (const float*)s->vbuf.p; a.z = (const float*)s->zbuf.p; a.ba = (const float*)s->proj_b.p;
-            a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale; a.state = (float*)L.recur_state.p;
+            a.qk = (const float*)s->f_qk.p; a.v = (const float*)s->vbuf.p; a.z = (const float*)s->zbuf.p; a.ge = (const float*)s->gbuf.p; a.beta = (const float*)s->betabuf.p;
+            a.scale = L.la_scale; a.state = (float*)L.recur_state.p;
             a.norm_w = (const float*)L.la_norm_w.p; a.out = (float*)s->attn_out.p; a.img_out = s->img_attn.p; a.img_k = s->weights[L.out_wid]->ms.view().ng * 128;
             a.nk = L.nk; a.nv = L.nv; a.hr = L.nv / L.nk; a.dk = L.dk; a.dv = L.dv; a.eps = s->eps;
             prof_mark(s, PK_LA_RECUR, st);

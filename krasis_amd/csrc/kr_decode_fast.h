@@ -27,13 +27,15 @@ struct KrFdmArgs {
     const float *hid_in, *res_in, *norm_w; float* res_out;
     const float* emb; const KrStep* step;   // mode 1, first layer: the added value is the embedding row of the current token
     int first; float eps; int bias_one;
-    // linear-attention conv epilogue on matrix 0 (null conv_state: plain store)
-    float* conv_state; const float* conv_w; float *qk_out, *v_out, *z_out; int nk, dk, hr, dv;
+    // linear-attention epilogues (null conv_state: plain stores): matrix conv_mi = in_proj_qkvz (conv1d + SiLU + state shift per channel, z copied),
+    // matrix gate_mi = in_proj_ba (beta = sigmoid(b), e^g with g = -e^{A_log} softplus(a + dt_bias); decode.rs:3891-3901)
+    float* conv_state; const float* conv_w; float *qk_out, *v_out, *z_out; int nk, dk, hr, dv; int conv_mi, gate_mi;
+    const float *a_log, *dt_bias; float *ge_out, *beta_out;
 };
 int kr_launch_fdm(const KrFdmArgs& a, hipStream_t st);    // non-zero: geometry not covered (caller takes the exact kernels)
 
 struct KrFlaArgs {
-    const float *qk, *v, *z, *ba, *a_log, *dt_bias; float scale;
+    const float *qk, *v, *z, *ge, *beta; float scale;     // ge = e^g, beta: per value head, from the projection launch
     float* state; const float* norm_w; float* out; void* img_out; int img_k;
     int nk, nv, hr, dk, dv; float eps;
 };

@@ -194,25 +194,32 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
     const int tw = wave / KS, ks = wave - tw * KS;
     [[maybe_unused]] const int sk = a.mode == 1 ? 0 : 2;
     KR_FSTAMP(sk, 0);
-    const int total = a.mm.tile_end[a.mm.n - 1];
+    // the matrix of this tile: every field sits at a CONSTANT kernarg offset (one scalar round trip for all of them) and is selected
+    // afterwards -- indexing the argument struct with a computed matrix index costs a second, dependent scalar round trip before the
+    // first weight request can be issued.  The host sets tile_end[i] = total for every i >= n - 1.
+    const int te0 = a.mm.tile_end[0], te1 = a.mm.tile_end[1], te2 = a.mm.tile_end[2], total = a.mm.tile_end[3];
     const int gt = blockIdx.x * TW + tw;
     const bool active = gt < total;
-    int mi = 0;
-    while (mi + 1 < a.mm.n && gt >= a.mm.tile_end[mi]) mi++;
-    const KrMatDev m = a.mm.m[mi];
-    const int tile = active ? gt - (mi ? a.mm.tile_end[mi - 1] : 0) : 0;
+    const int mi = active ? (gt >= te0) + (gt >= te1) + (gt >= te2) : 0;
+#define KR_MSEL(f) (mi == 0 ? a.mm.m[0].f : (mi == 1 ? a.mm.m[1].f : (mi == 2 ? a.mm.m[2].f : a.mm.m[3].f)))
+    KrMatDev m{};
+    m.q = KR_MSEL(q); m.s = KR_MSEL(s); m.ng = KR_MSEL(ng); m.ngp = KR_MSEL(ngp); m.N = KR_MSEL(N);
+    float* const my = mi == 0 ? a.mm.y[0] : (mi == 1 ? a.mm.y[1] : (mi == 2 ? a.mm.y[2] : a.mm.y[3]));
+#undef KR_MSEL
+    const int tile = active ? gt - (mi == 0 ? 0 : (mi == 1 ? te0 : (mi == 2 ? te1 : te2))) : 0;
     const int units = BITS == 4 ? m.ngp : m.ng;
     int u0, u1;
     if (NU > 0) { u0 = ks * NU; u1 = u0 + NU; }
     else { const int uw = (units + KS - 1) / KS; u0 = ks * uw; u1 = u0 + uw < units ? u0 + uw : units; }
     KrFw<BITS, NU> W;
     if (active) kr_f_fetch<BITS, NU>(W, m, m.q, m.s, tile, lane, u0, u1);
-    // the lane that will hold column `col` asks for its conv state / taps now (linear-attention epilogue)
+    // the lane that will hold column `col` asks for what its epilogue needs now: conv state / taps (linear-attention channels), gate constants
     const int col = tile * 8 + cl;
     const bool out_lane = active && ks == 0 && l8 == 0 && col < m.N;
-    int kind = -1, dst = 0, ch = 0;
+    int kind = -1, dst = 0, ch = 0;       // 0 q, 1 k, 2 v (conv channels), 3 z, 4 beta, 5 decay gate
     float4 cs = float4{0.0f, 0.0f, 0.0f, 0.0f}, cw = cs;
-    if (a.conv_state && mi == 0 && out_lane) {
+    float g_al = 0.0f, g_dt = 0.0f;
+    if (out_lane && a.conv_state && mi == a.conv_mi) {
         const int nt = a.hr * a.dv, gd = 2 * a.dk + 2 * nt, key_dim = a.nk * a.dk;
         const int kh = col / gd, cc = col - kh * gd;
         if (cc < a.dk) { kind = 0; ch = kh * a.dk + cc; dst = kh * 2 * a.dk + cc; }
@@ -220,6 +227,10 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
         else if (cc < 2 * a.dk + nt) { kind = 2; ch = 2 * key_dim + kh * nt + (cc - 2 * a.dk); dst = kh * nt + (cc - 2 * a.dk); }
         else { kind = 3; dst = kh * nt + (cc - 2 * a.dk - nt); }
         if (kind < 3) { cs = reinterpret_cast<const float4*>(a.conv_state)[ch]; cw = reinterpret_cast<const float4*>(a.conv_w)[ch]; }
+    } else if (out_lane && a.conv_state && mi == a.gate_mi) {   // ba row: [kh][beta raw (hr) | a raw (hr)] (decode.rs:3891-3901)
+        const int kh = col / (2 * a.hr), idx = col - kh * 2 * a.hr;
+        if (idx < a.hr) { kind = 4; dst = kh * a.hr + idx; }
+        else { kind = 5; dst = kh * a.hr + (idx - a.hr); g_al = a.a_log[dst]; g_dt = a.dt_bias[dst]; }
     }
     const int K = a.mm.m[0].ng * 128;
     const KrActLds L = kr_carve_lds(kr_fsm, K, BITS == 8);
@@ -248,9 +259,14 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
         }
     }
     if (out_lane) {
-        if (kind < 0) a.mm.y[mi][col] = acc;
+        if (kind < 0) my[col] = acc;
         else if (kind == 3) a.z_out[dst] = acc;
-        else {   // decode.rs:3815-3890: depthwise conv1d (kernel 4) over the shifted state, SiLU; the state shift is this lane's alone
+        else if (kind == 4) a.beta_out[dst] = 1.0f / (1.0f + kr_expf(-acc));
+        else if (kind == 5) {
+            const float ap_dt = acc + g_dt;
+            const float softplus = ap_dt > 20.0f ? ap_dt : kr_logf(1.0f + kr_expf(ap_dt));
+            a.ge_out[dst] = kr_expf(-(kr_expf(g_al)) * softplus);
+        } else {   // decode.rs:3815-3890: depthwise conv1d (kernel 4) over the shifted state, SiLU; the state shift is this lane's alone
             reinterpret_cast<float4*>(a.conv_state)[ch] = float4{cs.y, cs.z, cs.w, acc};
             float co = cs.y * cw.x + cs.z * cw.y + cs.w * cw.z + acc * cw.w;
             co = co * kr_sigmoid_poly5(co);
@@ -269,10 +285,9 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
     static_assert(RPS >= 1 && NS * RPS == DK, "geometry");
     __shared__ float s_qk[2 * DK];
     __shared__ float s_red[8];
-    __shared__ float s_gate[2];
     __shared__ __attribute__((aligned(16))) float s_part[NS][DV];
     __shared__ __attribute__((aligned(16))) float s_vec[DV];
-    const int vh = blockIdx.x, kh = vh / a.hr, r = vh - kh * a.hr;
+    const int vh = blockIdx.x, kh = vh / a.hr;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int slice = t / JQ, jq = t - slice * JQ;
     f32x4* S4 = reinterpret_cast<f32x4*>(a.state + (size_t)vh * DK * DV);
@@ -286,14 +301,7 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
     if (t < DV) { const size_t o = (size_t)vh * DV + t; zz = a.z[o]; vv = a.v[o]; wn = a.norm_w[o]; }
     const float sq = kr_f_wave_sum(qv * qv);
     if (lane == 0) s_red[wave] = sq;
-    if (t == 448) {   // gates (decode.rs:3891-3901) on a wave that has nothing else to do before the barrier
-        const float b_raw = a.ba[kh * 2 * a.hr + r], a_p = a.ba[kh * 2 * a.hr + a.hr + r];
-        s_gate[1] = 1.0f / (1.0f + kr_expf(-b_raw));
-        const float ap_dt = a_p + a.dt_bias[vh];
-        const float softplus = ap_dt > 20.0f ? ap_dt : kr_logf(1.0f + kr_expf(ap_dt));
-        const float g = -(kr_expf(a.a_log[vh])) * softplus;
-        s_gate[0] = kr_expf(g);
-    }
+    const float g_exp = a.ge[vh], beta = a.beta[vh];   // e^g and beta of this head: formed by the ba lanes of the projection launch
     KR_FSTAMP(1, 1);
     __syncthreads();
     KR_FSTAMP(1, 2);
@@ -301,7 +309,6 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
 #pragma unroll
     for (int w = 1; w < WQ; w++) { ssq += s_red[w]; ssk += s_red[WQ + w]; }
     const float inv_q = (ssq > 0.0f ? 1.0f / sqrtf(ssq) : 0.0f) * a.scale, inv_k = ssk > 0.0f ? 1.0f / sqrtf(ssk) : 0.0f;
-    const float g_exp = s_gate[0], beta = s_gate[1];
     float kk[RPS], qq[RPS];
 #pragma unroll
     for (int u = 0; u < RPS; u++) { kk[u] = s_qk[DK + slice * RPS + u] * inv_k; qq[u] = s_qk[slice * RPS + u] * inv_q; }
@@ -455,21 +462,76 @@ __global__ void __launch_bounds__(256) kr_frt_kernel(const KrFrtArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// wave-wide top-np in (value desc, index asc) order WITHOUT a tournament over all elements (kr_topk_wave_reg walks np rounds of: scan the
+// lane's NV keys, wave maximum, retire the winner -- ~65 instructions each on a lone wave):
+//   (1) T = a lower bound of the np-th largest element: np rounds of wave-max over the LANE maxima, every round retiring the lanes that hold
+//       the current maximum (so at least np elements are >= T),
+//   (2) the elements >= T (np of them plus, rarely, a few more) are compacted into lanes 0 .. M-1 through LDS,
+//   (3) every candidate counts the candidates that precede it in (value desc, index asc) -- its rank -- with lane broadcasts; ranks < np are
+//       written to pv / pi.  Returns false (nothing written) when more than 64 elements reach T: the caller runs the tournament.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ bool kr_f_topk(const float (&val)[NV], int n, int np, float* pv, int* pi, uint32_t* cand /* LDS [128] */) {
+    const int lane = threadIdx.x & 63;
+    uint32_t key[NV], h = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; i++) { const int e = lane * NV + i; key[i] = e < n ? kr_make_key(val[i]) : 0u; h = kr_umax(h, key[i]); }
+    uint32_t T = 0u;
+    for (int r = 0; r < np; r++) { const uint32_t w = kr_wave_umax(h); T = w; if (h == w) h = 0u; }
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const bool c = key[i] != 0u && key[i] >= T;
+        const uint64_t mask = __ballot(c);
+        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (c && pos < 64) { cand[2 * pos] = key[i]; cand[2 * pos + 1] = (uint32_t)(lane * NV + i); }
+        base += __popcll(mask);
+    }
+    const int M = base;
+    if (M > 64) return false;
+    kr_f_wave_sync();
+    uint32_t kj = 0u, ij = 0u;
+    if (lane < M) { kj = cand[2 * lane]; ij = cand[2 * lane + 1]; }
+    int rank = 0;
+    for (int i = 0; i < M; i++) {
+        const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)kj, i), ii = (uint32_t)__builtin_amdgcn_readlane((int)ij, i);
+        rank += (ki > kj || (ki == kj && ii < ij)) ? 1 : 0;
+    }
+    if (lane < M && rank < np) { pv[rank] = kr_key_value(kj); pi[rank] = (int)ij; }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // scoring + top-k by ONE wave (moe_route_score_topk + topk_indices, decode.rs:4088-4186, 1495-1535): the scores and the renormalisation are
 // wave trees; the selection is the (value desc, index asc) wave top-k of kr_topk.h; softmax without a correction bias selects on the LOGITS
 // (softmax is monotone), so for identical logits the ids are those of the exact kernel unless two of the leading k + 1 are EQUAL -- then the
 // reference's heap order decides and is emulated serially, as in the exact kernel.
-// sm: [E] scores, [E] selection values, [33] pv, [33] pi, [32] hv, [32] hi
+// sm: [E] scores, [E] selection values, [33] pv, [33] pi, [32] hv, [32] hi, [2] pad, [128] candidate list
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int NV>
 __device__ __forceinline__ void kr_f_select(const float* logits, const float* esc, int E, int k, int scoring, int norm, float* sm, int* s_ids, float* s_w) {
     float* scores = sm; float* sel = sm + E; float* pv = sel + E; int* pi = reinterpret_cast<int*>(pv + 33);
     float* hv = reinterpret_cast<float*>(pi + 33); int* hi = reinterpret_cast<int*>(hv + 32);
+    uint32_t* cand = reinterpret_cast<uint32_t*>(hi + 32 + 2);      // [128]
     const int lane = threadIdx.x & 63;
     const bool raw = scoring == 2;
     float lg[NV], sc[NV], sl[NV];
+    bool wide = false;
+    if constexpr (NV % 4 == 0) {
+        if (E % 4 == 0) {
+            wide = true;
 #pragma unroll
-    for (int i = 0; i < NV; i++) { const int e = lane * NV + i; lg[i] = e < E ? logits[e] : -__builtin_inff(); }
+            for (int i = 0; i < NV; i += 4) {
+                const int e = lane * NV + i;
+                const float4 v = e < E ? *reinterpret_cast<const float4*>(logits + e) : float4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                lg[i] = v.x; lg[i + 1] = v.y; lg[i + 2] = v.z; lg[i + 3] = v.w;
+            }
+        }
+    }
+    if (!wide) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; lg[i] = e < E ? logits[e] : -__builtin_inff(); }
+    }
     if (raw) {
 #pragma unroll
         for (int i = 0; i < NV; i++) sc[i] = lg[i];
@@ -498,7 +560,7 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
         if (e < E) { scores[e] = sc[i]; sel[e] = sl[i]; }
     }
     const int np = k + 1 <= E ? k + 1 : k;
-    kr_topk_wave_reg<NV>(sl, E, np, pv, pi);
+    if (!kr_f_topk<NV>(sl, E, np, pv, pi, cand)) kr_topk_wave_reg<NV>(sl, E, np, pv, pi);
     kr_f_wave_sync();
     {
         const float pa = lane < np ? pv[lane] : 0.0f, pb = lane + 1 < np ? pv[lane + 1] : 0.0f;
@@ -589,7 +651,7 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
     if (ks == 0 && l8 == 0) {
         const float g = s_x[tw][0][0][cl] + s_x[tw][1][0][cl], u = s_x[tw][0][1][cl] + s_x[tw][1][1][cl];
         if (pair) a.gu[(size_t)slot * a.gu_ld + unit * 8 + cl] = (g * kr_sigmoid_poly5(g)) * u;
-        else if (gate_row && cl == 0) a.gate_out[0] = g;
+        else if (gate_row && cl == 0) a.gate_out[0] = 1.0f / (1.0f + kr_expf(-g));   // sigmoid of the shared expert's gate row (decode.rs:3379-3393): the w2 launch multiplies by it
     }
     KR_FSTAMP(4, 5);
 }
@@ -604,12 +666,11 @@ template <int BITS, int NU>
 __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int slot_lds) {
     const KrMoeArgs& a = fa.m;
     __shared__ float s_y[16][8];
-    __shared__ float s_wt[16];
-    __shared__ int s_ok[16];
-    __shared__ float s_sig;
+    __shared__ __attribute__((aligned(16))) float s_wt[16];
     const int t = threadIdx.x, slot = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
     const int tile = blockIdx.x;
     KR_FSTAMP(5, 0);
+    const float sig = a.gate_out ? a.gate_out[0] : 1.0f;     // sigmoid(gate row) of the shared expert, formed by the gate|up launch
     const bool shared = slot >= a.topk;
     const KrMatDev& m = shared ? a.sw2 : a.w2;
     const int inter = shared ? a.I_shared : a.I;
@@ -642,22 +703,28 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
         kr_store_chunk<BITS == 8>(L, c, q);
         if ((c & 15) == 0) L.ascale[c >> 4] = scale;
     }
-    if (shared && lane == 0) s_sig = a.gate_out ? 1.0f / (1.0f + kr_expf(-a.gate_out[0])) : 1.0f;
     kr_f_wave_sync();
     KR_FSTAMP(5, 2);
     const float acc = kr_f_tile<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units, L);
     KR_FSTAMP(5, 3);
     if (l8 == 0) s_y[slot][cl] = acc;
-    if (lane == 0) { s_wt[slot] = wt; s_ok[slot] = valid ? 1 : 0; }
+    if (lane == 0) s_wt[slot] = valid ? wt : 0.0f;
+    if (t >= a.n_slots && t < 16) s_wt[t] = 0.0f;
     __syncthreads();
     KR_FSTAMP(5, 4);
     if (t < 8) {
+        float y[16], w[16];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) { const float4 v = reinterpret_cast<const float4*>(s_wt)[s4]; w[4 * s4] = v.x; w[4 * s4 + 1] = v.y; w[4 * s4 + 2] = v.z; w[4 * s4 + 3] = v.w; }
+#pragma unroll
+        for (int sl = 0; sl < 16; sl++) y[sl] = s_y[sl][t];
         float o = 0.0f;
-        for (int s = 0; s < a.topk; s++) if (s_ok[s]) o += s_wt[s] * s_y[s][t];
+#pragma unroll
+        for (int sl = 0; sl < 15; sl++) { const float pr = w[sl] * y[sl]; o += sl < a.topk ? pr : 0.0f; }    // routing order (moe.rs:661-667); an invalid id carries weight 0
         if (a.rsf != 1.0f) o *= a.rsf;
         if (a.n_slots > a.topk) {
             float sh = s_y[a.topk][t];
-            if (a.gate_out) sh *= s_sig;
+            if (a.gate_out) sh *= sig;
             o = o + sh;
         }
         const int col = tile * 8 + t;
@@ -688,7 +755,8 @@ int kr_launch_fdm(const KrFdmArgs& a, hipStream_t st) {
     const int bits = m0.bits, K = m0.ng * 128;
     for (int i = 1; i < a.mm.n; i++) if (a.mm.m[i].bits != bits || a.mm.m[i].ng != m0.ng) return 1;
     if (a.mode == 1 && (K > 4096 || K != m0.K)) return 1;
-    if (a.conv_state && (a.mm.m[0].N != a.nk * (2 * a.dk + 2 * a.hr * a.dv))) return 1;
+    if (a.conv_state && (a.conv_mi < 0 || a.conv_mi >= a.mm.n || a.mm.m[a.conv_mi].N != a.nk * (2 * a.dk + 2 * a.hr * a.dv) || a.gate_mi < 0 || a.gate_mi >= a.mm.n ||
+                         a.mm.m[a.gate_mi].N != a.nk * 2 * a.hr || !a.ge_out || !a.beta_out)) return 1;
     const int total = a.mm.tile_end[a.mm.n - 1];
     const int units = bits == 4 ? m0.ngp : m0.ng;
     // K split: near one or two workgroups per CU, and a wave's chain no longer than 8 units
@@ -700,14 +768,16 @@ int kr_launch_fdm(const KrFdmArgs& a, hipStream_t st) {
     const int nu = (nu_exact == 2 || nu_exact == 4 || nu_exact == 8 || nu_exact == 16) ? nu_exact : 0;
     dim3 grid((total + tw - 1) / tw);
     const size_t lds = kr_lds_bytes(K, bits == 8);
+    KrFdmArgs b = a;
+    for (int i = a.mm.n - 1; i < KR_MAX_MULTI; i++) b.mm.tile_end[i] = total;   // the kernel reads all four at constant offsets
     if (bits == 4) {
-        if (ks == 1) return kr_fdm_launch_nu<4, 1>(a, nu, grid, lds, st);
-        if (ks == 2) return kr_fdm_launch_nu<4, 2>(a, nu, grid, lds, st);
-        return kr_fdm_launch_nu<4, 4>(a, nu, grid, lds, st);
+        if (ks == 1) return kr_fdm_launch_nu<4, 1>(b, nu, grid, lds, st);
+        if (ks == 2) return kr_fdm_launch_nu<4, 2>(b, nu, grid, lds, st);
+        return kr_fdm_launch_nu<4, 4>(b, nu, grid, lds, st);
     }
-    if (ks == 1) return kr_fdm_launch_nu<8, 1>(a, nu, grid, lds, st);
-    if (ks == 2) return kr_fdm_launch_nu<8, 2>(a, nu, grid, lds, st);
-    return kr_fdm_launch_nu<8, 4>(a, nu, grid, lds, st);
+    if (ks == 1) return kr_fdm_launch_nu<8, 1>(b, nu, grid, lds, st);
+    if (ks == 2) return kr_fdm_launch_nu<8, 2>(b, nu, grid, lds, st);
+    return kr_fdm_launch_nu<8, 4>(b, nu, grid, lds, st);
 }
 
 int kr_launch_fla(const KrFlaArgs& a, hipStream_t st) {
@@ -757,7 +827,7 @@ int kr_launch_fw13(const KrFmoeArgs& fa, hipStream_t st) {
     int ntp = a.I / 8;
     if (has_shared && a.I_shared / 8 + (a.sgate.q ? 1 : 0) > ntp) ntp = a.I_shared / 8 + (a.sgate.q ? 1 : 0);
     dim3 grid((ntp + 1) / 2, a.n_slots);
-    const size_t lds = kr_lds_bytes(a.H, a.w13.bits == 8) + (size_t)(2 * a.E + 33 + 33 + 32 + 32 + 4) * 4;
+    const size_t lds = kr_lds_bytes(a.H, a.w13.bits == 8) + (size_t)(2 * a.E + 33 + 33 + 32 + 32 + 4 + 128) * 4;
     const int units = a.w13.bits == 4 ? a.w13.ngp : a.w13.ng;
     const bool even = (a.w13.bits == 8 || (a.w13.ng % 2) == 0) && units % 2 == 0;
     const int nu = even ? units / 2 : 0;

@@ -35,6 +35,12 @@ fast2)      # remaining FAST tests, in-kernel phase stamps (probe build), then t
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     timeout 2400 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -6
     ;;
+fast3)      # FAST tests + stamps + bench probe (no trace)
+    timeout 900 python -m pytest tests/test_decode_fast_gpu.py -x -q 2>&1 | tail -5
+    tail -16 $R/r03_decode_fast_err.txt
+    KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -7
+    timeout 600 python tools/probes/decode_fast_bench.py --only fast --route-tokens 200 "$@" 2>&1 | tail -14
+    ;;
 stamps)
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     ;;
