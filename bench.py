@@ -43,6 +43,9 @@ SYMBOL = {"proj_matvec": "kr_matvec_coop_kernel<float,4>", "lm_head": "kr_matvec
           "moe_w13": "kr_moe_w13_kernel<4>", "moe_w2": "kr_moe_w2_kernel<4,0>", "la_recurrent": "kr_la_step_kernel<128,128>",
           "route_logits": "kr_route_fused_decode_kernel<true,8>", "route_select": "kr_route_select_kernel",
           "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
+# the same kinds in KR_DECODE_FAST (kr_decode_fast.hip): the norms ride in the projection / router launches, top-k + silu*up in the gate|up launch, the combine in the down launch
+SYMBOL_FAST = {"proj_matvec": "kr_fdm_kernel<4,1,8>|<4,4,4>", "lm_head": "kr_matvec_kernel<float,4>", "moe_w13": "kr_fw13_kernel<4,4>", "moe_w2": "kr_fw2_kernel<4,2>",
+               "la_recurrent": "kr_fla_kernel<128,128>", "route_logits": "kr_frt_kernel<true>", "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
 WORKLOAD = {"qcn-q4": "Qwen3-Coder-Next Q4 int4gpu on 1×MI355X (512-expert top-10, hybrid linear+GQA, FP8 KV)",
             "qcn-q8": "Qwen3-Coder-Next Q8 int8gpu on 1×MI355X (int8 MFMA path, Q8_0 dequant)",
             "v2lite-q4": "DeepSeek-V2-Lite Q4 int4gpu on 1×MI355X (MLA + 64-expert top-6)"}
@@ -73,6 +76,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--decode-mode", default="fast", choices=["fast", "exact"],
+                    help="numerics of the headline decode steps: fast = KR_DECODE_FAST (the reference's products, tree reductions; logits within the tolerance of "
+                         "tests/test_decode_fast_gpu.py, router ids identical for identical logits), exact = bit-identical to the reference's CPU decode; the other mode is reported as a side leg")
     ap.add_argument("--prefill-chunk", type=int, default=0, help="tokens per chunk of the prompt pass (0 = library default)")
     ap.add_argument("--prefill-depth", type=int, default=0, help="chunks of the prompt pass in flight (0 = library default)")
     ap.add_argument("--prefill-reps", type=int, default=1, help="timed repetitions of the whole-model prompt pass per prompt length")
@@ -308,7 +314,7 @@ def prefill_ep(eng, dims, L, M, world, rank, torch, dist, experts_local=None):
     macs = world * M * k * 3 * H * I * L
     off = (world - 1) / world                          # share of the rows that leave the GPU under uniform routing
     useful = 2.0 * macs / dt / 1e12
-    return {"tokens_per_gpu": M, "tokens_total": world * M, "layers": L, "ms": dt * 1e3, "tok_s_experts_only": world * M / dt, "scaling": "weak",
+    return {"tokens_per_gpu": M, "tokens_total": world * M, "layers": L, "ms": dt * 1e3, "tok_s_experts_only": world * M / dt, "scaling": "weak", "rccl_ranks": ep.comm_ranks(),
             "experts_per_gpu": E // world, "roofline": {"bound": "mfma", "achieved": useful, "peak": I8_PEAK_TOPS * world, "unit": "TOP/s (int8, useful)", "frac": useful / (I8_PEAK_TOPS * world)},
             "exchange_GB_per_gpu_per_layer": {"dispatch_bf16": M * k * H * 2 * off / 1e9, "combine_bf16": M * k * H * 2 * off / 1e9},
             "note": "owner sort + RCCL send/recv dispatch (bf16 rows) + expert GEMMs (w2 scatters bf16 rows to their return slots) + RCCL send/recv return + combine in "
@@ -388,7 +394,7 @@ def profile_kinds(st, kvm, P=5):
 
 
 def long_context(st, kv_long, torch, kv_name, fast=False):
-    st.set_attention_mode(fast)
+    st.set_attention_mode(fast, decode_fast=fast)
     st.fill_state_synthetic(kv_long, 7)
     for i in range(3):
         st.decode_step(0, kv_long - 6 + i)
@@ -400,7 +406,7 @@ def long_context(st, kv_long, torch, kv_name, fast=False):
     d1 = (time.perf_counter() - t1) / 20
     st.set_attention_mode(False)
     return {"kv_max_seq": kv_long, "position": kv_long - 2, "kv": kv_name, "ms_per_step": d1 * 1e3, "tok_s": 1.0 / d1,
-            "attention": "fast: split-KV softmax + p.v, log-sum-exp merge (logits within ~1e-4 relative of the exact order)" if fast else
+            "attention": "fast: split-KV flash-decode on the f16 MFMA + log-sum-exp merge (KR_ATTN_FAST) and the tolerance-mode step kernels (KR_DECODE_FAST)" if fast else
                          "exact: the reference's sequential softmax sum / p.v order (bit-identical to the CPU decode)"}
 
 
@@ -419,6 +425,13 @@ def side_config(name, rank, local_rank, args, torch):
     ab = algorithmic_bytes(L, bw) if qcn else algorithmic_bytes_v2lite(L, bw)
     res = {"workload": WORKLOAD[name], "decode_tok_s": steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "kv": "FP8-E4M3", "weights": "INT%d-g128" % bits,
            "step_algorithmic_bytes": ab["total"], "step_frac_of_hbm_peak": ab["total"] * (steps / dt) / 1e9 / HBM_PEAK_GBS}
+    try:       # the same steps in KR_DECODE_FAST (layers / geometries its kernels do not cover -- MLA projections, dense MLP -- keep the exact kernels)
+        st.set_attention_mode(False, decode_fast=True)
+        dtf = time_decode(st, steps, args.warmup, dims["kv_max_seq"], torch, None, 1)
+        res["decode_fast_tok_s"] = steps / dtf; res["decode_fast_frac_of_hbm_peak"] = ab["total"] * (steps / dtf) / 1e9 / HBM_PEAK_GBS
+    except Exception as ex:
+        res["decode_fast_tok_s"] = {"error": repr(ex)}
+    st.set_attention_mode(False)
     try:
         macs = qcn_gemm_macs_per_token(L) if qcn else v2l_gemm_macs_per_token(L)
         res["prefill"] = prefill_model(st, dims, macs, L, 8192, 1, torch)
@@ -550,8 +563,20 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: spawn the N ranks (one per GPU, RCCL) -- the same launch line the driver uses
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py --gpus %d needs %d devices, this box has %d" % (args.gpus, args.gpus, have))
+        import subprocess
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the two must agree (n_gpus in the JSON line is the number of ranks that ran)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -571,6 +596,19 @@ def main():
     eng, st, keep = build(rank, local_rank, L, rope_len, bits, kv_fp8)      # rope table: prompt pass and the long-cache side measurement
     st.set_use_graph(not args.no_graph)
     kvm = dims["kv_max_seq"]
+    fast_mode = args.decode_mode == "fast"
+    # the mode that is NOT the headline first (side leg, fewer steps), then the headline: K timed steps with the barrier / max-over-ranks protocol
+    other = {}
+    try:
+        st.set_attention_mode(False, decode_fast=not fast_mode)
+        n_o = min(args.steps, 50)
+        d_o = time_decode(st, n_o, args.warmup, kvm, torch, None, 1)
+        other = {"tok_s": n_o / d_o, "ms_per_step": d_o / n_o * 1e3, "steps": n_o,
+                 "numerics": "KR_DECODE_FAST (tolerance mode)" if not fast_mode else "exact: bit-identical to the reference's CPU decode (tests/test_decode_gpu.py compares logits and every state tensor with array_equal)"}
+    except Exception as ex:
+        other = {"error": repr(ex)}
+    st.set_attention_mode(False, decode_fast=fast_mode)
+    st.fill_state_synthetic(kvm, seed=4242 + rank)
     dt = time_decode(st, args.steps, args.warmup, kvm, torch, dist, world)
 
     # per-kernel durations: un-graphed steps with HIP events around every launch on the launch stream
@@ -580,10 +618,10 @@ def main():
     if world == 1:       # side measurements belong to the N = 1 line only
         # the same decode step with the other KV element type (the headline follows BASELINE config 3: FP8 KV)
         try:
-            st.set_kv_dtype(not kv_fp8); st.fill_state_synthetic(kvm, seed=4242)
+            st.set_kv_dtype(not kv_fp8); st.set_attention_mode(False, decode_fast=fast_mode); st.fill_state_synthetic(kvm, seed=4242)
             d2 = time_decode(st, min(args.steps, 50), 3, kvm, torch, None, 1)
             side["decode_other_kv"] = {"kv": "FP16" if kv_fp8 else "FP8-E4M3", "tok_s": min(args.steps, 50) / d2, "ms_per_step": d2 / min(args.steps, 50) * 1e3}
-            st.set_kv_dtype(kv_fp8); st.fill_state_synthetic(kvm, seed=4242)
+            st.set_kv_dtype(kv_fp8); st.set_attention_mode(False, decode_fast=fast_mode); st.fill_state_synthetic(kvm, seed=4242)
         except Exception as ex:
             side["decode_other_kv"] = {"error": repr(ex)}
         if pf_list:
@@ -647,7 +685,7 @@ def main():
         emitted.append(1)
         sym_us, sym_bytes, sym_n = {}, {}, {}
         for j in range(15):
-            kname = KINDS[j]; sym = SYMBOL.get(kname, kname)
+            kname = KINDS[j]; sym = (SYMBOL_FAST if fast_mode and qcn and bits == 4 else SYMBOL).get(kname, kname)
             sym_us[sym] = sym_us.get(sym, 0.0) + per_kind_us[kname]; sym_bytes[sym] = sym_bytes.get(sym, 0.0) + ab.get(kname, 0.0)
             sym_n[sym] = sym_n.get(sym, 0) + n_per_step[kname]
         dom = max(sym_us, key=lambda s: sym_us[s])
@@ -658,13 +696,17 @@ def main():
             "metric": "decode tok/s, %s @%d MI355X" % ("Qwen3-Coder-Next Q%d" % bits if qcn else "DeepSeek-V2-Lite Q4", world),
             "value": tok_s, "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int%d-g128 weights x int16 activations -> i32, f32 scale chain (reference CPU-decode numerics, bit-exact)" % bits,
+            "dtype": ("int%d-g128 weights x int16 activations -> i32 group sums, f32 scales" % bits) +
+                     (" (KR_DECODE_FAST: the reference's products, f32 sums as lane / wave / workgroup trees -- logits within 2e-3 of the bit-exact mode, "
+                      "router ids identical for identical logits; tests/test_decode_fast_gpu.py)" if fast_mode else " (reference CPU-decode numerics, bit-exact)"),
             "data": "synthetic",
             "config": {"workload": WORKLOAD[name],
                        "scope": "full decode_step: embedding, %d layers (attention + MoE + shared expert), final norm, lm_head, greedy sample" % L,
                        "kv": ("FP8-E4M3" if kv_fp8 else "FP16") + " KV cache, kv_max_seq %d" % kvm, "layers": L,
                        "parallelism": "replica x%d (the model fits one GPU; decode is not expert-parallel)" % world,
-                       "hip_graph": not args.no_graph, "target_tok_s": 200},
+                       "hip_graph": not args.no_graph, "target_tok_s": 200,
+                       "decode_mode": "fast (KR_DECODE_FAST, opt-in tolerance mode; the library default is the bit-exact graph)" if fast_mode else "exact (library default)"},
+            ("decode_exact" if fast_mode else "decode_fast"): other,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "peak_measured_stream_read": 6996.0, "peak_measured_source": "tools/probes/hbm_stream.hip on this box type (8 GiB, 16-byte loads)", "traffic": traffic, "traffic_unit": "HBM fetch bytes per launch (PMC FETCH_SIZE, separate pass)",
                          "traffic_source": traffic_src,

@@ -177,7 +177,18 @@ int kr_ep_unique_id(void* id_out128);
 int kr_ep_init(kr_engine* e, int world, int rank, int n_experts_total, const void* id128 /* NULL when world == 1 */, int return_bf16);
 int kr_ep_destroy(kr_engine* e);
 int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids_global, const float* weights, void* out, int M, int topk,
-                      int out_dtype, int routed_only, void* stream);
+                      int out_dtype, int routed_only, void* stream);   /* COLLECTIVE: every rank calls, same layer order; M == 0 (empty shard, NULL pointers) is valid and still takes part */
+int kr_ep_comm_ranks(kr_engine* e, int* n_out);                        /* ranks of this engine's communicator as RCCL counts them (ncclCommCount) */
+int kr_ep_max_int(kr_engine* e, int value, int* max_out, void* stream);                /* collective: max of `value` over the ranks (kr_decode_prefill pads ranks with fewer chunks) */
+int kr_ep_allreduce_f32(kr_engine* e, float* buf_dev, size_t n, void* stream);         /* collective: in-place f32 sum over the ranks (expert-parallel decode step) */
+/* loopback transport: W virtual ranks = W engines of ONE process (normally on one device), every rank driven by its own host thread while a
+ * collective call is in flight; the exchanges are hipMemcpyAsync pulls between the engines' buffers bracketed by host barriers.  It runs the
+ * SAME split-size / offset / scatter code as the RCCL transport, so a single-GPU box can check world sizes 2, 3 (remainder slice), 8
+ * against single-engine execution (tests/test_ep_gpu.py).  Not a performance path. */
+typedef struct kr_ep_loop_group kr_ep_loop_group;
+int kr_ep_loopback_create(int world, kr_ep_loop_group** out);
+void kr_ep_loopback_destroy(kr_ep_loop_group* g);
+int kr_ep_init_loopback(kr_engine* e, kr_ep_loop_group* group, int rank, int n_experts_total, int return_bf16);
 
 int kr_synchronize(kr_engine* e);
 

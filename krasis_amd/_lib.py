@@ -17,7 +17,7 @@ SYMBOLS = [
     "kr_last_error", "kr_version", "kr_engine_create", "kr_engine_destroy", "kr_engine_get_config",
     "kr_engine_device_bytes", "kr_upload_expert_unified", "kr_upload_expert_bf16", "kr_upload_expert_gguf", "kr_fill_layer_synthetic", "kr_fill_layer_synthetic_gguf",
     "kr_download_expert_unified", "kr_marlin_repack", "kr_marlin_unpack", "kr_upload_expert_marlin", "kr_download_expert_marlin", "kr_moe_forward", "kr_moe_prefill", "kr_set_routing_config", "kr_set_routing_weights", "kr_set_routing_weights_synthetic",
-    "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_combine_rows", "kr_ep_unique_id", "kr_ep_init", "kr_ep_destroy", "kr_moe_prefill_ep", "kr_moe_set_prefill_pairs", "kr_moe_set_gemm_mode", "kr_synchronize", "kr_set_profiling",
+    "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_combine_rows", "kr_ep_unique_id", "kr_ep_init", "kr_ep_destroy", "kr_moe_prefill_ep", "kr_ep_comm_ranks", "kr_ep_max_int", "kr_ep_allreduce_f32", "kr_ep_loopback_create", "kr_ep_loopback_destroy", "kr_ep_init_loopback", "kr_moe_set_prefill_pairs", "kr_moe_set_gemm_mode", "kr_synchronize", "kr_set_profiling",
     "kr_get_profile", "kr_decode_create", "kr_decode_set_moe_store", "kr_decode_destroy", "kr_decode_store_weight_f32", "kr_decode_store_weight_synthetic",
     "kr_decode_download_weight", "kr_decode_store_norm_weight", "kr_decode_configure", "kr_decode_add_la_layer",
     "kr_decode_add_gqa_layer", "kr_decode_add_mla_layer", "kr_decode_prefill", "kr_decode_prefill_nll", "kr_decode_reset_state", "kr_decode_generate", "kr_decode_sample", "kr_decode_set_prefill_chunk", "kr_decode_set_prefill_depth", "kr_decode_set_layer_moe", "kr_decode_set_layer_dense", "kr_decode_set_rope", "kr_decode_finalize", "kr_decode_set_kv_dtype", "kr_decode_set_attention_mode",
@@ -99,6 +99,12 @@ def load_library() -> C.CDLL:
     lib.kr_ep_unique_id.argtypes = [C.c_void_p]
     lib.kr_ep_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     lib.kr_ep_destroy.argtypes = [C.c_void_p]
+    lib.kr_ep_comm_ranks.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.kr_ep_max_int.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]
+    lib.kr_ep_allreduce_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.kr_ep_loopback_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.kr_ep_loopback_destroy.argtypes = [C.c_void_p]; lib.kr_ep_loopback_destroy.restype = None
+    lib.kr_ep_init_loopback.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.kr_moe_prefill_ep.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.kr_synchronize.argtypes = [C.c_void_p]
     lib.kr_set_profiling.argtypes = [C.c_void_p, C.c_int]

@@ -176,8 +176,8 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
             kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st);
         kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
         // routed experts: exact CPU-engine arithmetic on the matrix cores, f32 weighted sum in routing order
-        // expert parallelism (kr_ep_init on the engine): this rank's chunk exchanges its (token, slot) rows with the owners over RCCL; every rank
-        // must run the same number of chunks and layers (equal prompt lengths).  One chunk in flight: the exchange buffers are per engine.
+        // expert parallelism (kr_ep_init on the engine): this rank's chunk exchanges its (token, slot) rows with the owners over RCCL.  A collective:
+        // prefill_impl pads ranks that have fewer chunks with empty-shard calls.  One chunk in flight: the exchange buffers are per engine.
         if (e->ep) { if (int rc = kr_moe_prefill_ep(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, st ? (void*)st : (void*)1)) return rc; }
         else if (int rc = kr_moe_prefill_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set | (s->gemm_fast ? KR_PF_SET_FAST : 0), st)) return rc;
         const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
@@ -351,6 +351,8 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
         KR_HIP(hipEventRecord(s->pf_events[ev_start], st));               // side streams start after everything already queued on the main one
         for (int i = 1; i < D; i++) KR_HIP(hipStreamWaitEvent(streams[i], s->pf_events[ev_start], 0));
     }
+    int n_chunks_max = n_chunks;     // expert parallelism: chunks of the longest prompt shard over the ranks -- agreed on BEFORE the first exchange of the pass
+    if (e->ep) if (int rc = kr_ep_max_int(e, n_chunks, &n_chunks_max, st ? (void*)st : (void*)1)) return rc;
     const auto t_enqueue = std::chrono::steady_clock::now();
     std::vector<Chunk> chunks(n_chunks);
     for (int c = 0; c < n_chunks; c++) {
@@ -375,6 +377,14 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
                     if (int rc = run_final_all(s, cx, (float*)((char*)s->pf_vlogits.p + (size_t)cx.set * vl_bytes), c * CH, n_tokens, c == n_chunks - 1)) return rc;
             }
         }
+    }
+    if (e->ep) {
+        // expert parallelism: kr_moe_prefill_ep is a collective, one call per (chunk, MoE layer) on every rank.  Ranks whose prompt shard has fewer
+        // chunks than the longest one keep answering with empty shards (their experts still serve the peers' rows) instead of leaving them blocked.
+        for (int c = n_chunks; c < n_chunks_max; c++)
+            for (auto& Ly : s->layers)
+                if (Ly.mlp == MLP_MOE)
+                    if (int rc = kr_moe_prefill_ep(e, Ly.moe_layer, nullptr, nullptr, nullptr, nullptr, 0, s->topk, KR_OUT_F32, 1, st ? (void*)st : (void*)1)) return rc;
     }
     Chunk& last = chunks[n_chunks - 1];
     if (!nll_out) run_final(s, last);

@@ -15,13 +15,34 @@
 // The split sizes of ncclSend / ncclRecv are host integers, so ONE 4 * world^2-byte device-to-host copy per call is waited for (the only host
 // synchronisation; it covers the sort kernels, not the previous layer's GEMMs when the caller alternates streams).  RCCL is bound at
 // kr_ep_init by dlopen("librccl.so.1") -- the runtime a framework already loaded is reused, and single-GPU users never load it.
+//
+// TRANSPORT.  The exchange is two primitives behind a small table (KrEpTransport): `gather_counts` (every rank contributes `world` ints, every rank
+// receives all world x world) and `exchange` (a personalised all-to-all of row blocks described by per-peer offsets).  Two implementations:
+//   * RCCL       -- one process per GPU: ncclAllGather + grouped ncclSend / ncclRecv on the caller's stream (kr_ep_init);
+//   * loopback   -- W virtual ranks = W engines of ONE process on one device (kr_ep_loopback_create / kr_ep_init_loopback): every rank runs in its own
+//                   host thread, publishes its buffers in a shared group object, the peers pull them with hipMemcpyAsync after an event wait, and
+//                   host barriers bracket each step.  It exists so that the offset arithmetic below (split sizes, per-peer offsets, the receive-side
+//                   scatter) runs at W = 2, 3 (remainder slice), 8 on a single-GPU box: tests/test_ep_gpu.py asserts bit-identity with one engine.
+// A rank whose token shard is EMPTY (M == 0) still takes part in every collective with zero-sized blocks -- returning early would leave its peers
+// blocked in the all-gather.  Failures after the first collective of a call abort the communicator (ncclCommAbort) so that the peers get an error
+// instead of waiting forever.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <vector>
+
+// the handful of RCCL declarations this file needs (the library itself is bound with dlopen at kr_ep_init): no <rccl/rccl.h> at build time
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclHalf = 6,
+               ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8, ncclBfloat16 = 9 } ncclDataType_t;
+}
 
 #include "kr_engine_internal.h"
 #include "kr_prefill.h"
@@ -32,7 +53,10 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, int /* ncclRedOp_t: ncclSum = 0 */, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -48,8 +72,8 @@ int load_rccl() {
     if (!h) return kr_fail(KR_ERR_STATE, "RCCL not available: %s", dlerror());
 #define KR_SYM(field, name) do { *(void**)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) return kr_fail(KR_ERR_STATE, "librccl has no symbol %s", name); } while (0)
     KR_SYM(GetUniqueId, "ncclGetUniqueId"); KR_SYM(CommInitRank, "ncclCommInitRank"); KR_SYM(CommDestroy, "ncclCommDestroy");
-    KR_SYM(AllGather, "ncclAllGather"); KR_SYM(Send, "ncclSend"); KR_SYM(Recv, "ncclRecv"); KR_SYM(GroupStart, "ncclGroupStart");
-    KR_SYM(GroupEnd, "ncclGroupEnd"); KR_SYM(GetErrorString, "ncclGetErrorString");
+    KR_SYM(AllGather, "ncclAllGather"); KR_SYM(AllReduce, "ncclAllReduce"); KR_SYM(Send, "ncclSend"); KR_SYM(Recv, "ncclRecv"); KR_SYM(GroupStart, "ncclGroupStart");
+    KR_SYM(GroupEnd, "ncclGroupEnd"); KR_SYM(GetErrorString, "ncclGetErrorString"); KR_SYM(CommAbort, "ncclCommAbort"); KR_SYM(CommCount, "ncclCommCount");
 #undef KR_SYM
     g_rccl.h = h;
     return KR_OK;
@@ -57,13 +81,118 @@ int load_rccl() {
 #define KR_NCCL(call) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) return kr_fail(KR_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(r__)); } while (0)
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// loopback group: W virtual ranks in one process (one host thread each)
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct kr_ep_loop_group {
+    int world = 0;
+    std::mutex mu; std::condition_variable cv; int arrived = 0; long gen = 0; bool failed = false;
+    struct Slot { const void* const* send = nullptr; const size_t* off = nullptr; const void* buf = nullptr; hipEvent_t ready = nullptr; };
+    Slot slots[64];
+    // generation barrier over the W rank threads; false = a rank failed (everybody gives up instead of waiting)
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
+        const long g = gen;
+        if (++arrived == world) { arrived = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g || failed; });
+        return !failed;
+    }
+    void fail() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
+};
+
 struct kr_ep_state {
     int world = 1, rank = 0, E_total = 0, per = 0, ret_bf16 = 0, full = 0;   // full: the engine holds ALL experts of the model (a replica that can also decode): local id = global id
-    ncclComm_t comm = nullptr;
-    DevBuf dest, lid, i32, rows, row_lid, rrows, rlid, eo, eo16, back, ones, cnt_all, shared_out, neg_ids;
+    ncclComm_t comm = nullptr;           // RCCL transport
+    kr_ep_loop_group* loop = nullptr;    // loopback transport
+    bool broken = false;                 // a collective failed: every later call is refused
+    DevBuf dest, lid, i32, rows, row_lid, rrows, rlid, eo, eo16, back, ones, cnt_all, shared_out, neg_ids, red;
     int* cnt_host = nullptr;          // pinned [world * world]
     hipEvent_t ev = nullptr;
 };
+
+namespace {
+// after a failure past the first collective of a call the peers must not be left waiting: tear the communicator down
+int ep_abort(kr_ep_state* s, int rc) {
+    s->broken = true;
+    if (s->comm && g_rccl.CommAbort) { (void)g_rccl.CommAbort(s->comm); s->comm = nullptr; }
+    if (s->loop) s->loop->fail();
+    return rc;
+}
+
+// ---- transport primitive 1: every rank contributes `world` ints, every rank receives world x world (row r = rank r's contribution)
+int ep_gather_counts(kr_ep_state* s, const int* mine_dev, int* all_dev, hipStream_t st) {
+    const int W = s->world;
+    if (s->comm) { KR_NCCL(g_rccl.AllGather(mine_dev, all_dev, W, ncclInt32, s->comm, st)); return KR_OK; }
+    kr_ep_loop_group* g = s->loop;
+    g->slots[s->rank].buf = mine_dev;
+    KR_HIP(hipEventRecord(g->slots[s->rank].ready, st));
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");
+    for (int p = 0; p < W; p++) {
+        KR_HIP(hipStreamWaitEvent(st, g->slots[p].ready, 0));
+        KR_HIP(hipMemcpyAsync(all_dev + (size_t)p * W, g->slots[p].buf, (size_t)W * 4, hipMemcpyDeviceToDevice, st));
+    }
+    KR_HIP(hipStreamSynchronize(st));
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");     // every pull is done: the sources may be reused
+    return KR_OK;
+}
+
+// ---- transport primitive 2: personalised all-to-all of row blocks.  Buffer b holds rows of row_bytes[b] bytes; rows [soff[r], soff[r+1]) of the
+// send buffers go to rank r, rows [roff[r], roff[r+1]) of the receive buffers come from rank r (soff / roff in rows, shared by the n buffers).
+int ep_exchange(kr_ep_state* s, int nbuf, const void* const* send, void* const* recv, const size_t* row_bytes, const size_t* soff, const size_t* roff, hipStream_t st) {
+    const int W = s->world;
+    if (s->comm) {
+        KR_NCCL(g_rccl.GroupStart());
+        for (int r = 0; r < W; r++) {
+            const size_t sc = soff[r + 1] - soff[r], rc = roff[r + 1] - roff[r];
+            for (int b = 0; b < nbuf; b++) {
+                if (sc) KR_NCCL(g_rccl.Send((const char*)send[b] + soff[r] * row_bytes[b], sc * row_bytes[b], ncclInt8, r, s->comm, st));
+                if (rc) KR_NCCL(g_rccl.Recv((char*)recv[b] + roff[r] * row_bytes[b], rc * row_bytes[b], ncclInt8, r, s->comm, st));
+            }
+        }
+        KR_NCCL(g_rccl.GroupEnd());
+        return KR_OK;
+    }
+    kr_ep_loop_group* g = s->loop;
+    g->slots[s->rank].send = send; g->slots[s->rank].off = soff;
+    KR_HIP(hipEventRecord(g->slots[s->rank].ready, st));
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");
+    for (int p = 0; p < W; p++) {
+        const size_t* po = g->slots[p].off;
+        const size_t n = po[s->rank + 1] - po[s->rank];
+        if (n != roff[p + 1] - roff[p]) return kr_fail(KR_ERR_STATE, "loopback exchange: rank %d sends %zu rows to rank %d, which expects %zu", p, n, s->rank, roff[p + 1] - roff[p]);
+        if (!n) continue;
+        KR_HIP(hipStreamWaitEvent(st, g->slots[p].ready, 0));
+        for (int b = 0; b < nbuf; b++)
+            KR_HIP(hipMemcpyAsync((char*)recv[b] + roff[p] * row_bytes[b], (const char*)g->slots[p].send[b] + po[s->rank] * row_bytes[b], n * row_bytes[b], hipMemcpyDeviceToDevice, st));
+    }
+    KR_HIP(hipStreamSynchronize(st));
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");
+    return KR_OK;
+}
+
+// ---- transport primitive 3: in-place sum of n f32 over the ranks, in rank order (decode: every element is non-zero on exactly one rank, so the
+// order does not matter there -- the sum is exact)
+int ep_allreduce_f32(kr_engine* e, float* buf, size_t n, hipStream_t st) {
+    kr_ep_state* s = e->ep;
+    const int W = s->world;
+    if (W == 1) return KR_OK;
+    if (s->comm) { KR_NCCL(g_rccl.AllReduce(buf, buf, n, ncclFloat32, 0, s->comm, st)); return KR_OK; }
+    kr_ep_loop_group* g = s->loop;
+    if (s->red.ensure((size_t)W * n * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the all-reduce staging failed");
+    g->slots[s->rank].buf = buf;
+    KR_HIP(hipEventRecord(g->slots[s->rank].ready, st));
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");
+    for (int p = 0; p < W; p++) {
+        KR_HIP(hipStreamWaitEvent(st, g->slots[p].ready, 0));
+        KR_HIP(hipMemcpyAsync((float*)s->red.p + (size_t)p * n, g->slots[p].buf, n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    KR_HIP(hipStreamSynchronize(st));
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");     // all pulls done before anybody overwrites its buffer
+    kr_launch_ep_sum_f32((const float*)s->red.p, W, n, buf, st);
+    return KR_OK;
+}
+}  // namespace
 
 extern "C" int kr_ep_unique_id(void* id_out128) {
     if (!id_out128) return kr_fail(KR_ERR_VALUE, "null argument");
@@ -74,10 +203,7 @@ extern "C" int kr_ep_unique_id(void* id_out128) {
     return KR_OK;
 }
 
-// world ranks, this process is `rank`; the engine holds the experts of its slice as local experts 0 .. n_local-1 (cfg.n_routed_experts = n_local);
-// n_experts_total = experts of the whole model.  id128 = kr_ep_unique_id of rank 0, carried to the other ranks by the host's own bootstrap
-// (world == 1: may be NULL, no communicator is created).  return_bf16 != 0: expert rows come back as bf16 instead of f32.
-extern "C" int kr_ep_init(kr_engine* e, int world, int rank, int n_experts_total, const void* id128, int return_bf16) {
+static int ep_init_common(kr_engine* e, int world, int rank, int n_experts_total, int return_bf16, std::unique_ptr<kr_ep_state>& s) {
     if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
     if (world < 1 || world > 64 || rank < 0 || rank >= world) return kr_fail(KR_ERR_VALUE, "bad world / rank (%d / %d; at most 64 ranks)", world, rank);
     if (n_experts_total < world) return kr_fail(KR_ERR_VALUE, "%d experts cannot be split over %d ranks", n_experts_total, world);
@@ -86,19 +212,61 @@ extern "C" int kr_ep_init(kr_engine* e, int world, int rank, int n_experts_total
         return kr_fail(KR_ERR_VALUE, "rank %d of %d owns %d of %d experts but the engine holds only %d", rank, world, n_local, n_experts_total, e->cfg.n_routed_experts);
     if (e->ep) return kr_fail(KR_ERR_STATE, "expert parallelism is already initialised");
     KR_HIP(hipSetDevice(e->device));
-    std::unique_ptr<kr_ep_state> s(new kr_ep_state);
+    s.reset(new kr_ep_state);
     s->world = world; s->rank = rank; s->E_total = n_experts_total; s->per = per; s->ret_bf16 = return_bf16 != 0;
     s->full = e->cfg.n_routed_experts >= n_experts_total && world > 0 ? 1 : 0;
+    return KR_OK;
+}
+static int ep_init_finish(kr_engine* e, std::unique_ptr<kr_ep_state>& s) {
+    KR_HIP(hipHostMalloc((void**)&s->cnt_host, sizeof(int) * s->world * s->world, hipHostMallocDefault));
+    KR_HIP(hipEventCreateWithFlags(&s->ev, hipEventDisableTiming));
+    e->ep = s.release();
+    return KR_OK;
+}
+
+// world ranks, this process is `rank`; the engine holds the experts of its slice as local experts 0 .. n_local-1 (cfg.n_routed_experts = n_local);
+// n_experts_total = experts of the whole model.  id128 = kr_ep_unique_id of rank 0, carried to the other ranks by the host's own bootstrap
+// (world == 1: may be NULL, no communicator is created).  return_bf16 != 0: expert rows come back as bf16 instead of f32.
+extern "C" int kr_ep_init(kr_engine* e, int world, int rank, int n_experts_total, const void* id128, int return_bf16) {
+    std::unique_ptr<kr_ep_state> s;
+    if (int rc = ep_init_common(e, world, rank, n_experts_total, return_bf16, s)) return rc;
     if (world > 1) {
         if (!id128) return kr_fail(KR_ERR_VALUE, "kr_ep_init needs the unique id of rank 0 when world > 1");
         if (int rc = load_rccl()) return rc;
         ncclUniqueId id; memcpy(&id, id128, sizeof id);
         KR_NCCL(g_rccl.CommInitRank(&s->comm, world, id, rank));
     }
-    KR_HIP(hipHostMalloc((void**)&s->cnt_host, sizeof(int) * world * world, hipHostMallocDefault));
-    KR_HIP(hipEventCreateWithFlags(&s->ev, hipEventDisableTiming));
-    e->ep = s.release();
+    return ep_init_finish(e, s);
+}
+
+// ranks the communicator of this engine spans, as RCCL counts them (ncclCommCount); 1 without a communicator, the group size under loopback
+extern "C" int kr_ep_comm_ranks(kr_engine* e, int* n_out) {
+    if (!e || !e->ep || !n_out) return kr_fail(KR_ERR_VALUE, "kr_ep_comm_ranks: no expert-parallel state");
+    *n_out = e->ep->loop ? e->ep->loop->world : 1;
+    if (e->ep->comm) KR_NCCL(g_rccl.CommCount(e->ep->comm, n_out));
     return KR_OK;
+}
+
+// ---- loopback transport: W engines of this process (usually on one device), one host thread per rank while a collective call is in flight
+extern "C" int kr_ep_loopback_create(int world, kr_ep_loop_group** out) {
+    if (!out || world < 1 || world > 64) return kr_fail(KR_ERR_VALUE, "kr_ep_loopback_create: world %d out of range [1, 64]", world);
+    std::unique_ptr<kr_ep_loop_group> g(new kr_ep_loop_group);
+    g->world = world;
+    for (int r = 0; r < world; r++) KR_HIP(hipEventCreateWithFlags(&g->slots[r].ready, hipEventDisableTiming));
+    *out = g.release();
+    return KR_OK;
+}
+extern "C" void kr_ep_loopback_destroy(kr_ep_loop_group* g) {
+    if (!g) return;
+    for (int r = 0; r < g->world; r++) if (g->slots[r].ready) (void)hipEventDestroy(g->slots[r].ready);
+    delete g;
+}
+extern "C" int kr_ep_init_loopback(kr_engine* e, kr_ep_loop_group* group, int rank, int n_experts_total, int return_bf16) {
+    if (!group) return kr_fail(KR_ERR_VALUE, "null loopback group");
+    std::unique_ptr<kr_ep_state> s;
+    if (int rc = ep_init_common(e, group->world, rank, n_experts_total, return_bf16, s)) return rc;
+    s->loop = group;
+    return ep_init_finish(e, s);
 }
 
 extern "C" int kr_ep_destroy(kr_engine* e) {
@@ -107,109 +275,127 @@ extern "C" int kr_ep_destroy(kr_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     if (s->comm) (void)g_rccl.CommDestroy(s->comm);
-    for (DevBuf* b : {&s->dest, &s->lid, &s->i32, &s->rows, &s->row_lid, &s->rrows, &s->rlid, &s->eo, &s->eo16, &s->back, &s->ones, &s->cnt_all, &s->shared_out, &s->neg_ids}) b->release();
+    for (DevBuf* b : {&s->dest, &s->lid, &s->i32, &s->rows, &s->row_lid, &s->rrows, &s->rlid, &s->eo, &s->eo16, &s->back, &s->ones, &s->cnt_all, &s->shared_out, &s->neg_ids, &s->red}) b->release();
     if (s->cnt_host) (void)hipHostFree(s->cnt_host);
     if (s->ev) (void)hipEventDestroy(s->ev);
     delete s; e->ep = nullptr;
     return KR_OK;
 }
 
+// every rank passes a value; max over the ranks comes back (a collective: all ranks must call).  Used by kr_decode_prefill to learn how many
+// chunks the longest prompt shard has, so that ranks with fewer chunks keep taking part in the exchanges with empty shards.
+extern "C" int kr_ep_max_int(kr_engine* e, int value, int* max_out, void* stream) {
+    if (!e || !e->ep || !max_out) return kr_fail(KR_ERR_VALUE, "kr_ep_max_int: no expert-parallel state");
+    kr_ep_state* s = e->ep;
+    *max_out = value;
+    if (s->world == 1) return KR_OK;
+    if (s->broken) return kr_fail(KR_ERR_STATE, "expert parallelism: an earlier collective failed");
+    KR_HIP(hipSetDevice(e->device));
+    hipStream_t st = kr_pick_stream(e, stream);
+    const int W = s->world;
+    if (s->i32.ensure((size_t)W * 4) || s->cnt_all.ensure((size_t)W * W * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    for (int r = 0; r < W; r++) s->cnt_host[r] = value;
+    KR_HIP(hipMemcpyAsync(s->i32.p, s->cnt_host, (size_t)W * 4, hipMemcpyHostToDevice, st));
+    if (int rc = ep_gather_counts(s, (const int*)s->i32.p, (int*)s->cnt_all.p, st)) return ep_abort(s, rc);
+    KR_HIP(hipMemcpyAsync(s->cnt_host, s->cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st));
+    KR_HIP(hipStreamSynchronize(st));
+    for (int r = 0; r < W; r++) if (s->cnt_host[r * W] > *max_out) *max_out = s->cnt_host[r * W];
+    return KR_OK;
+}
+
 // x bf16 [M, H] (this rank's token shard), ids i32 [M, topk] GLOBAL expert ids (-1 = skip), w f32 [M, topk]; out bf16 / f32 [M, H] =
 // the single-GPU kr_moe_prefill result of the same tokens.  routed_only == 0 adds rsf * routed + shared with this rank's shared expert.
+// M == 0 (an empty shard; pointers may be NULL) takes part in the exchanges with empty blocks and computes the rows its peers send.
+// A collective call: every rank of the group calls with the same layer, in the same order.
 extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk, int out_dtype,
                                  int routed_only, void* stream) {
     if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
     if (!e->ep) return kr_fail(KR_ERR_STATE, "call kr_ep_init first");
-    if (layer < 0 || layer >= (int)e->layers.size()) return kr_fail(KR_ERR_VALUE, "moe_layer_idx %d out of range", layer);
-    if (!x_bf16 || !ids || !wts || !out || M <= 0) return kr_fail(KR_ERR_VALUE, "bad arguments");
-    if (topk <= 0 || topk > KR_MAX_TOPK) return kr_fail(KR_ERR_VALUE, "topk %d exceeds MAX_TOPK %d", topk, KR_MAX_TOPK);
-    if (!is_device_ptr(x_bf16) || !is_device_ptr(ids) || !is_device_ptr(wts) || !is_device_ptr(out)) return kr_fail(KR_ERR_VALUE, "kr_moe_prefill_ep expects device pointers");
     kr_ep_state* s = e->ep;
+    if (s->broken) return kr_fail(KR_ERR_STATE, "expert parallelism: an earlier collective failed");
+    // ---- everything that can fail for a local reason is checked BEFORE the first collective (a rank that bails out later would strand its peers)
+    if (layer < 0 || layer >= (int)e->layers.size()) return kr_fail(KR_ERR_VALUE, "moe_layer_idx %d out of range", layer);
+    if (M < 0 || (M > 0 && (!x_bf16 || !ids || !wts || !out))) return kr_fail(KR_ERR_VALUE, "bad arguments");
+    if (topk <= 0 || topk > KR_MAX_TOPK) return kr_fail(KR_ERR_VALUE, "topk %d exceeds MAX_TOPK %d", topk, KR_MAX_TOPK);
+    if (M > 0 && (!is_device_ptr(x_bf16) || !is_device_ptr(ids) || !is_device_ptr(wts) || !is_device_ptr(out))) return kr_fail(KR_ERR_VALUE, "kr_moe_prefill_ep expects device pointers");
     Layer& L = e->layers[layer];
     KR_HIP(hipSetDevice(e->device));
     hipStream_t st = kr_pick_stream(e, stream);
     const int H = e->cfg.hidden_size, W = s->world, np = M * topk;
-    const bool use_shared = !routed_only && (L.shared_present || L.gguf_shared);
+    const bool use_shared = M > 0 && !routed_only && (L.shared_present || L.gguf_shared);
     // ---- owner sort: destination rank of every pair, rows grouped by destination (the prompt-pass sort with "experts" = ranks)
     const int max_tiles = np / 64 + W + 1;
     const size_t n_i32 = 3 * (size_t)W + 3 * (size_t)max_tiles + 4 + 2 * (size_t)np;
-    if (s->dest.ensure((size_t)np * 4) || s->lid.ensure((size_t)np * 4) || s->i32.ensure(n_i32 * 4) || s->rows.ensure((size_t)np * H * 2) || s->row_lid.ensure((size_t)np * 4) ||
-        s->cnt_all.ensure((size_t)W * W * 4))
+    const size_t np1 = np ? (size_t)np : 1;
+    if (s->dest.ensure(np1 * 4) || s->lid.ensure(np1 * 4) || s->i32.ensure(n_i32 * 4) || s->rows.ensure(np1 * H * 2) || s->row_lid.ensure(np1 * 4) ||
+        s->cnt_all.ensure((size_t)W * W * 4) || (use_shared && (s->shared_out.ensure((size_t)M * H * 4) || s->neg_ids.ensure((size_t)M * 4))))
         return kr_fail(KR_ERR_HIP, "hipMalloc of the expert-parallel scratch failed");
     int* ib = (int*)s->i32.p;
     KrPfSort so{};
     so.counts = ib; so.offsets = ib + W; so.cursor = ib + 2 * W; ib += 3 * W;
     so.tile_expert = ib; so.tile_row0 = ib + max_tiles; so.tile_rows = ib + 2 * max_tiles; ib += 3 * max_tiles;
     so.n_tiles = ib; ib += 4; so.row_pair = ib; so.pair_row = ib + np;
-    kr_launch_ep_dest(ids, np, s->E_total, s->per, W, s->full, (int32_t*)s->dest.p, (int32_t*)s->lid.p, st);
-    kr_launch_ep_sort((const int32_t*)s->dest.p, np, W, so, st);
-    kr_launch_ep_gather((const uint16_t*)x_bf16, so.row_pair, (const int32_t*)s->lid.p, topk, H, so.n_tiles + 1, np, (uint16_t*)s->rows.p, (int32_t*)s->row_lid.p, st);
+    if (np) {
+        kr_launch_ep_dest(ids, np, s->E_total, s->per, W, s->full, (int32_t*)s->dest.p, (int32_t*)s->lid.p, st);
+        kr_launch_ep_sort((const int32_t*)s->dest.p, np, W, so, st);
+        kr_launch_ep_gather((const uint16_t*)x_bf16, so.row_pair, (const int32_t*)s->lid.p, topk, H, so.n_tiles + 1, np, (uint16_t*)s->rows.p, (int32_t*)s->row_lid.p, st);
+    } else KR_HIP(hipMemsetAsync(so.counts, 0, (size_t)W * 4, st));
     // ---- send counts of every rank: cnt[src][dst]
     // The host needs the split sizes to post the sends / receives: one small DtoH and an event wait per call.  A world of one posts nothing:
     // it takes every pair slot as a row (rows past the last routed pair carry local id -1 and belong to no expert tile) and never waits.
     std::vector<size_t> soff(W + 1, 0), roff(W + 1, 0);
     if (W > 1) {
-        KR_NCCL(g_rccl.AllGather(so.counts, s->cnt_all.p, W, ncclInt32, s->comm, st));
-        KR_HIP(hipMemcpyAsync(s->cnt_host, s->cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st));
-        KR_HIP(hipEventRecord(s->ev, st));
-        KR_HIP(hipEventSynchronize(s->ev));
+        if (int rc = ep_gather_counts(s, so.counts, (int*)s->cnt_all.p, st)) return ep_abort(s, rc);
+        if (hipMemcpyAsync(s->cnt_host, s->cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(s->ev, st) != hipSuccess ||
+            hipEventSynchronize(s->ev) != hipSuccess)
+            return ep_abort(s, kr_fail(KR_ERR_HIP, "expert parallelism: reading the split sizes failed"));
         for (int r = 0; r < W; r++) { soff[r + 1] = soff[r] + (size_t)s->cnt_host[s->rank * W + r]; roff[r + 1] = roff[r] + (size_t)s->cnt_host[r * W + s->rank]; }
     } else { soff[1] = roff[1] = (size_t)np; }
     const size_t n_send = soff[W], n_recv = roff[W];
+    // ---- buffers whose size depends on what the peers send: a failure here aborts the communicator (the peers are already inside the call)
+    {
+        const size_t nr1 = n_recv ? n_recv : 1, esz = s->ret_bf16 ? 2 : 4;
+        const size_t n_ones = n_recv > (size_t)M ? n_recv : (size_t)(M ? M : 1);
+        bool bad = s->eo.ensure(nr1 * (size_t)H * 4);
+        if (W > 1) bad = bad || s->rrows.ensure(nr1 * H * 2) || s->rlid.ensure(nr1 * 4) || s->back.ensure((n_send ? n_send : 1) * (size_t)H * esz);
+        if (!bad && s->ones.bytes < n_ones * 4) {
+            bad = s->ones.ensure(n_ones * 4 * 2);
+            if (!bad) bad = hipMemsetD32Async((hipDeviceptr_t)s->ones.p, 0x3F800000, s->ones.bytes / 4, st) != hipSuccess;      // f32 1.0
+        }
+        if (bad) return ep_abort(s, kr_fail(KR_ERR_HIP, "hipMalloc of the expert-parallel exchange buffers failed"));
+    }
     // ---- dispatch
     const uint16_t* rrows = (const uint16_t*)s->rows.p; const int32_t* rlid = (const int32_t*)s->row_lid.p;
     if (W > 1) {
-        if (s->rrows.ensure((n_recv ? n_recv : 1) * H * 2) || s->rlid.ensure((n_recv ? n_recv : 1) * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the receive buffers failed");
-        KR_NCCL(g_rccl.GroupStart());
-        for (int r = 0; r < W; r++) {
-            const size_t sc = soff[r + 1] - soff[r], rc = roff[r + 1] - roff[r];
-            if (sc) { KR_NCCL(g_rccl.Send((const uint16_t*)s->rows.p + soff[r] * H, sc * H, ncclBfloat16, r, s->comm, st));
-                      KR_NCCL(g_rccl.Send((const int32_t*)s->row_lid.p + soff[r], sc, ncclInt32, r, s->comm, st)); }
-            if (rc) { KR_NCCL(g_rccl.Recv((uint16_t*)s->rrows.p + roff[r] * H, rc * H, ncclBfloat16, r, s->comm, st));
-                      KR_NCCL(g_rccl.Recv((int32_t*)s->rlid.p + roff[r], rc, ncclInt32, r, s->comm, st)); }
-        }
-        KR_NCCL(g_rccl.GroupEnd());
+        const void* sb[2] = {s->rows.p, s->row_lid.p}; void* rb[2] = {s->rrows.p, s->rlid.p}; const size_t rbts[2] = {(size_t)H * 2, 4};
+        if (int rc = ep_exchange(s, 2, sb, rb, rbts, soff.data(), roff.data(), st)) return ep_abort(s, rc);
         rrows = (const uint16_t*)s->rrows.p; rlid = (const int32_t*)s->rlid.p;
     }
     // ---- experts on the received rows (top-1 rows, weight 1, f32)
-    const size_t n_ones = n_recv > (size_t)M ? n_recv : (size_t)M;
-    if (s->eo.ensure((n_recv ? n_recv : 1) * (size_t)H * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the expert row buffer failed");
-    if (s->ones.bytes < n_ones * 4) {
-        if (s->ones.ensure(n_ones * 4 * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
-        KR_HIP(hipMemsetD32Async((hipDeviceptr_t)s->ones.p, 0x3F800000, s->ones.bytes / 4, st));      // f32 1.0
-    }
     // the w2 GEMM writes every row at its place, in the dtype it travels back in (kr_moe_prefill_rows); native-GGUF layers take the generic
     // prompt-pass entry (combine with weight 1 = a copy) and a conversion pass
     const void* back = s->eo.p;
     if (n_recv) {
-        const int rc = kr_moe_prefill_rows(e, layer, rrows, rlid, s->eo.p, (int)n_recv, s->ret_bf16 ? 1 : 0, 0, st);
-        if (rc > 0) return rc;
+        int rc = kr_moe_prefill_rows(e, layer, rrows, rlid, s->eo.p, (int)n_recv, s->ret_bf16 ? 1 : 0, 0, st);
         if (rc < 0) {
-            if (int rc2 = kr_moe_prefill_set(e, layer, rrows, rlid, (const float*)s->ones.p, s->eo.p, (int)n_recv, 1, KR_OUT_F32, 1, 0, st)) return rc2;
-            if (s->ret_bf16) {
-                if (s->eo16.ensure(n_recv * (size_t)H * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
-                kr_launch_ep_rows_bf16((const float*)s->eo.p, (uint16_t*)s->eo16.p, n_recv * (size_t)H, st);
-                back = s->eo16.p;
+            rc = kr_moe_prefill_set(e, layer, rrows, rlid, (const float*)s->ones.p, s->eo.p, (int)n_recv, 1, KR_OUT_F32, 1, 0, st);
+            if (!rc && s->ret_bf16) {
+                if (s->eo16.ensure(n_recv * (size_t)H * 2)) rc = kr_fail(KR_ERR_HIP, "hipMalloc failed");
+                else { kr_launch_ep_rows_bf16((const float*)s->eo.p, (uint16_t*)s->eo16.p, n_recv * (size_t)H, st); back = s->eo16.p; }
             }
         }
+        if (rc > 0) return W > 1 ? ep_abort(s, rc) : rc;
     }
     if (W > 1) {
         const size_t esz = s->ret_bf16 ? 2 : 4;
-        if (s->back.ensure((n_send ? n_send : 1) * (size_t)H * esz)) return kr_fail(KR_ERR_HIP, "hipMalloc of the return buffer failed");
-        const ncclDataType_t dt = s->ret_bf16 ? ncclBfloat16 : ncclFloat32;
-        KR_NCCL(g_rccl.GroupStart());
-        for (int r = 0; r < W; r++) {
-            const size_t sc = roff[r + 1] - roff[r], rc = soff[r + 1] - soff[r];
-            if (sc) KR_NCCL(g_rccl.Send((const char*)back + roff[r] * H * esz, sc * H, dt, r, s->comm, st));
-            if (rc) KR_NCCL(g_rccl.Recv((char*)s->back.p + soff[r] * H * esz, rc * H, dt, r, s->comm, st));
-        }
-        KR_NCCL(g_rccl.GroupEnd());
+        const void* sb[1] = {back}; void* rb[1] = {s->back.p}; const size_t rbts[1] = {(size_t)H * esz};
+        if (int rc = ep_exchange(s, 1, sb, rb, rbts, roff.data(), soff.data(), st)) return ep_abort(s, rc);
         back = s->back.p;
     }
+    if (!M) { KR_HIP(hipGetLastError()); return KR_OK; }
     // ---- shared expert of this rank's tokens (replicated weights), then the combine in routing order
     const float* shared_eo = nullptr;
     if (use_shared) {   // one all-skipped slot per token: kr_moe_prefill then returns rsf * 0 + shared = the shared expert's rows
-        if (s->shared_out.ensure((size_t)M * H * 4) || s->neg_ids.ensure((size_t)M * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
         KR_HIP(hipMemsetAsync(s->neg_ids.p, 0xFF, (size_t)M * 4, st));
         if (int rc = kr_moe_prefill_set(e, layer, x_bf16, (const int32_t*)s->neg_ids.p, (const float*)s->ones.p, s->shared_out.p, M, 1, KR_OUT_F32, 0, 1, st)) return rc;
         shared_eo = (const float*)s->shared_out.p;
@@ -217,5 +403,15 @@ extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, co
     if (s->ret_bf16) kr_launch_pf_combine_bf16rows((const uint16_t*)back, so.pair_row, wts, M, topk, H, shared_eo, e->cfg.routed_scaling_factor, out, out_dtype == KR_OUT_BF16, st);
     else kr_launch_pf_combine((const float*)back, so.pair_row, wts, M, topk, H, shared_eo, e->cfg.routed_scaling_factor, out, out_dtype == KR_OUT_BF16, st);
     KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
+// in-place sum over the ranks of n f32 on the device (collective); the decode graph's expert-parallel step and tests use it
+extern "C" int kr_ep_allreduce_f32(kr_engine* e, float* buf_dev, size_t n, void* stream) {
+    if (!e || !e->ep) return kr_fail(KR_ERR_STATE, "call kr_ep_init first");
+    if (e->ep->broken) return kr_fail(KR_ERR_STATE, "expert parallelism: an earlier collective failed");
+    KR_HIP(hipSetDevice(e->device));
+    hipStream_t st = kr_pick_stream(e, stream);
+    if (int rc = ep_allreduce_f32(e, buf_dev, n, st)) return ep_abort(e->ep, rc);
     return KR_OK;
 }

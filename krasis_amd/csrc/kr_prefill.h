@@ -39,6 +39,7 @@ void kr_launch_ep_dest(const int32_t* ids, int n, int E_total, int per, int worl
 void kr_launch_ep_gather(const uint16_t* x, const int* row_pair, const int32_t* lid, int topk, int H, const int* n_rows, int max_rows, uint16_t* rows, int32_t* row_lid,
                          hipStream_t st);
 void kr_launch_ep_rows_bf16(const float* in, uint16_t* out, size_t n, hipStream_t st);
+void kr_launch_ep_sum_f32(const float* parts, int W, size_t n, float* out, hipStream_t st);
 
 // FAST (tolerance) form, kr_prefill_h.hip: f16 rows with a power-of-two row multiplier x weights de-quantized in registers, f32 accumulation
 void kr_launch_pfh_rows_f32(const float* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st);

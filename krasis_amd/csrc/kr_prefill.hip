@@ -398,6 +398,18 @@ void kr_launch_ep_gather(const uint16_t* x, const int* row_pair, const int32_t* 
     if (max_rows <= 0) return;
     hipLaunchKernelGGL(kr_ep_gather_kernel, dim3(max_rows), dim3(H / 8 < 256 ? H / 8 : 256), 0, st, x, row_pair, lid, topk, H, n_rows, rows, row_lid);
 }
+// out[i] = parts[0][i] + parts[1][i] + ... in rank order (the loopback transport's all-reduce; RCCL does its own)
+__global__ void kr_ep_sum_f32_kernel(const float* __restrict__ parts, int W, size_t n, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float a = parts[i];
+        for (int r = 1; r < W; r++) a += parts[(size_t)r * n + i];
+        out[i] = a;
+    }
+}
+void kr_launch_ep_sum_f32(const float* parts, int W, size_t n, float* out, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(kr_ep_sum_f32_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st, parts, W, n, out);
+}
 void kr_launch_ep_rows_bf16(const float* in, uint16_t* out, size_t n, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(kr_ep_rows_bf16_kernel, dim3(2048), dim3(256), 0, st, in, out, n);

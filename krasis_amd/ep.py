@@ -118,11 +118,16 @@ class ExpertParallel:
     `ExpertParallelMoE` above is the same dataflow written against torch.distributed collectives; it exists so the sharding / ownership /
     combine logic can be exercised on CPU with gloo."""
 
-    def __init__(self, engine, num_experts_total: int, world: int = 1, rank: int = 0, dist_module=None, return_bf16: bool = True, group=None):
+    def __init__(self, engine, num_experts_total: int, world: int = 1, rank: int = 0, dist_module=None, return_bf16: bool = True, group=None, loopback=None):
+        """loopback: a LoopbackGroup -- this engine becomes virtual rank `rank` of an in-process group (kr_ep_init_loopback) instead of an RCCL rank"""
         import ctypes as C
         from ._lib import check
         self.engine, self.world, self.rank = engine, world, rank
         lib = engine._lib
+        if loopback is not None:
+            self.world = loopback.world
+            check(lib.kr_ep_init_loopback(engine._h, loopback._h, rank, num_experts_total, int(return_bf16)))
+            return
         idbuf = (C.c_char * 128)()
         if world > 1:
             if dist_module is None:
@@ -149,12 +154,59 @@ class ExpertParallel:
                                                  int(routed_only), st))
         return out
 
+    def comm_ranks(self) -> int:
+        """ranks of the communicator as RCCL counts them (ncclCommCount); the group size under loopback; 1 without a communicator"""
+        import ctypes as C
+        from ._lib import check
+        n = C.c_int(0)
+        check(self.engine._lib.kr_ep_comm_ranks(self.engine._h, C.byref(n)))
+        return int(n.value)
+
     def synchronize(self) -> None:
         self.engine.synchronize()
 
     def close(self) -> None:
         from ._lib import check
         check(self.engine._lib.kr_ep_destroy(self.engine._h))
+
+
+class LoopbackGroup:
+    """W virtual ranks inside one process (csrc/kr_ep.cpp, loopback transport): the exchanges of kr_moe_prefill_ep become device-to-device copies
+    between the W engines' buffers.  Every rank must be driven by its own host thread while a collective call is in flight (`run`).  Test /
+    bring-up aid: it executes the same split-size / offset / scatter code as the RCCL transport on a single-GPU box."""
+
+    def __init__(self, world: int):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load_library(); self.world = world
+        h = C.c_void_p()
+        _lib.check(self._lib.kr_ep_loopback_create(world, C.byref(h)))
+        self._h = h
+
+    def run(self, fns):
+        """run one callable per rank concurrently (ctypes releases the GIL inside the library); re-raises the first exception"""
+        import threading
+        assert len(fns) == self.world
+        res, err = [None] * self.world, [None] * self.world
+
+        def go(i):
+            try:
+                res[i] = fns[i]()
+            except BaseException as ex:   # noqa: BLE001 -- reported to the caller below
+                err[i] = ex
+        th = [threading.Thread(target=go, args=(i,)) for i in range(self.world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for ex in err:
+            if ex is not None:
+                raise ex
+        return res
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.kr_ep_loopback_destroy(self._h); self._h = None
 
 
 def engine_row_ops(engine) -> Tuple[RowOps, Callable]:

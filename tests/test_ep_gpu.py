@@ -88,3 +88,111 @@ def test_prompt_pass_through_the_ep_exchange_is_bit_identical():
     assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
     assert outs[0][1] == outs[1][1]
     assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32))
+
+
+def _slice_bounds(E, W, r):
+    per = E // W
+    return r * per, (E if r == W - 1 else (r + 1) * per)
+
+
+@pytest.mark.parametrize("W,Ms,ret_bf16,shared", [(2, [40, 25], False, False), (3, [33, 0, 70], False, True), (8, [9, 17, 1, 64, 0, 30, 5, 130], False, False),
+                                                  (3, [64, 64, 10], True, True), (2, [0, 50], False, False)])
+def test_library_expert_parallel_loopback_equals_single_engine(W, Ms, ret_bf16, shared):
+    """kr_moe_prefill_ep at WORLD SIZE > 1 on one GPU: W engines of this process, each holding its contiguous expert slice (gpu_prefill.py:353-359; the
+    last rank takes the remainder: E = 11 over 3 ranks = 3 + 3 + 5), exchange through the loopback transport of csrc/kr_ep.cpp -- the same split-size
+    exchange, per-peer offsets and receive-side scatter the RCCL transport runs.  Every rank's output must equal the single-engine operator on its
+    token shard BIT FOR BIT (f32 return rows), including a rank with an EMPTY shard (M = 0: it still serves its peers' rows)."""
+    import torch
+    from krasis_amd import KrasisEngine, ModelConfig, _lib
+    from krasis_amd._lib import check
+    from krasis_amd.ep import ExpertParallel, LoopbackGroup
+    H, I, E, k = 256, 128, 11, 3
+    rng = np.random.default_rng(100 * W + sum(Ms))
+    experts = make_experts(rng, E, H, I)
+    sh = make_experts(rng, 1, H, I)[0] if shared else None
+    full = KrasisEngine(); full.configure(ModelConfig(H, I, E, k, 1, 1 if shared else 0, 2.0)); upload(full, 0, experts, sh)
+    engs, eps, ins, outs, refs = [], [], [], [], []
+    grp = LoopbackGroup(W)
+    for r in range(W):
+        lo, hi = _slice_bounds(E, W, r)
+        e = KrasisEngine(); e.configure(ModelConfig(H, I, hi - lo, k, 1, 1 if shared else 0, 2.0)); upload(e, 0, experts[lo:hi], sh)
+        engs.append(e); eps.append(ExpertParallel(e, E, rank=r, loopback=grp, return_bf16=ret_bf16))
+        M = Ms[r]
+        x = rand_bf16(rng, (max(M, 1), H)); ids = np.stack([rng.choice(E, k, replace=False) for _ in range(max(M, 1))]).astype(np.int32); w = rng.random((max(M, 1), k)).astype(np.float32)
+        if M > 3:
+            ids[1, 2] = -1; ids[3, :] = -1
+        xt = torch.from_numpy(x.view(np.int16)).cuda().view(torch.bfloat16)[:M]; it = torch.from_numpy(ids).cuda()[:M]; wt = torch.from_numpy(w).cuda()[:M]
+        ins.append((xt, it, wt)); outs.append(torch.zeros((M, H), dtype=torch.float32, device="cuda"))
+        ref = torch.zeros((M, H), dtype=torch.float32, device="cuda")
+        if M:
+            check(full._lib.kr_moe_forward(full._h, 0, xt.data_ptr(), it.data_ptr(), wt.data_ptr(), ref.data_ptr(), M, k, _lib.KR_OUT_F32, int(not shared), 1))
+        refs.append(ref)
+    torch.cuda.synchronize(); full.synchronize()
+    assert eps[0].comm_ranks() == W
+
+    def call(r):
+        xt, it, wt = ins[r]
+        M = Ms[r]
+        check(engs[r]._lib.kr_moe_prefill_ep(engs[r]._h, 0, xt.data_ptr() if M else None, it.data_ptr() if M else None, wt.data_ptr() if M else None,
+                                             outs[r].data_ptr() if M else None, M, k, _lib.KR_OUT_F32, int(not shared), None))
+        engs[r].synchronize()
+    for rep in range(2):           # twice: buffers are reused, the second call runs without any allocation
+        grp.run([lambda r=r: call(r) for r in range(W)])
+    torch.cuda.synchronize()
+    for r in range(W):
+        if not Ms[r]:
+            continue
+        if not ret_bf16:
+            assert torch.equal(outs[r].view(torch.int32), refs[r].view(torch.int32)), r
+        else:
+            assert (outs[r] - refs[r]).abs().max().item() <= 2 ** -7 * refs[r].abs().max().item(), r
+    for ep in eps:
+        ep.close()
+    grp.close()
+
+
+@pytest.mark.parametrize("W,lens", [(2, [70, 70]), (3, [90, 20, 55])])
+def test_prompt_pass_on_expert_parallel_engines_equals_single_engine(W, lens):
+    """kr_decode_prefill on W expert-parallel replicas (every rank holds the whole model and serves its expert slice under the global ids), one
+    prompt shard per rank, loopback transport: logits, greedy token and the next decode step of every rank must equal the single-engine prompt
+    pass of the same prompt bit for bit.  Prompt shards of DIFFERENT lengths / chunk counts: the shorter ranks keep taking part with empty shards."""
+    from krasis_amd.ep import ExpertParallel, LoopbackGroup
+    from tests.test_decode_gpu import build
+    F = np.float32
+    grp = LoopbackGroup(W)
+    rng = np.random.default_rng(7)
+    stores, eps, toks, got = [], [], [], [None] * W
+    for r in range(W):
+        st, eng, orc, keep, d = build(seed=4, kv_max=128)
+        st.set_prefill_chunk(32)
+        stores.append((st, eng, keep, d)); eps.append(ExpertParallel(eng, 16, rank=r, loopback=grp, return_bf16=False))
+        toks.append([int(x) for x in rng.integers(0, d["V"], lens[r])])
+
+    def call(r):
+        st, eng, keep, d = stores[r]
+        lg = np.empty(d["V"], F); tok = st.prefill(toks[r], 3, lg.ctypes.data)
+        got[r] = (lg, tok)
+    grp.run([lambda r=r: call(r) for r in range(W)])
+    for r in range(W):
+        st, eng, orc, keep, d = build(seed=4, kv_max=128)
+        st.set_prefill_chunk(32)
+        lg = np.empty(d["V"], F); tok = st.prefill(toks[r], 3, lg.ctypes.data)
+        assert np.array_equal(lg.view(np.uint32), got[r][0].view(np.uint32)), r
+        assert tok == got[r][1]
+    for ep in eps:
+        ep.close()
+    grp.close()
+
+
+def test_bench_gpus_flag_fails_loudly_without_the_devices():
+    """`python bench.py --gpus N` spawns its N ranks itself; on a box with fewer devices it must refuse instead of reporting n_gpus: 1"""
+    import os
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0
+    assert "needs %d devices" % (n + 1) in (p.stderr + p.stdout)
