@@ -24,6 +24,7 @@
 // 62 % of the LDS bandwidth at full matrix rate (the exact kernel's 64 x 32 wave tile needs 112 %).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <type_traits>
 
 #include "kr_lds_optin.h"
@@ -284,7 +285,11 @@ __device__ __forceinline__ void pfh_store_tile(const ACC& acc, int nsb, int rows
     }
 }
 
-template <int NC, int BITS>
+// SB = 1: the de-quantized B fragments of a k-step are SINGLE-buffered -- fragment (c, h) of step t + 1 is formed right after the MFMAs of step t that
+// read fragment (c, h) have been issued, into the same registers (16 registers less than two fragment sets, 8 less for the raw INT4 words): the
+// 64 x 256 tile then fits the 256 registers of two waves per SIMD without scratch (the double-buffered form spilled 29 VGPRs, 11 of the reloads inside
+// the MFMA block).
+template <int NC, int BITS, int SB = 0>
 __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs a) {
     constexpr int BN = 128 * NC, LDA = PFH_LDA, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4, NS = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -368,31 +373,39 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     // (the 64 lanes of a wave copy one 1-KiB tile record row: scalar base + lane * 16).
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int last_tile = (m.N - 1) >> 3;
+    // Both operand streams are addressed through buffer descriptors: a wave-uniform base (the expert's weight block / the A matrix), ONE 32-bit
+    // lane offset and a scalar offset per request.  With flat 64-bit addresses the compiler keeps a register pair per request of the stage alive
+    // across the whole MFMA block (8 A + 8 B requests: ~32 registers) -- the difference between fitting the 256 registers of two waves per SIMD and
+    // spilling.  Record bases are scalars: the tile index of a request is wave-uniform.
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.a), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wq), 0, -1, 0x00020000);
+    const volatile uint32_t* rofs_v = rofs;       // volatile: the 8 row offsets are re-read from LDS every stage (hoisted into registers they end up in scratch)
+    uint32_t brec[RPT];                                              // byte offset of this wave's tile records inside the expert's block (scalars)
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+        int tile = (n0 >> 3) + wv + 4 * j; tile = tile < last_tile ? tile : last_tile;
+        brec[j] = (uint32_t)__builtin_amdgcn_readfirstlane(tile * (BITS == 8 ? m.ng : m.ngp) * 1024);
+    }
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     auto load_stage = [&](int st) {
 #pragma unroll
         for (int c = 0; c < NC; c++) pspv[c] = wsc[((size_t)ctile[c] * m.ngp + st) * 8 + cin[c]];
         {
             const int kvalid = K - st * PFH_KS;                  // 256, or 128 in the last stage of an odd group count: lines 2, 3 re-read lines 0, 1
-            const char* ab = reinterpret_cast<const char*>(a.a) + (size_t)st * (PFH_KS * 2) + (aseg * 64 < kvalid ? aseg : aseg - 2) * 128;
+            const uint32_t segoff = (uint32_t)((aseg * 64 < kvalid ? aseg : aseg - 2) * 128 + achk * 16);
 #pragma unroll
-            for (int j = 0; j < APT; j++) pa[j] = *reinterpret_cast<const u32x4*>(ab + achk * 16 + rofs[arow + 8 * j]);
+            for (int j = 0; j < APT; j++) pa[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, rofs_v[arow + 8 * j] + segoff, st * (PFH_KS * 2), 0);
         }
         if (BITS == 8) {
 #pragma unroll
             for (int gg = 0; gg < 2; gg++) {
                 int g = 2 * st + gg; g = g < m.ng ? g : m.ng - 1;
 #pragma unroll
-                for (int j = 0; j < RPT; j++) {
-                    int tile = (n0 >> 3) + wv + 4 * j; tile = tile < last_tile ? tile : last_tile;
-                    pbw[(BITS == 8 ? gg * RPT : 0) + j] = kr_ldg_nt(reinterpret_cast<const u32x4*>(wq + ((size_t)tile * m.ng + g) * 1024) + lane);
-                }
+                for (int j = 0; j < RPT; j++) pbw[(BITS == 8 ? gg * RPT : 0) + j] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, lane16, brec[j] + (uint32_t)g * 1024u, 2 /* nt */);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < RPT; j++) {
-                int tile = (n0 >> 3) + wv + 4 * j; tile = tile < last_tile ? tile : last_tile;
-                pbw[j] = kr_ldg_nt(reinterpret_cast<const u32x4*>(wq + ((size_t)tile * m.ngp + st) * 1024) + lane);
-            }
+            for (int j = 0; j < RPT; j++) pbw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, lane16, brec[j] + (uint32_t)st * 1024u, 2 /* nt */);
         }
     };
     uint32_t spv[NC];
@@ -444,7 +457,51 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
                 const _Float16 c1 = (_Float16)(-1536.0f * (float)s1);
                 cq[hh][c] = v2h{c1, c1};
             }
-        v8h af[2][NSA][2], bf[2][NC][2];
+        v8h af[2][NSA][2];
+        if constexpr (SB == 1) {
+            static_assert(BITS == 4, "single-buffered fragments: INT4 form");
+            v8h bf1[NC][2];
+            u32x2 br2[2][NC];
+            auto rd = [&](int t, int buf) {
+                const int hh = t >> 2, lp = 2 * (t & 3) + khalf;
+#pragma unroll
+                for (int s2 = 0; s2 < NSA; s2++) {
+                    af[buf][s2][0] = *reinterpret_cast<const v8h*>(As + (s2 * 32 + n31) * LDA + hh * 256 + lp * 32);
+                    af[buf][s2][1] = *reinterpret_cast<const v8h*>(As + (s2 * 32 + n31) * LDA + hh * 256 + lp * 32 + 16);
+                }
+#pragma unroll
+                for (int c = 0; c < NC; c++) br2[buf][c] = *reinterpret_cast<const u32x2*>(Bs + (cbase + c * 32 + n31) * LDB + lp * 16 + hh * 8);
+            };
+            auto dq1 = [&](int t, int buf, int c, int h) {
+                const int hh = t >> 2;
+                bf1[c][h] = pfh_dq4(h ? br2[buf][c].y : br2[buf][c].x, sq[hh][c], cq[hh][c], M0, M1, MH, Kc);
+            };
+            rd(0, 0); rd(1, 1);
+#pragma unroll
+            for (int c = 0; c < NC; c++) { dq1(0, 0, c, 0); dq1(0, 0, c, 1); }
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int cur = t & 1, nxt = cur ^ 1;
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+#pragma unroll
+                        for (int s2 = 0; s2 < NSA; s2++) acc[s2][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][s2][h], bf1[c][h], acc[s2][c], 0, 0, 0);
+                        if (t + 1 < 8) dq1(t + 1, nxt, c, h);
+                    }
+                if (t + 2 < 8) rd(t + 2, cur);
+                // issue order: the NSA MFMAs of a fragment, then the 12 VALU that rebuild it for the next step, ...; the LDS reads of step t + 2 last
+#pragma unroll
+                for (int i = 0; i < 2 * NC; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NSA, 0);     // NSA MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 13, 0);      // the fragment's de-quantization
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NSA + NC, 0);   // DS reads
+            }
+            return;
+        }
+        v8h bf[2][NC][2];
         u32x4 br[2][NC];          // raw B words of a step (INT4 uses .x .y)
         auto rd = [&](int t, int buf) {
             const int hh = t >> 2, lp = 2 * (t & 3) + khalf;             // lane record of this lane half: k = 16 lp .. 16 lp + 16 of group hh
@@ -506,7 +563,8 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
             PFH_STAMP(5);
         }
     };
-    if (two) main_loop(std::integral_constant<int, 2>{}); else main_loop(std::integral_constant<int, 1>{});
+    // SB form (big problems: nearly every tile is full): one copy of the loop -- the second copy's hoisted values were what pushed the kernel into scratch
+    if (SB || two) main_loop(std::integral_constant<int, 2>{}); else main_loop(std::integral_constant<int, 1>{});
     PFH_STAMPW(8);
     {
         const bool full = rows == (two ? 64 : 32) && n0 + BN <= m.N && !(a.scatter_rows && !a.single_expert);     // uniform
@@ -520,25 +578,29 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
 }
 
 
-template <int NC, int BITS>
+template <int NC, int BITS, int SB = 0>
 static void pfh_launch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     constexpr int BN = 128 * NC, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4;
     const size_t lds = (size_t)PFH_BM * PFH_LDA + (size_t)BN * LDB + 3 * PFH_BM * 4;
-    (void)kr_lds_optin((const void*)kr_pfh_gemm_kernel<NC, BITS>, 80 * 1024);
+    (void)kr_lds_optin((const void*)kr_pfh_gemm_kernel<NC, BITS, SB>, 80 * 1024);
     int ncb = (a.m.N + BN - 1) / BN;
     for (int i = 0; i < a.n_extra; i++) ncb += (a.mx[i].N + BN - 1) / BN;
     KrPfGemmHArgs b = a;
     dim3 grid;
     if (a.single_expert) { int n_super; kr_pf_super_tile(mt, ncb, &b.sr, &b.sc, &n_super); grid = dim3(((n_super + 7) / 8) * 8 * b.sr * b.sc); }
     else { const int span = 8 * a.run; grid = dim3(((mt + span - 1) / span) * span * ncb); }
-    hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS>), grid, dim3(256), lds, st, b);
+    hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS, SB>), grid, dim3(256), lds, st, b);
 }
 static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     if (a.m.bits == 8) { pfh_launch<1, 8>(a, mt, st); return; }
     // 256-column tiles when they still fill the chip (>= 2 workgroups per CU), else 128-column tiles
     long n128 = (a.m.N + 127) / 128;
     for (int i = 0; i < a.n_extra; i++) n128 += (a.mx[i].N + 127) / 128;
-    if ((long)mt * n128 >= 2048) pfh_launch<2, 4>(a, mt, st); else pfh_launch<1, 4>(a, mt, st);
+    // A/B hook (read once): KR_PFH_VARIANT=0 the round-2 form (two loop copies, double-buffered fragments: 29 VGPRs in scratch), 2 = one loop copy with
+    // double-buffered fragments, 1 (default) = one loop copy, single-buffered fragments
+    static const int variant = []() { const char* v = getenv("KR_PFH_VARIANT"); return v && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : 1; }();
+    if ((long)mt * n128 >= 2048) { if (variant == 0) pfh_launch<2, 4, 0>(a, mt, st); else if (variant == 2) pfh_launch<2, 4, 2>(a, mt, st); else pfh_launch<2, 4, 1>(a, mt, st); }
+    else pfh_launch<1, 4>(a, mt, st);
 }
 
 void kr_launch_pfh_rows_f32(const float* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st) {

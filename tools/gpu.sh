@@ -41,6 +41,21 @@ fast3)      # FAST tests + stamps + bench probe (no trace)
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -7
     timeout 600 python tools/probes/decode_fast_bench.py --only fast --route-tokens 200 "$@" 2>&1 | tail -14
     ;;
+ep)         # expert parallelism at world > 1 on one GPU (loopback transport) + bench --gpus refusal
+    timeout 900 python -m pytest tests/test_ep_gpu.py -x -q 2>&1 | tail -12
+    ;;
+gemmab)     # A/B of the 64 x 256 tolerance-GEMM variants (experts only), then the GEMM parity tests on the shipped default
+    for v in 0 1 2; do KR_PFH_VARIANT=$v timeout 300 python tools/probes/experts_gemm_probe.py 8 8192 fast 2>&1 | grep experts-only; done
+    timeout 300 python tools/probes/experts_gemm_probe.py 8 8192 exact,q4k 2>&1 | grep experts-only
+    timeout 900 python -m pytest tests/test_gemm_fast_gpu.py -x -q 2>&1 | tail -4
+    ;;
+gemmpmc)    # SQ counters of the shipped GEMM kernels (separate pass, counters only)
+    rm -rf $R/pmc_gemm
+    (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_WAVES -d $R/pmc_gemm --output-format csv -- \
+        python /root/repo/tools/probes/experts_gemm_probe.py 2 8192 exact,fast,q4k > $R/pmc_gemm.log 2>&1)
+    python tools/pmc_table.py $R/pmc_gemm $R/r03_gemm_pmc_sq.txt "Experts-only prompt-pass GEMMs, QCN shape, 8192 tokens, 2 layers: SQ counters per launch (rocprofv3 --pmc, counters-only pass)" gemm 2>&1 | tail -2
+    head -60 $R/r03_gemm_pmc_sq.txt
+    ;;
 stamps)
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     ;;
