@@ -202,6 +202,7 @@ typedef struct kr_decode_store kr_decode_store;
  * and binds the engine LAST (set_moe_store, decode.rs:2250; decode_setup.py:1010); the store then runs on the current HIP device until
  * kr_decode_set_moe_store hands it the engine that owns the routed experts and routers (same device). */
 int kr_decode_create(kr_engine* e, int group_size, int norm_bias_one, kr_decode_store** out);
+int kr_decode_create_on(int device_ordinal, int group_size, int norm_bias_one, kr_decode_store** out);   /* the same, bare engine on the NAMED device (multi-GPU hosts) */
 int kr_decode_set_moe_store(kr_decode_store* s, kr_engine* e);
 void kr_decode_destroy(kr_decode_store* s);
 /* store_weight_f32(ptr, rows, cols, bits) -> id (decode.rs:280): f32 [rows, cols] -> quantize_f32_to_transposed_int4/8
@@ -253,7 +254,8 @@ int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype);
 #define KR_ATTN_FAST 1
 #define KR_GEMM_FAST 2   /* or-ed into the mode: every GEMM of kr_decode_prefill (projections, shared expert, routed experts, lm_head of the scoring pass) in the tolerance form of kr_moe_set_gemm_mode; decode steps are unaffected */
 #define KR_DECODE_FAST 4 /* or-ed into the mode: decode steps run the tolerance-mode kernels of kr_decode_fast.hip -- the reference's products (INT16 activation digits, exact integer group sums, its sigmoid / libm functions), but every f32 reduction as a lane / wave / workgroup TREE instead of the reference's sequential chain, the norms folded into the launches that consume them, top-k + silu*up + the expert combine inside the expert launches (6 launches per linear-attention MoE layer).  Router ids are those of the exact kernels for identical logits (ties fall back to the reference's heap order); logits agree with the exact mode to the tolerance stated in tests/test_decode_fast_gpu.py.  Layers / geometries the kernels do not cover (MLA, dense MLP, GPT-OSS activation, E > 512, hidden > 4096) silently keep the exact kernels.  The prompt pass is unaffected. */
-int kr_decode_set_attention_mode(kr_decode_store* s, int mode);                                                                        /* decode.rs:2471 */
+int kr_decode_set_attention_mode(kr_decode_store* s, int mode);
+int kr_decode_set_option(kr_decode_store* s, const char* name, int value);   /* test / tuning hooks by name: "gqa_stream", "pfm_timing" (see kr_decode.cpp) */                                                                        /* decode.rs:2471 */
 /* Whole-model prompt pass.  Replaces the reference's GPU prefill (python/krasis/model.py forward_prefill_layer_grouped / server_prefill,
  * layer.py:242-461, attention.py:496-687, linear_attention.py:695-845 -- third-party kernels) AND the GPU->CPU state hand-off
  * (decode_setup.py:232-278): tokens[0..n) (host ints) at positions start_pos.. are run through every layer in chunks; afterwards the

@@ -449,7 +449,7 @@ int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st) {
     if (a.nh % a.nkv || G < 1 || G > FA_ROWS || (FA_ROWS % G) || (a.hd != 64 && a.hd != 128 && a.hd != 256)) return 1;
     const int TQ = FA_ROWS / G;
     dim3 grid((C + TQ - 1) / TQ, a.nkv);
-    if (a.hd >= 128 && !getenv("KR_FLASH4")) {      // eight waves, query tile in LDS, wave pairs split the positions of a tile (KR_FLASH4: A/B hook for the four-wave form)
+    if (a.hd >= 128) {      // eight waves, query tile in LDS, wave pairs split the positions of a tile (the four-wave form at these head sizes needed 512 registers + scratch: removed)
         const size_t l8 = (size_t)(FA_ROWS + FA_TK) * (a.hd * 2 + 16) + (size_t)a.hd * (FA_TK * 2 + 16);
         const size_t lm = (size_t)(4 * a.hd * 32 + 4 * 2 * 32) * 4;
         const size_t lds8 = l8 > lm ? l8 : lm;
@@ -462,18 +462,15 @@ int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st) {
 #undef KR_FA8
             return 0;
         }
+        return 1;           // LDS window refused: the caller takes the exact passes
     }
     const size_t lds = (size_t)FA_TK * (a.hd * 2 + 16) + (size_t)a.hd * (FA_TK * 2 + 16);
     {
-        const void* fn = a.hd == 256 ? (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash_kernel<256, true> : (const void*)kr_pfm_gqa_flash_kernel<256, false>)
-                       : a.hd == 128 ? (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash_kernel<128, true> : (const void*)kr_pfm_gqa_flash_kernel<128, false>)
-                                     : (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash_kernel<64, true> : (const void*)kr_pfm_gqa_flash_kernel<64, false>);
+        const void* fn = a.kv_fp8 ? (const void*)kr_pfm_gqa_flash_kernel<64, true> : (const void*)kr_pfm_gqa_flash_kernel<64, false>;
         if (kr_lds_optin(fn, 96 * 1024)) return 1;
     }
 #define KR_FA(H_, F_) hipLaunchKernelGGL((kr_pfm_gqa_flash_kernel<H_, F_>), grid, dim3(256), lds, st, a, C)
-    if (a.hd == 256) { if (a.kv_fp8) KR_FA(256, true); else KR_FA(256, false); }
-    else if (a.hd == 128) { if (a.kv_fp8) KR_FA(128, true); else KR_FA(128, false); }
-    else { if (a.kv_fp8) KR_FA(64, true); else KR_FA(64, false); }
+    if (a.kv_fp8) KR_FA(64, true); else KR_FA(64, false);      // head_dim 64: the four-wave form
 #undef KR_FA
     return 0;
 }

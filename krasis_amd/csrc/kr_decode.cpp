@@ -58,6 +58,16 @@ extern "C" int kr_decode_create(kr_engine* eng, int group_size, int norm_bias_on
     return KR_OK;
 }
 
+// the same with the device named explicitly (a store created before its engine on a box with several GPUs: ADVICE r2 -- the bare engine used to
+// land on whatever device the calling thread had current, and set_moe_store then refused the engine of the device the caller meant)
+extern "C" int kr_decode_create_on(int device_ordinal, int group_size, int norm_bias_one, kr_decode_store** out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); return kr_fail(KR_ERR_HIP, "no HIP device available: libkrasis_hip.so has no CPU fallback"); }
+    if (device_ordinal < 0 || device_ordinal >= ndev) return kr_fail(KR_ERR_VALUE, "device %d out of range (%d devices)", device_ordinal, ndev);
+    KR_HIP(hipSetDevice(device_ordinal));
+    return kr_decode_create(nullptr, group_size, norm_bias_one, out);
+}
+
 extern "C" void kr_decode_destroy(kr_decode_store* s) {
     if (!s) return;
     // the engine may already be gone (a garbage collector finalises an engine and its store in any order): only the store's own copy of the
@@ -601,6 +611,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             const bool o_img = img_ok && img_w(L.o_wid) && L.hd % 128 == 0 && s->weights[L.o_wid]->cols == L.nh * L.hd;
             a.img_out = o_img ? s->img_attn.p : nullptr;
             a.sc_g = s->kv_max_seq > s->gqa_split_min ? (float*)s->gqa_scores.p : nullptr;
+            a.force_stream = s->opt_gqa_stream;
             if (s->attn_fast && a.sc_g) { a.fd_o = (float*)s->fd_o.p; a.fd_ml = (float*)s->fd_ml.p; }
             PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
             if (o_img) out_proj(L.o_wid);
@@ -804,6 +815,16 @@ extern "C" int kr_decode_set_attention_mode(kr_decode_store* s, int mode) {
     if (mode < 0 || mode > 7) return kr_fail(KR_ERR_VALUE, "numerics mode %d unknown (bit 0 = KR_ATTN_FAST, bit 1 = KR_GEMM_FAST, bit 2 = KR_DECODE_FAST)", mode);
     s->attn_fast = mode & 1; s->gemm_fast = (mode >> 1) & 1; s->decode_fast = (mode >> 2) & 1; s->graph_ok = false;
     return KR_OK;
+}
+
+// test / tuning hooks by name (they used to be environment variables read on the launch path): "gqa_stream" = long-cache GQA decode attention streams
+// its score row from HBM even when it fits LDS; "pfm_timing" = kr_decode_prefill prints host-enqueue vs GPU-drain time to stderr
+extern "C" int kr_decode_set_option(kr_decode_store* s, const char* name, int value) {
+    if (int rc = chk_store(s)) return rc;
+    if (!name) return kr_fail(KR_ERR_VALUE, "null option name");
+    if (!strcmp(name, "gqa_stream")) { s->opt_gqa_stream = value != 0; s->graph_ok = false; return KR_OK; }
+    if (!strcmp(name, "pfm_timing")) { s->opt_pfm_timing = value != 0; return KR_OK; }
+    return kr_fail(KR_ERR_VALUE, "unknown option '%s'", name);
 }
 
 extern "C" int kr_decode_set_use_graph(kr_decode_store* s, int enable) {

@@ -1222,7 +1222,7 @@ void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s) {
     }
     if (a.sc_g) {      // long cache: scores over nh x max_seq / 256 workgroups (those past the current length leave at once), then softmax + p.v
         kr_launch_gqa_phase<1>(a, max_seq, dim3(a.nh, (max_seq + 255) / 256), 0, s);
-        const bool stream_hook = getenv("KR_GQA_STREAM") != nullptr;                   // (env: test hook)
+        const bool stream_hook = a.force_stream != 0;
         if (a.hd == 64 || a.hd == 128 || a.hd == 256) {
             const bool res = kr_gqa_pv_lds(max_seq, a.hd, a.kv_fp8) <= 160 * 1024 && !stream_hook;
             const int lds_seq = res ? max_seq : 4096;

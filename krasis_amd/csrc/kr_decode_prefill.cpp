@@ -394,7 +394,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     }
     KR_HIP(hipGetLastError());
     s->last_stream = st;
-    if (getenv("KR_PFM_TIMING")) {      // tuning aid: how long the host took to enqueue the pass vs how long the GPU needs to drain it
+    if (s->opt_pfm_timing) {      // tuning aid: how long the host took to enqueue the pass vs how long the GPU needs to drain it
         const double enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enqueue).count();
         (void)hipStreamSynchronize(st);
         const double tot = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enqueue).count();

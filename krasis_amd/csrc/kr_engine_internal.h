@@ -20,8 +20,14 @@ int kr_fail(int code, const char* fmt, ...);
         if (e__ != hipSuccess) return kr_fail(KR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
-struct DevBuf {
+struct DevBuf {     // owning device allocation: released by the destructor, so a new scratch member cannot be forgotten in a release list
     void* p = nullptr; size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
+    ~DevBuf() { release(); }
     int ensure(size_t n) {
         if (n <= bytes) return 0;
         if (p) (void)hipFree(p);

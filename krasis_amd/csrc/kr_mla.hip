@@ -671,7 +671,8 @@ static bool kr_launch_mla_staged(const KrMlaArgs& a, int max_seq, hipStream_t s,
     if (split && a.fast && kr_launch_mla_flash_decode(a, max_seq, s) == 0) return true;      // FAST: split-KV flash-decode on the f16 MFMA + merge
     if (split) {
         hipLaunchKernelGGL((kr_mla_scores_kernel<FP8, NBC, 8>), dim3((max_seq + KR_MLA_ROWS - 1) / KR_MLA_ROWS, (a.nh + KR_MLA_HG - 1) / KR_MLA_HG), dim3(512), lds_sc, s, a, max_seq);
-        if (a.fast && a.fd_o && a.fd_ml && a.nh <= 16) {     // tolerance mode: split-KV softmax + weighted sum over (chunk) workgroups, all heads share a latent row
+        // the merge launch has one thread per chunk (1024): longer caches keep the exact softmax + weighted sum (silently dropping the tail chunks was ADVICE r2)
+        if (a.fast && a.fd_o && a.fd_ml && a.nh <= 16 && (max_seq + KR_FD_CH - 1) / KR_FD_CH <= 1024) {     // tolerance mode: split-KV softmax + weighted sum over (chunk) workgroups, all heads share a latent row
             KrFdArgs f{};
             f.step = a.step; f.sc_g = a.sc_g; f.v_cache = a.ckv_cache; f.v_ld = a.klr; f.fd_o = a.fd_o; f.fd_ml = a.fd_ml; f.nh = a.nh; f.nkv = 1;
             f.gate = nullptr; f.gated = 0; f.out = a.attn_lat; f.img_out = nullptr;

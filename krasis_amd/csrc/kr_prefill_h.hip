@@ -596,10 +596,10 @@ static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     // 256-column tiles when they still fill the chip (>= 2 workgroups per CU), else 128-column tiles
     long n128 = (a.m.N + 127) / 128;
     for (int i = 0; i < a.n_extra; i++) n128 += (a.mx[i].N + 127) / 128;
-    // A/B hook (read once): KR_PFH_VARIANT=0 the round-2 form (two loop copies, double-buffered fragments: 29 VGPRs in scratch), 2 = one loop copy with
-    // double-buffered fragments, 1 (default) = one loop copy, single-buffered fragments
-    static const int variant = []() { const char* v = getenv("KR_PFH_VARIANT"); return v && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : 1; }();
-    if ((long)mt * n128 >= 2048) { if (variant == 0) pfh_launch<2, 4, 0>(a, mt, st); else if (variant == 2) pfh_launch<2, 4, 2>(a, mt, st); else pfh_launch<2, 4, 1>(a, mt, st); }
+    // the 64 x 256 form: ONE copy of the stage loop, single-buffered B fragments -- 220 VGPRs, no scratch.  Measured on MI355X (experts only, QCN shape,
+    // 8192 tokens, tools/probes/experts_gemm_probe.py): 1.65 ms per layer for the round-2 form (two loop copies, 29 VGPRs in scratch), 1.49 ms for
+    // this one, 1.48 ms with double-buffered fragments and one loop copy (223 VGPRs; not kept: same speed, fewer registers to spare)
+    if ((long)mt * n128 >= 2048) pfh_launch<2, 4, 1>(a, mt, st);
     else pfh_launch<1, 4>(a, mt, st);
 }
 

@@ -233,7 +233,7 @@ class CpuDecoder:
         self._attn_quant = attention_quant
         self._kv_fp8 = kv_fp8
         # norm_bias_one=False: the (1 + w) of qwen3_next is folded into the stored norm weights (decode_setup.py:45-49)
-        self._store = CpuDecodeStore(group_size=128, parallel=True, norm_bias_one=False)
+        self._store = CpuDecodeStore(group_size=128, parallel=True, norm_bias_one=False, device=device)
         self._decode_bits = decode_bits
         self._layers: List[dict] = []
         self._keep: list = []            # host arrays whose addresses were handed to the store

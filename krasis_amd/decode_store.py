@@ -17,7 +17,7 @@ from .engine import KrasisEngine, _addr
 
 
 class CpuDecodeStore:
-    def __init__(self, group_size: int = 128, parallel: bool = True, norm_bias_one: bool = False):
+    def __init__(self, group_size: int = 128, parallel: bool = True, norm_bias_one: bool = False, device: Optional[int] = None):
         # Like the reference (decode.rs:229) the store exists BEFORE an engine is bound: weights, norms and router gates can be stored first and
         # set_moe_store(engine) may come last (decode_setup.py:1010) -- or first, as the synthetic benchmark does.  Until then the store runs on
         # the current HIP device with a bare engine inside the library.
@@ -25,7 +25,10 @@ class CpuDecodeStore:
         self._group_size = group_size
         self._norm_bias_one = norm_bias_one
         self._h = C.c_void_p()
-        check(self._lib.kr_decode_create(None, group_size, int(norm_bias_one), C.byref(self._h)))
+        if device is None:
+            check(self._lib.kr_decode_create(None, group_size, int(norm_bias_one), C.byref(self._h)))
+        else:     # a named device: the store must live where the engine it will be bound to lives
+            check(self._lib.kr_decode_create_on(int(device), group_size, int(norm_bias_one), C.byref(self._h)))
         self._engine: Optional[KrasisEngine] = None
         self._vocab = 0
         self._n_layers = 0
@@ -267,6 +270,10 @@ class CpuDecodeStore:
         decode_fast True (KR_DECODE_FAST): decode steps on the tolerance-mode kernels -- the reference's products, tree reductions instead of its
         sequential chains, norms / top-k / activation / combine folded into the matvec launches; the prompt pass is unaffected."""
         self._need(); check(self._lib.kr_decode_set_attention_mode(self._h, (1 if fast else 0) | (2 if gemm_fast else 0) | (4 if decode_fast else 0)))
+
+    def set_option(self, name: str, value: int) -> None:
+        """test / tuning hooks by name ("gqa_stream", "pfm_timing")"""
+        self._need(); check(self._lib.kr_decode_set_option(self._h, name.encode(), int(value)))
 
     def finalize_decode(self) -> None:
         self._need()

@@ -150,12 +150,12 @@ def test_decode_step_split_attention_bit_exact(hd, graph):
 @pytest.mark.parametrize("hd,fp8,stream", [(64, False, True), (256, False, True), (128, True, True), (128, False, True), (256, True, True),
                                            (256, True, False), (128, True, False), (64, True, False), (256, "codes", False)])
 def test_decode_step_streamed_attention_bit_exact(hd, fp8, stream, monkeypatch):
-    """caches too long for an LDS-resident score row (> ~23 k positions) stream it from HBM in tiles; KR_GQA_STREAM forces that form
+    """caches too long for an LDS-resident score row (> ~23 k positions) stream it from HBM in tiles; set_option("gqa_stream") forces that form
     on a cache the oracle can follow, positions across the 128-row stage and 4096-value tile boundaries.  stream=False: the same long
     random E4M3 cache through the LDS-resident form (hardware FP8 widening in the p.v chain at head_dim 128 / 256)"""
-    if stream:
-        monkeypatch.setenv("KR_GQA_STREAM", "1")
     st, eng, orc, keep, d = build(seed=12, kv_max=4400, hd=hd)
+    if stream:
+        st.set_option("gqa_stream", 1)
     if fp8:
         st.set_kv_dtype(True); O.set_kv_fp8(True)
     try:
