@@ -31,7 +31,9 @@ QCN = dict(hidden=2048, inter=512, experts=512, topk=10, layers=48, shared_inter
 # DeepSeek-V2-Lite (H 2048, I 1408, 64 experts top-6, 2 shared, 27 layers = 1 dense + 26 MoE, MLA 16 heads, kv_lora 512, nope 128, rope 64, v 128)
 V2L = dict(hidden=2048, inter=1408, experts=64, topk=6, layers=27, n_shared=2, vocab=102400, nh=16, klr=512, nd=128, rd=64, vhd=128, dense_inter=10944,
            kv_max_seq=256, eps=1e-6)
-Q235 = dict(hidden=4096, inter=1536, experts=128, topk=8, layers=94)      # Qwen3-235B-A22B expert shape (config 4; 16 experts per GPU at EP-8)
+# Qwen3-235B-A22B (config 4; SURVEY 8: H 4096, I 1536, 128 experts top-8, 94 layers, GQA; head counts / vocab from the public model card: 64 q heads, 4 kv heads,
+# head_dim 128, per-head QK-norm, no shared expert, vocab 151936).  INT4-g128: experts 117 GB + attention 3.5 GB + lm_head 0.3 GB -- the whole model fits one MI355X.
+Q235 = dict(hidden=4096, inter=1536, experts=128, topk=8, layers=94, vocab=151936, nh=64, nkv=4, hd=128, kv_max_seq=256, eps=1e-6)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable with a float4 copy)
 I8_PEAK_TOPS = 4400.0      # dense int8 MFMA peak the roofline is priced against (MI355X_MICROARCH.md: >= 3944 TOP/s reached by a 16x16x64 microbenchmark)
 F16_PEAK_TFLOPS = 2500.0            # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
@@ -48,7 +50,8 @@ SYMBOL_FAST = {"proj_matvec": "kr_fdm_kernel<4,1,8>|<4,4,4>", "lm_head": "kr_mat
                "la_recurrent": "kr_fla_kernel<128,128>", "route_logits": "kr_frt_kernel<true>", "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
 WORKLOAD = {"qcn-q4": "Qwen3-Coder-Next Q4 int4gpu on 1×MI355X (512-expert top-10, hybrid linear+GQA, FP8 KV)",
             "qcn-q8": "Qwen3-Coder-Next Q8 int8gpu on 1×MI355X (int8 MFMA path, Q8_0 dequant)",
-            "v2lite-q4": "DeepSeek-V2-Lite Q4 int4gpu on 1×MI355X (MLA + 64-expert top-6)"}
+            "v2lite-q4": "DeepSeek-V2-Lite Q4 int4gpu on 1×MI355X (MLA + 64-expert top-6)",
+            "qwen3-235b-q4": "Qwen3-235B-A22B Q4 int4gpu, the WHOLE model resident on 1×MI355X (94 GQA layers, 128-expert top-8; BASELINE config 4 names expert parallelism on 8 GPUs: see prefill_experts_ep_235b on the N > 1 lines)"}
 
 
 def pmc_traffic(symbol):
@@ -88,7 +91,7 @@ def parse():
     ap.add_argument("--ep-selftest", action="store_true", help="run the expert-parallel leg at N = 1 too (no peer traffic: checks the row path)")
     ap.add_argument("--prefill-tokens", default="8192,20434,35139,49863",
                     help="prompt lengths of the prompt-pass side measurement (benchmark.py:434-505: 20 434 / 35 139 / 49 863 tokens; 0 = skip)")
-    ap.add_argument("--side-configs", default="v2lite-q4,qcn-q8", help="other single-GPU BASELINE configurations measured as side legs of the N = 1 line ('' = none)")
+    ap.add_argument("--side-configs", default="v2lite-q4,qcn-q8,qwen3-235b-q4", help="other single-GPU BASELINE configurations measured as side legs of the N = 1 line ('' = none)")
     return ap.parse_args()
 
 
@@ -127,6 +130,57 @@ def algorithmic_bytes_v2lite(L, bw=B4):
          "lm_head": v["vocab"] * H * bw, "route_logits": n_moe * v["experts"] * H * 2}
     b["total"] = sum(b.values())
     return b
+
+
+def algorithmic_bytes_q235(L, bw=B4):
+    """SURVEY 8d, Qwen3-235B: routed experts 94 * 8 * 3 * 4096 * 1536 * 0.5156 = 7.32 GB, GQA projections, lm_head, router gate (bf16)."""
+    q = Q235; H, I, E, k = q["hidden"], q["inter"], q["experts"], q["topk"]
+    attn_w = (q["nh"] * q["hd"] + 2 * q["nkv"] * q["hd"]) * H + H * q["nh"] * q["hd"]
+    b = {"moe_w13": L * k * H * 2 * I * bw, "moe_w2": L * k * I * H * bw, "proj_matvec": L * attn_w * bw, "lm_head": q["vocab"] * H * bw, "route_logits": L * E * H * 2}
+    b["total"] = sum(b.values())
+    return b
+
+
+def q235_gemm_macs_per_token(L):
+    q = Q235; H, I, k = q["hidden"], q["inter"], q["topk"]
+    return L * ((q["nh"] * q["hd"] + 2 * q["nkv"] * q["hd"]) * H + H * q["nh"] * q["hd"] + k * 3 * H * I)
+
+
+def build_q235(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
+    """Qwen3-235B-A22B-shaped decode graph (BASELINE config 4 on ONE GPU): 94 x [GQA (64 q / 4 kv heads, head_dim 128, per-head QK-norm) + 128-expert top-8 MoE, no shared expert]."""
+    import numpy as np
+    from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
+    q = Q235; H, I, E, k, V = q["hidden"], q["inter"], q["experts"], q["topk"], q["vocab"]
+    nh, nkv, hd = q["nh"], q["nkv"], q["hd"]
+    eng = KrasisEngine(device=local_rank); eng.configure(ModelConfig(H, I, E, k, L, 0, 1.0))
+    eng.fill_synthetic(bits, seed=0x235 + rank); eng.set_routing_config("softmax", True, k, E, H)
+    st = CpuDecodeStore(128, True, False); st.set_moe_store(eng)
+    rng = np.random.default_rng(235 + rank); keep = []; seed = [700 + rank * 100000]
+
+    def W(r, c):
+        seed[0] += 1; return st.store_weight_synthetic(r, c, bits, seed[0])
+
+    def N(n):
+        w = (rng.random(n, dtype=np.float32) * 0.2 + 0.9).astype(np.float32); keep.append(w); return st.store_norm_weight(w.ctypes.data, n)
+
+    fin, lm = N(H), W(V, H)
+    st.configure_decode(H, L, q["eps"], fin, lm, V, k, 1, True, 1.0, 0, synth_seed=235 + rank)
+    for l in range(L):
+        n_in, n_post = N(H), N(H)
+        qw, kw, vw, ow = W(nh * hd, H), W(nkv * hd, H), W(nkv * hd, H), W(H, nh * hd)
+        qn = (rng.random(hd, dtype=np.float32) + 0.5).astype(np.float32); kn = (rng.random(hd, dtype=np.float32) + 0.5).astype(np.float32); keep += [qn, kn]
+        st.add_decode_gqa_layer(n_in, n_post, qw, kw, vw, ow, qn.ctypes.data, hd, kn.ctypes.data, hd, False, nh, nkv, hd, 1.0 / hd ** 0.5)
+        eng.set_route_weight_synthetic(l, 0x12345678ABCDEF01 + rank, 0.02, True)
+        st.set_decode_layer_moe(l, l, l, None, None, None)
+    half = hd // 2; rope_len = max(rope_len, q["kv_max_seq"])
+    pos = np.arange(rope_len, dtype=np.float32)[:, None]
+    freq = (1.0 / (1000000.0 ** (2.0 * np.arange(half, dtype=np.float32) / hd))).astype(np.float32)[None, :]
+    cos, sin = np.cos(pos * freq).astype(np.float32), np.sin(pos * freq).astype(np.float32); keep += [cos, sin]
+    st.set_decode_rope(cos.ctypes.data, sin.ctypes.data, half, rope_len)
+    st.finalize_decode()
+    st.set_kv_dtype(kv_fp8)
+    st.fill_state_synthetic(q["kv_max_seq"], seed=235 + rank)
+    return eng, st, keep
 
 
 def build_qcn(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
@@ -412,17 +466,17 @@ def long_context(st, kv_long, torch, kv_name, fast=False):
 
 def side_config(name, rank, local_rank, args, torch):
     """Another single-GPU BASELINE configuration as a side leg: decode tok/s (same protocol, fewer steps) + prompt pass at 8192 tokens."""
-    qcn = name.startswith("qcn")
+    qcn = name.startswith("qcn"); q235 = name.startswith("qwen3-235b")
     bits = 8 if name.endswith("q8") else 4
-    dims = QCN if qcn else V2L
+    dims = QCN if qcn else (Q235 if q235 else V2L)
     L = dims["layers"]
-    build = build_qcn if qcn else build_v2lite
+    build = build_qcn if qcn else (build_q235 if q235 else build_v2lite)
     eng, st, keep = build(rank, local_rank, L, 8192 + 64, bits, kv_fp8=True)
     st.set_use_graph(not args.no_graph)
     steps = min(args.steps, 50)
     dt = time_decode(st, steps, args.warmup, dims["kv_max_seq"], torch, None, 1)
     bw = B8 if bits == 8 else B4
-    ab = algorithmic_bytes(L, bw) if qcn else algorithmic_bytes_v2lite(L, bw)
+    ab = algorithmic_bytes(L, bw) if qcn else (algorithmic_bytes_q235(L, bw) if q235 else algorithmic_bytes_v2lite(L, bw))
     res = {"workload": WORKLOAD[name], "decode_tok_s": steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "kv": "FP8-E4M3", "weights": "INT%d-g128" % bits,
            "step_algorithmic_bytes": ab["total"], "step_frac_of_hbm_peak": ab["total"] * (steps / dt) / 1e9 / HBM_PEAK_GBS}
     try:       # the same steps in KR_DECODE_FAST (layers / geometries its kernels do not cover -- MLA projections, dense MLP -- keep the exact kernels)
@@ -433,11 +487,14 @@ def side_config(name, rank, local_rank, args, torch):
         res["decode_fast_tok_s"] = {"error": repr(ex)}
     st.set_attention_mode(False)
     try:
-        macs = qcn_gemm_macs_per_token(L) if qcn else v2l_gemm_macs_per_token(L)
+        macs = qcn_gemm_macs_per_token(L) if qcn else (q235_gemm_macs_per_token(L) if q235 else v2l_gemm_macs_per_token(L))
         res["prefill"] = prefill_model(st, dims, macs, L, 8192, 1, torch)
         for key, gfast in (("prefill_fast", False), ("prefill_fast_gemm", True)):       # tolerance modes: attention (+ delta rule), then the GEMMs as well
             st.set_attention_mode(True, gemm_fast=gfast)
             res[key] = prefill_model(st, dims, macs, L, 8192, 1, torch)
+            if gfast:      # one f16 MFMA per MAC in this form: priced against the f16 matrix peak
+                r0 = res[key]["roofline"]
+                res[key]["roofline"] = {"bound": "mfma", "achieved": r0["achieved"], "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s (f16 MFMA; 2 x useful GEMM MACs / s)", "frac": r0["achieved"] / F16_PEAK_TFLOPS}
         st.set_attention_mode(False)
         res["prefill_experts_only"] = prefill_experts(eng, dims, L if qcn else L, 8192, torch)
     except Exception as ex:
@@ -584,15 +641,15 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=5))
 
     name = args.config
-    qcn = name.startswith("qcn")
-    dims = QCN if qcn else V2L
+    qcn = name.startswith("qcn"); q235 = name.startswith("qwen3-235b")
+    dims = QCN if qcn else (Q235 if q235 else V2L)
     bits = 8 if name.endswith("q8") else 4
     bw = B8 if bits == 8 else B4
     L = args.layers or dims["layers"]
     pf_list = [int(x) for x in str(args.prefill_tokens).split(",") if x.strip() and int(x) > 0]
     rope_len = max([32768] + pf_list) + 64              # long-cache side measurements run to position 32 766
     kv_fp8 = args.kv == "fp8"
-    build = build_qcn if qcn else build_v2lite
+    build = build_qcn if qcn else (build_q235 if q235 else build_v2lite)
     eng, st, keep = build(rank, local_rank, L, rope_len, bits, kv_fp8)      # rope table: prompt pass and the long-cache side measurement
     st.set_use_graph(not args.no_graph)
     kvm = dims["kv_max_seq"]
@@ -634,7 +691,7 @@ def main():
                 st.set_prefill_chunk(args.prefill_chunk)
             if args.prefill_depth:
                 st.set_prefill_depth(args.prefill_depth)
-            macs = qcn_gemm_macs_per_token(L) if qcn else v2l_gemm_macs_per_token(L)
+            macs = qcn_gemm_macs_per_token(L) if qcn else (q235_gemm_macs_per_token(L) if q235 else v2l_gemm_macs_per_token(L))
             for key, fast, gfast in (("prefill", False, False), ("prefill_fast", True, False), ("prefill_fast_gemm", True, True)):
                 st.set_attention_mode(fast, gemm_fast=gfast)
                 runs = []
@@ -674,7 +731,7 @@ def main():
             except Exception as ex:
                 side["decode_long_context"] = {"error": repr(ex)}
 
-    ab = (algorithmic_bytes(L, bw) if qcn else algorithmic_bytes_v2lite(L, bw))
+    ab = (algorithmic_bytes(L, bw) if qcn else (algorithmic_bytes_q235(L, bw) if q235 else algorithmic_bytes_v2lite(L, bw)))
     ep_legs = {}
     emitted = []
 
@@ -693,7 +750,7 @@ def main():
         tok_s = world * args.steps / dt
         traffic, traffic_src = pmc_traffic(dom)
         res = {
-            "metric": "decode tok/s, %s @%d MI355X" % ("Qwen3-Coder-Next Q%d" % bits if qcn else "DeepSeek-V2-Lite Q4", world),
+            "metric": "decode tok/s, %s @%d MI355X" % ("Qwen3-Coder-Next Q%d" % bits if qcn else ("Qwen3-235B-A22B Q4" if q235 else "DeepSeek-V2-Lite Q4"), world),
             "value": tok_s, "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("int%d-g128 weights x int16 activations -> i32 group sums, f32 scales" % bits) +

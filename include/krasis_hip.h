@@ -181,6 +181,10 @@ int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, const int32_t
 int kr_ep_comm_ranks(kr_engine* e, int* n_out);                        /* ranks of this engine's communicator as RCCL counts them (ncclCommCount) */
 int kr_ep_max_int(kr_engine* e, int value, int* max_out, void* stream);                /* collective: max of `value` over the ranks (kr_decode_prefill pads ranks with fewer chunks) */
 int kr_ep_allreduce_f32(kr_engine* e, float* buf_dev, size_t n, void* stream);         /* collective: in-place f32 sum over the ranks (expert-parallel decode step) */
+/* Expert-parallel DECODE: a decode store whose engine has expert parallelism initialised (world > 1) runs kr_decode_step as a collective -- router,
+ * attention, norms and the shared expert replicated on every rank, the routed experts of the rank's slice only, one f32 all-reduce of the k expert rows
+ * ([k, hidden]; each row is non-zero on exactly one rank, so the result equals single-engine decode bit for bit) per MoE layer before the combine in
+ * routing order.  The steps are enqueued eagerly (no hipGraph replay) and KR_DECODE_FAST is ignored on such stores. */
 /* loopback transport: W virtual ranks = W engines of ONE process (normally on one device), every rank driven by its own host thread while a
  * collective call is in flight; the exchanges are hipMemcpyAsync pulls between the engines' buffers bracketed by host barriers.  It runs the
  * SAME split-size / offset / scatter code as the RCCL transport, so a single-GPU box can check world sizes 2, 3 (remainder slice), 8

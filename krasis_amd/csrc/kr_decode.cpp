@@ -500,7 +500,11 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
     float* const res_b = (float*)s->res2.p;
     auto other = [&](float* r) { return r == res ? res_b : res; };
     // KR_DECODE_FAST (kr_decode_fast.hip): tolerance-mode kernels for the pieces whose geometry they cover; everything else stays exact
-    const bool fast = s->decode_fast && s->use_images && H % 128 == 0 && H <= 4096 && s->f_qk.p;
+    // expert-parallel decode: router, attention, norms and the shared expert are replicated; every rank runs the routed experts of ITS slice
+    // and the k expert rows are summed over the ranks (each row is non-zero on exactly one rank, so the sum is exact: logits equal single-engine decode
+    // bit for bit) before the combine in routing order.  Reference analogue: python/krasis/gpu_prefill.py:3700-3790 (local subset + partial-sum reduce).
+    const bool ep_dec = kr_ep_world(e) > 1;
+    const bool fast = s->decode_fast && s->use_images && H % 128 == 0 && H <= 4096 && s->f_qk.p && !ep_dec;
     for (size_t li = 0; li < s->layers.size(); li++) {
         DLayer& L = s->layers[li];
         // INT16 activation images: built once by the kernel that produces an activation, copied by every workgroup of the
@@ -725,9 +729,14 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             // the shared expert's sigmoid-gate row rides in the shared slot's w13 launch when routed, shared and gate weights have one width
             const bool fuse_gate = has_gate && a.w13.bits == a.sw13.bits && mv(s, L.sg_wid).bits == a.w13.bits;
             if (fuse_gate) { a.sgate = mv(s, L.sg_wid); a.gate_out = (float*)s->gate_val.p; }
+            if (ep_dec) {
+                kr_ep_slice(e, &a.e_lo, &a.e_hi, &a.e_sub);
+                KR_HIP(hipMemsetAsync(a.eo, 0, (size_t)k * H * 4, st));          // rows of experts other ranks own stay 0
+            }
             PROF(PK_MOE_W13, kr_launch_moe_w13(a, st));
             if (has_gate && !fuse_gate) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), act, 1, (float*)s->gate_val.p, st));
             PROF(PK_MOE_W2, kr_launch_moe_w2(a, st));
+            if (ep_dec) if (int rc = kr_ep_allreduce_on(e, a.eo, (size_t)k * H, st)) return rc;    // the shared expert's row (slot k) is replicated, not reduced
             // epilogue (weighted sum, rsf, shared * sigmoid(gate)) is folded into the next fused add+RMSNorm
             src = KrNormSrc{}; src.mode = 2; src.eo = a.eo; src.ids = a.ids; src.wts = a.wts; src.topk = k; src.has_shared = has_shared ? 1 : 0;
             src.gate_val = has_gate ? (const float*)s->gate_val.p : nullptr; src.rsf = s->rsf;
@@ -778,7 +787,7 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
         }
     kr_launch_set_step((KrStep*)s->step_dev.p, token, pos, st);   // by-value kernel arguments: no host slot shared between queued steps
     s->last_stream = st;
-    if (s->use_graph) {
+    if (s->use_graph && kr_ep_world(s->eng) == 1) {      // expert-parallel decode enqueues every step: the all-reduce is a host-driven collective
         if (!s->graph_ok) {
             if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
             hipGraph_t g = nullptr;

@@ -99,6 +99,11 @@ struct kr_engine {
     struct kr_ep_state* ep = nullptr;   // expert parallelism (kr_ep.cpp): communicator, exchange buffers
 };
 extern "C" int kr_ep_destroy(kr_engine* e);
+// kr_ep.cpp, for the decode graph's expert-parallel step: ranks of the group (1 without expert parallelism), this rank's expert slice [lo, hi) in
+// GLOBAL ids and the offset to subtract for the engine-local index (0 when the engine holds the whole model), in-place f32 sum over the ranks
+int kr_ep_world(const kr_engine* e);
+void kr_ep_slice(const kr_engine* e, int* lo, int* hi, int* sub);
+int kr_ep_allreduce_on(kr_engine* e, float* buf_dev, size_t n, hipStream_t st);
 
 bool is_device_ptr(const void* p);
 kr_engine* kr_engine_new_bare(int device);   // device + stream only (a decode store created before its MoE engine)

@@ -406,6 +406,17 @@ extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, co
     return KR_OK;
 }
 
+int kr_ep_world(const kr_engine* e) { return e && e->ep ? e->ep->world : 1; }
+void kr_ep_slice(const kr_engine* e, int* lo, int* hi, int* sub) {
+    const kr_ep_state* s = e->ep;
+    *lo = s->rank * s->per; *hi = s->rank == s->world - 1 ? s->E_total : (s->rank + 1) * s->per; *sub = s->full ? 0 : *lo;
+}
+int kr_ep_allreduce_on(kr_engine* e, float* buf_dev, size_t n, hipStream_t st) {
+    if (e->ep->broken) return kr_fail(KR_ERR_STATE, "expert parallelism: an earlier collective failed");
+    if (int rc = ep_allreduce_f32(e, buf_dev, n, st)) return ep_abort(e->ep, rc);
+    return KR_OK;
+}
+
 // in-place sum over the ranks of n f32 on the device (collective); the decode graph's expert-parallel step and tests use it
 extern "C" int kr_ep_allreduce_f32(kr_engine* e, float* buf_dev, size_t n, void* stream) {
     if (!e || !e->ep) return kr_fail(KR_ERR_STATE, "call kr_ep_init first");

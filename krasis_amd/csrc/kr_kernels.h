@@ -50,6 +50,7 @@ struct KrMoeArgs {
     const float* wts;      // [B,topk]
     int B, topk, n_slots;  // n_slots = topk (+1 when the shared expert runs in the same launches)
     int E;                 // routed experts of the layer: ids outside [0, E) are skipped like -1 (never an out-of-bounds read)
+    int e_lo, e_hi, e_sub; // expert-parallel decode (e_hi > 0): only ids in [e_lo, e_hi) are computed here, as local expert id - e_sub; the other slots' rows stay 0 for the all-reduce
     int H, I, I_shared;
     KrMatDev w13, w2;      // routed experts of the layer: expert e at q + e*q_stride
     KrMatDev sw13, sw2;    // shared expert (valid when n_slots > topk)

@@ -242,8 +242,9 @@ __device__ __forceinline__ KrSlot kr_resolve_slot(const KrMoeArgs& a, int b, int
         r.q13 = a.sw13.q; r.s13 = a.sw13.s; r.q2 = a.sw2.q; r.s2 = a.sw2.s;
     } else {
         const int e = a.ids[(size_t)b * a.topk + slot];
-        r.valid = e >= 0 && e < a.E; r.inter = a.I;
-        const size_t ee = (size_t)(r.valid ? e : 0);
+        const int lo = a.e_hi > 0 ? a.e_lo : 0, hi = a.e_hi > 0 ? a.e_hi : a.E;
+        r.valid = e >= lo && e < hi; r.inter = a.I;
+        const size_t ee = (size_t)(r.valid ? e - a.e_sub : 0);
         r.q13 = reinterpret_cast<const char*>(a.w13.q) + ee * a.w13.q_stride;
         r.s13 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.w13.s) + ee * a.w13.s_stride);
         r.q2 = reinterpret_cast<const char*>(a.w2.q) + ee * a.w2.q_stride;

@@ -196,3 +196,35 @@ def test_bench_gpus_flag_fails_loudly_without_the_devices():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode != 0
     assert "needs %d devices" % (n + 1) in (p.stderr + p.stdout)
+
+
+@pytest.mark.parametrize("W", [2, 3])
+def test_decode_step_expert_parallel_equals_single_engine(W):
+    """expert-parallel DECODE: every rank runs router / attention / norms / shared expert replicated and the routed experts of its own
+    slice only (16 experts over W ranks; W = 3: 5 + 5 + 6); the k expert rows are summed over the ranks before the combine in routing order -- a row
+    is non-zero on exactly one rank, so logits and greedy tokens of EVERY rank equal single-engine decode bit for bit.  Loopback transport,
+    W decode stores of this process, one host thread per rank."""
+    from krasis_amd.ep import ExpertParallel, LoopbackGroup
+    from tests.test_decode_gpu import build
+    F = np.float32
+    grp = LoopbackGroup(W)
+    ranks, eps = [], []
+    for r in range(W):
+        st, eng, orc, keep, d = build(seed=6)
+        ranks.append((st, eng, keep, d)); eps.append(ExpertParallel(eng, 16, rank=r, loopback=grp, return_bf16=False))
+    steps = [(7, 5), (3, 6), (11, 7), (2, 8)]
+    got = [[None] * len(steps) for _ in range(W)]
+
+    def run(r):
+        st, eng, keep, d = ranks[r]
+        for i, (tok, pos) in enumerate(steps):
+            lg = np.empty(d["V"], F); st.decode_step(tok, pos, lg.ctypes.data); got[r][i] = lg
+    grp.run([lambda r=r: run(r) for r in range(W)])
+    st, eng, orc, keep, d = build(seed=6)
+    for i, (tok, pos) in enumerate(steps):
+        ref = np.empty(d["V"], F); st.decode_step(tok, pos, ref.ctypes.data)
+        for r in range(W):
+            assert np.array_equal(ref.view(np.uint32), got[r][i].view(np.uint32)), (i, r)
+    for ep in eps:
+        ep.close()
+    grp.close()
