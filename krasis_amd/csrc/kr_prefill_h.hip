@@ -373,39 +373,33 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     // (the 64 lanes of a wave copy one 1-KiB tile record row: scalar base + lane * 16).
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int last_tile = (m.N - 1) >> 3;
-    // Both operand streams are addressed through buffer descriptors: a wave-uniform base (the expert's weight block / the A matrix), ONE 32-bit
-    // lane offset and a scalar offset per request.  With flat 64-bit addresses the compiler keeps a register pair per request of the stage alive
-    // across the whole MFMA block (8 A + 8 B requests: ~32 registers) -- the difference between fitting the 256 registers of two waves per SIMD and
-    // spilling.  Record bases are scalars: the tile index of a request is wave-uniform.
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.a), 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wq), 0, -1, 0x00020000);
-    const volatile uint32_t* rofs_v = rofs;       // volatile: the 8 row offsets are re-read from LDS every stage (hoisted into registers they end up in scratch)
+    // (buffer-descriptor loads for the two operand streams were measured here: 1.42 ms per expert layer against 1.22 ms with flat addresses)
     uint32_t brec[RPT];                                              // byte offset of this wave's tile records inside the expert's block (scalars)
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
         int tile = (n0 >> 3) + wv + 4 * j; tile = tile < last_tile ? tile : last_tile;
         brec[j] = (uint32_t)__builtin_amdgcn_readfirstlane(tile * (BITS == 8 ? m.ng : m.ngp) * 1024);
     }
-    const uint32_t lane16 = (uint32_t)lane * 16u;
     auto load_stage = [&](int st) {
 #pragma unroll
         for (int c = 0; c < NC; c++) pspv[c] = wsc[((size_t)ctile[c] * m.ngp + st) * 8 + cin[c]];
         {
             const int kvalid = K - st * PFH_KS;                  // 256, or 128 in the last stage of an odd group count: lines 2, 3 re-read lines 0, 1
             const uint32_t segoff = (uint32_t)((aseg * 64 < kvalid ? aseg : aseg - 2) * 128 + achk * 16);
+            const char* ab = reinterpret_cast<const char*>(a.a) + (size_t)st * (PFH_KS * 2) + segoff;
 #pragma unroll
-            for (int j = 0; j < APT; j++) pa[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, rofs_v[arow + 8 * j] + segoff, st * (PFH_KS * 2), 0);
+            for (int j = 0; j < APT; j++) pa[j] = *reinterpret_cast<const u32x4*>(ab + rofs[arow + 8 * j]);
         }
         if (BITS == 8) {
 #pragma unroll
             for (int gg = 0; gg < 2; gg++) {
                 int g = 2 * st + gg; g = g < m.ng ? g : m.ng - 1;
 #pragma unroll
-                for (int j = 0; j < RPT; j++) pbw[(BITS == 8 ? gg * RPT : 0) + j] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, lane16, brec[j] + (uint32_t)g * 1024u, 2 /* nt */);
+                for (int j = 0; j < RPT; j++) pbw[(BITS == 8 ? gg * RPT : 0) + j] = kr_ldg_nt(reinterpret_cast<const u32x4*>(wq + brec[j] + (size_t)g * 1024) + lane);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < RPT; j++) pbw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, lane16, brec[j] + (uint32_t)st * 1024u, 2 /* nt */);
+            for (int j = 0; j < RPT; j++) pbw[j] = kr_ldg_nt(reinterpret_cast<const u32x4*>(wq + brec[j] + (size_t)st * 1024) + lane);
         }
     };
     uint32_t spv[NC];

@@ -319,3 +319,143 @@ class KrasisEngine:
 
     def device_bytes(self) -> int:
         self._need(); return int(self._lib.kr_engine_device_bytes(self._h))
+
+    # ------------------------------------------------------------------ weight export (moe.rs:1972-2709)
+    # The reference hands its GPU-side (Marlin) expert tensors back to Python so that the prompt pass can DMA them to VRAM.  Here the experts are
+    # already resident in HBM in the lane-tiled layout; these methods convert an expert back to the reference's Marlin GPU format on demand
+    # (kr_download_expert_marlin: un-tile -> marlin_repack, word-for-word what the reference's cache holds) -- same names, argument meaning, byte
+    # layouts, length checks and exception classes, so a caller of the PyO3 class finds them where it expects them.
+    def _marlin_sizes(self, shared: bool = False):
+        """bytes per expert of (w13_packed, w13_scales, w2_packed, w2_scales) in the reference's Marlin GPU format (weights/mod.rs:506-640)"""
+        c = self._cfg
+        H, gs = c.hidden_size, c.group_size if getattr(c, "group_size", 0) else 128
+        inter = c.moe_intermediate_size * (c.n_shared_experts if shared else 1)
+        bits = self._gpu_bits or 4
+        n2 = H + 64 if (H == inter and H % 256 != 0) else H
+        per_word = 8 if bits == 4 else 4                       # weights per u32
+        return (2 * inter * H // per_word * 4, (H // gs) * 2 * inter * 2, n2 * inter // per_word * 4, (inter // gs) * n2 * 2)
+
+    def _need_gpu_weights(self):
+        self._need("Model not loaded")
+        if self._has_gguf and not self._gpu_bits:
+            raise RuntimeError("GPU weights not available")
+
+    def _export_one(self, layer: int, expert: int, shared: bool = False):
+        p13, s13, p2, s2 = self._marlin_sizes(shared)
+        a, b, c, d = (np.empty(p13 // 4, np.uint32), np.empty(s13 // 2, np.uint16), np.empty(p2 // 4, np.uint32), np.empty(s2 // 2, np.uint16))
+        check(self._lib.kr_download_expert_marlin(self._h, layer, -1 if shared else expert, _addr(a), _addr(b), _addr(c), _addr(d)))
+        return a, b, c, d
+
+    def _check_layer(self, moe_layer_idx: int):
+        if not 0 <= moe_layer_idx < self._cfg.num_moe_layers:
+            raise ValueError(f"moe_layer_idx {moe_layer_idx} out of range")
+
+    def _get_range(self, moe_layer_idx: int, start, end, which: int) -> bytes:
+        self._need_gpu_weights(); self._check_layer(moe_layer_idx)
+        s = 0 if start is None else start
+        e = self._cfg.n_routed_experts if end is None else end
+        if s > e or e > self._cfg.n_routed_experts:
+            raise ValueError(f"Invalid range [{s}, {e}), layer has {self._cfg.n_routed_experts} experts")
+        return b"".join(self._export_one(moe_layer_idx, x)[which].tobytes() for x in range(s, e))
+
+    def get_expert_w13_packed(self, moe_layer_idx: int, start=None, end=None) -> bytes:
+        """moe.rs:1973 -- bytes of [end-start, K//16, 2N * bits/2] u32 (Marlin), K = hidden, N = 2 * intermediate"""
+        return self._get_range(moe_layer_idx, start, end, 0)
+
+    def get_expert_w13_scales(self, moe_layer_idx: int, start=None, end=None) -> bytes:
+        return self._get_range(moe_layer_idx, start, end, 1)       # moe.rs:2005
+
+    def get_expert_w2_packed(self, moe_layer_idx: int, start=None, end=None) -> bytes:
+        return self._get_range(moe_layer_idx, start, end, 2)       # moe.rs:2037
+
+    def get_expert_w2_scales(self, moe_layer_idx: int, start=None, end=None) -> bytes:
+        return self._get_range(moe_layer_idx, start, end, 3)       # moe.rs:2069
+
+    _WEIGHT_TYPES = {"w13_packed": 0, "w13_scales": 1, "w2_packed": 2, "w2_scales": 3}
+
+    def get_experts_batch(self, moe_layer_idx: int, expert_ids: Sequence[int], weight_type: str) -> bytes:
+        """moe.rs:2112 -- one weight type of the listed experts, contiguous"""
+        self._need_gpu_weights(); self._check_layer(moe_layer_idx)
+        if weight_type not in self._WEIGHT_TYPES:
+            raise ValueError(f"Unknown weight_type: {weight_type}")
+        for x in expert_ids:
+            if not 0 <= x < self._cfg.n_routed_experts:
+                raise ValueError(f"expert index {x} out of range")
+        w = self._WEIGHT_TYPES[weight_type]
+        return b"".join(self._export_one(moe_layer_idx, x)[w].tobytes() for x in expert_ids)
+
+    def get_experts_all_batch(self, moe_layer_idx: int, expert_ids: Sequence[int]):
+        """moe.rs:2202 -- (w13_packed, w13_scales, w2_packed, w2_scales) of the listed experts"""
+        self._need_gpu_weights(); self._check_layer(moe_layer_idx)
+        parts = [self._export_one(moe_layer_idx, x) for x in expert_ids]
+        return tuple(b"".join(p[w].tobytes() for p in parts) for w in range(4))
+
+    def _write_into(self, moe_layer_idx: int, ids: Sequence[int], bufs, names, shared: bool = False):
+        per = self._marlin_sizes(shared)
+        n = 1 if shared else len(ids)
+        views = []
+        for buf, nm, pe in zip(bufs, names, per):
+            mv = memoryview(buf).cast("B")
+            if len(mv) < n * pe:
+                raise ValueError(f"{nm} too small: {len(mv)} < {n * pe}")            # moe.rs:2286-2300
+            views.append(mv)
+        for i, x in enumerate([0] if shared else ids):
+            parts = self._export_one(moe_layer_idx, x, shared)
+            for mv, part, pe in zip(views, parts, per):
+                mv[i * pe:(i + 1) * pe] = part.tobytes()
+
+    def write_experts_all_into(self, moe_layer_idx: int, w13p_buf, w13s_buf, w2p_buf, w2s_buf) -> None:
+        """moe.rs:2259 -- every expert of the layer into caller-owned writable buffers (bytearray / numpy); ValueError when one is too small"""
+        self._need_gpu_weights(); self._check_layer(moe_layer_idx)
+        self._write_into(moe_layer_idx, range(self._cfg.n_routed_experts), (w13p_buf, w13s_buf, w2p_buf, w2s_buf), ("w13p_buf", "w13s_buf", "w2p_buf", "w2s_buf"))
+
+    def write_experts_range_into(self, moe_layer_idx: int, start: int, end: int, w13p_buf, w13s_buf, w2p_buf, w2s_buf) -> None:
+        """moe.rs:2346"""
+        self._need_gpu_weights(); self._check_layer(moe_layer_idx)
+        if start >= end or end > self._cfg.n_routed_experts:
+            raise ValueError(f"Invalid range [{start}, {end}), layer has {self._cfg.n_routed_experts} experts")
+        self._write_into(moe_layer_idx, range(start, end), (w13p_buf, w13s_buf, w2p_buf, w2s_buf), ("w13p_buf", "w13s_buf", "w2p_buf", "w2s_buf"))
+
+    @staticmethod
+    def _raw(ptr: int, n: int):
+        import ctypes as C
+        return (C.c_ubyte * n).from_address(ptr)
+
+    def write_experts_range_into_pinned(self, moe_layer_idx: int, start: int, end: int, w13p_ptr: int, w13p_len: int, w13s_ptr: int, w13s_len: int,
+                                        w2p_ptr: int, w2p_len: int, w2s_ptr: int, w2s_len: int) -> None:
+        """moe.rs:2432 -- the same through raw (pinned) host addresses + lengths"""
+        self._need_gpu_weights(); self._check_layer(moe_layer_idx)
+        if start >= end or end > self._cfg.n_routed_experts:
+            raise ValueError(f"Invalid range [{start}, {end}), layer has {self._cfg.n_routed_experts} experts")
+        per = self._marlin_sizes(); n = end - start
+        for nm, ln, pe in zip(("w13p", "w13s", "w2p", "w2s"), (w13p_len, w13s_len, w2p_len, w2s_len), per):
+            if ln < n * pe:
+                raise ValueError(f"{nm} buffer too small")                        # moe.rs:2455-2466
+        bufs = (self._raw(w13p_ptr, n * per[0]), self._raw(w13s_ptr, n * per[1]), self._raw(w2p_ptr, n * per[2]), self._raw(w2s_ptr, n * per[3]))
+        self._write_into(moe_layer_idx, range(start, end), bufs, ("w13p", "w13s", "w2p", "w2s"))
+
+    def _need_shared(self):
+        self._need("Model not loaded")
+        if not self._cfg.n_shared_experts:
+            raise RuntimeError("No shared experts")
+
+    def get_shared_expert_weights(self, moe_layer_idx: int):
+        """moe.rs:2675"""
+        self._need_shared(); self._check_layer(moe_layer_idx)
+        return tuple(p.tobytes() for p in self._export_one(moe_layer_idx, -1, shared=True))
+
+    def write_shared_expert_into(self, moe_layer_idx: int, w13p_buf, w13s_buf, w2p_buf, w2s_buf) -> None:
+        """moe.rs:2582"""
+        self._need_shared(); self._check_layer(moe_layer_idx)
+        self._write_into(moe_layer_idx, [0], (w13p_buf, w13s_buf, w2p_buf, w2s_buf), ("w13p_buf", "w13s_buf", "w2p_buf", "w2s_buf"), shared=True)
+
+    def write_shared_expert_into_pinned(self, moe_layer_idx: int, w13p_ptr: int, w13p_len: int, w13s_ptr: int, w13s_len: int, w2p_ptr: int, w2p_len: int,
+                                        w2s_ptr: int, w2s_len: int) -> None:
+        """moe.rs:2631"""
+        self._need_shared(); self._check_layer(moe_layer_idx)
+        per = self._marlin_sizes(shared=True)
+        for nm, ln, pe in zip(("w13p", "w13s", "w2p", "w2s"), (w13p_len, w13s_len, w2p_len, w2s_len), per):
+            if ln < pe:
+                raise ValueError(f"{nm} buffer too small")
+        bufs = (self._raw(w13p_ptr, per[0]), self._raw(w13s_ptr, per[1]), self._raw(w2p_ptr, per[2]), self._raw(w2s_ptr, per[3]))
+        self._write_into(moe_layer_idx, [0], bufs, ("w13p", "w13s", "w2p", "w2s"), shared=True)

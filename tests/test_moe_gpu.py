@@ -119,3 +119,57 @@ def test_reduce_sum_bf16():
     eng.reduce_sum_bf16([d.data_ptr() for d in dev], out.data_ptr(), 1000)
     torch.cuda.synchronize(); eng.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint16), O.reduce_sum_bf16(ins))
+
+
+def test_weight_export_api_of_the_reference_engine():
+    """KrasisEngine.get_expert_w13_packed/_scales, get_expert_w2_packed/_scales, get_experts_batch, get_experts_all_batch, write_experts_{all,range}_into[_pinned],
+    get_shared_expert_weights, write_shared_expert_into[_pinned] (moe.rs:1972-2709): byte layouts = the reference's Marlin GPU format -- the exported
+    experts, uploaded into a second engine through kr_upload_expert_marlin, give a bit-identical moe_forward; range / batch / into / pinned variants agree
+    byte for byte; the reference's error classes (ValueError on short buffers and bad ranges, RuntimeError without shared experts)."""
+    from krasis_amd import KrasisEngine, ModelConfig
+    from krasis_amd._lib import check
+    from oracle import oracle as O  # noqa: F401  (test infrastructure only)
+    H, I, E, k = 256, 128, 6, 2
+    rng = np.random.default_rng(3)
+    experts = make_experts(rng, E, H, I); sh = make_experts(rng, 1, H, I)[0]
+    eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, 1, 1, 1.5)); upload(eng, 0, experts, sh)
+    p13 = eng.get_expert_w13_packed(0); s13 = eng.get_expert_w13_scales(0); p2 = eng.get_expert_w2_packed(0); s2 = eng.get_expert_w2_scales(0)
+    per = [len(x) // E for x in (p13, s13, p2, s2)]
+    assert per[0] == 2 * I * H // 8 * 4 and per[1] == (H // 128) * 2 * I * 2 and per[2] == H * I // 8 * 4 and per[3] == (I // 128) * H * 2
+    assert eng.get_expert_w13_packed(0, 2, 5) == p13[2 * per[0]:5 * per[0]]
+    assert eng.get_experts_batch(0, [4, 1], "w2_scales") == s2[4 * per[3]:5 * per[3]] + s2[per[3]:2 * per[3]]
+    a = eng.get_experts_all_batch(0, [3, 0])
+    assert a[0] == p13[3 * per[0]:4 * per[0]] + p13[:per[0]] and a[3] == s2[3 * per[3]:4 * per[3]] + s2[:per[3]]
+    bufs = [bytearray(E * n) for n in per]
+    eng.write_experts_all_into(0, *bufs)
+    assert [bytes(b) for b in bufs] == [p13, s13, p2, s2]
+    bufs = [bytearray(2 * n) for n in per]
+    eng.write_experts_range_into(0, 1, 3, *bufs)
+    assert bytes(bufs[2]) == p2[per[2]:3 * per[2]]
+    pinned = [np.zeros(2 * n, np.uint8) for n in per]
+    eng.write_experts_range_into_pinned(0, 1, 3, *[v for b in pinned for v in (b.ctypes.data, b.size)])
+    assert pinned[0].tobytes() == p13[per[0]:3 * per[0]] and pinned[3].tobytes() == s2[per[3]:3 * per[3]]
+    with pytest.raises(ValueError, match="too small"):
+        eng.write_experts_all_into(0, bytearray(10), bufs[1], bufs[2], bufs[3])
+    with pytest.raises(ValueError, match="Invalid range"):
+        eng.write_experts_range_into(0, 3, 3, *bufs)
+    with pytest.raises(ValueError, match="Unknown weight_type"):
+        eng.get_experts_batch(0, [0], "w3")
+    shw = eng.get_shared_expert_weights(0)
+    sb = [bytearray(len(x)) for x in shw]
+    eng.write_shared_expert_into(0, *sb)
+    assert [bytes(b) for b in sb] == list(shw)
+    # round trip through the Marlin upload: same bits out of the MoE operator
+    e2 = KrasisEngine(); e2.configure(ModelConfig(H, I, E, k, 1, 1, 1.5))
+    for x in range(E):
+        w = [np.frombuffer(t[x * n:(x + 1) * n], dt).copy() for t, n, dt in zip((p13, s13, p2, s2), per, (np.uint32, np.uint16, np.uint32, np.uint16))]
+        check(e2._lib.kr_upload_expert_marlin(e2._h, 0, x, I, w[0].ctypes.data, w[1].ctypes.data, w[2].ctypes.data, w[3].ctypes.data, 4))
+    w = [np.frombuffer(t, dt).copy() for t, dt in zip(shw, (np.uint32, np.uint16, np.uint32, np.uint16))]
+    check(e2._lib.kr_upload_expert_marlin(e2._h, 0, -1, I, w[0].ctypes.data, w[1].ctypes.data, w[2].ctypes.data, w[3].ctypes.data, 4))
+    e2._cpu_bits = e2._gpu_bits = 4
+    act = rand_bf16(rng, H); ids = [5, 2]; wt = [0.7, 0.3]
+    y1 = np.frombuffer(eng.moe_forward(0, act.tobytes(), ids, wt), np.float32); y2 = np.frombuffer(e2.moe_forward(0, act.tobytes(), ids, wt), np.float32)
+    assert np.array_equal(y1.view(np.uint32), y2.view(np.uint32))
+    e3 = KrasisEngine(); e3.configure(ModelConfig(H, I, E, k, 1, 0, 1.0)); upload(e3, 0, experts)
+    with pytest.raises(RuntimeError, match="No shared experts"):
+        e3.get_shared_expert_weights(0)

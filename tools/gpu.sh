@@ -56,6 +56,12 @@ gemmpmc)    # SQ counters of the shipped GEMM kernels (separate pass, counters o
     python tools/pmc_table.py $R/pmc_gemm $R/r03_gemm_pmc_sq.txt "Experts-only prompt-pass GEMMs, QCN shape, 8192 tokens, 2 layers: SQ counters per launch (rocprofv3 --pmc, counters-only pass)" gemm 2>&1 | tail -2
     head -60 $R/r03_gemm_pmc_sq.txt
     ;;
+gemmab2)    # shipped library vs the A/B build (make -C krasis_amd/csrc ab AB_SRC=... AB_DEFS=...), experts only, all 48 layers, interleaved
+    for rep in 1 2; do
+        timeout 300 python tools/probes/experts_gemm_probe.py 48 8192 fast 2>&1 | grep experts-only | sed 's/^/shipped: /'
+        KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_ab.so timeout 300 python tools/probes/experts_gemm_probe.py 48 8192 fast 2>&1 | grep experts-only | sed 's/^/ab:      /'
+    done
+    ;;
 stamps)
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     ;;
