@@ -84,6 +84,26 @@ def golden_la_recurrent(la):
         final_conv_state=m._conv_state[0].numpy(), final_recur_state=m._recurrent_state[0].numpy())
 
 
+def golden_la_steps(la):
+    """the recurrent (M = 1) path step by step: conv state and recurrent state after EVERY token (both f32 in the fixture), so the oracle is pinned per
+    step on the state it carries -- not only on bf16-rounded outputs and an end-of-sequence state"""
+    nk, nv, dk, dv, kd, steps = 2, 4, 128, 128, 4, 12
+    m, g = make_la(la, nk, nv, dk, dv, kd, seed=31)
+    qkvzs, bas, convs, recs, outs = [], [], [], [], []
+    for _ in range(steps):
+        h = (torch.rand(1, m.hidden_size, generator=g) * 2 - 1)
+        qkvzs.append(la._linear(h, m.in_proj_qkvz)[0].numpy().copy())
+        bas.append(la._linear(h, m.in_proj_ba)[0].numpy().copy())
+        out = m._forward_recurrent(h)
+        outs.append(out.float()[0].numpy().copy())
+        convs.append(m._conv_state[0].float().numpy().copy()); recs.append(m._recurrent_state[0].float().numpy().copy())
+    np.savez_compressed(
+        os.path.join(OUT, "la_steps.npz"),
+        dims=np.array([nk, nv, dk, dv, kd, steps], np.int32), eps=np.float32(1e-6), scale=np.float32(m.scale),
+        qkvz=np.stack(qkvzs), ba=np.stack(bas), conv_w=m.conv1d_weight.squeeze(1).numpy(), a_log=m.A_log.numpy(),
+        dt_bias=m.dt_bias.numpy(), norm_w=m.norm_weight.numpy(), out=np.stack(outs), conv_state=np.stack(convs), recur_state=np.stack(recs))
+
+
 def golden_la_chunked(la):
     """Prefill (chunked) form on M tokens from zero state; same module, same weights as a recurrent run -> both outputs stored."""
     nk, nv, dk, dv, kd, M = 2, 4, 128, 128, 4, 150
@@ -188,6 +208,7 @@ if __name__ == "__main__":
     torch.set_num_threads(1)
     la, layer, attn = import_reference()
     golden_la_recurrent(la)
+    golden_la_steps(la)
     golden_la_chunked(la)
     golden_routing(layer)
     golden_gqa_rope(attn)

@@ -32,6 +32,29 @@ class OracleDecode:
         q, s = O.quant_act_int16_f32(np.ascontiguousarray(x[:cols], F))
         return O.matvec_int4_t(pt, st, q, s) if bits == 4 else O.matvec_int8_t(pt, st, q, s)
 
+    def moe_block(self, L, hidden, ids_w=None):
+        """decode.rs:3286-3402: router on the f32 hidden; routed experts see bf16(hidden) (:3307-3309) and are summed in routing order by
+        moe_forward_unified; `moe_output *= rsf` when rsf != 1 (:3338-3340) -- the ROUTED sum only; the shared expert reads the F32 hidden
+        (:3356-3359), fast_silu_mul + f32::round digits (:3364-3374), and is scaled by 1 / (1 + exp(-gate)) with libm exp (:3379-3393);
+        hidden = moe_output + shared_out (:3396-3399).  ids_w: (ids, weights) to bypass the router (known-answer tests)."""
+        if ids_w is None:
+            ids, w, _ = O.route_decode(L["gate"], hidden, self.topk, self.scoring, self.norm_topk, L.get("bias"), L.get("esc"))
+        else:
+            ids, w = ids_w
+        act = O.f32_to_bf16(hidden)
+        moe = O.moe_forward_unified([L["experts"][i] for i in ids], np.asarray(w, F), act)
+        if self.rsf != F(1.0):
+            moe = (moe * self.rsf).astype(F)
+        if L.get("sgu") is not None:
+            gu = self.matvec(L["sgu"], hidden); si = gu.size // 2
+            hid = O.fast_silu_mul(gu[:si], gu[si:])
+            sh = self.matvec(L["sd"], hid)
+            if L.get("sg") is not None:
+                gv = self.matvec(L["sg"], hidden)[0]
+                sh = (sh * F(O.sigmoid(float(gv), O.SIG_LIBM))).astype(F)
+            return (moe + sh).astype(F)
+        return moe
+
     def step(self, token, pos):
         H = self.H
         self.hidden = self.emb[token].copy()
@@ -66,21 +89,7 @@ class OracleDecode:
                 self.hidden = self.matvec(L["o"], vp)
             self.hidden, self.residual = O.fused_add_rmsnorm(self.hidden, self.residual, self.norms[L["post_norm"]], self.eps, False, self.nbo)
             if L.get("mlp") == "moe":
-                ids, w, _ = O.route_decode(L["gate"], self.hidden, self.topk, self.scoring, self.norm_topk, L.get("bias"), L.get("esc"))
-                act = O.f32_to_bf16(self.hidden)
-                moe = O.moe_forward_unified([L["experts"][i] for i in ids], w, act)
-                if self.rsf != F(1.0):
-                    moe = (moe * self.rsf).astype(F)
-                if L.get("sgu") is not None:
-                    gu = self.matvec(L["sgu"], self.hidden); si = gu.size // 2
-                    hid = O.fast_silu_mul(gu[:si], gu[si:])
-                    sh = self.matvec(L["sd"], hid)
-                    if L.get("sg") is not None:
-                        gv = self.matvec(L["sg"], self.hidden)[0]
-                        sh = (sh * F(O.sigmoid(float(gv), O.SIG_LIBM))).astype(F)
-                    self.hidden = (moe + sh).astype(F)
-                else:
-                    self.hidden = moe
+                self.hidden = self.moe_block(L, self.hidden)
             elif L.get("mlp") == "dense":
                 g = self.matvec(L["gate_w"], self.hidden); u = self.matvec(L["up_w"], self.hidden)
                 K = self.weights[L["down_w"]][3]

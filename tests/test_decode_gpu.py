@@ -15,7 +15,10 @@ def _ptr(a):
     return a.ctypes.data
 
 
-def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4, dims=None, kinds=None, la_heads=(2, 4)):
+def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4, dims=None, kinds=None, la_heads=(2, 4), peaked=False):
+    """peaked=True: a model whose next-token distribution is PEAKED without training -- large embeddings, lm_head tied to them (x 0.05): the logit of the
+    current token stands ~8 above the rest, the layers (attention, router, experts) perturb it by an amount comparable to the noise floor, so on a token
+    stream with repeats the perplexity is O(10) and a routing flip or a tolerance-mode rounding difference shows up in it (tests/test_tolerance_peaked_gpu.py)"""
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     rng = np.random.default_rng(seed)
     H, V, E, k, I, SI = dims or (256, 512, 16, 4, 128, 128)
@@ -23,7 +26,7 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbit
     nkv, d2 = 2, 8
     kinds = kinds or (["la", "gqa", "la"] + (["gqa"] if with_dense else []))
     nL = len(kinds)
-    emb = ((rng.random((V, H)) - 0.5) * 0.2).astype(F)
+    emb = ((rng.random((V, H)) - 0.5) * (3.0 if peaked else 0.2)).astype(F)
     eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, nL, 0, rsf))
     eng.set_routing_config("softmax" if scoring == 1 else "sigmoid", True, k, E, H)
     st = CpuDecodeStore(128, True, norm_bias_one); st.set_moe_store(eng)
@@ -38,7 +41,12 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbit
         w = (rng.random(n) * 0.2 + (0.0 if norm_bias_one else 0.9)).astype(F); keep.append(w)
         return st.store_norm_weight(_ptr(w), n), orc.store_norm(w)
 
-    fin = N(H); lm = W(V, H)
+    fin = N(H)
+    if peaked:
+        lmw = (emb * F(0.05)).astype(F); keep.append(lmw)
+        lm = (st.store_weight_f32(_ptr(lmw), V, H, wbits), orc.store_weight_f32(lmw, wbits))
+    else:
+        lm = W(V, H)
     st.configure_decode(H, nL, 1e-6, fin[0], lm[0], V, k, scoring, True, rsf, _ptr(emb))
     orc.final_norm, orc.lm_head = fin[1], lm[1]
     cos = np.cos(np.arange(kv_max)[:, None] * (1.0 / 10000.0 ** (2 * np.arange(d2) / (2 * d2)))[None, :]).astype(F)
