@@ -40,13 +40,14 @@ F16_PEAK_TFLOPS = 2500.0            # dense f16 / bf16 MFMA peak (MI355X_MICROAR
 B4 = 0.515625              # bytes per INT4-g128 weight incl. bf16 group scale
 B8 = 1.015625              # INT8-g128
 KINDS = ["embed", "fused_add_rmsnorm", "proj_matvec", "la_conv", "la_recurrent", "gated_rmsnorm_silu", "gqa", "route_logits",
-         "route_select", "moe_w13", "moe_w2", "moe_combine", "lm_head", "argmax", "shared_gate"]
+         "route_select", "moe_w13", "moe_w2", "moe_combine", "lm_head", "argmax", "shared_gate", "out_proj_matvec"]
+NK = len(KINDS)
 SYMBOL = {"proj_matvec": "kr_matvec_coop_kernel<float,4>", "lm_head": "kr_matvec_kernel<float,4>", "shared_gate": "kr_matvec_kernel<float,4>",
           "moe_w13": "kr_moe_w13_kernel<4>", "moe_w2": "kr_moe_w2_kernel<4,0>", "la_recurrent": "kr_la_step_kernel<128,128>",
           "route_logits": "kr_route_fused_decode_kernel<true,8>", "route_select": "kr_route_select_kernel",
           "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
 # the same kinds in KR_DECODE_FAST (kr_decode_fast.hip): the norms ride in the projection / router launches, top-k + silu*up in the gate|up launch, the combine in the down launch
-SYMBOL_FAST = {"proj_matvec": "kr_fdm_kernel<4,1,8>|<4,4,4>", "lm_head": "kr_matvec_kernel<float,4>", "moe_w13": "kr_fw13_kernel<4,4>", "moe_w2": "kr_fw2_kernel<4,2>",
+SYMBOL_FAST = {"proj_matvec": "kr_fdm_kernel<4,1,8>", "out_proj_matvec": "kr_fdm_kernel<4,4,4>", "lm_head": "kr_matvec_kernel<float,4>", "moe_w13": "kr_fw13_kernel<4,4>", "moe_w2": "kr_fw2_kernel<4,2>",
                "la_recurrent": "kr_fla_kernel<128,128>", "route_logits": "kr_frt_kernel<true>", "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
 WORKLOAD = {"qcn-q4": "Qwen3-Coder-Next Q4 int4gpu on 1×MI355X (512-expert top-10, hybrid linear+GQA, FP8 KV)",
             "qcn-q8": "Qwen3-Coder-Next Q8 int8gpu on 1×MI355X (int8 MFMA path, Q8_0 dequant)",
@@ -99,8 +100,9 @@ def is_gqa(l):
     return (l + 1) % QCN["full_attn_interval"] == 0
 
 
-def algorithmic_bytes(L, bw=B4):
-    """Bytes a QCN decode token must touch, each weight/state byte once, per kernel kind."""
+def algorithmic_bytes(L, bw=B4, split_out=False):
+    """Bytes a QCN decode token must touch, each weight/state byte once, per kernel kind.  split_out: the out / o projections as
+    their own kind (KR_DECODE_FAST runs them on their own kernel instantiation)."""
     q = QCN; H, I, E, k = q["hidden"], q["inter"], q["experts"], q["topk"]
     n_la = sum(1 for l in range(L) if not is_gqa(l)); n_gqa = L - n_la
     group_dim = 2 * q["dk"] + 2 * q["dv"] * (q["nv"] // q["nk"])
@@ -108,6 +110,7 @@ def algorithmic_bytes(L, bw=B4):
     gqa_w = (q["nh"] * q["hd"] * 2 + 2 * q["nkv"] * q["hd"]) * H + H * (q["nh"] * q["hd"])
     b = {
         "proj_matvec": (n_la * la_w + n_gqa * gqa_w) * bw,
+        "out_proj_matvec": 0.0,
         "moe_w13": L * (k + 1) * H * 2 * I * bw,          # 10 routed + shared expert
         "moe_w2": L * (k + 1) * I * H * bw,
         "lm_head": q["vocab"] * H * bw,
@@ -115,6 +118,9 @@ def algorithmic_bytes(L, bw=B4):
         "la_recurrent": n_la * 2 * q["nv"] * q["dk"] * q["dv"] * 4,   # state read + write
         "shared_gate": L * H * bw,
     }
+    if split_out:
+        b["out_proj_matvec"] = (n_la * H * q["nv"] * q["dv"] + n_gqa * H * q["nh"] * q["hd"]) * bw
+        b["proj_matvec"] -= b["out_proj_matvec"]
     b["total"] = sum(b.values())
     return b
 
@@ -439,11 +445,11 @@ def profile_kinds(st, kvm, P=5):
     tot_ms = [0.0] * 16; tot_n = [0] * 16
     for i in range(P):
         _lib.check(st._lib.kr_decode_profile_step(st._h, 0, (10 + i) % (kvm - 1), ms, cnt, 16))
-        for j in range(15):
+        for j in range(NK):
             tot_ms[j] += ms[j]; tot_n[j] += cnt[j]
-    per_kind_us = {KINDS[j]: (tot_ms[j] / P) * 1e3 for j in range(15)}            # us per step
-    per_launch_us = {KINDS[j]: (tot_ms[j] / max(tot_n[j], 1)) * 1e3 for j in range(15)}
-    n_per_step = {KINDS[j]: tot_n[j] / P for j in range(15)}
+    per_kind_us = {KINDS[j]: (tot_ms[j] / P) * 1e3 for j in range(NK)}            # us per step
+    per_launch_us = {KINDS[j]: (tot_ms[j] / max(tot_n[j], 1)) * 1e3 for j in range(NK)}
+    n_per_step = {KINDS[j]: tot_n[j] / P for j in range(NK)}
     return per_kind_us, per_launch_us, n_per_step
 
 
@@ -731,7 +737,7 @@ def main():
             except Exception as ex:
                 side["decode_long_context"] = {"error": repr(ex)}
 
-    ab = (algorithmic_bytes(L, bw) if qcn else (algorithmic_bytes_q235(L, bw) if q235 else algorithmic_bytes_v2lite(L, bw)))
+    ab = (algorithmic_bytes(L, bw, split_out=fast_mode) if qcn else (algorithmic_bytes_q235(L, bw) if q235 else algorithmic_bytes_v2lite(L, bw)))
     ep_legs = {}
     emitted = []
 
@@ -741,7 +747,7 @@ def main():
             emitted.append(1); return
         emitted.append(1)
         sym_us, sym_bytes, sym_n = {}, {}, {}
-        for j in range(15):
+        for j in range(NK):
             kname = KINDS[j]; sym = (SYMBOL_FAST if fast_mode and qcn and bits == 4 else SYMBOL).get(kname, kname)
             sym_us[sym] = sym_us.get(sym, 0.0) + per_kind_us[kname]; sym_bytes[sym] = sym_bytes.get(sym, 0.0) + ab.get(kname, 0.0)
             sym_n[sym] = sym_n.get(sym, 0) + n_per_step[kname]
@@ -762,7 +768,11 @@ def main():
                        "kv": ("FP8-E4M3" if kv_fp8 else "FP16") + " KV cache, kv_max_seq %d" % kvm, "layers": L,
                        "parallelism": "replica x%d (the model fits one GPU; decode is not expert-parallel)" % world,
                        "hip_graph": not args.no_graph, "target_tok_s": 200,
-                       "decode_mode": "fast (KR_DECODE_FAST, opt-in tolerance mode; the library default is the bit-exact graph)" if fast_mode else "exact (library default)"},
+                       "decode_mode": "fast (KR_DECODE_FAST, opt-in tolerance mode; the library default is the bit-exact graph)" if fast_mode else "exact (library default)",
+                       "prefill_modes": "`prefill` = the library default (exact: bit-identical to token-by-token decode); `prefill_fast` (KR_ATTN_FAST) and "
+                                        "`prefill_fast_gemm` (KR_ATTN_FAST | KR_GEMM_FAST) are the opt-in throughput modes a serving deployment would run -- "
+                                        "the one to compare with the reference's GPU prompt pass (bf16 flash attention + Marlin GEMM) is prefill_fast_gemm",
+                       "decode_token_protocol": "token 0 at positions 10.. like bench_decode_synthetic (decode.rs:5450); weights are synthetic, so the token id does not change the work"},
             ("decode_exact" if fast_mode else "decode_fast"): other,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "peak_measured_stream_read": 6996.0, "peak_measured_source": "tools/probes/hbm_stream.hip on this box type (8 GiB, 16-byte loads)", "traffic": traffic, "traffic_unit": "HBM fetch bytes per launch (PMC FETCH_SIZE, separate pass)",

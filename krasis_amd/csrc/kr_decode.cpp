@@ -551,7 +551,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
         auto out_proj = [&](int wid) {
             if (fast) {
                 KrFdmArgs fo{}; fo.mode = 0; fo.img = s->img_attn.p; fo.mm.n = 1; fo.mm.m[0] = mv(s, wid); fo.mm.y[0] = hid; fo.mm.tile_end[0] = (fo.mm.m[0].N + 7) / 8;
-                prof_mark(s, PK_MATVEC, st);
+                prof_mark(s, PK_OUT_PROJ, st);
                 const int rc = kr_launch_fdm(fo, st);
                 prof_mark(s, -1, st);
                 if (rc == 0) return;

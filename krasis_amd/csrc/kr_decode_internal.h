@@ -72,7 +72,7 @@ struct kr_decode_store {
 };
 
 enum { PK_EMBED = 0, PK_RMSNORM, PK_MATVEC, PK_LA_CONV, PK_LA_RECUR, PK_GATED_NORM, PK_GQA, PK_ROUTE_LOGITS, PK_ROUTE_SELECT, PK_MOE_W13,
-       PK_MOE_W2, PK_MOE_COMBINE, PK_LM_HEAD, PK_ARGMAX, PK_SHARED_GATE, PK_COUNT };
+       PK_MOE_W2, PK_MOE_COMBINE, PK_LM_HEAD, PK_ARGMAX, PK_SHARED_GATE, PK_OUT_PROJ /* KR_DECODE_FAST: the out / o projection from the attention image (its own kernel instantiation) */, PK_COUNT };
 
 
 static inline KrMatDev mv(kr_decode_store* s, int wid) { return s->weights[wid]->ms.view(); }

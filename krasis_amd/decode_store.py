@@ -412,4 +412,4 @@ class CpuDecodeStore:
         self._need()
         ms = (C.c_double * 16)(); cnt = (C.c_long * 16)()
         check(self._lib.kr_decode_profile_step(self._h, token_id, position, ms, cnt, 16))
-        return [(ms[i], cnt[i]) for i in range(15)]
+        return [(ms[i], cnt[i]) for i in range(16)]

@@ -62,6 +62,18 @@ gemmab2)    # shipped library vs the A/B build (make -C krasis_amd/csrc ab AB_SR
         KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_ab.so timeout 300 python tools/probes/experts_gemm_probe.py 48 8192 fast 2>&1 | grep experts-only | sed 's/^/ab:      /'
     done
     ;;
+fastpmc)    # HBM fetch bytes per launch of the KR_DECODE_FAST kernels: counters-only pass (separate from the trace), then the kernel trace of the same command
+    rm -rf $R/pmc_fast
+    (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $R/pmc_fast --output-format csv -- python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 12 --route-tokens 0 --out /root/repo/gpurun_out/r03_decode_fast_pmcrun > $R/pmc_fast.log 2>&1)
+    python tools/rocprof_csv_summary.py pmc $R/pmc_fast $R/r03_decode_fast_pmc_fetch_size.txt "QCN Q4 decode step, KR_DECODE_FAST: HBM fetch per launch (rocprofv3 --pmc FETCH_SIZE, counters-only pass; x2 = gfx950 correction)" 2>&1 | tail -2
+    head -16 $R/r03_decode_fast_pmc_fetch_size.txt
+    kstats r03_decode_fast "QCN Q4 decode step, KR_DECODE_FAST, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only fast --steps 30)" -- \
+        python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r03_decode_fast_prof
+    ;;
+newtests)   # tests added since the last full-suite run
+    timeout 900 python -m pytest tests/test_tolerance_peaked_gpu.py tests/test_moe_gpu.py tests/test_decode_gpu.py -x -q 2>&1 | tail -8
+    cat $R/r03_tolerance_peaked.txt 2>/dev/null
+    ;;
 stamps)
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     ;;
