@@ -52,6 +52,7 @@ SYMBOL_FAST = {"proj_matvec": "kr_fdm_kernel<4,1,8>", "out_proj_matvec": "kr_fdm
 WORKLOAD = {"qcn-q4": "Qwen3-Coder-Next Q4 int4gpu on 1×MI355X (512-expert top-10, hybrid linear+GQA, FP8 KV)",
             "qcn-q8": "Qwen3-Coder-Next Q8 int8gpu on 1×MI355X (int8 MFMA path, Q8_0 dequant)",
             "v2lite-q4": "DeepSeek-V2-Lite Q4 int4gpu on 1×MI355X (MLA + 64-expert top-6)",
+            "qcn-q4k-gguf": "Qwen3-Coder-Next, routed experts as native GGUF Q4_K super-blocks (gguf_native), whole-model prompt pass on 1×MI355X",
             "qwen3-235b-q4": "Qwen3-235B-A22B Q4 int4gpu, the WHOLE model resident on 1×MI355X (94 GQA layers, 128-expert top-8; BASELINE config 4 names expert parallelism on 8 GPUs: see prefill_experts_ep_235b on the N > 1 lines)"}
 
 
@@ -92,7 +93,7 @@ def parse():
     ap.add_argument("--ep-selftest", action="store_true", help="run the expert-parallel leg at N = 1 too (no peer traffic: checks the row path)")
     ap.add_argument("--prefill-tokens", default="8192,20434,35139,49863",
                     help="prompt lengths of the prompt-pass side measurement (benchmark.py:434-505: 20 434 / 35 139 / 49 863 tokens; 0 = skip)")
-    ap.add_argument("--side-configs", default="v2lite-q4,qcn-q8,qwen3-235b-q4", help="other single-GPU BASELINE configurations measured as side legs of the N = 1 line ('' = none)")
+    ap.add_argument("--side-configs", default="v2lite-q4,qcn-q8,qcn-q4k-gguf,qwen3-235b-q4", help="other single-GPU BASELINE configurations measured as side legs of the N = 1 line ('' = none)")
     return ap.parse_args()
 
 
@@ -189,13 +190,16 @@ def build_q235(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
     return eng, st, keep
 
 
-def build_qcn(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
+def build_qcn(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, gguf=False):
     import numpy as np
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     q = QCN; H, I, E, k, V = q["hidden"], q["inter"], q["experts"], q["topk"], q["vocab"]
     eng = KrasisEngine(device=local_rank)
     eng.configure(ModelConfig(H, I, E, k, L, 0, 1.0))
-    eng.fill_synthetic(bits, seed=0x12345678ABCDEF01 + rank)
+    if gguf:      # routed experts as native Q4_K super-blocks (gguf_native=True of the reference): the prompt pass consumes them; the decode graph does not (path matrix)
+        eng.fill_synthetic_gguf(12, 12, seed=0x12345678ABCDEF01 + rank)
+    else:
+        eng.fill_synthetic(bits, seed=0x12345678ABCDEF01 + rank)
     eng.set_routing_config("softmax", True, k, E, H)
     st = CpuDecodeStore(128, True, True)                       # norm_bias_one: qwen3_next (decode.rs:4701)
     st.set_moe_store(eng)
@@ -327,14 +331,21 @@ def prefill_experts(eng, dims, L, M, torch, gemm_fast=False):
                     "twice (high / low INT16 activation digit) to reproduce the reference's integer arithmetic exactly"}
 
 
-def prefill_experts_gguf(local_rank, torch, gate_up_type=12, down_type=12, L=8):
+def prefill_experts_gguf(local_rank, torch, gate_up_type=12, down_type=12, L=8, gemm_fast=False):
     """Side measurement: the expert path of the prompt pass on NATIVE GGUF blocks (QCN shape, Q4_K gate / up / down): raw super-blocks staged
     in LDS feeding the int8 MFMA (kr_gguf_prefill.hip), L layers of 512 synthetic experts."""
     from krasis_amd import KrasisEngine, ModelConfig
     q = QCN
     eng = KrasisEngine(device=local_rank); eng.configure(ModelConfig(q["hidden"], q["inter"], q["experts"], q["topk"], L, 0, 1.0))
     eng.fill_synthetic_gguf(gate_up_type, down_type, seed=77)
-    r = prefill_experts(eng, q, L, 8192, torch)
+    r = prefill_experts(eng, q, L, 8192, torch, gemm_fast=gemm_fast)
+    if gemm_fast:
+        r["note"] = ("tolerance form of the native Q4_K experts: super-blocks re-tiled once (nibbles + per-sub-block f16 scale / offset tables), f16 MFMA with the scale "
+                     "folded into the de-quantization, offsets as K / 32 extra k-columns, libm SiLU; outputs within 1.5e-3 relative RMS of the exact path (tests/test_gguf_gpu.py)")
+        r["weights"] = "native GGUF Q4_K blocks (0.5625 B / weight) + the tolerance GEMM's re-tiled copy (0.625 B / weight, built on first use)"
+        del eng
+        gc.collect(); torch.cuda.empty_cache()
+        return r
     r["weights"] = "native GGUF blocks, gate/up ggml type %d, down type %d (Q4_K = 12: 0.5625 B / weight, Q8_0 = 8)" % (gate_up_type, down_type)
     r["note"] = ("sort + 3 grouped GEMMs (gate, up, down) + libm-SiLU act + combine; raw Q4_K super-blocks in LDS, one int8 MFMA per 32-wide sub-block and "
                  "activation digit, per-sub-block scale / min epilogue (one f32 chain per output: ~1e-6 relative to the streaming kernels)")
@@ -477,6 +488,22 @@ def side_config(name, rank, local_rank, args, torch):
     dims = QCN if qcn else (Q235 if q235 else V2L)
     L = dims["layers"]
     build = build_qcn if qcn else (build_q235 if q235 else build_v2lite)
+    if name == "qcn-q4k-gguf":      # prompt pass only: the decode graph runs on the INT4 / INT8 transposed experts (as the reference's decode_step does)
+        eng, st, keep = build_qcn(rank, local_rank, L, 8192 + 64, 4, kv_fp8=True, gguf=True)
+        res = {"workload": WORKLOAD[name], "kv": "FP8-E4M3", "weights": "routed experts: native Q4_K blocks (0.5625 B / weight); projections, shared expert, lm_head: INT4-g128"}
+        try:
+            macs = qcn_gemm_macs_per_token(L)
+            res["prefill"] = prefill_model(st, dims, macs, L, 8192, 1, torch)
+            st.set_attention_mode(True, gemm_fast=True)
+            res["prefill_fast_gemm"] = prefill_model(st, dims, macs, L, 8192, 1, torch)
+            r0 = res["prefill_fast_gemm"]["roofline"]
+            res["prefill_fast_gemm"]["roofline"] = {"bound": "mfma", "achieved": r0["achieved"], "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s (f16 MFMA; 2 x useful GEMM MACs / s)", "frac": r0["achieved"] / F16_PEAK_TFLOPS}
+            st.set_attention_mode(False)
+        except Exception as ex:
+            res["prefill"] = {"error": repr(ex)}
+        del st, eng, keep
+        gc.collect(); torch.cuda.empty_cache()
+        return res
     eng, st, keep = build(rank, local_rank, L, 8192 + 64, bits, kv_fp8=True)
     st.set_use_graph(not args.no_graph)
     steps = min(args.steps, 50)
@@ -832,6 +859,7 @@ def main():
     if world == 1 and pf_list:
         try:
             side["prefill_experts_only_q4k_gguf"] = prefill_experts_gguf(local_rank, torch)
+            side["prefill_experts_only_q4k_gguf_fast_gemm"] = prefill_experts_gguf(local_rank, torch, gemm_fast=True)
         except Exception as ex:
             side["prefill_experts_only_q4k_gguf"] = {"error": repr(ex)}
     if world == 1 and args.side_configs:

@@ -840,6 +840,79 @@ static int gg_ensure_ws(kr_engine* e, GgufSet& g, hipStream_t st) {
     return KR_OK;
 }
 
+// KR_GEMM_FAST / kr_moe_set_gemm_mode(1) on a native Q4_K layer: the tolerance GEMM's copy of (gate | up) and of down, built once
+static int gg_ensure_fast(kr_engine* e, GgufSet& a, GgufSet* b, hipStream_t st) {     // b: second matrix appended on N (up after gate), or null
+    if (a.fq.p || !a.allocated()) return KR_OK;
+    const int N = a.N + (b ? b->N : 0);
+    a.fN = N; a.fq_stride = kr_mat_q_bytes(a.K, N, 4); a.fqs_stride = (size_t)(N / 8) * (a.K / 256) * 8 * 8 * 2;
+    if (a.fq.ensure(a.fq_stride * a.count) || a.fqs.ensure(a.fqs_stride * a.count) || a.fqo.ensure(a.fqs_stride * a.count)) return kr_fail(KR_ERR_HIP, "hipMalloc of the Q4_K tolerance copy failed");
+    kr_launch_gq_repack(a.view(), a.count, a.fq.p, a.fq_stride, a.fqs.p, a.fqo.p, a.fqs_stride, 0, N / 8, st);
+    if (b) kr_launch_gq_repack(b->view(), b->count, a.fq.p, a.fq_stride, a.fqs.p, a.fqo.p, a.fqs_stride, a.N / 8, N / 8, st);
+    e->weight_bytes += (a.fq_stride + 2 * a.fqs_stride) * a.count;
+    return KR_OK;
+}
+static bool gg_fast_ok(const Layer& L, int H, bool use_shared) {
+    auto q4 = [](const GgufSet& g, int K) { return g.type == GG_Q4_K && K % 256 == 0 && g.N % 8 == 0; };
+    bool ok = q4(L.g_gate, H) && q4(L.g_up, H) && q4(L.g_down, L.inter) && L.inter % 256 == 0 && L.inter <= 2048;
+    if (use_shared) ok = ok && q4(L.gs_gate, H) && q4(L.gs_up, H) && q4(L.gs_down, L.shared_inter) && L.shared_inter % 256 == 0 && L.shared_inter <= 2048;
+    return ok;
+}
+// the prompt pass of a native Q4_K layer in the tolerance form: f16 rows (+ their per-32 sums) x nibbles de-quantized in registers with the
+// sub-block scale folded in, offsets as extra k-columns, libm SiLU like expert_forward_gguf (gguf_kernels.rs:690-756).  Same sort / combine as the exact path.
+static int moe_prefill_gguf_fast(kr_engine* e, Layer& L, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
+                                 int out_dtype, int routed_only, int set, hipStream_t st) {
+    kr_engine::PfSet& P = e->pf[set % KR_PF_MAX_DEPTH];
+    const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
+    const bool use_shared = L.gguf_shared && !routed_only;
+    const int SI = L.shared_inter;
+    if (int rc = gg_ensure_fast(e, L.g_gate, &L.g_up, st)) return rc;
+    if (int rc = gg_ensure_fast(e, L.g_down, nullptr, st)) return rc;
+    if (use_shared) { if (int rc = gg_ensure_fast(e, L.gs_gate, &L.gs_up, st)) return rc; if (int rc = gg_ensure_fast(e, L.gs_down, nullptr, st)) return rc; }
+    const int pairs = e->pf_pairs > 0 ? e->pf_pairs : KR_PF_PAIRS;
+    const int CHmax = pairs / topk > 64 ? pairs / topk : 64;
+    const int CH = M < CHmax ? M : CHmax;
+    const size_t np = (size_t)CH * topk;
+    const int max_tiles = (int)(np / 64) + E + 1;
+    const size_t n_i32 = 3 * (size_t)E + 3 * (size_t)max_tiles + 4 + 2 * np;
+    if ((size_t)CH * H * 2 >= (1ull << 32) || np * I * 2 >= (1ull << 32))
+        return kr_fail(KR_ERR_VALUE, "tolerance GEMM: %zu rows x %d values per pass exceed 4 GiB of f16 activations; lower kr_moe_set_prefill_pairs", np, H > I ? H : I);
+    if (P.i32.ensure(n_i32 * 4) || P.xf.ensure((size_t)CH * H * 2) || P.xfm.ensure((size_t)CH * 4) || P.xs.ensure((size_t)CH * (H / 32) * 2) || P.gu.ensure(np * 2 * I * 4) ||
+        P.hf.ensure(np * I * 2) || P.hfm.ensure(np * 4) || P.hs.ensure(np * (I / 32) * 2) || P.eo.ensure(np * H * 4))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
+    if (use_shared && (P.sgu.ensure((size_t)CH * 2 * SI * 4) || P.shf.ensure((size_t)CH * SI * 2) || P.shfm.ensure((size_t)CH * 4) || P.shs.ensure((size_t)CH * (SI / 32) * 2) ||
+                       P.seo.ensure((size_t)CH * H * 4)))
+        return kr_fail(KR_ERR_HIP, "hipMalloc of prefill scratch failed");
+    int* ib = (int*)P.i32.p;
+    KrPfSort so{};
+    so.counts = ib; so.offsets = ib + E; so.cursor = ib + 2 * E; ib += 3 * E;
+    so.tile_expert = ib; so.tile_row0 = ib + max_tiles; so.tile_rows = ib + 2 * max_tiles; ib += 3 * max_tiles;
+    so.n_tiles = ib; ib += 4; so.row_pair = ib; so.pair_row = ib + np;
+    const size_t ob = out_dtype == KR_OUT_BF16 ? 2 : 4;
+    const KrMatDev w13 = L.g_gate.fast_view(), w2 = L.g_down.fast_view();
+    for (int m0 = 0; m0 < M; m0 += CH) {
+        const int mc = M - m0 < CH ? M - m0 : CH;
+        const uint16_t* xc = (const uint16_t*)x_bf16 + (size_t)m0 * H;
+        const int32_t* idc = ids + (size_t)m0 * topk; const float* wc = wts + (size_t)m0 * topk;
+        const int tiles_bound = (mc * topk) / 64 + E + 1;
+        int run = (int)(((long)mc * topk / E + 63) / 64);
+        run = run < 1 ? 1 : (run > 4 ? 4 : run);
+        kr_launch_pf_sort(idc, mc, topk, E, so, st);
+        kr_launch_pfh_rows_bf16(xc, mc, H, H, (uint16_t*)P.xf.p, (float*)P.xfm.p, st, (uint16_t*)P.xs.p);
+        kr_launch_pfh_gemm(w13, (const uint16_t*)P.xf.p, (const float*)P.xfm.p, &so, topk, 1, tiles_bound, 0, (float*)P.gu.p, 2 * I, st, 0, 0, run, (const uint16_t*)P.xs.p);
+        kr_launch_pfh_act((const float*)P.gu.p, mc * topk, I, 2 * I, 3 /* libm SiLU */, 0.0f, 0.0f, (uint16_t*)P.hf.p, (float*)P.hfm.p, st, (uint16_t*)P.hs.p);
+        kr_launch_pfh_gemm(w2, (const uint16_t*)P.hf.p, (const float*)P.hfm.p, &so, topk, 0, tiles_bound, 0, (float*)P.eo.p, H, st, 0, 0, run, (const uint16_t*)P.hs.p);
+        if (use_shared) {
+            kr_launch_pfh_gemm(L.gs_gate.fast_view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, nullptr, topk, 0, 0, mc, (float*)P.sgu.p, 2 * SI, st, 0, 0, 1, (const uint16_t*)P.xs.p);
+            kr_launch_pfh_act((const float*)P.sgu.p, mc, SI, 2 * SI, 3, 0.0f, 0.0f, (uint16_t*)P.shf.p, (float*)P.shfm.p, st, (uint16_t*)P.shs.p);
+            kr_launch_pfh_gemm(L.gs_down.fast_view(), (const uint16_t*)P.shf.p, (const float*)P.shfm.p, nullptr, topk, 0, 0, mc, (float*)P.seo.p, H, st, 0, 0, 1, (const uint16_t*)P.shs.p);
+        }
+        kr_launch_pf_combine((const float*)P.eo.p, so.pair_row, wc, mc, topk, H, use_shared ? (const float*)P.seo.p : nullptr, e->cfg.routed_scaling_factor,
+                             (char*)out + (size_t)m0 * H * ob, out_dtype == KR_OUT_BF16, st);
+    }
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
 static int moe_prefill_gguf(kr_engine* e, Layer& L, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,
                             int out_dtype, int routed_only, int set, hipStream_t st) {
     const int H = e->cfg.hidden_size, I = L.inter, E = e->cfg.n_routed_experts;
@@ -973,7 +1046,10 @@ int kr_moe_prefill_set(kr_engine* e, int layer, const void* x_bf16, const int32_
     KR_HIP(hipSetDevice(e->device));
     const bool fast = e->gemm_fast || (set & KR_PF_SET_FAST);
     set &= 0xFF;
-    if (L.gguf) return moe_prefill_gguf(e, L, layer, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, set, st);      // native GGUF blocks: exact form only
+    if (L.gguf) {      // native GGUF blocks: the exact int8-MFMA form, or (tolerance mode, Q4_K layers) f16 MFMA on the re-tiled copy
+        if (fast && gg_fast_ok(L, e->cfg.hidden_size, L.gguf_shared && !routed_only)) return moe_prefill_gguf_fast(e, L, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, set, st);
+        return moe_prefill_gguf(e, L, layer, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, set, st);
+    }
     if (e->cfg.hidden_size % 128 || L.inter % 128) return kr_fail(KR_ERR_VALUE, "prefill path needs dims divisible by 128");
     if (fast && (!L.shared_present || routed_only || L.shared_inter % 128 == 0))
         return moe_prefill_fast(e, L, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, set, st);

@@ -29,4 +29,6 @@ void kr_launch_gpf_act(const float* gu, int rows, int n, int gu_ld, int8_t* hh, 
 void kr_launch_gpf_gemm(const GgMat& m, const void* ws, size_t ws_stride, const int8_t* a_hi, const int8_t* a_lo, const float* a_scale, const float* a_sum,
                         const KrPfSort* sort, int topk, int gather_tokens, int max_tiles, int single_expert_rows, float* out, int out_ld, int col_off,
                         hipStream_t st);
+// Q4_K -> the tolerance GEMM's operand form (INT4 lane tiles + per-sub-block f16 scale / offset tables); tile_off: first output tile (gate | up share one matrix)
+void kr_launch_gq_repack(const GgMat& m, int n_experts, void* q_out, size_t q_stride, void* qs_out, void* qo_out, size_t qs_stride, int tile_off, int tiles_out, hipStream_t st);
 void kr_launch_gpf_fill_synth(void* q, size_t q_bytes, void* h, size_t h_bytes, int type, uint64_t seed, hipStream_t st);

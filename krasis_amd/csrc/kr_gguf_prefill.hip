@@ -406,3 +406,63 @@ void kr_launch_gpf_gemm(const GgMat& m, const void* ws, size_t ws_stride, const 
     if (q4k) hipLaunchKernelGGL(kr_gpf_gemm_kernel<GG_Q4_K>, grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL(kr_gpf_gemm_kernel<GG_Q8_0>, grid, dim3(256), lds, st, a);
 }
+
+// ------------------------------------------------------------------------------------------
+// Q4_K -> the tolerance GEMM's operand form (kr_prefill_h.hip, G = 1; KrMatDev::qs / qo), built once per weight set on first use:
+//   nibbles n of every super-block in the INT4 lane-tiled layout of kr_kernels.h (k ascending inside a packed word, group pair = one super-block),
+//   qs[tile][block][col][j] = f16((d * sc_j) / 4),   qo[tile][block][col][j] = f16(16 * (8 * d * sc_j - dmin * mn_j))     (gguf.rs:666-732)
+// so that  w = d sc_j n - dmin mn_j = (d sc_j)(n - 8) + qo / 16.  The scale product d * sc_j is exact in f32 and rounds ONCE to f16 here (2^-12
+// relative per sub-block: the stated cost of this form on top of the f16 activations).
+// grid (tiles, blocks, experts), 64 threads = 8 rows x 8 lanes of the source tile
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) kr_gq_repack_kernel(const GgMat m, char* q_out, size_t q_stride, uint16_t* qs_out, uint16_t* qo_out, size_t qs_stride, int tile_off, int tiles_out) {
+    __shared__ uint8_t qs[8][128];
+    const int tile = blockIdx.x, blk = blockIdx.y, e = blockIdx.z, lane = threadIdx.x, r = lane >> 3, l = lane & 7;
+    const int blocks = m.K / 256;
+    const char* qsrc = reinterpret_cast<const char*>(m.q) + (size_t)e * m.q_stride;
+    const char* hsrc = reinterpret_cast<const char*>(m.h) + (size_t)e * m.h_stride;
+    const u32x4 w = *(reinterpret_cast<const u32x4*>(qsrc) + ((size_t)tile * blocks + blk) * 64 + lane);
+    const uint32_t wj[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) qs[r][32 * j + 2 * l + (p & 1) + 16 * (p >> 1)] = (uint8_t)(wj[j] >> (8 * p));     // record byte p of chunk j = qs[32j + e], e = 2l + (p & 1) + 16 (p >> 1)
+    __syncthreads();
+    // output record of (column r, lane l): packed words i = 2l, 2l + 1 of both 128-groups of the super-block
+    uint32_t ow[4];
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++) {
+            const int i = 2 * l + ii;
+            uint32_t word = 0;
+#pragma unroll
+            for (int mm = 0; mm < 8; mm++) {
+                const int k = g * 128 + 8 * i + mm, sb = k >> 5, el = k & 31;
+                const uint32_t b = qs[r][32 * (sb >> 1) + el];
+                word |= ((sb & 1) ? (b >> 4) : (b & 0xFu)) << (4 * mm);
+            }
+            ow[g * 2 + ii] = word;
+        }
+    char* qdst = q_out + (size_t)e * q_stride;
+    *(reinterpret_cast<u32x4*>(qdst) + ((size_t)(tile_off + tile) * blocks + blk) * 64 + lane) = u32x4{ow[0], ow[1], ow[2], ow[3]};
+    // scale / offset tables: lane l of row r takes sub-block j = l
+    const u32x4 hd = *(reinterpret_cast<const u32x4*>(hsrc) + ((size_t)tile * blocks + blk) * 8 + r);
+    const float d = gpf_f16(hd.x & 0xFFFFu), dmin = gpf_f16(hd.x >> 16);
+    const uint32_t w3[3] = {hd.y, hd.z, hd.w};
+    auto B = [&](int i) -> uint32_t { return (w3[i >> 2] >> ((i & 3) * 8)) & 0xFFu; };
+    const int j = l;
+    int sc, mn;                                                    // get_scale_min_k4 (gguf_kernels.rs:640-648)
+    if (j < 4) { sc = (int)(B(j) & 63u); mn = (int)(B(j + 4) & 63u); }
+    else { sc = (int)((B(j + 4) & 0xFu) | ((B(j - 4) >> 6) << 4)); mn = (int)((B(j + 4) >> 4) | ((B(j) >> 6) << 4)); }
+    const float sj = d * (float)sc, oj = dmin * (float)mn;
+    const size_t ti = (((size_t)(tile_off + tile) * blocks + blk) * 8 + r) * 8 + j;
+    const _Float16 hs = (_Float16)(sj * 0.25f), ho = (_Float16)(16.0f * (8.0f * sj - oj));
+    (qs_out + (size_t)e * (qs_stride / 2))[ti] = __builtin_bit_cast(uint16_t, hs);
+    (qo_out + (size_t)e * (qs_stride / 2))[ti] = __builtin_bit_cast(uint16_t, ho);
+    (void)tiles_out;
+}
+void kr_launch_gq_repack(const GgMat& m, int n_experts, void* q_out, size_t q_stride, void* qs_out, void* qo_out, size_t qs_stride, int tile_off, int tiles_out, hipStream_t st) {
+    hipLaunchKernelGGL(kr_gq_repack_kernel, dim3(m.N / 8, m.K / 256, n_experts), dim3(64), 0, st, m, (char*)q_out, q_stride, (uint16_t*)qs_out, (uint16_t*)qo_out, qs_stride, tile_off,
+                       tiles_out);
+}

@@ -18,6 +18,10 @@ struct KrMatDev {
     int n_fma;       // columns < n_fma accumulate with fma (avx2.rs:1175), the tail with mul+add (avx2.rs:1201)
     size_t q_stride; // bytes between consecutive experts (0 for a single matrix)
     size_t s_stride;
+    // tolerance-GEMM copy of a native Q4_K matrix (kr_prefill_h.hip, G = 1): the nibbles n of the super-blocks in the INT4 layout above and, per
+    // (column, 32-wide sub-block j), f16 tables  qs = (d * sc_j) / 4  and  qo = 16 * (8 * d * sc_j - dmin * mn_j)  so that  w = d sc_j (n - 8) + qo / 16:
+    // [N/8 tiles][K/256 blocks][8 cols][8 sub-blocks] (16 B per (column, block)); null for INT4 / INT8-g128 matrices
+    const uint16_t* qs; const uint16_t* qo; size_t qs_stride;
 };
 
 static inline size_t kr_mat_q_bytes(int K, int N, int bits) {

@@ -43,8 +43,10 @@ void kr_launch_ep_sum_f32(const float* parts, int W, size_t n, float* out, hipSt
 
 // FAST (tolerance) form, kr_prefill_h.hip: f16 rows with a power-of-two row multiplier x weights de-quantized in registers, f32 accumulation
 void kr_launch_pfh_rows_f32(const float* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st);
-void kr_launch_pfh_rows_bf16(const uint16_t* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st);
-void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, uint16_t* out, float* mul, hipStream_t st);
+void kr_launch_pfh_rows_bf16(const uint16_t* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st, uint16_t* sums32 = nullptr);   // sums32: f16 sums per 32 values (Q4_K copy)
+void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, uint16_t* out, float* mul, hipStream_t st,
+                       uint16_t* sums32 = nullptr);     // act_mode 3 = libm SiLU of expert_forward_gguf (rows of at most 2048 values)
 void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
-                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows = 0, int out_bf16 = 0, int run = 1);
+                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows = 0, int out_bf16 = 0, int run = 1,
+                        const uint16_t* a_sum32 = nullptr);     // a_sum32: required when m.qs is set (Q4_K copy)
 void kr_launch_pfh_gemm_multi(const KrMatDev* mats, float* const* outs, const int* out_lds, int n, const uint16_t* a_h, const float* a_mul, int M, hipStream_t st);

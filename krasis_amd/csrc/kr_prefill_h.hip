@@ -29,6 +29,7 @@
 
 #include "kr_lds_optin.h"
 #include "kr_device.h"
+#include "kr_libm.h"
 #include "kr_kernels.h"
 #include "kr_prefill.h"
 
@@ -70,8 +71,18 @@ __device__ __forceinline__ float pfh_block_max(float mx, uint32_t* slot) {   // 
 }
 
 // SRC 0: f32 rows (ld floats apart), SRC 1: bf16 rows (ld elements apart).  grid (rows), 256 threads, K % 8 == 0
+// f16 sum of the 8 ROUNDED values of a chunk, completed over the 4 consecutive lanes of a 32-wide block (Q4_K copy: the operand of the offset columns)
+__device__ __forceinline__ void pfh_store_sum32(const float (&v)[8], float scl, int c, uint16_t* sums_row) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += (float)(_Float16)(v[i] * scl);
+    s += __int_as_float(KR_DPP(__float_as_int(s), KR_DPP_XOR1));
+    s += __int_as_float(KR_DPP(__float_as_int(s), KR_DPP_XOR2));
+    if ((c & 3) == 0) { const _Float16 h = (_Float16)s; sums_row[c >> 2] = __builtin_bit_cast(uint16_t, h); }
+}
+
 template <int SRC>
-__global__ void __launch_bounds__(256) kr_pfh_rows_kernel(const void* __restrict__ x, int ld, int K, uint16_t* __restrict__ out, float* __restrict__ mul) {
+__global__ void __launch_bounds__(256) kr_pfh_rows_kernel(const void* __restrict__ x, int ld, int K, uint16_t* __restrict__ out, float* __restrict__ mul, uint16_t* __restrict__ sums) {
     __shared__ uint32_t smax;
     const int t = blockIdx.x;
     if (threadIdx.x == 0) smax = 0;
@@ -101,6 +112,7 @@ __global__ void __launch_bounds__(256) kr_pfh_rows_kernel(const void* __restrict
         o.x = pfh_pack_h2(v[0] * scl, v[1] * scl); o.y = pfh_pack_h2(v[2] * scl, v[3] * scl);
         o.z = pfh_pack_h2(v[4] * scl, v[5] * scl); o.w = pfh_pack_h2(v[6] * scl, v[7] * scl);
         *reinterpret_cast<u32x4*>(out + (size_t)t * K + (size_t)c * 8) = o;
+        if (sums) pfh_store_sum32(v, scl, c, sums + (size_t)t * (K / 32));
     }
     if (threadIdx.x == 0) mul[t] = inv * 0.0625f;       // 2^e / 16: undoes the row scaling and the weight factor 16
 }
@@ -150,9 +162,10 @@ __global__ void __launch_bounds__(256) kr_pfh_act_kernel(const float* __restrict
 
 // the same for rows of up to 2048 values (expert intermediates): one WAVE per row, the row's values stay in registers between the max and the store
 // (no second evaluation, no LDS, no barrier); 4 rows per workgroup.  CPL = 8-value chunks per lane.
+#define KR_ACT_SILU_LIBM 3   // expert_forward_gguf (gguf_kernels.rs:733-737): silu = g / (1 + exp(-g)) with libm exp, times up
 template <int ACT, int CPL>
 __global__ void __launch_bounds__(256) kr_pfh_act_wave_kernel(const float* __restrict__ gu, int rows, int n, int gu_ld, float swiglu_limit, float alpha,
-                                                             uint16_t* __restrict__ out, float* __restrict__ mul) {
+                                                             uint16_t* __restrict__ out, float* __restrict__ mul, uint16_t* __restrict__ sums) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* g = gu + (size_t)row * gu_ld;
@@ -173,7 +186,8 @@ __global__ void __launch_bounds__(256) kr_pfh_act_wave_kernel(const float* __res
                     if (up > swiglu_limit) up = swiglu_limit;
                     if (up < -swiglu_limit) up = -swiglu_limit;
                     h[q][i] = (up + 1.0f) * (gate * kr_sigmoid_poly5_scalar(gate * alpha));
-                } else h[q][i] = (gg[i] * kr_sigmoid_poly5(gg[i])) * uu[i];
+                } else if (ACT == KR_ACT_SILU_LIBM) h[q][i] = (gg[i] / (1.0f + kr_expf(-gg[i]))) * uu[i];
+                else h[q][i] = (gg[i] * kr_sigmoid_poly5(gg[i])) * uu[i];
                 mx = fmaxf(mx, fabsf(h[q][i]));
             }
         } else {
@@ -192,6 +206,7 @@ __global__ void __launch_bounds__(256) kr_pfh_act_wave_kernel(const float* __res
             o.x = pfh_pack_h2(h[q][0] * scl, h[q][1] * scl); o.y = pfh_pack_h2(h[q][2] * scl, h[q][3] * scl);
             o.z = pfh_pack_h2(h[q][4] * scl, h[q][5] * scl); o.w = pfh_pack_h2(h[q][6] * scl, h[q][7] * scl);
             *reinterpret_cast<u32x4*>(out + (size_t)row * n + (size_t)c * 8) = o;
+            if (sums) pfh_store_sum32(h[q], scl, c, sums + (size_t)row * (n / 32));
         }
     }
     if (lane == 0) mul[row] = inv * 0.0625f;
@@ -203,6 +218,7 @@ __global__ void __launch_bounds__(256) kr_pfh_act_wave_kernel(const float* __res
 struct KrPfGemmHArgs {
     KrMatDev m;
     const uint16_t* a; const float* a_mul;   // f16 rows [rows_or_tokens][K], row multipliers
+    const uint16_t* a_sum;                   // G = 1 (Q4_K copy): f16 sums of every 32 consecutive values of a row, [rows_or_tokens][K / 32]
     const int* row_pair; int topk; int gather_tokens;
     const int* tile_expert; const int* tile_row0; const int* tile_rows; const int* n_tiles;
     float* out; int out_ld;
@@ -289,8 +305,12 @@ __device__ __forceinline__ void pfh_store_tile(const ACC& acc, int nsb, int rows
 // read fragment (c, h) have been issued, into the same registers (16 registers less than two fragment sets, 8 less for the raw INT4 words): the
 // 64 x 256 tile then fits the 256 registers of two waves per SIMD without scratch (the double-buffered form spilled 29 VGPRs, 11 of the reloads inside
 // the MFMA block).
-template <int NC, int BITS, int SB = 0>
+// G = 1: the Q4_K copy (KrMatDev::qs / qo): one scale per 32-wide sub-block -- a k-step of this kernel IS one sub-block (both lane halves together
+// cover k = 32 t .. 32 t + 32 of the stage), so the step picks its scale from the 8 the stage loaded; the per-sub-block offsets
+// (8 d sc_j - dmin mn_j) enter after the k loop as K / 32 extra k-columns: A' = the rows' per-32 sums, B' = the offset table (K / 512 more MFMA steps).
+template <int NC, int BITS, int SB = 0, int G = 0>
 __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs a) {
+    static_assert(G == 0 || (SB == 1 && BITS == 4), "the Q4_K copy runs the single-buffered INT4 form");
     constexpr int BN = 128 * NC, LDA = PFH_LDA, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4, NS = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                                               // [64][LDA]  f16; BITS == 4: k permuted (0,4,1,5,2,6,3,7) inside every 8
@@ -298,6 +318,7 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     float* rmul = reinterpret_cast<float*>(Bs + BN * LDB);         // [64]
     int* row_src = reinterpret_cast<int*>(rmul + PFH_BM);          // [64]
     int* row_dst = row_src + PFH_BM;                               // [64]
+    int* row_idx = row_dst + PFH_BM;                               // [64] source row (G = 1: addresses the per-32 sums)
 
     PFH_STAMPW(6);
     const int ncb0 = (a.m.N + BN - 1) / BN, ncb1 = a.n_extra > 0 ? (a.mx[0].N + BN - 1) / BN : 0, ncb2 = a.n_extra > 1 ? (a.mx[1].N + BN - 1) / BN : 0;
@@ -336,6 +357,7 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
         }
         row_src[tid] = (int)((uint32_t)(src < 0 ? 0 : src) * (uint32_t)(K * 2));      // byte offset of the row in the A matrix (rows past `rows`: row 0)
         row_dst[tid] = (a.scatter_rows && !a.single_expert && tid < rows) ? a.row_pair[row0 + tid] : row0 + tid;
+        row_idx[tid] = src < 0 ? 0 : src;
         rmul[tid] = src >= 0 ? a.a_mul[src] : 0.0f;
     }
     __syncthreads();
@@ -367,6 +389,8 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     const int nst = m.ngp;
     u32x4 pa[APT], pbw[NBW];
     uint32_t pspv[NC];
+    u32x4 pq[G ? NC : 1], sqw[G ? NC : 1];            // G = 1: the 8 f16 sub-block scales of this lane's column(s) for the stage
+    const char* qs_b = G ? reinterpret_cast<const char*>(m.qs) + (size_t)expert * m.qs_stride : nullptr;
     // Loads are never masked: a tile row past `rows` reads row 0 / token 0, a column tile past the last one re-reads the last tile, a line past K
     // re-reads a valid line of the row -- all finite or irrelevant: rows and columns are independent in a GEMM, the stores are guarded and a group
     // past ng gets scale 0.  A: whole 128-byte lines per request, row offsets from the LDS table (above); B: a wave-uniform record base per load
@@ -381,8 +405,13 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
         brec[j] = (uint32_t)__builtin_amdgcn_readfirstlane(tile * (BITS == 8 ? m.ng : m.ngp) * 1024);
     }
     auto load_stage = [&](int st) {
+        if constexpr (G) {
 #pragma unroll
-        for (int c = 0; c < NC; c++) pspv[c] = wsc[((size_t)ctile[c] * m.ngp + st) * 8 + cin[c]];
+            for (int c = 0; c < NC; c++) pq[c] = *reinterpret_cast<const u32x4*>(qs_b + (((size_t)ctile[c] * m.ngp + st) * 8 + cin[c]) * 16);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; c++) pspv[c] = wsc[((size_t)ctile[c] * m.ngp + st) * 8 + cin[c]];
+        }
         {
             const int kvalid = K - st * PFH_KS;                  // 256, or 128 in the last stage of an odd group count: lines 2, 3 re-read lines 0, 1
             const uint32_t segoff = (uint32_t)((aseg * 64 < kvalid ? aseg : aseg - 2) * 128 + achk * 16);
@@ -404,8 +433,13 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     };
     uint32_t spv[NC];
     auto commit_stage = [&]() {
+        if constexpr (G) {
 #pragma unroll
-        for (int c = 0; c < NC; c++) spv[c] = pspv[c];
+            for (int c = 0; c < NC; c++) sqw[c] = pq[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; c++) spv[c] = pspv[c];
+        }
 #pragma unroll
         for (int j = 0; j < APT; j++) {
             u32x4 v = pa[j];
@@ -440,6 +474,7 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     auto stage_mfma = [&](int st, auto nsa) {
         constexpr int NSA = decltype(nsa)::value;
         v2h sq[2][NC], cq[2][NC];
+        if constexpr (!G)
 #pragma unroll
         for (int hh = 0; hh < 2; hh++)
 #pragma unroll
@@ -466,16 +501,31 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
 #pragma unroll
                 for (int c = 0; c < NC; c++) br2[buf][c] = *reinterpret_cast<const u32x2*>(Bs + (cbase + c * 32 + n31) * LDB + lp * 16 + hh * 8);
             };
+            v2h sqs[NC], cqs[NC];            // G = 1: scale / constant of the step being de-quantized
+            auto step_scale = [&](int t) {
+                if constexpr (G) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const uint32_t w4[4] = {sqw[c].x, sqw[c].y, sqw[c].z, sqw[c].w};
+                        const uint32_t wd = w4[t >> 1], s16 = (t & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+                        sqs[c] = __builtin_bit_cast(v2h, s16 | (s16 << 16));
+                        cqs[c] = sqs[c] * v2h{(_Float16)-1536.0f, (_Float16)-1536.0f};
+                    }
+                }
+            };
             auto dq1 = [&](int t, int buf, int c, int h) {
                 const int hh = t >> 2;
-                bf1[c][h] = pfh_dq4(h ? br2[buf][c].y : br2[buf][c].x, sq[hh][c], cq[hh][c], M0, M1, MH, Kc);
+                if constexpr (G) bf1[c][h] = pfh_dq4(h ? br2[buf][c].y : br2[buf][c].x, sqs[c], cqs[c], M0, M1, MH, Kc);
+                else bf1[c][h] = pfh_dq4(h ? br2[buf][c].y : br2[buf][c].x, sq[hh][c], cq[hh][c], M0, M1, MH, Kc);
             };
             rd(0, 0); rd(1, 1);
+            step_scale(0);
 #pragma unroll
             for (int c = 0; c < NC; c++) { dq1(0, 0, c, 0); dq1(0, 0, c, 1); }
 #pragma unroll
             for (int t = 0; t < 8; t++) {
                 const int cur = t & 1, nxt = cur ^ 1;
+                if (t + 1 < 8) step_scale(t + 1);
 #pragma unroll
                 for (int h = 0; h < 2; h++)
 #pragma unroll
@@ -559,6 +609,30 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     };
     // SB form (big problems: nearly every tile is full): one copy of the loop -- the second copy's hoisted values were what pushed the kernel into scratch
     if (SB || two) main_loop(std::integral_constant<int, 2>{}); else main_loop(std::integral_constant<int, 1>{});
+    if constexpr (G) {
+        // the offset columns: 16 sub-blocks per MFMA step, operands straight from global memory (8 f16 per lane and operand)
+        const int nsub = K / 32;
+        const char* qo_b = reinterpret_cast<const char*>(m.qo) + (size_t)expert * m.qs_stride;
+        for (int q0 = 0; q0 < nsub; q0 += 16) {
+            const int sb0 = q0 + 8 * khalf;                     // first sub-block of this lane half
+            const bool live = sb0 < nsub;
+            v8h av[NS], bv[NC];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; s2++) {
+                av[s2] = v8h{0, 0, 0, 0, 0, 0, 0, 0};
+                if (live) av[s2] = *reinterpret_cast<const v8h*>(a.a_sum + (size_t)row_idx[s2 * 32 + n31] * nsub + sb0);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                bv[c] = v8h{0, 0, 0, 0, 0, 0, 0, 0};
+                if (live) bv[c] = *reinterpret_cast<const v8h*>(qo_b + (((size_t)ctile[c] * m.ngp + (sb0 >> 3)) * 8 + cin[c]) * 16);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < NS; s2++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) acc[s2][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s2], bv[c], acc[s2][c], 0, 0, 0);
+        }
+    }
     PFH_STAMPW(8);
     {
         const bool full = rows == (two ? 64 : 32) && n0 + BN <= m.N && !(a.scatter_rows && !a.single_expert);     // uniform
@@ -572,18 +646,18 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
 }
 
 
-template <int NC, int BITS, int SB = 0>
+template <int NC, int BITS, int SB = 0, int G = 0>
 static void pfh_launch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     constexpr int BN = 128 * NC, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4;
-    const size_t lds = (size_t)PFH_BM * PFH_LDA + (size_t)BN * LDB + 3 * PFH_BM * 4;
-    (void)kr_lds_optin((const void*)kr_pfh_gemm_kernel<NC, BITS, SB>, 80 * 1024);
+    const size_t lds = (size_t)PFH_BM * PFH_LDA + (size_t)BN * LDB + 4 * PFH_BM * 4;
+    (void)kr_lds_optin((const void*)kr_pfh_gemm_kernel<NC, BITS, SB, G>, 80 * 1024);
     int ncb = (a.m.N + BN - 1) / BN;
     for (int i = 0; i < a.n_extra; i++) ncb += (a.mx[i].N + BN - 1) / BN;
     KrPfGemmHArgs b = a;
     dim3 grid;
     if (a.single_expert) { int n_super; kr_pf_super_tile(mt, ncb, &b.sr, &b.sc, &n_super); grid = dim3(((n_super + 7) / 8) * 8 * b.sr * b.sc); }
     else { const int span = 8 * a.run; grid = dim3(((mt + span - 1) / span) * span * ncb); }
-    hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS, SB>), grid, dim3(256), lds, st, b);
+    hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS, SB, G>), grid, dim3(256), lds, st, b);
 }
 static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     if (a.m.bits == 8) { pfh_launch<1, 8>(a, mt, st); return; }
@@ -593,34 +667,39 @@ static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     // the 64 x 256 form: ONE copy of the stage loop, single-buffered B fragments -- 220 VGPRs, no scratch.  Measured on MI355X (experts only, QCN shape,
     // 8192 tokens, tools/probes/experts_gemm_probe.py): 1.65 ms per layer for the round-2 form (two loop copies, 29 VGPRs in scratch), 1.49 ms for
     // this one, 1.48 ms with double-buffered fragments and one loop copy (223 VGPRs; not kept: same speed, fewer registers to spare)
+    if (a.m.qs) {      // Q4_K copy
+        if ((long)mt * n128 >= 2048) pfh_launch<2, 4, 1, 1>(a, mt, st); else pfh_launch<1, 4, 1, 1>(a, mt, st);
+        return;
+    }
     if ((long)mt * n128 >= 2048) pfh_launch<2, 4, 1>(a, mt, st);
     else pfh_launch<1, 4>(a, mt, st);
 }
 
 void kr_launch_pfh_rows_f32(const float* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(kr_pfh_rows_kernel<0>, dim3(rows), dim3(256), 0, st, (const void*)x, ld, K, out, mul);
+    hipLaunchKernelGGL(kr_pfh_rows_kernel<0>, dim3(rows), dim3(256), 0, st, (const void*)x, ld, K, out, mul, (uint16_t*)nullptr);
 }
-void kr_launch_pfh_rows_bf16(const uint16_t* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st) {
+void kr_launch_pfh_rows_bf16(const uint16_t* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st, uint16_t* sums32) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(kr_pfh_rows_kernel<1>, dim3(rows), dim3(256), 0, st, (const void*)x, ld, K, out, mul);
+    hipLaunchKernelGGL(kr_pfh_rows_kernel<1>, dim3(rows), dim3(256), 0, st, (const void*)x, ld, K, out, mul, sums32);
 }
-void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, uint16_t* out, float* mul, hipStream_t st) {
+void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode, float swiglu_limit, float alpha, uint16_t* out, float* mul, hipStream_t st, uint16_t* sums32) {
     if (rows <= 0) return;
-    const bool oss = act_mode == KR_ACT_GPTOSS;
-#define KR_ACTW(C_) do { if (oss) hipLaunchKernelGGL((kr_pfh_act_wave_kernel<KR_ACT_GPTOSS, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, gu, rows, n, gu_ld, swiglu_limit, alpha, out, mul); \
-                         else hipLaunchKernelGGL((kr_pfh_act_wave_kernel<KR_ACT_SILU_MUL, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, gu, rows, n, gu_ld, swiglu_limit, alpha, out, mul); } while (0)
+    const bool oss = act_mode == KR_ACT_GPTOSS, libm = act_mode == KR_ACT_SILU_LIBM;
+#define KR_ACTW(C_) do { if (oss) hipLaunchKernelGGL((kr_pfh_act_wave_kernel<KR_ACT_GPTOSS, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, gu, rows, n, gu_ld, swiglu_limit, alpha, out, mul, sums32); \
+                         else if (libm) hipLaunchKernelGGL((kr_pfh_act_wave_kernel<KR_ACT_SILU_LIBM, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, gu, rows, n, gu_ld, swiglu_limit, alpha, out, mul, sums32); \
+                         else hipLaunchKernelGGL((kr_pfh_act_wave_kernel<KR_ACT_SILU_MUL, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, gu, rows, n, gu_ld, swiglu_limit, alpha, out, mul, sums32); } while (0)
     if (n <= 512) { KR_ACTW(1); return; }
     if (n <= 1024) { KR_ACTW(2); return; }
-    if (n <= 2048) { KR_ACTW(4); return; }
+    if (n <= 2048 || libm || sums32) { KR_ACTW(4); if (n <= 2048) return; }
 #undef KR_ACTW
     if (oss) hipLaunchKernelGGL(kr_pfh_act_kernel<KR_ACT_GPTOSS>, dim3(rows), dim3(256), 0, st, gu, n, gu_ld, swiglu_limit, alpha, out, mul);
     else hipLaunchKernelGGL(kr_pfh_act_kernel<KR_ACT_SILU_MUL>, dim3(rows), dim3(256), 0, st, gu, n, gu_ld, swiglu_limit, alpha, out, mul);
 }
 void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
-                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows, int out_bf16, int run) {
+                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows, int out_bf16, int run, const uint16_t* a_sum32) {
     KrPfGemmHArgs a{};
-    a.m = m; a.a = a_h; a.a_mul = a_mul; a.topk = topk; a.gather_tokens = gather_tokens; a.scatter_rows = scatter_rows; a.out_bf16 = out_bf16;
+    a.m = m; a.a = a_h; a.a_mul = a_mul; a.a_sum = a_sum32; a.topk = topk; a.gather_tokens = gather_tokens; a.scatter_rows = scatter_rows; a.out_bf16 = out_bf16;
     if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
     a.out = out; a.out_ld = out_ld; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
     a.run = (single_expert_rows > 0 || run < 1) ? 1 : run;

@@ -145,3 +145,49 @@ def test_synthetic_gguf_fill_and_prefill_runs():
     r, g = ref.cpu().numpy(), got.cpu().numpy()
     assert np.isfinite(r).all() and np.abs(r).max() > 0
     assert np.abs(g - r).max() <= 2e-5 * np.abs(r).max()
+
+
+@pytest.mark.parametrize("H,I,E,k,M,shared", [(2048, 512, 6, 3, 200, True), (512, 256, 8, 4, 700, False), (1024, 512, 4, 2, 64, True)])
+def test_moe_prefill_q4k_tolerance_form(H, I, E, k, M, shared):
+    """kr_moe_set_gemm_mode(1) on a native Q4_K layer: the prompt-pass experts on the f16 matrix cores from the re-tiled copy of the super-blocks
+    (kr_gq_repack_kernel -> kr_pfh_gemm_kernel<..., G = 1>): nibbles de-quantized in registers with the sub-block scale d * sc_j folded in (rounded once
+    to f16), the offsets 8 d sc_j - dmin mn_j as K / 32 extra k-columns against the rows' per-32 sums, libm SiLU, f32 accumulation over the whole k
+    range.  Yardstick: the exact path of the same layer (kr_moe_forward, bit-identical to the oracle's moe_forward_gguf -- checked on a few rows).
+    STATED TOLERANCE: relative RMS error of the expert outputs <= 1.5e-3, max |diff| <= 1e-2 * max |ref| (f16 activations 2^-11, f16 sub-block scales
+    2^-12; the INT4-g128 tolerance form sits at 2-4e-4 with its exact bf16 scales)."""
+    import os
+    import torch
+    from krasis_amd import KrasisEngine, ModelConfig, _lib
+    from krasis_amd._lib import check
+    rng = np.random.default_rng(H + I + M)
+    experts = [make(rng, H, I, O.Q4_K, O.Q4_K) for _ in range(E)]
+    sh = make(rng, H, I, O.Q4_K, O.Q4_K) if shared else None
+    eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, 1, 1 if shared else 0, 1.5))
+    for e, ex in enumerate(experts):
+        eng.load_gguf_expert(0, e, ex.gate, ex.up, ex.down, O.Q4_K, O.Q4_K, I)
+    if shared:
+        eng.load_gguf_expert(0, -1, sh.gate, sh.up, sh.down, O.Q4_K, O.Q4_K, I)
+    act = rand_bf16(rng, (M, H)); ids = np.stack([rng.choice(E, k, replace=False) for _ in range(M)]).astype(np.int32)
+    ids[5, 1] = -1; ids[min(77, M - 1), :] = -1
+    w = rng.random((M, k)).astype(np.float32)
+    xd = torch.from_numpy(act.view(np.int16)).cuda(); idd = torch.from_numpy(ids).cuda(); wd = torch.from_numpy(w).cuda()
+    ref = torch.empty((M, H), dtype=torch.float32, device="cuda"); got = torch.empty_like(ref)
+    st = torch.cuda.current_stream().cuda_stream or 1
+    check(eng._lib.kr_moe_forward(eng._h, 0, xd.data_ptr(), idd.data_ptr(), wd.data_ptr(), ref.data_ptr(), M, k, _lib.KR_OUT_F32, 0, st))
+    check(eng._lib.kr_moe_set_gemm_mode(eng._h, 1))
+    for rep in range(2):        # second call: the copy exists, nothing is built
+        check(eng._lib.kr_moe_prefill(eng._h, 0, xd.data_ptr(), idd.data_ptr(), wd.data_ptr(), got.data_ptr(), M, k, _lib.KR_OUT_F32, 0, st))
+    check(eng._lib.kr_moe_set_gemm_mode(eng._h, 0))
+    torch.cuda.synchronize()
+    r, g = ref.cpu().numpy(), got.cpu().numpy()
+    b = 0
+    sel = [(experts[i], wi) for i, wi in zip(ids[b], w[b]) if i >= 0]
+    orc = O.moe_forward_gguf([s[0] for s in sel], [s[1] for s in sel], act[b], sh, 1.5)
+    assert np.array_equal(r[b].view(np.uint32), orc.view(np.uint32))
+    rms = float(np.sqrt(((g - r) ** 2).mean()) / np.sqrt((r ** 2).mean())); mx = float(np.abs(g - r).max() / np.abs(r).max())
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/r03_q4k_fast_err.txt", "a") as f:
+            f.write(f"Q4_K tolerance form H={H} I={I} E={E} k={k} M={M} shared={shared}: rel RMS {rms:.3e}  max|diff|/max|ref| {mx:.3e}\n")
+    assert np.isfinite(g).all() and rms <= 1.5e-3 and mx <= 1e-2, (rms, mx)
+    if not shared:
+        assert not g[min(77, M - 1)].any()            # every slot skipped: zeros

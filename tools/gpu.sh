@@ -74,6 +74,13 @@ newtests)   # tests added since the last full-suite run
     timeout 900 python -m pytest tests/test_tolerance_peaked_gpu.py tests/test_moe_gpu.py tests/test_decode_gpu.py -x -q 2>&1 | tail -8
     cat $R/r03_tolerance_peaked.txt 2>/dev/null
     ;;
+q4k)        # Q4_K tolerance form: parity test, experts-only timing (exact int8 form vs f16 form), peaked-model + export tests that have not run yet
+    timeout 900 python -m pytest tests/test_gguf_gpu.py -x -q -k "tolerance_form" 2>&1 | tail -6
+    cat $R/r03_q4k_fast_err.txt 2>/dev/null
+    timeout 300 python tools/probes/experts_gemm_probe.py 8 8192 q4kfast,q4k,fast 2>&1 | grep experts-only
+    timeout 900 python -m pytest tests/test_tolerance_peaked_gpu.py tests/test_moe_gpu.py -x -q 2>&1 | tail -5
+    cat $R/r03_tolerance_peaked.txt 2>/dev/null
+    ;;
 stamps)
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     ;;

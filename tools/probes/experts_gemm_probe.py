@@ -27,6 +27,9 @@ if "exact" in modes or "fast" in modes:
             mode, os.environ.get("KR_PFH_VARIANT", "default"), L, M, r["ms"] / L, r["tok_s_experts_only"], r["tok_s_experts_only"] * L / 48,
             r["roofline"]["achieved"], "TFLOP/s f16" if mode == "fast" else "TOP/s int8", r["roofline"]["frac"]), flush=True)
     del eng
+if "q4kfast" in modes:
+    r = bench.prefill_experts_gguf(0, torch, L=L, gemm_fast=True)
+    print("experts-only native Q4_K, tolerance form: %d layers x %d tokens: %.2f ms/layer  %.1f TFLOP/s f16 useful = %.3f of peak" % (L, 8192, r["ms"] / L, r["roofline"]["achieved"], r["roofline"]["frac"]), flush=True)
 if "q4k" in modes:
     r = bench.prefill_experts_gguf(0, torch, L=L)
     print("experts-only native Q4_K: %d layers x %d tokens: %.2f ms/layer  %.1f TOP/s int8 useful = %.3f of peak" % (L, 8192, r["ms"] / L, r["roofline"]["achieved"], r["roofline"]["frac"]), flush=True)
