@@ -308,8 +308,8 @@ __device__ __forceinline__ void pfh_store_tile(const ACC& acc, int nsb, int rows
 // G = 1: the Q4_K copy (KrMatDev::qs / qo): one scale per 32-wide sub-block -- a k-step of this kernel IS one sub-block (both lane halves together
 // cover k = 32 t .. 32 t + 32 of the stage), so the step picks its scale from the 8 the stage loaded; the per-sub-block offsets
 // (8 d sc_j - dmin mn_j) enter after the k loop as K / 32 extra k-columns: A' = the rows' per-32 sums, B' = the offset table (K / 512 more MFMA steps).
-template <int NC, int BITS, int SB = 0, int G = 0>
-__global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs a) {
+template <int NC, int BITS, int SB = 0, int G = 0, int OCC = 2>
+__global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHArgs a) {
     static_assert(G == 0 || (SB == 1 && BITS == 4), "the Q4_K copy runs the single-buffered INT4 form");
     constexpr int BN = 128 * NC, LDA = PFH_LDA, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4, NS = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -349,18 +349,6 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
     const uint32_t* wsc = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + (size_t)expert * m.s_stride);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < PFH_BM) {
-        int src = -1;
-        if (tid < rows) {
-            if (a.single_expert) src = row0 + tid;
-            else { const int pair = a.row_pair[row0 + tid]; src = a.gather_tokens ? pair / a.topk : row0 + tid; }
-        }
-        row_src[tid] = (int)((uint32_t)(src < 0 ? 0 : src) * (uint32_t)(K * 2));      // byte offset of the row in the A matrix (rows past `rows`: row 0)
-        row_dst[tid] = (a.scatter_rows && !a.single_expert && tid < rows) ? a.row_pair[row0 + tid] : row0 + tid;
-        row_idx[tid] = src < 0 ? 0 : src;
-        rmul[tid] = src >= 0 ? a.a_mul[src] : 0.0f;
-    }
-    __syncthreads();
 
     v16f acc[NS][NC];
 #pragma unroll
@@ -404,20 +392,13 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
         int tile = (n0 >> 3) + wv + 4 * j; tile = tile < last_tile ? tile : last_tile;
         brec[j] = (uint32_t)__builtin_amdgcn_readfirstlane(tile * (BITS == 8 ? m.ng : m.ngp) * 1024);
     }
-    auto load_stage = [&](int st) {
+    auto load_B = [&](int st) {      // scales + weight records of a stage: they do not depend on the row table
         if constexpr (G) {
 #pragma unroll
             for (int c = 0; c < NC; c++) pq[c] = *reinterpret_cast<const u32x4*>(qs_b + (((size_t)ctile[c] * m.ngp + st) * 8 + cin[c]) * 16);
         } else {
 #pragma unroll
             for (int c = 0; c < NC; c++) pspv[c] = wsc[((size_t)ctile[c] * m.ngp + st) * 8 + cin[c]];
-        }
-        {
-            const int kvalid = K - st * PFH_KS;                  // 256, or 128 in the last stage of an odd group count: lines 2, 3 re-read lines 0, 1
-            const uint32_t segoff = (uint32_t)((aseg * 64 < kvalid ? aseg : aseg - 2) * 128 + achk * 16);
-            const char* ab = reinterpret_cast<const char*>(a.a) + (size_t)st * (PFH_KS * 2) + segoff;
-#pragma unroll
-            for (int j = 0; j < APT; j++) pa[j] = *reinterpret_cast<const u32x4*>(ab + rofs[arow + 8 * j]);
         }
         if (BITS == 8) {
 #pragma unroll
@@ -431,6 +412,37 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
             for (int j = 0; j < RPT; j++) pbw[j] = kr_ldg_nt(reinterpret_cast<const u32x4*>(wq + brec[j] + (size_t)st * 1024) + lane);
         }
     };
+    auto load_A = [&](int st) {
+        {
+            const int kvalid = K - st * PFH_KS;                  // 256, or 128 in the last stage of an odd group count: lines 2, 3 re-read lines 0, 1
+            const uint32_t segoff = (uint32_t)((aseg * 64 < kvalid ? aseg : aseg - 2) * 128 + achk * 16);
+            const char* ab = reinterpret_cast<const char*>(a.a) + (size_t)st * (PFH_KS * 2) + segoff;
+#pragma unroll
+            for (int j = 0; j < APT; j++) pa[j] = *reinterpret_cast<const u32x4*>(ab + rofs[arow + 8 * j]);
+        }
+    };
+    auto load_stage = [&](int st) { load_A(st); load_B(st); };
+    // Prologue order: the first stage's weights are requested BEFORE the row table is built (tile info -> row_pair -> table -> barrier -> A rows is a
+    // chain of dependent round trips; the weight stream needs none of it), and the rows' multipliers -- only the store phase reads them -- are fetched
+    // here but parked in LDS after the k loop.  A w2 tile (K = 512: two stages) spent as long getting started as in its k loop.
+    // (wave 0 builds the table: the in-order load counter would make its table reads wait for the weight records, so it requests them after the table)
+    if (wave != 0) load_B(0);
+    float mulv = 0.0f;
+    if (tid < PFH_BM) {
+        int src = -1;
+        if (tid < rows) {
+            if (a.single_expert) src = row0 + tid;
+            else { const int pair = a.row_pair[row0 + tid]; src = a.gather_tokens ? pair / a.topk : row0 + tid; }
+        }
+        row_src[tid] = (int)((uint32_t)(src < 0 ? 0 : src) * (uint32_t)(K * 2));      // byte offset of the row in the A matrix (rows past `rows`: row 0)
+        row_dst[tid] = (a.scatter_rows && !a.single_expert && tid < rows) ? a.row_pair[row0 + tid] : row0 + tid;
+        row_idx[tid] = src < 0 ? 0 : src;
+        if (src >= 0) mulv = a.a_mul[src];
+    }
+    __syncthreads();
+
+    if (wave == 0) load_B(0);
+    load_A(0);
     uint32_t spv[NC];
     auto commit_stage = [&]() {
         if constexpr (G) {
@@ -590,7 +602,6 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * NSA + NC, 0);   // DS reads
         }
     };
-    load_stage(0);
     PFH_STAMPW(7);
     auto main_loop = [&](auto nsa) {          // one copy of the loop per number of active row blocks (chosen once per workgroup)
         for (int st = 0; st < nst; st++) {
@@ -634,6 +645,8 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
         }
     }
     PFH_STAMPW(8);
+    if (tid < PFH_BM) rmul[tid] = mulv;
+    __syncthreads();
     {
         const bool full = rows == (two ? 64 : 32) && n0 + BN <= m.N && !(a.scatter_rows && !a.single_expert);     // uniform
         const int nsb = two ? 2 : 1;
@@ -646,18 +659,18 @@ __global__ void __launch_bounds__(256, 2) kr_pfh_gemm_kernel(const KrPfGemmHArgs
 }
 
 
-template <int NC, int BITS, int SB = 0, int G = 0>
+template <int NC, int BITS, int SB = 0, int G = 0, int OCC = 2>
 static void pfh_launch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     constexpr int BN = 128 * NC, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4;
     const size_t lds = (size_t)PFH_BM * PFH_LDA + (size_t)BN * LDB + 4 * PFH_BM * 4;
-    (void)kr_lds_optin((const void*)kr_pfh_gemm_kernel<NC, BITS, SB, G>, 80 * 1024);
+    (void)kr_lds_optin((const void*)kr_pfh_gemm_kernel<NC, BITS, SB, G, OCC>, 80 * 1024);
     int ncb = (a.m.N + BN - 1) / BN;
     for (int i = 0; i < a.n_extra; i++) ncb += (a.mx[i].N + BN - 1) / BN;
     KrPfGemmHArgs b = a;
     dim3 grid;
     if (a.single_expert) { int n_super; kr_pf_super_tile(mt, ncb, &b.sr, &b.sc, &n_super); grid = dim3(((n_super + 7) / 8) * 8 * b.sr * b.sc); }
     else { const int span = 8 * a.run; grid = dim3(((mt + span - 1) / span) * span * ncb); }
-    hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS, SB, G>), grid, dim3(256), lds, st, b);
+    hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS, SB, G, OCC>), grid, dim3(256), lds, st, b);
 }
 static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     if (a.m.bits == 8) { pfh_launch<1, 8>(a, mt, st); return; }
@@ -671,8 +684,12 @@ static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
         if ((long)mt * n128 >= 2048) pfh_launch<2, 4, 1, 1>(a, mt, st); else pfh_launch<1, 4, 1, 1>(a, mt, st);
         return;
     }
+#ifdef KR_PFH_OCC3      // A/B build: 64 x 128 tiles, one loop copy, three workgroups per CU (<= 168 registers, 52 KB of LDS each)
+    pfh_launch<1, 4, 1, 0, 3>(a, mt, st);
+#else
     if ((long)mt * n128 >= 2048) pfh_launch<2, 4, 1>(a, mt, st);
     else pfh_launch<1, 4>(a, mt, st);
+#endif
 }
 
 void kr_launch_pfh_rows_f32(const float* x, int rows, int ld, int K, uint16_t* out, float* mul, hipStream_t st) {
