@@ -305,7 +305,7 @@ def prefill_experts(eng, dims, L, M, torch, gemm_fast=False):
     mgr = GpuPrefillManager(eng, k)
     _lib.check(eng._lib.kr_moe_set_gemm_mode(eng._h, 1 if gemm_fast else 0))
     try:
-        for l in range(min(L, 2)):
+        for l in range(L if gemm_fast else min(L, 2)):      # tolerance form of GGUF layers: every layer builds its re-tiled copy on first use -- outside the timed region
             mgr.forward(l, x, ids, w, routed_only=True)
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

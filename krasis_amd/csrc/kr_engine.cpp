@@ -898,16 +898,16 @@ static int moe_prefill_gguf_fast(kr_engine* e, Layer& L, const void* x_bf16, con
         run = run < 1 ? 1 : (run > 4 ? 4 : run);
         kr_launch_pf_sort(idc, mc, topk, E, so, st);
         kr_launch_pfh_rows_bf16(xc, mc, H, H, (uint16_t*)P.xf.p, (float*)P.xfm.p, st, (uint16_t*)P.xs.p);
-        kr_launch_pfh_gemm(w13, (const uint16_t*)P.xf.p, (const float*)P.xfm.p, &so, topk, 1, tiles_bound, 0, (float*)P.gu.p, 2 * I, st, 0, 0, run, (const uint16_t*)P.xs.p);
-        kr_launch_pfh_act((const float*)P.gu.p, mc * topk, I, 2 * I, 3 /* libm SiLU */, 0.0f, 0.0f, (uint16_t*)P.hf.p, (float*)P.hfm.p, st, (uint16_t*)P.hs.p);
-        kr_launch_pfh_gemm(w2, (const uint16_t*)P.hf.p, (const float*)P.hfm.p, &so, topk, 0, tiles_bound, 0, (float*)P.eo.p, H, st, 0, 0, run, (const uint16_t*)P.hs.p);
+        kr_launch_pfh_w13_act(w13, (const uint16_t*)P.xf.p, (const float*)P.xfm.p, &so, topk, 1, tiles_bound, 0, (float*)P.gu.p, mc * topk, 3 /* libm SiLU */, 0.0f, 0.0f,
+                              (uint16_t*)P.hf.p, (float*)P.hfm.p, st, run, (const uint16_t*)P.xs.p, (uint16_t*)P.hs.p);
+        kr_launch_pfh_gemm(w2, (const uint16_t*)P.hf.p, (const float*)P.hfm.p, &so, topk, 0, tiles_bound, 0, (float*)P.eo.p, H, st, 0, 2 /* f16 rows */, run, (const uint16_t*)P.hs.p);
         if (use_shared) {
             kr_launch_pfh_gemm(L.gs_gate.fast_view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, nullptr, topk, 0, 0, mc, (float*)P.sgu.p, 2 * SI, st, 0, 0, 1, (const uint16_t*)P.xs.p);
             kr_launch_pfh_act((const float*)P.sgu.p, mc, SI, 2 * SI, 3, 0.0f, 0.0f, (uint16_t*)P.shf.p, (float*)P.shfm.p, st, (uint16_t*)P.shs.p);
             kr_launch_pfh_gemm(L.gs_down.fast_view(), (const uint16_t*)P.shf.p, (const float*)P.shfm.p, nullptr, topk, 0, 0, mc, (float*)P.seo.p, H, st, 0, 0, 1, (const uint16_t*)P.shs.p);
         }
-        kr_launch_pf_combine((const float*)P.eo.p, so.pair_row, wc, mc, topk, H, use_shared ? (const float*)P.seo.p : nullptr, e->cfg.routed_scaling_factor,
-                             (char*)out + (size_t)m0 * H * ob, out_dtype == KR_OUT_BF16, st);
+        kr_launch_pf_combine_f16rows((const uint16_t*)P.eo.p, (const float*)P.hfm.p, so.pair_row, wc, mc, topk, H, use_shared ? (const float*)P.seo.p : nullptr, e->cfg.routed_scaling_factor,
+                                     (char*)out + (size_t)m0 * H * ob, out_dtype == KR_OUT_BF16, st);
     }
     KR_HIP(hipGetLastError());
     return KR_OK;
@@ -1017,16 +1017,16 @@ static int moe_prefill_fast(kr_engine* e, Layer& L, const void* x_bf16, const in
         run = run < 1 ? 1 : (run > 4 ? 4 : run);
         kr_launch_pf_sort(idc, mc, topk, E, so, st);
         kr_launch_pfh_rows_bf16(xc, mc, H, H, (uint16_t*)P.xf.p, (float*)P.xfm.p, st);
-        kr_launch_pfh_gemm(L.w13.view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, &so, topk, 1, tiles_bound, 0, (float*)P.gu.p, 2 * I, st, 0, 0, run);
-        kr_launch_pfh_act((const float*)P.gu.p, mc * topk, I, 2 * I, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (uint16_t*)P.hf.p, (float*)P.hfm.p, st);
-        kr_launch_pfh_gemm(L.w2.view(), (const uint16_t*)P.hf.p, (const float*)P.hfm.p, &so, topk, 0, tiles_bound, 0, (float*)P.eo.p, H, st, 0, 0, run);
+        kr_launch_pfh_w13_act(L.w13.view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, &so, topk, 1, tiles_bound, 0, (float*)P.gu.p, mc * topk, act_mode, e->cfg.swiglu_limit,
+                              e->cfg.activation_alpha, (uint16_t*)P.hf.p, (float*)P.hfm.p, st, run);
+        kr_launch_pfh_gemm(L.w2.view(), (const uint16_t*)P.hf.p, (const float*)P.hfm.p, &so, topk, 0, tiles_bound, 0, (float*)P.eo.p, H, st, 0, 2 /* f16 rows */, run);
         if (use_shared) {
             kr_launch_pfh_gemm(L.sw13.view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, nullptr, topk, 0, 0, mc, (float*)P.sgu.p, 2 * SI, st);
             kr_launch_pfh_act((const float*)P.sgu.p, mc, SI, 2 * SI, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (uint16_t*)P.shf.p, (float*)P.shfm.p, st);
             kr_launch_pfh_gemm(L.sw2.view(), (const uint16_t*)P.shf.p, (const float*)P.shfm.p, nullptr, topk, 0, 0, mc, (float*)P.seo.p, H, st);
         }
-        kr_launch_pf_combine((const float*)P.eo.p, so.pair_row, wc, mc, topk, H, use_shared ? (const float*)P.seo.p : nullptr, e->cfg.routed_scaling_factor,
-                             (char*)out + (size_t)m0 * H * ob, out_dtype == KR_OUT_BF16, st);
+        kr_launch_pf_combine_f16rows((const uint16_t*)P.eo.p, (const float*)P.hfm.p, so.pair_row, wc, mc, topk, H, use_shared ? (const float*)P.seo.p : nullptr, e->cfg.routed_scaling_factor,
+                                     (char*)out + (size_t)m0 * H * ob, out_dtype == KR_OUT_BF16, st);
     }
     KR_HIP(hipGetLastError());
     return KR_OK;

@@ -31,6 +31,8 @@ void kr_launch_pf_gemm_multi(const KrMatDev* mats, const uint32_t* const* wsums,
                              const float* a_scale, int M, hipStream_t st);
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                           int out_bf16, hipStream_t st);
+void kr_launch_pf_combine_f16rows(const uint16_t* eo, const float* row_mul, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf,
+                                  void* out, int out_bf16, hipStream_t st);
 void kr_launch_pf_combine_bf16rows(const uint16_t* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                                    int out_bf16, hipStream_t st);
 // expert parallelism helpers (kr_ep.cpp)
@@ -49,4 +51,7 @@ void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode
 void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
                         int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows = 0, int out_bf16 = 0, int run = 1,
                         const uint16_t* a_sum32 = nullptr);     // a_sum32: required when m.qs is set (Q4_K copy)
+void kr_launch_pfh_w13_act(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
+                           int single_expert_rows, float* gu, int rows, int act_mode, float swiglu_limit, float alpha, uint16_t* h_out, float* h_mul,
+                           hipStream_t st, int run = 1, const uint16_t* a_sum32 = nullptr, uint16_t* h_sums32 = nullptr);
 void kr_launch_pfh_gemm_multi(const KrMatDev* mats, float* const* outs, const int* out_lds, int n, const uint16_t* a_h, const float* a_mul, int M, hipStream_t st);

@@ -233,9 +233,12 @@ struct KrPfGemmArgs {
 // 4 columns per thread (16-byte loads of the f32 rows, 8-byte loads of bf16 rows): the expert rows are read once, 671 MB per layer of an 8192-token QCN
 // chunk -- the pass is HBM / L2 bound and one column per thread left it at half the achievable rate.  Per column the sum is the same sequence of
 // (mul, add) in routing order as before.  H % 4 == 0 (the GEMM path needs H % 128 == 0).
-template <bool ROWS_BF16>
+template <int ROWS>      // element type of the expert rows: 0 f32, 1 bf16, 2 f16 (tolerance GEMM)
 __global__ void __launch_bounds__(256) kr_pf_combine_kernel(const void* __restrict__ eo_v, const int* __restrict__ pair_row, const float* __restrict__ wts,
-                                                           int topk, int H, const float* __restrict__ shared_eo, float rsf, void* out, int out_bf16) {
+                                                           int topk, int H, const float* __restrict__ shared_eo, float rsf, void* out, int out_bf16,
+                                                           const float* __restrict__ row_mul) {
+    // ROWS == 2: the rows hold the RAW accumulators of the down GEMM (sums of 2^-e-scaled hidden values times 16 w: O(1..100) whatever the row's
+    // magnitude, so f16 neither overflows nor goes denormal); row_mul[r] = 2^e / 16 (a power of two: exact) restores the row here.
     const int t = blockIdx.y, j = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (j >= H) return;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -244,9 +247,14 @@ __global__ void __launch_bounds__(256) kr_pf_combine_kernel(const void* __restri
         if (r < 0) continue;
         const float w = wts[(size_t)t * topk + s];
         float v[4];
-        if (ROWS_BF16) {
+        if (ROWS == 1) {
             const u32x2 p = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(eo_v) + (size_t)r * H + j);
             v[0] = __uint_as_float(p.x << 16); v[1] = __uint_as_float(p.x & 0xFFFF0000u); v[2] = __uint_as_float(p.y << 16); v[3] = __uint_as_float(p.y & 0xFFFF0000u);
+        } else if (ROWS == 2) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 p = *reinterpret_cast<const h4*>(reinterpret_cast<const uint16_t*>(eo_v) + (size_t)r * H + j);
+            const float rm = row_mul[r];
+            v[0] = (float)p.x * rm; v[1] = (float)p.y * rm; v[2] = (float)p.z * rm; v[3] = (float)p.w * rm;
         } else {
             const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(eo_v) + (size_t)r * H + j);
             v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
@@ -320,11 +328,15 @@ void kr_launch_pf_gemm_multi(const KrMatDev* mats, const uint32_t* const* wsums,
 }
 void kr_launch_pf_combine(const float* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                           int out_bf16, hipStream_t st) {
-    hipLaunchKernelGGL(kr_pf_combine_kernel<false>, dim3((H + 1023) / 1024, M), dim3(256), 0, st, (const void*)eo, pair_row, wts, topk, H, shared_eo, rsf, out, out_bf16);
+    hipLaunchKernelGGL(kr_pf_combine_kernel<0>, dim3((H + 1023) / 1024, M), dim3(256), 0, st, (const void*)eo, pair_row, wts, topk, H, shared_eo, rsf, out, out_bf16, (const float*)nullptr);
+}
+void kr_launch_pf_combine_f16rows(const uint16_t* eo, const float* row_mul, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf,
+                                  void* out, int out_bf16, hipStream_t st) {
+    hipLaunchKernelGGL(kr_pf_combine_kernel<2>, dim3((H + 1023) / 1024, M), dim3(256), 0, st, (const void*)eo, pair_row, wts, topk, H, shared_eo, rsf, out, out_bf16, row_mul);
 }
 void kr_launch_pf_combine_bf16rows(const uint16_t* eo, const int* pair_row, const float* wts, int M, int topk, int H, const float* shared_eo, float rsf, void* out,
                                    int out_bf16, hipStream_t st) {
-    hipLaunchKernelGGL(kr_pf_combine_kernel<true>, dim3((H + 1023) / 1024, M), dim3(256), 0, st, (const void*)eo, pair_row, wts, topk, H, shared_eo, rsf, out, out_bf16);
+    hipLaunchKernelGGL(kr_pf_combine_kernel<1>, dim3((H + 1023) / 1024, M), dim3(256), 0, st, (const void*)eo, pair_row, wts, topk, H, shared_eo, rsf, out, out_bf16, (const float*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

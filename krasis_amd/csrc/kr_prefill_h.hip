@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(256) kr_pfh_act_kernel(const float* __restrict
 // the same for rows of up to 2048 values (expert intermediates): one WAVE per row, the row's values stay in registers between the max and the store
 // (no second evaluation, no LDS, no barrier); 4 rows per workgroup.  CPL = 8-value chunks per lane.
 #define KR_ACT_SILU_LIBM 3   // expert_forward_gguf (gguf_kernels.rs:733-737): silu = g / (1 + exp(-g)) with libm exp, times up
+#define KR_ACT_NONE 4        // the rows ARE the hidden values (formed in the epilogue of the gate | up GEMM): only the f16 row form is made here
 template <int ACT, int CPL>
 __global__ void __launch_bounds__(256) kr_pfh_act_wave_kernel(const float* __restrict__ gu, int rows, int n, int gu_ld, float swiglu_limit, float alpha,
                                                              uint16_t* __restrict__ out, float* __restrict__ mul, uint16_t* __restrict__ sums) {
@@ -176,11 +177,13 @@ __global__ void __launch_bounds__(256) kr_pfh_act_wave_kernel(const float* __res
         const int c = lane + 64 * q;
         if (c * 8 < n) {
             const float4 g0 = *reinterpret_cast<const float4*>(g + c * 8), g1 = *reinterpret_cast<const float4*>(g + c * 8 + 4);
-            const float4 u0 = *reinterpret_cast<const float4*>(g + n + c * 8), u1 = *reinterpret_cast<const float4*>(g + n + c * 8 + 4);
+            float4 u0 = g0, u1 = g1;
+            if (ACT != KR_ACT_NONE) { u0 = *reinterpret_cast<const float4*>(g + n + c * 8); u1 = *reinterpret_cast<const float4*>(g + n + c * 8 + 4); }
             const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                if (ACT == KR_ACT_GPTOSS) {
+                if (ACT == KR_ACT_NONE) h[q][i] = gg[i];
+                else if (ACT == KR_ACT_GPTOSS) {
                     float gate = gg[i], up = uu[i];
                     if (gate > swiglu_limit) gate = swiglu_limit;
                     if (up > swiglu_limit) up = swiglu_limit;
@@ -222,7 +225,8 @@ struct KrPfGemmHArgs {
     const int* row_pair; int topk; int gather_tokens;
     const int* tile_expert; const int* tile_row0; const int* tile_rows; const int* n_tiles;
     float* out; int out_ld;
-    int single_expert; int total_rows; int scatter_rows; int out_bf16;
+    int single_expert; int total_rows; int scatter_rows; int out_bf16;      // out_bf16: element type of out 0 f32, 1 bf16, 2 f16
+    int act_fused; float act_limit, act_alpha;      // gate | up GEMM of 256-column tiles: h = act(gate, up) formed in the epilogue, out = [rows][N / 2] f32
     int run;                                 // experts: consecutive row tiles given to one XCD (> 1: the tiles of one expert share an L2)
     int sr, sc;                              // dense: super-tile of sr row tiles x sc column blocks per XCD (kr_pf_super_tile)
     int n_extra; KrMatDev mx[2]; float* outx[2]; int out_ldx[2];
@@ -256,10 +260,34 @@ __device__ __forceinline__ v8h pfh_dq8(uint32_t w0, uint32_t w1, v2h sb) {
 // Stores of a 32 x 32 accumulator block set: lane (n31, khalf) holds column n31 of 16 rows (r & 3) + 8 (r >> 2) + 4 khalf.  FULL: every row and column
 // of the tile is valid and rows are stored in GEMM order (no scatter): the row base is wave-uniform (scalar), the lane part one 32-bit offset, no
 // exec-mask branches -- the guarded form costs ~20 instructions and two branches per store.  BF16: round to bf16 (RNE) on the way out.
-template <int NSB, int NC, bool FULL, bool BF16, typename ACC>
+// OT: element type of the output 0 f32, 1 bf16 (RNE), 2 f16 (the expert rows of the tolerance mode: half the bytes for the store and for the combine pass;
+// RAW accumulators -- the kernel parks multipliers of 1 -- so the values are O(1..100) for any row magnitude; kr_pf_combine_kernel<2> applies the row multiplier).
+// ACTF != 0 (NC == 2, gate | up GEMM): column block 0 holds gate columns, block 1 the matching up columns -- the epilogue forms h = act(g, u) and stores ONE
+// value per pair at the hidden column (f32): the [rows, 2 I] gate | up matrix is never written or re-read.  1 = silu with the poly-5 sigmoid
+// (avx2.rs:2331), 2 = GPT-OSS (moe.rs:268-287), 3 = libm silu (gguf_kernels.rs:733-737).
+__device__ __forceinline__ float pfh_act(int ACTF, float g, float u, float limit, float alpha) {      // ACTF is wave-uniform
+    if (ACTF == 2) {
+        float gate = g, up = u;
+        if (gate > limit) gate = limit;
+        if (up > limit) up = limit;
+        if (up < -limit) up = -limit;
+        return (up + 1.0f) * (gate * kr_sigmoid_poly5_scalar(gate * alpha));
+    }
+    if (ACTF == 3) return (g / (1.0f + kr_expf(-g))) * u;
+    return (g * kr_sigmoid_poly5(g)) * u;
+}
+template <int OT> __device__ __forceinline__ void pfh_put(void* base, size_t idx, float v) {
+    if (OT == 1) reinterpret_cast<uint16_t*>(base)[idx] = kr_f32_to_bf16(v);
+    else if (OT == 2) { const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);     // saturates instead of overflowing to inf
+         reinterpret_cast<uint16_t*>(base)[idx] = __builtin_bit_cast(uint16_t, h); }
+    else reinterpret_cast<float*>(base)[idx] = v;
+}
+template <int NSB, int NC, bool FULL, int OT, bool ACT, typename ACC>
 __device__ __forceinline__ void pfh_store_tile(const ACC& acc, int nsb, int rows, int row0, const float* rmul, const int* row_dst, void* out_p, int out_ld,
-                                               const int (&col)[NC], int N, int lane) {
+                                               const int (&col)[NC], int N, int lane, int ACTF = 0, float limit = 0.0f, float alpha = 0.0f) {
     const int khalf = lane >> 5;
+    constexpr int NCS = ACT ? 1 : NC;       // stores per (row, lane)
+    constexpr size_t ESZ = OT == 0 ? 4 : 2;
 #pragma unroll
     for (int s = 0; s < NSB; s++) {
         if (s >= nsb) break;
@@ -272,13 +300,12 @@ __device__ __forceinline__ void pfh_store_tile(const ACC& acc, int nsb, int rows
                 const uint32_t lane_off = (uint32_t)(4 * khalf) * (uint32_t)out_ld;      // elements; + col below
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    char* rb = reinterpret_cast<char*>(out_p) + (size_t)(row0 + s * 32 + 8 * rq + i) * out_ld * (BF16 ? 2 : 4);     // wave-uniform
+                    char* rb = reinterpret_cast<char*>(out_p) + (size_t)(row0 + s * 32 + 8 * rq + i) * out_ld * ESZ;     // wave-uniform
 #pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        const float v = acc[s][c][rq * 4 + i] * rm[i];
-                        const uint32_t eo = lane_off + (uint32_t)col[c];
-                        if (BF16) *reinterpret_cast<uint16_t*>(rb + (size_t)eo * 2) = kr_f32_to_bf16(v);
-                        else *reinterpret_cast<float*>(rb + (size_t)eo * 4) = v;
+                    for (int c = 0; c < NCS; c++) {
+                        float v = acc[s][c][rq * 4 + i] * rm[i];
+                        if (ACT) v = pfh_act(ACTF, v, acc[s][NC - 1][rq * 4 + i] * rm[i], limit, alpha);
+                        pfh_put<OT>(rb, (size_t)(lane_off + (uint32_t)col[c]), v);
                     }
                 }
             } else {
@@ -288,12 +315,11 @@ __device__ __forceinline__ void pfh_store_tile(const ACC& acc, int nsb, int rows
                 for (int i = 0; i < 4; i++)
                     if (rowb + i < rows) {
 #pragma unroll
-                        for (int c = 0; c < NC; c++)
+                        for (int c = 0; c < NCS; c++)
                             if (col[c] < N) {
-                                const float v = acc[s][c][rq * 4 + i] * rm[i];
-                                const size_t o = (size_t)rd[i] * out_ld + col[c];
-                                if (BF16) reinterpret_cast<uint16_t*>(out_p)[o] = kr_f32_to_bf16(v);
-                                else reinterpret_cast<float*>(out_p)[o] = v;
+                                float v = acc[s][c][rq * 4 + i] * rm[i];
+                                if (ACT) v = pfh_act(ACTF, v, acc[s][NC - 1][rq * 4 + i] * rm[i], limit, alpha);
+                                pfh_put<OT>(out_p, (size_t)rd[i] * out_ld + col[c], v);
                             }
                     }
             }
@@ -321,6 +347,7 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
     int* row_idx = row_dst + PFH_BM;                               // [64] source row (G = 1: addresses the per-32 sums)
 
     PFH_STAMPW(6);
+    const bool actf = NC == 2 && a.act_fused != 0;       // uniform; N = 2 I with I % 128 == 0 (the launcher checks): a tile = 128 gate + the 128 matching up columns
     const int ncb0 = (a.m.N + BN - 1) / BN, ncb1 = a.n_extra > 0 ? (a.mx[0].N + BN - 1) / BN : 0, ncb2 = a.n_extra > 1 ? (a.mx[1].N + BN - 1) / BN : 0;
     const int ncb = ncb0 + ncb1 + ncb2, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     int mt, cb;
@@ -360,10 +387,17 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
     const int n31 = lane & 31, khalf = lane >> 5;
     uint32_t M0 = 0x000F000Fu, M1 = 0x00F000F0u, MH = 0x03C003C0u, Kc = 0x64006400u;      // de-quantization masks, kept in registers (see pfh_dq4)
     asm volatile("" : "+v"(M0), "+v"(M1), "+v"(MH), "+v"(Kc));
-    const int cbase = wave * (32 * NC);
-    int col[NC], ctile[NC], cin[NC];
+    // column blocks of a wave inside the tile's 128 NC local columns: consecutive (wave * 32 NC + 32 c), or -- fused activation -- block c of the
+    // gate half / up half (local 128 c + 32 wave), so that accumulator element (c = 0, r) and (c = 1, r) of a lane are one (gate, up) pair
+    const int half_n = m.N >> 1, n0h = cb * 128;
+    int col[NC], ctile[NC], cin[NC], lcolb[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) { col[c] = n0 + cbase + c * 32 + n31; const int cc = col[c] < m.N ? col[c] : m.N - 1; ctile[c] = cc >> 3; cin[c] = cc & 7; }
+    for (int c = 0; c < NC; c++) {
+        const int lc = actf ? c * 128 + wave * 32 + n31 : wave * (32 * NC) + c * 32 + n31;
+        lcolb[c] = lc * LDB;
+        col[c] = actf ? c * half_n + n0h + wave * 32 + n31 : n0 + lc;
+        const int cc = col[c] < m.N ? col[c] : m.N - 1; ctile[c] = cc >> 3; cin[c] = cc & 7;
+    }
 
     constexpr int APT = 8;                         // 16-byte A chunks per thread per stage (4 threads per row, 128 B each)
     constexpr int RPT = BN * 8 / 256;              // B lane records per thread (per group for INT8)
@@ -389,7 +423,9 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
     uint32_t brec[RPT];                                              // byte offset of this wave's tile records inside the expert's block (scalars)
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
-        int tile = (n0 >> 3) + wv + 4 * j; tile = tile < last_tile ? tile : last_tile;
+        int tile = (n0 >> 3) + wv + 4 * j;
+        if (actf) tile = (n0h >> 3) + wv + 4 * (j % (RPT / 2)) + (j >= RPT / 2 ? half_n >> 3 : 0);
+        tile = tile < last_tile ? tile : last_tile;
         brec[j] = (uint32_t)__builtin_amdgcn_readfirstlane(tile * (BITS == 8 ? m.ng : m.ngp) * 1024);
     }
     auto load_B = [&](int st) {      // scales + weight records of a stage: they do not depend on the row table
@@ -511,7 +547,7 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
                     af[buf][s2][1] = *reinterpret_cast<const v8h*>(As + (s2 * 32 + n31) * LDA + hh * 256 + lp * 32 + 16);
                 }
 #pragma unroll
-                for (int c = 0; c < NC; c++) br2[buf][c] = *reinterpret_cast<const u32x2*>(Bs + (cbase + c * 32 + n31) * LDB + lp * 16 + hh * 8);
+                for (int c = 0; c < NC; c++) br2[buf][c] = *reinterpret_cast<const u32x2*>(Bs + lcolb[c] + lp * 16 + hh * 8);
             };
             v2h sqs[NC], cqs[NC];            // G = 1: scale / constant of the step being de-quantized
             auto step_scale = [&](int t) {
@@ -568,8 +604,8 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
             }
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                if (BITS == 8) br[buf][c] = *reinterpret_cast<const u32x4*>(Bs + (cbase + c * 32 + n31) * LDB + hh * 128 + lp * 16);
-                else { const u32x2 pk = *reinterpret_cast<const u32x2*>(Bs + (cbase + c * 32 + n31) * LDB + lp * 16 + hh * 8); br[buf][c].x = pk.x; br[buf][c].y = pk.y; }
+                if (BITS == 8) br[buf][c] = *reinterpret_cast<const u32x4*>(Bs + lcolb[c] + hh * 128 + lp * 16);
+                else { const u32x2 pk = *reinterpret_cast<const u32x2*>(Bs + lcolb[c] + lp * 16 + hh * 8); br[buf][c].x = pk.x; br[buf][c].y = pk.y; }
             }
         };
         auto dq = [&](int t, int buf) {
@@ -645,15 +681,17 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
         }
     }
     PFH_STAMPW(8);
-    if (tid < PFH_BM) rmul[tid] = mulv;
+    if (tid < PFH_BM) rmul[tid] = a.out_bf16 == 2 ? 1.0f : mulv;      // f16 rows carry the raw accumulators: the combine pass applies the row multiplier
     __syncthreads();
     {
-        const bool full = rows == (two ? 64 : 32) && n0 + BN <= m.N && !(a.scatter_rows && !a.single_expert);     // uniform
+        const bool full = rows == (two ? 64 : 32) && (actf || n0 + BN <= m.N) && !(a.scatter_rows && !a.single_expert);     // uniform
         const int nsb = two ? 2 : 1;
-        if (full) { if (a.out_bf16) pfh_store_tile<NS, NC, true, true>(acc, nsb, rows, row0, rmul, row_dst, out_p, out_ld, col, m.N, lane);
-                    else pfh_store_tile<NS, NC, true, false>(acc, nsb, rows, row0, rmul, row_dst, out_p, out_ld, col, m.N, lane); }
-        else { if (a.out_bf16) pfh_store_tile<NS, NC, false, true>(acc, nsb, rows, row0, rmul, row_dst, out_p, out_ld, col, m.N, lane);
-               else pfh_store_tile<NS, NC, false, false>(acc, nsb, rows, row0, rmul, row_dst, out_p, out_ld, col, m.N, lane); }
+#define PFH_ST(F_, OT_, A_) pfh_store_tile<NS, NC, F_, OT_, A_>(acc, nsb, rows, row0, rmul, row_dst, out_p, out_ld, col, m.N, lane, a.act_fused, a.act_limit, a.act_alpha)
+        if (NC == 2 && a.act_fused) { if (full) PFH_ST(true, 0, NC == 2); else PFH_ST(false, 0, NC == 2); }
+        else if (a.out_bf16 == 1) { if (full) PFH_ST(true, 1, false); else PFH_ST(false, 1, false); }
+        else if (a.out_bf16 == 2) { if (full) PFH_ST(true, 2, false); else PFH_ST(false, 2, false); }
+        else { if (full) PFH_ST(true, 0, false); else PFH_ST(false, 0, false); }
+#undef PFH_ST
     }
     PFH_STAMPW(9);
 }
@@ -722,6 +760,32 @@ void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_m
     a.run = (single_expert_rows > 0 || run < 1) ? 1 : run;
     const int mt = single_expert_rows > 0 ? (single_expert_rows + PFH_BM - 1) / PFH_BM : max_tiles;
     pfh_dispatch(a, mt, st);
+}
+// gate | up GEMM + activation -> the f16 hidden rows (+ multipliers, + per-32 sums for a Q4_K down copy).  Big problems (the 64 x 256 tile form) with
+// I % 128 == 0 form h in the GEMM's epilogue: `gu` then holds [rows][I] f32 hidden values instead of [rows][2 I] gate | up values, and the row pass
+// only makes the f16 form.  Otherwise: the GEMM, then the activation pass over gate | up rows.  Same arithmetic either way.
+void kr_launch_pfh_w13_act(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
+                           int single_expert_rows, float* gu, int rows, int act_mode, float swiglu_limit, float alpha, uint16_t* h_out, float* h_mul,
+                           hipStream_t st, int run, const uint16_t* a_sum32, uint16_t* h_sums32) {
+    const int I = m.N / 2;
+    const int mt = single_expert_rows > 0 ? (single_expert_rows + PFH_BM - 1) / PFH_BM : max_tiles;
+    const bool fuse = m.bits == 4 && I % 128 == 0 && I <= 2048 && (long)mt * (m.N / 128) >= 2048;
+    if (!fuse) {
+        kr_launch_pfh_gemm(m, a_h, a_mul, sort, topk, gather_tokens, max_tiles, single_expert_rows, gu, 2 * I, st, 0, 0, run, a_sum32);
+        kr_launch_pfh_act(gu, rows, I, 2 * I, act_mode, swiglu_limit, alpha, h_out, h_mul, st, h_sums32);
+        return;
+    }
+    KrPfGemmHArgs a{};
+    a.m = m; a.a = a_h; a.a_mul = a_mul; a.a_sum = a_sum32; a.topk = topk; a.gather_tokens = gather_tokens;
+    if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
+    a.out = gu; a.out_ld = I; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
+    a.run = (single_expert_rows > 0 || run < 1) ? 1 : run;
+    a.act_fused = act_mode == KR_ACT_GPTOSS ? 2 : (act_mode == KR_ACT_SILU_LIBM ? 3 : 1); a.act_limit = swiglu_limit; a.act_alpha = alpha;
+    if (m.qs) pfh_launch<2, 4, 1, 1>(a, mt, st); else pfh_launch<2, 4, 1>(a, mt, st);
+    const int cpl = I <= 512 ? 1 : (I <= 1024 ? 2 : 4);
+#define KR_ROWW(C_) hipLaunchKernelGGL((kr_pfh_act_wave_kernel<KR_ACT_NONE, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float*)gu, rows, I, I, 0.0f, 0.0f, h_out, h_mul, h_sums32)
+    if (rows > 0) { if (cpl == 1) KR_ROWW(1); else if (cpl == 2) KR_ROWW(2); else KR_ROWW(4); }
+#undef KR_ROWW
 }
 void kr_launch_pfh_gemm_multi(const KrMatDev* mats, float* const* outs, const int* out_lds, int n, const uint16_t* a_h, const float* a_mul, int M, hipStream_t st) {
     KrPfGemmHArgs a{};

@@ -81,6 +81,14 @@ q4k)        # Q4_K tolerance form: parity test, experts-only timing (exact int8 
     timeout 900 python -m pytest tests/test_tolerance_peaked_gpu.py tests/test_moe_gpu.py -x -q 2>&1 | tail -5
     cat $R/r03_tolerance_peaked.txt 2>/dev/null
     ;;
+gemmtrace)  # kernel trace of the experts-only tolerance pass (which launches carry the 1.2 ms per layer)
+    kstats r03_experts_8192_gemm_fast "QCN experts only, 8192 tokens x 16 layers, tolerance GEMM (tools/probes/experts_gemm_probe.py 16 8192 fast)" -- python /root/repo/tools/probes/experts_gemm_probe.py 16 8192 fast
+    ;;
+gemmchk)    # tolerance GEMM after a change: parity tests of the tolerance forms, experts-only timing, kernel trace
+    timeout 1200 python -m pytest tests/test_gemm_fast_gpu.py tests/test_gguf_gpu.py tests/test_tolerance_peaked_gpu.py -x -q 2>&1 | tail -6
+    timeout 300 python tools/probes/experts_gemm_probe.py 48 8192 fast,q4kfast 2>&1 | grep experts-only
+    kstats r03_experts_8192_gemm_fast "QCN experts only, 8192 tokens x 16 layers, tolerance GEMM (tools/probes/experts_gemm_probe.py 16 8192 fast)" -- python /root/repo/tools/probes/experts_gemm_probe.py 16 8192 fast
+    ;;
 stamps)
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     ;;
