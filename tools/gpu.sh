@@ -62,6 +62,13 @@ gemmab2)    # shipped library vs the A/B build (make -C krasis_amd/csrc ab AB_SR
         KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_ab.so timeout 300 python tools/probes/experts_gemm_probe.py 48 8192 fast 2>&1 | grep experts-only | sed 's/^/ab:      /'
     done
     ;;
+gemmab3)    # A/B build: parity tests of the tolerance forms on the A/B library, then interleaved timing
+    KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_ab.so timeout 900 python -m pytest tests/test_gemm_fast_gpu.py tests/test_gguf_gpu.py -x -q 2>&1 | tail -4
+    for rep in 1 2; do
+        timeout 300 python tools/probes/experts_gemm_probe.py 48 8192 fast,q4kfast 2>&1 | grep experts-only | sed 's/^/shipped: /'
+        KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_ab.so timeout 300 python tools/probes/experts_gemm_probe.py 48 8192 fast,q4kfast 2>&1 | grep experts-only | sed 's/^/ab:      /'
+    done
+    ;;
 fastpmc)    # HBM fetch bytes per launch of the KR_DECODE_FAST kernels: counters-only pass (separate from the trace), then the kernel trace of the same command
     rm -rf $R/pmc_fast
     (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $R/pmc_fast --output-format csv -- python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 12 --route-tokens 0 --out /root/repo/gpurun_out/r03_decode_fast_pmcrun > $R/pmc_fast.log 2>&1)
