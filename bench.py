@@ -602,17 +602,21 @@ def cpu_baseline(max_seconds, L):
                       "~1.9 GB streamed from DRAM), AVX2+OpenMP port of avx2.rs:1066 on tiled weights; norms/attention/state omitted "
                       "(optimistic for the CPU)" % L, ms_per_token=t_tok * 1e3)
     try:
-        res["v2lite_q4k_cpu"] = cpu_v2lite_q4k(min(2.0, max_seconds * 0.4), best_c)
+        res["v2lite_q4k_cpu"] = cpu_v2lite_q4k(min(8.0, max_seconds * 0.5), best_c)
     except Exception as ex:
         res["v2lite_q4k_cpu"] = {"error": repr(ex)}
     return res
 
 
 def cpu_v2lite_q4k(budget, threads):
-    """BASELINE config 1 (DeepSeek-V2-Lite Q4_K int4cpu pure-CPU decode): the MoE part of one token through the oracle's restatement of
-    moe_forward_gguf (moe.rs:990 -> gguf_kernels.rs:690: Q4_K gate/up, Q8_0 down since 1408 is not a multiple of 256), 26 layers x (6 routed
-    + 2 shared-width experts).  Experts only, scalar single-thread port (cores = 1); synthetic blocks per SURVEY 8d
-    (d = f16((0.005 + u * 0.045) / 63), dmin = f16(8 d), raw scale / quant bytes; Q8_0: d = f16((0.005 + u * 0.045) / 127))."""
+    """BASELINE config 1 (DeepSeek-V2-Lite Q4_K int4cpu pure-CPU decode, testconfigs/v2lite-4-4.conf): the quantized matvecs of ONE WHOLE TOKEN on
+    this host's cores -- 27 layers of MLA projections (q, kv_a, kv_b, o), the dense MLP of layer 0, 26 MoE layers of 6 routed experts + the
+    shared expert (I = 2 x 1408) through moe_forward_gguf (moe.rs:990 -> gguf_kernels.rs:690: Q4_K gate / up, Q8_0 down where the row length
+    is not a multiple of 256) and lm_head -- with the AVX2 integer rows of gguf_kernels.rs:271-432 (oracle q4k_row_avx2 / q8_0_row_avx2,
+    bit-identical to the scalar oracle: tests/test_oracle_avx2.py) and the output rows of every matvec split over an OpenMP team (rayon in the
+    reference).  Every layer has its own weights (~1.7 GB per token: streams from DRAM).  Norms, rope, the attention itself and the router are
+    left out (optimistic for the CPU).  Synthetic blocks per SURVEY 8d (d = f16((0.005 + u * 0.045) / 63), dmin = f16(8 d), raw scale / quant
+    bytes; Q8_0: d = f16((0.005 + u * 0.045) / 127))."""
     import numpy as np
     from oracle import oracle as O
     v = V2L; H, I, k = v["hidden"], v["inter"], v["topk"]
@@ -631,21 +635,70 @@ def cpu_v2lite_q4k(budget, threads):
             raw[:, :, 2] = dm & 0xFF; raw[:, :, 3] = dm >> 8
         return np.ascontiguousarray(raw.reshape(rows, nb * bb))
 
-    n_layers = 26
-    experts = [O.GgufExpert(blocks(O.Q4_K, I, H), blocks(O.Q4_K, I, H), blocks(O.Q8_0, H, I), O.Q4_K, O.Q8_0, H, I) for _ in range((k + 2) * 2)]
-    act = O.f32_to_bf16(((rng.random(H) - 0.5)).astype(np.float32)); w = np.full(k + 2, 1.0 / (k + 2), np.float32)
+    def mat(rows, K):                       # the type the int4cpu build gives a [rows, K] matrix: Q4_K when K is a multiple of 256, else Q8_0
+        t = O.Q4_K if K % 256 == 0 else O.Q8_0
+        return (t, blocks(t, rows, K), rows, K)
+
+    def expert(inter):
+        dt = O.Q4_K if inter % 256 == 0 else O.Q8_0
+        return O.GgufExpert(blocks(O.Q4_K, inter, H), blocks(O.Q4_K, inter, H), blocks(dt, H, inter), O.Q4_K, dt, H, inter)
+
+    n_layers, nh = 27, 16
+    kv_lora, rope, nope, vd = v["klr"], v["rd"], v["nd"], v["vhd"]
+    layers = []
+    for l in range(n_layers):
+        attn = [mat(nh * (nope + rope), H), mat(kv_lora + rope, H), mat(nh * (nope + vd), kv_lora), mat(H, nh * vd)]
+        if l == 0:
+            layers.append((attn, None, None, [mat(v["dense_inter"], H), mat(v["dense_inter"], H), mat(H, v["dense_inter"])]))
+        else:
+            layers.append((attn, [expert(I) for _ in range(k)], expert(2 * I), None))
+    lm = mat(v["vocab"], H)
+    act = O.f32_to_bf16(((rng.random(H) - 0.5)).astype(np.float32)); w = np.full(k, 1.0 / k, np.float32)
+    qx = {}
+    for K in sorted({H, kv_lora, nh * vd, v["dense_inter"]}):
+        qx[K] = O.gguf_quant_f32(((rng.random(K) - 0.5)).astype(np.float32))
+
+    def mv(m):
+        q, s, sm = qx[m[3]]
+        O.gguf_matvec_int(m[0], m[1], q, s, sm, m[2], m[3])
 
     def token():
-        for l in range(n_layers):          # two layers' worth of distinct experts, alternated
-            O.moe_forward_gguf(experts[(l % 2) * (k + 2): (l % 2 + 1) * (k + 2)], w, act)
+        for attn, routed, shared, dense in layers:
+            for m in attn:
+                mv(m)
+            if dense is not None:
+                for m in dense:
+                    mv(m)
+            else:
+                O.moe_forward_gguf(routed, w, act, shared=shared, rsf=1.0)
+        mv(lm)
 
-    token(); n, t0 = 0, time.perf_counter()
-    while n == 0 or time.perf_counter() - t0 < budget:
-        token(); n += 1
-    t = (time.perf_counter() - t0) / n
-    return {"value": 1.0 / t, "unit": "tok/s (MoE experts of one token only)", "ms_per_token": t * 1e3, "cores": 1, "kind": "port",
+    n_bytes = sum(m[1].nbytes for L_ in layers for m in L_[0]) + sum(m[1].nbytes for L_ in layers if L_[3] for m in L_[3]) + lm[1].nbytes
+    n_bytes += sum(e.gate.nbytes + e.up.nbytes + e.down.nbytes for L_ in layers if L_[1] for e in L_[1] + [L_[2]])
+
+    def timed(nt, b):
+        O.set_num_threads(nt)
+        token(); n, t0 = 0, time.perf_counter()
+        while n == 0 or time.perf_counter() - t0 < b:
+            token(); n += 1
+        return (time.perf_counter() - t0) / n
+
+    O.gguf_set_avx2(True)
+    try:
+        hw = O.num_threads()
+        cands = sorted({c for c in (8, 16, 32, 64, threads, hw) if 0 < c <= hw})
+        sweep = {c: timed(c, budget * 0.5 / len(cands)) for c in cands}
+        best = min(sweep, key=sweep.get)
+        t = timed(best, budget * 0.5)
+    finally:
+        O.gguf_set_avx2(False); O.set_num_threads(threads)
+    return {"value": 1.0 / t, "unit": "tok/s", "ms_per_token": t * 1e3, "cores": best, "host_threads": hw, "kind": "port",
+            "tok_s_by_threads": {c: round(1.0 / x, 2) for c, x in sweep.items()}, "weight_bytes_per_token": int(n_bytes),
+            "dram_GBs": n_bytes / t / 1e9,
             "workload": "DeepSeek-V2-Lite Q4_K int4cpu pure-CPU decode (testconfigs/v2lite-4-4.conf, no GPU)",
-            "sample": "26 MoE layers x 8 native-GGUF experts (Q4_K gate/up, Q8_0 down) through kro_moe_forward_gguf (scalar restatement of gguf_kernels.rs:690)"}
+            "sample": "whole-token passes over one token's weights: 27 x MLA projections, dense MLP of layer 0, 26 x (6 routed + shared native-GGUF experts: Q4_K gate/up, "
+                      "Q8_0 down at I = 1408, Q4_K at 2816) through kro_moe_forward_gguf, lm_head; AVX2 integer rows (gguf_kernels.rs:271-432) + OpenMP over "
+                      "output rows; norms / rope / attention / router omitted (optimistic for the CPU)"}
 
 
 def main():

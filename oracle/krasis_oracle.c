@@ -663,6 +663,57 @@ void kro_gguf_matvec_f32(int t, const uint8_t* w, const float* x, int n, int k, 
 
 static int gguf_int_path(int t) { return t == KRO_Q4_K || t == KRO_Q8_0 || t == KRO_Q4_0; } /* gguf_kernels.rs:99 */
 
+/* The same two rows with the host's AVX2 units (matvec_q4_k_avx2 / matvec_q8_0_avx2, gguf_kernels.rs:271-432): _mm256_madd_epi16 over
+ * 16 widened weights x 16 INT16 activations leaves lane l = w[2l] a[2l] + w[2l+1] a[2l+1]; the two halves of a 32-value sub-block are added
+ * as integers, converted, and enter the 8 f32 lane accumulators by one fused multiply-add with d * sc * a_scale; the min correction is a
+ * scalar chain.  Bit-identical to q4k_row / q8_0_row above (tests/test_oracle_avx2.py) -- those are this code with the lanes spelled out. */
+static void q4k_row_avx2(const uint8_t* row, int nblk, const int16_t* a, const float* a_s, const int32_t* a_sum, float* out) {
+    __m256 acc = _mm256_setzero_ps();
+    const __m128i m4 = _mm_set1_epi8(0x0F);
+    float corr = 0.0f;
+    for (int b = 0; b < nblk; b++) {
+        const uint8_t* blk = row + (size_t)b * 144;
+        float d = kro_f16_to_f32(rd16(blk)), dmin = kro_f16_to_f32(rd16(blk + 2));
+        const uint8_t* sp = blk + 4; const uint8_t* quants = blk + 16;
+        const int16_t* ab = a + (size_t)b * 256; int gb = b * 8;
+        for (int j = 0; j < 4; j++) {
+            uint8_t sc_lo, mn_lo, sc_hi, mn_hi;
+            kro_get_scale_min_k4(2 * j, sp, &sc_lo, &mn_lo); kro_get_scale_min_k4(2 * j + 1, sp, &sc_hi, &mn_hi);
+            const __m128i q0 = _mm_loadu_si128((const __m128i*)(quants + j * 32)), q1 = _mm_loadu_si128((const __m128i*)(quants + j * 32 + 16));
+            int lo_g = gb + j * 2, hi_g = lo_g + 1;
+            float as_lo = a_s[lo_g], as_hi = a_s[hi_g];
+            const int16_t* al = ab + j * 64;
+            __m256i ilo = _mm256_add_epi32(_mm256_madd_epi16(_mm256_cvtepu8_epi16(_mm_and_si128(q0, m4)), _mm256_loadu_si256((const __m256i*)al)),
+                                           _mm256_madd_epi16(_mm256_cvtepu8_epi16(_mm_and_si128(q1, m4)), _mm256_loadu_si256((const __m256i*)(al + 16))));
+            __m256i ihi = _mm256_add_epi32(_mm256_madd_epi16(_mm256_cvtepu8_epi16(_mm_and_si128(_mm_srli_epi16(q0, 4), m4)), _mm256_loadu_si256((const __m256i*)(al + 32))),
+                                           _mm256_madd_epi16(_mm256_cvtepu8_epi16(_mm_and_si128(_mm_srli_epi16(q1, 4), m4)), _mm256_loadu_si256((const __m256i*)(al + 48))));
+            float comb_lo = d * (float)sc_lo * as_lo;
+            acc = _mm256_fmadd_ps(_mm256_cvtepi32_ps(ilo), _mm256_set1_ps(comb_lo), acc);
+            corr += dmin * (float)mn_lo * as_lo * (float)a_sum[lo_g];
+            float comb_hi = d * (float)sc_hi * as_hi;
+            acc = _mm256_fmadd_ps(_mm256_cvtepi32_ps(ihi), _mm256_set1_ps(comb_hi), acc);
+            corr += dmin * (float)mn_hi * as_hi * (float)a_sum[hi_g];
+        }
+    }
+    float lanes[8]; _mm256_storeu_ps(lanes, acc);
+    *out = hsum8(lanes) - corr;
+}
+static void q8_0_row_avx2(const uint8_t* row, int nblk, const int16_t* a, const float* a_s, float* out) {
+    __m256 acc = _mm256_setzero_ps();
+    for (int b = 0; b < nblk; b++) {
+        const uint8_t* blk = row + (size_t)b * 34; float d = kro_f16_to_f32(rd16(blk));
+        float comb = d * a_s[b];
+        const int16_t* ab = a + (size_t)b * 32;
+        __m256i v = _mm256_add_epi32(_mm256_madd_epi16(_mm256_cvtepi8_epi16(_mm_loadu_si128((const __m128i*)(blk + 2))), _mm256_loadu_si256((const __m256i*)ab)),
+                                     _mm256_madd_epi16(_mm256_cvtepi8_epi16(_mm_loadu_si128((const __m128i*)(blk + 18))), _mm256_loadu_si256((const __m256i*)(ab + 16))));
+        acc = _mm256_fmadd_ps(_mm256_cvtepi32_ps(v), _mm256_set1_ps(comb), acc);
+    }
+    float lanes[8]; _mm256_storeu_ps(lanes, acc);
+    *out = hsum8(lanes);
+}
+static int g_gguf_avx2 = 0;   /* kro_gguf_set_avx2: rows through the AVX2 forms, output rows split over the OpenMP team (rayon in the reference) */
+void kro_gguf_set_avx2(int on) { g_gguf_avx2 = on; }
+
 void kro_gguf_matvec_int(int t, const uint8_t* w, const int16_t* a, const float* a_s, const int32_t* a_sum,
                          int n, int k, float* out) {
     size_t bs = kro_ggml_block_size(t), bb = kro_ggml_block_bytes(t);
@@ -672,6 +723,14 @@ void kro_gguf_matvec_int(int t, const uint8_t* w, const int16_t* a, const float*
         for (int g = 0; g < k / 32; g++) for (int i = 0; i < 32; i++) xf[g * 32 + i] = (float)a[g * 32 + i] * a_s[g];
         kro_gguf_matvec_f32(t, w, xf, n, k, out);
         free(xf); return;
+    }
+    if (g_gguf_avx2 && t != KRO_Q4_0) {
+#pragma omp parallel for schedule(static) if (n >= 256)
+        for (int r = 0; r < n; r++) {
+            const uint8_t* row = w + (size_t)r * row_bytes;
+            if (t == KRO_Q4_K) q4k_row_avx2(row, nblk, a, a_s, a_sum, out + r); else q8_0_row_avx2(row, nblk, a, a_s, out + r);
+        }
+        return;
     }
     for (int r = 0; r < n; r++) {
         const uint8_t* row = w + (size_t)r * row_bytes;

@@ -91,6 +91,9 @@ void kro_matvec_int4_rowmajor(const uint32_t* packed, const uint16_t* scales, co
 /* gguf_kernels.rs:271/379/436 (int16 act, AVX2 lane order) ; weights [N, K/blk] raw blocks */
 void kro_gguf_matvec_int(int dtype, const uint8_t* w, const int16_t* a, const float* a_s, const int32_t* a_sum,
                          int n, int k, float* out);
+/* Q4_K / Q8_0 rows of kro_gguf_matvec_int through AVX2 intrinsics with the output rows split over the OpenMP team (bit-identical results;
+ * bench.py's config-1 CPU leg).  Off by default: the scalar lane-by-lane form is the oracle the tests read. */
+void kro_gguf_set_avx2(int on);
 /* gguf_kernels.rs:495-635 scalar f32 activation fallbacks */
 void kro_gguf_matvec_f32(int dtype, const uint8_t* w, const float* x, int n, int k, float* out);
 

@@ -265,6 +265,11 @@ def gguf_matvec_int(t, w, a, a_s, a_sum, n, k):
     return out
 
 
+def gguf_set_avx2(on: bool):
+    """Q4_K / Q8_0 integer rows through the AVX2 + OpenMP forms (same bits as the scalar lane form; tests/test_oracle_avx2.py)"""
+    lib().kro_gguf_set_avx2(1 if on else 0)
+
+
 def gguf_matvec_f32(t, w, x, n, k):
     w = _c(w, np.uint8); x = _c(x, np.float32)
     out = np.empty(n, np.float32)
