@@ -63,8 +63,14 @@ def pmc_traffic(symbol):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
         try:
             d = json.load(open(f))
-            if symbol in d.get("kernels", {}):
-                return d["kernels"][symbol], os.path.basename(f)
+            ks = d.get("kernels", {})
+            if symbol in ks:
+                return ks[symbol], os.path.basename(f)
+            if "|" in symbol:      # a kind launched in several template forms, equally often ("kr_fdm_kernel<4,1,8>|<4,4,4>"): mean over the forms
+                parts = symbol.split("|"); base = parts[0].split("<")[0]
+                names = [parts[0]] + [(base + x if x.startswith("<") else x) for x in parts[1:]]
+                if all(n in ks for n in names):
+                    return sum(ks[n] for n in names) / len(names), os.path.basename(f) + " (mean of " + ", ".join(names) + ")"
         except Exception:
             pass
     return None, None

@@ -337,7 +337,7 @@ int kr_decode_num_route_weights(kr_decode_store* s);                            
 size_t kr_decode_weight_bytes(kr_decode_store* s, int weight_id);                                                             /* decode.rs:1107 */
 int kr_decode_last_token(kr_decode_store* s, int* token);
 int kr_decode_set_use_graph(kr_decode_store* s, int enable);
-int kr_decode_read_buffer(kr_decode_store* s, int which /*0 hidden, 1 residual*/, float* out, int n);
+int kr_decode_read_buffer(kr_decode_store* s, int which /* 0 hidden, 1 residual, 2 router ids (i32 bits), 3 router weights, 4 router logits, 5 second residual (KR_DECODE_FAST) */, float* out, int n);
 size_t kr_decode_device_bytes(const kr_decode_store* s);
 /* measurement hook (bench.py): one un-graphed step with HIP events around every launch; per-kind totals (ms) and launch counts.
  * kinds: 0 embed 1 fused_add_rmsnorm 2 projection matvec 3 la_conv 4 la_recurrent 5 gated_rmsnorm_silu 6 gqa 7 route_logits
