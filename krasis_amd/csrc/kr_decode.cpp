@@ -656,7 +656,8 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             if (s->own_eng || L.moe_layer >= (int)e->layers.size()) return kr_fail(KR_ERR_STATE, "set_moe_store was not called (MoE layer %d has no engine)", L.moe_layer);
             Layer& EL = e->layers[L.moe_layer];
             if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
-            if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
+            if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, EL.gguf ? "MoE layer %d holds native GGUF blocks: the decode step runs on INT4 / INT8 transposed experts (decode.rs:3330 calls moe_forward_unified); kr_decode_prefill and kr_moe_forward take GGUF layers"
+                                                                       : "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
             if (fast) {   // norm + gate GEMV | select + gate|up + silu*up | down + combine: three launches, the MoE output lands in `hid`
                 const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
                 KrFmoeArgs fa{}; KrMoeArgs& a = fa.m;

@@ -169,7 +169,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
     if (L.mlp == MLP_MOE) {
         Layer& EL = e->layers[L.moe_layer];
         if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
-        if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
+        if (!EL.w13.allocated() && !EL.gguf) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);   // native GGUF layers: kr_moe_prefill_set walks the block kernels
         const int E = e->r_ne;
         const float* rbias = EL.has_bias ? (const float*)EL.bias.p : nullptr;
         if (!(Cc >= 32 && EL.gate_row.p && 0 == kr_launch_route_logits_mfma(EL.gate_row.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st)))

@@ -42,7 +42,11 @@ class OracleDecode:
         else:
             ids, w = ids_w
         act = O.f32_to_bf16(hidden)
-        moe = O.moe_forward_unified([L["experts"][i] for i in ids], np.asarray(w, F), act)
+        sel = [L["experts"][i] for i in ids]
+        if sel and isinstance(sel[0], O.GgufExpert):      # native GGUF layer (moe.rs:990 moe_forward_gguf): only the prompt pass takes these
+            moe = O.moe_forward_gguf(sel, np.asarray(w, F), act)
+        else:
+            moe = O.moe_forward_unified(sel, np.asarray(w, F), act)
         if self.rsf != F(1.0):
             moe = (moe * self.rsf).astype(F)
         if L.get("sgu") is not None:

@@ -15,7 +15,7 @@ def _ptr(a):
     return a.ctypes.data
 
 
-def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4, dims=None, kinds=None, la_heads=(2, 4), peaked=False):
+def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4, dims=None, kinds=None, la_heads=(2, 4), peaked=False, gguf=False):
     """peaked=True: a model whose next-token distribution is PEAKED without training -- large embeddings, lm_head tied to them (x 0.05): the logit of the
     current token stands ~8 above the rest, the layers (attention, router, experts) perturb it by an amount comparable to the noise floor, so on a token
     stream with repeats the perplexity is O(10) and a routing flip or a tolerance-mode rounding difference shows up in it (tests/test_tolerance_peaked_gpu.py)"""
@@ -84,7 +84,14 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbit
             dw = (st.store_weight_f32(_ptr(wd), H, DI, wbits), orc.store_weight_f32(wd, wbits))
             st.set_decode_layer_dense(li, gw[0], uw[0], dw[0]); L.update(mlp="dense", gate_w=gw[1], up_w=uw[1], down_w=dw[1])
         else:
-            experts = make_experts(rng, E, H, I, wbits); upload(eng, li, experts)
+            if gguf:      # routed experts as native GGUF blocks (Q4_K gate / up; down Q4_K when I % 256 == 0, else Q8_0 -- the V2-Lite situation): prompt pass only
+                from tests.test_gguf_gpu import make as make_gguf
+                dn_t = O.Q4_K if I % 256 == 0 else O.Q8_0
+                experts = [make_gguf(rng, H, I, O.Q4_K, dn_t) for _ in range(E)]
+                for ei, ex in enumerate(experts):
+                    eng.load_gguf_expert(li, ei, ex.gate, ex.up, ex.down, O.Q4_K, dn_t, I)
+            else:
+                experts = make_experts(rng, E, H, I, wbits); upload(eng, li, experts)
             gate = ((rng.random((E, H)) - 0.5) * 0.1).astype(F); keep.append(gate)
             esc = ((rng.random(E) - 0.5) * 0.01).astype(F) if scoring == 0 else None
             eng.set_route_weight_f32(li, gate, None, esc)

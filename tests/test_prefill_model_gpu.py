@@ -52,6 +52,54 @@ def test_prefill_equals_sequential_decode(cfg, n_tok, start, chunk, depth):
     assert np.isfinite(nxt).all()
 
 
+@pytest.mark.parametrize("dims,n_tok,chunk", [((256, 512, 16, 4, 128, 128), 9, 0), ((256, 512, 16, 4, 128, 128), 20, 6), ((512, 512, 8, 2, 256, 128), 12, 0)])
+def test_prefill_with_native_gguf_experts_matches_the_oracle_driver(dims, n_tok, chunk):
+    """A model whose ROUTED experts are native GGUF blocks (Q4_K gate / up, Q8_0 or Q4_K down) through kr_decode_prefill, against the oracle driver
+    (decode.rs:2690-3520 control flow with moe_forward_gguf, moe.rs:990, as the routed-expert block).  The prompt pass runs the int8-MFMA block GEMM
+    at every chunk size: exact integer sub-block sums, ONE f32 chain per output instead of the AVX2 kernel's 8 lane chains + hsum -- STATED TOLERANCE
+    2e-5 of the largest logit (tests/test_gguf_gpu.py states the same for the operator; measured ~1e-6), same greedy token.  The decode STEP refuses
+    such layers (decode.rs:3330 runs moe_forward_unified) with a message that says so."""
+    st, eng, orc, keep, d = build(dims=dims, gguf=True, seed=11)
+    st.set_prefill_chunk(chunk)
+    rng = np.random.default_rng(n_tok)
+    toks = [int(x) for x in rng.integers(0, d["V"], n_tok)]
+    logits = np.empty(d["V"], F)
+    st.prefill(toks, 5, logits.ctypes.data)
+    ref = None
+    for i, t in enumerate(toks):
+        ref = orc.step(t, 5 + i)
+    err = float(np.abs(logits - ref).max() / np.abs(ref).max())
+    assert err <= 2e-5, err
+    assert int(np.argmax(logits)) == int(np.argmax(ref))
+    with pytest.raises(RuntimeError, match="native GGUF"):
+        st.decode_step(1, 5 + n_tok, logits.ctypes.data)
+
+
+def test_prefill_with_native_gguf_experts_mfma_chunks_and_tolerance_form():
+    """80 tokens in one chunk through the int8-MFMA block GEMM (one f32 chain per output instead of 8 lane chains): the last-bit differences of every
+    token's expert outputs reach the last token through the recurrent state and the KV cache -- STATED TOLERANCE 2e-4 of the largest logit against the
+    oracle driver (measured 4.2e-5), same greedy token; with KR_GEMM_FAST the Q4_K layers run the f16 tolerance form
+    (bound 5e-3 of the largest logit against the exact pass; Q8_0 down projections keep the exact form: I = 128 here -> the layer falls back whole)."""
+    for dims, bound_fast in (((256, 512, 16, 4, 128, 128), 5e-3), ((512, 512, 8, 2, 256, 128), 5e-3)):
+        st, eng, orc, keep, d = build(dims=dims, gguf=True, seed=12, kv_max=128)
+        rng = np.random.default_rng(3)
+        toks = [int(x) for x in rng.integers(0, d["V"], 80)]
+        logits = np.empty(d["V"], F)
+        st.prefill(toks, 0, logits.ctypes.data)
+        ref = None
+        for i, t in enumerate(toks):
+            ref = orc.step(t, i)
+        err = float(np.abs(logits - ref).max() / np.abs(ref).max())
+        assert err <= 2e-4, err
+        assert int(np.argmax(logits)) == int(np.argmax(ref))
+        d["reset"]()
+        st.set_attention_mode(False, gemm_fast=True)
+        fast = np.empty(d["V"], F)
+        st.prefill(toks, 0, fast.ctypes.data)
+        errf = float(np.abs(fast - logits).max() / np.abs(logits).max())
+        assert np.isfinite(fast).all() and errf <= bound_fast, errf
+
+
 @pytest.mark.parametrize("hd,nh,fp8", [(128, 8, False), (256, 16, False), (256, 16, True), (128, 4, True), (64, 16, False)])
 def test_prefill_wide_heads_long_prompt(hd, nh, fp8):
     """the head-dim / GQA-group / KV-dtype specialisations of the prompt-pass attention (QCN: head_dim 256, 8 query heads per KV head)

@@ -96,6 +96,11 @@ gemmchk)    # tolerance GEMM after a change: parity tests of the tolerance forms
     timeout 300 python tools/probes/experts_gemm_probe.py 48 8192 fast,q4kfast 2>&1 | grep experts-only
     kstats r03_experts_8192_gemm_fast "QCN experts only, 8192 tokens x 16 layers, tolerance GEMM (tools/probes/experts_gemm_probe.py 16 8192 fast)" -- python /root/repo/tools/probes/experts_gemm_probe.py 16 8192 fast
     ;;
+pfexact)    # exact prompt pass at 8192 tokens: tok/s twice, then the kernel trace
+    timeout 600 python tools/probes/prefill_profile.py 8192 0 2>&1 | tail -3
+    timeout 600 python tools/probes/prefill_profile.py 8192 0 2>&1 | tail -3
+    kstats r03_prefill_exact_8192 "QCN exact prompt pass, 8192 tokens (tools/probes/prefill_profile.py 8192 0)" -- python /root/repo/tools/probes/prefill_profile.py 8192 0
+    ;;
 stamps)
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     ;;
