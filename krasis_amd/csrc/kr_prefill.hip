@@ -32,6 +32,53 @@ __global__ void kr_pf_count_kernel(const int32_t* __restrict__ ids, int n_pairs,
     if (e >= 0 && e < E) atomicAdd(&counts[e], 1);
 }
 
+// The same two passes with the histogram PRIVATE to the workgroup (E <= 1024; 2048 pairs per workgroup): one global atomic per (workgroup, expert
+// present in its slice) instead of one per pair -- with a skewed routing thousands of pairs hit the same counter (the per-pair form took 108 us per
+// pass for the 81 920 pairs of an 8192-token chunk of the synthetic model, 26 us with uniform ids).  The scatter pass re-counts its slice, reserves a
+// contiguous range per expert with ONE atomic on the cursor, then places its pairs with LDS atomics.  Row order inside an expert: any (see above).
+#define KR_PF_WG_PAIRS 2048
+__global__ void __launch_bounds__(256) kr_pf_count_wg_kernel(const int32_t* __restrict__ ids, int n_pairs, int E, int* __restrict__ counts) {
+    __shared__ int s_cnt[1024];
+    const int t = threadIdx.x, base = blockIdx.x * KR_PF_WG_PAIRS;
+    for (int e = t; e < E; e += 256) s_cnt[e] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KR_PF_WG_PAIRS / 256; j++) {
+        const int i = base + j * 256 + t;
+        if (i < n_pairs) { const int e = ids[i]; if (e >= 0 && e < E) atomicAdd(&s_cnt[e], 1); }
+    }
+    __syncthreads();
+    for (int e = t; e < E; e += 256) { const int c = s_cnt[e]; if (c) atomicAdd(&counts[e], c); }
+}
+__global__ void __launch_bounds__(256) kr_pf_scatter_wg_kernel(const int32_t* __restrict__ ids, int n_pairs, int E, const int* __restrict__ offsets, int* __restrict__ cursor,
+                                                              int* __restrict__ row_pair, int* __restrict__ pair_row) {
+    __shared__ int s_cnt[1024], s_base[1024];
+    const int t = threadIdx.x, base = blockIdx.x * KR_PF_WG_PAIRS;
+    for (int e = t; e < E; e += 256) s_cnt[e] = 0;
+    __syncthreads();
+    int my[KR_PF_WG_PAIRS / 256];
+#pragma unroll
+    for (int j = 0; j < KR_PF_WG_PAIRS / 256; j++) {
+        const int i = base + j * 256 + t;
+        int e = -1;
+        if (i < n_pairs) { e = ids[i]; if (e < 0 || e >= E) e = -1; }
+        my[j] = e;
+        if (e >= 0) atomicAdd(&s_cnt[e], 1);
+    }
+    __syncthreads();
+    for (int e = t; e < E; e += 256) { const int c = s_cnt[e]; s_base[e] = c ? offsets[e] + atomicAdd(&cursor[e], c) : 0; s_cnt[e] = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KR_PF_WG_PAIRS / 256; j++) {
+        const int i = base + j * 256 + t;
+        if (i >= n_pairs) continue;
+        const int e = my[j];
+        if (e < 0) { pair_row[i] = -1; continue; }
+        const int r = s_base[e] + atomicAdd(&s_cnt[e], 1);
+        row_pair[r] = i; pair_row[i] = r;
+    }
+}
+
 // one block: exclusive scan of counts -> row offsets; tile table (expert, first row, rows) for every 64-row tile
 __global__ void __launch_bounds__(1024) kr_pf_scan_kernel(const int* __restrict__ counts, int E, int* __restrict__ offsets, int* __restrict__ cursor,
                                                          int* __restrict__ tile_expert, int* __restrict__ tile_row0, int* __restrict__ tile_rows,
@@ -283,6 +330,13 @@ void kr_launch_pf_sort(const int32_t* ids, int M, int topk, int E, KrPfSort s, h
         return;
     }
     (void)hipMemsetAsync(s.counts, 0, (size_t)E * 4, st);
+    if (E <= 1024) {
+        const int g = (n + KR_PF_WG_PAIRS - 1) / KR_PF_WG_PAIRS;
+        hipLaunchKernelGGL(kr_pf_count_wg_kernel, dim3(g), dim3(256), 0, st, ids, n, E, s.counts);
+        hipLaunchKernelGGL(kr_pf_scan_kernel, dim3(1), dim3(1024), 0, st, s.counts, E, s.offsets, s.cursor, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles, bm);
+        hipLaunchKernelGGL(kr_pf_scatter_wg_kernel, dim3(g), dim3(256), 0, st, ids, n, E, s.offsets, s.cursor, s.row_pair, s.pair_row);
+        return;
+    }
     hipLaunchKernelGGL(kr_pf_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E, s.counts);
     hipLaunchKernelGGL(kr_pf_scan_kernel, dim3(1), dim3(1024), 0, st, s.counts, E, s.offsets, s.cursor, s.tile_expert, s.tile_row0, s.tile_rows, s.n_tiles, bm);
     hipLaunchKernelGGL(kr_pf_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, n, E, s.offsets, s.cursor, s.row_pair, s.pair_row);

@@ -49,6 +49,25 @@ def test_prefill_bit_exact_vs_cpu_engine_numerics(H, I, E, k, M, n_shared, bits,
     assert np.array_equal(got, out2)
 
 
+def test_prefill_large_batch_sort_with_skewed_routing():
+    """more than 32 768 (token, slot) pairs take the three-launch sort (workgroup-private histograms: one global atomic per workgroup and expert);
+    routing skewed towards two hot experts, skipped slots, a ragged last workgroup slice.  Rows of the result = the streaming decode kernels' bits."""
+    H, I, E, k, M = 256, 128, 24, 4, 8300                            # 33 200 pairs
+    eng, mgr, experts, shared, rng, torch = _setup(H, I, E, k, 0, 1.0, seed=9)
+    x = rand_bf16(rng, (M, H))
+    p = np.full(E, 0.4 / (E - 2)); p[3] = 0.35; p[17] = 0.25
+    ids = np.stack([rng.choice(E, k, replace=False, p=p) for _ in range(M)]).astype(np.int32)
+    ids[5, 2] = -1; ids[4000, :] = -1; ids[M - 1, 0] = -1
+    w = rng.random((M, k)).astype(np.float32)
+    xt = torch.from_numpy(x.view(np.int16)).cuda().view(torch.bfloat16)
+    out = mgr.forward(0, xt, torch.from_numpy(ids).cuda(), torch.from_numpy(w).cuda())
+    got = out.view(torch.int16).cpu().numpy().view(np.uint16)
+    ref = np.empty((M, H), np.uint16)
+    eng.forward_moe_direct(0, x.ctypes.data, ids.ctypes.data, w.ctypes.data, ref.ctypes.data, M, k)
+    assert np.array_equal(got, ref)
+    assert not got[4000].any()
+
+
 @pytest.mark.parametrize("pairs", [64, 200, 1000])
 def test_prefill_pass_loop_equals_single_pass(pairs):
     """batches larger than the pair budget are walked in passes of pairs / topk tokens (kr_moe_set_prefill_pairs): same bits as one pass"""

@@ -101,6 +101,13 @@ pfexact)    # exact prompt pass at 8192 tokens: tok/s twice, then the kernel tra
     timeout 600 python tools/probes/prefill_profile.py 8192 0 2>&1 | tail -3
     kstats r03_prefill_exact_8192 "QCN exact prompt pass, 8192 tokens (tools/probes/prefill_profile.py 8192 0)" -- python /root/repo/tools/probes/prefill_profile.py 8192 0
     ;;
+pffast)     # tolerance prompt pass (KR_ATTN_FAST | KR_GEMM_FAST) at 8192 tokens: tok/s, then the kernel trace
+    timeout 600 python tools/probes/prefill_profile.py 8192 2 2>&1 | tail -2
+    kstats r03_prefill_8192_attn_fast_gemm_fast "QCN prompt pass, KR_ATTN_FAST | KR_GEMM_FAST, 8192 tokens (tools/probes/prefill_profile.py 8192 2)" -- python /root/repo/tools/probes/prefill_profile.py 8192 2
+    ;;
+ktrace)     # generic: bash tools/gpu.sh ktrace <name> "<title>" -- <command...>  -> gpurun_out/<name>_kernel_stats.txt
+    kstats "$@"
+    ;;
 stamps)
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     ;;
