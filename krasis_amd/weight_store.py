@@ -106,9 +106,12 @@ def _weight_map(model_dir: str) -> Dict[str, str]:
 
 
 def load_from_hf(engine, model_dir: str, num_bits: int = 4, w2_bits: Optional[int] = None, max_layers: Optional[int] = None,
-                 start_layer: Optional[int] = None) -> MoeConfig:
+                 start_layer: Optional[int] = None, use_cache: bool = True, write_cache: bool = False) -> MoeConfig:
     """KrasisEngine.load for BF16 safetensors (moe.rs:1538 -> weights/mod.rs:1181).  Configures the engine and fills layers
-    [start_layer, start_layer + max_layers) of the MoE stack (MoE layer m = model layer m + first_k_dense_replace)."""
+    [start_layer, start_layer + max_layers) of the MoE stack (MoE layer m = model layer m + first_k_dense_replace).
+    use_cache: an expert cache the REFERENCE left on disk for this model (`~/.krasis/cache/<model>/experts_cpu_int{bits}_g128.bin`, else the Marlin
+    file; weights/mod.rs:1226-1370 tries them in that spirit) is loaded instead of re-quantizing -- a stale or foreign file (hash / shape / size
+    mismatch) is skipped with its reason kept in `engine.cache_note`.  write_cache: after quantizing a WHOLE model, write the version-4 file."""
     import torch
     from safetensors import safe_open
 
@@ -129,6 +132,19 @@ def load_from_hf(engine, model_dir: str, num_bits: int = 4, w2_bits: Optional[in
         raise ValueError(f"start_layer {start} / max_layers {max_layers} select no MoE layer (model has {n_moe})")
     engine.configure(ModelConfig(cfg.hidden_size, cfg.moe_intermediate_size, cfg.n_routed_experts, cfg.num_experts_per_tok, count,
                                  cfg.n_shared_experts, cfg.routed_scaling_factor, swiglu_limit=cfg.swiglu_limit, activation_alpha=cfg.activation_alpha))
+    engine.cache_note = None
+    if use_cache and w2_bits == num_bits:
+        from . import expert_cache as EC
+        chash = EC.config_hash(model_dir)
+        for kind, path, loader in (("cpu", EC.cache_path_cpu(model_dir, num_bits, 128), EC.load_cpu_cache), ("marlin", EC.cache_path_marlin(model_dir, 128, num_bits), EC.load_marlin_cache)):
+            if not os.path.exists(path):
+                continue
+            try:
+                loader(engine, path, chash, num_bits, total_moe_layers=n_moe, start_moe_layer=start, num_layers_to_load=count)
+                engine.cache_note = f"loaded {kind} cache {path}"
+                return cfg
+            except RuntimeError as ex:
+                engine.cache_note = f"{kind} cache {path} not used: {ex}"
     prefix = detect_expert_prefix(wm)
     handles: Dict[str, object] = {}
 
@@ -160,6 +176,9 @@ def load_from_hf(engine, model_dir: str, num_bits: int = 4, w2_bits: Optional[in
             if base + ".gate_proj.weight" in wm:
                 upload(m, -1, base, cfg.n_shared_experts * cfg.moe_intermediate_size)
     engine._cpu_bits = engine._gpu_bits = num_bits
+    if write_cache and w2_bits == num_bits and start == 0 and count == n_moe:
+        from . import expert_cache as EC
+        EC.save_cpu_cache(engine, EC.cache_path_cpu(model_dir, num_bits, 128), EC.config_hash(model_dir), num_bits)
     return cfg
 
 
