@@ -844,6 +844,15 @@ static int gg_ensure_ws(kr_engine* e, GgufSet& g, hipStream_t st) {
 static int gg_ensure_fast(kr_engine* e, GgufSet& a, GgufSet* b, hipStream_t st) {     // b: second matrix appended on N (up after gate), or null
     if (a.fq.p || !a.allocated()) return KR_OK;
     const int N = a.N + (b ? b->N : 0);
+    if (a.type == GG_Q8_0) {      // INT8 lane tiles + one f16 scale per 32-wide block, no offsets
+        const int ngp = (a.K / 128 + 1) / 2;
+        a.fN = N; a.fq_stride = kr_mat_q_bytes(a.K, N, 8); a.fqs_stride = (size_t)(N / 8) * ngp * 8 * 8 * 2;
+        if (a.fq.ensure(a.fq_stride * a.count) || a.fqs.ensure(a.fqs_stride * a.count)) return kr_fail(KR_ERR_HIP, "hipMalloc of the Q8_0 tolerance copy failed");
+        kr_launch_gq8_repack(a.view(), a.count, a.fq.p, a.fq_stride, a.fqs.p, a.fqs_stride, 0, st);
+        if (b) kr_launch_gq8_repack(b->view(), b->count, a.fq.p, a.fq_stride, a.fqs.p, a.fqs_stride, a.N / 8, st);
+        e->weight_bytes += (a.fq_stride + a.fqs_stride) * a.count;
+        return KR_OK;
+    }
     a.fN = N; a.fq_stride = kr_mat_q_bytes(a.K, N, 4); a.fqs_stride = (size_t)(N / 8) * (a.K / 256) * 8 * 8 * 2;
     if (a.fq.ensure(a.fq_stride * a.count) || a.fqs.ensure(a.fqs_stride * a.count) || a.fqo.ensure(a.fqs_stride * a.count)) return kr_fail(KR_ERR_HIP, "hipMalloc of the Q4_K tolerance copy failed");
     kr_launch_gq_repack(a.view(), a.count, a.fq.p, a.fq_stride, a.fqs.p, a.fqo.p, a.fqs_stride, 0, N / 8, st);
@@ -852,9 +861,10 @@ static int gg_ensure_fast(kr_engine* e, GgufSet& a, GgufSet* b, hipStream_t st) 
     return KR_OK;
 }
 static bool gg_fast_ok(const Layer& L, int H, bool use_shared) {
-    auto q4 = [](const GgufSet& g, int K) { return g.type == GG_Q4_K && K % 256 == 0 && g.N % 8 == 0; };
-    bool ok = q4(L.g_gate, H) && q4(L.g_up, H) && q4(L.g_down, L.inter) && L.inter % 256 == 0 && L.inter <= 2048;
-    if (use_shared) ok = ok && q4(L.gs_gate, H) && q4(L.gs_up, H) && q4(L.gs_down, L.shared_inter) && L.shared_inter % 256 == 0 && L.shared_inter <= 2048;
+    // Q4_K over k ranges of whole super-blocks, Q8_0 over whole 128-k groups (V2-Lite's down projection: K = 1408 = 11 groups); gate and up of one type
+    auto q4 = [](const GgufSet& g, int K) { return ((g.type == GG_Q4_K && K % 256 == 0) || (g.type == GG_Q8_0 && K % 128 == 0)) && g.N % 8 == 0; };
+    bool ok = q4(L.g_gate, H) && q4(L.g_up, H) && L.g_gate.type == L.g_up.type && q4(L.g_down, L.inter) && L.inter % 32 == 0 && L.inter <= 2048;
+    if (use_shared) ok = ok && q4(L.gs_gate, H) && q4(L.gs_up, H) && L.gs_gate.type == L.gs_up.type && q4(L.gs_down, L.shared_inter) && L.shared_inter % 32 == 0 && L.shared_inter <= 2048;
     return ok;
 }
 // the prompt pass of a native Q4_K layer in the tolerance form: f16 rows (+ their per-32 sums) x nibbles de-quantized in registers with the

@@ -57,13 +57,13 @@ struct MatSet {            // all experts of one layer for one projection, conti
 struct GgufSet {          // native GGUF experts of one layer for one projection
     DevBuf q, h; int type = 0, K = 0, N = 0, count = 0; size_t q_stride = 0, h_stride = 0;
     DevBuf ws; size_t ws_stride = 0;   // prompt pass: per (row, sub-block) sums of the quants (kr_gguf_prefill.hip), built on first use
-    // KR_GEMM_FAST on Q4_K layers: operand form of the tolerance GEMM (kr_gq_repack_kernel), built on first use.  gate and up share ONE copy (N = 2 I,
+    // KR_GEMM_FAST on Q4_K / Q8_0 layers: operand form of the tolerance GEMM (kr_gq_repack_kernel / kr_gq8_repack_kernel), built on first use.  gate and up share ONE copy (N = 2 I,
     // held by the gate set) so that the gate | up GEMM is one launch like the INT4 path's w13.
     DevBuf fq, fqs, fqo; size_t fq_stride = 0, fqs_stride = 0; int fN = 0;
     KrMatDev fast_view() const {
         KrMatDev m{};
-        m.q = fq.p; m.K = K; m.N = fN; m.ng = K / 128; m.ngp = (m.ng + 1) / 2; m.bits = 4; m.n_fma = (fN / 8) * 8; m.q_stride = fq_stride;
-        m.qs = (const uint16_t*)fqs.p; m.qo = (const uint16_t*)fqo.p; m.qs_stride = fqs_stride;
+        m.q = fq.p; m.K = K; m.N = fN; m.ng = K / 128; m.ngp = (m.ng + 1) / 2; m.bits = type == GG_Q8_0 ? 8 : 4; m.n_fma = (fN / 8) * 8; m.q_stride = fq_stride;
+        m.qs = (const uint16_t*)fqs.p; m.qo = (const uint16_t*)fqo.p; m.qs_stride = fqs_stride;       // Q8_0: no offset table (qo == nullptr)
         return m;
     }
     bool allocated() const { return q.p != nullptr; }

@@ -31,4 +31,6 @@ void kr_launch_gpf_gemm(const GgMat& m, const void* ws, size_t ws_stride, const 
                         hipStream_t st);
 // Q4_K -> the tolerance GEMM's operand form (INT4 lane tiles + per-sub-block f16 scale / offset tables); tile_off: first output tile (gate | up share one matrix)
 void kr_launch_gq_repack(const GgMat& m, int n_experts, void* q_out, size_t q_stride, void* qs_out, void* qo_out, size_t qs_stride, int tile_off, int tiles_out, hipStream_t st);
+// Q8_0 -> the tolerance GEMM's INT8 operand form (INT8 lane tiles + one f16 scale per 32-wide block)
+void kr_launch_gq8_repack(const GgMat& m, int n_experts, void* q_out, size_t q_stride, void* qs_out, size_t qs_stride, int tile_off, hipStream_t st);
 void kr_launch_gpf_fill_synth(void* q, size_t q_bytes, void* h, size_t h_bytes, int type, uint64_t seed, hipStream_t st);

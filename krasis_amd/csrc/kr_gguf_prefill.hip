@@ -466,3 +466,38 @@ void kr_launch_gq_repack(const GgMat& m, int n_experts, void* q_out, size_t q_st
     hipLaunchKernelGGL(kr_gq_repack_kernel, dim3(m.N / 8, m.K / 256, n_experts), dim3(64), 0, st, m, (char*)q_out, q_stride, (uint16_t*)qs_out, (uint16_t*)qo_out, qs_stride, tile_off,
                        tiles_out);
 }
+
+// ------------------------------------------------------------------------------------------
+// Q8_0 -> the tolerance GEMM's INT8 operand form (kr_prefill_h.hip, BITS = 8, G = 1): the int8 quants of every 128-k group in the INT8 lane-tiled
+// layout of kr_kernels.h (lane record (column c, l8) = k 16 l8 .. 16 l8 + 15 of the group, natural order) and ONE f16 scale per 32-wide block,
+// qs[tile][group pair][col][j] = f16(16 d_j), j = 0..7 over the pair's 256 k (0 for a group past K: the half-empty last stage of an odd group
+// count).  w = d q exactly; 16 d rounds once to f16 (d is an f16: exact unless it overflows at d > 4094, which no Q8_0 block has).
+// grid (tiles, groups of the PADDED pair count, experts), 64 threads = 8 rows x 8 lanes of the source tile (kr_gguf.hip layout)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) kr_gq8_repack_kernel(const GgMat m, char* q_out, size_t q_stride, uint16_t* qs_out, size_t qs_stride, int tile_off) {
+    __shared__ uint8_t qb[8][128];
+    const int tile = blockIdx.x, g = blockIdx.y, e = blockIdx.z, lane = threadIdx.x, r = lane >> 3, l = lane & 7;
+    const int ng = m.K / 128, ngp = (ng + 1) / 2, nbg = (m.K / 32 + 3) / 4;
+    uint16_t* sdst = qs_out + (size_t)e * (qs_stride / 2) + ((((size_t)(tile_off + tile) * ngp + (g >> 1)) * 8 + r) * 8 + (g & 1) * 4);
+    if (g >= ng) { if (l < 4) sdst[l] = 0; return; }          // uniform per workgroup
+    const char* qsrc = reinterpret_cast<const char*>(m.q) + (size_t)e * m.q_stride;
+    const char* hsrc = reinterpret_cast<const char*>(m.h) + (size_t)e * m.h_stride;
+    const u32x4 w = *(reinterpret_cast<const u32x4*>(qsrc) + ((size_t)tile * nbg + g) * 64 + lane);
+    const uint32_t wu[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) qb[r][32 * u + 2 * l + (p & 1) + 16 * (p >> 1)] = (uint8_t)(wu[u] >> (8 * p));   // bytes {2l, 2l+1, 16+2l, 17+2l} of block u
+    __syncthreads();
+    const u32x4 o = *reinterpret_cast<const u32x4*>(&qb[r][16 * l]);
+    *(reinterpret_cast<u32x4*>(q_out + (size_t)e * q_stride) + ((size_t)(tile_off + tile) * ng + g) * 64 + lane) = o;
+    if (l < 4) {
+        const uint16_t db = *(reinterpret_cast<const uint16_t*>(hsrc) + (((size_t)tile * nbg + g) * 8 + r) * 4 + l);
+        const _Float16 hs = (_Float16)(gpf_f16(db) * 16.0f);
+        sdst[l] = __builtin_bit_cast(uint16_t, hs);
+    }
+}
+void kr_launch_gq8_repack(const GgMat& m, int n_experts, void* q_out, size_t q_stride, void* qs_out, size_t qs_stride, int tile_off, hipStream_t st) {
+    const int ng = m.K / 128, ngp = (ng + 1) / 2;
+    hipLaunchKernelGGL(kr_gq8_repack_kernel, dim3(m.N / 8, 2 * ngp, n_experts), dim3(64), 0, st, m, (char*)q_out, q_stride, (uint16_t*)qs_out, qs_stride, tile_off);
+}

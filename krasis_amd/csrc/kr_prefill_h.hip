@@ -336,7 +336,7 @@ __device__ __forceinline__ void pfh_store_tile(const ACC& acc, int nsb, int rows
 // (8 d sc_j - dmin mn_j) enter after the k loop as K / 32 extra k-columns: A' = the rows' per-32 sums, B' = the offset table (K / 512 more MFMA steps).
 template <int NC, int BITS, int SB = 0, int G = 0, int OCC = 2>
 __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHArgs a) {
-    static_assert(G == 0 || (SB == 1 && BITS == 4), "the Q4_K copy runs the single-buffered INT4 form");
+    static_assert(G == 0 || (SB == 1 && BITS == 4) || (SB == 0 && BITS == 8), "the Q4_K copy runs the single-buffered INT4 form, the Q8_0 copy the INT8 form");
     constexpr int BN = 128 * NC, LDA = PFH_LDA, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4, NS = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                                               // [64][LDA]  f16; BITS == 4: k permuted (0,4,1,5,2,6,3,7) inside every 8
@@ -612,6 +612,12 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
             const int hh = t >> 2;
 #pragma unroll
             for (int c = 0; c < NC; c++) {
+                if constexpr (G && BITS == 8) {      // Q8_0 copy: k-step t of the stage lies in 32-wide block t, whose f16 scale (16 d) is half t of the 8 the stage loaded
+                    const uint32_t w4[4] = {sqw[c].x, sqw[c].y, sqw[c].z, sqw[c].w};
+                    const uint32_t wd = w4[t >> 1], s16 = (t & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+                    const v2h sc2 = __builtin_bit_cast(v2h, s16 | (s16 << 16));
+                    bf[buf][c][0] = pfh_dq8(br[buf][c].x, br[buf][c].y, sc2); bf[buf][c][1] = pfh_dq8(br[buf][c].z, br[buf][c].w, sc2);
+                } else
                 if (BITS == 8) { bf[buf][c][0] = pfh_dq8(br[buf][c].x, br[buf][c].y, sq[hh][c]); bf[buf][c][1] = pfh_dq8(br[buf][c].z, br[buf][c].w, sq[hh][c]); }
                 else { bf[buf][c][0] = pfh_dq4(br[buf][c].x, sq[hh][c], cq[hh][c], M0, M1, MH, Kc); bf[buf][c][1] = pfh_dq4(br[buf][c].y, sq[hh][c], cq[hh][c], M0, M1, MH, Kc); }
             }
@@ -656,7 +662,7 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
     };
     // SB form (big problems: nearly every tile is full): one copy of the loop -- the second copy's hoisted values were what pushed the kernel into scratch
     if (SB || two) main_loop(std::integral_constant<int, 2>{}); else main_loop(std::integral_constant<int, 1>{});
-    if constexpr (G) {
+    if constexpr (G && BITS == 4) {
         // the offset columns: 16 sub-blocks per MFMA step, operands straight from global memory (8 f16 per lane and operand)
         const int nsub = K / 32;
         const char* qo_b = reinterpret_cast<const char*>(m.qo) + (size_t)expert * m.qs_stride;
@@ -711,7 +717,7 @@ static void pfh_launch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS, SB, G, OCC>), grid, dim3(256), lds, st, b);
 }
 static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
-    if (a.m.bits == 8) { pfh_launch<1, 8>(a, mt, st); return; }
+    if (a.m.bits == 8) { if (a.m.qs) pfh_launch<1, 8, 0, 1>(a, mt, st); else pfh_launch<1, 8>(a, mt, st); return; }
     // 256-column tiles when they still fill the chip (>= 2 workgroups per CU), else 128-column tiles
     long n128 = (a.m.N + 127) / 128;
     for (int i = 0; i < a.n_extra; i++) n128 += (a.mx[i].N + 127) / 128;

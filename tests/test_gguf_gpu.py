@@ -147,26 +147,33 @@ def test_synthetic_gguf_fill_and_prefill_runs():
     assert np.abs(g - r).max() <= 2e-5 * np.abs(r).max()
 
 
-@pytest.mark.parametrize("H,I,E,k,M,shared", [(2048, 512, 6, 3, 200, True), (512, 256, 8, 4, 700, False), (1024, 512, 4, 2, 64, True)])
-def test_moe_prefill_q4k_tolerance_form(H, I, E, k, M, shared):
+@pytest.mark.parametrize("H,I,E,k,M,shared,gu_t,dn_t", [
+    (2048, 512, 6, 3, 200, True, O.Q4_K, O.Q4_K), (512, 256, 8, 4, 700, False, O.Q4_K, O.Q4_K), (1024, 512, 4, 2, 64, True, O.Q4_K, O.Q4_K),
+    (512, 384, 8, 4, 300, True, O.Q4_K, O.Q8_0),      # the V2-Lite situation: Q8_0 down over an ODD number of 128-k groups (half-empty last stage)
+    (2048, 512, 6, 3, 200, False, O.Q8_0, O.Q8_0),    # QCN Q8_0 everywhere
+    (512, 1408, 4, 2, 150, False, O.Q4_K, O.Q8_0),    # V2-Lite's intermediate size itself (11 groups)
+])
+def test_moe_prefill_q4k_tolerance_form(H, I, E, k, M, shared, gu_t, dn_t):
     """kr_moe_set_gemm_mode(1) on a native Q4_K layer: the prompt-pass experts on the f16 matrix cores from the re-tiled copy of the super-blocks
     (kr_gq_repack_kernel -> kr_pfh_gemm_kernel<..., G = 1>): nibbles de-quantized in registers with the sub-block scale d * sc_j folded in (rounded once
     to f16), the offsets 8 d sc_j - dmin mn_j as K / 32 extra k-columns against the rows' per-32 sums, libm SiLU, f32 accumulation over the whole k
     range.  Yardstick: the exact path of the same layer (kr_moe_forward, bit-identical to the oracle's moe_forward_gguf -- checked on a few rows).
     STATED TOLERANCE: relative RMS error of the expert outputs <= 1.5e-3, max |diff| <= 1e-2 * max |ref| (f16 activations 2^-11, f16 sub-block scales
-    2^-12; the INT4-g128 tolerance form sits at 2-4e-4 with its exact bf16 scales)."""
+    2^-12; the INT4-g128 tolerance form sits at 2-4e-4 with its exact bf16 scales).  Q8_0 matrices (kr_gq8_repack_kernel -> BITS = 8, G = 1): int8 quants
+    de-quantized exactly, one f16 scale 16 d per 32-wide block picked per k-step, no offset columns.  The error must also be ABOVE the exact block
+    GEMM's (~1e-6): a silent fall-back to the exact form would pass every upper bound."""
     import os
     import torch
     from krasis_amd import KrasisEngine, ModelConfig, _lib
     from krasis_amd._lib import check
     rng = np.random.default_rng(H + I + M)
-    experts = [make(rng, H, I, O.Q4_K, O.Q4_K) for _ in range(E)]
-    sh = make(rng, H, I, O.Q4_K, O.Q4_K) if shared else None
+    experts = [make(rng, H, I, gu_t, dn_t) for _ in range(E)]
+    sh = make(rng, H, I, gu_t, dn_t) if shared else None
     eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, 1, 1 if shared else 0, 1.5))
     for e, ex in enumerate(experts):
-        eng.load_gguf_expert(0, e, ex.gate, ex.up, ex.down, O.Q4_K, O.Q4_K, I)
+        eng.load_gguf_expert(0, e, ex.gate, ex.up, ex.down, gu_t, dn_t, I)
     if shared:
-        eng.load_gguf_expert(0, -1, sh.gate, sh.up, sh.down, O.Q4_K, O.Q4_K, I)
+        eng.load_gguf_expert(0, -1, sh.gate, sh.up, sh.down, gu_t, dn_t, I)
     act = rand_bf16(rng, (M, H)); ids = np.stack([rng.choice(E, k, replace=False) for _ in range(M)]).astype(np.int32)
     ids[5, 1] = -1; ids[min(77, M - 1), :] = -1
     w = rng.random((M, k)).astype(np.float32)
@@ -187,7 +194,8 @@ def test_moe_prefill_q4k_tolerance_form(H, I, E, k, M, shared):
     rms = float(np.sqrt(((g - r) ** 2).mean()) / np.sqrt((r ** 2).mean())); mx = float(np.abs(g - r).max() / np.abs(r).max())
     if os.path.isdir("gpurun_out"):
         with open("gpurun_out/r03_q4k_fast_err.txt", "a") as f:
-            f.write(f"Q4_K tolerance form H={H} I={I} E={E} k={k} M={M} shared={shared}: rel RMS {rms:.3e}  max|diff|/max|ref| {mx:.3e}\n")
+            f.write(f"GGUF tolerance form types {gu_t}/{dn_t} H={H} I={I} E={E} k={k} M={M} shared={shared}: rel RMS {rms:.3e}  max|diff|/max|ref| {mx:.3e}\n")
     assert np.isfinite(g).all() and rms <= 1.5e-3 and mx <= 1e-2, (rms, mx)
+    assert rms > 2e-5, ("the tolerance form did not run", rms)
     if not shared:
         assert not g[min(77, M - 1)].any()            # every slot skipped: zeros
