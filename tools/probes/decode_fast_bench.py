@@ -41,7 +41,7 @@ def main():
         logits[mode] = lg
         st.fill_state_synthetic(kvm, seed=4242)
         dt = bench.time_decode(st, args.steps, 5, kvm, torch, None, 1)
-        per_kind_us, per_launch_us, n_per_step = bench.profile_kinds(st, kvm)
+        per_kind_us, per_launch_us, n_per_step = bench.profile_kinds(st, kvm, step_ms=dt / args.steps * 1e3)
         res[mode] = {"tok_s": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                      "per_kind_us_per_step": {k: round(v, 2) for k, v in per_kind_us.items() if v > 0},
                      "per_kind_us_per_launch": {k: round(v, 2) for k, v in per_launch_us.items() if n_per_step[k] > 0},
