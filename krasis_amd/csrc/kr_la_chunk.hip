@@ -14,8 +14,12 @@
 //                       solve in registers (one column of [W | Y] per thread, L rows broadcast from LDS), Q' = e^G Q - B W and O_0 = B Y.
 //   kr_lac_scan_kernel  grid (heads x 4 column slices of the state): walks the sub-chunks; per step U = Y - W S, O = O_0 + Q' S (four 32x32
 //                       blocks, one per wave) and S <- e^{G_T} S + K'^T U (four blocks), the next sub-chunk's tiles in flight in registers.
-// f32 MFMA (v_mfma_f32_32x32x2_f32) keeps f32 products and f32 accumulation; the result differs from the per-token order only by summation
-// order (tolerance mode: tests/test_attn_fast_gpu.py states it).  All exponents are differences G_t - G_j <= 0: nothing overflows, and a
+// The prep kernel's products run on the f32 MFMA (v_mfma_f32_32x32x2_f32: f32 products, f32 accumulation).  The SCAN -- the sequential part -- runs
+// its three products on the bf16 MFMA with every f32 operand split into two bf16 planes (x = hi + lo, hi = bf16(x), lo = bf16(x - hi)) and
+// acc += hi.hi + hi.lo + lo.hi: three v_mfma_f32_32x32x16_bf16 (96 matrix-pipe cycles per 16 k) instead of eight v_mfma_f32_32x32x2_f32 (512),
+// products exact to ~2^-17 relative, f32 accumulation, f32 exponent range.  W, Q' and K^T leave the prep kernel already split (and K transposed), so
+// the scan stages them with plain 16-byte copies; only the state slice and the delta rows are split inside the scan (16 values per lane and step).
+// (tolerance mode: tests/test_attn_fast_gpu.py states the bound.)  All exponents are differences G_t - G_j <= 0: nothing overflows, and a
 // decay that underflows gives 0, not NaN (g is clamped at -80 per token).
 #include <hip/hip_runtime.h>
 #include "kr_lds_optin.h"
@@ -33,17 +37,30 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // e^x for x <= 0 on the transcendental unit (v_exp_f32 of x * log2 e, ~1 ulp of 2^-22 relative): the precise expf costs ~40 VALU instructions,
 // 1.1 us per 16 values on a lone wave -- more than the epilogue it sits in
 __device__ __forceinline__ float lc_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+typedef __bf16 lc_b8 __attribute__((ext_vector_type(8)));
+typedef uint32_t lc_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t lc_u2 __attribute__((ext_vector_type(2)));
+// x = hi + lo in bf16 (round to nearest even, v_cvt_pk_bf16_f32): the pair carries x to ~2^-17 relative
+__device__ __forceinline__ void lc_split(float x, uint16_t& hi, uint16_t& lo) {
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    hi = __builtin_bit_cast(uint16_t, h); lo = __builtin_bit_cast(uint16_t, l);
+}
 #define LC_T 64
 #define LC_D 128
 #define LC_LD 132      // LDS row stride (floats) of the 64 x 128 tiles: rows 4 banks apart -> the float4 k-contiguous reads are conflict-free
 #define LC_LS 68       // row stride of the 64 x 64 matrices
 #define LC_SS 40       // row stride of the 32-column state / delta slices: rows k and k+4 are 32 banks apart
 #define LC_PREP_LDS ((3 * LC_T * LC_LD + 2 * LC_T * LC_LS + 3 * LC_T) * 4)
-#define LC_SCAN_LDS ((3 * LC_T * LC_LD + LC_D * LC_SS + LC_T * LC_SS + LC_T) * 4)
+#define LC_PA 272      // bytes per row of a [rows][128 k] bf16 plane in LDS (256 + 16: the 16-byte fragment reads of 32 consecutive rows spread over the banks)
+#define LC_PT 144      // bytes per row of a [rows][64 k] bf16 plane
+#define LC_SCAN_LDS (4 * LC_T * LC_PA + 2 * LC_D * LC_PT + 2 * 32 * LC_PA + 2 * 32 * LC_PT + LC_T * 4)
 
 struct KrLacArgs {
     const float *q, *k, *v, *gexp, *beta;   // [C][nv*128] x3, [C][nv] x2
-    float *W, *Y, *Qp, *G;                  // [n_sub*nv][64][128] x3, [n_sub*nv][64]
+    float *Y, *G;                           // [n_sub*nv][64][128], [n_sub*nv][64]
+    uint16_t *Wh, *Wl, *Qh, *Ql;            // bf16 planes [n_sub*nv][64][128] of W and Q' (hi, lo)
+    uint16_t *Kh, *Kl;                      // bf16 planes [n_sub*nv][128][64] of K^T
     float *out, *state;                     // [C][nv*128]; [nv][128][128]
     int nv, C, n_sub;
 };
@@ -109,6 +126,21 @@ __global__ void __launch_bounds__(256) kr_lac_prep_kernel(KrLacArgs a) {
     }
     __syncthreads();
     LC_STAMP(1);
+    // ---- K^T for the scan, split into bf16 planes [d][t] (the solve below overwrites the K tile with W): thread = (d, half of the tokens)
+    {
+        const int d = tid & (LC_D - 1), tb = (tid >> 7) * 32;
+        uint32_t hw[16], lw[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            uint16_t h0, l0, h1, l1;
+            lc_split(Kt[(tb + 2 * i) * LC_LD + d], h0, l0); lc_split(Kt[(tb + 2 * i + 1) * LC_LD + d], h1, l1);
+            hw[i] = (uint32_t)h0 | ((uint32_t)h1 << 16); lw[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        }
+        lc_u4* kh = reinterpret_cast<lc_u4*>(a.Kh + (tile * LC_D + (size_t)d * LC_T + tb));      // tile * LC_D = first element of this tile's [128][64] plane
+        lc_u4* kl = reinterpret_cast<lc_u4*>(a.Kl + (tile * LC_D + (size_t)d * LC_T + tb));
+#pragma unroll
+        for (int i = 0; i < 4; i++) { kh[i] = lc_u4{hw[4 * i], hw[4 * i + 1], hw[4 * i + 2], hw[4 * i + 3]}; kl[i] = lc_u4{lw[4 * i], lw[4 * i + 1], lw[4 * i + 2], lw[4 * i + 3]}; }
+    }
     // ---- K K^T -> L (strictly lower, decayed, row-scaled by b) and Q K^T -> B (lower incl. diagonal, decayed); the (0,1) blocks are zero
     if (wave < 3) {
         v16f acc0, acc1;
@@ -165,9 +197,9 @@ __global__ void __launch_bounds__(256) kr_lac_prep_kernel(KrLacArgs a) {
                 for (int j4 = 0; j4 < (t + 4) / 4; j4++) cur[j4] = nx[j4];
             }
         }
-        float* Xg = (tid < LC_D ? a.W : a.Y) + tile * LC_D + (tid & (LC_D - 1));
+        // W over K, Y over V in LDS: element (t, c) is read and written by thread c only.  They go to memory from there, at the end of the kernel.
 #pragma unroll
-        for (int t = 0; t < LC_T; t++) { const float xv = (t & 1) ? x[t / 2].y : x[t / 2].x; Xt[t * LC_LD] = xv; Xg[(size_t)t * LC_D] = xv; }   // W over K, Y over V: element (t, c) is read and written by thread c only
+        for (int t = 0; t < LC_T; t++) Xt[t * LC_LD] = (t & 1) ? x[t / 2].y : x[t / 2].x;
     }
     __syncthreads();
     LC_STAMP(4);
@@ -185,18 +217,82 @@ __global__ void __launch_bounds__(256) kr_lac_prep_kernel(KrLacArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int r0 = lc_row(r, lane), r1 = 32 + r0;
-            a.Qp[(tile + r0) * LC_D + col] = lc_exp(Gs[r0]) * Qt[r0 * LC_LD + col] - q0[r];
-            a.Qp[(tile + r1) * LC_D + col] = lc_exp(Gs[r1]) * Qt[r1 * LC_LD + col] - q1[r];
+            Qt[r0 * LC_LD + col] = lc_exp(Gs[r0]) * Qt[r0 * LC_LD + col] - q0[r];      // Q' over Q in LDS: element (row, col) is touched by this lane only
+            Qt[r1 * LC_LD + col] = lc_exp(Gs[r1]) * Qt[r1 * LC_LD + col] - q1[r];
             if (r0 < n) a.out[(size_t)(c0 + r0) * ld + (size_t)h * LC_D + col] = o0[r];
             if (r1 < n) a.out[(size_t)(c0 + r1) * ld + (size_t)h * LC_D + col] = o1[r];
         }
         LC_STAMP(6);
     }
+    __syncthreads();
+    // ---- W (K tile), Q' (Q tile) -> their bf16 planes, Y (V tile) -> f32, all with 16-byte stores: chunk u = 8 consecutive columns of row u >> 4
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int u = tid + 256 * i, t = u >> 4, c8 = (u & 15) * 8;
+        const size_t o = (tile + t) * LC_D + c8;
+        auto planes = [&](const float* src, uint16_t* ph, uint16_t* pl) {
+            const f4 v0 = *reinterpret_cast<const f4*>(src + t * LC_LD + c8), v1 = *reinterpret_cast<const f4*>(src + t * LC_LD + c8 + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            uint16_t hh[8], ll[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) lc_split(v[j], hh[j], ll[j]);
+            *reinterpret_cast<lc_u4*>(ph + o) = lc_u4{(uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16), (uint32_t)hh[4] | ((uint32_t)hh[5] << 16), (uint32_t)hh[6] | ((uint32_t)hh[7] << 16)};
+            *reinterpret_cast<lc_u4*>(pl + o) = lc_u4{(uint32_t)ll[0] | ((uint32_t)ll[1] << 16), (uint32_t)ll[2] | ((uint32_t)ll[3] << 16), (uint32_t)ll[4] | ((uint32_t)ll[5] << 16), (uint32_t)ll[6] | ((uint32_t)ll[7] << 16)};
+        };
+        planes(Kt, a.Wh, a.Wl);
+        planes(Qt, a.Qh, a.Ql);
+        *reinterpret_cast<f4*>(a.Y + o) = *reinterpret_cast<const f4*>(Vt + t * LC_LD + c8);
+        *reinterpret_cast<f4*>(a.Y + o + 4) = *reinterpret_cast<const f4*>(Vt + t * LC_LD + c8 + 4);
+    }
+}
+
+// acc(32x32) += A(32 x K) . B(K x 32) with both operands given as bf16 (hi, lo) planes whose rows hold k contiguously: A row = output row, B row =
+// output COLUMN (B is stored transposed).  Lane (r = lane & 31, h = lane >> 5) supplies k = 16 ks + 8 h .. + 8 of row r of both operands (one 16-byte
+// read per plane); three MFMAs per 16 k: hi.hi + hi.lo + lo.hi.  `between(ks)` issues the caller's global prefetch under the MFMAs of step ks.
+template <int K, typename F = LcNone>
+__device__ __forceinline__ void lc_blk3(v16f& acc, const char* Ah, const char* Al, int lda, const char* Bh, const char* Bl, int ldb, int lane, F&& between = LcNone()) {
+    const int r = lane & 31, h = lane >> 5;
+    const char* ah = Ah + r * lda + h * 16; const char* al = Al + r * lda + h * 16;
+    const char* bh = Bh + r * ldb + h * 16; const char* bl = Bl + r * ldb + h * 16;
+    lc_b8 fa[2][2], fb[2][2];
+    auto fetch = [&](int ks, int buf) {
+        fa[buf][0] = *reinterpret_cast<const lc_b8*>(ah + ks * 32); fa[buf][1] = *reinterpret_cast<const lc_b8*>(al + ks * 32);
+        fb[buf][0] = *reinterpret_cast<const lc_b8*>(bh + ks * 32); fb[buf][1] = *reinterpret_cast<const lc_b8*>(bl + ks * 32);
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < K / 16; ks++) {
+        if (ks + 1 < K / 16) fetch(ks + 1, (ks + 1) & 1);
+        between(ks);
+        const int b = ks & 1;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][0], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// 16 accumulator values of a lane (rows lc_row(r), column lane & 31) -> the two bf16 planes of the TRANSPOSED matrix [col][row]: registers 4 q .. 4 q + 3
+// are four consecutive rows -> one 8-byte store per plane and q
+__device__ __forceinline__ void lc_store_t(const float (&v)[16], char* Ph, char* Pl, int ld, int row0, int lane) {
+    const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint16_t hh[4], ll[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) lc_split(v[4 * q + i], hh[i], ll[i]);
+        const int off = n * ld + (row0 + 8 * q + 4 * h) * 2;
+        *reinterpret_cast<lc_u2*>(Ph + off) = lc_u2{(uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16)};
+        *reinterpret_cast<lc_u2*>(Pl + off) = lc_u2{(uint32_t)ll[0] | ((uint32_t)ll[1] << 16), (uint32_t)ll[2] | ((uint32_t)ll[3] << 16)};
+    }
 }
 
 __global__ void __launch_bounds__(256) kr_lac_scan_kernel(KrLacArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Wt = lds; float* Qt = Wt + LC_T * LC_LD; float* Kt = Qt + LC_T * LC_LD; float* Ss = Kt + LC_T * LC_LD; float* Us = Ss + LC_D * LC_SS; float* Gs = Us + LC_T * LC_SS;
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    char* Whs = lsm; char* Wls = Whs + LC_T * LC_PA; char* Qhs = Wls + LC_T * LC_PA; char* Qls = Qhs + LC_T * LC_PA;      // [64 t][128 k]
+    char* Khs = Qls + LC_T * LC_PA; char* Kls = Khs + LC_D * LC_PT;                                                       // K^T [128 d][64 t]
+    char* Shs = Kls + LC_D * LC_PT; char* Sls = Shs + 32 * LC_PA;                                                         // S^T slice [32 cols][128 d]
+    char* Uhs = Sls + 32 * LC_PA; char* Uls = Uhs + 32 * LC_PT;                                                           // U'^T [32 cols][64 t]
+    float* Gs = reinterpret_cast<float*>(Uls + 32 * LC_PT);
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the 4 column slices of one head read the same W / Q' / K tiles: keep them on one XCD (workgroup id % 8) so the re-reads hit its L2
     int h, slice;
@@ -204,62 +300,81 @@ __global__ void __launch_bounds__(256) kr_lac_scan_kernel(KrLacArgs a) {
     const size_t ld = (size_t)a.nv * LC_D;
     const int col = slice * 32 + (lane & 31);
     float* Sg = a.state + (size_t)h * LC_D * LC_D;
-    v16f S;
+    float S[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) { const int d = wave * 32 + lc_row(r, lane); S[r] = Sg[(size_t)d * LC_D + col]; Ss[d * LC_SS + (lane & 31)] = S[r]; }
-    // tile element u = tid + 256 i (i < 8): token row t = (tid >> 5) + 8 i, 16-byte column group tid & 31.  Running pointers: one add per sub-chunk.
-    const int t0 = tid >> 5, c4 = (tid & 31) * 4;
-    const size_t tile_stride = (size_t)a.nv * LC_T * LC_D;
-    const f4* Wp = reinterpret_cast<const f4*>(a.W + (size_t)h * LC_T * LC_D) + tid;
-    const f4* Qp = reinterpret_cast<const f4*>(a.Qp + (size_t)h * LC_T * LC_D) + tid;
-    const float* Kp = a.k + (size_t)h * LC_D + c4;
-    f4 pw[8], pq[8], pk[8]; float pg = 0.0f;
-    const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    // part i of sub-chunk SUB's tiles (W and Q' rows, or the K rows: rows past the chunk end read the last row and are zeroed when they are
-    // written to LDS -- no branch, and no wait at the request)
-#define LC_FETCH_WQ(SUB, I) { pw[I] = Wp[(size_t)(SUB) * (tile_stride / 4) + 256 * (I)]; pq[I] = Qp[(size_t)(SUB) * (tile_stride / 4) + 256 * (I)]; }
-#define LC_FETCH_K(SUB, I)  { pk[I] = *reinterpret_cast<const f4*>(Kp + (size_t)min((SUB) * LC_T + t0 + 8 * (I), a.C - 1) * ld); }
+    for (int r = 0; r < 16; r++) S[r] = Sg[(size_t)(wave * 32 + lc_row(r, lane)) * LC_D + col];
+    lc_store_t(S, Shs, Sls, LC_PA, wave * 32, lane);
+    // plane chunk u = tid + 256 i (i < 4) of 16 bytes: W / Q' planes [64][128] -> row u >> 4, chunk u & 15;  K^T planes [128][64] -> row u >> 3, chunk u & 7
+    const size_t tile_elems = (size_t)LC_T * LC_D, tile_stride = (size_t)a.nv * tile_elems;      // elements per tile / between sub-chunks
+    const lc_u4* pWh = reinterpret_cast<const lc_u4*>(a.Wh + (size_t)h * tile_elems) + tid; const lc_u4* pWl = reinterpret_cast<const lc_u4*>(a.Wl + (size_t)h * tile_elems) + tid;
+    const lc_u4* pQh = reinterpret_cast<const lc_u4*>(a.Qh + (size_t)h * tile_elems) + tid; const lc_u4* pQl = reinterpret_cast<const lc_u4*>(a.Ql + (size_t)h * tile_elems) + tid;
+    const lc_u4* pKh = reinterpret_cast<const lc_u4*>(a.Kh + (size_t)h * tile_elems) + tid; const lc_u4* pKl = reinterpret_cast<const lc_u4*>(a.Kl + (size_t)h * tile_elems) + tid;
+    lc_u4 pf[6][4]; float pg = 0.0f;
+#define LC_FETCH3(SUB, P, I) { const size_t o_ = (size_t)(SUB) * (tile_stride / 8) + 256 * (I); \
+        pf[P][I] = (P) == 0 ? pWh[o_] : (P) == 1 ? pWl[o_] : (P) == 2 ? pQh[o_] : (P) == 3 ? pQl[o_] : (P) == 4 ? pKh[o_] : pKl[o_]; }
 #pragma unroll
-    for (int i = 0; i < 8; i++) { LC_FETCH_WQ(0, i) LC_FETCH_K(0, i) }
+    for (int p = 0; p < 6; p++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) LC_FETCH3(0, p, i)
     if (tid < LC_T) pg = a.G[(size_t)h * LC_T + tid];
+    // the addend of the first product (Y rows for waves 0,1; O_0 rows, written by the prep kernel, for waves 2,3) is requested ONE STEP AHEAD as well:
+    // with the products at bf16 rate a step is shorter than a memory round trip
+    const int rbw = wave & 1;
+    float yn[16];
+    auto fetch_y = [&](int sb) {
+        const size_t tl = ((size_t)sb * a.nv + h) * LC_T;
+        const int cc = sb * LC_T, nn = min(LC_T, a.C - cc);
+        if (wave < 2) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) yn[r] = a.Y[(tl + rbw * 32 + lc_row(r, lane)) * LC_D + col];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const int row = min(rbw * 32 + lc_row(r, lane), nn - 1); yn[r] = a.out[(size_t)(cc + row) * ld + (size_t)h * LC_D + col]; }
+        }
+    };
+    fetch_y(0);
     for (int sub = 0; sub < a.n_sub; sub++) {
         const size_t tile = ((size_t)sub * a.nv + h) * LC_T;
         const int c0 = sub * LC_T, n = min(LC_T, a.C - c0);
         const int nxt = min(sub + 1, a.n_sub - 1);     // the last step re-requests its own tiles: no branch in the product loop
         if (sub == 1) LC_STAMP(10);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int t = t0 + 8 * i;
-            *reinterpret_cast<f4*>(Wt + t * LC_LD + c4) = pw[i]; *reinterpret_cast<f4*>(Qt + t * LC_LD + c4) = pq[i]; *reinterpret_cast<f4*>(Kt + t * LC_LD + c4) = c0 + t < a.C ? pk[i] : zero4;
+        for (int i = 0; i < 4; i++) {
+            const int u = tid + 256 * i, ro = (u >> 4) * LC_PA + (u & 15) * 16, ko = (u >> 3) * LC_PT + (u & 7) * 16;
+            *reinterpret_cast<lc_u4*>(Whs + ro) = pf[0][i]; *reinterpret_cast<lc_u4*>(Wls + ro) = pf[1][i];
+            *reinterpret_cast<lc_u4*>(Qhs + ro) = pf[2][i]; *reinterpret_cast<lc_u4*>(Qls + ro) = pf[3][i];
+            *reinterpret_cast<lc_u4*>(Khs + ko) = pf[4][i]; *reinterpret_cast<lc_u4*>(Kls + ko) = pf[5][i];
         }
         if (tid < LC_T) Gs[tid] = pg;
         __syncthreads();
         if (sub == 1) LC_STAMP(11);
         // ---- waves 0,1: U = Y - W S (row halves);  waves 2,3: O = O_0 + Q' S.  The Y / O_0 values are requested FIRST (the memory counter is in
-        // order: waiting for them must not wait for the prefetch), then the next sub-chunk's tiles are requested from inside the product loop
+        // order: waiting for them must not wait for the prefetch), then the next sub-chunk's planes are requested from inside the product loop
         {
-            const int rb = wave & 1;
+            const int rb = rbw;
             float y[16];
-            if (wave < 2) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) y[r] = a.Y[(tile + rb * 32 + lc_row(r, lane)) * LC_D + col];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; r++) { const int row = min(rb * 32 + lc_row(r, lane), n - 1); y[r] = a.out[(size_t)(c0 + row) * ld + (size_t)h * LC_D + col]; }
-            }
+            for (int r = 0; r < 16; r++) y[r] = yn[r];
+            fetch_y(nxt);
             if (tid < LC_T) pg = a.G[((size_t)nxt * a.nv + h) * LC_T + tid];
             v16f acc;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.0f;
             if (sub == 1) LC_STAMP(12);
-            lc_blk<true, false, LC_D>(acc, (wave < 2 ? Wt : Qt) + rb * 32 * LC_LD, LC_LD, Ss, LC_SS, lane, [&](int it) {
-                if (it & 1) LC_FETCH_K(nxt, it >> 1) else LC_FETCH_WQ(nxt, it >> 1)
+            lc_blk3<LC_D>(acc, (wave < 2 ? Whs : Qhs) + rb * 32 * LC_PA, (wave < 2 ? Wls : Qls) + rb * 32 * LC_PA, LC_PA, Shs, Sls, LC_PA, lane, [&](int ks) {
+                // 24 requests over 8 steps: plane ks >> 1 ... two planes per pair of steps, in plane order
+                if (ks < 6) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) LC_FETCH3(nxt, ks, i)
+                }
             });
             if (sub == 1) LC_STAMP(13);
             const float gT = Gs[LC_T - 1];
             if (wave < 2) {
+                float u[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) { const int row = rb * 32 + lc_row(r, lane); Us[row * LC_SS + (lane & 31)] = (y[r] - acc[r]) * lc_exp(gT - Gs[row]); }
+                for (int r = 0; r < 16; r++) { const int row = rb * 32 + lc_row(r, lane); u[r] = (y[r] - acc[r]) * lc_exp(gT - Gs[row]); }
+                lc_store_t(u, Uhs, Uls, LC_PT, rb * 32, lane);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; r++) { const int row = rb * 32 + lc_row(r, lane); if (row < n) a.out[(size_t)(c0 + row) * ld + (size_t)h * LC_D + col] = y[r] + acc[r]; }
@@ -271,15 +386,17 @@ __global__ void __launch_bounds__(256) kr_lac_scan_kernel(KrLacArgs a) {
         // ---- S <- e^{G_T} S + K^T U'   (U' rows already carry e^{G_T - G_t}); wave w owns state rows [32w, 32w+32)
         {
             const float gam = lc_exp(Gs[LC_T - 1]);
+            v16f sa;
 #pragma unroll
-            for (int r = 0; r < 16; r++) S[r] *= gam;
-            lc_blk<false, false, LC_T>(S, Kt + wave * 32, LC_LD, Us, LC_SS, lane);
+            for (int r = 0; r < 16; r++) sa[r] = S[r] * gam;
+            lc_blk3<LC_T>(sa, Khs + wave * 32 * LC_PT, Kls + wave * 32 * LC_PT, LC_PT, Uhs, Uls, LC_PT, lane);
+#pragma unroll
+            for (int r = 0; r < 16; r++) S[r] = sa[r];
         }
         if (sub == 1) LC_STAMP(16);
-        __syncthreads();
+        __syncthreads();              // every wave has read S^T (first product of this step) and U'^T before they are rewritten
         if (sub == 1) LC_STAMP(17);
-#pragma unroll
-        for (int r = 0; r < 16; r++) Ss[(wave * 32 + lc_row(r, lane)) * LC_SS + (lane & 31)] = S[r];
+        lc_store_t(S, Shs, Sls, LC_PA, wave * 32, lane);
         if (sub == 1) LC_STAMP(18);
         if (sub == 2) LC_STAMP(19);
     }
@@ -287,8 +404,8 @@ __global__ void __launch_bounds__(256) kr_lac_scan_kernel(KrLacArgs a) {
     for (int r = 0; r < 16; r++) Sg[(size_t)(wave * 32 + lc_row(r, lane)) * LC_D + col] = S[r];
 }
 
-// floats of scratch per padded token (a multiple of 64 tokens) and head: W, Y, Q' rows + one G
-size_t kr_pfm_la_chunk_scratch_floats(int C, int nv) { const size_t c64 = ((size_t)C + LC_T - 1) / LC_T * LC_T; return c64 * nv * (3 * LC_D + 1); }
+// floats of scratch per padded token (a multiple of 64 tokens) and head: Y rows, the bf16 plane pairs of W, Q', K^T (2 + 2 bytes per value each), one G
+size_t kr_pfm_la_chunk_scratch_floats(int C, int nv) { const size_t c64 = ((size_t)C + LC_T - 1) / LC_T * LC_T; return c64 * nv * (4 * LC_D + 1) + 4; }   // Y (f32), three pairs of bf16 planes, G
 bool kr_pfm_la_chunk_ok(int dk, int dv, int C) { return dk == LC_D && dv == LC_D && C >= LC_T; }
 
 // > 64 KB of dynamic LDS is an opt-in per device (and not allowed inside a stream capture: the prompt pass is never captured)
@@ -302,7 +419,9 @@ int kr_launch_pfm_la_chunked(const KrPfmLaArgs& p, float* state, float* out, flo
     KrLacArgs a{};
     a.q = p.q; a.k = p.k; a.v = p.v; a.gexp = p.gexp; a.beta = p.beta; a.nv = p.nv; a.C = C; a.n_sub = (C + LC_T - 1) / LC_T;
     const size_t tiles = (size_t)a.n_sub * p.nv * LC_T;
-    a.W = scratch; a.Y = a.W + tiles * LC_D; a.Qp = a.Y + tiles * LC_D; a.G = a.Qp + tiles * LC_D;
+    a.Y = scratch; a.G = a.Y + tiles * LC_D;
+    uint16_t* pl = reinterpret_cast<uint16_t*>(a.G + ((tiles + 3) / 4) * 4);        // planes start 16-byte aligned
+    a.Wh = pl; a.Wl = a.Wh + tiles * LC_D; a.Qh = a.Wl + tiles * LC_D; a.Ql = a.Qh + tiles * LC_D; a.Kh = a.Ql + tiles * LC_D; a.Kl = a.Kh + tiles * LC_D;
     a.out = out; a.state = state;
     hipLaunchKernelGGL(kr_lac_prep_kernel, dim3(a.n_sub, p.nv), dim3(256), LC_PREP_LDS, st, a);
     hipLaunchKernelGGL(kr_lac_scan_kernel, dim3(p.nv * 4), dim3(256), LC_SCAN_LDS, st, a);

@@ -26,7 +26,9 @@ int main(int argc, char** argv) {
     KrLacArgs a{};
     a.q = q; a.k = k; a.v = v; a.gexp = ge; a.beta = be; a.nv = nv; a.C = C; a.n_sub = (C + 63) / 64;
     const size_t tiles = (size_t)a.n_sub * nv * 64;
-    a.W = scr; a.Y = a.W + tiles * 128; a.Qp = a.Y + tiles * 128; a.G = a.Qp + tiles * 128; a.out = out; a.state = state;
+    a.Y = scr; a.G = a.Y + tiles * 128; a.out = out; a.state = state;
+    uint16_t* pl = reinterpret_cast<uint16_t*>(a.G + ((tiles + 3) / 4) * 4);
+    a.Wh = pl; a.Wl = a.Wh + tiles * 128; a.Qh = a.Wl + tiles * 128; a.Ql = a.Qh + tiles * 128; a.Kh = a.Ql + tiles * 128; a.Kl = a.Kh + tiles * 128;
     for (int rep = 0; rep < 4; rep++) {
         CK(hipEventRecord(e0, st));
         hipLaunchKernelGGL(kr_lac_prep_kernel, dim3(a.n_sub, nv), dim3(256), LC_PREP_LDS, st, a);
