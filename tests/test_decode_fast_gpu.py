@@ -110,6 +110,32 @@ def test_fast_router_ids_equal_oracle_topk_on_the_same_logits(scoring):
     assert wworst <= 2e-6, wworst
 
 
+@pytest.mark.parametrize("E,k,scoring", [(128, 8, 1), (130, 6, 1), (256, 8, 0), (60, 4, 1), (512, 10, 1)])
+def test_fast_router_other_expert_counts(E, k, scoring):
+    """the select's register forms: 2 / 4 / 8 logits per lane (E <= 128 / 256 / 512), expert counts that are not a multiple of 4 (scalar loads, padded
+    lanes) or of 64; Qwen3-235B's 128-expert top-8 among them.  ids against the oracle on the same logits, 400 tokens each, and logits against the exact graph."""
+    cfg = dict(kinds=["gqa"], scoring=scoring, norm_bias_one=scoring == 1, seed=E, dims=(256, 512, E, k, 128, 128))
+    st, eng, orc, keep, d = build(**cfg)
+    st.set_attention_mode(False, decode_fast=True)
+    esc = orc.layers[0].get("esc")
+    rng = np.random.default_rng(E + k)
+    lg = np.empty(d["V"], F)
+    bad, wworst = 0, 0.0
+    for i in range(400):
+        st.decode_step(int(rng.integers(0, d["V"])), 5 + (i % 20), lg.ctypes.data)
+        logits, ids, w = st.read_router(E, k)
+        rid, rw = O.route_score_topk(logits, k, scoring, True, esc)[:2]
+        bad += int(not np.array_equal(np.asarray(rid, np.int32), ids))
+        wworst = max(wworst, float(np.abs(np.asarray(rw, F) - w).max() / np.abs(rw).max()))
+    _log(f"router E={E} k={k} scoring={scoring}: {400 - bad}/400 ids identical, weights rel {wworst:.2e}")
+    assert bad == 0 and wworst <= 2e-6, (bad, wworst)
+    d["reset"]()
+    ref = np.empty(d["V"], F); st.set_attention_mode(False); st.decode_step(7, 5, ref.ctypes.data)
+    d["reset"]()
+    st.set_attention_mode(False, decode_fast=True); st.decode_step(7, 5, lg.ctypes.data)
+    assert float(np.abs(lg - ref).max() / np.abs(ref).max()) <= 2e-3
+
+
 def test_fast_router_tie_falls_back_to_heap_order():
     """equal logits among the leaders: the reference's heap order (not index order) decides -- decode.rs:1531.  A gate with duplicated rows makes
     pairs of experts tie exactly."""
