@@ -615,7 +615,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             const bool o_img = img_ok && img_w(L.o_wid) && L.hd % 128 == 0 && s->weights[L.o_wid]->cols == L.nh * L.hd;
             a.img_out = o_img ? s->img_attn.p : nullptr;
             a.sc_g = s->kv_max_seq > s->gqa_split_min ? (float*)s->gqa_scores.p : nullptr;
-            a.force_stream = s->opt_gqa_stream;
+            a.force_stream = s->opt_gqa_stream; a.tree_norm = fast ? 1 : 0;
             if (s->attn_fast && a.sc_g) { a.fd_o = (float*)s->fd_o.p; a.fd_ml = (float*)s->fd_ml.p; }
             PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
             if (o_img) out_proj(L.o_wid);

@@ -20,6 +20,7 @@ struct KrGqaArgs {
     void* img_out;   // optional: INT16 image of attn_out for the o-projection launch (hd % 128 == 0)
     float* sc_g;     // long caches: [nh][max_seq] score scratch -- the scores are computed by (nh x max_seq/256) workgroups in their own launch
     float *fd_o, *fd_ml;   // fast (tolerance) mode: split-KV partials [nkv][chunks][G][hd] and (max, sum) [nh][chunks][2]; null = exact order
+    int tree_norm;         // KR_DECODE_FAST: the QK-norm sums of squares as workgroup trees instead of the reference's element-order chain (decode.rs:2893)
     int force_stream;      // test hook (kr_decode_set_option "gqa_stream"): take the HBM-streamed score row even when it would fit LDS
 };
 

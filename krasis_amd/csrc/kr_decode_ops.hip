@@ -458,7 +458,20 @@ __global__ void __launch_bounds__(256) kr_gqa_prep_kernel(const KrGqaArgs a) {
     } else if (d < hd) x[d] = a.k_in[(size_t)h * hd + d];
     __syncthreads();
     const float* nw = is_q ? a.q_norm : a.k_norm;
-    if (nw) {
+    if (nw && a.tree_norm) {      // tolerance mode: lane / wave / workgroup tree (the exact chain below is 2 x hd dependent adds on one thread)
+        __shared__ float part[4];
+        float v = d < hd ? x[d] * x[d] : 0.0f;
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if ((d & 63) == 0) part[d >> 6] = v;
+        __syncthreads();
+        const float ss = (part[0] + part[1]) + (part[2] + part[3]);
+        const float rms = 1.0f / sqrtf(ss / (float)hd + a.eps);
+        const int per_head = is_q ? a.q_norm_per_head : a.k_norm_per_head;
+        const float xv = d < hd ? x[d] * (rms * nw[(per_head ? h * hd : 0) + d]) : 0.0f;
+        __syncthreads();
+        if (d < hd) x[d] = xv;
+        __syncthreads();
+    } else if (nw) {
         if (d == 0) {
             float ss = 0.0f; int i = 0;
             for (; i + 32 <= hd; i += 32) {      // 32 LDS values in flight, then the scalar chain in element order
