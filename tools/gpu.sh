@@ -52,7 +52,7 @@ gemmab)     # A/B of the 64 x 256 tolerance-GEMM variants (experts only), then t
 gemmpmc)    # SQ counters of the shipped GEMM kernels (separate pass, counters only)
     rm -rf $R/pmc_gemm
     (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_WAVES -d $R/pmc_gemm --output-format csv -- \
-        python /root/repo/tools/probes/experts_gemm_probe.py 2 8192 exact,fast,q4k > $R/pmc_gemm.log 2>&1)
+        python /root/repo/tools/probes/experts_gemm_probe.py 2 8192 exact,fast,q4k,q4kfast > $R/pmc_gemm.log 2>&1)
     python tools/pmc_table.py $R/pmc_gemm $R/r03_gemm_pmc_sq.txt "Experts-only prompt-pass GEMMs, QCN shape, 8192 tokens, 2 layers: SQ counters per launch (rocprofv3 --pmc, counters-only pass)" gemm 2>&1 | tail -2
     head -60 $R/r03_gemm_pmc_sq.txt
     ;;
