@@ -258,9 +258,13 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     // defaults: 1024 tokens x 3 chunks in flight for the exact pass (its serial per-token kernels need the overlap); with both tolerance bits set the
     // kernels are chunk-parallel and fatter chunks feed the expert GEMMs better (rows per expert grow with the chunk): 4096 x 2 measured best at
     // 8192 tokens (tools/probes/prefill_sweep.py: 1024 x 3 171 ms, 2048 x 2 168, 4096 x 2 164, 8192 x 1 193)
+    // (second sweep: three chunks in flight beat two once the prompt has three chunks to give -- 8192 tokens: 2752 x 3 148.6 ms vs 4096 x 2 151.4;
+    // 20 434 tokens: 4096 x 3 407 ms vs 4096 x 2 423 -- so: a third of the prompt per chunk, between 1024 and 4096 tokens, three in flight; 3000 tokens: 1024 x 3 56.8 ms vs 2048 + 952 60.9)
     const bool tol = s->attn_fast && s->gemm_fast;
-    const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : (tol ? 4096 : KR_PFM_CHUNK));
-    const int depth = e->ep ? 1 : (s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : (tol ? 2 : KR_PFM_DEPTH));   // chunks in flight (streams / arenas)
+    const int third = ((n_tokens + 2) / 3 + 63) / 64 * 64;
+    const int tol_chunk = std::min(4096, std::max(KR_PFM_CHUNK, third));
+    const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : (tol ? tol_chunk : KR_PFM_CHUNK));
+    const int depth = e->ep ? 1 : (s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : KR_PFM_DEPTH);   // chunks in flight (streams / arenas)
     const int n_chunks = (n_tokens + CH - 1) / CH, n_arenas = std::min(n_chunks, depth), D = n_arenas;
     const int L = (int)s->layers.size();
 
