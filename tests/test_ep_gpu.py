@@ -228,3 +228,35 @@ def test_decode_step_expert_parallel_equals_single_engine(W):
     for ep in eps:
         ep.close()
     grp.close()
+
+
+def test_round3_abi_argument_errors():
+    """error behaviour of the round-3 entry points: ValueError with a message that names the argument (the reference raises PyValueError for shape /
+    range errors, moe.rs:1790-1803)"""
+    import ctypes as C
+    from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig, _lib
+    from krasis_amd._lib import check
+    from krasis_amd.ep import ExpertParallel, LoopbackGroup
+    lib = _lib.load_library()
+    h = C.c_void_p()
+    with pytest.raises(ValueError, match="out of range"):
+        check(lib.kr_ep_loopback_create(0, C.byref(h)))
+    with pytest.raises(ValueError, match="out of range"):
+        check(lib.kr_decode_create_on(99, 128, 0, C.byref(h)))
+    st = CpuDecodeStore()
+    with pytest.raises(ValueError, match="numerics mode 8 unknown"):
+        check(lib.kr_decode_set_attention_mode(st._h, 8))
+    with pytest.raises(ValueError):
+        st.set_option("no_such_option", 1)
+    eng = KrasisEngine(); eng.configure(ModelConfig(256, 128, 4, 2, 1, 0, 1.0))
+    grp = LoopbackGroup(2)
+    with pytest.raises(ValueError, match="bad world / rank"):
+        ExpertParallel(eng, 8, rank=2, loopback=grp)
+    with pytest.raises(ValueError, match="cannot be split"):
+        ExpertParallel(eng, 1, rank=0, loopback=grp)
+    with pytest.raises(ValueError, match="engine holds only 4"):
+        ExpertParallel(eng, 16, rank=1, loopback=grp)       # rank 1 of 2 owns 8 of 16 experts
+    ep = ExpertParallel(eng, 8, rank=0, loopback=grp)
+    with pytest.raises(RuntimeError, match="already initialised"):
+        ExpertParallel(eng, 8, rank=0, loopback=grp)
+    ep.close(); grp.close()
