@@ -262,6 +262,7 @@ class CpuDecodeStore:
     def set_kv_dtype(self, fp8_e4m3: bool) -> None:
         """GQA KV cache element type: FP16 (reference CPU decode, default) or FP8-E4M3 (reference GPU cache, kv_cache.py:38)."""
         self._need(); check(self._lib.kr_decode_set_kv_dtype(self._h, 1 if fp8_e4m3 else 0))
+        self._kv_fp8 = bool(fp8_e4m3)
 
     def set_attention_mode(self, fast: bool, gemm_fast: bool = False, decode_fast: bool = False) -> None:
         """fast False (default): the reference's sequential softmax / p.v order (bit-exact).  True: split-KV / flash attention and the chunked
