@@ -53,6 +53,9 @@ typedef struct kr_engine kr_engine;
 
 const char* kr_last_error(void);
 int kr_version(void);
+/* measurement aid (no reference counterpart): device allocations the library has made so far, process-wide.  bench.py reads it on both sides of
+   every timed region and refuses a measurement that allocated (an allocation synchronises the device). */
+long kr_alloc_count_total(void);
 
 /* ---- engine lifetime: KrasisEngine::new / load (moe.rs:1435-1760) ---- */
 typedef struct {
@@ -191,7 +194,7 @@ int kr_ep_allreduce_f32(kr_engine* e, float* buf_dev, size_t n, void* stream);  
  * against single-engine execution (tests/test_ep_gpu.py).  Not a performance path. */
 typedef struct kr_ep_loop_group kr_ep_loop_group;
 int kr_ep_loopback_create(int world, kr_ep_loop_group** out);
-void kr_ep_loopback_destroy(kr_ep_loop_group* g);
+int kr_ep_loopback_destroy(kr_ep_loop_group* g);   /* refused (non-zero, group intact) while engines initialised on it have not been through kr_ep_destroy */
 int kr_ep_init_loopback(kr_engine* e, kr_ep_loop_group* group, int rank, int n_experts_total, int return_bf16);
 
 int kr_synchronize(kr_engine* e);

@@ -14,7 +14,7 @@ KR_ROUTE_RULE_ENGINE, KR_ROUTE_RULE_DECODE = 0, 1
 
 # every symbol include/krasis_hip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
-    "kr_last_error", "kr_version", "kr_engine_create", "kr_engine_destroy", "kr_engine_get_config",
+    "kr_last_error", "kr_version", "kr_alloc_count_total", "kr_engine_create", "kr_engine_destroy", "kr_engine_get_config",
     "kr_engine_device_bytes", "kr_upload_expert_unified", "kr_upload_expert_bf16", "kr_upload_expert_gguf", "kr_fill_layer_synthetic", "kr_fill_layer_synthetic_gguf",
     "kr_download_expert_unified", "kr_marlin_repack", "kr_marlin_unpack", "kr_upload_expert_marlin", "kr_download_expert_marlin", "kr_moe_forward", "kr_moe_prefill", "kr_set_routing_config", "kr_set_routing_weights", "kr_set_routing_weights_synthetic",
     "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_combine_rows", "kr_ep_unique_id", "kr_ep_init", "kr_ep_destroy", "kr_moe_prefill_ep", "kr_ep_comm_ranks", "kr_ep_max_int", "kr_ep_allreduce_f32", "kr_ep_loopback_create", "kr_ep_loopback_destroy", "kr_ep_init_loopback", "kr_moe_set_prefill_pairs", "kr_moe_set_gemm_mode", "kr_synchronize", "kr_set_profiling",
@@ -65,6 +65,7 @@ def load_library() -> C.CDLL:
         pass
     lib = C.CDLL(_LIB)
     lib.kr_last_error.restype = C.c_char_p
+    lib.kr_alloc_count_total.restype = C.c_long; lib.kr_alloc_count_total.argtypes = []
     lib.kr_engine_device_bytes.restype = C.c_size_t
     lib.kr_engine_device_bytes.argtypes = [C.c_void_p]
     lib.kr_engine_create.argtypes = [C.c_int, C.POINTER(ModelConfigC), C.POINTER(C.c_void_p)]
@@ -103,7 +104,7 @@ def load_library() -> C.CDLL:
     lib.kr_ep_max_int.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]
     lib.kr_ep_allreduce_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.kr_ep_loopback_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
-    lib.kr_ep_loopback_destroy.argtypes = [C.c_void_p]; lib.kr_ep_loopback_destroy.restype = None
+    lib.kr_ep_loopback_destroy.argtypes = [C.c_void_p]
     lib.kr_ep_init_loopback.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.kr_moe_prefill_ep.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.kr_synchronize.argtypes = [C.c_void_p]

@@ -444,9 +444,14 @@ __global__ void __launch_bounds__(512, 2) kr_pfm_gqa_flash8_kernel(const KrPfmGq
 }
 
 // non-zero = geometry not covered (the caller falls back to the exact passes)
+bool kr_pfm_gqa_flash_ok(int nh, int nkv, int hd) {
+    const int G = nkv > 0 ? nh / nkv : 0;
+    return nkv > 0 && nh % nkv == 0 && G >= 1 && G <= FA_ROWS && (FA_ROWS % G) == 0 && (hd == 64 || hd == 128 || hd == 256);
+}
+
 int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st) {
     const int G = a.nkv > 0 ? a.nh / a.nkv : 0;
-    if (a.nh % a.nkv || G < 1 || G > FA_ROWS || (FA_ROWS % G) || (a.hd != 64 && a.hd != 128 && a.hd != 256)) return 1;
+    if (!kr_pfm_gqa_flash_ok(a.nh, a.nkv, a.hd)) return 1;
     const int TQ = FA_ROWS / G;
     dim3 grid((C + TQ - 1) / TQ, a.nkv);
     if (a.hd >= 128) {      // eight waves, query tile in LDS, wave pairs split the positions of a tile (the four-wave form at these head sizes needed 512 registers + scratch: removed)

@@ -686,8 +686,10 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
                     const int rc = kr_launch_frt(ra, st);
                     prof_mark(s, -1, st);
                     if (rc == 0) {
-                        prof_mark(s, PK_MOE_W13, st); (void)kr_launch_fw13(fa, st); prof_mark(s, -1, st);
-                        prof_mark(s, PK_MOE_W2, st); (void)kr_launch_fw2(fa, st); prof_mark(s, -1, st);
+                        // kr_fmoe_check above covers every refusal of these two launchers; a non-zero return here would leave the layer half-run
+                        prof_mark(s, PK_MOE_W13, st); const int r13 = kr_launch_fw13(fa, st); prof_mark(s, -1, st);
+                        prof_mark(s, PK_MOE_W2, st); const int r2 = kr_launch_fw2(fa, st); prof_mark(s, -1, st);
+                        if (r13 || r2) return kr_fail(KR_ERR_STATE, "internal: KR_DECODE_FAST expert launch refused after kr_fmoe_check accepted layer %zu", li);
                         res_cur = other(res_cur); src = from_hidden; moe_done = true;
                     }
                 }

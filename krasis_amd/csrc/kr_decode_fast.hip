@@ -26,6 +26,7 @@ extern "C" int kr_debug_fstamps(unsigned long long* out) { return (int)hipMemcpy
 #define KR_FSTAMP(k, i) do { } while (0)
 #endif
 
+#define KR_FW2_LDS_MAX (64 * 1024)   // dynamic LDS of kr_fw2_kernel without a per-device opt-in (kr_lds_optin.h)
 #define KR_FU 16   // 16-byte weight records a lane keeps in flight per tile in the generic (guarded) form
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -817,7 +818,8 @@ int kr_fmoe_check(const KrFmoeArgs& fa) {
     const KrMoeArgs& a = fa.m;
     const bool has_shared = a.n_slots > a.topk;
     const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
-    return kr_lds_bytes(imax, a.w2.bits == 8) * a.n_slots > 150 * 1024 ? 1 : 0;
+    // kr_fw2_kernel takes slot_lds * n_slots of dynamic LDS and no opt-in is made for it: past the 64 KiB every kernel may use the layer falls back to the exact MoE kernels
+    return kr_lds_bytes(imax, a.w2.bits == 8) * a.n_slots > KR_FW2_LDS_MAX ? 1 : 0;
 }
 
 int kr_launch_fw13(const KrFmoeArgs& fa, hipStream_t st) {
@@ -844,7 +846,7 @@ int kr_launch_fw2(const KrFmoeArgs& fa, hipStream_t st) {
     const bool has_shared = a.n_slots > a.topk;
     const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
     const size_t slot_lds = kr_lds_bytes(imax, a.w2.bits == 8);
-    if (slot_lds * a.n_slots > 150 * 1024) return 1;
+    if (slot_lds * a.n_slots > KR_FW2_LDS_MAX) return 1;
     dim3 grid((a.H + 7) / 8);
     // exact unit count (no guards) when every slot has the same, even, group count
     const int units = a.w2.bits == 4 ? a.w2.ngp : a.w2.ng;

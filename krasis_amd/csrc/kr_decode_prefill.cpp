@@ -118,12 +118,14 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.k_cache = L.kv_k.p; a.v_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_out = B.q; a.gate = B.gate; a.attn_out = B.attn;
         a.gated = L.gated; a.nh = L.nh; a.nkv = L.nkv; a.hd = L.hd; a.pos0 = pos0; a.eps = s->eps; a.sm_scale = L.sm_scale;
         if (s->max_rope_seq > 0 && pos0 + Cc > s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "prompt exceeds the rope table (%d)", s->max_rope_seq);
-        bool flash = false;
-        if (s->attn_fast && L.hd <= 256 && L.hd % 8 == 0) {      // tolerance mode: flash attention on the matrix cores (same prep launch)
+        bool flash = false, flash_tried = false;
+        if (s->attn_fast && kr_pfm_gqa_flash_ok(L.nh, L.nkv, L.hd)) {      // tolerance mode: flash attention on the matrix cores (same prep launch)
             kr_launch_pfm_gqa_prep(a, Cc, st);
             flash = 0 == kr_launch_pfm_gqa_flash(a, Cc, st);
+            flash_tried = true;
         }
         if (!flash) {
+            if (flash_tried) return kr_fail(KR_ERR_HIP, "KR_ATTN_FAST: the flash-attention launch was refused (LDS window of head_dim %d)", L.hd);
             if (!cx.scores) return kr_fail(KR_ERR_STATE, "internal: no score scratch for the exact attention passes");
             const int sc_ld = (pos0 + Cc + 63) & ~63;
             float* scp = cx.scores;   // this chunk's arena (chunks in flight on other streams have their own)
@@ -280,14 +282,16 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
         } else if (Ly.attn == ATTN_GQA) {
             pa = std::max(pa, (size_t)s->weights[Ly.q_wid]->rows); pb = std::max(pb, (size_t)s->weights[Ly.k_wid]->rows); pc = std::max(pc, (size_t)s->weights[Ly.v_wid]->rows);
             qd = std::max(qd, (size_t)Ly.nh * Ly.hd); zd = std::max(zd, (size_t)Ly.nh * Ly.hd); ad = std::max(ad, (size_t)s->weights[Ly.o_wid]->cols);
-            sc_rows = std::max(sc_rows, (size_t)Ly.nh);
+            // the score scratch (rows x context f32, per arena) serves the EXACT attention passes only: under KR_ATTN_FAST the flash kernel has none.  Sizing it
+            // regardless made a 49 863-token tolerance pass allocate 3 x 13.5 GB it never touched (16.7 k instead of ~45 k tok/s)
+            if (!(s->attn_fast && kr_pfm_gqa_flash_ok(Ly.nh, Ly.nkv, Ly.hd))) sc_rows = std::max(sc_rows, (size_t)Ly.nh);
             for (int w : {Ly.q_wid, Ly.k_wid, Ly.v_wid, Ly.o_wid}) wids.push_back(w);
         } else if (Ly.attn == ATTN_MLA) {
             const size_t nq = (size_t)Ly.nh * (Ly.nd + Ly.rd);
             pa = std::max(pa, nq); pb = std::max(pb, (size_t)s->weights[Ly.kva_wid]->rows);
             qd = std::max(qd, (size_t)Ly.nh * Ly.klr); vd = std::max(vd, (size_t)Ly.nh * Ly.klr); zd = std::max(zd, (size_t)Ly.nh * Ly.rd);
             ad = std::max(ad, (size_t)s->weights[Ly.o_wid]->cols);
-            if (kr_mla_exact_mfma_ok(Ly.nh, Ly.klr, Ly.rd)) sc_rows = std::max(sc_rows, (size_t)Ly.nh);     // score scratch of the exact matrix-core passes
+            if (!s->attn_fast && kr_mla_exact_mfma_ok(Ly.nh, Ly.klr, Ly.rd)) sc_rows = std::max(sc_rows, (size_t)Ly.nh);     // score scratch of the exact matrix-core passes
             wids.push_back(Ly.kva_wid); wids.push_back(Ly.o_wid);
             if (Ly.mq_wid >= 0) wids.push_back(Ly.mq_wid);
             else { pc = std::max(pc, (size_t)s->weights[Ly.mqa_wid]->rows); kmax = std::max(kmax, (size_t)s->weights[Ly.mqa_wid]->rows); wids.push_back(Ly.mqa_wid); wids.push_back(Ly.mqb_wid); }

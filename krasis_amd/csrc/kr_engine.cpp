@@ -31,6 +31,7 @@ int kr_fail(int code, const char* fmt, ...) {
 
 extern "C" const char* kr_last_error(void) { return g_err.c_str(); }
 extern "C" int kr_version(void) { return 1; }
+extern "C" long kr_alloc_count_total(void) { return kr_alloc_count().load(std::memory_order_relaxed); }
 
 bool is_device_ptr(const void* p) {
     if (!p) return false;
@@ -410,8 +411,18 @@ static int ggset_alloc(kr_engine* e, GgufSet& gs, int type, int K, int N, int co
     e->weight_bytes += (gs.q_stride + gs.h_stride) * count;
     return KR_OK;
 }
-static int ggset_upload(GgufSet& gs, int idx, const uint8_t* src) {
+// the KR_GEMM_FAST copy of a matrix set (gg_ensure_fast) is derived data: any change of the blocks drops it, and it is rebuilt on the next
+// tolerance-mode call.  `up` has no copy of its own -- its columns live behind the gate set's -- so an upload to `up` passes the gate set as `owner`.
+static void ggset_drop_fast(kr_engine* e, GgufSet& gs) {
+    if (!gs.fq.p) return;
+    const size_t bytes = (gs.fq_stride + (gs.fqo.p ? 2 : 1) * gs.fqs_stride) * (size_t)gs.count;
+    e->weight_bytes = e->weight_bytes > bytes ? e->weight_bytes - bytes : 0;
+    gs.fq.release(); gs.fqs.release(); gs.fqo.release(); gs.fq_stride = gs.fqs_stride = 0; gs.fN = 0;
+}
+static int ggset_upload(kr_engine* e, GgufSet& gs, int idx, const uint8_t* src, GgufSet* owner = nullptr) {
     gs.ws.release();                                  // prompt-pass quant sums are rebuilt on the next kr_moe_prefill
+    ggset_drop_fast(e, gs);
+    if (owner) ggset_drop_fast(e, *owner);
     std::vector<uint8_t> dq(gs.q_stride), dh(gs.h_stride);
     retile_gguf(gs.type, src, gs.K, gs.N, dq.data(), dh.data());
     KR_HIP(hipMemcpy((char*)gs.q.p + (size_t)idx * gs.q_stride, dq.data(), gs.q_stride, hipMemcpyHostToDevice));
@@ -433,9 +444,9 @@ extern "C" int kr_upload_expert_gguf(kr_engine* e, int layer, int expert, int in
     if (int rc = ggset_alloc(e, G, gate_up_type, H, inter, cnt)) return rc;
     if (int rc = ggset_alloc(e, U, gate_up_type, H, inter, cnt)) return rc;
     if (int rc = ggset_alloc(e, D, down_type, inter, H, cnt)) return rc;
-    if (int rc = ggset_upload(G, idx, gate)) return rc;
-    if (int rc = ggset_upload(U, idx, up)) return rc;
-    if (int rc = ggset_upload(D, idx, down)) return rc;
+    if (int rc = ggset_upload(e, G, idx, gate)) return rc;
+    if (int rc = ggset_upload(e, U, idx, up, &G)) return rc;
+    if (int rc = ggset_upload(e, D, idx, down)) return rc;
     if (sh) { L.gguf_shared = true; L.shared_inter = inter; } else { L.gguf = true; L.inter = inter; L.present[expert] = 1; }
     return KR_OK;
 }
@@ -454,6 +465,7 @@ extern "C" int kr_fill_layer_synthetic_gguf(kr_engine* e, int layer, int gate_up
     int k = 0;
     for (GgufSet* g : {&L.g_gate, &L.g_up, &L.g_down}) {
         g->ws.release();
+        ggset_drop_fast(e, *g);
         kr_launch_gpf_fill_synth(g->q.p, g->q_stride * E, g->h.p, g->h_stride * E, g->type, seed * 8 + (uint64_t)(k++), e->stream);
     }
     KR_HIP(hipStreamSynchronize(e->stream));

@@ -1,5 +1,6 @@
 // kr_engine_internal.h -- engine state shared by kr_engine.cpp and kr_decode.cpp (not part of the C ABI)
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -20,6 +21,10 @@ int kr_fail(int code, const char* fmt, ...);
         if (e__ != hipSuccess) return kr_fail(KR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
+// number of device allocations made by the library so far (process-wide).  bench.py reads it on both sides of every timed region: an allocation
+// (hipFree + hipMalloc synchronise the device and can take seconds for tens of GB) inside a timed region is a measurement defect.
+inline std::atomic<long>& kr_alloc_count() { static std::atomic<long> n{0}; return n; }
+
 struct DevBuf {     // owning device allocation: released by the destructor, so a new scratch member cannot be forgotten in a release list
     void* p = nullptr; size_t bytes = 0;
     DevBuf() = default;
@@ -32,6 +37,7 @@ struct DevBuf {     // owning device allocation: released by the destructor, so 
         if (n <= bytes) return 0;
         if (p) (void)hipFree(p);
         p = nullptr; bytes = 0;
+        kr_alloc_count().fetch_add(1, std::memory_order_relaxed);      // every device allocation of the library passes here: kr_debug_alloc_count()
         if (hipMalloc(&p, n) != hipSuccess) return 1;
         bytes = n; return 0;
     }

@@ -33,6 +33,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 // the handful of RCCL declarations this file needs (the library itself is bound with dlopen at kr_ep_init): no <rccl/rccl.h> at build time
@@ -86,7 +87,9 @@ int load_rccl() {
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct kr_ep_loop_group {
     int world = 0;
+    int attached = 0;      // engines initialised on this group and not yet destroyed (guarded by mu): kr_ep_loopback_destroy refuses while > 0
     std::mutex mu; std::condition_variable cv; int arrived = 0; long gen = 0; bool failed = false;
+    int failed_rank = -1; std::string failed_why;      // first failure: which rank gave up and why (the peers' error text names it)
     struct Slot { const void* const* send = nullptr; const size_t* off = nullptr; const void* buf = nullptr; hipEvent_t ready = nullptr; };
     Slot slots[64];
     // generation barrier over the W rank threads; false = a rank failed (everybody gives up instead of waiting)
@@ -98,7 +101,12 @@ struct kr_ep_loop_group {
         else cv.wait(lk, [&] { return gen != g || failed; });
         return !failed;
     }
-    void fail() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
+    void fail(int rank = -1, const char* why = nullptr) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) { failed_rank = rank; failed_why = why ? why : ""; }
+        failed = true; cv.notify_all();
+    }
+    std::string why() { std::lock_guard<std::mutex> lk(mu); return "rank " + std::to_string(failed_rank) + (failed_why.empty() ? std::string() : ": " + failed_why); }
 };
 
 struct kr_ep_state {
@@ -116,7 +124,7 @@ namespace {
 int ep_abort(kr_ep_state* s, int rc) {
     s->broken = true;
     if (s->comm && g_rccl.CommAbort) { (void)g_rccl.CommAbort(s->comm); s->comm = nullptr; }
-    if (s->loop) s->loop->fail();
+    if (s->loop) s->loop->fail(s->rank, kr_last_error());
     return rc;
 }
 
@@ -127,13 +135,13 @@ int ep_gather_counts(kr_ep_state* s, const int* mine_dev, int* all_dev, hipStrea
     kr_ep_loop_group* g = s->loop;
     g->slots[s->rank].buf = mine_dev;
     KR_HIP(hipEventRecord(g->slots[s->rank].ready, st));
-    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed (%s)", g->why().c_str());
     for (int p = 0; p < W; p++) {
         KR_HIP(hipStreamWaitEvent(st, g->slots[p].ready, 0));
         KR_HIP(hipMemcpyAsync(all_dev + (size_t)p * W, g->slots[p].buf, (size_t)W * 4, hipMemcpyDeviceToDevice, st));
     }
     KR_HIP(hipStreamSynchronize(st));
-    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");     // every pull is done: the sources may be reused
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed (%s)", g->why().c_str());     // every pull is done: the sources may be reused
     return KR_OK;
 }
 
@@ -156,7 +164,7 @@ int ep_exchange(kr_ep_state* s, int nbuf, const void* const* send, void* const* 
     kr_ep_loop_group* g = s->loop;
     g->slots[s->rank].send = send; g->slots[s->rank].off = soff;
     KR_HIP(hipEventRecord(g->slots[s->rank].ready, st));
-    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed (%s)", g->why().c_str());
     for (int p = 0; p < W; p++) {
         const size_t* po = g->slots[p].off;
         const size_t n = po[s->rank + 1] - po[s->rank];
@@ -167,7 +175,7 @@ int ep_exchange(kr_ep_state* s, int nbuf, const void* const* send, void* const* 
             KR_HIP(hipMemcpyAsync((char*)recv[b] + roff[p] * row_bytes[b], (const char*)g->slots[p].send[b] + po[s->rank] * row_bytes[b], n * row_bytes[b], hipMemcpyDeviceToDevice, st));
     }
     KR_HIP(hipStreamSynchronize(st));
-    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed (%s)", g->why().c_str());
     return KR_OK;
 }
 
@@ -182,13 +190,13 @@ int ep_allreduce_f32(kr_engine* e, float* buf, size_t n, hipStream_t st) {
     if (s->red.ensure((size_t)W * n * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the all-reduce staging failed");
     g->slots[s->rank].buf = buf;
     KR_HIP(hipEventRecord(g->slots[s->rank].ready, st));
-    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed (%s)", g->why().c_str());
     for (int p = 0; p < W; p++) {
         KR_HIP(hipStreamWaitEvent(st, g->slots[p].ready, 0));
         KR_HIP(hipMemcpyAsync((float*)s->red.p + (size_t)p * n, g->slots[p].buf, n * 4, hipMemcpyDeviceToDevice, st));
     }
     KR_HIP(hipStreamSynchronize(st));
-    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed");     // all pulls done before anybody overwrites its buffer
+    if (!g->barrier()) return kr_fail(KR_ERR_STATE, "loopback expert parallelism: a peer rank failed (%s)", g->why().c_str());     // all pulls done before anybody overwrites its buffer
     kr_launch_ep_sum_f32((const float*)s->red.p, W, n, buf, st);
     return KR_OK;
 }
@@ -256,17 +264,26 @@ extern "C" int kr_ep_loopback_create(int world, kr_ep_loop_group** out) {
     *out = g.release();
     return KR_OK;
 }
-extern "C" void kr_ep_loopback_destroy(kr_ep_loop_group* g) {
-    if (!g) return;
+// Engines attached with kr_ep_init_loopback hold a pointer to the group: destroying it under them would leave that pointer dangling, so the
+// call is refused (non-zero, the group stays valid) until every attached engine went through kr_ep_destroy / kr_engine_destroy.
+extern "C" int kr_ep_loopback_destroy(kr_ep_loop_group* g) {
+    if (!g) return KR_OK;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (g->attached > 0) return kr_fail(KR_ERR_STATE, "kr_ep_loopback_destroy: %d engine(s) are still attached to the group (kr_ep_destroy them first)", g->attached);
+    }
     for (int r = 0; r < g->world; r++) if (g->slots[r].ready) (void)hipEventDestroy(g->slots[r].ready);
     delete g;
+    return KR_OK;
 }
 extern "C" int kr_ep_init_loopback(kr_engine* e, kr_ep_loop_group* group, int rank, int n_experts_total, int return_bf16) {
     if (!group) return kr_fail(KR_ERR_VALUE, "null loopback group");
     std::unique_ptr<kr_ep_state> s;
     if (int rc = ep_init_common(e, group->world, rank, n_experts_total, return_bf16, s)) return rc;
     s->loop = group;
-    return ep_init_finish(e, s);
+    if (int rc = ep_init_finish(e, s)) return rc;
+    { std::lock_guard<std::mutex> lk(group->mu); group->attached++; }
+    return KR_OK;
 }
 
 extern "C" int kr_ep_destroy(kr_engine* e) {
@@ -275,6 +292,7 @@ extern "C" int kr_ep_destroy(kr_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     if (s->comm) (void)g_rccl.CommDestroy(s->comm);
+    if (s->loop) { std::lock_guard<std::mutex> lk(s->loop->mu); s->loop->attached--; }
     for (DevBuf* b : {&s->dest, &s->lid, &s->i32, &s->rows, &s->row_lid, &s->rrows, &s->rlid, &s->eo, &s->eo16, &s->back, &s->ones, &s->cnt_all, &s->shared_out, &s->neg_ids, &s->red}) b->release();
     if (s->cnt_host) (void)hipHostFree(s->cnt_host);
     if (s->ev) (void)hipEventDestroy(s->ev);

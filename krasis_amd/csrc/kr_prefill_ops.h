@@ -50,6 +50,7 @@ int kr_launch_mla_scores_mfma(const float* q_abs, const float* q_pe, const void*
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st);
 // FAST mode (kr_attn_flash.hip): causal flash attention on f16 MFMA after the same prep launch; non-zero = geometry not covered
 int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st);
+bool kr_pfm_gqa_flash_ok(int nh, int nkv, int hd);      // geometries the flash kernel covers (the others take the exact passes and need their score scratch)
 void kr_launch_pfm_gqa_prep(const KrPfmGqaArgs& a, int C, hipStream_t st);
 int kr_launch_pfm_la_recur(float* state, const float* q, const float* k, const float* v, const float* gexp, const float* beta, float* out, int nv, int dk, int dv, int C, hipStream_t st);
 // FAST mode (kr_la_chunk.hip): the gated delta rule over the chunk in sub-chunks of 64 tokens on the f32 MFMA; non-zero = geometry not covered

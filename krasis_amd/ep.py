@@ -205,8 +205,10 @@ class LoopbackGroup:
         return res
 
     def close(self) -> None:
+        """destroy the group; raises RuntimeError while engines attached with ExpertParallel(..., loopback=group) are still alive (close them first)"""
         if self._h:
-            self._lib.kr_ep_loopback_destroy(self._h); self._h = None
+            from . import _lib
+            _lib.check(self._lib.kr_ep_loopback_destroy(self._h)); self._h = None
 
 
 def engine_row_ops(engine) -> Tuple[RowOps, Callable]:

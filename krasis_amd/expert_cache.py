@@ -154,6 +154,16 @@ def save_cpu_cache(engine, path: str, chash: int, num_bits: int, total_moe_layer
     return size
 
 
+def _close_map(mm, f) -> None:
+    """Close a cache mapping.  When an upload raised, the traceback still references numpy views of the map and mmap.close() answers BufferError
+    ("cannot close exported pointers exist"), which would mask the loader's own error: the map is then left to the garbage collector."""
+    try:
+        mm.close()
+    except BufferError:
+        pass
+    f.close()
+
+
 def load_cpu_cache(engine, path: str, chash: int, expected_bits: int, total_moe_layers: Optional[int] = None, start_moe_layer: int = 0,
                    num_layers_to_load: Optional[int] = None) -> None:
     """load_cpu_cache (weights/mod.rs:2794-2966) into a configured engine: layers [start, start + n) of the file become engine layers 0..n-1
@@ -198,7 +208,7 @@ def load_cpu_cache(engine, path: str, chash: int, expected_bits: int, total_moe_
         engine.synchronize()
         engine._cpu_bits = engine._gpu_bits = expected_bits
     finally:
-        mm.close(); f.close()
+        _close_map(mm, f)
 
 
 # ---------------------------------------------------------------------------------------------------------------- Marlin GPU cache (v3)
@@ -279,4 +289,4 @@ def load_marlin_cache(engine, path: str, chash: int, gpu_bits: int, total_moe_la
         engine.synchronize()
         engine._cpu_bits = engine._gpu_bits = gpu_bits
     finally:
-        mm.close(); f.close()
+        _close_map(mm, f)

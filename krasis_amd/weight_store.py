@@ -143,7 +143,7 @@ def load_from_hf(engine, model_dir: str, num_bits: int = 4, w2_bits: Optional[in
                 loader(engine, path, chash, num_bits, total_moe_layers=n_moe, start_moe_layer=start, num_layers_to_load=count)
                 engine.cache_note = f"loaded {kind} cache {path}"
                 return cfg
-            except RuntimeError as ex:
+            except (RuntimeError, BufferError, ValueError) as ex:      # a bad cache never aborts the load: fall through to quantization
                 engine.cache_note = f"{kind} cache {path} not used: {ex}"
     prefix = detect_expert_prefix(wm)
     handles: Dict[str, object] = {}

@@ -259,4 +259,6 @@ def test_round3_abi_argument_errors():
     ep = ExpertParallel(eng, 8, rank=0, loopback=grp)
     with pytest.raises(RuntimeError, match="already initialised"):
         ExpertParallel(eng, 8, rank=0, loopback=grp)
+    with pytest.raises(RuntimeError, match="still attached"):      # the group outlives every engine attached to it
+        grp.close()
     ep.close(); grp.close()

@@ -199,3 +199,43 @@ def test_moe_prefill_q4k_tolerance_form(H, I, E, k, M, shared, gu_t, dn_t):
     assert rms > 2e-5, ("the tolerance form did not run", rms)
     if not shared:
         assert not g[min(77, M - 1)].any()            # every slot skipped: zeros
+
+
+@pytest.mark.parametrize("which", ["gate", "up", "down"])
+def test_tolerance_copy_follows_a_later_upload(which):
+    """the KR_GEMM_FAST copy of a native-GGUF layer (gg_ensure_fast) is derived data.  An expert uploaded AFTER the first tolerance-mode
+    prompt pass must be what the next tolerance pass computes with -- including `up`, whose columns live behind the gate set's copy."""
+    import torch
+    from krasis_amd import KrasisEngine, ModelConfig, _lib
+    from krasis_amd._lib import check
+    H, I, E, k, M = 512, 256, 4, 2, 96
+    rng = np.random.default_rng(99)
+    experts = [make(rng, H, I, O.Q4_K, O.Q4_K) for _ in range(E)]
+    eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, 1, 0, 1.0))
+    for e, ex in enumerate(experts):
+        eng.load_gguf_expert(0, e, ex.gate, ex.up, ex.down, O.Q4_K, O.Q4_K, I)
+    act = rand_bf16(rng, (M, H)); ids = np.stack([rng.choice(E, k, replace=False) for _ in range(M)]).astype(np.int32)
+    w = rng.random((M, k)).astype(np.float32)
+    xd = torch.from_numpy(act.view(np.int16)).cuda(); idd = torch.from_numpy(ids).cuda(); wd = torch.from_numpy(w).cuda()
+    st = torch.cuda.current_stream().cuda_stream or 1
+
+    def run(fast):
+        out = torch.empty((M, H), dtype=torch.float32, device="cuda")
+        check(eng._lib.kr_moe_set_gemm_mode(eng._h, 1 if fast else 0))
+        check(eng._lib.kr_moe_prefill(eng._h, 0, xd.data_ptr(), idd.data_ptr(), wd.data_ptr(), out.data_ptr(), M, k, _lib.KR_OUT_F32, 1, st))
+        check(eng._lib.kr_moe_set_gemm_mode(eng._h, 0))
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    before = run(True)                                    # builds the tolerance copy
+    bytes_with_copy = eng.device_bytes()
+    new = make(rng, H, I, O.Q4_K, O.Q4_K)                 # replace ONE matrix of expert 1
+    ex = experts[1]
+    g, u, d = (new.gate if which == "gate" else ex.gate), (new.up if which == "up" else ex.up), (new.down if which == "down" else ex.down)
+    eng.load_gguf_expert(0, 1, g, u, d, O.Q4_K, O.Q4_K, I)
+    assert eng.device_bytes() < bytes_with_copy           # the stale copy's bytes are released and un-counted
+    exact, fast = run(False), run(True)
+    rms = float(np.sqrt(((fast - exact) ** 2).mean()) / np.sqrt((exact ** 2).mean()))
+    changed = float(np.sqrt(((fast - before) ** 2).mean()) / np.sqrt((before ** 2).mean()))
+    assert rms <= 1.5e-3, ("tolerance pass still reads the stale copy", rms)
+    assert changed > 1e-2, changed                        # the upload did change the layer's output
