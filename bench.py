@@ -92,7 +92,7 @@ def parse():
                          "tests/test_decode_fast_gpu.py, router ids identical for identical logits), exact = bit-identical to the reference's CPU decode; the other mode is reported as a side leg")
     ap.add_argument("--prefill-chunk", type=int, default=0, help="tokens per chunk of the prompt pass (0 = library default)")
     ap.add_argument("--prefill-depth", type=int, default=0, help="chunks of the prompt pass in flight (0 = library default)")
-    ap.add_argument("--prefill-reps", type=int, default=1, help="timed repetitions of the whole-model prompt pass per prompt length")
+    ap.add_argument("--prefill-reps", type=int, default=2, help="timed repetitions (>= 2) of the whole-model prompt pass per prompt length, after one un-timed pass of the same prompt; value = median")
     ap.add_argument("--no-long-context", action="store_true", help="skip the long-cache decode side measurement of the N = 1 line")
     ap.add_argument("--no-ep", action="store_true", help="skip the expert-parallel prompt-pass leg of the N > 1 lines")
     ap.add_argument("--ep-timeout", type=int, default=420, help="seconds the multi-GPU expert-parallel side legs may take before every rank gives up (rank 0 still prints the line)")
@@ -398,27 +398,42 @@ def prefill_ep(eng, dims, L, M, world, rank, torch, dist, experts_local=None):
                     "routing order, per layer, inside libkrasis_hip.so (kr_moe_prefill_ep); compare with prefill_experts_only of the N = 1 line"}
 
 
+def alloc_count():
+    """device allocations libkrasis_hip.so has made so far (kr_alloc_count_total): read on both sides of a timed region"""
+    from krasis_amd import _lib
+    return int(_lib.load_library().kr_alloc_count_total())
+
+
 def prefill_model(st, dims, gemm_macs_per_token, L, P, reps, torch):
     """Whole-model prompt pass (kr_decode_prefill): P synthetic tokens through all L layers.  tok/s = P / time.  Roofline per SURVEY 8(d):
-    useful GEMM MACs x 2 / t against the int8 MFMA peak."""
+    useful GEMM MACs x 2 / t against the int8 MFMA peak.  Protocol: ONE un-timed pass of the SAME prompt in the SAME
+    mode first (every arena, per-weight table and context-sized buffer the timed pass needs exists afterwards), then `reps` >= 2 timed passes, each
+    bracketed by a device synchronize; `value` is the MEDIAN pass, the best pass rides along; the library's allocation counter must not move inside
+    the timed region (`allocs_in_timed_region`, 0 or the measurement is flagged invalid)."""
     import numpy as np
+    reps = max(2, reps)
     st.fill_state_synthetic(P + 64, 7)                      # KV caches / states sized for the prompt
     toks = [int(x) for x in np.random.default_rng(5).integers(0, dims["vocab"], P)]
-    # warm-up: scratch arenas (sized by the chunk length the pass picks: up to 4096 tokens x 2 chunks in the tolerance modes), per-weight nibble sums,
-    # router gate copies, tolerance copies of GGUF layers -- nothing may be allocated inside the timed region
-    st.prefill(toks[: min(P, 8192)], 0)
-    if P > 8192:
-        st.prefill(toks[:64], P - 64)                       # ... and the buffers that grow with the context (score scratch of the exact mode)
+    st.prefill(toks, 0)                                     # warm-up: same length, same mode
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    a0 = alloc_count()
+    times = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         st.prefill(toks, 0)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    allocs = alloc_count() - a0
+    ts = sorted(times)
+    dt = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
     useful = 2.0 * P * gemm_macs_per_token / dt / 1e12
-    return {"value": P / dt, "unit": "tok/s", "tokens": P, "ms": dt * 1e3, "reps": reps, "layers": L, "target_tok_s": 3300,
-            "roofline": {"bound": "mfma", "achieved": useful, "peak": I8_PEAK_TOPS, "unit": "TOP/s (int8; 2 x useful GEMM MACs / s, SURVEY 8d)",
-                         "frac": useful / I8_PEAK_TOPS, "int8_TOPS_issued": 2.0 * useful}}
+    r = {"value": P / dt, "unit": "tok/s", "tokens": P, "ms": dt * 1e3, "reps": reps, "ms_best": ts[0] * 1e3, "tok_s_best": P / ts[0], "ms_all": [round(x * 1e3, 2) for x in times],
+         "allocs_in_timed_region": allocs, "layers": L, "target_tok_s": 3300,
+         "roofline": {"bound": "mfma", "achieved": useful, "peak": I8_PEAK_TOPS, "unit": "TOP/s (int8; 2 x useful GEMM MACs / s, SURVEY 8d)",
+                      "frac": useful / I8_PEAK_TOPS, "int8_TOPS_issued": 2.0 * useful}}
+    if allocs:
+        r["invalid"] = "the library allocated device memory %d time(s) inside the timed region" % allocs
+    return r
 
 
 def qcn_gemm_macs_per_token(L):
@@ -456,6 +471,24 @@ def time_decode(st, steps, warmup, kvm, torch, dist, world):
     if world > 1:
         t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     return dt
+
+
+def decode_generate(st, kvm, n_tokens=64, runs=3, lookahead=False):
+    """The reference's decode protocol (benchmark.py:434-505 -> generate_batch, decode.rs:3525-3600): `runs` generations of `n_tokens` tokens, every
+    sampled (greedy) token read back and fed to the next step; timed by the library's own clock around the loop (last_decode_elapsed_s, the
+    reference's Rust Instant).  lookahead = kr_decode_set_option("generate_lookahead"): the token feeds the next step on the device and the host reads
+    it while that step runs (same tokens; stated difference in the state after an early stop id -- none is used here)."""
+    st.set_option("generate_lookahead", 1 if lookahead else 0)
+    try:
+        st.generate_batch(0, 10, 8)                          # warm-up (graph capture, pinned ring)
+        per = []
+        for r in range(runs):
+            toks = st.generate_batch(0, 10, n_tokens)
+            per.append(len(toks) / st.last_decode_elapsed_s())
+    finally:
+        st.set_option("generate_lookahead", 0)
+    return {"tok_s": sum(per) / len(per), "runs": [round(x, 1) for x in per], "tokens_per_run": n_tokens,
+            "loop": "look-ahead (device-side token feedback, host reads token i during step i + 1)" if lookahead else "reference loop (host reads every token before queuing the next step)"}
 
 
 def profile_kinds(st, kvm, P=5, step_ms=None):
@@ -510,9 +543,9 @@ def side_config(name, rank, local_rank, args, torch):
         res = {"workload": WORKLOAD[name], "kv": "FP8-E4M3", "weights": "routed experts: native Q4_K blocks (0.5625 B / weight); projections, shared expert, lm_head: INT4-g128"}
         try:
             macs = qcn_gemm_macs_per_token(L)
-            res["prefill"] = prefill_model(st, dims, macs, L, 8192, 1, torch)
+            res["prefill"] = prefill_model(st, dims, macs, L, 8192, args.prefill_reps, torch)
             st.set_attention_mode(True, gemm_fast=True)
-            res["prefill_fast_gemm"] = prefill_model(st, dims, macs, L, 8192, 1, torch)
+            res["prefill_fast_gemm"] = prefill_model(st, dims, macs, L, 8192, args.prefill_reps, torch)
             r0 = res["prefill_fast_gemm"]["roofline"]
             res["prefill_fast_gemm"]["roofline"] = {"bound": "mfma", "achieved": r0["achieved"], "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s (f16 MFMA; 2 x useful GEMM MACs / s)", "frac": r0["achieved"] / F16_PEAK_TFLOPS}
             st.set_attention_mode(False)
@@ -538,10 +571,10 @@ def side_config(name, rank, local_rank, args, torch):
     st.set_attention_mode(False)
     try:
         macs = qcn_gemm_macs_per_token(L) if qcn else (q235_gemm_macs_per_token(L) if q235 else v2l_gemm_macs_per_token(L))
-        res["prefill"] = prefill_model(st, dims, macs, L, 8192, 1, torch)
+        res["prefill"] = prefill_model(st, dims, macs, L, 8192, args.prefill_reps, torch)
         for key, gfast in (("prefill_fast", False), ("prefill_fast_gemm", True)):       # tolerance modes: attention (+ delta rule), then the GEMMs as well
             st.set_attention_mode(True, gemm_fast=gfast)
-            res[key] = prefill_model(st, dims, macs, L, 8192, 1, torch)
+            res[key] = prefill_model(st, dims, macs, L, 8192, args.prefill_reps, torch)
             if gfast:      # one f16 MFMA per MAC in this form: priced against the f16 matrix peak
                 r0 = res[key]["roofline"]
                 res[key]["roofline"] = {"bound": "mfma", "achieved": r0["achieved"], "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s (f16 MFMA; 2 x useful GEMM MACs / s)", "frac": r0["achieved"] / F16_PEAK_TFLOPS}

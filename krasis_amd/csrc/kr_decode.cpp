@@ -85,6 +85,8 @@ extern "C" void kr_decode_destroy(kr_decode_store* s) {
                       &s->gbuf, &s->betabuf, &s->gatebuf, &s->latbuf, &s->recur_out, &s->attn_out, &s->logits, &s->gate_val, &s->tok, &s->step_dev,
                       &s->hid2, &s->res2, &s->f_qk, &s->r_counter, &s->gqa_scores, &s->fd_o, &s->fd_ml, &s->argmax_scratch, &s->img_in, &s->img_post, &s->img_post_bf16, &s->img_attn, &s->smp_seen, &s->smp_keys, &s->smp_temp, &s->smp_probs, &s->smp_rng, &s->pf_scratch, &s->pf_scores, &s->pf_vlogits, &s->pf_nll, &s->pf_tokens, &s->moe_gu, &s->moe_eo, &s->r_logits, &s->r_ids, &s->r_w, &s->dense_gu}) b->release();
     for (hipEvent_t ev : s->pf_events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : s->gen_ev) if (ev) (void)hipEventDestroy(ev);
+    if (s->gen_ring) (void)hipHostFree(s->gen_ring);
     for (hipStream_t ps : s->pf_side) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
     if (s->own_eng) kr_engine_destroy(s->eng);
     delete s;
@@ -503,8 +505,11 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
     // expert-parallel decode: router, attention, norms and the shared expert are replicated; every rank runs the routed experts of ITS slice
     // and the k expert rows are summed over the ranks (each row is non-zero on exactly one rank, so the sum is exact: logits equal single-engine decode
     // bit for bit) before the combine in routing order.  Reference analogue: python/krasis/gpu_prefill.py:3700-3790 (local subset + partial-sum reduce).
-    const bool ep_dec = kr_ep_world(e) > 1;
-    const bool fast = s->decode_fast && s->use_images && H % 128 == 0 && H <= 4096 && s->f_qk.p && !ep_dec;
+    // Under KR_DECODE_FAST the expert-parallel form is lighter: every rank's down launch leaves its PARTIAL combine (rsf * sum over its own slots; the layer's
+    // shared expert is evaluated by ONE rank, layer mod world, and added there) in the hidden buffer and ONE all-reduce of [hidden] f32 per MoE layer sums the
+    // partials -- 1 / k of the bytes of the exact form, and no combine left for the next norm.  The sum order over the ranks is RCCL's: tolerance mode.
+    const bool ep_dec = kr_ep_decode_active(e);
+    const bool fast = s->decode_fast && s->use_images && H % 128 == 0 && H <= 4096 && s->f_qk.p;
     for (size_t li = 0; li < s->layers.size(); li++) {
         DLayer& L = s->layers[li];
         // INT16 activation images: built once by the kernel that produces an activation, copied by every workgroup of the
@@ -656,9 +661,9 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             if (s->own_eng || L.moe_layer >= (int)e->layers.size()) return kr_fail(KR_ERR_STATE, "set_moe_store was not called (MoE layer %d has no engine)", L.moe_layer);
             Layer& EL = e->layers[L.moe_layer];
             if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
-            if (!EL.w13.allocated()) return kr_fail(KR_ERR_STATE, EL.gguf ? "MoE layer %d holds native GGUF blocks: the decode step runs on INT4 / INT8 transposed experts (decode.rs:3330 calls moe_forward_unified); kr_decode_prefill and kr_moe_forward take GGUF layers"
-                                                                       : "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
-            if (fast) {   // norm + gate GEMV | select + gate|up + silu*up | down + combine: three launches, the MoE output lands in `hid`
+            if (!EL.w13.allocated() && !EL.gguf) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);
+            if (EL.gguf && ep_dec) return kr_fail(KR_ERR_STATE, "expert-parallel decode on native GGUF layers is not implemented (MoE layer %d)", L.moe_layer);
+            if (fast && !EL.gguf) {   // norm + gate GEMV | select + gate|up + silu*up | down + combine: three launches, the MoE output lands in `hid`
                 const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
                 KrFmoeArgs fa{}; KrMoeArgs& a = fa.m;
                 a.shared_decode = 1; a.act_img = s->img_post.p; a.act_img_bf16 = s->img_post_bf16.p;
@@ -677,6 +682,10 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
                 }
                 fa.logits = (const float*)s->r_logits.p; fa.esc = EL.has_esc ? (const float*)EL.esc.p : nullptr; fa.scoring = s->scoring; fa.norm_topk = s->norm_topk;
                 fa.hid_out = hid;
+                if (ep_dec) {
+                    kr_ep_slice(e, &a.e_lo, &a.e_hi, &a.e_sub);
+                    fa.shared_skip = has_shared && kr_ep_rank(e) != (int)(li % (size_t)kr_ep_world(e)) ? 1 : 0;
+                }
                 if (ok && kr_fmoe_check(fa) == 0) {
                     KrFrtArgs ra{};
                     ra.gate_cm = EL.gate_cm.p; ra.gate_bf16 = EL.gate_bf16_exact; ra.bias = EL.has_bias ? (const float*)EL.bias.p : nullptr; ra.logits = (float*)s->r_logits.p;
@@ -690,6 +699,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
                         prof_mark(s, PK_MOE_W13, st); const int r13 = kr_launch_fw13(fa, st); prof_mark(s, -1, st);
                         prof_mark(s, PK_MOE_W2, st); const int r2 = kr_launch_fw2(fa, st); prof_mark(s, -1, st);
                         if (r13 || r2) return kr_fail(KR_ERR_STATE, "internal: KR_DECODE_FAST expert launch refused after kr_fmoe_check accepted layer %zu", li);
+                        if (ep_dec) if (int rc = kr_ep_allreduce_on(e, hid, (size_t)H, st)) return rc;
                         res_cur = other(res_cur); src = from_hidden; moe_done = true;
                     }
                 }
@@ -717,6 +727,38 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             }
             const bool has_shared = L.sgu_wid >= 0;
             const bool has_gate = has_shared && L.sg_wid >= 0;
+            if (EL.gguf) {
+                // NATIVE GGUF EXPERTS in the decode step.  The reference's Rust decode_step always calls moe_forward_unified (decode.rs:3334), its
+                // native-GGUF layers decode through the per-layer Python loop -> moe_forward_gguf (moe.rs:990-1110, tests/test_gguf_native.py:47-57).  Here the same
+                // arithmetic sits inside the captured step: router as above; the k routed experts through the block kernels of kr_gguf.hip on bf16(hidden)
+                // (per-32 INT16 activations, exact integer dots, the AVX2 kernel's 8 lane chains + hsum per row: bit-equal to kr_moe_forward = the oracle's
+                // moe_forward_gguf); the decode store's shared expert (INT4 / INT8 transposed, f32 hidden, decode.rs:3356-3378) as slot k of the same row
+                // buffer; weighted sum in routing order, rsf and shared * sigmoid(gate) in the next fused add+RMSNorm, as for transposed experts.
+                GgMoeArgs g{};
+                g.B = 1; g.topk = k; g.n_slots = k; g.H = H; g.E = e->cfg.n_routed_experts; g.act_f32 = act; g.ids = (const int32_t*)s->r_ids.p;
+                g.gate = EL.g_gate.view(); g.up = EL.g_up.view(); g.down = EL.g_down.view();
+                const int sI = has_shared ? s->weights[L.sgu_wid]->rows / 2 : 0;
+                g.I_max = EL.inter; g.gu_ld = 2 * (sI > EL.inter ? sI : EL.inter);       // row pitch of the shared gate|up scratch below
+                g.gu = (float*)s->moe_gu.p; g.eo = (float*)s->moe_eo.p;
+                prof_mark(s, PK_MOE_W13, st);
+                kr_launch_gguf_moe(g, st);
+                prof_mark(s, -1, st);
+                if (has_shared) {
+                    KrMoeArgs a{};
+                    a.act_f32 = act; a.shared_decode = 1; if (routed && img_ok) { a.act_img = s->img_post.p; a.act_img_bf16 = s->img_post_bf16.p; }
+                    a.B = 1; a.topk = 0; a.n_slots = 1; a.E = 0; a.H = H; a.I = sI; a.I_shared = sI;
+                    a.sw13 = mv(s, L.sgu_wid); a.sw2 = mv(s, L.sd_wid); a.w13 = a.sw13; a.w2 = a.sw2;      // launch geometry follows w13 / w2 (bits, K); slot 0 is the shared slot
+                    a.gu_ld = g.gu_ld; a.gu = g.gu + (size_t)k * g.gu_ld; a.eo = g.eo + (size_t)k * H;
+                    a.rsf = s->rsf; a.swiglu_limit = e->cfg.swiglu_limit; a.alpha = e->cfg.activation_alpha;
+                    a.act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
+                    PROF(PK_MOE_W13, kr_launch_moe_w13(a, st));
+                    if (has_gate) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), act, 1, (float*)s->gate_val.p, st));
+                    PROF(PK_MOE_W2, kr_launch_moe_w2(a, st));
+                }
+                src = KrNormSrc{}; src.mode = 2; src.eo = g.eo; src.ids = g.ids; src.wts = (const float*)s->r_w.p; src.topk = k; src.has_shared = has_shared ? 1 : 0;
+                src.gate_val = has_gate ? (const float*)s->gate_val.p : nullptr; src.rsf = s->rsf;
+                continue;
+            }
             KrMoeArgs a{};
             a.act = nullptr; a.act_f32 = act; a.shared_decode = 1;
             if (routed && img_ok) { a.act_img = s->img_post.p; a.act_img_bf16 = s->img_post_bf16.p; }
@@ -763,8 +805,10 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
     return KR_OK;
 }
 
+// token == KR_TOKEN_FROM_DEVICE: the step's token is whatever the previous step's sampler left in s->tok (always a valid id)
+#define KR_TOKEN_FROM_DEVICE (-2)
 static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
-    if (token < 0 || token >= s->vocab) return kr_fail(KR_ERR_VALUE, "token id %d out of range (vocab %d)", token, s->vocab);
+    if (token != KR_TOKEN_FROM_DEVICE && (token < 0 || token >= s->vocab)) return kr_fail(KR_ERR_VALUE, "token id %d out of range (vocab %d)", token, s->vocab);
     if (pos < 0) return kr_fail(KR_ERR_VALUE, "position %d must be >= 0", pos);
     if (s->kv_max_seq > 0 && pos >= s->kv_max_seq) return kr_fail(KR_ERR_VALUE, "position %d >= kv_max_seq %d", pos, s->kv_max_seq);
     if (s->max_rope_seq > 0 && pos >= s->max_rope_seq) return kr_fail(KR_ERR_VALUE, "position %d >= rope table length %d", pos, s->max_rope_seq);
@@ -788,9 +832,15 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
                 if (s->fd_o.ensure((size_t)L.nh * L.klr * nch * 4) || s->fd_ml.ensure((size_t)L.nh * nch * 8)) return kr_fail(KR_ERR_HIP, "hipMalloc of the split-KV partials failed");
             }
         }
-    kr_launch_set_step((KrStep*)s->step_dev.p, token, pos, st);   // by-value kernel arguments: no host slot shared between queued steps
+    if (token == KR_TOKEN_FROM_DEVICE) kr_launch_set_step_dev((KrStep*)s->step_dev.p, (const int*)s->tok.p, pos, st);
+    else kr_launch_set_step((KrStep*)s->step_dev.p, token, pos, st);   // by-value kernel arguments: no host slot shared between queued steps
     s->last_stream = st;
-    if (s->use_graph && kr_ep_world(s->eng) == 1) {      // expert-parallel decode enqueues every step: the all-reduce is a host-driven collective
+    // expert-parallel decode enqueues every step by default (the loopback transport's hand-off is host-driven and cannot be captured); over RCCL the
+    // all-reduce is a stream operation like any kernel: kr_decode_set_option("ep_graph", 1) captures it with the step.  The first two steps of a store run
+    // eagerly even then -- RCCL sets up its channels / proxy connections on the first collectives, which must not happen inside a capture.
+    const bool ep_active = kr_ep_decode_active(s->eng);
+    if (ep_active && s->ep_eager_steps < 2) s->ep_eager_steps++;
+    else if (s->use_graph && (!ep_active || (s->opt_ep_graph && kr_ep_is_rccl(s->eng)))) {
         if (!s->graph_ok) {
             if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
             hipGraph_t g = nullptr;
@@ -836,6 +886,8 @@ extern "C" int kr_decode_set_option(kr_decode_store* s, const char* name, int va
     if (!name) return kr_fail(KR_ERR_VALUE, "null option name");
     if (!strcmp(name, "gqa_stream")) { s->opt_gqa_stream = value != 0; s->graph_ok = false; return KR_OK; }
     if (!strcmp(name, "pfm_timing")) { s->opt_pfm_timing = value != 0; return KR_OK; }
+    if (!strcmp(name, "generate_lookahead")) { s->opt_gen_lookahead = value != 0; return KR_OK; }
+    if (!strcmp(name, "ep_graph")) { s->opt_ep_graph = value != 0; s->graph_ok = false; return KR_OK; }
     return kr_fail(KR_ERR_VALUE, "unknown option '%s'", name);
 }
 
@@ -844,10 +896,7 @@ extern "C" int kr_decode_set_use_graph(kr_decode_store* s, int enable) {
     s->use_graph = enable != 0; return KR_OK;
 }
 
-extern "C" int kr_decode_step(kr_decode_store* s, int token_id, int position, float* logits_out, void* stream) {
-    if (int rc = need_cfg(s)) return rc;
-    KR_HIP(hipSetDevice(s->eng->device));
-    hipStream_t st = kr_pick_stream(s->eng, stream);
+static int decode_step_on(kr_decode_store* s, int token_id, int position, float* logits_out, hipStream_t st) {
     // all scratch the MoE block needs must exist before capture (no allocation inside a capture)
     {
         kr_engine* e = s->eng; size_t gu = 0, eo = 0;
@@ -868,6 +917,13 @@ extern "C" int kr_decode_step(kr_decode_store* s, int token_id, int position, fl
         else { KR_HIP(hipMemcpyAsync(logits_out, s->logits.p, (size_t)s->vocab * 4, hipMemcpyDeviceToHost, st)); KR_HIP(hipStreamSynchronize(st)); }
     }
     return KR_OK;
+}
+
+extern "C" int kr_decode_step(kr_decode_store* s, int token_id, int position, float* logits_out, void* stream) {
+    if (int rc = need_cfg(s)) return rc;
+    if (token_id < 0) return kr_fail(KR_ERR_VALUE, "token id %d out of range (vocab %d)", token_id, s->vocab);
+    KR_HIP(hipSetDevice(s->eng->device));
+    return decode_step_on(s, token_id, position, logits_out, kr_pick_stream(s->eng, stream));
 }
 
 // ---- sampling state (generate_batch, decode.rs:3525-3600): seen-token bitmap, xorshift64 state, sort scratch -- all on the device
@@ -928,9 +984,9 @@ static int generate_core(kr_decode_store* s, int first_token, int start_pos, int
     int tok = first_token, n = 0;
     const auto t_start = std::chrono::steady_clock::now();
     auto stamp = [&]() { kr_standalone_set_elapsed(s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
-    for (int i = 0; i < max_tokens; i++) {
-        if (on_token && kr_standalone_cancelled(s)) { on_token(tok, 3, user); break; }
-        if (int rc = kr_decode_step(s, tok, start_pos + i, nullptr, st)) { stamp(); return rc; }     // graph replay ends with the greedy argmax into s->tok
+    // one decode step + the sampler; token < 0: the step consumes the token the previous sampler left on the device
+    auto step_and_sample = [&](int token, int pos) -> int {
+        if (int rc = decode_step_on(s, token, pos, nullptr, st)) return rc;     // graph replay ends with the greedy argmax into s->tok
         if (sampled) {
             uint64_t* keys = (uint64_t*)s->smp_keys.p;
             if (kr_launch_sample((float*)s->logits.p, s->vocab, temperature, top_k, top_p, presence_penalty, (uint32_t*)s->smp_seen.p, keys, keys + s->vocab,
@@ -941,6 +997,41 @@ static int generate_core(kr_decode_store* s, int first_token, int start_pos, int
             kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, st);
             kr_launch_mark_seen((uint32_t*)s->smp_seen.p, (const int*)s->tok.p, 0, st);
         }
+        return KR_OK;
+    };
+    if (s->opt_gen_lookahead && !on_token && max_tokens > 0) {
+        // LOOK-AHEAD form (kr_decode_set_option "generate_lookahead", off by default).  The reference's loop reads every sampled token on the host before it
+        // queues the next step (decode.rs:3560-3591), which idles the GPU for one host round trip per token.  Here the sampler's output stays on the
+        // device and feeds step i + 1 directly (kr_set_step_dev_kernel); the host reads token i from a pinned ring WHILE step i + 1 runs.  Same tokens
+        // as the plain loop.  One stated difference: when token i turns out to be a stop id, step i + 1 has already been queued -- the KV / recurrent
+        // state then includes the stop token (the plain loop leaves it out).  Callers that continue decoding from the state after a stop keep the default.
+        if (s->gen_ring_n < max_tokens) {
+            if (s->gen_ring) (void)hipHostFree(s->gen_ring);
+            s->gen_ring = nullptr; s->gen_ring_n = 0;
+            KR_HIP(hipHostMalloc((void**)&s->gen_ring, sizeof(int) * (size_t)max_tokens, hipHostMallocDefault));
+            s->gen_ring_n = max_tokens;
+        }
+        for (auto& ev : s->gen_ev) if (!ev) KR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (int rc = step_and_sample(tok, start_pos)) { stamp(); return rc; }
+        for (int i = 0; i < max_tokens; i++) {
+            KR_HIP(hipMemcpyAsync(&s->gen_ring[i], s->tok.p, 4, hipMemcpyDeviceToHost, st));
+            KR_HIP(hipEventRecord(s->gen_ev[i & 1], st));
+            if (i + 1 < max_tokens) if (int rc = step_and_sample(KR_TOKEN_FROM_DEVICE, start_pos + i + 1)) { stamp(); return rc; }
+            KR_HIP(hipEventSynchronize(s->gen_ev[i & 1]));
+            const int next = s->gen_ring[i];
+            tokens_out[n++] = next;
+            bool stop = false;
+            for (int j = 0; j < n_stop; j++) stop |= (stop_ids[j] == next);
+            if (stop) break;
+        }
+        KR_HIP(hipStreamSynchronize(st));
+        stamp();
+        *n_out = n;
+        return KR_OK;
+    }
+    for (int i = 0; i < max_tokens; i++) {
+        if (on_token && kr_standalone_cancelled(s)) { on_token(tok, 3, user); break; }
+        if (int rc = step_and_sample(tok, start_pos + i)) { stamp(); return rc; }
         int next = 0;
         KR_HIP(hipMemcpyAsync(&next, s->tok.p, 4, hipMemcpyDeviceToHost, st));
         KR_HIP(hipStreamSynchronize(st));

@@ -52,6 +52,8 @@ struct KrFmoeArgs {
     KrMoeArgs m;              // B == 1, act_img / act_img_bf16 set, ids / wts = OUTPUT of the w13 launch (read by the w2 launch), gu = expert hidden [n_slots][gu_ld]
     const float* logits; const float* esc; int scoring, norm_topk;
     float* hid_out;           // w2 launch: combined MoE output [H]
+    int shared_skip;          // expert-parallel decode (m.e_hi > 0): the shared expert of this layer is evaluated by another rank; this rank's hid_out is then its PARTIAL
+                              // rsf * sum over its own slots (+ the shared term on the one rank that evaluates it) and the ranks' partials are summed by one all-reduce of [H]
 };
 int kr_fmoe_check(const KrFmoeArgs& a);      // 0 when both launches below cover the geometry
 int kr_launch_fw13(const KrFmoeArgs& a, hipStream_t st);

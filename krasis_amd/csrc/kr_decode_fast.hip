@@ -622,10 +622,14 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
     const void* qb = m.q; const uint32_t* sb = m.s;
     const int inter = shared ? a.I_shared : a.I;
     if (!shared) {
-        const int e = s_ids[slot];
+        int e = s_ids[slot];
+        if (a.e_hi > 0) {      // expert-parallel decode: this rank evaluates the slots whose expert lies in its slice only (workgroup-uniform exit, no barrier is left behind it)
+            if (e < a.e_lo || e >= a.e_hi) return;
+            e -= a.e_sub;
+        }
         qb = reinterpret_cast<const char*>(m.q) + (size_t)e * m.q_stride;
         sb = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + (size_t)e * m.s_stride);
-    }
+    } else if (fa.shared_skip) return;      // expert-parallel decode: another rank evaluates this layer's (replicated) shared expert
     const int ntp = inter / 8;
     const int unit = blockIdx.x * TW + tw;
     const bool pair = unit < ntp;
@@ -677,20 +681,23 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     const int inter = shared ? a.I_shared : a.I;
     const void* qb = m.q; const uint32_t* sb = m.s;
     bool valid = true; float wt = 1.0f;
+    bool skip = false;        // expert-parallel decode: slot evaluated by another rank -- this wave contributes 0 and reads no weights
     if (!shared) {
-        const int e = a.ids[slot];
+        int e = a.ids[slot];
         valid = e >= 0 && e < a.E; wt = a.wts[slot];
-        const size_t ee = valid ? (size_t)e : 0;
+        if (a.e_hi > 0) { skip = !valid || e < a.e_lo || e >= a.e_hi; e -= a.e_sub; }
+        const size_t ee = valid && !skip ? (size_t)e : 0;
         qb = reinterpret_cast<const char*>(m.q) + ee * m.q_stride;
         sb = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + ee * m.s_stride);
-    }
+    } else skip = fa.shared_skip != 0;
     const int units = BITS == 4 ? m.ngp : m.ng;
     KrFw<BITS, NU, 8> W;     // 16 waves per workgroup leave 128 registers per lane: the guarded form keeps 8 records in flight
-    kr_f_fetch<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units);
+    if (!skip) kr_f_fetch<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units);
     const KrActLds L = kr_carve_lds(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(kr_fsm) + (size_t)slot * slot_lds), inter, BITS == 8);
     const float* h = a.gu + (size_t)slot * a.gu_ld;
     KR_FSTAMP(5, 1);
     const bool half_away = shared && a.shared_decode;
+    if (!skip)
     for (int c = lane; c < inter / 8; c += 64) {
         float v[8];
         kr_load8(h, c, v);
@@ -706,7 +713,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     }
     kr_f_wave_sync();
     KR_FSTAMP(5, 2);
-    const float acc = kr_f_tile<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units, L);
+    const float acc = skip ? 0.0f : kr_f_tile<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units, L);
     KR_FSTAMP(5, 3);
     if (l8 == 0) s_y[slot][cl] = acc;
     if (lane == 0) s_wt[slot] = valid ? wt : 0.0f;

@@ -51,6 +51,10 @@ struct kr_decode_store {
     int kv_fp8 = 0;            // GQA KV element type: 0 FP16 (reference CPU decode), 1 FP8-E4M3 (reference GPU cache dtype)
     DevBuf img_in, img_post, img_post_bf16, img_attn; bool use_images = true;   // pre-built INT16 activation images (input norm, post-attention norm f32 / bf16, attention output)
     int opt_gqa_stream = 0, opt_pfm_timing = 0;   // kr_decode_set_option: test / tuning hooks (no environment lookups on launch paths)
+    int opt_gen_lookahead = 0;                    // kr_decode_set_option("generate_lookahead"): generate_batch feeds the sampled token back ON THE DEVICE and queues step i + 1 before the host has read token i
+    int opt_ep_graph = 0;                         // kr_decode_set_option("ep_graph"): expert-parallel decode over RCCL replays a captured graph (the all-reduce is captured with the kernels)
+    int ep_eager_steps = 0;                        // expert-parallel decode: steps enqueued eagerly so far (RCCL warms up outside any capture)
+    int* gen_ring = nullptr; int gen_ring_n = 0; hipEvent_t gen_ev[2] = {nullptr, nullptr};   // pinned token ring + events of the look-ahead loop
     int decode_fast = 0; DevBuf f_qk;         // KR_DECODE_FAST: decode steps on the tolerance-mode kernels (kr_decode_fast.hip); f_qk = conv outputs [nk][q(dk) | k(dk)]
     int gemm_fast = 0;                        // KR_GEMM_FAST: prompt-pass GEMMs in the tolerance form (kr_prefill_h.hip)
     int attn_fast = 0; DevBuf fd_o, fd_ml;   // KR_ATTN_FAST: split-KV softmax + p.v with a log-sum-exp merge for long caches (tolerance mode)

@@ -60,6 +60,7 @@ size_t kr_mla_flash_decode_chunks(int max_seq);   // chunks of the FAST split-KV
 void kr_mla_attn_prepare(const KrMlaArgs& a, int max_seq);   // outside graph capture: LDS window of the staged attention kernel
 void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s, int rows = 1, int ld = 0);
 
+void kr_launch_set_step_dev(KrStep* dst, const int* token_dev, int pos, hipStream_t s);
 void kr_launch_set_step(KrStep* dst, int token, int pos, hipStream_t s);   // (token, pos) by value: safe with many steps queued
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s);
 struct KrNormSrc {   // where the value added to the residual comes from (see kr_fused_add_rmsnorm_kernel)

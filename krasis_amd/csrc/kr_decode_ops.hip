@@ -1150,6 +1150,9 @@ __global__ void __launch_bounds__(1024) kr_argmax_kernel(const float* __restrict
 // parameters before its DMA ran)
 __global__ void kr_set_step_kernel(KrStep* dst, int token, int pos) { dst->token = token; dst->pos = pos; }
 void kr_launch_set_step(KrStep* dst, int token, int pos, hipStream_t s) { hipLaunchKernelGGL(kr_set_step_kernel, dim3(1), dim3(1), 0, s, dst, token, pos); }
+// the same with the token taken from device memory (the previous step's sample): generate_batch's look-ahead loop queues step i + 1 without a host round trip
+__global__ void kr_set_step_dev_kernel(KrStep* dst, const int* token, int pos) { dst->token = *token; dst->pos = pos; }
+void kr_launch_set_step_dev(KrStep* dst, const int* token_dev, int pos, hipStream_t s) { hipLaunchKernelGGL(kr_set_step_dev_kernel, dim3(1), dim3(1), 0, s, dst, token_dev, pos); }
 
 void kr_launch_embed(const float* emb, const KrStep* st, float* hidden, int H, hipStream_t s) {
     hipLaunchKernelGGL(kr_embed_kernel, dim3((H + 255) / 256), dim3(256), 0, s, emb, st, hidden, H);

@@ -179,8 +179,9 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
         // routed experts: exact CPU-engine arithmetic on the matrix cores, f32 weighted sum in routing order
         // expert parallelism (kr_ep_init on the engine): this rank's chunk exchanges its (token, slot) rows with the owners over RCCL.  A collective:
-        // prefill_impl pads ranks that have fewer chunks with empty-shard calls.  One chunk in flight: the exchange buffers are per engine.
-        if (e->ep) { if (int rc = kr_moe_prefill_ep(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, st ? (void*)st : (void*)1)) return rc; }
+        // prefill_impl pads ranks that have fewer chunks with empty-shard calls.  Every chunk in flight has its own exchange-buffer set (cx.set) and stream; the
+        // collectives of all chunks are ISSUED in one host order that is the same on every rank (the loop structure below depends only on the agreed chunk count).
+        if (e->ep) { if (int rc = kr_moe_prefill_ep_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set, st ? (void*)st : (void*)1)) return rc; }
         else if (int rc = kr_moe_prefill_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set | (s->gemm_fast ? KR_PF_SET_FAST : 0), st)) return rc;
         const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
         if (has_shared) {   // decode-store numerics: f32 input digits, fast_silu_mul + f32::round digits (decode.rs:3356-3378)
@@ -266,8 +267,12 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     const int third = ((n_tokens + 2) / 3 + 63) / 64 * 64;
     const int tol_chunk = std::min(4096, std::max(KR_PFM_CHUNK, third));
     const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : (tol ? tol_chunk : KR_PFM_CHUNK));
-    const int depth = e->ep ? 1 : (s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : KR_PFM_DEPTH);   // chunks in flight (streams / arenas)
-    const int n_chunks = (n_tokens + CH - 1) / CH, n_arenas = std::min(n_chunks, depth), D = n_arenas;
+    const int depth = s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : KR_PFM_DEPTH;   // chunks in flight (streams / arenas)
+    // expert parallelism: every rank must walk the SAME (chunk, layer) schedule -- the exchanges are collectives -- so the schedule is built from the chunk
+    // count of the longest prompt shard (agreed below, before the first exchange); chunks a rank does not have run as empty shards
+    int n_chunks_max = (n_tokens + CH - 1) / CH;
+    if (e->ep) if (int rc = kr_ep_max_int(e, n_chunks_max, &n_chunks_max, st ? (void*)st : (void*)1)) return rc;
+    const int n_chunks = (n_tokens + CH - 1) / CH, n_arenas = std::min(e->ep ? n_chunks_max : n_chunks, depth), D = n_arenas;
     const int L = (int)s->layers.size();
 
     // ---- geometry of the widest layer -> scratch sizes (floats per token); nibble sums of every weight the GEMMs will touch
@@ -363,8 +368,6 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
         KR_HIP(hipEventRecord(s->pf_events[ev_start], st));               // side streams start after everything already queued on the main one
         for (int i = 1; i < D; i++) KR_HIP(hipStreamWaitEvent(streams[i], s->pf_events[ev_start], 0));
     }
-    int n_chunks_max = n_chunks;     // expert parallelism: chunks of the longest prompt shard over the ranks -- agreed on BEFORE the first exchange of the pass
-    if (e->ep) if (int rc = kr_ep_max_int(e, n_chunks, &n_chunks_max, st ? (void*)st : (void*)1)) return rc;
     const auto t_enqueue = std::chrono::steady_clock::now();
     std::vector<Chunk> chunks(n_chunks);
     for (int c = 0; c < n_chunks; c++) {
@@ -375,12 +378,23 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     }
     // D chunks in flight (one per stream / arena): groups of D chunks are enqueued layer-interleaved; chunk c + D follows chunk c on the same
     // stream, so its arena is free, and it waits layer by layer for chunk c + D - 1 -- the pipeline never drains between groups
-    for (int p0 = 0; p0 < n_chunks; p0 += D) {
-        const int nb = std::min(D, n_chunks - p0);
+    const int n_sched = e->ep ? n_chunks_max : n_chunks;      // expert parallelism: the schedule of the longest shard; this rank's missing chunks are phantoms
+    for (int p0 = 0; p0 < n_sched; p0 += D) {
+        const int nb = std::min(D, n_sched - p0);
         for (int d = 0; d < L + nb - 1; d++) {
             for (int j = 0; j < nb; j++) {
                 const int l = d - j, c = p0 + j;
                 if (l < 0 || l >= L) continue;
+                if (c >= n_chunks) {
+                    // phantom chunk: kr_moe_prefill_ep is a collective, one call per (chunk, MoE layer) on every rank IN THE SAME ORDER.  A rank whose prompt
+                    // shard has fewer chunks answers with an empty shard at the position the chunk would have had (its experts still serve the peers' rows).
+                    const DLayer& Ly = s->layers[(size_t)l];
+                    if (Ly.mlp == MLP_MOE) {
+                        hipStream_t ps = streams[c % D];
+                        if (int rc = kr_moe_prefill_ep_set(e, Ly.moe_layer, nullptr, nullptr, nullptr, nullptr, 0, s->topk, KR_OUT_F32, 1, c % D, ps ? (void*)ps : (void*)1)) return rc;
+                    }
+                    continue;
+                }
                 Chunk& cx = chunks[c];
                 if (c > 0 && D > 1) KR_HIP(hipStreamWaitEvent(cx.st, s->pf_events[(size_t)((c - 1) % D) * L + l], 0));
                 if (int rc = run_layer(s, cx, (size_t)l)) return rc;
@@ -389,14 +403,6 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
                     if (int rc = run_final_all(s, cx, (float*)((char*)s->pf_vlogits.p + (size_t)cx.set * vl_bytes), c * CH, n_tokens, c == n_chunks - 1)) return rc;
             }
         }
-    }
-    if (e->ep) {
-        // expert parallelism: kr_moe_prefill_ep is a collective, one call per (chunk, MoE layer) on every rank.  Ranks whose prompt shard has fewer
-        // chunks than the longest one keep answering with empty shards (their experts still serve the peers' rows) instead of leaving them blocked.
-        for (int c = n_chunks; c < n_chunks_max; c++)
-            for (auto& Ly : s->layers)
-                if (Ly.mlp == MLP_MOE)
-                    if (int rc = kr_moe_prefill_ep(e, Ly.moe_layer, nullptr, nullptr, nullptr, nullptr, 0, s->topk, KR_OUT_F32, 1, st ? (void*)st : (void*)1)) return rc;
     }
     Chunk& last = chunks[n_chunks - 1];
     if (!nll_out) run_final(s, last);

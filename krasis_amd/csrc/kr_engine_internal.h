@@ -119,6 +119,12 @@ extern "C" int kr_ep_destroy(kr_engine* e);
 int kr_ep_world(const kr_engine* e);
 void kr_ep_slice(const kr_engine* e, int* lo, int* hi, int* sub);
 int kr_ep_allreduce_on(kr_engine* e, float* buf_dev, size_t n, hipStream_t st);
+bool kr_ep_decode_active(const kr_engine* e);   // world > 1, or a one-rank RCCL communicator (bring-up): the decode step takes its expert-parallel form
+bool kr_ep_is_rccl(const kr_engine* e);          // the transport is an RCCL communicator (its collectives are stream operations: capturable in a hipGraph)
+int kr_ep_rank(const kr_engine* e);
+// kr_moe_prefill_ep with an explicit exchange-buffer set (one per prompt-pass chunk in flight, 0 .. KR_PF_MAX_DEPTH - 1)
+int kr_moe_prefill_ep_set(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk, int out_dtype,
+                          int routed_only, int set, void* stream);
 
 bool is_device_ptr(const void* p);
 kr_engine* kr_engine_new_bare(int device);   // device + stream only (a decode store created before its MoE engine)

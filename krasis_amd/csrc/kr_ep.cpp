@@ -114,9 +114,21 @@ struct kr_ep_state {
     ncclComm_t comm = nullptr;           // RCCL transport
     kr_ep_loop_group* loop = nullptr;    // loopback transport
     bool broken = false;                 // a collective failed: every later call is refused
-    DevBuf dest, lid, i32, rows, row_lid, rrows, rlid, eo, eo16, back, ones, cnt_all, shared_out, neg_ids, red;
-    int* cnt_host = nullptr;          // pinned [world * world]
-    hipEvent_t ev = nullptr;
+    // exchange buffers of one prompt-pass chunk in flight (kr_decode_prefill runs up to KR_PF_MAX_DEPTH chunks on as many streams: every chunk brings
+    // its own set, so that the rows of chunk c + 1 can be sorted / gathered / sent while chunk c's experts still run)
+    struct Bufs {
+        DevBuf dest, lid, i32, rows, row_lid, rrows, rlid, eo, eo16, back, ones, cnt_all, shared_out, neg_ids;
+        int* cnt_host = nullptr;          // pinned [world * world]
+        hipEvent_t ev = nullptr;
+    };
+    Bufs sets[KR_PF_MAX_DEPTH];
+    DevBuf red;                           // loopback all-reduce staging
+    int ensure_set(int i) {               // pinned split-size block + event of set i (created on first use)
+        Bufs& b = sets[i];
+        if (!b.cnt_host) KR_HIP(hipHostMalloc((void**)&b.cnt_host, sizeof(int) * world * world, hipHostMallocDefault));
+        if (!b.ev) KR_HIP(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+        return KR_OK;
+    }
 };
 
 namespace {
@@ -184,8 +196,8 @@ int ep_exchange(kr_ep_state* s, int nbuf, const void* const* send, void* const* 
 int ep_allreduce_f32(kr_engine* e, float* buf, size_t n, hipStream_t st) {
     kr_ep_state* s = e->ep;
     const int W = s->world;
-    if (W == 1) return KR_OK;
     if (s->comm) { KR_NCCL(g_rccl.AllReduce(buf, buf, n, ncclFloat32, 0, s->comm, st)); return KR_OK; }
+    if (W == 1) return KR_OK;
     kr_ep_loop_group* g = s->loop;
     if (s->red.ensure((size_t)W * n * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc of the all-reduce staging failed");
     g->slots[s->rank].buf = buf;
@@ -226,8 +238,7 @@ static int ep_init_common(kr_engine* e, int world, int rank, int n_experts_total
     return KR_OK;
 }
 static int ep_init_finish(kr_engine* e, std::unique_ptr<kr_ep_state>& s) {
-    KR_HIP(hipHostMalloc((void**)&s->cnt_host, sizeof(int) * s->world * s->world, hipHostMallocDefault));
-    KR_HIP(hipEventCreateWithFlags(&s->ev, hipEventDisableTiming));
+    if (int rc = s->ensure_set(0)) return rc;
     e->ep = s.release();
     return KR_OK;
 }
@@ -238,7 +249,8 @@ static int ep_init_finish(kr_engine* e, std::unique_ptr<kr_ep_state>& s) {
 extern "C" int kr_ep_init(kr_engine* e, int world, int rank, int n_experts_total, const void* id128, int return_bf16) {
     std::unique_ptr<kr_ep_state> s;
     if (int rc = ep_init_common(e, world, rank, n_experts_total, return_bf16, s)) return rc;
-    if (world > 1) {
+    if (world > 1 || id128) {      // world == 1 WITH an id: a one-rank RCCL communicator -- every collective then goes through librccl (bring-up aid: the RCCL
+                                   // transport, its grouped self send / recv and the captured all-reduce can be exercised on a single-GPU box)
         if (!id128) return kr_fail(KR_ERR_VALUE, "kr_ep_init needs the unique id of rank 0 when world > 1");
         if (int rc = load_rccl()) return rc;
         ncclUniqueId id; memcpy(&id, id128, sizeof id);
@@ -293,9 +305,10 @@ extern "C" int kr_ep_destroy(kr_engine* e) {
     (void)hipDeviceSynchronize();
     if (s->comm) (void)g_rccl.CommDestroy(s->comm);
     if (s->loop) { std::lock_guard<std::mutex> lk(s->loop->mu); s->loop->attached--; }
-    for (DevBuf* b : {&s->dest, &s->lid, &s->i32, &s->rows, &s->row_lid, &s->rrows, &s->rlid, &s->eo, &s->eo16, &s->back, &s->ones, &s->cnt_all, &s->shared_out, &s->neg_ids, &s->red}) b->release();
-    if (s->cnt_host) (void)hipHostFree(s->cnt_host);
-    if (s->ev) (void)hipEventDestroy(s->ev);
+    for (auto& b : s->sets) {      // the DevBufs release themselves with the state
+        if (b.cnt_host) (void)hipHostFree(b.cnt_host);
+        if (b.ev) (void)hipEventDestroy(b.ev);
+    }
     delete s; e->ep = nullptr;
     return KR_OK;
 }
@@ -311,13 +324,14 @@ extern "C" int kr_ep_max_int(kr_engine* e, int value, int* max_out, void* stream
     KR_HIP(hipSetDevice(e->device));
     hipStream_t st = kr_pick_stream(e, stream);
     const int W = s->world;
-    if (s->i32.ensure((size_t)W * 4) || s->cnt_all.ensure((size_t)W * W * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
-    for (int r = 0; r < W; r++) s->cnt_host[r] = value;
-    KR_HIP(hipMemcpyAsync(s->i32.p, s->cnt_host, (size_t)W * 4, hipMemcpyHostToDevice, st));
-    if (int rc = ep_gather_counts(s, (const int*)s->i32.p, (int*)s->cnt_all.p, st)) return ep_abort(s, rc);
-    KR_HIP(hipMemcpyAsync(s->cnt_host, s->cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st));
+    kr_ep_state::Bufs& B = s->sets[0];
+    if (B.i32.ensure((size_t)W * 4) || B.cnt_all.ensure((size_t)W * W * 4)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    for (int r = 0; r < W; r++) B.cnt_host[r] = value;
+    KR_HIP(hipMemcpyAsync(B.i32.p, B.cnt_host, (size_t)W * 4, hipMemcpyHostToDevice, st));
+    if (int rc = ep_gather_counts(s, (const int*)B.i32.p, (int*)B.cnt_all.p, st)) return ep_abort(s, rc);
+    KR_HIP(hipMemcpyAsync(B.cnt_host, B.cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st));
     KR_HIP(hipStreamSynchronize(st));
-    for (int r = 0; r < W; r++) if (s->cnt_host[r * W] > *max_out) *max_out = s->cnt_host[r * W];
+    for (int r = 0; r < W; r++) if (B.cnt_host[r * W] > *max_out) *max_out = B.cnt_host[r * W];
     return KR_OK;
 }
 
@@ -325,12 +339,15 @@ extern "C" int kr_ep_max_int(kr_engine* e, int value, int* max_out, void* stream
 // the single-GPU kr_moe_prefill result of the same tokens.  routed_only == 0 adds rsf * routed + shared with this rank's shared expert.
 // M == 0 (an empty shard; pointers may be NULL) takes part in the exchanges with empty blocks and computes the rows its peers send.
 // A collective call: every rank of the group calls with the same layer, in the same order.
-extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk, int out_dtype,
-                                 int routed_only, void* stream) {
+int kr_moe_prefill_ep_set(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk, int out_dtype,
+                          int routed_only, int set, void* stream) {
     if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
     if (!e->ep) return kr_fail(KR_ERR_STATE, "call kr_ep_init first");
     kr_ep_state* s = e->ep;
     if (s->broken) return kr_fail(KR_ERR_STATE, "expert parallelism: an earlier collective failed");
+    if (set < 0 || set >= KR_PF_MAX_DEPTH) return kr_fail(KR_ERR_VALUE, "exchange buffer set %d out of range", set);
+    if (int rc = s->ensure_set(set)) return rc;
+    kr_ep_state::Bufs& B = s->sets[set];
     // ---- everything that can fail for a local reason is checked BEFORE the first collective (a rank that bails out later would strand its peers)
     if (layer < 0 || layer >= (int)e->layers.size()) return kr_fail(KR_ERR_VALUE, "moe_layer_idx %d out of range", layer);
     if (M < 0 || (M > 0 && (!x_bf16 || !ids || !wts || !out))) return kr_fail(KR_ERR_VALUE, "bad arguments");
@@ -345,78 +362,79 @@ extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, co
     const int max_tiles = np / 64 + W + 1;
     const size_t n_i32 = 3 * (size_t)W + 3 * (size_t)max_tiles + 4 + 2 * (size_t)np;
     const size_t np1 = np ? (size_t)np : 1;
-    if (s->dest.ensure(np1 * 4) || s->lid.ensure(np1 * 4) || s->i32.ensure(n_i32 * 4) || s->rows.ensure(np1 * H * 2) || s->row_lid.ensure(np1 * 4) ||
-        s->cnt_all.ensure((size_t)W * W * 4) || (use_shared && (s->shared_out.ensure((size_t)M * H * 4) || s->neg_ids.ensure((size_t)M * 4))))
+    if (B.dest.ensure(np1 * 4) || B.lid.ensure(np1 * 4) || B.i32.ensure(n_i32 * 4) || B.rows.ensure(np1 * H * 2) || B.row_lid.ensure(np1 * 4) ||
+        B.cnt_all.ensure((size_t)W * W * 4) || (use_shared && (B.shared_out.ensure((size_t)M * H * 4) || B.neg_ids.ensure((size_t)M * 4))))
         return kr_fail(KR_ERR_HIP, "hipMalloc of the expert-parallel scratch failed");
-    int* ib = (int*)s->i32.p;
+    int* ib = (int*)B.i32.p;
     KrPfSort so{};
     so.counts = ib; so.offsets = ib + W; so.cursor = ib + 2 * W; ib += 3 * W;
     so.tile_expert = ib; so.tile_row0 = ib + max_tiles; so.tile_rows = ib + 2 * max_tiles; ib += 3 * max_tiles;
     so.n_tiles = ib; ib += 4; so.row_pair = ib; so.pair_row = ib + np;
     if (np) {
-        kr_launch_ep_dest(ids, np, s->E_total, s->per, W, s->full, (int32_t*)s->dest.p, (int32_t*)s->lid.p, st);
-        kr_launch_ep_sort((const int32_t*)s->dest.p, np, W, so, st);
-        kr_launch_ep_gather((const uint16_t*)x_bf16, so.row_pair, (const int32_t*)s->lid.p, topk, H, so.n_tiles + 1, np, (uint16_t*)s->rows.p, (int32_t*)s->row_lid.p, st);
+        kr_launch_ep_dest(ids, np, s->E_total, s->per, W, s->full, (int32_t*)B.dest.p, (int32_t*)B.lid.p, st);
+        kr_launch_ep_sort((const int32_t*)B.dest.p, np, W, so, st);
+        kr_launch_ep_gather((const uint16_t*)x_bf16, so.row_pair, (const int32_t*)B.lid.p, topk, H, so.n_tiles + 1, np, (uint16_t*)B.rows.p, (int32_t*)B.row_lid.p, st);
     } else KR_HIP(hipMemsetAsync(so.counts, 0, (size_t)W * 4, st));
     // ---- send counts of every rank: cnt[src][dst]
     // The host needs the split sizes to post the sends / receives: one small DtoH and an event wait per call.  A world of one posts nothing:
     // it takes every pair slot as a row (rows past the last routed pair carry local id -1 and belong to no expert tile) and never waits.
     std::vector<size_t> soff(W + 1, 0), roff(W + 1, 0);
-    if (W > 1) {
-        if (int rc = ep_gather_counts(s, so.counts, (int*)s->cnt_all.p, st)) return ep_abort(s, rc);
-        if (hipMemcpyAsync(s->cnt_host, s->cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(s->ev, st) != hipSuccess ||
-            hipEventSynchronize(s->ev) != hipSuccess)
+    const bool xchg = W > 1 || s->comm != nullptr;      // a one-rank communicator still runs the exchange (through RCCL, to itself)
+    if (xchg) {
+        if (int rc = ep_gather_counts(s, so.counts, (int*)B.cnt_all.p, st)) return ep_abort(s, rc);
+        if (hipMemcpyAsync(B.cnt_host, B.cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(B.ev, st) != hipSuccess ||
+            hipEventSynchronize(B.ev) != hipSuccess)
             return ep_abort(s, kr_fail(KR_ERR_HIP, "expert parallelism: reading the split sizes failed"));
-        for (int r = 0; r < W; r++) { soff[r + 1] = soff[r] + (size_t)s->cnt_host[s->rank * W + r]; roff[r + 1] = roff[r] + (size_t)s->cnt_host[r * W + s->rank]; }
+        for (int r = 0; r < W; r++) { soff[r + 1] = soff[r] + (size_t)B.cnt_host[s->rank * W + r]; roff[r + 1] = roff[r] + (size_t)B.cnt_host[r * W + s->rank]; }
     } else { soff[1] = roff[1] = (size_t)np; }
     const size_t n_send = soff[W], n_recv = roff[W];
     // ---- buffers whose size depends on what the peers send: a failure here aborts the communicator (the peers are already inside the call)
     {
         const size_t nr1 = n_recv ? n_recv : 1, esz = s->ret_bf16 ? 2 : 4;
         const size_t n_ones = n_recv > (size_t)M ? n_recv : (size_t)(M ? M : 1);
-        bool bad = s->eo.ensure(nr1 * (size_t)H * 4);
-        if (W > 1) bad = bad || s->rrows.ensure(nr1 * H * 2) || s->rlid.ensure(nr1 * 4) || s->back.ensure((n_send ? n_send : 1) * (size_t)H * esz);
-        if (!bad && s->ones.bytes < n_ones * 4) {
-            bad = s->ones.ensure(n_ones * 4 * 2);
-            if (!bad) bad = hipMemsetD32Async((hipDeviceptr_t)s->ones.p, 0x3F800000, s->ones.bytes / 4, st) != hipSuccess;      // f32 1.0
+        bool bad = B.eo.ensure(nr1 * (size_t)H * 4);
+        if (xchg) bad = bad || B.rrows.ensure(nr1 * H * 2) || B.rlid.ensure(nr1 * 4) || B.back.ensure((n_send ? n_send : 1) * (size_t)H * esz);
+        if (!bad && B.ones.bytes < n_ones * 4) {
+            bad = B.ones.ensure(n_ones * 4 * 2);
+            if (!bad) bad = hipMemsetD32Async((hipDeviceptr_t)B.ones.p, 0x3F800000, B.ones.bytes / 4, st) != hipSuccess;      // f32 1.0
         }
         if (bad) return ep_abort(s, kr_fail(KR_ERR_HIP, "hipMalloc of the expert-parallel exchange buffers failed"));
     }
     // ---- dispatch
-    const uint16_t* rrows = (const uint16_t*)s->rows.p; const int32_t* rlid = (const int32_t*)s->row_lid.p;
-    if (W > 1) {
-        const void* sb[2] = {s->rows.p, s->row_lid.p}; void* rb[2] = {s->rrows.p, s->rlid.p}; const size_t rbts[2] = {(size_t)H * 2, 4};
+    const uint16_t* rrows = (const uint16_t*)B.rows.p; const int32_t* rlid = (const int32_t*)B.row_lid.p;
+    if (xchg) {
+        const void* sb[2] = {B.rows.p, B.row_lid.p}; void* rb[2] = {B.rrows.p, B.rlid.p}; const size_t rbts[2] = {(size_t)H * 2, 4};
         if (int rc = ep_exchange(s, 2, sb, rb, rbts, soff.data(), roff.data(), st)) return ep_abort(s, rc);
-        rrows = (const uint16_t*)s->rrows.p; rlid = (const int32_t*)s->rlid.p;
+        rrows = (const uint16_t*)B.rrows.p; rlid = (const int32_t*)B.rlid.p;
     }
     // ---- experts on the received rows (top-1 rows, weight 1, f32)
     // the w2 GEMM writes every row at its place, in the dtype it travels back in (kr_moe_prefill_rows); native-GGUF layers take the generic
     // prompt-pass entry (combine with weight 1 = a copy) and a conversion pass
-    const void* back = s->eo.p;
+    const void* back = B.eo.p;
     if (n_recv) {
-        int rc = kr_moe_prefill_rows(e, layer, rrows, rlid, s->eo.p, (int)n_recv, s->ret_bf16 ? 1 : 0, 0, st);
+        int rc = kr_moe_prefill_rows(e, layer, rrows, rlid, B.eo.p, (int)n_recv, s->ret_bf16 ? 1 : 0, set, st);
         if (rc < 0) {
-            rc = kr_moe_prefill_set(e, layer, rrows, rlid, (const float*)s->ones.p, s->eo.p, (int)n_recv, 1, KR_OUT_F32, 1, 0, st);
+            rc = kr_moe_prefill_set(e, layer, rrows, rlid, (const float*)B.ones.p, B.eo.p, (int)n_recv, 1, KR_OUT_F32, 1, set, st);
             if (!rc && s->ret_bf16) {
-                if (s->eo16.ensure(n_recv * (size_t)H * 2)) rc = kr_fail(KR_ERR_HIP, "hipMalloc failed");
-                else { kr_launch_ep_rows_bf16((const float*)s->eo.p, (uint16_t*)s->eo16.p, n_recv * (size_t)H, st); back = s->eo16.p; }
+                if (B.eo16.ensure(n_recv * (size_t)H * 2)) rc = kr_fail(KR_ERR_HIP, "hipMalloc failed");
+                else { kr_launch_ep_rows_bf16((const float*)B.eo.p, (uint16_t*)B.eo16.p, n_recv * (size_t)H, st); back = B.eo16.p; }
             }
         }
-        if (rc > 0) return W > 1 ? ep_abort(s, rc) : rc;
+        if (rc > 0) return xchg ? ep_abort(s, rc) : rc;
     }
-    if (W > 1) {
+    if (xchg) {
         const size_t esz = s->ret_bf16 ? 2 : 4;
-        const void* sb[1] = {back}; void* rb[1] = {s->back.p}; const size_t rbts[1] = {(size_t)H * esz};
+        const void* sb[1] = {back}; void* rb[1] = {B.back.p}; const size_t rbts[1] = {(size_t)H * esz};
         if (int rc = ep_exchange(s, 1, sb, rb, rbts, roff.data(), soff.data(), st)) return ep_abort(s, rc);
-        back = s->back.p;
+        back = B.back.p;
     }
     if (!M) { KR_HIP(hipGetLastError()); return KR_OK; }
     // ---- shared expert of this rank's tokens (replicated weights), then the combine in routing order
     const float* shared_eo = nullptr;
     if (use_shared) {   // one all-skipped slot per token: kr_moe_prefill then returns rsf * 0 + shared = the shared expert's rows
-        KR_HIP(hipMemsetAsync(s->neg_ids.p, 0xFF, (size_t)M * 4, st));
-        if (int rc = kr_moe_prefill_set(e, layer, x_bf16, (const int32_t*)s->neg_ids.p, (const float*)s->ones.p, s->shared_out.p, M, 1, KR_OUT_F32, 0, 1, st)) return rc;
-        shared_eo = (const float*)s->shared_out.p;
+        KR_HIP(hipMemsetAsync(B.neg_ids.p, 0xFF, (size_t)M * 4, st));
+        if (int rc = kr_moe_prefill_set(e, layer, x_bf16, (const int32_t*)B.neg_ids.p, (const float*)B.ones.p, B.shared_out.p, M, 1, KR_OUT_F32, 0, set, st)) return rc;
+        shared_eo = (const float*)B.shared_out.p;
     }
     if (s->ret_bf16) kr_launch_pf_combine_bf16rows((const uint16_t*)back, so.pair_row, wts, M, topk, H, shared_eo, e->cfg.routed_scaling_factor, out, out_dtype == KR_OUT_BF16, st);
     else kr_launch_pf_combine((const float*)back, so.pair_row, wts, M, topk, H, shared_eo, e->cfg.routed_scaling_factor, out, out_dtype == KR_OUT_BF16, st);
@@ -424,7 +442,16 @@ extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, co
     return KR_OK;
 }
 
+extern "C" int kr_moe_prefill_ep(kr_engine* e, int layer, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk, int out_dtype,
+                                 int routed_only, void* stream) {
+    return kr_moe_prefill_ep_set(e, layer, x_bf16, ids, wts, out, M, topk, out_dtype, routed_only, 0, stream);
+}
+
 int kr_ep_world(const kr_engine* e) { return e && e->ep ? e->ep->world : 1; }
+// expert-parallel DECODE is in force: more than one rank, or a one-rank RCCL communicator (bring-up: the collective path on one GPU)
+bool kr_ep_decode_active(const kr_engine* e) { return e && e->ep && (e->ep->world > 1 || e->ep->comm != nullptr); }
+bool kr_ep_is_rccl(const kr_engine* e) { return e && e->ep && e->ep->comm != nullptr; }
+int kr_ep_rank(const kr_engine* e) { return e && e->ep ? e->ep->rank : 0; }
 void kr_ep_slice(const kr_engine* e, int* lo, int* hi, int* sub) {
     const kr_ep_state* s = e->ep;
     *lo = s->rank * s->per; *hi = s->rank == s->world - 1 ? s->E_total : (s->rank + 1) * s->per; *sub = s->full ? 0 : *lo;

@@ -11,6 +11,7 @@ struct GgMat {          // one projection [K -> N rows] of one (or all) expert(s
 };
 struct GgMoeArgs {
     const uint16_t* act; const int32_t* ids; int B, topk, n_slots, H, I_max; int E;   // ids outside [0, E) are skipped
+    const float* act_f32;        // decode graph: f32 hidden [B, H], rounded to bf16 (RNE) on the way in (decode.rs:3307-3309); when set `act` is unused
     GgMat gate, up, down;        // routed experts: expert e at q + e*q_stride
     GgMat sgate, sup, sdown;     // shared expert (n_slots > topk)
     float* gu; float* eo; int gu_ld;

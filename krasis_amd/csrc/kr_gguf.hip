@@ -73,6 +73,20 @@ __device__ __forceinline__ void gg_prologue_bf16(const uint16_t* x, int K, const
         gg_quant_store(v, c, A);
     }
 }
+// the decode graph's f32 hidden: the routed experts see bf16(hidden) (decode.rs:3307-3309: f32 -> bf16 RNE before moe_forward), then the bf16 path above
+__device__ __forceinline__ void gg_prologue_f32_as_bf16(const float* x, int K, const GgAct& A, bool keep_f32) {
+    for (int c = threadIdx.x; c < K / 8; c += GG_BLOCK) {
+        float v[8];
+        kr_load8(x, c, v);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = kr_bf16_to_f32(kr_f32_to_bf16(v[i]));
+        if (keep_f32) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) A.f32v[c * 8 + i] = v[i];
+        }
+        gg_quant_store(v, c, A);
+    }
+}
 // hidden = silu(gate) * up with libm exp (gguf_kernels.rs:733-737), then per-32 quantization
 __device__ __forceinline__ void gg_prologue_hidden_split(const float* gate, const float* up, int n, const GgAct& A, bool keep_f32, bool do_quant) {
     for (int c = threadIdx.x; c < n / 8; c += GG_BLOCK) {
@@ -266,7 +280,8 @@ __global__ void __launch_bounds__(GG_BLOCK) kr_gguf_w13_kernel(const GgMoeArgs a
     if (t0 >= 2 * nt) return;
     const bool intp = gg_int_path(gate.type) && (a.H % 32 == 0);
     const GgAct A = gg_carve(gg_smem, a.H);
-    gg_prologue_bf16(a.act + (size_t)b * a.H, a.H, A, !intp);
+    if (a.act_f32) gg_prologue_f32_as_bf16(a.act_f32 + (size_t)b * a.H, a.H, A, !intp);
+    else gg_prologue_bf16(a.act + (size_t)b * a.H, a.H, A, !intp);
     __syncthreads();
     float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
     // tiles [0, nt) are gate rows, [nt, 2nt) are up rows; a workgroup's span may straddle the boundary

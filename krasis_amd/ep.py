@@ -118,8 +118,11 @@ class ExpertParallel:
     `ExpertParallelMoE` above is the same dataflow written against torch.distributed collectives; it exists so the sharding / ownership /
     combine logic can be exercised on CPU with gloo."""
 
-    def __init__(self, engine, num_experts_total: int, world: int = 1, rank: int = 0, dist_module=None, return_bf16: bool = True, group=None, loopback=None):
-        """loopback: a LoopbackGroup -- this engine becomes virtual rank `rank` of an in-process group (kr_ep_init_loopback) instead of an RCCL rank"""
+    def __init__(self, engine, num_experts_total: int, world: int = 1, rank: int = 0, dist_module=None, return_bf16: bool = True, group=None, loopback=None,
+                 force_comm: bool = False):
+        """loopback: a LoopbackGroup -- this engine becomes virtual rank `rank` of an in-process group (kr_ep_init_loopback) instead of an RCCL rank.
+        force_comm (world == 1): create a ONE-RANK RCCL communicator anyway, so that every collective of the expert-parallel paths (the counts all-gather,
+        the grouped send / recv to itself, the decode all-reduce, its capture into a hipGraph) goes through librccl on a single-GPU box."""
         import ctypes as C
         from ._lib import check
         self.engine, self.world, self.rank = engine, world, rank
@@ -129,6 +132,10 @@ class ExpertParallel:
             check(lib.kr_ep_init_loopback(engine._h, loopback._h, rank, num_experts_total, int(return_bf16)))
             return
         idbuf = (C.c_char * 128)()
+        if world == 1 and force_comm:
+            check(lib.kr_ep_unique_id(idbuf))
+            check(lib.kr_ep_init(engine._h, 1, 0, num_experts_total, idbuf, int(return_bf16)))
+            return
         if world > 1:
             if dist_module is None:
                 raise ValueError("world > 1 needs a torch.distributed module to carry the RCCL unique id")

@@ -135,6 +135,41 @@ def test_decode_step_bit_exact(cfg, graph):
             assert np.array_equal(kc, L["kv_k"]) and np.array_equal(vc, L["kv_v"])
 
 
+@pytest.mark.parametrize("dims", [(256, 512, 16, 4, 128, 128), (512, 512, 8, 2, 256, 128)])
+@pytest.mark.parametrize("graph,fast", [(True, False), (False, False), (True, True)])
+def test_decode_step_on_native_gguf_experts_bit_exact(dims, graph, fast):
+    """kr_decode_step on a model whose ROUTED experts are native GGUF blocks (Q4_K gate / up; Q8_0 down at I = 128, Q4_K down at I = 256 --
+    the V2-Lite and QCN situations).  The reference drives such layers per layer from Python through moe_forward_gguf (moe.rs:990-1110,
+    tests/test_gguf_native.py:47-57); the oracle driver is that control flow.  Inside the captured step: router, k routed experts through the block
+    kernels on bf16(hidden) (decode.rs:3307), the decode store's shared expert on the f32 hidden, combine in routing order in the next norm launch.
+    Logits, greedy token and every state tensor BIT FOR BIT, graph and eager; with KR_DECODE_FAST set the GGUF layers keep these exact kernels (the
+    mode's attention / projection kernels run around them): logits within the mode's 2e-3, same greedy token."""
+    st, eng, orc, keep, d = build(dims=dims, gguf=True, seed=21)
+    st.set_use_graph(graph)
+    if fast:
+        st.set_attention_mode(False, decode_fast=True)
+    tok = 7
+    for step, pos in enumerate([5, 6, 7]):
+        logits = np.empty(d["V"], F)
+        st.decode_step(tok, pos, logits.ctypes.data)
+        ref = orc.step(tok, pos)
+        if fast:
+            assert float(np.abs(logits - ref).max() / np.abs(ref).max()) <= 2e-3
+            assert int(np.argmax(logits)) == O.sample_greedy(ref)
+        else:
+            assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (step, float(np.max(np.abs(logits - ref))))
+            assert st.last_token() == O.sample_greedy(ref)
+        tok = O.sample_greedy(ref)
+    if not fast:
+        for li, kind in enumerate(d["kinds"]):
+            L = orc.layers[li]
+            if kind == "la":
+                cs = np.empty(d["conv_dim"] * 4, F); rs = np.empty(d["nv"] * d["dk"] * d["dv"], F)
+                st.get_decode_state(li, None, None, cs, rs)
+                assert np.array_equal(cs.view(np.uint32), L["conv_state"].view(np.uint32))
+                assert np.array_equal(rs.view(np.uint32), L["recur_state"].view(np.uint32))
+
+
 @pytest.mark.parametrize("hd", [64, 128, 256])
 def test_decode_step_long_positions_bit_exact(hd):
     """positions past one / two 128-row stages of the attention kernel's K / V staging (decode.rs:4194 order kept across stages)"""

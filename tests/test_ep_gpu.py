@@ -262,3 +262,100 @@ def test_round3_abi_argument_errors():
     with pytest.raises(RuntimeError, match="still attached"):      # the group outlives every engine attached to it
         grp.close()
     ep.close(); grp.close()
+
+
+@pytest.mark.parametrize("W", [2, 3])
+def test_decode_step_expert_parallel_tolerance_mode(W):
+    """KR_DECODE_FAST on expert-parallel stores: every rank's down launch leaves its PARTIAL combine (its own slots; the shared expert on rank layer mod W)
+    and one all-reduce of [hidden] per MoE layer sums the partials -- the order of that sum differs from the single engine's routing-order sum.
+    STATED TOLERANCE: logits within 2e-4 of the single-engine KR_DECODE_FAST logits (max |diff| / max |ref|), greedy token and router ids identical;
+    all ranks end with identical bits (they route independently and must stay in lockstep)."""
+    from krasis_amd.ep import ExpertParallel, LoopbackGroup
+    from tests.test_decode_gpu import build
+    F = np.float32
+    grp = LoopbackGroup(W)
+    ranks, eps = [], []
+    for r in range(W):
+        st, eng, orc, keep, d = build(seed=6)
+        st.set_attention_mode(False, decode_fast=True)
+        ranks.append((st, eng, keep, d)); eps.append(ExpertParallel(eng, 16, rank=r, loopback=grp, return_bf16=False))
+    steps = [(7, 5), (3, 6), (11, 7), (2, 8)]
+    got = [[None] * len(steps) for _ in range(W)]
+    ids = [[None] * len(steps) for _ in range(W)]
+
+    def run(r):
+        st, eng, keep, d = ranks[r]
+        for i, (tok, pos) in enumerate(steps):
+            lg = np.empty(d["V"], F); st.decode_step(tok, pos, lg.ctypes.data); got[r][i] = lg
+            ids[r][i] = st.read_router(16, 4)[0].copy()
+    grp.run([lambda r=r: run(r) for r in range(W)])
+    st, eng, orc, keep, d = build(seed=6)
+    st.set_attention_mode(False, decode_fast=True)
+    for i, (tok, pos) in enumerate(steps):
+        ref = np.empty(d["V"], F); st.decode_step(tok, pos, ref.ctypes.data)
+        rid = st.read_router(16, 4)[0]
+        for r in range(W):
+            err = float(np.abs(got[r][i] - ref).max() / np.abs(ref).max())
+            assert err <= 2e-4, (i, r, err)
+            assert int(np.argmax(got[r][i])) == int(np.argmax(ref))
+            assert np.array_equal(ids[r][i], rid), (i, r)
+            assert np.array_equal(got[r][i].view(np.uint32), got[0][i].view(np.uint32)), (i, r)      # lockstep across the ranks
+    for ep in eps:
+        ep.close()
+    grp.close()
+
+
+@pytest.mark.parametrize("fast,graph", [(False, False), (False, True), (True, True)])
+def test_decode_step_through_a_one_rank_rccl_communicator(fast, graph):
+    """The RCCL transport itself on ONE GPU: kr_ep_init with world == 1 and a unique id creates a one-rank communicator, so the expert-parallel decode step
+    runs its all-reduce through librccl (dlopen, ncclCommInitRank, ncclAllReduce on the engine stream) -- eagerly and, with kr_decode_set_option
+    ("ep_graph"), CAPTURED into the step's hipGraph after two eager warm-up steps.  A sum over one rank is the identity: logits must equal the plain
+    store's bit for bit (exact mode) / within the tolerance of the mode (KR_DECODE_FAST: same kernels, same order -- also bit for bit)."""
+    from krasis_amd.ep import ExpertParallel
+    from tests.test_decode_gpu import build
+    F = np.float32
+    st, eng, orc, keep, d = build(seed=6)
+    st.set_attention_mode(False, decode_fast=fast)
+    ep = ExpertParallel(eng, 16, world=1, rank=0, return_bf16=False, force_comm=True)
+    assert ep.comm_ranks() == 1
+    st.set_option("ep_graph", 1 if graph else 0)
+    steps = [(7, 5), (3, 6), (11, 7), (2, 8), (5, 9)]           # steps 0, 1 eager (RCCL warm-up), 2 captures, 3, 4 replay
+    got = []
+    for tok, pos in steps:
+        lg = np.empty(d["V"], F); st.decode_step(tok, pos, lg.ctypes.data); got.append(lg)
+    st2, eng2, orc2, keep2, d2 = build(seed=6)
+    st2.set_attention_mode(False, decode_fast=fast)
+    for (tok, pos), g in zip(steps, got):
+        ref = np.empty(d["V"], F); st2.decode_step(tok, pos, ref.ctypes.data)
+        assert np.array_equal(ref.view(np.uint32), g.view(np.uint32)), (tok, pos)
+    ep.close()
+
+
+@pytest.mark.parametrize("M,ret_bf16", [(70, False), (33, True)])
+def test_prefill_exchange_through_a_one_rank_rccl_communicator(M, ret_bf16):
+    """kr_moe_prefill_ep over a one-rank RCCL communicator: the counts all-gather and the grouped ncclSend / ncclRecv (to itself) run through librccl;
+    the result must equal the single-engine operator (bit for bit with f32 return rows)."""
+    import torch
+    from krasis_amd import KrasisEngine, ModelConfig, _lib
+    from krasis_amd._lib import check
+    from krasis_amd.ep import ExpertParallel
+    H, I, E, k = 256, 128, 8, 3
+    rng = np.random.default_rng(5 + M)
+    experts = make_experts(rng, E, H, I)
+    eng = KrasisEngine(); eng.configure(ModelConfig(H, I, E, k, 1, 0, 2.0)); upload(eng, 0, experts)
+    ref_eng = KrasisEngine(); ref_eng.configure(ModelConfig(H, I, E, k, 1, 0, 2.0)); upload(ref_eng, 0, experts)
+    ep = ExpertParallel(eng, E, world=1, rank=0, return_bf16=ret_bf16, force_comm=True)
+    x = rand_bf16(rng, (M, H)); ids = np.stack([rng.choice(E, k, replace=False) for _ in range(M)]).astype(np.int32); w = rng.random((M, k)).astype(np.float32)
+    ids[1, 2] = -1; ids[3, :] = -1
+    xt = torch.from_numpy(x.view(np.int16)).cuda().view(torch.bfloat16); it = torch.from_numpy(ids).cuda(); wt = torch.from_numpy(w).cuda()
+    out = torch.zeros((M, H), dtype=torch.float32, device="cuda"); ref = torch.zeros_like(out)
+    for _ in range(2):
+        ep.forward(0, xt, it, wt, out)
+    ep.synchronize(); torch.cuda.synchronize()
+    check(ref_eng._lib.kr_moe_forward(ref_eng._h, 0, xt.data_ptr(), it.data_ptr(), wt.data_ptr(), ref.data_ptr(), M, k, _lib.KR_OUT_F32, 1, 1))
+    torch.cuda.synchronize(); ref_eng.synchronize()
+    if not ret_bf16:
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    else:
+        assert (out - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    ep.close()

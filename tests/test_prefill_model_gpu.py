@@ -57,8 +57,8 @@ def test_prefill_with_native_gguf_experts_matches_the_oracle_driver(dims, n_tok,
     """A model whose ROUTED experts are native GGUF blocks (Q4_K gate / up, Q8_0 or Q4_K down) through kr_decode_prefill, against the oracle driver
     (decode.rs:2690-3520 control flow with moe_forward_gguf, moe.rs:990, as the routed-expert block).  The prompt pass runs the int8-MFMA block GEMM
     at every chunk size: exact integer sub-block sums, ONE f32 chain per output instead of the AVX2 kernel's 8 lane chains + hsum -- STATED TOLERANCE
-    2e-5 of the largest logit (tests/test_gguf_gpu.py states the same for the operator; measured ~1e-6), same greedy token.  The decode STEP refuses
-    such layers (decode.rs:3330 runs moe_forward_unified) with a message that says so."""
+    2e-5 of the largest logit (tests/test_gguf_gpu.py states the same for the operator; measured ~1e-6), same greedy token.  The decode STEP on such
+    layers (round 4: the block kernels inside the captured step) is BIT-EXACT against the same driver: tests/test_decode_gpu.py."""
     st, eng, orc, keep, d = build(dims=dims, gguf=True, seed=11)
     st.set_prefill_chunk(chunk)
     rng = np.random.default_rng(n_tok)
@@ -71,8 +71,10 @@ def test_prefill_with_native_gguf_experts_matches_the_oracle_driver(dims, n_tok,
     err = float(np.abs(logits - ref).max() / np.abs(ref).max())
     assert err <= 2e-5, err
     assert int(np.argmax(logits)) == int(np.argmax(ref))
-    with pytest.raises(RuntimeError, match="native GGUF"):
-        st.decode_step(1, 5 + n_tok, logits.ctypes.data)
+    nxt = np.empty(d["V"], F)
+    st.decode_step(1, 5 + n_tok, nxt.ctypes.data)                  # the step after the prompt pass runs on the same native blocks
+    refn = orc.step(1, 5 + n_tok)
+    assert float(np.abs(nxt - refn).max() / np.abs(refn).max()) <= 2e-5
 
 
 def test_prefill_with_native_gguf_experts_mfma_chunks_and_tolerance_form():

@@ -54,3 +54,24 @@ def test_generate_stop_id_is_last_element():
     d["reset"]()                                                     # same initial KV / recurrent state for the second run
     stopped = st.generate_batch(11, 5, 5, stop_ids=(free[2],))      # decode.rs:3587-3591: push, then test
     assert stopped == free[:free.index(free[2]) + 1]
+
+
+@pytest.mark.parametrize("temperature,top_k,top_p,penalty", [(0.0, 0, 1.0, 0.0), (0.0, 0, 1.0, 1.5), (0.9, 10, 0.95, 0.7)])
+def test_generate_lookahead_gives_the_same_tokens(temperature, top_k, top_p, penalty):
+    """kr_decode_set_option("generate_lookahead", 1): the sampled token feeds step i + 1 on the device and the host reads token i while step i + 1 runs.
+    Same tokens as the plain loop (greedy, penalised greedy, sampled), the stop id still ends the list as its last element; without a stop the
+    state after the run is the plain loop's state too (the next decode step gives the same logits)."""
+    st, eng, orc, keep, d = build(seed=2)
+    seed = 0x1234567
+    plain = st.generate_batch(9, 5, 7, temperature, top_k, top_p, (), penalty, rng_seed=seed)
+    lg0 = np.empty(d["V"], F); st.decode_step(plain[-1], 12, lg0.ctypes.data)
+    d["reset"]()
+    st.set_option("generate_lookahead", 1)
+    ahead = st.generate_batch(9, 5, 7, temperature, top_k, top_p, (), penalty, rng_seed=seed)
+    lg1 = np.empty(d["V"], F); st.decode_step(ahead[-1], 12, lg1.ctypes.data)
+    assert ahead == plain
+    assert np.array_equal(lg0.view(np.uint32), lg1.view(np.uint32))
+    d["reset"]()
+    stopped = st.generate_batch(9, 5, 7, temperature, top_k, top_p, (plain[3],), penalty, rng_seed=seed)
+    assert stopped == plain[:plain.index(plain[3]) + 1]
+    st.set_option("generate_lookahead", 0)
