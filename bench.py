@@ -159,14 +159,25 @@ def q235_gemm_macs_per_token(L):
     return L * ((q["nh"] * q["hd"] + 2 * q["nkv"] * q["hd"]) * H + H * q["nh"] * q["hd"] + k * 3 * H * I)
 
 
-def build_q235(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
-    """Qwen3-235B-A22B-shaped decode graph (BASELINE config 4 on ONE GPU): 94 x [GQA (64 q / 4 kv heads, head_dim 128, per-head QK-norm) + 128-expert top-8 MoE, no shared expert]."""
+def ep_local_experts(E, world, rank):
+    """the reference's contiguous expert slices (gpu_prefill.py:353-359): floor(E / R) per rank, the last rank takes the remainder"""
+    per = E // world
+    return E - per * (world - 1) if rank == world - 1 else per
+
+
+def build_q235(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, ep_world=1):
+    """Qwen3-235B-A22B-shaped decode graph (BASELINE config 4): 94 x [GQA (64 q / 4 kv heads, head_dim 128, per-head QK-norm) + 128-expert top-8 MoE, no shared expert].
+    ep_world > 1: THIS RANK'S SHARD of an expert-parallel model -- E / ep_world routed experts per layer (its slice), everything else replicated with
+    rank-independent seeds (the ranks route independently and must see the same router, projections, norms and state)."""
     import numpy as np
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     q = Q235; H, I, E, k, V = q["hidden"], q["inter"], q["experts"], q["topk"], q["vocab"]
     nh, nkv, hd = q["nh"], q["nkv"], q["hd"]
-    eng = KrasisEngine(device=local_rank); eng.configure(ModelConfig(H, I, E, k, L, 0, 1.0))
-    eng.fill_synthetic(bits, seed=0x235 + rank); eng.set_routing_config("softmax", True, k, E, H)
+    e_rank = rank; E_loc = E
+    if ep_world > 1:
+        E_loc = ep_local_experts(E, ep_world, rank); rank = 0
+    eng = KrasisEngine(device=local_rank); eng.configure(ModelConfig(H, I, E_loc, k, L, 0, 1.0))
+    eng.fill_synthetic(bits, seed=0x235 + e_rank); eng.set_routing_config("softmax", True, k, E, H)
     st = CpuDecodeStore(128, True, False); st.set_moe_store(eng)
     rng = np.random.default_rng(235 + rank); keep = []; seed = [700 + rank * 100000]
 
@@ -196,16 +207,20 @@ def build_q235(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
     return eng, st, keep
 
 
-def build_qcn(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, gguf=False):
+def build_qcn(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, gguf=False, ep_world=1):
+    """ep_world > 1: this rank's shard of an expert-parallel model (see build_q235)"""
     import numpy as np
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     q = QCN; H, I, E, k, V = q["hidden"], q["inter"], q["experts"], q["topk"], q["vocab"]
+    e_rank = rank; E_loc = E
+    if ep_world > 1:
+        E_loc = ep_local_experts(E, ep_world, rank); rank = 0
     eng = KrasisEngine(device=local_rank)
-    eng.configure(ModelConfig(H, I, E, k, L, 0, 1.0))
-    if gguf:      # routed experts as native Q4_K super-blocks (gguf_native=True of the reference): the prompt pass consumes them; the decode graph does not (path matrix)
-        eng.fill_synthetic_gguf(12, 12, seed=0x12345678ABCDEF01 + rank)
+    eng.configure(ModelConfig(H, I, E_loc, k, L, 0, 1.0))
+    if gguf:      # routed experts as native Q4_K super-blocks (gguf_native=True of the reference): prompt pass and decode step consume them natively
+        eng.fill_synthetic_gguf(12, 12, seed=0x12345678ABCDEF01 + e_rank)
     else:
-        eng.fill_synthetic(bits, seed=0x12345678ABCDEF01 + rank)
+        eng.fill_synthetic(bits, seed=0x12345678ABCDEF01 + e_rank)
     eng.set_routing_config("softmax", True, k, E, H)
     st = CpuDecodeStore(128, True, True)                       # norm_bias_one: qwen3_next (decode.rs:4701)
     st.set_moe_store(eng)
@@ -256,14 +271,18 @@ def build_qcn(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, gguf=False)
     return eng, st, keep
 
 
-def build_v2lite(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False):
-    """DeepSeek-V2-Lite-shaped decode graph (BASELINE config 2): MLA attention (direct q projection), layer 0 dense, 64 experts top-6 + 2 shared."""
+def build_v2lite(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, ep_world=1):
+    """DeepSeek-V2-Lite-shaped decode graph (BASELINE config 2): MLA attention (direct q projection), layer 0 dense, 64 experts top-6 + 2 shared.
+    ep_world > 1: this rank's shard of an expert-parallel model (see build_q235)."""
     import numpy as np
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     v = V2L; H, I, E, k, V = v["hidden"], v["inter"], v["experts"], v["topk"], v["vocab"]
     nh, klr, nd, rd, vhd = v["nh"], v["klr"], v["nd"], v["rd"], v["vhd"]
-    eng = KrasisEngine(device=local_rank); eng.configure(ModelConfig(H, I, E, k, L, v["n_shared"], 1.0))
-    eng.fill_synthetic(bits, seed=11 + rank); eng.set_routing_config("softmax", False, k, E, H)
+    e_rank = rank; E_loc = E
+    if ep_world > 1:
+        E_loc = ep_local_experts(E, ep_world, rank); rank = 0
+    eng = KrasisEngine(device=local_rank); eng.configure(ModelConfig(H, I, E_loc, k, L, v["n_shared"], 1.0))
+    eng.fill_synthetic(bits, seed=11 + e_rank); eng.set_routing_config("softmax", False, k, E, H)
     st = CpuDecodeStore(128, True, False); st.set_moe_store(eng)
     rng = np.random.default_rng(3 + rank); keep = []; seed = [50 + rank * 100000]
 
@@ -311,17 +330,21 @@ def prefill_experts(eng, dims, L, M, torch, gemm_fast=False):
     mgr = GpuPrefillManager(eng, k)
     _lib.check(eng._lib.kr_moe_set_gemm_mode(eng._h, 1 if gemm_fast else 0))
     try:
-        for l in range(L if gemm_fast else min(L, 2)):      # tolerance form of GGUF layers: every layer builds its re-tiled copy on first use -- outside the timed region
+        for l in range(L):      # every layer builds its derived tables on first use (per-weight nibble sums; the tolerance copy of GGUF layers) -- outside the timed region
             mgr.forward(l, x, ids, w, routed_only=True)
         torch.cuda.synchronize()
+        a0 = alloc_count()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for l in range(L):
             mgr.forward(l, x, ids, w, routed_only=True)
         ev1.record(); torch.cuda.synchronize()
+        allocs = alloc_count() - a0
     finally:
         _lib.check(eng._lib.kr_moe_set_gemm_mode(eng._h, 0))
     ms = ev0.elapsed_time(ev1)
+    if allocs:
+        raise RuntimeError("prefill_experts: the library allocated device memory %d time(s) inside the timed region" % allocs)
     macs = M * k * 3 * H * I * L                       # routed experts only
     useful = 2.0 * macs / (ms * 1e-3) / 1e12
     if gemm_fast:
@@ -360,7 +383,7 @@ def prefill_experts_gguf(local_rank, torch, gate_up_type=12, down_type=12, L=8, 
     return r
 
 
-def prefill_ep(eng, dims, L, M, world, rank, torch, dist, experts_local=None):
+def prefill_ep(eng, dims, L, M, world, rank, torch, dist, experts_local=None, ep=None):
     """Expert-parallel prompt-pass experts over RCCL inside libkrasis_hip.so (kr_ep_init / kr_moe_prefill_ep): every rank owns
     E/N experts and M tokens; each (token, slot) row travels once to the rank that owns its expert (ncclSend/ncclRecv groups over the xGMI
     mesh), runs through the int8-MFMA expert GEMMs there (the w2 GEMM writes the row in bf16 at its return slot), comes back, and the source
@@ -371,7 +394,8 @@ def prefill_ep(eng, dims, L, M, world, rank, torch, dist, experts_local=None):
     x = ((torch.rand((M, H), device="cuda", generator=g) - 0.5)).to(torch.bfloat16)
     ids = torch.rand((M, E), device="cuda", generator=g).topk(k, dim=1).indices.to(torch.int32)
     w = torch.softmax(torch.randn((M, k), device="cuda", generator=g), dim=1)
-    ep = ExpertParallel(eng, E, world, rank, dist if world > 1 else None)
+    if ep is None:
+        ep = ExpertParallel(eng, E, world, rank, dist if world > 1 else None)
     out = torch.empty((M, H), dtype=torch.bfloat16, device="cuda")
     for l in range(min(L, 2)):
         ep.forward(l, x, ids, w, out)
@@ -511,6 +535,7 @@ def profile_kinds(st, kvm, P=5, step_ms=None):
     per_launch_us = {KINDS[j]: (net_ms[j] / max(tot_n[j], 1)) * 1e3 for j in range(NK)}
     n_per_step = {KINDS[j]: tot_n[j] / P for j in range(NK)}
     profile_kinds.event_overhead_us = ovh_ms * 1e3
+    profile_kinds.raw_us_per_step = {KINDS[j]: (tot_ms[j] / P) * 1e3 for j in range(NK)}      # the event times as measured (no excess taken off)
     return per_kind_us, per_launch_us, n_per_step
 
 
@@ -751,6 +776,213 @@ def cpu_v2lite_q4k(budget, threads):
                       "output rows; norms / rope / attention / router omitted (optimistic for the CPU)"}
 
 
+def ep_bytes_per_gpu(name, L, bw, world):
+    """Algorithmic bytes ONE rank of an expert-parallel decode step touches (SURVEY 8d per-unit figures): the routed experts' bytes divided by the
+    ranks (uniform routing: k / world slots per rank and layer on average), the shared expert on one rank per layer, everything else replicated."""
+    qcn = name.startswith("qcn"); q235 = name.startswith("qwen3-235b")
+    ab = algorithmic_bytes(L, bw, split_out=True) if qcn else (algorithmic_bytes_q235(L, bw) if q235 else algorithmic_bytes_v2lite(L, bw))
+    ab = dict(ab); ab.pop("total", None)
+    for kname in ("moe_w13", "moe_w2"):
+        ab[kname] = ab[kname] / world
+    ab["total"] = sum(ab.values())
+    return ab
+
+
+def ep_suite(name, args, torch, dist, world, rank, local_rank, with_replicas, with_prefill, force_comm=False):
+    """The expert-parallel measurements of ONE model configuration on `world` ranks (see main_multi).  Returns (legs, best) -- best = dict(value, dt, form).
+    world == 1 with force_comm: the same program over a ONE-RANK RCCL communicator (`--ep-selftest`, tests/test_ep_gpu.py): every collective still goes
+    through librccl, so the code path the driver's 2 / 4 / 8-GPU runs take is exercised on a single-GPU box."""
+    from krasis_amd.ep import ExpertParallel
+    qcn = name.startswith("qcn"); q235 = name.startswith("qwen3-235b")
+    dims = QCN if qcn else (Q235 if q235 else V2L)
+    bits = 8 if name.endswith("q8") else 4
+    L = args.layers or dims["layers"]
+    kv_fp8 = args.kv == "fp8"
+    kvm = dims["kv_max_seq"]
+    E = dims["experts"]
+    P = getattr(args, "ep_prompt_tokens", 8192)
+    build = build_qcn if qcn else (build_q235 if q235 else build_v2lite)
+    legs, best = {}, {"value": None, "dt": None, "form": None}
+    # ---- replicas first (no collective in the data path; the earlier rounds' N > 1 number, now a labelled side leg)
+    if with_replicas:
+        try:
+            eng0, st0, keep0 = build(rank, local_rank, L, 0, bits, kv_fp8)
+            st0.set_use_graph(not args.no_graph); st0.set_attention_mode(False, decode_fast=args.decode_mode == "fast")
+            d0 = time_decode(st0, args.steps, args.warmup, kvm, torch, dist, world)
+            legs["replicas"] = {"tok_s_aggregate": world * args.steps / d0, "tok_s_per_replica": args.steps / d0, "scaling": "weak",
+                                "note": "%d independent whole-model replicas, no collective: NOT the line's value (it measures no xGMI traffic)" % world}
+            del st0, eng0, keep0
+            gc.collect(); torch.cuda.empty_cache()
+        except Exception as ex:
+            legs["replicas"] = {"error": repr(ex)}
+    # ---- this rank's shard of the expert-parallel model
+    eng, st, keep = build(rank, local_rank, L, P + 64, bits, kv_fp8, ep_world=world)
+    ep = ExpertParallel(eng, E, world, rank, dist if world > 1 else None, return_bf16=False, force_comm=force_comm and world == 1)
+    legs["rccl_ranks"] = ep.comm_ranks()
+    legs["experts_per_gpu"] = ep_local_experts(E, world, rank)
+
+    def run_decode(key, fast, graph):
+        st.set_attention_mode(False, decode_fast=fast)
+        st.set_option("ep_graph", 1 if graph else 0)
+        st.set_use_graph(graph)
+        st.fill_state_synthetic(kvm, seed=4242)
+        d = time_decode(st, args.steps, args.warmup, kvm, torch, dist, world)
+        legs[key] = {"tok_s": args.steps / d, "ms_per_step": d / args.steps * 1e3, "hip_graph": graph,
+                     "form": ("KR_DECODE_FAST: partial combines, one all-reduce of [hidden] f32 per MoE layer" if fast else
+                              "exact: k expert rows summed over the ranks ([k, hidden] f32 all-reduce), combine in routing order -- bit-equal to single-engine decode")}
+        return d
+    forms = [("decode_ep_exact", False, False, "expert-parallel decode, exact form, eager launches"),
+             ("decode_ep_fast", True, False, "expert-parallel decode, KR_DECODE_FAST, eager launches")]
+    if not args.no_graph:
+        forms.append(("decode_ep_fast_graph", True, True, "expert-parallel decode, KR_DECODE_FAST, hipGraph replay with the RCCL all-reduces captured"))
+    ok = True
+    for key, fast, graph, label in forms:
+        try:
+            d = run_decode(key, fast, graph)
+            if best["value"] is None or args.steps / d > best["value"]:
+                best.update(value=args.steps / d, dt=d, form=label)
+        except Exception as ex:
+            legs[key] = {"error": repr(ex)}
+            ok = False
+            break                      # a failed collective leaves the communicator unusable: stop here, report what finished
+    try:
+        st.set_option("ep_graph", 0); st.set_use_graph(False)
+    except Exception:
+        pass
+    # ---- whole-model prompt pass on the expert-parallel stores: one prompt per rank
+    if ok and with_prefill and not args.no_ep:
+        import numpy as np
+        macs = qcn_gemm_macs_per_token(L) if qcn else (q235_gemm_macs_per_token(L) if q235 else v2l_gemm_macs_per_token(L))
+        for key, afast in (("prefill_model_ep", False), ("prefill_model_ep_attn_fast", True)):
+            try:
+                st.set_attention_mode(afast)
+                st.fill_state_synthetic(P + 64, 7)
+                toks = [int(x) for x in np.random.default_rng(5 + rank).integers(0, dims["vocab"], P)]
+                st.prefill(toks, 0)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                st.prefill(toks, 0)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                dtp = time.perf_counter() - t0
+                if world > 1:
+                    t = torch.tensor([dtp], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dtp = float(t.item())
+                useful = 2.0 * world * P * macs / dtp / 1e12
+                legs[key] = {"value": world * P / dtp, "unit": "tok/s", "tokens_per_gpu": P, "tokens_total": world * P, "ms": dtp * 1e3, "scaling": "weak", "layers": L,
+                             "attention": "KR_ATTN_FAST" if afast else "exact", "gemm": "exact (the expert-parallel row path runs the exact int8-MFMA kernels)",
+                             "roofline": {"bound": "mfma", "achieved": useful, "peak": I8_PEAK_TOPS * world, "unit": "TOP/s (int8, useful)", "frac": useful / (I8_PEAK_TOPS * world)}}
+            except Exception as ex:
+                legs[key] = {"error": repr(ex)}
+                ok = False
+                break
+        if ok:
+            try:
+                st.set_attention_mode(False)
+                legs["prefill_experts_ep_alltoall"] = prefill_ep(eng, dims, L, P, world, rank, torch, dist, ep=ep)
+            except Exception as ex:
+                legs["prefill_experts_ep_alltoall"] = {"error": repr(ex)}
+                ok = False
+    legs["_ok"] = ok
+    try:
+        ep.close()
+    except Exception:
+        pass
+    del st, eng, keep
+    gc.collect(); torch.cuda.empty_cache()
+    return legs, best
+
+
+def main_multi(args, torch, dist, world, rank, local_rank):
+    """N > 1: the SHARDED workload.  Every rank holds E / N routed experts of every layer (its contiguous slice) and a replica of
+    everything else.  Legs, every one a collective program that all ranks walk in the same order:
+      decode_ep_*      expert-parallel decode (kr_decode_step on expert-parallel stores): router / attention / norms replicated, a rank evaluates the slots its
+                       slice owns, one all-reduce per MoE layer over RCCL -- exact form ([k, hidden] f32 rows, bit-equal to one engine), KR_DECODE_FAST form
+                       ([hidden] f32 partial combines), and the FAST form replayed from a hipGraph that captured the all-reduces (kr_decode_set_option ep_graph).
+                       ONE token stream over N GPUs: strong scaling.  The best finished form is the line's `value`.
+      prefill_model_ep whole-model prompt pass (kr_decode_prefill on the same stores), one prompt of P tokens per rank, (token, slot) rows exchanged
+                       with the owners of their experts by grouped RCCL send / recv, several chunks in flight: weak scaling, tok/s = N * P / t.
+      prefill_experts_ep_alltoall   the expert path alone (as in earlier rounds).
+      replicas         N independent whole-model replicas (no collective): a labelled side leg, never the value.
+      qwen3_235b_ep    (default configuration only) the same decode legs for BASELINE config 4: Qwen3-235B-A22B, 128 / N experts per GPU.
+    A watchdog prints the line with whatever finished if a collective does not come back."""
+    name = args.config
+    qcn = name.startswith("qcn"); q235 = name.startswith("qwen3-235b")
+    dims = QCN if qcn else (Q235 if q235 else V2L)
+    bits = 8 if name.endswith("q8") else 4
+    bw = B8 if bits == 8 else B4
+    L = args.layers or dims["layers"]
+    kv_fp8 = args.kv == "fp8"
+    kvm = dims["kv_max_seq"]
+    E = dims["experts"]
+    legs, state = {}, {"value": None, "dt": None, "form": None}
+    emitted = []
+
+    def emit():
+        if emitted or rank != 0:
+            emitted.append(1); return
+        emitted.append(1)
+        ab = ep_bytes_per_gpu(name, L, bw, world)
+        model = "Qwen3-Coder-Next Q%d" % bits if qcn else ("Qwen3-235B-A22B Q4" if q235 else "DeepSeek-V2-Lite Q4")
+        value = state["value"]
+        if value is None and isinstance(legs.get("replicas"), dict) and "tok_s_aggregate" in legs["replicas"]:
+            value = legs["replicas"]["tok_s_aggregate"]; form = "FALLBACK: no expert-parallel decode form finished -- %d independent replicas (weak scaling, no collective)" % world
+            scaling = "weak"
+        else:
+            form = state["form"] or "no decode form finished"; scaling = "strong"
+        res = {"metric": "decode tok/s, %s expert-parallel @%d MI355X" % (model, world), "value": value, "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": (state["dt"] / args.steps * 1e3) if state["dt"] else None, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+               "dtype": "int%d-g128 weights x int16 activations -> i32 group sums, f32 scales; %s" % (bits, form),
+               "data": "synthetic",
+               "config": {"workload": WORKLOAD[name], "layers": L, "kv": ("FP8-E4M3" if kv_fp8 else "FP16") + " KV cache, kv_max_seq %d" % kvm,
+                          "parallelism": "ep%d: %d of %d routed experts per GPU and layer (contiguous slices, gpu_prefill.py:353-359); attention, router, norms, shared expert, lm_head replicated; "
+                                         "decode: one f32 all-reduce per MoE layer over RCCL; prompt pass: grouped ncclSend / ncclRecv of (token, slot) rows" % (world, E // world, E),
+                          "scope": "ONE token stream decoded by %d GPUs (strong scaling): full decode_step -- embedding, %d layers, final norm, lm_head, greedy sample" % (world, L),
+                          "value_is": form},
+               "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU", "step_algorithmic_bytes_per_gpu": ab["total"],
+                            "achieved": (ab["total"] * state["value"] / 1e9) if state["value"] else None,
+                            "frac": (ab["total"] * state["value"] / 1e9 / HBM_PEAK_GBS) if state["value"] else None,
+                            "kernel": "whole step (per GPU: routed experts / %d + replicated attention, router, lm_head)" % world, "traffic": None}}
+        res.update({k_: v for k_, v in legs.items() if not k_.startswith("_")})
+        print(json.dumps(res), flush=True)
+
+    import threading
+
+    def bail():
+        legs.setdefault("watchdog", "timeout after %d s: a rank did not come back from a collective; the line holds what had finished" % args.ep_timeout)
+        try:
+            emit()
+        finally:
+            os._exit(0)
+    watchdog = threading.Timer(args.ep_timeout, bail); watchdog.daemon = True; watchdog.start()
+    t_start = time.perf_counter()
+    try:
+        lg, best = ep_suite(name, args, torch, dist, world, rank, local_rank, with_replicas=not q235, with_prefill=True)
+        legs.update(lg); state.update(best)
+    except Exception as ex:
+        legs["expert_parallel"] = {"error": repr(ex)}
+    # BASELINE config 4 as a side leg of the default line: Qwen3-235B-A22B, 128 / N experts per GPU, decode only (time permitting: every rank takes the same decision)
+    if qcn and bits == 4 and legs.get("_ok") and not args.no_ep:
+        go = torch.tensor([1 if time.perf_counter() - t_start < args.ep_timeout * 0.45 else 0], device="cuda")
+        dist.all_reduce(go, op=dist.ReduceOp.MIN)
+        if int(go.item()):
+            try:
+                lg4, best4 = ep_suite("qwen3-235b-q4", args, torch, dist, world, rank, local_rank, with_replicas=False, with_prefill=False)
+                ab4 = ep_bytes_per_gpu("qwen3-235b-q4", Q235["layers"], B4, world)
+                lg4 = {k_: v for k_, v in lg4.items() if not k_.startswith("_")}
+                lg4.update({"workload": "Qwen3-235B-A22B Q4 expert-parallel on %d×MI355X via RCCL over xGMI (BASELINE config 4)" % world, "value": best4["value"], "unit": "tok/s", "value_is": best4["form"],
+                            "step_algorithmic_bytes_per_gpu": ab4["total"], "frac_of_hbm_peak_per_gpu": (ab4["total"] * best4["value"] / 1e9 / HBM_PEAK_GBS) if best4["value"] else None})
+                legs["qwen3_235b_ep"] = lg4
+            except Exception as ex:
+                legs["qwen3_235b_ep"] = {"error": repr(ex)}
+    watchdog.cancel()
+    emit()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     import torch
@@ -776,6 +1008,9 @@ def main():
         import datetime
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=5))
 
+    if world > 1:
+        return main_multi(args, torch, dist, world, rank, local_rank)
+
     name = args.config
     qcn = name.startswith("qcn"); q235 = name.startswith("qwen3-235b")
     dims = QCN if qcn else (Q235 if q235 else V2L)
@@ -791,18 +1026,34 @@ def main():
     kvm = dims["kv_max_seq"]
     fast_mode = args.decode_mode == "fast"
     # the mode that is NOT the headline first (side leg, fewer steps), then the headline: K timed steps with the barrier / max-over-ranks protocol
-    other = {}
+    other, gen = {}, {}
     try:
         st.set_attention_mode(False, decode_fast=not fast_mode)
         n_o = min(args.steps, 50)
         d_o = time_decode(st, n_o, args.warmup, kvm, torch, None, 1)
         other = {"tok_s": n_o / d_o, "ms_per_step": d_o / n_o * 1e3, "steps": n_o,
                  "numerics": "KR_DECODE_FAST (tolerance mode)" if not fast_mode else "exact: bit-identical to the reference's CPU decode (tests/test_decode_gpu.py compares logits and every state tensor with array_equal)"}
+        st.fill_state_synthetic(kvm, seed=4242)
+        gen["exact" if fast_mode else "fast"] = decode_generate(st, kvm)
     except Exception as ex:
         other = {"error": repr(ex)}
     st.set_attention_mode(False, decode_fast=fast_mode)
     st.fill_state_synthetic(kvm, seed=4242 + rank)
+    a0 = alloc_count()
     dt = time_decode(st, args.steps, args.warmup, kvm, torch, dist, world)
+    decode_allocs = alloc_count() - a0
+    # the reference's own decode protocol next to the back-to-back number: generate_batch, 3 x 64 tokens, the sampled token fed back
+    try:
+        st.fill_state_synthetic(kvm, seed=4242)
+        gen["fast" if fast_mode else "exact"] = decode_generate(st, kvm)
+        st.fill_state_synthetic(kvm, seed=4242)
+        gen["fast_lookahead" if fast_mode else "exact_lookahead"] = decode_generate(st, kvm, lookahead=True)
+        g0 = gen["fast" if fast_mode else "exact"]["tok_s"]
+        gen["tok_s"] = g0; gen["tok_s_over_value"] = g0 / (args.steps / dt)
+        gen["allocs_in_timed_decode_steps"] = decode_allocs
+    except Exception as ex:
+        gen["error"] = repr(ex)
+    st.fill_state_synthetic(kvm, seed=4242 + rank)
 
     # per-kernel durations: un-graphed steps with HIP events around every launch on the launch stream
     per_kind_us, per_launch_us, n_per_step = profile_kinds(st, kvm, step_ms=dt / args.steps * 1e3)
@@ -869,25 +1120,27 @@ def main():
 
     ab = (algorithmic_bytes(L, bw, split_out=fast_mode) if qcn else (algorithmic_bytes_q235(L, bw) if q235 else algorithmic_bytes_v2lite(L, bw)))
     ep_legs = {}
-    emitted = []
 
     def emit():
-        """rank 0's ONE JSON line.  Also called by the watchdog below if a collective of the multi-GPU side legs does not come back."""
-        if emitted or rank != 0:
-            emitted.append(1); return
-        emitted.append(1)
-        sym_us, sym_bytes, sym_n = {}, {}, {}
+        """rank 0's ONE JSON line (this function is the N = 1 line; N > 1 lines come from main_multi)"""
+        sym_us, sym_bytes, sym_n, sym_raw = {}, {}, {}, {}
+        raw_us = getattr(profile_kinds, "raw_us_per_step", {})
         for j in range(NK):
             kname = KINDS[j]; sym = (SYMBOL_FAST if fast_mode and qcn and bits == 4 else SYMBOL).get(kname, kname)
             sym_us[sym] = sym_us.get(sym, 0.0) + per_kind_us[kname]; sym_bytes[sym] = sym_bytes.get(sym, 0.0) + ab.get(kname, 0.0)
-            sym_n[sym] = sym_n.get(sym, 0) + n_per_step[kname]
+            sym_n[sym] = sym_n.get(sym, 0) + n_per_step[kname]; sym_raw[sym] = sym_raw.get(sym, 0.0) + raw_us.get(kname, 0.0)
         dom = max(sym_us, key=lambda s: sym_us[s])
         achieved = sym_bytes[dom] / (sym_us[dom] * 1e-6) / 1e9 if sym_us[dom] > 0 else 0.0
-        tok_s = world * args.steps / dt
+        achieved_raw = sym_bytes[dom] / (sym_raw[dom] * 1e-6) / 1e9 if sym_raw.get(dom, 0.0) > 0 else None
+        tok_s = args.steps / dt
         traffic, traffic_src = pmc_traffic(dom)
+        model = "Qwen3-Coder-Next Q%d" % bits if qcn else ("Qwen3-235B-A22B Q4" if q235 else "DeepSeek-V2-Lite Q4")
+        mode_tag = "KR_DECODE_FAST tolerance mode" if fast_mode else "bit-exact mode"
+        exact_tok_s = other.get("tok_s") if fast_mode else tok_s
+        fast_tok_s = tok_s if fast_mode else other.get("tok_s")
         res = {
-            "metric": "decode tok/s, %s @%d MI355X" % ("Qwen3-Coder-Next Q%d" % bits if qcn else ("Qwen3-235B-A22B Q4" if q235 else "DeepSeek-V2-Lite Q4"), world),
-            "value": tok_s, "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "decode tok/s, %s @1 MI355X (%s; both modes: value_exact / value_fast)" % (model, mode_tag),
+            "value": tok_s, "value_exact": exact_tok_s, "value_fast": fast_tok_s, "unit": "tok/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("int%d-g128 weights x int16 activations -> i32 group sums, f32 scales" % bits) +
                      (" (KR_DECODE_FAST: the reference's products, f32 sums as lane / wave / workgroup trees -- logits within 2e-3 of the bit-exact mode, "
@@ -896,79 +1149,61 @@ def main():
             "config": {"workload": WORKLOAD[name],
                        "scope": "full decode_step: embedding, %d layers (attention + MoE + shared expert), final norm, lm_head, greedy sample" % L,
                        "kv": ("FP8-E4M3" if kv_fp8 else "FP16") + " KV cache, kv_max_seq %d" % kvm, "layers": L,
-                       "parallelism": "replica x%d (the model fits one GPU; decode is not expert-parallel)" % world,
+                       "parallelism": "one GPU holds the whole model (N > 1 lines: expert parallelism, see main_multi)",
                        "hip_graph": not args.no_graph, "target_tok_s": 200,
-                       "decode_mode": "fast (KR_DECODE_FAST, opt-in tolerance mode; the library default is the bit-exact graph)" if fast_mode else "exact (library default)",
+                       "decode_mode": "`value` = fast (KR_DECODE_FAST, opt-in tolerance mode; the library default is the bit-exact graph = `value_exact`)" if fast_mode else "`value` = exact (library default); `value_fast` = KR_DECODE_FAST",
                        "prefill_modes": "`prefill` = the library default (exact: bit-identical to token-by-token decode); `prefill_fast` (KR_ATTN_FAST) and "
                                         "`prefill_fast_gemm` (KR_ATTN_FAST | KR_GEMM_FAST) are the opt-in throughput modes a serving deployment would run -- "
-                                        "the one to compare with the reference's GPU prompt pass (bf16 flash attention + Marlin GEMM) is prefill_fast_gemm",
-                       "decode_token_protocol": "token 0 at positions 10.. like bench_decode_synthetic (decode.rs:5450); weights are synthetic, so the token id does not change the work"},
+                                        "the one to compare with the reference's GPU prompt pass (bf16 flash attention + Marlin GEMM) is prefill_fast_gemm; protocol: one un-timed pass of the "
+                                        "same prompt in the same mode, then >= 2 timed passes (median), allocation counter checked",
+                       "decode_token_protocol": "`value`: token 0 at positions 10.. like bench_decode_synthetic (decode.rs:5450), K graph replays back to back; `decode_generate`: the "
+                                                "reference's generate_batch protocol (benchmark.py:434-505): 3 x 64 tokens, the sampled token fed back"},
             ("decode_exact" if fast_mode else "decode_fast"): other,
+            "decode_generate": gen,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "peak_measured_stream_read": 6996.0, "peak_measured_source": "tools/probes/hbm_stream.hip on this box type (8 GiB, 16-byte loads)", "traffic": traffic, "traffic_unit": "HBM fetch bytes per launch (PMC FETCH_SIZE, separate pass)",
+                         "frac": achieved / HBM_PEAK_GBS, "achieved_raw_events": achieved_raw, "frac_raw_events": (achieved_raw / HBM_PEAK_GBS) if achieved_raw else None,
+                         "peak_measured_stream_read": 6996.0, "peak_measured_source": "tools/probes/hbm_stream.hip on this box type (8 GiB, 16-byte loads)", "traffic": traffic, "traffic_unit": "HBM fetch bytes per launch (PMC FETCH_SIZE, separate pass)",
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": sym_bytes[dom] / max(sym_n[dom], 1), "us_per_launch": sym_us[dom] / max(sym_n[dom], 1),
+                         "us_per_launch_raw_events": (sym_raw[dom] / max(sym_n[dom], 1)) if sym_raw.get(dom) else None,
                          "launches_per_step": sym_n[dom],
-                         "timing": "HIP events around every launch of un-graphed steps on the launch stream, minus the constant per-launch excess of the event pairs "
-                                   "((sum of event times - graph-replayed step time) / launches)",
+                         "timing": "HIP events around every launch of un-graphed steps on the launch stream; `us_per_launch` / `achieved` / `frac` take off the constant per-launch excess "
+                                   "of the event pairs ((sum of event times - graph-replayed step time) / launches), the *_raw_events fields are the event times as measured",
                          "event_pair_overhead_us": round(getattr(profile_kinds, "event_overhead_us", 0.0), 2),
                          "step_algorithmic_bytes": ab["total"], "step_effective_GBs": ab["total"] * (args.steps / dt) / 1e9,
                          "step_frac_of_hbm_peak": ab["total"] * (args.steps / dt) / 1e9 / HBM_PEAK_GBS,
                          "per_kind_us_per_step": {k_: round(v, 2) for k_, v in per_kind_us.items()},
+                         "per_kind_us_per_step_raw_events": {k_: round(v, 2) for k_, v in raw_us.items()},
                          "per_kind_us_per_launch": {k_: round(v, 2) for k_, v in per_launch_us.items()}},
         }
         res.update(side)
         res.update(ep_legs)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, QCN["layers"])
             except Exception as ex:  # a reported side number, never the product path
                 res["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(res), flush=True)
 
-    watchdog = None
-    if world > 1 and pf_list and not args.no_ep:
-        # the expert-parallel side legs are collectives over RCCL: if one rank fails to join, the others would wait forever and the headline
-        # line (already measured) would be lost.  After `--ep-timeout` seconds every rank gives up; rank 0 prints the line first.
-        import threading
-
-        def bail():
-            ep_legs.setdefault("prefill_experts_ep_alltoall", {"error": "timeout after %d s (a rank did not join the RCCL exchange)" % args.ep_timeout})
-            try:
-                emit()
-            finally:
-                os._exit(0)
-        watchdog = threading.Timer(args.ep_timeout, bail); watchdog.daemon = True; watchdog.start()
-    if pf_list and not args.no_ep and (world > 1 or args.ep_selftest):   # every rank takes part; same call sequence on all
-        try:
-            ep_legs["prefill_experts_ep_alltoall"] = prefill_ep(eng, dims, L, 8192, world, rank, torch, dist)
-        except Exception as ex:
-            ep_legs["prefill_experts_ep_alltoall"] = {"error": repr(ex)}
-
     del st, eng, keep
     gc.collect(); torch.cuda.empty_cache()
 
-    if pf_list and not args.no_ep and (world > 1 or args.ep_selftest):
-        # BASELINE config 4: Qwen3-235B-A22B expert shape, E/N experts per GPU (16 at N = 8), a few layers' worth of resident experts
+    if args.ep_selftest:      # the N > 1 program of main_multi over a ONE-RANK RCCL communicator: every collective goes through librccl on this single GPU
         try:
-            from krasis_amd import KrasisEngine, ModelConfig
-            d4 = Q235; L4 = 4
-            e4 = KrasisEngine(device=local_rank); e4.configure(ModelConfig(d4["hidden"], d4["inter"], d4["experts"] // world, d4["topk"], L4, 0, 1.0))
-            e4.fill_synthetic(4, seed=99 + rank)
-            r = prefill_ep(e4, d4, L4, 8192, world, rank, torch, dist)
-            r["workload"] = "Qwen3-235B-A22B Q4 expert-parallel on %d×MI355X via RCCL all-to-all over xGMI (expert GEMMs of %d of 94 MoE layers)" % (world, L4)
-            ep_legs["prefill_experts_ep_235b"] = r
-            del e4; gc.collect(); torch.cuda.empty_cache()
+            lg, best = ep_suite(name, args, torch, None, 1, 0, local_rank, with_replicas=False, with_prefill=True, force_comm=True)
+            lg = {k_: v for k_, v in lg.items() if not k_.startswith("_")}
+            lg["value"] = best["value"]; lg["value_is"] = best["form"]
+            ep_legs["expert_parallel_selftest_one_rank_rccl"] = lg
         except Exception as ex:
-            ep_legs["prefill_experts_ep_235b"] = {"error": repr(ex)}
+            ep_legs["expert_parallel_selftest_one_rank_rccl"] = {"error": repr(ex)}
 
-    if world == 1 and pf_list:
+    if pf_list:
         try:
             side["prefill_experts_only_q4k_gguf"] = prefill_experts_gguf(local_rank, torch)
             side["prefill_experts_only_q4k_gguf_fast_gemm"] = prefill_experts_gguf(local_rank, torch, gemm_fast=True)
         except Exception as ex:
             side["prefill_experts_only_q4k_gguf"] = {"error": repr(ex)}
-    if world == 1 and args.side_configs:
+    if args.side_configs:
         side["configs"] = {}
         for sc in [s for s in args.side_configs.split(",") if s.strip() and s.strip() != name]:
             try:
@@ -976,11 +1211,7 @@ def main():
             except Exception as ex:
                 side["configs"][sc] = {"error": repr(ex)}
 
-    if watchdog is not None:
-        watchdog.cancel()
     emit()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -359,3 +359,24 @@ def test_prefill_exchange_through_a_one_rank_rccl_communicator(M, ret_bf16):
     else:
         assert (out - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
     ep.close()
+
+
+def test_bench_multi_gpu_program_runs_over_a_one_rank_communicator():
+    """bench.py's N > 1 program (ep_suite: expert-parallel decode in its three forms, whole-model prompt pass on expert-parallel stores, experts-only exchange)
+    over a ONE-RANK RCCL communicator on this GPU, 2 layers of the QCN shape: every leg must finish without an error entry and report a rate."""
+    import argparse
+    import importlib.util
+    import os
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    args = argparse.Namespace(layers=2, kv="fp8", steps=6, warmup=2, no_graph=False, decode_mode="fast", no_ep=False, ep_prompt_tokens=512)
+    legs, best = bench.ep_suite("qcn-q4", args, torch, None, 1, 0, 0, with_replicas=False, with_prefill=True, force_comm=True)
+    assert legs["_ok"], legs
+    assert legs["rccl_ranks"] == 1
+    for key in ("decode_ep_exact", "decode_ep_fast", "decode_ep_fast_graph"):
+        assert "error" not in legs[key] and legs[key]["tok_s"] > 0, (key, legs[key])
+    for key in ("prefill_model_ep", "prefill_model_ep_attn_fast"):
+        assert "error" not in legs[key] and legs[key]["value"] > 0, (key, legs[key])
+    assert "error" not in legs["prefill_experts_ep_alltoall"]
+    assert best["value"] and best["form"]
