@@ -52,7 +52,8 @@ SYMBOL_FAST = {"proj_matvec": "kr_fdm_kernel<4,1,8>", "out_proj_matvec": "kr_fdm
 WORKLOAD = {"qcn-q4": "Qwen3-Coder-Next Q4 int4gpu on 1×MI355X (512-expert top-10, hybrid linear+GQA, FP8 KV)",
             "qcn-q8": "Qwen3-Coder-Next Q8 int8gpu on 1×MI355X (int8 MFMA path, Q8_0 dequant)",
             "v2lite-q4": "DeepSeek-V2-Lite Q4 int4gpu on 1×MI355X (MLA + 64-expert top-6)",
-            "qcn-q4k-gguf": "Qwen3-Coder-Next, routed experts as native GGUF Q4_K super-blocks (gguf_native), whole-model prompt pass on 1×MI355X",
+            "qcn-q4k-gguf": "Qwen3-Coder-Next, routed experts as native GGUF Q4_K super-blocks (gguf_native), decode step + whole-model prompt pass on 1×MI355X",
+            "v2lite-q4k-gguf": "DeepSeek-V2-Lite, routed experts as native GGUF blocks (Q4_K gate / up, Q8_0 down: the int4cpu build of BASELINE config 1) decoded on 1×MI355X -- the GPU twin of cpu_baseline.v2lite_q4k_cpu",
             "qwen3-235b-q4": "Qwen3-235B-A22B Q4 int4gpu, the WHOLE model resident on 1×MI355X (94 GQA layers, 128-expert top-8; BASELINE config 4 names expert parallelism on 8 GPUs: see prefill_experts_ep_235b on the N > 1 lines)"}
 
 
@@ -99,7 +100,7 @@ def parse():
     ap.add_argument("--ep-selftest", action="store_true", help="run the expert-parallel leg at N = 1 too (no peer traffic: checks the row path)")
     ap.add_argument("--prefill-tokens", default="8192,20434,35139,49863",
                     help="prompt lengths of the prompt-pass side measurement (benchmark.py:434-505: 20 434 / 35 139 / 49 863 tokens; 0 = skip)")
-    ap.add_argument("--side-configs", default="v2lite-q4,qcn-q8,qcn-q4k-gguf,qwen3-235b-q4", help="other single-GPU BASELINE configurations measured as side legs of the N = 1 line ('' = none)")
+    ap.add_argument("--side-configs", default="v2lite-q4,v2lite-q4k-gguf,qcn-q8,qcn-q4k-gguf,qwen3-235b-q4", help="other single-GPU BASELINE configurations measured as side legs of the N = 1 line ('' = none)")
     return ap.parse_args()
 
 
@@ -271,7 +272,7 @@ def build_qcn(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, gguf=False,
     return eng, st, keep
 
 
-def build_v2lite(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, ep_world=1):
+def build_v2lite(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, ep_world=1, gguf=False):
     """DeepSeek-V2-Lite-shaped decode graph (BASELINE config 2): MLA attention (direct q projection), layer 0 dense, 64 experts top-6 + 2 shared.
     ep_world > 1: this rank's shard of an expert-parallel model (see build_q235)."""
     import numpy as np
@@ -282,7 +283,11 @@ def build_v2lite(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, ep_world
     if ep_world > 1:
         E_loc = ep_local_experts(E, ep_world, rank); rank = 0
     eng = KrasisEngine(device=local_rank); eng.configure(ModelConfig(H, I, E_loc, k, L, v["n_shared"], 1.0))
-    eng.fill_synthetic(bits, seed=11 + e_rank); eng.set_routing_config("softmax", False, k, E, H)
+    if gguf:      # routed experts as native GGUF blocks, the int4cpu build of BASELINE config 1: Q4_K gate / up, Q8_0 down (1408 is not a multiple of 256)
+        eng.fill_synthetic_gguf(12, 8, seed=11 + e_rank)
+    else:
+        eng.fill_synthetic(bits, seed=11 + e_rank)
+    eng.set_routing_config("softmax", False, k, E, H)
     st = CpuDecodeStore(128, True, False); st.set_moe_store(eng)
     rng = np.random.default_rng(3 + rank); keep = []; seed = [50 + rank * 100000]
 
@@ -508,7 +513,7 @@ def decode_generate(st, kvm, n_tokens=64, runs=3, lookahead=False):
         per = []
         for r in range(runs):
             toks = st.generate_batch(0, 10, n_tokens)
-            per.append(len(toks) / st.last_decode_elapsed_s())
+            per.append(len(toks) / st.last_decode_elapsed_s)
     finally:
         st.set_option("generate_lookahead", 0)
     return {"tok_s": sum(per) / len(per), "runs": [round(x, 1) for x in per], "tokens_per_run": n_tokens,
@@ -563,19 +568,41 @@ def side_config(name, rank, local_rank, args, torch):
     dims = QCN if qcn else (Q235 if q235 else V2L)
     L = dims["layers"]
     build = build_qcn if qcn else (build_q235 if q235 else build_v2lite)
-    if name == "qcn-q4k-gguf":      # prompt pass only: the decode graph runs on the INT4 / INT8 transposed experts (as the reference's decode_step does)
-        eng, st, keep = build_qcn(rank, local_rank, L, 8192 + 64, 4, kv_fp8=True, gguf=True)
-        res = {"workload": WORKLOAD[name], "kv": "FP8-E4M3", "weights": "routed experts: native Q4_K blocks (0.5625 B / weight); projections, shared expert, lm_head: INT4-g128"}
+    if name.endswith("-gguf"):      # routed experts as native GGUF blocks: decode step (kr_gguf.hip block kernels inside the graph) + prompt pass
+        eng, st, keep = (build_qcn if qcn else build_v2lite)(rank, local_rank, L, 8192 + 64, 4, kv_fp8=True, gguf=True)
+        st.set_use_graph(not args.no_graph)
+        H, I, k_ = dims["hidden"], dims["inter"], dims["topk"]
+        bq = 0.5625; bd = 0.5625 if I % 256 == 0 else 1.0625          # Q4_K 144 / 256, Q8_0 34 / 32 bytes per weight
+        res = {"workload": WORKLOAD[name], "kv": "FP8-E4M3",
+               "weights": "routed experts: native GGUF blocks (gate / up Q4_K 0.5625 B / weight, down %s); projections, shared expert, lm_head: INT4-g128" % ("Q4_K" if I % 256 == 0 else "Q8_0 1.0625 B / weight")}
         try:
-            macs = qcn_gemm_macs_per_token(L)
-            res["prefill"] = prefill_model(st, dims, macs, L, 8192, args.prefill_reps, torch)
-            st.set_attention_mode(True, gemm_fast=True)
-            res["prefill_fast_gemm"] = prefill_model(st, dims, macs, L, 8192, args.prefill_reps, torch)
-            r0 = res["prefill_fast_gemm"]["roofline"]
-            res["prefill_fast_gemm"]["roofline"] = {"bound": "mfma", "achieved": r0["achieved"], "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s (f16 MFMA; 2 x useful GEMM MACs / s)", "frac": r0["achieved"] / F16_PEAK_TFLOPS}
+            steps = min(args.steps, 50)
+            ab = dict(algorithmic_bytes(L, B4) if qcn else algorithmic_bytes_v2lite(L, B4))
+            n_moe = L if qcn else max(L - 1, 0); n_sh = 1 if qcn else V2L["n_shared"]
+            ab["moe_w13"] = n_moe * (k_ * H * 2 * I * bq + n_sh * H * 2 * I * B4); ab["moe_w2"] = n_moe * (k_ * I * H * bd + n_sh * I * H * B4)
+            ab.pop("total", None); tot = sum(ab.values())
+            dtg = time_decode(st, steps, args.warmup, dims["kv_max_seq"], torch, None, 1)
+            res.update({"decode_tok_s": steps / dtg, "ms_per_step": dtg / steps * 1e3, "steps": steps, "step_algorithmic_bytes": tot,
+                        "step_frac_of_hbm_peak": tot * (steps / dtg) / 1e9 / HBM_PEAK_GBS,
+                        "decode_numerics": "exact: the routed experts through the block kernels of kr_gguf.hip (per-32 INT16 activations, exact integer dots, the AVX2 kernel's 8 lane chains + hsum per row) -- bit-equal to the oracle's moe_forward_gguf driver (tests/test_decode_gpu.py)"})
+            st.set_attention_mode(False, decode_fast=True)
+            dtf = time_decode(st, steps, args.warmup, dims["kv_max_seq"], torch, None, 1)
+            res["decode_fast_tok_s"] = steps / dtf; res["decode_fast_frac_of_hbm_peak"] = tot * (steps / dtf) / 1e9 / HBM_PEAK_GBS
+            res["decode_fast_note"] = "KR_DECODE_FAST around the GGUF layers: attention / projection launches in the tolerance form, the expert block kernels stay exact"
             st.set_attention_mode(False)
         except Exception as ex:
-            res["prefill"] = {"error": repr(ex)}
+            res["decode_tok_s"] = {"error": repr(ex)}
+        if qcn:
+            try:
+                macs = qcn_gemm_macs_per_token(L)
+                res["prefill"] = prefill_model(st, dims, macs, L, 8192, args.prefill_reps, torch)
+                st.set_attention_mode(True, gemm_fast=True)
+                res["prefill_fast_gemm"] = prefill_model(st, dims, macs, L, 8192, args.prefill_reps, torch)
+                r0 = res["prefill_fast_gemm"]["roofline"]
+                res["prefill_fast_gemm"]["roofline"] = {"bound": "mfma", "achieved": r0["achieved"], "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s (f16 MFMA; 2 x useful GEMM MACs / s)", "frac": r0["achieved"] / F16_PEAK_TFLOPS}
+                st.set_attention_mode(False)
+            except Exception as ex:
+                res["prefill"] = {"error": repr(ex)}
         del st, eng, keep
         gc.collect(); torch.cuda.empty_cache()
         return res

@@ -287,13 +287,13 @@ def test_decode_step_expert_parallel_tolerance_mode(W):
         st, eng, keep, d = ranks[r]
         for i, (tok, pos) in enumerate(steps):
             lg = np.empty(d["V"], F); st.decode_step(tok, pos, lg.ctypes.data); got[r][i] = lg
-            ids[r][i] = st.read_router(16, 4)[0].copy()
+            ids[r][i] = st.read_router(16, 4)[1].copy()
     grp.run([lambda r=r: run(r) for r in range(W)])
     st, eng, orc, keep, d = build(seed=6)
     st.set_attention_mode(False, decode_fast=True)
     for i, (tok, pos) in enumerate(steps):
         ref = np.empty(d["V"], F); st.decode_step(tok, pos, ref.ctypes.data)
-        rid = st.read_router(16, 4)[0]
+        rid = st.read_router(16, 4)[1]
         for r in range(W):
             err = float(np.abs(got[r][i] - ref).max() / np.abs(ref).max())
             assert err <= 2e-4, (i, r, err)
