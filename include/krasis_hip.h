@@ -163,9 +163,7 @@ int kr_reduce_sum_bf16(kr_engine* e, const void* const* inputs, int n_inputs, vo
 int kr_moe_set_prefill_pairs(kr_engine* e, int pairs);
 /* numerics of the prompt-pass expert GEMMs of kr_moe_prefill: 0 (default) = the CPU engine's arithmetic (INT16 activation digits, one f32 fma per
  * 128-group: bit-identical to kr_moe_forward, moe.rs:184); 1 = tolerance form: f16 activations x weights de-quantized in registers, f32 accumulation
- * over the whole k range -- the dataflow of the reference's GPU prompt pass (gpu_prefill.py:64-239, Marlin).  3 = the same with every GEMM on the
- * 64-row tile form (round 3), 5 = the 96-row form of round 4 wherever the matrices allow it (tests); 1 lets big INT4 problems take the 96-row form -- the two forms give bit-identical results (same products, same
- * accumulation order per output), the switch exists for A/B timing and for the test that checks exactly that. */
+ * over the whole k range -- the dataflow of the reference's GPU prompt pass (gpu_prefill.py:64-239, Marlin).  Native GGUF layers stay exact. */
 int kr_moe_set_gemm_mode(kr_engine* e, int fast);
 /* expert-parallel combine: out[t] = sum_s w[t][s] * eo_rows[pair_row[t][s]] in routing order (moe.rs:661-667); pair_row -1 = skip */
 int kr_combine_rows(kr_engine* e, const float* eo_rows, const int32_t* pair_row, const float* weights, void* out, int M, int topk,

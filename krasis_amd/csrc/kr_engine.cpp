@@ -1034,20 +1034,14 @@ static int moe_prefill_fast(kr_engine* e, Layer& L, const void* x_bf16, const in
         const int mc = M - m0 < CH ? M - m0 : CH;
         const uint16_t* xc = (const uint16_t*)x_bf16 + (size_t)m0 * H;
         const int32_t* idc = ids + (size_t)m0 * topk; const float* wc = wts + (size_t)m0 * topk;
-        // big passes of plain INT4 experts cut their row tiles at 96 rows for the round-4 tile form (kr_pfh3_gemm_kernel): an expert's weights are converted
-        // to f16 once per 96 rows instead of once per 64.  Small passes (few rows per expert: weight-streaming bound) keep the 64-row form.
-        const long avg_rows = (long)mc * topk / (E > 0 ? E : 1);
-        const bool h3 = !kr_pfh3_disabled() && kr_pfh3_ok(L.w13.view()) && kr_pfh3_ok(L.w2.view()) && I % 128 == 0 && I <= 2048 &&
-                        (kr_pfh3_forced() || (avg_rows > 64 && ((long)mc * topk / KR_PFH3_BM + E) * (2 * I / 256) >= 512));
-        const int bm = h3 ? KR_PFH3_BM : 64;
-        const int tiles_bound = (mc * topk) / bm + E + 1;
-        int run = (int)((avg_rows + bm - 1) / bm);           // row tiles of an average expert: they share an XCD (one L2 fill of its weights)
+        const int tiles_bound = (mc * topk) / 64 + E + 1;
+        int run = (int)(((long)mc * topk / E + 63) / 64);           // row tiles of an average expert: they share an XCD (one L2 fill of its weights)
         run = run < 1 ? 1 : (run > 4 ? 4 : run);
-        kr_launch_pf_sort(idc, mc, topk, E, so, st, bm);
+        kr_launch_pf_sort(idc, mc, topk, E, so, st);
         kr_launch_pfh_rows_bf16(xc, mc, H, H, (uint16_t*)P.xf.p, (float*)P.xfm.p, st);
         kr_launch_pfh_w13_act(L.w13.view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, &so, topk, 1, tiles_bound, 0, (float*)P.gu.p, mc * topk, act_mode, e->cfg.swiglu_limit,
-                              e->cfg.activation_alpha, (uint16_t*)P.hf.p, (float*)P.hfm.p, st, run, nullptr, nullptr, bm);
-        kr_launch_pfh_gemm(L.w2.view(), (const uint16_t*)P.hf.p, (const float*)P.hfm.p, &so, topk, 0, tiles_bound, 0, (float*)P.eo.p, H, st, 0, 2 /* f16 rows */, run, nullptr, bm);
+                              e->cfg.activation_alpha, (uint16_t*)P.hf.p, (float*)P.hfm.p, st, run);
+        kr_launch_pfh_gemm(L.w2.view(), (const uint16_t*)P.hf.p, (const float*)P.hfm.p, &so, topk, 0, tiles_bound, 0, (float*)P.eo.p, H, st, 0, 2 /* f16 rows */, run);
         if (use_shared) {
             kr_launch_pfh_gemm(L.sw13.view(), (const uint16_t*)P.xf.p, (const float*)P.xfm.p, nullptr, topk, 0, 0, mc, (float*)P.sgu.p, 2 * SI, st);
             kr_launch_pfh_act((const float*)P.sgu.p, mc, SI, 2 * SI, act_mode, e->cfg.swiglu_limit, e->cfg.activation_alpha, (uint16_t*)P.shf.p, (float*)P.shfm.p, st);
@@ -1198,11 +1192,9 @@ extern "C" int kr_moe_set_prefill_pairs(kr_engine* e, int pairs) {
 // (default); 1 = tolerance form (f16 activations, f32 accumulation over the whole k range -- the dataflow of the reference's GPU prompt pass)
 extern "C" int kr_moe_set_gemm_mode(kr_engine* e, int fast) {
     if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
-    if (fast != 0 && fast != 1 && fast != 3 && fast != 5) return kr_fail(KR_ERR_VALUE, "gemm mode %d unknown (0 = exact, 1 = fast, 3 = fast / 64-row tile form only, 5 = fast / 96-row form wherever legal)", fast);
+    if (fast != 0 && fast != 1) return kr_fail(KR_ERR_VALUE, "gemm mode %d unknown (0 = exact, 1 = fast)", fast);
     std::lock_guard<std::mutex> lk(e->mu);
-    e->gemm_fast = fast != 0;
-    if (fast) kr_pfh3_set_mode(fast == 3 ? 1 : (fast == 5 ? 2 : -1));      // 1: back to the default (by problem size, or what KR_PFH3 in the environment says)
-    //      // process-wide: the tile form of the tolerance GEMMs (A/B measurements, parity test of the two forms)
+    e->gemm_fast = fast;
     return KR_OK;
 }
 

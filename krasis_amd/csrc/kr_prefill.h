@@ -50,13 +50,8 @@ void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode
                        uint16_t* sums32 = nullptr);     // act_mode 3 = libm SiLU of expert_forward_gguf (rows of at most 2048 values)
 void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
                         int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows = 0, int out_bf16 = 0, int run = 1,
-                        const uint16_t* a_sum32 = nullptr, int bm = 64);     // a_sum32: required when m.qs is set (Q4_K copy); bm: rows per tile of `sort` (96: the round-4 tile form)
+                        const uint16_t* a_sum32 = nullptr);     // a_sum32: required when m.qs is set (Q4_K copy)
 void kr_launch_pfh_w13_act(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
                            int single_expert_rows, float* gu, int rows, int act_mode, float swiglu_limit, float alpha, uint16_t* h_out, float* h_mul,
-                           hipStream_t st, int run = 1, const uint16_t* a_sum32 = nullptr, uint16_t* h_sums32 = nullptr, int bm = 64);
-bool kr_pfh3_ok(const KrMatDev& m);          // the 96 x 256 tile form takes this matrix (plain INT4-g128)
-bool kr_pfh3_disabled();                     // KR_PFH3=0 in the environment, or kr_moe_set_gemm_mode(e, 3): every tolerance GEMM keeps the 64-row tile form (A/B measurements, parity test of the two forms)
-bool kr_pfh3_forced();                       // kr_moe_set_gemm_mode(e, 5): the 96-row form whenever the matrices allow it, whatever the problem size (tests)
-void kr_pfh3_set_mode(int mode);             // 0 by problem size, 1 never, 2 always
-#define KR_PFH3_BM 96
+                           hipStream_t st, int run = 1, const uint16_t* a_sum32 = nullptr, uint16_t* h_sums32 = nullptr);
 void kr_launch_pfh_gemm_multi(const KrMatDev* mats, float* const* outs, const int* out_lds, int n, const uint16_t* a_h, const float* a_mul, int M, hipStream_t st);

@@ -703,245 +703,6 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
 }
 
 
-// =====================================================================================================================================
-// Round 4: the 96 x 256 tile form for big INT4 problems.
-// What bounded the 64 x 256 form (profiles/r03_gemm_experiments.txt): 7.3 VALU per MFMA, 6 of them the INT4 -> f16 conversion of a B fragment that only
-// TWO row blocks consume.  A B fragment feeds every 32-row block of the tile, so the conversion per MFMA falls as 12 / (row blocks): three blocks -> 4.
-// Four blocks (128 accumulators) do not fit two waves per SIMD; three do, once the rest of the register budget shrinks:
-//   * one quantization GROUP (128 k) per LDS stage instead of a pair: the global -> register staging of the next stage halves (A 6 x 16 B, B 8 x 8 B
-//     per thread), and an odd group count needs no half-empty stage;
-//   * A fragments are double-buffered per 16-k step (one 8-k word of a lane record) instead of per 32-k step: 2 x 3 x 4 registers instead of 2 x 2 x 2 x 4;
-//   => 96 accumulators + 24 (A fragments) + 16 (B fragments) + 8 (raw B words) + 24 + 16 (next stage) + scales, masks, addresses: <= 256, no scratch
-//      (checked at build time: `make -C krasis_amd/csrc resources`).
-// Row tiles of an expert are cut at 96 rows by the sort (kr_launch_pf_sort bm = 96): ~160 rows = 96 + 64 -> TWO conversions of the expert's weights per
-// column block instead of three (64 + 64 + 32), and a tile only issues the MFMAs of its ACTIVE 32-row blocks: NSA is a template parameter and every
-// instantiation is its own kernel (one copy of the stage loop each: two copies inside one kernel doubled the hoisted values and spilled, round 3),
-// launched over the same tile table; a workgroup whose tile belongs to another class returns at once.
-// Same arithmetic as kr_pfh_gemm_kernel<2, 4, 1>: the products and the f32 accumulation order per output are identical (k ascending in steps of 16,
-// the two lane halves' 8-k words in the same MFMA), so the results are BIT-IDENTICAL to the 64-row form (tests/test_gemm_fast_gpu.py checks it).
-// =====================================================================================================================================
-#define PF3_BM 96
-#define PF3_KS 128
-#define PF3_LDA (PF3_KS * 2 + 16)       // 272 B per A row of a stage: rows 68 words apart -> 8 consecutive rows x 16 B cover the 32 banks
-#define PF3_LDB 72                      // bytes per B column of a stage: 8 half lane records x 8 B + 8 pad
-
-template <int NSA>
-__global__ void __launch_bounds__(256, 2) kr_pfh3_gemm_kernel(const KrPfGemmHArgs a, int only_class) {
-    constexpr int NC = 2, BN = 256, LDA = PF3_LDA, LDB = PF3_LDB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                                               // [96][LDA]  f16, k permuted (0,4,1,5,2,6,3,7) inside every 8
-    char* Bs = As + PF3_BM * LDA;                                  // [256][LDB] the group's half of every lane record (8 B), copied verbatim
-    float* rmul = reinterpret_cast<float*>(Bs + BN * LDB);         // [96]
-    int* row_src = reinterpret_cast<int*>(rmul + PF3_BM);          // [96]
-    int* row_dst = row_src + PF3_BM;                               // [96]
-
-    const bool actf = a.act_fused != 0;       // uniform; N = 2 I with I % 128 == 0: a tile = 128 gate + the 128 matching up columns
-    const int ncb0 = (a.m.N + BN - 1) / BN, ncb1 = a.n_extra > 0 ? (a.mx[0].N + BN - 1) / BN : 0, ncb2 = a.n_extra > 1 ? (a.mx[1].N + BN - 1) / BN : 0;
-    const int ncb = ncb0 + ncb1 + ncb2, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    int mt, cb;
-    if (a.single_expert) {
-        const int nrt = (a.total_rows + PF3_BM - 1) / PF3_BM, nsc = (ncb + a.sc - 1) / a.sc, ssz = a.sr * a.sc;
-        const int sup = (slot / ssz) * 8 + xcd, w = slot % ssz;
-        mt = (sup / nsc) * a.sr + w % a.sr; cb = (sup % nsc) * a.sc + w / a.sr;
-        if (mt >= nrt || cb >= ncb) return;
-    } else {
-        const int per = ncb * a.run, grp = slot / per, local = slot - grp * per;
-        mt = (grp * 8 + xcd) * a.run + local / ncb; cb = local % ncb;
-    }
-    int expert, row0, rows;
-    if (a.single_expert) { expert = 0; row0 = mt * PF3_BM; rows = a.total_rows - row0 < PF3_BM ? a.total_rows - row0 : PF3_BM; if (rows <= 0) return; }
-    else { if (mt >= a.n_tiles[0]) return; expert = a.tile_expert[mt]; row0 = a.tile_row0[mt]; rows = a.tile_rows[mt]; }
-    if (only_class && ((rows + 31) >> 5) != NSA) return;           // this instantiation takes the tiles with exactly NSA active 32-row blocks
-    KrMatDev m = a.m; float* out_p = a.out; int out_ld = a.out_ld;
-    if (cb >= ncb0 + ncb1) { cb -= ncb0 + ncb1; m = a.mx[1]; out_p = a.outx[1]; out_ld = a.out_ldx[1]; }
-    else if (cb >= ncb0) { cb -= ncb0; m = a.mx[0]; out_p = a.outx[0]; out_ld = a.out_ldx[0]; }
-    const int n0 = cb * BN;
-    const int K = m.ng * 128;
-    const char* wq = reinterpret_cast<const char*>(m.q) + (size_t)expert * m.q_stride;
-    const uint32_t* wsc = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + (size_t)expert * m.s_stride);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-
-    v16f acc[NSA][NC];
-#pragma unroll
-    for (int s = 0; s < NSA; s++)
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[s][c][r] = 0.0f;
-    const int n31 = lane & 31, khalf = lane >> 5;
-    uint32_t M0 = 0x000F000Fu, M1 = 0x00F000F0u, MH = 0x03C003C0u, Kc = 0x64006400u;      // de-quantization masks, kept in registers (see pfh_dq4)
-    asm volatile("" : "+v"(M0), "+v"(M1), "+v"(MH), "+v"(Kc));
-    const int half_n = m.N >> 1, n0h = cb * 128;
-    int col[NC], ctile[NC], cin[NC], lcolb[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        const int lc = actf ? c * 128 + wave * 32 + n31 : wave * (32 * NC) + c * 32 + n31;
-        lcolb[c] = lc * LDB;
-        col[c] = actf ? c * half_n + n0h + wave * 32 + n31 : n0 + lc;
-        const int cc = col[c] < m.N ? col[c] : m.N - 1; ctile[c] = cc >> 3; cin[c] = cc & 7;
-    }
-    constexpr int APT = PF3_BM / 16;               // 16-byte A chunks per thread per stage: a wave-instruction takes 4 rows x 2 whole 128-byte lines
-    constexpr int RPT = BN * 8 / 256;              // B lane records per thread per stage (8 B each: the group's half of the record)
-    const int arow = tid >> 4, aseg = (tid >> 3) & 1, achk = tid & 7;
-    const uint32_t* rofs = reinterpret_cast<const uint32_t*>(row_src);      // byte offset of every tile row in the A matrix
-    const int nst = m.ng;
-    u32x4 pa[APT]; u32x2 pbw[RPT];
-    uint32_t pspv[NC];
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int last_tile = (m.N - 1) >> 3;
-    uint32_t brec[RPT];                                              // byte offset of this wave's tile records inside the expert's block (scalars)
-#pragma unroll
-    for (int j = 0; j < RPT; j++) {
-        int tile = (n0 >> 3) + wv + 4 * j;
-        if (actf) tile = (n0h >> 3) + wv + 4 * (j % (RPT / 2)) + (j >= RPT / 2 ? half_n >> 3 : 0);
-        tile = tile < last_tile ? tile : last_tile;
-        brec[j] = (uint32_t)__builtin_amdgcn_readfirstlane(tile * m.ngp * 1024);
-    }
-    // loads are never masked (rows past `rows` read row 0, column tiles past the last one re-read the last tile): the stores are guarded
-    auto load_B = [&](int st) {
-        const size_t so = (size_t)(st >> 1) * 1024 + (size_t)(st & 1) * 8 + (size_t)lane * 16;
-#pragma unroll
-        for (int c = 0; c < NC; c++) pspv[c] = wsc[((size_t)ctile[c] * m.ngp + (st >> 1)) * 8 + cin[c]];
-#pragma unroll
-        for (int j = 0; j < RPT; j++) pbw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wq + brec[j] + so));
-    };
-    auto load_A = [&](int st) {
-        const char* ab = reinterpret_cast<const char*>(a.a) + (size_t)st * (PF3_KS * 2) + (uint32_t)(aseg * 128 + achk * 16);
-#pragma unroll
-        for (int j = 0; j < APT; j++) pa[j] = *reinterpret_cast<const u32x4*>(ab + rofs[arow + 16 * j]);
-    };
-    if (wave != 0) load_B(0);
-    float mulv = 0.0f;
-    if (tid < PF3_BM) {
-        int src = -1;
-        if (tid < rows) {
-            if (a.single_expert) src = row0 + tid;
-            else { const int pair = a.row_pair[row0 + tid]; src = a.gather_tokens ? pair / a.topk : row0 + tid; }
-        }
-        row_src[tid] = (int)((uint32_t)(src < 0 ? 0 : src) * (uint32_t)(K * 2));
-        row_dst[tid] = (a.scatter_rows && !a.single_expert && tid < rows) ? a.row_pair[row0 + tid] : row0 + tid;
-        if (src >= 0) mulv = a.a_mul[src];
-    }
-    __syncthreads();
-    if (wave == 0) load_B(0);
-    load_A(0);
-    uint32_t spv[NC];
-    auto commit_stage = [&]() {
-#pragma unroll
-        for (int c = 0; c < NC; c++) spv[c] = pspv[c];
-#pragma unroll
-        for (int j = 0; j < APT; j++) {
-            const u32x4 v = pa[j];      // (a0,a1 | a2,a3 | a4,a5 | a6,a7) -> (a0,a4 | a1,a5 | a2,a6 | a3,a7): the order in which pfh_dq4 presents a word's nibbles
-            const u32x4 w = u32x4{__builtin_amdgcn_perm(v.z, v.x, 0x05040100u), __builtin_amdgcn_perm(v.z, v.x, 0x07060302u),
-                                  __builtin_amdgcn_perm(v.w, v.y, 0x05040100u), __builtin_amdgcn_perm(v.w, v.y, 0x07060302u)};
-            *reinterpret_cast<u32x4*>(As + (arow + 16 * j) * LDA + aseg * 128 + achk * 16) = w;
-        }
-#pragma unroll
-        for (int j = 0; j < RPT; j++) {
-            const int rec = tid + j * 256, t8 = rec >> 6, ln = rec & 63, c = ln >> 3, l8 = ln & 7;
-            *reinterpret_cast<u32x2*>(Bs + (t8 * 8 + c) * LDB + l8 * 8) = pbw[j];
-        }
-    };
-    // one stage = one group = 8 MFMA k-steps u = 2 t + h: lane half `khalf` holds lane record lp = 2 t + khalf (k = 16 lp .. + 16 of the group), word h of it.
-    // Software pipeline over the steps: while the NSA * NC MFMAs of step u run, the B words of step u + 1 are de-quantized and the A fragments of
-    // step u + 2 are read from LDS into the registers step u has just released.
-    auto stage_mfma = [&](int st) {
-        v2h sq[NC], cq[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const float sc = __uint_as_float(((st & 1) ? (spv[c] >> 16) : (spv[c] & 0xFFFFu)) << 16);
-            const _Float16 s1 = (_Float16)(sc * 0.25f);
-            sq[c] = v2h{s1, s1};
-            const _Float16 c1 = (_Float16)(-1536.0f * (float)s1);
-            cq[c] = v2h{c1, c1};
-        }
-        v8h af[2][NSA], bf[2][NC];
-        u32x2 br[2][NC];
-        auto rdA = [&](int u, int buf) {
-            const int lp = 2 * (u >> 1) + khalf;
-#pragma unroll
-            for (int s2 = 0; s2 < NSA; s2++) af[buf][s2] = *reinterpret_cast<const v8h*>(As + (s2 * 32 + n31) * LDA + lp * 32 + (u & 1) * 16);
-        };
-        auto rdB = [&](int t, int buf) {
-#pragma unroll
-            for (int c = 0; c < NC; c++) br[buf][c] = *reinterpret_cast<const u32x2*>(Bs + lcolb[c] + (2 * t + khalf) * 8);
-        };
-        auto dq = [&](int u, int buf, int c) {
-            const u32x2 w = br[(u >> 1) & 1][c];
-            bf[buf][c] = pfh_dq4((u & 1) ? w.y : w.x, sq[c], cq[c], M0, M1, MH, Kc);
-        };
-        rdA(0, 0); rdA(1, 1); rdB(0, 0); rdB(1, 1);
-#pragma unroll
-        for (int c = 0; c < NC; c++) dq(0, 0, c);
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int cur = u & 1, nxt = cur ^ 1;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-#pragma unroll
-                for (int s2 = 0; s2 < NSA; s2++) acc[s2][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][s2], bf[cur][c], acc[s2][c], 0, 0, 0);
-                if (u + 1 < 8) dq(u + 1, nxt, c);
-            }
-            if (u + 2 < 8) rdA(u + 2, cur);
-            if ((u & 1) == 0 && (u >> 1) + 2 < 4) rdB((u >> 1) + 2, (u >> 1) & 1);      // the words of record t were consumed by dq(2 t) and dq(2 t + 1), both issued by now
-#pragma unroll
-            for (int i = 0; i < NC; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, NSA, 0);     // NSA MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 13, 0);      // one fragment's de-quantization
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, NSA + NC, 0);    // DS reads
-        }
-    };
-    for (int st = 0; st < nst; st++) {
-        commit_stage();
-        if (st + 1 < nst) { load_A(st + 1); load_B(st + 1); }
-        __syncthreads();
-        stage_mfma(st);
-        __syncthreads();
-    }
-    if (tid < PF3_BM) rmul[tid] = a.out_bf16 == 2 ? 1.0f : mulv;      // f16 rows carry the raw accumulators: the combine pass applies the row multiplier
-    __syncthreads();
-    {
-        const bool full = rows == NSA * 32 && (actf || n0 + BN <= m.N) && !(a.scatter_rows && !a.single_expert);     // uniform
-#define PF3_ST(F_, OT_, A_) pfh_store_tile<NSA, NC, F_, OT_, A_>(acc, NSA, rows, row0, rmul, row_dst, out_p, out_ld, col, m.N, lane, a.act_fused, a.act_limit, a.act_alpha)
-        if (a.act_fused) { if (full) PF3_ST(true, 0, true); else PF3_ST(false, 0, true); }
-        else if (a.out_bf16 == 1) { if (full) PF3_ST(true, 1, false); else PF3_ST(false, 1, false); }
-        else if (a.out_bf16 == 2) { if (full) PF3_ST(true, 2, false); else PF3_ST(false, 2, false); }
-        else { if (full) PF3_ST(true, 0, false); else PF3_ST(false, 0, false); }
-#undef PF3_ST
-    }
-}
-
-// A/B switch for measurements (tools/probes): KR_PFH3=0 in the environment keeps every problem on the 64-row form.  Read once.
-static int g_pfh3_mode = -1;     // -1: not decided yet (environment on first use); 0 = by problem size, 1 = never, 2 = whenever the matrices allow it (tests)
-static int pfh3_mode() { if (g_pfh3_mode < 0) { const char* v = getenv("KR_PFH3"); g_pfh3_mode = v && v[0] == '0' ? 1 : (v && v[0] == '2' ? 2 : 0); } return g_pfh3_mode; }
-bool kr_pfh3_disabled() { return pfh3_mode() == 1; }
-bool kr_pfh3_forced() { return pfh3_mode() == 2; }
-void kr_pfh3_set_mode(int mode) { g_pfh3_mode = mode; }
-// does the 96-row form take this matrix?  plain INT4-g128 (no Q4_K copy), whole 8-column tiles
-bool kr_pfh3_ok(const KrMatDev& m) { return m.bits == 4 && m.qs == nullptr && m.N % 8 == 0 && m.ng > 0; }
-
-// mt96 = row tiles of 96 (dense: exact; experts: the bound of the tile table built with bm = 96)
-static void pfh3_launch(const KrPfGemmHArgs& a, int mt96, hipStream_t st) {
-    constexpr int BN = 256;
-    const size_t lds = (size_t)PF3_BM * PF3_LDA + (size_t)BN * PF3_LDB + 3 * PF3_BM * 4;
-    int ncb = (a.m.N + BN - 1) / BN;
-    for (int i = 0; i < a.n_extra; i++) ncb += (a.mx[i].N + BN - 1) / BN;
-    if (a.act_fused) ncb = (a.m.N / 2 + 127) / 128;
-    KrPfGemmHArgs b = a;
-    if (a.single_expert) {
-        int n_super; kr_pf_super_tile(mt96, ncb, &b.sr, &b.sc, &n_super);
-        dim3 grid(((n_super + 7) / 8) * 8 * b.sr * b.sc);
-        hipLaunchKernelGGL((kr_pfh3_gemm_kernel<3>), grid, dim3(256), lds, st, b, 0);       // dense: every tile but the last is full; the last one runs its padding rows
-        return;
-    }
-    const int span = 8 * a.run;
-    dim3 grid(((mt96 + span - 1) / span) * span * ncb);
-    hipLaunchKernelGGL((kr_pfh3_gemm_kernel<3>), grid, dim3(256), lds, st, b, 1);
-    hipLaunchKernelGGL((kr_pfh3_gemm_kernel<2>), grid, dim3(256), lds, st, b, 1);
-    hipLaunchKernelGGL((kr_pfh3_gemm_kernel<1>), grid, dim3(256), lds, st, b, 1);
-}
-
 template <int NC, int BITS, int SB = 0, int G = 0, int OCC = 2>
 static void pfh_launch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     constexpr int BN = 128 * NC, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4;
@@ -955,19 +716,8 @@ static void pfh_launch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     else { const int span = 8 * a.run; grid = dim3(((mt + span - 1) / span) * span * ncb); }
     hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS, SB, G, OCC>), grid, dim3(256), lds, st, b);
 }
-static bool pfh3_all_ok(const KrPfGemmHArgs& a) {
-    bool ok = kr_pfh3_ok(a.m);
-    for (int i = 0; i < a.n_extra; i++) ok = ok && kr_pfh3_ok(a.mx[i]) && a.mx[i].ng == a.m.ng;
-    return ok;
-}
 static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     if (a.m.bits == 8) { if (a.m.qs) pfh_launch<1, 8, 0, 1>(a, mt, st); else pfh_launch<1, 8>(a, mt, st); return; }
-    if (a.single_expert && pfh3_all_ok(a) && !kr_pfh3_disabled()) {      // dense INT4 GEMM with enough tiles to fill the chip: the 96-row form
-        long n256 = (a.m.N + 255) / 256;
-        for (int i = 0; i < a.n_extra; i++) n256 += (a.mx[i].N + 255) / 256;
-        const int mt96 = (a.total_rows + PF3_BM - 1) / PF3_BM;
-        if ((long)mt96 * n256 >= 512 || kr_pfh3_forced()) { pfh3_launch(a, mt96, st); return; }
-    }
     // 256-column tiles when they still fill the chip (>= 2 workgroups per CU), else 128-column tiles
     long n128 = (a.m.N + 127) / 128;
     for (int i = 0; i < a.n_extra; i++) n128 += (a.mx[i].N + 127) / 128;
@@ -1008,13 +758,12 @@ void kr_launch_pfh_act(const float* gu, int rows, int n, int gu_ld, int act_mode
     else hipLaunchKernelGGL(kr_pfh_act_kernel<KR_ACT_SILU_MUL>, dim3(rows), dim3(256), 0, st, gu, n, gu_ld, swiglu_limit, alpha, out, mul);
 }
 void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
-                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows, int out_bf16, int run, const uint16_t* a_sum32, int bm) {
+                        int single_expert_rows, float* out, int out_ld, hipStream_t st, int scatter_rows, int out_bf16, int run, const uint16_t* a_sum32) {
     KrPfGemmHArgs a{};
     a.m = m; a.a = a_h; a.a_mul = a_mul; a.a_sum = a_sum32; a.topk = topk; a.gather_tokens = gather_tokens; a.scatter_rows = scatter_rows; a.out_bf16 = out_bf16;
     if (sort) { a.row_pair = sort->row_pair; a.tile_expert = sort->tile_expert; a.tile_row0 = sort->tile_row0; a.tile_rows = sort->tile_rows; a.n_tiles = sort->n_tiles; }
     a.out = out; a.out_ld = out_ld; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
     a.run = (single_expert_rows > 0 || run < 1) ? 1 : run;
-    if (bm == PF3_BM && sort) { pfh3_launch(a, max_tiles, st); return; }      // expert tiles cut at 96 rows (the caller checked kr_pfh3_ok)
     const int mt = single_expert_rows > 0 ? (single_expert_rows + PFH_BM - 1) / PFH_BM : max_tiles;
     pfh_dispatch(a, mt, st);
 }
@@ -1023,11 +772,10 @@ void kr_launch_pfh_gemm(const KrMatDev& m, const uint16_t* a_h, const float* a_m
 // only makes the f16 form.  Otherwise: the GEMM, then the activation pass over gate | up rows.  Same arithmetic either way.
 void kr_launch_pfh_w13_act(const KrMatDev& m, const uint16_t* a_h, const float* a_mul, const KrPfSort* sort, int topk, int gather_tokens, int max_tiles,
                            int single_expert_rows, float* gu, int rows, int act_mode, float swiglu_limit, float alpha, uint16_t* h_out, float* h_mul,
-                           hipStream_t st, int run, const uint16_t* a_sum32, uint16_t* h_sums32, int bm) {
+                           hipStream_t st, int run, const uint16_t* a_sum32, uint16_t* h_sums32) {
     const int I = m.N / 2;
     const int mt = single_expert_rows > 0 ? (single_expert_rows + PFH_BM - 1) / PFH_BM : max_tiles;
-    const bool h3 = bm == PF3_BM && sort != nullptr;       // the caller cut the tiles at 96 rows: only the 96-row form reads that table
-    const bool fuse = h3 || (m.bits == 4 && I % 128 == 0 && I <= 2048 && (long)mt * (m.N / 128) >= 2048);
+    const bool fuse = m.bits == 4 && I % 128 == 0 && I <= 2048 && (long)mt * (m.N / 128) >= 2048;
     if (!fuse) {
         kr_launch_pfh_gemm(m, a_h, a_mul, sort, topk, gather_tokens, max_tiles, single_expert_rows, gu, 2 * I, st, 0, 0, run, a_sum32);
         kr_launch_pfh_act(gu, rows, I, 2 * I, act_mode, swiglu_limit, alpha, h_out, h_mul, st, h_sums32);
@@ -1039,8 +787,7 @@ void kr_launch_pfh_w13_act(const KrMatDev& m, const uint16_t* a_h, const float* 
     a.out = gu; a.out_ld = I; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
     a.run = (single_expert_rows > 0 || run < 1) ? 1 : run;
     a.act_fused = act_mode == KR_ACT_GPTOSS ? 2 : (act_mode == KR_ACT_SILU_LIBM ? 3 : 1); a.act_limit = swiglu_limit; a.act_alpha = alpha;
-    if (h3) pfh3_launch(a, max_tiles, st);
-    else if (m.qs) pfh_launch<2, 4, 1, 1>(a, mt, st); else pfh_launch<2, 4, 1>(a, mt, st);
+    if (m.qs) pfh_launch<2, 4, 1, 1>(a, mt, st); else pfh_launch<2, 4, 1>(a, mt, st);
     const int cpl = I <= 512 ? 1 : (I <= 1024 ? 2 : 4);
 #define KR_ROWW(C_) hipLaunchKernelGGL((kr_pfh_act_wave_kernel<KR_ACT_NONE, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float*)gu, rows, I, I, 0.0f, 0.0f, h_out, h_mul, h_sums32)
     if (rows > 0) { if (cpl == 1) KR_ROWW(1); else if (cpl == 2) KR_ROWW(2); else KR_ROWW(4); }

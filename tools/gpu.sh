@@ -111,18 +111,6 @@ ktrace)     # generic: bash tools/gpu.sh ktrace <name> "<title>" -- <command...>
 stamps)
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     ;;
-h3)         # round 4: the 96-row tile form -- parity (bit-identical to the 64-row form), tolerance tests, A/B timing experts-only and whole prompt pass
-    timeout 900 python -m pytest tests/test_gemm_fast_gpu.py tests/test_ep_gpu.py tests/test_decode_gpu.py tests/test_sampler_gpu.py -q -x 2>&1 | tail -12
-    for rep in 1 2; do
-        KR_PFH3=0 timeout 300 python tools/probes/experts_gemm_probe.py 48 8192 fast 2>&1 | grep experts-only | sed 's/^/64-row: /'
-        timeout 300 python tools/probes/experts_gemm_probe.py 48 8192 fast 2>&1 | grep experts-only | sed 's/^/96-row: /'
-    done
-    KR_PFH3=0 timeout 300 python tools/probes/prefill_profile.py 8192 2 2>&1 | tail -1 | sed 's/^/64-row: /'
-    timeout 300 python tools/probes/prefill_profile.py 8192 2 2>&1 | tail -1 | sed 's/^/96-row: /'
-    KR_PFH3=0 timeout 300 python tools/probes/prefill_profile.py 20434 2 2>&1 | tail -1 | sed 's/^/64-row: /'
-    timeout 300 python tools/probes/prefill_profile.py 20434 2 2>&1 | tail -1 | sed 's/^/96-row: /'
-    kstats r04_experts_8192_gemm_fast "QCN experts only, 8192 tokens x 16 layers, tolerance GEMM, 96-row tile form (tools/probes/experts_gemm_probe.py 16 8192 fast)" -- python /root/repo/tools/probes/experts_gemm_probe.py 16 8192 fast
-    ;;
 r4a)        # round 4, first contact: the whole GPU suite (all failures listed), then the driver's bench line
     timeout 1500 python -m pytest tests/ -q -m gpu -x --maxfail=8 2>&1 | tail -40
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r04_bench_line.json 2> $R/r04_bench_line.err; echo "bench rc=$?"; tail -c 1500 $R/r04_bench_line.err
