@@ -174,6 +174,8 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         if (!EL.w13.allocated() && !EL.gguf) return kr_fail(KR_ERR_STATE, "Model not loaded (MoE layer %d has no experts)", L.moe_layer);   // native GGUF layers: kr_moe_prefill_set walks the block kernels
         const int E = e->r_ne;
         const float* rbias = EL.has_bias ? (const float*)EL.bias.p : nullptr;
+        // KR_GEMM_FAST: the router's logits in the tolerance form too (bf16 MFMA on x = hi + lo; its input already carries the mode's f16 operand rounding)
+        if (!(s->gemm_fast && Cc >= 32 && EL.gate_row.p && 0 == kr_launch_route_logits_fast(EL.gate_row.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st)))
         if (!(Cc >= 32 && EL.gate_row.p && 0 == kr_launch_route_logits_mfma(EL.gate_row.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st)))
             kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st);
         kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);

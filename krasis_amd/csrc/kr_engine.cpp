@@ -740,7 +740,9 @@ static int route_device(kr_engine* e, Layer& L, const void* d_x, int m, int rule
         bool done = false;
         if (m >= 32) {      // batches: the same chains on the f32 MFMA
             if (int rc = kr_ensure_gate_row(e, (int)(&L - e->layers.data()))) return rc;
-            done = L.gate_row.p && 0 == kr_launch_route_logits_mfma(L.gate_row.p, L.gate_bf16_exact, (const float*)d_x, bias, (float*)e->r_logits.p, m, E, H, st);
+            // kr_moe_set_gemm_mode(e, 1): the tolerance form of the batch logits (bf16 MFMA on x = hi + lo) -- the form KR_GEMM_FAST prompt passes run
+            if (e->gemm_fast) done = L.gate_row.p && 0 == kr_launch_route_logits_fast(L.gate_row.p, L.gate_bf16_exact, (const float*)d_x, bias, (float*)e->r_logits.p, m, E, H, st);
+            if (!done) done = L.gate_row.p && 0 == kr_launch_route_logits_mfma(L.gate_row.p, L.gate_bf16_exact, (const float*)d_x, bias, (float*)e->r_logits.p, m, E, H, st);
         }
         if (!done) kr_launch_route_logits_decode(L.gate_cm.p, L.gate_bf16_exact, (const float*)d_x, bias, (float*)e->r_logits.p, m, E, H, st);
     } else {

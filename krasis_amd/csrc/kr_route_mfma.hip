@@ -210,6 +210,83 @@ int kr_launch_mla_wvc_mfma(const float* w_vc, const float* attn_lat, float* v_pr
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
+// TOLERANCE form of the router logits (KR_GEMM_FAST prompt pass; round 4).  The exact kernel above reproduces the reference's 16 fma chains on the
+// f32 MFMA -- 1/16 of the bf16 matrix rate, 512 accumulator registers, one wave per SIMD: 215 us per 2731-token chunk and layer (6.6 % of the kernel
+// time of the tolerance prompt pass, profiles/r03_prefill_8192_attn_fast_gemm_fast_kernel_stats.txt), 17 % of the f32 MFMA peak.  In the tolerance pass
+// the router's INPUT already differs from the exact pass in its last bits (f16 GEMM operands upstream), so what the mode keeps is "router ids exact for
+// the logits it computes, logits to a stated bound" -- as KR_DECODE_FAST does with its tree sums.  Here: gate values are bf16 (checkpoints are; the
+// launcher refuses an f32 gate), x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (x to 2^-17 relative), logit = sum over k of (hi + lo) * g on
+// v_mfma_f32_32x32x16_bf16 with f32 accumulation: two MFMAs per 16 k at 16 x the f32 MFMA rate.  No LDS: a lane's A fragment is 32 contiguous bytes
+// of its token row, its B fragment 16 contiguous bytes of its expert's gate row; both come from L2 (the x tile is read by the E / 128 column tiles,
+// the 2 MB gate by every row tile).  Workgroup: 4 waves = 64 tokens x 128 experts, each wave 32 x 64 (two accumulators); the k loop keeps the
+// fragments of the next two 16-k steps in flight.
+// STATED TOLERANCE (tests/test_router_gpu.py): |fast - exact| <= 2e-5 * sum_k |x_k g_k| per logit (measured ~3e-6); top-k ids equal to the exact
+// kernel's on every token whose k-th and (k+1)-th scores are further apart than that.
+// ------------------------------------------------------------------------------------------------------------------------------------
+typedef __bf16 rm_b8 __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(256) kr_route_logits_fast_kernel(const uint16_t* __restrict__ gate_row, const float* __restrict__ x, const float* __restrict__ bias,
+                                                                   float* __restrict__ logits, int T, int E, int H) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.y * 64 + (wave >> 1) * 32, e0 = blockIdx.x * 128 + (wave & 1) * 64;
+    const int tr = min(t0 + r, T - 1);
+    const float* xp = x + (size_t)tr * H + 8 * h;
+    const uint16_t* gp[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) gp[c] = gate_row + (size_t)min(e0 + 32 * c + r, E - 1) * H + 8 * h;
+    rm_v16f acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[c][i] = 0.0f;
+    constexpr int PD = 2;      // k-steps in flight
+    rm_f4 xa[PD][2]; rm_u4 gb[PD][2];
+    auto fetch = [&](int ks, int buf) {
+        xa[buf][0] = *reinterpret_cast<const rm_f4*>(xp + 16 * ks); xa[buf][1] = *reinterpret_cast<const rm_f4*>(xp + 16 * ks + 4);
+#pragma unroll
+        for (int c = 0; c < 2; c++) gb[buf][c] = *reinterpret_cast<const rm_u4*>(gp[c] + 16 * ks);
+    };
+    const int nks = H / 16;
+#pragma unroll
+    for (int p = 0; p < PD; p++) if (p < nks) fetch(p, p);
+    for (int ks = 0; ks < nks; ks += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; p++) {
+            if (ks + p >= nks) break;
+            const float v[8] = {xa[p][0].x, xa[p][0].y, xa[p][0].z, xa[p][0].w, xa[p][1].x, xa[p][1].y, xa[p][1].z, xa[p][1].w};
+            rm_b8 ahi, alo;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const __bf16 hi = (__bf16)v[j]; ahi[j] = hi; alo[j] = (__bf16)(v[j] - (float)hi); }
+            rm_b8 b[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) b[c] = __builtin_bit_cast(rm_b8, gb[p][c]);
+            if (ks + p + PD < nks) fetch(ks + p + PD, p);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, b[c], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, b[c], acc[c], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int e = e0 + 32 * c + r;
+        const float bv = (bias && e < E) ? bias[e] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int t = t0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (t < T && e < E) logits[(size_t)t * E + e] = acc[c][i] + bv;
+        }
+    }
+}
+// non-zero = not covered (f32 gate, H not a multiple of 16): the caller keeps the exact kernel
+int kr_launch_route_logits_fast(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* logits, int T, int E, int H, hipStream_t st) {
+    if (!gate_bf16 || H % 16 || T < 1 || E < 1) return 1;
+    const dim3 grid((E + 127) / 128, (T + 63) / 64);
+    hipLaunchKernelGGL(kr_route_logits_fast_kernel, grid, dim3(256), 0, st, reinterpret_cast<const uint16_t*>(gate_row), x, bias, logits, T, E, H);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
 // MLA prompt pass: the w_kc absorption of a chunk (mla_absorb_wkc_avx2, decode.rs:4508): q_abs[t][h][j] = chain over i ascending of
 // fma(q[t][h][i], w_kc[h][i][j], acc) -- ONE chain per output, so one accumulator per 32 x 32 block and the k pairs (2m, 2m+1) in order.
 // Workgroup: 64 tokens x 64 latent columns of one head, K = nd in one stage.  The q tile is stored with the k of every 8-group de-interleaved

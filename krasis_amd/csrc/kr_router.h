@@ -6,6 +6,7 @@ void kr_launch_route_logits_decode(const void* gate_cm, int gate_bf16, const flo
                                    int m, int E, int H, hipStream_t st);
 // prompt pass (m >= 32 tokens): the same logits, bit for bit, on the f32 MFMA (kr_route_mfma.hip); gate_row = row-major [E][H] bf16 or f32.
 // non-zero = geometry not covered
+int kr_launch_route_logits_fast(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* logits, int T, int E, int H, hipStream_t st);   // tolerance form (bf16 MFMA, x split hi + lo); non-zero = not covered
 int kr_launch_route_logits_mfma(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* logits, int T, int E, int H, hipStream_t st);
 int kr_launch_mla_wvc_mfma(const float* w_vc, const float* attn_lat, float* v_proj, int T, int nh, int vhd, int klr, hipStream_t st);   // the same chains: MLA w_vc projection of a chunk
 int kr_launch_mla_absorb_mfma(const float* q_full, int ld_q, int hd, int nd, const float* w_kc, int klr, float* q_abs, int T, int nh, hipStream_t st);   // MLA w_kc absorption of a chunk (one fma chain per output)

@@ -91,3 +91,39 @@ def test_engine_rule_bit_exact(sigmoid):
         r_ids, r_w = O.route_engine(gate, act[t], k, sigmoid, True, bias)
         assert np.array_equal(ids[t], r_ids)
         assert np.array_equal(w[t].view(np.uint32), r_w.view(np.uint32))
+
+
+@pytest.mark.parametrize("E,H,m,use_bias", [(512, 2048, 300, False), (72, 256, 70, True), (130, 512, 45, True)])
+def test_decode_rule_batch_logits_tolerance_form(E, H, m, use_bias):
+    """kr_moe_set_gemm_mode(e, 1) / KR_GEMM_FAST: the batch logits on the bf16 MFMA with x split into hi + lo bf16 (kr_route_logits_fast_kernel) instead of
+    the 16 f32 chains.  STATED TOLERANCE: |fast - exact| <= 2e-5 * sum_k |x_k g_k| per logit (x carried to 2^-17, products summed in another order);
+    the top-k ids equal the exact kernel's wherever the k-th and (k + 1)-th logits are further apart than twice that bound (partial token / expert tiles
+    included).  An f32 gate (not bf16-exact) keeps the exact kernel: bit-identical."""
+    from krasis_amd._lib import check
+    rng = np.random.default_rng(E + m)
+    gate = O.bf16_to_f32(O.f32_to_bf16(((rng.random((E, H), dtype=np.float32) - 0.5) * 0.04).astype(np.float32))).reshape(E, H)
+    bias = ((rng.random(E, dtype=np.float32) - 0.5) * 0.1).astype(np.float32) if use_bias else None
+    k = 6
+    eng = _engine(E, H, k, "softmax")
+    eng.set_route_weight_f32(0, gate, bias, None)
+    x = ((rng.random((m, H), dtype=np.float32) - 0.5) * 2).astype(np.float32)
+    ids0, w0, lg0 = eng.route(0, x, m, RULE_DECODE, want_logits=True)
+    check(eng._lib.kr_moe_set_gemm_mode(eng._h, 1))
+    ids1, w1, lg1 = eng.route(0, x, m, RULE_DECODE, want_logits=True)
+    check(eng._lib.kr_moe_set_gemm_mode(eng._h, 0))
+    bound = 2e-5 * (np.abs(x).astype(np.float64) @ np.abs(gate).astype(np.float64).T)
+    err = np.abs(lg1.astype(np.float64) - lg0.astype(np.float64))
+    assert (err <= bound).all(), float((err / bound).max())
+    assert err.max() > 0.0                                   # the tolerance kernel ran (another summation order), not the exact one
+    srt = np.sort(lg0, axis=1)[:, ::-1]
+    clear = (srt[:, k - 1] - srt[:, k]) > 2 * bound.max(axis=1)
+    assert clear.sum() >= m // 2
+    assert np.array_equal(ids0[clear], ids1[clear])
+    # an f32 gate that is not bf16-exact: the launcher refuses, the exact kernel runs
+    gate32 = ((rng.random((E, H), dtype=np.float32) - 0.5) * 0.04).astype(np.float32)
+    eng.set_route_weight_f32(0, gate32, bias, None)
+    a = eng.route(0, x, m, RULE_DECODE, want_logits=True)[2]
+    check(eng._lib.kr_moe_set_gemm_mode(eng._h, 1))
+    b = eng.route(0, x, m, RULE_DECODE, want_logits=True)[2]
+    check(eng._lib.kr_moe_set_gemm_mode(eng._h, 0))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -114,18 +114,12 @@ stamps)
 r4a)        # round 4, first contact: the whole GPU suite (all failures listed), then the driver's bench line
     timeout 1500 python -m pytest tests/ -q -m gpu -x --maxfail=8 2>&1 | tail -40
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r04_bench_line.json 2> $R/r04_bench_line.err; echo "bench rc=$?"; tail -c 1500 $R/r04_bench_line.err
-    python - <<'PY'
-import json
-d = json.load(open('/root/repo/gpurun_out/r04_bench_line.json'))
-g = lambda *k: __import__('functools').reduce(lambda a, b: a.get(b, {}) if isinstance(a, dict) else {}, k, d)
-print('value', d.get('value'), 'exact', d.get('value_exact'), 'gen', json.dumps(d.get('decode_generate'))[:600])
-print('roofline', {k: d['roofline'].get(k) for k in ('kernel', 'frac', 'frac_raw_events', 'us_per_launch', 'step_frac_of_hbm_peak')})
-for k in ('prefill', 'prefill_fast', 'prefill_fast_gemm'):
-    print(k, g(k, 'by_prompt_length'), 'allocs', g(k, 'allocs_in_timed_region'), 'ms_all', g(k, 'ms_all'))
-print('experts', g('prefill_experts_only', 'tok_s_experts_only'), g('prefill_experts_only_fast_gemm', 'tok_s_experts_only'), g('prefill_experts_only_fast_gemm', 'roofline', 'frac'))
-for c, v in (d.get('configs') or {}).items():
-    print(c, {k: (round(v[k], 1) if isinstance(v.get(k), float) else v.get(k)) for k in ('decode_tok_s', 'decode_fast_tok_s', 'error') if k in v}, g('configs', c, 'prefill', 'value'), g('configs', c, 'prefill_fast_gemm', 'value'))
-PY
+    python tools/bench_summary.py $R/r04_bench_line.json
+    ;;
+r4b)        # round 4: tests that failed / are new since r4a, the bench line, the kernel trace of the bench command
+    timeout 900 python -m pytest tests/test_ep_gpu.py tests/test_sampler_gpu.py tests/test_decode_gpu.py tests/test_gguf_gpu.py tests/test_prefill_model_gpu.py -q -x 2>&1 | tail -6
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r04_bench_line.json 2> $R/r04_bench_line.err; echo "bench rc=$?"; tail -c 600 $R/r04_bench_line.err
+    python tools/bench_summary.py $R/r04_bench_line.json
     ;;
 tests)      # the whole GPU suite, as the driver runs it
     timeout 2400 python -m pytest tests/ -x -q -m gpu "$@" 2>&1 | tail -15
