@@ -522,9 +522,13 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             if (L.attn == ATTN_LA) in_img = img_w(L.qkvz_wid) && img_w(L.ba_wid, L.qkvz_wid);
             else if (L.attn == ATTN_GQA) in_img = img_w(L.q_wid) && img_w(L.k_wid, L.q_wid) && img_w(L.v_wid, L.q_wid);
         }
+        // KR_DECODE_FAST on MLA layers (round 4): the input add + RMSNorm folded into the first projection launch (kv_a | q, or kv_a | q_a on the LoRA path) and
+        // the o projection on the K-split tree-sum matvec; the attention launches themselves (absorb, scores, weighted sum, w_vc) keep the reference's order
+        const int mla_w2 = L.attn == ATTN_MLA ? (L.mq_wid >= 0 ? L.mq_wid : L.mqa_wid) : -1;
+        const bool mla_in = fast && L.attn == ATTN_MLA && img_w(L.kva_wid) && img_w(mla_w2, L.kva_wid);
         // FAST: the input add+RMSNorm folded into the first projection launch (every workgroup rebuilds the normalised vector with tree sums)
         bool did_in = false, la_conv_done = false;
-        if (fast && in_img && src.mode != 2) {
+        if (fast && (in_img || mla_in) && src.mode != 2) {
             KrFdmArgs fa{};
             fa.mode = 1; fa.hid_in = hid; fa.res_in = res_cur; fa.res_out = other(res_cur); fa.norm_w = (const float*)s->norms[L.input_norm]->p;
             fa.first = first ? 1 : 0; fa.eps = s->eps; fa.bias_one = s->norm_bias_one;
@@ -539,7 +543,8 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
                     fa.nk = L.nk; fa.dk = L.dk; fa.hr = hr; fa.dv = L.dv; fa.conv_mi = 1; fa.gate_mi = 0;
                     fa.a_log = (const float*)L.a_log.p; fa.dt_bias = (const float*)L.dt_bias.p; fa.ge_out = (float*)s->gbuf.p; fa.beta_out = (float*)s->betabuf.p;
                 }
-            } else { add(L.q_wid, (float*)s->proj_a.p); add(L.k_wid, (float*)s->kbuf.p); add(L.v_wid, (float*)s->vbuf.p); }
+            } else if (L.attn == ATTN_MLA) { add(L.kva_wid, (float*)s->kbuf.p); add(mla_w2, L.mq_wid >= 0 ? (float*)s->proj_a.p : (float*)s->proj_b.p); }
+            else { add(L.q_wid, (float*)s->proj_a.p); add(L.k_wid, (float*)s->kbuf.p); add(L.v_wid, (float*)s->vbuf.p); }
             prof_mark(s, PK_MATVEC, st);
             did_in = 0 == kr_launch_fdm(fa, st);
             prof_mark(s, -1, st);
@@ -630,6 +635,12 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             if (!L.kv_k.p) return kr_fail(KR_ERR_STATE, "set_decode_state was not called (no MLA cache for layer %zu)", li);
             if (L.mla_rope_seq < s->kv_max_seq) return kr_fail(KR_ERR_VALUE, "MLA rope table (%d) shorter than kv_max_seq (%d)", L.mla_rope_seq, s->kv_max_seq);
             float* kv_out = (float*)s->kbuf.p; float* q_full = (float*)s->proj_a.p;
+            if (did_in) {          // KR_DECODE_FAST: kv_a | q (or kv_a | q_a) came out of the folded norm + projection launch above
+                if (L.mq_wid < 0) {
+                    if (L.q_a_norm_len) PROF(PK_RMSNORM, kr_launch_rmsnorm_seq((float*)s->proj_b.p, (const float*)L.q_a_norm.p, s->weights[L.mqa_wid]->rows, s->eps, st));
+                    PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.mqb_wid), s->proj_b.p, 1, q_full, st));
+                }
+            } else
             if (L.mq_wid >= 0) {   // direct query projection shares the activation with kv_a_proj: one launch
                 const KrMatDev mats[2] = {mv(s, L.kva_wid), mv(s, L.mq_wid)};
                 float* ys[2] = {kv_out, q_full};
@@ -652,7 +663,14 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.sc_g = s->kv_max_seq > s->mla_split_min ? (float*)s->gqa_scores.p : nullptr;
             if (s->attn_fast && a.sc_g) { a.fast = 1; a.fd_o = (float*)s->fd_o.p; a.fd_ml = (float*)s->fd_ml.p; }
             PROF(PK_GQA, kr_launch_mla(a, s->kv_max_seq, st));
-            PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
+            bool o_done = false;
+            if (fast && s->weights[L.o_wid]->cols == L.nh * L.vhd) {      // o projection straight from the f32 w_vc output: every workgroup quantises it, K split over the waves
+                KrFdmArgs fo{}; fo.mode = 2; fo.hid_in = (const float*)s->attn_out.p; fo.mm.n = 1; fo.mm.m[0] = mv(s, L.o_wid); fo.mm.y[0] = hid; fo.mm.tile_end[0] = (fo.mm.m[0].N + 7) / 8;
+                prof_mark(s, PK_OUT_PROJ, st);
+                o_done = 0 == kr_launch_fdm(fo, st);
+                prof_mark(s, -1, st);
+            }
+            if (!o_done) PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }
         // post-attention fused add+RMSNorm: folded into the router launch of MoE layers, its own launch otherwise
         const float* act = hid;   // normalised hidden the MLP block reads

@@ -22,7 +22,7 @@
 
 struct KrFdmArgs {
     KrMultiMat mm;
-    int mode;                 // 0: `img` is the INT16 image of the input vector; 1: input = RMSNorm(hid_in (+ res_in)) built by every workgroup
+    int mode;                 // 0: `img` is the INT16 image of the input vector; 1: input = RMSNorm(hid_in (+ res_in)) built by every workgroup; 2: input = the f32 vector hid_in as is
     const void* img;
     const float *hid_in, *res_in, *norm_w; float* res_out;
     const float* emb; const KrStep* step;   // mode 1, first layer: the added value is the embedding row of the current token

@@ -237,7 +237,13 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
     const KrActLds L = kr_carve_lds(kr_fsm, K, BITS == 8);
     KR_FSTAMP(sk, 1);
     if (a.mode == 0) kr_f_image_copy<BITS>(a.img, K, kr_fsm, L, t, 256);
-    else {
+    else if (a.mode == 2) {      // plain f32 input vector (MLA: the w_vc output feeding o_proj): every workgroup quantises it (quantize_activation_int16_f32, avx2.rs:274)
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int c = t + 256 * u;
+            if (c < K / 8) { float x8[8]; kr_load8(a.hid_in, c, x8); kr_f_quant_chunk<BITS == 8>(x8, c, L, false); }
+        }
+    } else {
         KrFNormIn in{a.emb ? a.emb + (size_t)a.step->token * K : a.hid_in, a.res_in, a.norm_w, a.res_out, a.first, a.eps, a.bias_one, K};
         float x[2][8];
         kr_f_norm(in, x, s_red, blockIdx.x == 0);
@@ -517,6 +523,11 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
     const int lane = threadIdx.x & 63;
     const bool raw = scoring == 2;
     float lg[NV], sc[NV], sl[NV];
+    // softmax scoring without a correction bias, weights renormalised over the k leaders (QCN, Qwen3-235B): the selection runs on the logits (softmax is
+    // monotone) and the renormalised weight of leader i is e^{l_i - m} / sum over the LEADERS of e^{l_j - m} -- the full-softmax denominator cancels, so the E
+    // exponentials, their wave sum and the score / selection arrays in LDS are never formed (round 4: ~1 us of the 3.4 us this prologue cost on the serial path
+    // of every gate|up workgroup).  Against the reference's (e_i / S) / sum_j (e_j / S): two roundings fewer per weight, within 3e-7 relative (test bound).
+    const bool lean = scoring == 1 && esc == nullptr && norm != 0;
     bool wide = false;
     if constexpr (NV % 4 == 0) {
         if (E % 4 == 0) {
@@ -533,7 +544,7 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
 #pragma unroll
         for (int i = 0; i < NV; i++) { const int e = lane * NV + i; lg[i] = e < E ? logits[e] : -__builtin_inff(); }
     }
-    if (raw) {
+    if (raw || lean) {
 #pragma unroll
         for (int i = 0; i < NV; i++) sc[i] = lg[i];
     } else if (scoring == 0) {
@@ -558,7 +569,7 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
     for (int i = 0; i < NV; i++) {
         const int e = lane * NV + i;
         sl[i] = on_logits ? lg[i] : ((!raw && esc && e < E) ? sc[i] + esc[e] : sc[i]);
-        if (e < E) { scores[e] = sc[i]; sel[e] = sl[i]; }
+        if (!lean && e < E) { scores[e] = sc[i]; sel[e] = sl[i]; }
     }
     const int np = k + 1 <= E ? k + 1 : k;
     if (!kr_f_topk<NV>(sl, E, np, pv, pi, cand)) kr_topk_wave_reg<NV>(sl, E, np, pv, pi);
@@ -567,11 +578,25 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
         const float pa = lane < np ? pv[lane] : 0.0f, pb = lane + 1 < np ? pv[lane + 1] : 0.0f;
         const bool tie = __ballot(lane + 1 < np && pa == pb) != 0ull;
         if (tie) {   // heap order governs ties (decode.rs:1531)
+            if (lean) {      // the selection values were not parked: do it now (rare path)
+#pragma unroll
+                for (int i = 0; i < NV; i++) { const int e = lane * NV + i; if (e < E) sel[e] = sl[i]; }
+                kr_f_wave_sync();
+            }
             if (lane == 0) kr_topk_heap_serial(sel, E, k, hv, hi, pi);
             kr_f_wave_sync();
         }
     }
     const int my = lane < k ? pi[lane] : 0;
+    if (lean) {
+        // pv[0] is the largest logit (the leaders come out in descending order; under a tie the heap order may permute EQUAL values only)
+        const float mx = pv[0];
+        float wv = lane < k ? __builtin_amdgcn_exp2f((logits[my] - mx) * 1.4426950408889634f) : 0.0f;
+        const float se = kr_f_wave_sum(wv);
+        wv = wv / se;
+        if (lane < k) { s_ids[lane] = my; s_w[lane] = wv; }
+        return;
+    }
     float wv = lane < k ? scores[my] : 0.0f;
     if (raw) {
         const float mx = kr_f_wave_max(lane < k ? wv : -__builtin_inff());
@@ -762,7 +787,7 @@ int kr_launch_fdm(const KrFdmArgs& a, hipStream_t st) {
     const KrMatDev& m0 = a.mm.m[0];
     const int bits = m0.bits, K = m0.ng * 128;
     for (int i = 1; i < a.mm.n; i++) if (a.mm.m[i].bits != bits || a.mm.m[i].ng != m0.ng) return 1;
-    if (a.mode == 1 && (K > 4096 || K != m0.K)) return 1;
+    if ((a.mode == 1 || a.mode == 2) && (K > 4096 || K != m0.K)) return 1;
     if (a.conv_state && (a.conv_mi < 0 || a.conv_mi >= a.mm.n || a.mm.m[a.conv_mi].N != a.nk * (2 * a.dk + 2 * a.hr * a.dv) || a.gate_mi < 0 || a.gate_mi >= a.mm.n ||
                          a.mm.m[a.gate_mi].N != a.nk * 2 * a.hr || !a.ge_out || !a.beta_out)) return 1;
     const int total = a.mm.tile_end[a.mm.n - 1];

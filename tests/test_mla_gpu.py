@@ -246,3 +246,28 @@ def test_mla_geometry_errors():
     st = CpuDecodeStore(128, True, False); st.set_moe_store(eng)
     with pytest.raises(RuntimeError):                        # configure_decode first (decode.rs:2153-2154)
         st.add_decode_mla_layer(0, 0, 0, 0, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 512, 128, 64, 128, 0.1)
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(lora=True, seed=2), dict(klr=256, nh=3, seed=4), dict(dims=(2048, 512, 16, 6, 256, 512), nh=16, seed=9)])
+def test_mla_decode_step_tolerance_mode(cfg):
+    """KR_DECODE_FAST on MLA layers (round 4): the input add + RMSNorm folded into the kv_a | q (LoRA: kv_a | q_a) projection launch, the o projection on the
+    K-split tree-sum matvec fed by the f32 w_vc output, the MoE block on the mode's three launches; absorb / scores / weighted sum / w_vc keep the exact
+    kernels.  STATED TOLERANCE (the mode's): logits within 2e-3 of the oracle driver (max |diff| / max |ref|), same greedy token, latent caches within
+    3e-3; the last case has V2-Lite's widths (H 2048, 16 heads)."""
+    st, eng, orc, keep, d = build(**cfg)
+    st.set_attention_mode(False, decode_fast=True)
+    tok = 9
+    for step, pos in enumerate([5, 6, 7, 8]):
+        logits = np.empty(d["V"], F)
+        st.decode_step(tok, pos, logits.ctypes.data)
+        ref = orc.step(tok, pos)
+        err = float(np.abs(logits - ref).max() / np.abs(ref).max())
+        assert np.isfinite(logits).all() and err <= 2e-3, (step, err)
+        assert err > 0.0 or step > 0                      # the tolerance kernels ran (another summation order)
+        assert int(np.argmax(logits)) == O.sample_greedy(ref)
+        tok = O.sample_greedy(ref)
+    for li in range(d["nL"]):
+        ck = np.empty((d["kv_max"], d["klr"]), np.uint16); kp = np.empty((d["kv_max"], d["rd"]), np.uint16)
+        st.get_decode_state(li, ck, kp, None, None)
+        a = ck.view(np.float16).astype(F); b = orc.layers[li]["ckv"].view(np.float16).astype(F)
+        assert float(np.abs(a - b).max() / np.abs(b).max()) <= 3e-3
