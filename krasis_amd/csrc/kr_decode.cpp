@@ -722,7 +722,22 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
                     }
                 }
             }
-            if (!moe_done && s->fuse_router) {
+            // KR_DECODE_FAST around a native-GGUF layer: the mode's norm + gate GEMV launch and the stand-alone select in front of the (exact) block kernels
+            if (!moe_done && fast && EL.gguf && src.mode != 2) {
+                KrFrtArgs ra{};
+                ra.gate_cm = EL.gate_cm.p; ra.gate_bf16 = EL.gate_bf16_exact; ra.bias = EL.has_bias ? (const float*)EL.bias.p : nullptr; ra.logits = (float*)s->r_logits.p;
+                ra.E = e->r_ne; ra.H = H; ra.hid_in = hid; ra.res_in = res_cur; ra.norm_w = (const float*)s->norms[L.post_norm]->p; ra.hid_out = (float*)s->hid2.p;
+                ra.res_out = other(res_cur); ra.eps = s->eps; ra.bias_one = s->norm_bias_one; ra.img_f32 = s->img_post.p; ra.img_bf16 = s->img_post_bf16.p;
+                prof_mark(s, PK_ROUTE_LOGITS, st);
+                const int rc = kr_launch_frt(ra, st);
+                prof_mark(s, -1, st);
+                if (rc == 0) {
+                    PROF(PK_ROUTE_SELECT, kr_launch_route_select((const float*)s->r_logits.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p, (float*)s->r_w.p, 1, e->r_ne, s->topk,
+                                                                 s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st));
+                    routed = true; act = (const float*)s->hid2.p; res_cur = other(res_cur);
+                }
+            }
+            if (!moe_done && !routed && s->fuse_router) {
                 prof_mark(s, PK_ROUTE_LOGITS, st);
                 routed = 0 == kr_launch_route_fused_decode(EL.gate_cm.p, EL.gate_bf16_exact, EL.has_bias ? (const float*)EL.bias.p : nullptr, (float*)s->r_logits.p,
                                                            (unsigned*)s->r_counter.p, EL.has_esc ? (const float*)EL.esc.p : nullptr, (int32_t*)s->r_ids.p,
@@ -769,9 +784,16 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
                     a.gu_ld = g.gu_ld; a.gu = g.gu + (size_t)k * g.gu_ld; a.eo = g.eo + (size_t)k * H;
                     a.rsf = s->rsf; a.swiglu_limit = e->cfg.swiglu_limit; a.alpha = e->cfg.activation_alpha;
                     a.act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
+                    const bool fuse_gate = has_gate && mv(s, L.sg_wid).bits == a.sw13.bits;      // the sigmoid-gate row rides in the shared slot's gate|up launch
+                    if (fuse_gate) { a.sgate = mv(s, L.sg_wid); a.gate_out = (float*)s->gate_val.p; }
                     PROF(PK_MOE_W13, kr_launch_moe_w13(a, st));
-                    if (has_gate) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), act, 1, (float*)s->gate_val.p, st));
+                    if (has_gate && !fuse_gate) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), act, 1, (float*)s->gate_val.p, st));
                     PROF(PK_MOE_W2, kr_launch_moe_w2(a, st));
+                }
+                if (fast) {      // KR_DECODE_FAST: the combine as its own small launch into `hid`, so that the next layer's folded norm + projection launch applies
+                    PROF(PK_MOE_COMBINE, kr_launch_moe_combine_decode(g.eo, g.ids, (const float*)s->r_w.p, k, has_shared ? 1 : 0, has_gate ? (const float*)s->gate_val.p : nullptr, s->rsf, hid, H, st));
+                    src = from_hidden;
+                    continue;
                 }
                 src = KrNormSrc{}; src.mode = 2; src.eo = g.eo; src.ids = g.ids; src.wts = (const float*)s->r_w.p; src.topk = k; src.has_shared = has_shared ? 1 : 0;
                 src.gate_val = has_gate ? (const float*)s->gate_val.p : nullptr; src.rsf = s->rsf;

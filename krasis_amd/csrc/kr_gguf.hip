@@ -112,32 +112,44 @@ __device__ __forceinline__ void gg_scale_min_k4(int j, uint32_t s0, uint32_t s1,
 }
 
 // ---- one row tile (8 rows x 8 lanes), int path; returns the row result in every lane of the row's 8-lane group ----
+// The block records of a tile are REQUESTED IN BATCHES of GG_PF before the first one is consumed (round 4): the loop used to issue one block's two loads,
+// wait for them (one HBM / fabric round trip each), compute, and go on -- K / 256 dependent round trips per tile, the whole duration of the launch.  Indices
+// past the last block are clamped (the load is unconditional, its value unused), the arithmetic and its order are unchanged: same bits.
+#define GG_PF 8
 __device__ __forceinline__ float gg_tile_q4k(const GgMat& m, int tile, const GgAct& A, int lane) {
     const int l = lane & 7, row = lane >> 3;
     const int nb = m.K / 256;
     const u32x4* q = reinterpret_cast<const u32x4*>(m.q) + (size_t)tile * nb * 64 + lane;
     const u32x4* h = reinterpret_cast<const u32x4*>(m.h) + (size_t)tile * nb * 8 + row;
     float acc = 0.0f, corr = 0.0f;
-    for (int b = 0; b < nb; b++) {
-        const u32x4 w = kr_ldg_nt(q + (size_t)b * 64);
-        const u32x4 hd = kr_ldg_nt(h + (size_t)b * 8);
-        const float d = gg_f16(hd.x & 0xFFFFu), dmin = gg_f16(hd.x >> 16);
-        const uint32_t wj[4] = {w.x, w.y, w.z, w.w};
+    for (int b0 = 0; b0 < nb; b0 += GG_PF) {
+        u32x4 wv[GG_PF], hv[GG_PF];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int sc_lo, mn_lo, sc_hi, mn_hi;
-            gg_scale_min_k4(2 * j, hd.y, hd.z, hd.w, sc_lo, mn_lo); gg_scale_min_k4(2 * j + 1, hd.y, hd.z, hd.w, sc_hi, mn_hi);
-            const int s_lo = b * 8 + 2 * j, s_hi = s_lo + 1;
-            const u32x2 r_lo = *reinterpret_cast<const u32x2*>(A.rec + ((size_t)s_lo * 8 + l) * 2);
-            const u32x2 r_hi = *reinterpret_cast<const u32x2*>(A.rec + ((size_t)s_hi * 8 + l) * 2);
-            const uint32_t lo = wj[j] & 0x0F0F0F0Fu, hi = (wj[j] >> 4) & 0x0F0F0F0Fu;
-            const int i_lo = (__builtin_amdgcn_sdot4((int)lo, (int)r_lo.x, 0, false) << 8) + (int)__builtin_amdgcn_udot4(lo, r_lo.y, 0u, false);
-            const int i_hi = (__builtin_amdgcn_sdot4((int)hi, (int)r_hi.x, 0, false) << 8) + (int)__builtin_amdgcn_udot4(hi, r_hi.y, 0u, false);
-            const float as_lo = A.scale[s_lo], as_hi = A.scale[s_hi];
-            acc = __builtin_fmaf((float)i_lo, d * (float)sc_lo * as_lo, acc);
-            corr += dmin * (float)mn_lo * as_lo * (float)A.sum[s_lo];
-            acc = __builtin_fmaf((float)i_hi, d * (float)sc_hi * as_hi, acc);
-            corr += dmin * (float)mn_hi * as_hi * (float)A.sum[s_hi];
+        for (int u = 0; u < GG_PF; u++) { const int bb = b0 + u < nb ? b0 + u : nb - 1; wv[u] = kr_ldg_nt(q + (size_t)bb * 64); hv[u] = kr_ldg_nt(h + (size_t)bb * 8); }
+#pragma unroll
+        for (int u = 0; u < GG_PF; u++) {
+            const int b = b0 + u;
+            if (b < nb) {
+                const u32x4 w = wv[u], hd = hv[u];
+                const float d = gg_f16(hd.x & 0xFFFFu), dmin = gg_f16(hd.x >> 16);
+                const uint32_t wj[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int sc_lo, mn_lo, sc_hi, mn_hi;
+                    gg_scale_min_k4(2 * j, hd.y, hd.z, hd.w, sc_lo, mn_lo); gg_scale_min_k4(2 * j + 1, hd.y, hd.z, hd.w, sc_hi, mn_hi);
+                    const int s_lo = b * 8 + 2 * j, s_hi = s_lo + 1;
+                    const u32x2 r_lo = *reinterpret_cast<const u32x2*>(A.rec + ((size_t)s_lo * 8 + l) * 2);
+                    const u32x2 r_hi = *reinterpret_cast<const u32x2*>(A.rec + ((size_t)s_hi * 8 + l) * 2);
+                    const uint32_t lo = wj[j] & 0x0F0F0F0Fu, hi = (wj[j] >> 4) & 0x0F0F0F0Fu;
+                    const int i_lo = (__builtin_amdgcn_sdot4((int)lo, (int)r_lo.x, 0, false) << 8) + (int)__builtin_amdgcn_udot4(lo, r_lo.y, 0u, false);
+                    const int i_hi = (__builtin_amdgcn_sdot4((int)hi, (int)r_hi.x, 0, false) << 8) + (int)__builtin_amdgcn_udot4(hi, r_hi.y, 0u, false);
+                    const float as_lo = A.scale[s_lo], as_hi = A.scale[s_hi];
+                    acc = __builtin_fmaf((float)i_lo, d * (float)sc_lo * as_lo, acc);
+                    corr += dmin * (float)mn_lo * as_lo * (float)A.sum[s_lo];
+                    acc = __builtin_fmaf((float)i_hi, d * (float)sc_hi * as_hi, acc);
+                    corr += dmin * (float)mn_hi * as_hi * (float)A.sum[s_hi];
+                }
+            }
         }
     }
     return gg_hsum8(acc) - corr;
@@ -149,19 +161,27 @@ __device__ __forceinline__ float gg_tile_q8_0(const GgMat& m, int tile, const Gg
     const u32x4* q = reinterpret_cast<const u32x4*>(m.q) + (size_t)tile * nbg * 64 + lane;
     const u32x2* h = reinterpret_cast<const u32x2*>(m.h) + (size_t)tile * nbg * 8 + row;
     float acc = 0.0f;
-    for (int bg = 0; bg < nbg; bg++) {
-        const u32x4 w = kr_ldg_nt(q + (size_t)bg * 64);
-        const u32x2 hd = h[(size_t)bg * 8];
-        const uint32_t wb[4] = {w.x, w.y, w.z, w.w};
-        const float dd[4] = {gg_f16(hd.x & 0xFFFFu), gg_f16(hd.x >> 16), gg_f16(hd.y & 0xFFFFu), gg_f16(hd.y >> 16)};
+    for (int g0 = 0; g0 < nbg; g0 += GG_PF) {      // batched requests, as gg_tile_q4k
+        u32x4 wv[GG_PF]; u32x2 hv[GG_PF];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int s = bg * 4 + u;
-            if (s < nb) {
-                const u32x2 r = *reinterpret_cast<const u32x2*>(A.rec + ((size_t)s * 8 + l) * 2);
-                const int iv = (__builtin_amdgcn_sdot4((int)wb[u], (int)r.x, 0, false) << 8) + __builtin_amdgcn_sdot4((int)wb[u], (int)(r.y ^ 0x80808080u), 0, false) +
-                               (__builtin_amdgcn_sdot4((int)wb[u], 0x01010101, 0, false) << 7);
-                acc = __builtin_fmaf((float)iv, dd[u] * A.scale[s], acc);
+        for (int v = 0; v < GG_PF; v++) { const int gg = g0 + v < nbg ? g0 + v : nbg - 1; wv[v] = kr_ldg_nt(q + (size_t)gg * 64); hv[v] = h[(size_t)gg * 8]; }
+#pragma unroll
+        for (int v = 0; v < GG_PF; v++) {
+            const int bg = g0 + v;
+            if (bg < nbg) {
+                const u32x4 w = wv[v]; const u32x2 hd = hv[v];
+                const uint32_t wb[4] = {w.x, w.y, w.z, w.w};
+                const float dd[4] = {gg_f16(hd.x & 0xFFFFu), gg_f16(hd.x >> 16), gg_f16(hd.y & 0xFFFFu), gg_f16(hd.y >> 16)};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int s = bg * 4 + u;
+                    if (s < nb) {
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(A.rec + ((size_t)s * 8 + l) * 2);
+                        const int iv = (__builtin_amdgcn_sdot4((int)wb[u], (int)r.x, 0, false) << 8) + __builtin_amdgcn_sdot4((int)wb[u], (int)(r.y ^ 0x80808080u), 0, false) +
+                                       (__builtin_amdgcn_sdot4((int)wb[u], 0x01010101, 0, false) << 7);
+                        acc = __builtin_fmaf((float)iv, dd[u] * A.scale[s], acc);
+                    }
+                }
             }
         }
     }
@@ -280,14 +300,16 @@ __global__ void __launch_bounds__(GG_BLOCK) kr_gguf_w13_kernel(const GgMoeArgs a
     if (t0 >= 2 * nt) return;
     const bool intp = gg_int_path(gate.type) && (a.H % 32 == 0);
     const GgAct A = gg_carve(gg_smem, a.H);
+    // tiles [0, nt) are gate rows, [nt, 2nt) are up rows; a workgroup's span may straddle the boundary
+    const int t1 = t0 + tiles_per_wg < 2 * nt ? t0 + tiles_per_wg : 2 * nt;
+    const int ng = t0 < nt ? (t1 < nt ? t1 : nt) - t0 : 0;           // gate tiles of this workgroup, then its up tiles [us, us + nu)
+    const int us = t0 > nt ? t0 - nt : 0, nu = t1 > nt ? (t1 - nt) - us : 0;
     if (a.act_f32) gg_prologue_f32_as_bf16(a.act_f32 + (size_t)b * a.H, a.H, A, !intp);
     else gg_prologue_bf16(a.act + (size_t)b * a.H, a.H, A, !intp);
     __syncthreads();
     float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
-    // tiles [0, nt) are gate rows, [nt, 2nt) are up rows; a workgroup's span may straddle the boundary
-    const int t1 = t0 + tiles_per_wg < 2 * nt ? t0 + tiles_per_wg : 2 * nt;
-    if (t0 < nt) gg_run_rows(gate, A, gu, 0, t0, (t1 < nt ? t1 : nt) - t0);
-    if (t1 > nt) { const int s = t0 > nt ? t0 - nt : 0; gg_run_rows(up, A, gu, a.gu_ld / 2, s, (t1 - nt) - s); }
+    if (ng > 0) gg_run_rows(gate, A, gu, 0, t0, ng);
+    if (nu > 0) gg_run_rows(up, A, gu, a.gu_ld / 2, us, nu);
 }
 
 // stage 2: eo[b][slot] = down . q(silu(gate)*up)

@@ -116,6 +116,16 @@ r4a)        # round 4, first contact: the whole GPU suite (all failures listed),
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r04_bench_line.json 2> $R/r04_bench_line.err; echo "bench rc=$?"; tail -c 1500 $R/r04_bench_line.err
     python tools/bench_summary.py $R/r04_bench_line.json
     ;;
+gguf)       # native-GGUF experts inside the decode step: parity tests, decode tok/s of the two GGUF side configurations
+    timeout 900 python -m pytest tests/test_gguf_gpu.py tests/test_decode_gpu.py -q -x -k "gguf" 2>&1 | tail -4
+    timeout 600 python tools/probes/gguf_decode_bench.py 30 2>&1 | grep decode
+    ;;
+r4c)        # round 4: lean select, MLA tolerance wiring, tolerance router logits, GGUF gate fuse -- their tests, then decode / prompt-pass timings
+    timeout 1200 python -m pytest tests/test_decode_fast_gpu.py tests/test_mla_gpu.py tests/test_router_gpu.py tests/test_decode_gpu.py tests/test_gemm_fast_gpu.py tests/test_tolerance_peaked_gpu.py -q -x 2>&1 | tail -6
+    timeout 600 python tools/probes/decode_fast_bench.py --only fast --route-tokens 200 2>&1 | tail -8
+    timeout 300 python tools/probes/prefill_profile.py 8192 2 2>&1 | tail -1
+    timeout 300 python tools/probes/prefill_profile.py 20434 2 2>&1 | tail -1
+    ;;
 r4b)        # round 4: tests that failed / are new since r4a, the bench line, the kernel trace of the bench command
     timeout 900 python -m pytest tests/test_ep_gpu.py tests/test_sampler_gpu.py tests/test_decode_gpu.py tests/test_gguf_gpu.py tests/test_prefill_model_gpu.py -q -x 2>&1 | tail -6
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r04_bench_line.json 2> $R/r04_bench_line.err; echo "bench rc=$?"; tail -c 600 $R/r04_bench_line.err
