@@ -121,6 +121,30 @@ def quantize_int8(w_bf16: np.ndarray, gs: int = 128):
     return data, scales
 
 
+def quantize_and_pack_legacy(w_bf16_kn: np.ndarray, gs: int = 128, bits: int = 4):
+    """The reference's LEGACY GPU quantizer `_quantize_and_pack_gpu` (python/krasis/gpu_prefill.py:240-291), restated in numpy: w [K, N] bf16 ->
+    (packed int32 [K / vals, N], scale bf16 [K / gs, N]).  Differs from the live rule (marlin.rs:145-207 = quantize_int4 above) in three places
+    (trap 2): scale = max(|max| / qmax, |min| / (qmax + 1)) per group instead of amax / qmax; the DIVISION uses the unrounded f32 scale
+    (the bf16 rounding happens only on the stored copy); round-half-EVEN (torch.round) instead of half-away.  Pinned by tests/golden/legacy_quant.npz
+    (outputs of the imported reference function).  No product path uses this rule: kr_upload_expert_bf16 implements marlin.rs."""
+    w = bf16_to_f32(_c(w_bf16_kn, np.uint16)).reshape(w_bf16_kn.shape).astype(np.float32)
+    K, N = w.shape
+    qmax = 7.0 if bits == 4 else 127.0
+    g = w.reshape(K // gs, gs, N)
+    mx = g.max(axis=1, keepdims=True); mn = g.min(axis=1, keepdims=True)
+    scale = np.maximum(np.abs(mx) / np.float32(qmax), np.abs(mn) / np.float32(qmax + 1.0)).astype(np.float32)
+    scale = np.maximum(scale, np.float32(1e-10))
+    q = np.rint(g / scale)                                  # numpy rint == torch.round: half to even
+    q = np.clip(q, -(qmax + 1.0), qmax).astype(np.int32) + int(qmax + 1)
+    q = q.reshape(K, N)
+    vals = 8 if bits == 4 else 4
+    qv = q.reshape(K // vals, vals, N)
+    packed = qv[:, 0, :].copy()
+    for i in range(1, vals):
+        packed |= qv[:, i, :] << (bits * i)
+    return packed.astype(np.int32), f32_to_bf16(scale.reshape(K // gs, N)).reshape(K // gs, N)
+
+
 def dequantize_int4(packed, scales, gs=128):
     packed = _c(packed, np.uint32); scales = _c(scales, np.uint16)
     rows, pc = packed.shape
