@@ -19,6 +19,7 @@ import numpy as np
 CACHE_MAGIC = b"KRAS"
 CACHE_VERSION_MARLIN = 3
 CACHE_VERSION_CPU = 4
+CACHE_VERSION_CPU_GGUF = 5
 CACHE_HEADER_SIZE = 64
 
 
@@ -46,6 +47,11 @@ def cache_path_cpu(model_dir: str, num_bits: int, group_size: int) -> str:
     return os.path.join(cache_dir_for_model(model_dir), f"experts_cpu_int{num_bits}_g{group_size}.bin")
 
 
+def cache_path_gguf_avx2(model_dir: str, group_size: int) -> str:
+    """weights/mod.rs:930-933: the version-5 file built from a GGUF (gguf_native=False: de-quantized and re-quantized to INT4 / INT8, w13 and w2 widths may differ)"""
+    return os.path.join(cache_dir_for_model(model_dir), f"experts_gguf_avx2_g{group_size}.bin")
+
+
 def cache_path_marlin(model_dir: str, group_size: int, gpu_bits: int) -> str:
     return os.path.join(cache_dir_for_model(model_dir), f"experts_marlin_int{gpu_bits}_g{group_size}.bin")
 
@@ -60,6 +66,20 @@ def cpu_expert_byte_sizes(h: int, m: int, gs: int, bits: int) -> Tuple[int, int,
     if bits == 4:
         return (h // 8) * two_n * 4, (h // gs) * two_n * 2, (m // 8) * h * 4, (m // gs) * h * 2
     return ((h * two_n + 3) // 4) * 4, (h // gs) * two_n * 2, ((m * h + 3) // 4) * 4, (m // gs) * h * 2
+
+
+def cpu_expert_byte_sizes_mixed(h: int, m: int, gs: int, w13_bits: int, w2_bits: int) -> Tuple[int, int, int, int]:
+    """weights/mod.rs:1000-1017: the version-5 file's per-expert sizes, gate|up and down each at its own width"""
+    a = cpu_expert_byte_sizes(h, m, gs, w13_bits); b = cpu_expert_byte_sizes(h, m, gs, w2_bits)
+    return a[0], a[1], b[2], b[3]
+
+
+def expected_gguf_cpu_cache_size(h, m, n_experts, gs, w13_bits, w2_bits, num_moe_layers, n_shared) -> int:
+    """weights/mod.rs:1020-1041"""
+    total = CACHE_HEADER_SIZE + num_moe_layers * n_experts * sum(cpu_expert_byte_sizes_mixed(h, m, gs, w13_bits, w2_bits))
+    if n_shared > 0:
+        total += num_moe_layers * sum(cpu_expert_byte_sizes_mixed(h, n_shared * m, gs, w13_bits, w2_bits))
+    return total
 
 
 def marlin_expert_byte_sizes(h: int, m: int, gs: int, bits: int, shared: bool = False) -> Tuple[int, int, int, int]:
@@ -288,5 +308,98 @@ def load_marlin_cache(engine, path: str, chash: int, gpu_bits: int, total_moe_la
                 off = upload(layer, -1, off, ns * m, True)
         engine.synchronize()
         engine._cpu_bits = engine._gpu_bits = gpu_bits
+    finally:
+        _close_map(mm, f)
+
+
+# ---------------------------------------------------------------------------------------------------------------- GGUF-sourced CPU cache (v5)
+def pack_header_v5(h: int, m: int, n_experts: int, num_moe_layers: int, gs: int, chash: int, n_shared: int, w13_bits: int, w2_bits: int) -> bytes:
+    """write_cpu_cache_header_v5 (weights/mod.rs:4176-4206): bytes 56..64 = n_shared (low 16 bits) | w13_bits << 48 | w2_bits << 56"""
+    meta = (n_shared & 0xFFFF) | (w13_bits << 48) | (w2_bits << 56)
+    return CACHE_MAGIC + struct.pack("<I6Q", CACHE_VERSION_CPU_GGUF, h, m, n_experts, num_moe_layers, gs, chash) + struct.pack("<Q", meta)
+
+
+def save_gguf_cpu_cache(engine, path: str, chash: int, w13_bits: int, w2_bits: int, total_moe_layers: Optional[int] = None) -> int:
+    """Write the engine's experts as the reference's version-5 file (streaming_build_cpu_cache_from_gguf's output, weights/mod.rs:3700-3905): the version-4
+    body with gate|up at w13_bits and down at w2_bits."""
+    h, m, E, L, gs, ns = _dims(engine)
+    L = total_moe_layers or L
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(pack_header_v5(h, m, E, L, gs, chash, ns, w13_bits, w2_bits))
+        for layer in range(L):
+            for e in range(E):
+                for a in engine.download_expert(layer, e, w13_bits, w2_bits):
+                    f.write(a.tobytes())
+        if ns > 0:
+            for layer in range(L):
+                for a in engine.download_expert(layer, -1, w13_bits, w2_bits):
+                    f.write(a.tobytes())
+        size = f.tell()
+    os.replace(tmp, path)
+    assert size == expected_gguf_cpu_cache_size(h, m, E, gs, w13_bits, w2_bits, L, ns)
+    return size
+
+
+def load_gguf_cpu_cache(engine, path: str, chash: int, total_moe_layers: Optional[int] = None, start_moe_layer: int = 0,
+                        num_layers_to_load: Optional[int] = None) -> Tuple[int, int]:
+    """load_gguf_cpu_cache (weights/mod.rs:3908-4062) into a configured engine; returns (w13_bits, w2_bits) as stored in the header.  Validation order and
+    messages are the reference's."""
+    h, m, E, L_eng, gs, ns = _dims(engine)
+    total = total_moe_layers or L_eng
+    n = num_layers_to_load if num_layers_to_load is not None else min(L_eng, total - start_moe_layer)
+    f, mm = _open(path, "GGUF CPU")
+    try:
+        if len(mm) < CACHE_HEADER_SIZE:
+            raise RuntimeError("GGUF CPU cache too small for header")
+        if bytes(mm[0:4]) != CACHE_MAGIC:
+            raise RuntimeError("Bad magic in GGUF CPU cache")
+        v, fh, fm, fe, fl, fg, fc, meta = struct.unpack("<I7Q", bytes(mm[4:64]))
+        if v != CACHE_VERSION_CPU_GGUF:
+            raise RuntimeError(f"Cache version {v}, expected {CACHE_VERSION_CPU_GGUF} (GGUF CPU)")
+        if (fh, fm, fe, fl, fg) != (h, m, E, total, gs):
+            raise RuntimeError(f"GGUF CPU cache header mismatch: file has {fh}h/{fm}m/{fe}e/{fl}L/g{fg}, expected {h}h/{m}m/{E}e/{total}L/g{gs}")
+        if fc != chash:
+            raise RuntimeError("Config hash mismatch in GGUF CPU cache")
+        f_shared, w13_bits, w2_bits = meta & 0xFFFF, (meta >> 48) & 0xFF, (meta >> 56) & 0xFF
+        if f_shared != ns:
+            raise RuntimeError(f"Shared expert count mismatch: cache={f_shared}, config={ns}")
+        if w13_bits not in (4, 8):
+            raise RuntimeError(f"Invalid w13_bits in cache: {w13_bits}")
+        if w2_bits not in (4, 8):
+            raise RuntimeError(f"Invalid w2_bits in cache: {w2_bits}")
+        expected = expected_gguf_cpu_cache_size(h, m, E, gs, w13_bits, w2_bits, total, ns)
+        if len(mm) != expected:
+            raise RuntimeError(f"GGUF CPU cache size mismatch: expected {expected} bytes, got {len(mm)}")
+        if start_moe_layer + n > total:
+            raise RuntimeError(f"Range [{start_moe_layer}, {start_moe_layer + n}) exceeds total MoE layers {total}")
+        if n > L_eng:
+            raise RuntimeError(f"engine was configured for {L_eng} MoE layers, cannot hold {n}")
+
+        def upload(layer: int, expert: int, off: int, inter: int) -> int:
+            p13, s13, p2, s2 = cpu_expert_byte_sizes_mixed(h, inter, gs, w13_bits, w2_bits)
+            w13 = (np.frombuffer(mm, np.uint32, p13 // 4, off).reshape(h // 8, 2 * inter) if w13_bits == 4
+                   else np.frombuffer(mm, np.int8, h * 2 * inter, off).reshape(h, 2 * inter))
+            w13s = np.frombuffer(mm, np.uint16, s13 // 2, off + p13).reshape(h // gs, 2 * inter)
+            w2 = (np.frombuffer(mm, np.uint32, p2 // 4, off + p13 + s13).reshape(inter // 8, h) if w2_bits == 4
+                  else np.frombuffer(mm, np.int8, inter * h, off + p13 + s13).reshape(inter, h))
+            w2s = np.frombuffer(mm, np.uint16, s2 // 2, off + p13 + s13 + p2).reshape(inter // gs, h)
+            engine.load_unified_expert(layer, expert, w13, w13s, w2, w2s, num_bits=w13_bits, w2_bits=w2_bits)
+            return off + p13 + s13 + p2 + s2
+
+        per_layer = E * sum(cpu_expert_byte_sizes_mixed(h, m, gs, w13_bits, w2_bits))
+        off = CACHE_HEADER_SIZE + start_moe_layer * per_layer
+        for layer in range(n):
+            for e in range(E):
+                off = upload(layer, e, off, m)
+        if ns > 0:
+            per_shared = sum(cpu_expert_byte_sizes_mixed(h, ns * m, gs, w13_bits, w2_bits))
+            off = CACHE_HEADER_SIZE + total * per_layer + start_moe_layer * per_shared
+            for layer in range(n):
+                off = upload(layer, -1, off, ns * m)
+        engine.synchronize()
+        engine._cpu_bits = engine._gpu_bits = max(w13_bits, w2_bits)
+        return w13_bits, w2_bits
     finally:
         _close_map(mm, f)

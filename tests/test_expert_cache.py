@@ -61,3 +61,16 @@ def test_header_bytes_and_validation_order():
     # a wrong shape is reported before a wrong hash, a wrong hash before the shared count (the reference's order)
     with pytest.raises(RuntimeError, match="header mismatch"):
         EC.check_header(hdr, **{**ok, "h": 1024, "chash": 1, "n_shared": 0})
+
+
+def test_v5_gguf_cpu_cache_sizes_and_header():
+    """version 5 (weights/mod.rs:1000-1041, 4176-4206): per-projection widths; bytes 56..64 = n_shared | w13_bits << 48 | w2_bits << 56"""
+    h, m, E, L, gs = 2048, 512, 512, 48, 128
+    a = EC.cpu_expert_byte_sizes_mixed(h, m, gs, 4, 8)
+    assert a == ((h // 8) * 2 * m * 4, (h // gs) * 2 * m * 2, m * h, (m // gs) * h * 2)
+    assert EC.cpu_expert_byte_sizes_mixed(h, m, gs, 4, 4) == EC.cpu_expert_byte_sizes(h, m, gs, 4)
+    assert EC.expected_gguf_cpu_cache_size(h, m, E, gs, 4, 8, L, 1) == 64 + L * E * sum(a) + L * sum(EC.cpu_expert_byte_sizes_mixed(h, m, gs, 4, 8))
+    hdr = EC.pack_header_v5(h, m, E, L, gs, 0x99, 1, 4, 8)
+    assert len(hdr) == 64 and struct.unpack("<I", hdr[4:8])[0] == 5
+    assert struct.unpack("<Q", hdr[56:64])[0] == 1 | (4 << 48) | (8 << 56)
+    assert EC.cache_path_gguf_avx2("/models/M", 128).endswith("/experts_gguf_avx2_g128.bin")

@@ -134,3 +134,45 @@ def test_engine_load_picks_up_a_reference_cache(tmp_path, monkeypatch):
     assert "Config hash mismatch" in c.cache_note
     for x, y in zip(a.download_expert(0, 1, 4), c.download_expert(0, 1, 4)):
         assert np.array_equal(x, y)
+
+
+def test_gguf_cpu_cache_v5_mixed_widths_round_trips(tmp_path):
+    """version 5 (`experts_gguf_avx2_g128.bin`, weights/mod.rs:883,930,3908-4062,4176-4206): the CPU transposed body with gate|up and down at their OWN widths
+    (a GGUF whose down projections are Q6_K / Q8_0 re-quantizes them to INT8 while Q4_K gate / up stay INT4: weights/mod.rs:26-42).  Header bytes 56..64 =
+    n_shared | w13_bits << 48 | w2_bits << 56.  An engine writes the file, the body equals the independently assembled one byte for byte, a second engine
+    loads it (incl. a pipeline-stage range) and computes the same bits; the reference's validation messages."""
+    import struct
+    from krasis_amd import expert_cache as EC
+    H, I, E, k, L, ns = 256, 128, 5, 2, 3, 1
+    rng = np.random.default_rng(55)
+    eng = _engine(H, I, E, k, L, ns)
+    layers = []
+    for li in range(L):
+        ex = make_experts(rng, E, H, I, 4, 8); sh = make_experts(rng, 1, H, ns * I, 4, 8)[0]
+        upload(eng, li, ex, sh); layers.append((ex, sh))
+    path = str(tmp_path / "experts_gguf_avx2_g128.bin")
+    size = EC.save_gguf_cpu_cache(eng, path, 0xFEED, 4, 8)
+    raw = open(path, "rb").read()
+    assert size == len(raw) == EC.expected_gguf_cpu_cache_size(H, I, E, 128, 4, 8, L, ns)
+    assert raw[:4] == b"KRAS" and struct.unpack("<I", raw[4:8])[0] == 5
+    assert struct.unpack("<Q", raw[56:64])[0] == (ns | (4 << 48) | (8 << 56))
+    body = b"".join(a.tobytes() for ex, _ in layers for e in ex for a in (e.w13, e.w13_scales, e.w2, e.w2_scales))
+    body += b"".join(a.tobytes() for _, sh in layers for a in (sh.w13, sh.w13_scales, sh.w2, sh.w2_scales))
+    assert raw[64:] == body
+    eng2 = _engine(H, I, E, k, L, ns)
+    assert EC.load_gguf_cpu_cache(eng2, path, 0xFEED) == (4, 8)
+    r1, (act, ids, w) = _forward(eng, np.random.default_rng(1), H, E, k, 2)
+    r2 = np.frombuffer(eng2.moe_forward(2, act.tobytes(), ids, w), np.float32)
+    assert np.array_equal(r1.view(np.uint32), r2.view(np.uint32))
+    eng3 = _engine(H, I, E, k, 2, ns)
+    EC.load_gguf_cpu_cache(eng3, path, 0xFEED, total_moe_layers=L, start_moe_layer=1, num_layers_to_load=2)
+    r3 = np.frombuffer(eng3.moe_forward(1, act.tobytes(), ids, w), np.float32)
+    assert np.array_equal(r1.view(np.uint32), r3.view(np.uint32))
+    with pytest.raises(RuntimeError, match="Config hash mismatch in GGUF CPU cache"):
+        EC.load_gguf_cpu_cache(eng2, path, 1)
+    v4 = str(tmp_path / "v4.bin"); open(v4, "wb").write(EC.pack_header(4, H, I, E, L, 128, 0xFEED, ns, 4))
+    with pytest.raises(RuntimeError, match=r"Cache version 4, expected 5 \(GGUF CPU\)"):
+        EC.load_gguf_cpu_cache(eng2, v4, 0xFEED)
+    open(path, "ab").write(b"\0")
+    with pytest.raises(RuntimeError, match="GGUF CPU cache size mismatch: expected %d bytes, got %d" % (size, size + 1)):
+        EC.load_gguf_cpu_cache(eng2, path, 0xFEED)
