@@ -224,47 +224,55 @@ int kr_launch_mla_wvc_mfma(const float* w_vc, const float* attn_lat, float* v_pr
 // kernel's on every token whose k-th and (k+1)-th scores are further apart than that.
 // ------------------------------------------------------------------------------------------------------------------------------------
 typedef __bf16 rm_b8 __attribute__((ext_vector_type(8)));
-__global__ void __launch_bounds__(256) kr_route_logits_fast_kernel(const uint16_t* __restrict__ gate_row, const float* __restrict__ x, const float* __restrict__ bias,
+// k mapping: the MFMA sums its 16 k in any order as long as A and B agree, so an iteration covers 32 k and lane half h takes the CONTIGUOUS 16 of them
+// [32 j + 16 h, + 16) -- two MFMA steps (its first / second 8) -- instead of two separate 8-k chunks: a lane reads 64 contiguous bytes of its token row and
+// 32 of its gate row, and the two lanes of a row cover one whole 128-byte line (the first form asked for half lines and ran at 120 us per 2752-token chunk).
+__global__ void __launch_bounds__(128, 2) kr_route_logits_fast_kernel(const uint16_t* __restrict__ gate_row, const float* __restrict__ x, const float* __restrict__ bias,
                                                                    float* __restrict__ logits, int T, int E, int H) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int t0 = blockIdx.y * 64 + (wave >> 1) * 32, e0 = blockIdx.x * 128 + (wave & 1) * 64;
+    const int t0 = blockIdx.y * 32, e0 = blockIdx.x * 128 + wave * 64;      // two waves per workgroup: 32 tokens x 128 experts (a 2752-token chunk: 344 workgroups over the 256 CUs)
     const int tr = min(t0 + r, T - 1);
-    const float* xp = x + (size_t)tr * H + 8 * h;
+    const float* xp = x + (size_t)tr * H + 16 * h;
     const uint16_t* gp[2];
 #pragma unroll
-    for (int c = 0; c < 2; c++) gp[c] = gate_row + (size_t)min(e0 + 32 * c + r, E - 1) * H + 8 * h;
+    for (int c = 0; c < 2; c++) gp[c] = gate_row + (size_t)min(e0 + 32 * c + r, E - 1) * H + 16 * h;
     rm_v16f acc[2];
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[c][i] = 0.0f;
-    constexpr int PD = 2;      // k-steps in flight
-    rm_f4 xa[PD][2]; rm_u4 gb[PD][2];
-    auto fetch = [&](int ks, int buf) {
-        xa[buf][0] = *reinterpret_cast<const rm_f4*>(xp + 16 * ks); xa[buf][1] = *reinterpret_cast<const rm_f4*>(xp + 16 * ks + 4);
+    constexpr int PD = 2;      // 32-k iterations in flight
+    rm_f4 xa[PD][4]; rm_u4 gb[PD][2][2];
+    auto fetch = [&](int j, int buf) {
 #pragma unroll
-        for (int c = 0; c < 2; c++) gb[buf][c] = *reinterpret_cast<const rm_u4*>(gp[c] + 16 * ks);
+        for (int q = 0; q < 4; q++) xa[buf][q] = *reinterpret_cast<const rm_f4*>(xp + 32 * j + 4 * q);
+#pragma unroll
+        for (int c = 0; c < 2; c++) { gb[buf][c][0] = *reinterpret_cast<const rm_u4*>(gp[c] + 32 * j); gb[buf][c][1] = *reinterpret_cast<const rm_u4*>(gp[c] + 32 * j + 8); }
     };
-    const int nks = H / 16;
+    const int nit = H / 32;
 #pragma unroll
-    for (int p = 0; p < PD; p++) if (p < nks) fetch(p, p);
-    for (int ks = 0; ks < nks; ks += PD) {
+    for (int p = 0; p < PD; p++) if (p < nit) fetch(p, p);
+    for (int j0 = 0; j0 < nit; j0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; p++) {
-            if (ks + p >= nks) break;
-            const float v[8] = {xa[p][0].x, xa[p][0].y, xa[p][0].z, xa[p][0].w, xa[p][1].x, xa[p][1].y, xa[p][1].z, xa[p][1].w};
-            rm_b8 ahi, alo;
+            if (j0 + p >= nit) break;
+            rm_b8 ahi[2], alo[2], b[2][2];
 #pragma unroll
-            for (int j = 0; j < 8; j++) { const __bf16 hi = (__bf16)v[j]; ahi[j] = hi; alo[j] = (__bf16)(v[j] - (float)hi); }
-            rm_b8 b[2];
+            for (int u = 0; u < 2; u++) {
+                const float v[8] = {xa[p][2 * u].x, xa[p][2 * u].y, xa[p][2 * u].z, xa[p][2 * u].w, xa[p][2 * u + 1].x, xa[p][2 * u + 1].y, xa[p][2 * u + 1].z, xa[p][2 * u + 1].w};
 #pragma unroll
-            for (int c = 0; c < 2; c++) b[c] = __builtin_bit_cast(rm_b8, gb[p][c]);
-            if (ks + p + PD < nks) fetch(ks + p + PD, p);
+                for (int i = 0; i < 8; i++) { const __bf16 hi = (__bf16)v[i]; ahi[u][i] = hi; alo[u][i] = (__bf16)(v[i] - (float)hi); }
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, b[c], acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, b[c], acc[c], 0, 0, 0);
+                for (int c = 0; c < 2; c++) b[c][u] = __builtin_bit_cast(rm_b8, gb[p][c][u]);
             }
+            if (j0 + p + PD < nit) fetch(j0 + p + PD, p);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[u], b[c][u], acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[u], b[c][u], acc[c], 0, 0, 0);
+                }
         }
     }
 #pragma unroll
@@ -278,11 +286,11 @@ __global__ void __launch_bounds__(256) kr_route_logits_fast_kernel(const uint16_
         }
     }
 }
-// non-zero = not covered (f32 gate, H not a multiple of 16): the caller keeps the exact kernel
+// non-zero = not covered (f32 gate, H not a multiple of 32): the caller keeps the exact kernel
 int kr_launch_route_logits_fast(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* logits, int T, int E, int H, hipStream_t st) {
-    if (!gate_bf16 || H % 16 || T < 1 || E < 1) return 1;
-    const dim3 grid((E + 127) / 128, (T + 63) / 64);
-    hipLaunchKernelGGL(kr_route_logits_fast_kernel, grid, dim3(256), 0, st, reinterpret_cast<const uint16_t*>(gate_row), x, bias, logits, T, E, H);
+    if (!gate_bf16 || H % 32 || T < 1 || E < 1) return 1;
+    const dim3 grid((E + 127) / 128, (T + 31) / 32);
+    hipLaunchKernelGGL(kr_route_logits_fast_kernel, grid, dim3(128), 0, st, reinterpret_cast<const uint16_t*>(gate_row), x, bias, logits, T, E, H);
     return 0;
 }
 

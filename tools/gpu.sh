@@ -116,6 +116,11 @@ r4a)        # round 4, first contact: the whole GPU suite (all failures listed),
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r04_bench_line.json 2> $R/r04_bench_line.err; echo "bench rc=$?"; tail -c 1500 $R/r04_bench_line.err
     python tools/bench_summary.py $R/r04_bench_line.json
     ;;
+pf4)        # round 4: kernel trace of the tolerance prompt pass (8192 tokens) and of the decode step
+    kstats r04_prefill_8192_attn_fast_gemm_fast "QCN prompt pass, KR_ATTN_FAST | KR_GEMM_FAST, 8192 tokens (tools/probes/prefill_profile.py 8192 2)" -- python /root/repo/tools/probes/prefill_profile.py 8192 2
+    kstats r04_decode_fast "QCN Q4 decode step, KR_DECODE_FAST, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only fast --steps 30)" -- \
+        python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r04_decode_fast_prof
+    ;;
 gguf)       # native-GGUF experts inside the decode step: parity tests, decode tok/s of the two GGUF side configurations
     timeout 900 python -m pytest tests/test_gguf_gpu.py tests/test_decode_gpu.py -q -x -k "gguf" 2>&1 | tail -4
     timeout 600 python tools/probes/gguf_decode_bench.py 30 2>&1 | grep decode
