@@ -125,6 +125,19 @@ gguf)       # native-GGUF experts inside the decode step: parity tests, decode t
     timeout 900 python -m pytest tests/test_gguf_gpu.py tests/test_decode_gpu.py -q -x -k "gguf" 2>&1 | tail -4
     timeout 600 python tools/probes/gguf_decode_bench.py 30 2>&1 | grep decode
     ;;
+r4final)    # round 4 closing run: the whole GPU suite as the driver runs it, the driver's bench line, PMC fetch pass + kernel trace of the decode step
+    # (raw rocprof directories are removed on the box once summarised: gpurun merges at most 64 MiB back)
+    timeout 1800 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -5 | tee $R/r04_gpu_tests_tail.txt
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r04_bench_line.json 2> $R/r04_bench_line.err; echo "bench rc=$?"; tail -c 400 $R/r04_bench_line.err
+    python tools/bench_summary.py $R/r04_bench_line.json
+    rm -rf $R/pmc_fast
+    (cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE -d $R/pmc_fast --output-format csv -- python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 12 --route-tokens 0 --out /root/repo/gpurun_out/r04_decode_fast_pmcrun > $R/pmc_fast.log 2>&1)
+    python tools/rocprof_csv_summary.py pmc $R/pmc_fast $R/r04_decode_fast_pmc_fetch_size.txt "QCN Q4 decode step, KR_DECODE_FAST: HBM fetch per launch (rocprofv3 --pmc FETCH_SIZE, counters-only pass; x2 = gfx950 correction)" 2>&1 | tail -2
+    head -14 $R/r04_decode_fast_pmc_fetch_size.txt
+    kstats r04_decode_fast "QCN Q4 decode step, KR_DECODE_FAST, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only fast --steps 30)" -- \
+        python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r04_decode_fast_prof
+    rm -rf $R/prof_* $R/pmc_* $R/*.log
+    ;;
 r4c)        # round 4: lean select, MLA tolerance wiring, tolerance router logits, GGUF gate fuse -- their tests, then decode / prompt-pass timings
     timeout 1200 python -m pytest tests/test_decode_fast_gpu.py tests/test_mla_gpu.py tests/test_router_gpu.py tests/test_decode_gpu.py tests/test_gemm_fast_gpu.py tests/test_tolerance_peaked_gpu.py -q -x 2>&1 | tail -6
     timeout 600 python tools/probes/decode_fast_bench.py --only fast --route-tokens 200 2>&1 | tail -8
