@@ -16,6 +16,7 @@
 //                   B = P^T straight from the S^T accumulators (f16-packed in registers): the k order of an MFMA is free as long as A and
 //                   B agree, so B uses the accumulator's own row order {0-3, 8-11} / {4-7, 12-15} and A reads V^T in two 8-byte pieces.
 // The V tile of the current 64 positions is fetched while S^T and the softmax run, the next K tile while O^T accumulates (two barriers per tile).
+#include <type_traits>
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_lds_optin.h"
@@ -31,8 +32,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifdef KR_TIMING   // tools/probes/flash_timing.hip: wall-clock stamps (10 ns units) of wave 0 of workgroup (0, 0) at one tile; no-op in the product build
 __device__ unsigned long long kr_fstamps[32];
 #define FA_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && tile == 40) kr_fstamps[i] = wall_clock64(); } while (0)
+#define FA_STAMP2(i) do { if (threadIdx.x == 256 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && tile == 40) kr_fstamps[i] = wall_clock64(); } while (0)
 #else
 #define FA_STAMP(i) do { } while (0)
+#define FA_STAMP2(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ uint32_t fa_fp8x2_to_h2(uint32_t w, bool hi) {      // two E4M3 bytes -> packed f16 pair (exact): ONE v_cvt_scalef32_pk_f16_fp8 (scale 1)
@@ -40,6 +43,12 @@ __device__ __forceinline__ uint32_t fa_fp8x2_to_h2(uint32_t w, bool hi) {      /
     const h2_t h = hi ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true) : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false);
     return __builtin_bit_cast(uint32_t, h);
 }
+
+// V^T rows in LDS hold the 64 positions of a tile as 32 dwords (position pairs).  Inside every group of 16 positions the pairs are stored in the order
+// (0-3, 8-11 | 4-7, 12-15) -- pair index bits 1 and 2 swapped -- so that the 8 positions lane half `khalf` multiplies with its P^T fragment (the S^T
+// accumulator's own row order) are ONE 16-byte read; in natural order they were two 8-byte reads whose 144-byte row stride put lanes i and i + 16 on
+// the same banks (the P.V phase ran at half the LDS rate).
+__device__ __forceinline__ int fa_vslot(int pp) { return (pp & ~6) | ((pp & 2) << 1) | ((pp & 4) >> 1); }
 
 template <int HD, bool FP8>
 __global__ void __launch_bounds__(256) kr_pfm_gqa_flash_kernel(const KrPfmGqaArgs a, int C) {
@@ -131,7 +140,7 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_flash_kernel(const KrPfmGqaArg
                 } else {
                     ha[0] = pva[j].x; ha[1] = pva[j].y; ha[2] = pva[j].z; ha[3] = pva[j].w; hb[0] = pvb[j].x; hb[1] = pvb[j].y; hb[2] = pvb[j].z; hb[3] = pvb[j].w;
                 }
-                char* base = Vt + (size_t)(dc * (FP8 ? 16 : 8)) * LDV + pp * 4;
+                char* base = Vt + (size_t)(dc * (FP8 ? 16 : 8)) * LDV + fa_vslot(pp) * 4;
 #pragma unroll
                 for (int m = 0; m < NW; m++) {            // dims 2m, 2m+1 of the chunk: {row a, row b} -> one dword each
                     *reinterpret_cast<uint32_t*>(base + (2 * m) * LDV) = __builtin_amdgcn_perm(hb[m], ha[m], 0x05040100u);
@@ -213,10 +222,8 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_flash_kernel(const KrPfmGqaArg
         for (int db = 0; db < DB; db++)
 #pragma unroll
             for (int kt = 0; kt < 4; kt++) {
-                const char* vr = Vt + (size_t)(32 * db + n31) * LDV + (16 * kt + 4 * khalf) * 2;
-                const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr), v1 = *reinterpret_cast<const u32x2*>(vr + 16);
-                const u32x4 vv = {v0.x, v0.y, v1.x, v1.y};
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, vv), pf[kt >> 1][kt & 1], oacc[db], 0, 0, 0);
+                const v8h vv = *reinterpret_cast<const v8h*>(Vt + (size_t)(32 * db + n31) * LDV + 32 * kt + 16 * khalf);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vv, pf[kt >> 1][kt & 1], oacc[db], 0, 0, 0);
                 if (kt == 3) __builtin_amdgcn_sched_barrier(0);
             }
         FA_STAMP(6);
@@ -241,205 +248,234 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_flash_kernel(const KrPfmGqaArg
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// Eight-wave form (head_dim 128 / 256): the phase probe of the four-wave kernel (tools/probes/flash_timing.hip) shows S^T 0.9 / softmax 1.1 /
-// staging 1.2 / PV 1.1 us per 64-position tile, strictly one after the other -- with 471 registers there is ONE wave per SIMD and nothing
-// overlaps the matrix core with the vector ALU.  Here the query tile lives in LDS instead of registers and the work of a tile is split over
-// wave PAIRS by position: wave (rg, ph) takes query rows [32 rg, +32) and the positions [32 ph, +32) of every tile, with its OWN online-softmax
-// state (max, sum, O) -- two independent flash streams over disjoint position subsets, merged once at the end (the split-KV merge, inside the
-// workgroup).  Half the MFMAs, half the softmax and half the registers per wave: two waves per SIMD, the one's softmax under the other's MFMAs.
+// Wave-specialised form (head_dim 128 / 256).  Round 3 ran these head sizes as eight waves that all did the same thing in lock step (query tile in LDS, wave
+// pairs splitting the positions of a tile, a split-KV merge at the end): every S^T MFMA fetched a K AND a Q fragment from LDS (2 KB per 32 x 32 x 16 MFMA),
+// the phases of a tile stood one after the other on both waves of a SIMD (staging 0.9, S^T 0.56, softmax 0.44, P.V 0.56 of 2.64 us) and V reached LDS through
+// a transposing register pass (16 conversions + 16 byte permutes + 16 four-byte LDS writes per thread and tile).  Here the two waves of a SIMD do DIFFERENT things:
+//   waves 0-3 ("S waves")   own 32 query rows each, Q^T in REGISTERS (no Q in LDS at all): S^T over the 64-position tile, the online softmax (the row
+//                           state m, l lives here only), P as f16 rows + the row's rescale factor into LDS (double-buffered); they stage K
+//   waves 4-7 ("PV waves")  own HD / 4 output dims each for ALL 128 rows (a V^T fragment serves four row blocks): O^T += V^T P^T one tile BEHIND the S
+//                           waves, so the softmax arithmetic of tile t runs under the P.V MFMAs of tile t - 1 on the same SIMD; they stage V, ROW-major like
+//                           K -- the transposed fragments come out of gfx950's LDS transpose-read (ds_read_b64_tr_b16)
+// No split-KV merge at the end: one softmax stream per row.  tools/probes/flash_timing.hip (1024 queries late in a 32 k cache, E4M3): 355 -> 449 TFLOP/s;
+// per tile S^T 0.72 | softmax 0.84 | K staging 0.40 on the S side, P.V 1.40 | V staging 0.64 on the PV side (both sides' MFMAs share the SIMD's matrix pipe
+// during the first 1.4 us; the staging between the two barriers is the part still uncovered).  Tried on the way and not kept: a 32-position tile with K, V and
+// P all double-buffered and one barrier per tile (same speed: the waves' own instruction streams, not the barriers, are the limit), S^T(t+1) issued between
+// the pieces of the softmax of tile t in the same wave (slower: the K fragment waits came to stand in front of every piece).
 // ------------------------------------------------------------------------------------------------------------------------------------
+// the value lane ^ 32 holds: one v_permlane32_swap (the ds_bpermute of __shfl_xor is an LDS round trip on the softmax's serial path)
+__device__ __forceinline__ float fa_other_half(float x, int khalf) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, khalf ? sw[0] : sw[1]);
+}
 template <int HD, bool FP8>
-__global__ void __launch_bounds__(512, 2) kr_pfm_gqa_flash8_kernel(const KrPfmGqaArgs a, int C) {
-    constexpr int KSTEPS = HD / 16, DB = HD / 32, LDK = HD * 2 + 16, LDV = FA_TK * 2 + 16;
-    constexpr int CPR = FP8 ? HD / 16 : HD / 8;                 // 16-byte global chunks per cache row
-    constexpr int KCH = FA_TK * CPR / 512;                      // K chunks per thread per tile
-    constexpr int VUN = (FA_TK / 2) * CPR, VPT = (VUN + 511) / 512;
+__global__ void __launch_bounds__(512, 2) kr_pfm_gqa_flashw_kernel(const KrPfmGqaArgs a, int C) {
+    constexpr int KSTEPS = HD / 16, DBW = HD / 128, LDK = HD * 2 + 16, LDP = FA_TK * 2 + 16;
+    constexpr int LDV = HD * 2 + 64;                            // V rows [position][dim]: 16 banks between rows, so the four rows x 64 bytes a 32-lane group of a transpose-read touches are disjoint
+    constexpr int CPR = HD / 8;                                 // staging chunks per cache row: 8 values each (8 bytes of an E4M3 row, 16 of an FP16 row) -> 16 bytes of f16 in LDS,
+    constexpr int NCH = FA_TK * CPR / 256;                      // consecutive lanes on consecutive 16-byte slots (conflict-free writes); chunks per thread and tile
     extern __shared__ __attribute__((aligned(16))) char fa_smem[];
-    char* Qs = fa_smem;                                         // [128 rows][LDK]       f16, scale and log2 e folded in
-    char* Ks = Qs + FA_ROWS * LDK;                              // [64 positions][LDK]   f16
-    char* Vt = Ks + FA_TK * LDK;                                // [HD dims][LDV]        f16, positions contiguous
+    char* Ks = fa_smem;                                         // [64 positions][LDK]   f16
+    char* Vs = Ks + FA_TK * LDK;                                // [64 positions][LDV]   f16, ROW-major like K: the P.V fragments come out of ds_read_b64_tr_b16
+    char* Ps = Vs + FA_TK * LDV;                                // [2][128 rows][LDP]    f16 probabilities of a tile, positions contiguous
+    float* Al = reinterpret_cast<float*>(Ps + 2 * FA_ROWS * LDP);      // [2][128] rescale factor of the row for the tile
+    float* Il = Al + 2 * FA_ROWS;                               // [128] 1 / l at the end
     const int G = a.nh / a.nkv, TQ = FA_ROWS / G;
-    const int kvh = blockIdx.y, t0 = blockIdx.x * TQ;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n31 = lane & 31, khalf = lane >> 5, rg = wave & 3, ph = wave >> 2;
-    const int r = rg * 32 + n31, hl = r / TQ, ti = r % TQ, tok = t0 + ti;
-    const bool row_ok = tok < C;
-    const int h = kvh * G + hl, p_q = a.pos0 + tok;
+    const int kvh = blockIdx.y, t0 = (gridDim.x - 1 - blockIdx.x) * TQ;      // longest rows first: the tail of the launch is made of short workgroups
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n31 = lane & 31, khalf = lane >> 5;
     const int kvs = a.nkv * HD, esz = FP8 ? 1 : 2;
     const int kv_end = a.pos0 + (t0 + TQ < C ? t0 + TQ : C);
     const int n_tiles = (kv_end + FA_TK - 1) / FA_TK;
     const int full_vis = a.pos0 + t0;
-    // ---- query tile -> LDS
-    {
-        const float sc = a.sm_scale * 1.4426950408889634f;
-        for (int i = tid; i < FA_ROWS * (HD / 8); i += 512) {
-            const int rr = i / (HD / 8), c8 = i % (HD / 8), hh = rr / TQ, tt = t0 + rr % TQ;
-            u32x4 o = {0, 0, 0, 0};
-            if (tt < C) {
-                const float* src = a.q_out + ((size_t)tt * a.nh + kvh * G + hh) * HD + c8 * 8;
-                const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
-                o = u32x4{__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x0.x * sc, x0.y * sc)), __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x0.z * sc, x0.w * sc)),
-                          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x1.x * sc, x1.y * sc)), __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x1.z * sc, x1.w * sc))};
-            }
-            *reinterpret_cast<u32x4*>(Qs + rr * LDK + c8 * 16) = o;
-        }
-    }
-    v16f oacc[DB];
+    // ---- staging of a K (S waves) or V (PV waves) tile by the 256 threads of a side: global -> registers (a tile ahead) -> f16 rows in LDS
+    typedef typename std::conditional<FP8, u32x2, u32x4>::type chunk_t;
+    const int stid = tid & 255, srow = stid / CPR, sdc = stid % CPR;
+    constexpr int RSTEP = 256 / CPR;
+    chunk_t stg[NCH];
+    const unsigned char* cache = reinterpret_cast<const unsigned char*>(wave < 4 ? a.k_cache : a.v_cache) + (size_t)kvh * HD * esz + sdc * (FP8 ? 8 : 16);
+    const size_t rowb = (size_t)kvs * esz;                       // bytes between cache rows (wave-uniform)
+    auto stage_load = [&](int p0, bool zero_past_end) {
+        if (p0 + FA_TK <= kv_end) {                             // whole tile inside the cache rows this workgroup may see: one 64-bit multiply per tile, then row steps
+            const unsigned char* rp = cache + (size_t)(p0 + srow) * rowb;
 #pragma unroll
-    for (int db = 0; db < DB; db++)
+            for (int j = 0; j < NCH; j++) stg[j] = *reinterpret_cast<const chunk_t*>(rp + (size_t)(RSTEP * j) * rowb);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 16; i++) oacc[db][i] = 0.0f;
-    float m_run = -__builtin_inff(), l_run = 0.0f;
-    const unsigned char* kc = reinterpret_cast<const unsigned char*>(a.k_cache) + (size_t)kvh * HD * esz;
-    const unsigned char* vc = reinterpret_cast<const unsigned char*>(a.v_cache) + (size_t)kvh * HD * esz;
-    u32x4 pk[KCH], pva[VPT], pvb[VPT];
-    auto load_k = [&](int p0) {
-#pragma unroll
-        for (int j = 0; j < KCH; j++) {
-            const int c = tid + j * 512, row = c / CPR, dc = c % CPR, p = min(p0 + row, kv_end - 1);      // rows past the end are masked below
-            pk[j] = *reinterpret_cast<const u32x4*>(kc + (size_t)p * kvs * esz + dc * 16);
-        }
-    };
-    auto load_v = [&](int p0) {
-#pragma unroll
-        for (int j = 0; j < VPT; j++) {
-            const int u = tid + j * 512, pp = u & 31, dc = u >> 5, p = p0 + 2 * pp;
-            pva[j] = u32x4{0, 0, 0, 0}; pvb[j] = u32x4{0, 0, 0, 0};
-            if (u < VUN) {
-                const u32x4 va = *reinterpret_cast<const u32x4*>(vc + (size_t)min(p, kv_end - 1) * kvs * esz + dc * 16);
-                const u32x4 vb = *reinterpret_cast<const u32x4*>(vc + (size_t)min(p + 1, kv_end - 1) * kvs * esz + dc * 16);
-                if (p < kv_end) pva[j] = va;
-                if (p + 1 < kv_end) pvb[j] = vb;
+            for (int j = 0; j < NCH; j++) {
+                const int p = p0 + srow + RSTEP * j;
+                const chunk_t v = *reinterpret_cast<const chunk_t*>(cache + (size_t)min(p, kv_end - 1) * rowb);
+                stg[j] = (zero_past_end && p >= kv_end) ? chunk_t{} : v;      // K rows past the end are masked by the causal test; V rows meet P = 0 and must be finite
             }
         }
     };
-    auto commit_k = [&]() {
+    auto stage_commit = [&](char* dst, int ld) {
 #pragma unroll
-        for (int j = 0; j < KCH; j++) {
-            const int c = tid + j * 512, row = c / CPR, dc = c % CPR;
-            if (FP8) {
-                const u32x4 w = pk[j];
-                u32x4 lo = {fa_fp8x2_to_h2(w.x, false), fa_fp8x2_to_h2(w.x, true), fa_fp8x2_to_h2(w.y, false), fa_fp8x2_to_h2(w.y, true)};
-                u32x4 hi = {fa_fp8x2_to_h2(w.z, false), fa_fp8x2_to_h2(w.z, true), fa_fp8x2_to_h2(w.w, false), fa_fp8x2_to_h2(w.w, true)};
-                *reinterpret_cast<u32x4*>(Ks + row * LDK + dc * 32) = lo; *reinterpret_cast<u32x4*>(Ks + row * LDK + dc * 32 + 16) = hi;
-            } else *reinterpret_cast<u32x4*>(Ks + row * LDK + dc * 16) = pk[j];
+        for (int j = 0; j < NCH; j++) {
+            u32x4 o;
+            if constexpr (FP8) o = u32x4{fa_fp8x2_to_h2(stg[j].x, false), fa_fp8x2_to_h2(stg[j].x, true), fa_fp8x2_to_h2(stg[j].y, false), fa_fp8x2_to_h2(stg[j].y, true)};
+            else o = stg[j];
+            *reinterpret_cast<u32x4*>(dst + (srow + RSTEP * j) * ld + sdc * 16) = o;
         }
     };
-    auto commit_v = [&]() {
+    if (wave < 4) {
+        // ================================================================ S waves
+        const int r = wave * 32 + n31, hl = r / TQ, ti = r % TQ, tok = t0 + ti;
+        const bool row_ok = tok < C;
+        const int h = kvh * G + hl, p_q = a.pos0 + tok;
+        v8h qf[KSTEPS];
+        {
+            const float* q = a.q_out + ((size_t)(row_ok ? tok : 0) * a.nh + h) * HD + 8 * khalf;
+            const float sc = a.sm_scale * 1.4426950408889634f;
 #pragma unroll
-        for (int j = 0; j < VPT; j++) {
-            const int u = tid + j * 512, pp = u & 31, dc = u >> 5;
-            if (u < VUN) {
-                uint32_t ha[8], hb[8];
-                constexpr int NW = FP8 ? 8 : 4;
-                if (FP8) {
-                    const uint32_t wa[4] = {pva[j].x, pva[j].y, pva[j].z, pva[j].w}, wb[4] = {pvb[j].x, pvb[j].y, pvb[j].z, pvb[j].w};
+            for (int ks = 0; ks < KSTEPS; ks++) {
+                const float4 x0 = *reinterpret_cast<const float4*>(q + 16 * ks), x1 = *reinterpret_cast<const float4*>(q + 16 * ks + 4);
+                const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-                    for (int m = 0; m < 4; m++) { ha[2 * m] = fa_fp8x2_to_h2(wa[m], false); ha[2 * m + 1] = fa_fp8x2_to_h2(wa[m], true);
-                                                  hb[2 * m] = fa_fp8x2_to_h2(wb[m], false); hb[2 * m + 1] = fa_fp8x2_to_h2(wb[m], true); }
-                } else {
-                    ha[0] = pva[j].x; ha[1] = pva[j].y; ha[2] = pva[j].z; ha[3] = pva[j].w; hb[0] = pvb[j].x; hb[1] = pvb[j].y; hb[2] = pvb[j].z; hb[3] = pvb[j].w;
+                for (int i = 0; i < 8; i++) qf[ks][i] = (_Float16)(row_ok ? xv[i] * sc : 0.0f);
+            }
+        }
+        float m_run = -__builtin_inff(), l_run = 0.0f;
+        const char* krow = Ks + n31 * LDK + 16 * khalf;
+        stage_load(0, false);
+        stage_commit(Ks, LDK);
+        if (n_tiles > 1) stage_load(FA_TK, false);
+        for (int tile = 0; tile <= n_tiles; tile++) {
+            FA_STAMP(0);
+            __syncthreads();                                  // X: K(tile) is in LDS (and, for the other side, V(tile - 1) and P(tile - 1))
+            FA_STAMP(1);
+            if (tile < n_tiles) {
+                const int p0 = tile * FA_TK;
+                v16f sacc[2];
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) sacc[pb][i] = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < KSTEPS; ks++)
+                        sacc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const v8h*>(krow + 32 * pb * LDK + 32 * ks), qf[ks], sacc[pb], 0, 0, 0);
                 }
-                char* base = Vt + (size_t)(dc * (FP8 ? 16 : 8)) * LDV + pp * 4;
+                FA_STAMP(2);
+                const bool need_mask = p0 + FA_TK - 1 > full_vis || p0 + FA_TK > kv_end;
+                float mloc = -__builtin_inff();
 #pragma unroll
-                for (int m = 0; m < NW; m++) {
-                    *reinterpret_cast<uint32_t*>(base + (2 * m) * LDV) = __builtin_amdgcn_perm(hb[m], ha[m], 0x05040100u);
-                    *reinterpret_cast<uint32_t*>(base + (2 * m + 1) * LDV) = __builtin_amdgcn_perm(hb[m], ha[m], 0x07060302u);
-                }
+                for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        if (need_mask) { const int p = p0 + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * khalf; if (p > p_q || !row_ok) sacc[pb][i] = -__builtin_inff(); }
+                        mloc = fmaxf(mloc, sacc[pb][i]);
+                    }
+                mloc = fmaxf(mloc, fa_other_half(mloc, khalf));
+                const float m_new = fmaxf(m_run, mloc);
+                const float m_use = m_new == -__builtin_inff() ? 0.0f : m_new;                   // nothing visible yet: exp2(-inf - 0) = 0 everywhere
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);                        // m_run = -inf -> 0
+                float lsum = 0.0f;
+                char* prow = Ps + (size_t)(tile & 1) * FA_ROWS * LDP + (size_t)r * LDP + 8 * khalf;
+#pragma unroll
+                for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; g4++) {      // accumulator rows 4 g4 .. + 3 = positions 32 pb + 8 g4 + 4 khalf .. + 3: one 8-byte store
+                        float pv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { pv[u] = __builtin_amdgcn_exp2f(sacc[pb][4 * g4 + u] - m_use); lsum += pv[u]; }
+                        const u32x2 w = {__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pv[0], pv[1])), __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pv[2], pv[3]))};
+                        *reinterpret_cast<u32x2*>(prow + (32 * pb + 8 * g4) * 2) = w;
+                    }
+                lsum += fa_other_half(lsum, khalf);
+                l_run = l_run * alpha + lsum;
+                m_run = m_new;
+                if (khalf == 0) Al[(tile & 1) * FA_ROWS + r] = alpha;
+                FA_STAMP(3);
             }
+            __syncthreads();                                  // Y: every S wave is past its K reads
+            FA_STAMP(4);
+            if (tile + 1 < n_tiles) { stage_commit(Ks, LDK); if (tile + 2 < n_tiles) stage_load((tile + 2) * FA_TK, false); }
+            FA_STAMP(5);
         }
-    };
-    load_k(0); load_v(0);
-    for (int tile = 0; tile < n_tiles; tile++) {
-        const int p0 = tile * FA_TK;
-        commit_k();
-        if (tile + 1 < n_tiles) load_k(p0 + FA_TK);
-        __syncthreads();                                  // K tile (and, in the first round, the query tile) is complete
-        // ---- S^T of this wave's 32 positions
-        v16f sacc;
-#pragma unroll
-        for (int i = 0; i < 16; i++) sacc[i] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ks++) {
-            const v8h kf = *reinterpret_cast<const v8h*>(Ks + (32 * ph + n31) * LDK + (16 * ks + 8 * khalf) * 2);
-            const v8h qf = *reinterpret_cast<const v8h*>(Qs + r * LDK + (16 * ks + 8 * khalf) * 2);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, sacc, 0, 0, 0);
-        }
-        const bool need_mask = p0 + FA_TK - 1 > full_vis || p0 + FA_TK > kv_end;
-        float mloc = -__builtin_inff();
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            if (need_mask) { const int p = p0 + 32 * ph + (i & 3) + 8 * (i >> 2) + 4 * khalf; if (p > p_q || !row_ok) sacc[i] = -__builtin_inff(); }
-            mloc = fmaxf(mloc, sacc[i]);
-        }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);
-        const float m_use = m_new == -__builtin_inff() ? 0.0f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        float lsum = 0.0f;
-        v8h pf[2];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const float pv = __builtin_amdgcn_exp2f(sacc[i] - m_use);
-            lsum += pv;
-            pf[i >> 3][i & 7] = (_Float16)pv;
-        }
-        lsum += __shfl_xor(lsum, 32);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-        if (__any(alpha != 1.0f)) {
-#pragma unroll
-            for (int db = 0; db < DB; db++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) oacc[db][i] *= alpha;
-        }
-        commit_v();
-        if (tile + 1 < n_tiles) load_v(p0 + FA_TK);
+        if (khalf == 0) Il[r] = l_run > 0.0f ? 1.0f / l_run : 0.0f;
         __syncthreads();
-        // ---- O^T += V^T P^T over this wave's 32 positions
+    } else {
+        // ================================================================ PV waves
+        const int pw = wave - 4;
+        v16f oacc[4][DBW];
 #pragma unroll
-        for (int db = 0; db < DB; db++)
+        for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-            for (int kt = 0; kt < 2; kt++) {
-                const char* vr = Vt + (size_t)(32 * db + n31) * LDV + (32 * ph + 16 * kt + 4 * khalf) * 2;
-                const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr), v1 = *reinterpret_cast<const u32x2*>(vr + 16);
-                const u32x4 vv = {v0.x, v0.y, v1.x, v1.y};
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, vv), pf[kt], oacc[db], 0, 0, 0);
-            }
-    }
-    // ---- merge the two position streams of a row group: the ph = 1 waves hand (m, l, O) over through LDS (everything staged there is dead now)
-    __syncthreads();
-    float* Ox = reinterpret_cast<float*>(fa_smem);              // [4 row groups][HD dims][32 rows] f32 + [4][2][32] (m, l)   (HD = 256: 128 KiB + 1 KiB)
-    float* MLx = Ox + 4 * HD * 32;
-    if (ph == 1) {
+            for (int db = 0; db < DBW; db++)
 #pragma unroll
-        for (int db = 0; db < DB; db++)
+                for (int i = 0; i < 16; i++) oacc[rb][db][i] = 0.0f;
+        // V is staged exactly like K (f16 rows in LDS).  The A operand of O^T += V^T P^T wants, per lane, 8 POSITIONS of one dim -- a column of this image;
+        // gfx950's LDS transpose-read delivers it: within a 16-lane group, lane i receives element (i & 3) of the 8 bytes addressed by lanes (i >> 2) + 4 j,
+        // j = 0..3.  So lane s = 4 j + c of a group points at row (position) j, dims 4 c .. 4 c + 3 of the group's 16 dims, and lane i ends up with dim i
+        // of positions 0..3: two reads (positions +0..3, +4..7) make one MFMA fragment.  (The transposing register pass of the eight-wave kernel -- 16
+        // conversions + 16 byte permutes + 16 four-byte LDS writes per thread and tile -- was the longest phase of a tile.)
+        typedef __fp16 fa_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+        const int tr_off = (8 * khalf + ((lane & 15) >> 2)) * LDV + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;      // this lane's source row / dim quad inside a (16-position, 32-dim) block
+        stage_load(0, true);
+        for (int tile = 0; tile <= n_tiles; tile++) {
+            FA_STAMP2(8);
+            __syncthreads();                                  // X: V(tile - 1) and P(tile - 1) are in LDS
+            FA_STAMP2(9);
+            if (tile >= 1) {
+                const char* pb_ = Ps + (size_t)((tile - 1) & 1) * FA_ROWS * LDP;
+                const float* al = Al + ((tile - 1) & 1) * FA_ROWS;
+                float av[4];
 #pragma unroll
-            for (int i = 0; i < 16; i++) Ox[((size_t)rg * HD + 32 * db + (i & 3) + 8 * (i >> 2) + 4 * khalf) * 32 + n31] = oacc[db][i];
-        if (khalf == 0) { MLx[(rg * 2 + 0) * 32 + n31] = m_run; MLx[(rg * 2 + 1) * 32 + n31] = l_run; }
-    }
-    __syncthreads();
-    if (ph == 0 && row_ok) {
-        const float m1 = MLx[(rg * 2 + 0) * 32 + n31], l1 = MLx[(rg * 2 + 1) * 32 + n31];
-        const float M = fmaxf(m_run, m1), Mu = M == -__builtin_inff() ? 0.0f : M;
-        const float w0 = __builtin_amdgcn_exp2f(m_run - Mu), w1 = __builtin_amdgcn_exp2f(m1 - Mu);
-        const float lt = l_run * w0 + l1 * w1;
-        const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
-        const size_t ob = ((size_t)tok * a.nh + h) * HD;
+                for (int rb = 0; rb < 4; rb++) av[rb] = al[32 * rb + n31];
+                if (__any(av[0] != 1.0f || av[1] != 1.0f || av[2] != 1.0f || av[3] != 1.0f)) {
 #pragma unroll
-        for (int db = 0; db < DB; db++)
+                    for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                const int d = 32 * db + 8 * g4 + 4 * khalf;
-                float o4[4];
+                        for (int db = 0; db < DBW; db++)
 #pragma unroll
-                for (int u = 0; u < 4; u++) o4[u] = (oacc[db][4 * g4 + u] * w0 + Ox[((size_t)rg * HD + d + u) * 32 + n31] * w1) * inv;
-                float4 o = make_float4(o4[0], o4[1], o4[2], o4[3]);
-                if (a.gated) {
-                    const float4 gt = *reinterpret_cast<const float4*>(a.gate + ob + d);
-                    o.x *= 1.0f / (1.0f + kr_expf(-gt.x)); o.y *= 1.0f / (1.0f + kr_expf(-gt.y)); o.z *= 1.0f / (1.0f + kr_expf(-gt.z)); o.w *= 1.0f / (1.0f + kr_expf(-gt.w));
+                            for (int i = 0; i < 16; i++) oacc[rb][db][i] *= av[rb];
                 }
-                *reinterpret_cast<float4*>(a.attn_out + ob + d) = o;
+#pragma unroll
+                for (int kt = 0; kt < 4; kt++) {
+                    v8h vf[DBW], pf[4];
+#pragma unroll
+                    for (int db = 0; db < DBW; db++) {
+                        const char* va = Vs + (size_t)(16 * kt) * LDV + 32 * (pw * DBW + db) * 2 + tr_off;
+                        const fa_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fa_h4*)(va));
+                        const fa_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fa_h4*)(va + 4 * LDV));
+                        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                        vf[db] = __builtin_bit_cast(v8h, u32x4{l2.x, l2.y, h2.x, h2.y});
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < 4; rb++) pf[rb] = *reinterpret_cast<const v8h*>(pb_ + (size_t)(32 * rb + n31) * LDP + (16 * kt + 8 * khalf) * 2);
+#pragma unroll
+                    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                        for (int db = 0; db < DBW; db++) oacc[rb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[db], pf[rb], oacc[rb][db], 0, 0, 0);
+                }
             }
+            FA_STAMP2(11);
+            __syncthreads();                                  // Y: every PV wave is past its V reads
+            FA_STAMP2(12);
+            if (tile < n_tiles) { stage_commit(Vs, LDV); if (tile + 1 < n_tiles) stage_load((tile + 1) * FA_TK, true); }
+            FA_STAMP2(13);
+        }
+        __syncthreads();                                      // 1 / l of every row is in LDS
+        // ---- normalise, gate (attention.py:664-666 / decode.rs:4272-4280), store: accumulator rows 4 g .. 4 g + 3 are dims 32 (pw DBW + db) + 8 g + 4 khalf + 0..3
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            const int r = 32 * rb + n31, hl = r / TQ, ti = r % TQ, tok = t0 + ti;
+            if (tok >= C) continue;
+            const float inv = Il[r];
+            const size_t ob = ((size_t)tok * a.nh + kvh * G + hl) * HD;
+#pragma unroll
+            for (int db = 0; db < DBW; db++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int d = 32 * (pw * DBW + db) + 8 * g4 + 4 * khalf;
+                    float4 o = make_float4(oacc[rb][db][4 * g4] * inv, oacc[rb][db][4 * g4 + 1] * inv, oacc[rb][db][4 * g4 + 2] * inv, oacc[rb][db][4 * g4 + 3] * inv);
+                    if (a.gated) {
+                        const float4 gt = *reinterpret_cast<const float4*>(a.gate + ob + d);
+                        o.x *= 1.0f / (1.0f + kr_expf(-gt.x)); o.y *= 1.0f / (1.0f + kr_expf(-gt.y)); o.z *= 1.0f / (1.0f + kr_expf(-gt.z)); o.w *= 1.0f / (1.0f + kr_expf(-gt.w));
+                    }
+                    *reinterpret_cast<float4*>(a.attn_out + ob + d) = o;
+                }
+        }
     }
 }
 
@@ -454,20 +490,18 @@ int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st) {
     if (!kr_pfm_gqa_flash_ok(a.nh, a.nkv, a.hd)) return 1;
     const int TQ = FA_ROWS / G;
     dim3 grid((C + TQ - 1) / TQ, a.nkv);
-    if (a.hd >= 128) {      // eight waves, query tile in LDS, wave pairs split the positions of a tile (the four-wave form at these head sizes needed 512 registers + scratch: removed)
-        const size_t l8 = (size_t)(FA_ROWS + FA_TK) * (a.hd * 2 + 16) + (size_t)a.hd * (FA_TK * 2 + 16);
-        const size_t lm = (size_t)(4 * a.hd * 32 + 4 * 2 * 32) * 4;
-        const size_t lds8 = l8 > lm ? l8 : lm;
-        const void* fn8 = a.hd == 256 ? (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash8_kernel<256, true> : (const void*)kr_pfm_gqa_flash8_kernel<256, false>)
-                                      : (a.kv_fp8 ? (const void*)kr_pfm_gqa_flash8_kernel<128, true> : (const void*)kr_pfm_gqa_flash8_kernel<128, false>);
-        if (lds8 <= 160 * 1024 && kr_lds_optin(fn8, lds8) == 0) {
-#define KR_FA8(H_, F_) hipLaunchKernelGGL((kr_pfm_gqa_flash8_kernel<H_, F_>), grid, dim3(512), lds8, st, a, C)
-            if (a.hd == 256) { if (a.kv_fp8) KR_FA8(256, true); else KR_FA8(256, false); }
-            else { if (a.kv_fp8) KR_FA8(128, true); else KR_FA8(128, false); }
-#undef KR_FA8
+    if (a.hd >= 128) {      // wave-specialised form (S waves / PV waves)
+        const size_t ldw = (size_t)FA_TK * (a.hd * 2 + 16) + (size_t)FA_TK * (a.hd * 2 + 64) + 2 * (size_t)FA_ROWS * (FA_TK * 2 + 16) + 3 * FA_ROWS * 4;
+        const void* fnw = a.hd == 256 ? (a.kv_fp8 ? (const void*)kr_pfm_gqa_flashw_kernel<256, true> : (const void*)kr_pfm_gqa_flashw_kernel<256, false>)
+                                      : (a.kv_fp8 ? (const void*)kr_pfm_gqa_flashw_kernel<128, true> : (const void*)kr_pfm_gqa_flashw_kernel<128, false>);
+        if (kr_lds_optin(fnw, ldw) == 0) {
+#define KR_FAW(H_, F_) hipLaunchKernelGGL((kr_pfm_gqa_flashw_kernel<H_, F_>), grid, dim3(512), ldw, st, a, C)
+            if (a.hd == 256) { if (a.kv_fp8) KR_FAW(256, true); else KR_FAW(256, false); }
+            else { if (a.kv_fp8) KR_FAW(128, true); else KR_FAW(128, false); }
+#undef KR_FAW
             return 0;
         }
-        return 1;           // LDS window refused: the caller takes the exact passes
+        return 1;           // LDS window refused: the caller reports it
     }
     const size_t lds = (size_t)FA_TK * (a.hd * 2 + 16) + (size_t)a.hd * (FA_TK * 2 + 16);
     {
@@ -574,7 +608,7 @@ __global__ void __launch_bounds__(256) kr_fd_flash_kernel(const KrFdFlashArgs a,
                 } else {
                     ha[0] = pva[j].x; ha[1] = pva[j].y; ha[2] = pva[j].z; ha[3] = pva[j].w; hb[0] = pvb[j].x; hb[1] = pvb[j].y; hb[2] = pvb[j].z; hb[3] = pvb[j].w;
                 }
-                char* base = Vt + (size_t)(dc * (FP8 ? 16 : 8)) * LDV + pp * 4;
+                char* base = Vt + (size_t)(dc * (FP8 ? 16 : 8)) * LDV + fa_vslot(pp) * 4;
 #pragma unroll
                 for (int m = 0; m < NW; m++) {
                     *reinterpret_cast<uint32_t*>(base + (2 * m) * LDV) = __builtin_amdgcn_perm(hb[m], ha[m], 0x05040100u);
@@ -640,10 +674,8 @@ __global__ void __launch_bounds__(256) kr_fd_flash_kernel(const KrFdFlashArgs a,
             for (int db = 0; db < DBW; db++)
 #pragma unroll
                 for (int kt = 0; kt < 4; kt++) {
-                    const char* vr = Vt + (size_t)(32 * (wave * DBW + db) + n31) * LDV + (16 * kt + 4 * khalf) * 2;
-                    const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr), v1 = *reinterpret_cast<const u32x2*>(vr + 16);
-                    const u32x4 vv = {v0.x, v0.y, v1.x, v1.y};
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, vv), pf[kt >> 1][kt & 1], oacc[db], 0, 0, 0);
+                    const v8h vv = *reinterpret_cast<const v8h*>(Vt + (size_t)(32 * (wave * DBW + db) + n31) * LDV + 32 * kt + 16 * khalf);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vv, pf[kt >> 1][kt & 1], oacc[db], 0, 0, 0);
                 }
         }
     }

@@ -37,11 +37,13 @@ Act X(const Scratch& B) { return Act{B.xh, B.xl, B.xs, B.xf, B.xfm}; }
 Act Y(const Scratch& B) { return Act{B.yh, B.yl, B.ys, B.yf, B.yfm}; }
 struct Chunk {      // one chunk of the prompt in flight: its arena, stream and running flags
     Scratch B; float* scores; const int* tok; int Cc, pos0, set; bool first, add_is_emb; hipStream_t st;
+    KrPfSync sy;      // this (chunk, layer)'s hand-overs with the previous / next chunk (set by the scheduler before every run_layer)
 };
 size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
 }  // namespace
 
 static int pf_gemm(kr_decode_store* s, int wid, const Act& A, int C, float* out, int ld, hipStream_t st) {
+    if (KR_AB_ON(512)) return KR_OK;
     DWeight& W = *s->weights[wid];
     if (s->gemm_fast) { kr_launch_pfh_gemm(W.ms.view(), A.f, A.fm, nullptr, 1, 0, 0, C, out, ld, st); return KR_OK; }
     if (!W.ms.wsum.p) return kr_fail(KR_ERR_STATE, "internal: nibble sums of weight %d were not prepared", wid);
@@ -51,6 +53,7 @@ static int pf_gemm(kr_decode_store* s, int wid, const Act& A, int C, float* out,
 // up to three projections of the same input in ONE launch (q | k | v, qkvz | ba, shared gate_up | shared gate); falls back to one launch each
 // when the weight widths or K differ
 static int pf_gemm_multi(kr_decode_store* s, const int* wids, float* const* outs, const int* lds, int n, const Act& A, int C, hipStream_t st) {
+    if (KR_AB_ON(512)) return KR_OK;
     KrMatDev mats[3]; const uint32_t* ws[3];
     bool same = n <= 3;
     for (int i = 0; i < n; i++) {
@@ -88,7 +91,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
     na.w = (const float*)s->norms[L.input_norm]->p; na.out = B.normed; na.xh = B.xh; na.xl = B.xl; na.xs = B.xs; na.H = H; na.first = cx.first ? 1 : 0;
     na.bias_one = s->norm_bias_one; na.eps = s->eps;
     if (s->gemm_fast) { na.xh = nullptr; na.xl = nullptr; na.xs = nullptr; }      // tolerance GEMMs take f16 rows of the normalised value instead of the digits
-    kr_launch_pfm_norm(na, Cc, st);
+    KR_AB(64, kr_launch_pfm_norm(na, Cc, st));
     if (s->gemm_fast) kr_launch_pfh_rows_f32(B.normed, Cc, H, H, B.xf, B.xfm, st);
     cx.first = false; cx.add_is_emb = false;
     if (L.attn == ATTN_LA) {
@@ -100,7 +103,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale; a.q = B.q; a.k = B.k; a.v = B.v; a.z = B.z;
         a.gexp = B.gexp; a.beta = B.beta; a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
         a.lac = B.lac; a.fast = s->attn_fast;
-        if (kr_launch_pfm_la(a, (float*)L.recur_state.p, B.recur, (const float*)L.la_norm_w.p, B.attn, Cc, s->eps, st))
+        if (kr_launch_pfm_la(a, (float*)L.recur_state.p, B.recur, (const float*)L.la_norm_w.p, B.attn, Cc, s->eps, st, &cx.sy))
             return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
         if (oc != L.nv * L.dv) return kr_fail(KR_ERR_VALUE, "out_proj cols %d != nv*dv", oc);
         pf_rows(s, B.attn, Cc, oc, oc, B, true, st);
@@ -121,7 +124,8 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         bool flash = false, flash_tried = false;
         if (s->attn_fast && kr_pfm_gqa_flash_ok(L.nh, L.nkv, L.hd)) {      // tolerance mode: flash attention on the matrix cores (same prep launch)
             kr_launch_pfm_gqa_prep(a, Cc, st);
-            flash = 0 == kr_launch_pfm_gqa_flash(a, Cc, st);
+            kr_pf_wait(st, cx.sy.wait_b); kr_pf_rec(st, cx.sy.rec_b);      // own rows appended; the previous chunks' rows are read from here on
+            flash = true; KR_AB(128, flash = 0 == kr_launch_pfm_gqa_flash(a, Cc, st));
             flash_tried = true;
         }
         if (!flash) {
@@ -129,7 +133,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
             if (!cx.scores) return kr_fail(KR_ERR_STATE, "internal: no score scratch for the exact attention passes");
             const int sc_ld = (pos0 + Cc + 63) & ~63;
             float* scp = cx.scores;   // this chunk's arena (chunks in flight on other streams have their own)
-            if (kr_launch_pfm_gqa(a, Cc, scp, sc_ld, scp + (size_t)Cc * L.nh * sc_ld, st)) return kr_fail(KR_ERR_VALUE, "unsupported GQA geometry for the prompt pass");
+            if (kr_launch_pfm_gqa(a, Cc, scp, sc_ld, scp + (size_t)Cc * L.nh * sc_ld, st, &cx.sy)) return kr_fail(KR_ERR_VALUE, "unsupported GQA geometry for the prompt pass");
         }
         if (oc != L.nh * L.hd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*hd", oc);
         pf_rows(s, B.attn, Cc, oc, oc, B, true, st);
@@ -159,14 +163,16 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.ckv_cache = L.kv_k.p; a.kpe_cache = L.kv_v.p; a.kv_fp8 = s->kv_fp8; a.q_abs = B.q; a.q_pe = B.z; a.attn_lat = B.recur; a.v_proj = B.attn;
         a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale; a.fast = s->attn_fast;
         if (!s->attn_fast && cx.scores) { a.pf_sc = cx.scores; a.pf_sc_ld = (pos0 + Cc + 63) & ~63; }      // exact mode: this chunk's score scratch for the matrix-core passes
+        kr_pf_wait(st, cx.sy.wait_b);            // the latent / rope rows of the earlier chunks (the three MLA launches append and read in one go)
         kr_launch_mla(a, s->kv_max_seq, st, Cc);
+        kr_pf_rec(st, cx.sy.rec_b);
         if (oc != L.nh * L.vhd) return kr_fail(KR_ERR_VALUE, "o_proj cols %d != nh*v_head_dim", oc);
         pf_rows(s, B.attn, Cc, oc, oc, B, true, st);
         if (int rc = pf_gemm(s, L.o_wid, Y(B), Cc, B.hid, H, st)) return rc;
     }
     // ---- post-attention norm: f32 hidden, digits (shared expert / dense MLP), bf16 copy (routed experts)
     na.mode = 0; na.add_in = B.hid; na.first = 0; na.w = (const float*)s->norms[L.post_norm]->p; na.out_bf16 = L.mlp == MLP_MOE ? B.xb : nullptr;
-    kr_launch_pfm_norm(na, Cc, st);
+    KR_AB(64, kr_launch_pfm_norm(na, Cc, st));
     if (s->gemm_fast && (L.mlp == MLP_DENSE || (L.mlp == MLP_MOE && L.sgu_wid >= 0))) kr_launch_pfh_rows_f32(B.normed, Cc, H, H, B.xf, B.xfm, st);
     if (L.mlp == MLP_MOE) {
         Layer& EL = e->layers[L.moe_layer];
@@ -175,15 +181,16 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         const int E = e->r_ne;
         const float* rbias = EL.has_bias ? (const float*)EL.bias.p : nullptr;
         // KR_GEMM_FAST: the router's logits in the tolerance form too (bf16 MFMA on x = hi + lo; its input already carries the mode's f16 operand rounding)
-        if (!(s->gemm_fast && Cc >= 32 && EL.gate_row.p && 0 == kr_launch_route_logits_fast(EL.gate_row.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st)))
+        if (!(s->gemm_fast && Cc >= 32 && EL.gate_row.p && 0 == (KR_AB_ON(16) ? 0 : kr_launch_route_logits_fast(EL.gate_row.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st))))
         if (!(Cc >= 32 && EL.gate_row.p && 0 == kr_launch_route_logits_mfma(EL.gate_row.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st)))
             kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st);
-        kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
+        KR_AB(32, kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st));
         // routed experts: exact CPU-engine arithmetic on the matrix cores, f32 weighted sum in routing order
         // expert parallelism (kr_ep_init on the engine): this rank's chunk exchanges its (token, slot) rows with the owners over RCCL.  A collective:
         // prefill_impl pads ranks that have fewer chunks with empty-shard calls.  Every chunk in flight has its own exchange-buffer set (cx.set) and stream; the
         // collectives of all chunks are ISSUED in one host order that is the same on every rank (the loop structure below depends only on the agreed chunk count).
         if (e->ep) { if (int rc = kr_moe_prefill_ep_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set, st ? (void*)st : (void*)1)) return rc; }
+        else if (KR_AB_ON(256)) {}
         else if (int rc = kr_moe_prefill_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set | (s->gemm_fast ? KR_PF_SET_FAST : 0), st)) return rc;
         const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
         if (has_shared) {   // decode-store numerics: f32 input digits, fast_silu_mul + f32::round digits (decode.rs:3356-3378)
@@ -356,13 +363,16 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
         return B;
     };
 
-    // ---- streams: chunk c runs on stream c % 2 with arena c % 2.  Cell (chunk c, layer l) needs (c, l-1) [same stream] and (c-1, l)
-    // [other stream: recurrent / conv state and the KV cache of layer l] -> one event per (parity, layer).  The serial, low-occupancy
-    // kernels of one chunk (gated-delta-rule recurrence, softmax sums, router top-k) overlap with the GEMMs and attention passes of
-    // its neighbour, which is one layer behind.
+    // ---- streams: chunk c runs on stream c % D with arena c % D.  Cell (chunk c, layer l) needs (c, l-1) [same stream] and, from (c-1, l) on another
+    // stream, exactly two things: the carried conv slots before its conv launch, and the recurrent state before its scan (linear attention) or the
+    // appended KV / latent rows before its attention launch -> two events per (arena, layer), waited for AT THOSE LAUNCHES (KrPfSync), not at the top of the
+    // layer.  (Round 3 recorded one event at the END of a layer and waited for it at the start of the next chunk's layer: the kernel trace showed the state
+    // scan of a chunk running alone for 62 % of its time -- 8.5 % of the wall clock -- with both neighbours parked behind whole-layer waits, and two kernels
+    // in flight 78 % of the time at a depth of three.)  The serial, low-occupancy kernels of one chunk (delta-rule scan, softmax sums, router top-k) overlap
+    // with the GEMMs and attention passes of its neighbours.
     hipStream_t streams[KR_PF_MAX_DEPTH];
     for (auto& x : streams) x = st;
-    const size_t ev_start = (size_t)D * L, ev_end = ev_start + 1;     // + one end event per side stream
+    const size_t ev_start = (size_t)2 * D * L, ev_end = ev_start + 1;     // [arena][layer][a | b], + one start event, + one end event per side stream
     if (D > 1) {
         while ((int)s->pf_side.size() < D - 1) { hipStream_t ns; KR_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking)); s->pf_side.push_back(ns); }
         for (int i = 1; i < D; i++) streams[i] = s->pf_side[i - 1];
@@ -398,9 +408,13 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
                     continue;
                 }
                 Chunk& cx = chunks[c];
-                if (c > 0 && D > 1) KR_HIP(hipStreamWaitEvent(cx.st, s->pf_events[(size_t)((c - 1) % D) * L + l], 0));
+                cx.sy = KrPfSync{};
+                if (D > 1) {
+                    hipEvent_t* own = &s->pf_events[((size_t)(c % D) * L + l) * 2];
+                    cx.sy.rec_a = own[0]; cx.sy.rec_b = own[1];
+                    if (c > 0) { hipEvent_t* prev = &s->pf_events[((size_t)((c - 1) % D) * L + l) * 2]; cx.sy.wait_a = prev[0]; cx.sy.wait_b = prev[1]; }
+                }
                 if (int rc = run_layer(s, cx, (size_t)l)) return rc;
-                if (D > 1) KR_HIP(hipEventRecord(s->pf_events[(size_t)(c % D) * L + l], cx.st));
                 if (nll_out && l == L - 1)
                     if (int rc = run_final_all(s, cx, (float*)((char*)s->pf_vlogits.p + (size_t)cx.set * vl_bytes), c * CH, n_tokens, c == n_chunks - 1)) return rc;
             }

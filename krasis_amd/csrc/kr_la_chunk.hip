@@ -108,7 +108,9 @@ __device__ __forceinline__ void lc_blk_s(v16f& acc, const float* A, int lda, con
 }
 __device__ __forceinline__ int lc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }   // accumulator register r -> block row
 
-__global__ void __launch_bounds__(256) kr_lac_prep_kernel(KrLacArgs a) {
+#define LC_PTH 512     // threads of a prep workgroup: its LDS (134 KB) allows one per CU, so the workgroup itself brings the second wave per SIMD that overlaps
+                       // the split arithmetic of one wave with the LDS / MFMA latency of another (256 threads: 24.7 us per workgroup, 512: see lac_timing)
+__global__ void __launch_bounds__(LC_PTH) kr_lac_prep_kernel(KrLacArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Kt = lds; float* Qt = Kt + LC_T * LC_LD; float* Vt = Qt + LC_T * LC_LD; float* Lm = Vt + LC_T * LC_LD; float* Bm = Lm + LC_T * LC_LS;
     float* Gs = Bm + LC_T * LC_LS; float* bs = Gs + LC_T; float* bg = bs + LC_T;
@@ -117,7 +119,7 @@ __global__ void __launch_bounds__(256) kr_lac_prep_kernel(KrLacArgs a) {
     const size_t ld = (size_t)a.nv * LC_D, tile = ((size_t)sub * a.nv + h) * LC_T;
     LC_STAMP(0);
     // ---- tiles (rows past the chunk end are zero: b = 0, g = 0 make them inert)
-    for (int u = tid; u < LC_T * 32; u += 256) {
+    for (int u = tid; u < LC_T * 32; u += LC_PTH) {
         const int t = u >> 5, c4 = (u & 31) * 4;
         float4 kk = make_float4(0, 0, 0, 0), qq = kk, vv = kk;
         if (t < n) {
@@ -137,12 +139,12 @@ __global__ void __launch_bounds__(256) kr_lac_prep_kernel(KrLacArgs a) {
     }
     __syncthreads();
     LC_STAMP(1);
-    // ---- K^T for the scan, split into bf16 planes [d][t] (the solve below overwrites the K tile with W): thread = (d, half of the tokens)
+    // ---- K^T for the scan, split into bf16 planes [d][t] (the solve below overwrites the K tile with W): thread = (d, a quarter of the tokens)
     {
-        const int d = tid & (LC_D - 1), tb = (tid >> 7) * 32;
-        uint32_t hw[16], lw[16];
+        const int d = tid & (LC_D - 1), tb = (tid >> 7) * 16;
+        uint32_t hw[8], lw[8];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < 8; i++) {
             uint16_t h0, l0, h1, l1;
             lc_split(Kt[(tb + 2 * i) * LC_LD + d], h0, l0); lc_split(Kt[(tb + 2 * i + 1) * LC_LD + d], h1, l1);
             hw[i] = (uint32_t)h0 | ((uint32_t)h1 << 16); lw[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
@@ -150,96 +152,124 @@ __global__ void __launch_bounds__(256) kr_lac_prep_kernel(KrLacArgs a) {
         lc_u4* kh = reinterpret_cast<lc_u4*>(a.Kh + (tile * LC_D + (size_t)d * LC_T + tb));      // tile * LC_D = first element of this tile's [128][64] plane
         lc_u4* kl = reinterpret_cast<lc_u4*>(a.Kl + (tile * LC_D + (size_t)d * LC_T + tb));
 #pragma unroll
-        for (int i = 0; i < 4; i++) { kh[i] = lc_u4{hw[4 * i], hw[4 * i + 1], hw[4 * i + 2], hw[4 * i + 3]}; kl[i] = lc_u4{lw[4 * i], lw[4 * i + 1], lw[4 * i + 2], lw[4 * i + 3]}; }
+        for (int i = 0; i < 2; i++) { kh[i] = lc_u4{hw[4 * i], hw[4 * i + 1], hw[4 * i + 2], hw[4 * i + 3]}; kl[i] = lc_u4{lw[4 * i], lw[4 * i + 1], lw[4 * i + 2], lw[4 * i + 3]}; }
     }
     // ---- K K^T -> L (strictly lower, decayed, row-scaled by b) and Q K^T -> B (lower incl. diagonal, decayed); the (0,1) blocks are zero
-    if (wave < 3) {
-        v16f acc0, acc1;
+    if (wave < 6) {
+        // one 32 x 32 block per wave: waves 0-2 L(0,0), L(1,1), L(1,0); waves 3-5 B(0,0), B(1,1), B(1,0)
+        const bool isL = wave < 3;
+        const int wb = wave % 3, rb = wb == 0 ? 0 : 1, cb = wb == 1 ? 1 : 0;
+        v16f acc;
 #pragma unroll
-        for (int i = 0; i < 16; i++) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-        // wave 0: L(0,0), L(1,1);  wave 1: B(0,0), B(1,1);  wave 2: L(1,0), B(1,0)
-        const float* A0 = wave == 1 ? Qt : Kt; const float* A1 = wave == 0 ? Kt : Qt;
-        const int rb0 = wave == 2 ? 1 : 0, cb0 = 0, rb1 = 1, cb1 = wave == 2 ? 0 : 1;
-        lc_blk_s<true, true, LC_D>(acc0, A0 + rb0 * 32 * LC_LD, LC_LD, Kt + cb0 * 32 * LC_LD, LC_LD, lane);
-        lc_blk_s<true, true, LC_D>(acc1, A1 + rb1 * 32 * LC_LD, LC_LD, Kt + cb1 * 32 * LC_LD, LC_LD, lane);
-        const bool l0 = wave != 1, l1 = wave == 0;   // which result is an L block (else a B block)
+        for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+        lc_blk_s<true, true, LC_D>(acc, (isL ? Kt : Qt) + rb * 32 * LC_LD, LC_LD, Kt + cb * 32 * LC_LD, LC_LD, lane);
+        float* M = isL ? Lm : Bm;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            { const int row = rb0 * 32 + lc_row(r, lane), col = cb0 * 32 + (lane & 31);
-              const float d = lc_exp(Gs[row] - Gs[col]) * acc0[r];
-              if (l0) Lm[row * LC_LS + col] = col < row ? bs[row] * d : 0.0f; else Bm[row * LC_LS + col] = col <= row ? d : 0.0f; }
-            { const int row = rb1 * 32 + lc_row(r, lane), col = cb1 * 32 + (lane & 31);
-              const float d = lc_exp(Gs[row] - Gs[col]) * acc1[r];
-              if (l1) Lm[row * LC_LS + col] = col < row ? bs[row] * d : 0.0f; else Bm[row * LC_LS + col] = col <= row ? d : 0.0f; }
+            const int row = rb * 32 + lc_row(r, lane), col = cb * 32 + (lane & 31);
+            const float d = lc_exp(Gs[row] - Gs[col]) * acc[r];
+            M[row * LC_LS + col] = isL ? (col < row ? bs[row] * d : 0.0f) : (col <= row ? d : 0.0f);
         }
     } else {
-        for (int u = lane; u < 32 * 32; u += 64) { const int row = u >> 5, col = 32 + (u & 31); Lm[row * LC_LS + col] = 0.0f; Bm[row * LC_LS + col] = 0.0f; }
+        for (int u = tid - 6 * 64; u < 32 * 32; u += 128) { const int row = u >> 5, col = 32 + (u & 31); Lm[row * LC_LS + col] = 0.0f; Bm[row * LC_LS + col] = 0.0f; }
     }
     __syncthreads();
     LC_STAMP(2);
-    // ---- (I + L) X = [diag(b e^G) K | diag(b) V]: thread c owns column c of X = [W | Y] in registers; row t of L is a broadcast read
-    {
-        f2 x[LC_T / 2];                                    // pairs of rows: the two fma chains of a row run as one v_pk_fma_f32
-        float* Xt = tid < LC_D ? Kt + tid : Vt + (tid - LC_D);
-        const float* sc = tid < LC_D ? bg : bs;
+    // ---- (I + L) X = R,  R = [diag(b e^G) K | diag(b) V]  (X = [W | Y], 64 x 256), by 32-row blocks on the matrix cores:
+    //          X_top = T11 R_top,   X_bot = T22 (R_bot - L21 X_top),   T_ii = (I + L_ii)^-1
+    // Wave 0 inverts the two unit-lower-triangular diagonal blocks: lane (i, c) carries column c of T_ii through a 32-step forward substitution in
+    // registers (rows of L_ii are broadcast reads) -- 496 fma per lane instead of the 2016 of the 64-step column solve this replaces, whose chains
+    // were the longest phase of the kernel (8.5 of 28 us per workgroup) -- and parks T11 / T22 in the (0,1) blocks of Lm / Bm, which hold zeros nothing reads.
+    // Waves 1-3 scale the K and V rows in place meanwhile (K is not needed unscaled any more: its products and the K^T planes are done).
+    if (wave == 0) {
+        const int blk = lane >> 5, c = lane & 31;
+        const float* Lb = Lm + blk * 32 * LC_LS + blk * 32;
+        float x[32];
 #pragma unroll
-        for (int t = 0; t < LC_T; t += 2) { x[t / 2].x = sc[t] * Xt[t * LC_LD]; x[t / 2].y = sc[t + 1] * Xt[(t + 1) * LC_LD]; }
-        // row t + 1 of L leaves LDS (broadcast reads) while row t's chains run: with one wave per SIMD nothing else hides that latency
-        f4 cur[LC_T / 4], nx[LC_T / 4];
-        cur[0] = *reinterpret_cast<const f4*>(Lm + LC_LS);
+        for (int t = 0; t < 32; t++) x[t] = 0.0f;
+        x[0] = c == 0 ? 1.0f : 0.0f;
 #pragma unroll
-        for (int t = 1; t < LC_T; t++) {
-            if (t + 1 < LC_T) {
-#pragma unroll
-                for (int j4 = 0; j4 < (t + 4) / 4; j4++) nx[j4] = *reinterpret_cast<const f4*>(Lm + (t + 1) * LC_LS + 4 * j4);
-            }
+        for (int t = 1; t < 32; t++) {
             f2 sa = {0.0f, 0.0f}, sb = {0.0f, 0.0f};
 #pragma unroll
-            for (int j4 = 0; j4 < (t + 3) / 4; j4++) {        // entries at j >= t are stored zeros
-                const f4 l = cur[j4];
-                sa = __builtin_elementwise_fma((f2){l.x, l.y}, x[2 * j4], sa);
-                sb = __builtin_elementwise_fma((f2){l.z, l.w}, x[2 * j4 + 1], sb);
+            for (int j4 = 0; j4 < (t + 3) / 4; j4++) {        // entries at j >= t are stored zeros, x[j >= t] still 0
+                const f4 l = *reinterpret_cast<const f4*>(Lb + t * LC_LS + 4 * j4);
+                sa = __builtin_elementwise_fma((f2){l.x, l.y}, (f2){x[4 * j4], x[4 * j4 + 1]}, sa);
+                sb = __builtin_elementwise_fma((f2){l.z, l.w}, (f2){x[4 * j4 + 2], x[4 * j4 + 3]}, sb);
             }
-            const float sum = (sa.x + sa.y) + (sb.x + sb.y);
-            if (t & 1) x[t / 2].y -= sum; else x[t / 2].x -= sum;
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < LC_T) {
-#pragma unroll
-                for (int j4 = 0; j4 < (t + 4) / 4; j4++) cur[j4] = nx[j4];
-            }
+            x[t] = t == c ? 1.0f : -((sa.x + sa.y) + (sb.x + sb.y));
         }
-        // W over K, Y over V in LDS: element (t, c) is read and written by thread c only.  They go to memory from there, at the end of the kernel.
+        float* Td = (blk ? Bm : Lm) + 32 + c;
 #pragma unroll
-        for (int t = 0; t < LC_T; t++) Xt[t * LC_LD] = (t & 1) ? x[t / 2].y : x[t / 2].x;
+        for (int t = 0; t < 32; t++) Td[t * LC_LS] = x[t];
+    } else {
+        for (int u = tid - 64; u < LC_T * 64; u += LC_PTH - 64) {      // 16-byte units: row u >> 6; 32 units of K, 32 of V
+            const int t = u >> 6, j = u & 63;
+            float* p = j < 32 ? Kt + t * LC_LD + 4 * j : Vt + t * LC_LD + 4 * (j - 32);
+            const float sc = j < 32 ? bg[t] : bs[t];
+            f4 v = *reinterpret_cast<f4*>(p);
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+            *reinterpret_cast<f4*>(p) = v;
+        }
+    }
+    __syncthreads();
+    LC_STAMP(3);
+    // wave w owns 32 of the 256 columns of [W | Y] through all three products: what it reads of R / X it wrote itself, so the hand-over between the
+    // products is LDS order inside one wave (a wave's LDS operations execute in issue order), not a workgroup barrier
+    {
+        float* X = wave < 4 ? Kt + wave * 32 : Vt + (wave - 4) * 32;
+        const float* T11 = Lm + 32; const float* T22 = Bm + 32; const float* L21 = Lm + 32 * LC_LS;
+        const int n31 = lane & 31;
+        v16f x0, x1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) x0[i] = 0.0f;
+        lc_blk_s<true, false, 32>(x0, T11, LC_LS, X, LC_LD, lane);
+#pragma unroll
+        for (int r = 0; r < 16; r++) X[lc_row(r, lane) * LC_LD + n31] = x0[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; i++) x1[i] = 0.0f;
+        lc_blk_s<true, false, 32>(x1, L21, LC_LS, X, LC_LD, lane);
+#pragma unroll
+        for (int r = 0; r < 16; r++) { float* e = X + (32 + lc_row(r, lane)) * LC_LD + n31; *e = *e - x1[r]; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; i++) x1[i] = 0.0f;
+        lc_blk_s<true, false, 32>(x1, T22, LC_LS, X + 32 * LC_LD, LC_LD, lane);
+#pragma unroll
+        for (int r = 0; r < 16; r++) X[(32 + lc_row(r, lane)) * LC_LD + n31] = x1[r];
     }
     __syncthreads();
     LC_STAMP(4);
-    // ---- Q' = diag(e^G) Q - B W  and  O_0 = B Y: wave w takes the 32 columns [32w, 32w+32) of both, both row halves (row half 0 only needs j < 32)
+    // ---- Q' = diag(e^G) Q - B W (waves 0-3)  and  O_0 = B Y (waves 4-7): a wave takes 32 columns, both row halves (row half 0 only needs j < 32)
     {
-        v16f q0, q1, o0, o1;
+        const bool isQ = wave < 4;
+        const int col = (wave & 3) * 32 + (lane & 31);
+        const float* Rt = (isQ ? Kt : Vt) + (wave & 3) * 32;
+        v16f p0, p1;
 #pragma unroll
-        for (int i = 0; i < 16; i++) { q0[i] = 0.0f; q1[i] = 0.0f; o0[i] = 0.0f; o1[i] = 0.0f; }
-        lc_blk_s<true, false, 32>(q0, Bm, LC_LS, Kt + wave * 32, LC_LD, lane);
-        lc_blk_s<true, false, 32>(o0, Bm, LC_LS, Vt + wave * 32, LC_LD, lane);
-        lc_blk_s<true, false, 64>(q1, Bm + 32 * LC_LS, LC_LS, Kt + wave * 32, LC_LD, lane);
-        lc_blk_s<true, false, 64>(o1, Bm + 32 * LC_LS, LC_LS, Vt + wave * 32, LC_LD, lane);
-        const int col = wave * 32 + (lane & 31);
+        for (int i = 0; i < 16; i++) { p0[i] = 0.0f; p1[i] = 0.0f; }
+        lc_blk_s<true, false, 32>(p0, Bm, LC_LS, Rt, LC_LD, lane);
+        lc_blk_s<true, false, 64>(p1, Bm + 32 * LC_LS, LC_LS, Rt, LC_LD, lane);
         LC_STAMP(5);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int r0 = lc_row(r, lane), r1 = 32 + r0;
-            Qt[r0 * LC_LD + col] = lc_exp(Gs[r0]) * Qt[r0 * LC_LD + col] - q0[r];      // Q' over Q in LDS: element (row, col) is touched by this lane only
-            Qt[r1 * LC_LD + col] = lc_exp(Gs[r1]) * Qt[r1 * LC_LD + col] - q1[r];
-            if (r0 < n) a.out[(size_t)(c0 + r0) * ld + (size_t)h * LC_D + col] = o0[r];
-            if (r1 < n) a.out[(size_t)(c0 + r1) * ld + (size_t)h * LC_D + col] = o1[r];
+            if (isQ) {
+                Qt[r0 * LC_LD + col] = lc_exp(Gs[r0]) * Qt[r0 * LC_LD + col] - p0[r];      // Q' over Q in LDS: element (row, col) is touched by this lane only
+                Qt[r1 * LC_LD + col] = lc_exp(Gs[r1]) * Qt[r1 * LC_LD + col] - p1[r];
+            } else {
+                if (r0 < n) a.out[(size_t)(c0 + r0) * ld + (size_t)h * LC_D + col] = p0[r];
+                if (r1 < n) a.out[(size_t)(c0 + r1) * ld + (size_t)h * LC_D + col] = p1[r];
+            }
         }
         LC_STAMP(6);
     }
     __syncthreads();
     // ---- W (K tile), Q' (Q tile) -> their bf16 planes, Y (V tile) -> f32, all with 16-byte stores: chunk u = 8 consecutive columns of row u >> 4
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int u = tid + 256 * i, t = u >> 4, c8 = (u & 15) * 8;
+    for (int i = 0; i < 2; i++) {
+        const int u = tid + LC_PTH * i, t = u >> 4, c8 = (u & 15) * 8;
         const size_t o = (tile + t) * LC_D + c8;
         auto planes = [&](const float* src, uint16_t* ph, uint16_t* pl) {
             const f4 v0 = *reinterpret_cast<const f4*>(src + t * LC_LD + c8), v1 = *reinterpret_cast<const f4*>(src + t * LC_LD + c8 + 4);
@@ -423,7 +453,7 @@ static int lac_prepare() {
     return kr_lds_optin(reinterpret_cast<const void*>(kr_lac_prep_kernel), LC_PREP_LDS) || kr_lds_optin(reinterpret_cast<const void*>(kr_lac_scan_kernel), LC_SCAN_LDS);
 }
 
-int kr_launch_pfm_la_chunked(const KrPfmLaArgs& p, float* state, float* out, float* scratch, int C, hipStream_t st) {
+int kr_launch_pfm_la_chunked(const KrPfmLaArgs& p, float* state, float* out, float* scratch, int C, hipStream_t st, const KrPfSync* sy) {
     if (!kr_pfm_la_chunk_ok(p.dk, p.dv, C) || !scratch) return 1;
     if (lac_prepare()) return 1;
     KrLacArgs a{};
@@ -433,7 +463,8 @@ int kr_launch_pfm_la_chunked(const KrPfmLaArgs& p, float* state, float* out, flo
     uint16_t* pl = reinterpret_cast<uint16_t*>(a.G + ((tiles + 3) / 4) * 4);        // planes start 16-byte aligned
     a.Wh = pl; a.Wl = a.Wh + tiles * LC_D; a.Qh = a.Wl + tiles * LC_D; a.Ql = a.Qh + tiles * LC_D; a.Kh = a.Ql + tiles * LC_D; a.Kl = a.Kh + tiles * LC_D;
     a.out = out; a.state = state;
-    hipLaunchKernelGGL(kr_lac_prep_kernel, dim3(a.n_sub, p.nv), dim3(256), LC_PREP_LDS, st, a);
-    hipLaunchKernelGGL(kr_lac_scan_kernel, dim3(p.nv * 4), dim3(256), LC_SCAN_LDS, st, a);
+    KR_AB(2, hipLaunchKernelGGL(kr_lac_prep_kernel, dim3(a.n_sub, p.nv), dim3(LC_PTH), LC_PREP_LDS, st, a));
+    if (sy) kr_pf_wait(st, sy->wait_b);      // only the scan reads the state the previous chunk of the prompt leaves
+    KR_AB(4, hipLaunchKernelGGL(kr_lac_scan_kernel, dim3(p.nv * 4), dim3(256), LC_SCAN_LDS, st, a));
     return 0;
 }

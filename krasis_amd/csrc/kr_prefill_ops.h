@@ -12,6 +12,24 @@ struct KrPfmNormArgs {
     uint16_t* out_bf16;           // optional bf16 copy (input of the routed experts)
     int H, first, bias_one; float eps;
 };
+// Cross-chunk ordering INSIDE a layer (kr_decode_prefill.cpp runs several chunks of a prompt on their own streams): what chunk c needs from chunk c - 1 is
+// not "layer l finished" but two narrow hand-overs -- (a) the carried conv state, (b) the recurrent state (linear attention) or the KV / latent rows
+// (GQA, MLA) of layer l.  wait_* are the previous chunk's events (null: first chunk / one chunk in flight), rec_* this chunk's.  Every record is issued AFTER
+// the matching wait on the same stream, so an event implies the whole chain of earlier chunks (a chunk two back has no event of its own to wait for).
+#ifdef KR_AB_SKIP      // A/B library only (make ab AB_DEFS=-DKR_AB_SKIP): leave out launches named by the bit mask in $KR_AB_SKIP to price them in wall-clock terms
+#include <cstdlib>     // (results are wrong by construction; the product library has no such hook)
+static inline bool kr_ab_skip(int bit) { static const int m = getenv("KR_AB_SKIP") ? atoi(getenv("KR_AB_SKIP")) : 0; return (m & bit) != 0; }
+#define KR_AB(bit, stmt) do { if (!kr_ab_skip(bit)) { stmt; } } while (0)
+#define KR_AB_ON(bit) kr_ab_skip(bit)
+#else
+#define KR_AB(bit, stmt) do { stmt; } while (0)
+#define KR_AB_ON(bit) false
+#endif
+struct KrPfSync {
+    hipEvent_t wait_a = nullptr, rec_a = nullptr, wait_b = nullptr, rec_b = nullptr;
+};
+static inline void kr_pf_wait(hipStream_t st, hipEvent_t ev) { if (ev) (void)hipStreamWaitEvent(st, ev, 0); }
+static inline void kr_pf_rec(hipStream_t st, hipEvent_t ev) { if (ev) (void)hipEventRecord(ev, st); }
 struct KrPfmLaArgs {
     const float* qkvz; int ld_qkvz; const float* ba; int ld_ba;
     float* conv_state; const float* conv_w; const float* a_log; const float* dt_bias; float scale;
@@ -31,11 +49,11 @@ void kr_launch_pfm_norm(const KrPfmNormArgs& a, int C, hipStream_t st);
 void kr_launch_pfm_nll(const float* logits, size_t ld, const int* labels, float* nll, int rows, int V, hipStream_t st);
 void kr_launch_pfm_quant_f32(const float* x, int rows, int ld, int K, int8_t* xh, int8_t* xl, float* xs, hipStream_t st);
 // conv + conv-state update + gated delta rule over the chunk + gated RMSNorm; non-zero = unsupported geometry
-int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out, const float* norm_w, float* gated_out, int C, float eps, hipStream_t st);
+int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out, const float* norm_w, float* gated_out, int C, float eps, hipStream_t st, const KrPfSync* sy = nullptr);
 // prep (norm, RoPE, KV append) + scores -> softmax -> P.V over the score scratch sc[C*nh rows][sc_ld] (sc_ld >= pos0 + C, multiple of 64),
 // inv[C*nh * (1 + sc_ld/32)] (1 / sum per row, then the per-32-position row maxima of the matrix-core passes);
 // non-zero = unsupported geometry
-int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st);
+int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st, const KrPfSync* sy = nullptr);
 // passes A and C of the above on the f32 matrix cores, bit-identical (kr_attn_exact_mfma.hip); *_ok: the geometry is covered (group divides 32, head_dim 64 / 128 / 256)
 int kr_pfm_gqa_exact_mfma_ok(const KrPfmGqaArgs& a);
 void kr_launch_pfm_gqa_scores_mfma(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* tmax /* [C*nh][sc_ld/32] row maxima per 32 positions, or null */, hipStream_t st);
@@ -54,6 +72,6 @@ bool kr_pfm_gqa_flash_ok(int nh, int nkv, int hd);      // geometries the flash 
 void kr_launch_pfm_gqa_prep(const KrPfmGqaArgs& a, int C, hipStream_t st);
 int kr_launch_pfm_la_recur(float* state, const float* q, const float* k, const float* v, const float* gexp, const float* beta, float* out, int nv, int dk, int dv, int C, hipStream_t st);
 // FAST mode (kr_la_chunk.hip): the gated delta rule over the chunk in sub-chunks of 64 tokens on the f32 MFMA; non-zero = geometry not covered
-int kr_launch_pfm_la_chunked(const KrPfmLaArgs& a, float* recur_state, float* recur_out, float* scratch, int C, hipStream_t st);
+int kr_launch_pfm_la_chunked(const KrPfmLaArgs& a, float* recur_state, float* recur_out, float* scratch, int C, hipStream_t st, const KrPfSync* sy = nullptr);
 size_t kr_pfm_la_chunk_scratch_floats(int C, int nv);
 bool kr_pfm_la_chunk_ok(int dk, int dv, int C);

@@ -695,16 +695,25 @@ void kr_launch_pfm_quant_f32(const float* x, int rows, int ld, int K, int8_t* xh
     const int thr = K / 8 < 1024 ? ((K / 8 + 15) / 16) * 16 : 1024;
     hipLaunchKernelGGL(kr_pfm_quant_f32_kernel, dim3(rows), dim3(thr), 0, st, x, ld, K, xh, xl, xs);
 }
-int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out, const float* norm_w, float* gated_out, int C, float eps, hipStream_t st) {
+int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out, const float* norm_w, float* gated_out, int C, float eps, hipStream_t st, const KrPfSync* sy) {
     if (a.dv > 256 || a.dv % 8 || a.dv < a.dk || a.dk % 8) return 1;
-    hipLaunchKernelGGL(kr_pfm_la_conv_kernel, dim3(a.nk, (C + PFC_TT - 1) / PFC_TT), dim3(256), (size_t)(2 * PFC_TT * a.dk + 2 * PFC_TT) * 4, st, a, C);
+    const KrPfSync none{};
+    if (!sy) sy = &none;
+    kr_pf_wait(st, sy->wait_a);              // the previous chunk's carried conv slots
+    KR_AB(1, hipLaunchKernelGGL(kr_pfm_la_conv_kernel, dim3(a.nk, (C + PFC_TT - 1) / PFC_TT), dim3(256), (size_t)(2 * PFC_TT * a.dk + 2 * PFC_TT) * 4, st, a, C));
     const int conv_dim = 2 * a.nk * a.dk + a.nv * a.dv;
     hipLaunchKernelGGL(kr_pfm_la_conv_state_kernel, dim3((conv_dim + 255) / 256), dim3(256), 0, st, a, C);
-    if (a.fast && a.lac && kr_pfm_la_chunk_ok(a.dk, a.dv, C) && kr_launch_pfm_la_chunked(a, recur_state, recur_out, a.lac, C, st) == 0) {}
-    else if (a.dk == 128) hipLaunchKernelGGL(kr_pfm_la_recur_kernel<128>, dim3(a.nv), dim3(a.dv), 0, st, recur_state, a.q, a.k, a.v, a.gexp, a.beta, recur_out, a.nv, a.dv, C);
-    else if (a.dk == 64) hipLaunchKernelGGL(kr_pfm_la_recur_kernel<64>, dim3(a.nv), dim3(a.dv), 0, st, recur_state, a.q, a.k, a.v, a.gexp, a.beta, recur_out, a.nv, a.dv, C);
-    else return 1;
-    hipLaunchKernelGGL(kr_pfm_gated_norm_kernel, dim3(a.nv, C), dim3(a.dv), 0, st, recur_out, a.z, norm_w, gated_out, a.nv, a.dv, eps);
+    kr_pf_rec(st, sy->rec_a);
+    // the recurrent state: the chunked form waits between its two launches (the first needs no state), the per-token kernel before its one launch
+    if (a.fast && a.lac && kr_pfm_la_chunk_ok(a.dk, a.dv, C) && kr_launch_pfm_la_chunked(a, recur_state, recur_out, a.lac, C, st, sy) == 0) {}
+    else {
+        if (a.dk != 128 && a.dk != 64) return 1;
+        kr_pf_wait(st, sy->wait_b);
+        if (a.dk == 128) hipLaunchKernelGGL(kr_pfm_la_recur_kernel<128>, dim3(a.nv), dim3(a.dv), 0, st, recur_state, a.q, a.k, a.v, a.gexp, a.beta, recur_out, a.nv, a.dv, C);
+        else hipLaunchKernelGGL(kr_pfm_la_recur_kernel<64>, dim3(a.nv), dim3(a.dv), 0, st, recur_state, a.q, a.k, a.v, a.gexp, a.beta, recur_out, a.nv, a.dv, C);
+    }
+    kr_pf_rec(st, sy->rec_b);
+    KR_AB(8, hipLaunchKernelGGL(kr_pfm_gated_norm_kernel, dim3(a.nv, C), dim3(a.dv), 0, st, recur_out, a.z, norm_w, gated_out, a.nv, a.dv, eps));
     return 0;
 }
 // the recurrence alone (stand-alone operator linear_attention_recurrent, decode.rs:609): gexp = e^g per (token, head); non-zero = unsupported geometry
@@ -719,10 +728,11 @@ int kr_pfm_gqa_tile(int nh, int nkv) { const int group = nh / nkv; int tt = PFA_
 void kr_launch_pfm_gqa_prep(const KrPfmGqaArgs& a, int C, hipStream_t st) {
     hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, C), dim3(256), 0, st, a);
 }
-int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st) {
+int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st, const KrPfSync* sy) {
     const int group = a.nh / a.nkv, TT = kr_pfm_gqa_tile(a.nh, a.nkv);
     if (TT == 0 || a.hd > 256 || a.hd % 32 || a.nh % a.nkv) return 1;
     hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, C), dim3(256), 0, st, a);
+    if (sy) { kr_pf_wait(st, sy->wait_b); kr_pf_rec(st, sy->rec_b); }      // this chunk's rows are appended; the earlier chunks' rows are what the passes below read
     static const bool no_mfma = getenv("KR_EXACT_ATTN_VALU") != nullptr;       // tuning / A-B hook: keep the vector-ALU passes
     if (!no_mfma && kr_pfm_gqa_exact_mfma_ok(a)) {                              // scores and P.V on the f32 matrix cores, same bits (kr_attn_exact_mfma.hip)
         const int rows = C * a.nh;

@@ -125,6 +125,16 @@ gguf)       # native-GGUF experts inside the decode step: parity tests, decode t
     timeout 900 python -m pytest tests/test_gguf_gpu.py tests/test_decode_gpu.py -q -x -k "gguf" 2>&1 | tail -4
     timeout 600 python tools/probes/gguf_decode_bench.py 30 2>&1 | grep decode
     ;;
+tl)         # concurrency view of the tolerance prompt pass: which kernels own the wall clock with three chunks in flight
+    P=${1:-8192}
+    rm -rf $R/prof_tl
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/prof_tl --output-format csv -- python /root/repo/tools/probes/prefill_profile.py $P 2 > $R/prof_tl.log 2>&1)
+    grep "prompt pass" $R/prof_tl.log
+    python tools/rocprof_timeline.py $R/prof_tl $R/r04_prefill_${P}_timeline.txt "QCN prompt pass, KR_ATTN_FAST | KR_GEMM_FAST, $P tokens: concurrency of the kernel trace (tools/probes/prefill_profile.py $P 2)"
+    cat $R/r04_prefill_${P}_timeline.txt | cut -c1-170
+    [ -n "$2" ] && python tools/probes/tl_queues.py $R/prof_tl > $R/tl_queues.txt 2>&1
+    rm -rf $R/prof_tl
+    ;;
 r4final)    # round 4 closing run: the whole GPU suite as the driver runs it, the driver's bench line, PMC fetch pass + kernel trace of the decode step
     # (raw rocprof directories are removed on the box once summarised: gpurun merges at most 64 MiB back)
     timeout 1800 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -5 | tee $R/r04_gpu_tests_tail.txt

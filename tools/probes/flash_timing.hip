@@ -3,6 +3,8 @@
 #define KR_TIMING 1
 #include "../../krasis_amd/csrc/kr_attn_flash.hip"
 #include <cstdio>
+#include <cmath>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -19,6 +21,30 @@ int main(int argc, char** argv) {
     a.k_cache = kc; a.v_cache = vc; a.kv_fp8 = 1; a.q_out = q; a.gate = gate; a.attn_out = out; a.gated = 1; a.nh = nh; a.nkv = nkv; a.hd = hd; a.pos0 = pos0; a.sm_scale = 0.0625f;
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto e4m3 = [](unsigned char b) -> double {      // OCP E4M3 (finite codes only here)
+        const int s = b >> 7, e = (b >> 3) & 15, m = b & 7;
+        const double v = e == 0 ? m / 8.0 * 0.015625 : (1.0 + m / 8.0) * std::pow(2.0, e - 7);
+        return s ? -v : v;
+    };
+    {   // correctness: a few (token, head) rows against a double softmax over the decoded cache
+        if (kr_launch_pfm_gqa_flash(a, C, st)) { printf("launch refused\n"); return 1; }
+        CK(hipStreamSynchronize(st));
+        std::vector<float> ho((size_t)C * nh * hd); CK(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));
+        double emax = 0, omax = 0;
+        const int rows[4][2] = {{0, 0}, {C / 2 + 3, 5}, {C - 1, nh - 1}, {17, 9}};
+        for (auto& rw : rows) {
+            const int t = rw[0], h = rw[1], kvh2 = h / (nh / nkv), np = pos0 + t + 1;
+            std::vector<double> sc(np); double mx = -1e300;
+            for (int p = 0; p < np; p++) { double d2 = 0; for (int i = 0; i < hd; i++) d2 += (double)hq[((size_t)t * nh + h) * hd + i] * e4m3(hb[((size_t)p * nkv + kvh2) * hd + i]); sc[p] = d2 * 0.0625; mx = std::max(mx, sc[p]); }
+            double l = 0; for (auto& x : sc) { x = std::exp(x - mx); l += x; }
+            for (int i = 0; i < hd; i++) {
+                double o = 0; for (int p = 0; p < np; p++) o += sc[p] * e4m3(hb[((size_t)p * nkv + kvh2) * hd + i]);
+                o /= l; const double g = hq[((size_t)t * nh + h) * hd + i]; o *= 1.0 / (1.0 + std::exp(-g));
+                emax = std::max(emax, std::fabs(o - (double)ho[((size_t)t * nh + h) * hd + i])); omax = std::max(omax, std::fabs(o));
+            }
+        }
+        printf("check (4 rows, double softmax over the decoded E4M3 cache): max|err| %.3e of max|out| %.3e\n", emax, omax);
+    }
     for (int rep = 0; rep < 3; rep++) {
         CK(hipEventRecord(e0, st));
         if (kr_launch_pfm_gqa_flash(a, C, st)) { printf("launch refused\n"); return 1; }
@@ -27,8 +53,9 @@ int main(int argc, char** argv) {
         unsigned long long s[32]; CK(hipMemcpyFromSymbol(s, HIP_SYMBOL(kr_fstamps), sizeof(s)));
         auto d = [&](int x, int y) { return (double)(long long)(s[y] - s[x]) * 0.01; };
         const double flop = 4.0 * C * nh * (double)(pos0 + C / 2) * hd;
-        printf("rep %d: %.1f us, %.0f TFLOP/s | tile 40 of the last query tile: K commit + barrier %.2f | S^T %.2f | softmax %.2f | V commit + loads %.2f | barrier %.2f | PV %.2f | tile %.2f us\n",
-               rep, ms * 1e3, flop / (ms * 1e-3) / 1e12, d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(5, 6), d(0, 6));
+        printf("rep %d: %.1f us, %.0f TFLOP/s | S wave, tile 40: barrier X %.2f | S^T %.2f | softmax + P store %.2f | barrier Y %.2f | K commit + loads %.2f | tile %.2f us\n",
+               rep, ms * 1e3, flop / (ms * 1e-3) / 1e12, d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(0, 5));
+        printf("        PV wave, tile 40: barrier X %.2f | rescale + P.V %.2f | barrier Y %.2f | V commit + loads %.2f | tile %.2f us\n", d(8, 9), d(9, 11), d(11, 12), d(12, 13), d(8, 13));
     }
     return 0;
 }

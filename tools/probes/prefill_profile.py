@@ -13,5 +13,6 @@ if len(sys.argv) > 5 and int(sys.argv[5]): st.set_prefill_depth(int(sys.argv[5])
 st.fill_state_synthetic(P + 64, 7)
 toks = [int(x) for x in np.random.default_rng(5).integers(0, bench.QCN["vocab"], P)]
 st.prefill(toks, 0); torch.cuda.synchronize()          # full-length warm-up: the scratch arenas are sized by the chunk length
+if os.environ.get("KR_PFM_TIMING"): st.set_option("pfm_timing", 1)
 t0 = time.perf_counter(); st.prefill(toks, 0); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("prompt pass %d tokens fast=%d: %.1f ms (%.0f tok/s)" % (P, fast, dt * 1e3, P / dt), flush=True)
