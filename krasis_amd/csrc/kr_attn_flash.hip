@@ -257,12 +257,19 @@ __global__ void __launch_bounds__(256) kr_pfm_gqa_flash_kernel(const KrPfmGqaArg
 //   waves 4-7 ("PV waves")  own HD / 4 output dims each for ALL 128 rows (a V^T fragment serves four row blocks): O^T += V^T P^T one tile BEHIND the S
 //                           waves, so the softmax arithmetic of tile t runs under the P.V MFMAs of tile t - 1 on the same SIMD; they stage V, ROW-major like
 //                           K -- the transposed fragments come out of gfx950's LDS transpose-read (ds_read_b64_tr_b16)
-// No split-KV merge at the end: one softmax stream per row.  tools/probes/flash_timing.hip (1024 queries late in a 32 k cache, E4M3): 355 -> 449 TFLOP/s;
-// per tile S^T 0.72 | softmax 0.84 | K staging 0.40 on the S side, P.V 1.40 | V staging 0.64 on the PV side (both sides' MFMAs share the SIMD's matrix pipe
-// during the first 1.4 us; the staging between the two barriers is the part still uncovered).  Tried on the way and not kept: a 32-position tile with K, V and
-// P all double-buffered and one barrier per tile (same speed: the waves' own instruction streams, not the barriers, are the limit), S^T(t+1) issued between
-// the pieces of the softmax of tile t in the same wave (slower: the K fragment waits came to stand in front of every piece).
+// No split-KV merge at the end: one softmax stream per row.  V is double-buffered: the PV waves stage V(t) FIRST (their matrix work would only queue behind the S
+// waves' S^T on the same SIMD) and run P.V(t - 1) while the S waves are in their softmax.  The S^T accumulators start at -m (the row's running maximum), so once
+// the maximum has settled no element needs a subtraction before its exponential and the rescale factor is 1; fragments of both sides are requested several
+// MFMAs ahead by hand (one wave of a kind per SIMD: nothing else covers an LDS round trip).
+// tools/probes/flash_timing.hip (1024 queries late in a 32 k cache, E4M3, 128 of 256 CUs busy): 355 -> 476 TFLOP/s; per 64-position tile S^T 0.72 | softmax
+// 0.56 | K staging 0.40 on the S side, V staging 0.88 (with the fragment requests) | P.V 0.92 on the PV side, 2.28 us in all against 1.02 us of pure MFMA time
+// at the 2.0 GHz the chip holds under matrix load (tools/probes/clock_probe.hip).  Tried on the way and not kept: a 32-position tile with K, V and P all
+// double-buffered and one barrier per tile (same speed: the waves' own instruction streams, not the barriers, are the limit), S^T(t + 1) issued between the
+// pieces of the softmax of tile t in the same wave (slower: the K fragment waits came to stand in front of every piece), K double-buffered instead of V
+// (433: P.V and S^T collide on the matrix pipe again).
 // ------------------------------------------------------------------------------------------------------------------------------------
+// one v_max3_f32 (the compiler's fmaxf chain canonicalises MFMA results first: two instructions per value)
+__device__ __forceinline__ float fa_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 // the value lane ^ 32 holds: one v_permlane32_swap (the ds_bpermute of __shfl_xor is an LDS round trip on the softmax's serial path)
 __device__ __forceinline__ float fa_other_half(float x, int khalf) {
     const uint32_t u = __builtin_bit_cast(uint32_t, x);
@@ -277,8 +284,8 @@ __global__ void __launch_bounds__(512, 2) kr_pfm_gqa_flashw_kernel(const KrPfmGq
     constexpr int NCH = FA_TK * CPR / 256;                      // consecutive lanes on consecutive 16-byte slots (conflict-free writes); chunks per thread and tile
     extern __shared__ __attribute__((aligned(16))) char fa_smem[];
     char* Ks = fa_smem;                                         // [64 positions][LDK]   f16
-    char* Vs = Ks + FA_TK * LDK;                                // [64 positions][LDV]   f16, ROW-major like K: the P.V fragments come out of ds_read_b64_tr_b16
-    char* Ps = Vs + FA_TK * LDV;                                // [2][128 rows][LDP]    f16 probabilities of a tile, positions contiguous
+    char* Vs = Ks + FA_TK * LDK;                                // [2][64 positions][LDV] f16, ROW-major like K: the P.V fragments come out of ds_read_b64_tr_b16
+    char* Ps = Vs + 2 * FA_TK * LDV;                                // [2][128 rows][LDP]    f16 probabilities of a tile, positions contiguous
     float* Al = reinterpret_cast<float*>(Ps + 2 * FA_ROWS * LDP);      // [2][128] rescale factor of the row for the tile
     float* Il = Al + 2 * FA_ROWS;                               // [128] 1 / l at the end
     const int G = a.nh / a.nkv, TQ = FA_ROWS / G;
@@ -335,7 +342,7 @@ __global__ void __launch_bounds__(512, 2) kr_pfm_gqa_flashw_kernel(const KrPfmGq
                 for (int i = 0; i < 8; i++) qf[ks][i] = (_Float16)(row_ok ? xv[i] * sc : 0.0f);
             }
         }
-        float m_run = -__builtin_inff(), l_run = 0.0f;
+        float m_run = 0.0f, l_run = 0.0f;                      // m_run: the origin the row's scores are measured from (its running maximum from the first tile on)
         const char* krow = Ks + n31 * LDK + 16 * khalf;
         stage_load(0, false);
         stage_commit(Ks, LDK);
@@ -348,42 +355,59 @@ __global__ void __launch_bounds__(512, 2) kr_pfm_gqa_flashw_kernel(const KrPfmGq
                 const int p0 = tile * FA_TK;
                 v16f sacc[2];
 #pragma unroll
-                for (int pb = 0; pb < 2; pb++) {
-#pragma unroll
-                    for (int i = 0; i < 16; i++) sacc[pb][i] = 0.0f;
-#pragma unroll
-                    for (int ks = 0; ks < KSTEPS; ks++)
-                        sacc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const v8h*>(krow + 32 * pb * LDK + 32 * ks), qf[ks], sacc[pb], 0, 0, 0);
-                }
-                FA_STAMP(2);
-                const bool need_mask = p0 + FA_TK - 1 > full_vis || p0 + FA_TK > kv_end;
-                float mloc = -__builtin_inff();
-#pragma unroll
                 for (int pb = 0; pb < 2; pb++)
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        if (need_mask) { const int p = p0 + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * khalf; if (p > p_q || !row_ok) sacc[pb][i] = -__builtin_inff(); }
-                        mloc = fmaxf(mloc, sacc[pb][i]);
-                    }
-                mloc = fmaxf(mloc, fa_other_half(mloc, khalf));
-                const float m_new = fmaxf(m_run, mloc);
-                const float m_use = m_new == -__builtin_inff() ? 0.0f : m_new;                   // nothing visible yet: exp2(-inf - 0) = 0 everywhere
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);                        // m_run = -inf -> 0
+                    for (int i = 0; i < 16; i++) sacc[pb][i] = -m_run;
+                // K fragments through a ring of FW_RING registers sets: with one wave of this kind per SIMD an LDS round trip (a few hundred cycles while the
+                // other side writes its tile) has to be covered by this wave's own MFMAs -- the compiler's schedule kept ~2 in flight and S^T ran at 0.58 of the pipe
+                constexpr int NF = 2 * KSTEPS, RING = 8;
+                v8h kf[RING];
+                auto kaddr = [&](int f) { return krow + 32 * (f & 1) * LDK + 32 * (f >> 1); };      // fragment f: position block f & 1, k-step f >> 1 (the two accumulators alternate)
+#pragma unroll
+                for (int f = 0; f < RING; f++) kf[f] = *reinterpret_cast<const v8h*>(kaddr(f));
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+                    sacc[f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[f % RING], qf[f >> 1], sacc[f & 1], 0, 0, 0);
+                    if (f + RING < NF) kf[f % RING] = *reinterpret_cast<const v8h*>(kaddr(f + RING));
+                    if ((f & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                FA_STAMP(2);
+                // The accumulators were started at -m (the row's running maximum, 0 before the first tile), so sacc = s - m already.  Once the maximum has settled
+                // -- almost every tile of a long prompt -- no element needs another subtraction and the rescale factor is 1.
+                const bool need_mask = p0 + FA_TK - 1 > full_vis || p0 + FA_TK > kv_end;
+                if (need_mask) {
+#pragma unroll
+                    for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) { const int p = p0 + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * khalf; if (p > p_q || !row_ok) sacc[pb][i] = -__builtin_inff(); }
+                }
+                float mloc = fa_max3(sacc[0][0], sacc[1][0], sacc[0][1]);
+#pragma unroll
+                for (int i = 1; i < 16; i++) mloc = fa_max3(mloc, sacc[0][i], sacc[1][i]);      // (element [0][1] twice: harmless)
+                mloc = fa_max3(mloc, fa_other_half(mloc, khalf), tile == 0 ? -__builtin_inff() : 0.0f);      // the first tile sets the maximum, later ones only raise it
+                const float shift = mloc == -__builtin_inff() ? 0.0f : mloc;       // >= 0 after the first tile; a row that has seen nothing keeps its origin
+                const float alpha = __builtin_amdgcn_exp2f(-shift);
                 float lsum = 0.0f;
                 char* prow = Ps + (size_t)(tile & 1) * FA_ROWS * LDP + (size_t)r * LDP + 8 * khalf;
+                if (__any(shift != 0.0f)) {
+#pragma unroll
+                    for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) sacc[pb][i] -= shift;
+                }
 #pragma unroll
                 for (int pb = 0; pb < 2; pb++)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; g4++) {      // accumulator rows 4 g4 .. + 3 = positions 32 pb + 8 g4 + 4 khalf .. + 3: one 8-byte store
                         float pv[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) { pv[u] = __builtin_amdgcn_exp2f(sacc[pb][4 * g4 + u] - m_use); lsum += pv[u]; }
+                        for (int u = 0; u < 4; u++) { pv[u] = __builtin_amdgcn_exp2f(sacc[pb][4 * g4 + u]); lsum += pv[u]; }
                         const u32x2 w = {__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pv[0], pv[1])), __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pv[2], pv[3]))};
                         *reinterpret_cast<u32x2*>(prow + (32 * pb + 8 * g4) * 2) = w;
                     }
                 lsum += fa_other_half(lsum, khalf);
                 l_run = l_run * alpha + lsum;
-                m_run = m_new;
+                m_run += shift;
                 if (khalf == 0) Al[(tile & 1) * FA_ROWS + r] = alpha;
                 FA_STAMP(3);
             }
@@ -411,17 +435,38 @@ __global__ void __launch_bounds__(512, 2) kr_pfm_gqa_flashw_kernel(const KrPfmGq
         // conversions + 16 byte permutes + 16 four-byte LDS writes per thread and tile -- was the longest phase of a tile.)
         typedef __fp16 fa_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
         const int tr_off = (8 * khalf + ((lane & 15) >> 2)) * LDV + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;      // this lane's source row / dim quad inside a (16-position, 32-dim) block
+        // V is double-buffered: the PV waves bring V(tile) in FIRST (their matrix work would only queue up behind the S waves' S^T MFMAs on the same SIMD for the
+        // first half microsecond of an iteration), then run P.V(tile - 1) on the other buffer while the S waves are in their softmax
         stage_load(0, true);
         for (int tile = 0; tile <= n_tiles; tile++) {
             FA_STAMP2(8);
-            __syncthreads();                                  // X: V(tile - 1) and P(tile - 1) are in LDS
+            __syncthreads();                                  // X: P(tile - 1) is in LDS; V(tile - 1) was committed before the previous Y
             FA_STAMP2(9);
-            if (tile >= 1) {
-                const char* pb_ = Ps + (size_t)((tile - 1) & 1) * FA_ROWS * LDP;
+            const char* pb_ = Ps + (size_t)((tile - 1) & 1) * FA_ROWS * LDP;
+            const char* vb_ = Vs + (size_t)((tile - 1) & 1) * FA_TK * LDV;
+            v8h vf[2][DBW], pf[2][4];
+            auto fetch = [&](int kt, int bsel) {
+#pragma unroll
+                for (int db = 0; db < DBW; db++) {
+                    const char* va = vb_ + (size_t)(16 * kt) * LDV + 32 * (pw * DBW + db) * 2 + tr_off;
+                    const fa_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fa_h4*)(va));
+                    const fa_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fa_h4*)(va + 4 * LDV));
+                    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    vf[bsel][db] = __builtin_bit_cast(v8h, u32x4{l2.x, l2.y, h2.x, h2.y});
+                }
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) pf[bsel][rb] = *reinterpret_cast<const v8h*>(pb_ + (size_t)(32 * rb + n31) * LDP + (16 * kt + 8 * khalf) * 2);
+            };
+            float av[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (tile >= 1) {                                   // the first two k-steps' fragments (and the rows' factors) travel while this wave stages V
                 const float* al = Al + ((tile - 1) & 1) * FA_ROWS;
-                float av[4];
 #pragma unroll
                 for (int rb = 0; rb < 4; rb++) av[rb] = al[32 * rb + n31];
+                fetch(0, 0); fetch(1, 1);
+            }
+            if (tile < n_tiles) { stage_commit(Vs + (size_t)(tile & 1) * FA_TK * LDV, LDV); if (tile + 1 < n_tiles) stage_load((tile + 1) * FA_TK, true); }
+            FA_STAMP2(10);
+            if (tile >= 1) {
                 if (__any(av[0] != 1.0f || av[1] != 1.0f || av[2] != 1.0f || av[3] != 1.0f)) {
 #pragma unroll
                     for (int rb = 0; rb < 4; rb++)
@@ -432,28 +477,17 @@ __global__ void __launch_bounds__(512, 2) kr_pfm_gqa_flashw_kernel(const KrPfmGq
                 }
 #pragma unroll
                 for (int kt = 0; kt < 4; kt++) {
-                    v8h vf[DBW], pf[4];
-#pragma unroll
-                    for (int db = 0; db < DBW; db++) {
-                        const char* va = Vs + (size_t)(16 * kt) * LDV + 32 * (pw * DBW + db) * 2 + tr_off;
-                        const fa_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fa_h4*)(va));
-                        const fa_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fa_h4*)(va + 4 * LDV));
-                        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-                        vf[db] = __builtin_bit_cast(v8h, u32x4{l2.x, l2.y, h2.x, h2.y});
-                    }
-#pragma unroll
-                    for (int rb = 0; rb < 4; rb++) pf[rb] = *reinterpret_cast<const v8h*>(pb_ + (size_t)(32 * rb + n31) * LDP + (16 * kt + 8 * khalf) * 2);
 #pragma unroll
                     for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-                        for (int db = 0; db < DBW; db++) oacc[rb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[db], pf[rb], oacc[rb][db], 0, 0, 0);
+                        for (int db = 0; db < DBW; db++) oacc[rb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kt & 1][db], pf[kt & 1][rb], oacc[rb][db], 0, 0, 0);
+                    if (kt + 2 < 4) fetch(kt + 2, kt & 1);      // two steps ahead, into the set this step has just consumed
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             FA_STAMP2(11);
-            __syncthreads();                                  // Y: every PV wave is past its V reads
+            __syncthreads();                                  // Y (the S waves' K buffer turns over)
             FA_STAMP2(12);
-            if (tile < n_tiles) { stage_commit(Vs, LDV); if (tile + 1 < n_tiles) stage_load((tile + 1) * FA_TK, true); }
-            FA_STAMP2(13);
         }
         __syncthreads();                                      // 1 / l of every row is in LDS
         // ---- normalise, gate (attention.py:664-666 / decode.rs:4272-4280), store: accumulator rows 4 g .. 4 g + 3 are dims 32 (pw DBW + db) + 8 g + 4 khalf + 0..3
@@ -491,7 +525,7 @@ int kr_launch_pfm_gqa_flash(const KrPfmGqaArgs& a, int C, hipStream_t st) {
     const int TQ = FA_ROWS / G;
     dim3 grid((C + TQ - 1) / TQ, a.nkv);
     if (a.hd >= 128) {      // wave-specialised form (S waves / PV waves)
-        const size_t ldw = (size_t)FA_TK * (a.hd * 2 + 16) + (size_t)FA_TK * (a.hd * 2 + 64) + 2 * (size_t)FA_ROWS * (FA_TK * 2 + 16) + 3 * FA_ROWS * 4;
+        const size_t ldw = (size_t)FA_TK * (a.hd * 2 + 16) + 2 * (size_t)FA_TK * (a.hd * 2 + 64) + 2 * (size_t)FA_ROWS * (FA_TK * 2 + 16) + 3 * FA_ROWS * 4;
         const void* fnw = a.hd == 256 ? (a.kv_fp8 ? (const void*)kr_pfm_gqa_flashw_kernel<256, true> : (const void*)kr_pfm_gqa_flashw_kernel<256, false>)
                                       : (a.kv_fp8 ? (const void*)kr_pfm_gqa_flashw_kernel<128, true> : (const void*)kr_pfm_gqa_flashw_kernel<128, false>);
         if (kr_lds_optin(fnw, ldw) == 0) {

@@ -125,6 +125,11 @@ gguf)       # native-GGUF experts inside the decode step: parity tests, decode t
     timeout 900 python -m pytest tests/test_gguf_gpu.py tests/test_decode_gpu.py -q -x -k "gguf" 2>&1 | tail -4
     timeout 600 python tools/probes/gguf_decode_bench.py 30 2>&1 | grep decode
     ;;
+ks)         # kernel table of the tolerance prompt pass at a given length
+    P=${1:-49863}
+    kstats r04_prefill_${P}_attn_fast_gemm_fast "QCN prompt pass, KR_ATTN_FAST | KR_GEMM_FAST, $P tokens (tools/probes/prefill_profile.py $P 2)" -- python /root/repo/tools/probes/prefill_profile.py $P 2
+    rm -rf $R/prof_*
+    ;;
 tl)         # concurrency view of the tolerance prompt pass: which kernels own the wall clock with three chunks in flight
     P=${1:-8192}
     rm -rf $R/prof_tl

@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
         const double flop = 4.0 * C * nh * (double)(pos0 + C / 2) * hd;
         printf("rep %d: %.1f us, %.0f TFLOP/s | S wave, tile 40: barrier X %.2f | S^T %.2f | softmax + P store %.2f | barrier Y %.2f | K commit + loads %.2f | tile %.2f us\n",
                rep, ms * 1e3, flop / (ms * 1e-3) / 1e12, d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(0, 5));
-        printf("        PV wave, tile 40: barrier X %.2f | rescale + P.V %.2f | barrier Y %.2f | V commit + loads %.2f | tile %.2f us\n", d(8, 9), d(9, 11), d(11, 12), d(12, 13), d(8, 13));
+        printf("        PV wave, tile 40: barrier X %.2f | fragment requests + V commit + loads %.2f | rescale + P.V %.2f | barrier Y %.2f | tile %.2f us\n", d(8, 9), d(9, 10), d(10, 11), d(11, 12), d(8, 12));
     }
     return 0;
 }
