@@ -142,7 +142,8 @@ tl)         # concurrency view of the tolerance prompt pass: which kernels own t
     ;;
 r4final)    # round 4 closing run: the whole GPU suite as the driver runs it, the driver's bench line, PMC fetch pass + kernel trace of the decode step
     # (raw rocprof directories are removed on the box once summarised: gpurun merges at most 64 MiB back)
-    timeout 1800 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -5 | tee $R/r04_gpu_tests_tail.txt
+    timeout 1800 python -m pytest tests/ -x -q -m gpu > $R/r04_gpu_tests_full.txt 2>&1; echo "pytest rc=$?"
+    grep -E " passed| failed| error|skipped" $R/r04_gpu_tests_full.txt | tail -3 | tee $R/r04_gpu_tests_tail.txt
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r04_bench_line.json 2> $R/r04_bench_line.err; echo "bench rc=$?"; tail -c 400 $R/r04_bench_line.err
     python tools/bench_summary.py $R/r04_bench_line.json
     rm -rf $R/pmc_fast
@@ -151,6 +152,12 @@ r4final)    # round 4 closing run: the whole GPU suite as the driver runs it, th
     head -14 $R/r04_decode_fast_pmc_fetch_size.txt
     kstats r04_decode_fast "QCN Q4 decode step, KR_DECODE_FAST, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only fast --steps 30)" -- \
         python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r04_decode_fast_prof
+    kstats r04_prefill_8192_attn_fast_gemm_fast "QCN prompt pass, KR_ATTN_FAST | KR_GEMM_FAST, 8192 tokens (tools/probes/prefill_profile.py 8192 2)" -- python /root/repo/tools/probes/prefill_profile.py 8192 2 > /dev/null
+    kstats r04_prefill_49863_attn_fast_gemm_fast "QCN prompt pass, KR_ATTN_FAST | KR_GEMM_FAST, 49863 tokens (tools/probes/prefill_profile.py 49863 2)" -- python /root/repo/tools/probes/prefill_profile.py 49863 2 > /dev/null
+    (echo "# tools/probes/flash_timing (1024 queries at the end of a 32768-position E4M3 cache, QCN heads), then the same at 8192 positions"; timeout 120 tools/probes/flash_timing; timeout 120 tools/probes/flash_timing 8192) > $R/r04_flash_timing.txt 2>&1
+    (echo "# tools/probes/lac_timing 2752 / 8192 (chunked gated delta rule, 32 heads): correctness against the per-token recurrence in double, launch times, phases of a prep workgroup and a scan step"; timeout 120 tools/probes/lac_timing 2752; timeout 120 tools/probes/lac_timing 8192) > $R/r04_lac_timing.txt 2>&1
+    (echo "# tools/probes/clock_probe: MFMA 32x32x16 f16 issue rate and shader clock, one workgroup / every CU"; timeout 60 tools/probes/clock_probe) > $R/r04_clock_probe.txt 2>&1
+    tail -3 $R/r04_flash_timing.txt | cut -c1-200
     rm -rf $R/prof_* $R/pmc_* $R/*.log
     ;;
 r4c)        # round 4: lean select, MLA tolerance wiring, tolerance router logits, GGUF gate fuse -- their tests, then decode / prompt-pass timings
