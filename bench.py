@@ -588,7 +588,7 @@ def side_config(name, rank, local_rank, args, torch):
             st.set_attention_mode(False, decode_fast=True)
             dtf = time_decode(st, steps, args.warmup, dims["kv_max_seq"], torch, None, 1)
             res["decode_fast_tok_s"] = steps / dtf; res["decode_fast_frac_of_hbm_peak"] = tot * (steps / dtf) / 1e9 / HBM_PEAK_GBS
-            res["decode_fast_note"] = "KR_DECODE_FAST around the GGUF layers: attention / projection launches in the tolerance form, the expert block kernels stay exact"
+            res["decode_fast_note"] = "KR_DECODE_FAST: the routed slots of the mode's gate|up and down launches walk the native GGUF blocks (the block kernels' products on per-32 INT16 activations, a row's blocks split over two waves; select, libm SiLU and the weighted combine folded in), the shared expert keeps its transposed INT4 form"
             st.set_attention_mode(False)
         except Exception as ex:
             res["decode_tok_s"] = {"error": repr(ex)}

@@ -722,7 +722,44 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
                     }
                 }
             }
-            // KR_DECODE_FAST around a native-GGUF layer: the mode's norm + gate GEMV launch and the stand-alone select in front of the (exact) block kernels
+            // KR_DECODE_FAST on a native-GGUF layer: the same three launches as for transposed experts -- the routed slots of the gate|up and down launches walk the
+            // GGUF blocks (kr_gguf_dev.h: the block kernels' products, a row's blocks split over two waves), the shared expert keeps its transposed form
+            if (!moe_done && fast && EL.gguf && src.mode != 2) {
+                const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
+                KrFmoeArgs fa{}; KrMoeArgs& a = fa.m;
+                fa.gguf = 1; fa.ggate = EL.g_gate.view(); fa.gup = EL.g_up.view(); fa.gdown = EL.g_down.view(); fa.act_f32 = (const float*)s->hid2.p;
+                a.shared_decode = 1; a.act_img = s->img_post.p; a.act_img_bf16 = s->img_post_bf16.p;
+                a.ids = (const int32_t*)s->r_ids.p; a.wts = (const float*)s->r_w.p;
+                a.B = 1; a.topk = s->topk; a.n_slots = s->topk + (has_shared ? 1 : 0); a.E = e->cfg.n_routed_experts; a.H = H; a.I = EL.inter;
+                if (has_shared) { a.sw13 = mv(s, L.sgu_wid); a.sw2 = mv(s, L.sd_wid); a.I_shared = s->weights[L.sgu_wid]->rows / 2; }
+                const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
+                a.gu_ld = 2 * imax; a.gu = (float*)s->moe_gu.p; a.eo = (float*)s->moe_eo.p;
+                a.rsf = s->rsf; a.swiglu_limit = e->cfg.swiglu_limit; a.alpha = e->cfg.activation_alpha;
+                a.act_mode = e->cfg.swiglu_limit > 0.0f ? KR_ACT_GPTOSS : KR_ACT_SILU_FUSED;
+                bool ok = e->r_ne == e->cfg.n_routed_experts;
+                if (has_gate) {
+                    if (mv(s, L.sg_wid).bits == a.sw13.bits) { a.sgate = mv(s, L.sg_wid); a.gate_out = (float*)s->gate_val.p; }
+                    else ok = false;
+                }
+                fa.logits = (const float*)s->r_logits.p; fa.esc = EL.has_esc ? (const float*)EL.esc.p : nullptr; fa.scoring = s->scoring; fa.norm_topk = s->norm_topk;
+                fa.hid_out = hid;
+                if (ok && kr_fmoe_check(fa) == 0) {
+                    KrFrtArgs ra{};
+                    ra.gate_cm = EL.gate_cm.p; ra.gate_bf16 = EL.gate_bf16_exact; ra.bias = EL.has_bias ? (const float*)EL.bias.p : nullptr; ra.logits = (float*)s->r_logits.p;
+                    ra.E = e->r_ne; ra.H = H; ra.hid_in = hid; ra.res_in = res_cur; ra.norm_w = (const float*)s->norms[L.post_norm]->p; ra.hid_out = (float*)s->hid2.p;
+                    ra.res_out = other(res_cur); ra.eps = s->eps; ra.bias_one = s->norm_bias_one; ra.img_f32 = s->img_post.p; ra.img_bf16 = s->img_post_bf16.p;
+                    prof_mark(s, PK_ROUTE_LOGITS, st);
+                    const int rc = kr_launch_frt(ra, st);
+                    prof_mark(s, -1, st);
+                    if (rc == 0) {
+                        prof_mark(s, PK_MOE_W13, st); const int r13 = kr_launch_fw13(fa, st); prof_mark(s, -1, st);
+                        prof_mark(s, PK_MOE_W2, st); const int r2 = kr_launch_fw2(fa, st); prof_mark(s, -1, st);
+                        if (r13 || r2) return kr_fail(KR_ERR_STATE, "internal: KR_DECODE_FAST expert launch refused after kr_fmoe_check accepted GGUF layer %zu", li);
+                        res_cur = other(res_cur); src = from_hidden; moe_done = true;
+                    }
+                }
+            }
+            // ... and, for GGUF geometries those launches do not cover: the mode's norm + gate GEMV launch and the stand-alone select in front of the (exact) block kernels
             if (!moe_done && fast && EL.gguf && src.mode != 2) {
                 KrFrtArgs ra{};
                 ra.gate_cm = EL.gate_cm.p; ra.gate_bf16 = EL.gate_bf16_exact; ra.bias = EL.has_bias ? (const float*)EL.bias.p : nullptr; ra.logits = (float*)s->r_logits.p;

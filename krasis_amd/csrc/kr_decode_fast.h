@@ -19,6 +19,7 @@
 
 #include "kr_decode_ops.h"
 #include "kr_kernels.h"
+#include "kr_gguf.h"
 
 struct KrFdmArgs {
     KrMultiMat mm;
@@ -52,6 +53,9 @@ struct KrFmoeArgs {
     KrMoeArgs m;              // B == 1, act_img / act_img_bf16 set, ids / wts = OUTPUT of the w13 launch (read by the w2 launch), gu = expert hidden [n_slots][gu_ld]
     const float* logits; const float* esc; int scoring, norm_topk;
     float* hid_out;           // w2 launch: combined MoE output [H]
+    int gguf;                 // the ROUTED experts are native GGUF blocks (ggate / gup / gdown: Q4_K, Q8_0 or Q4_0 with K % 32 == 0): m.w13 / m.w2 are unset, the shared expert
+    GgMat ggate, gup, gdown;  // (m.sw13 / m.sw2, transposed INT4 / INT8) keeps the path above.  Per-32 INT16 activations of bf16(act_f32) (gguf_kernels.rs:110-172), the
+    const float* act_f32;     // block kernels' products (kr_gguf_dev.h) with a row's blocks split over two waves, libm SiLU (gguf_kernels.rs:733-737)
     int shared_skip;          // expert-parallel decode (m.e_hi > 0): the shared expert of this layer is evaluated by another rank; this rank's hid_out is then its PARTIAL
                               // rsf * sum over its own slots (+ the shared term on the one rank that evaluates it) and the ranks' partials are summed by one all-reduce of [H]
 };

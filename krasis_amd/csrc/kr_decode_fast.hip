@@ -9,6 +9,7 @@
 // 6 launches per linear-attention MoE layer (7 before), none of them a single-workgroup kernel.
 // The exact kernels stay the default and the yardstick: tests/test_decode_fast_gpu.py states and checks the tolerances.
 #include "kr_decode_fast.h"
+#include "kr_gguf_dev.h"
 
 #include "kr_device.h"
 #include "kr_libm.h"
@@ -626,11 +627,23 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
     const int tw = wave >> 1, ks = wave & 1;
     const KrActLds L = kr_carve_lds(kr_fsm, a.H, BITS == 8);
+    const bool gg = fa.gguf && !shared;                  // routed slot on native GGUF blocks: per-32 activation image instead of the per-128 one
+    const GgAct GA = gg_carve(reinterpret_cast<char*>(kr_fsm), a.H);
+    const size_t img_bytes = fa.gguf ? (kr_lds_bytes(a.H, BITS == 8) > gg_lds_bytes(a.H, false) ? kr_lds_bytes(a.H, BITS == 8) : gg_lds_bytes(a.H, false)) : kr_lds_bytes(a.H, BITS == 8);
     KR_FSTAMP(4, 0);
     if (shared) kr_f_image_copy<BITS>(a.act_img, a.H, kr_fsm, L, t, 256);
-    else if (wave > 0) kr_f_image_copy<BITS>(a.act_img_bf16, a.H, kr_fsm, L, t - 64, 192);
-    else {
-        float* selsm = reinterpret_cast<float*>(reinterpret_cast<char*>(kr_fsm) + kr_lds_bytes(a.H, BITS == 8));
+    else if (wave > 0) {
+        if (gg) {      // quantize_bf16_to_int16 of bf16(hidden) (gguf_kernels.rs:110, decode.rs:3307-3309), 8 values per thread, 4 consecutive lanes per sub-block
+            for (int c = t - 64; c < a.H / 8; c += 192) {
+                float v[8];
+                kr_load8(fa.act_f32, c, v);
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = kr_bf16_to_f32(kr_f32_to_bf16(v[i]));
+                gg_quant_store(v, c, GA);
+            }
+        } else kr_f_image_copy<BITS>(a.act_img_bf16, a.H, kr_fsm, L, t - 64, 192);
+    } else {
+        float* selsm = reinterpret_cast<float*>(reinterpret_cast<char*>(kr_fsm) + img_bytes);
         const int nv = (a.E + 63) / 64;
         if (nv <= 1) kr_f_select<1>(fa.logits, fa.esc, a.E, a.topk, fa.scoring, fa.norm_topk, selsm, s_ids, s_w);
         else if (nv <= 2) kr_f_select<2>(fa.logits, fa.esc, a.E, a.topk, fa.scoring, fa.norm_topk, selsm, s_ids, s_w);
@@ -643,6 +656,25 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
     KR_FSTAMP(4, 1);
     __syncthreads();
     KR_FSTAMP(4, 2);
+    if (gg) {
+        // ---- native GGUF blocks: tile pair (gate tile `unit`, up tile `unit`) of expert e, the row's blocks split over the two k-waves
+        int e = s_ids[slot];
+        if (a.e_hi > 0) { if (e < a.e_lo || e >= a.e_hi) return; e -= a.e_sub; }
+        const GgMat gm = gg_expert_mat(fa.ggate, e), um = gg_expert_mat(fa.gup, e);
+        const int ntp = gm.N / 8, unit = blockIdx.x * TW + tw;
+        float ag = 0.0f, au = 0.0f;
+        if (unit < ntp) {
+            if (gm.type == GG_Q4_K) ag = gg_tile_q4k(gm, unit, GA, lane, ks, KS); else if (gm.type == GG_Q8_0) ag = gg_tile_q8_0(gm, unit, GA, lane, ks, KS); else ag = gg_tile_q4_0(gm, unit, GA, lane, ks, KS);
+            if (um.type == GG_Q4_K) au = gg_tile_q4k(um, unit, GA, lane, ks, KS); else if (um.type == GG_Q8_0) au = gg_tile_q8_0(um, unit, GA, lane, ks, KS); else au = gg_tile_q4_0(um, unit, GA, lane, ks, KS);
+        }
+        if (l8 == 0) { s_x[tw][ks][0][cl] = ag; s_x[tw][ks][1][cl] = au; }
+        __syncthreads();
+        if (ks == 0 && l8 == 0 && unit < ntp) {
+            const float g = s_x[tw][0][0][cl] + s_x[tw][1][0][cl], u = s_x[tw][0][1][cl] + s_x[tw][1][1][cl];
+            a.gu[(size_t)slot * a.gu_ld + unit * 8 + cl] = (g / (1.0f + kr_expf(-g))) * u;      // gguf_kernels.rs:733-737
+        }
+        return;
+    }
     const KrMatDev& m = shared ? a.sw13 : a.w13;
     const void* qb = m.q; const uint32_t* sb = m.s;
     const int inter = shared ? a.I_shared : a.I;
@@ -702,21 +734,40 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     KR_FSTAMP(5, 0);
     const float sig = a.gate_out ? a.gate_out[0] : 1.0f;     // sigmoid(gate row) of the shared expert, formed by the gate|up launch
     const bool shared = slot >= a.topk;
-    const KrMatDev& m = shared ? a.sw2 : a.w2;
+    const bool gg = fa.gguf && !shared;
+    const KrMatDev& m = (shared || fa.gguf) ? a.sw2 : a.w2;      // (a GGUF slot never reads m: the shared expert's matrix stands in so that the fields are defined)
     const int inter = shared ? a.I_shared : a.I;
     const void* qb = m.q; const uint32_t* sb = m.s;
     bool valid = true; float wt = 1.0f;
     bool skip = false;        // expert-parallel decode: slot evaluated by another rank -- this wave contributes 0 and reads no weights
+    size_t ee = 0;
     if (!shared) {
         int e = a.ids[slot];
         valid = e >= 0 && e < a.E; wt = a.wts[slot];
         if (a.e_hi > 0) { skip = !valid || e < a.e_lo || e >= a.e_hi; e -= a.e_sub; }
-        const size_t ee = valid && !skip ? (size_t)e : 0;
-        qb = reinterpret_cast<const char*>(m.q) + ee * m.q_stride;
-        sb = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + ee * m.s_stride);
+        ee = valid && !skip ? (size_t)e : 0;
+        if (!gg) {
+            qb = reinterpret_cast<const char*>(m.q) + ee * m.q_stride;
+            sb = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(m.s) + ee * m.s_stride);
+        }
     } else skip = fa.shared_skip != 0;
+    if (gg) {
+        // ---- native GGUF down projection: per-32 INT16 image of the hidden (f32::round, gguf_kernels.rs:143), the block kernel's row tile, result into the combine below
+        const GgAct GA = gg_carve(reinterpret_cast<char*>(kr_fsm) + (size_t)slot * slot_lds, inter);
+        const float* hg = a.gu + (size_t)slot * a.gu_ld;
+        float accg = 0.0f;
+        if (!skip && valid) {
+            for (int c = lane; c < inter / 8; c += 64) { float v[8]; kr_load8(hg, c, v); gg_quant_store(v, c, GA); }
+            kr_f_wave_sync();
+            const GgMat dm = gg_expert_mat(fa.gdown, (int)ee);
+            accg = dm.type == GG_Q4_K ? gg_tile_q4k(dm, tile, GA, lane) : dm.type == GG_Q8_0 ? gg_tile_q8_0(dm, tile, GA, lane) : gg_tile_q4_0(dm, tile, GA, lane);
+        }
+        if (l8 == 0) s_y[slot][cl] = accg;
+        if (lane == 0) s_wt[slot] = valid ? wt : 0.0f;
+    }
     const int units = BITS == 4 ? m.ngp : m.ng;
     KrFw<BITS, NU, 8> W;     // 16 waves per workgroup leave 128 registers per lane: the guarded form keeps 8 records in flight
+    if (gg) skip = true;     // handled above: the rest of the slot's work is the barrier and the combine
     if (!skip) kr_f_fetch<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units);
     const KrActLds L = kr_carve_lds(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(kr_fsm) + (size_t)slot * slot_lds), inter, BITS == 8);
     const float* h = a.gu + (size_t)slot * a.gu_ld;
@@ -740,8 +791,10 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     KR_FSTAMP(5, 2);
     const float acc = skip ? 0.0f : kr_f_tile<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units, L);
     KR_FSTAMP(5, 3);
-    if (l8 == 0) s_y[slot][cl] = acc;
-    if (lane == 0) s_wt[slot] = valid ? wt : 0.0f;
+    if (!gg) {
+        if (l8 == 0) s_y[slot][cl] = acc;
+        if (lane == 0) s_wt[slot] = valid ? wt : 0.0f;
+    }
     if (t >= a.n_slots && t < 16) s_wt[t] = 0.0f;
     __syncthreads();
     KR_FSTAMP(5, 4);
@@ -836,6 +889,15 @@ static bool kr_fmoe_ok(const KrFmoeArgs& fa) {
     const KrMoeArgs& a = fa.m;
     const bool has_shared = a.n_slots > a.topk;
     if (a.B != 1 || a.n_slots > 16 || a.topk > 15 || a.E > 512 || a.act_mode != KR_ACT_SILU_FUSED) return false;
+    if (fa.gguf) {      // routed experts on native GGUF blocks: the integer block kernels only, a transposed shared expert (if any) of one bit width
+        auto ok_mat = [&](const GgMat& g, int K, int N) { return (g.type == GG_Q4_K ? K % 256 == 0 : ((g.type == GG_Q8_0 || g.type == GG_Q4_0) && K % 32 == 0)) && g.K == K && g.N == N && N % 8 == 0; };
+        if (!fa.act_f32 || !ok_mat(fa.ggate, a.H, a.I) || !ok_mat(fa.gup, a.H, a.I) || !ok_mat(fa.gdown, a.I, a.H) || a.H % 128) return false;
+        if (has_shared) {
+            if (!a.act_img || a.sw13.bits != a.sw2.bits || a.I_shared % 128 || a.sw13.ng * 128 != a.H || a.sw2.ng * 128 != a.I_shared) return false;
+            if (a.sgate.q && (a.sgate.bits != a.sw13.bits || a.sgate.ng != a.sw13.ng || !a.gate_out)) return false;
+        }
+        return true;
+    }
     if (!a.act_img || !a.act_img_bf16 || a.H % 128 || a.I % 128) return false;
     if (a.w13.ng * 128 != a.H || a.w2.ng * 128 != a.I) return false;
     if (has_shared) {
@@ -845,13 +907,20 @@ static bool kr_fmoe_ok(const KrFmoeArgs& fa) {
     return true;
 }
 
-int kr_fmoe_check(const KrFmoeArgs& fa) {
-    if (!kr_fmoe_ok(fa)) return 1;
+// dynamic LDS of one slot of the down + combine launch: the larger of the two activation images a slot may build (per-128 transposed form / per-32 GGUF form)
+static size_t kr_fw2_slot_lds(const KrFmoeArgs& fa) {
     const KrMoeArgs& a = fa.m;
     const bool has_shared = a.n_slots > a.topk;
     const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
+    size_t n = fa.gguf ? (has_shared ? kr_lds_bytes(a.I_shared, a.sw2.bits == 8) : 0) : kr_lds_bytes(imax, a.w2.bits == 8);
+    if (fa.gguf) { const size_t g = (gg_lds_bytes(a.I, false) + 15) & ~(size_t)15; if (g > n) n = g; }
+    return n;
+}
+int kr_fmoe_check(const KrFmoeArgs& fa) {
+    if (!kr_fmoe_ok(fa)) return 1;
+    const KrMoeArgs& a = fa.m;
     // kr_fw2_kernel takes slot_lds * n_slots of dynamic LDS and no opt-in is made for it: past the 64 KiB every kernel may use the layer falls back to the exact MoE kernels
-    return kr_lds_bytes(imax, a.w2.bits == 8) * a.n_slots > KR_FW2_LDS_MAX ? 1 : 0;
+    return kr_fw2_slot_lds(fa) * a.n_slots > KR_FW2_LDS_MAX ? 1 : 0;
 }
 
 int kr_launch_fw13(const KrFmoeArgs& fa, hipStream_t st) {
@@ -861,12 +930,16 @@ int kr_launch_fw13(const KrFmoeArgs& fa, hipStream_t st) {
     int ntp = a.I / 8;
     if (has_shared && a.I_shared / 8 + (a.sgate.q ? 1 : 0) > ntp) ntp = a.I_shared / 8 + (a.sgate.q ? 1 : 0);
     dim3 grid((ntp + 1) / 2, a.n_slots);
-    const size_t lds = kr_lds_bytes(a.H, a.w13.bits == 8) + (size_t)(2 * a.E + 33 + 33 + 32 + 32 + 4 + 128) * 4;
-    const int units = a.w13.bits == 4 ? a.w13.ngp : a.w13.ng;
-    const bool even = (a.w13.bits == 8 || (a.w13.ng % 2) == 0) && units % 2 == 0;
+    const KrMatDev& wm = fa.gguf ? a.sw13 : a.w13;      // GGUF routed experts: the template follows the (transposed) shared expert; INT4 form when there is none
+    const int wbits = fa.gguf && !has_shared ? 4 : wm.bits;
+    size_t img = kr_lds_bytes(a.H, wbits == 8);
+    if (fa.gguf && gg_lds_bytes(a.H, false) > img) img = gg_lds_bytes(a.H, false);
+    const size_t lds = img + (size_t)(2 * a.E + 33 + 33 + 32 + 32 + 4 + 128) * 4;
+    const int units = fa.gguf && !has_shared ? 0 : (wbits == 4 ? wm.ngp : wm.ng);
+    const bool even = !fa.gguf && (a.w13.bits == 8 || (a.w13.ng % 2) == 0) && units % 2 == 0;
     const int nu = even ? units / 2 : 0;
 #define KR_FW13(B_, N_) hipLaunchKernelGGL((kr_fw13_kernel<B_, N_>), grid, dim3(256), lds, st, fa)
-    if (a.w13.bits == 4) { if (nu == 4) KR_FW13(4, 4); else if (nu == 8) KR_FW13(4, 8); else KR_FW13(4, 0); }
+    if (wbits == 4) { if (nu == 4) KR_FW13(4, 4); else if (nu == 8) KR_FW13(4, 8); else KR_FW13(4, 0); }
     else { if (nu == 8) KR_FW13(8, 8); else KR_FW13(8, 0); }
 #undef KR_FW13
     return 0;
@@ -876,16 +949,16 @@ int kr_launch_fw2(const KrFmoeArgs& fa, hipStream_t st) {
     if (!kr_fmoe_ok(fa)) return 1;
     const KrMoeArgs& a = fa.m;
     const bool has_shared = a.n_slots > a.topk;
-    const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
-    const size_t slot_lds = kr_lds_bytes(imax, a.w2.bits == 8);
+    const size_t slot_lds = kr_fw2_slot_lds(fa);
     if (slot_lds * a.n_slots > KR_FW2_LDS_MAX) return 1;
     dim3 grid((a.H + 7) / 8);
     // exact unit count (no guards) when every slot has the same, even, group count
-    const int units = a.w2.bits == 4 ? a.w2.ngp : a.w2.ng;
-    const bool uniform = (!has_shared || a.I_shared == a.I) && (a.w2.bits == 8 || a.w2.ng % 2 == 0);
+    const int wbits = fa.gguf ? (has_shared ? a.sw2.bits : 4) : a.w2.bits;
+    const int units = fa.gguf ? 0 : (a.w2.bits == 4 ? a.w2.ngp : a.w2.ng);
+    const bool uniform = !fa.gguf && (!has_shared || a.I_shared == a.I) && (a.w2.bits == 8 || a.w2.ng % 2 == 0);
     const int nu = uniform && (units == 2 || units == 4 || units == 8) ? units : 0;
 #define KR_FW2(B_, N_) hipLaunchKernelGGL((kr_fw2_kernel<B_, N_>), grid, dim3(64 * a.n_slots), slot_lds * a.n_slots, st, fa, (int)slot_lds)
-    if (a.w2.bits == 4) { if (nu == 2) KR_FW2(4, 2); else if (nu == 4) KR_FW2(4, 4); else if (nu == 8) KR_FW2(4, 8); else KR_FW2(4, 0); }
+    if (wbits == 4) { if (nu == 2) KR_FW2(4, 2); else if (nu == 4) KR_FW2(4, 4); else if (nu == 8) KR_FW2(4, 8); else KR_FW2(4, 0); }
     else { if (nu == 4) KR_FW2(8, 4); else if (nu == 8) KR_FW2(8, 8); else KR_FW2(8, 0); }
 #undef KR_FW2
     return 0;

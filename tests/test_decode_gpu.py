@@ -142,8 +142,9 @@ def test_decode_step_on_native_gguf_experts_bit_exact(dims, graph, fast):
     the V2-Lite and QCN situations).  The reference drives such layers per layer from Python through moe_forward_gguf (moe.rs:990-1110,
     tests/test_gguf_native.py:47-57); the oracle driver is that control flow.  Inside the captured step: router, k routed experts through the block
     kernels on bf16(hidden) (decode.rs:3307), the decode store's shared expert on the f32 hidden, combine in routing order in the next norm launch.
-    Logits, greedy token and every state tensor BIT FOR BIT, graph and eager; with KR_DECODE_FAST set the GGUF layers keep these exact kernels (the
-    mode's attention / projection kernels run around them): logits within the mode's 2e-3, same greedy token."""
+    Logits, greedy token and every state tensor BIT FOR BIT, graph and eager; with KR_DECODE_FAST set the routed slots of the mode's gate|up and down launches
+    walk the GGUF blocks (the block kernels' products, a row's blocks split over two waves, select and combine folded in): logits within the mode's 2e-3,
+    same greedy token."""
     st, eng, orc, keep, d = build(dims=dims, gguf=True, seed=21)
     st.set_use_graph(graph)
     if fast:

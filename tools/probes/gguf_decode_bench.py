@@ -19,5 +19,5 @@ for name in ("qcn-q4k-gguf", "v2lite-q4k-gguf"):
         r = bench.side_config(name, 0, 0, args, torch)
     finally:
         bench.prefill_model = orig
-    print("%s: decode %.1f tok/s (%.3f ms/step, %.3f of the HBM peak for %.2f GB/token), KR_DECODE_FAST around the GGUF layers %.1f tok/s" % (
+    print("%s: decode %.1f tok/s (%.3f ms/step, %.3f of the HBM peak for %.2f GB/token), KR_DECODE_FAST (routed slots on the GGUF blocks inside the mode's three MoE launches) %.1f tok/s" % (
         name, r["decode_tok_s"], r["ms_per_step"], r["step_frac_of_hbm_peak"], r["step_algorithmic_bytes"] / 1e9, r["decode_fast_tok_s"]), flush=True)
