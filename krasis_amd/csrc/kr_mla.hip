@@ -419,6 +419,86 @@ __global__ void __launch_bounds__(128) kr_mla_wvc_kernel(KrMlaArgs a) {
     if ((t & 15) == 0) a.v_proj[(size_t)h * a.vhd + o] = v;
 }
 
+// ---- KR_DECODE_FAST forms of launches 1 and 3 (decode only): the same products, tree sums ------------------------------------------------------------
+// The exact prep launch gives an output ONE thread that walks nd = 128 weights with a stride of klr (the reference's chain), 128 waves in all for 4 MB of
+// f32 weights per layer, and its latent RMSNorm is a 512-term sum on one lane; the exact w_vc launch reads 2-KB weight rows 64 bytes at a time with 16 lanes
+// per output.  8.3 + 9.4 us per layer, more than the mode's expert launches.  Here: absorption -- a workgroup per (head, 64 outputs), its four waves take a
+// quarter of the k range each (32 coalesced row reads in flight per lane), partial sums meet in LDS; the norm's sum of squares is a workgroup tree; w_vc --
+// a wave per TWO output rows, a row is one 2-KB sweep of the wave (two 16-byte reads per lane), wave tree per row.
+__global__ void __launch_bounds__(256) kr_mla_prep_fast_kernel(KrMlaArgs a) {
+    __shared__ float sh[4][64];
+    __shared__ float xs[640];
+    const int pos = a.step->pos;
+    const int tiles = a.klr / 64, nb_abs = a.nh * tiles, hd = a.nd + a.rd, half = a.rd / 2;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    if ((int)blockIdx.x < nb_abs) {
+        const int h = blockIdx.x / tiles, jt = blockIdx.x % tiles, j = jt * 64 + lane;
+        const float* qh = a.q_full + (size_t)h * hd;
+        const int per = (a.nd + 3) / 4, i0 = wave * per, i1 = i0 + per < a.nd ? i0 + per : a.nd;
+        const float* w = a.w_kc + (size_t)h * a.nd * a.klr + j;
+        float o = 0.0f;
+        for (int i = i0; i < i1; i += 16) {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) wv[u] = __builtin_nontemporal_load(w + (size_t)(i + u < i1 ? i + u : i1 - 1) * a.klr);
+#pragma unroll
+            for (int u = 0; u < 16; u++) if (i + u < i1) o = __builtin_fmaf(qh[i + u], wv[u], o);
+        }
+        sh[wave][lane] = o;
+        __syncthreads();
+        if (wave == 0) a.q_abs[(size_t)h * a.klr + j] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        if (jt == 0 && t < half) {   // decode.rs:3113-3128
+            const float x1 = qh[a.nd + 2 * t], x2 = qh[a.nd + 2 * t + 1];
+            const float c = a.rope_cos[(size_t)pos * half + t], s = a.rope_sin[(size_t)pos * half + t];
+            a.q_pe[(size_t)h * a.rd + t] = x1 * c - x2 * s;
+            a.q_pe[(size_t)h * a.rd + half + t] = x2 * c + x1 * s;
+        }
+        return;
+    }
+    // ---- compressed KV: RMSNorm (tree sum of squares), k_pe de-interleave + RoPE, cache append at `pos`
+    float ss = 0.0f;
+    for (int i = t; i < a.klr; i += 256) { const float v = a.kv_out[i]; xs[i] = v; ss += v * v; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) sh[0][wave] = ss;
+    __syncthreads();
+    const float rms = 1.0f / sqrtf(((sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3])) / (float)a.klr + a.eps);
+    for (int i = t; i < a.klr; i += 256) {
+        const float v = xs[i] * (rms * a.kv_a_norm[i]);
+        if (a.kv_fp8) kr_mla_st<true>(a.ckv_cache, (size_t)pos * a.klr + i, v); else kr_mla_st<false>(a.ckv_cache, (size_t)pos * a.klr + i, v);
+    }
+    if (t < half) {
+        const float x1 = a.kv_out[a.klr + 2 * t], x2 = a.kv_out[a.klr + 2 * t + 1];
+        const float c = a.rope_cos[(size_t)pos * half + t], s = a.rope_sin[(size_t)pos * half + t];
+        if (a.kv_fp8) { kr_mla_st<true>(a.kpe_cache, (size_t)pos * a.rd + t, x1 * c - x2 * s); kr_mla_st<true>(a.kpe_cache, (size_t)pos * a.rd + half + t, x2 * c + x1 * s); }
+        else { kr_mla_st<false>(a.kpe_cache, (size_t)pos * a.rd + t, x1 * c - x2 * s); kr_mla_st<false>(a.kpe_cache, (size_t)pos * a.rd + half + t, x2 * c + x1 * s); }
+    }
+}
+// v_projected[h][o] = w_vc[h][o][:] . attn_lat[h][:]     grid (vhd / 8, nh), 256 threads: wave w takes rows 2 w, 2 w + 1 of the workgroup's eight
+__global__ void __launch_bounds__(256) kr_mla_wvc_fast_kernel(KrMlaArgs a) {
+    const int h = blockIdx.y, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const float* lat = a.attn_lat + (size_t)h * a.klr;
+    const int nchunk = a.klr / 4;                            // float4 chunks of a row
+    float acc[2] = {0.0f, 0.0f};
+    const int o0 = blockIdx.x * 8 + wave * 2;
+    for (int c = lane; c < nchunk; c += 64) {
+        const float4 x = *reinterpret_cast<const float4*>(lat + 4 * c);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int o = o0 + r < a.vhd ? o0 + r : a.vhd - 1;
+            const float4 w = *reinterpret_cast<const float4*>(a.w_vc + ((size_t)h * a.vhd + o) * a.klr + 4 * c);
+            acc[r] = __builtin_fmaf(w.x, x.x, __builtin_fmaf(w.y, x.y, __builtin_fmaf(w.z, x.z, __builtin_fmaf(w.w, x.w, acc[r]))));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        float v = acc[r];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && o0 + r < a.vhd) a.v_proj[(size_t)h * a.vhd + o0 + r] = v;
+    }
+}
+
 // plain sequential RMSNorm (decode.rs:3053-3062, q_a_layernorm of the LoRA query path); one workgroup, in place
 __global__ void __launch_bounds__(256) kr_rmsnorm_seq_kernel(float* __restrict__ x, const float* __restrict__ w, int n, float eps, int ld) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -698,7 +778,9 @@ void kr_launch_mla(const KrMlaArgs& a_in, int max_seq, hipStream_t s, int n_tok)
     // ropes q_pe (one workgroup per head) and appends the latent / rope rows
     if (!a.step && n_tok >= 32 && kr_launch_mla_absorb_mfma(a.q_full, a.ld_q, a.nd + a.rd, a.nd, a.w_kc, a.klr, a.q_abs, n_tok, a.nh, s) == 0) a.absorb_done = 1;
     const int prep_blocks = a.nh * (a.absorb_done ? 1 : a.klr / 64) + 1;
-    if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_prep_kernel<true>, dim3(prep_blocks, n_tok), dim3(64), 0, s, a);
+    const bool dfast = a.step && a.decode_fast && n_tok == 1 && a.klr % 64 == 0 && a.klr <= 640 && a.klr % 4 == 0 && a.rd / 2 <= 256;      // tree-sum forms of the prep / w_vc launches
+    if (dfast) hipLaunchKernelGGL(kr_mla_prep_fast_kernel, dim3(prep_blocks), dim3(256), 0, s, a);
+    else if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_prep_kernel<true>, dim3(prep_blocks, n_tok), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(kr_mla_prep_kernel<false>, dim3(prep_blocks, n_tok), dim3(64), 0, s, a);
     if (a.fast && !a.step && kr_launch_mla_flash(a, n_tok, s) == 0) {
         // prompt pass, tolerance mode: one flash-attention launch streams the latent cache once per 64 (token, head) rows
@@ -720,6 +802,7 @@ void kr_launch_mla(const KrMlaArgs& a_in, int max_seq, hipStream_t s, int n_tok)
     // prompt pass: the w_vc projection of the whole chunk on the f32 MFMA (its two-accumulator dot is the router's 16-chain structure:
     // kr_route_mfma.hip), bit-identical to the per-token launch below
     if (!a.step && n_tok >= 32 && kr_launch_mla_wvc_mfma(a.w_vc, a.attn_lat, a.v_proj, n_tok, a.nh, a.vhd, a.klr, s) == 0) return;
+    if (dfast) { hipLaunchKernelGGL(kr_mla_wvc_fast_kernel, dim3((a.vhd + 7) / 8, a.nh), dim3(256), 0, s, a); return; }
     hipLaunchKernelGGL(kr_mla_wvc_kernel, dim3((a.vhd + 7) / 8, a.nh, n_tok), dim3(128), (size_t)a.klr * 4, s, a);
 }
 void kr_launch_rmsnorm_seq(float* x, const float* w, int n, float eps, hipStream_t s, int rows, int ld) {
