@@ -729,7 +729,11 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     const KrMoeArgs& a = fa.m;
     __shared__ float s_y[16][8];
     __shared__ __attribute__((aligned(16))) float s_wt[16];
-    const int t = threadIdx.x, slot = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
+    // A shared expert twice as wide as a routed one (DeepSeek: two shared experts fused) would make its one wave the workgroup's critical path: the launcher then
+    // adds a wave (blockDim = 64 (n_slots + 1)) and the two take half of the shared expert's groups each ("part"); their column sums meet in the combine.
+    const int t = threadIdx.x, vslot = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
+    const bool split = (int)blockDim.x > 64 * a.n_slots;
+    const int slot = vslot < a.n_slots ? vslot : a.topk, part = vslot < a.n_slots ? 0 : 1;
     const int tile = blockIdx.x;
     KR_FSTAMP(5, 0);
     const float sig = a.gate_out ? a.gate_out[0] : 1.0f;     // sigmoid(gate row) of the shared expert, formed by the gate|up launch
@@ -766,15 +770,18 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
         if (lane == 0) s_wt[slot] = valid ? wt : 0.0f;
     }
     const int units = BITS == 4 ? m.ngp : m.ng;
+    const bool halves = split && shared;                      // this wave walks units [u0, u1) of the shared expert and quantises the matching chunks of its hidden
+    const int u0 = halves && part ? units / 2 : 0, u1 = halves && !part ? units / 2 : units;
     KrFw<BITS, NU, 8> W;     // 16 waves per workgroup leave 128 registers per lane: the guarded form keeps 8 records in flight
     if (gg) skip = true;     // handled above: the rest of the slot's work is the barrier and the combine
-    if (!skip) kr_f_fetch<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units);
+    if (!skip) kr_f_fetch<BITS, NU, 8>(W, m, qb, sb, tile, lane, u0, u1);
     const KrActLds L = kr_carve_lds(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(kr_fsm) + (size_t)slot * slot_lds), inter, BITS == 8);
     const float* h = a.gu + (size_t)slot * a.gu_ld;
     KR_FSTAMP(5, 1);
     const bool half_away = shared && a.shared_decode;
+    const int cpu = (BITS == 4 ? 256 : 128) / 8;            // 8-value chunks per unit
     if (!skip)
-    for (int c = lane; c < inter / 8; c += 64) {
+    for (int c = u0 * cpu + lane; c < (u1 * cpu < inter / 8 ? u1 * cpu : inter / 8); c += 64) {
         float v[8];
         kr_load8(h, c, v);
         float mx = 0.0f;
@@ -789,11 +796,11 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     }
     kr_f_wave_sync();
     KR_FSTAMP(5, 2);
-    const float acc = skip ? 0.0f : kr_f_tile<BITS, NU, 8>(W, m, qb, sb, tile, lane, 0, units, L);
+    const float acc = skip ? 0.0f : kr_f_tile<BITS, NU, 8>(W, m, qb, sb, tile, lane, u0, u1, L);
     KR_FSTAMP(5, 3);
     if (!gg) {
-        if (l8 == 0) s_y[slot][cl] = acc;
-        if (lane == 0) s_wt[slot] = valid ? wt : 0.0f;
+        if (l8 == 0) s_y[part ? 15 : slot][cl] = acc;
+        if (lane == 0 && !part) s_wt[slot] = valid ? wt : 0.0f;
     }
     if (t >= a.n_slots && t < 16) s_wt[t] = 0.0f;
     __syncthreads();
@@ -810,6 +817,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
         if (a.rsf != 1.0f) o *= a.rsf;
         if (a.n_slots > a.topk) {
             float sh = s_y[a.topk][t];
+            if (split) sh += s_y[15][t];
             if (a.gate_out) sh *= sig;
             o = o + sh;
         }
@@ -956,9 +964,12 @@ int kr_launch_fw2(const KrFmoeArgs& fa, hipStream_t st) {
     const int wbits = fa.gguf ? (has_shared ? a.sw2.bits : 4) : a.w2.bits;
     const int units = fa.gguf ? 0 : (a.w2.bits == 4 ? a.w2.ngp : a.w2.ng);
     const bool uniform = !fa.gguf && (!has_shared || a.I_shared == a.I) && (a.w2.bits == 8 || a.w2.ng % 2 == 0);
-    const int nu = uniform && (units == 2 || units == 4 || units == 8) ? units : 0;
-#define KR_FW2(B_, N_) hipLaunchKernelGGL((kr_fw2_kernel<B_, N_>), grid, dim3(64 * a.n_slots), slot_lds * a.n_slots, st, fa, (int)slot_lds)
-    if (wbits == 4) { if (nu == 2) KR_FW2(4, 2); else if (nu == 4) KR_FW2(4, 4); else if (nu == 8) KR_FW2(4, 8); else KR_FW2(4, 0); }
+    const int nu = uniform && (units == 2 || units == 4 || units == 6 || units == 8) ? units : 0;      // (6: I = 1536, Qwen3-235B)
+    // shared expert at least twice as wide as the routed ones (and an even unit count): one more wave, the two halves of the shared expert side by side
+    const int sunits = has_shared ? (a.sw2.bits == 4 ? a.sw2.ngp : a.sw2.ng) : 0;
+    const bool split = has_shared && a.I_shared >= 2 * a.I && a.n_slots <= 15 && sunits >= 2 && sunits % 2 == 0 && !fa.shared_skip;
+#define KR_FW2(B_, N_) hipLaunchKernelGGL((kr_fw2_kernel<B_, N_>), grid, dim3(64 * (a.n_slots + (split ? 1 : 0))), slot_lds * a.n_slots, st, fa, (int)slot_lds)
+    if (wbits == 4) { if (nu == 2) KR_FW2(4, 2); else if (nu == 4) KR_FW2(4, 4); else if (nu == 6) KR_FW2(4, 6); else if (nu == 8) KR_FW2(4, 8); else KR_FW2(4, 0); }
     else { if (nu == 4) KR_FW2(8, 4); else if (nu == 8) KR_FW2(8, 8); else KR_FW2(8, 0); }
 #undef KR_FW2
     return 0;
