@@ -86,10 +86,10 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbit
         else:
             if gguf:      # routed experts as native GGUF blocks (Q4_K gate / up; down Q4_K when I % 256 == 0, else Q8_0 -- the V2-Lite situation): prompt pass only
                 from tests.test_gguf_gpu import make as make_gguf
-                dn_t = O.Q4_K if I % 256 == 0 else O.Q8_0
-                experts = [make_gguf(rng, H, I, O.Q4_K, dn_t) for _ in range(E)]
+                gu_t, dn_t = gguf if isinstance(gguf, tuple) else (O.Q4_K, O.Q4_K if I % 256 == 0 else O.Q8_0)
+                experts = [make_gguf(rng, H, I, gu_t, dn_t) for _ in range(E)]
                 for ei, ex in enumerate(experts):
-                    eng.load_gguf_expert(li, ei, ex.gate, ex.up, ex.down, O.Q4_K, dn_t, I)
+                    eng.load_gguf_expert(li, ei, ex.gate, ex.up, ex.down, gu_t, dn_t, I)
             else:
                 experts = make_experts(rng, E, H, I, wbits); upload(eng, li, experts)
             gate = ((rng.random((E, H)) - 0.5) * 0.1).astype(F); keep.append(gate)
@@ -135,17 +135,18 @@ def test_decode_step_bit_exact(cfg, graph):
             assert np.array_equal(kc, L["kv_k"]) and np.array_equal(vc, L["kv_v"])
 
 
-@pytest.mark.parametrize("dims", [(256, 512, 16, 4, 128, 128), (512, 512, 8, 2, 256, 128)])
+@pytest.mark.parametrize("dims,types", [((256, 512, 16, 4, 128, 128), True), ((512, 512, 8, 2, 256, 128), True), ((256, 512, 16, 4, 128, 128), (O.Q8_0, O.Q4_0)),
+                                        ((512, 512, 8, 2, 256, 128), (O.Q4_0, O.Q8_0))])
 @pytest.mark.parametrize("graph,fast", [(True, False), (False, False), (True, True)])
-def test_decode_step_on_native_gguf_experts_bit_exact(dims, graph, fast):
-    """kr_decode_step on a model whose ROUTED experts are native GGUF blocks (Q4_K gate / up; Q8_0 down at I = 128, Q4_K down at I = 256 --
-    the V2-Lite and QCN situations).  The reference drives such layers per layer from Python through moe_forward_gguf (moe.rs:990-1110,
+def test_decode_step_on_native_gguf_experts_bit_exact(dims, types, graph, fast):
+    """kr_decode_step on a model whose ROUTED experts are native GGUF blocks (Q4_K gate / up with Q8_0 down at I = 128 or Q4_K down at I = 256 --
+    the V2-Lite and QCN situations -- and Q8_0 / Q4_0 mixes, so every integer block kernel runs in both modes).  The reference drives such layers per layer from Python through moe_forward_gguf (moe.rs:990-1110,
     tests/test_gguf_native.py:47-57); the oracle driver is that control flow.  Inside the captured step: router, k routed experts through the block
     kernels on bf16(hidden) (decode.rs:3307), the decode store's shared expert on the f32 hidden, combine in routing order in the next norm launch.
     Logits, greedy token and every state tensor BIT FOR BIT, graph and eager; with KR_DECODE_FAST set the routed slots of the mode's gate|up and down launches
     walk the GGUF blocks (the block kernels' products, a row's blocks split over two waves, select and combine folded in): logits within the mode's 2e-3,
     same greedy token."""
-    st, eng, orc, keep, d = build(dims=dims, gguf=True, seed=21)
+    st, eng, orc, keep, d = build(dims=dims, gguf=types, seed=21)
     st.set_use_graph(graph)
     if fast:
         st.set_attention_mode(False, decode_fast=True)
