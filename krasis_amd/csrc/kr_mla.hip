@@ -437,12 +437,12 @@ __global__ void __launch_bounds__(256) kr_mla_prep_fast_kernel(KrMlaArgs a) {
         const int per = (a.nd + 3) / 4, i0 = wave * per, i1 = i0 + per < a.nd ? i0 + per : a.nd;
         const float* w = a.w_kc + (size_t)h * a.nd * a.klr + j;
         float o = 0.0f;
-        for (int i = i0; i < i1; i += 16) {
-            float wv[16];
+        for (int i = i0; i < i1; i += 32) {                  // 32 row reads in flight per lane: the whole slice of nd = 128
+            float wv[32];
 #pragma unroll
-            for (int u = 0; u < 16; u++) wv[u] = __builtin_nontemporal_load(w + (size_t)(i + u < i1 ? i + u : i1 - 1) * a.klr);
+            for (int u = 0; u < 32; u++) wv[u] = __builtin_nontemporal_load(w + (size_t)(i + u < i1 ? i + u : i1 - 1) * a.klr);
 #pragma unroll
-            for (int u = 0; u < 16; u++) if (i + u < i1) o = __builtin_fmaf(qh[i + u], wv[u], o);
+            for (int u = 0; u < 32; u++) if (i + u < i1) o = __builtin_fmaf(qh[i + u], wv[u], o);
         }
         sh[wave][lane] = o;
         __syncthreads();
