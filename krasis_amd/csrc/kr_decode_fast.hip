@@ -728,15 +728,16 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
 // rsf * sum_i w_i y_i (routing order, moe.rs:661-667) + shared * sigmoid(gate) (decode.rs:3379-3402).
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int BITS, int NU>
-__global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int slot_lds) {
+__global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int slot_lds, int pr, int ps) {
     const KrMoeArgs& a = fa.m;
     __shared__ float s_y[16][8];
     __shared__ __attribute__((aligned(16))) float s_wt[16];
-    // A shared expert twice as wide as a routed one (DeepSeek: two shared experts fused) would make its one wave the workgroup's critical path: the launcher then
-    // adds a wave (blockDim = 64 (n_slots + 1)) and the two take half of the shared expert's groups each ("part"); their column sums meet in the combine.
+    // A slot may be walked by SEVERAL waves ("parts": pr per routed slot, ps for the shared one; blockDim = 64 (topk pr + ps)): each takes a slice of the expert's
+    // units and quantises the matching chunks of its hidden, the column sums meet in the combine.  With one wave per slot a wide expert (I = 1408: 176 chunks to
+    // quantise on 64 lanes, then 6 units) made the launch twice as long as at I = 512, and a shared expert twice as wide again was the workgroup's critical path.
     const int t = threadIdx.x, vslot = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
-    const bool split = (int)blockDim.x > 64 * a.n_slots;
-    const int slot = vslot < a.n_slots ? vslot : a.topk, part = vslot < a.n_slots ? 0 : 1;
+    const int nrw = a.topk * pr;                             // waves of the routed slots
+    const int slot = vslot < nrw ? vslot / pr : a.topk, part = vslot < nrw ? vslot % pr : vslot - nrw, parts = vslot < nrw ? pr : ps;
     const int tile = blockIdx.x;
     KR_FSTAMP(5, 0);
     const float sig = a.gate_out ? a.gate_out[0] : 1.0f;     // sigmoid(gate row) of the shared expert, formed by the gate|up launch
@@ -769,12 +770,11 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
             const GgMat dm = gg_expert_mat(fa.gdown, (int)ee);
             accg = dm.type == GG_Q4_K ? gg_tile_q4k(dm, tile, GA, lane) : dm.type == GG_Q8_0 ? gg_tile_q8_0(dm, tile, GA, lane) : gg_tile_q4_0(dm, tile, GA, lane);
         }
-        if (l8 == 0) s_y[slot][cl] = accg;
+        if (l8 == 0) s_y[vslot][cl] = accg;                 // (GGUF routed slots: pr = 1, the launcher sees to it)
         if (lane == 0) s_wt[slot] = valid ? wt : 0.0f;
     }
     const int units = BITS == 4 ? m.ngp : m.ng;
-    const bool halves = split && shared;                      // this wave walks units [u0, u1) of the shared expert and quantises the matching chunks of its hidden
-    const int u0 = halves && part ? units / 2 : 0, u1 = halves && !part ? units / 2 : units;
+    const int u0 = units * part / parts, u1 = units * (part + 1) / parts;      // this wave's units of the slot's expert
     KrFw<BITS, NU, 8> W;     // 16 waves per workgroup leave 128 registers per lane: the guarded form keeps 8 records in flight
     if (gg) skip = true;     // handled above: the rest of the slot's work is the barrier and the combine
     if (!skip) kr_f_fetch<BITS, NU, 8>(W, m, qb, sb, tile, lane, u0, u1);
@@ -802,7 +802,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     const float acc = skip ? 0.0f : kr_f_tile<BITS, NU, 8>(W, m, qb, sb, tile, lane, u0, u1, L);
     KR_FSTAMP(5, 3);
     if (!gg) {
-        if (l8 == 0) s_y[part ? 15 : slot][cl] = acc;
+        if (l8 == 0) s_y[vslot][cl] = acc;
         if (lane == 0 && !part) s_wt[slot] = valid ? wt : 0.0f;
     }
     if (t >= a.n_slots && t < 16) s_wt[t] = 0.0f;
@@ -815,12 +815,18 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
 #pragma unroll
         for (int sl = 0; sl < 16; sl++) y[sl] = s_y[sl][t];
         float o = 0.0f;
+        if (pr == 1) {
 #pragma unroll
-        for (int sl = 0; sl < 15; sl++) { const float pr = w[sl] * y[sl]; o += sl < a.topk ? pr : 0.0f; }    // routing order (moe.rs:661-667); an invalid id carries weight 0
+            for (int sl = 0; sl < 15; sl++) { const float pd = w[sl] * y[sl]; o += sl < a.topk ? pd : 0.0f; }    // routing order (moe.rs:661-667); an invalid id carries weight 0
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < 8; sl++) { const float pd = w[sl] * (y[2 * sl] + y[2 * sl + 1]); o += sl < a.topk ? pd : 0.0f; }      // pr == 2: the two parts of a slot sit side by side
+        }
         if (a.rsf != 1.0f) o *= a.rsf;
         if (a.n_slots > a.topk) {
-            float sh = s_y[a.topk][t];
-            if (split) sh += s_y[15][t];
+            float sh = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 4; p++) sh += p < ps ? s_y[(nrw + p) & 15][t] : 0.0f;
             if (a.gate_out) sh *= sig;
             o = o + sh;
         }
@@ -968,10 +974,17 @@ int kr_launch_fw2(const KrFmoeArgs& fa, hipStream_t st) {
     const int units = fa.gguf ? 0 : (a.w2.bits == 4 ? a.w2.ngp : a.w2.ng);
     const bool uniform = !fa.gguf && (!has_shared || a.I_shared == a.I) && (a.w2.bits == 8 || a.w2.ng % 2 == 0);
     const int nu = uniform && (units == 2 || units == 4 || units == 6 || units == 8) ? units : 0;      // (6: I = 1536, Qwen3-235B)
-    // shared expert at least twice as wide as the routed ones (and an even unit count): one more wave, the two halves of the shared expert side by side
+    // waves per slot: a wide routed expert (guarded form only: the exact-unit forms walk the whole expert) on two waves, the shared expert on as many as keep its
+    // slice no longer than a routed one's -- within the 16 waves of a workgroup
     const int sunits = has_shared ? (a.sw2.bits == 4 ? a.sw2.ngp : a.sw2.ng) : 0;
-    const bool split = has_shared && a.I_shared >= 2 * a.I && a.n_slots <= 15 && sunits >= 2 && sunits % 2 == 0 && !fa.shared_skip;
-#define KR_FW2(B_, N_) hipLaunchKernelGGL((kr_fw2_kernel<B_, N_>), grid, dim3(64 * (a.n_slots + (split ? 1 : 0))), slot_lds * a.n_slots, st, fa, (int)slot_lds)
+    int pr = 1, ps = has_shared ? 1 : 0;
+    if (nu == 0 && !fa.gguf && units >= 4 && a.I >= 1024 && a.topk <= 7) pr = 2;
+    if (has_shared && nu == 0 && !fa.shared_skip) {
+        ps = (a.I_shared * pr + a.I - 1) / a.I;
+        if (ps > 4) ps = 4;
+        while (ps > 1 && (a.topk * pr + ps > 16 || ps > sunits)) ps--;
+    }
+#define KR_FW2(B_, N_) hipLaunchKernelGGL((kr_fw2_kernel<B_, N_>), grid, dim3(64 * (a.topk * pr + ps)), slot_lds * a.n_slots, st, fa, (int)slot_lds, pr, ps)
     if (wbits == 4) { if (nu == 2) KR_FW2(4, 2); else if (nu == 4) KR_FW2(4, 4); else if (nu == 6) KR_FW2(4, 6); else if (nu == 8) KR_FW2(4, 8); else KR_FW2(4, 0); }
     else { if (nu == 4) KR_FW2(8, 4); else if (nu == 8) KR_FW2(8, 8); else KR_FW2(8, 0); }
 #undef KR_FW2

@@ -248,12 +248,14 @@ def test_mla_geometry_errors():
         st.add_decode_mla_layer(0, 0, 0, 0, 0, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 512, 128, 64, 128, 0.1)
 
 
-@pytest.mark.parametrize("cfg", [dict(), dict(lora=True, seed=2), dict(klr=256, nh=3, seed=4), dict(dims=(2048, 512, 16, 6, 256, 512), nh=16, seed=9)])
+@pytest.mark.parametrize("cfg", [dict(), dict(lora=True, seed=2), dict(klr=256, nh=3, seed=4), dict(dims=(2048, 512, 16, 6, 256, 512), nh=16, seed=9),
+                                 dict(dims=(512, 384, 8, 6, 1408, 2816), nh=4, seed=13)])
 def test_mla_decode_step_tolerance_mode(cfg):
     """KR_DECODE_FAST on MLA layers (round 4): the input add + RMSNorm folded into the kv_a | q (LoRA: kv_a | q_a) projection launch, the o projection on the
     K-split tree-sum matvec fed by the f32 w_vc output, the MoE block on the mode's three launches; absorb / scores / weighted sum / w_vc keep the exact
     kernels.  STATED TOLERANCE (the mode's): logits within 2e-3 of the oracle driver (max |diff| / max |ref|), same greedy token, latent caches within
-    3e-3; the last case has V2-Lite's widths (H 2048, 16 heads)."""
+    3e-3; the fourth case has V2-Lite's widths (H 2048, 16 heads), the last its expert widths (I = 1408: an odd group count, two waves per routed slot and
+    four for the twice-as-wide shared expert in the down + combine launch; the absorption / latent norm / w_vc launches are the mode's tree-sum forms)."""
     st, eng, orc, keep, d = build(**cfg)
     st.set_attention_mode(False, decode_fast=True)
     tok = 9
