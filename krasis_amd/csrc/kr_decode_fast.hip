@@ -727,9 +727,10 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
 // decode.rs:3364-3374) into its own LDS region, walks the I / 128 groups and leaves 8 column values; 8 lanes then form
 // rsf * sum_i w_i y_i (routing order, moe.rs:661-667) + shared * sigmoid(gate) (decode.rs:3379-3402).
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int BITS, int NU>
-__global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int slot_lds, int pr, int ps) {
+template <int BITS, int NU, bool MULTI>
+__global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int slot_lds, int pr_, int ps_) {
     const KrMoeArgs& a = fa.m;
+    const int pr = MULTI ? pr_ : 1, ps = MULTI ? ps_ : 1;      // MULTI = false: one wave per slot, the part arithmetic below folds away (the headline shapes: every cycle of this launch is on the token's path)
     __shared__ float s_y[16][8];
     __shared__ __attribute__((aligned(16))) float s_wt[16];
     // A slot may be walked by SEVERAL waves ("parts": pr per routed slot, ps for the shared one; blockDim = 64 (topk pr + ps)): each takes a slice of the expert's
@@ -984,9 +985,11 @@ int kr_launch_fw2(const KrFmoeArgs& fa, hipStream_t st) {
         if (ps > 4) ps = 4;
         while (ps > 1 && (a.topk * pr + ps > 16 || ps > sunits)) ps--;
     }
-#define KR_FW2(B_, N_) hipLaunchKernelGGL((kr_fw2_kernel<B_, N_>), grid, dim3(64 * (a.topk * pr + ps)), slot_lds * a.n_slots, st, fa, (int)slot_lds, pr, ps)
-    if (wbits == 4) { if (nu == 2) KR_FW2(4, 2); else if (nu == 4) KR_FW2(4, 4); else if (nu == 6) KR_FW2(4, 6); else if (nu == 8) KR_FW2(4, 8); else KR_FW2(4, 0); }
-    else { if (nu == 4) KR_FW2(8, 4); else if (nu == 8) KR_FW2(8, 8); else KR_FW2(8, 0); }
+    const bool multi = pr > 1 || ps > 1;
+#define KR_FW2(B_, N_, M_) hipLaunchKernelGGL((kr_fw2_kernel<B_, N_, M_>), grid, dim3(64 * (a.topk * pr + ps)), slot_lds * a.n_slots, st, fa, (int)slot_lds, pr, ps)
+    if (multi) { if (wbits == 4) KR_FW2(4, 0, true); else KR_FW2(8, 0, true); }      // (several waves per slot only with the guarded form)
+    else if (wbits == 4) { if (nu == 2) KR_FW2(4, 2, false); else if (nu == 4) KR_FW2(4, 4, false); else if (nu == 6) KR_FW2(4, 6, false); else if (nu == 8) KR_FW2(4, 8, false); else KR_FW2(4, 0, false); }
+    else { if (nu == 4) KR_FW2(8, 4, false); else if (nu == 8) KR_FW2(8, 8, false); else KR_FW2(8, 0, false); }
 #undef KR_FW2
     return 0;
 }
