@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
     const bool shared = slot >= a.topk;
     // the grid's x extent follows the widest slot (a shared expert may be wider than the routed ones): a routed workgroup past its expert's last tile pair leaves
     // before the select and the image copy, not after them (DeepSeek-V2-Lite: half of the launch's workgroups)
-    if (!shared && (int)blockIdx.x * 2 >= a.I / 8 && !(blockIdx.x == 0 && slot == 0)) return;
+    if (!shared && (int)blockIdx.x * 2 /* TW */ >= a.I / 8) return;      // (workgroup (0, 0), which publishes the routing, always has a tile pair)
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
     const int tw = wave >> 1, ks = wave & 1;
     const KrActLds L = kr_carve_lds(kr_fsm, a.H, BITS == 8);
