@@ -43,7 +43,6 @@ size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
 }  // namespace
 
 static int pf_gemm(kr_decode_store* s, int wid, const Act& A, int C, float* out, int ld, hipStream_t st) {
-    if (KR_AB_ON(512)) return KR_OK;
     DWeight& W = *s->weights[wid];
     if (s->gemm_fast) { kr_launch_pfh_gemm(W.ms.view(), A.f, A.fm, nullptr, 1, 0, 0, C, out, ld, st); return KR_OK; }
     if (!W.ms.wsum.p) return kr_fail(KR_ERR_STATE, "internal: nibble sums of weight %d were not prepared", wid);
@@ -53,7 +52,6 @@ static int pf_gemm(kr_decode_store* s, int wid, const Act& A, int C, float* out,
 // up to three projections of the same input in ONE launch (q | k | v, qkvz | ba, shared gate_up | shared gate); falls back to one launch each
 // when the weight widths or K differ
 static int pf_gemm_multi(kr_decode_store* s, const int* wids, float* const* outs, const int* lds, int n, const Act& A, int C, hipStream_t st) {
-    if (KR_AB_ON(512)) return KR_OK;
     KrMatDev mats[3]; const uint32_t* ws[3];
     bool same = n <= 3;
     for (int i = 0; i < n; i++) {
@@ -91,7 +89,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
     na.w = (const float*)s->norms[L.input_norm]->p; na.out = B.normed; na.xh = B.xh; na.xl = B.xl; na.xs = B.xs; na.H = H; na.first = cx.first ? 1 : 0;
     na.bias_one = s->norm_bias_one; na.eps = s->eps;
     if (s->gemm_fast) { na.xh = nullptr; na.xl = nullptr; na.xs = nullptr; }      // tolerance GEMMs take f16 rows of the normalised value instead of the digits
-    KR_AB(64, kr_launch_pfm_norm(na, Cc, st));
+    kr_launch_pfm_norm(na, Cc, st);
     if (s->gemm_fast) kr_launch_pfh_rows_f32(B.normed, Cc, H, H, B.xf, B.xfm, st);
     cx.first = false; cx.add_is_emb = false;
     if (L.attn == ATTN_LA) {
@@ -125,7 +123,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         if (s->attn_fast && kr_pfm_gqa_flash_ok(L.nh, L.nkv, L.hd)) {      // tolerance mode: flash attention on the matrix cores (same prep launch)
             kr_launch_pfm_gqa_prep(a, Cc, st);
             kr_pf_wait(st, cx.sy.wait_b); kr_pf_rec(st, cx.sy.rec_b);      // own rows appended; the previous chunks' rows are read from here on
-            flash = true; KR_AB(128, flash = 0 == kr_launch_pfm_gqa_flash(a, Cc, st));
+            flash = 0 == kr_launch_pfm_gqa_flash(a, Cc, st);
             flash_tried = true;
         }
         if (!flash) {
@@ -172,7 +170,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
     }
     // ---- post-attention norm: f32 hidden, digits (shared expert / dense MLP), bf16 copy (routed experts)
     na.mode = 0; na.add_in = B.hid; na.first = 0; na.w = (const float*)s->norms[L.post_norm]->p; na.out_bf16 = L.mlp == MLP_MOE ? B.xb : nullptr;
-    KR_AB(64, kr_launch_pfm_norm(na, Cc, st));
+    kr_launch_pfm_norm(na, Cc, st);
     if (s->gemm_fast && (L.mlp == MLP_DENSE || (L.mlp == MLP_MOE && L.sgu_wid >= 0))) kr_launch_pfh_rows_f32(B.normed, Cc, H, H, B.xf, B.xfm, st);
     if (L.mlp == MLP_MOE) {
         Layer& EL = e->layers[L.moe_layer];
@@ -181,16 +179,15 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         const int E = e->r_ne;
         const float* rbias = EL.has_bias ? (const float*)EL.bias.p : nullptr;
         // KR_GEMM_FAST: the router's logits in the tolerance form too (bf16 MFMA on x = hi + lo; its input already carries the mode's f16 operand rounding)
-        if (!(s->gemm_fast && Cc >= 32 && EL.gate_row.p && 0 == (KR_AB_ON(16) ? 0 : kr_launch_route_logits_fast(EL.gate_row.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st))))
+        if (!(s->gemm_fast && Cc >= 32 && EL.gate_row.p && 0 == kr_launch_route_logits_fast(EL.gate_row.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st)))
         if (!(Cc >= 32 && EL.gate_row.p && 0 == kr_launch_route_logits_mfma(EL.gate_row.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st)))
             kr_launch_route_logits_decode(EL.gate_cm.p, EL.gate_bf16_exact, B.normed, rbias, B.logits, Cc, E, H, st);
-        KR_AB(32, kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st));
+        kr_launch_route_select(B.logits, EL.has_esc ? (const float*)EL.esc.p : nullptr, B.ids, B.w, Cc, E, k, s->scoring, s->norm_topk, KR_ROUTE_RULE_DECODE, 0, st);
         // routed experts: exact CPU-engine arithmetic on the matrix cores, f32 weighted sum in routing order
         // expert parallelism (kr_ep_init on the engine): this rank's chunk exchanges its (token, slot) rows with the owners over RCCL.  A collective:
         // prefill_impl pads ranks that have fewer chunks with empty-shard calls.  Every chunk in flight has its own exchange-buffer set (cx.set) and stream; the
         // collectives of all chunks are ISSUED in one host order that is the same on every rank (the loop structure below depends only on the agreed chunk count).
         if (e->ep) { if (int rc = kr_moe_prefill_ep_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set, st ? (void*)st : (void*)1)) return rc; }
-        else if (KR_AB_ON(256)) {}
         else if (int rc = kr_moe_prefill_set(e, L.moe_layer, B.xb, B.ids, B.w, B.moe, Cc, k, KR_OUT_F32, 1, cx.set | (s->gemm_fast ? KR_PF_SET_FAST : 0), st)) return rc;
         const bool has_shared = L.sgu_wid >= 0, has_gate = has_shared && L.sg_wid >= 0;
         if (has_shared) {   // decode-store numerics: f32 input digits, fast_silu_mul + f32::round digits (decode.rs:3356-3378)

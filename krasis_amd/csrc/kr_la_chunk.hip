@@ -463,8 +463,8 @@ int kr_launch_pfm_la_chunked(const KrPfmLaArgs& p, float* state, float* out, flo
     uint16_t* pl = reinterpret_cast<uint16_t*>(a.G + ((tiles + 3) / 4) * 4);        // planes start 16-byte aligned
     a.Wh = pl; a.Wl = a.Wh + tiles * LC_D; a.Qh = a.Wl + tiles * LC_D; a.Ql = a.Qh + tiles * LC_D; a.Kh = a.Ql + tiles * LC_D; a.Kl = a.Kh + tiles * LC_D;
     a.out = out; a.state = state;
-    KR_AB(2, hipLaunchKernelGGL(kr_lac_prep_kernel, dim3(a.n_sub, p.nv), dim3(LC_PTH), LC_PREP_LDS, st, a));
+    hipLaunchKernelGGL(kr_lac_prep_kernel, dim3(a.n_sub, p.nv), dim3(LC_PTH), LC_PREP_LDS, st, a);
     if (sy) kr_pf_wait(st, sy->wait_b);      // only the scan reads the state the previous chunk of the prompt leaves
-    KR_AB(4, hipLaunchKernelGGL(kr_lac_scan_kernel, dim3(p.nv * 4), dim3(256), LC_SCAN_LDS, st, a));
+    hipLaunchKernelGGL(kr_lac_scan_kernel, dim3(p.nv * 4), dim3(256), LC_SCAN_LDS, st, a);
     return 0;
 }

@@ -16,15 +16,6 @@ struct KrPfmNormArgs {
 // not "layer l finished" but two narrow hand-overs -- (a) the carried conv state, (b) the recurrent state (linear attention) or the KV / latent rows
 // (GQA, MLA) of layer l.  wait_* are the previous chunk's events (null: first chunk / one chunk in flight), rec_* this chunk's.  Every record is issued AFTER
 // the matching wait on the same stream, so an event implies the whole chain of earlier chunks (a chunk two back has no event of its own to wait for).
-#ifdef KR_AB_SKIP      // A/B library only (make ab AB_DEFS=-DKR_AB_SKIP): leave out launches named by the bit mask in $KR_AB_SKIP to price them in wall-clock terms
-#include <cstdlib>     // (results are wrong by construction; the product library has no such hook)
-static inline bool kr_ab_skip(int bit) { static const int m = getenv("KR_AB_SKIP") ? atoi(getenv("KR_AB_SKIP")) : 0; return (m & bit) != 0; }
-#define KR_AB(bit, stmt) do { if (!kr_ab_skip(bit)) { stmt; } } while (0)
-#define KR_AB_ON(bit) kr_ab_skip(bit)
-#else
-#define KR_AB(bit, stmt) do { stmt; } while (0)
-#define KR_AB_ON(bit) false
-#endif
 struct KrPfSync {
     hipEvent_t wait_a = nullptr, rec_a = nullptr, wait_b = nullptr, rec_b = nullptr;
 };

@@ -700,7 +700,7 @@ int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out,
     const KrPfSync none{};
     if (!sy) sy = &none;
     kr_pf_wait(st, sy->wait_a);              // the previous chunk's carried conv slots
-    KR_AB(1, hipLaunchKernelGGL(kr_pfm_la_conv_kernel, dim3(a.nk, (C + PFC_TT - 1) / PFC_TT), dim3(256), (size_t)(2 * PFC_TT * a.dk + 2 * PFC_TT) * 4, st, a, C));
+    hipLaunchKernelGGL(kr_pfm_la_conv_kernel, dim3(a.nk, (C + PFC_TT - 1) / PFC_TT), dim3(256), (size_t)(2 * PFC_TT * a.dk + 2 * PFC_TT) * 4, st, a, C);
     const int conv_dim = 2 * a.nk * a.dk + a.nv * a.dv;
     hipLaunchKernelGGL(kr_pfm_la_conv_state_kernel, dim3((conv_dim + 255) / 256), dim3(256), 0, st, a, C);
     kr_pf_rec(st, sy->rec_a);
@@ -713,7 +713,7 @@ int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out,
         else hipLaunchKernelGGL(kr_pfm_la_recur_kernel<64>, dim3(a.nv), dim3(a.dv), 0, st, recur_state, a.q, a.k, a.v, a.gexp, a.beta, recur_out, a.nv, a.dv, C);
     }
     kr_pf_rec(st, sy->rec_b);
-    KR_AB(8, hipLaunchKernelGGL(kr_pfm_gated_norm_kernel, dim3(a.nv, C), dim3(a.dv), 0, st, recur_out, a.z, norm_w, gated_out, a.nv, a.dv, eps));
+    hipLaunchKernelGGL(kr_pfm_gated_norm_kernel, dim3(a.nv, C), dim3(a.dv), 0, st, recur_out, a.z, norm_w, gated_out, a.nv, a.dv, eps);
     return 0;
 }
 // the recurrence alone (stand-alone operator linear_attention_recurrent, decode.rs:609): gexp = e^g per (token, head); non-zero = unsupported geometry
