@@ -77,6 +77,222 @@ def pmc_traffic(symbol):
     return None, None
 
 
+LINE_TARGET_BYTES = 6000        # the printed line (VERDICT r4 next #1: target <= 6 KB)
+LINE_HARD_CAP_BYTES = 12000     # never printed above this: fields are dropped, least important first
+
+
+def _r(x, nd=4):
+    """numbers of the compact line: floats to `nd` significant decimals of their magnitude, everything else as is"""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        ax = abs(x)
+        if ax >= 1000:
+            return round(x, 1)
+        if ax >= 1:
+            return round(x, 3)
+        return float("%.4g" % x)
+    return x
+
+
+def _pick(d, *keys):
+    """{key: rounded number} of the keys present in dict d (an {"error": ...} leg keeps a short error string)"""
+    if not isinstance(d, dict):
+        return None
+    if "error" in d and len(d) == 1:
+        return {"error": str(d["error"])[:120]}
+    out = {}
+    for k in keys:
+        src, dst = (k if isinstance(k, tuple) else (k, k))
+        v = d
+        for part in src.split("."):
+            v = v.get(part) if isinstance(v, dict) else None
+        if v is not None and not isinstance(v, (dict, list, str)):
+            out[dst] = _r(v)
+        elif isinstance(v, str) and len(v) <= 48:
+            out[dst] = v
+    return out or None
+
+
+def _prefill_leg(d):
+    """a whole-model prompt-pass leg as numbers only: tok/s at the first length, every length, roofline fraction, validity"""
+    if not isinstance(d, dict):
+        return None
+    if "value" not in d:
+        return {"error": str(d.get("error", "no value"))[:120]}
+    out = {"tok_s": _r(float(d["value"])), "ms": _r(float(d.get("ms", 0.0))), "frac": _r(float(d.get("roofline", {}).get("frac", 0.0)))}
+    if d.get("by_prompt_length"):
+        out["by_len"] = {k: round(float(v)) for k, v in d["by_prompt_length"].items()}
+    if d.get("allocs_in_timed_region"):
+        out["allocs"] = d["allocs_in_timed_region"]
+    if d.get("invalid"):
+        out["invalid"] = True
+    return out
+
+
+def _experts_leg(d):
+    if not isinstance(d, dict):
+        return None
+    if "tok_s_experts_only" not in d:
+        return {"error": str(d.get("error", "no value"))[:120]}
+    return {"tok_s": _r(float(d["tok_s_experts_only"])), "ms": _r(float(d["ms"])), "layers": d.get("layers"), "frac": _r(float(d.get("roofline", {}).get("frac", 0.0))),
+            "peak": d.get("roofline", {}).get("peak")}
+
+
+def _side_leg(d):
+    """a side configuration: numbers only (VERDICT r4 next #1)"""
+    if not isinstance(d, dict):
+        return None
+    if "error" in d and "decode_tok_s" not in d:
+        return {"error": str(d["error"])[:120]}
+    out = _pick(d, "decode_tok_s", "decode_fast_tok_s", ("step_frac_of_hbm_peak", "frac"), ("decode_fast_frac_of_hbm_peak", "fast_frac")) or {}
+    for key, short in (("prefill", "prefill"), ("prefill_fast", "prefill_attn_fast"), ("prefill_fast_gemm", "prefill_fast_gemm")):
+        if isinstance(d.get(key), dict) and "value" in d[key]:
+            out[short] = round(float(d[key]["value"]))
+        elif isinstance(d.get(key), dict) and "error" in d[key]:
+            out[short] = "error"
+    if isinstance(d.get("prefill_experts_only"), dict) and "tok_s_experts_only" in d["prefill_experts_only"]:
+        out["experts_only"] = round(float(d["prefill_experts_only"]["tok_s_experts_only"]))
+    for k in ("decode_tok_s", "decode_fast_tok_s"):
+        if isinstance(d.get(k), dict):
+            out[k] = "error"
+    return out
+
+
+def compact_line(res, detail_path=None):
+    """The ONE JSON line the driver parses, from the full result dict: contract keys, the roofline and cpu_baseline objects, and NUMBERS ONLY for
+    every side leg.  Prose notes, per-kind tables, ms_all, by-thread sweeps stay in the detail file (`detail`).  Kept under LINE_TARGET_BYTES by
+    construction; if a future leg pushes it over LINE_HARD_CAP_BYTES the optional groups are dropped from the end of `order` until it fits."""
+    cfg = res.get("config", {})
+    line = {k: res.get(k) for k in ("metric", "value", "value_exact", "value_fast", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                      "scaling", "vs_baseline", "dtype", "data") if k in res}
+    for k in ("value", "value_exact", "value_fast", "ms_per_step"):
+        if isinstance(line.get(k), float):
+            line[k] = _r(line[k])
+    line["metric"] = str(res.get("metric", ""))[:160]
+    line["dtype"] = str(res.get("dtype", ""))[:96]
+    line["config"] = {k: (v if not isinstance(v, str) else v[:140]) for k, v in cfg.items()
+                      if k in ("workload", "kv", "layers", "hip_graph", "decode_mode", "parallelism", "value_is")}
+    rf = res.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = _pick(rf, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", ("algorithmic_bytes_per_launch", "algorithmic_bytes"),
+                                 "us_per_launch", "launches_per_step", ("us_per_launch_raw_events", "us_per_launch_raw"), ("frac_raw_events", "frac_raw"),
+                                 ("event_pair_overhead_us", "event_overhead_us"), ("step_algorithmic_bytes", "step_bytes"), ("step_frac_of_hbm_peak", "step_frac"),
+                                 ("peak_measured_stream_read", "peak_measured"), "traffic_source",
+                                 ("step_algorithmic_bytes_per_gpu", "step_bytes_per_gpu")) or {}
+        if "traffic" not in line["roofline"]:
+            line["roofline"]["traffic"] = None
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, "value", "unit", "cores", "kind", "host_threads", "ms_per_token") or {}
+        if "error" in cb:
+            c = {"error": str(cb["error"])[:120]}
+        else:
+            c["sample"] = "whole-token passes over one token's weight set (~1.9 GB), AVX2+OpenMP port of avx2.rs:1066; ~%gs" % res.get("_cpu_seconds", 5)
+            v2 = cb.get("v2lite_q4k_cpu")
+            if isinstance(v2, dict):
+                c["v2lite_q4k_cpu"] = _pick(v2, "value", "cores", "dram_GBs") or {"error": str(v2.get("error"))[:80]}
+        line["cpu_baseline"] = c
+    opt = {}
+    oth = res.get("decode_exact") or res.get("decode_fast")
+    if isinstance(oth, dict):
+        opt["decode_other_mode"] = _pick(oth, "tok_s", "ms_per_step", "steps")
+    g = res.get("decode_generate")
+    if isinstance(g, dict):
+        gg = _pick(g, "tok_s", "tok_s_over_value", ("allocs_in_timed_decode_steps", "allocs")) or {}
+        for k in ("exact", "fast", "fast_lookahead", "exact_lookahead"):
+            if isinstance(g.get(k), dict) and "tok_s" in g[k]:
+                gg[k] = _r(float(g[k]["tok_s"]))
+        if "error" in g:
+            gg["error"] = str(g["error"])[:120]
+        opt["decode_generate"] = gg
+    for k in ("router_id_flip_rate",):
+        if k in res:
+            opt[k] = res[k]
+    for k in ("prefill", "prefill_fast", "prefill_fast_gemm"):
+        if k in res:
+            opt[k] = _prefill_leg(res[k])
+    for k in ("prefill_experts_only", "prefill_experts_only_fast_gemm", "prefill_experts_only_q4k_gguf", "prefill_experts_only_q4k_gguf_fast_gemm"):
+        if k in res:
+            opt[k] = _experts_leg(res[k])
+    if isinstance(res.get("decode_other_kv"), dict):
+        opt["decode_other_kv"] = _pick(res["decode_other_kv"], "kv", "tok_s")
+    lc = {}
+    for k, short in (("decode_long_context", "8k_exact"), ("decode_long_context_fast", "8k_fast"), ("decode_long_context_32k", "32k_exact"), ("decode_long_context_32k_fast", "32k_fast")):
+        if isinstance(res.get(k), dict):
+            lc[short] = _r(float(res[k]["tok_s"])) if "tok_s" in res[k] else "error"
+    if lc:
+        opt["decode_long_context_tok_s"] = lc
+    if isinstance(res.get("configs"), dict):
+        opt["configs"] = {k: _side_leg(v) for k, v in res["configs"].items()}
+    # N > 1 legs (main_multi) and the one-rank RCCL self-test
+    for k in ("decode_ep_exact", "decode_ep_fast", "decode_ep_fast_graph"):
+        if isinstance(res.get(k), dict):
+            opt[k] = _pick(res[k], "tok_s", "ms_per_step", "hip_graph")
+    for k in ("prefill_model_ep", "prefill_model_ep_attn_fast"):
+        if isinstance(res.get(k), dict):
+            opt[k] = _pick(res[k], ("value", "tok_s"), "ms", "tokens_total", ("roofline.frac", "frac"))
+    if isinstance(res.get("prefill_experts_ep_alltoall"), dict):
+        opt["prefill_experts_ep_alltoall"] = _pick(res["prefill_experts_ep_alltoall"], ("tok_s_experts_only", "tok_s"), "ms", "tokens_total", ("roofline.frac", "frac"))
+    if isinstance(res.get("replicas"), dict):
+        opt["replicas"] = _pick(res["replicas"], "tok_s_aggregate", "tok_s_per_replica")
+    for k in ("rccl_ranks", "experts_per_gpu", "watchdog"):
+        if k in res:
+            opt[k] = res[k] if not isinstance(res[k], str) else res[k][:100]
+    if isinstance(res.get("qwen3_235b_ep"), dict):
+        q = res["qwen3_235b_ep"]
+        o = _pick(q, "value", "frac_of_hbm_peak_per_gpu") or {}
+        for k in ("decode_ep_exact", "decode_ep_fast", "decode_ep_fast_graph"):
+            if isinstance(q.get(k), dict):
+                o[k] = _r(float(q[k]["tok_s"])) if "tok_s" in q[k] else "error"
+        if "error" in q:
+            o["error"] = str(q["error"])[:120]
+        opt["qwen3_235b_ep"] = o
+    if isinstance(res.get("expert_parallel_selftest_one_rank_rccl"), dict):
+        q = res["expert_parallel_selftest_one_rank_rccl"]
+        o = _pick(q, "value", "rccl_ranks") or {}
+        for k in ("decode_ep_exact", "decode_ep_fast", "decode_ep_fast_graph"):
+            if isinstance(q.get(k), dict):
+                o[k] = _r(float(q[k]["tok_s"])) if "tok_s" in q[k] else "error"
+        opt["ep_selftest_one_rank_rccl"] = o
+    if isinstance(res.get("expert_parallel"), dict):
+        opt["expert_parallel"] = {"error": str(res["expert_parallel"].get("error"))[:160]}
+    if detail_path:
+        opt["detail"] = detail_path
+    order = list(opt)                                    # least important last
+    out = dict(line); out.update({k: v for k, v in opt.items() if v is not None})
+    text = json.dumps(out, separators=(",", ":"))
+    while len(text) > LINE_HARD_CAP_BYTES and order:
+        out.pop(order.pop(), None)
+        text = json.dumps(out, separators=(",", ":"))
+    return out, text
+
+
+def emit_line(res, args):
+    """write the full result dict to the detail file (and to stderr), print the compact line as the LAST stdout line"""
+    detail_path = None
+    full = json.dumps(res)
+    for cand in (getattr(args, "detail_file", None), os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "/tmp/bench_detail.json"):
+        if not cand:
+            continue
+        try:
+            os.makedirs(os.path.dirname(cand) or ".", exist_ok=True)
+            with open(cand, "w") as f:
+                f.write(full + "\n")
+            detail_path = cand
+            break
+        except OSError:
+            continue
+    res = dict(res); res["_cpu_seconds"] = getattr(args, "cpu_seconds", 5)
+    rel = os.path.relpath(detail_path, ROOT) if detail_path and detail_path.startswith(ROOT) else detail_path
+    out, text = compact_line(res, rel)
+    assert len(text) <= LINE_HARD_CAP_BYTES, "bench line is %d bytes" % len(text)
+    sys.stderr.write("bench.py: full detail (%d bytes) -> %s; compact line %d bytes\n" % (len(full), detail_path, len(text)))
+    sys.stderr.flush()
+    print(text, flush=True)
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +316,7 @@ def parse():
     ap.add_argument("--ep-selftest", action="store_true", help="run the expert-parallel leg at N = 1 too (no peer traffic: checks the row path)")
     ap.add_argument("--prefill-tokens", default="8192,20434,35139,49863",
                     help="prompt lengths of the prompt-pass side measurement (benchmark.py:434-505: 20 434 / 35 139 / 49 863 tokens; 0 = skip)")
+    ap.add_argument("--detail-file", default="", help="where the full (un-abridged) result dict goes; default gpurun_out/bench_detail.json")
     ap.add_argument("--side-configs", default="v2lite-q4,v2lite-q4k-gguf,qcn-q8,qcn-q4k-gguf,qwen3-235b-q4", help="other single-GPU BASELINE configurations measured as side legs of the N = 1 line ('' = none)")
     return ap.parse_args()
 
@@ -962,7 +1179,7 @@ def main_multi(args, torch, dist, world, rank, local_rank):
             form = state["form"] or "no decode form finished"; scaling = "strong"
         res = {"metric": "decode tok/s, %s expert-parallel @%d MI355X" % (model, world), "value": value, "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": (state["dt"] / args.steps * 1e3) if state["dt"] else None, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-               "dtype": "int%d-g128 weights x int16 activations -> i32 group sums, f32 scales; %s" % (bits, form),
+               "dtype": "int%d-g128 w x int16 act -> i32, f32 scales" % bits, "dtype_note": form,
                "data": "synthetic",
                "config": {"workload": WORKLOAD[name], "layers": L, "kv": ("FP8-E4M3" if kv_fp8 else "FP16") + " KV cache, kv_max_seq %d" % kvm,
                           "parallelism": "ep%d: %d of %d routed experts per GPU and layer (contiguous slices, gpu_prefill.py:353-359); attention, router, norms, shared expert, lm_head replicated; "
@@ -974,7 +1191,7 @@ def main_multi(args, torch, dist, world, rank, local_rank):
                             "frac": (ab["total"] * state["value"] / 1e9 / HBM_PEAK_GBS) if state["value"] else None,
                             "kernel": "whole step (per GPU: routed experts / %d + replicated attention, router, lm_head)" % world, "traffic": None}}
         res.update({k_: v for k_, v in legs.items() if not k_.startswith("_")})
-        print(json.dumps(res), flush=True)
+        emit_line(res, args)
 
     import threading
 
@@ -1169,7 +1386,8 @@ def main():
             "metric": "decode tok/s, %s @1 MI355X (%s; both modes: value_exact / value_fast)" % (model, mode_tag),
             "value": tok_s, "value_exact": exact_tok_s, "value_fast": fast_tok_s, "unit": "tok/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("int%d-g128 weights x int16 activations -> i32 group sums, f32 scales" % bits) +
+            "dtype": "int%d-g128 w x int16 act -> i32, f32 scales" % bits,
+            "dtype_note": ("int%d-g128 weights x int16 activations -> i32 group sums, f32 scales" % bits) +
                      (" (KR_DECODE_FAST: the reference's products, f32 sums as lane / wave / workgroup trees -- logits within 2e-3 of the bit-exact mode, "
                       "router ids identical for identical logits; tests/test_decode_fast_gpu.py)" if fast_mode else " (reference CPU-decode numerics, bit-exact)"),
             "data": "synthetic",
@@ -1210,7 +1428,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, QCN["layers"])
             except Exception as ex:  # a reported side number, never the product path
                 res["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(res), flush=True)
+        emit_line(res, args)
 
     del st, eng, keep
     gc.collect(); torch.cuda.empty_cache()

@@ -38,3 +38,48 @@ def test_pmc_traffic_lookup_handles_template_families(tmp_path, monkeypatch):
 def test_side_config_names_are_described():
     for name in ("v2lite-q4", "qcn-q8", "qcn-q4k-gguf", "qwen3-235b-q4", "qcn-q4"):
         assert name in bench.WORKLOAD and len(bench.WORKLOAD[name]) > 20
+
+
+def test_compact_line_fits_the_driver(tmp_path):
+    """the LAST stdout line is one compact JSON object (<= 6 KB target, 12 KB hard cap) whatever the full result dict holds;
+    the r02-r04 full lines (13-25 KB; r04's was the one the driver could not parse) are the inputs."""
+    import glob
+    import json
+    import os
+    import bench
+    files = sorted(glob.glob(os.path.join(bench.ROOT, "profiles", "r0[234]_bench_line.json")))
+    assert files
+    for f in files:
+        full = json.load(open(f))
+        out, text = bench.compact_line(full, "gpurun_out/bench_detail.json")
+        assert len(text) <= bench.LINE_TARGET_BYTES, (f, len(text))
+        assert "\n" not in text
+        back = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in back, (f, k)
+        assert abs(back["value"] - full["value"]) < 1e-2 * full["value"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in back["roofline"], k
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in back["cpu_baseline"], k
+        assert "workload" in back["config"] and "model" not in back["config"]
+        # numbers only below the contract keys: no string longer than a label anywhere in the side legs
+        def walk(x, path):
+            if isinstance(x, dict):
+                for k, v in x.items():
+                    walk(v, path + [k])
+            elif isinstance(x, str) and path[0] not in ("metric", "config", "dtype", "cpu_baseline"):
+                assert len(x) <= 130, (path, x)
+        walk(back, [])
+
+
+def test_compact_line_hard_cap_drops_optional_groups():
+    import json
+    import bench
+    full = {"metric": "m", "value": 1.0, "unit": "tok/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int4", "data": "synthetic", "config": {"workload": "w"}, "roofline": {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None},
+            "cpu_baseline": {"value": 1.0, "unit": "tok/s", "cores": 1, "kind": "port"},
+            "configs": {("cfg%d" % i): {"decode_tok_s": 1.0 * i, "decode_fast_tok_s": 2.0 * i, "step_frac_of_hbm_peak": 0.1} for i in range(400)}}
+    out, text = bench.compact_line(full, None)
+    assert len(text) <= bench.LINE_HARD_CAP_BYTES
+    assert "configs" not in out and out["roofline"]["frac"] == 0.1 and json.loads(text)["value"] == 1.0
