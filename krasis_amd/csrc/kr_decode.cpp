@@ -212,6 +212,7 @@ extern "C" int kr_decode_configure(kr_decode_store* s, int hidden, int n_layers,
         return kr_fail(KR_ERR_HIP, "hipMalloc failed");
     KR_HIP(hipMemset(s->r_counter.p, 0, 64));
     KR_HIP(hipMemset(s->argmax_scratch.p, 0, 1024));
+    KR_HIP(hipMemset(s->gate_val.p, 0, 64));
     s->configured = true; s->graph_ok = false;
     return KR_OK;
 }
@@ -917,6 +918,9 @@ static int run_step(kr_decode_store* s, int token, int pos, hipStream_t st) {
     // all-reduce is a stream operation like any kernel: kr_decode_set_option("ep_graph", 1) captures it with the step.  The first two steps of a store run
     // eagerly even then -- RCCL sets up its channels / proxy connections on the first collectives, which must not happen inside a capture.
     const bool ep_active = kr_ep_decode_active(s->eng);
+    if (s->eng->ep_generation != s->ep_generation_seen) {      // communicator created or destroyed since the last step: nothing captured or warmed up before survives it
+        s->ep_generation_seen = s->eng->ep_generation; s->graph_ok = false; s->ep_eager_steps = 0;
+    }
     if (ep_active && s->ep_eager_steps < 2) s->ep_eager_steps++;
     else if (s->use_graph && (!ep_active || (s->opt_ep_graph && kr_ep_is_rccl(s->eng)))) {
         if (!s->graph_ok) {
@@ -1082,7 +1086,9 @@ static int generate_core(kr_decode_store* s, int first_token, int start_pos, int
         // queues the next step (decode.rs:3560-3591), which idles the GPU for one host round trip per token.  Here the sampler's output stays on the
         // device and feeds step i + 1 directly (kr_set_step_dev_kernel); the host reads token i from a pinned ring WHILE step i + 1 runs.  Same tokens
         // as the plain loop.  One stated difference: when token i turns out to be a stop id, step i + 1 has already been queued -- the KV / recurrent
-        // state then includes the stop token (the plain loop leaves it out).  Callers that continue decoding from the state after a stop keep the default.
+        // state then includes the stop token (the plain loop leaves it out), and the sampler's RNG state / seen-token bitmap / device token slot have advanced one
+        // sample past where the plain loop leaves them.  Callers that continue decoding from the state after a stop keep the default.  A step whose position is past
+        // the cache or the rope table is never queued ahead: the loop reads the token first, as the plain loop does (which returns its tokens when that token stops).
         if (s->gen_ring_n < max_tokens) {
             if (s->gen_ring) (void)hipHostFree(s->gen_ring);
             s->gen_ring = nullptr; s->gen_ring_n = 0;
@@ -1094,13 +1100,17 @@ static int generate_core(kr_decode_store* s, int first_token, int start_pos, int
         for (int i = 0; i < max_tokens; i++) {
             KR_HIP(hipMemcpyAsync(&s->gen_ring[i], s->tok.p, 4, hipMemcpyDeviceToHost, st));
             KR_HIP(hipEventRecord(s->gen_ev[i & 1], st));
-            if (i + 1 < max_tokens) if (int rc = step_and_sample(KR_TOKEN_FROM_DEVICE, start_pos + i + 1)) { stamp(); return rc; }
+            const int npos = start_pos + i + 1;
+            const bool in_range = !((s->kv_max_seq > 0 && npos >= s->kv_max_seq) || (s->max_rope_seq > 0 && npos >= s->max_rope_seq));
+            const bool ahead = i + 1 < max_tokens && in_range;
+            if (ahead) if (int rc = step_and_sample(KR_TOKEN_FROM_DEVICE, npos)) { stamp(); return rc; }
             KR_HIP(hipEventSynchronize(s->gen_ev[i & 1]));
             const int next = s->gen_ring[i];
             tokens_out[n++] = next;
             bool stop = false;
             for (int j = 0; j < n_stop; j++) stop |= (stop_ids[j] == next);
             if (stop) break;
+            if (i + 1 < max_tokens && !ahead) if (int rc = step_and_sample(next, npos)) { stamp(); return rc; }      // out of range: the plain loop's error, after the plain loop's check of the stop ids
         }
         KR_HIP(hipStreamSynchronize(st));
         stamp();

@@ -513,7 +513,8 @@ __device__ __forceinline__ bool kr_f_topk(const float (&val)[NV], int n, int np,
 // scoring + top-k by ONE wave (moe_route_score_topk + topk_indices, decode.rs:4088-4186, 1495-1535): the scores and the renormalisation are
 // wave trees; the selection is the (value desc, index asc) wave top-k of kr_topk.h; softmax without a correction bias selects on the LOGITS
 // (softmax is monotone), so for identical logits the ids are those of the exact kernel unless two of the leading k + 1 are EQUAL -- then the
-// reference's heap order decides and is emulated serially, as in the exact kernel.
+// reference's heap order decides and is emulated serially, as in the exact kernel.  (Stated exception of the `lean` path below, krasis_hip.h KR_DECODE_FAST: it compares
+// LOGITS; two distinct logits whose f32 softmax scores coincide are a tie for the exact kernel only.)
 // sm: [E] scores, [E] selection values, [33] pv, [33] pi, [32] hv, [32] hi, [2] pad, [128] candidate list
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int NV>
@@ -741,7 +742,9 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     const int slot = vslot < nrw ? vslot / pr : a.topk, part = vslot < nrw ? vslot % pr : vslot - nrw, parts = vslot < nrw ? pr : ps;
     const int tile = blockIdx.x;
     KR_FSTAMP(5, 0);
-    const float sig = a.gate_out ? a.gate_out[0] : 1.0f;     // sigmoid(gate row) of the shared expert, formed by the gate|up launch
+    // sigmoid(gate row) of the shared expert, formed by the gate|up launch.  A rank that skips this layer's shared expert (expert-parallel decode) never wrote it:
+    // it neither reads the value nor adds the term (0 * stale bits could be NaN and the all-reduce would spread it -- ADVICE r4 #2)
+    const float sig = (a.gate_out && !fa.shared_skip) ? a.gate_out[0] : 1.0f;
     const bool shared = slot >= a.topk;
     const bool gg = fa.gguf && !shared;
     const KrMatDev& m = (shared || fa.gguf) ? a.sw2 : a.w2;      // (a GGUF slot never reads m: the shared expert's matrix stands in so that the fields are defined)
@@ -824,7 +827,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
             for (int sl = 0; sl < 8; sl++) { const float pd = w[sl] * (y[2 * sl] + y[2 * sl + 1]); o += sl < a.topk ? pd : 0.0f; }      // pr == 2: the two parts of a slot sit side by side
         }
         if (a.rsf != 1.0f) o *= a.rsf;
-        if (a.n_slots > a.topk) {
+        if (a.n_slots > a.topk && !fa.shared_skip) {
             float sh = 0.0f;
 #pragma unroll
             for (int p = 0; p < 4; p++) sh += p < ps ? s_y[(nrw + p) & 15][t] : 0.0f;

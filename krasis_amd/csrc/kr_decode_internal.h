@@ -53,6 +53,7 @@ struct kr_decode_store {
     int opt_gqa_stream = 0, opt_pfm_timing = 0;   // kr_decode_set_option: test / tuning hooks (no environment lookups on launch paths)
     int opt_gen_lookahead = 0;                    // kr_decode_set_option("generate_lookahead"): generate_batch feeds the sampled token back ON THE DEVICE and queues step i + 1 before the host has read token i
     int opt_ep_graph = 0;                         // kr_decode_set_option("ep_graph"): expert-parallel decode over RCCL replays a captured graph (the all-reduce is captured with the kernels)
+    uint64_t ep_generation_seen = 0;               // kr_engine::ep_generation at the last step: a new / destroyed communicator invalidates the graph and restarts the warm-up
     int ep_eager_steps = 0;                        // expert-parallel decode: steps enqueued eagerly so far (RCCL warms up outside any capture)
     int* gen_ring = nullptr; int gen_ring_n = 0; hipEvent_t gen_ev[2] = {nullptr, nullptr};   // pinned token ring + events of the look-ahead loop
     int decode_fast = 0; DevBuf f_qk;         // KR_DECODE_FAST: decode steps on the tolerance-mode kernels (kr_decode_fast.hip); f_qk = conv outputs [nk][q(dk) | k(dk)]
@@ -81,6 +82,7 @@ enum { PK_EMBED = 0, PK_RMSNORM, PK_MATVEC, PK_LA_CONV, PK_LA_RECUR, PK_GATED_NO
 
 static inline KrMatDev mv(kr_decode_store* s, int wid) { return s->weights[wid]->ms.view(); }
 int kr_ensure_wsum(kr_engine* e, MatSet& ms, hipStream_t st);
+int kr_moe_prefill_prepare(kr_engine* e, int layer, int fast, int routed_only, hipStream_t st);   // kr_engine.cpp: the lazily derived data of a native-GGUF layer, built on `st` now
 void kr_standalone_release(kr_decode_store* s);
 int kr_standalone_cancelled(kr_decode_store* s);
 void kr_standalone_set_elapsed(kr_decode_store* s, double sec);   // kr_engine.cpp: per (group, column) nibble sums for the int8-MFMA GEMM

@@ -315,6 +315,7 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
             if (int rc = kr_ensure_gate_row(e, Ly.moe_layer)) return rc;
             if (int rc = kr_ensure_wsum(e, EL.w13, st)) return rc;
             if (int rc = kr_ensure_wsum(e, EL.w2, st)) return rc;
+            if (int rc = kr_moe_prefill_prepare(e, Ly.moe_layer, s->gemm_fast ? 1 : 0, 1, st)) return rc;     // native-GGUF layers: block sums / tolerance copies, before any chunk stream runs
         } else if (Ly.mlp == MLP_DENSE) {
             sid = std::max(sid, 2 * (size_t)s->weights[Ly.down_wid]->cols); kmax = std::max(kmax, (size_t)s->weights[Ly.down_wid]->cols);
             for (int w : {Ly.gate_wid, Ly.up_wid, Ly.down_wid}) wids.push_back(w);

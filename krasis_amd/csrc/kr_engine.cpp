@@ -881,6 +881,27 @@ static bool gg_fast_ok(const Layer& L, int H, bool use_shared) {
     if (use_shared) ok = ok && q4(L.gs_gate, H) && q4(L.gs_up, H) && L.gs_gate.type == L.gs_up.type && q4(L.gs_down, L.shared_inter) && L.shared_inter % 32 == 0 && L.shared_inter <= 2048;
     return ok;
 }
+// Everything moe_prefill_gguf / moe_prefill_gguf_fast would build lazily for one layer, built NOW on `st`.  The whole-model prompt pass calls this for every
+// MoE layer on its main stream before the start event (kr_decode_prefill.cpp prefill_impl): with several chunks in flight on several streams, a lazy build
+// queued on chunk c's stream is not ordered before chunk c + 1's GEMMs on another stream.
+int kr_moe_prefill_prepare(kr_engine* e, int layer, int fast, int routed_only, hipStream_t st) {
+    Layer& L = e->layers[layer];
+    if (!L.gguf) return KR_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
+    const bool use_shared = L.gguf_shared && !routed_only;
+    if (fast && gg_fast_ok(L, e->cfg.hidden_size, use_shared)) {
+        if (int rc = gg_ensure_fast(e, L.g_gate, &L.g_up, st)) return rc;
+        if (int rc = gg_ensure_fast(e, L.g_down, nullptr, st)) return rc;
+        if (use_shared) { if (int rc = gg_ensure_fast(e, L.gs_gate, &L.gs_up, st)) return rc; if (int rc = gg_ensure_fast(e, L.gs_down, nullptr, st)) return rc; }
+        return KR_OK;
+    }
+    bool mfma = kr_gpf_type_supported(L.g_gate.type, e->cfg.hidden_size) && kr_gpf_type_supported(L.g_down.type, L.inter);
+    if (use_shared) mfma = mfma && kr_gpf_type_supported(L.gs_gate.type, e->cfg.hidden_size) && kr_gpf_type_supported(L.gs_down.type, L.shared_inter);
+    if (!mfma) return KR_OK;
+    for (GgufSet* g : {&L.g_gate, &L.g_up, &L.g_down}) if (int rc = gg_ensure_ws(e, *g, st)) return rc;
+    if (use_shared) for (GgufSet* g : {&L.gs_gate, &L.gs_up, &L.gs_down}) if (int rc = gg_ensure_ws(e, *g, st)) return rc;
+    return KR_OK;
+}
 // the prompt pass of a native Q4_K layer in the tolerance form: f16 rows (+ their per-32 sums) x nibbles de-quantized in registers with the
 // sub-block scale folded in, offsets as extra k-columns, libm SiLU like expert_forward_gguf (gguf_kernels.rs:690-756).  Same sort / combine as the exact path.
 static int moe_prefill_gguf_fast(kr_engine* e, Layer& L, const void* x_bf16, const int32_t* ids, const float* wts, void* out, int M, int topk,

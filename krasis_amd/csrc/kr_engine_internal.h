@@ -111,6 +111,7 @@ struct kr_engine {
     // per-kernel profiling (kr_set_profiling): HIP events around each launch, accumulated per kernel kind
     bool prof = false; hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr}; double prof_ms[8] = {0}; long prof_n[8] = {0};
     std::mutex mu;
+    uint64_t ep_generation = 0;         // bumped by kr_ep_init* / kr_ep_destroy: a decode store drops its captured graph and its eager warm-up count when it changes
     struct kr_ep_state* ep = nullptr;   // expert parallelism (kr_ep.cpp): communicator, exchange buffers
 };
 extern "C" int kr_ep_destroy(kr_engine* e);

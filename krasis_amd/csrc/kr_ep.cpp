@@ -239,7 +239,7 @@ static int ep_init_common(kr_engine* e, int world, int rank, int n_experts_total
 }
 static int ep_init_finish(kr_engine* e, std::unique_ptr<kr_ep_state>& s) {
     if (int rc = s->ensure_set(0)) return rc;
-    e->ep = s.release();
+    e->ep = s.release(); e->ep_generation++;
     return KR_OK;
 }
 
@@ -309,7 +309,7 @@ extern "C" int kr_ep_destroy(kr_engine* e) {
         if (b.cnt_host) (void)hipHostFree(b.cnt_host);
         if (b.ev) (void)hipEventDestroy(b.ev);
     }
-    delete s; e->ep = nullptr;
+    delete s; e->ep = nullptr; e->ep_generation++;
     return KR_OK;
 }
 

@@ -75,3 +75,27 @@ def test_generate_lookahead_gives_the_same_tokens(temperature, top_k, top_p, pen
     stopped = st.generate_batch(9, 5, 7, temperature, top_k, top_p, (plain[3],), penalty, rng_seed=seed)
     assert stopped == plain[:plain.index(plain[3]) + 1]
     st.set_option("generate_lookahead", 0)
+
+
+def test_generate_lookahead_stop_at_the_last_cache_position():
+    """the look-ahead loop queues step i + 1 before it reads token i.  When token i is a stop id produced at the LAST position of the cache
+    (kv_max_seq - 1), there is no step i + 1 to queue: the loop must return the tokens like the plain loop, not the position error of a speculative step."""
+    st, eng, orc, keep, d = build(seed=3)                           # kv_max = 32
+    start = d["kv_max"] - 3
+    plain = st.generate_batch(11, start, 3)                          # positions kv_max - 3 .. kv_max - 1: fills the cache exactly
+    assert len(plain) == 3
+    d["reset"]()
+    stopped_plain = st.generate_batch(11, start, 8, stop_ids=(plain[2],))
+    d["reset"]()
+    st.set_option("generate_lookahead", 1)
+    try:
+        stopped_ahead = st.generate_batch(11, start, 8, stop_ids=(plain[2],))
+        assert stopped_ahead == stopped_plain == plain[:plain.index(plain[2]) + 1]
+        d["reset"]()
+        with pytest.raises(ValueError):                                  # no stop id: both loops run off the end of the cache and say so
+            st.generate_batch(11, start, 8)
+    finally:
+        st.set_option("generate_lookahead", 0)
+    d["reset"]()
+    with pytest.raises(ValueError):
+        st.generate_batch(11, start, 8)

@@ -171,6 +171,17 @@ r4b)        # round 4: tests that failed / are new since r4a, the bench line, th
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r04_bench_line.json 2> $R/r04_bench_line.err; echo "bench rc=$?"; tail -c 600 $R/r04_bench_line.err
     python tools/bench_summary.py $R/r04_bench_line.json
     ;;
+r5a)        # round 5, first contact: ADVICE r4 fixes (their tests), the compact bench line as the driver reads it, cache-residency upper bound of the decode step, kernel trace
+    timeout 900 python -m pytest tests/test_sampler_gpu.py tests/test_ep_gpu.py tests/test_decode_fast_gpu.py tests/test_prefill_model_gpu.py -q -x 2>&1 | tail -5
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r05_bench_stdout.txt 2> $R/r05_bench_stderr.txt; echo "bench rc=$?"
+    tail -1 $R/r05_bench_stdout.txt > $R/r05_bench_line.json; echo "last stdout line: $(wc -c < $R/r05_bench_line.json) bytes, stdout lines: $(wc -l < $R/r05_bench_stdout.txt)"
+    python -c "import json,sys; d=json.load(open('$R/r05_bench_line.json')); print({k: d[k] for k in ('value','value_exact','ms_per_step')}, d['roofline'])"
+    cp $R/bench_detail.json $R/r05_bench_detail.json 2>/dev/null
+    timeout 600 python tools/probes/decode_mall_probe.py 2>&1 | tail -24
+    kstats r05_decode_fast_a "QCN Q4 decode step, KR_DECODE_FAST, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only fast --steps 30)" -- \
+        python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r05_decode_fast_prof
+    rm -rf $R/prof_* $R/*.log
+    ;;
 tests)      # the whole GPU suite, as the driver runs it
     timeout 2400 python -m pytest tests/ -x -q -m gpu "$@" 2>&1 | tail -15
     ;;
