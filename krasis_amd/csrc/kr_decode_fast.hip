@@ -115,43 +115,78 @@ __device__ __forceinline__ float kr_f_tile(KrFw<BITS, NU, FU>& p, const KrMatDev
     return kr_f_red8(acc);
 }
 
-// pre-built activation image (global memory, byte layout == the LDS image for INT4 weights) -> LDS by threads [t0, t0 + nthr) of the workgroup
-template <int BITS>
-__device__ __forceinline__ void kr_f_image_copy(const void* img, int K, u32x4* smem, const KrActLds& L, int tt, int nthr) {
+// pre-built activation image (global memory, byte layout == the LDS image for INT4 weights) -> LDS by threads [t0, t0 + nthr) of the workgroup.
+// Two phases: the first KR_FIMG records of a thread are requested by kr_f_image_load (before the caller's weight stream, see kr_f_norm_load) and stored by
+// kr_f_image_store, which also walks whatever lies beyond them (K > 4096 * nthr / 256).
+#define KR_FIMG 3
+struct KrFImg { u32x4 r[KR_FIMG]; };
+__device__ __forceinline__ void kr_f_image_load(const void* img, int K, KrFImg& R, int tt, int nthr) {
     const int n16 = (int)(kr_lds_bytes(K, false) / 16);
     const u32x4* src = reinterpret_cast<const u32x4*>(img);
-    for (int i = tt; i < n16; i += nthr) {
-        const u32x4 r = src[i];
-        smem[i] = r;
-        if constexpr (BITS == 8) {
-            if (i < K / 8) {
-                uint32_t* p = reinterpret_cast<uint32_t*>(L.planes8) + (i >> 1) * 8 + (i & 1) * 2;
-                p[0] = __builtin_amdgcn_perm(r.y, r.x, 0x05010400u);
-                p[1] = __builtin_amdgcn_perm(r.y, r.x, 0x07030602u);
-                p[4] = __builtin_amdgcn_perm(r.w, r.z, 0x05010400u) ^ 0x80808080u;
-                p[5] = __builtin_amdgcn_perm(r.w, r.z, 0x07030602u) ^ 0x80808080u;
-            }
+#pragma unroll
+    for (int j = 0; j < KR_FIMG; j++)
+        if (j == 0 || n16 > j * nthr) { const int i = tt + j * nthr; R.r[j] = src[i < n16 ? i : n16 - 1]; }      // (uniform guard, every lane loads: see kr_f_norm_load)
+}
+template <int BITS>
+__device__ __forceinline__ void kr_f_image_put(const u32x4 r, int i, int K, u32x4* smem, const KrActLds& L) {
+    smem[i] = r;
+    if constexpr (BITS == 8) {
+        if (i < K / 8) {
+            uint32_t* p = reinterpret_cast<uint32_t*>(L.planes8) + (i >> 1) * 8 + (i & 1) * 2;
+            p[0] = __builtin_amdgcn_perm(r.y, r.x, 0x05010400u);
+            p[1] = __builtin_amdgcn_perm(r.y, r.x, 0x07030602u);
+            p[4] = __builtin_amdgcn_perm(r.w, r.z, 0x05010400u) ^ 0x80808080u;
+            p[5] = __builtin_amdgcn_perm(r.w, r.z, 0x07030602u) ^ 0x80808080u;
         }
     }
 }
+template <int BITS>
+__device__ __forceinline__ void kr_f_image_store(const void* img, int K, const KrFImg& R, u32x4* smem, const KrActLds& L, int tt, int nthr) {
+    const int n16 = (int)(kr_lds_bytes(K, false) / 16);
+    const u32x4* src = reinterpret_cast<const u32x4*>(img);
+#pragma unroll
+    for (int j = 0; j < KR_FIMG; j++) { const int i = tt + j * nthr; if (i < n16) kr_f_image_put<BITS>(R.r[j], i, K, smem, L); }
+    for (int i = tt + KR_FIMG * nthr; i < n16; i += nthr) kr_f_image_put<BITS>(src[i], i, K, smem, L);
+}
+template <int BITS>
+__device__ __forceinline__ void kr_f_image_copy(const void* img, int K, u32x4* smem, const KrActLds& L, int tt, int nthr) {
+    KrFImg R;
+    kr_f_image_load(img, K, R, tt, nthr);
+    kr_f_image_store<BITS>(img, K, R, smem, L, tt, nthr);
+}
 
-// fused add + RMSNorm (decode.rs:1199) of a vector of n <= 4096 values by a 256-thread workgroup: thread t owns chunks t and t + 256 (8 values
-// each).  Returns the normalised values in x[u][*]; the caller quantises / stores them.  The sum of squares is a tree (lane, wave, workgroup).
 struct KrFNormIn { const float *hid, *res, *w; float* res_out; int first; float eps; int bias_one; int n; };
-__device__ __forceinline__ void kr_f_norm(const KrFNormIn& in, float (&x)[2][8], float* s_red, bool write_res) {
+// The inputs of the norm are REQUESTED by kr_f_norm_load and consumed by kr_f_norm_finish: a kernel issues these (and every other small load whose address it
+// knows) BEFORE its weight stream.  The memory counter of a wave is in-order: a small load issued behind 16 weight records is not back before all of them are,
+// and (round 4's kernels) a prologue that loads, waits, computes, loads again walks one memory round trip after the other behind the whole weight stream
+// (profiles/r05_decode_fast_stamps.txt: "norm + image" 2.1 us of the in-projection launch).
+struct KrFNormRegs { float h[2][8], r[2][8], w[2][8]; };
+// (Every lane loads: a lane without a chunk reads the last one and never uses it.  A load under a lane mask whose destination has a default value costs a
+// wait for the WHOLE memory counter at the merge -- the default's v_mov is a write-after-write on a register with a load in flight.)
+__device__ __forceinline__ void kr_f_norm_load(const KrFNormIn& in, KrFNormRegs& R) {
     const int t = threadIdx.x, nch = in.n / 8;
-    float wv[2][8];
+    {
+        const int c = t < nch ? t : nch - 1;
+        kr_load8(in.hid, c, R.h[0]);
+        if (!in.first) kr_load8(in.res, c, R.r[0]);
+        kr_load8(in.w, c, R.w[0]);
+    }
+    if (nch > 256) {      // workgroup-uniform
+        const int c = t + 256 < nch ? t + 256 : nch - 1;
+        kr_load8(in.hid, c, R.h[1]);
+        if (!in.first) kr_load8(in.res, c, R.r[1]);
+        kr_load8(in.w, c, R.w[1]);
+    }
+}
+__device__ __forceinline__ void kr_f_norm_finish(const KrFNormIn& in, const KrFNormRegs& R, float (&x)[2][8], float* s_red, bool write_res) {
+    const int t = threadIdx.x, nch = in.n / 8;
     float ss = 0.0f;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int c = t + 256 * u;
         if (c < nch) {
-            float h[8], r[8];
-            kr_load8(in.hid, c, h);
-            kr_load8(in.w, c, wv[u]);
-            if (!in.first) kr_load8(in.res, c, r);
 #pragma unroll
-            for (int i = 0; i < 8; i++) { x[u][i] = in.first ? h[i] : (h[i] + r[i]); ss = __builtin_fmaf(x[u][i], x[u][i], ss); }
+            for (int i = 0; i < 8; i++) { x[u][i] = in.first ? R.h[u][i] : (R.h[u][i] + R.r[u][i]); ss = __builtin_fmaf(x[u][i], x[u][i], ss); }
             if (write_res) {
                 float4* ro = reinterpret_cast<float4*>(in.res_out + (size_t)c * 8);
                 ro[0] = float4{x[u][0], x[u][1], x[u][2], x[u][3]}; ro[1] = float4{x[u][4], x[u][5], x[u][6], x[u][7]};
@@ -166,7 +201,14 @@ __device__ __forceinline__ void kr_f_norm(const KrFNormIn& in, float (&x)[2][8],
 #pragma unroll
     for (int u = 0; u < 2; u++)
 #pragma unroll
-        for (int i = 0; i < 8; i++) x[u][i] = (x[u][i] * rms) * (in.bias_one ? (wv[u][i] + 1.0f) : wv[u][i]);
+        for (int i = 0; i < 8; i++) x[u][i] = (x[u][i] * rms) * (in.bias_one ? (R.w[u][i] + 1.0f) : R.w[u][i]);
+}
+// fused add + RMSNorm (decode.rs:1199) of a vector of n <= 4096 values by a 256-thread workgroup: thread t owns chunks t and t + 256 (8 values
+// each).  Returns the normalised values in x[u][*]; the caller quantises / stores them.  The sum of squares is a tree (lane, wave, workgroup).
+__device__ __forceinline__ void kr_f_norm(const KrFNormIn& in, float (&x)[2][8], float* s_red, bool write_res) {
+    KrFNormRegs R;
+    kr_f_norm_load(in, R);
+    kr_f_norm_finish(in, R, x, s_red, write_res);
 }
 
 // quantize_activation_int16_f32 (avx2.rs:274) of the thread's chunk straight from registers (its 128-group = its 16-lane row)
@@ -187,75 +229,92 @@ __device__ __forceinline__ void kr_f_quant_chunk(const float (&v)[8], int c, con
 // ---------------------------------------------------------------------------------------------------------------------------------
 // K1 / K3: multi-matrix dequant-matvec.  KS waves split the K range of a tile, 4 / KS tiles per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int BITS, int KS, int NU>
+template <int BITS, int KS, int NU, int MODE>
 __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
     constexpr int TW = 4 / KS;
     __shared__ float s_red[4];
     __shared__ float s_x[TW][KS][8];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
     const int tw = wave / KS, ks = wave - tw * KS;
-    [[maybe_unused]] const int sk = a.mode == 1 ? 0 : 2;
+    [[maybe_unused]] constexpr int sk = MODE == 1 ? 0 : 2;
     KR_FSTAMP(sk, 0);
+    // ---- requests, in the order they are needed back (a wave's memory counter is in-order): the input vector / image, then the weight stream, then the
+    //      epilogue's operands.  MODE is a template parameter so that no register of one mode's loads is ever seen as pending by another mode's code.
+    const int K = a.mm.m[0].ng * 128;
+    const KrActLds L = kr_carve_lds(kr_fsm, K, BITS == 8);
+    [[maybe_unused]] KrFNormRegs NR; [[maybe_unused]] KrFImg IR; [[maybe_unused]] float x8[2][8];
+    [[maybe_unused]] KrFNormIn in{nullptr, a.res_in, a.norm_w, a.res_out, a.first, a.eps, a.bias_one, K};
+    if constexpr (MODE == 0) kr_f_image_load(a.img, K, IR, t, 256);
+    else if constexpr (MODE == 2) {
+        const int nch = K / 8;
+        kr_load8(a.hid_in, t < nch ? t : nch - 1, x8[0]);
+        if (nch > 256) kr_load8(a.hid_in, t + 256 < nch ? t + 256 : nch - 1, x8[1]);
+    } else {
+        in.hid = a.emb ? a.emb + (size_t)a.step->token * K : a.hid_in;
+        kr_f_norm_load(in, NR);
+    }
     // the matrix of this tile: every field sits at a CONSTANT kernarg offset (one scalar round trip for all of them) and is selected
     // afterwards -- indexing the argument struct with a computed matrix index costs a second, dependent scalar round trip before the
     // first weight request can be issued.  The host sets tile_end[i] = total for every i >= n - 1.
     const int te0 = a.mm.tile_end[0], te1 = a.mm.tile_end[1], te2 = a.mm.tile_end[2], total = a.mm.tile_end[3];
-    const int gt = blockIdx.x * TW + tw;
-    const bool active = gt < total;
-    const int mi = active ? (gt >= te0) + (gt >= te1) + (gt >= te2) : 0;
+    const int gt0 = blockIdx.x * TW + tw;
+    const bool active = gt0 < total;
+    const int gt = active ? gt0 : total - 1;      // a wave past the last tile walks the last tile again and stores nothing: every wave issues the same requests (see kr_f_norm_load)
+    const int mi = (gt >= te0) + (gt >= te1) + (gt >= te2);
 #define KR_MSEL(f) (mi == 0 ? a.mm.m[0].f : (mi == 1 ? a.mm.m[1].f : (mi == 2 ? a.mm.m[2].f : a.mm.m[3].f)))
     KrMatDev m{};
     m.q = KR_MSEL(q); m.s = KR_MSEL(s); m.ng = KR_MSEL(ng); m.ngp = KR_MSEL(ngp); m.N = KR_MSEL(N);
     float* const my = mi == 0 ? a.mm.y[0] : (mi == 1 ? a.mm.y[1] : (mi == 2 ? a.mm.y[2] : a.mm.y[3]));
 #undef KR_MSEL
-    const int tile = active ? gt - (mi == 0 ? 0 : (mi == 1 ? te0 : (mi == 2 ? te1 : te2))) : 0;
+    const int tile = gt - (mi == 0 ? 0 : (mi == 1 ? te0 : (mi == 2 ? te1 : te2)));
     const int units = BITS == 4 ? m.ngp : m.ng;
     int u0, u1;
     if (NU > 0) { u0 = ks * NU; u1 = u0 + NU; }
     else { const int uw = (units + KS - 1) / KS; u0 = ks * uw; u1 = u0 + uw < units ? u0 + uw : units; }
     KrFw<BITS, NU> W;
-    if (active) kr_f_fetch<BITS, NU>(W, m, m.q, m.s, tile, lane, u0, u1);
-    // the lane that will hold column `col` asks for what its epilogue needs now: conv state / taps (linear-attention channels), gate constants
+    kr_f_fetch<BITS, NU>(W, m, m.q, m.s, tile, lane, u0, u1);
+    // the lane that will hold column `col` asks for what its epilogue needs -- conv state / taps of the linear-attention channels, gate constants -- BEHIND the
+    // weight stream (nothing of it is touched before the dot is done).  Every lane loads (index 0 where it has nothing to ask for) and no destination has a default.
     const int col = tile * 8 + cl;
     const bool out_lane = active && ks == 0 && l8 == 0 && col < m.N;
     int kind = -1, dst = 0, ch = 0;       // 0 q, 1 k, 2 v (conv channels), 3 z, 4 beta, 5 decay gate
-    float4 cs = float4{0.0f, 0.0f, 0.0f, 0.0f}, cw = cs;
+    float4 cs = float4{0.0f, 0.0f, 0.0f, 0.0f}, cw = cs;      // (MODE 1 assigns all four unconditionally below: the initial values are dead there and cost nothing)
     float g_al = 0.0f, g_dt = 0.0f;
-    if (out_lane && a.conv_state && mi == a.conv_mi) {
-        const int nt = a.hr * a.dv, gd = 2 * a.dk + 2 * nt, key_dim = a.nk * a.dk;
-        const int kh = col / gd, cc = col - kh * gd;
-        if (cc < a.dk) { kind = 0; ch = kh * a.dk + cc; dst = kh * 2 * a.dk + cc; }
-        else if (cc < 2 * a.dk) { kind = 1; ch = key_dim + kh * a.dk + (cc - a.dk); dst = kh * 2 * a.dk + cc; }
-        else if (cc < 2 * a.dk + nt) { kind = 2; ch = 2 * key_dim + kh * nt + (cc - 2 * a.dk); dst = kh * nt + (cc - 2 * a.dk); }
-        else { kind = 3; dst = kh * nt + (cc - 2 * a.dk - nt); }
-        if (kind < 3) { cs = reinterpret_cast<const float4*>(a.conv_state)[ch]; cw = reinterpret_cast<const float4*>(a.conv_w)[ch]; }
-    } else if (out_lane && a.conv_state && mi == a.gate_mi) {   // ba row: [kh][beta raw (hr) | a raw (hr)] (decode.rs:3891-3901)
-        const int kh = col / (2 * a.hr), idx = col - kh * 2 * a.hr;
-        if (idx < a.hr) { kind = 4; dst = kh * a.hr + idx; }
-        else { kind = 5; dst = kh * a.hr + (idx - a.hr); g_al = a.a_log[dst]; g_dt = a.dt_bias[dst]; }
-    }
-    const int K = a.mm.m[0].ng * 128;
-    const KrActLds L = kr_carve_lds(kr_fsm, K, BITS == 8);
-    KR_FSTAMP(sk, 1);
-    if (a.mode == 0) kr_f_image_copy<BITS>(a.img, K, kr_fsm, L, t, 256);
-    else if (a.mode == 2) {      // plain f32 input vector (MLA: the w_vc output feeding o_proj): every workgroup quantises it (quantize_activation_int16_f32, avx2.rs:274)
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int c = t + 256 * u;
-            if (c < K / 8) { float x8[8]; kr_load8(a.hid_in, c, x8); kr_f_quant_chunk<BITS == 8>(x8, c, L, false); }
+    if constexpr (MODE == 1) {
+        const bool la = a.conv_state != nullptr;      // workgroup-uniform; without the epilogue the four requests read the norm weights (any valid address) and are dropped
+        if (la && out_lane && mi == a.conv_mi) {
+            // (24-bit multiplies and selects instead of branches: a 64-bit v_mad here pairs its 32-bit addend with whatever register follows it -- one that a weight
+            //  request is still writing, as it happened -- and the wave waits for the whole stream before it may start on the norm)
+            const int nt = a.hr * a.dv, gd = 2 * a.dk + 2 * nt, key_dim = a.nk * a.dk;
+            const int kh = col / gd, cc = col - __mul24(kh, gd);
+            const int khk = __mul24(kh, a.dk), kht = __mul24(kh, nt);
+            kind = cc < a.dk ? 0 : (cc < 2 * a.dk ? 1 : (cc < 2 * a.dk + nt ? 2 : 3));
+            ch = kind == 0 ? khk + cc : (kind == 1 ? key_dim + khk + (cc - a.dk) : 2 * key_dim + kht + (cc - 2 * a.dk));
+            dst = kind < 2 ? 2 * khk + cc : (kind == 2 ? kht + (cc - 2 * a.dk) : kht + (cc - 2 * a.dk - nt));
+        } else if (la && out_lane && mi == a.gate_mi) {   // ba row: [kh][beta raw (hr) | a raw (hr)] (decode.rs:3891-3901)
+            const int kh = col / (2 * a.hr), idx = col - __mul24(kh, 2 * a.hr);
+            kind = idx < a.hr ? 4 : 5;
+            dst = __mul24(kh, a.hr) + (idx < a.hr ? idx : idx - a.hr);
         }
+        const int chl = (kind >= 0 && kind < 3) ? ch : 0, gl = kind == 5 ? dst : 0;
+        cs = reinterpret_cast<const float4*>(la ? a.conv_state : a.norm_w)[chl]; cw = reinterpret_cast<const float4*>(la ? a.conv_w : a.norm_w)[chl];
+        g_al = (la ? a.a_log : a.norm_w)[gl]; g_dt = (la ? a.dt_bias : a.norm_w)[gl];
+    }
+    KR_FSTAMP(sk, 1);
+    if constexpr (MODE == 0) kr_f_image_store<BITS>(a.img, K, IR, kr_fsm, L, t, 256);
+    else if constexpr (MODE == 2) {      // plain f32 input vector (MLA: the w_vc output feeding o_proj): every workgroup quantises it (quantize_activation_int16_f32, avx2.rs:274)
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int c = t + 256 * u; if (c < K / 8) kr_f_quant_chunk<BITS == 8>(x8[u], c, L, false); }
     } else {
-        KrFNormIn in{a.emb ? a.emb + (size_t)a.step->token * K : a.hid_in, a.res_in, a.norm_w, a.res_out, a.first, a.eps, a.bias_one, K};
         float x[2][8];
-        kr_f_norm(in, x, s_red, blockIdx.x == 0);
+        kr_f_norm_finish(in, NR, x, s_red, blockIdx.x == 0);
 #pragma unroll
         for (int u = 0; u < 2; u++) { const int c = t + 256 * u; if (c < K / 8) kr_f_quant_chunk<BITS == 8>(x[u], c, L, false); }
     }
     KR_FSTAMP(sk, 2);
     __syncthreads();
     KR_FSTAMP(sk, 3);
-    float acc = 0.0f;
-    if (active) acc = kr_f_tile<BITS, NU>(W, m, m.q, m.s, tile, lane, u0, u1, L);
+    float acc = kr_f_tile<BITS, NU>(W, m, m.q, m.s, tile, lane, u0, u1, L);
     KR_FSTAMP(sk, 4);
     if constexpr (KS > 1) {
         if (l8 == 0) s_x[tw][ks][cl] = acc;
@@ -396,9 +455,8 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
 // K4: post-attention add + RMSNorm folded into the router gate GEMV (decode.rs:1385-1429).  One workgroup per block of 4 experts, its 4 waves
 // split the K range of the chain-major gate rows.  Workgroups 0 / 1 also publish the residual and the two INT16 images.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <bool GATE_BF16>
+template <bool GATE_BF16, int CPW>      // CPW: 16-byte gate chunks per lane and wave kept in flight, the power of two >= ceil(chunks / 4) (H <= 4096: bf16 <= 8, f32 <= 16)
 __global__ void __launch_bounds__(256) kr_frt_kernel(const KrFrtArgs a) {
-    constexpr int CPW = 16;   // 16-byte gate chunks per lane and wave kept in flight (H <= 4096: bf16 8, f32 16)
     float* xs = reinterpret_cast<float*>(kr_fsm);   // [16][ld] chain-major copy of the normalised hidden
     __shared__ float s_red[4];
     __shared__ float s_part[4][4];
@@ -409,12 +467,14 @@ __global__ void __launch_bounds__(256) kr_frt_kernel(const KrFrtArgs a) {
     const int ncg = GATE_BF16 ? H / 128 : H / 64;
     const int cpw = (ncg + 3) / 4, c0 = wave * cpw, c1 = c0 + cpw < ncg ? c0 + cpw : ncg;
     const u32x4* gp = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)eb * ncg * 64 + lane;
+    KrFNormIn in{a.hid_in, a.res_in, a.norm_w, a.res_out, 0, a.eps, a.bias_one, H};
+    KrFNormRegs NR;
+    kr_f_norm_load(in, NR);      // the norm's inputs come back first, the gate rows stream behind them (kr_f_norm_load)
     u32x4 gw[CPW];
 #pragma unroll
-    for (int u = 0; u < CPW; u++) if (c0 + u < c1) gw[u] = kr_ldg_nt(gp + (size_t)(c0 + u) * 64);
-    KrFNormIn in{a.hid_in, a.res_in, a.norm_w, a.res_out, 0, a.eps, a.bias_one, H};
+    for (int u = 0; u < CPW; u++) { const int c = c0 + u < ncg ? c0 + u : ncg - 1; gw[u] = kr_ldg_nt(gp + (size_t)c * 64); }      // (every wave issues CPW requests: past the row's end it re-reads the last chunk)
     float x[2][8];
-    kr_f_norm(in, x, s_red, blockIdx.x == 0);
+    kr_f_norm_finish(in, NR, x, s_red, blockIdx.x == 0);
     KR_FSTAMP(3, 1);
     const bool img_f = a.img_f32 && blockIdx.x == 0, img_b = a.img_bf16 && blockIdx.x == (gridDim.x > 1 ? 1 : 0);
 #pragma unroll
@@ -485,7 +545,9 @@ __device__ __forceinline__ bool kr_f_topk(const float (&val)[NV], int n, int np,
 #pragma unroll
     for (int i = 0; i < NV; i++) { const int e = lane * NV + i; key[i] = e < n ? kr_make_key(val[i]) : 0u; h = kr_umax(h, key[i]); }
     uint32_t T = 0u;
+    KR_FSTAMP(6, 2);
     for (int r = 0; r < np; r++) { const uint32_t w = kr_wave_umax(h); T = w; if (h == w) h = 0u; }
+    KR_FSTAMP(6, 3);
     int base = 0;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
@@ -498,6 +560,7 @@ __device__ __forceinline__ bool kr_f_topk(const float (&val)[NV], int n, int np,
     const int M = base;
     if (M > 64) return false;
     kr_f_wave_sync();
+    KR_FSTAMP(6, 4);
     uint32_t kj = 0u, ij = 0u;
     if (lane < M) { kj = cand[2 * lane]; ij = cand[2 * lane + 1]; }
     int rank = 0;
@@ -524,6 +587,7 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
     uint32_t* cand = reinterpret_cast<uint32_t*>(hi + 32 + 2);      // [128]
     const int lane = threadIdx.x & 63;
     const bool raw = scoring == 2;
+    KR_FSTAMP(6, 0);
     float lg[NV], sc[NV], sl[NV];
     // softmax scoring without a correction bias, weights renormalised over the k leaders (QCN, Qwen3-235B): the selection runs on the logits (softmax is
     // monotone) and the renormalised weight of leader i is e^{l_i - m} / sum over the LEADERS of e^{l_j - m} -- the full-softmax denominator cancels, so the E
@@ -546,6 +610,10 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
 #pragma unroll
         for (int i = 0; i < NV; i++) { const int e = lane * NV + i; lg[i] = e < E ? logits[e] : -__builtin_inff(); }
     }
+#ifdef KR_FTIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    KR_FSTAMP(6, 1);
     if (raw || lean) {
 #pragma unroll
         for (int i = 0; i < NV; i++) sc[i] = lg[i];
@@ -576,6 +644,7 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
     const int np = k + 1 <= E ? k + 1 : k;
     if (!kr_f_topk<NV>(sl, E, np, pv, pi, cand)) kr_topk_wave_reg<NV>(sl, E, np, pv, pi);
     kr_f_wave_sync();
+    KR_FSTAMP(6, 5);
     {
         const float pa = lane < np ? pv[lane] : 0.0f, pb = lane + 1 < np ? pv[lane + 1] : 0.0f;
         const bool tie = __ballot(lane + 1 < np && pa == pb) != 0ull;
@@ -597,6 +666,7 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
         const float se = kr_f_wave_sum(wv);
         wv = wv / se;
         if (lane < k) { s_ids[lane] = my; s_w[lane] = wv; }
+        KR_FSTAMP(6, 6);
         return;
     }
     float wv = lane < k ? scores[my] : 0.0f;
@@ -749,6 +819,15 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     const bool gg = fa.gguf && !shared;
     const KrMatDev& m = (shared || fa.gguf) ? a.sw2 : a.w2;      // (a GGUF slot never reads m: the shared expert's matrix stands in so that the fields are defined)
     const int inter = shared ? a.I_shared : a.I;
+    // one wave per slot over an exact unit count: the lane's chunks of the expert hidden are requested before anything else (ahead of the routing record and the
+    // weight stream, which waits for the record: see kr_f_norm_load)
+    constexpr int HC = (NU > 0 && !MULTI) ? (BITS == 4 ? NU / 2 : NU / 4) : 0;
+    [[maybe_unused]] float hpre[HC > 0 ? HC : 1][8];
+    if constexpr (HC > 0) {
+        const float* hp = a.gu + (size_t)slot * a.gu_ld;
+#pragma unroll
+        for (int j = 0; j < HC; j++) kr_load8(hp, lane + 64 * j, hpre[j]);
+    }
     const void* qb = m.q; const uint32_t* sb = m.s;
     bool valid = true; float wt = 1.0f;
     bool skip = false;        // expert-parallel decode: slot evaluated by another rank -- this wave contributes 0 and reads no weights
@@ -787,7 +866,22 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     KR_FSTAMP(5, 1);
     const bool half_away = shared && a.shared_decode;
     const int cpu = (BITS == 4 ? 256 : 128) / 8;            // 8-value chunks per unit
-    if (!skip)
+    if constexpr (HC > 0) {
+        if (!skip)
+#pragma unroll
+        for (int j = 0; j < HC; j++) {
+            const int c = lane + 64 * j;
+            float mx = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(hpre[j][i]));
+            float scale, inv;
+            kr_group_scale(mx, scale, inv);
+            int q[8];
+            if (half_away) kr_quant8<false>(hpre[j], inv, q); else kr_quant8<true>(hpre[j], inv, q);
+            kr_store_chunk<BITS == 8>(L, c, q);
+            if ((c & 15) == 0) L.ascale[c >> 4] = scale;
+        }
+    } else if (!skip)
     for (int c = u0 * cpu + lane; c < (u1 * cpu < inter / 8 ? u1 * cpu : inter / 8); c += 64) {
         float v[8];
         kr_load8(h, c, v);
@@ -843,9 +937,9 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
 // ---------------------------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int BITS, int KS>
-static int kr_fdm_launch_nu(const KrFdmArgs& a, int nu, dim3 grid, size_t lds, hipStream_t st) {
-#define KR_FDM(N_) hipLaunchKernelGGL((kr_fdm_kernel<BITS, KS, N_>), grid, dim3(256), lds, st, a)
+template <int BITS, int KS, int MODE>
+static int kr_fdm_launch_nu2(const KrFdmArgs& a, int nu, dim3 grid, size_t lds, hipStream_t st) {
+#define KR_FDM(N_) hipLaunchKernelGGL((kr_fdm_kernel<BITS, KS, N_, MODE>), grid, dim3(256), lds, st, a)
     switch (nu) {
         case 2: KR_FDM(2); break;
         case 4: KR_FDM(4); break;
@@ -855,6 +949,12 @@ static int kr_fdm_launch_nu(const KrFdmArgs& a, int nu, dim3 grid, size_t lds, h
     }
 #undef KR_FDM
     return 0;
+}
+template <int BITS, int KS>
+static int kr_fdm_launch_nu(const KrFdmArgs& a, int nu, dim3 grid, size_t lds, hipStream_t st) {
+    if (a.mode == 0) return kr_fdm_launch_nu2<BITS, KS, 0>(a, nu, grid, lds, st);
+    if (a.mode == 2) return kr_fdm_launch_nu2<BITS, KS, 2>(a, nu, grid, lds, st);
+    return kr_fdm_launch_nu2<BITS, KS, 1>(a, nu, grid, lds, st);
 }
 
 int kr_launch_fdm(const KrFdmArgs& a, hipStream_t st) {
@@ -901,8 +1001,11 @@ int kr_launch_frt(const KrFrtArgs& a, hipStream_t st) {
     if (a.H % 128 || a.H > 4096 || a.H < 256) return 1;
     const size_t lds = (size_t)16 * (a.H / 16 + 4) * 4;
     dim3 grid((a.E + 3) / 4);
-    if (a.gate_bf16) hipLaunchKernelGGL(kr_frt_kernel<true>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(kr_frt_kernel<false>, grid, dim3(256), lds, st, a);
+    const int ncg = a.gate_bf16 ? a.H / 128 : a.H / 64, cpw = (ncg + 3) / 4;
+#define KR_FRT(B_, C_) hipLaunchKernelGGL((kr_frt_kernel<B_, C_>), grid, dim3(256), lds, st, a)
+    if (a.gate_bf16) { if (cpw <= 1) KR_FRT(true, 1); else if (cpw <= 2) KR_FRT(true, 2); else if (cpw <= 4) KR_FRT(true, 4); else KR_FRT(true, 8); }
+    else { if (cpw <= 2) KR_FRT(false, 2); else if (cpw <= 4) KR_FRT(false, 4); else if (cpw <= 8) KR_FRT(false, 8); else KR_FRT(false, 16); }
+#undef KR_FRT
     return 0;
 }
 

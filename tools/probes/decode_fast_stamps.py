@@ -28,7 +28,7 @@ def main():
     st.set_attention_mode(False, decode_fast=True)
     lib = st._lib
     buf = (C.c_ulonglong * (8 * 16))()
-    acc = {}
+    acc = {}; raws = []; raw_last = None; acc6 = []
     reps = 20
     for i in range(reps + 3):
         st.decode_step(0, 10 + i)
@@ -40,14 +40,29 @@ def main():
         for k, (nm, ph) in NAMES.items():
             d = np.diff(a[k, : len(ph) + 1]) * 0.01
             acc.setdefault(k, []).append(d)
+        raws.append(a.copy()); raw_last = a
+        acc6.append(np.diff(a[6, :7]) * 0.01)
     lines = []
+    # the select prologue of kr_fw13 in finer steps (row 6) and the data-path gap between consecutive launches: last stamp of launch i -> first stamp of launch i + 1
+    # (s_memrealtime is one constant-rate counter for the whole device, 10 ns)
+    sel = ["entry -> logits in registers", "keys + lane maxima", "k + 1 wave-max rounds (threshold)", "ballot compaction into LDS", "rank by lane broadcasts + write", "tie check, weights, ids to LDS"]
+    if raw_last is not None and raw_last[6, 0] > 0:
+        d6 = np.mean(acc6, axis=0)
+        lines.append("%-45s in-select %.2f us : " % ("kr_fw13 select prologue, finer", d6.sum()) + "  ".join("%s %.2f" % (p, v) for p, v in zip(sel, d6)))
+    chain = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)]
+    gl = []
+    for (a_, b_) in chain:
+        na, nb = len(NAMES[a_][1]), 0
+        g = np.mean([(r[b_, nb] - r[a_, na]) * 0.01 for r in raws])
+        gl.append("%s -> %s %.2f" % (NAMES[a_][0].split(" ")[0] + str(a_), NAMES[b_][0].split(" ")[0] + str(b_), g))
+    lines.append("gap on the data path, end of the middle workgroup's wave 0 -> start of the next launch's (us; rows 0..5 = K1..K6 of the last layer of the step): " + "  ".join(gl))
     for k, (nm, ph) in NAMES.items():
         m = np.mean(acc[k], axis=0)
         lines.append("%-45s in-kernel %.2f us : " % (nm, m.sum()) + "  ".join("%s %.2f" % (p, v) for p, v in zip(ph, m)))
     out = "\n".join(lines)
     print(out)
     os.makedirs("gpurun_out", exist_ok=True)
-    open("gpurun_out/r03_decode_fast_stamps.txt", "w").write("# QCN Q4 decode step, KR_DECODE_FAST: phases inside the kernels (us, wave 0 of the middle workgroup, last layer, mean of %d steps)\n" % reps + out + "\n")
+    open(os.environ.get("STAMPS_OUT", "gpurun_out/r05_decode_fast_stamps.txt"), "w").write("# QCN Q4 decode step, KR_DECODE_FAST: phases inside the kernels (us, wave 0 of the middle workgroup, last layer, mean of %d steps)\n" % reps + out + "\n")
 
 
 if __name__ == "__main__":
