@@ -229,8 +229,11 @@ __device__ __forceinline__ void kr_f_quant_chunk(const float (&v)[8], int c, con
 // ---------------------------------------------------------------------------------------------------------------------------------
 // K1 / K3: multi-matrix dequant-matvec.  KS waves split the K range of a tile, 4 / KS tiles per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Kernel arguments: the pointers a wave needs for its FIRST requests are leading scalar arguments, which the Makefile asks the compiler to have preloaded into
+// SGPRs (-amdgpu-kernarg-preload-count): those requests leave without the scalar round trip to the argument block that the by-value structs cost.
+//   p0: MODE 0 the INT16 image, MODE 1 / 2 the input vector (null: first layer, the embedding row of the step's token); p1: residual (null: none); p2: norm weights
 template <int BITS, int KS, int NU, int MODE>
-__global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
+__global__ void __launch_bounds__(256) kr_fdm_kernel(const void* p0, const float* p1, const float* p2, int Kp, const KrFdmArgs a) {
     constexpr int TW = 4 / KS;
     __shared__ float s_red[4];
     __shared__ float s_x[TW][KS][8];
@@ -240,17 +243,17 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
     KR_FSTAMP(sk, 0);
     // ---- requests, in the order they are needed back (a wave's memory counter is in-order): the input vector / image, then the weight stream, then the
     //      epilogue's operands.  MODE is a template parameter so that no register of one mode's loads is ever seen as pending by another mode's code.
-    const int K = a.mm.m[0].ng * 128;
+    const int K = Kp;
     const KrActLds L = kr_carve_lds(kr_fsm, K, BITS == 8);
     [[maybe_unused]] KrFNormRegs NR; [[maybe_unused]] KrFImg IR; [[maybe_unused]] float x8[2][8];
-    [[maybe_unused]] KrFNormIn in{nullptr, a.res_in, a.norm_w, a.res_out, a.first, a.eps, a.bias_one, K};
-    if constexpr (MODE == 0) kr_f_image_load(a.img, K, IR, t, 256);
+    [[maybe_unused]] KrFNormIn in{reinterpret_cast<const float*>(p0), p1, p2, a.res_out, p1 == nullptr, a.eps, a.bias_one, K};
+    if constexpr (MODE == 0) kr_f_image_load(p0, K, IR, t, 256);
     else if constexpr (MODE == 2) {
         const int nch = K / 8;
-        kr_load8(a.hid_in, t < nch ? t : nch - 1, x8[0]);
-        if (nch > 256) kr_load8(a.hid_in, t + 256 < nch ? t + 256 : nch - 1, x8[1]);
+        kr_load8(reinterpret_cast<const float*>(p0), t < nch ? t : nch - 1, x8[0]);
+        if (nch > 256) kr_load8(reinterpret_cast<const float*>(p0), t + 256 < nch ? t + 256 : nch - 1, x8[1]);
     } else {
-        in.hid = a.emb ? a.emb + (size_t)a.step->token * K : a.hid_in;
+        if (p0 == nullptr) in.hid = a.emb + (size_t)a.step->token * K;
         kr_f_norm_load(in, NR);
     }
     // the matrix of this tile: every field sits at a CONSTANT kernarg offset (one scalar round trip for all of them) and is selected
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
         g_al = (la ? a.a_log : a.norm_w)[gl]; g_dt = (la ? a.dt_bias : a.norm_w)[gl];
     }
     KR_FSTAMP(sk, 1);
-    if constexpr (MODE == 0) kr_f_image_store<BITS>(a.img, K, IR, kr_fsm, L, t, 256);
+    if constexpr (MODE == 0) kr_f_image_store<BITS>(p0, K, IR, kr_fsm, L, t, 256);
     else if constexpr (MODE == 2) {      // plain f32 input vector (MLA: the w_vc output feeding o_proj): every workgroup quantises it (quantize_activation_int16_f32, avx2.rs:274)
 #pragma unroll
         for (int u = 0; u < 2; u++) { const int c = t + 256 * u; if (c < K / 8) kr_f_quant_chunk<BITS == 8>(x8[u], c, L, false); }
@@ -347,28 +350,30 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const KrFdmArgs a) {
 // K2: gated delta-rule step of one VALUE head (decode.rs:3891-3945, 1293, 3979).  512 threads: NS slices of RPS state rows x DV / 4 column quads.
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int DK, int DV>
-__global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
+__global__ void __launch_bounds__(512) kr_fla_kernel(const float* p_qk, const float* p_z, const float* p_v, const float* p_ge, const float* p_beta, float* p_state, int p_hr, const KrFlaArgs a) {
     constexpr int JQ = DV / 4, NS = 512 / JQ, RPS = DK / NS, WQ = DK / 64;
     static_assert(RPS >= 1 && NS * RPS == DK, "geometry");
     __shared__ float s_qk[2 * DK];
     __shared__ float s_red[8];
     __shared__ __attribute__((aligned(16))) float s_part[NS][DV];
     __shared__ __attribute__((aligned(16))) float s_vec[DV];
-    const int vh = blockIdx.x, kh = vh / a.hr;
+    const int vh = blockIdx.x, kh = vh / p_hr;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int slice = t / JQ, jq = t - slice * JQ;
-    f32x4* S4 = reinterpret_cast<f32x4*>(a.state + (size_t)vh * DK * DV);
+    f32x4* S4 = reinterpret_cast<f32x4*>(p_state + (size_t)vh * DK * DV);
     KR_FSTAMP(1, 0);
+    // the head's vectors first (every thread loads, clamped: kr_f_norm_load), the 64 KB of state behind them -- the q / k sums run while the state streams in
+    const float g_exp = p_ge[vh], beta = p_beta[vh];   // e^g and beta of this head: formed by the ba lanes of the projection launch
+    float qv = p_qk[(size_t)kh * 2 * DK + (t < 2 * DK ? t : 0)];
+    const size_t ov_ = (size_t)vh * DV + (t < DV ? t : 0);
+    float zz = p_z[ov_], vv = p_v[ov_], wn = a.norm_w[ov_];
+    asm volatile("" ::: "memory");      // (keeps the compiler from sinking these requests below the state's)
     f32x4 c[RPS];
 #pragma unroll
     for (int u = 0; u < RPS; u++) c[u] = __builtin_nontemporal_load(S4 + (size_t)(slice * RPS + u) * JQ + jq);
-    float qv = 0.0f;
-    if (t < 2 * DK) { qv = a.qk[(size_t)kh * 2 * DK + t]; s_qk[t] = qv; }
-    float zz = 0.0f, vv = 0.0f, wn = 0.0f;
-    if (t < DV) { const size_t o = (size_t)vh * DV + t; zz = a.z[o]; vv = a.v[o]; wn = a.norm_w[o]; }
+    if (t < 2 * DK) s_qk[t] = qv; else qv = 0.0f;
     const float sq = kr_f_wave_sum(qv * qv);
     if (lane == 0) s_red[wave] = sq;
-    const float g_exp = a.ge[vh], beta = a.beta[vh];   // e^g and beta of this head: formed by the ba lanes of the projection launch
     KR_FSTAMP(1, 1);
     __syncthreads();
     KR_FSTAMP(1, 2);
@@ -456,18 +461,18 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const KrFlaArgs a) {
 // split the K range of the chain-major gate rows.  Workgroups 0 / 1 also publish the residual and the two INT16 images.
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <bool GATE_BF16, int CPW>      // CPW: 16-byte gate chunks per lane and wave kept in flight, the power of two >= ceil(chunks / 4) (H <= 4096: bf16 <= 8, f32 <= 16)
-__global__ void __launch_bounds__(256) kr_frt_kernel(const KrFrtArgs a) {
+__global__ void __launch_bounds__(256) kr_frt_kernel(const float* p_hid, const float* p_res, const float* p_nw, const void* p_gate, int p_H, const KrFrtArgs a) {
     float* xs = reinterpret_cast<float*>(kr_fsm);   // [16][ld] chain-major copy of the normalised hidden
     __shared__ float s_red[4];
     __shared__ float s_part[4][4];
-    const int H = a.H, ld = H / 16 + 4;
+    const int H = p_H, ld = H / 16 + 4;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int eb = blockIdx.x;
     KR_FSTAMP(3, 0);
     const int ncg = GATE_BF16 ? H / 128 : H / 64;
     const int cpw = (ncg + 3) / 4, c0 = wave * cpw, c1 = c0 + cpw < ncg ? c0 + cpw : ncg;
-    const u32x4* gp = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)eb * ncg * 64 + lane;
-    KrFNormIn in{a.hid_in, a.res_in, a.norm_w, a.res_out, 0, a.eps, a.bias_one, H};
+    const u32x4* gp = reinterpret_cast<const u32x4*>(p_gate) + (size_t)eb * ncg * 64 + lane;
+    KrFNormIn in{p_hid, p_res, p_nw, a.res_out, 0, a.eps, a.bias_one, H};
     KrFNormRegs NR;
     kr_f_norm_load(in, NR);      // the norm's inputs come back first, the gate rows stream behind them (kr_f_norm_load)
     u32x4 gw[CPW];
@@ -686,26 +691,28 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
 // K5: gate | up of the k routed experts + the shared expert (+ its sigmoid-gate row).  grid (units, n_slots); 2 tile PAIRS per workgroup
 // (gate tile t and up tile t + I / 8 of the same hidden column), 2 waves split K; epilogue h = silu(g) * u (avx2.rs:2331-2333, decode.rs:1731-1733).
 // ---------------------------------------------------------------------------------------------------------------------------------
+// (leading scalars = what the select wave and the image copy need for their first requests, preloaded into SGPRs: see kr_fdm_kernel)
 template <int BITS, int NU>
-__global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
+__global__ void __launch_bounds__(256) kr_fw13_kernel(const float* p_logits, const float* p_esc, const void* p_img_bf16, int p_E, int p_topk, int p_scoring, int p_norm, int p_H, int p_I, int p_gguf,
+                                                      const KrFmoeArgs fa) {
     const KrMoeArgs& a = fa.m;
     constexpr int KS = 2, TW = 2;
     __shared__ int s_ids[32];
     __shared__ float s_w[32];
     __shared__ float s_x[TW][KS][2][8];
     const int slot = blockIdx.y;
-    const bool shared = slot >= a.topk;
+    const bool shared = slot >= p_topk;
     // the grid's x extent follows the widest slot (a shared expert may be wider than the routed ones): a routed workgroup past its expert's last tile pair leaves
     // before the select and the image copy, not after them (DeepSeek-V2-Lite: half of the launch's workgroups)
-    if (!shared && (int)blockIdx.x * 2 /* TW */ >= a.I / 8) return;      // (workgroup (0, 0), which publishes the routing, always has a tile pair)
+    if (!shared && (int)blockIdx.x * 2 /* TW */ >= p_I / 8) return;      // (workgroup (0, 0), which publishes the routing, always has a tile pair)
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
     const int tw = wave >> 1, ks = wave & 1;
-    const KrActLds L = kr_carve_lds(kr_fsm, a.H, BITS == 8);
-    const bool gg = fa.gguf && !shared;                  // routed slot on native GGUF blocks: per-32 activation image instead of the per-128 one
-    const GgAct GA = gg_carve(reinterpret_cast<char*>(kr_fsm), a.H);
-    const size_t img_bytes = fa.gguf ? (kr_lds_bytes(a.H, BITS == 8) > gg_lds_bytes(a.H, false) ? kr_lds_bytes(a.H, BITS == 8) : gg_lds_bytes(a.H, false)) : kr_lds_bytes(a.H, BITS == 8);
+    const KrActLds L = kr_carve_lds(kr_fsm, p_H, BITS == 8);
+    const bool gg = p_gguf && !shared;                  // routed slot on native GGUF blocks: per-32 activation image instead of the per-128 one
+    const GgAct GA = gg_carve(reinterpret_cast<char*>(kr_fsm), p_H);
+    const size_t img_bytes = p_gguf ? (kr_lds_bytes(p_H, BITS == 8) > gg_lds_bytes(p_H, false) ? kr_lds_bytes(p_H, BITS == 8) : gg_lds_bytes(p_H, false)) : kr_lds_bytes(p_H, BITS == 8);
     KR_FSTAMP(4, 0);
-    if (shared) kr_f_image_copy<BITS>(a.act_img, a.H, kr_fsm, L, t, 256);
+    if (shared) kr_f_image_copy<BITS>(a.act_img, p_H, kr_fsm, L, t, 256);
     else if (wave > 0) {
         if (gg) {      // quantize_bf16_to_int16 of bf16(hidden) (gguf_kernels.rs:110, decode.rs:3307-3309), 8 values per thread, 4 consecutive lanes per sub-block
             for (int c = t - 64; c < a.H / 8; c += 192) {
@@ -715,15 +722,15 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
                 for (int i = 0; i < 8; i++) v[i] = kr_bf16_to_f32(kr_f32_to_bf16(v[i]));
                 gg_quant_store(v, c, GA);
             }
-        } else kr_f_image_copy<BITS>(a.act_img_bf16, a.H, kr_fsm, L, t - 64, 192);
+        } else kr_f_image_copy<BITS>(p_img_bf16, p_H, kr_fsm, L, t - 64, 192);
     } else {
         float* selsm = reinterpret_cast<float*>(reinterpret_cast<char*>(kr_fsm) + img_bytes);
-        const int nv = (a.E + 63) / 64;
-        if (nv <= 1) kr_f_select<1>(fa.logits, fa.esc, a.E, a.topk, fa.scoring, fa.norm_topk, selsm, s_ids, s_w);
-        else if (nv <= 2) kr_f_select<2>(fa.logits, fa.esc, a.E, a.topk, fa.scoring, fa.norm_topk, selsm, s_ids, s_w);
-        else if (nv <= 4) kr_f_select<4>(fa.logits, fa.esc, a.E, a.topk, fa.scoring, fa.norm_topk, selsm, s_ids, s_w);
-        else kr_f_select<8>(fa.logits, fa.esc, a.E, a.topk, fa.scoring, fa.norm_topk, selsm, s_ids, s_w);
-        if (blockIdx.x == 0 && slot == 0 && lane < a.topk) {   // the routing of this token, for the w2 launch (and anyone who asks)
+        const int nv = (p_E + 63) / 64;
+        if (nv <= 1) kr_f_select<1>(p_logits, p_esc, p_E, p_topk, p_scoring, p_norm, selsm, s_ids, s_w);
+        else if (nv <= 2) kr_f_select<2>(p_logits, p_esc, p_E, p_topk, p_scoring, p_norm, selsm, s_ids, s_w);
+        else if (nv <= 4) kr_f_select<4>(p_logits, p_esc, p_E, p_topk, p_scoring, p_norm, selsm, s_ids, s_w);
+        else kr_f_select<8>(p_logits, p_esc, p_E, p_topk, p_scoring, p_norm, selsm, s_ids, s_w);
+        if (blockIdx.x == 0 && slot == 0 && lane < p_topk) {   // the routing of this token, for the w2 launch (and anyone who asks)
             const_cast<int32_t*>(a.ids)[lane] = s_ids[lane]; const_cast<float*>(a.wts)[lane] = s_w[lane];
         }
     }
@@ -799,7 +806,7 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const KrFmoeArgs fa) {
 // rsf * sum_i w_i y_i (routing order, moe.rs:661-667) + shared * sigmoid(gate) (decode.rs:3379-3402).
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int BITS, int NU, bool MULTI>
-__global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int slot_lds, int pr_, int ps_) {
+__global__ void __launch_bounds__(1024) kr_fw2_kernel(const float* p_gu, const int32_t* p_ids, const float* p_wts, int p_gu_ld, int p_topk, int slot_lds, int pr_, int ps_, const KrFmoeArgs fa) {
     const KrMoeArgs& a = fa.m;
     const int pr = MULTI ? pr_ : 1, ps = MULTI ? ps_ : 1;      // MULTI = false: one wave per slot, the part arithmetic below folds away (the headline shapes: every cycle of this launch is on the token's path)
     __shared__ float s_y[16][8];
@@ -808,14 +815,14 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     // units and quantises the matching chunks of its hidden, the column sums meet in the combine.  With one wave per slot a wide expert (I = 1408: 176 chunks to
     // quantise on 64 lanes, then 6 units) made the launch twice as long as at I = 512, and a shared expert twice as wide again was the workgroup's critical path.
     const int t = threadIdx.x, vslot = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
-    const int nrw = a.topk * pr;                             // waves of the routed slots
-    const int slot = vslot < nrw ? vslot / pr : a.topk, part = vslot < nrw ? vslot % pr : vslot - nrw, parts = vslot < nrw ? pr : ps;
+    const int nrw = p_topk * pr;                             // waves of the routed slots
+    const int slot = vslot < nrw ? vslot / pr : p_topk, part = vslot < nrw ? vslot % pr : vslot - nrw, parts = vslot < nrw ? pr : ps;
     const int tile = blockIdx.x;
     KR_FSTAMP(5, 0);
     // sigmoid(gate row) of the shared expert, formed by the gate|up launch.  A rank that skips this layer's shared expert (expert-parallel decode) never wrote it:
     // it neither reads the value nor adds the term (0 * stale bits could be NaN and the all-reduce would spread it -- ADVICE r4 #2)
     const float sig = (a.gate_out && !fa.shared_skip) ? a.gate_out[0] : 1.0f;
-    const bool shared = slot >= a.topk;
+    const bool shared = slot >= p_topk;
     const bool gg = fa.gguf && !shared;
     const KrMatDev& m = (shared || fa.gguf) ? a.sw2 : a.w2;      // (a GGUF slot never reads m: the shared expert's matrix stands in so that the fields are defined)
     const int inter = shared ? a.I_shared : a.I;
@@ -824,7 +831,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     constexpr int HC = (NU > 0 && !MULTI) ? (BITS == 4 ? NU / 2 : NU / 4) : 0;
     [[maybe_unused]] float hpre[HC > 0 ? HC : 1][8];
     if constexpr (HC > 0) {
-        const float* hp = a.gu + (size_t)slot * a.gu_ld;
+        const float* hp = p_gu + (size_t)slot * p_gu_ld;
 #pragma unroll
         for (int j = 0; j < HC; j++) kr_load8(hp, lane + 64 * j, hpre[j]);
     }
@@ -833,8 +840,8 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
     bool skip = false;        // expert-parallel decode: slot evaluated by another rank -- this wave contributes 0 and reads no weights
     size_t ee = 0;
     if (!shared) {
-        int e = a.ids[slot];
-        valid = e >= 0 && e < a.E; wt = a.wts[slot];
+        int e = p_ids[slot];
+        valid = e >= 0 && e < a.E; wt = p_wts[slot];
         if (a.e_hi > 0) { skip = !valid || e < a.e_lo || e >= a.e_hi; e -= a.e_sub; }
         ee = valid && !skip ? (size_t)e : 0;
         if (!gg) {
@@ -939,7 +946,10 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const KrFmoeArgs fa, int s
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int BITS, int KS, int MODE>
 static int kr_fdm_launch_nu2(const KrFdmArgs& a, int nu, dim3 grid, size_t lds, hipStream_t st) {
-#define KR_FDM(N_) hipLaunchKernelGGL((kr_fdm_kernel<BITS, KS, N_, MODE>), grid, dim3(256), lds, st, a)
+    const void* p0 = MODE == 0 ? a.img : ((MODE == 1 && a.emb) ? nullptr : (const void*)a.hid_in);
+    const float* p1 = (MODE == 1 && !a.first) ? a.res_in : nullptr;
+    const int Kp = a.mm.m[0].ng * 128;
+#define KR_FDM(N_) hipLaunchKernelGGL((kr_fdm_kernel<BITS, KS, N_, MODE>), grid, dim3(256), lds, st, p0, p1, a.norm_w, Kp, a)
     switch (nu) {
         case 2: KR_FDM(2); break;
         case 4: KR_FDM(4); break;
@@ -989,7 +999,7 @@ int kr_launch_fdm(const KrFdmArgs& a, hipStream_t st) {
 
 int kr_launch_fla(const KrFlaArgs& a, hipStream_t st) {
     if (a.nv != a.nk * a.hr) return 1;
-#define KR_FLA(DK_, DV_) hipLaunchKernelGGL((kr_fla_kernel<DK_, DV_>), dim3(a.nv), dim3(512), 0, st, a)
+#define KR_FLA(DK_, DV_) hipLaunchKernelGGL((kr_fla_kernel<DK_, DV_>), dim3(a.nv), dim3(512), 0, st, a.qk, a.z, a.v, a.ge, a.beta, a.state, a.hr, a)
     if (a.dk == 128 && a.dv == 128) KR_FLA(128, 128);
     else if (a.dk == 64 && a.dv == 128) KR_FLA(64, 128);
     else return 1;
@@ -1002,7 +1012,7 @@ int kr_launch_frt(const KrFrtArgs& a, hipStream_t st) {
     const size_t lds = (size_t)16 * (a.H / 16 + 4) * 4;
     dim3 grid((a.E + 3) / 4);
     const int ncg = a.gate_bf16 ? a.H / 128 : a.H / 64, cpw = (ncg + 3) / 4;
-#define KR_FRT(B_, C_) hipLaunchKernelGGL((kr_frt_kernel<B_, C_>), grid, dim3(256), lds, st, a)
+#define KR_FRT(B_, C_) hipLaunchKernelGGL((kr_frt_kernel<B_, C_>), grid, dim3(256), lds, st, a.hid_in, a.res_in, a.norm_w, a.gate_cm, a.H, a)
     if (a.gate_bf16) { if (cpw <= 1) KR_FRT(true, 1); else if (cpw <= 2) KR_FRT(true, 2); else if (cpw <= 4) KR_FRT(true, 4); else KR_FRT(true, 8); }
     else { if (cpw <= 2) KR_FRT(false, 2); else if (cpw <= 4) KR_FRT(false, 4); else if (cpw <= 8) KR_FRT(false, 8); else KR_FRT(false, 16); }
 #undef KR_FRT
@@ -1062,7 +1072,7 @@ int kr_launch_fw13(const KrFmoeArgs& fa, hipStream_t st) {
     const int units = fa.gguf && !has_shared ? 0 : (wbits == 4 ? wm.ngp : wm.ng);
     const bool even = !fa.gguf && (a.w13.bits == 8 || (a.w13.ng % 2) == 0) && units % 2 == 0;
     const int nu = even ? units / 2 : 0;
-#define KR_FW13(B_, N_) hipLaunchKernelGGL((kr_fw13_kernel<B_, N_>), grid, dim3(256), lds, st, fa)
+#define KR_FW13(B_, N_) hipLaunchKernelGGL((kr_fw13_kernel<B_, N_>), grid, dim3(256), lds, st, fa.logits, fa.esc, a.act_img_bf16, a.E, a.topk, fa.scoring, fa.norm_topk, a.H, a.I, fa.gguf, fa)
     if (wbits == 4) { if (nu == 4) KR_FW13(4, 4); else if (nu == 8) KR_FW13(4, 8); else KR_FW13(4, 0); }
     else { if (nu == 8) KR_FW13(8, 8); else KR_FW13(8, 0); }
 #undef KR_FW13
@@ -1092,7 +1102,7 @@ int kr_launch_fw2(const KrFmoeArgs& fa, hipStream_t st) {
         while (ps > 1 && (a.topk * pr + ps > 16 || ps > sunits)) ps--;
     }
     const bool multi = pr > 1 || ps > 1;
-#define KR_FW2(B_, N_, M_) hipLaunchKernelGGL((kr_fw2_kernel<B_, N_, M_>), grid, dim3(64 * (a.topk * pr + ps)), slot_lds * a.n_slots, st, fa, (int)slot_lds, pr, ps)
+#define KR_FW2(B_, N_, M_) hipLaunchKernelGGL((kr_fw2_kernel<B_, N_, M_>), grid, dim3(64 * (a.topk * pr + ps)), slot_lds * a.n_slots, st, a.gu, a.ids, a.wts, a.gu_ld, a.topk, (int)slot_lds, pr, ps, fa)
     if (multi) { if (wbits == 4) KR_FW2(4, 0, true); else KR_FW2(8, 0, true); }      // (several waves per slot only with the guarded form)
     else if (wbits == 4) { if (nu == 2) KR_FW2(4, 2, false); else if (nu == 4) KR_FW2(4, 4, false); else if (nu == 6) KR_FW2(4, 6, false); else if (nu == 8) KR_FW2(4, 8, false); else KR_FW2(4, 0, false); }
     else { if (nu == 4) KR_FW2(8, 4, false); else if (nu == 8) KR_FW2(8, 8, false); else KR_FW2(8, 0, false); }
