@@ -276,8 +276,20 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const void* p0, const float
     else { const int uw = (units + KS - 1) / KS; u0 = ks * uw; u1 = u0 + uw < units ? u0 + uw : units; }
     KrFw<BITS, NU> W;
     kr_f_fetch<BITS, NU>(W, m, m.q, m.s, tile, lane, u0, u1);
+    KR_FSTAMP(sk, 1);
+    if constexpr (MODE == 0) kr_f_image_store<BITS>(p0, K, IR, kr_fsm, L, t, 256);
+    else if constexpr (MODE == 2) {      // plain f32 input vector (MLA: the w_vc output feeding o_proj): every workgroup quantises it (quantize_activation_int16_f32, avx2.rs:274)
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int c = t + 256 * u; if (c < K / 8) kr_f_quant_chunk<BITS == 8>(x8[u], c, L, false); }
+    } else {
+        float x[2][8];
+        kr_f_norm_finish(in, NR, x, s_red, blockIdx.x == 0);
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int c = t + 256 * u; if (c < K / 8) kr_f_quant_chunk<BITS == 8>(x[u], c, L, false); }
+    }
     // the lane that will hold column `col` asks for what its epilogue needs -- conv state / taps of the linear-attention channels, gate constants -- BEHIND the
-    // weight stream (nothing of it is touched before the dot is done).  Every lane loads (index 0 where it has nothing to ask for) and no destination has a default.
+    // weight stream and after the norm / image work (its index arithmetic is ~100 instructions of a lone wave: placed here it runs while the weights are still in
+    // flight instead of delaying the norm; nothing of it is touched before the dot is done).  Every lane loads (index 0 where it has nothing to ask for) and no destination has a default.
     const int col = tile * 8 + cl;
     const bool out_lane = active && ks == 0 && l8 == 0 && col < m.N;
     int kind = -1, dst = 0, ch = 0;       // 0 q, 1 k, 2 v (conv channels), 3 z, 4 beta, 5 decay gate
@@ -302,17 +314,6 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const void* p0, const float
         const int chl = (kind >= 0 && kind < 3) ? ch : 0, gl = kind == 5 ? dst : 0;
         cs = reinterpret_cast<const float4*>(la ? a.conv_state : a.norm_w)[chl]; cw = reinterpret_cast<const float4*>(la ? a.conv_w : a.norm_w)[chl];
         g_al = (la ? a.a_log : a.norm_w)[gl]; g_dt = (la ? a.dt_bias : a.norm_w)[gl];
-    }
-    KR_FSTAMP(sk, 1);
-    if constexpr (MODE == 0) kr_f_image_store<BITS>(p0, K, IR, kr_fsm, L, t, 256);
-    else if constexpr (MODE == 2) {      // plain f32 input vector (MLA: the w_vc output feeding o_proj): every workgroup quantises it (quantize_activation_int16_f32, avx2.rs:274)
-#pragma unroll
-        for (int u = 0; u < 2; u++) { const int c = t + 256 * u; if (c < K / 8) kr_f_quant_chunk<BITS == 8>(x8[u], c, L, false); }
-    } else {
-        float x[2][8];
-        kr_f_norm_finish(in, NR, x, s_red, blockIdx.x == 0);
-#pragma unroll
-        for (int u = 0; u < 2; u++) { const int c = t + 256 * u; if (c < K / 8) kr_f_quant_chunk<BITS == 8>(x[u], c, L, false); }
     }
     KR_FSTAMP(sk, 2);
     __syncthreads();
@@ -536,22 +537,37 @@ __global__ void __launch_bounds__(256) kr_frt_kernel(const float* p_hid, const f
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // wave-wide top-np in (value desc, index asc) order WITHOUT a tournament over all elements (kr_topk_wave_reg walks np rounds of: scan the
-// lane's NV keys, wave maximum, retire the winner -- ~65 instructions each on a lone wave):
-//   (1) T = a lower bound of the np-th largest element: np rounds of wave-max over the LANE maxima, every round retiring the lanes that hold
-//       the current maximum (so at least np elements are >= T),
-//   (2) the elements >= T (np of them plus, rarely, a few more) are compacted into lanes 0 .. M-1 through LDS,
-//   (3) every candidate counts the candidates that precede it in (value desc, index asc) -- its rank -- with lane broadcasts; ranks < np are
-//       written to pv / pi.  Returns false (nothing written) when more than 64 elements reach T: the caller runs the tournament.
+// lane's NV keys, wave maximum, retire the winner -- ~65 instructions each on a lone wave, and a lone wave issues one instruction per ~9 cycles):
+//   (1) T = a lower bound of the np-th largest element from ceil(np / 4) rounds PER 16-LANE ROW: the row maximum of the lane maxima (four DPP steps, no cross-row
+//       step), the lanes that hold it retire.  Every row-round retires at least one lane whose maximum is >= that row's last maximum, so at least 4 ceil(np / 4) >= np
+//       elements are >= T = the smallest of the four rows' last maxima.  (Round 4 ran np rounds of a whole-wave maximum here: 0.9 us of the 3.3 us select.)
+//   (2) the elements >= T (np of them plus, typically, ten more) are compacted into an LDS list of 64-bit records (key << 32 | ~index: one unsigned compare orders two
+//       candidates by value desc, index asc),
+//   (3) every candidate lane counts the records that precede its own -- its rank -- reading the list from LDS four records at a time (uniform addresses: broadcasts);
+//       ranks < np are written to pv / pi.  (Round 4: one lane-broadcast pair + three compares per candidate, 0.7 us.)
+// Returns false (nothing written) when more than 64 elements reach T (a row ran out of lanes: tiny or heavily tied inputs): the caller runs the tournament.
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int NV>
-__device__ __forceinline__ bool kr_f_topk(const float (&val)[NV], int n, int np, float* pv, int* pi, uint32_t* cand /* LDS [128] */) {
+__device__ __forceinline__ bool kr_f_topk(const float (&val)[NV], int n, int np, float* pv, int* pi, uint64_t* cand /* LDS [64 + 4], 8-byte aligned */) {
     const int lane = threadIdx.x & 63;
     uint32_t key[NV], h = 0u;
 #pragma unroll
     for (int i = 0; i < NV; i++) { const int e = lane * NV + i; key[i] = e < n ? kr_make_key(val[i]) : 0u; h = kr_umax(h, key[i]); }
-    uint32_t T = 0u;
     KR_FSTAMP(6, 2);
-    for (int r = 0; r < np; r++) { const uint32_t w = kr_wave_umax(h); T = w; if (h == w) h = 0u; }
+    uint32_t trow = 0u;
+    const int rounds = (np + 3) >> 2;
+    for (int r = 0; r < rounds; r++) {
+        uint32_t w = h;
+        w = kr_umax(w, (uint32_t)KR_DPP((int)w, KR_DPP_XOR1));
+        w = kr_umax(w, (uint32_t)KR_DPP((int)w, KR_DPP_XOR2));
+        w = kr_umax(w, (uint32_t)KR_DPP((int)w, KR_DPP_HALF_MIRROR));
+        w = kr_umax(w, (uint32_t)KR_DPP((int)w, KR_DPP_MIRROR));      // every lane of the row holds the row maximum
+        trow = w;
+        if (h == w) h = 0u;
+    }
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)trow, 0), t1 = (uint32_t)__builtin_amdgcn_readlane((int)trow, 16);
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)trow, 32), t3 = (uint32_t)__builtin_amdgcn_readlane((int)trow, 48);
+    const uint32_t T01 = t0 < t1 ? t0 : t1, T23 = t2 < t3 ? t2 : t3, T = T01 < T23 ? T01 : T23;
     KR_FSTAMP(6, 3);
     int base = 0;
 #pragma unroll
@@ -559,21 +575,21 @@ __device__ __forceinline__ bool kr_f_topk(const float (&val)[NV], int n, int np,
         const bool c = key[i] != 0u && key[i] >= T;
         const uint64_t mask = __ballot(c);
         const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (c && pos < 64) { cand[2 * pos] = key[i]; cand[2 * pos + 1] = (uint32_t)(lane * NV + i); }
+        if (c && pos < 64) cand[pos] = ((uint64_t)key[i] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(lane * NV + i));
         base += __popcll(mask);
     }
     const int M = base;
     if (M > 64) return false;
+    if (lane < 4) cand[M + lane] = 0ull;      // the rank loop reads four records at a time: an empty record precedes nothing
     kr_f_wave_sync();
     KR_FSTAMP(6, 4);
-    uint32_t kj = 0u, ij = 0u;
-    if (lane < M) { kj = cand[2 * lane]; ij = cand[2 * lane + 1]; }
+    const uint64_t cj = cand[lane < M ? lane : 0];
     int rank = 0;
-    for (int i = 0; i < M; i++) {
-        const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)kj, i), ii = (uint32_t)__builtin_amdgcn_readlane((int)ij, i);
-        rank += (ki > kj || (ki == kj && ii < ij)) ? 1 : 0;
+    for (int i = 0; i < M; i += 4) {
+        const uint64_t c0 = cand[i], c1 = cand[i + 1], c2 = cand[i + 2], c3 = cand[i + 3];
+        rank += (c0 > cj ? 1 : 0) + (c1 > cj ? 1 : 0) + (c2 > cj ? 1 : 0) + (c3 > cj ? 1 : 0);
     }
-    if (lane < M && rank < np) { pv[rank] = kr_key_value(kj); pi[rank] = (int)ij; }
+    if (lane < M && rank < np) { pv[rank] = kr_key_value((uint32_t)(cj >> 32)); pi[rank] = (int)(0xFFFFFFFFu - (uint32_t)cj); }
     return true;
 }
 
@@ -583,22 +599,64 @@ __device__ __forceinline__ bool kr_f_topk(const float (&val)[NV], int n, int np,
 // (softmax is monotone), so for identical logits the ids are those of the exact kernel unless two of the leading k + 1 are EQUAL -- then the
 // reference's heap order decides and is emulated serially, as in the exact kernel.  (Stated exception of the `lean` path below, krasis_hip.h KR_DECODE_FAST: it compares
 // LOGITS; two distinct logits whose f32 softmax scores coincide are a tie for the exact kernel only.)
-// sm: [E] scores, [E] selection values, [33] pv, [33] pi, [32] hv, [32] hi, [2] pad, [128] candidate list
+// sm: [E] scores, [E] selection values, [33] pv, [33] pi, [32] hv, [32] hi, [2] pad, [136] candidate list (68 records of 8 bytes)
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The `lean` rule on its own straight path: softmax scoring without a correction bias, weights renormalised over the k leaders (QCN, Qwen3-235B).  The selection runs on
+// the logits (softmax is monotone) and the renormalised weight of leader i is e^{l_i - m} / sum over the LEADERS of e^{l_j - m} -- the full-softmax denominator cancels,
+// so the E exponentials, their wave sum and the score / selection arrays in LDS are never formed.  Against the reference's (e_i / S) / sum_j (e_j / S): two roundings fewer
+// per weight, within 3e-7 relative (test bound).  The leaders' logits are read back from the sorted list (pv), not from global memory.
+template <int NV>
+__device__ __forceinline__ void kr_f_select_lean(const float* logits, int E, int k, float* sm, int* s_ids, float* s_w) {
+    float* sel = sm + E; float* pv = sel + E; int* pi = reinterpret_cast<int*>(pv + 33);
+    float* hv = reinterpret_cast<float*>(pi + 33); int* hi = reinterpret_cast<int*>(hv + 32);
+    uint64_t* cand = reinterpret_cast<uint64_t*>(hi + 32 + 2);
+    const int lane = threadIdx.x & 63;
+    KR_FSTAMP(6, 0);
+    float lg[NV];
+    if (NV % 4 == 0 && E % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i + 3 < NV; i += 4) {
+            const int e = lane * NV + i;
+            const float4 v = *reinterpret_cast<const float4*>(logits + (e < E ? e : 0));
+            lg[i] = v.x; lg[i + 1] = v.y; lg[i + 2] = v.z; lg[i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; lg[i] = logits[e < E ? e : 0]; }
+    }
+#ifdef KR_FTIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    KR_FSTAMP(6, 1);
+    const int np = k + 1 <= E ? k + 1 : k;
+    if (!kr_f_topk<NV>(lg, E, np, pv, pi, cand)) kr_topk_wave_reg<NV>(lg, E, np, pv, pi);      // (elements e >= E carry key 0 in both: never selected)
+    kr_f_wave_sync();
+    KR_FSTAMP(6, 5);
+    const float pa = lane < np ? pv[lane] : 0.0f, pb = lane + 1 < np ? pv[lane + 1] : 0.0f;
+    if (__ballot(lane + 1 < np && pa == pb) != 0ull) {   // two of the leading k + 1 are equal: the heap order governs (decode.rs:1531); rare
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int e = lane * NV + i; if (e < E) sel[e] = lg[i]; }
+        kr_f_wave_sync();
+        if (lane == 0) kr_topk_heap_serial(sel, E, k, hv, hi, pi);
+        kr_f_wave_sync();
+    }
+    // the leaders come out in descending order, pv[0] is the largest logit; under a tie the heap order may permute EQUAL values only, so pv[lane] is the logit of leader `lane`
+    float wv = lane < k ? __builtin_amdgcn_exp2f((pa - pv[0]) * 1.4426950408889634f) : 0.0f;
+    const float se = kr_f_wave_sum(wv);
+    wv = wv / se;
+    if (lane < k) { s_ids[lane] = pi[lane]; s_w[lane] = wv; }
+    KR_FSTAMP(6, 6);
+}
+
 template <int NV>
 __device__ __forceinline__ void kr_f_select(const float* logits, const float* esc, int E, int k, int scoring, int norm, float* sm, int* s_ids, float* s_w) {
+    if (scoring == 1 && esc == nullptr && norm != 0) { kr_f_select_lean<NV>(logits, E, k, sm, s_ids, s_w); return; }
     float* scores = sm; float* sel = sm + E; float* pv = sel + E; int* pi = reinterpret_cast<int*>(pv + 33);
     float* hv = reinterpret_cast<float*>(pi + 33); int* hi = reinterpret_cast<int*>(hv + 32);
-    uint32_t* cand = reinterpret_cast<uint32_t*>(hi + 32 + 2);      // [128]
+    uint64_t* cand = reinterpret_cast<uint64_t*>(hi + 32 + 2);      // [64 + 4] records of 8 bytes (the offset from `sm` is 8 E + 528 bytes)
     const int lane = threadIdx.x & 63;
     const bool raw = scoring == 2;
-    KR_FSTAMP(6, 0);
     float lg[NV], sc[NV], sl[NV];
-    // softmax scoring without a correction bias, weights renormalised over the k leaders (QCN, Qwen3-235B): the selection runs on the logits (softmax is
-    // monotone) and the renormalised weight of leader i is e^{l_i - m} / sum over the LEADERS of e^{l_j - m} -- the full-softmax denominator cancels, so the E
-    // exponentials, their wave sum and the score / selection arrays in LDS are never formed (round 4: ~1 us of the 3.4 us this prologue cost on the serial path
-    // of every gate|up workgroup).  Against the reference's (e_i / S) / sum_j (e_j / S): two roundings fewer per weight, within 3e-7 relative (test bound).
-    const bool lean = scoring == 1 && esc == nullptr && norm != 0;
     bool wide = false;
     if constexpr (NV % 4 == 0) {
         if (E % 4 == 0) {
@@ -615,11 +673,7 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
 #pragma unroll
         for (int i = 0; i < NV; i++) { const int e = lane * NV + i; lg[i] = e < E ? logits[e] : -__builtin_inff(); }
     }
-#ifdef KR_FTIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    KR_FSTAMP(6, 1);
-    if (raw || lean) {
+    if (raw) {
 #pragma unroll
         for (int i = 0; i < NV; i++) sc[i] = lg[i];
     } else if (scoring == 0) {
@@ -644,36 +698,20 @@ __device__ __forceinline__ void kr_f_select(const float* logits, const float* es
     for (int i = 0; i < NV; i++) {
         const int e = lane * NV + i;
         sl[i] = on_logits ? lg[i] : ((!raw && esc && e < E) ? sc[i] + esc[e] : sc[i]);
-        if (!lean && e < E) { scores[e] = sc[i]; sel[e] = sl[i]; }
+        if (e < E) { scores[e] = sc[i]; sel[e] = sl[i]; }
     }
     const int np = k + 1 <= E ? k + 1 : k;
     if (!kr_f_topk<NV>(sl, E, np, pv, pi, cand)) kr_topk_wave_reg<NV>(sl, E, np, pv, pi);
     kr_f_wave_sync();
-    KR_FSTAMP(6, 5);
     {
         const float pa = lane < np ? pv[lane] : 0.0f, pb = lane + 1 < np ? pv[lane + 1] : 0.0f;
         const bool tie = __ballot(lane + 1 < np && pa == pb) != 0ull;
         if (tie) {   // heap order governs ties (decode.rs:1531)
-            if (lean) {      // the selection values were not parked: do it now (rare path)
-#pragma unroll
-                for (int i = 0; i < NV; i++) { const int e = lane * NV + i; if (e < E) sel[e] = sl[i]; }
-                kr_f_wave_sync();
-            }
             if (lane == 0) kr_topk_heap_serial(sel, E, k, hv, hi, pi);
             kr_f_wave_sync();
         }
     }
     const int my = lane < k ? pi[lane] : 0;
-    if (lean) {
-        // pv[0] is the largest logit (the leaders come out in descending order; under a tie the heap order may permute EQUAL values only)
-        const float mx = pv[0];
-        float wv = lane < k ? __builtin_amdgcn_exp2f((logits[my] - mx) * 1.4426950408889634f) : 0.0f;
-        const float se = kr_f_wave_sum(wv);
-        wv = wv / se;
-        if (lane < k) { s_ids[lane] = my; s_w[lane] = wv; }
-        KR_FSTAMP(6, 6);
-        return;
-    }
     float wv = lane < k ? scores[my] : 0.0f;
     if (raw) {
         const float mx = kr_f_wave_max(lane < k ? wv : -__builtin_inff());
@@ -1068,7 +1106,7 @@ int kr_launch_fw13(const KrFmoeArgs& fa, hipStream_t st) {
     const int wbits = fa.gguf && !has_shared ? 4 : wm.bits;
     size_t img = kr_lds_bytes(a.H, wbits == 8);
     if (fa.gguf && gg_lds_bytes(a.H, false) > img) img = gg_lds_bytes(a.H, false);
-    const size_t lds = img + (size_t)(2 * a.E + 33 + 33 + 32 + 32 + 4 + 128) * 4;
+    const size_t lds = img + (size_t)(2 * a.E + 33 + 33 + 32 + 32 + 4 + 136) * 4;
     const int units = fa.gguf && !has_shared ? 0 : (wbits == 4 ? wm.ngp : wm.ng);
     const bool even = !fa.gguf && (a.w13.bits == 8 || (a.w13.ng % 2) == 0) && units % 2 == 0;
     const int nu = even ? units / 2 : 0;

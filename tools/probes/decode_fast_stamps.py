@@ -45,7 +45,7 @@ def main():
     lines = []
     # the select prologue of kr_fw13 in finer steps (row 6) and the data-path gap between consecutive launches: last stamp of launch i -> first stamp of launch i + 1
     # (s_memrealtime is one constant-rate counter for the whole device, 10 ns)
-    sel = ["entry -> logits in registers", "keys + lane maxima", "k + 1 wave-max rounds (threshold)", "ballot compaction into LDS", "rank by lane broadcasts + write", "tie check, weights, ids to LDS"]
+    sel = ["entry -> logits in registers", "keys + lane maxima", "row-maximum rounds (threshold)", "ballot compaction into LDS", "rank from the LDS list + write", "tie check, weights, ids to LDS"]
     if raw_last is not None and raw_last[6, 0] > 0:
         d6 = np.mean(acc6, axis=0)
         lines.append("%-45s in-select %.2f us : " % ("kr_fw13 select prologue, finer", d6.sum()) + "  ".join("%s %.2f" % (p, v) for p, v in zip(sel, d6)))
