@@ -26,13 +26,25 @@
 // prologues: build the INT16 activation image in LDS (whole workgroup cooperates)
 // ------------------------------------------------------------------------------------------
 
+// The first chunk of every prologue below is REQUESTED by a *_load function and consumed by the prologue itself: the kernels call the load before they request their
+// weight records.  A wave's memory counter is in-order -- an input chunk requested behind eight weight records is not back before all of them are, and the image
+// build then starts one whole weight fetch late (round 5; the arithmetic and its order are untouched).  Every thread loads (clamped index): no lane-masked merges.
+struct KrVecPre { float v[8]; };
+template <typename T>
+__device__ __forceinline__ void kr_vec_load(const T* x, int K, KrVecPre& P) {
+    const int nch = K / 8;
+    kr_load8(x, (int)threadIdx.x < nch ? (int)threadIdx.x : nch - 1, P.v);
+}
 // quantize_activation_int16 / _f32 (avx2.rs:234,274): per-128 scale, round half away from zero
 template <typename T, bool I8>
-__device__ __forceinline__ void kr_prologue_quant(const T* x, int K, const KrActLds& L) {
+__device__ __forceinline__ void kr_prologue_quant(const T* x, int K, const KrActLds& L, const KrVecPre& P) {
     const int nchunks = K / 8;
     for (int c = threadIdx.x; c < nchunks; c += KR_BLOCK) {
         float v[8];
-        kr_load8(x, c, v);
+        if (c == (int)threadIdx.x) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = P.v[i];
+        } else kr_load8(x, c, v);
         float mx = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v[i]));
@@ -47,11 +59,14 @@ __device__ __forceinline__ void kr_prologue_quant(const T* x, int K, const KrAct
 
 // decode graph: f32 hidden, optionally rounded to bf16 first (decode.rs:3307-3309 feeds bf16(hidden) to the routed experts)
 template <bool I8>
-__device__ __forceinline__ void kr_prologue_quant_f32(const float* x, int K, const KrActLds& L, bool round_bf16) {
+__device__ __forceinline__ void kr_prologue_quant_f32(const float* x, int K, const KrActLds& L, bool round_bf16, const KrVecPre& P) {
     const int nchunks = K / 8;
     for (int c = threadIdx.x; c < nchunks; c += KR_BLOCK) {
         float v[8];
-        kr_load8(x, c, v);
+        if (c == (int)threadIdx.x) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = P.v[i];
+        } else kr_load8(x, c, v);
         float mx = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -68,13 +83,24 @@ __device__ __forceinline__ void kr_prologue_quant_f32(const float* x, int K, con
 }
 
 // hidden = act(gate, up) then per-128 INT16 quantization, from gu = [gate(n) | up(n)] in global memory
+struct KrHidPre { float g[8], u[8]; };
+__device__ __forceinline__ void kr_hidden_load(const float* gu, int n, KrHidPre& P) {
+    const int nch = n / 8, c = (int)threadIdx.x < nch ? (int)threadIdx.x : nch - 1;
+    kr_load8(gu, c, P.g);
+    kr_load8(gu + n, c, P.u);
+}
 template <int ACT, bool I8>
-__device__ __forceinline__ void kr_prologue_hidden(const float* gu, int n, float swiglu_limit, float alpha, const KrActLds& L) {
+__device__ __forceinline__ void kr_prologue_hidden(const float* gu, int n, float swiglu_limit, float alpha, const KrActLds& L, const KrHidPre& P) {
     const int nchunks = n / 8;
     for (int c = threadIdx.x; c < nchunks; c += KR_BLOCK) {
         float g[8], u[8], h[8];
-        kr_load8(gu, c, g);
-        kr_load8(gu + n, c, u);
+        if (c == (int)threadIdx.x) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { g[i] = P.g[i]; u[i] = P.u[i]; }
+        } else {
+            kr_load8(gu, c, g);
+            kr_load8(gu + n, c, u);
+        }
         float mx = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -255,23 +281,36 @@ __device__ __forceinline__ KrSlot kr_resolve_slot(const KrMoeArgs& a, int b, int
 
 // pre-built activation image (global memory, byte layout == the LDS image for INT4 weights) -> LDS.  INT8 weights read the same INT16
 // values in natural byte order (kr_store_chunk<true>): that second plane set is a byte permutation of the record, formed on the way in.
-template <int BITS>
-__device__ __forceinline__ void kr_image_copy(const void* img, int K, u32x4* smem, const KrActLds& L) {
+// Two phases (see kr_vec_load): the first KR_IMG_PRE records of a thread are requested by kr_image_load, before the caller's weight records.
+#define KR_IMG_PRE 3
+struct KrImgPre { u32x4 r[KR_IMG_PRE]; };
+__device__ __forceinline__ void kr_image_load(const void* img, int K, KrImgPre& P) {
     const int n16 = (int)(kr_lds_bytes(K, false) / 16);
     const u32x4* src = reinterpret_cast<const u32x4*>(img);
-    for (int i = threadIdx.x; i < n16; i += KR_BLOCK) {
-        const u32x4 r = src[i];
-        smem[i] = r;
-        if constexpr (BITS == 8) {
-            if (i < K / 8) {         // record of chunk i: x / y = high bytes of the even / odd values, z / w = low bytes
-                uint32_t* p = reinterpret_cast<uint32_t*>(L.planes8) + (i >> 1) * 8 + (i & 1) * 2;
-                p[0] = __builtin_amdgcn_perm(r.y, r.x, 0x05010400u);
-                p[1] = __builtin_amdgcn_perm(r.y, r.x, 0x07030602u);
-                p[4] = __builtin_amdgcn_perm(r.w, r.z, 0x05010400u) ^ 0x80808080u;    // (low byte) - 128 as i8
-                p[5] = __builtin_amdgcn_perm(r.w, r.z, 0x07030602u) ^ 0x80808080u;
-            }
+#pragma unroll
+    for (int j = 0; j < KR_IMG_PRE; j++)
+        if (j == 0 || n16 > j * KR_BLOCK) { const int i = threadIdx.x + j * KR_BLOCK; P.r[j] = src[i < n16 ? i : n16 - 1]; }
+}
+template <int BITS>
+__device__ __forceinline__ void kr_image_put(const u32x4 r, int i, int K, u32x4* smem, const KrActLds& L) {
+    smem[i] = r;
+    if constexpr (BITS == 8) {
+        if (i < K / 8) {         // record of chunk i: x / y = high bytes of the even / odd values, z / w = low bytes
+            uint32_t* p = reinterpret_cast<uint32_t*>(L.planes8) + (i >> 1) * 8 + (i & 1) * 2;
+            p[0] = __builtin_amdgcn_perm(r.y, r.x, 0x05010400u);
+            p[1] = __builtin_amdgcn_perm(r.y, r.x, 0x07030602u);
+            p[4] = __builtin_amdgcn_perm(r.w, r.z, 0x05010400u) ^ 0x80808080u;    // (low byte) - 128 as i8
+            p[5] = __builtin_amdgcn_perm(r.w, r.z, 0x07030602u) ^ 0x80808080u;
         }
     }
+}
+template <int BITS>
+__device__ __forceinline__ void kr_image_copy(const void* img, int K, u32x4* smem, const KrActLds& L, const KrImgPre& P) {
+    const int n16 = (int)(kr_lds_bytes(K, false) / 16);
+    const u32x4* src = reinterpret_cast<const u32x4*>(img);
+#pragma unroll
+    for (int j = 0; j < KR_IMG_PRE; j++) { const int i = threadIdx.x + j * KR_BLOCK; if (i < n16) kr_image_put<BITS>(P.r[j], i, K, smem, L); }
+    for (int i = threadIdx.x + KR_IMG_PRE * KR_BLOCK; i < n16; i += KR_BLOCK) kr_image_put<BITS>(src[i], i, K, smem, L);
 }
 
 // stage 1: gu[b][slot][0..2I) = W13 . q(act[b])      grid = (tile groups, n_slots, B)
@@ -279,6 +318,13 @@ __device__ __forceinline__ void kr_image_copy(const void* img, int K, u32x4* sme
 template <int BITS>
 __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a, int tiles_per_wave) {
     const int slot = blockIdx.y, b = blockIdx.z;
+    // the activation (image or vector) is requested first: it depends on nothing this launch reads, the weight records wait for the routing record
+    const bool round_bf16 = !(slot >= a.topk && a.shared_decode);
+    const void* img = a.B == 1 ? (round_bf16 ? a.act_img_bf16 : a.act_img) : nullptr;   // pre-built by the router launch
+    KrImgPre IP; KrVecPre VP;
+    if (img) kr_image_load(img, a.H, IP);
+    else if (a.act_f32) kr_vec_load(a.act_f32 + (size_t)b * a.H, a.H, VP);
+    else kr_vec_load(a.act + (size_t)b * a.H, a.H, VP);
     const KrSlot sl = kr_resolve_slot(a, b, slot);
     if (!sl.valid) return;
     const KrMatDev& m = sl.shared ? a.sw13 : a.w13;
@@ -293,11 +339,9 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a,
     if (first < ntiles) kr_preload<BITS>(pre, sl.q13, sl.s13, m, first, lane, 0);
     else if (gate_wave) kr_preload<BITS>(pre, a.sgate.q, a.sgate.s, a.sgate, 0, lane, 0);   // the gate row has the width of the launch (host check)
     const KrActLds L = kr_carve_lds(kr_smem, a.H, BITS == 8);
-    const bool round_bf16 = !(sl.shared && a.shared_decode);
-    const void* img = a.B == 1 ? (round_bf16 ? a.act_img_bf16 : a.act_img) : nullptr;   // pre-built by the router launch
-    if (img) kr_image_copy<BITS>(img, a.H, kr_smem, L);
-    else if (a.act_f32) kr_prologue_quant_f32<BITS == 8>(a.act_f32 + (size_t)b * a.H, a.H, L, round_bf16);
-    else kr_prologue_quant<uint16_t, BITS == 8>(a.act + (size_t)b * a.H, a.H, L);
+    if (img) kr_image_copy<BITS>(img, a.H, kr_smem, L, IP);
+    else if (a.act_f32) kr_prologue_quant_f32<BITS == 8>(a.act_f32 + (size_t)b * a.H, a.H, L, round_bf16, VP);
+    else kr_prologue_quant<uint16_t, BITS == 8>(a.act + (size_t)b * a.H, a.H, L, VP);
     __syncthreads();
     float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
     for (int t = 0; t < tiles_per_wave; t++) {
@@ -317,6 +361,9 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a,
 template <int BITS, int ACT>
 __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w2_kernel(const KrMoeArgs a, int tiles_per_wave) {
     const int slot = blockIdx.y, b = blockIdx.z;
+    const float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
+    KrHidPre HP;
+    kr_hidden_load(gu, slot >= a.topk ? a.I_shared : a.I, HP);      // the slot's gate | up values first (kr_vec_load), then the routing record and the weights
     const KrSlot sl = kr_resolve_slot(a, b, slot);
     if (!sl.valid) return;
     const KrMatDev& m = sl.shared ? a.sw2 : a.w2;
@@ -328,9 +375,8 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w2_kernel(const KrMoeArgs a, 
     KrPre pre;
     if (first < ntiles) kr_preload<BITS>(pre, sl.q2, sl.s2, m, first, lane, 0);
     const KrActLds L = kr_carve_lds(kr_smem, sl.inter, BITS == 8);
-    const float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
-    if (sl.shared && a.shared_decode) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(gu, sl.inter, a.swiglu_limit, a.alpha, L);
-    else kr_prologue_hidden<ACT, BITS == 8>(gu, sl.inter, a.swiglu_limit, a.alpha, L);
+    if (sl.shared && a.shared_decode) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(gu, sl.inter, a.swiglu_limit, a.alpha, L, HP);
+    else kr_prologue_hidden<ACT, BITS == 8>(gu, sl.inter, a.swiglu_limit, a.alpha, L, HP);
     __syncthreads();
     float* eo = a.eo + ((size_t)b * a.n_slots + slot) * a.H;
     for (int t = 0; t < tiles_per_wave; t++) {
@@ -370,12 +416,14 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_matvec_kernel(const KrMultiMat mm
     const int first = tile0 + wave * tiles_per_wave;
     int mi = 0;
     while (mi + 1 < mm.n && first >= mm.tile_end[mi]) mi++;
+    const int K = mm.m[0].ng * 128;
+    KrHidPre HP; KrVecPre VP;
+    if (act_mode == KR_ACT_SILU_MUL) kr_hidden_load(reinterpret_cast<const float*>(x), K, HP); else kr_vec_load(x, K, VP);      // the input first, the weight records behind it (kr_vec_load)
     KrPre pre;
     if (first < total) kr_preload<BITS>(pre, mm.m[mi].q, mm.m[mi].s, mm.m[mi], first - (mi ? mm.tile_end[mi - 1] : 0), lane, 0);
-    const int K = mm.m[0].ng * 128;
     const KrActLds L = kr_carve_lds(kr_smem, K, BITS == 8);
-    if (act_mode == KR_ACT_SILU_MUL) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(reinterpret_cast<const float*>(x), K, 0.0f, 0.0f, L);
-    else kr_prologue_quant<T, BITS == 8>(x, K, L);
+    if (act_mode == KR_ACT_SILU_MUL) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(reinterpret_cast<const float*>(x), K, 0.0f, 0.0f, L, HP);
+    else kr_prologue_quant<T, BITS == 8>(x, K, L, VP);
     __syncthreads();
     for (int t = 0; t < tiles_per_wave; t++) {
         const int gt = first + t;
@@ -400,13 +448,17 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_matvec_coop_kernel(const KrMultiM
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int mi = 0;
     while (mi + 1 < mm.n && gt0 >= mm.tile_end[mi]) mi++;
+    const int K = mm.m[0].ng * 128;
+    KrImgPre IP; KrHidPre HP; KrVecPre VP;
+    if (x_kind == 2) kr_image_load(x, K, IP);      // the input first, the weight records behind it (kr_vec_load)
+    else if (act_mode == KR_ACT_SILU_MUL) kr_hidden_load(reinterpret_cast<const float*>(x), K, HP);
+    else kr_vec_load(x, K, VP);
     KrCo<BITS> cur;
     kr_co_preload<BITS>(cur, mm.m[mi].q, mm.m[mi].s, mm.m[mi], gt0 - (mi ? mm.tile_end[mi - 1] : 0), lane, wave);
-    const int K = mm.m[0].ng * 128;
     const KrActLds L = kr_carve_lds(kr_smem, K, BITS == 8);
-    if (x_kind == 2) kr_image_copy<BITS>(x, K, kr_smem, L);
-    else if (act_mode == KR_ACT_SILU_MUL) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(reinterpret_cast<const float*>(x), K, 0.0f, 0.0f, L);
-    else kr_prologue_quant<T, BITS == 8>(x, K, L);
+    if (x_kind == 2) kr_image_copy<BITS>(x, K, kr_smem, L, IP);
+    else if (act_mode == KR_ACT_SILU_MUL) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(reinterpret_cast<const float*>(x), K, 0.0f, 0.0f, L, HP);
+    else kr_prologue_quant<T, BITS == 8>(x, K, L, VP);
     __syncthreads();
     for (int t = 0; t < tpb; t++) {
         const int gt = gt0 + t;
