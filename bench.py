@@ -206,9 +206,8 @@ def compact_line(res, detail_path=None):
         if "error" in g:
             gg["error"] = str(g["error"])[:120]
         opt["decode_generate"] = gg
-    for k in ("router_id_flip_rate",):
-        if k in res:
-            opt[k] = res[k]
+    if isinstance(res.get("router_id_flip_rate"), dict):
+        opt["router_id_flip_rate"] = _pick(res["router_id_flip_rate"], "tokens", "flips_ordered", "flips_set", "rate_ordered", "rate_set") or {"error": str(res["router_id_flip_rate"].get("error"))[:120]}
     for k in ("prefill", "prefill_fast", "prefill_fast_gemm"):
         if k in res:
             opt[k] = _prefill_leg(res[k])
@@ -316,6 +315,7 @@ def parse():
     ap.add_argument("--ep-selftest", action="store_true", help="run the expert-parallel leg at N = 1 too (no peer traffic: checks the row path)")
     ap.add_argument("--prefill-tokens", default="8192,20434,35139,49863",
                     help="prompt lengths of the prompt-pass side measurement (benchmark.py:434-505: 20 434 / 35 139 / 49 863 tokens; 0 = skip)")
+    ap.add_argument("--flip-tokens", type=int, default=2000, help="tokens of the exact-vs-KR_DECODE_FAST router-id comparison on the N = 1 line (0 = skip)")
     ap.add_argument("--detail-file", default="", help="where the full (un-abridged) result dict goes; default gpurun_out/bench_detail.json")
     ap.add_argument("--side-configs", default="v2lite-q4,v2lite-q4k-gguf,qcn-q8,qcn-q4k-gguf,qwen3-235b-q4", help="other single-GPU BASELINE configurations measured as side legs of the N = 1 line ('' = none)")
     return ap.parse_args()
@@ -735,6 +735,32 @@ def decode_generate(st, kvm, n_tokens=64, runs=3, lookahead=False):
         st.set_option("generate_lookahead", 0)
     return {"tok_s": sum(per) / len(per), "runs": [round(x, 1) for x in per], "tokens_per_run": n_tokens,
             "loop": "look-ahead (device-side token feedback, host reads token i during step i + 1)" if lookahead else "reference loop (host reads every token before queuing the next step)"}
+
+
+def router_flip_rate(st, dims, kvm, n_tokens, seed=12345):
+    """Cross-mode companion of "router ids identical for identical logits" (VERDICT r4 next #3c): the SAME token stream decoded in the exact mode and in
+    KR_DECODE_FAST, each from the same initial state and each carrying its own state forward; per token, the ids the LAST MoE layer's router selected
+    (kr_decode_read_buffer) are compared -- as ordered lists and as sets.  The inputs of that router differ in the last bits between the modes (47 layers of
+    another summation order before it), so a flip is a near-tie between the k-th and the (k + 1)-th expert; on synthetic (un-trained) router weights the
+    margins are what random gates give -- a lower bound for a trained router."""
+    import numpy as np
+    E, k = dims["experts"], dims["topk"]
+    toks = [int(x) for x in np.random.default_rng(seed).integers(0, dims["vocab"], n_tokens)]
+    got = {}
+    for mode in ("exact", "fast"):
+        st.set_attention_mode(False, decode_fast=mode == "fast")
+        st.fill_state_synthetic(kvm, seed=4242)
+        ids = np.empty((n_tokens, k), np.int32); mg = np.empty(n_tokens, np.float32)
+        for i, t in enumerate(toks):
+            st.decode_step(t, 10 + (i % (kvm - 12)))
+            lg, ii, _w = st.read_router(E, k)
+            ids[i] = ii
+            srt = np.sort(lg)[::-1]; mg[i] = srt[k - 1] - srt[k]
+        got[mode] = (ids, mg)
+    a, b = got["exact"][0], got["fast"][0]
+    ordered = int((a != b).any(axis=1).sum()); as_set = int(sum(1 for x, y in zip(a, b) if set(x.tolist()) != set(y.tolist())))
+    return {"tokens": n_tokens, "layer": "last MoE layer", "flips_ordered": ordered, "flips_set": as_set, "rate_ordered": ordered / n_tokens, "rate_set": as_set / n_tokens,
+            "min_margin_kth_vs_next_logit_exact": float(got["exact"][1].min()), "experts": E, "topk": k}
 
 
 def profile_kinds(st, kvm, P=5, step_ms=None):
@@ -1303,6 +1329,12 @@ def main():
     per_kind_us, per_launch_us, n_per_step = profile_kinds(st, kvm, step_ms=dt / args.steps * 1e3)
 
     side = {}
+    if world == 1 and args.flip_tokens > 0 and dims.get("experts"):
+        try:
+            side["router_id_flip_rate"] = router_flip_rate(st, dims, kvm, args.flip_tokens)
+        except Exception as ex:
+            side["router_id_flip_rate"] = {"error": repr(ex)}
+        st.set_attention_mode(False, decode_fast=fast_mode); st.fill_state_synthetic(kvm, seed=4242 + rank)
     if world == 1:       # side measurements belong to the N = 1 line only
         # the same decode step with the other KV element type (the headline follows BASELINE config 3: FP8 KV)
         try:

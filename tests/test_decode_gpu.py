@@ -172,6 +172,30 @@ def test_decode_step_on_native_gguf_experts_bit_exact(dims, types, graph, fast):
                 assert np.array_equal(rs.view(np.uint32), L["recur_state"].view(np.uint32))
 
 
+@pytest.mark.parametrize("graph,fast", [(True, False), (True, True)])
+def test_decode_step_native_gguf_at_qcn_widths(graph, fast):
+    """VERDICT r4 next #3b: bench.py's `qcn-q4k-gguf` shape as a parity test -- hidden 2048, expert intermediate 512, Q4_K gate / up / down (8 super-blocks per
+    gate row, 2 per down row), top-10 with renormalisation, shared expert 512 with its sigmoid gate; linear-attention + gated-GQA layers; expert count reduced
+    to 24.  Exact: bit for bit against the oracle's moe_forward_gguf-driven decode; KR_DECODE_FAST: within the mode's 2e-3, same greedy token."""
+    st, eng, orc, keep, d = build(dims=(2048, 512, 24, 10, 512, 512), gguf=True, seed=33, kinds=["la", "gqa"], hd=64)
+    st.set_use_graph(graph)
+    if fast:
+        st.set_attention_mode(False, decode_fast=True)
+    tok = 7
+    for step, pos in enumerate([5, 6, 7]):
+        logits = np.empty(d["V"], F)
+        st.decode_step(tok, pos, logits.ctypes.data)
+        ref = orc.step(tok, pos)
+        if fast:
+            err = float(np.abs(logits - ref).max() / np.abs(ref).max())
+            assert 0.0 < err <= 2e-3, (step, err)
+            assert int(np.argmax(logits)) == O.sample_greedy(ref)
+        else:
+            assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (step, float(np.max(np.abs(logits - ref))))
+            assert st.last_token() == O.sample_greedy(ref)
+        tok = O.sample_greedy(ref)
+
+
 @pytest.mark.parametrize("hd", [64, 128, 256])
 def test_decode_step_long_positions_bit_exact(hd):
     """positions past one / two 128-row stages of the attention kernel's K / V staging (decode.rs:4194 order kept across stages)"""
