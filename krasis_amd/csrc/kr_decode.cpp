@@ -628,7 +628,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.sc_g = s->kv_max_seq > s->gqa_split_min ? (float*)s->gqa_scores.p : nullptr;
             a.force_stream = s->opt_gqa_stream; a.tree_norm = fast ? 1 : 0;
             if (s->attn_fast && a.sc_g) { a.fd_o = (float*)s->fd_o.p; a.fd_ml = (float*)s->fd_ml.p; }
-            PROF(PK_GQA, kr_launch_gqa(a, s->kv_max_seq, st));
+            PROF(PK_GQA, { if (!(fast && !a.sc_g && kr_launch_fgqa(a, s->kv_max_seq, st) == 0)) kr_launch_gqa(a, s->kv_max_seq, st); });      // KR_DECODE_FAST, short cache: one launch
             if (o_img) out_proj(L.o_wid);
             else PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }

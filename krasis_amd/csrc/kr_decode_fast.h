@@ -62,3 +62,7 @@ struct KrFmoeArgs {
 int kr_fmoe_check(const KrFmoeArgs& a);      // 0 when both launches below cover the geometry
 int kr_launch_fw13(const KrFmoeArgs& a, hipStream_t st);
 int kr_launch_fw2(const KrFmoeArgs& a, hipStream_t st);
+
+// GQA layers over a short cache (kv_max_seq <= 1024) in KR_DECODE_FAST: prep (gated split, QK-norm, RoPE, KV append) + attention of one query head per workgroup in ONE
+// launch (the exact path: kr_gqa_prep_kernel + kr_gqa_attn_kernel).  Non-zero: geometry not covered (caller takes kr_launch_gqa).
+int kr_launch_fgqa(const KrGqaArgs& a, int max_seq, hipStream_t st);

@@ -980,6 +980,218 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const float* p_gu, const i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// GQA layers over a SHORT cache (kv_max_seq <= KR_FGQA_MAX, the reference's decode benchmark runs 256): what the exact path does in two launches -- kr_gqa_prep_kernel
+// (gated split, per-head QK RMSNorm, half-split RoPE, KV append; decode.rs:2873-2966) and kr_gqa_attn_kernel (decode.rs:4194-4281: q.k, softmax, p.v, output gate)
+// -- as ONE launch of one workgroup per query head.  Same operations and the same libm functions; what changes is the order of the f32 sums (lane / wave trees) and
+// who walks what: 16 lanes per cache position in the score pass (a wave takes 4 positions per step, the workgroup 16), one wave per cache row in the p.v pass (the
+// four waves take every fourth position and meet in LDS).  The new K / V row of this step is used as the cache will hold it (rounded to FP16 / E4M3), every query head
+// of a KV group forms it for itself and the group's first head stores it.  Requests run a batch of positions ahead of the arithmetic.
+// (Round 3 tried a single launch with one thread per output dimension in the p.v pass: faster below 100 positions, slower at 200 -- not kept.  The two passes here
+// spread every position over lanes, so a 256-position cache costs ~16 steps of each.)
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define KR_FGQA_MAX 1024
+template <int N, bool FP8> struct KrKvRaw { static constexpr int W = FP8 ? (N + 3) / 4 : (N + 1) / 2; uint32_t w[W]; };
+template <int N, bool FP8>
+__device__ __forceinline__ void kr_kv_raw_load(KrKvRaw<N, FP8>& r, const void* base, size_t elem) {
+    constexpr int bytes = FP8 ? N : 2 * N;
+    const char* p = reinterpret_cast<const char*>(base) + elem * (FP8 ? 1 : 2);
+    if constexpr (bytes >= 16) {
+#pragma unroll
+        for (int i = 0; i < bytes / 16; i++) { const u32x4 v = *reinterpret_cast<const u32x4*>(p + 16 * i); r.w[4 * i] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w; }
+    } else if constexpr (bytes == 8) { const u32x2 v = *reinterpret_cast<const u32x2*>(p); r.w[0] = v.x; r.w[1] = v.y; }
+    else if constexpr (bytes == 4) r.w[0] = *reinterpret_cast<const uint32_t*>(p);
+    else if constexpr (bytes == 2) r.w[0] = *reinterpret_cast<const uint16_t*>(p);
+    else r.w[0] = *reinterpret_cast<const uint8_t*>(p);
+}
+template <int N, bool FP8>
+__device__ __forceinline__ void kr_kv_raw_f32(const KrKvRaw<N, FP8>& r, float (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if constexpr (FP8) {
+            const int w = (int)r.w[i >> 2];
+            x[i] = (i & 3) == 0 ? __builtin_amdgcn_cvt_f32_fp8(w, 0) : ((i & 3) == 1 ? __builtin_amdgcn_cvt_f32_fp8(w, 1) : ((i & 3) == 2 ? __builtin_amdgcn_cvt_f32_fp8(w, 2) : __builtin_amdgcn_cvt_f32_fp8(w, 3)));
+        } else {
+            const uint16_t hb = (uint16_t)((i & 1) ? (r.w[i >> 1] >> 16) : (r.w[i >> 1] & 0xFFFFu));
+            x[i] = (float)__builtin_bit_cast(_Float16, hb);
+        }
+    }
+}
+template <bool FP8> __device__ __forceinline__ float kr_kv_round(float v) {      // the value a cache element holds after kr_kv_store (kr_device.h)
+    if constexpr (FP8) return kr_e4m3_to_f32(kr_f32_to_e4m3(v));
+    else return (float)(_Float16)v;
+}
+
+template <int HD, bool FP8>
+__global__ void __launch_bounds__(256) kr_fgqa_kernel(const KrStep* p_step, const float* p_q, const float* p_k, const float* p_v, const void* p_kc, const void* p_vc,
+                                                      int p_nh, int p_nkv, const KrGqaArgs a) {
+    constexpr int D16 = HD / 16;        // dimensions per lane in the score pass (16 lanes per position)
+    constexpr int DPL = HD / 64;        // dimensions per lane in the p.v pass (a wave spans one cache row)
+    constexpr int SB = 2;               // score pass: 16-position steps requested per batch
+    constexpr int PB = 8;               // p.v pass: positions per wave requested per batch
+    __shared__ __attribute__((aligned(16))) float s_q[HD], s_k[HD], s_v[HD], s_sc[KR_FGQA_MAX + 64], s_part[4][HD];
+    __shared__ float s_red[2][4];
+    const int h = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int grp = p_nh / p_nkv, kvh = h / grp;
+    const int pos = p_step->pos, seq = pos + 1;
+    const size_t rowe = (size_t)p_nkv * HD, headoff = (size_t)kvh * HD;
+    const int d = t < HD ? t : HD - 1;     // every thread loads (clamped)
+    const bool own = t < HD;
+    // ---- requests: this step's q / gate / k / v of the head, norm weights, the rope row; then the first batch of K rows
+    const float qraw = a.gated ? p_q[(size_t)h * HD * 2 + d] : p_q[(size_t)h * HD + d];
+    const float graw = a.gated ? p_q[(size_t)h * HD * 2 + HD + d] : 0.0f;
+    const float kraw = p_k[headoff + d], vraw = p_v[headoff + d];
+    const float qw = a.q_norm ? a.q_norm[(a.q_norm_per_head ? h * HD : 0) + d] : 1.0f;
+    const float kw = a.k_norm ? a.k_norm[(a.k_norm_per_head ? kvh * HD : 0) + d] : 1.0f;
+    const int d2 = a.rope_half;
+    const bool rot = t < 2 * d2 && own;
+    const int ri = rot ? (t < d2 ? t : t - d2) : 0;
+    const float rc = a.rope_cos[(size_t)pos * d2 + ri], rs = a.rope_sin[(size_t)pos * d2 + ri];
+    const int l16 = lane & 15, pw = lane >> 4;
+    KrKvRaw<D16, FP8> kqA[SB], kqB[SB];      // two request batches, named (a run-time buffer index would send the arrays to scratch)
+    auto issue_k = [&](KrKvRaw<D16, FP8> (&kq)[SB], int s0) {
+#pragma unroll
+        for (int u = 0; u < SB; u++) { const int sp = s0 + 16 * u + wave * 4 + pw; kr_kv_raw_load<D16, FP8>(kq[u], p_kc, (size_t)(sp < pos ? sp : 0) * rowe + headoff + l16 * D16); }
+    };
+    issue_k(kqA, 0);
+    // ---- per-head QK RMSNorm (trees), RoPE
+    float sq = own ? qraw * qraw : 0.0f, sk = own ? kraw * kraw : 0.0f;
+    sq = kr_f_wave_sum(sq); sk = kr_f_wave_sum(sk);
+    if (lane == 0) { s_red[0][wave] = sq; s_red[1][wave] = sk; }
+    __syncthreads();
+    float qx = qraw, kx = kraw;
+    if (a.q_norm) { const float ss = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]); qx = qraw * ((1.0f / sqrtf(ss / (float)HD + a.eps)) * qw); }
+    if (a.k_norm) { const float ss = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]); kx = kraw * ((1.0f / sqrtf(ss / (float)HD + a.eps)) * kw); }
+    if (own) { s_q[t] = qx; s_k[t] = kx; }
+    __syncthreads();
+    float qv = qx, kv = kx;
+    if (rot) {
+        if (t < d2) { qv = qx * rc - s_q[d2 + t] * rs; kv = kx * rc - s_k[d2 + t] * rs; }      // x1 cos - x2 sin
+        else { qv = qx * rc + s_q[t - d2] * rs; kv = kx * rc + s_k[t - d2] * rs; }              // x2 cos + x1 sin
+    }
+    __syncthreads();
+    if (own) {
+        s_q[t] = qv; s_k[t] = kr_kv_round<FP8>(kv); s_v[t] = kr_kv_round<FP8>(vraw);
+        if (h == kvh * grp) {      // the group's first head appends the row
+            const size_t o = (size_t)pos * rowe + headoff + t;
+            kr_kv_store(const_cast<void*>(p_kc), o, kv, FP8 ? 1 : 0);
+            kr_kv_store(const_cast<void*>(p_vc), o, vraw, FP8 ? 1 : 0);
+        }
+    }
+    __syncthreads();
+    // ---- scores: 16 lanes per position
+    float qreg[D16], knew[D16];
+#pragma unroll
+    for (int i = 0; i < D16; i++) { qreg[i] = s_q[l16 * D16 + i]; knew[i] = s_k[l16 * D16 + i]; }
+    auto score_batch = [&](const KrKvRaw<D16, FP8> (&kq)[SB], int s0) {
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+            const int sp = s0 + 16 * u + wave * 4 + pw;
+            float kx_[D16];
+            kr_kv_raw_f32<D16, FP8>(kq[u], kx_);
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D16; i++) acc = __builtin_fmaf(qreg[i], sp == pos ? knew[i] : kx_[i], acc);
+            acc = kr_f_red16(acc);
+            if (l16 == 0 && sp < seq) s_sc[sp] = acc * a.sm_scale;
+        }
+    };
+    constexpr int SSTEP = 16 * SB;
+    for (int s0 = 0; s0 < seq; s0 += 2 * SSTEP) {
+        if (s0 + SSTEP < seq) issue_k(kqB, s0 + SSTEP);
+        score_batch(kqA, s0);
+        if (s0 + 2 * SSTEP < seq) issue_k(kqA, s0 + 2 * SSTEP);
+        if (s0 + SSTEP < seq) score_batch(kqB, s0 + SSTEP);
+    }
+    // ---- the first batch of V rows leaves before the softmax
+    KrKvRaw<DPL, FP8> vqA[PB], vqB[PB];
+    auto issue_v = [&](KrKvRaw<DPL, FP8> (&vq)[PB], int s0) {
+#pragma unroll
+        for (int u = 0; u < PB; u++) { const int sp = s0 + 4 * u + wave; kr_kv_raw_load<DPL, FP8>(vq[u], p_vc, (size_t)(sp < pos ? sp : 0) * rowe + headoff + lane * DPL); }
+    };
+    issue_v(vqA, 0);
+    __syncthreads();
+    float mx = -__builtin_inff();
+    for (int sp = t; sp < seq; sp += 256) mx = fmaxf(mx, s_sc[sp]);
+    mx = kr_f_wave_max(mx);
+    if (lane == 0) s_red[0][wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+    float se = 0.0f;
+    for (int sp = t; sp < seq; sp += 256) { const float e = kr_expf(s_sc[sp] - mx); s_sc[sp] = e; se += e; }
+    se = kr_f_wave_sum(se);
+    if (lane == 0) s_red[1][wave] = se;
+    __syncthreads();
+    const float inv = 1.0f / ((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
+    for (int sp = t; sp < seq; sp += 256) s_sc[sp] *= inv;      // sc[s] *= inv (decode.rs:4260)
+    float vnew[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; i++) vnew[i] = s_v[lane * DPL + i];
+    __syncthreads();
+    // ---- p.v: wave w takes positions w, w + 4, ...; lane l the dimensions l DPL .. l DPL + DPL
+    float o[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; i++) o[i] = 0.0f;
+    auto pv_batch = [&](const KrKvRaw<DPL, FP8> (&vq)[PB], int s0) {
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            const int sp = s0 + 4 * u + wave;
+            float vx[DPL];
+            kr_kv_raw_f32<DPL, FP8>(vq[u], vx);
+            const float pr = sp < seq ? s_sc[sp] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < DPL; i++) o[i] = __builtin_fmaf(pr, sp == pos ? vnew[i] : vx[i], o[i]);
+        }
+    };
+    constexpr int PSTEP = 4 * PB;
+    for (int s0 = 0; s0 < seq; s0 += 2 * PSTEP) {
+        if (s0 + PSTEP < seq) issue_v(vqB, s0 + PSTEP);
+        pv_batch(vqA, s0);
+        if (s0 + 2 * PSTEP < seq) issue_v(vqA, s0 + 2 * PSTEP);
+        if (s0 + PSTEP < seq) pv_batch(vqB, s0 + PSTEP);
+    }
+#pragma unroll
+    for (int i = 0; i < DPL; i++) s_part[wave][lane * DPL + i] = o[i];
+    __syncthreads();
+    float ov = 0.0f;
+    if (own) {
+        ov = (s_part[0][t] + s_part[1][t]) + (s_part[2][t] + s_part[3][t]);
+        if (a.gated) ov *= 1.0f / (1.0f + kr_expf(-graw));
+        a.attn_out[(size_t)h * HD + t] = ov;
+        s_q[t] = ov;
+    }
+    if (a.img_out) {   // HD % 128 == 0: the head's output is HD / 128 whole quantization groups of the o-projection's input
+        __syncthreads();
+        const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(a.img_out), p_nh * HD, false);
+        constexpr int nch = HD / 8;
+        if (t < nch) {
+            float v8[8];
+            kr_load8(s_q, t, v8);
+            float mxq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) mxq = fmaxf(mxq, fabsf(v8[i]));
+            float scale, invq;
+            kr_group_scale(mxq, scale, invq);
+            int q8[8];
+            kr_quant8<false>(v8, invq, q8);
+            const int gc = h * nch + t;
+            kr_store_chunk<false>(Lg, gc, q8);
+            if ((gc & 15) == 0) Lg.ascale[gc >> 4] = scale;
+        }
+    }
+}
+
+int kr_launch_fgqa(const KrGqaArgs& a, int max_seq, hipStream_t st) {
+    if (max_seq > KR_FGQA_MAX || a.sc_g || a.nh % a.nkv || 2 * a.rope_half > a.hd || (a.img_out && a.hd % 128)) return 1;
+#define KR_FGQA(H_, F_) hipLaunchKernelGGL((kr_fgqa_kernel<H_, F_>), dim3(a.nh), dim3(256), 0, st, a.step, a.q_in, a.k_in, a.v_in, (const void*)a.k_cache, (const void*)a.v_cache, a.nh, a.nkv, a)
+    if (a.hd == 256) { if (a.kv_fp8) KR_FGQA(256, true); else KR_FGQA(256, false); }
+    else if (a.hd == 128) { if (a.kv_fp8) KR_FGQA(128, true); else KR_FGQA(128, false); }
+    else if (a.hd == 64) { if (a.kv_fp8) KR_FGQA(64, true); else KR_FGQA(64, false); }
+    else return 1;
+#undef KR_FGQA
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int BITS, int KS, int MODE>

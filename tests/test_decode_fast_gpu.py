@@ -172,3 +172,54 @@ def test_fast_mode_generate_and_profile_step():
     lg = np.empty(d["V"], F); st.decode_step(7, 5, lg.ctypes.data)
     ref = orc.step(7, 5)
     assert np.array_equal(lg.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("hd,fp8", [(64, False), (128, False), (256, False), (64, True), (128, True), (256, True)])
+def test_fast_gqa_short_cache_one_launch(hd, fp8):
+    """KR_DECODE_FAST over a short cache (kv_max_seq <= 1024): prep + attention of a GQA layer in ONE launch (kr_fgqa_kernel: QK-norm trees, RoPE, KV append,
+    16 lanes per position in the score pass, one wave per cache row in the p.v pass, request batches of 32 positions).  Positions on both sides of the batch
+    boundaries and up to the end of a 300-position cache, FP16 and E4M3 caches, head_dim 64 / 128 / 256: logits within the mode's 2e-3 of the oracle driver (the
+    exact reference order), same greedy token; the appended K / V rows are the exact path's rows up to the tolerance of their inputs."""
+    st, eng, orc, keep, d = build(seed=5, kv_max=300, hd=hd, kinds=["gqa", "la", "gqa"])
+    if fp8:
+        st.set_kv_dtype(True); O.set_kv_fp8(True)
+    try:
+        if fp8:
+            rng = np.random.default_rng(5); kv = {}
+            for li, kind in enumerate(d["kinds"]):
+                if kind == "gqa":
+                    kc = O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)); vc = O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F))
+                    kv[li] = (kc, vc); orc.layers[li]["kv_k"] = kc.astype(np.uint16); orc.layers[li]["kv_v"] = vc.astype(np.uint16)
+            n = len(d["kinds"]); ptr = lambda a: a.ctypes.data
+            st.set_decode_state(5, d["kv_max"], [ptr(kv[i][0]) if i in kv else 0 for i in range(n)], [ptr(kv[i][1]) if i in kv else 0 for i in range(n)],
+                                [ptr(x) if x is not None else 0 for x in d["state"]["conv"]], [ptr(x) if x is not None else 0 for x in d["state"]["recur"]])
+        st.set_attention_mode(False, decode_fast=True)
+        tok = 11; worst = 0.0
+        for pos in [0, 1, 15, 16, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 299]:
+            logits = np.empty(d["V"], F)
+            st.decode_step(tok, pos, logits.ctypes.data)
+            ref = orc.step(tok, pos)
+            err = float(np.abs(logits - ref).max() / np.abs(ref).max()); worst = max(worst, err)
+            assert np.isfinite(logits).all() and err <= 2e-3, (pos, err)
+            assert int(np.argmax(logits)) == O.sample_greedy(ref), pos
+            tok = O.sample_greedy(ref)
+        _log("fused short-cache GQA launch hd %d %s: worst logits rel err over 17 positions %.3e" % (hd, "E4M3" if fp8 else "FP16", worst))
+        for li, kind in enumerate(d["kinds"]):
+            if kind != "gqa":
+                continue
+            if fp8:
+                kc = np.empty((d["kv_max"], d["nkv"] * d["hd"]), np.uint8); vc = np.empty_like(kc)
+                st.get_decode_state(li, kc, vc, None, None)
+                a = O.e4m3_to_f32(kc) if hasattr(O, "e4m3_to_f32") else None
+                if a is not None:
+                    b = O.e4m3_to_f32(orc.layers[li]["kv_k"].astype(np.uint8))
+                    assert float(np.abs(a[:300] - b[:300]).max()) <= 0.13 * float(np.abs(b[:300]).max())      # one E4M3 step of the largest row value at most
+            else:
+                kc = np.empty((d["kv_max"], d["nkv"] * d["hd"]), np.uint16); vc = np.empty_like(kc)
+                st.get_decode_state(li, kc, vc, None, None)
+                a = kc.view(np.float16).astype(F); b = orc.layers[li]["kv_k"].view(np.float16).astype(F)
+                assert float(np.abs(a - b).max()) <= 3e-3 * float(np.abs(b).max())
+                a = vc.view(np.float16).astype(F); b = orc.layers[li]["kv_v"].view(np.float16).astype(F)
+                assert float(np.abs(a - b).max()) <= 3e-3 * float(np.abs(b).max())
+    finally:
+        O.set_kv_fp8(False)
