@@ -628,7 +628,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.sc_g = s->kv_max_seq > s->gqa_split_min ? (float*)s->gqa_scores.p : nullptr;
             a.force_stream = s->opt_gqa_stream; a.tree_norm = fast ? 1 : 0;
             if (s->attn_fast && a.sc_g) { a.fd_o = (float*)s->fd_o.p; a.fd_ml = (float*)s->fd_ml.p; }
-            PROF(PK_GQA, { if (!(fast && !a.sc_g && kr_launch_fgqa(a, s->kv_max_seq, st) == 0)) kr_launch_gqa(a, s->kv_max_seq, st); });      // KR_DECODE_FAST, short cache: one launch
+            PROF(PK_GQA, { if (!(fast && s->opt_gqa_fused && !a.sc_g && kr_launch_fgqa(a, s->kv_max_seq, st) == 0)) kr_launch_gqa(a, s->kv_max_seq, st); });      // KR_DECODE_FAST, short cache: one launch
             if (o_img) out_proj(L.o_wid);
             else PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.o_wid), s->attn_out.p, 1, hid, st));
         }
@@ -967,6 +967,7 @@ extern "C" int kr_decode_set_option(kr_decode_store* s, const char* name, int va
     if (int rc = chk_store(s)) return rc;
     if (!name) return kr_fail(KR_ERR_VALUE, "null option name");
     if (!strcmp(name, "gqa_stream")) { s->opt_gqa_stream = value != 0; s->graph_ok = false; return KR_OK; }
+    if (!strcmp(name, "gqa_fused")) { s->opt_gqa_fused = value != 0; s->graph_ok = false; return KR_OK; }      // KR_DECODE_FAST, short caches: 0 = prep + attention as two launches (A/B and test hook)
     if (!strcmp(name, "pfm_timing")) { s->opt_pfm_timing = value != 0; return KR_OK; }
     if (!strcmp(name, "generate_lookahead")) { s->opt_gen_lookahead = value != 0; return KR_OK; }
     if (!strcmp(name, "ep_graph")) { s->opt_ep_graph = value != 0; s->graph_ok = false; return KR_OK; }

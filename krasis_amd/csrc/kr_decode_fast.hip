@@ -814,17 +814,17 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const float* p_logits, con
     int u0, u1;
     if (NU > 0) { u0 = ks * NU; u1 = u0 + NU; }
     else { const int uw = (units + KS - 1) / KS; u0 = ks * uw; u1 = u0 + uw < units ? u0 + uw : units; }
-    KrFw<BITS, NU> Wg, Wu;
+    KrFw<BITS, NU, 8> Wg, Wu;      // guarded form: 8 records per tile in flight (two K-waves: enough for K <= 4096 in one pass; 16 made the launch a one-workgroup-per-CU kernel)
     float ag = 0.0f, au = 0.0f;
     if (pair) {
-        kr_f_fetch<BITS, NU>(Wg, m, qb, sb, unit, lane, u0, u1);
-        kr_f_fetch<BITS, NU>(Wu, m, qb, sb, unit + ntp, lane, u0, u1);
+        kr_f_fetch<BITS, NU, 8>(Wg, m, qb, sb, unit, lane, u0, u1);
+        kr_f_fetch<BITS, NU, 8>(Wu, m, qb, sb, unit + ntp, lane, u0, u1);
         KR_FSTAMP(4, 3);
-        ag = kr_f_tile<BITS, NU>(Wg, m, qb, sb, unit, lane, u0, u1, L);
-        au = kr_f_tile<BITS, NU>(Wu, m, qb, sb, unit + ntp, lane, u0, u1, L);
+        ag = kr_f_tile<BITS, NU, 8>(Wg, m, qb, sb, unit, lane, u0, u1, L);
+        au = kr_f_tile<BITS, NU, 8>(Wu, m, qb, sb, unit + ntp, lane, u0, u1, L);
     } else if (gate_row) {
-        kr_f_fetch<BITS, NU>(Wg, a.sgate, a.sgate.q, a.sgate.s, 0, lane, u0, u1);
-        ag = kr_f_tile<BITS, NU>(Wg, a.sgate, a.sgate.q, a.sgate.s, 0, lane, u0, u1, L);
+        kr_f_fetch<BITS, NU, 8>(Wg, a.sgate, a.sgate.q, a.sgate.s, 0, lane, u0, u1);
+        ag = kr_f_tile<BITS, NU, 8>(Wg, a.sgate, a.sgate.q, a.sgate.s, 0, lane, u0, u1, L);
     }
     KR_FSTAMP(4, 4);
     if (l8 == 0) { s_x[tw][ks][0][cl] = ag; s_x[tw][ks][1][cl] = au; }
@@ -866,13 +866,10 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const float* p_gu, const i
     const int inter = shared ? a.I_shared : a.I;
     // one wave per slot over an exact unit count: the lane's chunks of the expert hidden are requested before anything else (ahead of the routing record and the
     // weight stream, which waits for the record: see kr_f_norm_load)
-    constexpr int HC = (NU > 0 && !MULTI) ? (BITS == 4 ? NU / 2 : NU / 4) : 0;
-    [[maybe_unused]] float hpre[HC > 0 ? HC : 1][8];
-    if constexpr (HC > 0) {
-        const float* hp = p_gu + (size_t)slot * p_gu_ld;
-#pragma unroll
-        for (int j = 0; j < HC; j++) kr_load8(hp, lane + 64 * j, hpre[j]);
-    }
+    constexpr int HCN = (NU > 0 && !MULTI) ? (BITS == 4 ? NU / 2 : NU / 4) : 0;      // chunks per lane; the FIRST is requested here (16 waves of a workgroup leave 128 registers a lane:
+    constexpr int HC = HCN > 0 ? 1 : 0;                                               //  more would spill at I >= 1024), the others in the loop below
+    [[maybe_unused]] float hpre[1][8];
+    if constexpr (HC > 0) kr_load8(p_gu + (size_t)slot * p_gu_ld, lane, hpre[0]);
     const void* qb = m.q; const uint32_t* sb = m.s;
     bool valid = true; float wt = 1.0f;
     bool skip = false;        // expert-parallel decode: slot evaluated by another rank -- this wave contributes 0 and reads no weights
@@ -914,15 +911,20 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const float* p_gu, const i
     if constexpr (HC > 0) {
         if (!skip)
 #pragma unroll
-        for (int j = 0; j < HC; j++) {
+        for (int j = 0; j < HCN; j++) {
             const int c = lane + 64 * j;
+            float v[8];
+            if (j == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = hpre[0][i];
+            } else kr_load8(h, c, v);
             float mx = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(hpre[j][i]));
+            for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v[i]));
             float scale, inv;
             kr_group_scale(mx, scale, inv);
             int q[8];
-            if (half_away) kr_quant8<false>(hpre[j], inv, q); else kr_quant8<true>(hpre[j], inv, q);
+            if (half_away) kr_quant8<false>(v, inv, q); else kr_quant8<true>(v, inv, q);
             kr_store_chunk<BITS == 8>(L, c, q);
             if ((c & 15) == 0) L.ascale[c >> 4] = scale;
         }

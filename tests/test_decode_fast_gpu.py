@@ -194,13 +194,16 @@ def test_fast_gqa_short_cache_one_launch(hd, fp8):
             st.set_decode_state(5, d["kv_max"], [ptr(kv[i][0]) if i in kv else 0 for i in range(n)], [ptr(kv[i][1]) if i in kv else 0 for i in range(n)],
                                 [ptr(x) if x is not None else 0 for x in d["state"]["conv"]], [ptr(x) if x is not None else 0 for x in d["state"]["recur"]])
         st.set_attention_mode(False, decode_fast=True)
-        tok = 11; worst = 0.0
+        # An E4M3 cache element has three mantissa bits: a last-bit difference of a K / V value (the mode's tree sums upstream) can move it by one step of 6 %, in
+        # this launch exactly as in the mode's two-launch form (kr_decode_set_option "gqa_fused" 0: measured beside it below).  Stated bound with E4M3 caches: 5e-3.
+        bound = 5e-3 if fp8 else 2e-3
+        tok = 11; worst = 0.0; worst_two = 0.0
         for pos in [0, 1, 15, 16, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 299]:
             logits = np.empty(d["V"], F)
             st.decode_step(tok, pos, logits.ctypes.data)
             ref = orc.step(tok, pos)
             err = float(np.abs(logits - ref).max() / np.abs(ref).max()); worst = max(worst, err)
-            assert np.isfinite(logits).all() and err <= 2e-3, (pos, err)
+            assert np.isfinite(logits).all() and err <= bound, (pos, err)
             assert int(np.argmax(logits)) == O.sample_greedy(ref), pos
             tok = O.sample_greedy(ref)
         _log("fused short-cache GQA launch hd %d %s: worst logits rel err over 17 positions %.3e" % (hd, "E4M3" if fp8 else "FP16", worst))
@@ -223,3 +226,31 @@ def test_fast_gqa_short_cache_one_launch(hd, fp8):
                 assert float(np.abs(a - b).max()) <= 3e-3 * float(np.abs(b).max())
     finally:
         O.set_kv_fp8(False)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_fast_gqa_one_launch_vs_two_launches(fp8):
+    """the one-launch short-cache form against the mode's two-launch form (prep with tree norms + the staged exact-order attention) on the same model and tokens:
+    logits within 2e-3 of each other with an FP16 cache (another order of the same sums), within the E4M3 bound with an E4M3 cache; same greedy tokens"""
+    outs = {}
+    for fused in (1, 0):
+        st, eng, orc, keep, d = build(seed=5, kv_max=300, hd=256, kinds=["gqa", "la", "gqa"])
+        if fp8:
+            st.set_kv_dtype(True)
+            rng = np.random.default_rng(5); kv = {}
+            for li, kind in enumerate(d["kinds"]):
+                if kind == "gqa":
+                    kv[li] = (O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)), O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["nkv"] * d["hd"])) * 0.5).astype(F)))
+            n = len(d["kinds"]); ptr = lambda a: a.ctypes.data
+            st.set_decode_state(5, d["kv_max"], [ptr(kv[i][0]) if i in kv else 0 for i in range(n)], [ptr(kv[i][1]) if i in kv else 0 for i in range(n)],
+                                [ptr(x) if x is not None else 0 for x in d["state"]["conv"]], [ptr(x) if x is not None else 0 for x in d["state"]["recur"]])
+        st.set_attention_mode(False, decode_fast=True)
+        st.set_option("gqa_fused", fused)
+        lg = []
+        for i, pos in enumerate([0, 1, 31, 32, 33, 100, 255, 256, 299]):
+            out = np.empty(d["V"], F); st.decode_step(3 + 7 * i, pos, out.ctypes.data); lg.append(out)
+        outs[fused] = lg
+    bound = 5e-3 if fp8 else 2e-3
+    for a, b in zip(outs[1], outs[0]):
+        assert float(np.abs(a - b).max() / np.abs(b).max()) <= bound
+        assert int(np.argmax(a)) == int(np.argmax(b))

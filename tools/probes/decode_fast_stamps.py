@@ -24,7 +24,7 @@ NAMES = {0: ("kr_fdm (norm folded, qkvz|ba / q|k|v)", ["fetch issued", "norm + i
 def main():
     import torch  # noqa: F401
     q = bench.QCN
-    eng, st, keep = bench.build_qcn(0, 0, int(os.environ.get("LAYERS", "48")), 0, 4, kv_fp8=True)
+    eng, st, keep = bench.build_qcn(0, 0, int(os.environ.get("LAYERS", "48")), 0, 4, kv_fp8=True, gguf=os.environ.get("GGUF", "0") == "1")
     st.set_attention_mode(False, decode_fast=True)
     lib = st._lib
     buf = (C.c_ulonglong * (8 * 16))()
