@@ -94,46 +94,63 @@ __global__ void kr_pfm_quant_f32_kernel(const float* __restrict__ x, int ld, int
 }
 
 // ---- linear attention: causal conv + SiLU + L2 norms + gates for every token (decode.rs:3815-3945) -------------------------
-// grid (nk, ceil(C / 8)): a workgroup takes one key head and EIGHT consecutive tokens.  Tap j of token t is X(t-3+j): a chunk row for >= 0, the carried
-// conv state slot 4+i for i < 0.  A thread walks its channel down the 8 tokens with the 4-tap window in registers (11 row reads instead of 32; the
-// one-token form launched 16 384 workgroups per chunk whose whole life was one load -> barrier -> 16-step norm chain -> barrier -> store sequence:
-// 85 us per 1024-token chunk).  Per value the arithmetic is unchanged: the tap products are added left to right, SiLU with the degree-5 sigmoid,
-// the two L2 norms as 8-lane fma chains over the head's 128 conv outputs.
+// grid (nk, ceil(C / 16)): a workgroup takes one key head and SIXTEEN consecutive tokens, as two tiles of eight; a thread takes FOUR consecutive channels of one tile
+// and walks them down the 8 tokens with the 4-tap window in registers: 11 row reads of 16 bytes per lane (round 2-4: one channel per thread, 4-byte reads -- the
+// launch moved 180 MB per 2731-token chunk at 1.1 TB/s, 5.9 % of the tolerance prompt pass).  Tap j of token t is X(t-3+j): a chunk row for >= 0, the carried conv
+// state slot 4+i for i < 0.  Per value the arithmetic is unchanged: the tap products are added left to right, SiLU with the degree-5 sigmoid, the two L2 norms as
+// 8-lane fma chains over the head's 128 conv outputs.  Needs dk % 4 == 0, dv % 4 == 0 and (2 dk + hr dv) / 4 <= 128 (the launcher falls back to one tile of channels
+// per pass otherwise: the loop below strides over channel quads).
 #define PFC_TT 8
+#define PFC_WT 16      // tokens per workgroup
 __global__ void __launch_bounds__(256) kr_pfm_la_conv_kernel(const KrPfmLaArgs a, int C) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int kh = blockIdx.x, t0 = blockIdx.y * PFC_TT, dk = a.dk, dv = a.dv, hr = a.hr, nk = a.nk;
-    const int nt = C - t0 < PFC_TT ? C - t0 : PFC_TT;
+    const int kh = blockIdx.x, w0 = blockIdx.y * PFC_WT, dk = a.dk, dv = a.dv, hr = a.hr, nk = a.nk;
+    const int nw = C - w0 < PFC_WT ? C - w0 : PFC_WT;                       // tokens of this workgroup
     const int group_dim = 2 * dk + 2 * dv * hr, key_dim = nk * dk, nvdk = a.nv * dk, nvdv = a.nv * dv;
-    float* qc = sm; float* kc = sm + PFC_TT * dk; float* nrm = sm + 2 * PFC_TT * dk;       // [8][dk], [8][dk], [8][2]
-    const int nch = 2 * dk + hr * dv;
-    for (int c = threadIdx.x; c < nch; c += 256) {
+    float* qc = sm; float* kc = sm + PFC_WT * dk; float* nrm = sm + 2 * PFC_WT * dk;       // [16][dk], [16][dk], [16][2]
+    const int nch = 2 * dk + hr * dv, nq = nch / 4;
+    const int half = threadIdx.x >> 7, t0 = w0 + half * PFC_TT;               // this thread's token tile
+    const int nt = C - t0 < PFC_TT ? (C - t0 < 0 ? 0 : C - t0) : PFC_TT;
+    for (int cq = threadIdx.x & 127; cq < nq; cq += 128) {
+        const int c = cq * 4;
         int ch, off;
         if (c < dk) { ch = kh * dk + c; off = c; }
         else if (c < 2 * dk) { ch = key_dim + kh * dk + (c - dk); off = c; }
         else { const int r = (c - 2 * dk) / dv, i = (c - 2 * dk) % dv; ch = 2 * key_dim + (kh * hr + r) * dv + i; off = 2 * dk + r * dv + i; }
         const float* cs = a.conv_state + (size_t)ch * 4;
-        const float4 cw = *reinterpret_cast<const float4*>(a.conv_w + (size_t)ch * 4);
-        const float* col = a.qkvz + (size_t)kh * group_dim + off;
-        float x[PFC_TT + 3];                       // X(t0 - 3) .. X(t0 + 7) of this channel, all requested before the first use
+        float4 cw[4];
 #pragma unroll
-        for (int j = 0; j < PFC_TT + 3; j++) { const int i = t0 - 3 + j; x[j] = i < 0 ? cs[4 + i] : (i < C ? col[(size_t)i * a.ld_qkvz] : 0.0f); }
+        for (int q = 0; q < 4; q++) cw[q] = *reinterpret_cast<const float4*>(a.conv_w + (size_t)(ch + q) * 4);
+        const float* col = a.qkvz + (size_t)kh * group_dim + off;
+        float4 x[PFC_TT + 3];                       // X(t0 - 3) .. X(t0 + 7) of the four channels, all requested before the first use
+#pragma unroll
+        for (int j = 0; j < PFC_TT + 3; j++) {
+            const int i = t0 - 3 + j;
+            if (i < 0) x[j] = float4{cs[4 + i], cs[8 + i], cs[12 + i], cs[16 + i]};        // slot 4 + i of channels ch .. ch + 3 (first tile of the chunk only)
+            else x[j] = i < C ? *reinterpret_cast<const float4*>(col + (size_t)i * a.ld_qkvz) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
 #pragma unroll
         for (int tt = 0; tt < PFC_TT; tt++)
             if (tt < nt) {
-                float co = x[tt] * cw.x + x[tt + 1] * cw.y + x[tt + 2] * cw.z + x[tt + 3] * cw.w;
-                co = co * kr_sigmoid_poly5(co);
-                if (c < dk) qc[tt * dk + c] = co;
-                else if (c < 2 * dk) kc[tt * dk + (c - dk)] = co;
-                else a.v[(size_t)(t0 + tt) * nvdv + (ch - 2 * key_dim)] = co;
+                float4 co;
+                co.x = x[tt].x * cw[0].x + x[tt + 1].x * cw[0].y + x[tt + 2].x * cw[0].z + x[tt + 3].x * cw[0].w;
+                co.y = x[tt].y * cw[1].x + x[tt + 1].y * cw[1].y + x[tt + 2].y * cw[1].z + x[tt + 3].y * cw[1].w;
+                co.z = x[tt].z * cw[2].x + x[tt + 1].z * cw[2].y + x[tt + 2].z * cw[2].z + x[tt + 3].z * cw[2].w;
+                co.w = x[tt].w * cw[3].x + x[tt + 1].w * cw[3].y + x[tt + 2].w * cw[3].z + x[tt + 3].w * cw[3].w;
+                co.x = co.x * kr_sigmoid_poly5(co.x); co.y = co.y * kr_sigmoid_poly5(co.y); co.z = co.z * kr_sigmoid_poly5(co.z); co.w = co.w * kr_sigmoid_poly5(co.w);
+                const int wt = half * PFC_TT + tt;
+                if (c < dk) *reinterpret_cast<float4*>(qc + wt * dk + c) = co;
+                else if (c < 2 * dk) *reinterpret_cast<float4*>(kc + wt * dk + (c - dk)) = co;
+                else *reinterpret_cast<float4*>(a.v + (size_t)(t0 + tt) * nvdv + (ch - 2 * key_dim)) = co;
             }
     }
-    for (int c = threadIdx.x; c < nt * hr * dv; c += 256) {
-        const int tt = c / (hr * dv), rem = c % (hr * dv), r = rem / dv, i = rem % dv;
-        a.z[(size_t)(t0 + tt) * nvdv + (size_t)(kh * hr + r) * dv + i] = a.qkvz[(size_t)(t0 + tt) * a.ld_qkvz + (size_t)kh * group_dim + 2 * dk + hr * dv + r * dv + i];
+    for (int c = threadIdx.x; c < nw * hr * dv / 4; c += 256) {
+        const int e = c * 4, tt = e / (hr * dv), rem = e % (hr * dv), r = rem / dv, i = rem % dv;
+        *reinterpret_cast<float4*>(a.z + (size_t)(w0 + tt) * nvdv + (size_t)(kh * hr + r) * dv + i) =
+            *reinterpret_cast<const float4*>(a.qkvz + (size_t)(w0 + tt) * a.ld_qkvz + (size_t)kh * group_dim + 2 * dk + hr * dv + r * dv + i);
     }
-    if ((int)threadIdx.x < nt * hr) {   // decode.rs:3891-3901
-        const int tt = threadIdx.x / hr, r = threadIdx.x % hr, vh = kh * hr + r, t = t0 + tt;
+    if ((int)threadIdx.x < nw * hr) {   // decode.rs:3891-3901
+        const int tt = threadIdx.x / hr, r = threadIdx.x % hr, vh = kh * hr + r, t = w0 + tt;
         const float* ba = a.ba + (size_t)t * a.ld_ba;
         const float b_raw = ba[kh * 2 * hr + r], a_p = ba[kh * 2 * hr + hr + r];
         a.beta[(size_t)t * a.nv + vh] = 1.0f / (1.0f + kr_expf(-b_raw));
@@ -143,17 +160,20 @@ __global__ void __launch_bounds__(256) kr_pfm_la_conv_kernel(const KrPfmLaArgs a
         a.gexp[(size_t)t * a.nv + vh] = kr_expf(g);   // decode.rs:1293 decays the state by exp(g)
     }
     __syncthreads();
-    if (threadIdx.x < 16 * PFC_TT) {            // 8 lanes per (token, q | k) chain
+    if (threadIdx.x < 16 * PFC_WT) {            // 8 lanes per (token, q | k) chain
         const int tt = threadIdx.x >> 4, which = (threadIdx.x >> 3) & 1, l = threadIdx.x & 7;
-        const float ss = kr_pfm_sumsq8((which ? kc : qc) + tt * dk, dk, l);
-        if (l == 0) nrm[tt * 2 + which] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        if (tt < nw) {
+            const float ss = kr_pfm_sumsq8((which ? kc : qc) + tt * dk, dk, l);
+            if (l == 0) nrm[tt * 2 + which] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < nt * hr * dk; c += 256) {
-        const int tt = c / (hr * dk), rem = c % (hr * dk), r = rem / dk, i = rem % dk, vh = kh * hr + r;
+    for (int c = threadIdx.x; c < nw * hr * dk / 4; c += 256) {
+        const int e = c * 4, tt = e / (hr * dk), rem = e % (hr * dk), r = rem / dk, i = rem % dk, vh = kh * hr + r;
         const float inv_q = nrm[tt * 2] * a.scale, inv_k = nrm[tt * 2 + 1] * 1.0f;
-        a.q[(size_t)(t0 + tt) * nvdk + (size_t)vh * dk + i] = qc[tt * dk + i] * inv_q;
-        a.k[(size_t)(t0 + tt) * nvdk + (size_t)vh * dk + i] = kc[tt * dk + i] * inv_k;
+        const float4 qv = *reinterpret_cast<const float4*>(qc + tt * dk + i), kv = *reinterpret_cast<const float4*>(kc + tt * dk + i);
+        *reinterpret_cast<float4*>(a.q + (size_t)(w0 + tt) * nvdk + (size_t)vh * dk + i) = float4{qv.x * inv_q, qv.y * inv_q, qv.z * inv_q, qv.w * inv_q};
+        *reinterpret_cast<float4*>(a.k + (size_t)(w0 + tt) * nvdk + (size_t)vh * dk + i) = float4{kv.x * inv_k, kv.y * inv_k, kv.z * inv_k, kv.w * inv_k};
     }
 }
 
@@ -700,7 +720,8 @@ int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out,
     const KrPfSync none{};
     if (!sy) sy = &none;
     kr_pf_wait(st, sy->wait_a);              // the previous chunk's carried conv slots
-    hipLaunchKernelGGL(kr_pfm_la_conv_kernel, dim3(a.nk, (C + PFC_TT - 1) / PFC_TT), dim3(256), (size_t)(2 * PFC_TT * a.dk + 2 * PFC_TT) * 4, st, a, C);
+    if (a.dk % 4 || a.dv % 4 || a.ld_qkvz % 4) return 1;      // 16-byte row reads
+    hipLaunchKernelGGL(kr_pfm_la_conv_kernel, dim3(a.nk, (C + PFC_WT - 1) / PFC_WT), dim3(256), (size_t)(2 * PFC_WT * a.dk + 2 * PFC_WT) * 4, st, a, C);
     const int conv_dim = 2 * a.nk * a.dk + a.nv * a.dv;
     hipLaunchKernelGGL(kr_pfm_la_conv_state_kernel, dim3((conv_dim + 255) / 256), dim3(256), 0, st, a, C);
     kr_pf_rec(st, sy->rec_a);
