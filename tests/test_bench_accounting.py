@@ -83,3 +83,27 @@ def test_compact_line_hard_cap_drops_optional_groups():
     out, text = bench.compact_line(full, None)
     assert len(text) <= bench.LINE_HARD_CAP_BYTES
     assert "configs" not in out and out["roofline"]["frac"] == 0.1 and json.loads(text)["value"] == 1.0
+
+
+def test_compact_line_of_a_multi_gpu_result():
+    """the N > 1 line (main_multi): contract keys survive, every expert-parallel leg is reduced to numbers"""
+    import json
+    import bench
+    leg = {"tok_s": 1234.5, "ms_per_step": 0.81, "hip_graph": True, "form": "x" * 300}
+    full = {"metric": "decode tok/s, Qwen3-Coder-Next Q4 expert-parallel @8 MI355X", "value": 1234.5, "unit": "tok/s", "n_gpus": 8, "steps": 20, "warmup": 5, "ms_per_step": 0.81,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int4-g128 w x int16 act -> i32, f32 scales", "dtype_note": "y" * 400, "data": "synthetic",
+            "config": {"workload": "w", "layers": 48, "kv": "FP8", "parallelism": "ep8: " + "z" * 400, "scope": "s" * 300, "value_is": "expert-parallel decode, KR_DECODE_FAST, hipGraph replay"},
+            "roofline": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s per GPU", "step_algorithmic_bytes_per_gpu": 5e8, "achieved": 617.0, "frac": 0.077, "kernel": "whole step", "traffic": None},
+            "decode_ep_exact": dict(leg), "decode_ep_fast": dict(leg), "decode_ep_fast_graph": dict(leg), "rccl_ranks": 8, "experts_per_gpu": 64,
+            "prefill_model_ep": {"value": 3e5, "unit": "tok/s", "tokens_per_gpu": 8192, "tokens_total": 65536, "ms": 218.0, "roofline": {"frac": 0.03}, "attention": "a" * 200},
+            "prefill_experts_ep_alltoall": {"tok_s_experts_only": 7e5, "ms": 93.0, "tokens_total": 65536, "roofline": {"frac": 0.05}, "note": "n" * 500},
+            "replicas": {"tok_s_aggregate": 5000.0, "tok_s_per_replica": 625.0, "note": "r" * 200},
+            "qwen3_235b_ep": {"value": 900.0, "frac_of_hbm_peak_per_gpu": 0.1, "decode_ep_fast_graph": dict(leg), "workload": "q" * 200}}
+    out, text = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    back = json.loads(text)
+    assert len(text) <= bench.LINE_TARGET_BYTES
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in back, k
+    assert back["n_gpus"] == 8 and back["scaling"] == "strong" and back["decode_ep_fast_graph"]["tok_s"] == 1234.5
+    assert back["prefill_model_ep"]["tok_s"] == 300000.0 and back["qwen3_235b_ep"]["decode_ep_fast_graph"] == 1234.5
+    assert back["roofline"]["traffic"] is None and back["roofline"]["step_bytes_per_gpu"] == 5e8
