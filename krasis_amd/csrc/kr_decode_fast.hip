@@ -23,8 +23,14 @@ extern __shared__ __attribute__((aligned(16))) u32x4 kr_fsm[];
 __device__ unsigned long long kr_fstamps[8][16];
 #define KR_FSTAMP(k, i) do { if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) kr_fstamps[k][i] = wall_clock64(); } while (0)
 extern "C" int kr_debug_fstamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kr_fstamps), sizeof(kr_fstamps)); }
+// entry / exit time and hardware id of EVERY workgroup of a launch (wave 0), for the launches of the last layer of a step: where a launch's tail comes from
+__device__ unsigned long long kr_fwg[6][1024][3];
+#define KR_FWG(k, i) do { if (threadIdx.x == 0) { const unsigned b_ = blockIdx.x + gridDim.x * blockIdx.y; if (b_ < 1024) { kr_fwg[k][b_][i] = wall_clock64(); \
+        if ((i) == 0) kr_fwg[k][b_][2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32); } } } while (0)
+extern "C" int kr_debug_fwg(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kr_fwg), sizeof(kr_fwg)); }
 #else
 #define KR_FSTAMP(k, i) do { } while (0)
+#define KR_FWG(k, i) do { } while (0)
 #endif
 
 #define KR_FW2_LDS_MAX (64 * 1024)   // dynamic LDS of kr_fw2_kernel without a per-device opt-in (kr_lds_optin.h)
@@ -232,6 +238,10 @@ __device__ __forceinline__ void kr_f_quant_chunk(const float (&v)[8], int c, con
 // Kernel arguments: the pointers a wave needs for its FIRST requests are leading scalar arguments, which the Makefile asks the compiler to have preloaded into
 // SGPRs (-amdgpu-kernarg-preload-count): those requests leave without the scalar round trip to the argument block that the by-value structs cost.
 //   p0: MODE 0 the INT16 image, MODE 1 / 2 the input vector (null: first layer, the embedding row of the step's token); p1: residual (null: none); p2: norm weights
+// (Measured and removed, round 5: a BALANCED form of the in-projection launch -- exactly 256 workgroups of 6 or 7 one-tile waves, one per CU, the norm built once per
+//  CU -- against the 386 four-tile workgroups that put two workgroups on 130 CUs.  Per-workgroup times say why it is worth nothing: alone on a CU a workgroup takes
+//  4.3 us, sharing one 5.2, and a 6 - 7-wave workgroup 5.1: the launch follows the bytes a CU streams (profiles/r05_decode_fast_wg_times.txt), first entry -> last
+//  exit 6.34 -> 6.13 us, 620.9 vs 620.9 tok/s in an interleaved A/B.)
 template <int BITS, int KS, int NU, int MODE>
 __global__ void __launch_bounds__(256) kr_fdm_kernel(const void* p0, const float* p1, const float* p2, int Kp, const KrFdmArgs a) {
     constexpr int TW = 4 / KS;
@@ -240,7 +250,7 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const void* p0, const float
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, l8 = lane & 7, cl = lane >> 3;
     const int tw = wave / KS, ks = wave - tw * KS;
     [[maybe_unused]] constexpr int sk = MODE == 1 ? 0 : 2;
-    KR_FSTAMP(sk, 0);
+    KR_FSTAMP(sk, 0); KR_FWG(sk, 0);
     // ---- requests, in the order they are needed back (a wave's memory counter is in-order): the input vector / image, then the weight stream, then the
     //      epilogue's operands.  MODE is a template parameter so that no register of one mode's loads is ever seen as pending by another mode's code.
     const int K = Kp;
@@ -256,11 +266,15 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const void* p0, const float
         if (p0 == nullptr) in.hid = a.emb + (size_t)a.step->token * K;
         kr_f_norm_load(in, NR);
     }
+    // (Measured and removed, round 5: requesting the weight records of matrix-0 tiles from preloaded arguments right behind the input requests -- 1 us earlier than the
+    //  descriptor fields of the argument struct allow.  The stream then queues ahead of the norm's inputs in the memory system: "norm + image" 1.4 -> 2.9 us, the launch
+    //  6.1 -> 6.5 us, 626 -> 613 tok/s; a workgroup barrier between the two request groups did not help (615).  The scalar work below is a useful delay.)
+    const int bx = blockIdx.x;
+    const int gt0 = bx * TW + tw;
     // the matrix of this tile: every field sits at a CONSTANT kernarg offset (one scalar round trip for all of them) and is selected
     // afterwards -- indexing the argument struct with a computed matrix index costs a second, dependent scalar round trip before the
     // first weight request can be issued.  The host sets tile_end[i] = total for every i >= n - 1.
     const int te0 = a.mm.tile_end[0], te1 = a.mm.tile_end[1], te2 = a.mm.tile_end[2], total = a.mm.tile_end[3];
-    const int gt0 = blockIdx.x * TW + tw;
     const bool active = gt0 < total;
     const int gt = active ? gt0 : total - 1;      // a wave past the last tile walks the last tile again and stores nothing: every wave issues the same requests (see kr_f_norm_load)
     const int mi = (gt >= te0) + (gt >= te1) + (gt >= te2);
@@ -344,7 +358,7 @@ __global__ void __launch_bounds__(256) kr_fdm_kernel(const void* p0, const float
             if (kind == 2) a.v_out[dst] = co; else a.qk_out[dst] = co;
         }
     }
-    KR_FSTAMP(sk, 5);
+    KR_FSTAMP(sk, 5); KR_FWG(sk, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -362,7 +376,7 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const float* p_qk, const fl
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int slice = t / JQ, jq = t - slice * JQ;
     f32x4* S4 = reinterpret_cast<f32x4*>(p_state + (size_t)vh * DK * DV);
-    KR_FSTAMP(1, 0);
+    KR_FSTAMP(1, 0); KR_FWG(1, 0);
     // the head's vectors first (every thread loads, clamped: kr_f_norm_load), the 64 KB of state behind them -- the q / k sums run while the state streams in
     const float g_exp = p_ge[vh], beta = p_beta[vh];   // e^g and beta of this head: formed by the ba lanes of the projection launch
     float qv = p_qk[(size_t)kh * 2 * DK + (t < 2 * DK ? t : 0)];
@@ -454,7 +468,7 @@ __global__ void __launch_bounds__(512) kr_fla_kernel(const float* p_qk, const fl
             if (t == 0) Lg.ascale[vh] = scale;
         }
     }
-    KR_FSTAMP(1, 7);
+    KR_FSTAMP(1, 7); KR_FWG(1, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -469,7 +483,7 @@ __global__ void __launch_bounds__(256) kr_frt_kernel(const float* p_hid, const f
     const int H = p_H, ld = H / 16 + 4;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int eb = blockIdx.x;
-    KR_FSTAMP(3, 0);
+    KR_FSTAMP(3, 0); KR_FWG(3, 0);
     const int ncg = GATE_BF16 ? H / 128 : H / 64;
     const int cpw = (ncg + 3) / 4, c0 = wave * cpw, c1 = c0 + cpw < ncg ? c0 + cpw : ncg;
     const u32x4* gp = reinterpret_cast<const u32x4*>(p_gate) + (size_t)eb * ncg * 64 + lane;
@@ -532,7 +546,7 @@ __global__ void __launch_bounds__(256) kr_frt_kernel(const float* p_hid, const f
             a.logits[e] = v;
         }
     }
-    KR_FSTAMP(3, 4);
+    KR_FSTAMP(3, 4); KR_FWG(3, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -749,7 +763,7 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const float* p_logits, con
     const bool gg = p_gguf && !shared;                  // routed slot on native GGUF blocks: per-32 activation image instead of the per-128 one
     const GgAct GA = gg_carve(reinterpret_cast<char*>(kr_fsm), p_H);
     const size_t img_bytes = p_gguf ? (kr_lds_bytes(p_H, BITS == 8) > gg_lds_bytes(p_H, false) ? kr_lds_bytes(p_H, BITS == 8) : gg_lds_bytes(p_H, false)) : kr_lds_bytes(p_H, BITS == 8);
-    KR_FSTAMP(4, 0);
+    KR_FSTAMP(4, 0); KR_FWG(4, 0);
     if (shared) kr_f_image_copy<BITS>(a.act_img, p_H, kr_fsm, L, t, 256);
     else if (wave > 0) {
         if (gg) {      // quantize_bf16_to_int16 of bf16(hidden) (gguf_kernels.rs:110, decode.rs:3307-3309), 8 values per thread, 4 consecutive lanes per sub-block
@@ -834,7 +848,7 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const float* p_logits, con
         if (pair) a.gu[(size_t)slot * a.gu_ld + unit * 8 + cl] = (g * kr_sigmoid_poly5(g)) * u;
         else if (gate_row && cl == 0) a.gate_out[0] = 1.0f / (1.0f + kr_expf(-g));   // sigmoid of the shared expert's gate row (decode.rs:3379-3393): the w2 launch multiplies by it
     }
-    KR_FSTAMP(4, 5);
+    KR_FSTAMP(4, 5); KR_FWG(4, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -856,7 +870,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const float* p_gu, const i
     const int nrw = p_topk * pr;                             // waves of the routed slots
     const int slot = vslot < nrw ? vslot / pr : p_topk, part = vslot < nrw ? vslot % pr : vslot - nrw, parts = vslot < nrw ? pr : ps;
     const int tile = blockIdx.x;
-    KR_FSTAMP(5, 0);
+    KR_FSTAMP(5, 0); KR_FWG(5, 0);
     // sigmoid(gate row) of the shared expert, formed by the gate|up launch.  A rank that skips this layer's shared expert (expert-parallel decode) never wrote it:
     // it neither reads the value nor adds the term (0 * stale bits could be NaN and the all-reduce would spread it -- ADVICE r4 #2)
     const float sig = (a.gate_out && !fa.shared_skip) ? a.gate_out[0] : 1.0f;
@@ -978,7 +992,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const float* p_gu, const i
         const int col = tile * 8 + t;
         if (col < a.H) fa.hid_out[col] = o;
     }
-    KR_FSTAMP(5, 5);
+    KR_FSTAMP(5, 5); KR_FWG(5, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
