@@ -808,6 +808,8 @@ __global__ void __launch_bounds__(256) kr_fw13_kernel(const float* p_logits, con
         }
         return;
     }
+    // (Measured and removed, round 5: reading the struct fields this part needs BEFORE the select and pinning them in SGPRs -- the pin is a wait: the select wave
+    //  then starts behind those scalar loads, "weight fetch issued" 1.34 -> 1.80 us.)
     const KrMatDev& m = shared ? a.sw13 : a.w13;
     const void* qb = m.q; const uint32_t* sb = m.s;
     const int inter = shared ? a.I_shared : a.I;
@@ -880,10 +882,17 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const float* p_gu, const i
     const int inter = shared ? a.I_shared : a.I;
     // one wave per slot over an exact unit count: the lane's chunks of the expert hidden are requested before anything else (ahead of the routing record and the
     // weight stream, which waits for the record: see kr_f_norm_load)
-    constexpr int HCN = (NU > 0 && !MULTI) ? (BITS == 4 ? NU / 2 : NU / 4) : 0;      // chunks per lane; the FIRST is requested here (16 waves of a workgroup leave 128 registers a lane:
-    constexpr int HC = HCN > 0 ? 1 : 0;                                               //  more would spill at I >= 1024), the others in the loop below
+    constexpr int HCN = (NU > 0 && !MULTI) ? (BITS == 4 ? NU / 2 : NU / 4) : 0;      // exact-unit forms: chunks per lane
+    constexpr int HC = HCN > 0 ? 1 : 0;
+    // this wave's units of the slot's expert and the FIRST chunk of the hidden it will quantise: requested here, ahead of the routing record and the weight records
+    // (16 waves of a workgroup leave 128 registers a lane: one chunk ahead, the others in the loops below)
+    const int units = BITS == 4 ? m.ngp : m.ng;
+    const int u0 = units * part / parts, u1 = units * (part + 1) / parts;
+    const int cpu = (BITS == 4 ? 256 : 128) / 8;            // 8-value chunks per unit
+    const int c0 = u0 * cpu + lane, cend = u1 * cpu < inter / 8 ? u1 * cpu : inter / 8;
+    constexpr bool PRE = !MULTI;      // (the several-waves-per-slot form is at its 128 registers: one chunk ahead spills there)
     [[maybe_unused]] float hpre[1][8];
-    if constexpr (HC > 0) kr_load8(p_gu + (size_t)slot * p_gu_ld, lane, hpre[0]);
+    if constexpr (PRE) kr_load8(p_gu + (size_t)slot * p_gu_ld, c0 < inter / 8 ? c0 : inter / 8 - 1, hpre[0]);
     const void* qb = m.q; const uint32_t* sb = m.s;
     bool valid = true; float wt = 1.0f;
     bool skip = false;        // expert-parallel decode: slot evaluated by another rank -- this wave contributes 0 and reads no weights
@@ -912,16 +921,14 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const float* p_gu, const i
         if (l8 == 0) s_y[vslot][cl] = accg;                 // (GGUF routed slots: pr = 1, the launcher sees to it)
         if (lane == 0) s_wt[slot] = valid ? wt : 0.0f;
     }
-    const int units = BITS == 4 ? m.ngp : m.ng;
-    const int u0 = units * part / parts, u1 = units * (part + 1) / parts;      // this wave's units of the slot's expert
-    KrFw<BITS, NU, 8> W;     // 16 waves per workgroup leave 128 registers per lane: the guarded form keeps 8 records in flight
+    constexpr int FU2 = 8;      // 16 waves per workgroup leave 128 registers per lane: the guarded form keeps 8 records in flight
+    KrFw<BITS, NU, FU2> W;
     if (gg) skip = true;     // handled above: the rest of the slot's work is the barrier and the combine
-    if (!skip) kr_f_fetch<BITS, NU, 8>(W, m, qb, sb, tile, lane, u0, u1);
+    if (!skip) kr_f_fetch<BITS, NU, FU2>(W, m, qb, sb, tile, lane, u0, u1);
     const KrActLds L = kr_carve_lds(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(kr_fsm) + (size_t)slot * slot_lds), inter, BITS == 8);
     const float* h = a.gu + (size_t)slot * a.gu_ld;
     KR_FSTAMP(5, 1);
     const bool half_away = shared && a.shared_decode;
-    const int cpu = (BITS == 4 ? 256 : 128) / 8;            // 8-value chunks per unit
     if constexpr (HC > 0) {
         if (!skip)
 #pragma unroll
@@ -943,9 +950,12 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const float* p_gu, const i
             if ((c & 15) == 0) L.ascale[c >> 4] = scale;
         }
     } else if (!skip)
-    for (int c = u0 * cpu + lane; c < (u1 * cpu < inter / 8 ? u1 * cpu : inter / 8); c += 64) {
+    for (int c = c0; c < cend; c += 64) {
         float v[8];
-        kr_load8(h, c, v);
+        if (PRE && c == c0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = hpre[0][i];
+        } else kr_load8(h, c, v);
         float mx = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) mx = fmaxf(mx, fabsf(v[i]));
@@ -958,7 +968,7 @@ __global__ void __launch_bounds__(1024) kr_fw2_kernel(const float* p_gu, const i
     }
     kr_f_wave_sync();
     KR_FSTAMP(5, 2);
-    const float acc = skip ? 0.0f : kr_f_tile<BITS, NU, 8>(W, m, qb, sb, tile, lane, u0, u1, L);
+    const float acc = skip ? 0.0f : kr_f_tile<BITS, NU, FU2>(W, m, qb, sb, tile, lane, u0, u1, L);
     KR_FSTAMP(5, 3);
     if (!gg) {
         if (l8 == 0) s_y[vslot][cl] = acc;
