@@ -316,13 +316,14 @@ __device__ __forceinline__ void kr_image_copy(const void* img, int K, u32x4* sme
 // stage 1: gu[b][slot][0..2I) = W13 . q(act[b])      grid = (tile groups, n_slots, B)
 // The shared slot may carry one extra tile: the shared expert's sigmoid-gate row (decode.rs:3379-3390), N = 1.
 template <int BITS>
-__global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a, int tiles_per_wave) {
+__global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const void* p_img_bf16, const void* p_img_f32, int p_H, int p_topk, int p_shared_decode, int p_B,
+                                                              const KrMoeArgs a, int tiles_per_wave) {      // leading scalars: preloaded (see kr_matvec_coop_kernel)
     const int slot = blockIdx.y, b = blockIdx.z;
     // the activation (image or vector) is requested first: it depends on nothing this launch reads, the weight records wait for the routing record
-    const bool round_bf16 = !(slot >= a.topk && a.shared_decode);
-    const void* img = a.B == 1 ? (round_bf16 ? a.act_img_bf16 : a.act_img) : nullptr;   // pre-built by the router launch
+    const bool round_bf16 = !(slot >= p_topk && p_shared_decode);
+    const void* img = p_B == 1 ? (round_bf16 ? p_img_bf16 : p_img_f32) : nullptr;   // pre-built by the router launch
     KrImgPre IP; KrVecPre VP;
-    if (img) kr_image_load(img, a.H, IP);
+    if (img) kr_image_load(img, p_H, IP);
     else if (a.act_f32) kr_vec_load(a.act_f32 + (size_t)b * a.H, a.H, VP);
     else kr_vec_load(a.act + (size_t)b * a.H, a.H, VP);
     const KrSlot sl = kr_resolve_slot(a, b, slot);
@@ -359,11 +360,11 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w13_kernel(const KrMoeArgs a,
 
 // stage 2: eo[b][slot][0..H) = W2 . q(act_fn(gu[b][slot]))
 template <int BITS, int ACT>
-__global__ void __launch_bounds__(KR_BLOCK) kr_moe_w2_kernel(const KrMoeArgs a, int tiles_per_wave) {
+__global__ void __launch_bounds__(KR_BLOCK) kr_moe_w2_kernel(const float* p_gu, int p_n_slots, int p_gu_ld, int p_I, int p_I_shared, int p_topk, const KrMoeArgs a, int tiles_per_wave) {
     const int slot = blockIdx.y, b = blockIdx.z;
-    const float* gu = a.gu + ((size_t)b * a.n_slots + slot) * a.gu_ld;
+    const float* gu = p_gu + ((size_t)b * p_n_slots + slot) * p_gu_ld;
     KrHidPre HP;
-    kr_hidden_load(gu, slot >= a.topk ? a.I_shared : a.I, HP);      // the slot's gate | up values first (kr_vec_load), then the routing record and the weights
+    kr_hidden_load(gu, slot >= p_topk ? p_I_shared : p_I, HP);      // the slot's gate | up values first (kr_vec_load; preloaded arguments), then the routing record and the weights
     const KrSlot sl = kr_resolve_slot(a, b, slot);
     if (!sl.valid) return;
     const KrMatDev& m = sl.shared ? a.sw2 : a.w2;
@@ -441,18 +442,19 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_matvec_kernel(const KrMultiMat mm
 // workgroup split the K range of a tile (see "Cooperative tile" above); a workgroup walks `tpb` consecutive tiles.
 // x_kind: 0 bf16 vector, 1 f32 vector, 2 pre-built INT16 image in global memory
 template <typename T, int BITS>
-__global__ void __launch_bounds__(KR_BLOCK) kr_matvec_coop_kernel(const KrMultiMat mm, const T* x, int tpb, int act_mode, int x_kind) {
+// (x, K and the modes are leading scalar arguments: the Makefile asks for them to be preloaded into SGPRs, so the input request leaves without a scalar round trip to
+//  the argument block -- see kr_decode_fast.hip)
+__global__ void __launch_bounds__(KR_BLOCK) kr_matvec_coop_kernel(const T* x, int Kp, int tpb, int act_mode, int x_kind, const KrMultiMat mm) {
     __shared__ KrXch X[2];
-    const int total = mm.tile_end[mm.n - 1], gt0 = blockIdx.x * tpb;
-    if (gt0 >= total) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int mi = 0;
-    while (mi + 1 < mm.n && gt0 >= mm.tile_end[mi]) mi++;
-    const int K = mm.m[0].ng * 128;
+    const int K = Kp;
     KrImgPre IP; KrHidPre HP; KrVecPre VP;
     if (x_kind == 2) kr_image_load(x, K, IP);      // the input first, the weight records behind it (kr_vec_load)
     else if (act_mode == KR_ACT_SILU_MUL) kr_hidden_load(reinterpret_cast<const float*>(x), K, HP);
     else kr_vec_load(x, K, VP);
+    const int total = mm.tile_end[mm.n - 1], gt0 = blockIdx.x * tpb;      // (the launcher's grid has no workgroup past the last tile)
+    int mi = 0;
+    while (mi + 1 < mm.n && gt0 >= mm.tile_end[mi]) mi++;
     KrCo<BITS> cur;
     kr_co_preload<BITS>(cur, mm.m[mi].q, mm.m[mi].s, mm.m[mi], gt0 - (mi ? mm.tile_end[mi - 1] : 0), lane, wave);
     const KrActLds L = kr_carve_lds(kr_smem, K, BITS == 8);
@@ -502,8 +504,8 @@ void kr_launch_moe_w13(const KrMoeArgs& a, hipStream_t st) {
     const int tpw = kr_pick_tpw(a.H, nt);
     dim3 grid((nt + KR_WAVES * tpw - 1) / (KR_WAVES * tpw), a.n_slots, a.B);
     const size_t lds = kr_lds_bytes(a.H, a.w13.bits == 8);
-    if (a.w13.bits == 4) hipLaunchKernelGGL(kr_moe_w13_kernel<4>, grid, dim3(KR_BLOCK), lds, st, a, tpw);
-    else hipLaunchKernelGGL(kr_moe_w13_kernel<8>, grid, dim3(KR_BLOCK), lds, st, a, tpw);
+    if (a.w13.bits == 4) hipLaunchKernelGGL(kr_moe_w13_kernel<4>, grid, dim3(KR_BLOCK), lds, st, a.act_img_bf16, a.act_img, a.H, a.topk, a.shared_decode, a.B, a, tpw);
+    else hipLaunchKernelGGL(kr_moe_w13_kernel<8>, grid, dim3(KR_BLOCK), lds, st, a.act_img_bf16, a.act_img, a.H, a.topk, a.shared_decode, a.B, a, tpw);
 }
 
 void kr_launch_moe_w2(const KrMoeArgs& a, hipStream_t st) {
@@ -513,7 +515,7 @@ void kr_launch_moe_w2(const KrMoeArgs& a, hipStream_t st) {
     const int tpw = kr_pick_tpw(a.I, nt);
     dim3 grid((nt + KR_WAVES * tpw - 1) / (KR_WAVES * tpw), a.n_slots, a.B);
     const size_t lds = kr_lds_bytes(imax, a.w2.bits == 8);
-#define KR_W2(B_, A_) hipLaunchKernelGGL((kr_moe_w2_kernel<B_, A_>), grid, dim3(KR_BLOCK), lds, st, a, tpw)
+#define KR_W2(B_, A_) hipLaunchKernelGGL((kr_moe_w2_kernel<B_, A_>), grid, dim3(KR_BLOCK), lds, st, a.gu, a.n_slots, a.gu_ld, a.I, a.I_shared, a.topk, a, tpw)
     if (a.w2.bits == 4) {
         if (a.act_mode == KR_ACT_SILU_FUSED) KR_W2(4, KR_ACT_SILU_FUSED);
         else if (a.act_mode == KR_ACT_GPTOSS) KR_W2(4, KR_ACT_GPTOSS);
@@ -548,8 +550,8 @@ void kr_launch_multi_matvec(const KrMatDev* mats, float* const* ys, int n, const
     if (x_is_f32 == 2) {
         int tpb = 1;
         while ((total + tpb - 1) / tpb > 3072) tpb *= 2;
-        if (bits == 4) hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 4>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, mm, (const float*)x, tpb, act_mode, 2);
-        else hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 8>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, mm, (const float*)x, tpb, act_mode, 2);
+        if (bits == 4) hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 4>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, (const float*)x, mats[0].ng * 128, tpb, act_mode, 2, mm);
+        else hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 8>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, (const float*)x, mats[0].ng * 128, tpb, act_mode, 2, mm);
         return;
     }
     const int tpw = kr_pick_tpw(mats[0].K, total);
