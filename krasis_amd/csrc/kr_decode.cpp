@@ -663,7 +663,7 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             a.nh = L.nh; a.klr = L.klr; a.nd = L.nd; a.rd = L.rd; a.vhd = L.vhd; a.eps = s->eps; a.sm_scale = L.sm_scale;
             a.sc_g = s->kv_max_seq > s->mla_split_min ? (float*)s->gqa_scores.p : nullptr;
             if (s->attn_fast && a.sc_g) { a.fast = 1; a.fd_o = (float*)s->fd_o.p; a.fd_ml = (float*)s->fd_ml.p; }
-            a.decode_fast = fast ? 1 : 0;
+            a.decode_fast = fast ? 1 : 0; a.decode_fused = fast && s->opt_gqa_fused ? 1 : 0;
             PROF(PK_GQA, kr_launch_mla(a, s->kv_max_seq, st));
             bool o_done = false;
             if (fast && s->weights[L.o_wid]->cols == L.nh * L.vhd) {      // o projection straight from the f32 w_vc output: every workgroup quantises it, K split over the waves

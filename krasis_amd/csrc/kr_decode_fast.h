@@ -66,3 +66,6 @@ int kr_launch_fw2(const KrFmoeArgs& a, hipStream_t st);
 // GQA layers over a short cache (kv_max_seq <= 1024) in KR_DECODE_FAST: prep (gated split, QK-norm, RoPE, KV append) + attention of one query head per workgroup in ONE
 // launch (the exact path: kr_gqa_prep_kernel + kr_gqa_attn_kernel).  Non-zero: geometry not covered (caller takes kr_launch_gqa).
 int kr_launch_fgqa(const KrGqaArgs& a, int max_seq, hipStream_t st);
+// MLA layers over a short cache in KR_DECODE_FAST: scores + softmax + weighted sum of the latent rows of one head per workgroup with tree sums (the exact path:
+// kr_mla_attn_staged_kernel).  Non-zero: geometry not covered (caller takes the exact-order launch).
+int kr_launch_fmla(const KrMlaArgs& a, int max_seq, hipStream_t st);

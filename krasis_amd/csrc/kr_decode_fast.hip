@@ -1206,6 +1206,113 @@ __global__ void __launch_bounds__(256) kr_fgqa_kernel(const KrStep* p_step, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// MLA layers over a SHORT cache (kv_max_seq <= KR_FGQA_MAX) in the mode: scores over the latent + rope caches, softmax and the weighted sum of the latent rows of one
+// head per workgroup (decode.rs:3150-3225; the exact path: kr_mla_attn_staged_kernel with the reference's 16-lane dot order, position-ordered softmax sum and one
+// fma chain per latent element).  Same products, tree sums; the passes spread positions over lanes as kr_fgqa_kernel does: 16 lanes per position in the score
+// pass (KLR / 16 latent + RD / 16 rope elements per lane), one wave per cache row in the weighted sum.  The row of the current position was appended by the prep launch.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int KLR, int RD, bool FP8>
+__global__ void __launch_bounds__(256) kr_fmla_kernel(const KrStep* p_step, const float* p_qabs, const float* p_qpe, const void* p_ckv, const void* p_kpe, float* p_out, float p_scale) {
+    constexpr int DC = KLR / 16, DR = RD / 16, DPL = KLR / 64, SB = 2, PB = 8;
+    __shared__ __attribute__((aligned(16))) float s_sc[KR_FGQA_MAX + 64], s_part[4][KLR];
+    __shared__ float s_red[2][4];
+    const int h = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63, l16 = lane & 15, pw = lane >> 4;
+    const int pos = p_step->pos, seq = pos + 1;
+    KrKvRaw<DC, FP8> kcA[SB], kcB[SB]; KrKvRaw<DR, FP8> krA[SB], krB[SB];
+    auto issue_k = [&](KrKvRaw<DC, FP8> (&kc)[SB], KrKvRaw<DR, FP8> (&kr)[SB], int s0) {
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+            const int sp = s0 + 16 * u + wave * 4 + pw, sr = sp < seq ? sp : 0;
+            kr_kv_raw_load<DC, FP8>(kc[u], p_ckv, (size_t)sr * KLR + l16 * DC);
+            kr_kv_raw_load<DR, FP8>(kr[u], p_kpe, (size_t)sr * RD + l16 * DR);
+        }
+    };
+    float qc[DC], qr[DR];
+#pragma unroll
+    for (int i = 0; i < DC; i += 4) { const float4 v = *reinterpret_cast<const float4*>(p_qabs + (size_t)h * KLR + l16 * DC + i); qc[i] = v.x; qc[i + 1] = v.y; qc[i + 2] = v.z; qc[i + 3] = v.w; }
+#pragma unroll
+    for (int i = 0; i < DR; i += 4) { const float4 v = *reinterpret_cast<const float4*>(p_qpe + (size_t)h * RD + l16 * DR + i); qr[i] = v.x; qr[i + 1] = v.y; qr[i + 2] = v.z; qr[i + 3] = v.w; }
+    issue_k(kcA, krA, 0);
+    auto score_batch = [&](const KrKvRaw<DC, FP8> (&kc)[SB], const KrKvRaw<DR, FP8> (&kr)[SB], int s0) {
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+            const int sp = s0 + 16 * u + wave * 4 + pw;
+            float xc[DC], xr[DR];
+            kr_kv_raw_f32<DC, FP8>(kc[u], xc); kr_kv_raw_f32<DR, FP8>(kr[u], xr);
+            float acc = 0.0f, acr = 0.0f;
+#pragma unroll
+            for (int i = 0; i < DC; i++) acc = __builtin_fmaf(qc[i], xc[i], acc);
+#pragma unroll
+            for (int i = 0; i < DR; i++) acr = __builtin_fmaf(qr[i], xr[i], acr);
+            acc = kr_f_red16(acc); acr = kr_f_red16(acr);
+            if (l16 == 0 && sp < seq) s_sc[sp] = (acc + acr) * p_scale;      // latent dot + rope dot, then the scale (decode.rs:3176-3184)
+        }
+    };
+    constexpr int SSTEP = 16 * SB;
+    for (int s0 = 0; s0 < seq; s0 += 2 * SSTEP) {
+        if (s0 + SSTEP < seq) issue_k(kcB, krB, s0 + SSTEP);
+        score_batch(kcA, krA, s0);
+        if (s0 + 2 * SSTEP < seq) issue_k(kcA, krA, s0 + 2 * SSTEP);
+        if (s0 + SSTEP < seq) score_batch(kcB, krB, s0 + SSTEP);
+    }
+    KrKvRaw<DPL, FP8> vqA[PB], vqB[PB];
+    auto issue_v = [&](KrKvRaw<DPL, FP8> (&vq)[PB], int s0) {
+#pragma unroll
+        for (int u = 0; u < PB; u++) { const int sp = s0 + 4 * u + wave; kr_kv_raw_load<DPL, FP8>(vq[u], p_ckv, (size_t)(sp < seq ? sp : 0) * KLR + lane * DPL); }
+    };
+    issue_v(vqA, 0);
+    __syncthreads();
+    float mx = -__builtin_inff();
+    for (int sp = t; sp < seq; sp += 256) mx = fmaxf(mx, s_sc[sp]);
+    mx = kr_f_wave_max(mx);
+    if (lane == 0) s_red[0][wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+    float se = 0.0f;
+    for (int sp = t; sp < seq; sp += 256) { const float e = kr_expf(s_sc[sp] - mx); s_sc[sp] = e; se += e; }
+    se = kr_f_wave_sum(se);
+    if (lane == 0) s_red[1][wave] = se;
+    __syncthreads();
+    const float inv = 1.0f / ((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
+    for (int sp = t; sp < seq; sp += 256) s_sc[sp] *= inv;
+    __syncthreads();
+    float o[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; i++) o[i] = 0.0f;
+    auto pv_batch = [&](const KrKvRaw<DPL, FP8> (&vq)[PB], int s0) {
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            const int sp = s0 + 4 * u + wave;
+            float vx[DPL];
+            kr_kv_raw_f32<DPL, FP8>(vq[u], vx);
+            const float pr = sp < seq ? s_sc[sp] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < DPL; i++) o[i] = __builtin_fmaf(pr, vx[i], o[i]);
+        }
+    };
+    constexpr int PSTEP = 4 * PB;
+    for (int s0 = 0; s0 < seq; s0 += 2 * PSTEP) {
+        if (s0 + PSTEP < seq) issue_v(vqB, s0 + PSTEP);
+        pv_batch(vqA, s0);
+        if (s0 + 2 * PSTEP < seq) issue_v(vqA, s0 + 2 * PSTEP);
+        if (s0 + PSTEP < seq) pv_batch(vqB, s0 + PSTEP);
+    }
+#pragma unroll
+    for (int i = 0; i < DPL; i++) s_part[wave][lane * DPL + i] = o[i];
+    __syncthreads();
+    for (int j = t; j < KLR; j += 256) p_out[(size_t)h * KLR + j] = (s_part[0][j] + s_part[1][j]) + (s_part[2][j] + s_part[3][j]);
+}
+
+int kr_launch_fmla(const KrMlaArgs& a, int max_seq, hipStream_t st) {
+    if (!a.step || max_seq > KR_FGQA_MAX || a.sc_g || a.rd != 64 || (a.klr != 512 && a.klr != 256)) return 1;
+#define KR_FMLA(K_, F_) hipLaunchKernelGGL((kr_fmla_kernel<K_, 64, F_>), dim3(a.nh), dim3(256), 0, st, a.step, (const float*)a.q_abs, (const float*)a.q_pe, (const void*)a.ckv_cache, (const void*)a.kpe_cache, a.attn_lat, a.sm_scale)
+    if (a.klr == 512) { if (a.kv_fp8) KR_FMLA(512, true); else KR_FMLA(512, false); }
+    else { if (a.kv_fp8) KR_FMLA(256, true); else KR_FMLA(256, false); }
+#undef KR_FMLA
+    return 0;
+}
+
 int kr_launch_fgqa(const KrGqaArgs& a, int max_seq, hipStream_t st) {
     if (max_seq > KR_FGQA_MAX || a.sc_g || a.nh % a.nkv || 2 * a.rope_half > a.hd || (a.img_out && a.hd % 128)) return 1;
 #define KR_FGQA(H_, F_) hipLaunchKernelGGL((kr_fgqa_kernel<H_, F_>), dim3(a.nh), dim3(256), 0, st, a.step, a.q_in, a.k_in, a.v_in, (const void*)a.k_cache, (const void*)a.v_cache, a.nh, a.nkv, a)

@@ -53,6 +53,7 @@ struct KrMlaArgs {   // decode.rs:2993-3252
     // per-token buffers starts at t * ld_* floats (kv_out, q_full) or t * their natural size (q_abs, q_pe, attn_lat, v_proj)
     int pos0; int ld_kv, ld_q;
     int decode_fast;   // KR_DECODE_FAST (decode, step != nullptr): the absorption, the latent RMSNorm and the w_vc projection as tree sums (same products)
+    int decode_fused;  // ... and, over a short cache, the attention launch itself as kr_fmla_kernel (kr_decode_set_option "gqa_fused" 0 keeps the exact-order launch)
     int absorb_done;   // prompt pass: q_abs of the chunk was produced by kr_launch_mla_absorb_mfma -- the prep launch skips its absorption loop
     float* pf_sc; int pf_sc_ld;   // prompt pass, exact mode: score scratch [n_tok * nh][pf_sc_ld] + n_tok * nh * (1 + pf_sc_ld / 32) floats (1 / sum, row maxima) for the matrix-core passes; null: per-token launches
 };

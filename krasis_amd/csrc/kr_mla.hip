@@ -14,6 +14,7 @@
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_decode_ops.h"
+#include "kr_decode_fast.h"
 #include "kr_prefill_ops.h"
 #include "kr_attn_fd.h"
 #include <hip/hip_fp16.h>
@@ -795,6 +796,8 @@ void kr_launch_mla(const KrMlaArgs& a_in, int max_seq, hipStream_t s, int n_tok)
         KrPfmGqaArgs g{};
         g.v_cache = a.ckv_cache; g.kv_fp8 = a.kv_fp8; g.nh = a.nh; g.nkv = 1; g.hd = a.klr; g.pos0 = a.pos0; g.gated = 0; g.attn_out = a.attn_lat;
         kr_launch_pfm_gqa_pv_mfma(g, n_tok, a.pf_sc, a.pf_sc_ld, inv, s);
+    } else if (dfast && s && a.decode_fused && kr_launch_fmla(a, max_seq, s) == 0) {
+        // KR_DECODE_FAST over a short cache: tree-sum scores / softmax / weighted sum (kr_decode_fast.hip)
     } else if (!kr_mla_staged(a, max_seq, s, n_tok)) {      // other geometries: the generic kernel
         if (a.kv_fp8) hipLaunchKernelGGL(kr_mla_attn_kernel<true>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);
         else hipLaunchKernelGGL(kr_mla_attn_kernel<false>, dim3(a.nh, n_tok), dim3(512), (size_t)(a.klr + a.rd + max_seq + 8) * 4, s, a);

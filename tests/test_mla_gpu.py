@@ -307,3 +307,43 @@ def test_mla_native_gguf_decode_at_v2lite_widths(graph, fast):
             assert np.array_equal(logits.view(np.uint32), ref.view(np.uint32)), (step, float(np.max(np.abs(logits - ref))))
             assert st.last_token() == O.sample_greedy(ref)
         tok = O.sample_greedy(ref)
+
+
+@pytest.mark.parametrize("klr,fp8", [(512, False), (256, False), (512, True), (256, True)])
+def test_mla_tolerance_attention_short_cache(klr, fp8):
+    """KR_DECODE_FAST, MLA over a short cache (kv_max_seq <= 1024): scores + softmax + weighted sum of the latent rows as ONE tree-sum launch per head
+    (kr_fmla_kernel: 16 lanes per position, one wave per cache row, request batches of 32 positions) instead of the exact-order staged launch.  Positions on both
+    sides of the batch boundaries up to the end of a 200-position cache, FP16 and E4M3 latent caches, kv_lora 512 / 256: logits within the mode's bound of the
+    oracle driver (2e-3 with FP16 caches, 5e-3 with E4M3: docs/design/11), same greedy token, and within the same bound of the mode's exact-order attention launch
+    (kr_decode_set_option "gqa_fused" 0) on the same steps."""
+    outs = {}
+    try:
+        for fused in (1, 0):
+            st, eng, orc, keep, d = build(seed=7, klr=klr, nh=4, kv_max=200)
+            nL = d["nL"]
+            if fp8:
+                st.set_kv_dtype(True); O.set_kv_fp8(True)
+                rng = np.random.default_rng(9)
+                ck = [O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["klr"])) * 0.5).astype(F)) for _ in range(nL)]
+                kp = [O.f32_to_e4m3((rng.standard_normal((d["kv_max"], d["rd"])) * 0.5).astype(F)) for _ in range(nL)]
+                for li in range(nL):
+                    orc.layers[li]["ckv"] = ck[li].astype(np.uint16); orc.layers[li]["kpe"] = kp[li].astype(np.uint16)
+                st.set_decode_state(5, d["kv_max"], [0] * nL, [0] * nL, [0] * nL, [0] * nL, [_ptr(x) for x in ck], [_ptr(x) for x in kp])
+                keep += ck + kp
+            st.set_attention_mode(False, decode_fast=True)
+            st.set_option("gqa_fused", fused)
+            bound = 5e-3 if fp8 else 2e-3
+            tok = 9; lg = []
+            for pos in [0, 1, 15, 16, 31, 32, 33, 63, 64, 65, 127, 128, 199]:
+                logits = np.empty(d["V"], F)
+                st.decode_step(tok, pos, logits.ctypes.data)
+                ref = orc.step(tok, pos)
+                err = float(np.abs(logits - ref).max() / np.abs(ref).max())
+                assert np.isfinite(logits).all() and err <= bound, (fused, pos, err)
+                assert int(np.argmax(logits)) == O.sample_greedy(ref), (fused, pos)
+                tok = O.sample_greedy(ref); lg.append(logits)
+            outs[fused] = lg
+        for a, b in zip(outs[1], outs[0]):
+            assert float(np.abs(a - b).max() / np.abs(b).max()) <= (5e-3 if fp8 else 2e-3)
+    finally:
+        O.set_kv_fp8(False)

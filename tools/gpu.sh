@@ -200,7 +200,9 @@ r5final)    # round 5 closing run: GPU suite as the driver runs it; PMC fetch pa
     kstats r05_decode_exact "QCN Q4 decode step, exact mode, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only exact --steps 30)" -- \
         python /root/repo/tools/probes/decode_fast_bench.py --only exact --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r05_decode_exact_prof
     kstats r05_prefill_8192_attn_fast_gemm_fast "QCN prompt pass, KR_ATTN_FAST | KR_GEMM_FAST, 8192 tokens (tools/probes/prefill_profile.py 8192 2)" -- python /root/repo/tools/probes/prefill_profile.py 8192 2 > /dev/null
+    [ -f krasis_amd/libkrasis_hip_timing.so ] || make -C krasis_amd/csrc timing > $R/make_timing.log 2>&1      # the stamp build is not shipped: built on the box
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so LAYERS=47 STAMPS_OUT=$R/r05_decode_fast_stamps.txt timeout 250 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
+    KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so LAYERS=47 WG_OUT=$R/r05_decode_fast_wg_times.txt timeout 250 python tools/probes/decode_fast_wg_times.py 2>&1 | tail -7
     rm -rf $R/prof_* $R/pmc_* $R/*.log
     ;;
 r5t)        # round 5: a list of test files + the decode probe in both modes
