@@ -244,8 +244,8 @@ __global__ void __launch_bounds__(256) kr_mla_scores_mfma_kernel(const float* __
     const int lnh = __builtin_ctz(nh);                                        // nh divides 32: a power of two
     const int p_lo = blockIdx.x * 64, p_max = pos0 + ((row0 + R - 1) >> lnh);  // last position any row of the tile may see
     if (p_lo > p_max) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r31 = lane & 31, kh = lane >> 5;
-    const int rb = (wave >> 1) * 32, pb = (wave & 1) * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r31 = lane & 31, kh = lane >> 5;
+    const int rb = (wave >> 1) * 32, pb = (wave & 1) * 32;                    // scalars: as lane values they were spilled across the 256-register epilogue (ROPE form)
     constexpr int ESZ = FP8 ? 1 : 2, KCH = FP8 ? 1 : 2;                       // 16-byte cache chunks per thread per 64-k stage
     // staging maps of a 64-k stage: q 64 rows x 64 floats (4 float4 per thread), cache 64 positions x 64 values (rows past p_max re-read p_max)
     int qrow[4], qc4[4];
@@ -312,10 +312,14 @@ __global__ void __launch_bounds__(256) kr_mla_scores_mfma_kernel(const float* __
             for (int j = 0; j < 16; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[j], 0, 0, 0);
         }
     }
-    const int pos = p_lo + pb + r31;
+    // the lane id is formed again here (v_mbcnt needs no live register): kept across the k loop, the lane half was the one value the 256-register tree spilled
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int r31e = lane_e & 31, khe = lane_e >> 5;
+    const int pos = p_lo + pb + r31e;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const int r = rb + (i & 3) + 8 * (i >> 2) + 4 * kh;
+        const int r = rb + (i & 3) + 8 * (i >> 2) + 4 * khe;
         const float c0 = (acc[0][i] + acc[8][i]) + (acc[4][i] + acc[12][i]);
         const float c1 = (acc[1][i] + acc[9][i]) + (acc[5][i] + acc[13][i]);
         const float c2 = (acc[2][i] + acc[10][i]) + (acc[6][i] + acc[14][i]);
@@ -330,7 +334,7 @@ __global__ void __launch_bounds__(256) kr_mla_scores_mfma_kernel(const float* __
         if (!ROPE && tmax) {
             mv = kr_red16_max_f32(mv);                            // 4 DPP steps inside each 16-lane row, then one exchange between the two rows of the lane half
             mv = fmaxf(mv, __shfl_xor(mv, 16));
-            if (r31 == 0 && r < R) tmax[rowi * (size_t)(sc_ld >> 5) + ((p_lo + pb) >> 5)] = mv;
+            if (r31e == 0 && r < R) tmax[rowi * (size_t)(sc_ld >> 5) + ((p_lo + pb) >> 5)] = mv;
         }
     }
 }

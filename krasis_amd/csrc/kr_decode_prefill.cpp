@@ -21,7 +21,7 @@
 #include "kr_prefill_ops.h"
 #include "kr_router.h"
 
-#define KR_PFM_CHUNK 1024     // tokens per chunk; with KR_PFM_DEPTH chunks in flight (sweep in tools/dbg/sweep_depth.sh: 1024 x 3 beats 2048 x 2 at 4k / 8k / 20k prompts)
+#define KR_PFM_CHUNK 1024     // tokens per chunk; with KR_PFM_DEPTH chunks in flight (round-1 sweep, docs/design/08-measurement.md: 1024 x 3 beats 2048 x 2 at 4k / 8k / 20k prompts)
 #define KR_PFM_DEPTH 3
 
 namespace {

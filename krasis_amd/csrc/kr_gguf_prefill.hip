@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256, 2) kr_gpf_gemm_kernel(const GpfGemmArgs a
     const char* wh = reinterpret_cast<const char*>(m.h) + (size_t)expert * m.h_stride;
     const char* wws = a.ws + (size_t)expert * a.ws_stride;
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     if (tid < GPF_BM) {
         int src = -1;
         if (tid < rows) {
@@ -200,7 +200,9 @@ __global__ void __launch_bounds__(256, 2) kr_gpf_gemm_kernel(const GpfGemmArgs a
             }
             const int src = row_src[ar];
             pasc = make_float2(0.0f, 0.0f); pasm = make_float2(0.0f, 0.0f);
-            const int sb0 = st * 8 + aq * 2;
+            int aqv = aq;
+            asm volatile("" : "+v"(aqv));      // keeps the widened per-lane offset out of the loop-invariant set (the Q8_0 form spilled it: 256 registers, two workgroups per CU)
+            const int sb0 = st * 8 + aqv * 2;
             if (src >= 0 && sb0 < nsub) {      // nsub is even for every supported K (K % 64 == 0 is checked on the host)
                 pasc = *reinterpret_cast<const float2*>(a.a_scale + (size_t)src * nsub + sb0);
                 pasm = *reinterpret_cast<const float2*>(a.a_sum + (size_t)src * nsub + sb0);
@@ -326,13 +328,15 @@ __global__ void __launch_bounds__(256, 2) kr_gpf_gemm_kernel(const GpfGemmArgs a
         }
         __syncthreads();
     }
-    const int col = n0 + cw;
+    int lane_e;      // the lane id again (v_mbcnt needs no live register): column and lane half of the store phase are not carried across the k loop
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int col = n0 + wave * 32 + (lane_e & 31), khalf_e = lane_e >> 5;
     if (col < m.N) {
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int row = s * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf_e;
                 if (row < rows) a.out[(size_t)(row0 + row) * a.out_ld + a.col_off + col] = Q4K ? outv[s][r] - corr[s][r] : outv[s][r];
             }
     }

@@ -621,7 +621,9 @@ __global__ void __launch_bounds__(NBC * 8 / KR_MPV_EPT + 256) kr_mla_pv_kernel(K
         if (t == 0) { se = kr_seq_sum(tile, n32, se); red[15] = se; }
         __syncthreads();
     }
-    const float inv = 1.0f / red[15];
+    // workgroup-uniform: kept in a scalar register (as a lane value it was the one register the <64, FP16> form spilled at 3 waves per SIMD)
+    float inv;
+    { const float inv_lane = 1.0f / red[15]; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(inv) : "v"(inv_lane)); }
     if (t < KR_MPV_ROWS) pw[0][t] = t < seq ? row[t] * inv : 0.0f;                      // sc[s] *= inv, stage 0
     __syncthreads();
     // ---- weighted sum

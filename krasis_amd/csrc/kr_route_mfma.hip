@@ -32,7 +32,7 @@ typedef uint32_t rm_u4 __attribute__((ext_vector_type(4)));
 // j = {0,1,4,5,8,9,12,13} + 2 c, i.e. the sub-trees (c0 + c1) or (c2 + c3) of the fold; the halves meet through LDS and the last add is the
 // tree's root -- the same 15 adds in the same order.  Twice the workgroups, half the accumulators (two waves per SIMD).
 template <bool GATE_BF16, bool SPLIT>
-__global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* __restrict__ gate_row_, const float* __restrict__ x_, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256, SPLIT ? 2 : 1) kr_route_logits_mfma_kernel(const void* __restrict__ gate_row_, const float* __restrict__ x_, const float* __restrict__ bias,
                                                                    float* __restrict__ logits_, int T, int E, int H, int ldx, int ldo, size_t x_bs, size_t g_bs, size_t o_bs) {
     const float* x = x_ + (size_t)blockIdx.z * x_bs; float* logits = logits_ + (size_t)blockIdx.z * o_bs;
     const void* gate_row = GATE_BF16 ? (const void*)(reinterpret_cast<const uint16_t*>(gate_row_) + (size_t)blockIdx.z * g_bs)
@@ -89,6 +89,9 @@ __global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* _
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[j][i] = 0.0f;
     const int nst = H / RM_KS;
+    // the bias is fetched here: a conditional load between the k loop and the tree made the compiler copy all 256 accumulators out in front of it (one spill)
+    const int e = e0 + eb + r;
+    const float bv = (bias && e < E) ? bias[e] : 0.0f;
     load_stage(0);
     commit_stage(0);
     __syncthreads();
@@ -138,8 +141,6 @@ __global__ void __launch_bounds__(256) kr_route_logits_mfma_kernel(const void* _
         __syncthreads();
     }
     // ---- the reference's tree over the 16 chains (decode.rs:1419-1427), then + bias (decode.rs:3292)
-    const int e = e0 + eb + r;
-    const float bv = (bias && e < E) ? bias[e] : 0.0f;
     if (SPLIT) {
         // local chains l = 2 q + i <-> chain 4 q + 2 ch + i: (l0 + l4) + (l2 + l6) is (a0 + a8) + (a4 + a12) for half 0 and (a2 + a10) + (a6 + a14) for half 1
         float* xch = reinterpret_cast<float*>(smem) + ((wave & 1) * 64 + lane) * 16;      // the stage buffers are free after the last barrier

@@ -52,3 +52,39 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "krasis_oracle" not in txt, f
+
+
+def test_no_kernel_of_the_library_has_a_scratch_segment(lib, tmp_path):
+    """Every gfx950 kernel in libkrasis_hip.so keeps its working set in registers: private_segment_fixed_size == 0 in
+    the code objects' metadata (a kernel with a scratch segment runs with a fraction of the waves; VERDICT r4 counted
+    six instantiations with 8 - 20 B)."""
+    from krasis_amd import _lib
+    import struct
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objcopy, readelf = os.path.join(llvm, "llvm-objcopy"), os.path.join(llvm, "llvm-readelf")
+    if not (os.path.exists(objcopy) and os.path.exists(readelf)):
+        pytest.skip("llvm-objcopy / llvm-readelf not in this image")
+    fat = tmp_path / "fatbin"
+    subprocess.check_call([objcopy, f"--dump-section=.hip_fatbin={fat}", _lib.lib_path(), str(tmp_path / "copy.so")])
+    blob = fat.read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    objs = []
+    for m in re.finditer(magic, blob):          # one bundle per translation unit: u64 entry count, then (offset, size, triple size, triple)
+        p = m.start() + len(magic)
+        (count,) = struct.unpack_from("<Q", blob, p)
+        p += 8
+        for _ in range(count):
+            off, size, tsz = struct.unpack_from("<QQQ", blob, p)
+            p += 24
+            triple = blob[p:p + tsz].decode()
+            p += tsz
+            if "gfx950" in triple and size:
+                path = tmp_path / f"co_{len(objs)}.o"
+                path.write_bytes(blob[m.start() + off:m.start() + off + size])
+                objs.append(str(path))
+    assert len(objs) >= 10, "code objects not found in .hip_fatbin"
+    notes = subprocess.check_output([readelf, "--notes"] + objs, text=True)
+    kernels = re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", notes)
+    assert len(kernels) > 500, f"only {len(kernels)} kernels parsed from the metadata"
+    spilling = [(n, int(b)) for n, b in kernels if int(b)]
+    assert not spilling, f"kernels with a scratch segment: {spilling}"
