@@ -875,10 +875,27 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
         }
     }
     const bool lm_img = false;   // the vocabulary projection is wide enough that per-wave tiles beat the cooperative form (measured)
-    PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st,
-                                                 lm_img ? s->img_in.p : nullptr));
-    if (lm_img) PROF(PK_LM_HEAD, kr_launch_matvec(mv(s, s->lm_head), s->img_in.p, 2, (float*)s->logits.p, st));
-    else PROF(PK_LM_HEAD, kr_launch_matvec(mv(s, s->lm_head), hid, 1, (float*)s->logits.p, st));
+    bool lm_done = false;
+    if (fast && s->opt_lm_fused && src.mode == 0 && !first) {
+        // KR_DECODE_FAST: final norm + vocabulary projection as ONE launch of the projection kernel (the norm folded into every workgroup, tree sums) --
+        // one launch and one boundary less per token
+        const KrMatDev lm = mv(s, s->lm_head);
+        if (lm.bits == 4 || lm.bits == 8) {
+            KrFdmArgs fl{};
+            fl.mode = 1; fl.hid_in = hid; fl.res_in = res_cur; fl.res_out = other(res_cur); fl.norm_w = (const float*)s->norms[s->final_norm]->p;
+            fl.eps = s->eps; fl.bias_one = s->norm_bias_one;
+            fl.mm.n = 1; fl.mm.m[0] = lm; fl.mm.y[0] = (float*)s->logits.p; fl.mm.tile_end[0] = (lm.N + 7) / 8;
+            prof_mark(s, PK_LM_HEAD, st);
+            lm_done = 0 == kr_launch_fdm(fl, st);
+            prof_mark(s, -1, st);
+        }
+    }
+    if (!lm_done) {
+        PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res, (const float*)s->norms[s->final_norm]->p, H, s->eps, first ? 1 : 0, s->norm_bias_one, st,
+                                                     lm_img ? s->img_in.p : nullptr));
+        if (lm_img) PROF(PK_LM_HEAD, kr_launch_matvec(mv(s, s->lm_head), s->img_in.p, 2, (float*)s->logits.p, st));
+        else PROF(PK_LM_HEAD, kr_launch_matvec(mv(s, s->lm_head), hid, 1, (float*)s->logits.p, st));
+    }
     PROF(PK_ARGMAX, kr_launch_argmax((const float*)s->logits.p, s->vocab, (int*)s->tok.p, (float*)s->argmax_scratch.p, st));
     KR_HIP(hipGetLastError());
     return KR_OK;
@@ -967,6 +984,7 @@ extern "C" int kr_decode_set_option(kr_decode_store* s, const char* name, int va
     if (int rc = chk_store(s)) return rc;
     if (!name) return kr_fail(KR_ERR_VALUE, "null option name");
     if (!strcmp(name, "gqa_stream")) { s->opt_gqa_stream = value != 0; s->graph_ok = false; return KR_OK; }
+    if (!strcmp(name, "lm_fused")) { s->opt_lm_fused = value != 0; s->graph_ok = false; return KR_OK; }        // KR_DECODE_FAST: 0 = final norm and vocabulary projection as two launches (A/B and test hook)
     if (!strcmp(name, "gqa_fused")) { s->opt_gqa_fused = value != 0; s->graph_ok = false; return KR_OK; }      // KR_DECODE_FAST, short caches: 0 = prep + attention as two launches (A/B and test hook)
     if (!strcmp(name, "pfm_timing")) { s->opt_pfm_timing = value != 0; return KR_OK; }
     if (!strcmp(name, "generate_lookahead")) { s->opt_gen_lookahead = value != 0; return KR_OK; }

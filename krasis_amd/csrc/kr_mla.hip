@@ -623,7 +623,9 @@ __global__ void __launch_bounds__(NBC * 8 / KR_MPV_EPT + 256) kr_mla_pv_kernel(K
     }
     // workgroup-uniform: kept in a scalar register (as a lane value it was the one register the <64, FP16> form spilled at 3 waves per SIMD)
     float inv;
-    { const float inv_lane = 1.0f / red[15]; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(inv) : "v"(inv_lane)); }
+    // (the s_nop pair: gfx950 wants one wait state between a VALU write of a VGPR and a lane read of it, two between a VALU write of an SGPR and a VALU
+    //  read -- the compiler's hazard pass does not look inside an asm statement)
+    { const float inv_lane = 1.0f / red[15]; asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(inv) : "v"(inv_lane)); }
     if (t < KR_MPV_ROWS) pw[0][t] = t < seq ? row[t] * inv : 0.0f;                      // sc[s] *= inv, stage 0
     __syncthreads();
     // ---- weighted sum

@@ -254,3 +254,21 @@ def test_fast_gqa_one_launch_vs_two_launches(fp8):
     for a, b in zip(outs[1], outs[0]):
         assert float(np.abs(a - b).max() / np.abs(b).max()) <= bound
         assert int(np.argmax(a)) == int(np.argmax(b))
+
+
+def test_fast_final_norm_and_lm_head_one_launch_vs_two():
+    """KR_DECODE_FAST ends the step with ONE launch (final add + RMSNorm folded into the vocabulary projection, tree sums) instead of the exact-order
+    norm launch + the exact-order vocabulary matvec: logits within 1e-4 of the two-launch form (another order of the same products), same greedy tokens"""
+    outs = {}
+    for fused in (1, 0):
+        st, eng, orc, keep, d = build(seed=11, kinds=["la", "gqa"])
+        st.set_attention_mode(False, decode_fast=True)
+        st.set_option("lm_fused", fused)
+        lg = []
+        for i, pos in enumerate([0, 1, 2, 17, 31]):
+            out = np.empty(d["V"], F); st.decode_step(5 + 3 * i, pos, out.ctypes.data); lg.append(out)
+        outs[fused] = lg
+    for a, b in zip(outs[1], outs[0]):
+        assert np.isfinite(a).all()
+        assert float(np.abs(a - b).max() / np.abs(b).max()) <= 1e-4
+        assert int(np.argmax(a)) == int(np.argmax(b))

@@ -209,6 +209,12 @@ r5t)        # round 5: a list of test files + the decode probe in both modes
     timeout 1200 python -m pytest "$@" -q -x > $R/r05_tests.txt 2>&1; grep -E " passed| failed|rror" $R/r05_tests.txt | tail -4
     timeout 300 python tools/probes/decode_fast_bench.py --route-tokens 0 --out gpurun_out/r05_df 2>&1 | grep -E "^fast|^exact|logits"
     ;;
+r5u)        # round 5: whole GPU suite, then the decode probe with the one-launch final norm + vocabulary projection on / off (interleaved)
+    timeout 2400 python -m pytest tests/ -x -q -m gpu > $R/r05_gpu_tests_full.txt 2>&1; grep -E " passed| failed|rror" $R/r05_gpu_tests_full.txt | tail -4 | tee $R/r05_gpu_tests_summary.txt
+    for rep in 1 2; do for v in 1 0; do
+        echo "lm_fused=$v"; timeout 300 python tools/probes/decode_fast_bench.py --only fast --route-tokens 0 --opt lm_fused=$v --out gpurun_out/r05_lm$v 2>&1 | grep -E "^fast|lm_head|rmsnorm"
+    done; done
+    ;;
 tests)      # the whole GPU suite, as the driver runs it
     timeout 2400 python -m pytest tests/ -x -q -m gpu "$@" 2>&1 | tail -15
     ;;

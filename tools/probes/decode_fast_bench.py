@@ -24,11 +24,14 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--bits", type=int, default=4)
     ap.add_argument("--out", default="gpurun_out/r03_decode_fast_bench")
+    ap.add_argument("--opt", action="append", default=[], help="name=value for kr_decode_set_option (A/B hooks), e.g. --opt lm_fused=0")
     args = ap.parse_args()
     import torch
     q = bench.QCN; kvm = q["kv_max_seq"]; L = args.layers
     eng, st, keep = bench.build_qcn(0, 0, L, 0, args.bits, kv_fp8=True)
     res = {"layers": L, "steps": args.steps, "bits": args.bits}
+    for o in args.opt:
+        name, val = o.split("="); st.set_option(name, int(val)); res.setdefault("options", {})[name] = int(val)
     lines = []
     modes = [m for m in ("exact", "fast") if not args.only or args.only == m]
     logits = {}
