@@ -580,10 +580,21 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             prof_mark(s, -1, st);
             out_proj(L.out_wid);
         } else if (L.attn == ATTN_LA) {
+            bool la_heads = false;      // exact step: conv + gates ran as the in-projection's epilogue, the recurrence runs one workgroup per value head
             if (!did_in) {
                 const KrMatDev mats[2] = {mv(s, L.qkvz_wid), mv(s, L.ba_wid)};
                 float* ys[2] = {(float*)s->proj_a.p, (float*)s->proj_b.p};
-                if (mats[0].bits == mats[1].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 2, xin, xin_kind, st));
+                if (s->opt_la_heads && s->fuse_la && xin_kind == 2 && mats[0].bits == mats[1].bits && s->f_qk.p && L.kd == 4 && L.nv == L.nk * (L.nv / L.nk) &&
+                    (L.dk == 128 || L.dk == 64) && (L.dv == 128 || L.dv == 64)) {
+                    KrCoLa la{};
+                    la.conv_state = (float*)L.conv_state.p; la.conv_w = (const float*)L.conv_w.p; la.qk_out = (float*)s->f_qk.p; la.v_out = (float*)s->vbuf.p; la.z_out = (float*)s->zbuf.p;
+                    la.nk = L.nk; la.dk = L.dk; la.hr = L.nv / L.nk; la.dv = L.dv; la.conv_mi = 0;
+                    prof_mark(s, PK_MATVEC, st);
+                    la_heads = 0 == kr_launch_multi_matvec_la(mats, ys, 2, xin, la, st);
+                    prof_mark(s, -1, st);
+                }
+                if (la_heads) {}
+                else if (mats[0].bits == mats[1].bits) PROF(PK_MATVEC, kr_launch_multi_matvec(mats, ys, 2, xin, xin_kind, st));
                 else { PROF(PK_MATVEC, kr_launch_matvec(mats[0], hid, 1, ys[0], st)); PROF(PK_MATVEC, kr_launch_matvec(mats[1], hid, 1, ys[1], st)); }
             }
             KrLaArgs a{};
@@ -594,7 +605,13 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             void* la_img = (img_ok && img_w(L.out_wid) && L.dv == 128) ? s->img_attn.p : nullptr;
             const int nt_la = a.hr * L.dv;
             const bool la_fused = s->fuse_la && nt_la <= 256 && nt_la % 64 == 0 && (L.dv == 128 || L.dv == 64) && L.nv == L.nk * a.hr && (L.dk == 128 || L.dk == 64);
-            if (la_fused) {
+            if (la_heads) {
+                a.q = (float*)s->f_qk.p;      // [nk][2 dk] conv + SiLU outputs of q | k (normalised inside the launch)
+                prof_mark(s, PK_LA_RECUR, st);
+                if (kr_launch_la_step_heads(a, (float*)L.recur_state.p, (const float*)L.la_norm_w.p, (float*)s->attn_out.p, s->eps, st, la_img))
+                    return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
+                prof_mark(s, -1, st);
+            } else if (la_fused) {
                 prof_mark(s, PK_LA_RECUR, st);
                 (void)kr_launch_la_step(a, (float*)L.recur_state.p, (const float*)L.la_norm_w.p, (float*)s->attn_out.p, s->eps, st, la_img);
                 prof_mark(s, -1, st);
@@ -984,6 +1001,7 @@ extern "C" int kr_decode_set_option(kr_decode_store* s, const char* name, int va
     if (int rc = chk_store(s)) return rc;
     if (!name) return kr_fail(KR_ERR_VALUE, "null option name");
     if (!strcmp(name, "gqa_stream")) { s->opt_gqa_stream = value != 0; s->graph_ok = false; return KR_OK; }
+    if (!strcmp(name, "la_heads")) { s->opt_la_heads = value != 0; s->graph_ok = false; return KR_OK; }        // exact step, linear-attention layers: 0 = in-projection + the one-launch conv / recurrence per KEY head (A/B and test hook)
     if (!strcmp(name, "lm_fused")) { s->opt_lm_fused = value != 0; s->graph_ok = false; return KR_OK; }        // KR_DECODE_FAST: 0 = final norm and vocabulary projection as two launches (A/B and test hook)
     if (!strcmp(name, "gqa_fused")) { s->opt_gqa_fused = value != 0; s->graph_ok = false; return KR_OK; }      // KR_DECODE_FAST, short caches: 0 = prep + attention as two launches (A/B and test hook)
     if (!strcmp(name, "pfm_timing")) { s->opt_pfm_timing = value != 0; return KR_OK; }

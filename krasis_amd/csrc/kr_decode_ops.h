@@ -76,6 +76,7 @@ void kr_launch_la_conv(const KrLaArgs& a, hipStream_t s);
 int kr_launch_la_recurrent_gnorm(float* state, const float* q, const float* k, const float* v, const float* g, const float* beta, const float* z,
                                  const float* w, float* out, int nv, int dk, int dv, float eps, hipStream_t s, void* img_out = nullptr);
 int kr_launch_la_step(const KrLaArgs& a, float* state, const float* w, float* out, float eps, hipStream_t s, void* img_out = nullptr);
+int kr_launch_la_step_heads(const KrLaArgs& a, float* state, const float* w, float* out, float eps, hipStream_t s, void* img_out = nullptr);
 void kr_launch_gated_rmsnorm_silu(const float* recur, const float* z, const float* w, float* out, int nv, int dv, float eps, hipStream_t s);
 void kr_launch_gqa(const KrGqaArgs& a, int max_seq, hipStream_t s);   // a.sc_g != nullptr: prep, scores (many workgroups), softmax + p.v
 void kr_launch_moe_combine_decode(const float* eo, const int32_t* ids, const float* wts, int topk, int has_shared, const float* gate_val,

@@ -282,33 +282,58 @@ __global__ void __launch_bounds__(256) kr_la_recurrent_gnorm_kernel(float* __res
 // heads) are read and shifted by this workgroup only, so the in-place conv-state update needs no cross-workgroup ordering.
 // The thread's whole state column (DK values) is requested before anything else and stays in registers for both passes: the
 // conv / gate / norm work runs under that one memory latency, and the second pass re-reads nothing (k / q are broadcast LDS reads).
-template <int DK, int DV>
+// CONV = false (the in-projection launch already ran the conv and the gates: kr_matvec_coop_kernel<.., LA = true>): one workgroup per VALUE head, dv threads -- twice
+// (hr times) the CUs pull the state, which is what bounds this launch (64 KB per value head through one CU's ~20 - 35 GB/s).  a.q = the key heads' conv + SiLU outputs
+// [nk][2 DK] (q | k, not yet normalised), a.v / a.z [nv][dv], a.ba = the raw in_proj_ba rows.  The head's vectors are requested BEFORE the state column: a wave's memory
+// counter is in-order.
+template <int DK, int DV, bool CONV = true>
 __global__ void __launch_bounds__(256) kr_la_step_kernel(const KrLaArgs a, float* __restrict__ state, const float* __restrict__ w, float* __restrict__ out,
                                                         float eps, void* img_out, int img_k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int dv = DV;       // compile-time row pitch: the column's 2 * DK loads / stores use immediate offsets from a few bases
-    const int kh = blockIdx.x, hr = a.hr, t = threadIdx.x, nt = hr * dv;
+    const int hr = CONV ? a.hr : 1, t = threadIdx.x, nt = hr * dv;      // hr: value heads of THIS workgroup
+    const int kh = CONV ? blockIdx.x : blockIdx.x / a.hr, vh0 = CONV ? kh * hr : blockIdx.x;
     float* qc = sm; float* kc = qc + DK; float* vs = kc + DK; float* rr = vs + nt;
     float* nrm = rr + nt; float* ge = nrm + 2; float* bt = ge + hr; float* rms = bt + hr;
-    const int r = t / dv, j = t - r * dv, vh = kh * hr + r;
-    // buffer addressing: descriptor = this key head's hr state slices (workgroup-uniform), voffset = the thread's column, rows by
+    const int r = t / dv, j = t - r * dv, vh = vh0 + r;
+    // buffer addressing: descriptor = this workgroup's hr state slices (workgroup-uniform), voffset = the thread's column, rows by
     // immediate offset (8 rows of DV floats per 4 KiB window) + a scalar window offset -- no per-row address registers
-    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(state + (size_t)kh * hr * DK * dv, 0, hr * DK * dv * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(state + (size_t)vh0 * DK * dv, 0, hr * DK * dv * 4, 0x00020000);
     const int voff = (r * DK * dv + j) * 4;
     constexpr int RW = 4096 / (dv * 4);     // rows per immediate-offset window
+    const size_t o = (size_t)vh * dv + j;
+    float zz = 0.0f, wn = 0.0f, pq = 0.0f, pk = 0.0f, pv = 0.0f, pg = 0.0f, pb = 0.0f, pdt = 0.0f, pal = 0.0f;
+    if constexpr (!CONV) {
+        const int tq = t < DK ? t : 0;
+        const int rh = blockIdx.x - kh * a.hr;
+        zz = a.z[o]; wn = w[o]; pv = a.v[o]; pq = a.q[(size_t)kh * 2 * DK + tq]; pk = a.q[(size_t)kh * 2 * DK + DK + tq];
+        pb = a.ba[kh * 2 * a.hr + rh]; pg = a.ba[kh * 2 * a.hr + a.hr + rh]; pdt = a.dt_bias[vh0]; pal = a.a_log[vh0];      // the head's raw gate inputs (decode.rs:3891-3901)
+        asm volatile("" ::: "memory");      // (keeps the compiler from sinking these requests below the state's)
+    }
     float c[DK];
 #pragma unroll
     for (int u = 0; u < DK; u++)
         c[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, voff + (u % RW) * dv * 4, (u / RW) * 4096, 0));
     const int group_dim = 2 * DK + 2 * nt, key_dim = a.nk * DK;
     const float* src = a.qkvz + (size_t)kh * group_dim;
-    const size_t o = (size_t)vh * dv + j;
-    const float zz = src[2 * DK + nt + t], wn = w[o];
+    if constexpr (CONV) { zz = src[2 * DK + nt + t]; wn = w[o]; }
     // ---- conv1d (kernel 4) + SiLU; channel c of this key head's group: q [0,DK), k [DK,2DK), v [2DK, 2DK + hr*dv)
     const int nch = 2 * DK + nt;
     auto chan = [&](int cc) { return cc < DK ? kh * DK + cc : (cc < 2 * DK ? key_dim + kh * DK + (cc - DK) : 2 * key_dim + kh * nt + (cc - 2 * DK)); };
     auto put = [&](int cc, float co) { if (cc < DK) qc[cc] = co; else if (cc < 2 * DK) kc[cc - DK] = co; else vs[cc - 2 * DK] = co; };
-    for (int c0 = t; c0 < nch; c0 += 2 * nt) {
+    if constexpr (!CONV) {
+        if (t < DK) { qc[t] = pq; kc[t] = pk; }
+        for (int i = t + nt; i < DK; i += nt) { qc[i] = a.q[(size_t)kh * 2 * DK + i]; kc[i] = a.q[(size_t)kh * 2 * DK + DK + i]; }      // DK > dv only
+        vs[t] = pv;
+        if (t == 0) {      // gates, the arithmetic of the CONV form below
+            bt[0] = 1.0f / (1.0f + kr_expf(-pb));
+            const float ap_dt = pg + pdt;
+            const float softplus = ap_dt > 20.0f ? ap_dt : kr_logf(1.0f + kr_expf(ap_dt));
+            const float g = -(kr_expf(pal)) * softplus;
+            ge[0] = kr_expf(g);
+        }
+    }
+    for (int c0 = t; CONV && c0 < nch; c0 += 2 * nt) {
         const int c1 = c0 + nt; const bool two = c1 < nch;
         const int ch0 = chan(c0), ch1 = two ? chan(c1) : ch0;
         float4* cs0 = reinterpret_cast<float4*>(a.conv_state) + ch0; float4* cs1 = reinterpret_cast<float4*>(a.conv_state) + ch1;
@@ -324,7 +349,7 @@ __global__ void __launch_bounds__(256) kr_la_step_kernel(const KrLaArgs a, float
             put(c1, co * kr_sigmoid_poly5(co));
         }
     }
-    if (t < hr) {   // gates (decode.rs:3891-3901)
+    if (CONV && t < hr) {   // gates (decode.rs:3891-3901)
         const int vg = kh * hr + t;
         const float b_raw = a.ba[kh * 2 * hr + t], a_p = a.ba[kh * 2 * hr + hr + t];
         bt[t] = 1.0f / (1.0f + kr_expf(-b_raw));
@@ -412,7 +437,7 @@ __global__ void __launch_bounds__(256) kr_la_step_kernel(const KrLaArgs a, float
         __syncthreads();
         const KrActLds Lg = kr_carve_lds(reinterpret_cast<u32x4*>(img_out), img_k, false);
         if (t < 16 * hr) {
-            const int hh = t >> 4, jj = t & 15, vg = kh * hr + hh;
+            const int hh = t >> 4, jj = t & 15, vg = vh0 + hh;
             float v8[8];
             kr_load8(rr + hh * dv, jj, v8);
             float mx = 0.0f;
@@ -1176,6 +1201,18 @@ int kr_launch_la_recurrent_gnorm(float* state, const float* q, const float* k, c
     return 0;
 }
 // fused conv + recurrence + gated norm (one launch); returns 1 when the geometry needs the two-launch path
+// the recurrence + gated norm of kr_la_step with one workgroup per VALUE head; conv outputs and gates come from the in-projection launch (kr_launch_multi_matvec_la):
+// a.q = [nk][2 dk] conv + SiLU outputs of q | k, a.v / a.z [nv][dv], a.ba = the raw in_proj_ba rows (gates are formed here).  Non-zero: geometry not covered
+int kr_launch_la_step_heads(const KrLaArgs& a, float* state, const float* w, float* out, float eps, hipStream_t s, void* img_out) {
+    if (a.nv != a.nk * a.hr || (a.dk != 128 && a.dk != 64) || (a.dv != 128 && a.dv != 64)) return 1;
+    if (a.dv != 128) img_out = nullptr;
+    const size_t lds = (size_t)(2 * a.dk + 2 * a.dv + 2 + 3 + 4) * 4;
+#define KR_LAH(DK_, DV_) hipLaunchKernelGGL((kr_la_step_kernel<DK_, DV_, false>), dim3(a.nv), dim3(a.dv), lds, s, a, state, w, out, eps, img_out, a.nv * a.dv)
+    if (a.dk == 128) { if (a.dv == 128) KR_LAH(128, 128); else KR_LAH(128, 64); }
+    else { if (a.dv == 128) KR_LAH(64, 128); else KR_LAH(64, 64); }
+#undef KR_LAH
+    return 0;
+}
 int kr_launch_la_step(const KrLaArgs& a, float* state, const float* w, float* out, float eps, hipStream_t s, void* img_out) {
     const int nt = a.hr * a.dv;
     if (nt > 256 || nt % 64 || a.nv != a.nk * a.hr || (a.dk != 128 && a.dk != 64) || (a.dv != 128 && a.dv != 64)) return 1;

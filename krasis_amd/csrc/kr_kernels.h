@@ -82,6 +82,12 @@ void kr_launch_moe_combine(const KrMoeArgs& a, hipStream_t st);
 void kr_launch_matvec(const KrMatDev& m, const void* x, int x_is_f32, float* y, hipStream_t st, int act_mode = -1);
 // several matrices sharing one input vector (same K, same bits) in ONE launch
 void kr_launch_multi_matvec(const KrMatDev* mats, float* const* ys, int n, const void* x, int x_is_f32, hipStream_t st, int act_mode = -1);
+// linear-attention in-projection with the conv1d + SiLU + conv-state shift and the gates as its epilogue (exact decode step; kr_moe_decode.hip)
+struct KrCoLa {
+    float* conv_state; const float* conv_w; float *qk_out, *v_out, *z_out;
+    int nk, dk, hr, dv, conv_mi;
+};
+int kr_launch_multi_matvec_la(const KrMatDev* mats, float* const* ys, int n, const void* x_img, const KrCoLa& la, hipStream_t st);
 
 void kr_launch_fill_synth(void* q, size_t q_bytes, uint32_t* s, size_t s_words, uint64_t seed, hipStream_t st);
 void kr_launch_fill_uniform_f32(float* x, size_t n, float amp, uint64_t seed, hipStream_t st);

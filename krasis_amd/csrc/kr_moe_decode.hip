@@ -440,47 +440,78 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_matvec_kernel(const KrMultiMat mm
 
 // Cooperative form of the multi-matrix matvec (used for mid-sized projections fed by a pre-built activation image): the waves of a
 // workgroup split the K range of a tile (see "Cooperative tile" above); a workgroup walks `tpb` consecutive tiles.
-// x_kind: 0 bf16 vector, 1 f32 vector, 2 pre-built INT16 image in global memory
-template <typename T, int BITS>
+// x_kind / act_mode: kept in the signature (leading scalars, preloaded); the input of this kernel is always the pre-built INT16 image in global memory (x_kind 2)
+// LA = true (exact decode step, linear-attention layers; tpb == 1): the in-projection's EPILOGUE is the layer's conv1d + SiLU + conv-state shift (decode.rs:3815-3890) and
+// -- every output row of in_proj_qkvz is one conv channel (or a z value), formed by the one lane that holds the row's sum, with the arithmetic of kr_la_step_kernel
+// (the in_proj_ba rows are stored as they are: the recurrence launch forms the gates from them while its state streams in).  The recurrence then runs one workgroup per VALUE head (kr_la_step_kernel<.., false>): twice the CUs pull the
+// state.  The lane's conv state / weights / gate parameters are requested with the input image, ahead of the weight records (a wave's memory counter is in-order).
+template <typename T, int BITS, bool LA = false>
 // (x, K and the modes are leading scalar arguments: the Makefile asks for them to be preloaded into SGPRs, so the input request leaves without a scalar round trip to
 //  the argument block -- see kr_decode_fast.hip)
-__global__ void __launch_bounds__(KR_BLOCK) kr_matvec_coop_kernel(const T* x, int Kp, int tpb, int act_mode, int x_kind, const KrMultiMat mm) {
+__global__ void __launch_bounds__(KR_BLOCK) kr_matvec_coop_kernel(const T* x, int Kp, int tpb, int act_mode, int x_kind, const KrMultiMat mm, const KrCoLa la) {
     __shared__ KrXch X[2];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int K = Kp;
-    KrImgPre IP; KrHidPre HP; KrVecPre VP;
-    if (x_kind == 2) kr_image_load(x, K, IP);      // the input first, the weight records behind it (kr_vec_load)
-    else if (act_mode == KR_ACT_SILU_MUL) kr_hidden_load(reinterpret_cast<const float*>(x), K, HP);
-    else kr_vec_load(x, K, VP);
+    // the input is always the pre-built INT16 image (the launchers pass x_kind = 2): the vector forms of the per-wave kernel above are not instantiated here -- as
+    // run-time branches they cost this kernel 25 registers (78 -> 54: six -> eight workgroups per CU)
+    (void)act_mode; (void)x_kind;
+    KrImgPre IP;
+    kr_image_load(x, K, IP);      // the input first, the weight records behind it (kr_vec_load)
     const int total = mm.tile_end[mm.n - 1], gt0 = blockIdx.x * tpb;      // (the launcher's grid has no workgroup past the last tile)
     int mi = 0;
     while (mi + 1 < mm.n && gt0 >= mm.tile_end[mi]) mi++;
     KrCo<BITS> cur;
     kr_co_preload<BITS>(cur, mm.m[mi].q, mm.m[mi].s, mm.m[mi], gt0 - (mi ? mm.tile_end[mi - 1] : 0), lane, wave);
+    // LA: what the epilogue lane of this workgroup's tile (wave 0, lanes 0 .. 7) will do with its row -- worked out (two integer divisions) BEHIND the request for the
+    // tile's weight records: wave 0 also carries a quarter of the tile's sums
+    int la_kind = -1, la_dst = 0;      // 0 q / k channel -> qk_out, 1 v channel -> v_out, 2 z -> z_out; -1: plain store (the in_proj_ba rows: the recurrence launch forms the gates)
+    float4 la_cs = {0.0f, 0.0f, 0.0f, 0.0f}, la_cw = la_cs; int la_ch = 0;
+    __shared__ int la_park[3][8];      // the three indices wait in LDS while the sums run (three more live registers cost the kernel a workgroup per CU)
+    if (LA && wave == 0) {
+        const int col = (gt0 - (mi ? mm.tile_end[mi - 1] : 0)) * 8 + (lane & 7);
+        if (mi == la.conv_mi && col < mm.m[mi].N) {
+            const int nt = la.hr * la.dv, group_dim = 2 * la.dk + 2 * nt, key_dim = la.nk * la.dk;
+            const int kh = col / group_dim, cc = col - kh * group_dim;
+            if (cc < la.dk) { la_kind = 0; la_ch = kh * la.dk + cc; la_dst = kh * 2 * la.dk + cc; }
+            else if (cc < 2 * la.dk) { la_kind = 0; la_ch = key_dim + kh * la.dk + (cc - la.dk); la_dst = kh * 2 * la.dk + cc; }
+            else if (cc < 2 * la.dk + nt) { la_kind = 1; la_ch = 2 * key_dim + kh * nt + (cc - 2 * la.dk); la_dst = kh * nt + (cc - 2 * la.dk); }
+            else { la_kind = 2; la_dst = kh * nt + (cc - 2 * la.dk - nt); }
+        }
+        if (lane < 8) { la_park[0][lane] = la_kind; la_park[1][lane] = la_dst; la_park[2][lane] = la_ch; }
+    }
     const KrActLds L = kr_carve_lds(kr_smem, K, BITS == 8);
-    if (x_kind == 2) kr_image_copy<BITS>(x, K, kr_smem, L, IP);
-    else if (act_mode == KR_ACT_SILU_MUL) kr_prologue_hidden<KR_ACT_SILU_MUL, BITS == 8>(reinterpret_cast<const float*>(x), K, 0.0f, 0.0f, L, HP);
-    else kr_prologue_quant<T, BITS == 8>(x, K, L, VP);
+    kr_image_copy<BITS>(x, K, kr_smem, L, IP);
     __syncthreads();
-    for (int t = 0; t < tpb; t++) {
+    for (int t = 0; t < (LA ? 1 : tpb); t++) {      // LA: one tile per workgroup (the launcher), nothing of a next tile stays live across the epilogue
         const int gt = gt0 + t;
         if (gt >= total) break;
         const KrMatDev& m = mm.m[mi];
         const int tile = gt - (mi ? mm.tile_end[mi - 1] : 0);
         int mn = mi;
         KrCo<BITS> nxt;
-        const bool more = t + 1 < tpb && gt + 1 < total;
+        const bool more = !LA && t + 1 < tpb && gt + 1 < total;
         if (more) {   // the next tile's weights are requested before this tile's sums are formed
             while (mn + 1 < mm.n && gt + 1 >= mm.tile_end[mn]) mn++;
             kr_co_preload<BITS>(nxt, mm.m[mn].q, mm.m[mn].s, mm.m[mn], gt + 1 - (mn ? mm.tile_end[mn - 1] : 0), lane, wave);
         }
         KrXch& Xc = X[t & 1];
         kr_co_sums<BITS>(cur, m.q, m.s, m, tile, L, Xc, lane);
+        if (LA && wave == 0) {      // the epilogue's operands, requested once the weight registers are free (held across the sums they cost the kernel two workgroups per CU)
+            la_kind = la_park[0][lane & 7]; la_dst = la_park[1][lane & 7]; la_ch = la_park[2][lane & 7];      // written by this wave: no barrier needed
+            la_cs = reinterpret_cast<const float4*>(la.conv_state)[la_ch]; la_cw = reinterpret_cast<const float4*>(la.conv_w)[la_ch];      // clamped to channel 0 when unused: never masked
+        }
         __syncthreads();      // one barrier per tile: the exchange buffer alternates, so the chain of tile t overlaps the sums of tile t + 1
         if (wave == (t & (KR_WAVES - 1)) && lane < 8) {
             const int col = tile * 8 + lane;
             const float acc = kr_co_chain(Xc, m.ng, lane, col < m.n_fma);
-            if (col < m.N) mm.y[mi][col] = acc;
+            if (LA && la_kind >= 0) {      // (tpb == 1: t == 0, this is wave 0 and `col` the row the operands above were requested for)
+                if (la_kind <= 1) {        // depthwise conv1d (kernel 4) over the shifted state, SiLU (fast_silu_avx2); the state shift is this lane's alone
+                    reinterpret_cast<float4*>(la.conv_state)[la_ch] = float4{la_cs.y, la_cs.z, la_cs.w, acc};
+                    float co = la_cs.y * la_cw.x + la_cs.z * la_cw.y + la_cs.w * la_cw.z + acc * la_cw.w;
+                    co = co * kr_sigmoid_poly5(co);
+                    if (la_kind == 0) la.qk_out[la_dst] = co; else la.v_out[la_dst] = co;
+                } else la.z_out[la_dst] = acc;
+            } else if (col < m.N) mm.y[mi][col] = acc;
         }
         if (more) { cur = nxt; mi = mn; }
     }
@@ -539,6 +570,22 @@ void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st) {
     kr_launch_moe_combine(a, st);
 }
 
+// exact decode step, linear-attention layers: in_proj_qkvz | in_proj_ba from the INT16 image with the conv / gate epilogue (kr_matvec_coop_kernel<.., LA = true>);
+// non-zero = geometry not covered (the caller keeps kr_launch_multi_matvec + the one-launch kr_la_step)
+int kr_launch_multi_matvec_la(const KrMatDev* mats, float* const* ys, int n, const void* x_img, const KrCoLa& la, hipStream_t st) {
+    KrMultiMat mm{};
+    mm.n = n;
+    int total = 0;
+    for (int i = 0; i < n; i++) { mm.m[i] = mats[i]; mm.y[i] = ys[i]; total += (mats[i].N + 7) / 8; mm.tile_end[i] = total; if (mats[i].bits != mats[0].bits || mats[i].ng != mats[0].ng) return 1; }
+    if (n > KR_MAX_MULTI || total > 3072 || la.conv_mi < 0 || la.conv_mi >= n) return 1;      // one tile per workgroup
+    if (mats[la.conv_mi].N != la.nk * (2 * la.dk + 2 * la.hr * la.dv)) return 1;
+    const int bits = mats[0].bits;
+    const size_t lds = kr_lds_bytes(mats[0].ng * 128, bits == 8);
+    if (bits == 4) hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 4, true>), dim3(total), dim3(KR_BLOCK), lds, st, (const float*)x_img, mats[0].ng * 128, 1, -1, 2, mm, la);
+    else hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 8, true>), dim3(total), dim3(KR_BLOCK), lds, st, (const float*)x_img, mats[0].ng * 128, 1, -1, 2, mm, la);
+    return 0;
+}
+
 void kr_launch_multi_matvec(const KrMatDev* mats, float* const* ys, int n, const void* x, int x_is_f32, hipStream_t st, int act_mode) {
     // x_is_f32: 0 bf16 vector, 1 f32 vector, 2 pre-built INT16 image (kr_act_image_bytes(K) bytes) -> cooperative kernel
     KrMultiMat mm{};
@@ -550,8 +597,8 @@ void kr_launch_multi_matvec(const KrMatDev* mats, float* const* ys, int n, const
     if (x_is_f32 == 2) {
         int tpb = 1;
         while ((total + tpb - 1) / tpb > 3072) tpb *= 2;
-        if (bits == 4) hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 4>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, (const float*)x, mats[0].ng * 128, tpb, act_mode, 2, mm);
-        else hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 8>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, (const float*)x, mats[0].ng * 128, tpb, act_mode, 2, mm);
+        if (bits == 4) hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 4>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, (const float*)x, mats[0].ng * 128, tpb, act_mode, 2, mm, KrCoLa{});
+        else hipLaunchKernelGGL((kr_matvec_coop_kernel<float, 8>), dim3((total + tpb - 1) / tpb), dim3(KR_BLOCK), lds, st, (const float*)x, mats[0].ng * 128, tpb, act_mode, 2, mm, KrCoLa{});
         return;
     }
     const int tpw = kr_pick_tpw(mats[0].K, total);

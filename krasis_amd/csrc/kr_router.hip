@@ -304,19 +304,29 @@ __global__ void __launch_bounds__(256) kr_route_fused_decode_kernel(const KrRout
     // the wave's gate rows do not depend on the hidden vector: the first KR_GPF 16-byte chunks per lane are in flight while the norm runs
     constexpr int KR_GPF = 16;
     const int ncg = GATE_BF16 ? H / 128 : H / 64;
-    const u32x4* gp = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)eb * ncg * 64 + lane;
+    const int ebc = eb * 4 < E ? eb : (E - 1) / 4;      // waves past the last expert block re-read it (requests are never masked: the compiler's load count stays exact)
+    const u32x4* gp = reinterpret_cast<const u32x4*>(a.gate_cm) + (size_t)ebc * ncg * 64 + lane;
     u32x4 gw[KR_GPF];
-    if (eb * 4 < E) {
+    // The norm's inputs are requested FIRST: a wave's memory counter is in-order, so behind the 16 gate chunks per lane they came back last and the norm
+    // (the serial part of this launch) started when the whole gate prefetch had landed (round 5, docs/design/11-round5-decode-latency.md).
+    const bool vec4 = a.norm_w && (H & 1023) == 0;
+    float4 hv[4], rv[4];
+    if (vec4) {
+        const float4* h4 = reinterpret_cast<const float4*>(a.hid_in); const float4* r4 = reinterpret_cast<const float4*>(a.res_in);
 #pragma unroll
-        for (int u = 0; u < KR_GPF; u++) if (u < ncg) gw[u] = kr_ldg_nt(gp + (size_t)u * 64);
+        for (int u = 0; u < 4; u++) { const int i = u * 256 < H / 4 ? u * 256 + t : t; hv[u] = h4[i]; rv[u] = r4[i]; }      // clamped, never masked
+        asm volatile("" ::: "memory");
     }
+#pragma unroll
+    for (int u = 0; u < KR_GPF; u++) gw[u] = kr_ldg_nt(gp + (size_t)(u < ncg ? u : ncg - 1) * 64);
     if (a.norm_w) {
-        if ((H & 1023) == 0) {   // float4 loads, all in flight before the first add
+        if (vec4) {   // float4 loads, all in flight before the first add
             const float4* h4 = reinterpret_cast<const float4*>(a.hid_in); const float4* r4 = reinterpret_cast<const float4*>(a.res_in);
             for (int i0 = 0; i0 < H / 4; i0 += 1024) {
-                float4 hv[4], rv[4];
+                if (i0 > 0) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (i0 + u * 256 < H / 4) { hv[u] = h4[i0 + u * 256 + t]; rv[u] = r4[i0 + u * 256 + t]; }
+                    for (int u = 0; u < 4; u++) if (i0 + u * 256 < H / 4) { hv[u] = h4[i0 + u * 256 + t]; rv[u] = r4[i0 + u * 256 + t]; }
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++) if (i0 + u * 256 < H / 4) {
                     const float4 v = {hv[u].x + rv[u].x, hv[u].y + rv[u].y, hv[u].z + rv[u].z, hv[u].w + rv[u].w};
