@@ -215,6 +215,11 @@ r5u)        # round 5: whole GPU suite, then the decode probe with the one-launc
         echo "lm_fused=$v"; timeout 300 python tools/probes/decode_fast_bench.py --only fast --route-tokens 0 --opt lm_fused=$v --out gpurun_out/r05_lm$v 2>&1 | grep -E "^fast|lm_head|rmsnorm"
     done; done
     ;;
+r5s)        # round 5: only the stamp / per-workgroup probes of the KR_DECODE_FAST launches (timing build made on the box)
+    [ -f krasis_amd/libkrasis_hip_timing.so ] || make -C krasis_amd/csrc timing > $R/make_timing.log 2>&1
+    KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so LAYERS=47 STAMPS_OUT=$R/r05_decode_fast_stamps.txt timeout 250 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
+    KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so LAYERS=47 WG_OUT=$R/r05_decode_fast_wg_times.txt timeout 250 python tools/probes/decode_fast_wg_times.py 2>&1 | tail -7
+    ;;
 tests)      # the whole GPU suite, as the driver runs it
     timeout 2400 python -m pytest tests/ -x -q -m gpu "$@" 2>&1 | tail -15
     ;;

@@ -26,6 +26,7 @@ def main():
     q = bench.QCN
     eng, st, keep = bench.build_qcn(0, 0, int(os.environ.get("LAYERS", "48")), 0, 4, kv_fp8=True, gguf=os.environ.get("GGUF", "0") == "1")
     st.set_attention_mode(False, decode_fast=True)
+    st.set_option("lm_fused", 0)      # the one-launch final norm + vocabulary projection is a kr_fdm launch too: it would overwrite the in-projection's stamps
     lib = st._lib
     buf = (C.c_ulonglong * (8 * 16))()
     acc = {}; raws = []; raw_last = None; acc6 = []

@@ -20,6 +20,7 @@ def main():
     import torch
     eng, st, keep = bench.build_qcn(0, 0, int(os.environ.get("LAYERS", "47")), 0, 4, kv_fp8=True)
     st.set_attention_mode(False, decode_fast=True)
+    st.set_option("lm_fused", 0)      # the one-launch final norm + vocabulary projection is a kr_fdm launch too: it would overwrite the in-projection's stamps
     buf = (C.c_ulonglong * (6 * 1024 * 3))()
     lines = ["# QCN decode step, KR_DECODE_FAST, launches of the last (linear-attention) layer: per workgroup entry / exit (us, relative to the launch's first entry)"]
     acc = {}
