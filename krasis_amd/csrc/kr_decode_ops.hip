@@ -69,8 +69,41 @@ __global__ void __launch_bounds__(KR_NORM_THREADS) kr_fused_add_rmsnorm_kernel(c
     const int ldt = n / 8 + 4;
     float* rt = sm + n + 4;              // [8][ldt] lane-major copy for the sum-of-squares chain (n % 8 == 0)
     const bool tr = (n & 7) == 0;
-    if (src.mode == 2 && src.topk <= 16) {
-        // MoE epilogue: sum_i w_i * eo_i in routing order (moe.rs:661-667), *rsf, + shared * sigmoid(gate).  Every load of the
+    if (src.mode == 2 && src.topk <= 16 && src.topk >= 1 && (n & 7) == 0 && n <= 4 * KR_NORM_THREADS) {
+        // MoE epilogue, four consecutive elements per thread: this ONE workgroup pulls (topk + 1) rows of n floats through one CU, and 16-byte requests move about
+        // twice what 4-byte requests do there (kr_fla vs the 4-byte column loads of kr_la_step).  Requests are never masked (slots past topk re-read the last slot:
+        // the compiler's load count stays exact); the sums are the same per-element chains in routing order (moe.rs:661-667), *rsf, + shared * sigmoid(gate).
+        const int i4 = threadIdx.x, n4 = n >> 2;
+        if (i4 < n4) {
+            const float4* eo4 = reinterpret_cast<const float4*>(src.eo);
+            float4 e[16]; float wv[16]; int idv[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const int uc = u < src.topk ? u : src.topk - 1; e[u] = eo4[(size_t)uc * n4 + i4]; wv[u] = src.wts[uc]; idv[u] = src.ids[uc]; }
+            float4 sh = {0.0f, 0.0f, 0.0f, 0.0f}; float gv = 0.0f;
+            if (src.has_shared) { sh = eo4[(size_t)src.topk * n4 + i4]; if (src.gate_val) gv = src.gate_val[0]; }
+            float4 rv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (!first) rv = reinterpret_cast<const float4*>(res_in)[i4];
+            const float sig = (src.has_shared && src.gate_val) ? 1.0f / (1.0f + kr_expf(-gv)) : 1.0f;
+            float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int u = 0; u < 16; u++) if (u < src.topk && idv[u] >= 0) { a[0] += wv[u] * e[u].x; a[1] += wv[u] * e[u].y; a[2] += wv[u] * e[u].z; a[3] += wv[u] * e[u].w; }
+            const float shv[4] = {sh.x, sh.y, sh.z, sh.w}, rr4[4] = {rv.x, rv.y, rv.z, rv.w};
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float ac = a[c];
+                if (src.rsf != 1.0f) ac *= src.rsf;
+                if (src.has_shared) { float s1 = shv[c]; if (src.gate_val) s1 *= sig; ac = ac + s1; }
+                v[c] = first ? ac : (ac + rr4[c]);
+            }
+            const int i0 = i4 * 4;
+            reinterpret_cast<float4*>(r)[i4] = float4{v[0], v[1], v[2], v[3]};
+            reinterpret_cast<float4*>(residual)[i4] = float4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+            for (int c = 0; c < 4; c++) rt[((i0 + c) & 7) * ldt + ((i0 + c) >> 3)] = v[c];
+        }
+    } else if (src.mode == 2 && src.topk <= 16) {
+        // (general widths) MoE epilogue: sum_i w_i * eo_i in routing order (moe.rs:661-667), *rsf, + shared * sigmoid(gate).  Every load of the
         // thread (slot rows, weights, ids, residual) is issued before the first use: one memory latency for the whole gather.
         for (int i0 = threadIdx.x; i0 < n; i0 += 2 * KR_NORM_THREADS) {
             const int i1 = i0 + KR_NORM_THREADS; const bool two = i1 < n;
