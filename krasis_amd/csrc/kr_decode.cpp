@@ -876,6 +876,12 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             }
             PROF(PK_MOE_W13, kr_launch_moe_w13(a, st));
             if (has_gate && !fuse_gate) PROF(PK_SHARED_GATE, kr_launch_matvec(mv(s, L.sg_wid), act, 1, (float*)s->gate_val.p, st));
+            if (!ep_dec && s->opt_w2_combine) {      // stage 2 + the routing-order combine in one launch: the MoE output lands in `hid`, the next norm launch reads it like any hidden vector
+                prof_mark(s, PK_MOE_W2, st);
+                const bool done = 0 == kr_launch_moe_w2c(a, has_gate ? (const float*)s->gate_val.p : nullptr, hid, st);
+                prof_mark(s, -1, st);
+                if (done) { src = from_hidden; continue; }
+            }
             PROF(PK_MOE_W2, kr_launch_moe_w2(a, st));
             if (ep_dec) if (int rc = kr_ep_allreduce_on(e, a.eo, (size_t)k * H, st)) return rc;    // the shared expert's row (slot k) is replicated, not reduced
             // epilogue (weighted sum, rsf, shared * sigmoid(gate)) is folded into the next fused add+RMSNorm
@@ -1001,6 +1007,7 @@ extern "C" int kr_decode_set_option(kr_decode_store* s, const char* name, int va
     if (int rc = chk_store(s)) return rc;
     if (!name) return kr_fail(KR_ERR_VALUE, "null option name");
     if (!strcmp(name, "gqa_stream")) { s->opt_gqa_stream = value != 0; s->graph_ok = false; return KR_OK; }
+    if (!strcmp(name, "w2_combine")) { s->opt_w2_combine = value != 0; s->graph_ok = false; return KR_OK; }    // exact step: 0 = down projection per slot, combine inside the next norm launch (A/B and test hook)
     if (!strcmp(name, "la_heads")) { s->opt_la_heads = value != 0; s->graph_ok = false; return KR_OK; }        // exact step, linear-attention layers: 0 = in-projection + the one-launch conv / recurrence per KEY head (A/B and test hook)
     if (!strcmp(name, "lm_fused")) { s->opt_lm_fused = value != 0; s->graph_ok = false; return KR_OK; }        // KR_DECODE_FAST: 0 = final norm and vocabulary projection as two launches (A/B and test hook)
     if (!strcmp(name, "gqa_fused")) { s->opt_gqa_fused = value != 0; s->graph_ok = false; return KR_OK; }      // KR_DECODE_FAST, short caches: 0 = prep + attention as two launches (A/B and test hook)

@@ -76,6 +76,7 @@ void kr_launch_moe_decode(const KrMoeArgs& a, hipStream_t st);
 void kr_launch_moe_w13(const KrMoeArgs& a, hipStream_t st);
 void kr_launch_moe_w2(const KrMoeArgs& a, hipStream_t st);
 void kr_launch_moe_combine(const KrMoeArgs& a, hipStream_t st);
+int kr_launch_moe_w2c(const KrMoeArgs& a, const float* gate_val, float* out, hipStream_t st);      // decode step: stage 2 + the routing-order combine in one launch
 
 // generic single-matrix matvec: y[N] = W . quant(x[K]); x f32 or bf16; used for projections / lm_head
 // act_mode < 0: x[K] is quantized as is; otherwise x = [gate(K) | up(K)] and the kernel applies KR_ACT_* first (dense MLP)

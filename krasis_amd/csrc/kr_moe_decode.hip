@@ -17,6 +17,7 @@
 #include "kr_device.h"
 #include "kr_kernels.h"
 #include "kr_matvec_dev.h"
+#include "kr_libm.h"
 #include <cstdio>
 
 #define KR_BLOCK 256
@@ -389,6 +390,98 @@ __global__ void __launch_bounds__(KR_BLOCK) kr_moe_w2_kernel(const float* p_gu, 
     }
 }
 
+// stages 2 + 3 of the DECODE STEP in one launch (B == 1, round 5): one workgroup per 8-column tile of the output, ONE WAVE PER SLOT.  Every wave quantizes its slot's hidden
+// values into a wave-private image (the arithmetic of kr_prologue_hidden, chunk = lane), runs the exact per-wave tile (kr_matvec_tile: the reference's chain order) and
+// leaves its 8 column sums in LDS; lanes 0 .. 7 of wave 0 then form the step's MoE output in routing order -- sum_i w_i * eo_i (moe.rs:661-667), * rsf, + shared *
+// sigmoid(gate) (decode.rs:3343-3402): the arithmetic the next layer's fused add + RMSNorm launch used to run over (topk + 1) rows of H floats pulled through ONE CU.
+// That launch now reads `out` like any hidden vector (KrNormSrc mode 0).  Expert-parallel decode keeps stage 2 alone (its per-slot rows are all-reduced).
+template <int BITS, int ACT>
+// (the pointers of the first requests and the widths are leading scalar arguments: preloaded into SGPRs, see kr_matvec_coop_kernel)
+__global__ void __launch_bounds__(1024) kr_moe_w2c_kernel(const float* p_gu, const int32_t* p_ids, const float* p_wts, const float* p_gate_val, int p_gu_ld, int p_I, int p_I_shared,
+                                                         int p_topk, int p_img16, float* p_out, const KrMoeArgs a) {
+    __shared__ float s_e[16][8];
+    const int slot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, tile = blockIdx.x;
+    const bool shared = slot >= p_topk;
+    const int inter = shared ? p_I_shared : p_I, nch = inter / 8;
+    const float* gu = p_gu + (size_t)slot * p_gu_ld;
+    // the slot's gate | up values first, the routing record and the weight records behind them (a wave's memory counter is in-order)
+    float pg[8], pu[8];
+    { const int c = lane < nch ? lane : nch - 1; kr_load8(gu, c, pg); kr_load8(gu + inter, c, pu); }
+    float wv = 0.0f; int idv = -1; float gval = 0.0f;
+    if (slot == 0) {      // the combine's operands: lane s holds slot s
+        const int sc = lane < p_topk ? lane : p_topk - 1;
+        wv = p_wts[sc]; idv = p_ids[sc];
+        if (p_gate_val) gval = p_gate_val[0];
+    }
+    KrSlot sl;      // kr_resolve_slot for b = 0, no expert-parallel slice (the launcher refuses one)
+    {
+        const int e = shared ? 0 : p_ids[slot];
+        sl.shared = shared; sl.inter = inter; sl.valid = shared || (e >= 0 && e < a.E);
+        const size_t ee = (size_t)(sl.valid ? e : 0);
+        sl.q2 = shared ? a.sw2.q : (const void*)(reinterpret_cast<const char*>(a.w2.q) + ee * a.w2.q_stride);
+        sl.s2 = shared ? a.sw2.s : reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.w2.s) + ee * a.w2.s_stride);
+        sl.q13 = nullptr; sl.s13 = nullptr;
+    }
+    const KrMatDev& m = shared ? a.sw2 : a.w2;
+    KrPre pre;
+    if (sl.valid) kr_preload<BITS>(pre, sl.q2, sl.s2, m, tile, lane, 0);
+    const KrActLds L = kr_carve_lds(kr_smem + (size_t)slot * p_img16, inter, BITS == 8);
+    if (sl.valid) {
+        const bool mul = shared && a.shared_decode;      // the decode store's shared expert: silu * up with f32::round (KR_ACT_SILU_MUL)
+        for (int c = lane; c < nch; c += 64) {
+            float g[8], u[8], h[8];
+            if (c == lane) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) { g[i] = pg[i]; u[i] = pu[i]; }
+            } else { kr_load8(gu, c, g); kr_load8(gu + inter, c, u); }
+            float mx = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (ACT == KR_ACT_GPTOSS && !mul) {  // moe.rs:272-280
+                    float gate = g[i], up = u[i];
+                    if (gate > a.swiglu_limit) gate = a.swiglu_limit;
+                    if (up > a.swiglu_limit) up = a.swiglu_limit;
+                    if (up < -a.swiglu_limit) up = -a.swiglu_limit;
+                    const float glu = gate * kr_sigmoid_poly5_scalar(gate * a.alpha);
+                    h[i] = (up + 1.0f) * glu;
+                } else {                      // avx2.rs:2331-2333 / decode.rs:1731-1733
+                    const float silu = g[i] * kr_sigmoid_poly5(g[i]);
+                    h[i] = silu * u[i];
+                }
+                mx = fmaxf(mx, fabsf(h[i]));
+            }
+            float scale, inv;
+            kr_group_scale(mx, scale, inv);
+            int q[8];
+            if (ACT == KR_ACT_SILU_FUSED && !mul) kr_quant8<true>(h, inv, q);   // _mm256_cvtps_epi32
+            else kr_quant8<false>(h, inv, q);                                    // f32::round
+            kr_store_chunk<BITS == 8>(L, c, q);
+            if ((c & 15) == 0) L.ascale[c >> 4] = scale;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image is wave-private: the wave's own LDS writes are complete before its reads, no workgroup barrier
+    float acc = 0.0f;
+    if (sl.valid) acc = kr_matvec_tile<BITS>(pre, true, sl.q2, sl.s2, m, tile, L, lane);
+    if ((lane & 7) == 0) s_e[slot][lane >> 3] = acc;
+    __syncthreads();
+    if (slot == 0) {
+        const int c8 = lane & 7, col = tile * 8 + c8;
+        float o = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) if (s2 < p_topk) {      // v_readlane with a constant lane: one instruction per operand
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), s2)); const int id = __builtin_amdgcn_readlane(idv, s2);
+            if (id >= 0) o += w * s_e[s2][c8];
+        }
+        if (a.rsf != 1.0f) o *= a.rsf;
+        if (a.n_slots > p_topk) {
+            float sh = s_e[p_topk][c8];
+            if (p_gate_val) sh *= 1.0f / (1.0f + kr_expf(-gval));
+            o = o + sh;
+        }
+        if (lane < 8 && col < a.H) p_out[col] = o;
+    }
+}
+
 // stage 3: out[b][j] = sum_i w_i * eo_i[j] in routing order (moe.rs:661-667); then rsf*out + shared (moe.rs:703-706)
 __global__ void __launch_bounds__(KR_BLOCK) kr_moe_combine_kernel(const KrMoeArgs a) {
     const int b = blockIdx.y;
@@ -557,6 +650,28 @@ void kr_launch_moe_w2(const KrMoeArgs& a, hipStream_t st) {
         else KR_W2(8, KR_ACT_SILU_MUL);
     }
 #undef KR_W2
+}
+
+// stages 2 + 3 of the decode step in one launch (kr_moe_w2c_kernel); non-zero = geometry not covered (the caller keeps kr_launch_moe_w2 + the combine inside the next norm launch)
+int kr_launch_moe_w2c(const KrMoeArgs& a, const float* gate_val, float* out, hipStream_t st) {
+    const bool has_shared = a.n_slots > a.topk;
+    if (a.B != 1 || a.n_slots < 1 || a.n_slots > 16 || a.topk < 1 || a.H % 8 || a.I % 128 || (has_shared && (a.I_shared % 128 || a.sw2.bits != a.w2.bits)) || a.e_hi > 0) return 1;
+    const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
+    const size_t img = (kr_lds_bytes(imax, a.w2.bits == 8) + 15) / 16 * 16, lds = img * a.n_slots;
+    if (lds > 60 * 1024) return 1;
+    dim3 grid(a.H / 8), block(64 * a.n_slots);
+#define KR_W2C(B_, A_) hipLaunchKernelGGL((kr_moe_w2c_kernel<B_, A_>), grid, block, lds, st, a.gu, a.ids, a.wts, gate_val, a.gu_ld, a.I, a.I_shared, a.topk, (int)(img / 16), out, a)
+    if (a.w2.bits == 4) {
+        if (a.act_mode == KR_ACT_SILU_FUSED) KR_W2C(4, KR_ACT_SILU_FUSED);
+        else if (a.act_mode == KR_ACT_GPTOSS) KR_W2C(4, KR_ACT_GPTOSS);
+        else KR_W2C(4, KR_ACT_SILU_MUL);
+    } else {
+        if (a.act_mode == KR_ACT_SILU_FUSED) KR_W2C(8, KR_ACT_SILU_FUSED);
+        else if (a.act_mode == KR_ACT_GPTOSS) KR_W2C(8, KR_ACT_GPTOSS);
+        else KR_W2C(8, KR_ACT_SILU_MUL);
+    }
+#undef KR_W2C
+    return 0;
 }
 
 void kr_launch_moe_combine(const KrMoeArgs& a, hipStream_t st) {

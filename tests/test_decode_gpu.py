@@ -110,13 +110,15 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbit
 
 @pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True), dict(wbits=8, with_dense=True)])
 @pytest.mark.parametrize("graph", [True, False])
-@pytest.mark.parametrize("la_heads", [1, 0])
-def test_decode_step_bit_exact(cfg, graph, la_heads):
-    """la_heads = 1 (default): linear-attention layers run conv + gates as the in-projection's epilogue and the recurrence one workgroup per VALUE head;
-    0: in-projection, then conv + recurrence in one launch per KEY head.  Both forms bit-equal to the oracle (logits, conv state, recurrent state)."""
+@pytest.mark.parametrize("round5_forms", [1, 0])
+def test_decode_step_bit_exact(cfg, graph, round5_forms):
+    """round5_forms = 1 (default): linear-attention layers run the conv as the in-projection's epilogue and the recurrence one workgroup per VALUE head; the experts'
+    down projection and the routing-order combine are one launch.  0: in-projection, then conv + recurrence in one launch per KEY head; down projection per slot, the
+    combine inside the next norm launch.  Both forms bit-equal to the oracle (logits, conv state, recurrent state)."""
     st, eng, orc, keep, d = build(**cfg)
     st.set_use_graph(graph)
-    st.set_option("la_heads", la_heads)
+    st.set_option("la_heads", round5_forms)
+    st.set_option("w2_combine", round5_forms)
     tok = 7
     for step, pos in enumerate([5, 6, 7]):
         logits = np.empty(d["V"], F)
