@@ -47,7 +47,8 @@ SYMBOL = {"proj_matvec": "kr_matvec_coop_kernel<float,4>", "lm_head": "kr_matvec
           "route_logits": "kr_route_fused_decode_kernel<true,8>", "route_select": "kr_route_select_kernel",
           "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
 # the same kinds in KR_DECODE_FAST (kr_decode_fast.hip): the norms ride in the projection / router launches, top-k + silu*up in the gate|up launch, the combine in the down launch
-SYMBOL_FAST = {"proj_matvec": "kr_fdm_kernel<4,1,8,1>", "out_proj_matvec": "kr_fdm_kernel<4,4,4,0>", "lm_head": "kr_matvec_kernel<float,4>", "moe_w13": "kr_fw13_kernel<4,4>", "moe_w2": "kr_fw2_kernel<4,2,false>",
+SYMBOL_FAST = {"proj_matvec": "kr_fdm_kernel<4,1,8,1>", "out_proj_matvec": "kr_fdm_kernel<4,4,4,0>", "lm_head": "kr_fdm_kernel<4,1,8,1>@grid1215488",      # (final norm + vocabulary projection: the in-projection kernel on ceil(151936 / 32) workgroups of 256 threads -- its own row in the PMC summary)
+               "moe_w13": "kr_fw13_kernel<4,4>", "moe_w2": "kr_fw2_kernel<4,2,false>",
                "la_recurrent": "kr_fla_kernel<128,128>", "route_logits": "kr_frt_kernel<true,4>", "fused_add_rmsnorm": "kr_fused_add_rmsnorm_kernel"}
 WORKLOAD = {"qcn-q4": "Qwen3-Coder-Next Q4 int4gpu on 1×MI355X (512-expert top-10, hybrid linear+GQA, FP8 KV)",
             "qcn-q8": "Qwen3-Coder-Next Q8 int8gpu on 1×MI355X (int8 MFMA path, Q8_0 dequant)",

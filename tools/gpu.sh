@@ -184,6 +184,7 @@ r5a)        # round 5, first contact: ADVICE r4 fixes (their tests), the compact
     ;;
 r5final)    # round 5 closing run: GPU suite as the driver runs it; PMC fetch pass FIRST (its json lands in profiles/ on the box), then the driver's bench line (so
             # roofline.traffic in the line is the number of the json committed beside it); kernel traces; stamps
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
     timeout 1800 python -m pytest tests/ -x -q -m gpu > $R/r05_gpu_tests_full.txt 2>&1; echo "pytest rc=$?"
     grep -E " passed| failed| error|skipped" $R/r05_gpu_tests_full.txt | tail -3 | tee $R/r05_gpu_tests_summary.txt
     rm -rf $R/pmc_fast
@@ -214,6 +215,18 @@ r5u)        # round 5: whole GPU suite, then the decode probe with the one-launc
     for rep in 1 2; do for v in 1 0; do
         echo "lm_fused=$v"; timeout 300 python tools/probes/decode_fast_bench.py --only fast --route-tokens 0 --opt lm_fused=$v --out gpurun_out/r05_lm$v 2>&1 | grep -E "^fast|lm_head|rmsnorm"
     done; done
+    ;;
+r5line)     # round 5: PMC fetch pass (json into profiles/ on the box) -> the driver's bench line -> kernel trace of the fast step
+    rm -rf $R/pmc_fast
+    (cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE -d $R/pmc_fast --output-format csv -- python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 12 --route-tokens 0 --out /root/repo/gpurun_out/r05_decode_fast_pmcrun > $R/pmc_fast.log 2>&1)
+    python tools/rocprof_csv_summary.py pmc $R/pmc_fast $R/r05_decode_fast_pmc_fetch_size.txt "QCN Q4 decode step, KR_DECODE_FAST: HBM fetch per launch (rocprofv3 --pmc FETCH_SIZE, counters-only pass; x2 = gfx950 correction)" 2>&1 | tail -2
+    cp $R/r05_decode_fast_pmc_fetch_size.json $R/r05_decode_fast_pmc_fetch_size.txt profiles/ 2>/dev/null
+    head -16 $R/r05_decode_fast_pmc_fetch_size.txt
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r05_bench_stdout.txt 2> $R/r05_bench_stderr.txt; echo "bench rc=$?"
+    tail -1 $R/r05_bench_stdout.txt > $R/r05_bench_line.json; echo "last stdout line: $(wc -c < $R/r05_bench_line.json) bytes, stdout lines: $(wc -l < $R/r05_bench_stdout.txt)"
+    cp $R/bench_detail.json $R/r05_bench_detail.json 2>/dev/null
+    python tools/bench_summary.py $R/r05_bench_detail.json
+    rm -rf $R/prof_* $R/pmc_* $R/*.log
     ;;
 r5s)        # round 5: only the stamp / per-workgroup probes of the KR_DECODE_FAST launches (timing build made on the box)
     [ -f krasis_amd/libkrasis_hip_timing.so ] || make -C krasis_amd/csrc timing > $R/make_timing.log 2>&1

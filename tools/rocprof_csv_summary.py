@@ -40,10 +40,18 @@ def statsdb(d, out, title):
 
 def pmc(d, out, title):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
-    agg = collections.defaultdict(list)
+    raw = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == "FETCH_SIZE":
-            agg[r["Kernel_Name"].split("(")[0]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+            raw[r["Kernel_Name"].split("(")[0]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r.get("Grid_Size") or 0)))
+    # one template instantiation launched on very different grids is two different jobs (round 5: kr_fdm_kernel<4,1,8,1> is the in-projection of every layer AND, once per
+    # step, the final norm + vocabulary projection on a 12 x larger grid): launches whose grid is >= 4 x (or <= 1/4 of) the name's most frequent grid get their own row
+    agg = collections.defaultdict(list)
+    for k, v in raw.items():
+        common = collections.Counter(x[2] for x in v).most_common(1)[0][0]
+        for x in v:
+            far = common > 0 and x[2] > 0 and (x[2] >= 4 * common or 4 * x[2] <= common)
+            agg[(k + "@grid%d" % x[2]) if far else k].append(x[:2])
     lines = [f"# {title}", f"# source: rocprofv3 --kernel-trace --pmc FETCH_SIZE ({f.split('gpurun_out/')[-1]}); per launch averages",
              f"{'launches':>8} {'fetch_KiB_raw':>14} {'fetch_MiB_x2':>13} {'avg_us':>9}  kernel"]
     for k, v in sorted(agg.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
