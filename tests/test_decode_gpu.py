@@ -108,7 +108,8 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbit
                                     state=state)
 
 
-@pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True), dict(wbits=8, with_dense=True)])
+@pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True), dict(wbits=8, with_dense=True),
+                                 dict(dims=(256, 512, 16, 4, 128, 384), seed=3)])      # shared expert three times as wide as the routed ones (V2-Lite has 2 x)
 @pytest.mark.parametrize("graph", [True, False])
 @pytest.mark.parametrize("round5_forms", [1, 0])
 def test_decode_step_bit_exact(cfg, graph, round5_forms):
