@@ -268,6 +268,26 @@ def compact_line(res, detail_path=None):
     return out, text
 
 
+def flush_native_stdout():
+    """libc's own stdout buffer (RCCL prints its version banner there; on a pipe it stays buffered until exit) is written out NOW"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def silence_stdout():
+    """nothing this process writes to fd 1 from here on reaches the driver: the compact line stays the LAST stdout line (a native library's buffered text, flushed at
+    exit, or a message at communicator teardown would otherwise follow it)"""
+    try:
+        sys.stdout.flush(); flush_native_stdout()
+        fd = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(fd, 1); os.close(fd)
+    except Exception:
+        pass
+
+
 def emit_line(res, args):
     """write the full result dict to the detail file (and to stderr), print the compact line as the LAST stdout line"""
     detail_path = None
@@ -289,7 +309,9 @@ def emit_line(res, args):
     assert len(text) <= LINE_HARD_CAP_BYTES, "bench line is %d bytes" % len(text)
     sys.stderr.write("bench.py: full detail (%d bytes) -> %s; compact line %d bytes\n" % (len(full), detail_path, len(text)))
     sys.stderr.flush()
+    flush_native_stdout()      # buffered text of native libraries goes out BEFORE the line
     print(text, flush=True)
+    silence_stdout()           # ... and nothing follows it
     return out
 
 
@@ -1250,6 +1272,14 @@ def main_multi(args, torch, dist, world, rank, local_rank):
             except Exception as ex:
                 legs["qwen3_235b_ep"] = {"error": repr(ex)}
     watchdog.cancel()
+    # the ranks share one stdout under torch.distributed.run: every rank writes out what its native libraries buffered, ranks != 0 close their stdout, THEN rank 0 prints
+    flush_native_stdout()
+    if rank != 0:
+        silence_stdout()
+    try:
+        dist.barrier()
+    except Exception:
+        pass
     emit()
     dist.destroy_process_group()
 

@@ -107,3 +107,29 @@ def test_compact_line_of_a_multi_gpu_result():
     assert back["n_gpus"] == 8 and back["scaling"] == "strong" and back["decode_ep_fast_graph"]["tok_s"] == 1234.5
     assert back["prefill_model_ep"]["tok_s"] == 300000.0 and back["qwen3_235b_ep"]["decode_ep_fast_graph"] == 1234.5
     assert back["roofline"]["traffic"] is None and back["roofline"]["step_bytes_per_gpu"] == 5e8
+
+
+def test_the_line_is_the_last_stdout_line_even_with_native_output(tmp_path):
+    """RCCL prints its version banner through libc's stdout, which on a pipe stays buffered until exit -- behind the JSON line (seen with --ep-selftest, round 5).
+    emit_line writes native buffers out BEFORE the line and closes stdout after it: whatever a native library prints later never reaches the driver."""
+    import subprocess
+    import sys
+    prog = r"""
+import ctypes, json, os, sys, glob, types
+sys.path.insert(0, %r)
+import bench
+libc = ctypes.CDLL(None)
+libc.printf(b"native banner, buffered in libc\n")            # like RCCL's version text: not flushed yet
+full = json.load(open(sorted(glob.glob(os.path.join(bench.ROOT, "profiles", "r04_bench_line.json")))[0]))
+args = types.SimpleNamespace(detail_file=%r, cpu_seconds=5)
+bench.emit_line(full, args)
+libc.printf(b"native text at teardown\n")                     # like a message at communicator destroy / exit
+print("python text after the line")
+""" % (bench.ROOT, str(tmp_path / "detail.json"))
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert lines[0].startswith("native banner"), lines[:2]
+    back = json.loads(lines[-1])                                  # the LAST stdout line is the compact object
+    assert "value" in back and "roofline" in back
+    assert len(lines) == 2
