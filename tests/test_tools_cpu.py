@@ -41,3 +41,28 @@ def test_timeline_exclusive_time_and_concurrency(tmp_path):
     assert a[0] == "1" and b[0] == "1" and c[0] == "1"
     assert float(a[3].rstrip("%")) == 20.0 and float(b[3].rstrip("%")) == 20.0 and float(c[3].rstrip("%")) == 20.0
     assert float(a[4]) == 0.5 and float(b[4]) == 0.5 and float(c[4]) == 0.0
+
+
+def test_pmc_summary_gives_a_kernel_on_two_grid_classes_two_rows(tmp_path):
+    """tools/rocprof_csv_summary.py pmc: one template instantiation launched on very different grids is two different jobs (round 5: kr_fdm_kernel<4,1,8,1> is
+    every layer's in-projection AND, once per step, the final norm + vocabulary projection on a 12 x larger grid) -- the rare grid class gets its own row / json key,
+    the x2 gfx950 correction is applied to both"""
+    import json
+    d = tmp_path / "pmc" / "host"
+    d.mkdir(parents=True)
+    with open(d / "7_counter_collection.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"])
+        for i in range(6):
+            w.writerow([98816, "void kr_fdm_kernel<4, 1, 8, 1>(void const*, int)", "FETCH_SIZE", 6000.0, 1000 * i, 1000 * i + 700])
+        w.writerow([1215488, "void kr_fdm_kernel<4, 1, 8, 1>(void const*, int)", "FETCH_SIZE", 78000.0, 9000, 9000 + 31000])
+        w.writerow([98816, "void kr_fdm_kernel<4, 1, 8, 1>(void const*, int)", "SOMETHING_ELSE", 1.0, 0, 1])
+        w.writerow([256, "kr_small(int)", "FETCH_SIZE", 10.0, 0, 100])
+    out = tmp_path / "pmc.txt"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_csv_summary.py"), "pmc", str(tmp_path / "pmc"), str(out), "synthetic"], check=True)
+    ks = json.load(open(tmp_path / "pmc.json"))["kernels"]
+    assert ks["kr_fdm_kernel<4,1,8,1>"] == 2.0 * 1024.0 * 6000.0
+    assert ks["kr_fdm_kernel<4,1,8,1>@grid1215488"] == 2.0 * 1024.0 * 78000.0
+    assert ks["kr_small"] == 2.0 * 1024.0 * 10.0 and len(ks) == 3
+    text = out.read_text()
+    assert "@grid1215488" in text and text.count("kr_fdm_kernel") == 2
