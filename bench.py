@@ -562,7 +562,7 @@ def build_v2lite(rank, local_rank, L, rope_len=0, bits=4, kv_fp8=False, ep_world
     return eng, st, keep
 
 
-def prefill_experts(eng, dims, L, M, torch, gemm_fast=False):
+def prefill_experts(eng, dims, L, M, torch, gemm_fast=False, gemm_mode=None):
     """Side measurement (NOT the headline value): the prefill expert path alone -- token sort + int8-MFMA grouped GEMM + combine of all
     L MoE layers for one chunk of M tokens with uniform random routing (k distinct experts per token).  Roofline per SURVEY 8(d):
     achieved = 2 * T * k * 3 * H * I / t (useful MACs x 2); `int8_TOPS_issued` counts both INT16-digit passes the exact arithmetic issues."""
@@ -573,7 +573,8 @@ def prefill_experts(eng, dims, L, M, torch, gemm_fast=False):
     ids = torch.rand((M, E), device="cuda", generator=g).topk(k, dim=1).indices.to(torch.int32)
     w = torch.softmax(torch.randn((M, k), device="cuda", generator=g), dim=1)
     mgr = GpuPrefillManager(eng, k)
-    _lib.check(eng._lib.kr_moe_set_gemm_mode(eng._h, 1 if gemm_fast else 0))
+    # gemm_mode 3: tolerance form on the register-staged kernels only (A/B against the default LDS-ring form, same bits)
+    _lib.check(eng._lib.kr_moe_set_gemm_mode(eng._h, gemm_mode if gemm_mode is not None else (1 if gemm_fast else 0)))
     try:
         for l in range(L):      # every layer builds its derived tables on first use (per-weight nibble sums; the tolerance copy of GGUF layers) -- outside the timed region
             mgr.forward(l, x, ids, w, routed_only=True)
@@ -586,6 +587,8 @@ def prefill_experts(eng, dims, L, M, torch, gemm_fast=False):
         ev1.record(); torch.cuda.synchronize()
         allocs = alloc_count() - a0
     finally:
+        if gemm_mode is not None:
+            _lib.check(eng._lib.kr_moe_set_gemm_mode(eng._h, 1))       # the ring kernel back to its default dispatch
         _lib.check(eng._lib.kr_moe_set_gemm_mode(eng._h, 0))
     ms = ev0.elapsed_time(ev1)
     if allocs:

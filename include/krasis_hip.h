@@ -163,7 +163,9 @@ int kr_reduce_sum_bf16(kr_engine* e, const void* const* inputs, int n_inputs, vo
 int kr_moe_set_prefill_pairs(kr_engine* e, int pairs);
 /* numerics of the prompt-pass expert GEMMs of kr_moe_prefill: 0 (default) = the CPU engine's arithmetic (INT16 activation digits, one f32 fma per
  * 128-group: bit-identical to kr_moe_forward, moe.rs:184); 1 = tolerance form: f16 activations x weights de-quantized in registers, f32 accumulation
- * over the whole k range -- the dataflow of the reference's GPU prompt pass (gpu_prefill.py:64-239, Marlin).  Native GGUF layers stay exact. */
+ * over the whole k range -- the dataflow of the reference's GPU prompt pass (gpu_prefill.py:64-239, Marlin).  Native GGUF layers stay exact.
+ * 3 = the tolerance form on the register-staged kernels only (the LDS-ring kernel of kr_prefill_ring.hip off, process-wide): A/B and test hook,
+ * results are bit-identical to mode 1; 5 = the ring kernel for every shape it takes, not only problems that fill the chip (test hook, same bits). */
 int kr_moe_set_gemm_mode(kr_engine* e, int fast);
 /* expert-parallel combine: out[t] = sum_s w[t][s] * eo_rows[pair_row[t][s]] in routing order (moe.rs:661-667); pair_row -1 = skip */
 int kr_combine_rows(kr_engine* e, const float* eo_rows, const int32_t* pair_row, const float* weights, void* out, int M, int topk,

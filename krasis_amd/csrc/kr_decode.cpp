@@ -18,6 +18,7 @@
 #include "kr_decode_ops.h"
 #include "kr_engine_internal.h"
 #include "kr_kernels.h"
+#include "kr_prefill.h"
 #include "kr_router.h"
 #include "kr_sampler.h"
 #include <chrono>
@@ -1011,6 +1012,7 @@ extern "C" int kr_decode_set_option(kr_decode_store* s, const char* name, int va
     if (!strcmp(name, "la_heads")) { s->opt_la_heads = value != 0; s->graph_ok = false; return KR_OK; }        // exact step, linear-attention layers: 0 = in-projection + the one-launch conv / recurrence per KEY head (A/B and test hook)
     if (!strcmp(name, "lm_fused")) { s->opt_lm_fused = value != 0; s->graph_ok = false; return KR_OK; }        // KR_DECODE_FAST: 0 = final norm and vocabulary projection as two launches (A/B and test hook)
     if (!strcmp(name, "gqa_fused")) { s->opt_gqa_fused = value != 0; s->graph_ok = false; return KR_OK; }      // KR_DECODE_FAST, short caches: 0 = prep + attention as two launches (A/B and test hook)
+    if (!strcmp(name, "gemm_ring")) { kr_pfr_set_enabled(value); return KR_OK; }                              // KR_GEMM_FAST: 0 = register-staged tolerance GEMMs only, 1 = ring form for big problems (default), 2 = for every shape it takes (process-wide A/B and test hook; same bits)
     if (!strcmp(name, "pfm_timing")) { s->opt_pfm_timing = value != 0; return KR_OK; }
     if (!strcmp(name, "generate_lookahead")) { s->opt_gen_lookahead = value != 0; return KR_OK; }
     if (!strcmp(name, "ep_graph")) { s->opt_ep_graph = value != 0; s->graph_ok = false; return KR_OK; }

@@ -1215,9 +1215,10 @@ extern "C" int kr_moe_set_prefill_pairs(kr_engine* e, int pairs) {
 // (default); 1 = tolerance form (f16 activations, f32 accumulation over the whole k range -- the dataflow of the reference's GPU prompt pass)
 extern "C" int kr_moe_set_gemm_mode(kr_engine* e, int fast) {
     if (!e) return kr_fail(KR_ERR_VALUE, "null engine");
-    if (fast != 0 && fast != 1) return kr_fail(KR_ERR_VALUE, "gemm mode %d unknown (0 = exact, 1 = fast)", fast);
+    if (fast != 0 && fast != 1 && fast != 3 && fast != 5) return kr_fail(KR_ERR_VALUE, "gemm mode %d unknown (0 = exact, 1 = fast, 3 = fast on the register-staged kernels only, 5 = fast with the ring kernel for every shape it takes)", fast);
     std::lock_guard<std::mutex> lk(e->mu);
-    e->gemm_fast = fast;
+    e->gemm_fast = fast & 1;
+    if (fast) kr_pfr_set_enabled(fast == 1 ? 1 : (fast == 5 ? 2 : 0));      // 3: A/B and test hook, process-wide -- the LDS-ring GEMM (kr_prefill_ring.hip) off; results are bit-identical either way
     return KR_OK;
 }
 

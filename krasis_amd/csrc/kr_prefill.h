@@ -55,3 +55,5 @@ void kr_launch_pfh_w13_act(const KrMatDev& m, const uint16_t* a_h, const float* 
                            int single_expert_rows, float* gu, int rows, int act_mode, float swiglu_limit, float alpha, uint16_t* h_out, float* h_mul,
                            hipStream_t st, int run = 1, const uint16_t* a_sum32 = nullptr, uint16_t* h_sums32 = nullptr);
 void kr_launch_pfh_gemm_multi(const KrMatDev* mats, float* const* outs, const int* out_lds, int n, const uint16_t* a_h, const float* a_mul, int M, hipStream_t st);
+// the LDS-ring form of the INT4 tolerance GEMM (kr_prefill_ring.hip) is on by default; 0 keeps the register-staged kernels (process-wide A/B and test hook)
+void kr_pfr_set_enabled(int on);

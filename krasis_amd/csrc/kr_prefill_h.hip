@@ -33,9 +33,8 @@
 #include "kr_kernels.h"
 #include "kr_prefill.h"
 
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-typedef _Float16 v2h __attribute__((ext_vector_type(2)));
-typedef float v16f __attribute__((ext_vector_type(16)));
+#include "kr_pfh_dev.h"
+
 
 #define PFH_BM 64
 #ifdef KR_TIMING   // tools/probes/gemm_h_timing.hip: shader-clock stamps of wave 0 of one mid-grid workgroup at stage 3; no-op in the product build
@@ -109,8 +108,8 @@ __global__ void __launch_bounds__(256) kr_pfh_rows_kernel(const void* __restrict
     for (int c = threadIdx.x; c < K / 8; c += 256) {
         float v[8]; load8(c, v);
         u32x4 o;
-        o.x = pfh_pack_h2(v[0] * scl, v[1] * scl); o.y = pfh_pack_h2(v[2] * scl, v[3] * scl);
-        o.z = pfh_pack_h2(v[4] * scl, v[5] * scl); o.w = pfh_pack_h2(v[6] * scl, v[7] * scl);
+        o.x = pfh_pack_h2(v[0] * scl, v[4] * scl); o.y = pfh_pack_h2(v[1] * scl, v[5] * scl);      // image order (0,4,1,5,2,6,3,7): kr_pfh_dev.h
+        o.z = pfh_pack_h2(v[2] * scl, v[6] * scl); o.w = pfh_pack_h2(v[3] * scl, v[7] * scl);
         *reinterpret_cast<u32x4*>(out + (size_t)t * K + (size_t)c * 8) = o;
         if (sums) pfh_store_sum32(v, scl, c, sums + (size_t)t * (K / 32));
     }
@@ -153,8 +152,8 @@ __global__ void __launch_bounds__(256) kr_pfh_act_kernel(const float* __restrict
     for (int c = threadIdx.x; c < n / 8; c += 256) {
         float h[8]; act8(c, h);
         u32x4 o;
-        o.x = pfh_pack_h2(h[0] * scl, h[1] * scl); o.y = pfh_pack_h2(h[2] * scl, h[3] * scl);
-        o.z = pfh_pack_h2(h[4] * scl, h[5] * scl); o.w = pfh_pack_h2(h[6] * scl, h[7] * scl);
+        o.x = pfh_pack_h2(h[0] * scl, h[4] * scl); o.y = pfh_pack_h2(h[1] * scl, h[5] * scl);
+        o.z = pfh_pack_h2(h[2] * scl, h[6] * scl); o.w = pfh_pack_h2(h[3] * scl, h[7] * scl);
         *reinterpret_cast<u32x4*>(out + (size_t)row * n + (size_t)c * 8) = o;
     }
     if (threadIdx.x == 0) mul[row] = inv * 0.0625f;
@@ -206,8 +205,8 @@ __global__ void __launch_bounds__(256) kr_pfh_act_wave_kernel(const float* __res
         const int c = lane + 64 * q;
         if (c * 8 < n) {
             u32x4 o;
-            o.x = pfh_pack_h2(h[q][0] * scl, h[q][1] * scl); o.y = pfh_pack_h2(h[q][2] * scl, h[q][3] * scl);
-            o.z = pfh_pack_h2(h[q][4] * scl, h[q][5] * scl); o.w = pfh_pack_h2(h[q][6] * scl, h[q][7] * scl);
+            o.x = pfh_pack_h2(h[q][0] * scl, h[q][4] * scl); o.y = pfh_pack_h2(h[q][1] * scl, h[q][5] * scl);
+            o.z = pfh_pack_h2(h[q][2] * scl, h[q][6] * scl); o.w = pfh_pack_h2(h[q][3] * scl, h[q][7] * scl);
             *reinterpret_cast<u32x4*>(out + (size_t)row * n + (size_t)c * 8) = o;
             if (sums) pfh_store_sum32(h[q], scl, c, sums + (size_t)row * (n / 32));
         }
@@ -218,114 +217,9 @@ __global__ void __launch_bounds__(256) kr_pfh_act_wave_kernel(const float* __res
 // ------------------------------------------------------------------------------------------
 // the GEMM
 // ------------------------------------------------------------------------------------------
-struct KrPfGemmHArgs {
-    KrMatDev m;
-    const uint16_t* a; const float* a_mul;   // f16 rows [rows_or_tokens][K], row multipliers
-    const uint16_t* a_sum;                   // G = 1 (Q4_K copy): f16 sums of every 32 consecutive values of a row, [rows_or_tokens][K / 32]
-    const int* row_pair; int topk; int gather_tokens;
-    const int* tile_expert; const int* tile_row0; const int* tile_rows; const int* n_tiles;
-    float* out; int out_ld;
-    int single_expert; int total_rows; int scatter_rows; int out_bf16;      // out_bf16: element type of out 0 f32, 1 bf16, 2 f16
-    int act_fused; float act_limit, act_alpha;      // gate | up GEMM of 256-column tiles: h = act(gate, up) formed in the epilogue, out = [rows][N / 2] f32
-    int run;                                 // experts: consecutive row tiles given to one XCD (> 1: the tiles of one expert share an L2)
-    int sr, sc;                              // dense: super-tile of sr row tiles x sc column blocks per XCD (kr_pf_super_tile)
-    int n_extra; KrMatDev mx[2]; float* outx[2]; int out_ldx[2];
-};
-
-// one packed INT4 word (nibbles k .. k + 7 of a column) -> 8 f16 in the order (0,4,1,5,2,6,3,7); sq = s / 4 (both halves), cq = -1536 * sq.
-// 12 VALU: and + (shift | or) for the two low pairs, shift + and-or for the two high pairs, 4 packed fma.  M0 / M1 / M2 / Kc are held in registers by the
-// caller (opaque to the compiler): VOP3 takes no literal on gfx9, with literals the compiler falls back to separate v_and / v_or (16 VALU).
-__device__ __forceinline__ v8h pfh_dq4(uint32_t w, v2h sq, v2h cq, uint32_t M0, uint32_t M1, uint32_t MH, uint32_t Kc) {
-    const uint32_t t0 = ((w & M0) << 6) | Kc;                  // v_and, v_lshl_or       (n0, n4) at mantissa bits 6..9
-    const uint32_t t1 = ((w & M1) << 2) | Kc;                  // v_and, v_lshl_or       (n1, n5)
-    const uint32_t t2 = ((w >> 2) & MH) | Kc;                  // v_lshrrev, v_and_or    (n2, n6)
-    const uint32_t t3 = ((w >> 6) & MH) | Kc;                  // v_lshrrev, v_and_or    (n3, n7)
-    const v2h r0 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, t0), sq, cq), r1 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, t1), sq, cq);
-    const v2h r2 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, t2), sq, cq), r3 = __builtin_elementwise_fma(__builtin_bit_cast(v2h, t3), sq, cq);
-    return v8h{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
-}
-// 8 INT8 weights (two words, natural k order) -> 8 f16: (1024 + (b ^ 0x80)) - 1152 = b, times sb = s * 16
-__device__ __forceinline__ v8h pfh_dq8(uint32_t w0, uint32_t w1, v2h sb) {
-    const uint32_t x0 = w0 ^ 0x80808080u, x1 = w1 ^ 0x80808080u, Kc = 0x64646464u;
-    const v2h off = {(_Float16)-1152.0f, (_Float16)-1152.0f};
-    // v_perm: selector bytes 0-3 pick from the second operand, 4-7 from the first
-    const uint32_t t0 = __builtin_amdgcn_perm(Kc, x0, 0x04010400u), t1 = __builtin_amdgcn_perm(Kc, x0, 0x04030402u);
-    const uint32_t t2 = __builtin_amdgcn_perm(Kc, x1, 0x04010400u), t3 = __builtin_amdgcn_perm(Kc, x1, 0x04030402u);
-    const v2h r0 = (__builtin_bit_cast(v2h, t0) + off) * sb, r1 = (__builtin_bit_cast(v2h, t1) + off) * sb;
-    const v2h r2 = (__builtin_bit_cast(v2h, t2) + off) * sb, r3 = (__builtin_bit_cast(v2h, t3) + off) * sb;
-    return v8h{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
-}
 
 
-// Stores of a 32 x 32 accumulator block set: lane (n31, khalf) holds column n31 of 16 rows (r & 3) + 8 (r >> 2) + 4 khalf.  FULL: every row and column
-// of the tile is valid and rows are stored in GEMM order (no scatter): the row base is wave-uniform (scalar), the lane part one 32-bit offset, no
-// exec-mask branches -- the guarded form costs ~20 instructions and two branches per store.  BF16: round to bf16 (RNE) on the way out.
-// OT: element type of the output 0 f32, 1 bf16 (RNE), 2 f16 (the expert rows of the tolerance mode: half the bytes for the store and for the combine pass;
-// RAW accumulators -- the kernel parks multipliers of 1 -- so the values are O(1..100) for any row magnitude; kr_pf_combine_kernel<2> applies the row multiplier).
-// ACTF != 0 (NC == 2, gate | up GEMM): column block 0 holds gate columns, block 1 the matching up columns -- the epilogue forms h = act(g, u) and stores ONE
-// value per pair at the hidden column (f32): the [rows, 2 I] gate | up matrix is never written or re-read.  1 = silu with the poly-5 sigmoid
-// (avx2.rs:2331), 2 = GPT-OSS (moe.rs:268-287), 3 = libm silu (gguf_kernels.rs:733-737).
-__device__ __forceinline__ float pfh_act(int ACTF, float g, float u, float limit, float alpha) {      // ACTF is wave-uniform
-    if (ACTF == 2) {
-        float gate = g, up = u;
-        if (gate > limit) gate = limit;
-        if (up > limit) up = limit;
-        if (up < -limit) up = -limit;
-        return (up + 1.0f) * (gate * kr_sigmoid_poly5_scalar(gate * alpha));
-    }
-    if (ACTF == 3) return (g / (1.0f + kr_expf(-g))) * u;
-    return (g * kr_sigmoid_poly5(g)) * u;
-}
-template <int OT> __device__ __forceinline__ void pfh_put(void* base, size_t idx, float v) {
-    if (OT == 1) reinterpret_cast<uint16_t*>(base)[idx] = kr_f32_to_bf16(v);
-    else if (OT == 2) { const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);     // saturates instead of overflowing to inf
-         reinterpret_cast<uint16_t*>(base)[idx] = __builtin_bit_cast(uint16_t, h); }
-    else reinterpret_cast<float*>(base)[idx] = v;
-}
-template <int NSB, int NC, bool FULL, int OT, bool ACT, typename ACC>
-__device__ __forceinline__ void pfh_store_tile(const ACC& acc, int nsb, int rows, int row0, const float* rmul, const int* row_dst, void* out_p, int out_ld,
-                                               const int (&col)[NC], int N, int lane, int ACTF = 0, float limit = 0.0f, float alpha = 0.0f) {
-    const int khalf = lane >> 5;
-    constexpr int NCS = ACT ? 1 : NC;       // stores per (row, lane)
-    constexpr size_t ESZ = OT == 0 ? 4 : 2;
-#pragma unroll
-    for (int s = 0; s < NSB; s++) {
-        if (s >= nsb) break;
-#pragma unroll
-        for (int rq = 0; rq < 4; rq++) {
-            const int rowb = s * 32 + 8 * rq + 4 * khalf;
-            const float4 rm4 = *reinterpret_cast<const float4*>(rmul + rowb);
-            const float rm[4] = {rm4.x, rm4.y, rm4.z, rm4.w};
-            if (FULL) {
-                const uint32_t lane_off = (uint32_t)(4 * khalf) * (uint32_t)out_ld;      // elements; + col below
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    char* rb = reinterpret_cast<char*>(out_p) + (size_t)(row0 + s * 32 + 8 * rq + i) * out_ld * ESZ;     // wave-uniform
-#pragma unroll
-                    for (int c = 0; c < NCS; c++) {
-                        float v = acc[s][c][rq * 4 + i] * rm[i];
-                        if (ACT) v = pfh_act(ACTF, v, acc[s][NC - 1][rq * 4 + i] * rm[i], limit, alpha);
-                        pfh_put<OT>(rb, (size_t)(lane_off + (uint32_t)col[c]), v);
-                    }
-                }
-            } else {
-                const int4 rd4 = *reinterpret_cast<const int4*>(row_dst + rowb);
-                const int rd[4] = {rd4.x, rd4.y, rd4.z, rd4.w};
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (rowb + i < rows) {
-#pragma unroll
-                        for (int c = 0; c < NCS; c++)
-                            if (col[c] < N) {
-                                float v = acc[s][c][rq * 4 + i] * rm[i];
-                                if (ACT) v = pfh_act(ACTF, v, acc[s][NC - 1][rq * 4 + i] * rm[i], limit, alpha);
-                                pfh_put<OT>(out_p, (size_t)rd[i] * out_ld + col[c], v);
-                            }
-                    }
-            }
-        }
-    }
-}
+
 
 // SB = 1: the de-quantized B fragments of a k-step are SINGLE-buffered -- fragment (c, h) of step t + 1 is formed right after the MFMAs of step t that
 // read fragment (c, h) have been issued, into the same registers (16 registers less than two fragment sets, 8 less for the raw INT4 words): the
@@ -339,7 +233,7 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
     static_assert(G == 0 || (SB == 1 && BITS == 4) || (SB == 0 && BITS == 8), "the Q4_K copy runs the single-buffered INT4 form, the Q8_0 copy the INT8 form");
     constexpr int BN = 128 * NC, LDA = PFH_LDA, LDB = BITS == 8 ? PFH_LDB8 : PFH_LDB4, NS = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                                               // [64][LDA]  f16; BITS == 4: k permuted (0,4,1,5,2,6,3,7) inside every 8
+    char* As = smem;                                               // [64][LDA]  f16; BITS == 4: k in image order (0,4,1,5,2,6,3,7) inside every 8, BITS == 8: natural
     char* Bs = As + PFH_BM * LDA;                                  // [BN][LDB]  packed lane records, copied verbatim
     float* rmul = reinterpret_cast<float*>(Bs + BN * LDB);         // [64]
     int* row_src = reinterpret_cast<int*>(rmul + PFH_BM);          // [64]
@@ -491,9 +385,9 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
 #pragma unroll
         for (int j = 0; j < APT; j++) {
             u32x4 v = pa[j];
-            if (BITS == 4)      // (a0,a1 | a2,a3 | a4,a5 | a6,a7) -> (a0,a4 | a1,a5 | a2,a6 | a3,a7)
-                v = u32x4{__builtin_amdgcn_perm(v.z, v.x, 0x05040100u), __builtin_amdgcn_perm(v.z, v.x, 0x07060302u),
-                          __builtin_amdgcn_perm(v.w, v.y, 0x05040100u), __builtin_amdgcn_perm(v.w, v.y, 0x07060302u)};
+            if (BITS == 8)      // the row image holds (a0,a4 | a1,a5 | a2,a6 | a3,a7) (kr_pfh_dev.h); pfh_dq8 emits natural k order: (a0,a1 | a2,a3 | a4,a5 | a6,a7)
+                v = u32x4{__builtin_amdgcn_perm(v.y, v.x, 0x05040100u), __builtin_amdgcn_perm(v.w, v.z, 0x05040100u),
+                          __builtin_amdgcn_perm(v.y, v.x, 0x07060302u), __builtin_amdgcn_perm(v.w, v.z, 0x07060302u)};
             *reinterpret_cast<u32x4*>(As + (arow + 8 * j) * LDA + aseg * 128 + achk * 16) = v;
         }
         if (BITS == 8) {
@@ -717,6 +611,7 @@ static void pfh_launch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
     hipLaunchKernelGGL((kr_pfh_gemm_kernel<NC, BITS, SB, G, OCC>), grid, dim3(256), lds, st, b);
 }
 static void pfh_dispatch(const KrPfGemmHArgs& a, int mt, hipStream_t st) {
+    if (kr_pfr_try_launch(a, mt, st) == 0) return;       // big INT4 problems: the LDS-ring form (bit-identical results)
     if (a.m.bits == 8) { if (a.m.qs) pfh_launch<1, 8, 0, 1>(a, mt, st); else pfh_launch<1, 8>(a, mt, st); return; }
     // 256-column tiles when they still fill the chip (>= 2 workgroups per CU), else 128-column tiles
     long n128 = (a.m.N + 127) / 128;
@@ -787,7 +682,7 @@ void kr_launch_pfh_w13_act(const KrMatDev& m, const uint16_t* a_h, const float* 
     a.out = gu; a.out_ld = I; a.single_expert = single_expert_rows > 0; a.total_rows = single_expert_rows;
     a.run = (single_expert_rows > 0 || run < 1) ? 1 : run;
     a.act_fused = act_mode == KR_ACT_GPTOSS ? 2 : (act_mode == KR_ACT_SILU_LIBM ? 3 : 1); a.act_limit = swiglu_limit; a.act_alpha = alpha;
-    if (m.qs) pfh_launch<2, 4, 1, 1>(a, mt, st); else pfh_launch<2, 4, 1>(a, mt, st);
+    if (m.qs) pfh_launch<2, 4, 1, 1>(a, mt, st); else if (kr_pfr_try_launch(a, mt, st) != 0) pfh_launch<2, 4, 1>(a, mt, st);
     const int cpl = I <= 512 ? 1 : (I <= 1024 ? 2 : 4);
 #define KR_ROWW(C_) hipLaunchKernelGGL((kr_pfh_act_wave_kernel<KR_ACT_NONE, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, (const float*)gu, rows, I, I, 0.0f, 0.0f, h_out, h_mul, h_sums32)
     if (rows > 0) { if (cpl == 1) KR_ROWW(1); else if (cpl == 2) KR_ROWW(2); else KR_ROWW(4); }

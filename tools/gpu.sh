@@ -239,6 +239,12 @@ tests)      # the whole GPU suite, as the driver runs it
 bench)      # the driver's bench line
     timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 "$@" > $R/bench_line.json 2> $R/bench_line.err; echo "bench rc=$?"; tail -c 3000 $R/bench_line.json
     ;;
+ring1)      # round 6: LDS-ring tolerance GEMM -- bit identity against the register-staged kernels, tolerance tests, interleaved experts-only A/B
+    timeout 900 python -m pytest tests/test_gemm_ring_gpu.py -x -q 2>&1 | tail -15
+    timeout 900 python -m pytest tests/test_gemm_fast_gpu.py -x -q 2>&1 | tail -5
+    timeout 600 python tools/probes/experts_gemm_probe.py 16 8192 staged,fast,staged,fast 2>&1 | grep experts-only
+    timeout 600 python tools/probes/experts_gemm_probe.py 16 2752 staged,fast,staged,fast 2>&1 | grep experts-only
+    ;;
 *)
     echo "unknown step $step"; exit 2;;
 esac
