@@ -239,6 +239,17 @@ tests)      # the whole GPU suite, as the driver runs it
 bench)      # the driver's bench line
     timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 "$@" > $R/bench_line.json 2> $R/bench_line.err; echo "bench rc=$?"; tail -c 3000 $R/bench_line.json
     ;;
+ringp)      # round 6: the stand-alone probe of the ring GEMM (dense problem): bit comparison, timing of both forms, stamps
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -o /tmp/grp tools/probes/gemm_ring_probe.hip 2>&1 | grep -E "error" -A3
+    /tmp/grp 4096 2048 12288 | grep -v "^  mismatch"; /tmp/grp 8192 2048 4096 | grep -v "^  mismatch"; /tmp/grp 2752 2048 12288 | grep -v "^  mismatch"
+    ;;
+ringabl)    # round 6: ablations of the ring GEMM's loop (results wrong by construction): what bounds a unit
+    for abl in 0 1 2 4 8 3 7 15; do
+        hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -DPFR_ABL=$abl -o /tmp/grp$abl tools/probes/gemm_ring_probe.hip 2>&1 | grep -E "error" -A3
+        echo "== PFR_ABL=$abl (1 no de-quantization, 2 no requests in the loop, 4 no fragment reads in the loop, 8 no barriers in the loop)"
+        /tmp/grp$abl 4096 2048 12288 | grep "ring   rep [23]\|ring stamps"
+    done
+    ;;
 ring1)      # round 6: LDS-ring tolerance GEMM -- bit identity against the register-staged kernels, tolerance tests, interleaved experts-only A/B
     timeout 900 python -m pytest tests/test_gemm_ring_gpu.py -x -q 2>&1 | tail -15
     timeout 900 python -m pytest tests/test_gemm_fast_gpu.py -x -q 2>&1 | tail -5

@@ -77,8 +77,9 @@ int main(int argc, char** argv) {
     unsigned long long t[64]; CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(kr_rstamps), sizeof(t)));
     for (int w = 0; w < 2; w++) {
         const unsigned long long* p = t + 32 * w;
-        printf("ring stamps wave %d (shader clocks from kernel entry): setup %lld | B(0) landed %lld | first fragments %lld | last stage: wait+barrier..issue %lld, issue..unit0 done %lld | loop end %lld | stores %lld\n",
-               4 * w, (long long)(p[1] - p[0]), (long long)(p[2] - p[0]), 0LL, (long long)(p[4] - p[3]), (long long)(p[5] - p[4]), (long long)(p[6] - p[0]), (long long)(p[7] - p[6]));
+        printf("ring stamps wave %d (shader clocks): prologue to first barrier %lld | to loop start %lld | mid-loop unit (q = 0): wait + barrier %lld, unit body %lld | whole loop %lld (%d units: %.0f per unit) | stores %lld\n",
+               4 * w, (long long)(p[1] - p[0]), (long long)(p[2] - p[0]), (long long)(p[9] - p[8]), (long long)(p[10] - p[9]), (long long)(p[6] - p[2]), 2 * m.ng,
+               (double)(p[6] - p[2]) / (2 * m.ng), (long long)(p[7] - p[6]));
     }
     return 0;
 }
