@@ -656,6 +656,9 @@ void kr_launch_moe_w2(const KrMoeArgs& a, hipStream_t st) {
 int kr_launch_moe_w2c(const KrMoeArgs& a, const float* gate_val, float* out, hipStream_t st) {
     const bool has_shared = a.n_slots > a.topk;
     if (a.B != 1 || a.n_slots < 1 || a.n_slots > 16 || a.topk < 1 || a.H % 8 || a.I % 128 || (has_shared && (a.I_shared % 128 || a.sw2.bits != a.w2.bits)) || a.e_hi > 0) return 1;
+    // the GPT-OSS activation of this kernel is a hand copy of kr_prologue_hidden's branch that no bit-exact decode test reaches (the oracle's decode driver has no
+    // GPT-OSS model): such layers keep the per-slot launch + the combine inside the next norm launch, which the kr_moe_forward tests cover
+    if (a.act_mode == KR_ACT_GPTOSS) return 1;
     const int imax = has_shared && a.I_shared > a.I ? a.I_shared : a.I;
     const size_t img = (kr_lds_bytes(imax, a.w2.bits == 8) + 15) / 16 * 16, lds = img * a.n_slots;
     if (lds > 60 * 1024) return 1;
@@ -663,11 +666,9 @@ int kr_launch_moe_w2c(const KrMoeArgs& a, const float* gate_val, float* out, hip
 #define KR_W2C(B_, A_) hipLaunchKernelGGL((kr_moe_w2c_kernel<B_, A_>), grid, block, lds, st, a.gu, a.ids, a.wts, gate_val, a.gu_ld, a.I, a.I_shared, a.topk, (int)(img / 16), out, a)
     if (a.w2.bits == 4) {
         if (a.act_mode == KR_ACT_SILU_FUSED) KR_W2C(4, KR_ACT_SILU_FUSED);
-        else if (a.act_mode == KR_ACT_GPTOSS) KR_W2C(4, KR_ACT_GPTOSS);
         else KR_W2C(4, KR_ACT_SILU_MUL);
     } else {
         if (a.act_mode == KR_ACT_SILU_FUSED) KR_W2C(8, KR_ACT_SILU_FUSED);
-        else if (a.act_mode == KR_ACT_GPTOSS) KR_W2C(8, KR_ACT_GPTOSS);
         else KR_W2C(8, KR_ACT_SILU_MUL);
     }
 #undef KR_W2C

@@ -98,8 +98,8 @@ __global__ void kr_pfm_quant_f32_kernel(const float* __restrict__ x, int ld, int
 // and walks them down the 8 tokens with the 4-tap window in registers: 11 row reads of 16 bytes per lane (round 2-4: one channel per thread, 4-byte reads -- the
 // launch moved 180 MB per 2731-token chunk at 1.1 TB/s, 5.9 % of the tolerance prompt pass).  Tap j of token t is X(t-3+j): a chunk row for >= 0, the carried conv
 // state slot 4+i for i < 0.  Per value the arithmetic is unchanged: the tap products are added left to right, SiLU with the degree-5 sigmoid, the two L2 norms as
-// 8-lane fma chains over the head's 128 conv outputs.  Needs dk % 4 == 0, dv % 4 == 0 and (2 dk + hr dv) / 4 <= 128 (the launcher falls back to one tile of channels
-// per pass otherwise: the loop below strides over channel quads).
+// 8-lane fma chains over the head's conv outputs.  Needs dk % 4 == 0, dv % 4 == 0 and ld_qkvz % 4 == 0 (kr_launch_pfm_la refuses other shapes); any channel count and
+// any hr: the channel-quad loop, the z copy and the gate block all stride over the workgroup's threads.
 #define PFC_TT 8
 #define PFC_WT 16      // tokens per workgroup
 __global__ void __launch_bounds__(256) kr_pfm_la_conv_kernel(const KrPfmLaArgs a, int C) {
@@ -149,8 +149,8 @@ __global__ void __launch_bounds__(256) kr_pfm_la_conv_kernel(const KrPfmLaArgs a
         *reinterpret_cast<float4*>(a.z + (size_t)(w0 + tt) * nvdv + (size_t)(kh * hr + r) * dv + i) =
             *reinterpret_cast<const float4*>(a.qkvz + (size_t)(w0 + tt) * a.ld_qkvz + (size_t)kh * group_dim + 2 * dk + hr * dv + r * dv + i);
     }
-    if ((int)threadIdx.x < nw * hr) {   // decode.rs:3891-3901
-        const int tt = threadIdx.x / hr, r = threadIdx.x % hr, vh = kh * hr + r, t = w0 + tt;
+    for (int gi = threadIdx.x; gi < nw * hr; gi += 256) {   // decode.rs:3891-3901; strided: 16 tokens x hr value heads per key head can exceed the 256 threads (hr > 16)
+        const int tt = gi / hr, r = gi % hr, vh = kh * hr + r, t = w0 + tt;
         const float* ba = a.ba + (size_t)t * a.ld_ba;
         const float b_raw = ba[kh * 2 * hr + r], a_p = ba[kh * 2 * hr + hr + r];
         a.beta[(size_t)t * a.nv + vh] = 1.0f / (1.0f + kr_expf(-b_raw));

@@ -4,7 +4,7 @@ reference's CPU decode, src/decode.rs:2690-3520 -- tests/test_decode_gpu.py) on 
 What FAST changes: the ORDER of the f32 sums only (lane / wave / workgroup trees instead of the reference's sequential chains: RMSNorm sum of
 squares, per-group scale chains of the matvecs, softmax denominator, the kv / output chains of the gated delta rule, L2 norms) and the launch
 structure.  The products are the reference's: INT16 activation digits, exact integer group sums, bf16(w_scale) * a_scale, the poly-5 sigmoid,
-libm exp / log for the gates.  STATED TOLERANCES (each asserted below, measured values are appended to gpurun_out/r03_decode_fast_err.txt):
+libm exp / log for the gates.  STATED TOLERANCES (each asserted below, measured values are appended to gpurun_out/decode_fast_err.txt):
     logits        max |fast - exact| <= 2e-3 * max |exact|      (a last-bit difference of a layer output moves single INT16 digits of the next
                                                                   projection's input by one step; that step is what the logits see)
     state         recurrent / conv state and KV rows written by the steps: <= 2e-3 of the tensor's largest magnitude (fp16 KV rows: 1 ulp of fp16 on top)
@@ -24,7 +24,7 @@ F = np.float32
 
 def _log(msg):
     if os.path.isdir("gpurun_out"):
-        with open("gpurun_out/r03_decode_fast_err.txt", "a") as f:
+        with open("gpurun_out/decode_fast_err.txt", "a") as f:
             f.write(msg + "\n")
 
 

@@ -15,14 +15,15 @@ def _ptr(a):
     return a.ctypes.data
 
 
-def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4, dims=None, kinds=None, la_heads=(2, 4), peaked=False, gguf=False):
+def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbits=4, kv_max=32, hd=64, nh=4, dims=None, kinds=None, la_heads=(2, 4), peaked=False, gguf=False,
+          la_dkdv=(128, 128)):
     """peaked=True: a model whose next-token distribution is PEAKED without training -- large embeddings, lm_head tied to them (x 0.05): the logit of the
     current token stands ~8 above the rest, the layers (attention, router, experts) perturb it by an amount comparable to the noise floor, so on a token
     stream with repeats the perplexity is O(10) and a routing flip or a tolerance-mode rounding difference shows up in it (tests/test_tolerance_peaked_gpu.py)"""
     from krasis_amd import CpuDecodeStore, KrasisEngine, ModelConfig
     rng = np.random.default_rng(seed)
     H, V, E, k, I, SI = dims or (256, 512, 16, 4, 128, 128)
-    (nk, nv), dk, dv = la_heads, 128, 128
+    (nk, nv), (dk, dv) = la_heads, la_dkdv
     nkv, d2 = 2, 8
     kinds = kinds or (["la", "gqa", "la"] + (["gqa"] if with_dense else []))
     nL = len(kinds)
@@ -109,7 +110,8 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbit
 
 
 @pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True), dict(wbits=8, with_dense=True),
-                                 dict(dims=(256, 512, 16, 4, 128, 384), seed=3)])      # shared expert three times as wide as the routed ones (V2-Lite has 2 x)
+                                 dict(dims=(256, 512, 16, 4, 128, 384), seed=3),       # shared expert three times as wide as the routed ones (V2-Lite has 2 x)
+                                 dict(la_dkdv=(64, 64), seed=4), dict(la_dkdv=(128, 64), la_heads=(2, 2), seed=5)])   # the 64-wide key / value head forms of the in-projection epilogue and the per-value-head recurrence
 @pytest.mark.parametrize("graph", [True, False])
 @pytest.mark.parametrize("round5_forms", [1, 0])
 def test_decode_step_bit_exact(cfg, graph, round5_forms):

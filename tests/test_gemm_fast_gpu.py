@@ -77,7 +77,7 @@ def test_fast_expert_gemm_vs_exact(H, I, E, k, M, n_shared, bits, w2_bits):
     rowmax = np.abs(ex).max(axis=1); ok = rowmax > 0
     worst = float((np.abs(fa - ex).max(axis=1)[ok] / rowmax[ok]).max())
     if os.path.isdir("gpurun_out"):
-        with open("gpurun_out/r02_gemm_fast_err.txt", "a") as f:
+        with open("gpurun_out/gemm_fast_err.txt", "a") as f:
             f.write(f"experts H={H} I={I} E={E} k={k} M={M} shared={n_shared} bits={bits}/{w2_bits}: rel_rms={rel:.3e} worst_row_rel={worst:.3e}\n")
     assert rel <= 1e-3, rel
     assert worst <= 5e-3, worst
@@ -110,7 +110,7 @@ def test_fast_gemm_is_closer_to_real_arithmetic_than_its_tolerance():
     den = np.sqrt(np.mean(ref ** 2))
     e_ex = float(np.sqrt(np.mean((ex - ref) ** 2)) / den); e_fa = float(np.sqrt(np.mean((fa - ref) ** 2)) / den)
     if os.path.isdir("gpurun_out"):
-        with open("gpurun_out/r02_gemm_fast_err.txt", "a") as f:
+        with open("gpurun_out/gemm_fast_err.txt", "a") as f:
             f.write(f"vs float64 on de-quantized weights: exact form {e_ex:.3e}, tolerance form {e_fa:.3e}\n")
     assert e_ex < 5e-3, e_ex            # the layout reading of _deq_t is right (the exact form is the oracle's arithmetic)
     assert e_fa <= max(3.0 * e_ex, 5e-4), (e_fa, e_ex)
@@ -144,7 +144,7 @@ def test_gemm_fast_prompt_pass_logits_and_perplexity(kinds, fp8):
     rel = abs(b["perplexity"] / a["perplexity"] - 1.0); dn = abs(b["mean_loss"] - a["mean_loss"])
     lrel = float(np.abs(res[False][1] - res[True][1]).max() / np.abs(res[False][1]).max())
     if os.path.isdir("gpurun_out"):
-        with open("gpurun_out/r02_gemm_fast_err.txt", "a") as f:
+        with open("gpurun_out/gemm_fast_err.txt", "a") as f:
             f.write(f"prompt pass kinds={'+'.join(kinds)} fp8={fp8}: ppl exact {a['perplexity']:.6f} fast {b['perplexity']:.6f} rel {rel:.3e} "
                     f"mean-nll diff {dn:.3e} logits rel {lrel:.3e}\n")
     assert np.isfinite(res[True][1]).all()
@@ -168,7 +168,7 @@ def test_gemm_fast_mla_prompt_pass(cfg):
         res[mode] = (pl.copy(), ptok)
     rel = float(np.abs(res[False][0] - res[True][0]).max() / np.abs(res[False][0]).max())
     if os.path.isdir("gpurun_out"):
-        with open("gpurun_out/r02_gemm_fast_err.txt", "a") as f:
+        with open("gpurun_out/gemm_fast_err.txt", "a") as f:
             f.write(f"mla prompt pass cfg={cfg}: logits rel {rel:.3e}\n")
     assert np.isfinite(res[True][0]).all() and rel <= 1e-2, rel
     assert res[False][1] == res[True][1]

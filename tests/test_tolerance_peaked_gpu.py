@@ -2,7 +2,7 @@
 perplexity ~ vocabulary size, where a relative perplexity bound says little).  tests/test_decode_gpu.build(peaked=True): embeddings tied to lm_head
 so that the current token's logit leads by ~8; token stream = a Markov chain that repeats the previous token with probability 0.8 -- the exact
 mode's perplexity is O(10), every layer (linear attention, gated GQA, router, experts, shared expert) contributes at the noise-floor level, and a
-flipped expert or a last-bit difference moves the score of many positions.  Reported per mode (appended to gpurun_out/r03_tolerance_peaked.txt) and
+flipped expert or a last-bit difference moves the score of many positions.  Reported per mode (appended to gpurun_out/tolerance_peaked.txt) and
 asserted:
     KR_ATTN_FAST, KR_ATTN_FAST | KR_GEMM_FAST   prompt pass (evaluate_perplexity = perplexity/measure_ppl.py:154-297): |PPL_fast / PPL_exact - 1| <= 2e-3
                                                 (measured on MI355X: 0.8e-5 .. 3.0e-4); per-position NLL: at most 1 % of the positions move by more than 2e-2
@@ -32,7 +32,7 @@ def _stream(V, n, seed=0):
 
 def _log(msg):
     if os.path.isdir("gpurun_out"):
-        with open("gpurun_out/r03_tolerance_peaked.txt", "a") as f:
+        with open("gpurun_out/tolerance_peaked.txt", "a") as f:
             f.write(msg + "\n")
 
 

@@ -19,7 +19,7 @@ kstats() {   # kstats <name> <title> -- <command...>: rocprofv3 --kernel-trace -
 case "$step" in
 fast1)      # KR_DECODE_FAST bring-up: parity tests, exact vs fast decode bench, kernel trace of the fast graph
     timeout 900 python -m pytest tests/test_decode_fast_gpu.py -x -q 2>&1 | tail -25
-    cat $R/r03_decode_fast_err.txt 2>/dev/null
+    cat $R/decode_fast_err.txt 2>/dev/null
     timeout 600 python tools/probes/decode_fast_bench.py "$@" 2>&1 | tail -60
     kstats r03_decode_fast "QCN Q4 decode step, KR_DECODE_FAST, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only fast --steps 30)" -- \
         python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r03_decode_fast_prof
@@ -31,13 +31,13 @@ fastbench)  # only the bench probe (+ trace)
     ;;
 fast2)      # remaining FAST tests, in-kernel phase stamps (probe build), then the whole GPU suite
     timeout 900 python -m pytest tests/test_decode_fast_gpu.py -q -k "router or generate" 2>&1 | tail -8
-    cat $R/r03_decode_fast_err.txt 2>/dev/null | tail -4
+    cat $R/decode_fast_err.txt 2>/dev/null | tail -4
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
     timeout 2400 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -6
     ;;
 fast3)      # FAST tests + stamps + bench probe (no trace)
     timeout 900 python -m pytest tests/test_decode_fast_gpu.py -x -q 2>&1 | tail -5
-    tail -16 $R/r03_decode_fast_err.txt
+    tail -16 $R/decode_fast_err.txt
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so timeout 300 python tools/probes/decode_fast_stamps.py 2>&1 | tail -7
     timeout 600 python tools/probes/decode_fast_bench.py --only fast --route-tokens 200 "$@" 2>&1 | tail -14
     ;;
