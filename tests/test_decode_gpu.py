@@ -111,7 +111,8 @@ def build(seed=0, norm_bias_one=True, scoring=1, rsf=1.0, with_dense=False, wbit
 
 @pytest.mark.parametrize("cfg", [dict(), dict(norm_bias_one=False, scoring=0, rsf=2.5), dict(with_dense=True), dict(wbits=8, with_dense=True),
                                  dict(dims=(256, 512, 16, 4, 128, 384), seed=3),       # shared expert three times as wide as the routed ones (V2-Lite has 2 x)
-                                 dict(la_dkdv=(64, 64), seed=4), dict(la_dkdv=(128, 64), la_heads=(2, 2), seed=5)])   # the 64-wide key / value head forms of the in-projection epilogue and the per-value-head recurrence
+                                 dict(la_dkdv=(64, 64), seed=4), dict(la_dkdv=(128, 64), la_heads=(2, 2), seed=5),    # the 64-wide key / value head forms of the in-projection epilogue and the per-value-head recurrence
+                                 dict(dims=(256, 512, 512, 10, 128, 128), seed=6), dict(dims=(256, 512, 256, 8, 128, 128), seed=7, kinds=["la", "gqa"])])   # E = 512 / 256: the fused router's selection with the exponentials on four waves (8 / 4 values per lane)
 @pytest.mark.parametrize("graph", [True, False])
 @pytest.mark.parametrize("round5_forms", [1, 0])
 def test_decode_step_bit_exact(cfg, graph, round5_forms):

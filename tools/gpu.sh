@@ -79,14 +79,14 @@ fastpmc)    # HBM fetch bytes per launch of the KR_DECODE_FAST kernels: counters
     ;;
 newtests)   # tests added since the last full-suite run
     timeout 900 python -m pytest tests/test_tolerance_peaked_gpu.py tests/test_moe_gpu.py tests/test_decode_gpu.py -x -q 2>&1 | tail -8
-    cat $R/r03_tolerance_peaked.txt 2>/dev/null
+    cat $R/tolerance_peaked.txt 2>/dev/null
     ;;
 q4k)        # Q4_K tolerance form: parity test, experts-only timing (exact int8 form vs f16 form), peaked-model + export tests that have not run yet
     timeout 900 python -m pytest tests/test_gguf_gpu.py -x -q -k "tolerance_form" 2>&1 | tail -6
     cat $R/r03_q4k_fast_err.txt 2>/dev/null
     timeout 300 python tools/probes/experts_gemm_probe.py 8 8192 q4kfast,q4k,fast 2>&1 | grep experts-only
     timeout 900 python -m pytest tests/test_tolerance_peaked_gpu.py tests/test_moe_gpu.py -x -q 2>&1 | tail -5
-    cat $R/r03_tolerance_peaked.txt 2>/dev/null
+    cat $R/tolerance_peaked.txt 2>/dev/null
     ;;
 gemmtrace)  # kernel trace of the experts-only tolerance pass (which launches carry the 1.2 ms per layer)
     kstats r03_experts_8192_gemm_fast "QCN experts only, 8192 tokens x 16 layers, tolerance GEMM (tools/probes/experts_gemm_probe.py 16 8192 fast)" -- python /root/repo/tools/probes/experts_gemm_probe.py 16 8192 fast
@@ -238,6 +238,12 @@ tests)      # the whole GPU suite, as the driver runs it
     ;;
 bench)      # the driver's bench line
     timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 "$@" > $R/bench_line.json 2> $R/bench_line.err; echo "bench rc=$?"; tail -c 3000 $R/bench_line.json
+    ;;
+exact1)     # round 6: exact decode step after the router / ADVICE changes: bit-exact tests, then the exact-vs-fast bench probe and the kernel trace of the exact graph
+    timeout 1500 python -m pytest tests/test_decode_gpu.py tests/test_router_gpu.py tests/test_prefill_model_gpu.py -x -q 2>&1 | tail -5
+    timeout 600 python tools/probes/decode_fast_bench.py --only exact --route-tokens 0 "$@" 2>&1 | tail -12
+    kstats r06_decode_exact "QCN Q4 decode step, exact mode, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only exact --steps 30)" -- \
+        python /root/repo/tools/probes/decode_fast_bench.py --only exact --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r06_decode_exact_prof
     ;;
 ringp)      # round 6: the stand-alone probe of the ring GEMM (dense problem): bit comparison, timing of both forms, stamps
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -o /tmp/grp tools/probes/gemm_ring_probe.hip 2>&1 | grep -E "error" -A3
