@@ -11,6 +11,7 @@
 // MFMAs.  The kernel runs at the f32-MFMA rate (2.1 GFLOP per 1024-token chunk and layer): 131 us as a GEMV -> see DESIGN.md 5b.
 // Workgroup: 4 waves = 64 tokens x 64 experts, 128-k stages double-buffered in LDS (next stage's global loads in flight during the MFMAs).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "kr_lds_optin.h"
@@ -228,15 +229,23 @@ typedef __bf16 rm_b8 __attribute__((ext_vector_type(8)));
 // k mapping: the MFMA sums its 16 k in any order as long as A and B agree, so an iteration covers 32 k and lane half h takes the CONTIGUOUS 16 of them
 // [32 j + 16 h, + 16) -- two MFMA steps (its first / second 8) -- instead of two separate 8-k chunks: a lane reads 64 contiguous bytes of its token row and
 // 32 of its gate row, and the two lanes of a row cover one whole 128-byte line (the first form asked for half lines and ran at 120 us per 2752-token chunk).
-__global__ void __launch_bounds__(128, 2) kr_route_logits_fast_kernel(const uint16_t* __restrict__ gate_row, const float* __restrict__ x, const float* __restrict__ bias,
+// KS = 4 (round 6): the k range split over the FOUR waves of a workgroup -- one 32 x 64 output tile per workgroup, partial accumulators added in wave order
+// through LDS.  The two-wave form above put 688 waves on the chip's 1024 SIMDs for a 2752-token chunk and each of them walked all of K behind its own
+// hi / lo conversions (8 vector instructions per MFMA): 101 us per chunk and layer, 114 TFLOP/s.  Same products; the f32 sum of a logit is now four partial
+// sums in k order added in wave order -- inside the bound stated above.
+template <int KS>
+__global__ void __launch_bounds__(64 * (KS == 1 ? 2 : KS), 2) kr_route_logits_fast_kernel(const uint16_t* __restrict__ gate_row, const float* __restrict__ x, const float* __restrict__ bias,
                                                                    float* __restrict__ logits, int T, int E, int H) {
+    __shared__ float s_part[KS == 1 ? 1 : (KS - 1) * 2 * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int t0 = blockIdx.y * 32, e0 = blockIdx.x * 128 + wave * 64;      // two waves per workgroup: 32 tokens x 128 experts (a 2752-token chunk: 344 workgroups over the 256 CUs)
+    // KS == 1: two waves per workgroup = 32 tokens x 128 experts, each wave all of K; KS > 1: KS waves = 32 tokens x 64 experts, each wave H / KS of K
+    const int t0 = blockIdx.y * 32, e0 = KS == 1 ? blockIdx.x * 128 + wave * 64 : blockIdx.x * 64;
+    const int kq = KS == 1 ? 0 : wave * (H / KS);
     const int tr = min(t0 + r, T - 1);
-    const float* xp = x + (size_t)tr * H + 16 * h;
+    const float* xp = x + (size_t)tr * H + kq + 16 * h;
     const uint16_t* gp[2];
 #pragma unroll
-    for (int c = 0; c < 2; c++) gp[c] = gate_row + (size_t)min(e0 + 32 * c + r, E - 1) * H + 16 * h;
+    for (int c = 0; c < 2; c++) gp[c] = gate_row + (size_t)min(e0 + 32 * c + r, E - 1) * H + kq + 16 * h;
     rm_v16f acc[2];
 #pragma unroll
     for (int c = 0; c < 2; c++)
@@ -250,7 +259,7 @@ __global__ void __launch_bounds__(128, 2) kr_route_logits_fast_kernel(const uint
 #pragma unroll
         for (int c = 0; c < 2; c++) { gb[buf][c][0] = *reinterpret_cast<const rm_u4*>(gp[c] + 32 * j); gb[buf][c][1] = *reinterpret_cast<const rm_u4*>(gp[c] + 32 * j + 8); }
     };
-    const int nit = H / 32;
+    const int nit = H / 32 / KS;
 #pragma unroll
     for (int p = 0; p < PD; p++) if (p < nit) fetch(p, p);
     for (int j0 = 0; j0 < nit; j0 += PD) {
@@ -276,6 +285,22 @@ __global__ void __launch_bounds__(128, 2) kr_route_logits_fast_kernel(const uint
                 }
         }
     }
+    if constexpr (KS > 1) {      // partial sums of waves 1 .. KS - 1 -> LDS ([wave - 1][c][i][lane]: conflict-free), wave 0 adds them in wave order
+        if (wave > 0) {
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) s_part[(((wave - 1) * 2 + c) * 16 + i) * 64 + lane] = acc[c][i];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 1; w < KS; w++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[c][i] += s_part[(((w - 1) * 2 + c) * 16 + i) * 64 + lane];
+    }
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int e = e0 + 32 * c + r;
@@ -290,8 +315,13 @@ __global__ void __launch_bounds__(128, 2) kr_route_logits_fast_kernel(const uint
 // non-zero = not covered (f32 gate, H not a multiple of 32): the caller keeps the exact kernel
 int kr_launch_route_logits_fast(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* logits, int T, int E, int H, hipStream_t st) {
     if (!gate_bf16 || H % 32 || T < 1 || E < 1) return 1;
+    if (H % 128 == 0 && H >= 512) {      // four k quarters per output tile: 4 x the waves (2752 tokens: 57.7 us against 70.1 stand-alone, profiles/r06_route_fast_kernel_stats.txt)
+        const dim3 grid((E + 63) / 64, (T + 31) / 32);
+        hipLaunchKernelGGL(kr_route_logits_fast_kernel<4>, grid, dim3(256), 0, st, reinterpret_cast<const uint16_t*>(gate_row), x, bias, logits, T, E, H);
+        return 0;
+    }
     const dim3 grid((E + 127) / 128, (T + 31) / 32);
-    hipLaunchKernelGGL(kr_route_logits_fast_kernel, grid, dim3(128), 0, st, reinterpret_cast<const uint16_t*>(gate_row), x, bias, logits, T, E, H);
+    hipLaunchKernelGGL(kr_route_logits_fast_kernel<1>, grid, dim3(128), 0, st, reinterpret_cast<const uint16_t*>(gate_row), x, bias, logits, T, E, H);
     return 0;
 }
 

@@ -245,6 +245,10 @@ exact1)     # round 6: exact decode step after the router / ADVICE changes: bit-
     kstats r06_decode_exact "QCN Q4 decode step, exact mode, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only exact --steps 30)" -- \
         python /root/repo/tools/probes/decode_fast_bench.py --only exact --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r06_decode_exact_prof
     ;;
+routefast)  # round 6: the tolerance router of the prompt pass: tests, then the kernel trace of one chunk's logits + select
+    timeout 600 python -m pytest tests/test_router_gpu.py -x -q 2>&1 | tail -3
+    kstats r06_route_fast "Batch router of the tolerance prompt pass, QCN shape, 2752 tokens x 23 calls (tools/probes/route_fast_probe.py)" -- python /root/repo/tools/probes/route_fast_probe.py 2752 20
+    ;;
 ringp)      # round 6: the stand-alone probe of the ring GEMM (dense problem): bit comparison, timing of both forms, stamps
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -o /tmp/grp tools/probes/gemm_ring_probe.hip 2>&1 | grep -E "error" -A3
     /tmp/grp 4096 2048 12288 | grep -v "^  mismatch"; /tmp/grp 8192 2048 4096 | grep -v "^  mismatch"; /tmp/grp 2752 2048 12288 | grep -v "^  mismatch"

@@ -5,7 +5,7 @@ device-to-device copies where RCCL would send them over xGMI.  What this measure
 hand-off, row gather / scatter, receive-side GEMMs on top-1 rows, return, combine) at growing W with the transfer cost near zero and the W ranks
 SHARING one GPU -- an upper bound for the per-rank software overhead, not a scaling number.  Every rank's output is checked against the single
 engine operator (bf16 return rows: 2^-7 of the row's largest value).
-    python tools/probes/ep_loopback_probe.py [layers=4] [tokens=8192]  ->  gpurun_out/r03_ep_loopback.txt"""
+    python tools/probes/ep_loopback_probe.py [layers=4] [tokens=8192]  ->  gpurun_out/r06_ep_loopback.txt"""
 import os
 import sys
 import time
@@ -70,5 +70,5 @@ for W in (1, 2, 4, 8):
     grp.close(); del engs, eps, outs
     torch.cuda.empty_cache()
 os.makedirs("gpurun_out", exist_ok=True)
-open("gpurun_out/r03_ep_loopback.txt", "w").write("# " + __doc__.split("\n")[0] + "\n" + "\n".join(lines) + "\n")
+open("gpurun_out/r06_ep_loopback.txt", "w").write("# " + __doc__.split("\n")[0] + "\n" + "\n".join(lines) + "\n")
 print("\n".join(lines))
