@@ -380,13 +380,29 @@ int kr_moe_prefill_ep_set(kr_engine* e, int layer, const void* x_bf16, const int
     // it takes every pair slot as a row (rows past the last routed pair carry local id -1 and belong to no expert tile) and never waits.
     std::vector<size_t> soff(W + 1, 0), roff(W + 1, 0);
     const bool xchg = W > 1 || s->comm != nullptr;      // a one-rank communicator still runs the exchange (through RCCL, to itself)
+    // Round 6: the shared expert of this rank's own tokens (replicated weights) depends on nothing the exchange moves.  It is launched BETWEEN the request for the split
+    // sizes (count all-gather + DtoH + event) and the host's wait for them: the stream has ~0.2 - 0.4 ms of GEMMs queued while the 4 W^2 bytes travel, so the wait no longer
+    // idles the GPU between the counts and the row exchange of the same layer.  Same launches, same results, another order.
+    const float* shared_eo = nullptr;
+    auto run_shared = [&]() -> int {   // one all-skipped slot per token: kr_moe_prefill then returns rsf * 0 + shared = the shared expert's rows
+        if (!use_shared) return KR_OK;
+        if (B.ones.bytes < (size_t)M * 4) {
+            if (B.ones.ensure((size_t)M * 4 * 2)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+            if (hipMemsetD32Async((hipDeviceptr_t)B.ones.p, 0x3F800000, B.ones.bytes / 4, st) != hipSuccess) return kr_fail(KR_ERR_HIP, "hipMemsetD32Async failed");
+        }
+        KR_HIP(hipMemsetAsync(B.neg_ids.p, 0xFF, (size_t)M * 4, st));
+        if (int rc = kr_moe_prefill_set(e, layer, x_bf16, (const int32_t*)B.neg_ids.p, (const float*)B.ones.p, B.shared_out.p, M, 1, KR_OUT_F32, 0, set, st)) return rc;
+        shared_eo = (const float*)B.shared_out.p;
+        return KR_OK;
+    };
     if (xchg) {
         if (int rc = ep_gather_counts(s, so.counts, (int*)B.cnt_all.p, st)) return ep_abort(s, rc);
-        if (hipMemcpyAsync(B.cnt_host, B.cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(B.ev, st) != hipSuccess ||
-            hipEventSynchronize(B.ev) != hipSuccess)
+        if (hipMemcpyAsync(B.cnt_host, B.cnt_all.p, (size_t)W * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(B.ev, st) != hipSuccess)
             return ep_abort(s, kr_fail(KR_ERR_HIP, "expert parallelism: reading the split sizes failed"));
+        if (int rc = run_shared()) return ep_abort(s, rc);      // queued behind the event: runs while the host waits
+        if (hipEventSynchronize(B.ev) != hipSuccess) return ep_abort(s, kr_fail(KR_ERR_HIP, "expert parallelism: reading the split sizes failed"));
         for (int r = 0; r < W; r++) { soff[r + 1] = soff[r] + (size_t)B.cnt_host[s->rank * W + r]; roff[r + 1] = roff[r] + (size_t)B.cnt_host[r * W + s->rank]; }
-    } else { soff[1] = roff[1] = (size_t)np; }
+    } else { soff[1] = roff[1] = (size_t)np; if (int rc = run_shared()) return rc; }
     const size_t n_send = soff[W], n_recv = roff[W];
     // ---- buffers whose size depends on what the peers send: a failure here aborts the communicator (the peers are already inside the call)
     {
@@ -429,13 +445,7 @@ int kr_moe_prefill_ep_set(kr_engine* e, int layer, const void* x_bf16, const int
         back = B.back.p;
     }
     if (!M) { KR_HIP(hipGetLastError()); return KR_OK; }
-    // ---- shared expert of this rank's tokens (replicated weights), then the combine in routing order
-    const float* shared_eo = nullptr;
-    if (use_shared) {   // one all-skipped slot per token: kr_moe_prefill then returns rsf * 0 + shared = the shared expert's rows
-        KR_HIP(hipMemsetAsync(B.neg_ids.p, 0xFF, (size_t)M * 4, st));
-        if (int rc = kr_moe_prefill_set(e, layer, x_bf16, (const int32_t*)B.neg_ids.p, (const float*)B.ones.p, B.shared_out.p, M, 1, KR_OUT_F32, 0, set, st)) return rc;
-        shared_eo = (const float*)B.shared_out.p;
-    }
+    // ---- the combine in routing order (+ the shared expert's rows computed above)
     if (s->ret_bf16) kr_launch_pf_combine_bf16rows((const uint16_t*)back, so.pair_row, wts, M, topk, H, shared_eo, e->cfg.routed_scaling_factor, out, out_dtype == KR_OUT_BF16, st);
     else kr_launch_pf_combine((const float*)back, so.pair_row, wts, M, topk, H, shared_eo, e->cfg.routed_scaling_factor, out, out_dtype == KR_OUT_BF16, st);
     KR_HIP(hipGetLastError());
