@@ -480,6 +480,16 @@ __global__ void __launch_bounds__(256, OCC) kr_pfh_gemm_kernel(const KrPfGemmHAr
                 // issue order: the NSA MFMAs of a fragment, then the 12 VALU that rebuild it for the next step, ...; the LDS reads of step t + 2 last
 #pragma unroll
                 for (int i = 0; i < 2 * NC; i++) {
+                    // round 6 (the ring kernel's finding, A/B on one box: experts only 0.98 -> 0.96 ms per layer, Q4_K copy 1.09 -> 1.07): a pair issued back to back parks the
+                    // wave on the busy matrix pipe while its vector work waits -- one MFMA, the 8 mask / shift operations of the fragment being rebuilt, the second MFMA,
+                    // the 4 packed fma (+ address work); the fma write the registers the pair's second MFMA still reads, so they cannot move up
+                    if (NSA == 2) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                        continue;
+                    }
                     __builtin_amdgcn_sched_group_barrier(0x008, NSA, 0);     // NSA MFMA
                     __builtin_amdgcn_sched_group_barrier(0x002, 13, 0);      // the fragment's de-quantization
                 }
