@@ -88,3 +88,12 @@ def test_no_kernel_of_the_library_has_a_scratch_segment(lib, tmp_path):
     assert len(kernels) > 500, f"only {len(kernels)} kernels parsed from the metadata"
     spilling = [(n, int(b)) for n, b in kernels if int(b)]
     assert not spilling, f"kernels with a scratch segment: {spilling}"
+    # round 6: the LDS-ring tolerance GEMM (kr_prefill_ring.hip) moves its operands by LDS-DMA -- the code object that holds kr_pfr_gemm_kernel must contain
+    # global_load_lds_dwordx4 sites ("zero LDS-DMA instructions anywhere in the library")
+    objdump = os.path.join(llvm, "llvm-objdump")
+    if os.path.exists(objdump):
+        ring = [o for o in objs if b"kr_pfr_gemm_kernel" in open(o, "rb").read()]
+        assert ring, "kr_pfr_gemm_kernel not found in any code object"
+        dis = subprocess.check_output([objdump, "-d", "--mcpu=gfx950"] + ring, text=True)
+        assert dis.count("global_load_lds_dwordx4") >= 16, dis.count("global_load_lds_dwordx4")
+        assert "global_load_lds_dword " in dis or "global_load_lds_dword\t" in dis

@@ -1,7 +1,8 @@
 """The de-quantization arithmetic of the tolerance GEMM (krasis_amd/csrc/kr_prefill_h.hip: pfh_dq4 / pfh_dq8 / the A permutation), restated in
 numpy bit for bit (f16 fma = exact product + sum in float64, one rounding to f16).  No GPU: this pins the CLAIMS the kernel's header makes --
 an INT4 weight becomes (nibble - 8) * s * 16 exactly for every nibble and every bf16 scale in the normal f16 range, an INT8 weight becomes
-b exactly before its single rounding multiply, and the (0,4,1,5,2,6,3,7) order of the unpacked values matches the permuted A rows."""
+b exactly before its single rounding multiply, and the (0,4,1,5,2,6,3,7) order of the unpacked values is the order the A row image is stored in (the INT8
+kernel's commit pass restores natural order)."""
 import numpy as np
 
 M0, M1, MH, KC = 0x000F000F, 0x00F000F0, 0x03C003C0, 0x64006400
@@ -72,12 +73,14 @@ def test_int8_weights_and_the_a_permutation():
             vals += [_h(t & 0xFFFF) - 1152.0, _h(t >> 16) - 1152.0]
     got = np.stack(vals, axis=1)
     assert np.array_equal(got, b.astype(np.float64))             # (1024 + (b ^ 0x80)) - 1152 = b, natural order, exact in f16
-    # A rows: 8 f16 (a0 .. a7) in four words -> (a0,a4 | a1,a5 | a2,a6 | a3,a7), the order pfh_dq4 emits
+    # A rows (round 6): the row kernels store the 8 values of a group in the order pfh_dq4 emits, (a0,a4 | a1,a5 | a2,a6 | a3,a7) -- the INT4 kernels (register-staged
+    # and LDS-ring: LDS-DMA cannot permute) copy rows verbatim; the INT8 kernel, whose pfh_dq8 emits natural k order, un-permutes in its commit pass with four v_perm
     a = np.arange(8, dtype=np.uint16)[None, :].repeat(3, 0) + np.array([[0], [100], [200]], np.uint16)
-    v = np.ascontiguousarray(a).view(np.uint32)
-    o = np.stack([_perm(np.ascontiguousarray(v[:, 2]), np.ascontiguousarray(v[:, 0]), 0x05040100), _perm(np.ascontiguousarray(v[:, 2]), np.ascontiguousarray(v[:, 0]), 0x07060302),
-                  _perm(np.ascontiguousarray(v[:, 3]), np.ascontiguousarray(v[:, 1]), 0x05040100), _perm(np.ascontiguousarray(v[:, 3]), np.ascontiguousarray(v[:, 1]), 0x07060302)], axis=1)
-    assert np.array_equal(np.ascontiguousarray(o).view(np.uint16), a[:, [0, 4, 1, 5, 2, 6, 3, 7]])
+    image = np.ascontiguousarray(a[:, [0, 4, 1, 5, 2, 6, 3, 7]])
+    v = image.view(np.uint32)
+    o = np.stack([_perm(np.ascontiguousarray(v[:, 1]), np.ascontiguousarray(v[:, 0]), 0x05040100), _perm(np.ascontiguousarray(v[:, 3]), np.ascontiguousarray(v[:, 2]), 0x05040100),
+                  _perm(np.ascontiguousarray(v[:, 1]), np.ascontiguousarray(v[:, 0]), 0x07060302), _perm(np.ascontiguousarray(v[:, 3]), np.ascontiguousarray(v[:, 2]), 0x07060302)], axis=1)
+    assert np.array_equal(np.ascontiguousarray(o).view(np.uint16), a)
 
 
 def test_row_multiplier_is_a_power_of_two():
