@@ -249,6 +249,14 @@ routefast)  # round 6: the tolerance router of the prompt pass: tests, then the 
     timeout 600 python -m pytest tests/test_router_gpu.py -x -q 2>&1 | tail -3
     kstats r06_route_fast "Batch router of the tolerance prompt pass, QCN shape, 2752 tokens x 23 calls (tools/probes/route_fast_probe.py)" -- python /root/repo/tools/probes/route_fast_probe.py 2752 20
     ;;
+ringx)      # round 6: kernel trace of the experts-only pass at the prompt pass's chunk length, ring kernel forced vs register-staged
+    kstats r06_experts_2752_ring "Experts only, QCN shape, 2752 tokens x 8 layers, LDS-ring GEMM forced (tools/probes/experts_gemm_probe.py 8 2752 ring)" -- python /root/repo/tools/probes/experts_gemm_probe.py 8 2752 ring
+    kstats r06_experts_2752_staged "Experts only, QCN shape, 2752 tokens x 8 layers, register-staged GEMM (tools/probes/experts_gemm_probe.py 8 2752 staged)" -- python /root/repo/tools/probes/experts_gemm_probe.py 8 2752 staged
+    ;;
+pf1)        # round 6: the tolerance prompt pass as ONE chunk on one stream (no overlap): stand-alone duration of every kernel
+    kstats r06_prefill_8192_one_chunk "QCN prompt pass, KR_ATTN_FAST | KR_GEMM_FAST, 8192 tokens as ONE chunk, depth 1 (tools/probes/prefill_profile.py 8192 2 48 8192 1): stand-alone kernel durations" -- \
+        python /root/repo/tools/probes/prefill_profile.py 8192 2 48 8192 1
+    ;;
 ringp)      # round 6: the stand-alone probe of the ring GEMM (dense problem): bit comparison, timing of both forms, stamps
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -o /tmp/grp tools/probes/gemm_ring_probe.hip 2>&1 | grep -E "error" -A3
     /tmp/grp 4096 2048 12288 | grep -v "^  mismatch"; /tmp/grp 8192 2048 4096 | grep -v "^  mismatch"; /tmp/grp 2752 2048 12288 | grep -v "^  mismatch"

@@ -17,10 +17,10 @@ modes = (sys.argv[3] if len(sys.argv) > 3 else "exact,fast,q4k").split(",")
 from krasis_amd import KrasisEngine, ModelConfig  # noqa: E402
 
 q = bench.QCN
-if "exact" in modes or "fast" in modes or "staged" in modes:
+if any(m in modes for m in ("exact", "fast", "staged", "ring")):
     eng = KrasisEngine(device=0); eng.configure(ModelConfig(q["hidden"], q["inter"], q["experts"], q["topk"], L, 0, 1.0)); eng.fill_synthetic(4, seed=5)
-    for mode in [m for m in modes if m in ("exact", "fast", "staged")]:      # "staged" = tolerance form on the register-staged kernels (kr_moe_set_gemm_mode 3); list a mode twice to interleave
-        r = bench.prefill_experts(eng, q, L, M, torch, gemm_fast=(mode != "exact"), gemm_mode=(3 if mode == "staged" else None))
+    for mode in [m for m in modes if m in ("exact", "fast", "staged", "ring")]:      # "staged" / "ring" = tolerance form on the register-staged kernels only / with the LDS-ring kernel forced (kr_moe_set_gemm_mode 3 / 5); list a mode twice to interleave
+        r = bench.prefill_experts(eng, q, L, M, torch, gemm_fast=(mode != "exact"), gemm_mode=(3 if mode == "staged" else (5 if mode == "ring" else None)))
         print("experts-only %-5s variant=%s: %d layers x %d tokens: %.2f ms/layer  %.0f tok/s (48-layer equivalent %.0f)  %.1f %s = %.3f of peak" % (
             mode, os.environ.get("KR_PFH_VARIANT", "default"), L, M, r["ms"] / L, r["tok_s_experts_only"], r["tok_s_experts_only"] * L / 48,
             r["roofline"]["achieved"], "TFLOP/s f16" if mode != "exact" else "TOP/s int8", r["roofline"]["frac"]), flush=True)
