@@ -89,8 +89,9 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
     na.w = (const float*)s->norms[L.input_norm]->p; na.out = B.normed; na.xh = B.xh; na.xl = B.xl; na.xs = B.xs; na.H = H; na.first = cx.first ? 1 : 0;
     na.bias_one = s->norm_bias_one; na.eps = s->eps;
     if (s->gemm_fast) { na.xh = nullptr; na.xl = nullptr; na.xs = nullptr; }      // tolerance GEMMs take f16 rows of the normalised value instead of the digits
+    if (s->gemm_fast && s->opt_norm_rows) { na.xf = B.xf; na.xfm = B.xfm; }      // ... and the norm launch writes that row image itself (round 6: one launch per norm less)
     kr_launch_pfm_norm(na, Cc, st);
-    if (s->gemm_fast) kr_launch_pfh_rows_f32(B.normed, Cc, H, H, B.xf, B.xfm, st);
+    if (s->gemm_fast && !s->opt_norm_rows) kr_launch_pfh_rows_f32(B.normed, Cc, H, H, B.xf, B.xfm, st);
     cx.first = false; cx.add_is_emb = false;
     if (L.attn == ATTN_LA) {
         const int nq = s->weights[L.qkvz_wid]->rows, nb = s->weights[L.ba_wid]->rows, oc = s->weights[L.out_wid]->cols;
@@ -170,8 +171,10 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
     }
     // ---- post-attention norm: f32 hidden, digits (shared expert / dense MLP), bf16 copy (routed experts)
     na.mode = 0; na.add_in = B.hid; na.first = 0; na.w = (const float*)s->norms[L.post_norm]->p; na.out_bf16 = L.mlp == MLP_MOE ? B.xb : nullptr;
+    const bool post_rows = s->gemm_fast && (L.mlp == MLP_DENSE || (L.mlp == MLP_MOE && L.sgu_wid >= 0));      // the shared expert / dense MLP take the f16 rows of the normalised value
+    na.xf = post_rows && s->opt_norm_rows ? B.xf : nullptr; na.xfm = post_rows && s->opt_norm_rows ? B.xfm : nullptr;
     kr_launch_pfm_norm(na, Cc, st);
-    if (s->gemm_fast && (L.mlp == MLP_DENSE || (L.mlp == MLP_MOE && L.sgu_wid >= 0))) kr_launch_pfh_rows_f32(B.normed, Cc, H, H, B.xf, B.xfm, st);
+    if (post_rows && !s->opt_norm_rows) kr_launch_pfh_rows_f32(B.normed, Cc, H, H, B.xf, B.xfm, st);
     if (L.mlp == MLP_MOE) {
         Layer& EL = e->layers[L.moe_layer];
         if (!EL.routing_present) return kr_fail(KR_ERR_STATE, "Routing weights not set for layer %d", L.moe_layer);
@@ -239,8 +242,9 @@ static int run_final_all(kr_decode_store* s, Chunk& cx, float* vlogits, int firs
     na.w = (const float*)s->norms[s->final_norm]->p; na.out = B.normed; na.xh = B.xh; na.xl = B.xl; na.xs = B.xs; na.H = H; na.first = cx.first ? 1 : 0;
     na.bias_one = s->norm_bias_one; na.eps = s->eps;
     if (s->gemm_fast) { na.xh = nullptr; na.xl = nullptr; na.xs = nullptr; }
+    if (s->gemm_fast && s->opt_norm_rows) { na.xf = B.xf; na.xfm = B.xfm; }
     kr_launch_pfm_norm(na, cx.Cc, cx.st);
-    if (s->gemm_fast) kr_launch_pfh_rows_f32(B.normed, cx.Cc, H, H, B.xf, B.xfm, cx.st);
+    if (s->gemm_fast && !s->opt_norm_rows) kr_launch_pfh_rows_f32(B.normed, cx.Cc, H, H, B.xf, B.xfm, cx.st);
     if (int rc = pf_gemm(s, s->lm_head, X(B), cx.Cc, vlogits, (int)V, cx.st)) return rc;
     const int scored = std::min(cx.Cc, n_tokens - 1 - first_tok);      // the last prompt token has no label
     kr_launch_pfm_nll(vlogits, V, cx.tok + 1, (float*)s->pf_nll.p + first_tok, scored, (int)V, cx.st);

@@ -15,6 +15,27 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+// ------------------------------------------------------------------------------------------
+// A operand: rows -> f16 with a power-of-two row multiplier (shared by the row kernels of kr_prefill_h.hip and the norm kernel of kr_prefill_ops.hip, which writes the
+// image of its own output in the tolerance pass)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pfh_row_scale(float mx, float& scl, float& inv) {    // mx >= 0: scl = 2^-e, inv = 2^e, e = exponent of mx
+    uint32_t E = __float_as_uint(mx) >> 23;
+    if (E == 0 || E > 253) { scl = 1.0f; inv = 1.0f; return; }       // zero row (or not finite): unscaled
+    scl = __uint_as_float((254u - E) << 23); inv = __uint_as_float(E << 23);
+}
+__device__ __forceinline__ uint32_t pfh_pack_h2(float a, float b) {
+    const v2h h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float pfh_block_max(float mx, uint32_t* slot) {   // slot: LDS word zeroed before the call + barrier
+    mx = kr_red16_max_f32(mx);
+    if ((threadIdx.x & 15) == 0) atomicMax(slot, __float_as_uint(mx));        // non-negative floats order like their bit patterns
+    __syncthreads();
+    return __uint_as_float(*slot);
+}
+
+
 struct KrPfGemmHArgs {
     KrMatDev m;
     const uint16_t* a; const float* a_mul;   // f16 rows [rows_or_tokens][K], row multipliers

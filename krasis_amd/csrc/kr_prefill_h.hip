@@ -53,22 +53,6 @@ __device__ unsigned long long kr_hstamps[16];
 // ------------------------------------------------------------------------------------------
 // A operand: rows -> f16 with a power-of-two row multiplier
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pfh_row_scale(float mx, float& scl, float& inv) {    // mx >= 0: scl = 2^-e, inv = 2^e, e = exponent of mx
-    uint32_t E = __float_as_uint(mx) >> 23;
-    if (E == 0 || E > 253) { scl = 1.0f; inv = 1.0f; return; }       // zero row (or not finite): unscaled
-    scl = __uint_as_float((254u - E) << 23); inv = __uint_as_float(E << 23);
-}
-__device__ __forceinline__ uint32_t pfh_pack_h2(float a, float b) {
-    const v2h h = {(_Float16)a, (_Float16)b};
-    return __builtin_bit_cast(uint32_t, h);
-}
-__device__ __forceinline__ float pfh_block_max(float mx, uint32_t* slot) {   // slot: LDS word zeroed before the call + barrier
-    mx = kr_red16_max_f32(mx);
-    if ((threadIdx.x & 15) == 0) atomicMax(slot, __float_as_uint(mx));        // non-negative floats order like their bit patterns
-    __syncthreads();
-    return __uint_as_float(*slot);
-}
-
 // SRC 0: f32 rows (ld floats apart), SRC 1: bf16 rows (ld elements apart).  grid (rows), 256 threads, K % 8 == 0
 // f16 sum of the 8 ROUNDED values of a chunk, completed over the 4 consecutive lanes of a 32-wide block (Q4_K copy: the operand of the offset columns)
 __device__ __forceinline__ void pfh_store_sum32(const float (&v)[8], float scl, int c, uint16_t* sums_row) {

@@ -10,6 +10,7 @@ struct KrPfmNormArgs {
     const float* w; float* out;   // norm weight [H]; normalised hidden f32 [C,H]
     int8_t *xh, *xl; float* xs;   // optional INT16 digits of the normalised hidden (quantize_activation_int16_f32)
     uint16_t* out_bf16;           // optional bf16 copy (input of the routed experts)
+    uint16_t* xf; float* xfm;     // optional f16 row image of the normalised hidden + row multipliers: the tolerance GEMMs' A operand (kr_pfh_dev.h; what kr_pfh_rows_kernel<0> makes of `out`)
     int H, first, bias_one; float eps;
 };
 // Cross-chunk ordering INSIDE a layer (kr_decode_prefill.cpp runs several chunks of a prompt on their own streams): what chunk c needs from chunk c - 1 is

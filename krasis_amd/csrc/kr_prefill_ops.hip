@@ -9,6 +9,7 @@
 #include "kr_device.h"
 #include "kr_libm.h"
 #include "kr_prefill_ops.h"
+#include "kr_pfh_dev.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
@@ -55,7 +56,9 @@ __device__ __forceinline__ void kr_pfm_quant_chunk(const float (&v)[8], int8_t* 
 // quantise bf16(hidden), decode.rs:3307-3309).
 __global__ void __launch_bounds__(256) kr_pfm_norm_kernel(const KrPfmNormArgs a) {
     extern __shared__ __attribute__((aligned(16))) float r[];   // [H + 4]
+    __shared__ uint32_t s_max;
     const int t = blockIdx.x, H = a.H, tid = threadIdx.x;
+    if (tid == 0) s_max = 0;
     const float* add = a.mode == 1 ? a.emb + (size_t)a.tokens[t] * H : a.add_in + (size_t)t * H;
     float* res = a.res + (size_t)t * H;
     for (int i = tid; i < H; i += 256) { const float v = a.first ? add[i] : (add[i] + res[i]); r[i] = v; res[i] = v; }
@@ -67,10 +70,11 @@ __global__ void __launch_bounds__(256) kr_pfm_norm_kernel(const KrPfmNormArgs a)
     __syncthreads();
     const float rms = r[H];
     float* out = a.out + (size_t)t * H;
+    float mx = 0.0f;
     for (int c = tid; c < H / 8; c += 256) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = c * 8 + u; v[u] = (r[i] * rms) * (a.bias_one ? (a.w[i] + 1.0f) : a.w[i]); }
+        for (int u = 0; u < 8; u++) { const int i = c * 8 + u; v[u] = (r[i] * rms) * (a.bias_one ? (a.w[i] + 1.0f) : a.w[i]); mx = fmaxf(mx, fabsf(v[u])); }
         *reinterpret_cast<float4*>(out + c * 8) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(out + c * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
         if (a.xh) kr_pfm_quant_chunk(v, a.xh + (size_t)t * H + c * 8, a.xl + (size_t)t * H + c * 8, a.xs + (size_t)t * (H / 128) + (c >> 4), (c & 15) == 0);
@@ -80,6 +84,20 @@ __global__ void __launch_bounds__(256) kr_pfm_norm_kernel(const KrPfmNormArgs a)
             p.z = (uint32_t)kr_f32_to_bf16(v[4]) | ((uint32_t)kr_f32_to_bf16(v[5]) << 16); p.w = (uint32_t)kr_f32_to_bf16(v[6]) | ((uint32_t)kr_f32_to_bf16(v[7]) << 16);
             *reinterpret_cast<u32x4*>(a.out_bf16 + (size_t)t * H + c * 8) = p;
         }
+    }
+    if (a.xf) {      // the f16 row image of the values just stored, exactly as kr_pfh_rows_kernel<0> forms it from `out` (uniform per launch: every thread meets the barrier inside)
+        mx = pfh_block_max(mx, &s_max);
+        float scl, inv; pfh_row_scale(mx, scl, inv);
+        for (int c = tid; c < H / 8; c += 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = c * 8 + u; v[u] = (r[i] * rms) * (a.bias_one ? (a.w[i] + 1.0f) : a.w[i]); }      // the same expression: the same bits
+            u32x4 o;
+            o.x = pfh_pack_h2(v[0] * scl, v[4] * scl); o.y = pfh_pack_h2(v[1] * scl, v[5] * scl);      // image order (0,4,1,5,2,6,3,7)
+            o.z = pfh_pack_h2(v[2] * scl, v[6] * scl); o.w = pfh_pack_h2(v[3] * scl, v[7] * scl);
+            *reinterpret_cast<u32x4*>(a.xf + (size_t)t * H + c * 8) = o;
+        }
+        if (tid == 0) a.xfm[t] = inv * 0.0625f;
     }
 }
 

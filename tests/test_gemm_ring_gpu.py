@@ -84,3 +84,27 @@ def test_ring_gemm_prompt_pass_bit_identical(kinds):
         st.set_option("gemm_ring", 1)
     assert np.isfinite(res[1]).all()
     assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32)), float(np.abs(res[0] - res[1]).max())
+
+
+@pytest.mark.parametrize("kinds", [["la", "gqa"]])
+def test_norm_launch_writes_the_f16_row_image_bit_identically(kinds):
+    """round 6: in the tolerance prompt pass the norm launch writes the f16 row image of its own output (kr_pfm_norm_kernel, KrPfmNormArgs::xf) instead of a separate
+    kr_pfh_rows_kernel<0> launch over the stored f32 rows: same values, same row maximum, same rounding -- last-position logits AND the scoring pass's NLL bit for bit"""
+    from tests.test_attn_fast_gpu import build
+    rng = np.random.default_rng(6)
+    toks = None
+    res = []
+    for fused in (0, 1):
+        st, eng, orc, keep, d = build(seed=29, kv_max=400, kinds=kinds, hd=128, nh=8)
+        st.set_attention_mode(True, gemm_fast=True)
+        st.set_option("norm_rows", fused)
+        if toks is None:
+            toks = [int(t) for t in rng.integers(0, d["V"], 300)]
+        lg = np.empty(d["V"], F)
+        st.prefill(toks, 0, lg.ctypes.data)
+        st.reset_decode_state(d["kv_max"])
+        nll = st.prefill_nll(toks, 0)
+        res.append((lg.copy(), np.array(nll, copy=True)))
+    assert np.isfinite(res[1][0]).all()
+    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))

@@ -206,6 +206,30 @@ r5final)    # round 5 closing run: GPU suite as the driver runs it; PMC fetch pa
     KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so LAYERS=47 WG_OUT=$R/r05_decode_fast_wg_times.txt timeout 250 python tools/probes/decode_fast_wg_times.py 2>&1 | tail -7
     rm -rf $R/prof_* $R/pmc_* $R/*.log
     ;;
+r6final)    # round 6 closing run: GPU suite as the driver runs it; PMC fetch pass FIRST (its json lands in profiles/ on the box), then the driver's bench line (so
+            # roofline.traffic in the line is the number of the json committed beside it); kernel traces; stamps
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+    timeout 1800 python -m pytest tests/ -x -q -m gpu > $R/r06_gpu_tests_full.txt 2>&1; echo "pytest rc=$?"
+    grep -E " passed| failed| error|skipped" $R/r06_gpu_tests_full.txt | tail -3 | tee $R/r06_gpu_tests_summary.txt
+    rm -rf $R/pmc_fast
+    (cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE -d $R/pmc_fast --output-format csv -- python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 12 --route-tokens 0 --out /root/repo/gpurun_out/r06_decode_fast_pmcrun > $R/pmc_fast.log 2>&1)
+    python tools/rocprof_csv_summary.py pmc $R/pmc_fast $R/r06_decode_fast_pmc_fetch_size.txt "QCN Q4 decode step, KR_DECODE_FAST: HBM fetch per launch (rocprofv3 --pmc FETCH_SIZE, counters-only pass; x2 = gfx950 correction)" 2>&1 | tail -2
+    cp $R/r06_decode_fast_pmc_fetch_size.json $R/r06_decode_fast_pmc_fetch_size.txt profiles/ 2>/dev/null
+    head -14 $R/r06_decode_fast_pmc_fetch_size.txt
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/r06_bench_stdout.txt 2> $R/r06_bench_stderr.txt; echo "bench rc=$?"
+    tail -1 $R/r06_bench_stdout.txt > $R/r06_bench_line.json; echo "last stdout line: $(wc -c < $R/r06_bench_line.json) bytes, stdout lines: $(wc -l < $R/r06_bench_stdout.txt)"
+    cp $R/bench_detail.json $R/r06_bench_detail.json 2>/dev/null
+    python tools/bench_summary.py $R/r06_bench_detail.json
+    kstats r06_decode_fast "QCN Q4 decode step, KR_DECODE_FAST, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only fast --steps 30)" -- \
+        python /root/repo/tools/probes/decode_fast_bench.py --only fast --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r06_decode_fast_prof
+    kstats r06_decode_exact "QCN Q4 decode step, exact mode, FP8-E4M3 KV, positions 10.. (tools/probes/decode_fast_bench.py --only exact --steps 30)" -- \
+        python /root/repo/tools/probes/decode_fast_bench.py --only exact --steps 30 --route-tokens 0 --out /root/repo/gpurun_out/r06_decode_exact_prof
+    kstats r06_prefill_8192_attn_fast_gemm_fast "QCN prompt pass, KR_ATTN_FAST | KR_GEMM_FAST, 8192 tokens (tools/probes/prefill_profile.py 8192 2)" -- python /root/repo/tools/probes/prefill_profile.py 8192 2 > /dev/null
+    [ -f krasis_amd/libkrasis_hip_timing.so ] || make -C krasis_amd/csrc timing > $R/make_timing.log 2>&1      # the stamp build is not shipped: built on the box
+    KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so LAYERS=47 STAMPS_OUT=$R/r06_decode_fast_stamps.txt timeout 250 python tools/probes/decode_fast_stamps.py 2>&1 | tail -8
+    KRASIS_HIP_LIB=/root/repo/krasis_amd/libkrasis_hip_timing.so LAYERS=47 WG_OUT=$R/r06_decode_fast_wg_times.txt timeout 250 python tools/probes/decode_fast_wg_times.py 2>&1 | tail -7
+    rm -rf $R/prof_* $R/pmc_* $R/*.log
+    ;;
 r5t)        # round 5: a list of test files + the decode probe in both modes
     timeout 1200 python -m pytest "$@" -q -x > $R/r05_tests.txt 2>&1; grep -E " passed| failed|rror" $R/r05_tests.txt | tail -4
     timeout 300 python tools/probes/decode_fast_bench.py --route-tokens 0 --out gpurun_out/r05_df 2>&1 | grep -E "^fast|^exact|logits"

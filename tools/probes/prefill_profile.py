@@ -10,6 +10,8 @@ eng, st, keep = bench.build_qcn(0, 0, L, P + 64, 4, True)
 st.set_attention_mode(bool(fast), gemm_fast=(fast == 2))
 if len(sys.argv) > 4 and int(sys.argv[4]): st.set_prefill_chunk(int(sys.argv[4]))
 if len(sys.argv) > 5 and int(sys.argv[5]): st.set_prefill_depth(int(sys.argv[5]))
+for kv in os.environ.get("KR_OPTS", "").split(","):          # A/B hooks: KR_OPTS="norm_rows=0,gemm_ring=2"
+    if "=" in kv: st.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 st.fill_state_synthetic(P + 64, 7)
 toks = [int(x) for x in np.random.default_rng(5).integers(0, bench.QCN["vocab"], P)]
 st.prefill(toks, 0); torch.cuda.synchronize()          # full-length warm-up: the scratch arenas are sized by the chunk length
