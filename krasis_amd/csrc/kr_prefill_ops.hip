@@ -298,20 +298,46 @@ __global__ void __launch_bounds__(256) kr_pfm_la_recur_kernel(float* __restrict_
     for (int i = 0; i < DK; i++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S[i]), srd, j * 4, i * dv * 4, 0);
 }
 
-// ---- gated RMSNorm + SiLU gate per (token, head) (decode.rs:3979); grid (nv, C), dv threads ----------------------------------
-__global__ void __launch_bounds__(256) kr_pfm_gated_norm_kernel(const float* __restrict__ recur, const float* __restrict__ z, const float* __restrict__ w,
-                                                               float* __restrict__ out, int nv, int dv, float eps) {
-    __shared__ float r[256]; __shared__ float rms_s;
-    const int h = blockIdx.x, t = blockIdx.y, i = threadIdx.x;
-    const size_t o = (size_t)t * nv * dv + (size_t)h * dv + i;
-    if (i < dv) r[i] = recur[o];
-    __syncthreads();
-    if (i < 8) { const float ss = kr_pfm_sumsq8(r, dv, i); if (i == 0) rms_s = 1.0f / sqrtf(ss / (float)dv + eps); }
-    __syncthreads();
-    if (i < dv) {
-        const float normed = (r[i] * rms_s) * w[(size_t)h * dv + i];
-        const float zz = z[o];
-        out[o] = (zz * kr_sigmoid_poly5(zz)) * normed;
+// ---- gated RMSNorm + SiLU gate per (token, head) (decode.rs:3979) ----------------------------------------------------------------
+// grid (nv, ceil(C / 8)), 256 threads: a WAVE takes one (token, head) row at a time (two rows per wave: 8 tokens per workgroup), the row in a wave-private LDS slice,
+// the sum of squares as the reference's 8-lane chain + hsum (kr_pfm_sumsq8) on lanes 0..7, no workgroup barrier.  (Rounds 1-5: one workgroup of dv threads per
+// (token, head) -- 262 144 workgroups of two waves for an 8192-token chunk, 140 us against ~80 us of traffic.)  z may sit inside the in-projection's output
+// (z_ld = its row stride, z_head = floats between the z blocks of consecutive value heads): the stand-alone copy of z is then never made.
+#define PFG_TT 8
+__global__ void __launch_bounds__(256) kr_pfm_gated_norm_kernel(const float* __restrict__ recur, const float* __restrict__ z, size_t z_ld, int z_hr, int z_kstride, const float* __restrict__ w,
+                                                               float* __restrict__ out, int nv, int dv, int C, float eps) {
+    __shared__ __attribute__((aligned(16))) float rs[4][256 + 8];
+    const int h = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* r = rs[wave];
+    const int nj = (dv + 63) / 64;
+    // z of value head h: block (h / z_hr) of z_kstride floats, then head h % z_hr inside it (plain [C][nv * dv] rows: z_hr = nv... handled by the launcher's numbers)
+    const size_t zoff = (size_t)(h / z_hr) * z_kstride + (size_t)(h % z_hr) * dv;
+    for (int tw = 0; tw < PFG_TT / 4; tw++) {
+        const int t = blockIdx.y * PFG_TT + tw * 4 + wave;
+        if (t >= C) break;                                        // wave-uniform
+        const size_t o = (size_t)t * nv * dv + (size_t)h * dv;
+        float v[4], zz[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = lane + 64 * j;
+            v[j] = (j < nj && i < dv) ? recur[o + i] : 0.0f;
+            zz[j] = (j < nj && i < dv) ? z[(size_t)t * z_ld + zoff + i] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int i = lane + 64 * j; if (j < nj && i < dv) r[i] = v[j]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        if (lane < 8) { const float ss = kr_pfm_sumsq8(r, dv, lane); if (lane == 0) r[256] = 1.0f / sqrtf(ss / (float)dv + eps); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        const float rms = r[256];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = lane + 64 * j;
+            if (j < nj && i < dv) {
+                const float normed = (v[j] * rms) * w[(size_t)h * dv + i];
+                out[o + i] = (zz[j] * kr_sigmoid_poly5(zz[j])) * normed;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();      // the slice is rewritten by the wave's next row
     }
 }
 
@@ -752,7 +778,8 @@ int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out,
         else hipLaunchKernelGGL(kr_pfm_la_recur_kernel<64>, dim3(a.nv), dim3(a.dv), 0, st, recur_state, a.q, a.k, a.v, a.gexp, a.beta, recur_out, a.nv, a.dv, C);
     }
     kr_pf_rec(st, sy->rec_b);
-    hipLaunchKernelGGL(kr_pfm_gated_norm_kernel, dim3(a.nv, C), dim3(a.dv), 0, st, recur_out, a.z, norm_w, gated_out, a.nv, a.dv, eps);
+    // z: the stand-alone copy [C][nv * dv] the conv launch makes (z_hr = nv: one block)
+    hipLaunchKernelGGL(kr_pfm_gated_norm_kernel, dim3(a.nv, (C + PFG_TT - 1) / PFG_TT), dim3(256), 0, st, recur_out, (const float*)a.z, (size_t)a.nv * a.dv, a.nv, 0, norm_w, gated_out, a.nv, a.dv, C, eps);
     return 0;
 }
 // the recurrence alone (stand-alone operator linear_attention_recurrent, decode.rs:609): gexp = e^g per (token, head); non-zero = unsupported geometry
