@@ -342,43 +342,87 @@ __global__ void __launch_bounds__(256) kr_pfm_gated_norm_kernel(const float* __r
 }
 
 // ---- GQA: gated split, per-head RMS norm, RoPE, FP16 KV append for every token (decode.rs:2873-2966); grid (nh + nkv, C) ---------
-__global__ void __launch_bounds__(256) kr_pfm_gqa_prep_kernel(const KrPfmGqaArgs a) {
-    __shared__ float x[256]; __shared__ float rms_s;
-    const int b = blockIdx.x, t = blockIdx.y, d = threadIdx.x, hd = a.hd, pos = a.pos0 + t;
+// (round 6) grid (nh + nkv, ceil(C / 8)), 256 threads: a WAVE takes one (head, token) row at a time (two per wave: 8 tokens per workgroup) in a wave-private LDS slice;
+// the per-head RMS norm's sum of squares stays the reference's sequential sum (lane 0, values read four at a time).  Rounds 1-5 ran one 256-thread workgroup per row --
+// 147 k workgroups per 8192-token chunk with ONE lane busy in the sum: 341 us per launch.
+#define PFQ_TT 8
+__global__ void __launch_bounds__(256) kr_pfm_gqa_prep_kernel(const KrPfmGqaArgs a, int C) {
+    __shared__ __attribute__((aligned(16))) float xs[4][256 + 8];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hd = a.hd;
     const bool is_q = b < a.nh;
     const int h = is_q ? b : b - a.nh;
-    const float* q_in = a.q_in + (size_t)t * a.ld_q; const float* k_in = a.k_in + (size_t)t * a.ld_k; const float* v_in = a.v_in + (size_t)t * a.ld_v;
-    if (is_q) {
-        if (a.gated) { if (d < hd) { x[d] = q_in[(size_t)h * hd * 2 + d]; a.gate[(size_t)t * a.nh * hd + (size_t)h * hd + d] = q_in[(size_t)h * hd * 2 + hd + d]; } }
-        else if (d < hd) x[d] = q_in[(size_t)h * hd + d];
-    } else if (d < hd) x[d] = k_in[(size_t)h * hd + d];
-    __syncthreads();
+    float* x = xs[wave];
+    const int nc = hd / 4, njc = (nc + 63) / 64;                  // 16-byte chunks of a row, chunks per lane (hd % 32 == 0: the launcher checks)
     const float* nw = is_q ? a.q_norm : a.k_norm;
-    if (nw) {
-        if (d == 0) {
-            float ss = 0.0f;
-            for (int i = 0; i < hd; i++) ss += x[i] * x[i];
-            rms_s = 1.0f / sqrtf(ss / (float)hd + a.eps);
-        }
-        __syncthreads();
-        const int per_head = is_q ? a.q_norm_per_head : a.k_norm_per_head;
-        if (d < hd) x[d] = x[d] * (rms_s * nw[(per_head ? h * hd : 0) + d]);
-        __syncthreads();
-    }
+    const int per_head = is_q ? a.q_norm_per_head : a.k_norm_per_head;
     const int d2 = a.rope_half;
-    float val = d < hd ? x[d] : 0.0f;
-    if (d < 2 * d2) {
-        const float c = a.rope_cos[(size_t)pos * d2 + (d % d2)], s = a.rope_sin[(size_t)pos * d2 + (d % d2)];
-        if (d < d2) val = x[d] * c - x[d2 + d] * s;
-        else val = x[d] * c + x[d - d2] * s;
-    }
-    if (d < hd) {
-        if (is_q) a.q_out[(size_t)t * a.nh * hd + (size_t)h * hd + d] = val;
-        else {
-            const size_t o = (size_t)pos * a.nkv * hd + (size_t)h * hd + d;
-            kr_kv_store(a.k_cache, o, val, a.kv_fp8);
-            kr_kv_store(a.v_cache, o, v_in[(size_t)h * hd + d], a.kv_fp8);
+    for (int tw = 0; tw < PFQ_TT / 4; tw++) {
+        const int t = blockIdx.y * PFQ_TT + tw * 4 + wave;
+        if (t >= C) break;                                        // wave-uniform
+        const int pos = a.pos0 + t;
+        const float* q_in = a.q_in + (size_t)t * a.ld_q; const float* k_in = a.k_in + (size_t)t * a.ld_k; const float* v_in = a.v_in + (size_t)t * a.ld_v;
+        float4 vv[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {                             // hd <= 256: at most one chunk per lane (two iterations keep hd up to 512 correct)
+            const int ci = lane + 64 * j;
+            vv[j] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (j < njc && ci < nc) {
+                float4 xv;
+                if (is_q) {
+                    if (a.gated) {
+                        xv = *reinterpret_cast<const float4*>(q_in + (size_t)h * hd * 2 + 4 * ci);
+                        *reinterpret_cast<float4*>(a.gate + (size_t)t * a.nh * hd + (size_t)h * hd + 4 * ci) = *reinterpret_cast<const float4*>(q_in + (size_t)h * hd * 2 + hd + 4 * ci);
+                    } else xv = *reinterpret_cast<const float4*>(q_in + (size_t)h * hd + 4 * ci);
+                } else { xv = *reinterpret_cast<const float4*>(k_in + (size_t)h * hd + 4 * ci); vv[j] = *reinterpret_cast<const float4*>(v_in + (size_t)h * hd + 4 * ci); }
+                *reinterpret_cast<float4*>(x + 4 * ci) = xv;
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        if (nw) {
+            if (lane == 0) {
+                float ss = 0.0f;
+                const float4* x4 = reinterpret_cast<const float4*>(x);
+                for (int i = 0; i < nc; i++) { const float4 v = x4[i]; ss += v.x * v.x; ss += v.y * v.y; ss += v.z * v.z; ss += v.w * v.w; }      // index order (decode.rs:2891)
+                x[hd] = 1.0f / sqrtf(ss / (float)hd + a.eps);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            const float rms = x[hd];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {                         // a lane rewrites only the chunk it owns: no hazard inside the wave
+                const int ci = lane + 64 * j;
+                if (j < njc && ci < nc) {
+                    const float4 xv = *reinterpret_cast<const float4*>(x + 4 * ci);
+                    const float4 wv = *reinterpret_cast<const float4*>(nw + (per_head ? h * hd : 0) + 4 * ci);
+                    *reinterpret_cast<float4*>(x + 4 * ci) = float4{xv.x * (rms * wv.x), xv.y * (rms * wv.y), xv.z * (rms * wv.z), xv.w * (rms * wv.w)};
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int ci = lane + 64 * j;
+            if (j < njc && ci < nc) {
+                float val[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int d = 4 * ci + e;
+                    val[e] = x[d];
+                    if (d < 2 * d2) {
+                        const float c = a.rope_cos[(size_t)pos * d2 + (d % d2)], sn = a.rope_sin[(size_t)pos * d2 + (d % d2)];
+                        if (d < d2) val[e] = x[d] * c - x[d2 + d] * sn;
+                        else val[e] = x[d] * c + x[d - d2] * sn;
+                    }
+                }
+                if (is_q) *reinterpret_cast<float4*>(a.q_out + (size_t)t * a.nh * hd + (size_t)h * hd + 4 * ci) = float4{val[0], val[1], val[2], val[3]};
+                else {
+                    const size_t o = (size_t)pos * a.nkv * hd + (size_t)h * hd + 4 * ci;
+                    const float ve[4] = {vv[j].x, vv[j].y, vv[j].z, vv[j].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { kr_kv_store(a.k_cache, o + e, val[e], a.kv_fp8); kr_kv_store(a.v_cache, o + e, ve[e], a.kv_fp8); }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();      // the slice is rewritten by the wave's next row
     }
 }
 
@@ -792,12 +836,12 @@ int kr_launch_pfm_la_recur(float* state, const float* q, const float* k, const f
 }
 int kr_pfm_gqa_tile(int nh, int nkv) { const int group = nh / nkv; int tt = PFA_TT_MAX / group; return tt < 1 ? 0 : tt; }
 void kr_launch_pfm_gqa_prep(const KrPfmGqaArgs& a, int C, hipStream_t st) {
-    hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, C), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, (C + PFQ_TT - 1) / PFQ_TT), dim3(256), 0, st, a, C);
 }
 int kr_launch_pfm_gqa(const KrPfmGqaArgs& a, int C, float* sc, int sc_ld, float* inv, hipStream_t st, const KrPfSync* sy) {
     const int group = a.nh / a.nkv, TT = kr_pfm_gqa_tile(a.nh, a.nkv);
     if (TT == 0 || a.hd > 256 || a.hd % 32 || a.nh % a.nkv) return 1;
-    hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, C), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kr_pfm_gqa_prep_kernel, dim3(a.nh + a.nkv, (C + PFQ_TT - 1) / PFQ_TT), dim3(256), 0, st, a, C);
     if (sy) { kr_pf_wait(st, sy->wait_b); kr_pf_rec(st, sy->rec_b); }      // this chunk's rows are appended; the earlier chunks' rows are what the passes below read
     static const bool no_mfma = getenv("KR_EXACT_ATTN_VALU") != nullptr;       // tuning / A-B hook: keep the vector-ALU passes
     if (!no_mfma && kr_pfm_gqa_exact_mfma_ok(a)) {                              // scores and P.V on the f32 matrix cores, same bits (kr_attn_exact_mfma.hip)
