@@ -309,33 +309,26 @@ __global__ void __launch_bounds__(256) kr_pfm_gated_norm_kernel(const float* __r
     __shared__ __attribute__((aligned(16))) float rs[4][256 + 8];
     const int h = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* r = rs[wave];
-    const int nj = (dv + 63) / 64;
-    // z of value head h: block (h / z_hr) of z_kstride floats, then head h % z_hr inside it (plain [C][nv * dv] rows: z_hr = nv... handled by the launcher's numbers)
+    const int nc = dv / 4;                                          // 16-byte chunks of a row (dv % 8 == 0, dv <= 256: one chunk per lane at most)
+    // z of value head h: block (h / z_hr) of z_kstride floats, then head h % z_hr inside it (plain [C][nv * dv] rows: z_hr = nv, one block)
     const size_t zoff = (size_t)(h / z_hr) * z_kstride + (size_t)(h % z_hr) * dv;
+    const bool act = lane < nc;
+    const float4 wv = act ? *reinterpret_cast<const float4*>(w + (size_t)h * dv + 4 * lane) : float4{0.0f, 0.0f, 0.0f, 0.0f};
     for (int tw = 0; tw < PFG_TT / 4; tw++) {
         const int t = blockIdx.y * PFG_TT + tw * 4 + wave;
         if (t >= C) break;                                        // wave-uniform
         const size_t o = (size_t)t * nv * dv + (size_t)h * dv;
-        float v[4], zz[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i = lane + 64 * j;
-            v[j] = (j < nj && i < dv) ? recur[o + i] : 0.0f;
-            zz[j] = (j < nj && i < dv) ? z[(size_t)t * z_ld + zoff + i] : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) { const int i = lane + 64 * j; if (j < nj && i < dv) r[i] = v[j]; }
+        float4 v = float4{0.0f, 0.0f, 0.0f, 0.0f}, zz = v;
+        if (act) { v = *reinterpret_cast<const float4*>(recur + o + 4 * lane); zz = *reinterpret_cast<const float4*>(z + (size_t)t * z_ld + zoff + 4 * lane); *reinterpret_cast<float4*>(r + 4 * lane) = v; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
         if (lane < 8) { const float ss = kr_pfm_sumsq8(r, dv, lane); if (lane == 0) r[256] = 1.0f / sqrtf(ss / (float)dv + eps); }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
         const float rms = r[256];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i = lane + 64 * j;
-            if (j < nj && i < dv) {
-                const float normed = (v[j] * rms) * w[(size_t)h * dv + i];
-                out[o + i] = (zz[j] * kr_sigmoid_poly5(zz[j])) * normed;
-            }
+        if (act) {
+            float4 ov;
+            ov.x = (zz.x * kr_sigmoid_poly5(zz.x)) * ((v.x * rms) * wv.x); ov.y = (zz.y * kr_sigmoid_poly5(zz.y)) * ((v.y * rms) * wv.y);
+            ov.z = (zz.z * kr_sigmoid_poly5(zz.z)) * ((v.z * rms) * wv.z); ov.w = (zz.w * kr_sigmoid_poly5(zz.w)) * ((v.w * rms) * wv.w);
+            *reinterpret_cast<float4*>(out + o + 4 * lane) = ov;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();      // the slice is rewritten by the wave's next row
     }
