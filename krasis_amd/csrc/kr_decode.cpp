@@ -1013,6 +1013,7 @@ extern "C" int kr_decode_set_option(kr_decode_store* s, const char* name, int va
     if (!strcmp(name, "lm_fused")) { s->opt_lm_fused = value != 0; s->graph_ok = false; return KR_OK; }        // KR_DECODE_FAST: 0 = final norm and vocabulary projection as two launches (A/B and test hook)
     if (!strcmp(name, "gqa_fused")) { s->opt_gqa_fused = value != 0; s->graph_ok = false; return KR_OK; }      // KR_DECODE_FAST, short caches: 0 = prep + attention as two launches (A/B and test hook)
     if (!strcmp(name, "gemm_ring")) { kr_pfr_set_enabled(value); return KR_OK; }                              // KR_GEMM_FAST: 0 = register-staged tolerance GEMMs only, 1 = ring form for big problems (default), 2 = for every shape it takes (process-wide A/B and test hook; same bits)
+    if (!strcmp(name, "la_conv_fused")) { s->opt_la_conv_fused = value != 0; return KR_OK; }                // KR_ATTN_FAST prompt pass: 0 = the stand-alone conv launch in front of the delta-rule prep (A/B and test hook; same bits)
     if (!strcmp(name, "norm_rows")) { s->opt_norm_rows = value != 0; return KR_OK; }                        // KR_GEMM_FAST prompt pass: 0 = the f16 row image of a norm's output by its own launch (A/B and test hook; same bits)
     if (!strcmp(name, "pfm_timing")) { s->opt_pfm_timing = value != 0; return KR_OK; }
     if (!strcmp(name, "generate_lookahead")) { s->opt_gen_lookahead = value != 0; return KR_OK; }

@@ -101,7 +101,7 @@ static int run_layer(kr_decode_store* s, Chunk& cx, size_t li) {
         a.qkvz = B.pa; a.ld_qkvz = nq; a.ba = B.pb; a.ld_ba = nb; a.conv_state = (float*)L.conv_state.p; a.conv_w = (const float*)L.conv_w.p;
         a.a_log = (const float*)L.a_log.p; a.dt_bias = (const float*)L.dt_bias.p; a.scale = L.la_scale; a.q = B.q; a.k = B.k; a.v = B.v; a.z = B.z;
         a.gexp = B.gexp; a.beta = B.beta; a.nk = L.nk; a.nv = L.nv; a.dk = L.dk; a.dv = L.dv; a.hr = L.nv / L.nk;
-        a.lac = B.lac; a.fast = s->attn_fast;
+        a.lac = B.lac; a.fast = s->attn_fast; a.conv_fused = s->opt_la_conv_fused;
         if (kr_launch_pfm_la(a, (float*)L.recur_state.p, B.recur, (const float*)L.la_norm_w.p, B.attn, Cc, s->eps, st, &cx.sy))
             return kr_fail(KR_ERR_VALUE, "unsupported linear-attention geometry");
         if (oc != L.nv * L.dv) return kr_fail(KR_ERR_VALUE, "out_proj cols %d != nv*dv", oc);

@@ -23,6 +23,8 @@
 // decay that underflows gives 0, not NaN (g is clamped at -80 per token).
 #include <hip/hip_runtime.h>
 #include "kr_lds_optin.h"
+#include "kr_device.h"
+#include "kr_libm.h"
 #include "kr_prefill_ops.h"
 
 #ifdef KR_TIMING   // tools/probes/lac_timing.hip: wall-clock stamps (10 ns units) by thread 0 of workgroup (0, 0); no-op in the product build
@@ -38,6 +40,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // 1.1 us per 16 values on a lone wave -- more than the epilogue it sits in
 __device__ __forceinline__ float lc_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 typedef __bf16 lc_b8 __attribute__((ext_vector_type(8)));
+// sum of squares of x[0..n) with 8 fma lanes (lane l owns elements 8 b + l, b ascending) folded by the reference's hsum tree: kr_pfm_sumsq8 of kr_prefill_ops.hip,
+// callable by ANY aligned group of 8 lanes (the fold uses xor shuffles inside the group)
+__device__ __forceinline__ float kr_lc_sumsq8(const float* x, int n, int l) {
+    float acc = 0.0f;
+    for (int b = 0; b < n / 8; b++) { const float v = x[b * 8 + l]; acc = __builtin_fmaf(v, v, acc); }
+    acc = acc + __shfl_xor(acc, 4); acc = acc + __shfl_xor(acc, 1); acc = acc + __shfl_xor(acc, 2);
+    return acc;
+}
 typedef uint32_t lc_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t lc_u2 __attribute__((ext_vector_type(2)));
 // x = hi + lo in bf16 (round to nearest even, v_cvt_pk_bf16_f32): the pair carries x to ~2^-17 relative
@@ -51,13 +61,17 @@ __device__ __forceinline__ void lc_split(float x, uint16_t& hi, uint16_t& lo) {
 #define LC_LD 132      // LDS row stride (floats) of the 64 x 128 tiles: rows 4 banks apart -> the float4 k-contiguous reads are conflict-free
 #define LC_LS 68       // row stride of the 64 x 64 matrices
 #define LC_SS 40       // row stride of the 32-column state / delta slices: rows k and k+4 are 32 banks apart
-#define LC_PREP_LDS ((3 * LC_T * LC_LD + 2 * LC_T * LC_LS + 3 * LC_T) * 4)
+#define LC_PREP_LDS ((3 * LC_T * LC_LD + 2 * LC_T * LC_LS + 3 * LC_T + 2 * LC_T) * 4)      // K, Q, V tiles, L, B, G / b / b e^G, (fused) the 2 x 64 inverse norms
 #define LC_PA 272      // bytes per row of a [rows][128 k] bf16 plane in LDS (256 + 16: the 16-byte fragment reads of 32 consecutive rows spread over the banks)
 #define LC_PT 144      // bytes per row of a [rows][64 k] bf16 plane
 #define LC_SCAN_LDS (4 * LC_T * LC_PA + 2 * LC_D * LC_PT + 2 * 32 * LC_PA + 2 * 32 * LC_PT + LC_T * 4)
 
 struct KrLacArgs {
-    const float *q, *k, *v, *gexp, *beta;   // [C][nv*128] x3, [C][nv] x2
+    const float *q, *k, *v, *gexp, *beta;   // [C][nv*128] x3, [C][nv] x2   (unused when `fused`)
+    // fused != 0 (round 6): the prep launch forms q / k / v / e^g / beta itself from the in-projection's output -- causal conv over the carried conv slots + the
+    // chunk's rows, SiLU, the two L2 norms, the gates: the arithmetic of kr_pfm_la_conv_kernel (kr_prefill_ops.hip), value for value -- so that launch, its
+    // 540 MB of q / k / v / z stores per 8192 tokens and the prep's re-read of them disappear from the tolerance pass
+    int fused; const float* qkvz; int ld_qkvz; const float* ba; int ld_ba; const float *conv_state, *conv_w, *a_log, *dt_bias; float scale; int nk, hr;
     float *Y, *G;                           // [n_sub*nv][64][128], [n_sub*nv][64]
     uint16_t *Wh, *Wl, *Qh, *Ql;            // bf16 planes [n_sub*nv][64][128] of W and Q' (hi, lo)
     uint16_t *Kh, *Kl;                      // bf16 planes [n_sub*nv][128][64] of K^T
@@ -118,6 +132,76 @@ __global__ void __launch_bounds__(LC_PTH) kr_lac_prep_kernel(KrLacArgs a) {
     const int c0 = sub * LC_T, n = min(LC_T, a.C - c0);
     const size_t ld = (size_t)a.nv * LC_D, tile = ((size_t)sub * a.nv + h) * LC_T;
     LC_STAMP(0);
+    float* nrm = bg + LC_T;       // [64][2] inverse L2 norms of the q / k rows (fused form)
+    if (a.fused) {
+        // ---- the tiles from the in-projection's output: thread = (4 consecutive tokens, 4 consecutive channels), three passes (q, k, v); the 4-tap window of the four
+        // tokens is 7 rows of 16 bytes.  Tap j of token t is X(t - 3 + j): a chunk row for >= 0, carried conv slot 4 + i for i < 0 (kr_pfm_la_conv_kernel).
+        const int kh = h / a.hr, rr = h % a.hr, gd = 2 * LC_D + 2 * LC_D * a.hr, key_dim = a.nk * LC_D;
+        const int tg = tid >> 5, c = (tid & 31) * 4;
+#pragma unroll 1
+        for (int arr = 0; arr < 3; arr++) {
+            const int ch = arr == 0 ? kh * LC_D + c : (arr == 1 ? key_dim + kh * LC_D + c : 2 * key_dim + h * LC_D + c);       // conv channel of column c
+            const int off = arr == 0 ? c : (arr == 1 ? LC_D + c : 2 * LC_D + rr * LC_D + c);                                     // its column inside the key head's group
+            const float* col = a.qkvz + (size_t)kh * gd + off;
+            const float* cs = a.conv_state + (size_t)ch * 4;
+            float4 cw[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) cw[q4] = *reinterpret_cast<const float4*>(a.conv_w + (size_t)(ch + q4) * 4);
+            float4 x[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const int i = c0 + 4 * tg - 3 + j;
+                if (i < 0) x[j] = float4{cs[4 + i], cs[8 + i], cs[12 + i], cs[16 + i]};
+                else x[j] = i < a.C ? *reinterpret_cast<const float4*>(col + (size_t)i * a.ld_qkvz) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            float* T = arr == 0 ? Qt : (arr == 1 ? Kt : Vt);
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) {
+                const int t = 4 * tg + tt;
+                float4 co = float4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (t < n) {
+                    co.x = x[tt].x * cw[0].x + x[tt + 1].x * cw[0].y + x[tt + 2].x * cw[0].z + x[tt + 3].x * cw[0].w;
+                    co.y = x[tt].y * cw[1].x + x[tt + 1].y * cw[1].y + x[tt + 2].y * cw[1].z + x[tt + 3].y * cw[1].w;
+                    co.z = x[tt].z * cw[2].x + x[tt + 1].z * cw[2].y + x[tt + 2].z * cw[2].z + x[tt + 3].z * cw[2].w;
+                    co.w = x[tt].w * cw[3].x + x[tt + 1].w * cw[3].y + x[tt + 2].w * cw[3].z + x[tt + 3].w * cw[3].w;
+                    co.x = co.x * kr_sigmoid_poly5(co.x); co.y = co.y * kr_sigmoid_poly5(co.y); co.z = co.z * kr_sigmoid_poly5(co.z); co.w = co.w * kr_sigmoid_poly5(co.w);
+                }
+                *reinterpret_cast<float4*>(T + t * LC_LD + c) = co;
+            }
+        }
+        if (wave == 0) {      // gates of the 64 tokens (decode.rs:3891-3901), then the running sum of g as below
+            const int t = lane;
+            float g = 0.0f, b = 0.0f;
+            if (t < n) {
+                const float* ba = a.ba + (size_t)(c0 + t) * a.ld_ba;
+                const float b_raw = ba[kh * 2 * a.hr + rr], a_p = ba[kh * 2 * a.hr + a.hr + rr];
+                b = 1.0f / (1.0f + kr_expf(-b_raw));
+                const float ap_dt = a_p + a.dt_bias[h];
+                const float softplus = ap_dt > 20.0f ? ap_dt : kr_logf(1.0f + kr_expf(ap_dt));
+                const float ge = kr_expf(-(kr_expf(a.a_log[h])) * softplus);
+                g = fmaxf(logf(fmaxf(ge, 1e-37f)), -80.0f);
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(g, o); if (lane >= o) g += y; }
+            Gs[t] = g; bs[t] = b; bg[t] = b * lc_exp(g);
+            a.G[tile + t] = g;
+        }
+        __syncthreads();
+        // L2 norms of the 64 q rows and 64 k rows: 8 lanes per chain, the reference's order (kr_pfm_sumsq8); 128 chains on 512 threads in two rounds
+        for (int u = tid; u < 2 * LC_T * 8; u += LC_PTH) {
+            const int rowi = u >> 3, l = u & 7, t = rowi >> 1, which = rowi & 1;
+            const float ss = kr_lc_sumsq8((which ? Kt : Qt) + t * LC_LD, LC_D, l);
+            if (l == 0) nrm[t * 2 + which] = ss > 0.0f ? 1.0f / sqrtf(ss) : 0.0f;
+        }
+        __syncthreads();
+        for (int u = tid; u < LC_T * 32; u += LC_PTH) {
+            const int t = u >> 5, c4 = (u & 31) * 4;
+            const float inv_q = nrm[t * 2] * a.scale, inv_k = nrm[t * 2 + 1] * 1.0f;
+            float4 qv = *reinterpret_cast<float4*>(Qt + t * LC_LD + c4), kv = *reinterpret_cast<float4*>(Kt + t * LC_LD + c4);
+            *reinterpret_cast<float4*>(Qt + t * LC_LD + c4) = float4{qv.x * inv_q, qv.y * inv_q, qv.z * inv_q, qv.w * inv_q};
+            *reinterpret_cast<float4*>(Kt + t * LC_LD + c4) = float4{kv.x * inv_k, kv.y * inv_k, kv.z * inv_k, kv.w * inv_k};
+        }
+    } else {
     // ---- tiles (rows past the chunk end are zero: b = 0, g = 0 make them inert)
     for (int u = tid; u < LC_T * 32; u += LC_PTH) {
         const int t = u >> 5, c4 = (u & 31) * 4;
@@ -136,6 +220,7 @@ __global__ void __launch_bounds__(LC_PTH) kr_lac_prep_kernel(KrLacArgs a) {
         const float b = t < n ? a.beta[(size_t)(c0 + t) * a.nv + h] : 0.0f;
         Gs[t] = g; bs[t] = b; bg[t] = b * lc_exp(g);
         a.G[tile + t] = g;
+    }
     }
     __syncthreads();
     LC_STAMP(1);
@@ -453,10 +538,15 @@ static int lac_prepare() {
     return kr_lds_optin(reinterpret_cast<const void*>(kr_lac_prep_kernel), LC_PREP_LDS) || kr_lds_optin(reinterpret_cast<const void*>(kr_lac_scan_kernel), LC_SCAN_LDS);
 }
 
-int kr_launch_pfm_la_chunked(const KrPfmLaArgs& p, float* state, float* out, float* scratch, int C, hipStream_t st, const KrPfSync* sy) {
+// fused != 0: the prep launch forms q / k / v and the gates from the in-projection's output itself (no conv launch ran); `between` (may be null) is called between the
+// two launches, on the stream -- the carried conv slots are advanced there, AFTER the prep launch has read the old ones
+int kr_launch_pfm_la_chunked(const KrPfmLaArgs& p, float* state, float* out, float* scratch, int C, hipStream_t st, const KrPfSync* sy, int fused, void (*between)(const KrPfmLaArgs&, int, hipStream_t, const KrPfSync*)) {
     if (!kr_pfm_la_chunk_ok(p.dk, p.dv, C) || !scratch) return 1;
+    if (fused && (p.nv != p.nk * p.hr || p.ld_qkvz % 4)) return 1;
     if (lac_prepare()) return 1;
     KrLacArgs a{};
+    a.fused = fused; a.qkvz = p.qkvz; a.ld_qkvz = p.ld_qkvz; a.ba = p.ba; a.ld_ba = p.ld_ba; a.conv_state = p.conv_state; a.conv_w = p.conv_w; a.a_log = p.a_log; a.dt_bias = p.dt_bias;
+    a.scale = p.scale; a.nk = p.nk; a.hr = p.hr;
     a.q = p.q; a.k = p.k; a.v = p.v; a.gexp = p.gexp; a.beta = p.beta; a.nv = p.nv; a.C = C; a.n_sub = (C + LC_T - 1) / LC_T;
     const size_t tiles = (size_t)a.n_sub * p.nv * LC_T;
     a.Y = scratch; a.G = a.Y + tiles * LC_D;
@@ -464,6 +554,7 @@ int kr_launch_pfm_la_chunked(const KrPfmLaArgs& p, float* state, float* out, flo
     a.Wh = pl; a.Wl = a.Wh + tiles * LC_D; a.Qh = a.Wl + tiles * LC_D; a.Ql = a.Qh + tiles * LC_D; a.Kh = a.Ql + tiles * LC_D; a.Kl = a.Kh + tiles * LC_D;
     a.out = out; a.state = state;
     hipLaunchKernelGGL(kr_lac_prep_kernel, dim3(a.n_sub, p.nv), dim3(LC_PTH), LC_PREP_LDS, st, a);
+    if (between) between(p, C, st, sy);
     if (sy) kr_pf_wait(st, sy->wait_b);      // only the scan reads the state the previous chunk of the prompt leaves
     hipLaunchKernelGGL(kr_lac_scan_kernel, dim3(p.nv * 4), dim3(256), LC_SCAN_LDS, st, a);
     return 0;

@@ -28,6 +28,7 @@ struct KrPfmLaArgs {
     float *q, *k, *v, *z, *gexp, *beta;   // [C, nv*dk] x2, [C, nv*dv] x2, [C, nv] x2
     int nk, nv, dk, dv, hr;
     float* lac; int fast;                 // FAST mode: scratch of the 64-token closed form (kr_la_chunk.hip), kr_pfm_la_chunk_scratch_floats(C, nv) floats
+    int conv_fused;                       // FAST mode (round 6): the conv / norms / gates inside the prep launch, z read by the gated norm where the in-projection left it (no conv launch)
 };
 struct KrPfmGqaArgs {
     const float *q_in, *k_in, *v_in; int ld_q, ld_k, ld_v;
@@ -64,6 +65,7 @@ bool kr_pfm_gqa_flash_ok(int nh, int nkv, int hd);      // geometries the flash 
 void kr_launch_pfm_gqa_prep(const KrPfmGqaArgs& a, int C, hipStream_t st);
 int kr_launch_pfm_la_recur(float* state, const float* q, const float* k, const float* v, const float* gexp, const float* beta, float* out, int nv, int dk, int dv, int C, hipStream_t st);
 // FAST mode (kr_la_chunk.hip): the gated delta rule over the chunk in sub-chunks of 64 tokens on the f32 MFMA; non-zero = geometry not covered
-int kr_launch_pfm_la_chunked(const KrPfmLaArgs& a, float* recur_state, float* recur_out, float* scratch, int C, hipStream_t st, const KrPfSync* sy = nullptr);
+int kr_launch_pfm_la_chunked(const KrPfmLaArgs& a, float* recur_state, float* recur_out, float* scratch, int C, hipStream_t st, const KrPfSync* sy = nullptr, int fused = 0,
+                             void (*between)(const KrPfmLaArgs&, int, hipStream_t, const KrPfSync*) = nullptr);
 size_t kr_pfm_la_chunk_scratch_floats(int C, int nv);
 bool kr_pfm_la_chunk_ok(int dk, int dv, int C);

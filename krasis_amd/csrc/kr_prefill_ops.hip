@@ -796,16 +796,29 @@ void kr_launch_pfm_quant_f32(const float* x, int rows, int ld, int K, int8_t* xh
     const int thr = K / 8 < 1024 ? ((K / 8 + 15) / 16) * 16 : 1024;
     hipLaunchKernelGGL(kr_pfm_quant_f32_kernel, dim3(rows), dim3(thr), 0, st, x, ld, K, xh, xl, xs);
 }
+static void pfm_la_conv_state(const KrPfmLaArgs& a, int C, hipStream_t st, const KrPfSync* sy) {      // advance the carried conv slots, then publish them to the next chunk
+    const int conv_dim = 2 * a.nk * a.dk + a.nv * a.dv;
+    hipLaunchKernelGGL(kr_pfm_la_conv_state_kernel, dim3((conv_dim + 255) / 256), dim3(256), 0, st, a, C);
+    kr_pf_rec(st, sy->rec_a);
+}
 int kr_launch_pfm_la(const KrPfmLaArgs& a, float* recur_state, float* recur_out, const float* norm_w, float* gated_out, int C, float eps, hipStream_t st, const KrPfSync* sy) {
     if (a.dv > 256 || a.dv % 8 || a.dv < a.dk || a.dk % 8) return 1;
     const KrPfSync none{};
     if (!sy) sy = &none;
     kr_pf_wait(st, sy->wait_a);              // the previous chunk's carried conv slots
     if (a.dk % 4 || a.dv % 4 || a.ld_qkvz % 4) return 1;      // 16-byte row reads
+    // tolerance pass, round 6: no conv launch -- the delta rule's prep launch forms q / k / v / gates from the in-projection's output (same arithmetic), the carried conv
+    // slots are advanced behind it, the gated norm reads z in place
+    if (a.fast && a.conv_fused && a.lac && kr_pfm_la_chunk_ok(a.dk, a.dv, C) && a.nv == a.nk * a.hr &&
+        kr_launch_pfm_la_chunked(a, recur_state, recur_out, a.lac, C, st, sy, 1, pfm_la_conv_state) == 0) {
+        kr_pf_rec(st, sy->rec_b);
+        const int gd = 2 * a.dk + 2 * a.dv * a.hr;
+        hipLaunchKernelGGL(kr_pfm_gated_norm_kernel, dim3(a.nv, (C + PFG_TT - 1) / PFG_TT), dim3(256), 0, st, recur_out, a.qkvz + 2 * a.dk + a.hr * a.dv, (size_t)a.ld_qkvz, a.hr, gd, norm_w,
+                           gated_out, a.nv, a.dv, C, eps);
+        return 0;
+    }
     hipLaunchKernelGGL(kr_pfm_la_conv_kernel, dim3(a.nk, (C + PFC_WT - 1) / PFC_WT), dim3(256), (size_t)(2 * PFC_WT * a.dk + 2 * PFC_WT) * 4, st, a, C);
-    const int conv_dim = 2 * a.nk * a.dk + a.nv * a.dv;
-    hipLaunchKernelGGL(kr_pfm_la_conv_state_kernel, dim3((conv_dim + 255) / 256), dim3(256), 0, st, a, C);
-    kr_pf_rec(st, sy->rec_a);
+    pfm_la_conv_state(a, C, st, sy);
     // the recurrent state: the chunked form waits between its two launches (the first needs no state), the per-token kernel before its one launch
     if (a.fast && a.lac && kr_pfm_la_chunk_ok(a.dk, a.dv, C) && kr_launch_pfm_la_chunked(a, recur_state, recur_out, a.lac, C, st, sy) == 0) {}
     else {

@@ -108,3 +108,35 @@ def test_norm_launch_writes_the_f16_row_image_bit_identically(kinds):
     assert np.isfinite(res[1][0]).all()
     assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
     assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+
+
+@pytest.mark.parametrize("kinds,ntok", [(["la", "gqa", "la"], 300), (["la", "la"], 131)])
+def test_conv_inside_the_delta_rule_prep_launch_bit_identical(kinds, ntok):
+    """round 6: in the KR_ATTN_FAST prompt pass the causal conv + SiLU + L2 norms + gates of a linear-attention layer are formed by the delta rule's prep launch from
+    the in-projection's output (kr_lac_prep_kernel, KrLacArgs::fused) and the gated norm reads z in place; kr_pfm_la_conv_kernel does not run.  Same arithmetic value for
+    value: last-position logits, recurrent state and carried conv state bit for bit against the stand-alone conv launch (option la_conv_fused = 0); chunks of 64 tokens so
+    that the carried conv slots cross chunk borders, a ragged last sub-chunk."""
+    from tests.test_attn_fast_gpu import build
+    rng = np.random.default_rng(8)
+    toks = None
+    res = []
+    for fused in (0, 1):
+        st, eng, orc, keep, d = build(seed=31, kv_max=400, kinds=kinds, hd=128, nh=8)
+        st.set_attention_mode(True, gemm_fast=False)
+        st.set_option("la_conv_fused", fused)
+        st.set_prefill_chunk(128)
+        if toks is None:
+            toks = [int(t) for t in rng.integers(0, d["V"], ntok)]
+        lg = np.empty(d["V"], F)
+        st.prefill(toks, 0, lg.ctypes.data)
+        states = []
+        for li, kind in enumerate(d["kinds"]):
+            if kind == "la":
+                cs = np.empty(d["conv_dim"] * 4, F); rs = np.empty(d["nv"] * d["dk"] * d["dv"], F)
+                st.get_decode_state(li, None, None, cs, rs)
+                states += [cs, rs]
+        res.append((lg.copy(), states))
+    assert np.isfinite(res[1][0]).all()
+    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32)), float(np.abs(res[0][0] - res[1][0]).max())
+    for a_, b_ in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a_.view(np.uint32), b_.view(np.uint32))
