@@ -312,9 +312,118 @@ __global__ void __launch_bounds__(64 * (KS == 1 ? 2 : KS), 2) kr_route_logits_fa
         }
     }
 }
+// Round 6, second form: the same products as a workgroup-tiled GEMM.  The fragment-from-global kernels above re-read the x tile once per 64-expert column tile and the
+// gate once per 32-token row tile -- 1 GB of L2 -> CU traffic per 8192-token launch (134 us: the L2 path, not the matrix pipe) -- and every wave converts the x values it
+// reads.  Here a workgroup of four waves owns TM tokens x 128 experts: per 32-k step the x tile is read ONCE in whole 128-byte lines, split into its hi / lo bf16 planes
+// by the thread that loaded it, and parked in LDS beside the gate tile (both double-buffered: the next step's global loads are in flight during the MFMAs, one barrier
+// per step); a wave's fragments are 16-byte LDS reads (rows 80 bytes apart: conflict-free).  Per logit: MFMA(hi) then MFMA(lo) per 16 k, k ascending -- the order
+// of the KS = 1 kernel.
+#define RLT_LD 80            // bytes per LDS row: 32 bf16 + 16 pad
+template <int TM>            // 64 or 128 tokens per workgroup; waves 2 x 2, each TM / 2 x 64
+__global__ void __launch_bounds__(256) kr_route_logits_tiled_kernel(const uint16_t* __restrict__ gate_row, const float* __restrict__ x, const float* __restrict__ bias,
+                                                                   float* __restrict__ logits, int T, int E, int H) {
+    constexpr int NRB = TM / 64;                 // 32-row blocks per wave
+    constexpr int XPT = TM / 32;                 // float4 of x per thread and step
+    __shared__ __attribute__((aligned(16))) char lds[2][(2 * TM + 128) * RLT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int t0 = blockIdx.y * TM, e0 = blockIdx.x * 128;
+    // staging maps: x -- row (tid >> 3) + 32 j, float4 tid & 7 of the step's 32 floats (8 lanes = one 128-byte line); gate -- row (tid >> 2) + 64 j, 16-byte chunk tid & 3
+    const float* xp[XPT];
+#pragma unroll
+    for (int j = 0; j < XPT; j++) xp[j] = x + (size_t)min(t0 + (tid >> 3) + 32 * j, T - 1) * H + (tid & 7) * 4;
+    const uint16_t* gp[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) gp[j] = gate_row + (size_t)min(e0 + (tid >> 2) + 64 * j, E - 1) * H + (tid & 3) * 8;
+    rm_f4 px[XPT]; rm_u4 pg[2];
+    auto fetch = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < XPT; j++) px[j] = *reinterpret_cast<const rm_f4*>(xp[j] + 32 * st);
+#pragma unroll
+        for (int j = 0; j < 2; j++) pg[j] = *reinterpret_cast<const rm_u4*>(gp[j] + 32 * st);
+    };
+    auto commit = [&](int buf) {
+        char* Xh = lds[buf]; char* Xl = Xh + TM * RLT_LD; char* G = Xl + TM * RLT_LD;
+#pragma unroll
+        for (int j = 0; j < XPT; j++) {
+            const float v[4] = {px[j].x, px[j].y, px[j].z, px[j].w};
+            uint16_t hi[4], lo[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const __bf16 hb = (__bf16)v[i]; const __bf16 lb = (__bf16)(v[i] - (float)hb); hi[i] = __builtin_bit_cast(uint16_t, hb); lo[i] = __builtin_bit_cast(uint16_t, lb); }
+            const int off = ((tid >> 3) + 32 * j) * RLT_LD + (tid & 7) * 8;
+            *reinterpret_cast<uint2*>(Xh + off) = uint2{(uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16)};
+            *reinterpret_cast<uint2*>(Xl + off) = uint2{(uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16)};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) *reinterpret_cast<rm_u4*>(G + ((tid >> 2) + 64 * j) * RLT_LD + (tid & 3) * 16) = pg[j];
+    };
+    rm_v16f acc[NRB][2];
+#pragma unroll
+    for (int a_ = 0; a_ < NRB; a_++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[a_][c][i] = 0.0f;
+    const int nst = H / 32;
+    fetch(0); commit(0);
+    __syncthreads();
+    for (int st = 0; st < nst; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nst) fetch(st + 1);
+        const char* Xh = lds[buf]; const char* Xl = Xh + TM * RLT_LD; const char* G = Xl + TM * RLT_LD;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            rm_b8 ah[NRB], al[NRB], b[2];
+#pragma unroll
+            for (int a_ = 0; a_ < NRB; a_++) {
+                const int row = wr * (TM / 2) + a_ * 32 + r;
+                ah[a_] = *reinterpret_cast<const rm_b8*>(Xh + row * RLT_LD + ks * 32 + h * 16);
+                al[a_] = *reinterpret_cast<const rm_b8*>(Xl + row * RLT_LD + ks * 32 + h * 16);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; c++) b[c] = *reinterpret_cast<const rm_b8*>(G + (wc * 64 + c * 32 + r) * RLT_LD + ks * 32 + h * 16);
+            // every accumulator's hi product, then every accumulator's lo product: consecutive MFMAs never share an accumulator (per logit still hi, then lo)
+#pragma unroll
+            for (int a_ = 0; a_ < NRB; a_++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) acc[a_][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a_], b[c], acc[a_][c], 0, 0, 0);
+#pragma unroll
+            for (int a_ = 0; a_ < NRB; a_++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) acc[a_][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a_], b[c], acc[a_][c], 0, 0, 0);
+        }
+        if (st + 1 < nst) commit(buf ^ 1);      // the other buffer: its last readers passed the barrier of the previous step
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a_ = 0; a_ < NRB; a_++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int e = e0 + wc * 64 + c * 32 + r;
+            const float bv = (bias && e < E) ? bias[e] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int t = t0 + wr * (TM / 2) + a_ * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (t < T && e < E) logits[(size_t)t * E + e] = acc[a_][c][i] + bv;
+            }
+        }
+}
 // non-zero = not covered (f32 gate, H not a multiple of 32): the caller keeps the exact kernel
 int kr_launch_route_logits_fast(const void* gate_row, int gate_bf16, const float* x, const float* bias, float* logits, int T, int E, int H, hipStream_t st) {
     if (!gate_bf16 || H % 32 || T < 1 || E < 1) return 1;
+    {   // workgroup-tiled form where its tiles still give (nearly) every CU a workgroup: 128-token tiles from ~7 k tokens x 512 experts on (8192 tokens: 74 us against 134),
+        // 64-token tiles for shorter chunks only when the k-split form below does not apply (2752 tokens: both 58 us)
+        const int n128 = (E + 127) / 128;
+        const bool ksplit_ok = H % 128 == 0 && H >= 512;
+        if ((long)((T + 127) / 128) * n128 >= 224) {
+            hipLaunchKernelGGL(kr_route_logits_tiled_kernel<128>, dim3(n128, (T + 127) / 128), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(gate_row), x, bias, logits, T, E, H);
+            return 0;
+        }
+        if (T >= 256 && !ksplit_ok) {
+            hipLaunchKernelGGL(kr_route_logits_tiled_kernel<64>, dim3(n128, (T + 63) / 64), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(gate_row), x, bias, logits, T, E, H);
+            return 0;
+        }
+    }
     if (H % 128 == 0 && H >= 512) {      // four k quarters per output tile: 4 x the waves (2752 tokens: 57.7 us against 70.1 stand-alone, profiles/r06_route_fast_kernel_stats.txt)
         const dim3 grid((E + 63) / 64, (T + 31) / 32);
         hipLaunchKernelGGL(kr_route_logits_fast_kernel<4>, grid, dim3(256), 0, st, reinterpret_cast<const uint16_t*>(gate_row), x, bias, logits, T, E, H);

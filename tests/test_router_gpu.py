@@ -93,7 +93,8 @@ def test_engine_rule_bit_exact(sigmoid):
         assert np.array_equal(w[t].view(np.uint32), r_w.view(np.uint32))
 
 
-@pytest.mark.parametrize("E,H,m,use_bias", [(512, 2048, 300, False), (72, 256, 70, True), (130, 512, 45, True)])
+@pytest.mark.parametrize("E,H,m,use_bias", [(512, 2048, 300, False), (72, 256, 70, True), (130, 512, 45, True),
+                                                (200, 256, 300, True), (130, 256, 700, False), (512, 1024, 7100, True)])      # the workgroup-tiled kernel: 64-token tiles (H = 256: no k-split form) and 128-token tiles (7100 tokens x 512 experts), partial tiles
 def test_decode_rule_batch_logits_tolerance_form(E, H, m, use_bias):
     """kr_moe_set_gemm_mode(e, 1) / KR_GEMM_FAST: the batch logits on the bf16 MFMA with x split into hi + lo bf16 (kr_route_logits_fast_kernel) instead of
     the 16 f32 chains.  STATED TOLERANCE: |fast - exact| <= 2e-5 * sum_k |x_k g_k| per logit (x carried to 2^-17, products summed in another order);
