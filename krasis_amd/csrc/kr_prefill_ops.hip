@@ -772,18 +772,33 @@ __global__ void __launch_bounds__(64) kr_pfm_gqa_pv_kernel(const KrPfmGqaArgs a,
 }
 
 // ---- MoE block epilogue (decode.rs:3343-3402): hidden = moe (*rsf) + shared (*sigmoid(gate)) -------------------------------------
+// (round 6: four columns per thread, 16-byte accesses, the gate's sigmoid once per thread instead of once per element; the same operations per value)
 __global__ void __launch_bounds__(256) kr_pfm_moe_epilogue_kernel(const float* __restrict__ moe, const float* __restrict__ shared, const float* __restrict__ gate_val,
                                                                  int gate_ld, float rsf, float* __restrict__ hidden, int H) {
-    const int t = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y, j = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (j >= H) return;
-    float acc = moe[(size_t)t * H + j];
-    if (rsf != 1.0f) acc *= rsf;
-    if (shared) {
-        float sh = shared[(size_t)t * H + j];
-        if (gate_val) sh *= 1.0f / (1.0f + kr_expf(-gate_val[(size_t)t * gate_ld]));
-        acc = acc + sh;
+    const float sg = (shared && gate_val) ? 1.0f / (1.0f + kr_expf(-gate_val[(size_t)t * gate_ld])) : 1.0f;
+    if (j + 4 <= H && (H & 3) == 0) {
+        float4 acc = *reinterpret_cast<const float4*>(moe + (size_t)t * H + j);
+        if (rsf != 1.0f) { acc.x *= rsf; acc.y *= rsf; acc.z *= rsf; acc.w *= rsf; }
+        if (shared) {
+            float4 sh = *reinterpret_cast<const float4*>(shared + (size_t)t * H + j);
+            if (gate_val) { sh.x *= sg; sh.y *= sg; sh.z *= sg; sh.w *= sg; }
+            acc.x = acc.x + sh.x; acc.y = acc.y + sh.y; acc.z = acc.z + sh.z; acc.w = acc.w + sh.w;
+        }
+        *reinterpret_cast<float4*>(hidden + (size_t)t * H + j) = acc;
+        return;
     }
-    hidden[(size_t)t * H + j] = acc;
+    for (int jj = j; jj < H && jj < j + 4; jj++) {
+        float acc = moe[(size_t)t * H + jj];
+        if (rsf != 1.0f) acc *= rsf;
+        if (shared) {
+            float sh = shared[(size_t)t * H + jj];
+            if (gate_val) sh *= sg;
+            acc = acc + sh;
+        }
+        hidden[(size_t)t * H + jj] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -891,7 +906,7 @@ void kr_launch_pfm_softmax_rows(float* sc, int sc_ld, float* inv, int nh, int po
     hipLaunchKernelGGL(kr_pfm_gqa_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, sc_ld, inv, nh, pos0, rows, tmax);
 }
 void kr_launch_pfm_moe_epilogue(const float* moe, const float* shared, const float* gate_val, int gate_ld, float rsf, float* hidden, int C, int H, hipStream_t st) {
-    hipLaunchKernelGGL(kr_pfm_moe_epilogue_kernel, dim3((H + 255) / 256, C), dim3(256), 0, st, moe, shared, gate_val, gate_ld, rsf, hidden, H);
+    hipLaunchKernelGGL(kr_pfm_moe_epilogue_kernel, dim3((H + 1023) / 1024, C), dim3(256), 0, st, moe, shared, gate_val, gate_ld, rsf, hidden, H);
 }
 
 // ---- negative log-likelihood of the next token per prompt position (perplexity/measure_ppl.py:218-227: cross_entropy(logits[:-1], tokens[1:],
