@@ -302,6 +302,9 @@ int kr_decode_generate(kr_decode_store* s, int first_token, int start_pos, int m
 /* sample_from_logits on the logits of the last decode_step / prefill (modifies them in place like the reference) */
 int kr_decode_sample(kr_decode_store* s, float temperature, int top_k, float top_p, float presence_penalty, uint64_t rng_seed, int reset_seen,
                      int* token_out, void* stream);
+/* test aid (no reference counterpart): the token ids kr_decode_sample draws from, in its order -- the top_k largest of `logits` (host pointers), value descending,
+   equal values by ascending id (decode.rs:3740-3760 sorts by value only; oracle.sample_from_logits fixes the same rule); top_k <= 0: the whole vocabulary */
+int kr_sample_order(const float* logits_host, int vocab, int top_k, int32_t* ids_out_host);
 /* generate_batch (decode.rs:3525), greedy sampling only in this round */
 int kr_decode_generate_greedy(kr_decode_store* s, int first_token, int start_pos, int max_tokens, const int* stop_ids, int n_stop,
                               int* tokens_out, int* n_out, void* stream);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "kr_route_topk", "kr_forward_moe_routed", "kr_reduce_sum_bf16", "kr_combine_rows", "kr_ep_unique_id", "kr_ep_init", "kr_ep_destroy", "kr_moe_prefill_ep", "kr_ep_comm_ranks", "kr_ep_max_int", "kr_ep_allreduce_f32", "kr_ep_loopback_create", "kr_ep_loopback_destroy", "kr_ep_init_loopback", "kr_moe_set_prefill_pairs", "kr_moe_set_gemm_mode", "kr_synchronize", "kr_set_profiling",
     "kr_get_profile", "kr_decode_create", "kr_decode_set_moe_store", "kr_decode_destroy", "kr_decode_store_weight_f32", "kr_decode_store_weight_synthetic",
     "kr_decode_download_weight", "kr_decode_store_norm_weight", "kr_decode_configure", "kr_decode_add_la_layer",
-    "kr_decode_add_gqa_layer", "kr_decode_add_mla_layer", "kr_decode_prefill", "kr_decode_prefill_nll", "kr_decode_reset_state", "kr_decode_generate", "kr_decode_sample", "kr_decode_set_prefill_chunk", "kr_decode_set_prefill_depth", "kr_decode_set_layer_moe", "kr_decode_set_layer_dense", "kr_decode_set_rope", "kr_decode_finalize", "kr_decode_set_kv_dtype", "kr_decode_set_attention_mode", "kr_decode_set_option", "kr_decode_create_on",
+    "kr_decode_add_gqa_layer", "kr_decode_add_mla_layer", "kr_decode_prefill", "kr_decode_prefill_nll", "kr_decode_reset_state", "kr_decode_generate", "kr_decode_sample", "kr_sample_order", "kr_decode_set_prefill_chunk", "kr_decode_set_prefill_depth", "kr_decode_set_layer_moe", "kr_decode_set_layer_dense", "kr_decode_set_rope", "kr_decode_finalize", "kr_decode_set_kv_dtype", "kr_decode_set_attention_mode", "kr_decode_set_option", "kr_decode_create_on",
     "kr_decode_set_state", "kr_decode_fill_state_synthetic", "kr_decode_get_state", "kr_decode_step", "kr_decode_generate_greedy",
     "kr_decode_last_token", "kr_decode_set_use_graph", "kr_decode_read_buffer", "kr_decode_device_bytes", "kr_decode_profile_step",
     "kr_decode_generate_stream", "kr_decode_cancel", "kr_decode_reset_cancel", "kr_decode_last_elapsed_s", "kr_decode_matmul", "kr_decode_matmul_batch",
@@ -126,6 +126,7 @@ def load_library() -> C.CDLL:
     lib.kr_decode_reset_state.argtypes = [vp, ci]
     lib.kr_decode_generate.argtypes = [vp, ci, ci, ci, cf, ci, cf, vp, ci, cf, C.c_uint64, vp, vp, vp]
     lib.kr_decode_sample.argtypes = [vp, cf, ci, cf, cf, C.c_uint64, ci, vp, vp]
+    lib.kr_sample_order.argtypes = [vp, ci, ci, vp]
     lib.kr_decode_set_prefill_chunk.argtypes = [vp, ci]
     lib.kr_decode_set_prefill_depth.argtypes = [vp, ci]
     lib.kr_decode_add_mla_layer.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, C.c_size_t, vp, C.c_size_t, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci,

@@ -1068,6 +1068,26 @@ static int sampler_prepare(kr_decode_store* s) {
 
 // sample_from_logits (decode.rs:3718) applied to the logits of the last step; temperature 0 = greedy (first maximum).
 // rng_seed != 0 re-seeds the xorshift64 state (the reference seeds from the wall clock; 0xDEADBEEF if that is 0).
+// test aid (no reference counterpart): the token ids kr_decode_sample would draw from, in its order -- the top_k largest of `logits` (host, f32), value descending, equal values
+// by ascending id (decode.rs:3740-3760 sorts by value only; the oracle fixes the same tie rule).  top_k <= 0 or >= vocab: the whole vocabulary.
+extern "C" int kr_sample_order(const float* logits_host, int vocab, int top_k, int32_t* ids_out_host) {
+    if (!logits_host || !ids_out_host || vocab <= 0) return kr_fail(KR_ERR_VALUE, "kr_sample_order: null pointer or empty vocabulary");
+    int dev_count = 0;
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count == 0) return kr_fail(KR_ERR_HIP, "no HIP device");
+    const int k = (top_k > 0 && top_k < vocab) ? top_k : vocab;
+    DevBuf lg, keys, tmp;
+    const size_t tb = kr_sampler_temp_bytes(vocab);
+    if (lg.ensure((size_t)vocab * 4) || keys.ensure((size_t)vocab * 16) || tmp.ensure(tb ? tb : 16)) return kr_fail(KR_ERR_HIP, "hipMalloc failed");
+    KR_HIP(hipMemcpy(lg.p, logits_host, (size_t)vocab * 4, hipMemcpyHostToDevice));
+    uint64_t* kin = (uint64_t*)keys.p;
+    if (kr_launch_sample_order((float*)lg.p, vocab, top_k, nullptr, kin, kin + vocab, tmp.p, tb, nullptr)) return kr_fail(KR_ERR_HIP, "sampler order launch failed");
+    KR_HIP(hipDeviceSynchronize());
+    std::vector<uint64_t> h((size_t)k);
+    KR_HIP(hipMemcpy(h.data(), kin + vocab, (size_t)k * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < k; i++) ids_out_host[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)h[i]);
+    return KR_OK;
+}
+
 extern "C" int kr_decode_sample(kr_decode_store* s, float temperature, int top_k, float top_p, float presence_penalty, uint64_t rng_seed,
                                 int reset_seen, int* token_out, void* stream) {
     if (int rc = need_cfg(s)) return rc;

@@ -24,6 +24,24 @@ def test_sample_matches_oracle(temperature, top_k, top_p):
         tok = got
 
 
+@pytest.mark.parametrize("vocab,top_k", [(151936, 1), (151936, 20), (151936, 50), (151936, 1000), (151936, 4096), (151936, 5000), (4099, 0), (3000, 0), (64, 7)])
+def test_sampler_order_with_ties_at_the_cut(vocab, top_k):
+    """kr_sample_order = the order kr_decode_sample draws from: top_k <= 4096 by radix select + LDS sort, more by the full radix sort; value descending, equal values by
+    ascending id.  Logits on a coarse grid: every value repeats ~vocab / 400 times, so the k-th value is (almost) always tied across the cut."""
+    import ctypes as C
+    from krasis_amd import _lib
+    lib = _lib.load_library()
+    rng = np.random.default_rng(vocab * 31 + top_k)
+    lg = (rng.integers(-200, 200, vocab).astype(F) * F(0.125)).astype(F)
+    lg[rng.integers(0, vocab, 3)] = F(-0.0)           # signed zeros compare equal (partial_cmp)
+    k = top_k if 0 < top_k < vocab else vocab
+    ids = np.empty(k, np.int32)
+    assert lib.kr_sample_order(lg.ctypes.data_as(C.c_void_p), vocab, top_k, ids.ctypes.data_as(C.c_void_p)) == 0, lib.kr_last_error()
+    v = np.where(lg == 0, F(0), lg)
+    ref = np.lexsort((np.arange(vocab), -v.astype(np.float64)))[:k]
+    assert np.array_equal(ids, ref.astype(np.int32))
+
+
 def test_sample_ties_break_by_token_id():
     st, eng, orc, keep, d = build()
     lg = np.empty(d["V"], F)
