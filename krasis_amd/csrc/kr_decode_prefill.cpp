@@ -273,10 +273,11 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     // 8192 tokens (tools/probes/prefill_sweep.py: 1024 x 3 171 ms, 2048 x 2 168, 4096 x 2 164, 8192 x 1 193)
     // (second sweep: three chunks in flight beat two once the prompt has three chunks to give -- 8192 tokens: 2752 x 3 148.6 ms vs 4096 x 2 151.4;
     // 20 434 tokens: 4096 x 3 407 ms vs 4096 x 2 423 -- so: a third of the prompt per chunk, between 1024 and 4096 tokens, three in flight; 3000 tokens: 1024 x 3 56.8 ms vs 2048 + 952 60.9)
-    const bool tol = s->attn_fast && s->gemm_fast;
     const int third = ((n_tokens + 2) / 3 + 63) / 64 * 64;
     const int tol_chunk = std::min(4096, std::max(KR_PFM_CHUNK, third));
-    const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : (tol ? tol_chunk : KR_PFM_CHUNK));
+    // (round 6: the same rule with KR_ATTN_FAST alone -- its attention / delta-rule kernels are chunk-parallel too and the exact expert GEMM likes the fatter chunks:
+    // 8192 tokens 173.8 -> 162.0 ms, 20 434: 448.5 -> 428.1, 49 863: 1221.6 -> 1185.4; the exact pass keeps 1024 x 3: its per-token recurrences need the overlap)
+    const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : (s->attn_fast ? tol_chunk : KR_PFM_CHUNK));
     const int depth = s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : KR_PFM_DEPTH;   // chunks in flight (streams / arenas)
     // expert parallelism: every rank must walk the SAME (chunk, layer) schedule -- the exchanges are collectives -- so the schedule is built from the chunk
     // count of the longest prompt shard (agreed below, before the first exchange); chunks a rank does not have run as empty shards

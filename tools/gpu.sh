@@ -277,6 +277,10 @@ ringx)      # round 6: kernel trace of the experts-only pass at the prompt pass'
     kstats r06_experts_2752_ring "Experts only, QCN shape, 2752 tokens x 8 layers, LDS-ring GEMM forced (tools/probes/experts_gemm_probe.py 8 2752 ring)" -- python /root/repo/tools/probes/experts_gemm_probe.py 8 2752 ring
     kstats r06_experts_2752_staged "Experts only, QCN shape, 2752 tokens x 8 layers, register-staged GEMM (tools/probes/experts_gemm_probe.py 8 2752 staged)" -- python /root/repo/tools/probes/experts_gemm_probe.py 8 2752 staged
     ;;
+pfmode)     # round 6: kernel trace of the prompt pass at 8192 tokens in mode $1 (0 exact, 1 KR_ATTN_FAST, 2 both bits), three chunks in flight
+    kstats r06_prefill_8192_mode$1 "QCN prompt pass, mode $1 (0 exact, 1 KR_ATTN_FAST, 2 + KR_GEMM_FAST), 8192 tokens (tools/probes/prefill_profile.py 8192 $1)" -- python /root/repo/tools/probes/prefill_profile.py 8192 $1 > /dev/null
+    head -34 $R/r06_prefill_8192_mode$1_kernel_stats.txt
+    ;;
 pf1)        # round 6: the tolerance prompt pass as ONE chunk on one stream (no overlap): stand-alone duration of every kernel
     kstats r06_prefill_8192_one_chunk "QCN prompt pass, KR_ATTN_FAST | KR_GEMM_FAST, 8192 tokens as ONE chunk, depth 1 (tools/probes/prefill_profile.py 8192 2 48 8192 1): stand-alone kernel durations" -- \
         python /root/repo/tools/probes/prefill_profile.py 8192 2 48 8192 1
