@@ -277,8 +277,12 @@ static int prefill_impl(kr_decode_store* s, const int32_t* tokens, int n_tokens,
     const int tol_chunk = std::min(4096, std::max(KR_PFM_CHUNK, third));
     // (round 6: the same rule with KR_ATTN_FAST alone -- its attention / delta-rule kernels are chunk-parallel too and the exact expert GEMM likes the fatter chunks:
     // 8192 tokens 173.8 -> 162.0 ms, 20 434: 448.5 -> 428.1, 49 863: 1221.6 -> 1185.4; the exact pass keeps 1024 x 3: its per-token recurrences need the overlap)
-    const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : (s->attn_fast ? tol_chunk : KR_PFM_CHUNK));
     const int depth = s->pf_depth >= 1 && s->pf_depth <= KR_PF_MAX_DEPTH ? s->pf_depth : KR_PFM_DEPTH;   // chunks in flight (streams / arenas)
+    // exact pass: chunks of ~1024 tokens, their COUNT a multiple of the depth when the prompt has that many -- the last round of chunks then fills every stream
+    // (8192 tokens: 8 x 1024 = 3 + 3 + 2 chunks 382.9 ms, 6 x 1366 355.8; 20 434: 20 x 1024 1207.9, 18 x 1136 1180.1; 49 863: unchanged, attention-bound)
+    const int q1k = (n_tokens + KR_PFM_CHUNK - 1) / KR_PFM_CHUNK, nc_exact = q1k >= depth ? (q1k / depth) * depth : q1k;
+    const int exact_chunk = (n_tokens + nc_exact - 1) / nc_exact;
+    const int CH = std::min(n_tokens, s->pf_chunk > 0 ? s->pf_chunk : (s->attn_fast ? tol_chunk : exact_chunk));
     // expert parallelism: every rank must walk the SAME (chunk, layer) schedule -- the exchanges are collectives -- so the schedule is built from the chunk
     // count of the longest prompt shard (agreed below, before the first exchange); chunks a rank does not have run as empty shards
     int n_chunks_max = (n_tokens + CH - 1) / CH;
