@@ -215,84 +215,105 @@ __global__ void kr_pfm_la_conv_state_kernel(const KrPfmLaArgs a, int C) {
 
 // ---- gated delta rule over the chunk (decode.rs:1293): one thread per state column, the column lives in registers ------------
 // grid nv, dv threads.  Per token: kv = chain_i fma(S[i]*e^g, k[i]); delta = (v - kv)*beta; S[i] = fma(k[i], delta, S[i]*e^g); o = chain_i fma(S[i], q[i]).
-// The two DK-long fma chains per token are inherent to the reference order and run at the dependent-issue latency (~8 cycles per
-// step, ~2 x DK x 8 cycles per token); what must NOT sit on the token loop is memory: every per-token scalar (e^g, beta, v) and the
-// next k / q rows are fetched one token ahead, and the state slice is addressed through a buffer descriptor (scalar row offsets)
-// so that no per-row 64-bit addresses stay live across the loop.  Measured alternatives (LDS-staged token blocks; one packed fma
-// advancing the kv chain of token t and the output chain of token t-1 on a {S*e^g, S} register pair -- needs 2 x DK registers; a
-// merged in-place loop -- the compiler hoists the decay into the previous update and spills) were slower on MI355X.
+// The two DK-long fma chains per token are inherent to the reference order, and a dependent v_fmac issues only every ~15 cycles on this part: run one after the other they
+// cost 2 x DK x 15 cycles per token (1.8 us at DK = 128: the round-5 form).  Round 6: the OUTPUT chain of token t and the kv chain of token t + 1 are independent once
+// S(t)[i] exists, so they advance together, element by element -- update S[i] with delta_t, step o_t, decay S[i] by e^g(t+1), step kv_(t+1): four instructions per element,
+// two chains in each other's latency shadow; every value is produced by the same operation in the same order as before (bit-identical).  Behind the last token runs a
+// phantom one with e^g = 1 (S * 1.0f is S) whose chain nobody reads.  The rows (k, q, v) and the two gate scalars of a token reach an LDS ring of RS slots by LDS-DMA
+// (global_load_lds_dword: lane i's word lands at M0 + 4 i), requested three tokens ahead: no staging registers, one loop body; the state slice is addressed through a
+// buffer descriptor (scalar row offsets) so that no per-row 64-bit addresses stay live across the loop.
+// (Measured earlier and slower: LDS-staged token blocks; one packed fma advancing both chains on a {S*e^g, S} register pair -- 2 x DK registers; the same interleave with
+// the rows prefetched into rotating register sets -- three copies of the loop, 328 registers.)
+__device__ __forceinline__ void pfm_dma4(uint32_t lds_dst, const void* gptr) {      // this lane's 4 bytes at gptr -> lds_dst + 4 * lane; not counted by the compiler's waits
+    unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(lds_dst), "v"(gptr) : "memory");
+}
 template <int DK>
 __global__ void __launch_bounds__(256) kr_pfm_la_recur_kernel(float* __restrict__ state, const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, const float* __restrict__ gexp, const float* __restrict__ beta,
                                                              float* __restrict__ out, int nv, int dv, int C) {
-    __shared__ __attribute__((aligned(16))) float ks[2][DK], qs[2][DK];
-    const int h = blockIdx.x, j = threadIdx.x, nvdk = nv * DK, nvdv = nv * dv;
+    constexpr int RS = 5, ROW = 256;                 // ring slots; floats per row region (dv <= 256)
+    constexpr int SLOT = 3 * ROW + 128;              // floats per slot: k row, q row, v row, e^g at [3 ROW], beta at [3 ROW + 1] (wave 0's other lanes land behind them), a 64-word dump at [3 ROW + 64]
+    __shared__ __attribute__((aligned(16))) float ring[RS][SLOT];
+    const int h = blockIdx.x, j = threadIdx.x, lane = j & 63, wv = __builtin_amdgcn_readfirstlane(j >> 6), nvdk = nv * DK, nvdv = nv * dv;
     float S[DK];
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(state + (size_t)h * DK * dv, 0, DK * dv * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < DK; i++) S[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, j * 4, i * dv * 4, 0));
-    if (j < DK) { ks[0][j] = k[(size_t)h * DK + j]; qs[0][j] = q[(size_t)h * DK + j]; }   // DK <= blockDim (dv >= DK is checked by the launcher)
-    float ge = gexp[h], bt = beta[h], vj = v[(size_t)h * dv + j];
+    const uint32_t ring0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)&ring[0][0];
+    const bool kq_wave = wv * 64 < DK;                                   // wave-uniform: this wave's columns have k / q words
+    const int jk = kq_wave ? j : lane;                                    // other waves fetch (harmless) words into the slot's spare area: every wave issues 5 DMAs per token
+    auto request = [&](int tt, int slot) {           // token tt (clamped: a phantom token behind the chunk re-reads the last one; its gates are forced below)
+        const int tc = tt < C ? tt : C - 1;
+        const uint32_t base = ring0 + (uint32_t)slot * (SLOT * 4), dump = base + (3 * ROW + 64) * 4;
+        pfm_dma4(kq_wave ? base + wv * 256 : dump, k + (size_t)tc * nvdk + (size_t)h * DK + jk);
+        pfm_dma4(kq_wave ? base + ROW * 4 + wv * 256 : dump, q + (size_t)tc * nvdk + (size_t)h * DK + jk);
+        pfm_dma4(base + 2 * ROW * 4 + wv * 256, v + (size_t)tc * nvdv + (size_t)h * dv + j);
+        pfm_dma4(wv == 0 ? base + 3 * ROW * 4 : dump, (lane == 0 ? gexp : beta) + (size_t)tc * nv + h);      // wave 0: lane 0 -> e^g, lane 1 -> beta (lanes 2 .. 63 land behind them, unread)
+        pfm_dma4(dump, beta + (size_t)tc * nv + h);                                                          // filler: every wave issues exactly 5 requests per token (the wait below counts them)
+    };
+    request(0, 0); request(1, 1); request(2, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int t = 0; t < C; t++) {
-        const int cur = t & 1;
-        float kn = 0.0f, qn = 0.0f, ge_n = 1.0f, bt_n = 0.0f, vj_n = 0.0f;                 // token t + 1, in flight under this token's chains
-        const bool more = t + 1 < C;
-        if (more) {
-            if (j < DK) { kn = k[(size_t)(t + 1) * nvdk + (size_t)h * DK + j]; qn = q[(size_t)(t + 1) * nvdk + (size_t)h * DK + j]; }
-            ge_n = gexp[(size_t)(t + 1) * nv + h]; bt_n = beta[(size_t)(t + 1) * nv + h]; vj_n = v[(size_t)(t + 1) * nvdv + (size_t)h * dv + j];
-        }
-        // blocks of 16 elements: the next block's k (and q) rows leave LDS (4 / 8 x ds_read_b128) while the current block's chain
-        // steps run; the scheduling barriers stop the compiler from sinking each read next to its use (one exposed LDS latency per pair)
-        const float4* k4 = reinterpret_cast<const float4*>(ks[cur]); const float4* q4 = reinterpret_cast<const float4*>(qs[cur]);
+    // prologue: decay + kv chain of token 0 alone
+    float delta;
+    {
+        const float4* k4 = reinterpret_cast<const float4*>(&ring[0][0]);
+        const float ge0 = ring[0][3 * ROW], bt0 = ring[0][3 * ROW + 1], vj0 = ring[0][2 * ROW + j];
         float kv = 0.0f;
-        float4 ka[4] = {k4[0], k4[1], k4[2], k4[3]};
 #pragma unroll
-        for (int b = 0; b < DK / 16; b++) {
-            float4 kb[4] = {ka[0], ka[1], ka[2], ka[3]};
-            if (b + 1 < DK / 16) { kb[0] = k4[4 * b + 4]; kb[1] = k4[4 * b + 5]; kb[2] = k4[4 * b + 6]; kb[3] = k4[4 * b + 7]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                float* Sb = S + 16 * b + 4 * u;
-                Sb[0] = Sb[0] * ge; kv = __builtin_fmaf(Sb[0], ka[u].x, kv);
-                Sb[1] = Sb[1] * ge; kv = __builtin_fmaf(Sb[1], ka[u].y, kv);
-                Sb[2] = Sb[2] * ge; kv = __builtin_fmaf(Sb[2], ka[u].z, kv);
-                Sb[3] = Sb[3] * ge; kv = __builtin_fmaf(Sb[3], ka[u].w, kv);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; u++) ka[u] = kb[u];
+        for (int u = 0; u < DK / 4; u++) {
+            const float4 kk = k4[u];
+            float* Sb = S + 4 * u;
+            Sb[0] = Sb[0] * ge0; kv = __builtin_fmaf(Sb[0], kk.x, kv);
+            Sb[1] = Sb[1] * ge0; kv = __builtin_fmaf(Sb[1], kk.y, kv);
+            Sb[2] = Sb[2] * ge0; kv = __builtin_fmaf(Sb[2], kk.z, kv);
+            Sb[3] = Sb[3] * ge0; kv = __builtin_fmaf(Sb[3], kk.w, kv);
         }
-        const float delta = (vj - kv) * bt;
-        float ob = 0.0f;
-        float4 qa[4] = {q4[0], q4[1], q4[2], q4[3]};
-#pragma unroll
-        for (int u = 0; u < 4; u++) ka[u] = k4[u];
+        delta = (vj0 - kv) * bt0;
+    }
+    int slot = 0;
+    for (int t = 0; t < C; t++) {
+        // token t: S update + output chain of token t, together with decay + kv chain of token t + 1; blocks of 16 elements, the next block's rows leave LDS while the
+        // current block's steps run (the scheduling fences keep the reads from sinking next to their uses)
+        const int s1 = slot + 1 >= RS ? slot + 1 - RS : slot + 1, s3 = slot + 3 >= RS ? slot + 3 - RS : slot + 3;
+        request(t + 3, s3);          // slot s3 held token t - 2: last read two barriers ago
+        const float4* k4 = reinterpret_cast<const float4*>(&ring[slot][0]); const float4* q4 = reinterpret_cast<const float4*>(&ring[slot][ROW]);
+        const float4* n4 = reinterpret_cast<const float4*>(&ring[s1][0]);
+        const bool has_next = t + 1 < C;
+        const float ge1 = has_next ? ring[s1][3 * ROW] : 1.0f, bt1 = ring[s1][3 * ROW + 1], vj1 = ring[s1][2 * ROW + j];
+        float ob = 0.0f, kv = 0.0f;
+        float4 ka[4] = {k4[0], k4[1], k4[2], k4[3]}, qa[4] = {q4[0], q4[1], q4[2], q4[3]}, na[4] = {n4[0], n4[1], n4[2], n4[3]};
 #pragma unroll
         for (int b = 0; b < DK / 16; b++) {
-            float4 kb[4] = {ka[0], ka[1], ka[2], ka[3]}, qb[4] = {qa[0], qa[1], qa[2], qa[3]};
+            float4 kb[4] = {ka[0], ka[1], ka[2], ka[3]}, qb[4] = {qa[0], qa[1], qa[2], qa[3]}, nb[4] = {na[0], na[1], na[2], na[3]};
             if (b + 1 < DK / 16) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) { kb[u] = k4[4 * b + 4 + u]; qb[u] = q4[4 * b + 4 + u]; }
+                for (int u = 0; u < 4; u++) { kb[u] = k4[4 * b + 4 + u]; qb[u] = q4[4 * b + 4 + u]; nb[u] = n4[4 * b + 4 + u]; }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 float* Sb = S + 16 * b + 4 * u;
-                Sb[0] = __builtin_fmaf(ka[u].x, delta, Sb[0]); ob = __builtin_fmaf(Sb[0], qa[u].x, ob);
-                Sb[1] = __builtin_fmaf(ka[u].y, delta, Sb[1]); ob = __builtin_fmaf(Sb[1], qa[u].y, ob);
-                Sb[2] = __builtin_fmaf(ka[u].z, delta, Sb[2]); ob = __builtin_fmaf(Sb[2], qa[u].z, ob);
-                Sb[3] = __builtin_fmaf(ka[u].w, delta, Sb[3]); ob = __builtin_fmaf(Sb[3], qa[u].w, ob);
+                const float kk[4] = {ka[u].x, ka[u].y, ka[u].z, ka[u].w}, qq[4] = {qa[u].x, qa[u].y, qa[u].z, qa[u].w}, nn[4] = {na[u].x, na[u].y, na[u].z, na[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    Sb[e] = __builtin_fmaf(kk[e], delta, Sb[e]); ob = __builtin_fmaf(Sb[e], qq[e], ob);
+                    Sb[e] = Sb[e] * ge1; kv = __builtin_fmaf(Sb[e], nn[e], kv);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 4; u++) { ka[u] = kb[u]; qa[u] = qb[u]; }
+            for (int u = 0; u < 4; u++) { ka[u] = kb[u]; qa[u] = qb[u]; na[u] = nb[u]; }
         }
         out[(size_t)t * nvdv + (size_t)h * dv + j] = ob;
-        if (more && j < DK) { ks[cur ^ 1][j] = kn; qs[cur ^ 1][j] = qn; }
-        ge = ge_n; bt = bt_n; vj = vj_n;
+        delta = (vj1 - kv) * bt1;
+        // the next token reads slots t + 1 and t + 2: this wave's requests for token t + 2 (issued one token ago) are older than its 5 requests for t + 3 and the two
+        // output stores since -- at most 7 vector-memory operations may still be in flight
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         __syncthreads();
+        slot = s1;
     }
 #pragma unroll
     for (int i = 0; i < DK; i++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S[i]), srd, j * 4, i * dv * 4, 0);
