@@ -262,7 +262,7 @@ int kr_decode_set_kv_dtype(kr_decode_store* s, int kv_dtype);
 #define KR_ATTN_EXACT 0
 #define KR_ATTN_FAST 1
 #define KR_GEMM_FAST 2   /* or-ed into the mode: every GEMM of kr_decode_prefill (projections, shared expert, routed experts, lm_head of the scoring pass) in the tolerance form of kr_moe_set_gemm_mode; decode steps are unaffected */
-#define KR_DECODE_FAST 4 /* or-ed into the mode: decode steps run the tolerance-mode kernels of kr_decode_fast.hip -- the reference's products (INT16 activation digits, exact integer group sums, its sigmoid / libm functions), but every f32 reduction as a lane / wave / workgroup TREE instead of the reference's sequential chain, the norms folded into the launches that consume them, top-k + silu*up + the expert combine inside the expert launches (6 launches per linear-attention MoE layer).  Router ids are those of the exact kernels for identical logits, with one stated exception: exact ties fall back to the reference's heap order, but with plain softmax scoring + renormalised weights the selection runs on the LOGITS, so two distinct logits among the leading k + 1 whose f32 softmax scores round to the same value (a few ulp apart) are ordered by value here and by the heap's tie rule in the exact kernel; logits agree with the exact mode to the tolerance stated in tests/test_decode_fast_gpu.py.  MLA layers: projections, absorption, latent norm and w_vc in this form, the attention launch itself in the exact order.  Native-GGUF MoE layers (Q4_K / Q8_0 / Q4_0): the routed slots of the two expert launches walk the GGUF blocks (the block kernels' products, a row's blocks split over two waves).  Geometries the kernels do not cover (dense MLP, GPT-OSS activation, E > 512, hidden > 4096, Q5_0 / Q6_K blocks) keep the exact kernels for that layer -- never a CPU path.  The prompt pass is unaffected. */
+#define KR_DECODE_FAST 4 /* or-ed into the mode: decode steps run the tolerance-mode kernels of kr_decode_fast.hip -- the reference's products (INT16 activation digits, exact integer group sums, its sigmoid / libm functions), but every f32 reduction as a lane / wave / workgroup TREE instead of the reference's sequential chain, the norms folded into the launches that consume them, top-k + silu*up + the expert combine inside the expert launches (6 launches per linear-attention MoE layer).  Router ids are those of the exact kernels for identical logits, with one stated exception: exact ties fall back to the reference's heap order, but with plain softmax scoring + renormalised weights the selection runs on the LOGITS, so two distinct logits among the leading k + 1 whose f32 softmax scores round to the same value (a few ulp apart) are ordered by value here and by the heap's tie rule in the exact kernel; logits agree with the exact mode to the tolerance stated in tests/test_decode_fast_gpu.py.  MLA layers: projections, absorption, latent norm and w_vc in this form, the attention launch itself in the exact order.  Native-GGUF MoE layers (Q4_K / Q8_0 / Q4_0): the routed slots of the two expert launches walk the GGUF blocks (the block kernels' products, a row's blocks split over two waves).  Geometries the kernels do not cover (the down projection of a dense MLP, GPT-OSS activation, E > 512, hidden > 4096, Q5_0 / Q6_K blocks) keep the exact kernels for that layer -- never a CPU path.  The prompt pass is unaffected. */
 int kr_decode_set_attention_mode(kr_decode_store* s, int mode);
 int kr_decode_set_option(kr_decode_store* s, const char* name, int value);   /* test / tuning hooks by name: "gqa_stream", "pfm_timing" (see kr_decode.cpp) */                                                                        /* decode.rs:2471 */
 /* Whole-model prompt pass.  Replaces the reference's GPU prefill (python/krasis/model.py forward_prefill_layer_grouped / server_prefill,

@@ -806,6 +806,27 @@ static int enqueue_step(kr_decode_store* s, hipStream_t st) {
             }
         }
         if (moe_done) continue;
+        // KR_DECODE_FAST on a dense MLP layer (V2-Lite's first, decode.rs:1693-1741; round 6): the post-attention add + RMSNorm folded into the gate | up projection launch
+        // (every workgroup rebuilds the normalised vector with tree sums, as the attention in-projections of the mode do); the down projection keeps the exact kernel with
+        // its silu * up + INT16 prologue -- its K (10 944) is beyond what a folded prologue holds
+        if (fast && !routed && L.mlp == MLP_DENSE && src.mode == 0 && s->opt_dense_fast) {
+            const KrMatDev g = mv(s, L.gate_wid), u = mv(s, L.up_wid);
+            const int K = s->weights[L.down_wid]->cols;
+            if (g.bits == u.bits && (g.bits == 4 || g.bits == 8)) {
+                KrFdmArgs fd{};
+                fd.mode = 1; fd.hid_in = hid; fd.res_in = res_cur; fd.res_out = other(res_cur); fd.norm_w = (const float*)s->norms[L.post_norm]->p; fd.eps = s->eps; fd.bias_one = s->norm_bias_one;
+                fd.mm.n = 2; fd.mm.m[0] = g; fd.mm.y[0] = (float*)s->dense_gu.p; fd.mm.tile_end[0] = (g.N + 7) / 8;
+                fd.mm.m[1] = u; fd.mm.y[1] = (float*)s->dense_gu.p + K; fd.mm.tile_end[1] = fd.mm.tile_end[0] + (u.N + 7) / 8;
+                prof_mark(s, PK_MATVEC, st);
+                const bool done = 0 == kr_launch_fdm(fd, st);
+                prof_mark(s, -1, st);
+                if (done) {
+                    res_cur = other(res_cur);
+                    PROF(PK_MATVEC, kr_launch_matvec(mv(s, L.down_wid), s->dense_gu.p, 1, hid, st, KR_ACT_SILU_MUL));
+                    continue;
+                }
+            }
+        }
         if (!routed) PROF(PK_RMSNORM, kr_launch_fused_add_rmsnorm(src, hid, res_cur, res_cur, (const float*)s->norms[L.post_norm]->p, H, s->eps, 0, s->norm_bias_one, st));
         if (L.mlp == MLP_MOE) {
             Layer& EL = e->layers[L.moe_layer];
@@ -1014,6 +1035,7 @@ extern "C" int kr_decode_set_option(kr_decode_store* s, const char* name, int va
     if (!strcmp(name, "gqa_fused")) { s->opt_gqa_fused = value != 0; s->graph_ok = false; return KR_OK; }      // KR_DECODE_FAST, short caches: 0 = prep + attention as two launches (A/B and test hook)
     if (!strcmp(name, "gemm_ring")) { kr_pfr_set_enabled(value); return KR_OK; }                              // KR_GEMM_FAST: 0 = register-staged tolerance GEMMs only, 1 = ring form for big problems (default), 2 = for every shape it takes (process-wide A/B and test hook; same bits)
     if (!strcmp(name, "la_conv_fused")) { s->opt_la_conv_fused = value != 0; return KR_OK; }                // KR_ATTN_FAST prompt pass: 0 = the stand-alone conv launch in front of the delta-rule prep (A/B and test hook; same bits)
+    if (!strcmp(name, "dense_fast")) { s->opt_dense_fast = value != 0; s->graph_ok = false; return KR_OK; }       // KR_DECODE_FAST: 0 = a dense MLP layer keeps the exact norm + gate | up launches (A/B and test hook)
     if (!strcmp(name, "norm_rows")) { s->opt_norm_rows = value != 0; return KR_OK; }                        // KR_GEMM_FAST prompt pass: 0 = the f16 row image of a norm's output by its own launch (A/B and test hook; same bits)
     if (!strcmp(name, "pfm_timing")) { s->opt_pfm_timing = value != 0; return KR_OK; }
     if (!strcmp(name, "generate_lookahead")) { s->opt_gen_lookahead = value != 0; return KR_OK; }

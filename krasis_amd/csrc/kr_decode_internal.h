@@ -50,7 +50,7 @@ struct kr_decode_store {
     DevBuf hid2, res2, r_counter, argmax_scratch;
     int kv_fp8 = 0;            // GQA KV element type: 0 FP16 (reference CPU decode), 1 FP8-E4M3 (reference GPU cache dtype)
     DevBuf img_in, img_post, img_post_bf16, img_attn; bool use_images = true;   // pre-built INT16 activation images (input norm, post-attention norm f32 / bf16, attention output)
-    int opt_gqa_stream = 0, opt_pfm_timing = 0, opt_norm_rows = 1, opt_la_conv_fused = 1, opt_gqa_fused = 1, opt_lm_fused = 1, opt_la_heads = 1, opt_w2_combine = 1;   // kr_decode_set_option: test / tuning hooks (no environment lookups on launch paths)
+    int opt_gqa_stream = 0, opt_pfm_timing = 0, opt_norm_rows = 1, opt_la_conv_fused = 1, opt_gqa_fused = 1, opt_lm_fused = 1, opt_la_heads = 1, opt_w2_combine = 1, opt_dense_fast = 1;   // kr_decode_set_option: test / tuning hooks (no environment lookups on launch paths)
     int opt_gen_lookahead = 0;                    // kr_decode_set_option("generate_lookahead"): generate_batch feeds the sampled token back ON THE DEVICE and queues step i + 1 before the host has read token i
     int opt_ep_graph = 0;                         // kr_decode_set_option("ep_graph"): expert-parallel decode over RCCL replays a captured graph (the all-reduce is captured with the kernels)
     uint64_t ep_generation_seen = 0;               // kr_engine::ep_generation at the last step: a new / destroyed communicator invalidates the graph and restarts the warm-up

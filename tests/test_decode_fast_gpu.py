@@ -57,7 +57,7 @@ CFGS = [
     dict(kinds=["la"]), dict(kinds=["gqa"]),                   # one layer each: localises a failure
     dict(kinds=["la", "la", "la", "la"], la_heads=(4, 16)),    # hr = 4
     dict(wbits=8),                                             # INT8-g128 everywhere
-    dict(with_dense=True),                                     # dense MLP layer: that layer keeps the exact MLP kernels
+    dict(with_dense=True),                                     # dense MLP layer: its post-attention norm folded into the gate | up launch (round 6); the down projection is the exact kernel
     dict(dims=(2048, 1024, 32, 10, 512, 512), kinds=["la", "gqa"], la_heads=(4, 8), hd=256, nh=8, seed=3),   # QCN-like widths (H 2048, I 512, k 10)
     dict(dims=(4096, 512, 128, 8, 256, 256), kinds=["gqa", "gqa"], hd=128, nh=16, seed=4),                   # Qwen3-235B-like widths (H 4096: the widest the kernels take, E 128, k 8)
 ]
